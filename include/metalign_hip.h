@@ -1,0 +1,237 @@
+/*
+ * metalign_hip.h — C ABI of libmetalign_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the two data-parallel stages of Metalign.
+ * Every entry point replaces a process/file seam of the reference (cited as
+ * path:line under /root/reference); none of them takes a torch type.  All
+ * functions return 0 on success and a negative mg_status on failure; the text
+ * of the last failure on the calling thread is available from mg_last_error().
+ * Nothing is thrown across the ABI.
+ *
+ * Ownership: the caller owns every host buffer, in and out.  Pointers named
+ * d_* are DEVICE pointers (HBM) owned by the caller (mg_dev_malloc, or any
+ * other allocator of the same HIP runtime, e.g. a torch tensor's data_ptr()).
+ * Opaque handles (mg_sketch, mg_db, mg_profile) own device memory inside the
+ * library and are released by their *_free function or by mg_shutdown().
+ *
+ * Threading: calls are not re-entrant; one host thread drives one device.
+ */
+#ifndef METALIGN_HIP_H
+#define METALIGN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+typedef enum mg_status {
+  MG_OK = 0,
+  MG_ERR_HIP = -1,       /* a HIP runtime call failed (text in mg_last_error) */
+  MG_ERR_ARG = -2,       /* invalid argument (k out of range, null pointer, ...) */
+  MG_ERR_CAPACITY = -3,  /* caller-provided output buffer too small */
+  MG_ERR_STATE = -4,     /* mg_init not called / handle used out of order */
+  MG_ERR_NOMEM = -5
+} mg_status;
+
+/* Largest supported k (2-bit packed k-mer in two 64-bit words).  The stock
+ * reference uses k=60 with CMash k-range 30-60-10 (scripts/select_db.py:44,50,75);
+ * BASELINE.json configs use k in {21,31,51}. */
+#define MG_MAX_K 64
+
+/* ------------------------------------------------------------------------ *
+ * Alignment record: one retained SAM line, pre-tokenised at ingest.
+ * "Retained" = survives the line filter of map_and_process
+ * (scripts/map_and_profile.py:206-213: not '@', >= 6 fields, not unmapped,
+ * CIGAR != '*').  Field meaning follows the columns the reference reads:
+ *   FLAG  [1] :104-111   RNAME [2] :217   CIGAR [5] :86-100   SEQ [9] :142-144
+ * ------------------------------------------------------------------------ */
+typedef struct mg_aln_rec {
+  uint32_t ref_new;   /* bit 31: QNAME differs from the previous retained line
+                         (the `read != prev_read` test, :220);
+                         bits 0..30: accession index (row of ref2tax)        */
+  uint32_t matched;   /* sum of CIGAR 'M' op lengths (filter_line, :91-92)     */
+  uint32_t total;     /* sum of all CIGAR op lengths (:94); never 0           */
+  uint32_t flag_len;  /* bits 0..11: SAM FLAG; bits 12..31: len(SEQ), 0 if '*' */
+} mg_aln_rec;
+
+#define MG_REC_NEW_BIT 0x80000000u
+#define MG_REC_REF_MASK 0x7fffffffu
+#define MG_REC_FLAG_MASK 0xfffu
+#define MG_REC_LEN_SHIFT 12
+#define MG_REC_MAX_SEQLEN ((1u << 20) - 1u)
+
+/* ------------------------------------------------------------------------ *
+ * Lifecycle, errors, raw device memory
+ * ------------------------------------------------------------------------ */
+int mg_abi_version(void);
+int mg_device_count(void);
+/* Binds the calling process to `device` and creates the library stream. */
+int mg_init(int device);
+/* As mg_init, but launches on a caller-owned hipStream_t (e.g. torch's). */
+int mg_init_on_stream(int device, void* hip_stream);
+void mg_shutdown(void);
+const char* mg_last_error(void);
+int mg_device_name(char* buf, int cap);
+
+int mg_dev_malloc(void** d_ptr, uint64_t bytes);
+int mg_dev_free(void* d_ptr);
+int mg_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes);
+int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes);
+int mg_sync(void);
+
+/* Per-kernel timing with HIP events on the library stream (bench.py's
+ * roofline leg).  Names are the kernel family names listed in DESIGN.md. */
+int mg_prof_enable(int on);
+int mg_prof_reset(void);
+/* Returns number of launches and their summed device time in milliseconds. */
+int mg_prof_get(const char* kernel, uint64_t* launches, double* total_ms);
+
+/* ------------------------------------------------------------------------ *
+ * Stage A — read sketch.
+ * Replaces: `kmc -k60 -ci2 -cs3 ...` canonical k-mer counting of the reads
+ * (scripts/select_db.py:50-52) and the k-mer enumeration / hashing inside
+ * CMash's StreamingQueryDNADatabase.py (scripts/select_db.py:73-76).
+ *
+ * Definition (the oracle, oracle/mg_oracle.c, is the normative statement):
+ * every window of k consecutive [ACGTacgt] bases of every read is upper-cased,
+ * replaced by the lexicographically smaller of itself and its reverse
+ * complement, and hashed with MurmurHash3_x64_128(ASCII k-mer, seed 0), first
+ * 64 bits.  The sketch is the ascending list of DISTINCT hashes <= hmax with
+ * their occurrence counts (saturating at 2^32-1), truncated to the s smallest
+ * when s > 0 (`truncated` reports whether entries were cut).
+ * ------------------------------------------------------------------------ */
+typedef struct mg_sketch mg_sketch;
+
+int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
+                        uint64_t nreads, int k, uint64_t hmax, uint64_t s,
+                        mg_sketch** out);
+/* Union of (hash,count) runs, counts of equal hashes summed, then truncated to
+ * s: the merge step after an all-gather of per-GPU sketches.  Inputs need not
+ * be sorted.  `any_truncated`: OR of the inputs' truncated flags with
+ * `bound` = the smallest last-hash among truncated inputs (entries above it
+ * are dropped so the union is a complete bottom set). */
+int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
+                             uint64_t n, uint64_t s, int any_truncated,
+                             uint64_t bound, mg_sketch** out);
+uint64_t mg_sketch_size(const mg_sketch* sk);
+int mg_sketch_truncated(const mg_sketch* sk);
+uint64_t mg_sketch_kmers_seen(const mg_sketch* sk); /* valid k-mer windows hashed */
+int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes,
+                          const uint32_t** d_counts);
+int mg_sketch_download(const mg_sketch* sk, uint64_t* hashes, uint32_t* counts,
+                       uint64_t cap);
+void mg_sketch_free(mg_sketch* sk);
+
+/* Host-buffer convenience: upload, sketch, download. */
+int mg_sketch_reads(const uint8_t* bases, const uint64_t* offsets,
+                    uint64_t nreads, int k, uint64_t hmax, uint64_t s,
+                    uint64_t* out_hashes, uint32_t* out_counts, uint64_t out_cap,
+                    uint64_t* out_n, int* out_truncated, uint64_t* out_kmers_seen);
+
+/* ------------------------------------------------------------------------ *
+ * Stage A' — genome sketch table (the pre-built DB the hot path consumes).
+ * Replaces: CMash MakeStreamingDNADatabase.py -n 1000 -k 60
+ * (local_tests/retrain_and_test_metalign.sh:49) and the .h5 / KMC-dump / bloom
+ * trio (scripts/select_db.py:44,69-70).  Same k-mer / hash definition as
+ * Stage A; genome g's sketch is its n smallest distinct hashes, ascending, at
+ * out_hashes[out_offsets[g] .. out_offsets[g+1]).  out_hashes needs
+ * ngenomes*n entries, out_offsets ngenomes+1.
+ * ------------------------------------------------------------------------ */
+int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets,
+                      uint64_t ngenomes, int k, uint64_t n,
+                      uint64_t* out_hashes, uint64_t* out_offsets);
+
+typedef struct mg_db mg_db;
+int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets,
+                 uint64_t ngenomes, mg_db** out);
+uint64_t mg_db_ngenomes(const mg_db* db);
+uint64_t mg_db_max_hash(const mg_db* db); /* the hmax to sketch reads with */
+void mg_db_free(mg_db* db);
+
+/* ------------------------------------------------------------------------ *
+ * Stage B — containment of each genome sketch in the read sketch.
+ * Replaces: `kmc_tools simple ... intersect` (scripts/select_db.py:54-56) and
+ * the per-genome containment index of StreamingQueryDNADatabase.py
+ * (scripts/select_db.py:73-76; CSV consumed at :80-85).
+ * For genome g: bound = last hash of the read sketch if it was truncated,
+ * else 2^64-1; sizes[g] = #{h in sketch(g): h <= bound};
+ * hits[g] = #{h in sketch(g): h <= bound, h in read sketch with count >= ci}
+ * (ci = 2 reproduces kmc -ci2).  The containment index written to the CSV is
+ * the double hits/sizes, computed on the host.
+ * ------------------------------------------------------------------------ */
+int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci,
+                       uint32_t* d_hits, uint32_t* d_sizes);
+int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts,
+                   uint64_t qn, int q_truncated, uint32_t ci,
+                   const uint64_t* db_hashes, const uint64_t* db_offsets,
+                   uint64_t ngenomes, uint32_t* out_hits, uint32_t* out_sizes);
+
+/* ------------------------------------------------------------------------ *
+ * Stage C — per-read taxon assignment + abundance histogram.
+ * Replaces the loop of map_and_process (scripts/map_and_profile.py:193-264)
+ * with parse_flag :104-111, filter_line :86-100, clean_read_hits :130-147,
+ * intersect_read_hits :115-125 and process_read :152-176, INCLUDING the
+ * carried state of :229-232 (an Ambiguous read drops the next read's first
+ * line), the always-Ambiguous first boundary (:155-156) and the unflushed
+ * last read (:259-264).
+ *
+ * A shard is a contiguous range of records that starts on a read boundary.
+ * mg_profile_begin_dev computes the shard's composed state map
+ * (incoming "first line dropped" bit -> outgoing bit); the caller composes
+ * the maps of preceding shards (first shard: incoming = 1, the phantom
+ * boundary) and then calls mg_profile_commit_dev.
+ *   has_lookahead != 0: d_recs[nrecs] is the first record of the next shard
+ *     (its pair flags decide the last read of this shard, :225-226);
+ *   has_lookahead == 0: this is the global last shard; its last read is
+ *     never processed (reference behaviour).
+ * Outputs (device, zero-initialised by the caller, accumulated into):
+ *   d_count[t], d_bases[t]  unique reads / bases per dense taxon id (:235-240)
+ *   d_first_seen[t]         min over unique reads of (group_base + local
+ *                           read index); caller initialises to UINT64_MAX.
+ *                           Rebuilds dict insertion order (:240).
+ *   d_scalars[0] += reads (tot_rds, :221); d_scalars[1] += Ambiguous reads
+ *   (:229-231, the phantom boundary included when first_shard != 0).
+ * Multimapped reads (:245-248) are kept in the handle and fetched with
+ * mg_profile_multimapped (CSR, ascending read index).
+ * ------------------------------------------------------------------------ */
+typedef struct mg_profile mg_profile;
+
+int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs,
+                         int has_lookahead, const uint32_t* d_ref2tax,
+                         uint32_t nref, uint32_t ntax, double pct_id,
+                         mg_profile** out);
+/* map[0] = outgoing bit if incoming is 0, map[1] = ... if incoming is 1. */
+int mg_profile_state_map(const mg_profile* p, uint8_t map[2]);
+uint64_t mg_profile_ngroups(const mg_profile* p);
+int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard,
+                          uint64_t group_base, uint64_t* d_count,
+                          uint64_t* d_bases, uint64_t* d_first_seen,
+                          uint64_t* d_scalars);
+/* Sizes of the multimapped CSR after commit. */
+int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads,
+                                uint64_t* nentries);
+/* mm_offsets[nreads+1], mm_tax[nentries] (dense taxon ids, SAM order within
+ * the read), mm_hitlen[nreads], mm_read[nreads] (group_base + local index). */
+int mg_profile_multimapped(const mg_profile* p, uint64_t* mm_offsets,
+                           uint32_t* mm_tax, uint64_t* mm_hitlen,
+                           uint64_t* mm_read);
+void mg_profile_free(mg_profile* p);
+
+/* Host-buffer convenience, single shard = whole stream. Capacities: mm_* as
+ * above with mm_cap_reads / mm_cap_entries entries available. */
+int mg_profile_assign(const mg_aln_rec* recs, uint64_t nrecs,
+                      const uint32_t* ref2tax, uint32_t nref, uint32_t ntax,
+                      double pct_id, uint64_t* out_count, uint64_t* out_bases,
+                      uint64_t* out_first_seen, uint64_t* out_tot_rds,
+                      uint64_t* out_n_ambig, uint64_t* mm_offsets,
+                      uint32_t* mm_tax, uint64_t* mm_hitlen, uint64_t* mm_read,
+                      uint64_t mm_cap_reads, uint64_t mm_cap_entries,
+                      uint64_t* mm_nreads, uint64_t* mm_nentries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METALIGN_HIP_H */

@@ -1,0 +1,380 @@
+"""ctypes binding of libmetalign_hip.so (include/metalign_hip.h).
+
+The HIP library is the ONLY compute path of this package: if the shared object
+is missing or no MI355X is visible, every entry point raises
+`HipUnavailable` — there is no CPU fallback (the CPU oracle under oracle/ is
+test infrastructure and is never imported from here).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmetalign_hip.so")
+
+REC_DTYPE = np.dtype([("ref_new", "<u4"), ("matched", "<u4"), ("total", "<u4"), ("flag_len", "<u4")])
+NEW_BIT = 0x80000000
+REF_MASK = 0x7FFFFFFF
+LEN_SHIFT = 12
+MAX_SEQLEN = (1 << 20) - 1
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+MAX_K = 64
+
+# every symbol include/metalign_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
+    "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_sync",
+    "mg_prof_enable", "mg_prof_reset", "mg_prof_get",
+    "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_size", "mg_sketch_truncated",
+    "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
+    "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
+    "mg_containment_dev", "mg_containment",
+    "mg_profile_begin_dev", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev",
+    "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_free", "mg_profile_assign",
+]
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+
+
+def _np(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the C-ABI library and declare return types; raises HipUnavailable when absent."""
+    if not os.path.exists(path):
+        raise HipUnavailable(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    lib.mg_last_error.restype = ctypes.c_char_p
+    for name in ("mg_sketch_size", "mg_sketch_kmers_seen", "mg_db_ngenomes", "mg_db_max_hash", "mg_profile_ngroups"):
+        getattr(lib, name).restype = ctypes.c_uint64
+    lib.mg_sketch_free.restype = None
+    lib.mg_db_free.restype = None
+    lib.mg_profile_free.restype = None
+    lib.mg_shutdown.restype = None
+    return lib
+
+
+class DeviceArray:
+    """A caller-owned HBM allocation (mg_dev_malloc) with a numpy-like shape/dtype."""
+
+    def __init__(self, hip, count, dtype):
+        self.hip = hip
+        self.dtype = np.dtype(dtype)
+        self.count = int(count)
+        self.nbytes = self.count * self.dtype.itemsize
+        p = _vp()
+        hip._chk(hip.lib.mg_dev_malloc(ctypes.byref(p), ctypes.c_uint64(self.nbytes + 16)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.size == self.count, (host.size, self.count)
+        self.hip._chk(self.hip.lib.mg_memcpy_h2d(_vp(self.ptr), _vp(host.ctypes.data), ctypes.c_uint64(self.nbytes)))
+        return self
+
+    def download(self):
+        out = np.empty(self.count, dtype=self.dtype)
+        self.hip._chk(self.hip.lib.mg_memcpy_d2h(_vp(out.ctypes.data), _vp(self.ptr), ctypes.c_uint64(self.nbytes)))
+        return out
+
+    def fill_bytes(self, host_bytes_array):
+        self.upload(host_bytes_array)
+
+    def free(self):
+        if self.ptr:
+            self.hip.lib.mg_dev_free(_vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):  # best effort
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Sketch:
+    """Device-resident read sketch for one k (opaque mg_sketch handle)."""
+
+    def __init__(self, hip, handle, k):
+        self.hip, self.handle, self.k = hip, handle, k
+
+    @property
+    def size(self):
+        return int(self.hip.lib.mg_sketch_size(self.handle))
+
+    @property
+    def truncated(self):
+        return bool(self.hip.lib.mg_sketch_truncated(self.handle))
+
+    @property
+    def kmers_seen(self):
+        return int(self.hip.lib.mg_sketch_kmers_seen(self.handle))
+
+    def device_ptrs(self):
+        h, c = _vp(), _vp()
+        self.hip._chk(self.hip.lib.mg_sketch_device_ptrs(self.handle, ctypes.byref(h), ctypes.byref(c)))
+        return h.value, c.value
+
+    def download(self):
+        n = self.size
+        h = np.empty(n, dtype=np.uint64)
+        c = np.empty(n, dtype=np.uint32)
+        self.hip._chk(self.hip.lib.mg_sketch_download(self.handle, _np(h, ctypes.c_uint64), _np(c, ctypes.c_uint32),
+                                                      ctypes.c_uint64(n)))
+        return h, c
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_sketch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class SketchTable:
+    """Device-resident genome sketch table for one k (opaque mg_db handle)."""
+
+    def __init__(self, hip, handle):
+        self.hip, self.handle = hip, handle
+
+    @property
+    def ngenomes(self):
+        return int(self.hip.lib.mg_db_ngenomes(self.handle))
+
+    @property
+    def max_hash(self):
+        return int(self.hip.lib.mg_db_max_hash(self.handle))
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_db_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class ProfileShard:
+    """One contiguous shard of alignment records in flight (opaque mg_profile handle)."""
+
+    def __init__(self, hip, handle):
+        self.hip, self.handle = hip, handle
+
+    def state_map(self):
+        m = (ctypes.c_uint8 * 2)()
+        self.hip._chk(self.hip.lib.mg_profile_state_map(self.handle, m))
+        return int(m[0]), int(m[1])
+
+    @property
+    def ngroups(self):
+        return int(self.hip.lib.mg_profile_ngroups(self.handle))
+
+    def commit(self, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars):
+        self.hip._chk(self.hip.lib.mg_profile_commit_dev(
+            self.handle, ctypes.c_int(int(incoming_dropped)), ctypes.c_int(int(first_shard)),
+            ctypes.c_uint64(group_base), _vp(d_count), _vp(d_bases), _vp(d_first_seen), _vp(d_scalars)))
+
+    def multimapped(self):
+        nr, ne = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self.hip._chk(self.hip.lib.mg_profile_multimapped_size(self.handle, ctypes.byref(nr), ctypes.byref(ne)))
+        off = np.zeros(nr.value + 1, dtype=np.uint64)
+        tax = np.zeros(max(ne.value, 1), dtype=np.uint32)
+        hl = np.zeros(max(nr.value, 1), dtype=np.uint64)
+        rd = np.zeros(max(nr.value, 1), dtype=np.uint64)
+        self.hip._chk(self.hip.lib.mg_profile_multimapped(self.handle, _np(off, ctypes.c_uint64),
+                                                          _np(tax, ctypes.c_uint32), _np(hl, ctypes.c_uint64),
+                                                          _np(rd, ctypes.c_uint64)))
+        return off, tax[: ne.value], hl[: nr.value], rd[: nr.value]
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_profile_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Hip:
+    """Process-wide handle on the library + one device."""
+
+    _instance = None
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        if self.lib.mg_device_count() <= 0:
+            raise HipUnavailable("libmetalign_hip.so loaded but no HIP device is visible; there is no CPU fallback")
+        if stream is None:
+            self._chk(self.lib.mg_init(ctypes.c_int(device)))
+        else:
+            self._chk(self.lib.mg_init_on_stream(ctypes.c_int(device), _vp(stream)))
+        self.device = device
+
+    @classmethod
+    def get(cls, device=0, stream=None):
+        if cls._instance is None:
+            cls._instance = cls(device, stream)
+        return cls._instance
+
+    @classmethod
+    def reset(cls):
+        if cls._instance is not None:
+            cls._instance.lib.mg_shutdown()
+            cls._instance = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError("libmetalign_hip rc=%d: %s" % (rc, self.lib.mg_last_error().decode("utf-8", "replace")))
+
+    # ---- misc ----
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._chk(self.lib.mg_device_name(buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        self._chk(self.lib.mg_sync())
+
+    def array(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DeviceArray(self, host.size, host.dtype).upload(host)
+
+    def empty(self, count, dtype):
+        return DeviceArray(self, count, dtype)
+
+    def prof_enable(self, on=True):
+        self._chk(self.lib.mg_prof_enable(ctypes.c_int(1 if on else 0)))
+
+    def prof_reset(self):
+        self._chk(self.lib.mg_prof_reset())
+
+    def prof_get(self, kernel):
+        n, ms = ctypes.c_uint64(0), ctypes.c_double(0.0)
+        self._chk(self.lib.mg_prof_get(kernel.encode(), ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    # ---- stage A ----
+    def sketch_reads_dev(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0):
+        h = _vp()
+        self._chk(self.lib.mg_sketch_reads_dev(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_int(k),
+                                               ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.byref(h)))
+        return Sketch(self, h, k)
+
+    def sketch_from_pairs_dev(self, d_hashes, d_counts, n, k, s=0, any_truncated=False, bound=U64_MAX):
+        h = _vp()
+        self._chk(self.lib.mg_sketch_from_pairs_dev(_vp(d_hashes), _vp(d_counts), ctypes.c_uint64(n),
+                                                    ctypes.c_uint64(s), ctypes.c_int(int(any_truncated)),
+                                                    ctypes.c_uint64(bound), ctypes.byref(h)))
+        return Sketch(self, h, k)
+
+    def sketch_reads(self, bases, offsets, k, hmax=U64_MAX, s=0):
+        """Host arrays in, host arrays out: (hashes, counts, truncated, kmers_seen)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nreads = len(offsets) - 1
+        d_b = self.array(bases if bases.size else np.zeros(1, np.uint8))
+        d_o = self.array(offsets)
+        sk = self.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, hmax, s)
+        try:
+            h, c = sk.download()
+            return h, c, sk.truncated, sk.kmers_seen
+        finally:
+            sk.free()
+            d_b.free()
+            d_o.free()
+
+    # ---- stage A' ----
+    def sketch_genomes(self, bases, offsets, k, n):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        g = len(offsets) - 1
+        out_h = np.zeros(max(g * n, 1), dtype=np.uint64)
+        out_o = np.zeros(g + 1, dtype=np.uint64)
+        self._chk(self.lib.mg_sketch_genomes(_np(bases, ctypes.c_uint8), _np(offsets, ctypes.c_uint64),
+                                             ctypes.c_uint64(g), ctypes.c_int(k), ctypes.c_uint64(n),
+                                             _np(out_h, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
+        return out_h[: int(out_o[-1])].copy(), out_o
+
+    def upload_table(self, hashes, offsets):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if hashes.size == 0:
+            hashes = np.zeros(1, dtype=np.uint64)
+        h = _vp()
+        self._chk(self.lib.mg_db_upload(_np(hashes, ctypes.c_uint64), _np(offsets, ctypes.c_uint64),
+                                        ctypes.c_uint64(len(offsets) - 1), ctypes.byref(h)))
+        return SketchTable(self, h)
+
+    # ---- stage B ----
+    def containment_dev(self, sketch, table, ci, d_hits, d_sizes):
+        self._chk(self.lib.mg_containment_dev(sketch.handle, table.handle, ctypes.c_uint32(ci), _vp(d_hits),
+                                              _vp(d_sizes)))
+
+    def containment(self, sketch, table, ci=2):
+        g = table.ngenomes
+        d_h, d_s = self.empty(max(g, 1), np.uint32), self.empty(max(g, 1), np.uint32)
+        try:
+            self.containment_dev(sketch, table, ci, d_h.ptr, d_s.ptr)
+            return d_h.download()[:g], d_s.download()[:g]
+        finally:
+            d_h.free()
+            d_s.free()
+
+    # ---- stage C ----
+    def profile_begin_dev(self, d_recs, nrecs, has_lookahead, d_ref2tax, nref, ntax, pct_id):
+        h = _vp()
+        self._chk(self.lib.mg_profile_begin_dev(_vp(d_recs), ctypes.c_uint64(nrecs), ctypes.c_int(int(has_lookahead)),
+                                                _vp(d_ref2tax), ctypes.c_uint32(nref), ctypes.c_uint32(ntax),
+                                                ctypes.c_double(pct_id), ctypes.byref(h)))
+        return ProfileShard(self, h)
+
+    def profile_assign(self, recs, ref2tax, ntax, pct_id):
+        """Whole stream on one device: host arrays in, dict of host arrays out (same keys as the oracle)."""
+        recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        ref2tax = np.ascontiguousarray(ref2tax, dtype=np.uint32)
+        n = len(recs)
+        count = np.zeros(max(ntax, 1), dtype=np.uint64)
+        bases = np.zeros(max(ntax, 1), dtype=np.uint64)
+        first = np.zeros(max(ntax, 1), dtype=np.uint64)
+        mm_off = np.zeros(n + 2, dtype=np.uint64)
+        mm_tax = np.zeros(n + 1, dtype=np.uint32)
+        mm_len = np.zeros(n + 1, dtype=np.uint64)
+        mm_read = np.zeros(n + 1, dtype=np.uint64)
+        tot, amb, nmm, nent = (ctypes.c_uint64(0) for _ in range(4))
+        r2t = ref2tax if ref2tax.size else np.zeros(1, np.uint32)
+        self._chk(self.lib.mg_profile_assign(
+            _vp(recs.ctypes.data), ctypes.c_uint64(n), _np(r2t, ctypes.c_uint32), ctypes.c_uint32(len(ref2tax)),
+            ctypes.c_uint32(ntax), ctypes.c_double(pct_id), _np(count, ctypes.c_uint64), _np(bases, ctypes.c_uint64),
+            _np(first, ctypes.c_uint64), ctypes.byref(tot), ctypes.byref(amb), _np(mm_off, ctypes.c_uint64),
+            _np(mm_tax, ctypes.c_uint32), _np(mm_len, ctypes.c_uint64), _np(mm_read, ctypes.c_uint64),
+            ctypes.c_uint64(n + 1), ctypes.c_uint64(n + 1), ctypes.byref(nmm), ctypes.byref(nent)))
+        m, e = nmm.value, nent.value
+        return dict(count=count[:ntax], bases=bases[:ntax], first_seen=first[:ntax], tot_rds=tot.value,
+                    n_ambig=amb.value, mm_offsets=mm_off[: m + 1].copy(), mm_tax=mm_tax[:e].copy(),
+                    mm_hitlen=mm_len[:m].copy(), mm_read=mm_read[:m].copy())

@@ -1,0 +1,178 @@
+// mg_core.hip — lifecycle, error text, raw device memory, per-kernel event timing.
+#include <cstring>
+
+#include "mg_internal.h"
+
+namespace mg {
+
+static thread_local char g_err[512] = "";
+
+Context& ctx() {
+  static Context c;
+  return c;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+void* scratch(const char* name, uint64_t bytes) {
+  Context& c = ctx();
+  DevBuf*& b = c.scratch[name];
+  if (!b) b = new DevBuf();
+  if (b->bytes < bytes || !b->p) {
+    uint64_t want = bytes + bytes / 4 + 256;
+    if (b->alloc(want) != MG_OK) return nullptr;
+  }
+  return b->p;
+}
+
+void scratch_release_all() {
+  Context& c = ctx();
+  for (auto& kv : c.scratch) delete kv.second;
+  c.scratch.clear();
+}
+
+ProfScope::ProfScope(const char* n) : name(n), on(ctx().prof_on) {
+  if (on) (void)hipEventRecord(ctx().ev0, ctx().stream);
+}
+
+ProfScope::~ProfScope() {
+  if (!on) return;
+  Context& c = ctx();
+  (void)hipEventRecord(c.ev1, c.stream);
+  (void)hipEventSynchronize(c.ev1);
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, c.ev0, c.ev1) == hipSuccess) {
+    ProfEntry& e = c.prof[name];
+    e.launches += 1;
+    e.total_ms += ms;
+  }
+}
+
+}  // namespace mg
+
+using mg::ctx;
+using mg::fail;
+
+extern "C" {
+
+int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+int mg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int init_common(int device, void* stream) {
+  mg::Context& c = ctx();
+  if (c.ready) mg_shutdown();
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(MG_ERR_HIP, "no HIP device visible (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(MG_ERR_ARG, "device %d out of range [0,%d)", device, n);
+  MG_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MG_HIP(hipGetDeviceProperties(&prop, device));
+  c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) {
+    c.stream = reinterpret_cast<hipStream_t>(stream);
+    c.own_stream = false;
+  } else {
+    MG_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.own_stream = true;
+  }
+  MG_HIP(hipEventCreate(&c.ev0));
+  MG_HIP(hipEventCreate(&c.ev1));
+  c.device = device;
+  c.ready = true;
+  return MG_OK;
+}
+
+int mg_init(int device) { return init_common(device, nullptr); }
+int mg_init_on_stream(int device, void* hip_stream) { return init_common(device, hip_stream); }
+
+void mg_shutdown(void) {
+  mg::Context& c = ctx();
+  if (!c.ready) return;
+  (void)hipStreamSynchronize(c.stream);
+  mg::scratch_release_all();
+  if (c.ev0) (void)hipEventDestroy(c.ev0);
+  if (c.ev1) (void)hipEventDestroy(c.ev1);
+  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  c = mg::Context();
+}
+
+const char* mg_last_error(void) { return mg::g_err; }
+
+int mg_device_name(char* buf, int cap) {
+  MG_REQUIRE_READY();
+  hipDeviceProp_t prop;
+  MG_HIP(hipGetDeviceProperties(&prop, ctx().device));
+  snprintf(buf, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return MG_OK;
+}
+
+int mg_dev_malloc(void** d_ptr, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (!d_ptr) return fail(MG_ERR_ARG, "null out pointer");
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+  if (e != hipSuccess) return fail(MG_ERR_NOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+  return MG_OK;
+}
+
+int mg_dev_free(void* d_ptr) {
+  MG_REQUIRE_READY();
+  if (d_ptr) MG_HIP(hipFree(d_ptr));
+  return MG_OK;
+}
+
+int mg_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (bytes == 0) return MG_OK;
+  MG_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  MG_HIP(hipStreamSynchronize(ctx().stream));
+  return MG_OK;
+}
+
+int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (bytes == 0) return MG_OK;
+  MG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+  MG_HIP(hipStreamSynchronize(ctx().stream));
+  return MG_OK;
+}
+
+int mg_sync(void) {
+  MG_REQUIRE_READY();
+  MG_HIP(hipStreamSynchronize(ctx().stream));
+  return MG_OK;
+}
+
+int mg_prof_enable(int on) {
+  MG_REQUIRE_READY();
+  ctx().prof_on = on != 0;
+  return MG_OK;
+}
+
+int mg_prof_reset(void) {
+  MG_REQUIRE_READY();
+  ctx().prof.clear();
+  return MG_OK;
+}
+
+int mg_prof_get(const char* kernel, uint64_t* launches, double* total_ms) {
+  MG_REQUIRE_READY();
+  auto it = ctx().prof.find(kernel ? kernel : "");
+  if (launches) *launches = it == ctx().prof.end() ? 0 : it->second.launches;
+  if (total_ms) *total_ms = it == ctx().prof.end() ? 0.0 : it->second.total_ms;
+  return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// mg_internal.h — shared state of libmetalign_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/metalign_hip.h"
+
+namespace mg {
+
+constexpr uint64_t kReservedHash = 0xFFFFFFFFFFFFFFFFull;  // never a sketch member
+
+struct ProfEntry {
+  uint64_t launches = 0;
+  double total_ms = 0.0;
+};
+
+struct DevBuf;
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 256;
+  // profiling
+  bool prof_on = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::map<std::string, ProfEntry> prof;
+  // grow-only named scratch buffers (sort temp storage, candidate lists, ...) so that
+  // steady-state calls do not hipMalloc/hipFree (hipFree synchronises the device)
+  std::map<std::string, DevBuf*> scratch;
+};
+
+Context& ctx();
+int fail(int code, const char* fmt, ...);
+
+#define MG_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return ::mg::fail(MG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+                        __FILE__, __LINE__);                                                  \
+  } while (0)
+
+#define MG_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != MG_OK) return rc__; \
+  } while (0)
+
+#define MG_REQUIRE_READY()                                                        \
+  do {                                                                            \
+    if (!::mg::ctx().ready) return ::mg::fail(MG_ERR_STATE, "mg_init not called"); \
+  } while (0)
+
+// RAII device buffer on the library stream's device.
+struct DevBuf {
+  void* p = nullptr;
+  uint64_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  int alloc(uint64_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { p = nullptr; return fail(MG_ERR_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)n, hipGetErrorString(e)); }
+    bytes = n;
+    return MG_OK;
+  }
+  void release() {
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Grow-only scratch buffer `name` of at least `bytes` bytes; nullptr (and error text set) on failure.
+void* scratch(const char* name, uint64_t bytes);
+void scratch_release_all();
+
+// Times one kernel family with HIP events on the library stream when profiling is on.
+struct ProfScope {
+  const char* name;
+  bool on;
+  explicit ProfScope(const char* n);
+  ~ProfScope();
+};
+
+inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks) {
+  uint64_t b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (unsigned)b;
+}
+
+// ---- internal services implemented in mg_sort.hip (rocPRIM-backed plain library ops) ----
+// Sorts n u64 keys ascending using bits [0,end_bit). out may not alias in.
+int sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, unsigned end_bit);
+int sort_pairs(const uint64_t* d_kin, uint64_t* d_kout, const uint32_t* d_vin, uint32_t* d_vout, uint64_t n);
+// Run-length encode sorted keys -> (unique, counts, *h_runs).
+int rle_keys(const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* h_runs);
+// Sum values of equal adjacent keys (saturating u32) -> (unique, sums, *h_runs).
+int reduce_pairs(const uint64_t* d_keys, const uint32_t* d_vals, uint64_t n, uint64_t* d_unique, uint32_t* d_sums,
+                 uint64_t* h_runs);
+// Sort every segment [offs[i], offs[i+1]) of keys independently.
+int segmented_sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, const uint64_t* d_offsets, uint64_t nseg);
+// Exclusive prefix sums; *h_total receives the grand total.
+int exclusive_sum_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* h_total);
+
+}  // namespace mg
+
+// Opaque handle layouts (shared between translation units).
+struct mg_sketch {
+  mg::DevBuf hashes;   // u64[n]
+  mg::DevBuf counts;   // u32[n]
+  uint64_t n = 0;
+  int truncated = 0;
+  uint64_t kmers_seen = 0;
+  uint64_t last_hash = 0;  // hashes[n-1] when n > 0
+  // bucket index for containment look-ups (built lazily)
+  mg::DevBuf index;    // u32[nbuckets+1]
+  unsigned index_shift = 0;
+  uint64_t index_buckets = 0;
+};
+
+struct mg_db {
+  mg::DevBuf hashes;   // u64[total]
+  mg::DevBuf offsets;  // u64[ngenomes+1]
+  uint64_t ngenomes = 0;
+  uint64_t total = 0;
+  uint64_t max_hash = 0;
+};

@@ -1,0 +1,144 @@
+// mg_kmer.h — device-side k-mer roller + MurmurHash3_x64_128 specialised on k.
+//
+// One lane walks one sequence and keeps, in registers,
+//   * the forward k-mer and its reverse complement as ASCII bytes (what
+//     MurmurHash3 consumes), rolled one byte per base with v_alignbyte, and
+//   * both strands 2-bit packed (first base most significant) so that the
+//     canonical choice "lexicographically smaller of k-mer and revcomp" is one
+//     integer compare.
+// The hash is MurmurHash3_x64_128(seed 0), first 64 bits, of the canonical
+// ASCII k-mer: block/tail structure is resolved at compile time from K.
+// Normative statement: oracle/mg_oracle.c (canonical_hash).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mg {
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t v) {
+  v ^= v >> 33;
+  v *= 0xff51afd7ed558ccdULL;
+  v ^= v >> 33;
+  v *= 0xc4ceb9fe1a85ec53ULL;
+  v ^= v >> 33;
+  return v;
+}
+
+// Base decode: A,C,G,T (either case) -> 0..3 (lexicographic order), anything else -> invalid.
+// idx = (b & 0xDF) - 'A'; valid letters sit at idx 0 (A), 2 (C), 6 (G), 19 (T).
+__device__ __forceinline__ bool decode_base(uint32_t b, uint32_t& code) {
+  uint32_t idx = (b & 0xDFu) - 0x41u;
+  bool ok = idx < 20u && ((0x80045u >> idx) & 1u);
+  uint32_t x = (b >> 1) & 3u;  // A:0 C:1 T:2 G:3
+  code = x ^ (x >> 1);         // A:0 C:1 G:2 T:3
+  return ok;
+}
+
+template <int K>
+struct Roller {
+  static_assert(K >= 1 && K <= 64, "k out of range");
+  static constexpr int ND = (K + 3) / 4;       // dwords holding K ASCII bytes
+  static constexpr int NB = K - 4 * (ND - 1);  // valid bytes in the last dword, 1..4
+  static constexpr int NW = (K + 31) / 32;     // 64-bit words of the 2-bit form
+  static constexpr uint32_t LAST_MASK = NB == 4 ? 0xffffffffu : ((1u << (8 * NB)) - 1u);
+
+  uint32_t f[ND];  // forward strand, ASCII, byte j of the string at bits 8*(j%4) of f[j/4]
+  uint32_t r[ND];  // reverse complement, ASCII
+  uint64_t pf_lo, pf_hi, pr_lo, pr_hi;  // 2-bit packed strands (hi unused when K <= 32)
+  int run;                              // consecutive valid bases seen
+
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) { f[j] = 0; r[j] = 0; }
+    pf_lo = pf_hi = pr_lo = pr_hi = 0;
+    run = 0;
+  }
+
+  // Append one valid base with code c (0..3).
+  __device__ __forceinline__ void push(uint32_t c) {
+    const uint32_t up = (0x54474341u >> (8 * c)) & 0xffu;  // "ACGT"[c]
+    const uint32_t cu = (0x41434754u >> (8 * c)) & 0xffu;  // complement: "TGCA"[c]
+    // forward ASCII window: drop byte 0, append `up` as byte K-1
+#pragma unroll
+    for (int j = 0; j + 1 < ND; ++j) f[j] = __builtin_amdgcn_alignbyte(f[j + 1], f[j], 1);
+    f[ND - 1] = (f[ND - 1] >> 8) | (up << (8 * (NB - 1)));
+    // reverse-complement ASCII window: prepend `cu` as byte 0, drop byte K-1
+#pragma unroll
+    for (int j = ND - 1; j >= 1; --j) r[j] = __builtin_amdgcn_alignbyte(r[j], r[j - 1], 3);
+    r[0] = (r[0] << 8) | cu;
+    r[ND - 1] &= LAST_MASK;
+    // 2-bit packed strands
+    const uint64_t cc = 3u - c;
+    if constexpr (NW == 1) {
+      constexpr uint64_t M = K == 32 ? ~0ull : ((1ull << (2 * K)) - 1ull);
+      pf_lo = ((pf_lo << 2) | c) & M;
+      pr_lo = (pr_lo >> 2) | (cc << (2 * (K - 1)));
+    } else {
+      constexpr int HB = 2 * (K - 32);  // bits used in the high word
+      constexpr uint64_t MH = HB == 64 ? ~0ull : ((1ull << HB) - 1ull);
+      pf_hi = ((pf_hi << 2) | (pf_lo >> 62)) & MH;
+      pf_lo = (pf_lo << 2) | c;
+      pr_lo = (pr_lo >> 2) | (pr_hi << 62);
+      pr_hi = (pr_hi >> 2) | (cc << (HB - 2));
+    }
+    ++run;
+  }
+
+  __device__ __forceinline__ bool full() const { return run >= K; }
+
+  __device__ __forceinline__ bool forward_is_canonical() const {
+    if constexpr (NW == 1) return pf_lo <= pr_lo;
+    return pf_hi < pr_hi || (pf_hi == pr_hi && pf_lo <= pr_lo);
+  }
+
+  // MurmurHash3_x64_128(canonical ASCII k-mer, seed 0) -> first 64 bits.
+  __device__ __forceinline__ uint64_t hash() const {
+    const bool fw = forward_is_canonical();
+    uint32_t w[ND + 4];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) w[j] = fw ? f[j] : r[j];
+#pragma unroll
+    for (int j = ND; j < ND + 4; ++j) w[j] = 0;
+    constexpr uint64_t C1 = 0x87c37b91114253d5ULL, C2 = 0x4cf5ad432745937fULL;
+    constexpr int NBLK = K / 16, TAIL = K & 15;
+    uint64_t h1 = 0, h2 = 0;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      uint64_t k1 = (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32);
+      uint64_t k2 = (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32);
+      k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+      h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+      k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+      h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    }
+    if constexpr (TAIL > 8) {
+      uint64_t k2 = (uint64_t)w[4 * NBLK + 2] | ((uint64_t)w[4 * NBLK + 3] << 32);
+      k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+    }
+    if constexpr (TAIL > 0) {
+      uint64_t k1 = (uint64_t)w[4 * NBLK] | ((uint64_t)w[4 * NBLK + 1] << 32);
+      k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+  }
+};
+
+// Calls F.template operator()<K>() for the runtime k; false when k is unsupported.
+template <class F, int K = 1>
+inline bool dispatch_k(int k, F&& fn) {
+  if constexpr (K > MG_MAX_K) {
+    return false;
+  } else {
+    if (k == K) { fn.template operator()<K>(); return true; }
+    return dispatch_k<F, K + 1>(k, static_cast<F&&>(fn));
+  }
+}
+
+}  // namespace mg

@@ -1,0 +1,495 @@
+// mg_sketch.hip — Stage A (read sketch) and Stage A' (genome sketch table).
+//
+// K1 `k_sketch_reads<K>`: one lane per read, one wavefront per tile of 64
+// consecutive reads.  The tile's bases (contiguous in the concatenated read
+// buffer) are copied HBM -> LDS with 16-byte coalesced loads, then every lane
+// rolls its own read out of LDS (mg_kmer.h) and hashes one canonical k-mer per
+// base.  Hashes <= hmax are compacted per wavefront (ballot + popcount) into an
+// LDS candidate buffer that is flushed to HBM with one atomic reservation per
+// flush.  The candidate list is then sorted / run-length encoded (mg_sort.hip)
+// into the sketch: ascending distinct hashes with counts.
+//
+// Replaces: kmc -k60 -ci2 -cs3 (scripts/select_db.py:50-52) + k-mer hashing in
+// CMash's streaming query (scripts/select_db.py:73-76).
+#include "mg_internal.h"
+#include "mg_kmer.h"
+
+namespace mg {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+constexpr int kCandBuf = 256;  // u64 entries per wavefront
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS traffic of one wavefront is executed in order; this only pins the compiler.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint64_t t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Wave-level candidate sink: LDS staging + one global reservation per flush.
+struct CandSink {
+  uint64_t* lds;      // this wave's kCandBuf entries
+  uint64_t* out;      // global candidate list
+  uint64_t cap;       // entries available in `out`
+  unsigned long long* out_n;
+  int n;              // entries staged (wave-uniform)
+
+  __device__ __forceinline__ void flush(int lane) {
+    if (n == 0) return;
+    wave_lds_sync();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(out_n, (unsigned long long)n);
+    base = __shfl(base, 0, 64);
+    for (int i = lane; i < n; i += 64)
+      if (base + i < cap) out[base + i] = lds[i];
+    wave_lds_sync();
+    n = 0;
+  }
+
+  __device__ __forceinline__ void offer(bool hit, uint64_t h, int lane) {
+    const unsigned long long m = __ballot(hit);
+    if (m == 0) return;
+    if (hit) lds[n + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    n += __popcll(m);
+    if (n > kCandBuf - 64) flush(lane);
+  }
+};
+
+template <int K, bool FROM_LDS>
+__device__ __forceinline__ void walk_reads(const uint8_t* src, uint64_t len, uint64_t maxlen, uint64_t hmax,
+                                           CandSink& sink, uint64_t& kmers, int lane) {
+  Roller<K> roll;
+  roll.reset();
+  for (uint64_t pos = 0; pos < maxlen; ++pos) {
+    bool hit = false;
+    uint64_t h = 0;
+    if (pos < len) {
+      uint32_t b = src[pos];
+      uint32_t c;
+      if (decode_base(b, c)) {
+        roll.push(c);
+        if (roll.full()) {
+          h = roll.hash();
+          ++kmers;
+          hit = h <= hmax;
+        }
+      } else {
+        roll.run = 0;
+      }
+    }
+    sink.offer(hit, h, lane);
+  }
+}
+
+// counters[0] = candidates produced (may exceed cap: overflow => caller retries), counters[1] = k-mers hashed
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restrict__ bases,
+                                                         const uint64_t* __restrict__ offsets, uint64_t nreads,
+                                                         uint64_t hmax, uint64_t* __restrict__ cand, uint64_t cand_cap,
+                                                         unsigned long long* __restrict__ counters,
+                                                         unsigned stage_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* stage = smem + (size_t)wave * stage_bytes;
+  uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
+  CandSink sink{cbuf, cand, cand_cap, counters, 0};
+  uint64_t kmers = 0;
+  const uint64_t ntiles = (nreads + 63) / 64;
+  for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
+       tile += (uint64_t)gridDim.x * kWavesPerBlock) {
+    const uint64_t r0 = tile * 64;
+    const uint64_t r = r0 + lane;
+    uint64_t beg = 0, end = 0;
+    if (r < nreads) { beg = offsets[r]; end = offsets[r + 1]; }
+    const uint64_t len = end - beg;
+    const uint64_t maxlen = wave_max_u64(len);
+    const uint64_t t_beg = __shfl(beg, 0, 64);
+    const uint64_t t_end = wave_max_u64(end);
+    const uintptr_t a_first = reinterpret_cast<uintptr_t>(bases) + t_beg;
+    const uintptr_t a0 = a_first & ~(uintptr_t)15;
+    const uint64_t shift = a_first - a0;
+    const uint64_t nbytes = shift + (t_end - t_beg);
+    if (nbytes <= stage_bytes) {
+      // coalesced HBM -> LDS copy of the whole tile (16 B per lane per step)
+      const uint4* g = reinterpret_cast<const uint4*>(a0);
+      uint4* s = reinterpret_cast<uint4*>(stage);
+      for (uint64_t i = lane; i * 16 < nbytes; i += 64) s[i] = g[i];
+      wave_lds_sync();
+      walk_reads<K, true>(stage + shift + (beg - t_beg), len, maxlen, hmax, sink, kmers, lane);
+      wave_lds_sync();
+    } else {
+      walk_reads<K, false>(bases + beg, len, maxlen, hmax, sink, kmers, lane);
+    }
+  }
+  sink.flush(lane);
+  kmers = wave_sum_u64(kmers);
+  if (lane == 0 && kmers) atomicAdd(counters + 1, (unsigned long long)kmers);
+}
+
+// Stage A': hash of the k-mer ENDING at every base position of a batch of genomes
+// (kReservedHash where there is none).  One lane per run of kChunk positions.
+constexpr int kChunk = 64;
+
+template <int K>
+__global__ __launch_bounds__(256) void k_hash_positions(const uint8_t* __restrict__ bases,
+                                                        const uint64_t* __restrict__ offsets, uint64_t nseq,
+                                                        uint64_t nbases, uint64_t* __restrict__ out) {
+  const uint64_t nchunks = (nbases + kChunk - 1) / kChunk;
+  for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
+       ch += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p0 = ch * kChunk;
+    const uint64_t p1 = p0 + kChunk < nbases ? p0 + kChunk : nbases;
+    // sequence containing p0: last g with offsets[g] <= p0 (empty sequences are skipped by the walk below)
+    uint64_t lo = 0, hi = nseq;  // invariant: offsets[lo] <= p0 < offsets[hi]
+    while (hi - lo > 1) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (offsets[mid] <= p0) lo = mid; else hi = mid;
+    }
+    uint64_t g = lo;
+    uint64_t g_beg = offsets[g], g_end = offsets[g + 1];
+    Roller<K> roll;
+    roll.reset();
+    uint64_t p = p0 >= (uint64_t)(K - 1) ? p0 - (K - 1) : 0;
+    if (p < g_beg) p = g_beg;  // warm-up never crosses into the previous sequence
+    for (; p < p1; ++p) {
+      while (p >= g_end) {  // entered the next sequence
+        ++g;
+        g_beg = g_end;
+        g_end = offsets[g + 1];
+        roll.run = 0;
+      }
+      uint32_t c;
+      uint64_t h = kReservedHash;
+      if (decode_base(bases[p], c)) {
+        roll.push(c);
+        if (roll.full()) h = roll.hash();
+      } else {
+        roll.run = 0;
+      }
+      if (p >= p0) out[p] = h;
+    }
+  }
+}
+
+// Per genome: first n distinct values of its sorted hash segment -> out[g*n ..], cnt[g].
+__global__ __launch_bounds__(256) void k_take_bottom_n(const uint64_t* __restrict__ sorted,
+                                                       const uint64_t* __restrict__ offsets, uint64_t nseq, uint64_t n,
+                                                       uint64_t* __restrict__ out, uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t wave_tot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t g = blockIdx.x; g < nseq; g += gridDim.x) {
+    const uint64_t beg = offsets[g], end = offsets[g + 1];
+    uint64_t taken = 0;
+    for (uint64_t base = beg; base < end && taken < n; base += 256) {
+      const uint64_t i = base + threadIdx.x;
+      uint64_t v = kReservedHash;
+      bool head = false;
+      if (i < end) {
+        v = sorted[i];
+        head = v != kReservedHash && (i == beg || sorted[i - 1] != v);
+      }
+      const unsigned long long m = __ballot(head);
+      if (lane == 0) wave_tot[wave] = __popcll(m);
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += wave_tot[w];
+        total += wave_tot[w];
+      }
+      const uint64_t pos = taken + before + __popcll(m & ((1ull << lane) - 1ull));
+      if (head && pos < n) out[g * n + pos] = v;
+      taken += total;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[g] = (uint32_t)(taken < n ? taken : n);
+  }
+}
+
+__global__ void k_gather_counts_ge(const uint32_t* counts, uint64_t n, uint32_t ci, uint32_t* flags) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = counts[i] >= ci;
+}
+
+static unsigned bit_length(uint64_t v) {
+  unsigned b = 0;
+  while (v) { ++b; v >>= 1; }
+  return b ? b : 1;
+}
+
+// Finalise a sketch from n sorted-unique (hash,count) entries living in scratch.
+static int adopt_runs(mg_sketch* sk, const uint64_t* d_unique, const uint32_t* d_counts, uint64_t runs, uint64_t s) {
+  hipStream_t st = ctx().stream;
+  uint64_t keep = runs;
+  if (s > 0 && runs > s) { keep = s; sk->truncated = 1; }
+  MG_TRY(sk->hashes.alloc(keep * sizeof(uint64_t)));
+  MG_TRY(sk->counts.alloc(keep * sizeof(uint32_t)));
+  if (keep) {
+    MG_HIP(hipMemcpyAsync(sk->hashes.p, d_unique, keep * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    MG_HIP(hipMemcpyAsync(sk->counts.p, d_counts, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    MG_HIP(hipMemcpyAsync(&sk->last_hash, d_unique + (keep - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+  }
+  sk->n = keep;
+  return MG_OK;
+}
+
+template <int K>
+static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t hmax,
+                               uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, unsigned stage_bytes) {
+  Context& c = ctx();
+  const size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
+  const uint64_t ntiles = (nreads + 63) / 64;
+  // enough resident blocks to fill every CU at the LDS-limited occupancy, grid-stride over the rest
+  unsigned per_cu = (unsigned)(160 * 1024 / (lds ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
+  ProfScope ps("sketch_reads");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
+                     nreads, hmax, d_cand, cap, d_counters, stage_bytes);
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
+}  // namespace mg
+
+using namespace mg;
+
+extern "C" {
+
+int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
+                        uint64_t s, mg_sketch** out) {
+  MG_REQUIRE_READY();
+  if (!out) return fail(MG_ERR_ARG, "null out handle");
+  *out = nullptr;
+  if (k < 1 || k > MG_MAX_K) return fail(MG_ERR_ARG, "k=%d outside [1,%d]", k, MG_MAX_K);
+  if (nreads > 0 && (!d_bases || !d_offsets)) return fail(MG_ERR_ARG, "null device input");
+  if (hmax == kReservedHash) hmax = kReservedHash - 1;
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  mg_sketch* sk = new mg_sketch();
+  auto bail = [&](int rc) { delete sk; return rc; };
+  if (nreads == 0) {
+    int rc = sk->hashes.alloc(0); if (rc) return bail(rc);
+    rc = sk->counts.alloc(0); if (rc) return bail(rc);
+    *out = sk;
+    return MG_OK;
+  }
+  // total bases -> candidate capacity estimate and LDS tile size
+  uint64_t h_off[2];
+  MG_HIP(hipMemcpyAsync(&h_off[0], d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipMemcpyAsync(&h_off[1], d_offsets + nreads, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  const uint64_t nbases = h_off[1] - h_off[0];
+  const double frac = ((double)hmax + 1.0) / 18446744073709551616.0;
+  uint64_t cap = (uint64_t)((double)nbases * frac * 1.25) + (1u << 16);
+  if (cap > nbases + 64) cap = nbases + 64;
+  // LDS tile: 64 reads of average length, 12.5 % slack, 16-byte granules, at most 14 KiB per wavefront
+  uint64_t avg = (nbases + nreads - 1) / nreads;
+  uint64_t stage = ((64 * avg * 9 / 8 + 64 + 15) / 16) * 16;
+  if (stage < 2048) stage = 2048;
+  if (stage > 14336) stage = 14336;
+  unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 2 * sizeof(unsigned long long));
+  if (!d_counters) return bail(MG_ERR_NOMEM);
+  unsigned long long h_counters[2] = {0, 0};
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    uint64_t* d_cand = (uint64_t*)scratch("sk_cand", cap * sizeof(uint64_t));
+    if (!d_cand) return bail(MG_ERR_NOMEM);
+    MG_HIP(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
+    int rc = MG_ERR_ARG;
+    bool ok = dispatch_k(k, [&]<int K>() {
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, d_cand, cap, d_counters, (unsigned)stage);
+    });
+    if (!ok) return bail(fail(MG_ERR_ARG, "unsupported k=%d", k));
+    if (rc) return bail(rc);
+    MG_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    if (h_counters[0] <= cap) break;
+    if (attempt == 1) return bail(fail(MG_ERR_CAPACITY, "candidate list overflow after retry"));
+    cap = h_counters[0] + 64;  // exact size is known now; rerun once
+  }
+  const uint64_t ncand = h_counters[0];
+  sk->kmers_seen = h_counters[1];
+  uint64_t* d_cand = (uint64_t*)scratch("sk_cand", cap * sizeof(uint64_t));
+  uint64_t* d_sorted = (uint64_t*)scratch("sk_sorted", (ncand + 1) * sizeof(uint64_t));
+  uint64_t* d_unique = (uint64_t*)scratch("sk_unique", (ncand + 1) * sizeof(uint64_t));
+  uint32_t* d_counts = (uint32_t*)scratch("sk_counts", (ncand + 1) * sizeof(uint32_t));
+  if (!d_sorted || !d_unique || !d_counts) return bail(MG_ERR_NOMEM);
+  uint64_t runs = 0;
+  {
+    ProfScope ps("sketch_sort");
+    int rc = sort_keys(d_cand, d_sorted, ncand, bit_length(hmax));
+    if (rc) return bail(rc);
+  }
+  {
+    ProfScope ps("sketch_rle");
+    int rc = rle_keys(d_sorted, ncand, d_unique, d_counts, &runs);
+    if (rc) return bail(rc);
+  }
+  int rc = adopt_runs(sk, d_unique, d_counts, runs, s);
+  if (rc) return bail(rc);
+  *out = sk;
+  return MG_OK;
+}
+
+int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
+                             int any_truncated, uint64_t bound, mg_sketch** out) {
+  MG_REQUIRE_READY();
+  if (!out) return fail(MG_ERR_ARG, "null out handle");
+  *out = nullptr;
+  mg_sketch* sk = new mg_sketch();
+  auto bail = [&](int rc) { delete sk; return rc; };
+  uint64_t* d_ks = (uint64_t*)scratch("mp_keys", (n + 1) * sizeof(uint64_t));
+  uint32_t* d_vs = (uint32_t*)scratch("mp_vals", (n + 1) * sizeof(uint32_t));
+  uint64_t* d_unique = (uint64_t*)scratch("sk_unique", (n + 1) * sizeof(uint64_t));
+  uint32_t* d_sums = (uint32_t*)scratch("sk_counts", (n + 1) * sizeof(uint32_t));
+  if (!d_ks || !d_vs || !d_unique || !d_sums) return bail(MG_ERR_NOMEM);
+  uint64_t runs = 0;
+  int rc = sort_pairs(d_hashes, d_ks, d_counts, d_vs, n);
+  if (rc) return bail(rc);
+  rc = reduce_pairs(d_ks, d_vs, n, d_unique, d_sums, &runs);
+  if (rc) return bail(rc);
+  if (any_truncated && runs > 0) {
+    // keep only the complete part of the union: entries <= bound (host-side lower_bound on the device array)
+    std::vector<uint64_t> h(runs);
+    MG_HIP(hipMemcpyAsync(h.data(), d_unique, runs * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
+    MG_HIP(hipStreamSynchronize(ctx().stream));
+    uint64_t keep = 0;
+    while (keep < runs && h[keep] <= bound) ++keep;
+    if (keep < runs) { runs = keep; sk->truncated = 1; }
+    else sk->truncated = 1;
+  }
+  rc = adopt_runs(sk, d_unique, d_sums, runs, s);
+  if (rc) return bail(rc);
+  *out = sk;
+  return MG_OK;
+}
+
+uint64_t mg_sketch_size(const mg_sketch* sk) { return sk ? sk->n : 0; }
+int mg_sketch_truncated(const mg_sketch* sk) { return sk ? sk->truncated : 0; }
+uint64_t mg_sketch_kmers_seen(const mg_sketch* sk) { return sk ? sk->kmers_seen : 0; }
+
+int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes, const uint32_t** d_counts) {
+  if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  if (d_hashes) *d_hashes = sk->hashes.as<uint64_t>();
+  if (d_counts) *d_counts = sk->counts.as<uint32_t>();
+  return MG_OK;
+}
+
+int mg_sketch_download(const mg_sketch* sk, uint64_t* hashes, uint32_t* counts, uint64_t cap) {
+  MG_REQUIRE_READY();
+  if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  if (cap < sk->n) return fail(MG_ERR_CAPACITY, "sketch has %llu entries, buffer holds %llu", (unsigned long long)sk->n,
+                               (unsigned long long)cap);
+  if (sk->n == 0) return MG_OK;
+  hipStream_t st = ctx().stream;
+  if (hashes) MG_HIP(hipMemcpyAsync(hashes, sk->hashes.p, sk->n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  if (counts) MG_HIP(hipMemcpyAsync(counts, sk->counts.p, sk->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  return MG_OK;
+}
+
+void mg_sketch_free(mg_sketch* sk) { delete sk; }
+
+int mg_sketch_reads(const uint8_t* bases, const uint64_t* offsets, uint64_t nreads, int k, uint64_t hmax, uint64_t s,
+                    uint64_t* out_hashes, uint32_t* out_counts, uint64_t out_cap, uint64_t* out_n, int* out_truncated,
+                    uint64_t* out_kmers_seen) {
+  MG_REQUIRE_READY();
+  if (!offsets || !out_n) return fail(MG_ERR_ARG, "null argument");
+  const uint64_t nbases = offsets[nreads];
+  DevBuf d_bases, d_offsets;
+  MG_TRY(d_bases.alloc(nbases + 16));
+  MG_TRY(d_offsets.alloc((nreads + 1) * sizeof(uint64_t)));
+  MG_TRY(mg_memcpy_h2d(d_bases.p, bases, nbases));
+  MG_TRY(mg_memcpy_h2d(d_offsets.p, offsets, (nreads + 1) * sizeof(uint64_t)));
+  mg_sketch* sk = nullptr;
+  MG_TRY(mg_sketch_reads_dev(d_bases.as<uint8_t>(), d_offsets.as<uint64_t>(), nreads, k, hmax, s, &sk));
+  *out_n = sk->n;
+  if (out_truncated) *out_truncated = sk->truncated;
+  if (out_kmers_seen) *out_kmers_seen = sk->kmers_seen;
+  int rc = mg_sketch_download(sk, out_hashes, out_counts, out_cap);
+  mg_sketch_free(sk);
+  return rc;
+}
+
+int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                      uint64_t* out_hashes, uint64_t* out_offsets) {
+  MG_REQUIRE_READY();
+  if (!offsets || !out_offsets) return fail(MG_ERR_ARG, "null argument");
+  if (k < 1 || k > MG_MAX_K) return fail(MG_ERR_ARG, "k=%d outside [1,%d]", k, MG_MAX_K);
+  if (n == 0) return fail(MG_ERR_ARG, "n must be positive");
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  out_offsets[0] = 0;
+  const uint64_t kBatchBases = 1ull << 28;  // 2 GiB of position hashes per batch
+  uint64_t g0 = 0, written = 0;
+  std::vector<uint64_t> h_slots;
+  std::vector<uint32_t> h_cnt;
+  std::vector<uint64_t> rel;
+  while (g0 < ngenomes) {
+    uint64_t g1 = g0 + 1;
+    while (g1 < ngenomes && offsets[g1 + 1] - offsets[g0] <= kBatchBases && g1 - g0 < (1u << 20)) ++g1;
+    const uint64_t ng = g1 - g0, nb = offsets[g1] - offsets[g0];
+    if (nb > 0xffffffffull) return fail(MG_ERR_ARG, "single genome of %llu bases exceeds 2^32-1", (unsigned long long)nb);
+    rel.resize(ng + 1);
+    for (uint64_t i = 0; i <= ng; ++i) rel[i] = offsets[g0 + i] - offsets[g0];
+    uint8_t* d_bases = (uint8_t*)scratch("g_bases", nb + 16);
+    uint64_t* d_off = (uint64_t*)scratch("g_off", (ng + 1) * sizeof(uint64_t));
+    uint64_t* d_pos = (uint64_t*)scratch("g_pos", (nb + 1) * sizeof(uint64_t));
+    uint64_t* d_sorted = (uint64_t*)scratch("g_sorted", (nb + 1) * sizeof(uint64_t));
+    uint64_t* d_out = (uint64_t*)scratch("g_out", ng * n * sizeof(uint64_t));
+    uint32_t* d_cnt = (uint32_t*)scratch("g_cnt", ng * sizeof(uint32_t));
+    if (!d_bases || !d_off || !d_pos || !d_sorted || !d_out || !d_cnt) return MG_ERR_NOMEM;
+    if (nb) MG_HIP(hipMemcpyAsync(d_bases, bases + offsets[g0], nb, hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemcpyAsync(d_off, rel.data(), (ng + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    if (nb) {
+      ProfScope ps("hash_positions");
+      const uint64_t nchunks = (nb + kChunk - 1) / kChunk;
+      unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
+      bool ok = dispatch_k(k, [&]<int K>() {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
+                           d_pos);
+      });
+      if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
+      MG_HIP(hipGetLastError());
+    }
+    MG_TRY(segmented_sort_keys(d_pos, d_sorted, nb, d_off, ng));
+    {
+      ProfScope ps("take_bottom_n");
+      hipLaunchKernelGGL(k_take_bottom_n, dim3(grid_for(ng, 1, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_sorted,
+                         d_off, ng, n, d_out, d_cnt);
+      MG_HIP(hipGetLastError());
+    }
+    h_slots.resize(ng * n);
+    h_cnt.resize(ng);
+    MG_HIP(hipMemcpyAsync(h_slots.data(), d_out, ng * n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt, ng * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < ng; ++i) {
+      for (uint32_t j = 0; j < h_cnt[i]; ++j) out_hashes[written + j] = h_slots[i * n + j];
+      written += h_cnt[i];
+      out_offsets[g0 + i + 1] = written;
+    }
+    g0 = g1;
+  }
+  return MG_OK;
+}
+
+}  // extern "C"

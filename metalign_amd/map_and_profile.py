@@ -1,0 +1,410 @@
+#! /usr/bin/env python
+"""Map + profile stage (drop-in for /root/reference/scripts/map_and_profile.py).
+
+Same command line, same function names and return shapes as the reference
+module, so `metalign.py` and third-party callers can swap it in:
+
+    get_acc2info(args)                        scripts/map_and_profile.py:64-81
+    map_and_process(args, instream, a2i, t2i) :193-264   <- runs on the MI355X
+    preprocess_multimapped / resolve_multi_prop / tree_results_cami /
+    compute_abundances / gather_results / write_results / map_main
+
+What changed: the per-line / per-read Python loop of map_and_process is
+replaced by (1) a tokeniser that turns each retained SAM line into a 16-byte
+record and (2) the HIP kernels behind `mg_profile_*` (metalign_amd/csrc/
+mg_profile.hip), which reproduce the reference's read classification —
+carried "drop the next first line" state, phantom first boundary and
+unflushed last read included.  Everything after the loop is O(#taxa) host
+arithmetic kept in double precision in the reference's operation order so the
+CAMI file is byte-identical.
+
+There is no CPU fallback: without libmetalign_hip.so / a GPU, map_and_process
+raises (metalign_amd._hip.HipUnavailable).
+"""
+import argparse
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+from . import _hip
+
+start = time.time()
+RANKS = ['superkingdom', 'phylum', 'class', 'order', 'family', 'genus', 'species', 'strain']
+_RANK_POS = {r: i for i, r in enumerate(RANKS)}
+
+
+def echo(msg, verbose):
+    if not verbose:
+        return
+    elapsed = int(time.time() - start)
+    print('[%02d:%02d:%02d] %s' % (elapsed // 3600, (elapsed // 60) % 60, elapsed % 60, msg))
+
+
+def profile_parseargs(argv=None):
+    p = argparse.ArgumentParser(description='Compute abundance estimations for species in a sample.')
+    p.add_argument('infiles', nargs='+', help='sam or reads file(s) (space-delimited if multiple). Required.')
+    p.add_argument('data', help='Path to data/ directory with the files from setup_data.sh')
+    p.add_argument('--db', default='NONE', help='Path to database from select_db.py. Required if read files given')
+    p.add_argument('--dbinfo', default='AUTO', help='Location of db_info file. Default: data/db_info.txt')
+    p.add_argument('--input_type', default='AUTO', choices=['fastq', 'fasta', 'sam', 'AUTO'],
+                   help='Type of input file (fastq/fasta/sam). Default: try to automatically determine')
+    p.add_argument('--length_normalize', action='store_true', help='Normalize abundances by genome length.')
+    p.add_argument('--low_mem', action='store_true',
+                   help='Run in low memory mode, with inexact multimapped processing.')
+    p.add_argument('--min_abundance', type=float, default=10**-4,
+                   help='Minimum abundance for a taxa to be included in the results. Default: 10^(-4).')
+    p.add_argument('--rank_renormalize', action='store_true',
+                   help='Renormalize abundances to 100 pct. at each rank, e.g if an organism has a species but not genus label.')
+    p.add_argument('--output', default='abundances.tsv', help='Output abundances file. Default: abundances.txt')
+    p.add_argument('--pct_id', type=float, default=0.5,
+                   help='Minimum percent identity from reference to count a hit.')
+    p.add_argument('--no_quantify_unmapped', action='store_true',
+                   help='Do not factor in unmapped reads in abundance estimation.')
+    p.add_argument('--read_cutoff', type=int, default=1, help='Number of reads to count an organism as present.')
+    p.add_argument('--sampleID', default='NONE', help='Sample ID for output. Defaults to input file name(s).')
+    p.add_argument('--threads', type=int, default=4, help='Number of compute threads for Minimap2. Default: 4')
+    p.add_argument('--verbose', action='store_true', help='Print verbose output.')
+    return p.parse_args(argv)
+
+
+def get_taxid_rank(taxlin):
+    """Rank named by the last non-empty field of a 7-pipe lineage (reference :49-57)."""
+    fields = taxlin.split('|')
+    trailing = 0
+    for i in range(1, len(taxlin) + 1):  # the reference bounds this walk by the STRING length
+        if fields[-i] != '':
+            break
+        trailing += 1
+    return RANKS[-(trailing + 1)]
+
+
+def get_acc2info(args):
+    """db_info -> (acc2info, taxid2info) exactly as the reference builds them (:64-81)."""
+    echo('Reading dbinfo file...', args.verbose)
+    acc2info, taxid2info = {}, {}
+    with open(args.dbinfo, 'r') as fh:
+        fh.readline()
+        for row in fh:
+            acc, acclen, taxid, namelin, taxlin = row.strip().split('\t')
+            rank = get_taxid_rank(taxlin)
+            if rank == 'strain' and acc != 'Unmapped':
+                taxid, taxlin = taxid + '.1', taxlin + '.1'
+            acclen = int(acclen)
+            acc2info[acc] = [acclen, taxid, namelin, taxlin]
+            if taxid in taxid2info:
+                taxid2info[taxid][0] += acclen
+            else:
+                taxid2info[taxid] = [acclen, rank, namelin, taxlin]
+    return acc2info, taxid2info
+
+
+# --------------------------------------------------------------------------------------
+# SAM text -> 16-byte records (include/metalign_hip.h: mg_aln_rec)
+# --------------------------------------------------------------------------------------
+class _Tokeniser:
+    """Line filter of :201-217 + CIGAR walk of :86-100, producing one record per retained line.
+
+    Errors are raised eagerly, with the exception types the reference raises lazily for the same
+    input (KeyError for an unknown RNAME :217, IndexError for < 12 fields :97, ValueError for a
+    CIGAR the reference cannot parse :90-93).
+    """
+
+    def __init__(self, acc_index):
+        self.acc_index = acc_index
+        self.prev = ''
+        self.rows = []
+
+    def feed(self, line):
+        if line.startswith('@'):
+            return
+        f = line.strip().split()
+        if len(f) < 6:
+            return
+        flag = int(f[1])
+        cigar = f[5]
+        if (flag & 4) or cigar == '*':
+            return
+        ref = self.acc_index[f[2]]
+        matched = total = num = 0
+        for ch in cigar:
+            if ch.isalpha():
+                if ch == 'M':
+                    matched += num
+                total += num
+                num = 0
+            else:
+                num = num * 10 + int(ch)  # '=' lands here and raises ValueError, as in the reference
+        int(f[11][5:])
+        if total == 0:
+            raise ZeroDivisionError('float division by zero')
+        seqlen = 0 if f[9] == '*' else len(f[9])
+        if seqlen > _hip.MAX_SEQLEN or matched > 0xFFFFFFFF or total > 0xFFFFFFFF:
+            raise OverflowError('alignment longer than the record format allows')
+        new = f[0] != self.prev
+        self.prev = f[0]
+        self.rows.append((ref | (_hip.NEW_BIT if new else 0), matched, total,
+                          (flag & 0xFFF) | (seqlen << _hip.LEN_SHIFT)))
+
+    def records(self):
+        if not self.rows:
+            return np.zeros(0, dtype=_hip.REC_DTYPE)
+        return np.array(self.rows, dtype=_hip.REC_DTYPE)
+
+
+def tokenise_sam(lines, acc_index, decode=False):
+    tk = _Tokeniser(acc_index)
+    for line in lines:
+        if decode:
+            line = line.decode('utf-8')
+            if not line:
+                break
+        tk.feed(line)
+    return tk.records()
+
+
+def dense_tables(acc2info, taxid2info):
+    """Dense ids for the device: accession row -> taxon row."""
+    taxids = list(taxid2info)
+    tax_index = {t: i for i, t in enumerate(taxids)}
+    acc_index = {a: i for i, a in enumerate(acc2info)}
+    ref2tax = np.fromiter((tax_index[v[1]] for v in acc2info.values()), dtype=np.uint32, count=len(acc2info))
+    return acc_index, taxids, ref2tax
+
+
+def _device_assign(recs, ref2tax, ntax, pct_id):
+    return _hip.Hip.get().profile_assign(recs, ref2tax, ntax, pct_id)
+
+
+def assemble_taxids2abs(args, res, taxids, taxid2info):
+    """Kernel outputs -> the (taxids2abs, multimapped, low_mem_mmap) triple of the reference (:193-264)."""
+    taxids2abs = {'Unmapped': [0.0, 0.0] + taxid2info['Unmapped']}
+    tot_rds, n_ambig = int(res['tot_rds']), int(res['n_ambig'])
+    if not args.no_quantify_unmapped:
+        taxids2abs['Unmapped'][0] += float(n_ambig)
+    count, bases, first = res['count'], res['bases'], res['first_seen']
+    hit = np.nonzero(count)[0]
+    for t in hit[np.argsort(first[hit], kind='stable')]:  # dict order = order of first unique hit (:236-240)
+        taxid = taxids[int(t)]
+        nreads, nbases = int(count[t]), int(bases[t])
+        if args.length_normalize:
+            nbases = nbases / taxid2info[taxid][0]  # reference: sum of per-read hitlen/len (:233-234), <=1e-15 rel. apart
+        if taxid in taxids2abs:
+            taxids2abs[taxid][0] += nreads
+            taxids2abs[taxid][1] += nbases
+        else:
+            taxids2abs[taxid] = [nreads, nbases] + taxid2info[taxid]
+    off, mtax, mlen = res['mm_offsets'], res['mm_tax'], res['mm_hitlen']
+    if args.low_mem and len(mlen) > 0:
+        raise TypeError("object of type 'int' has no len()")  # what the reference does at :253,255
+    multimapped = []
+    for i in range(len(mlen)):
+        row = [taxids[int(t)] for t in mtax[int(off[i]):int(off[i + 1])]]
+        row.append(int(mlen[i]))
+        multimapped.append(row)
+    if not args.no_quantify_unmapped:
+        if tot_rds == 0:
+            sys.exit('No reads mapped. Aborting...')
+        taxids2abs['Unmapped'][1] = taxids2abs['Unmapped'][0] / float(tot_rds)
+    return taxids2abs, multimapped, {}
+
+
+def map_and_process(args, instream, acc2info, taxid2info, _assign=None):
+    """Reference signature (:193).  `_assign` is a test seam; product code never passes it."""
+    acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
+    _ = taxid2info['Unmapped']  # KeyError here, as at :197, when db_info lacks the Unmapped row
+    recs = tokenise_sam(instream, acc_index, decode=(args.input_type != 'sam'))
+    res = (_assign or _device_assign)(recs, ref2tax, len(taxids), float(args.pct_id))
+    return assemble_taxids2abs(args, res, taxids, taxid2info)
+
+
+def preprocess_multimapped(args, multimapped, taxids2abs):
+    """Drop hits to taxa without unique reads; drop reads left empty (:180-188)."""
+    out = []
+    for read in multimapped:
+        keep = [t for t in read[:-1] if t in taxids2abs]
+        if keep:
+            keep.append(read[-1])
+            out.append(keep)
+    return out
+
+
+def resolve_multi_prop(args, taxids2abs, multimapped, low_mem_mmap, taxid2info):
+    """Split each multimapped read's bases in proportion to unique bases (:269-312)."""
+    echo('Assigning multimapped reads...', args.verbose)
+    if args.low_mem:
+        total = float(sum(v[1] for v in taxids2abs.values()))
+        for taxid, nhits in low_mem_mmap.items():
+            if taxid not in taxids2abs:
+                continue
+            share = nhits * (taxids2abs[taxid][1] / total)
+            if args.length_normalize:
+                share /= taxid2info[taxid][0]
+            taxids2abs[taxid][1] += share
+        return taxids2abs
+    pending = {}
+    for read in multimapped:
+        taxa = list(dict.fromkeys(t for t in read[:-1] if t in taxids2abs))
+        if not taxa:
+            continue
+        weights = [taxids2abs[t][1] for t in taxa]
+        denom = sum(weights)
+        if denom == 0.0:
+            continue
+        hitlen = read[-1]
+        for t, w in zip(taxa, weights):
+            part = (w / denom) * hitlen
+            if args.length_normalize:
+                part /= taxid2info[t][0]
+            pending[t] = pending[t] + part if t in pending else part
+    for t, extra in pending.items():
+        taxids2abs[t][1] += extra
+    return taxids2abs
+
+
+def rank_renormalize(args, clades2abs, only_strains=False):
+    """Scale abundances so each rank sums to the mapped percentage (:316-339)."""
+    totals = dict.fromkeys(RANKS, 0.0)
+    mapped_pct = 100.0
+    if not args.no_quantify_unmapped and 'Unmapped' in clades2abs:
+        mapped_pct = 100.0 - (100.0 * clades2abs['Unmapped'][-1])
+    members = [k for k, v in clades2abs.items()
+               if k != 'Unmapped' and not (only_strains and v[1] != 'strain')]
+    for k in members:
+        totals[clades2abs[k][1]] += clades2abs[k][-1]
+    for k in members:
+        clades2abs[k][-1] /= (totals[clades2abs[k][1]] / mapped_pct)
+    return clades2abs
+
+
+def gen_lower_taxa(taxids2abs):
+    """Push every non-strain taxon down to a synthetic '<taxid>.0 unknown strain' (:344-364)."""
+    extra = {}
+    for key in taxids2abs:
+        taxid, rank, taxlin, namelin, ab = taxids2abs[key]
+        if rank == 'strain':
+            continue
+        label = namelin.split('|')[_RANK_POS[rank]] + ' unknown strain'
+        child = taxid + '.0'
+        extra[child] = [child, 'strain', taxlin + child, namelin + label, ab]
+    taxids2abs.update(extra)
+    return {k: v for k, v in taxids2abs.items() if v[1] == 'strain'}
+
+
+def tree_results_cami(args, taxids2abs):
+    """Strain-level profile -> all clades, CAMI field order (:368-399)."""
+    for taxid, old in taxids2abs.items():
+        taxids2abs[taxid] = [taxid, old[3], old[5], old[4], old[1]]
+    taxids2abs = gen_lower_taxa(taxids2abs)
+    taxids2abs = rank_renormalize(args, taxids2abs, only_strains=True)
+    clades2abs = dict(taxids2abs)  # shallow on purpose: strain rows are shared, as in the reference
+    for taxid in taxids2abs:
+        tax_path = taxids2abs[taxid][2].split('|')
+        name_path = taxids2abs[taxid][3].split('|')
+        for depth in range(len(tax_path) - 1):
+            clade = tax_path[depth]
+            if clade == '':
+                continue
+            if clade in clades2abs:
+                clades2abs[clade][-1] += taxids2abs[taxid][-1]
+            else:
+                clades2abs[clade] = [clade, RANKS[depth], '|'.join(tax_path[:depth + 1]),
+                                     '|'.join(name_path[:depth + 1]), taxids2abs[taxid][-1]]
+    if args.rank_renormalize:
+        clades2abs = rank_renormalize(args, clades2abs)
+    return clades2abs
+
+
+def compute_abundances(args, infile, acc2info, tax2info):
+    """One input file -> clade abundances (:404-433)."""
+    if args.input_type == 'sam':
+        instream = open(infile, 'r')
+    else:  # stream minimap2's SAM, exactly the reference's invocation (:413-416)
+        mapper = subprocess.Popen(['minimap2', '-ax', 'sr', '-t', str(args.threads), '-2', '-n' '1',
+                                   '--secondary=yes', args.db, infile], stdout=subprocess.PIPE, bufsize=1)
+        instream = iter(mapper.stdout.readline, b'')
+    taxids2abs, multimapped, low_mem_mmap = map_and_process(args, instream, acc2info, tax2info)
+    if args.input_type == 'sam':
+        instream.close()
+    else:
+        mapper.stdout.close()
+        mapper.wait()
+    if len(multimapped) > 0:
+        multimapped = preprocess_multimapped(args, multimapped, taxids2abs)
+    taxids2abs = {k: v for k, v in taxids2abs.items() if v[0] > args.read_cutoff}
+    if len(multimapped) > 0 or len(low_mem_mmap) > 0:
+        taxids2abs = resolve_multi_prop(args, taxids2abs, multimapped, low_mem_mmap, tax2info)
+    return tree_results_cami(args, taxids2abs)
+
+
+def gather_results(args, acc2info, taxid2info):
+    """Average over input files and bucket by rank (:438-463)."""
+    merged = {}
+    for infile in args.infiles:
+        echo('Computing abundances for input file: ' + infile, args.verbose)
+        for clade, row in compute_abundances(args, infile, acc2info, taxid2info).items():
+            if clade in merged:
+                merged[clade][-1] += row[-1]
+            else:
+                merged[clade] = row
+    merged.pop('Unmapped', None)
+    echo('Compiling and writing results...', args.verbose)
+    rank_results = {i: [] for i in range(len(RANKS))}
+    nfiles = len(args.infiles)
+    for row in merged.values():
+        row[4] = row[4] / nfiles
+        depth = _RANK_POS[row[1]]
+        if depth == 7:
+            row.extend([row[0], row[0].split('.')[0]])  # _CAMI_genomeID, _CAMI_OTU
+        rank_results[depth].append(row)
+    return rank_results
+
+
+def write_results(args, rank_results):
+    """CAMI profile (:467-494)."""
+    with open(args.output, 'w') as out:
+        sample = ','.join(args.infiles) if args.sampleID == 'NONE' else args.sampleID
+        out.write('@SampleID:' + sample + '\n')
+        out.write('@Version:Metalign\n')
+        out.write('@Ranks: ' + '|'.join(RANKS) + '\n\n')
+        out.write('\t'.join(['@@TAXID', 'RANK', 'TAXPATH', 'TAXPATHSN', 'PERCENTAGE',
+                             '_CAMI_genomeID', '_CAMI_OTU']) + '\n')
+        for depth in range(len(RANKS)):
+            rows = rank_results[depth]
+            rows.sort(key=lambda r: 100.0 - r[4])
+            for row in rows:
+                if row[4] < args.min_abundance:
+                    continue
+                row[4] = 0.00001 if row[4] < 0.00001 else float('%.5f' % row[4])
+                out.write('\t'.join(str(x) for x in row) + '\n')
+
+
+def map_main(args=None):
+    if args is None:
+        args = profile_parseargs()
+    if args.pct_id > 1.0 or args.pct_id < 0.0:
+        sys.exit('Error: --pct_id must be between 0.0 and 1.0, inclusive.')
+    if args.db == 'NONE' and not args.infiles[0].endswith('sam'):
+        sys.exit('Error: --db must be specified unless sam files are provided.')
+    if not args.data.endswith('/'):
+        args.data += '/'
+    if args.dbinfo == 'AUTO':
+        args.dbinfo = args.data + 'db_info.txt'
+    if args.input_type == 'AUTO':
+        parts = args.infiles[0].split('.')
+        if parts[-1] == 'gz':
+            parts = parts[:-1]
+        kind = {'fq': 'fastq', 'fastq': 'fastq', 'fa': 'fasta', 'fna': 'fasta', 'fasta': 'fasta',
+                'sam': 'sam'}.get(parts[-1])
+        if kind is None:
+            sys.exit('Could not auto-determine file type. Use --input_type.')
+        args.input_type = kind
+    open(args.output, 'w').close()
+    acc2info, taxid2info = get_acc2info(args)
+    rank_results = gather_results(args, acc2info, taxid2info)
+    write_results(args, rank_results)
+
+
+if __name__ == '__main__':
+    map_main(profile_parseargs())

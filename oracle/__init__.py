@@ -1,0 +1,191 @@
+"""CPU ORACLE — test infrastructure, not product code.
+
+ctypes front end of oracle/libmg_oracle.so (built by oracle/Makefile) plus a
+pure-Python restatement of the SAM line filter used at ingest.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; metalign_amd/ never does.
+
+Pinning: see the header of oracle/mg_oracle.c and DESIGN.md.  Stage C and
+MurmurHash3 are pinned by golden vectors; the sketch / containment arithmetic
+is "parity unpinned" (KMC 3 and CMash are absent from the reference tree).
+
+Reference paths below are relative to /root/reference.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+REC_DTYPE = np.dtype([("ref_new", "<u4"), ("matched", "<u4"), ("total", "<u4"), ("flag_len", "<u4")])
+NEW_BIT = 0x80000000
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+def build():
+    """Compile the C restatement (gcc); idempotent."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libmg_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmg_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def murmur3_x64_128(data: bytes, seed: int = 0):
+    out = (ctypes.c_uint64 * 2)()
+    lib().mgo_murmur3_x64_128(ctypes.c_char_p(data), ctypes.c_int(len(data)), ctypes.c_uint32(seed), out)
+    return int(out[0]), int(out[1])
+
+
+def kmer_hashes(seq: bytes, k: int):
+    """(hashes, valid) per window start of one sequence."""
+    n = max(len(seq) - k + 1, 0)
+    out = np.zeros(n, dtype=np.uint64)
+    valid = np.zeros(n, dtype=np.uint8)
+    buf = np.frombuffer(seq, dtype=np.uint8)
+    if n:
+        lib().mgo_kmer_hashes.restype = ctypes.c_uint64
+        lib().mgo_kmer_hashes(_p(buf, ctypes.c_uint8), ctypes.c_uint64(len(seq)), ctypes.c_int(k),
+                              _p(out, ctypes.c_uint64), _p(valid, ctypes.c_uint8))
+    return out, valid.astype(bool)
+
+
+def sketch_reads(bases, offsets, k, hmax=U64_MAX, s=0, cap=None):
+    """-> (hashes u64[n], counts u32[n], truncated, kmers_seen)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nreads = len(offsets) - 1
+    if cap is None:
+        cap = int(s) if s else max(int(bases.size), 1)
+    h = np.zeros(cap, dtype=np.uint64)
+    c = np.zeros(cap, dtype=np.uint32)
+    n = ctypes.c_uint64(0)
+    trunc = ctypes.c_int(0)
+    seen = ctypes.c_uint64(0)
+    bptr = _p(bases, ctypes.c_uint8) if bases.size else ctypes.POINTER(ctypes.c_uint8)()
+    rc = lib().mgo_sketch_reads(bptr, _p(offsets, ctypes.c_uint64), ctypes.c_uint64(nreads), ctypes.c_int(k),
+                                ctypes.c_uint64(hmax), ctypes.c_uint64(s), _p(h, ctypes.c_uint64),
+                                _p(c, ctypes.c_uint32), ctypes.c_uint64(cap), ctypes.byref(n),
+                                ctypes.byref(trunc), ctypes.byref(seen))
+    if rc != 0:
+        raise RuntimeError("mgo_sketch_reads rc=%d" % rc)
+    return h[: n.value].copy(), c[: n.value].copy(), bool(trunc.value), int(seen.value)
+
+
+def sketch_genomes(bases, offsets, k, n):
+    """-> (hashes u64[*], offsets u64[G+1])."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    g = len(offsets) - 1
+    h = np.zeros(max(g * n, 1), dtype=np.uint64)
+    o = np.zeros(g + 1, dtype=np.uint64)
+    rc = lib().mgo_sketch_genomes(_p(bases, ctypes.c_uint8), _p(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                                  ctypes.c_int(k), ctypes.c_uint64(n), _p(h, ctypes.c_uint64),
+                                  _p(o, ctypes.c_uint64))
+    if rc != 0:
+        raise RuntimeError("mgo_sketch_genomes rc=%d" % rc)
+    return h[: int(o[-1])].copy(), o
+
+
+def containment(q_hashes, q_counts, q_truncated, ci, db_hashes, db_offsets):
+    """-> (hits u32[G], sizes u32[G])."""
+    q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)
+    q_counts = np.ascontiguousarray(q_counts, dtype=np.uint32)
+    db_hashes = np.ascontiguousarray(db_hashes, dtype=np.uint64)
+    db_offsets = np.ascontiguousarray(db_offsets, dtype=np.uint64)
+    g = len(db_offsets) - 1
+    hits = np.zeros(g, dtype=np.uint32)
+    sizes = np.zeros(g, dtype=np.uint32)
+    lib().mgo_containment(_p(q_hashes, ctypes.c_uint64), _p(q_counts, ctypes.c_uint32),
+                          ctypes.c_uint64(len(q_hashes)), ctypes.c_int(int(q_truncated)), ctypes.c_uint32(ci),
+                          _p(db_hashes, ctypes.c_uint64), _p(db_offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                          _p(hits, ctypes.c_uint32), _p(sizes, ctypes.c_uint32))
+    return hits, sizes
+
+
+def profile_assign(recs, ref2tax, ntax, pct_id):
+    """Sequential restatement of map_and_process over records.
+
+    -> dict(count, bases, first_seen, tot_rds, n_ambig, mm_offsets, mm_tax, mm_hitlen, mm_read)
+    """
+    recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+    ref2tax = np.ascontiguousarray(ref2tax, dtype=np.uint32)
+    n = len(recs)
+    count = np.zeros(ntax, dtype=np.uint64)
+    bases = np.zeros(ntax, dtype=np.uint64)
+    first = np.zeros(ntax, dtype=np.uint64)
+    mm_off = np.zeros(n + 2, dtype=np.uint64)
+    mm_tax = np.zeros(n + 1, dtype=np.uint32)
+    mm_len = np.zeros(n + 1, dtype=np.uint64)
+    mm_read = np.zeros(n + 1, dtype=np.uint64)
+    tot = ctypes.c_uint64(0)
+    amb = ctypes.c_uint64(0)
+    nmm = ctypes.c_uint64(0)
+    nent = ctypes.c_uint64(0)
+    rc = lib().mgo_profile_assign(
+        recs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n), _p(ref2tax, ctypes.c_uint32),
+        ctypes.c_uint32(len(ref2tax)), ctypes.c_uint32(ntax), ctypes.c_double(pct_id),
+        _p(count, ctypes.c_uint64), _p(bases, ctypes.c_uint64), _p(first, ctypes.c_uint64),
+        ctypes.byref(tot), ctypes.byref(amb), _p(mm_off, ctypes.c_uint64), _p(mm_tax, ctypes.c_uint32),
+        _p(mm_len, ctypes.c_uint64), _p(mm_read, ctypes.c_uint64), ctypes.c_uint64(n + 1),
+        ctypes.c_uint64(n + 1), ctypes.byref(nmm), ctypes.byref(nent))
+    if rc != 0:
+        raise RuntimeError("mgo_profile_assign rc=%d" % rc)
+    m, e = nmm.value, nent.value
+    return dict(count=count, bases=bases, first_seen=first, tot_rds=tot.value, n_ambig=amb.value,
+                mm_offsets=mm_off[: m + 1].copy(), mm_tax=mm_tax[:e].copy(), mm_hitlen=mm_len[:m].copy(),
+                mm_read=mm_read[:m].copy())
+
+
+# --------------------------------------------------------------------------
+# SAM text -> records, the plain way (line filter of
+# scripts/map_and_profile.py:201-217 and the CIGAR walk of :86-100).
+# --------------------------------------------------------------------------
+def sam_to_records(lines, acc_index):
+    """lines: iterable of str; acc_index: {accession: row}. -> REC_DTYPE array.
+
+    Raises what the reference raises on the same input: KeyError for an unknown
+    RNAME (:217), IndexError for a retained line with < 12 fields (:97),
+    ValueError for a CIGAR with '=' (:90-93).
+    """
+    out = []
+    prev = ""
+    for line in lines:
+        if line.startswith("@"):
+            continue
+        f = line.strip().split()
+        if len(f) < 6:
+            continue
+        flag = int(f[1])
+        if (flag & 4) or f[5] == "*":
+            continue
+        ref = acc_index[f[2]]
+        matched = total = cur = 0
+        for ch in f[5]:
+            if not ch.isalpha():
+                cur = cur * 10 + int(ch)
+            else:
+                if ch == "M" or ch == "=":
+                    matched += cur
+                total += cur
+                cur = 0
+        int(f[11][5:])  # parsed and unused by the reference; still raises on short / malformed lines
+        float(matched) / float(total)  # ZeroDivisionError parity for op-less CIGARs
+        seqlen = 0 if f[9] == "*" else len(f[9])
+        new = f[0] != prev
+        prev = f[0]
+        out.append((ref | (NEW_BIT if new else 0), matched, total, (flag & 0xFFF) | (seqlen << 12)))
+    return np.array(out, dtype=REC_DTYPE) if out else np.zeros(0, dtype=REC_DTYPE)

@@ -1,0 +1,407 @@
+/*
+ * mg_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain, sequential C restatement of the algorithms on Metalign's hot path,
+ * used only as the checker in tests/, by __graft_entry__.smoke() and by the
+ * cpu_baseline leg of bench.py.  The product path (metalign_amd/) never loads
+ * this file; it fails loudly when libmetalign_hip.so is missing.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   Stage C  (mgo_profile_assign)    PINNED — follows scripts/map_and_profile.py
+ *            line by line and is checked against golden vectors produced by
+ *            importing that file in the build container
+ *            (tests/golden/make_golden.py).
+ *   MurmurHash3_x64_128              PINNED — public known-answer vectors
+ *            (tests/golden/murmur3_kat.json).
+ *   Stage A/B (sketch / containment) PARITY UNPINNED — the arithmetic lives in
+ *            KMC 3 and CMash (scripts/select_db.py:50-59,73-76), neither
+ *            vendored nor version-pinned by the reference and absent from this
+ *            image.  This file is the normative statement of what the build
+ *            computes for those stages; the GPU must match it bit for bit.
+ *
+ * All paths below are relative to /root/reference.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/metalign_hip.h"
+
+/* ---------------------------------------------------------------------- *
+ * MurmurHash3_x64_128 (Austin Appleby, public domain algorithm), restated.
+ * CMash hashes k-mers with the first 64 bits of this function, seed 0
+ * [UPSTREAM-RECOLLECTION, SURVEY.md §8c].
+ * ---------------------------------------------------------------------- */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+static inline uint64_t fmix64(uint64_t v) {
+  v ^= v >> 33;
+  v *= 0xff51afd7ed558ccdULL;
+  v ^= v >> 33;
+  v *= 0xc4ceb9fe1a85ec53ULL;
+  v ^= v >> 33;
+  return v;
+}
+
+static inline uint64_t load_le64(const uint8_t* p, int nbytes) {
+  uint64_t v = 0;
+  for (int i = 0; i < nbytes; ++i) v |= (uint64_t)p[i] << (8 * i);
+  return v;
+}
+
+void mgo_murmur3_x64_128(const void* key, int len, uint32_t seed, uint64_t out[2]) {
+  const uint64_t C1 = 0x87c37b91114253d5ULL, C2 = 0x4cf5ad432745937fULL;
+  const uint8_t* p = (const uint8_t*)key;
+  uint64_t h1 = seed, h2 = seed;
+  int done = 0;
+  while (len - done >= 16) {
+    uint64_t k1 = load_le64(p + done, 8), k2 = load_le64(p + done + 8, 8);
+    k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+    k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    done += 16;
+  }
+  int rem = len - done;
+  if (rem > 8) {
+    uint64_t k2 = load_le64(p + done + 8, rem - 8);
+    k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+  }
+  if (rem > 0) {
+    uint64_t k1 = load_le64(p + done, rem > 8 ? 8 : rem);
+    k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+  }
+  h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2; h2 += h1;
+  out[0] = h1; out[1] = h2;
+}
+
+/* ---------------------------------------------------------------------- *
+ * k-mer enumeration.  KMC counts CANONICAL k-mers (lexicographic min of the
+ * k-mer and its reverse complement; scripts/select_db.py:50-52 runs it with
+ * default canonical mode) over windows free of non-ACGT symbols.
+ * ---------------------------------------------------------------------- */
+static inline int base_code(uint8_t b) { /* A,C,G,T (either case) -> 0..3, else -1 */
+  switch (b) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+
+static const char kUpper[4] = {'A', 'C', 'G', 'T'};
+
+/* Hash of the canonical form of the k-mer seq[0..k) (all symbols valid). */
+static uint64_t canonical_hash(const uint8_t* seq, int k) {
+  char fwd[MG_MAX_K], rc[MG_MAX_K];
+  for (int i = 0; i < k; ++i) {
+    int c = base_code(seq[i]);
+    fwd[i] = kUpper[c];
+    rc[k - 1 - i] = kUpper[3 - c];
+  }
+  const char* pick = memcmp(fwd, rc, (size_t)k) <= 0 ? fwd : rc;
+  uint64_t out[2];
+  mgo_murmur3_x64_128(pick, k, 0, out);
+  return out[0];
+}
+
+/* Per-position canonical hash of one sequence: out[i] for window starting at i,
+ * UINT64_MAX-with-flag semantics avoided: valid[i] says whether the window is a
+ * k-mer.  Returns number of valid windows.  (Helper for tests.) */
+uint64_t mgo_kmer_hashes(const uint8_t* seq, uint64_t len, int k, uint64_t* out,
+                         uint8_t* valid) {
+  uint64_t nvalid = 0;
+  if (len < (uint64_t)k) return 0;
+  uint64_t run = 0; /* consecutive valid symbols ending at position j */
+  for (uint64_t j = 0; j < len; ++j) {
+    run = base_code(seq[j]) >= 0 ? run + 1 : 0;
+    if (j + 1 >= (uint64_t)k) {
+      uint64_t i = j + 1 - (uint64_t)k;
+      if (run >= (uint64_t)k) {
+        out[i] = canonical_hash(seq + i, k);
+        valid[i] = 1;
+        ++nvalid;
+      } else {
+        out[i] = 0;
+        valid[i] = 0;
+      }
+    }
+  }
+  return nvalid;
+}
+
+static int cmp_u64(const void* a, const void* b) {
+  uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+typedef struct { uint64_t* v; uint64_t n, cap; } u64vec;
+
+static int vec_push(u64vec* a, uint64_t x) {
+  if (a->n == a->cap) {
+    uint64_t nc = a->cap ? a->cap * 2 : 1024;
+    uint64_t* nv = (uint64_t*)realloc(a->v, nc * sizeof(uint64_t));
+    if (!nv) return -1;
+    a->v = nv; a->cap = nc;
+  }
+  a->v[a->n++] = x;
+  return 0;
+}
+
+static int collect_hashes(const uint8_t* seq, uint64_t len, int k, uint64_t hmax,
+                          u64vec* acc, uint64_t* kmers_seen) {
+  if (len < (uint64_t)k) return 0;
+  uint64_t run = 0;
+  for (uint64_t j = 0; j < len; ++j) {
+    run = base_code(seq[j]) >= 0 ? run + 1 : 0;
+    if (run >= (uint64_t)k) {
+      uint64_t h = canonical_hash(seq + (j + 1 - (uint64_t)k), k);
+      ++*kmers_seen;
+      if (h <= hmax && vec_push(acc, h)) return -1;
+    }
+  }
+  return 0;
+}
+
+/* Stage A.  See include/metalign_hip.h (mg_sketch_reads) for the definition. */
+int mgo_sketch_reads(const uint8_t* bases, const uint64_t* offsets, uint64_t nreads,
+                     int k, uint64_t hmax, uint64_t s, uint64_t* out_hashes,
+                     uint32_t* out_counts, uint64_t out_cap, uint64_t* out_n,
+                     int* out_truncated, uint64_t* out_kmers_seen) {
+  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
+  u64vec acc = {0, 0, 0};
+  uint64_t seen = 0;
+  for (uint64_t r = 0; r < nreads; ++r)
+    if (collect_hashes(bases + offsets[r], offsets[r + 1] - offsets[r], k, hmax, &acc, &seen)) {
+      free(acc.v);
+      return MG_ERR_NOMEM;
+    }
+  qsort(acc.v, acc.n, sizeof(uint64_t), cmp_u64);
+  uint64_t n = 0;
+  int truncated = 0, rc = MG_OK;
+  for (uint64_t i = 0; i < acc.n;) {
+    uint64_t j = i;
+    while (j < acc.n && acc.v[j] == acc.v[i]) ++j;
+    if (s > 0 && n == s) { truncated = 1; break; }
+    if (n == out_cap) { rc = MG_ERR_CAPACITY; break; }
+    uint64_t c = j - i;
+    out_hashes[n] = acc.v[i];
+    out_counts[n] = c > 0xffffffffULL ? 0xffffffffu : (uint32_t)c;
+    ++n;
+    i = j;
+  }
+  free(acc.v);
+  *out_n = n;
+  if (out_truncated) *out_truncated = truncated;
+  if (out_kmers_seen) *out_kmers_seen = seen;
+  return rc;
+}
+
+/* Stage A'.  Per-genome bottom-n distinct hashes, ascending. */
+int mgo_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes,
+                       int k, uint64_t n, uint64_t* out_hashes, uint64_t* out_offsets) {
+  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
+  uint64_t w = 0;
+  out_offsets[0] = 0;
+  for (uint64_t g = 0; g < ngenomes; ++g) {
+    u64vec acc = {0, 0, 0};
+    uint64_t seen = 0;
+    if (collect_hashes(bases + offsets[g], offsets[g + 1] - offsets[g], k, UINT64_MAX, &acc, &seen)) {
+      free(acc.v);
+      return MG_ERR_NOMEM;
+    }
+    qsort(acc.v, acc.n, sizeof(uint64_t), cmp_u64);
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < acc.n && kept < n; ++i)
+      if (i == 0 || acc.v[i] != acc.v[i - 1]) { out_hashes[w++] = acc.v[i]; ++kept; }
+    free(acc.v);
+    out_offsets[g + 1] = w;
+  }
+  return MG_OK;
+}
+
+/* Stage B.  See include/metalign_hip.h (mg_containment). */
+int mgo_containment(const uint64_t* q_hashes, const uint32_t* q_counts, uint64_t qn,
+                    int q_truncated, uint32_t ci, const uint64_t* db_hashes,
+                    const uint64_t* db_offsets, uint64_t ngenomes, uint32_t* out_hits,
+                    uint32_t* out_sizes) {
+  uint64_t bound = (q_truncated && qn > 0) ? q_hashes[qn - 1] : UINT64_MAX;
+  for (uint64_t g = 0; g < ngenomes; ++g) {
+    uint32_t hits = 0, size = 0;
+    for (uint64_t i = db_offsets[g]; i < db_offsets[g + 1]; ++i) {
+      uint64_t h = db_hashes[i];
+      if (h > bound) continue;
+      ++size;
+      uint64_t lo = 0, hi = qn; /* lower_bound */
+      while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (q_hashes[mid] < h) lo = mid + 1; else hi = mid;
+      }
+      if (lo < qn && q_hashes[lo] == h && q_counts[lo] >= ci) ++hits;
+    }
+    out_hits[g] = hits;
+    out_sizes[g] = size;
+  }
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------- *
+ * Stage C.  Sequential restatement of map_and_process
+ * (scripts/map_and_profile.py:193-264) over pre-tokenised records.
+ * The variable names mirror the reference so the two can be read side by side.
+ * ---------------------------------------------------------------------- */
+typedef struct { int pair1, pair2, chimeric; } flagbits;
+
+static inline flagbits parse_flag(uint32_t flag) { /* :104-111 (is_bad handled at ingest) */
+  flagbits f;
+  f.pair1 = (flag & 1u) && (flag & 64u);
+  f.pair2 = (flag & 1u) && (flag & 128u);
+  f.chimeric = (flag & 2048u) != 0;
+  return f;
+}
+
+static inline int filter_line(const mg_aln_rec* r, double pct_id) { /* :86-100 */
+  return (double)r->matched / (double)r->total < pct_id;
+}
+
+typedef struct {
+  int kind;          /* 0 = Ambiguous, 1 = unique, 2 = multimapped */
+  uint32_t taxid;    /* unique: dense taxon id */
+  uint64_t hitlen;
+} read_verdict;
+
+/* process_read (:152-176) on lines hits[0..nh) (indices into recs); when the
+ * verdict is multimapped the taxon list is appended to mm_tax. */
+static read_verdict process_read(const mg_aln_rec* recs, const uint64_t* hits, uint64_t nh,
+                                 int pair1, int pair2, long pair1maps, long pair2maps,
+                                 const uint32_t* ref2tax, double pct_id, uint64_t* kept,
+                                 uint32_t* mm_tax, uint64_t* mm_n, uint64_t mm_cap, int* overflow) {
+  read_verdict v = {0, 0, 0};
+  /* clean_read_hits (:130-147) */
+  uint64_t nk = 0, hitlen = 0;
+  for (uint64_t i = 0; i < nh; ++i) {
+    const mg_aln_rec* r = &recs[hits[i]];
+    flagbits f = parse_flag(r->flag_len & MG_REC_FLAG_MASK);
+    if (filter_line(r, pct_id) || f.chimeric) {
+      if (f.pair1) pair1maps -= 1;
+      else if (f.pair2) pair2maps -= 1;
+    } else {
+      kept[nk++] = hits[i];
+    }
+    hitlen += r->flag_len >> MG_REC_LEN_SHIFT; /* len(SEQ), 0 when SEQ == '*' (:142-144) */
+  }
+  v.hitlen = hitlen;
+  if (nk == 0) return v; /* :155-156 */
+#define TAX(i) (ref2tax[recs[kept[(i)]].ref_new & MG_REC_REF_MASK])
+  if (pair1 || pair2) { /* :157 */
+    if (pair1maps + pair2maps == 1) { v.kind = 1; v.taxid = TAX(0); return v; } /* :158-160 */
+    /* intersect_read_hits (:115-125) */
+    if (pair1maps == 0 || pair2maps == 0) return v; /* -> len(intersect)==0 -> Ambiguous */
+    uint64_t split = (uint64_t)(pair1maps < 0 ? 0 : pair1maps);
+    if (split > nk) split = nk;
+    /* distinct taxa of the first `split` hits that also occur among the rest */
+    uint64_t ndistinct = 0;
+    for (uint64_t i = 0; i < split; ++i) {
+      uint32_t t = TAX(i);
+      int in2 = 0, dup = 0;
+      for (uint64_t j = split; j < nk && !in2; ++j) in2 = TAX(j) == t;
+      if (!in2) continue;
+      for (uint64_t j = 0; j < i && !dup; ++j) dup = TAX(j) == t;
+      if (!dup) ++ndistinct;
+    }
+    if (ndistinct == 0) return v;                                   /* :164-165 */
+    if (ndistinct == 1) { v.kind = 1; v.taxid = TAX(0); return v; } /* :166-167 */
+    v.kind = 2;                                                     /* :168-169 */
+    for (uint64_t h = 0; h < nk; ++h) {
+      uint32_t t = TAX(h);
+      int in1 = 0, in2 = 0;
+      for (uint64_t j = 0; j < split && !in1; ++j) in1 = TAX(j) == t;
+      for (uint64_t j = split; j < nk && !in2; ++j) in2 = TAX(j) == t;
+      if (in1 && in2) {
+        if (*mm_n < mm_cap) mm_tax[(*mm_n)++] = t; else *overflow = 1;
+      }
+    }
+    return v;
+  }
+  if (pair1maps > 1) { /* single end, multimapped (:172-173) */
+    v.kind = 2;
+    for (uint64_t h = 0; h < nk; ++h) {
+      if (*mm_n < mm_cap) mm_tax[(*mm_n)++] = TAX(h); else *overflow = 1;
+    }
+    return v;
+  }
+  v.kind = 1; v.taxid = TAX(0); /* :174-176 */
+  return v;
+#undef TAX
+}
+
+int mgo_profile_assign(const mg_aln_rec* recs, uint64_t nrecs, const uint32_t* ref2tax,
+                       uint32_t nref, uint32_t ntax, double pct_id, uint64_t* out_count,
+                       uint64_t* out_bases, uint64_t* out_first_seen, uint64_t* out_tot_rds,
+                       uint64_t* out_n_ambig, uint64_t* mm_offsets, uint32_t* mm_tax,
+                       uint64_t* mm_hitlen, uint64_t* mm_read, uint64_t mm_cap_reads,
+                       uint64_t mm_cap_entries, uint64_t* mm_nreads, uint64_t* mm_nentries) {
+  (void)nref;
+  for (uint32_t t = 0; t < ntax; ++t) { out_count[t] = 0; out_bases[t] = 0; out_first_seen[t] = UINT64_MAX; }
+  uint64_t cap = 16, nh = 0;
+  uint64_t* read_hits = (uint64_t*)malloc(cap * sizeof(uint64_t));
+  uint64_t* kept = (uint64_t*)malloc(cap * sizeof(uint64_t));
+  if (!read_hits || !kept) { free(read_hits); free(kept); return MG_ERR_NOMEM; }
+  long pair1maps = 0, pair2maps = 0;
+  uint64_t tot_rds = 0, n_ambig = 0, n_mm = 0, n_ent = 0;
+  int overflow = 0;
+  if (mm_cap_reads > 0 || mm_offsets) mm_offsets[0] = 0;
+  for (uint64_t i = 0; i < nrecs; ++i) {
+    const mg_aln_rec* r = &recs[i];
+    flagbits f = parse_flag(r->flag_len & MG_REC_FLAG_MASK);
+    if (r->ref_new & MG_REC_NEW_BIT) { /* read != prev_read (:220) */
+      tot_rds += 1;
+      uint64_t ent_before = n_ent;
+      read_verdict v = process_read(recs, read_hits, nh, f.pair1, f.pair2, pair1maps, pair2maps,
+                                    ref2tax, pct_id, kept, mm_tax, &n_ent, mm_cap_entries, &overflow);
+      nh = 0; pair1maps = 0; pair2maps = 0; /* :227 */
+      if (v.kind == 0) { /* Ambiguous: count and DROP this line (:229-232) */
+        n_ambig += 1;
+        continue;
+      }
+      uint64_t read_index = tot_rds - 2; /* index of the read just decided (0-based) */
+      if (v.kind == 1) { /* :235-240 */
+        out_count[v.taxid] += 1;
+        out_bases[v.taxid] += v.hitlen;
+        if (out_first_seen[v.taxid] == UINT64_MAX) out_first_seen[v.taxid] = read_index;
+      } else { /* :245-248 */
+        if (n_mm < mm_cap_reads) {
+          mm_hitlen[n_mm] = v.hitlen;
+          mm_read[n_mm] = read_index;
+          mm_offsets[n_mm + 1] = n_ent;
+          ++n_mm;
+        } else {
+          overflow = 1;
+          n_ent = ent_before;
+        }
+      }
+    }
+    pair1maps += (f.pair1 || !(f.pair1 || f.pair2)) ? 1 : 0; /* :257 */
+    pair2maps += f.pair2 ? 1 : 0;                            /* :258 */
+    if (nh == cap) {
+      cap *= 2;
+      uint64_t* a = (uint64_t*)realloc(read_hits, cap * sizeof(uint64_t));
+      if (!a) { free(read_hits); free(kept); return MG_ERR_NOMEM; }
+      read_hits = a;
+      uint64_t* b = (uint64_t*)realloc(kept, cap * sizeof(uint64_t));
+      if (!b) { free(read_hits); free(kept); return MG_ERR_NOMEM; }
+      kept = b;
+    }
+    read_hits[nh++] = i; /* :259 */
+  }
+  free(read_hits); free(kept);
+  *out_tot_rds = tot_rds;
+  *out_n_ambig = n_ambig;
+  *mm_nreads = n_mm;
+  *mm_nentries = n_ent;
+  return overflow ? MG_ERR_CAPACITY : MG_OK;
+}

@@ -1,0 +1,168 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import stage_c_checks as sc
+import util
+
+pytestmark = pytest.mark.gpu
+
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.parametrize("k", [1, 4, 11, 16, 21, 31, 32, 33, 48, 51, 60, 64])
+def test_sketch_reads_every_kmer(hip, oracle_lib, k):
+    """hmax = max: the sketch is the full distinct k-mer hash set with counts; bit-exact."""
+    rng = np.random.default_rng(100 + k)
+    gb, go = util.random_genomes(rng, 3, 4000, with_n=True)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 700, 150, err=0.02, ragged=(k % 2 == 0), lower=True)
+    h, c, trunc, seen = hip.sketch_reads(bases, offsets, k)
+    oh, oc, otrunc, oseen = oracle_lib.sketch_reads(bases, offsets, k)
+    assert seen == oseen
+    assert trunc == otrunc is False
+    assert np.array_equal(h, oh) and np.array_equal(c, oc)
+    assert np.all(h[1:] > h[:-1])
+
+
+@pytest.mark.parametrize("k,frac,s", [(21, 0.02, 0), (21, 0.3, 500), (31, 0.05, 0), (51, 0.1, 64), (60, 1.0, 1000)])
+def test_sketch_reads_threshold_and_truncation(hip, oracle_lib, k, frac, s):
+    rng = np.random.default_rng(7 * k)
+    gb, go = util.random_genomes(rng, 5, 6000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 3000, 150, err=0.01)
+    hmax = U64_MAX if frac >= 1.0 else int(frac * 2**64)
+    h, c, trunc, seen = hip.sketch_reads(bases, offsets, k, hmax=hmax, s=s)
+    oh, oc, otrunc, oseen = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax, s=s)
+    assert (trunc, seen) == (otrunc, oseen)
+    assert np.array_equal(h, oh) and np.array_equal(c, oc)
+    assert c.max() >= 2  # coverage is high enough that the count>=2 path is exercised
+
+
+def test_sketch_reads_edge_inputs(hip, oracle_lib):
+    k = 21
+    # empty read set
+    h, c, trunc, seen = hip.sketch_reads(np.zeros(0, np.uint8), np.zeros(1, np.uint64), k)
+    assert h.size == 0 and seen == 0
+    # reads shorter than k, empty reads, a read of exactly k, all-N read
+    seqs = [b"", b"ACGT", b"ACGTACGTACGTACGTACGTA", b"N" * 40, b"ACGTACGTACGTACGTACGTAN" + b"ACGTTGCATGCATGCATGCATGCAA", b""]
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+    h, c, trunc, seen = hip.sketch_reads(bases, offsets, k)
+    oh, oc, _, oseen = oracle_lib.sketch_reads(bases, offsets, k)
+    assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+    # long reads (tile larger than the LDS stage -> direct path) mixed with short ones
+    rng = np.random.default_rng(5)
+    gb, go = util.random_genomes(rng, 2, 30000)
+    b1, o1, _ = util.sample_reads(rng, gb, go, 70, 3000, err=0.0)
+    h, c, _, seen = hip.sketch_reads(b1, o1, 31, hmax=int(0.2 * 2**64))
+    oh, oc, _, oseen = oracle_lib.sketch_reads(b1, o1, 31, hmax=int(0.2 * 2**64))
+    assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+
+
+def test_sketch_reverse_complement_invariance(hip):
+    """Size-independent property: a read set and its reverse complement have the same sketch."""
+    rng = np.random.default_rng(11)
+    gb, go = util.random_genomes(rng, 4, 20000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 20000, 150, err=0.0)
+    rc = bases.copy()
+    for i in range(len(offsets) - 1):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        rc[a:b] = util._COMP[bases[a:b][::-1]]
+    for k in (21, 51):
+        h1, c1, _, s1 = hip.sketch_reads(bases, offsets, k, hmax=2**60)
+        h2, c2, _, s2 = hip.sketch_reads(rc, offsets, k, hmax=2**60)
+        assert s1 == s2 and np.array_equal(h1, h2) and np.array_equal(c1, c2)
+
+
+@pytest.mark.parametrize("k,n", [(21, 1000), (31, 200), (51, 1000), (60, 50), (5, 1000)])
+def test_sketch_genomes_matches_oracle(hip, oracle_lib, k, n):
+    rng = np.random.default_rng(k + n)
+    lens = [12000, 0, 37, 5000, k - 1 if k > 1 else 0, 9000]
+    bases = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), p=[.2495, .2495, .2495, .2495, .002], size=sum(lens)).astype(np.uint8)
+    offsets = np.cumsum([0] + lens).astype(np.uint64)
+    h, o = hip.sketch_genomes(bases, offsets, k, n)
+    oh, oo = oracle_lib.sketch_genomes(bases, offsets, k, n)
+    assert np.array_equal(o, oo) and np.array_equal(h, oh)
+
+
+@pytest.mark.parametrize("k,s,ci", [(21, 0, 2), (21, 3000, 1), (31, 0, 2), (51, 800, 3)])
+def test_containment_matches_oracle(hip, oracle_lib, k, s, ci):
+    rng = np.random.default_rng(31 + k)
+    gb, go = util.random_genomes(rng, 40, 8000)
+    dbh, dbo = oracle_lib.sketch_genomes(gb, go, k, 300)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 6000, 150, err=0.01, present=[1, 5, 9, 33])
+    hmax = int(dbh.max())
+    table = hip.upload_table(dbh, dbo)
+    assert table.max_hash == hmax
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, s)
+    hits, sizes = hip.containment(sk, table, ci)
+    qh, qc = sk.download()
+    oh, oc, otrunc, _ = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax, s=s)
+    assert np.array_equal(qh, oh) and np.array_equal(qc, oc) and sk.truncated == otrunc
+    ohits, osizes = oracle_lib.containment(oh, oc, otrunc, ci, dbh, dbo)
+    assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes)
+    if s == 0:
+        ci_vals = hits / np.maximum(sizes, 1)
+        assert ci_vals[[1, 5, 9, 33]].min() > 0.5 and np.delete(ci_vals, [1, 5, 9, 33]).max() < 0.1
+
+
+def test_sketch_merge_equals_single_pass(hip, oracle_lib):
+    """Two read shards sketched separately and merged == one pass over all reads (the multi-GPU merge)."""
+    rng = np.random.default_rng(77)
+    gb, go = util.random_genomes(rng, 6, 9000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 4000, 150, err=0.01)
+    k, hmax = 21, int(0.25 * 2**64)
+    for s in (0, 700):
+        half = 2000
+        cut = int(offsets[half])
+        parts = [(bases[:cut], offsets[: half + 1]), (bases[cut:], offsets[half:] - offsets[half])]
+        hs, cs, truncs = [], [], []
+        for b, o in parts:
+            h, c, t, _ = hip.sketch_reads(b, o, k, hmax=hmax, s=s)
+            hs.append(h); cs.append(c); truncs.append(t)
+        allh, allc = np.concatenate(hs), np.concatenate(cs)
+        bound = min([h[-1] for h, t in zip(hs, truncs) if t] or [U64_MAX])
+        d_h, d_c = hip.array(allh), hip.array(allc)
+        merged = hip.sketch_from_pairs_dev(d_h.ptr, d_c.ptr, allh.size, k, s=s, any_truncated=any(truncs), bound=int(bound))
+        mh, mc = merged.download()
+        oh, oc, otrunc, _ = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax, s=s)
+        assert np.array_equal(mh, oh) and np.array_equal(mc, oc)
+        assert merged.truncated == otrunc
+
+
+@pytest.mark.parametrize("name,idx,run", sc.hand_cases(), ids=lambda v: str(v) if not isinstance(v, dict) else "")
+def test_stage_c_hand_cases_hip(hip, name, idx, run, monkeypatch, tmp_path):
+    sc.check_hand_case(name, run, None, monkeypatch, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["single_3k", "paired_2k", "single_100k", "paired_40k"])
+def test_stage_c_bulk_hip(hip, name, monkeypatch, tmp_path):
+    spec = sc.load_bulk()[name]
+    sam, dbp = sc.materialise_bulk(name, spec, tmp_path)
+    for run in spec["runs"]:
+        sc.check_run(sam, dbp, run, None, monkeypatch, tmp_path, mm_digest_only=True)
+
+
+def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib):
+    """Random record streams straight into the C ABI: >2048 taxa forces the global-atomic histogram path."""
+    rng = np.random.default_rng(9)
+    for ntax, nref in ((37, 90), (5000, 9000)):
+        n = 300000
+        ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
+        recs = np.zeros(n, dtype=oracle_lib.REC_DTYPE)
+        new = rng.random(n) < 0.7
+        new[0] = True
+        hot = rng.integers(0, nref, size=20)
+        ref = np.where(rng.random(n) < 0.6, hot[rng.integers(0, 20, size=n)], rng.integers(0, nref, size=n))
+        recs["ref_new"] = ref.astype(np.uint32) | (new.astype(np.uint32) << 31)
+        total = rng.integers(30, 151, size=n).astype(np.uint32)
+        recs["total"] = total
+        recs["matched"] = (total * np.clip(rng.normal(0.8, 0.25, size=n), 0, 1)).astype(np.uint32)
+        flags = rng.choice([0, 16, 256, 272, 2048, 99, 147, 355, 403, 65, 129, 73, 137], size=n,
+                           p=[.3, .3, .1, .1, .02, .03, .03, .02, .02, .02, .02, .02, .02]).astype(np.uint32)
+        seqlen = np.where(rng.random(n) < 0.8, total, 0).astype(np.uint32)
+        recs["flag_len"] = flags | (seqlen << 12)
+        got = hip.profile_assign(recs, ref2tax, ntax, 0.5)
+        want = oracle_lib.profile_assign(recs, ref2tax, ntax, 0.5)
+        for key in want:
+            assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
