@@ -80,6 +80,8 @@ int mg_dev_malloc(void** d_ptr, uint64_t bytes);
 int mg_dev_free(void* d_ptr);
 int mg_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes);
 int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes);
+/* Asynchronous on the library stream (accumulator reset between batches). */
+int mg_dev_memset(void* d_ptr, int byte_value, uint64_t bytes);
 int mg_sync(void);
 
 /* Per-kernel timing with HIP events on the library stream (bench.py's

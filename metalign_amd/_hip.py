@@ -24,7 +24,7 @@ MAX_K = 64
 # every symbol include/metalign_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
-    "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_sync",
+    "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_size", "mg_sketch_truncated",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
@@ -93,8 +93,9 @@ class DeviceArray:
         self.hip._chk(self.hip.lib.mg_memcpy_d2h(_vp(out.ctypes.data), _vp(self.ptr), ctypes.c_uint64(self.nbytes)))
         return out
 
-    def fill_bytes(self, host_bytes_array):
-        self.upload(host_bytes_array)
+    def memset(self, byte_value=0):
+        self.hip._chk(self.hip.lib.mg_dev_memset(_vp(self.ptr), ctypes.c_int(byte_value), ctypes.c_uint64(self.nbytes)))
+        return self
 
     def free(self):
         if self.ptr:

@@ -37,21 +37,47 @@ void scratch_release_all() {
   c.scratch.clear();
 }
 
+static hipEvent_t prof_event() {
+  Context& c = ctx();
+  if (!c.prof_pool.empty()) {
+    hipEvent_t e = c.prof_pool.back();
+    c.prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
 ProfScope::ProfScope(const char* n) : name(n), on(ctx().prof_on) {
-  if (on) (void)hipEventRecord(ctx().ev0, ctx().stream);
+  if (!on) return;
+  a = prof_event();
+  b = prof_event();
+  if (!a || !b) { on = false; return; }
+  (void)hipEventRecord(a, ctx().stream);
 }
 
 ProfScope::~ProfScope() {
   if (!on) return;
   Context& c = ctx();
-  (void)hipEventRecord(c.ev1, c.stream);
-  (void)hipEventSynchronize(c.ev1);
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, c.ev0, c.ev1) == hipSuccess) {
-    ProfEntry& e = c.prof[name];
-    e.launches += 1;
-    e.total_ms += ms;
+  (void)hipEventRecord(b, c.stream);
+  c.prof_pending.push_back({name, a, b});
+}
+
+void prof_collect() {
+  Context& c = ctx();
+  for (auto& p : c.prof_pending) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ProfEntry& e = c.prof[p.name];
+      e.launches += 1;
+      e.total_ms += ms;
+    }
+    c.prof_pool.push_back(p.a);
+    c.prof_pool.push_back(p.b);
   }
+  c.prof_pending.clear();
 }
 
 }  // namespace mg
@@ -88,8 +114,6 @@ static int init_common(int device, void* stream) {
     MG_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     c.own_stream = true;
   }
-  MG_HIP(hipEventCreate(&c.ev0));
-  MG_HIP(hipEventCreate(&c.ev1));
   c.device = device;
   c.ready = true;
   return MG_OK;
@@ -103,8 +127,8 @@ void mg_shutdown(void) {
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
   mg::scratch_release_all();
-  if (c.ev0) (void)hipEventDestroy(c.ev0);
-  if (c.ev1) (void)hipEventDestroy(c.ev1);
+  mg::prof_collect();
+  for (hipEvent_t e : c.prof_pool) (void)hipEventDestroy(e);
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   c = mg::Context();
 }
@@ -149,6 +173,13 @@ int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes) {
   return MG_OK;
 }
 
+int mg_dev_memset(void* d_ptr, int byte_value, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (bytes == 0) return MG_OK;
+  MG_HIP(hipMemsetAsync(d_ptr, byte_value, bytes, ctx().stream));
+  return MG_OK;
+}
+
 int mg_sync(void) {
   MG_REQUIRE_READY();
   MG_HIP(hipStreamSynchronize(ctx().stream));
@@ -163,12 +194,14 @@ int mg_prof_enable(int on) {
 
 int mg_prof_reset(void) {
   MG_REQUIRE_READY();
+  mg::prof_collect();
   ctx().prof.clear();
   return MG_OK;
 }
 
 int mg_prof_get(const char* kernel, uint64_t* launches, double* total_ms) {
   MG_REQUIRE_READY();
+  mg::prof_collect();
   auto it = ctx().prof.find(kernel ? kernel : "");
   if (launches) *launches = it == ctx().prof.end() ? 0 : it->second.launches;
   if (total_ms) *total_ms = it == ctx().prof.end() ? 0.0 : it->second.total_ms;

@@ -30,8 +30,10 @@ struct Context {
   int num_cus = 256;
   // profiling
   bool prof_on = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::map<std::string, ProfEntry> prof;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> prof_pending;   // recorded, not yet read (no sync inside the timed region)
+  std::vector<hipEvent_t> prof_pool;   // recycled events
   // grow-only named scratch buffers (sort temp storage, candidate lists, ...) so that
   // steady-state calls do not hipMalloc/hipFree (hipFree synchronises the device)
   std::map<std::string, DevBuf*> scratch;
@@ -94,9 +96,12 @@ void scratch_release_all();
 struct ProfScope {
   const char* name;
   bool on;
+  hipEvent_t a = nullptr, b = nullptr;
   explicit ProfScope(const char* n);
   ~ProfScope();
 };
+// Reads every pending event pair (synchronises on them) into ctx().prof.
+void prof_collect();
 
 inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks) {
   uint64_t b = (items + per_block - 1) / per_block;

@@ -1,0 +1,237 @@
+"""One process per GPU: sharding of the hot path and its two exchange steps.
+
+Partitioning
+  reads / alignment records   contiguous shards in stream order, cut on read boundaries (rank r holds shard r)
+  genome sketch table         sharded by genome id: rank r holds genomes [G*r/W, G*(r+1)/W)
+Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)
+  1. all-gather of the per-rank read sketches (hash,count runs) -> every rank merges them into the sample
+     sketch (bottom-s of a union = bottom-s of the union of per-shard bottom-s sets; counts add).
+  2. all-gather of one tiny word per rank: the shard's 2-bit carried-state map and its read count, so each
+     rank can compose the state entering its shard (scripts/map_and_profile.py:229-232 crosses shard edges).
+  3. ONE all-reduce(sum, int64) of [containment hits | sizes | per-taxon read counts | bases |
+     per-rank first-seen slots | tot_rds, n_ambig].  <= a few MB: latency-bound on xGMI, not bandwidth-bound.
+The compute calls go through an `engine` (HipEngine below: libmetalign_hip.so on this rank's GPU).  The
+CPU tests substitute an oracle-backed engine to check the choreography under gloo; product code never does.
+"""
+import numpy as np
+
+from . import _hip
+
+U64_MAX = _hip.U64_MAX
+
+
+def genome_shard(ngenomes, rank, world):
+    return (ngenomes * rank) // world, (ngenomes * (rank + 1)) // world
+
+
+def compose_incoming(maps, rank):
+    """State entering shard `rank`: start from 1 (the phantom first boundary, :155-156) and apply the maps of
+    the preceding non-empty shards in order.  maps[r] = (out_if_in_0, out_if_in_1)."""
+    x = 1
+    for r in range(rank):
+        x = maps[r][x]
+    return x
+
+
+class _CudaView:
+    """Zero-copy view of a library-owned HBM range for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class HipEngine:
+    """Compute side of one rank: device-resident inputs + calls into libmetalign_hip.so."""
+
+    def __init__(self, hip, torch_mod=None):
+        self.hip = hip
+        self.torch = torch_mod  # None in single-process mode: results are returned as numpy arrays
+        self.keep = []
+
+    # ---- inputs ----
+    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, dbh, dbo):
+        hip = self.hip
+        self.nreads = len(roffsets) - 1
+        self.d_rb = hip.array(rbases if len(rbases) else np.zeros(1, np.uint8))
+        self.d_ro = hip.array(roffsets)
+        self.nrecs = len(recs) - (1 if has_lookahead else 0)
+        self.has_lookahead = has_lookahead
+        self.d_recs = hip.array(recs if len(recs) else np.zeros(1, _hip.REC_DTYPE))
+        self.d_r2t = hip.array(ref2tax)
+        self.nref, self.ntax = len(ref2tax), ntax
+        self.table = hip.upload_table(dbh, dbo)
+        self.ngen_local = len(dbo) - 1
+        self.d_hits = hip.empty(max(self.ngen_local, 1), np.uint32)
+        self.d_sizes = hip.empty(max(self.ngen_local, 1), np.uint32)
+        # [count T | bases T | first_seen T | scalars 2]
+        self.d_acc = hip.empty(3 * ntax + 2, np.uint64)
+
+    # ---- stage A ----
+    def sketch_local(self, k, hmax, s):
+        return self.hip.sketch_reads_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)
+
+    def export_sketch(self, sk):
+        """(hashes int64 tensor, counts int32 tensor) on this rank's device, zero-copy."""
+        t = self.torch
+        n = sk.size
+        if n == 0:
+            return t.zeros(0, dtype=t.int64, device="cuda"), t.zeros(0, dtype=t.int32, device="cuda")
+        ph, pc = sk.device_ptrs()
+        return (t.as_tensor(_CudaView(ph, n, "<i8"), device="cuda"), t.as_tensor(_CudaView(pc, n, "<i4"), device="cuda"))
+
+    def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound):
+        n = int(hashes_t.numel())
+        self.keep = [hashes_t, counts_t]
+        return self.hip.sketch_from_pairs_dev(hashes_t.data_ptr(), counts_t.data_ptr(), n, k, s, any_truncated, bound)
+
+    # ---- stage B ----
+    def containment(self, sk, ci):
+        self.hip.containment_dev(sk, self.table, ci, self.d_hits.ptr, self.d_sizes.ptr)
+        return self.d_hits.download()[: self.ngen_local], self.d_sizes.download()[: self.ngen_local]
+
+    # ---- stage C ----
+    def profile_begin(self, pct_id):
+        self.shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
+                                                self.nref, self.ntax, pct_id)
+        return self.shard.state_map(), self.shard.ngroups
+
+    def profile_commit(self, incoming, first_shard, group_base, want_multimapped=True):
+        T = self.ntax
+        hipl = self.hip.lib
+        import ctypes
+        base = self.d_acc.ptr
+        self.hip._chk(hipl.mg_dev_memset(ctypes.c_void_p(base), 0, ctypes.c_uint64(2 * T * 8)))
+        self.hip._chk(hipl.mg_dev_memset(ctypes.c_void_p(base + 2 * T * 8), 0xFF, ctypes.c_uint64(T * 8)))
+        self.hip._chk(hipl.mg_dev_memset(ctypes.c_void_p(base + 3 * T * 8), 0, ctypes.c_uint64(16)))
+        self.shard.commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8)
+        acc = self.d_acc.download()
+        mm = self.shard.multimapped() if want_multimapped else None
+        self.shard.free()
+        return acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm
+
+
+class ShardJob:
+    """One rank's share of a sample and the collective choreography around it."""
+
+    def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.k, self.ci, self.pct_id, self.s = k, ci, pct_id, s
+        if engine is not None:
+            self.engine = engine
+            self.torch = engine.torch
+        else:
+            tm = None
+            if dist is not None:
+                import torch as tm  # noqa: F811
+            self.torch = tm
+            self.engine = HipEngine(hip, tm)
+        self.device = getattr(self.engine, "device", "cuda")
+
+    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo):
+        """recs: this rank's shard (starts on a read boundary).  dbh/dbo: the FULL table; sliced here."""
+        G = len(dbo) - 1
+        self.G, self.T = G, len(ref2tax)
+        self.g0, self.g1 = genome_shard(G, self.rank, self.world)
+        lo, hi = int(dbo[self.g0]), int(dbo[self.g1])
+        tails = dbo[1:][dbo[1:] > dbo[:-1]] - 1
+        self.hmax = int(dbh[tails.astype(np.int64)].max()) if len(tails) else 0
+        has_look = False
+        if self.world > 1:
+            # the first record of the NEXT non-empty shard closes this shard's last read (:225-226)
+            t = self.torch
+            mine = np.zeros(5, dtype=np.int64)
+            if len(recs):
+                mine[0] = 1
+                mine[1:] = [int(recs[0][f]) for f in ("ref_new", "matched", "total", "flag_len")]
+            gathered = [t.zeros(5, dtype=t.int64, device=self.device) for _ in range(self.world)]
+            self.dist.all_gather(gathered, t.as_tensor(mine, device=self.device))
+            heads = [g.cpu().numpy() for g in gathered]
+            nxt = next((h for h in heads[self.rank + 1:] if h[0]), None)
+            self.nonempty = [bool(h[0]) for h in heads]
+            if nxt is not None and len(recs):
+                look = np.zeros(1, dtype=_hip.REC_DTYPE)
+                look[0] = tuple(int(v) for v in nxt[1:])
+                recs = np.concatenate([recs, look])
+                has_look = True
+        else:
+            self.nonempty = [len(recs) > 0]
+        self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh[lo:hi], dbo[self.g0:self.g1 + 1] - dbo[self.g0])
+
+    # ------------------------------------------------------------------
+    def _merged_sketch(self):
+        sk = self.engine.sketch_local(self.k, self.hmax, self.s)
+        if self.world == 1:
+            return sk
+        t, dist = self.torch, self.dist
+        h, c = self.engine.export_sketch(sk)
+        n = int(h.numel())
+        last = int(h[-1].item()) if n else 0
+        meta = t.as_tensor([n, int(sk.truncated), last], dtype=t.int64, device=self.device)
+        metas = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(metas, meta)
+        metas = [m.cpu().numpy() for m in metas]
+        nmax = int(max(m[0] for m in metas))
+        hp = t.zeros(nmax, dtype=t.int64, device=self.device)
+        cp = t.zeros(nmax, dtype=t.int32, device=self.device)
+        hp[:n] = h
+        cp[:n] = c
+        hs = [t.zeros(nmax, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        cs = [t.zeros(nmax, dtype=t.int32, device=self.device) for _ in range(self.world)]
+        dist.all_gather(hs, hp)
+        dist.all_gather(cs, cp)
+        allh = t.cat([hs[r][: int(metas[r][0])] for r in range(self.world)]).contiguous()
+        allc = t.cat([cs[r][: int(metas[r][0])] for r in range(self.world)]).contiguous()
+        any_trunc = any(int(m[1]) for m in metas)
+        bounds = [int(np.uint64(np.int64(m[2]))) for m in metas if int(m[1]) and int(m[0])]
+        bound = min(bounds) if bounds else U64_MAX
+        merged = self.engine.merge_sketches(allh, allc, self.k, self.s, any_trunc, bound)
+        sk.free()
+        return merged
+
+    def step(self, want_multimapped=False):
+        """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank)."""
+        eng = self.engine
+        sk = self._merged_sketch()
+        hits, sizes = eng.containment(sk, self.ci)
+        qn = sk.size
+        sk.free()
+        (m0, m1), ngroups = eng.profile_begin(self.pct_id)
+        if self.world > 1:
+            t, dist = self.torch, self.dist
+            word = t.as_tensor([m0, m1, ngroups], dtype=t.int64, device=self.device)
+            words = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(self.world)]
+            dist.all_gather(words, word)
+            words = [w.cpu().numpy() for w in words]
+            maps = [(int(w[0]), int(w[1])) for w in words]
+            incoming = compose_incoming(maps, self.rank)
+            group_base = int(sum(int(w[2]) for w in words[: self.rank]))
+            first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
+        else:
+            incoming, group_base, first_shard = 1, 0, True
+        count, bases, first, scalars, mm = eng.profile_commit(incoming, first_shard, group_base, want_multimapped)
+        G, T, W = self.G, self.T, self.world
+        if W > 1:
+            t, dist = self.torch, self.dist
+            buf = np.zeros(2 * G + 2 * T + W * T + 2, dtype=np.int64)
+            buf[self.g0:self.g1] = hits
+            buf[G + self.g0:G + self.g1] = sizes
+            buf[2 * G:2 * G + T] = count.view(np.int64)
+            buf[2 * G + T:2 * G + 2 * T] = bases.view(np.int64)
+            o = 2 * G + 2 * T + self.rank * T
+            buf[o:o + T] = first.view(np.int64)
+            buf[-2:] = scalars.view(np.int64)
+            tb = t.as_tensor(buf, device=self.device)
+            dist.all_reduce(tb, op=dist.ReduceOp.SUM)  # THE all-reduce
+            buf = tb.cpu().numpy()
+            hits, sizes = buf[:G].astype(np.uint32), buf[G:2 * G].astype(np.uint32)
+            count, bases = buf[2 * G:2 * G + T].view(np.uint64), buf[2 * G + T:2 * G + 2 * T].view(np.uint64)
+            slots = buf[2 * G + 2 * T:2 * G + 2 * T + W * T].view(np.uint64).reshape(W, T)
+            first = slots.min(axis=0)  # shards hold disjoint, increasing read-index ranges
+            scalars = buf[-2:].view(np.uint64)
+        out = dict(hits=hits, sizes=sizes, count=count, bases=bases, first_seen=first, tot_rds=int(scalars[0]),
+                   n_ambig=int(scalars[1]), sketch_size=qn, multimapped=mm)
+        ci_vals = hits / np.maximum(sizes, 1)
+        out["containment"] = ci_vals
+        out["top_ok"] = bool(ci_vals.max() > 0.5) if len(ci_vals) else None
+        return out
