@@ -89,7 +89,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1 or args.gpus > 1:
+    force_dist = os.environ.get("MG_FORCE_DIST") == "1"  # single-GPU validation of the torch/RCCL path
+    if world > 1 or args.gpus > 1 or force_dist:
         # torch first: the library then binds to the same HIP runtime and launches on torch's stream
         import torch
         import torch.distributed as dist
@@ -103,7 +104,7 @@ def main():
 
     w = build_workload(args, rank, hip)
     from metalign_amd import distributed as mgd
-    job = mgd.ShardJob(hip, dist, rank, world, k=args.k, ci=2, pct_id=0.5)
+    job = mgd.ShardJob(hip, dist, rank, world, k=args.k, ci=2, pct_id=0.5, always_exchange=force_dist)
     job.load(w["rb"], w["ro"], w["recs"], w["ref2tax"], w["dbh"], w["dbo"])
 
     def sync():

@@ -1,0 +1,77 @@
+#! /usr/bin/env python
+"""Build the genome sketch table the pre-filter consumes (metalign_amd/formats.py).
+
+Counterpart of the reference's offline recipe — CMash MakeStreamingDNADatabase.py -n 1000 -k 60, the bloom
+pre-filter and the KMC dump (/root/reference/local_tests/retrain_and_test_metalign.sh:49-66) — as one GPU
+pass per k (mg_sketch_genomes: k_hash_positions + segmented sort + k_take_bottom_n).
+
+    python -m metalign_amd.build_db <organism_dir | file-list.txt> <out_dir> [-n 1000] [-k 30,40,50,60]
+"""
+import argparse
+import os
+
+import numpy as np
+
+from . import _hip, formats
+
+
+def genome_bases(path):
+    """All records of one organism file as one byte string; records are joined by 'N' so that no k-mer
+    spans two contigs."""
+    kind = 'fasta'
+    b, o, _ = formats.read_sequences(path, kind)
+    if len(o) <= 2:
+        return b
+    parts = []
+    for i in range(len(o) - 1):
+        if i:
+            parts.append(np.frombuffer(b'N', dtype=np.uint8))
+        parts.append(b[int(o[i]):int(o[i + 1])])
+    return np.concatenate(parts)
+
+
+def build(paths, out_dir, ks, n, batch_bases=1 << 27):
+    hip = _hip.Hip.get()
+    names = [os.path.basename(p) for p in paths]
+    per_k = {k: ([], [0]) for k in ks}
+    i = 0
+    while i < len(paths):
+        seqs, total = [], 0
+        while i < len(paths) and (not seqs or total < batch_bases):
+            g = genome_bases(paths[i])
+            seqs.append(g)
+            total += len(g)
+            i += 1
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(s) for s in seqs])
+        bases = np.concatenate(seqs) if total else np.zeros(1, np.uint8)
+        for k in ks:
+            h, o = hip.sketch_genomes(bases, offs, k, n)
+            hs, os_ = per_k[k]
+            base = os_[-1]
+            hs.append(h)
+            os_.extend(int(v) + base for v in o[1:])
+    final = {k: (np.concatenate(per_k[k][0]) if per_k[k][0] else np.zeros(0, np.uint64),
+                 np.asarray(per_k[k][1], dtype=np.uint64)) for k in ks}
+    formats.write_sketch_table(out_dir, names, ks, n, final)
+    return final
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description='Build the MI355X genome sketch table from organism FASTA files.')
+    p.add_argument('genomes', help='Directory of organism files (taxid_*_genomic.fna[.gz]) or a text file listing them.')
+    p.add_argument('out_dir', help='Sketch table directory to write (default location: data/sketch_table).')
+    p.add_argument('-n', '--num_hashes', type=int, default=1000, help='Sketch size per genome. Default: 1000')
+    p.add_argument('-k', '--ks', default='30,40,50,60', help='Comma-separated k-mer sizes. Default: 30,40,50,60')
+    a = p.parse_args(argv)
+    if os.path.isdir(a.genomes):
+        paths = sorted(os.path.join(a.genomes, f) for f in os.listdir(a.genomes)
+                       if '.fna' in f or f.endswith(('.fa', '.fa.gz', '.fasta', '.fasta.gz')))
+    else:
+        with open(a.genomes) as fh:
+            paths = [ln.strip() for ln in fh if ln.strip()]
+    build(paths, a.out_dir, [int(x) for x in a.ks.split(',')], a.num_hashes)
+
+
+if __name__ == '__main__':
+    main()

@@ -20,6 +20,56 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+static uint64_t size_class(uint64_t n) {
+  if (n < 256) return 256;
+  // classes: powers of two and the midpoints between them (<= 33 % slack)
+  uint64_t p = 256;
+  while (p < n) {
+    if (p + p / 2 >= n) return p + p / 2;
+    p <<= 1;
+  }
+  return p;
+}
+
+void* pool_alloc(uint64_t bytes, uint64_t* got) {
+  Context& c = ctx();
+  const uint64_t cls = size_class(bytes);
+  auto& fl = c.pool[cls];
+  if (!fl.empty()) {
+    void* p = fl.back();
+    fl.pop_back();
+    *got = cls;
+    return p;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e != hipSuccess) {
+    pool_release_all();  // give cached blocks back and retry once
+    e = hipMalloc(&p, cls);
+  }
+  if (e != hipSuccess) {
+    fail(MG_ERR_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)cls, hipGetErrorString(e));
+    return nullptr;
+  }
+  *got = cls;
+  return p;
+}
+
+void pool_free(void* p, uint64_t bytes) {
+  Context& c = ctx();
+  if (!c.ready) { (void)hipFree(p); return; }
+  c.pool[bytes].push_back(p);
+}
+
+void pool_release_all() {
+  Context& c = ctx();
+  for (auto& kv : c.pool)
+    for (void* p : kv.second) (void)hipFree(p);
+  c.pool.clear();
+}
+
+uint64_t* host_words() { return ctx().pinned; }
+
 void* scratch(const char* name, uint64_t bytes) {
   Context& c = ctx();
   DevBuf*& b = c.scratch[name];
@@ -114,6 +164,7 @@ static int init_common(int device, void* stream) {
     MG_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     c.own_stream = true;
   }
+  MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), 64 * sizeof(uint64_t), hipHostMallocDefault));
   c.device = device;
   c.ready = true;
   return MG_OK;
@@ -127,6 +178,8 @@ void mg_shutdown(void) {
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
   mg::scratch_release_all();
+  mg::pool_release_all();
+  if (c.pinned) (void)hipHostFree(c.pinned);
   mg::prof_collect();
   for (hipEvent_t e : c.prof_pool) (void)hipEventDestroy(e);
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);

@@ -37,6 +37,8 @@ struct Context {
   // grow-only named scratch buffers (sort temp storage, candidate lists, ...) so that
   // steady-state calls do not hipMalloc/hipFree (hipFree synchronises the device)
   std::map<std::string, DevBuf*> scratch;
+  std::map<uint64_t, std::vector<void*>> pool;  // size class -> free blocks
+  uint64_t* pinned = nullptr;
 };
 
 Context& ctx();
@@ -61,6 +63,13 @@ int fail(int code, const char* fmt, ...);
     if (!::mg::ctx().ready) return ::mg::fail(MG_ERR_STATE, "mg_init not called"); \
   } while (0)
 
+// Size-class cached device allocator.  pool_alloc returns nullptr (error text set) on failure.
+void* pool_alloc(uint64_t bytes, uint64_t* got);
+void pool_free(void* p, uint64_t bytes);
+void pool_release_all();
+// Pinned host words for small read-backs (index < 64).
+uint64_t* host_words();
+
 // RAII device buffer on the library stream's device.
 struct DevBuf {
   void* p = nullptr;
@@ -74,16 +83,19 @@ struct DevBuf {
     return *this;
   }
   ~DevBuf() { release(); }
+  // Allocations come from a size-class cache (pool_alloc / pool_free in mg_core.hip): steady-state
+  // batches reuse the previous batch's buffers instead of paying hipMalloc / hipFree (which
+  // synchronises the device) per handle.
   int alloc(uint64_t n) {
     release();
-    if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) { p = nullptr; return fail(MG_ERR_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)n, hipGetErrorString(e)); }
-    bytes = n;
+    uint64_t got = 0;
+    p = pool_alloc(n, &got);
+    if (!p) return MG_ERR_NOMEM;
+    bytes = got;
     return MG_OK;
   }
   void release() {
-    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    if (p) { pool_free(p, bytes); p = nullptr; bytes = 0; }
   }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -114,11 +126,11 @@ inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks
 // Sorts n u64 keys ascending using bits [0,end_bit). out may not alias in.
 int sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, unsigned end_bit);
 int sort_pairs(const uint64_t* d_kin, uint64_t* d_kout, const uint32_t* d_vin, uint32_t* d_vout, uint64_t n);
-// Run-length encode sorted keys -> (unique, counts, *h_runs).
-int rle_keys(const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* h_runs);
-// Sum values of equal adjacent keys (saturating u32) -> (unique, sums, *h_runs).
+// Run-length encode sorted keys -> (unique, counts, *d_runs); asynchronous, run count stays on the device.
+int rle_keys(const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* d_runs);
+// Sum values of equal adjacent keys (saturating u32) -> (unique, sums, *d_runs); asynchronous.
 int reduce_pairs(const uint64_t* d_keys, const uint32_t* d_vals, uint64_t n, uint64_t* d_unique, uint32_t* d_sums,
-                 uint64_t* h_runs);
+                 uint64_t* d_runs);
 // Sort every segment [offs[i], offs[i+1]) of keys independently.
 int segmented_sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, const uint64_t* d_offsets, uint64_t nseg);
 // Exclusive prefix sums; *h_total receives the grand total.

@@ -17,6 +17,7 @@
 //                      to an LDS-privatised histogram (count, bases, first
 //                      seen) flushed with global atomics; multimapped reads
 //                      record their list length
+//   k_profile_scan_mm  one block: exclusive sums of the per-tile multimapped totals
 //   k_profile_fill_mm  writes the multimapped CSR (lists in SAM order)
 // Records are 16 B and are streamed with coalesced 16-byte loads.
 #include <memory>
@@ -206,44 +207,102 @@ __global__ __launch_bounds__(kPB) void k_profile_maps(const mg_aln_rec* __restri
   if (threadIdx.x == 0) { blk_map[blockIdx.x] = (uint8_t)total; blk_groups[blockIdx.x] = ngroups; }
 }
 
-// One block.  In: per-block aggregates.  Out: exclusive prefixes per block, totals in out_tot[0..1].
+// ---- helpers for the single-block (1024 threads) scans over per-tile aggregates ----
+template <int NT>
+__device__ __forceinline__ uint64_t blockN_excl_sum(uint64_t v, uint64_t* lds, uint64_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint64_t prev = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += prev;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint64_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const uint64_t t = lds[w];
+    if (w < wave) before += t;
+    all += t;
+  }
+  __syncthreads();
+  *total = all;
+  return before + inc - v;
+}
+
+template <int NT>
+__device__ __forceinline__ uint32_t blockN_excl_map(uint32_t m, uint32_t* lds, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = m;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t prev = __shfl_up(inc, o, 64);
+    if (lane >= o) inc = map_then(prev, inc);
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t before = kIdentity, all = kIdentity;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const uint32_t t = lds[w];
+    if (w < wave) before = map_then(before, t);
+    all = map_then(all, t);
+  }
+  uint32_t excl = __shfl_up(inc, 1, 64);
+  if (lane == 0) excl = kIdentity;
+  __syncthreads();
+  *total = all;
+  return map_then(before, excl);
+}
+
+// One block.  In: per-tile aggregates.  Out: exclusive prefixes per tile, totals in out_tot[0..1].
 __global__ __launch_bounds__(1024) void k_profile_scan(const uint8_t* __restrict__ blk_map,
                                                        const uint32_t* __restrict__ blk_groups, uint64_t nblocks,
                                                        uint8_t* __restrict__ pre_map, uint64_t* __restrict__ pre_groups,
                                                        uint64_t* __restrict__ out_tot) {
-  __shared__ uint32_t s_map[1024];
-  __shared__ uint64_t s_grp[1024];
+  __shared__ uint32_t s_map[16];
+  __shared__ uint64_t s_grp[16];
   const uint64_t per = (nblocks + 1023) / 1024;
   const uint64_t b0 = (uint64_t)threadIdx.x * per;
   const uint64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
   uint32_t m = kIdentity;
   uint64_t g = 0;
   for (uint64_t b = b0; b < b1; ++b) { m = map_then(m, blk_map[b]); g += blk_groups[b]; }
-  s_map[threadIdx.x] = m;
-  s_grp[threadIdx.x] = g;
-  __syncthreads();
-  if (threadIdx.x == 0) {  // 1024 sequential steps on 2-bit values: negligible
-    uint32_t am = kIdentity;
-    uint64_t ag = 0;
-    for (int t = 0; t < 1024; ++t) {
-      uint32_t tm = s_map[t];
-      uint64_t tg = s_grp[t];
-      s_map[t] = am;
-      s_grp[t] = ag;
-      am = map_then(am, tm);
-      ag += tg;
-    }
-    out_tot[0] = am;
-    out_tot[1] = ag;
-  }
-  __syncthreads();
-  m = s_map[threadIdx.x];
-  g = s_grp[threadIdx.x];
+  uint32_t tot_m;
+  uint64_t tot_g;
+  m = blockN_excl_map<1024>(m, s_map, &tot_m);
+  g = blockN_excl_sum<1024>(g, s_grp, &tot_g);
+  if (threadIdx.x == 0) { out_tot[0] = tot_m; out_tot[1] = tot_g; }
   for (uint64_t b = b0; b < b1; ++b) {
     pre_map[b] = (uint8_t)m;
     pre_groups[b] = g;
     m = map_then(m, blk_map[b]);
     g += blk_groups[b];
+  }
+}
+
+// One block: exclusive sums of the per-tile multimapped entry / read totals (in place), grand totals out.
+__global__ __launch_bounds__(1024) void k_profile_scan_mm(uint64_t* __restrict__ tile_ent,
+                                                          uint64_t* __restrict__ tile_reads, uint64_t ntiles,
+                                                          uint64_t* __restrict__ out_tot) {
+  __shared__ uint64_t s_a[16];
+  __shared__ uint64_t s_b[16];
+  const uint64_t per = (ntiles + 1023) / 1024;
+  const uint64_t b0 = (uint64_t)threadIdx.x * per;
+  const uint64_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+  uint64_t e = 0, r = 0;
+  for (uint64_t b = b0; b < b1; ++b) { e += tile_ent[b]; r += tile_reads[b]; }
+  uint64_t tot_e, tot_r;
+  e = blockN_excl_sum<1024>(e, s_a, &tot_e);
+  r = blockN_excl_sum<1024>(r, s_b, &tot_r);
+  if (threadIdx.x == 0) { out_tot[2] = tot_e; out_tot[3] = tot_r; }
+  for (uint64_t b = b0; b < b1; ++b) {
+    const uint64_t te = tile_ent[b], tr = tile_reads[b];
+    tile_ent[b] = e;
+    tile_reads[b] = r;
+    e += te;
+    r += tr;
   }
 }
 
@@ -254,9 +313,11 @@ __global__ __launch_bounds__(kPB) void k_profile_commit(
     const uint64_t* __restrict__ pre_groups, uint32_t incoming, uint32_t first_shard, uint64_t group_base,
     uint32_t ntax, uint32_t use_lds_hist, unsigned long long* __restrict__ g_count,
     unsigned long long* __restrict__ g_bases, unsigned long long* __restrict__ g_first,
-    unsigned long long* __restrict__ g_scalars, uint32_t* __restrict__ mm_cnt, uint64_t ntiles) {
+    unsigned long long* __restrict__ g_scalars, uint32_t* __restrict__ mm_cnt, uint64_t* __restrict__ tile_ent,
+    uint64_t* __restrict__ tile_reads, uint64_t ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
   __shared__ uint32_t lds[8];
+  __shared__ uint64_t lds64[4];
   __shared__ unsigned long long s_ambig, s_groups;
   unsigned long long* h_count = hist;
   unsigned long long* h_bases = hist + ntax;
@@ -305,7 +366,11 @@ __global__ __launch_bounds__(kPB) void k_profile_commit(
       }
     }
     if (i < nrecs) mm_cnt[i] = my_cnt;
-    if (threadIdx.x == 0) s_groups += ngroups;
+    uint64_t t_ent;
+    uint32_t t_reads;
+    (void)blockN_excl_sum<kPB>((uint64_t)my_cnt, lds64, &t_ent);
+    (void)block_rank(my_cnt != 0, lds + 4, &t_reads);
+    if (threadIdx.x == 0) { s_groups += ngroups; tile_ent[tile] = t_ent; tile_reads[tile] = t_reads; }
   }
   __syncthreads();
   if (use_lds_hist) {
@@ -323,28 +388,27 @@ __global__ __launch_bounds__(kPB) void k_profile_commit(
   }
 }
 
-__global__ void k_flag_nonzero(const uint32_t* in, uint32_t* out, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = in[i] != 0;
-}
-
 __global__ __launch_bounds__(kPB) void k_profile_fill_mm(
     const mg_aln_rec* __restrict__ recs, uint64_t nrecs, uint64_t ntotal, const uint32_t* __restrict__ ref2tax,
     double pct_id, const uint8_t* __restrict__ dropped, const uint64_t* __restrict__ pre_groups, uint64_t group_base,
-    const uint32_t* __restrict__ mm_cnt, const uint64_t* __restrict__ ent_off, const uint64_t* __restrict__ slot_off,
+    const uint32_t* __restrict__ mm_cnt, const uint64_t* __restrict__ tile_ent, const uint64_t* __restrict__ tile_reads,
     uint64_t* __restrict__ mm_offsets, uint32_t* __restrict__ mm_tax, uint64_t* __restrict__ mm_hitlen,
     uint64_t* __restrict__ mm_read, uint64_t ntiles) {
-  __shared__ uint32_t lds[4];
+  __shared__ uint32_t lds[8];
+  __shared__ uint64_t lds64[4];
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint64_t i = tile * kPB + threadIdx.x;
     const bool leader = i < nrecs && (recs[i].ref_new & MG_REC_NEW_BIT);
-    uint32_t ngroups;
+    const uint32_t cnt = i < nrecs ? mm_cnt[i] : 0;
+    uint32_t ngroups, nreads_t;
+    uint64_t nent_t;
     const uint32_t rank = block_rank(leader, lds, &ngroups);
-    if (leader && mm_cnt[i] != 0) {
+    const uint32_t slot_in = block_rank(cnt != 0, lds + 4, &nreads_t);
+    const uint64_t ent_in = blockN_excl_sum<kPB>((uint64_t)cnt, lds64, &nent_t);
+    if (cnt != 0) {
       const uint64_t e = group_end(recs, i, ntotal);
       const uint32_t nf = recs[e].flag_len & MG_REC_FLAG_MASK;
-      const uint64_t eo = ent_off[i], so = slot_off[i];
+      const uint64_t eo = tile_ent[tile] + ent_in, so = tile_reads[tile] + slot_in;
       const Verdict v = eval_group(recs, i + dropped[i], e, nf, ref2tax, pct_id, mm_tax + eo);
       mm_offsets[so] = eo;
       mm_hitlen[so] = v.hitlen;
@@ -369,7 +433,7 @@ struct mg_profile {
   uint64_t ngroups = 0;
   bool committed = false;
   // multimapped CSR (device)
-  DevBuf mm_cnt, ent_off, flags, slot_off, mm_offsets, mm_tax, mm_hitlen, mm_read;
+  DevBuf mm_cnt, tile_ent, tile_reads, mm_offsets, mm_tax, mm_hitlen, mm_read;
   uint64_t mm_nreads = 0, mm_nentries = 0;
 };
 
@@ -398,7 +462,7 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs, int has_looka
   MG_TRY(p->blk_groups.alloc(p->nblocks * sizeof(uint32_t)));
   MG_TRY(p->pre_map.alloc(p->nblocks));
   MG_TRY(p->pre_groups.alloc(p->nblocks * sizeof(uint64_t)));
-  MG_TRY(p->tot.alloc(2 * sizeof(uint64_t)));
+  MG_TRY(p->tot.alloc(4 * sizeof(uint64_t)));
   {
     ProfScope ps("profile_maps");
     hipLaunchKernelGGL(k_profile_maps, dim3((unsigned)p->nblocks), dim3(kPB), 0, st, d_recs, nrecs, p->ntotal,
@@ -413,8 +477,8 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs, int has_looka
                        p->pre_groups.as<uint64_t>(), p->tot.as<uint64_t>());
     MG_HIP(hipGetLastError());
   }
-  uint64_t h_tot[2];
-  MG_HIP(hipMemcpyAsync(h_tot, p->tot.p, sizeof(h_tot), hipMemcpyDeviceToHost, st));
+  uint64_t* h_tot = host_words() + 16;
+  MG_HIP(hipMemcpyAsync(h_tot, p->tot.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
   p->map[0] = (uint8_t)(h_tot[0] & 1u);
   p->map[1] = (uint8_t)((h_tot[0] >> 1) & 1u);
@@ -447,6 +511,8 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
     return MG_OK;
   }
   MG_TRY(p->mm_cnt.alloc(p->nrecs * sizeof(uint32_t)));
+  MG_TRY(p->tile_ent.alloc(p->nblocks * sizeof(uint64_t)));
+  MG_TRY(p->tile_reads.alloc(p->nblocks * sizeof(uint64_t)));
   const uint32_t use_lds = p->ntax <= 2048 ? 1u : 0u;
   const size_t lds = use_lds ? 3 * (size_t)p->ntax * sizeof(unsigned long long) : 0;
   {
@@ -457,20 +523,20 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
                        (uint32_t)(incoming_dropped ? 1 : 0), (uint32_t)(first_shard ? 1 : 0), group_base, p->ntax,
                        use_lds, (unsigned long long*)d_count, (unsigned long long*)d_bases,
                        (unsigned long long*)d_first_seen, (unsigned long long*)d_scalars, p->mm_cnt.as<uint32_t>(),
-                       p->nblocks);
+                       p->tile_ent.as<uint64_t>(), p->tile_reads.as<uint64_t>(), p->nblocks);
     MG_HIP(hipGetLastError());
   }
-  // multimapped CSR: entry offsets, read slots, then the fill pass
-  MG_TRY(p->ent_off.alloc((p->nrecs + 1) * sizeof(uint64_t)));
-  MG_TRY(p->flags.alloc(p->nrecs * sizeof(uint32_t)));
-  MG_TRY(p->slot_off.alloc((p->nrecs + 1) * sizeof(uint64_t)));
   {
-    ProfScope ps("profile_mm_scan");
-    MG_TRY(exclusive_sum_u32_to_u64(p->mm_cnt.as<uint32_t>(), p->ent_off.as<uint64_t>(), p->nrecs, &p->mm_nentries));
-    hipLaunchKernelGGL(k_flag_nonzero, dim3(grid_for(p->nrecs, 256, 4096)), dim3(256), 0, st,
-                       p->mm_cnt.as<uint32_t>(), p->flags.as<uint32_t>(), p->nrecs);
-    MG_TRY(exclusive_sum_u32_to_u64(p->flags.as<uint32_t>(), p->slot_off.as<uint64_t>(), p->nrecs, &p->mm_nreads));
+    ProfScope ps("profile_scan_mm");
+    hipLaunchKernelGGL(k_profile_scan_mm, dim3(1), dim3(1024), 0, st, p->tile_ent.as<uint64_t>(),
+                       p->tile_reads.as<uint64_t>(), p->nblocks, p->tot.as<uint64_t>());
+    MG_HIP(hipGetLastError());
   }
+  uint64_t* h_tot = host_words() + 16;
+  MG_HIP(hipMemcpyAsync(h_tot + 2, p->tot.as<uint64_t>() + 2, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  p->mm_nentries = h_tot[2];
+  p->mm_nreads = h_tot[3];
   MG_TRY(p->mm_offsets.alloc((p->mm_nreads + 1) * sizeof(uint64_t)));
   MG_TRY(p->mm_tax.alloc(p->mm_nentries * sizeof(uint32_t)));
   MG_TRY(p->mm_hitlen.alloc(p->mm_nreads * sizeof(uint64_t)));
@@ -480,14 +546,14 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
     unsigned grid = grid_for(p->nblocks, 1, (unsigned)c.num_cus * 8);
     hipLaunchKernelGGL(k_profile_fill_mm, dim3(grid), dim3(kPB), 0, st, p->d_recs, p->nrecs, p->ntotal, p->d_ref2tax,
                        p->pct_id, p->maps.as<uint8_t>(), p->pre_groups.as<uint64_t>(), group_base,
-                       p->mm_cnt.as<uint32_t>(), p->ent_off.as<uint64_t>(), p->slot_off.as<uint64_t>(),
+                       p->mm_cnt.as<uint32_t>(), p->tile_ent.as<uint64_t>(), p->tile_reads.as<uint64_t>(),
                        p->mm_offsets.as<uint64_t>(), p->mm_tax.as<uint32_t>(), p->mm_hitlen.as<uint64_t>(),
                        p->mm_read.as<uint64_t>(), p->nblocks);
     MG_HIP(hipGetLastError());
   }
-  MG_HIP(hipMemcpyAsync(p->mm_offsets.as<uint64_t>() + p->mm_nreads, &p->mm_nentries, sizeof(uint64_t),
-                        hipMemcpyHostToDevice, st));
-  MG_HIP(hipStreamSynchronize(st));
+  // closing offset; written from the device-side total so that no host buffer has to outlive this call
+  MG_HIP(hipMemcpyAsync(p->mm_offsets.as<uint64_t>() + p->mm_nreads, p->tot.as<uint64_t>() + 2, sizeof(uint64_t),
+                        hipMemcpyDeviceToDevice, st));
   return MG_OK;
 }
 

@@ -11,6 +11,8 @@
 //
 // Replaces: kmc -k60 -ci2 -cs3 (scripts/select_db.py:50-52) + k-mer hashing in
 // CMash's streaming query (scripts/select_db.py:73-76).
+#include <cstdlib>
+
 #include "mg_internal.h"
 #include "mg_kmer.h"
 
@@ -71,30 +73,35 @@ struct CandSink {
   }
 };
 
+// One lane walks its read two bases per iteration.  Straight-line body (invalid bases and
+// positions past the end are folded into the run counter instead of branches) so that the two
+// independent MurmurHash3 chains of an iteration interleave in the VALU.
 template <int K, bool FROM_LDS>
-__device__ __forceinline__ void walk_reads(const uint8_t* src, uint64_t len, uint64_t maxlen, uint64_t hmax,
+__device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uint32_t maxlen, uint64_t hmax,
                                            CandSink& sink, uint64_t& kmers, int lane) {
   Roller<K> roll;
   roll.reset();
-  for (uint64_t pos = 0; pos < maxlen; ++pos) {
-    bool hit = false;
-    uint64_t h = 0;
-    if (pos < len) {
-      uint32_t b = src[pos];
-      uint32_t c;
-      if (decode_base(b, c)) {
-        roll.push(c);
-        if (roll.full()) {
-          h = roll.hash();
-          ++kmers;
-          hit = h <= hmax;
-        }
-      } else {
-        roll.run = 0;
-      }
-    }
-    sink.offer(hit, h, lane);
+  uint32_t nk = 0;
+  for (uint32_t pos = 0; pos < maxlen; pos += 2) {
+    uint32_t b0 = 'N', b1 = 'N';
+    if (pos < len) b0 = src[pos];
+    if (pos + 1 < len) b1 = src[pos + 1];
+    uint32_t c0, c1;
+    const bool ok0 = decode_base(b0, c0);
+    const bool ok1 = decode_base(b1, c1);
+    roll.push(c0);
+    roll.run = ok0 ? roll.run : 0;
+    const uint64_t h0 = roll.hash();
+    const bool full0 = roll.run >= K;
+    roll.push(c1);
+    roll.run = ok1 ? roll.run : 0;
+    const uint64_t h1 = roll.hash();
+    const bool full1 = roll.run >= K;
+    nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
+    sink.offer(full0 && h0 <= hmax, h0, lane);
+    sink.offer(full1 && h1 <= hmax, h1, lane);
   }
+  kmers += nk;
 }
 
 // counters[0] = candidates produced (may exceed cap: overflow => caller retries), counters[1] = k-mers hashed
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
     const uint64_t r = r0 + lane;
     uint64_t beg = 0, end = 0;
     if (r < nreads) { beg = offsets[r]; end = offsets[r + 1]; }
-    const uint64_t len = end - beg;
+    const uint64_t len = end - beg;  // < 2^32: a read longer than that is rejected on the host side
     const uint64_t maxlen = wave_max_u64(len);
     const uint64_t t_beg = __shfl(beg, 0, 64);
     const uint64_t t_end = wave_max_u64(end);
@@ -131,10 +138,10 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
       uint4* s = reinterpret_cast<uint4*>(stage);
       for (uint64_t i = lane; i * 16 < nbytes; i += 64) s[i] = g[i];
       wave_lds_sync();
-      walk_reads<K, true>(stage + shift + (beg - t_beg), len, maxlen, hmax, sink, kmers, lane);
+      walk_reads<K, true>(stage + shift + (beg - t_beg), (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
       wave_lds_sync();
     } else {
-      walk_reads<K, false>(bases + beg, len, maxlen, hmax, sink, kmers, lane);
+      walk_reads<K, false>(bases + beg, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
     }
   }
   sink.flush(lane);
@@ -222,31 +229,46 @@ __global__ __launch_bounds__(256) void k_take_bottom_n(const uint64_t* __restric
   }
 }
 
-__global__ void k_gather_counts_ge(const uint32_t* counts, uint64_t n, uint32_t ci, uint32_t* flags) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flags[i] = counts[i] >= ci;
-}
-
 static unsigned bit_length(uint64_t v) {
   unsigned b = 0;
   while (v) { ++b; v >>= 1; }
   return b ? b : 1;
 }
 
-// Finalise a sketch from n sorted-unique (hash,count) entries living in scratch.
-static int adopt_runs(mg_sketch* sk, const uint64_t* d_unique, const uint32_t* d_counts, uint64_t runs, uint64_t s) {
-  hipStream_t st = ctx().stream;
+// meta[0] = runs, then: apply the complete-part bound (entries > bound dropped) and the s cut;
+// meta[1] = kept entries, meta[2] = last kept hash, meta[3] = 1 if anything was cut.
+__global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __restrict__ meta, uint64_t s,
+                              uint32_t use_bound, uint64_t bound) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint64_t runs = meta[0];
   uint64_t keep = runs;
-  if (s > 0 && runs > s) { keep = s; sk->truncated = 1; }
-  MG_TRY(sk->hashes.alloc(keep * sizeof(uint64_t)));
-  MG_TRY(sk->counts.alloc(keep * sizeof(uint32_t)));
-  if (keep) {
-    MG_HIP(hipMemcpyAsync(sk->hashes.p, d_unique, keep * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    MG_HIP(hipMemcpyAsync(sk->counts.p, d_counts, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    MG_HIP(hipMemcpyAsync(&sk->last_hash, d_unique + (keep - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
+  uint64_t cut = 0;
+  if (use_bound) {  // upper_bound(unique, bound)
+    uint64_t lo = 0, hi = runs;
+    while (lo < hi) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (unique[mid] <= bound) lo = mid + 1; else hi = mid;
+    }
+    keep = lo;
+    cut = 1;  // a truncated input makes the union a truncated sketch
   }
-  sk->n = keep;
+  if (s > 0 && keep > s) { keep = s; cut = 1; }
+  meta[1] = keep;
+  meta[2] = keep ? unique[keep - 1] : 0;
+  meta[3] = cut;
+}
+
+// Finalise a sketch whose (hash,count) runs were written straight into its own buffers; *d_meta[0] = runs.
+static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_bound, uint64_t bound) {
+  hipStream_t st = ctx().stream;
+  hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), d_meta, s,
+                     (uint32_t)(use_bound ? 1 : 0), bound);
+  uint64_t* pin = host_words();
+  MG_HIP(hipMemcpyAsync(pin + 4, d_meta, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  sk->n = pin[5];
+  sk->last_hash = pin[6];
+  sk->truncated = pin[7] ? 1 : 0;
   return MG_OK;
 }
 
@@ -254,7 +276,8 @@ template <int K>
 static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t hmax,
                                uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, unsigned stage_bytes) {
   Context& c = ctx();
-  const size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
+  size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
+  if (const char* pad = getenv("MG_DEBUG_LDS_PAD")) lds += (size_t)atol(pad);  // occupancy experiments only
   const uint64_t ntiles = (nreads + 63) / 64;
   // enough resident blocks to fill every CU at the LDS-limited occupancy, grid-stride over the rest
   unsigned per_cu = (unsigned)(160 * 1024 / (lds ? lds : 1));
@@ -293,11 +316,11 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
     return MG_OK;
   }
   // total bases -> candidate capacity estimate and LDS tile size
-  uint64_t h_off[2];
-  MG_HIP(hipMemcpyAsync(&h_off[0], d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipMemcpyAsync(&h_off[1], d_offsets + nreads, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  uint64_t* pin = host_words();
+  MG_HIP(hipMemcpyAsync(pin + 0, d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipMemcpyAsync(pin + 1, d_offsets + nreads, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
-  const uint64_t nbases = h_off[1] - h_off[0];
+  const uint64_t nbases = pin[1] - pin[0];
   const double frac = ((double)hmax + 1.0) / 18446744073709551616.0;
   uint64_t cap = (uint64_t)((double)nbases * frac * 1.25) + (1u << 16);
   if (cap > nbases + 64) cap = nbases + 64;
@@ -306,7 +329,7 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   uint64_t stage = ((64 * avg * 9 / 8 + 64 + 15) / 16) * 16;
   if (stage < 2048) stage = 2048;
   if (stage > 14336) stage = 14336;
-  unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 2 * sizeof(unsigned long long));
+  unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return bail(MG_ERR_NOMEM);
   unsigned long long h_counters[2] = {0, 0};
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -319,8 +342,10 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
     });
     if (!ok) return bail(fail(MG_ERR_ARG, "unsupported k=%d", k));
     if (rc) return bail(rc);
-    MG_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipMemcpyAsync(pin + 2, d_counters, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
+    h_counters[0] = pin[2];
+    h_counters[1] = pin[3];
     if (h_counters[0] <= cap) break;
     if (attempt == 1) return bail(fail(MG_ERR_CAPACITY, "candidate list overflow after retry"));
     cap = h_counters[0] + 64;  // exact size is known now; rerun once
@@ -329,21 +354,24 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   sk->kmers_seen = h_counters[1];
   uint64_t* d_cand = (uint64_t*)scratch("sk_cand", cap * sizeof(uint64_t));
   uint64_t* d_sorted = (uint64_t*)scratch("sk_sorted", (ncand + 1) * sizeof(uint64_t));
-  uint64_t* d_unique = (uint64_t*)scratch("sk_unique", (ncand + 1) * sizeof(uint64_t));
-  uint32_t* d_counts = (uint32_t*)scratch("sk_counts", (ncand + 1) * sizeof(uint32_t));
-  if (!d_sorted || !d_unique || !d_counts) return bail(MG_ERR_NOMEM);
-  uint64_t runs = 0;
+  if (!d_sorted) return bail(MG_ERR_NOMEM);
+  // the run-length pass writes straight into the sketch's own (pooled) buffers, sized for the worst case
+  int rc = sk->hashes.alloc((ncand + 1) * sizeof(uint64_t));
+  if (rc) return bail(rc);
+  rc = sk->counts.alloc((ncand + 1) * sizeof(uint32_t));
+  if (rc) return bail(rc);
+  uint64_t* d_meta = reinterpret_cast<uint64_t*>(d_counters) + 4;
   {
     ProfScope ps("sketch_sort");
-    int rc = sort_keys(d_cand, d_sorted, ncand, bit_length(hmax));
+    rc = sort_keys(d_cand, d_sorted, ncand, bit_length(hmax));
     if (rc) return bail(rc);
   }
   {
     ProfScope ps("sketch_rle");
-    int rc = rle_keys(d_sorted, ncand, d_unique, d_counts, &runs);
+    rc = rle_keys(d_sorted, ncand, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), d_meta);
     if (rc) return bail(rc);
   }
-  int rc = adopt_runs(sk, d_unique, d_counts, runs, s);
+  rc = adopt_runs(sk, d_meta, s, false, 0);
   if (rc) return bail(rc);
   *out = sk;
   return MG_OK;
@@ -358,25 +386,17 @@ int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
   auto bail = [&](int rc) { delete sk; return rc; };
   uint64_t* d_ks = (uint64_t*)scratch("mp_keys", (n + 1) * sizeof(uint64_t));
   uint32_t* d_vs = (uint32_t*)scratch("mp_vals", (n + 1) * sizeof(uint32_t));
-  uint64_t* d_unique = (uint64_t*)scratch("sk_unique", (n + 1) * sizeof(uint64_t));
-  uint32_t* d_sums = (uint32_t*)scratch("sk_counts", (n + 1) * sizeof(uint32_t));
-  if (!d_ks || !d_vs || !d_unique || !d_sums) return bail(MG_ERR_NOMEM);
-  uint64_t runs = 0;
-  int rc = sort_pairs(d_hashes, d_ks, d_counts, d_vs, n);
+  uint64_t* d_meta = (uint64_t*)scratch("mp_meta", 4 * sizeof(uint64_t));
+  if (!d_ks || !d_vs || !d_meta) return bail(MG_ERR_NOMEM);
+  int rc = sk->hashes.alloc((n + 1) * sizeof(uint64_t));
   if (rc) return bail(rc);
-  rc = reduce_pairs(d_ks, d_vs, n, d_unique, d_sums, &runs);
+  rc = sk->counts.alloc((n + 1) * sizeof(uint32_t));
   if (rc) return bail(rc);
-  if (any_truncated && runs > 0) {
-    // keep only the complete part of the union: entries <= bound (host-side lower_bound on the device array)
-    std::vector<uint64_t> h(runs);
-    MG_HIP(hipMemcpyAsync(h.data(), d_unique, runs * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
-    MG_HIP(hipStreamSynchronize(ctx().stream));
-    uint64_t keep = 0;
-    while (keep < runs && h[keep] <= bound) ++keep;
-    if (keep < runs) { runs = keep; sk->truncated = 1; }
-    else sk->truncated = 1;
-  }
-  rc = adopt_runs(sk, d_unique, d_sums, runs, s);
+  rc = sort_pairs(d_hashes, d_ks, d_counts, d_vs, n);
+  if (rc) return bail(rc);
+  rc = reduce_pairs(d_ks, d_vs, n, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), d_meta);
+  if (rc) return bail(rc);
+  rc = adopt_runs(sk, d_meta, s, any_truncated != 0, bound);
   if (rc) return bail(rc);
   *out = sk;
   return MG_OK;

@@ -54,30 +54,22 @@ int sort_pairs(const uint64_t* d_kin, uint64_t* d_kout, const uint32_t* d_vin, u
   return MG_OK;
 }
 
-int rle_keys(const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* h_runs) {
-  *h_runs = 0;
-  if (n == 0) return MG_OK;
-  if (n > 0xffffffffull) return fail(MG_ERR_ARG, "candidate list of %llu entries exceeds 2^32-1", (unsigned long long)n);
+int rle_keys(const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* d_runs) {
   hipStream_t st = ctx().stream;
-  uint64_t* d_runs = (uint64_t*)scratch("rle_runs", sizeof(uint64_t));
-  if (!d_runs) return MG_ERR_NOMEM;
+  if (n == 0) { MG_HIP(hipMemsetAsync(d_runs, 0, sizeof(uint64_t), st)); return MG_OK; }
+  if (n > 0xffffffffull) return fail(MG_ERR_ARG, "candidate list of %llu entries exceeds 2^32-1", (unsigned long long)n);
   size_t tmp = 0;
   MG_HIP(rocprim::run_length_encode(nullptr, tmp, d_sorted, (unsigned)n, d_unique, d_counts, d_runs, st));
   void* t = scratch("rle_tmp", tmp);
   if (!t) return MG_ERR_NOMEM;
   MG_HIP(rocprim::run_length_encode(t, tmp, d_sorted, (unsigned)n, d_unique, d_counts, d_runs, st));
-  MG_HIP(hipMemcpyAsync(h_runs, d_runs, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipStreamSynchronize(st));
   return MG_OK;
 }
 
 int reduce_pairs(const uint64_t* d_keys, const uint32_t* d_vals, uint64_t n, uint64_t* d_unique, uint32_t* d_sums,
-                 uint64_t* h_runs) {
-  *h_runs = 0;
-  if (n == 0) return MG_OK;
+                 uint64_t* d_runs) {
   hipStream_t st = ctx().stream;
-  uint64_t* d_runs = (uint64_t*)scratch("rle_runs", sizeof(uint64_t));
-  if (!d_runs) return MG_ERR_NOMEM;
+  if (n == 0) { MG_HIP(hipMemsetAsync(d_runs, 0, sizeof(uint64_t), st)); return MG_OK; }
   size_t tmp = 0;
   MG_HIP(rocprim::reduce_by_key(nullptr, tmp, d_keys, d_vals, (size_t)n, d_unique, d_sums, d_runs, sat_add_u32(),
                                 rocprim::equal_to<uint64_t>(), st));
@@ -85,8 +77,6 @@ int reduce_pairs(const uint64_t* d_keys, const uint32_t* d_vals, uint64_t n, uin
   if (!t) return MG_ERR_NOMEM;
   MG_HIP(rocprim::reduce_by_key(t, tmp, d_keys, d_vals, (size_t)n, d_unique, d_sums, d_runs, sat_add_u32(),
                                 rocprim::equal_to<uint64_t>(), st));
-  MG_HIP(hipMemcpyAsync(h_runs, d_runs, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipStreamSynchronize(st));
   return MG_OK;
 }
 
@@ -118,8 +108,10 @@ int exclusive_sum_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, uint64_t n, 
   void* t = scratch("scan_tmp", tmp);
   if (!t) return MG_ERR_NOMEM;
   MG_HIP(rocprim::exclusive_scan(t, tmp, d_wide, d_out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), st));
-  MG_HIP(hipMemcpyAsync(h_total, d_out + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  uint64_t* pin = host_words();
+  MG_HIP(hipMemcpyAsync(pin + 8, d_out + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
+  *h_total = pin[8];
   return MG_OK;
 }
 

@@ -114,8 +114,10 @@ class HipEngine:
 class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 
-    def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None):
+    def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None, always_exchange=False):
         self.dist, self.rank, self.world = dist, rank, world
+        # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
+        self.exchange = dist is not None and (world > 1 or always_exchange)
         self.k, self.ci, self.pct_id, self.s = k, ci, pct_id, s
         if engine is not None:
             self.engine = engine
@@ -128,16 +130,18 @@ class ShardJob:
             self.engine = HipEngine(hip, tm)
         self.device = getattr(self.engine, "device", "cuda")
 
-    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo):
-        """recs: this rank's shard (starts on a read boundary).  dbh/dbo: the FULL table; sliced here."""
+    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo, ntax=None):
+        """recs: this rank's shard (starts on a read boundary).  dbh/dbo: the FULL table; sliced here.
+        ntax: number of dense taxon ids (default: max(ref2tax) + 1)."""
         G = len(dbo) - 1
-        self.G, self.T = G, len(ref2tax)
+        self.G = G
+        self.T = int(ntax) if ntax is not None else (int(np.max(ref2tax)) + 1 if len(ref2tax) else 0)
         self.g0, self.g1 = genome_shard(G, self.rank, self.world)
         lo, hi = int(dbo[self.g0]), int(dbo[self.g1])
         tails = dbo[1:][dbo[1:] > dbo[:-1]] - 1
         self.hmax = int(dbh[tails.astype(np.int64)].max()) if len(tails) else 0
         has_look = False
-        if self.world > 1:
+        if self.exchange:
             # the first record of the NEXT non-empty shard closes this shard's last read (:225-226)
             t = self.torch
             mine = np.zeros(5, dtype=np.int64)
@@ -161,7 +165,7 @@ class ShardJob:
     # ------------------------------------------------------------------
     def _merged_sketch(self):
         sk = self.engine.sketch_local(self.k, self.hmax, self.s)
-        if self.world == 1:
+        if not self.exchange:
             return sk
         t, dist = self.torch, self.dist
         h, c = self.engine.export_sketch(sk)
@@ -197,7 +201,7 @@ class ShardJob:
         qn = sk.size
         sk.free()
         (m0, m1), ngroups = eng.profile_begin(self.pct_id)
-        if self.world > 1:
+        if self.exchange:
             t, dist = self.torch, self.dist
             word = t.as_tensor([m0, m1, ngroups], dtype=t.int64, device=self.device)
             words = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(self.world)]
@@ -211,7 +215,7 @@ class ShardJob:
             incoming, group_base, first_shard = 1, 0, True
         count, bases, first, scalars, mm = eng.profile_commit(incoming, first_shard, group_base, want_multimapped)
         G, T, W = self.G, self.T, self.world
-        if W > 1:
+        if self.exchange:
             t, dist = self.torch, self.dist
             buf = np.zeros(2 * G + 2 * T + W * T + 2, dtype=np.int64)
             buf[self.g0:self.g1] = hits

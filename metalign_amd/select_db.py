@@ -1,0 +1,206 @@
+#! /usr/bin/env python
+"""Database pre-filter stage (drop-in for /root/reference/scripts/select_db.py).
+
+Same command line, same function names, same files written (subset FASTA, subset db_info, and — when
+not supplied with --cmash_results — temp_dir/cmash_query_results.csv in the CSV layout the reference's
+cutoff logic reads, scripts/select_db.py:80-85).  What changed is how that CSV is produced:
+
+  reference                                              here
+  ---------                                              ----
+  kmc -k60 -ci2 -cs3 over the reads      (:50-52)        mg_sketch_reads_dev   (k_sketch_reads)
+  kmc_tools intersect with DB k-mers     (:54-56)   }    mg_containment_dev    (k_containment)
+  kmc_dump + FASTA rewrite               (:58-65)   }
+  StreamingQueryDNADatabase.py 30-60-10  (:73-76)   }
+  cmash_db_n1000_k60.h5 / .bf / KMC dump (:44,69-70)     data/sketch_table/  (metalign_amd/formats.py)
+
+k values, sketch size and the count threshold come from the sketch table / flags (--ks-free: the table's
+own k list is used; the stock table is n=1000, k in {30,40,50,60}); containment of the LARGEST k is the last
+CSV column, which is the one the cutoff applies to (:85-86).  Parity status of this arithmetic: unpinned by
+the reference (KMC / CMash are not vendored), pinned to oracle/mg_oracle.c bit for bit — see DESIGN.md.
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+from . import _hip, formats
+
+
+def select_parseargs(argv=None):
+    p = argparse.ArgumentParser(description='Run CMash and select a subset of the whole database to align to.')
+    p.add_argument('reads', help='Path to reads file.')
+    p.add_argument('data', help='Path to data/ directory with the files from setup_data.sh')
+    p.add_argument('--cmash_results', default='NONE', help='Give location of CMash query results if already done.')
+    p.add_argument('--cutoff', type=float, default=0.01, help='CMash cutoff value. Default is 0.01.')
+    p.add_argument('--db', default='AUTO', help='Where to write subset database. Default: temp_dir/cmashed_db.fna')
+    p.add_argument('--db_dir', default='AUTO', help='Directory with all organism files in the full database.')
+    p.add_argument('--dbinfo_in', default='AUTO', help='Specify location of db_info file. Default is data/db_info.txt')
+    p.add_argument('--dbinfo_out', default='AUTO',
+                   help='Where to write subset db_info. Default: temp_dir/subset_db_info.txt')
+    p.add_argument('--input_type', default='AUTO', choices=['fastq', 'fasta', 'AUTO'],
+                   help='Type of input file (fastq/fasta). Default: try to auto-determine')
+    p.add_argument('--keep_temp_files', action='store_true', help='Retain KMC files after this script finishes.')
+    p.add_argument('--strain_level', action='store_true',
+                   help='Include all strains above cutoff. Default: 1 strain per species.')
+    p.add_argument('--temp_dir', default='AUTO/', help='Directory to write temporary files to.')
+    p.add_argument('--threads', type=int, default=4, help='How many compute threads for KMC to use. Default: 4')
+    # build-only additions (defaults keep the reference behaviour)
+    p.add_argument('--sketch_table', default='AUTO', help='Genome sketch table directory. Default: data/sketch_table')
+    p.add_argument('--min_count', type=int, default=2, help='k-mer count threshold (kmc -ci). Default: 2')
+    p.add_argument('--sketch_size', type=int, default=0, help='Read sketch size per k; 0 = every hash <= table max.')
+    return p.parse_args(argv)
+
+
+def read_dbinfo(args):
+    """{taxid: [[accessions], length_of_first_row, namelin, taxlin]} (reference :27-40)."""
+    taxid2info = {}
+    with open(args.dbinfo_in, 'r') as fh:
+        fh.readline()
+        for row in fh:
+            f = row.strip().split('\t')
+            entry = taxid2info.get(f[2])
+            if entry is None:
+                taxid2info[f[2]] = [[f[0]], f[1]] + f[3:]
+            else:
+                entry[0].append(f[0])
+    return taxid2info
+
+
+def containment_rows(names, per_k_ci):
+    """CSV rows as the streaming query writes them: organisms with containment > 0 at the smallest k
+    (`-c 0 --sensitive`, :75), sorted by the largest-k column, descending, ties in table order."""
+    first, last = per_k_ci[0], per_k_ci[-1]
+    keep = np.nonzero(first > 0)[0]
+    order = keep[np.argsort(-last[keep], kind='stable')]
+    return [(names[g], [float(ci[g]) for ci in per_k_ci]) for g in order]
+
+
+def write_containment_csv(path, ks, rows):
+    with open(path, 'w') as fh:
+        fh.write(',' + ','.join('k=%d' % k for k in ks) + '\n')
+        for name, vals in rows:
+            fh.write(name + ',' + ','.join(repr(v) for v in vals) + '\n')
+
+
+def run_sketch_steps(args):
+    """Stages A+B on the MI355X: reads -> per-k read sketch -> containment of every genome sketch ->
+    temp_dir/cmash_query_results.csv.  Replaces run_kmc_steps (:43-65) and the CMash call (:69-76)."""
+    hip = _hip.Hip.get()
+    table_dir = getattr(args, 'sketch_table', 'AUTO')
+    if table_dir in (None, 'AUTO'):
+        table_dir = formats.default_table_dir(args.data)
+    table = formats.SketchTable(table_dir)
+    bases, offsets, _ = formats.read_sequences(args.reads, args.input_type)
+    nreads = len(offsets) - 1
+    d_b = hip.array(bases if bases.size else np.zeros(1, np.uint8))
+    d_o = hip.array(offsets)
+    min_count = int(getattr(args, 'min_count', 2))
+    s = int(getattr(args, 'sketch_size', 0))
+    per_k = []
+    for k in table.ks:
+        h, o = table.arrays(k)
+        dev_table = hip.upload_table(np.asarray(h), o)
+        sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, dev_table.max_hash, s)
+        hits, sizes = hip.containment(sk, dev_table, min_count)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ci = np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0)
+        per_k.append(ci)
+        sk.free()
+        dev_table.free()
+    d_b.free()
+    d_o.free()
+    out = args.temp_dir + 'cmash_query_results.csv'
+    write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
+    return out
+
+
+run_kmc_steps = run_sketch_steps  # the reference's name for this step
+
+
+def run_cmash_and_cutoff(args, taxid2info):
+    """CSV -> organisms to align against (reference :68-96; cutoff on the LAST column, first strain per
+    species unless --strain_level, empty species never deduplicated)."""
+    cmash_out = args.temp_dir + 'cmash_query_results.csv' if args.cmash_results == 'NONE' else args.cmash_results
+    chosen, seen_species = [], set()
+    with open(cmash_out, 'r') as fh:
+        fh.readline()
+        for row in fh:
+            f = row.strip().split(',')
+            organism, ci = f[0], float(f[-1])
+            if not ci >= args.cutoff:
+                continue
+            if not args.strain_level:
+                taxid = organism.split('taxid_')[1].split('_genomic.fna')[0].replace('_', '.')
+                species = taxid2info[taxid][3].split('|')[-2]
+                if species in seen_species and species != '':
+                    continue
+                seen_species.add(species)
+            chosen.append(organism)
+    return chosen
+
+
+def make_db_and_dbinfo(args, organisms_to_include, taxid2info):
+    """Concatenate the selected genomes and write the subset db_info (reference :99-117)."""
+    open(args.db, 'w').close()
+    with open(args.db, 'a') as out:
+        for organism in organisms_to_include:
+            subprocess.Popen(['zcat', args.db_dir + organism], stdout=out).wait()
+    with open(args.dbinfo_out, 'w') as out:
+        out.write('Accesion\tLength\tTaxID\tLineage\tTaxID_Lineage\n')  # sic: the reference's header
+        out.write('Unmapped\t0\tUnmapped\t|||||||Unmapped\t|||||||Unmapped\n')
+        for organism in organisms_to_include:
+            taxid = organism.split('taxid_')[1].split('_genomic.fna')[0].replace('_', '.')
+            accs, length, namelin, taxlin = taxid2info[taxid][:4]
+            for acc in accs:
+                out.write('\t'.join([acc, length, taxid, namelin, taxlin]) + '\n')
+
+
+def select_main(args=None):
+    if args is None:
+        args = select_parseargs()
+    elif args.cutoff < 0.0 or args.cutoff > 1.0:
+        print('Error: args.cutoff must be between 0 and 1, inclusive.')
+        sys.exit()
+    if not args.data.endswith('/'):
+        args.data += '/'
+    if args.db_dir == 'AUTO':
+        args.db_dir = args.data + 'organism_files/'
+    if not args.db_dir.endswith('/'):
+        args.db_dir += '/'
+    if args.temp_dir == 'AUTO/':
+        args.temp_dir = tempfile.mkdtemp(prefix=args.data)
+    if not args.temp_dir.endswith('/'):
+        args.temp_dir += '/'
+    if not os.path.exists(args.temp_dir):
+        os.makedirs(args.temp_dir)
+    if args.dbinfo_in == 'AUTO':
+        args.dbinfo_in = args.data + 'db_info.txt'
+    if args.dbinfo_out == 'AUTO':
+        args.dbinfo_out = args.temp_dir + 'subset_db_info.txt'
+    if args.db == 'AUTO':
+        args.db = args.temp_dir + 'cmashed_db.fna'
+    if args.input_type == 'AUTO':
+        parts = args.reads.split('.')
+        if parts[-1] == 'gz':
+            parts = parts[:-1]
+        if parts[-1] in ('fq', 'fastq'):
+            args.input_type = 'fastq'
+        elif parts[-1] in ('fa', 'fna', 'fasta'):
+            args.input_type = 'fasta'
+        else:
+            sys.exit('Could not auto-determine file type. Use --input_type.')
+
+    taxid2info = read_dbinfo(args)
+    if args.cmash_results == 'NONE':
+        run_sketch_steps(args)
+    organisms = run_cmash_and_cutoff(args, taxid2info)
+    make_db_and_dbinfo(args, organisms, taxid2info)
+    # the reference removes its KMC intermediates here (:161-167); this path creates none.
+    # cmash_query_results.csv stays in temp_dir, as it does in the reference.
+
+
+if __name__ == '__main__':
+    select_main(select_parseargs())

@@ -161,7 +161,8 @@ static int collect_hashes(const uint8_t* seq, uint64_t len, int k, uint64_t hmax
     if (run >= (uint64_t)k) {
       uint64_t h = canonical_hash(seq + (j + 1 - (uint64_t)k), k);
       ++*kmers_seen;
-      if (h <= hmax && vec_push(acc, h)) return -1;
+      /* 2^64-1 is reserved (the GPU uses it as the "no k-mer here" marker): never a sketch member */
+      if (h <= hmax && h != UINT64_MAX && vec_push(acc, h)) return -1;
     }
   }
   return 0;

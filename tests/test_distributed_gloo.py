@@ -1,0 +1,182 @@
+"""CPU, world_size 2 over gloo: the sharding choreography of metalign_amd/distributed.py.
+
+The compute calls are served by an ORACLE-backed engine here (test infrastructure); what is under test is
+the exchange logic — sketch all-gather + merge, carried-state composition across shard edges, lookahead
+record, and the single all-reduce — whose result must equal the single-process oracle on the unsharded input."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """Same interface as metalign_amd.distributed.HipEngine, numpy + CPU tensors."""
+    device = "cpu"
+
+    def __init__(self, torch_mod):
+        import oracle
+        self.o = oracle
+        self.torch = torch_mod
+
+    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, dbh, dbo):
+        self.rb, self.ro = rbases, roffsets
+        self.recs, self.has_look = recs, has_lookahead
+        self.ref2tax, self.ntax = ref2tax, ntax
+        self.dbh, self.dbo = dbh, dbo
+
+    class _Sk:
+        def __init__(self, h, c, trunc):
+            self.h, self.c, self.truncated = h, c, trunc
+            self.size = len(h)
+
+        def free(self):
+            pass
+
+    def sketch_local(self, k, hmax, s):
+        h, c, t, _ = self.o.sketch_reads(self.rb, self.ro, k, hmax=hmax, s=s)
+        return self._Sk(h, c, t)
+
+    def export_sketch(self, sk):
+        t = self.torch
+        return t.from_numpy(sk.h.view(np.int64).copy()), t.from_numpy(sk.c.view(np.int32).copy())
+
+    def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound):
+        h = hashes_t.numpy().view(np.uint64)
+        c = counts_t.numpy().view(np.uint32).astype(np.uint64)
+        order = np.argsort(h, kind="stable")
+        h, c = h[order], c[order]
+        uh, start = np.unique(h, return_index=True)
+        uc = np.minimum(np.add.reduceat(c, start), 0xFFFFFFFF).astype(np.uint32) if len(h) else np.zeros(0, np.uint32)
+        trunc = bool(any_truncated)
+        if any_truncated:
+            keep = uh <= np.uint64(bound)
+            uh, uc = uh[keep], uc[keep]
+        if s and len(uh) > s:
+            uh, uc, trunc = uh[:s], uc[:s], True
+        return self._Sk(uh, uc, trunc)
+
+    def containment(self, sk, ci):
+        return self.o.containment(sk.h, sk.c, sk.truncated, ci, self.dbh, self.dbo)
+
+    def profile_begin(self, pct_id):
+        import shard_ref
+        self.pct_id = pct_id
+        self.nrecs = len(self.recs) - (1 if self.has_look else 0)
+        outs = [shard_ref.run_shard(self.recs, self.nrecs, self.has_look, self.ref2tax, self.ntax, pct_id, x, False,
+                                    0)["outgoing"] for x in (0, 1)]
+        ngroups = int(((self.recs["ref_new"][: self.nrecs] >> 31) & 1).sum())
+        return (outs[0], outs[1]), ngroups
+
+    def profile_commit(self, incoming, first_shard, group_base, want_multimapped=True):
+        import shard_ref
+        r = shard_ref.run_shard(self.recs, self.nrecs, self.has_look, self.ref2tax, self.ntax, self.pct_id, incoming,
+                                first_shard, group_base)
+        scal = np.array([r["groups"], r["ambig"]], dtype=np.uint64)
+        return r["count"], r["bases"], r["first_seen"], scal, r["mm"]
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    import util
+    from metalign_amd import distributed as mgd
+    rng = np.random.default_rng(5)
+    gb, go = util.random_genomes(rng, 10, 4000)
+    k, n = 21, 200
+    dbh, dbo = oracle.sketch_genomes(gb, go, k, n)
+    rb, ro, src = util.sample_reads(rng, gb, go, 1200, 100, err=0.01, present=[2, 6])
+    nref, ntax = 30, 9
+    ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
+    nrec = 5000
+    recs = np.zeros(nrec, dtype=oracle.REC_DTYPE)
+    new = rng.random(nrec) < 0.7
+    new[0] = True
+    recs["ref_new"] = rng.integers(1, nref, size=nrec).astype(np.uint32) | (new.astype(np.uint32) << 31)
+    recs["total"] = 100
+    recs["matched"] = rng.integers(30, 101, size=nrec)
+    recs["flag_len"] = rng.choice([0, 16, 256, 272], size=nrec).astype(np.uint32) | (np.where(rng.random(nrec) < 0.8, 100, 0).astype(np.uint32) << 12)
+    # shard: reads split in half; records cut at the read boundary nearest the middle
+    starts = np.nonzero(new)[0]
+    cut = int(starts[len(starts) // 2])
+    rcut = 600
+    my_reads = (rb[: int(ro[rcut])], ro[: rcut + 1]) if rank == 0 else (rb[int(ro[rcut]):], ro[rcut:] - ro[rcut])
+    my_recs = recs[:cut] if rank == 0 else recs[cut:]
+    res = {}
+    for s in (0, 400):
+        job = mgd.ShardJob(None, dist, rank, world, k=k, ci=2, pct_id=0.5, s=s, engine=OracleEngine(torch))
+        job.load(my_reads[0], my_reads[1], my_recs, ref2tax, dbh, dbo, ntax=ntax)
+        out = job.step()
+        # single-process truth
+        qh, qc, tr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()), s=s)
+        hits, sizes = oracle.containment(qh, qc, tr, 2, dbh, dbo)
+        want = oracle.profile_assign(recs, ref2tax, ntax, 0.5)
+        checks = dict(hits=np.array_equal(out["hits"], hits), sizes=np.array_equal(out["sizes"], sizes),
+                      count=np.array_equal(out["count"], want["count"]), bases=np.array_equal(out["bases"], want["bases"]),
+                      first=np.array_equal(out["first_seen"], want["first_seen"]),
+                      tot=out["tot_rds"] == want["tot_rds"], ambig=out["n_ambig"] == want["n_ambig"],
+                      qn=out["sketch_size"] == len(qh))
+        ok = all(checks.values())
+        if not ok:
+            print("rank", rank, "s", s, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
+        res[s] = bool(ok)
+    with open(os.path.join(tmpdir, "rank%d.txt" % rank), "w") as fh:
+        fh.write(repr(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 400: True})
+
+
+def test_shard_reference_equals_c_oracle_unsharded():
+    """The shard-aware Python restatement used by the engine above == the pinned C oracle on whole streams."""
+    import oracle
+    import shard_ref
+    rng = np.random.default_rng(17)
+    for trial in range(4):
+        n, nref, ntax = 3000, 25, 7
+        ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
+        recs = np.zeros(n, dtype=oracle.REC_DTYPE)
+        new = rng.random(n) < (0.5 + 0.1 * trial)
+        new[0] = True
+        recs["ref_new"] = rng.integers(0, nref, size=n).astype(np.uint32) | (new.astype(np.uint32) << 31)
+        recs["total"] = 100
+        recs["matched"] = rng.integers(20, 101, size=n)
+        recs["flag_len"] = rng.choice([0, 16, 256, 2048, 99, 147, 355, 403, 73, 137], size=n).astype(np.uint32) | (
+            np.where(rng.random(n) < 0.7, 100, 0).astype(np.uint32) << 12)
+        want = oracle.profile_assign(recs, ref2tax, ntax, 0.5)
+        got = shard_ref.run_shard(recs, n, False, ref2tax, ntax, 0.5, 1, True, 0)
+        assert np.array_equal(got["count"], want["count"]) and np.array_equal(got["bases"], want["bases"])
+        assert np.array_equal(got["first_seen"], want["first_seen"])
+        assert (got["groups"], got["ambig"]) == (want["tot_rds"], want["n_ambig"])
+        assert [m[0] for m in got["mm"]] == list(want["mm_read"])
+        flat = [t for m in got["mm"] for t in m[1]]
+        assert flat == list(want["mm_tax"]) and [m[2] for m in got["mm"]] == list(want["mm_hitlen"])
+
+
+def test_compose_incoming():
+    from metalign_amd.distributed import compose_incoming
+    ident, const0, const1, flip = (0, 1), (0, 0), (1, 1), (1, 0)
+    assert compose_incoming([ident, ident, ident], 2) == 1
+    assert compose_incoming([const0, ident], 2) == 0
+    assert compose_incoming([const0, flip], 2) == 1
+    assert compose_incoming([const1, const0, ident], 3) == 0
+    assert compose_incoming([flip], 0) == 1

@@ -1,0 +1,118 @@
+"""-m gpu: the kept command line end to end on a synthetic data/ directory.
+
+minimap2 is not on the path being accelerated and is absent from the image; a stub `minimap2` that replays
+a canned SAM stands in for it so that the subprocess plumbing of map_and_profile (scripts/
+map_and_profile.py:413-416) is exercised too."""
+import gzip
+import os
+import stat
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_data_dir(tmp_path, rng, ngen=12, glen=6000):
+    data = tmp_path / "data"
+    org = data / "organism_files"
+    org.mkdir(parents=True)
+    gb, go = util.random_genomes(rng, ngen, glen)
+    rows = ["Accession\tLength\tTaxID\tLineage\tTaxID_Lineage\n"]
+    names, accs = [], []
+    for g in range(ngen):
+        species = 1000 + g // 2  # two strains per species
+        taxid = "%d.%d" % (species, g % 2 + 1)
+        name = "taxid_%s_genomic.fna.gz" % taxid.replace(".", "_")
+        acc = "NZ_G%03d.1" % g
+        seq = bytes(gb[int(go[g]):int(go[g + 1])]).decode()
+        half = len(seq) // 2
+        with gzip.open(str(org / name), "wt") as fh:  # two contigs per genome
+            fh.write(">%s c1\n%s\n>%s_b c2\n%s\n" % (acc, seq[:half], acc, seq[half:]))
+        for a, ln in ((acc, half), (acc + "_b", len(seq) - half)):
+            rows.append("\t".join([a, str(ln), taxid, "Bacteria|P|C|O|F|G%d|G%d s%d|G%d s%d str%d" % (g // 4, g // 4, species, g // 4, species, g % 2),
+                                   "2|10|20|30|40|%d|%d|%s" % (500 + g // 4, species, taxid)]) + "\n")
+        names.append(name)
+        accs.append(acc)
+    (data / "db_info.txt").write_text("".join(rows))
+    return data, gb, go, names, accs
+
+
+def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
+    from metalign_amd import build_db, formats, metalign
+    rng = np.random.default_rng(2024)
+    data, gb, go, names, accs = _make_data_dir(tmp_path, rng)
+    ks, n = [21, 31], 150
+    paths = [str(data / "organism_files" / nm) for nm in names]
+    built = build_db.build(paths, str(data / "sketch_table"), ks, n)
+    # the table equals the oracle's sketch of the same contigs joined by 'N'
+    table = formats.SketchTable(str(data / "sketch_table"))
+    assert table.names == names and table.ks == ks
+    joined, offs = [], [0]
+    for g in range(len(names)):
+        s = gb[int(go[g]):int(go[g + 1])]
+        half = len(s) // 2
+        j = np.concatenate([s[:half], np.frombuffer(b"N", np.uint8), s[half:]])
+        joined.append(j)
+        offs.append(offs[-1] + len(j))
+    jb, jo = np.concatenate(joined), np.asarray(offs, dtype=np.uint64)
+    for k in ks:
+        oh, oo = oracle_lib.sketch_genomes(jb, jo, k, n)
+        h, o = table.arrays(k)
+        assert np.array_equal(np.asarray(h), oh) and np.array_equal(o, oo)
+        assert np.array_equal(built[k][0], oh)
+    # reads from genomes 3 and 8 (strain 1000+1.2 / 1004.1), FASTQ
+    rb, ro, src = util.sample_reads(rng, gb, go, 3000, 150, err=0.005, present=[3, 8])
+    fq = tmp_path / "sample.fq"
+    with open(fq, "w") as fh:
+        for i in range(len(ro) - 1):
+            s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    # canned SAM for the stub aligner: every read hits its source genome's first contig, 20 % also hit the sibling strain
+    sam = tmp_path / "canned.sam"
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\n")
+        for i in range(len(ro) - 1):
+            s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
+            fh.write("\t".join(["r%d" % i, "0", accs[src[i]], "1", "60", "150M", "*", "0", "0", s, "I" * 150, "NM:i:0"]) + "\n")
+            if i % 5 == 0:
+                fh.write("\t".join(["r%d" % i, "256", accs[src[i] ^ 1], "1", "0", "140M10S", "*", "0", "0", "*", "*", "NM:i:4"]) + "\n")
+    stub = tmp_path / "bin"
+    stub.mkdir()
+    exe = stub / "minimap2"
+    exe.write_text("#!/bin/sh\ncat %s\n" % sam)
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(stub) + os.pathsep + os.environ["PATH"])
+    out = tmp_path / "abundances.tsv"
+    tmpd = tmp_path / "tmp"
+    metalign.main([str(fq), str(data), "--output", str(out), "--temp_dir", str(tmpd), "--keep_temp_files",
+                   "--sketch_table", str(data / "sketch_table"), "--sampleID", "s1"])
+    # stage A/B: the CSV equals what the oracle computes for the same reads and table
+    csv = (tmpd / "cmash_query_results.csv").read_text().splitlines()
+    assert csv[0] == ",k=21,k=31"
+    per_k = []
+    for k in ks:
+        h, o = table.arrays(k)
+        qh, qc, tr, _ = oracle_lib.sketch_reads(rb, ro, k, hmax=int(np.asarray(h).max()))
+        hits, sizes = oracle_lib.containment(qh, qc, tr, 2, np.asarray(h), o)
+        per_k.append(hits / np.maximum(sizes, 1))
+    got = {ln.split(",")[0]: [float(x) for x in ln.split(",")[1:]] for ln in csv[1:]}
+    for g, nm in enumerate(names):
+        if per_k[0][g] > 0:
+            assert got[nm] == [float(per_k[0][g]), float(per_k[1][g])]
+        else:
+            assert nm not in got
+    assert csv[1].split(",")[0] in (names[3], names[8])
+    # selection: one strain per species above the 0.01 cutoff -> genomes 3 and 8 (their siblings share k-mers only by chance)
+    sub = (tmpd / "subset_db_info.txt").read_text().splitlines()
+    assert sub[0].startswith("Accesion") and sub[1].startswith("Unmapped")
+    chosen = {ln.split("\t")[2] for ln in sub[2:]}
+    assert {"1001.2", "1004.1"} <= chosen
+    # stage C ran on the stub aligner's SAM against the SUBSET db_info
+    text = out.read_text()
+    assert text.startswith("@SampleID:s1\n@Version:Metalign\n")
+    strains = [ln.split("\t") for ln in text.splitlines() if "\tstrain\t" in ln]
+    assert {s[0] for s in strains} >= {"1001.2.1", "1004.1.1"}
+    assert abs(sum(float(s[4]) for s in strains) - 100.0) < 1.0

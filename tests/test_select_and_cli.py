@@ -1,0 +1,109 @@
+"""CPU: the pre-filter's host logic and the three command lines against the reference's golden vectors."""
+import argparse
+import json
+import os
+
+import pytest
+
+from metalign_amd import map_and_profile, metalign, select_db
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SEL = os.path.join(GOLDEN, "select")
+
+
+def _capture_parser(fn):
+    got = []
+
+    class Stop(Exception):
+        pass
+
+    def fake(self, *a, **k):
+        got.append(self)
+        raise Stop()
+
+    real = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = fake
+    try:
+        try:
+            fn()
+        except Stop:
+            pass
+    finally:
+        argparse.ArgumentParser.parse_args = real
+    return got[0]
+
+
+@pytest.mark.parametrize("name,fn", [("metalign", metalign.metalign_parseargs),
+                                     ("select_db", select_db.select_parseargs),
+                                     ("map_and_profile", map_and_profile.profile_parseargs)])
+def test_cli_flags_match_reference(name, fn):
+    """Every flag of the reference exists with the same default / type / choices / arity; the build's own
+    additions are optional flags only."""
+    with open(os.path.join(GOLDEN, "cli_flags.json")) as fh:
+        want = json.load(fh)[name]
+    parser = _capture_parser(fn)
+    mine = {a.dest: a for a in parser._actions if not isinstance(a, argparse._HelpAction)}
+    for f in want:
+        a = mine.pop(f["dest"])
+        assert list(a.option_strings) == f["options"]
+        assert a.default == f["default"], f["dest"]
+        assert getattr(a.type, "__name__", None) == f["type"]
+        assert (list(a.choices) if a.choices else None) == f["choices"]
+        assert a.nargs == f["nargs"]
+        assert type(a).__name__ == f["action"]
+    for extra in mine.values():
+        assert extra.option_strings, "build-only additions must be optional flags: %s" % extra.dest
+
+
+@pytest.mark.parametrize("case", ["basic", "all_below", "single_k"])
+def test_select_from_cmash_csv_matches_reference(case, tmp_path):
+    with open(os.path.join(SEL, case + ".json")) as fh:
+        runs = json.load(fh)
+    for run in runs:
+        args = argparse.Namespace(reads="reads.fq", data=SEL + "/", cmash_results=os.path.join(SEL, case + ".csv"),
+                                  cutoff=0.01, db=str(tmp_path / "db.fna"), db_dir="AUTO", dbinfo_in="AUTO",
+                                  dbinfo_out=str(tmp_path / "sub.txt"), input_type="AUTO", keep_temp_files=False,
+                                  strain_level=False, temp_dir=str(tmp_path) + "/", threads=1)
+        for k, v in run["args"].items():
+            setattr(args, k, v)
+        select_db.select_main(args)
+        t2i = select_db.read_dbinfo(args)
+        assert select_db.run_cmash_and_cutoff(args, t2i) == run["organisms"]
+        assert open(args.dbinfo_out).read() == run["subset_dbinfo"]
+        assert open(args.db).read() == run["fasta"]
+
+
+def test_cutoff_out_of_range_exits(capsys):
+    args = argparse.Namespace(cutoff=1.5)
+    with pytest.raises(SystemExit):
+        select_db.select_main(args)
+    assert "between 0 and 1" in capsys.readouterr().out
+
+
+def test_containment_csv_layout(tmp_path):
+    import numpy as np
+    names = ["taxid_1_1_genomic.fna.gz", "taxid_2_1_genomic.fna.gz", "taxid_3_1_genomic.fna.gz", "taxid_4_1_genomic.fna.gz"]
+    per_k = [np.array([0.5, 0.0, 0.25, 0.1]), np.array([0.2, 0.0, 0.9, 0.2])]
+    rows = select_db.containment_rows(names, per_k)
+    assert [r[0] for r in rows] == [names[2], names[0], names[3]]  # zero-at-smallest-k dropped; ties keep table order
+    p = tmp_path / "q.csv"
+    select_db.write_containment_csv(str(p), [21, 31], rows)
+    lines = p.read_text().splitlines()
+    assert lines[0] == ",k=21,k=31"
+    assert lines[1] == names[2] + ",0.25,0.9"
+    assert float(lines[2].split(",")[-1]) == 0.2
+
+
+def test_fasta_fastq_readers(tmp_path):
+    import gzip
+
+    from metalign_amd import formats
+    fa = tmp_path / "x.fa"
+    fa.write_text(">a desc\nACGT\nNNac\n>b\n\n>c\nTT\n")
+    b, o, n = formats.read_sequences(str(fa), "fasta")
+    assert n == ["a", "b", "c"] and list(o) == [0, 8, 8, 10] and bytes(b) == b"ACGTNNacTT"
+    fq = tmp_path / "x.fq.gz"
+    with gzip.open(str(fq), "wt") as fh:
+        fh.write("@r1 x\nACG\n+\nIII\n@r2\nTTTT\n+\nIIII\n")
+    b, o, n = formats.read_sequences(str(fq), "fastq")
+    assert n == ["r1", "r2"] and list(o) == [0, 3, 7] and bytes(b) == b"ACGTTTT"
