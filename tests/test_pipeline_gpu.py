@@ -70,7 +70,8 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
         for i in range(len(ro) - 1):
             s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
             fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
-    # canned SAM for the stub aligner: every read hits its source genome's first contig, 20 % also hit the sibling strain
+    # canned SAM for the stub aligner: every read hits its source genome's first contig, 20 % also hit the other
+    # present genome (a real aligner only sees the SUBSET database, so every RNAME is in the subset db_info)
     sam = tmp_path / "canned.sam"
     with open(sam, "w") as fh:
         fh.write("@HD\tVN:1.6\n")
@@ -78,7 +79,7 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
             s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
             fh.write("\t".join(["r%d" % i, "0", accs[src[i]], "1", "60", "150M", "*", "0", "0", s, "I" * 150, "NM:i:0"]) + "\n")
             if i % 5 == 0:
-                fh.write("\t".join(["r%d" % i, "256", accs[src[i] ^ 1], "1", "0", "140M10S", "*", "0", "0", "*", "*", "NM:i:4"]) + "\n")
+                fh.write("\t".join(["r%d" % i, "256", accs[8 if src[i] == 3 else 3], "1", "0", "140M10S", "*", "0", "0", "*", "*", "NM:i:4"]) + "\n")
     stub = tmp_path / "bin"
     stub.mkdir()
     exe = stub / "minimap2"
