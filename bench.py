@@ -83,6 +83,22 @@ def cpu_baseline(args, w):
                       "scalar C oracle, %.1f s" % (n, args.reads, args.genomes, t)}
 
 
+def pmc_traffic(args):
+    """HBM bytes per k_sketch_reads launch from the committed rocprofv3 PMC passes (a benchmark cannot profile
+    itself): profiles/<round>/pmc_traffic.json, newest round whose workload matches this run; else None."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, rnd, "pmc_traffic.json")
+        if os.path.exists(f):
+            with open(f) as fh:
+                d = json.load(fh)
+            wl = d.get("workload", {})
+            if (wl.get("reads"), wl.get("genomes"), wl.get("k")) == (args.reads, args.genomes, args.k):
+                best = d["k_sketch_reads"]["hbm_bytes_per_launch"]
+    return best
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,7 +177,7 @@ def main():
                                    % (args.reads, args.genomes, args.sketch_n, args.k, len(w["recs"])),
                        "parallelism": "reads sharded x%d, sketch table sharded by genome" % world},
             "roofline": {"kernel": "k_sketch_reads<%d>" % args.k, "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                          "avg_launch_ms": k1_avg, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ_K1 * args.reads,
                          "note": "integer-ALU bound (MurmurHash3 per k-mer), see DESIGN.md"},
             "kernel_avg_ms": kernels,
