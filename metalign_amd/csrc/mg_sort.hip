@@ -2,6 +2,7 @@
 // These are plain library operations on small derived lists (sketch candidates,
 // multimapped offsets), delegated to rocPRIM; the hot kernels are hand-written
 // in mg_sketch.hip, mg_contain.hip and mg_profile.hip.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>

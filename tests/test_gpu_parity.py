@@ -166,3 +166,37 @@ def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib):
         want = oracle_lib.profile_assign(recs, ref2tax, ntax, 0.5)
         for key in want:
             assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
+
+
+def test_sketch_two_million_distinct(hip, oracle_lib):
+    """~2.4M distinct hashes at hmax = max (bucket path, thousands of buckets) against the oracle's full sort."""
+    rng = np.random.default_rng(99)
+    gb, go = util.random_genomes(rng, 40, 60000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 20000, 150, err=0.0)
+    oh, oc, _, oseen = oracle_lib.sketch_reads(bases, offsets, 31)
+    h, c, _, seen = hip.sketch_reads(bases, offsets, 31)
+    assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+
+
+def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch):
+    """A k-mer repeated far more often than a bucket slab holds (adapter-like reads) forces the list path;
+    MG_DEBUG_FORCE_LIST exercises the list path on ordinary input.  Same sketch either way."""
+    rng = np.random.default_rng(123)
+    gb, go = util.random_genomes(rng, 8, 30000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 30000, 150, err=0.005)
+    k = 21
+    oh, oc, _, oseen = oracle_lib.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("MG_DEBUG_FORCE_LIST", "1")
+        h, c, _, seen = hip.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
+        assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+    monkeypatch.delenv("MG_DEBUG_FORCE_LIST", raising=False)
+    # 6000 copies of one read: each of its k-mers occurs 6000x > 2048 slab slots
+    rep = np.tile(bases[: 150], 6000)
+    b2 = np.concatenate([bases, rep])
+    o2 = np.concatenate([offsets, offsets[-1] + (np.arange(1, 6001, dtype=np.uint64) * np.uint64(150))])
+    oh, oc, _, oseen = oracle_lib.sketch_reads(b2, o2, k, hmax=int(0.3 * 2**64))
+    h, c, _, seen = hip.sketch_reads(b2, o2, k, hmax=int(0.3 * 2**64))
+    assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+    assert c.max() >= 6000
