@@ -285,7 +285,8 @@ __global__ __launch_bounds__(1024) void k_profile_scan(const uint8_t* __restrict
 // One block: exclusive sums of the per-tile multimapped entry / read totals (in place), grand totals out.
 __global__ __launch_bounds__(1024) void k_profile_scan_mm(uint64_t* __restrict__ tile_ent,
                                                           uint64_t* __restrict__ tile_reads, uint64_t ntiles,
-                                                          uint64_t* __restrict__ out_tot) {
+                                                          uint64_t* __restrict__ out_tot,
+                                                          uint64_t* __restrict__ mm_offsets) {
   __shared__ uint64_t s_a[16];
   __shared__ uint64_t s_b[16];
   const uint64_t per = (ntiles + 1023) / 1024;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_profile_scan_mm(uint64_t* __restrict__
   uint64_t tot_e, tot_r;
   e = blockN_excl_sum<1024>(e, s_a, &tot_e);
   r = blockN_excl_sum<1024>(r, s_b, &tot_r);
-  if (threadIdx.x == 0) { out_tot[2] = tot_e; out_tot[3] = tot_r; }
+  if (threadIdx.x == 0) { out_tot[2] = tot_e; out_tot[3] = tot_r; mm_offsets[tot_r] = tot_e; }
   for (uint64_t b = b0; b < b1; ++b) {
     const uint64_t te = tile_ent[b], tr = tile_reads[b];
     tile_ent[b] = e;
@@ -431,6 +432,8 @@ struct mg_profile {
   DevBuf maps, blk_map, blk_groups, pre_map, pre_groups, tot;
   uint8_t map[2] = {0, 1};
   uint64_t ngroups = 0;
+  bool have_map = false;     // totals of pass A read back (lazily: a single shard never needs them)
+  bool have_mm = false;      // multimapped totals read back (lazily)
   bool committed = false;
   // multimapped CSR (device)
   DevBuf mm_cnt, tile_ent, tile_reads, mm_offsets, mm_tax, mm_hitlen, mm_read;
@@ -477,24 +480,50 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs, int has_looka
                        p->pre_groups.as<uint64_t>(), p->tot.as<uint64_t>());
     MG_HIP(hipGetLastError());
   }
+  *out = p.release();
+  return MG_OK;
+}
+
+// Pass-A totals (composed state map, read count) are fetched on first use.
+static int fetch_map(mg_profile* p) {
+  if (p->have_map || p->nrecs == 0) { p->have_map = true; return MG_OK; }
+  hipStream_t st = ctx().stream;
   uint64_t* h_tot = host_words() + 16;
   MG_HIP(hipMemcpyAsync(h_tot, p->tot.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
   p->map[0] = (uint8_t)(h_tot[0] & 1u);
   p->map[1] = (uint8_t)((h_tot[0] >> 1) & 1u);
   p->ngroups = h_tot[1];
-  *out = p.release();
+  p->have_map = true;
+  return MG_OK;
+}
+
+static int fetch_mm(mg_profile* p) {
+  if (p->have_mm || p->nrecs == 0) { p->have_mm = true; return MG_OK; }
+  hipStream_t st = ctx().stream;
+  uint64_t* h_tot = host_words() + 16;
+  MG_HIP(hipMemcpyAsync(h_tot + 2, p->tot.as<uint64_t>() + 2, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  p->mm_nentries = h_tot[2];
+  p->mm_nreads = h_tot[3];
+  p->have_mm = true;
   return MG_OK;
 }
 
 int mg_profile_state_map(const mg_profile* p, uint8_t map[2]) {
   if (!p || !map) return fail(MG_ERR_ARG, "null argument");
+  MG_REQUIRE_READY();
+  MG_TRY(fetch_map(const_cast<mg_profile*>(p)));
   map[0] = p->map[0];
   map[1] = p->map[1];
   return MG_OK;
 }
 
-uint64_t mg_profile_ngroups(const mg_profile* p) { return p ? p->ngroups : 0; }
+uint64_t mg_profile_ngroups(const mg_profile* p) {
+  if (!p || !ctx().ready) return 0;
+  if (fetch_map(const_cast<mg_profile*>(p)) != MG_OK) return 0;
+  return p->ngroups;
+}
 
 int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base, uint64_t* d_count,
                           uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
@@ -526,22 +555,19 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
                        p->tile_ent.as<uint64_t>(), p->tile_reads.as<uint64_t>(), p->nblocks);
     MG_HIP(hipGetLastError());
   }
+  // multimapped CSR buffers sized by their upper bounds (pooled), so that nothing has to be read back here:
+  // entries <= records, multimapped reads <= records
+  MG_TRY(p->mm_offsets.alloc((p->nrecs + 2) * sizeof(uint64_t)));
+  MG_TRY(p->mm_tax.alloc((p->nrecs + 1) * sizeof(uint32_t)));
+  MG_TRY(p->mm_hitlen.alloc((p->nrecs + 1) * sizeof(uint64_t)));
+  MG_TRY(p->mm_read.alloc((p->nrecs + 1) * sizeof(uint64_t)));
   {
     ProfScope ps("profile_scan_mm");
     hipLaunchKernelGGL(k_profile_scan_mm, dim3(1), dim3(1024), 0, st, p->tile_ent.as<uint64_t>(),
-                       p->tile_reads.as<uint64_t>(), p->nblocks, p->tot.as<uint64_t>());
+                       p->tile_reads.as<uint64_t>(), p->nblocks, p->tot.as<uint64_t>(), p->mm_offsets.as<uint64_t>());
     MG_HIP(hipGetLastError());
   }
-  uint64_t* h_tot = host_words() + 16;
-  MG_HIP(hipMemcpyAsync(h_tot + 2, p->tot.as<uint64_t>() + 2, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipStreamSynchronize(st));
-  p->mm_nentries = h_tot[2];
-  p->mm_nreads = h_tot[3];
-  MG_TRY(p->mm_offsets.alloc((p->mm_nreads + 1) * sizeof(uint64_t)));
-  MG_TRY(p->mm_tax.alloc(p->mm_nentries * sizeof(uint32_t)));
-  MG_TRY(p->mm_hitlen.alloc(p->mm_nreads * sizeof(uint64_t)));
-  MG_TRY(p->mm_read.alloc(p->mm_nreads * sizeof(uint64_t)));
-  if (p->mm_nreads) {
+  {
     ProfScope ps("profile_fill_mm");
     unsigned grid = grid_for(p->nblocks, 1, (unsigned)c.num_cus * 8);
     hipLaunchKernelGGL(k_profile_fill_mm, dim3(grid), dim3(kPB), 0, st, p->d_recs, p->nrecs, p->ntotal, p->d_ref2tax,
@@ -551,14 +577,14 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
                        p->mm_read.as<uint64_t>(), p->nblocks);
     MG_HIP(hipGetLastError());
   }
-  // closing offset; written from the device-side total so that no host buffer has to outlive this call
-  MG_HIP(hipMemcpyAsync(p->mm_offsets.as<uint64_t>() + p->mm_nreads, p->tot.as<uint64_t>() + 2, sizeof(uint64_t),
-                        hipMemcpyDeviceToDevice, st));
   return MG_OK;
 }
 
 int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads, uint64_t* nentries) {
   if (!p) return fail(MG_ERR_ARG, "null profile");
+  MG_REQUIRE_READY();
+  if (!p->committed) return fail(MG_ERR_STATE, "profile shard not committed");
+  MG_TRY(fetch_mm(const_cast<mg_profile*>(p)));
   if (nreads) *nreads = p->mm_nreads;
   if (nentries) *nentries = p->mm_nentries;
   return MG_OK;
@@ -570,6 +596,7 @@ int mg_profile_multimapped(const mg_profile* p, uint64_t* mm_offsets, uint32_t* 
   if (!p) return fail(MG_ERR_ARG, "null profile");
   if (!p->committed) return fail(MG_ERR_STATE, "profile shard not committed");
   if (p->nrecs == 0) { if (mm_offsets) mm_offsets[0] = 0; return MG_OK; }
+  MG_TRY(fetch_mm(const_cast<mg_profile*>(p)));
   MG_TRY(mg_memcpy_d2h(mm_offsets, p->mm_offsets.p, (p->mm_nreads + 1) * sizeof(uint64_t)));
   MG_TRY(mg_memcpy_d2h(mm_tax, p->mm_tax.p, p->mm_nentries * sizeof(uint32_t)));
   MG_TRY(mg_memcpy_d2h(mm_hitlen, p->mm_hitlen.p, p->mm_nreads * sizeof(uint64_t)));
@@ -607,6 +634,7 @@ int mg_profile_assign(const mg_aln_rec* recs, uint64_t nrecs, const uint32_t* re
   MG_TRY(mg_memcpy_d2h(sc, acc + 3 * (uint64_t)ntax, sizeof(sc)));
   *out_tot_rds = sc[0];
   *out_n_ambig = sc[1];
+  MG_TRY(fetch_mm(p));
   *mm_nreads = p->mm_nreads;
   *mm_nentries = p->mm_nentries;
   if (p->mm_nreads > mm_cap_reads || p->mm_nentries > mm_cap_entries)

@@ -5,17 +5,19 @@
 // buffer) are copied HBM -> LDS with 16-byte coalesced loads, then every lane
 // rolls its own read out of LDS (mg_kmer.h) and hashes one canonical k-mer per
 // base.  Hashes <= hmax are compacted per wavefront (ballot + popcount) into an
-// LDS candidate buffer.  Hashes are uniform, so a flush scatters its candidates
-// into equal-width HASH-RANGE BUCKETS in HBM (one slab of kBucketCap slots per
-// bucket, slot claimed with an atomic): concatenating the buckets in order is a
-// globally sorted list once every bucket is sorted.  `k_bucket_sort` then sorts
-// each bucket in LDS (bitonic network on <= 2048 keys), run-length encodes it in
-// place, and `k_bucket_scan` / `k_bucket_compact` pack the distinct hashes and
-// counts into the sketch.  No global radix sort: ~0.03 ms instead of 8 onesweep
-// passes (~0.3 ms) at 2.6 M candidates.  A bucket that overflows its slab (a
-// k-mer repeated thousands of times, e.g. adapters) or a tiny candidate set
-// falls back to the list path: flat candidate list + rocPRIM sort / run-length
-// (mg_sort.hip).
+// LDS candidate buffer.  A flush inserts its candidates into a COUNTING HASH
+// TABLE in HBM that is partitioned by hash range: bucket = leading bits of the
+// hash, kBucketSlots open-addressed slots per bucket (atomicCAS to claim a slot,
+// atomicAdd on its counter) — the GPU analogue of what KMC does on disk.  The
+// table therefore holds each DISTINCT hash once, whatever the coverage, and
+// because hashes are uniform every bucket holds ~the same number of distinct
+// hashes.  `k_bucket_sort` (one wavefront per bucket) compacts a bucket into
+// LDS, sorts its (hash,count) pairs with a bitonic network and writes them
+// out; buckets are hash ranges, so their concatenation (`k_bucket_scan` +
+// `k_bucket_compact`) is the ascending sketch.  No global radix sort: ~0.05 ms
+// instead of 8 onesweep passes (~0.3 ms) at 2.6 M candidates.  Inputs whose
+// distinct count defeats the table sizing, and tiny candidate sets, take the
+// list path: flat candidate list + rocPRIM sort / run-length (mg_sort.hip).
 //
 // Replaces: kmc -k60 -ci2 -cs3 (scripts/select_db.py:50-52) + k-mer hashing in
 // CMash's streaming query (scripts/select_db.py:73-76).
@@ -53,16 +55,17 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
-constexpr uint32_t kBucketCap = 2048;  // slab slots per bucket == LDS sort width
+constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
+constexpr uint32_t kBucketTarget = 96;  // expected distinct hashes per bucket (load factor <= 3/8)
 
-// Wave-level candidate sink: LDS staging, then either one reservation in the flat list (list mode) or one
-// slot claim per candidate in its hash-range bucket (bucket mode, shift < 64).
+// Wave-level candidate sink: LDS staging, then either one reservation in the flat list (list mode) or an
+// insert-or-increment per candidate in the partitioned counting table (table mode, shift < 64).
 struct CandSink {
   uint64_t* lds;      // this wave's kCandBuf entries
-  uint64_t* out;      // list mode: candidate list; bucket mode: slabs [nbuckets][kBucketCap]
+  uint64_t* out;      // list mode: candidate list; table mode: keys [nbuckets][kBucketSlots], 0 = empty, else hash+1
   uint64_t cap;       // list mode: entries available in `out`
-  unsigned long long* counters;  // [0] candidates produced, [1] k-mers hashed, [2] bucket overflows
-  uint32_t* bucket_cnt;          // bucket mode: claimed slots per bucket
+  unsigned long long* counters;  // [0] candidates produced, [1] k-mers hashed, [2] table overflows
+  uint32_t* slot_cnt;            // table mode: occurrence count per slot
   unsigned shift;                // bucket = hash >> shift; 64 = list mode
   int n;              // entries staged (wave-uniform)
 
@@ -79,9 +82,16 @@ struct CandSink {
       uint32_t lost = 0;
       for (int i = lane; i < n; i += 64) {
         const uint64_t h = lds[i];
-        const uint64_t b = h >> shift;
-        const uint32_t slot = atomicAdd(&bucket_cnt[b], 1u);
-        if (slot < kBucketCap) out[b * kBucketCap + slot] = h; else ++lost;
+        const unsigned long long v = h + 1;  // hashes are <= 2^64-2, so v is never the empty marker 0
+        const uint64_t base = (h >> shift) * kBucketSlots;
+        uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
+        uint32_t t = 0;
+        for (; t < kBucketSlots; ++t) {
+          const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(out + base + p), 0ull, v);
+          if (old == 0ull || old == v) { atomicAdd(slot_cnt + base + p, 1u); break; }
+          p = (p + 1) & (kBucketSlots - 1);
+        }
+        if (t == kBucketSlots) ++lost;
       }
       if (lane == 0) atomicAdd(counters, (unsigned long long)n);
       if (lost) atomicAdd(counters + 2, (unsigned long long)lost);
@@ -136,13 +146,13 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
                                                          const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                          uint64_t hmax, uint64_t* __restrict__ cand, uint64_t cand_cap,
                                                          unsigned long long* __restrict__ counters,
-                                                         uint32_t* __restrict__ bucket_cnt, unsigned bucket_shift,
+                                                         uint32_t* __restrict__ slot_cnt, unsigned bucket_shift,
                                                          unsigned stage_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
-  CandSink sink{cbuf, cand, cand_cap, counters, bucket_cnt, bucket_shift, 0};
+  CandSink sink{cbuf, cand, cand_cap, counters, slot_cnt, bucket_shift, 0};
   uint64_t kmers = 0;
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -262,74 +272,58 @@ static unsigned bit_length(uint64_t v) {
   return b ? b : 1;
 }
 
-// One workgroup per bucket: sort the bucket's slab in LDS (bitonic, width = next power of two >= n), then
-// run-length encode it in place: slab[b][r] = r-th distinct hash, cnts[b][r] = its multiplicity,
-// nuniq[b] = number of distinct hashes.
-__global__ __launch_bounds__(256) void k_bucket_sort(uint64_t* __restrict__ slab, const uint32_t* __restrict__ bucket_cnt,
-                                                     uint64_t nbuckets, uint32_t* __restrict__ cnts,
+// One WAVEFRONT per bucket (no workgroup barriers: buckets are independent, four in flight per workgroup):
+// compact the bucket's occupied slots into the wave's LDS region, sort the (hash,count) pairs by hash with a
+// bitonic network (width = next power of two >= n, wave-synchronous steps) and write them to the bucket's
+// staging rows: stage_h[b][r], stage_c[b][r], r < nuniq[b].  Every hash of the bucket is distinct already.
+__global__ __launch_bounds__(256) void k_bucket_sort(const uint64_t* __restrict__ tab_keys,
+                                                     const uint32_t* __restrict__ tab_cnt, uint64_t nbuckets,
+                                                     uint64_t* __restrict__ stage_h, uint32_t* __restrict__ stage_c,
                                                      uint32_t* __restrict__ nuniq) {
-  __shared__ uint64_t keys[kBucketCap];
-  __shared__ uint32_t pos[kBucketCap + 1];
-  __shared__ uint32_t wave_tot[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (uint64_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-    uint32_t n = bucket_cnt[b];
-    if (n > kBucketCap) n = kBucketCap;
-    if (n == 0) {
-      if (tid == 0) nuniq[b] = 0;
-      continue;
+  __shared__ uint64_t s_keys[4][kBucketSlots];
+  __shared__ uint32_t s_cnt[4][kBucketSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t* keys = s_keys[wave];
+  uint32_t* cnt = s_cnt[wave];
+  const uint64_t gwave = (uint64_t)blockIdx.x * 4 + wave, nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t b = gwave; b < nbuckets; b += nwaves) {
+    const uint64_t base = b * kBucketSlots;
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t c0 = 0; c0 < kBucketSlots; c0 += 64) {
+      const uint64_t v = tab_keys[base + c0 + lane];
+      const unsigned long long m = __ballot(v != 0);
+      if (v != 0) {
+        const uint32_t d = n + __popcll(m & ((1ull << lane) - 1ull));
+        keys[d] = v - 1;
+        cnt[d] = tab_cnt[base + c0 + lane];
+      }
+      n += __popcll(m);
     }
-    uint32_t N = 256;
+    if (lane == 0) nuniq[b] = n;
+    if (n == 0) continue;
+    uint32_t N = 64;
     while (N < n) N <<= 1;
-    uint64_t* src = slab + b * kBucketCap;
-    for (uint32_t i = tid; i < N; i += 256) keys[i] = i < n ? src[i] : kReservedHash;
-    __syncthreads();
+    for (uint32_t i = n + lane; i < N; i += 64) keys[i] = kReservedHash;
+    wave_lds_sync();
     for (uint32_t k = 2; k <= N; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t t = tid; t < N / 2; t += 256) {
+        for (uint32_t t = lane; t < N / 2; t += 64) {
           const uint32_t ix = ((t & ~(j - 1)) << 1) | (t & (j - 1));
           const uint32_t px = ix | j;
           const uint64_t x = keys[ix], y = keys[px];
           const bool up = (ix & k) == 0;
-          if ((x > y) == up) { keys[ix] = y; keys[px] = x; }
+          if ((x > y) == up) {
+            keys[ix] = y; keys[px] = x;
+            const uint32_t cx = cnt[ix], cy = cnt[px];
+            cnt[ix] = cy; cnt[px] = cx;
+          }
         }
-        __syncthreads();
+        wave_lds_sync();
       }
     }
-    // heads of runs among the first n sorted keys; each thread owns N/256 consecutive positions
-    const uint32_t per = N / 256, i0 = tid * per;
-    uint32_t mine = 0;
-    for (uint32_t q = 0; q < per; ++q) {
-      const uint32_t i = i0 + q;
-      mine += (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
-    }
-    uint32_t inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t prev = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += prev;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) before += wave_tot[w];
-      total += wave_tot[w];
-    }
-    uint32_t r = before + inc - mine;
-    for (uint32_t q = 0; q < per; ++q) {
-      const uint32_t i = i0 + q;
-      if (i < n && (i == 0 || keys[i] != keys[i - 1])) pos[r++] = i;
-    }
-    if (tid == 0) { pos[total] = n; nuniq[b] = total; }
-    __syncthreads();
-    uint32_t* cdst = cnts + b * kBucketCap;
-    for (uint32_t q = tid; q < total; q += 256) {
-      src[q] = keys[pos[q]];
-      cdst[q] = pos[q + 1] - pos[q];
-    }
-    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) { stage_h[base + i] = keys[i]; stage_c[base + i] = cnt[i]; }
+    wave_lds_sync();
   }
 }
 
@@ -374,8 +368,8 @@ __global__ __launch_bounds__(256) void k_bucket_compact(const uint64_t* __restri
     const uint32_t n = nuniq[b];
     const uint64_t o = offs[b];
     for (uint32_t i = lane; i < n && o + i < out_cap; i += 64) {  // out_cap: see the size check on the host
-      out_hashes[o + i] = slab[b * kBucketCap + i];
-      out_counts[o + i] = cnts[b * kBucketCap + i];
+      out_hashes[o + i] = slab[b * kBucketSlots + i];
+      out_counts[o + i] = cnts[b * kBucketSlots + i];
     }
   }
 }
@@ -423,7 +417,7 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
 
 template <int K>
 static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t hmax,
-                               uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, uint32_t* d_bucket_cnt,
+                               uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, uint32_t* d_slot_cnt,
                                unsigned bucket_shift, unsigned stage_bytes) {
   Context& c = ctx();
   size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
@@ -436,7 +430,7 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
-                     nreads, hmax, d_cand, cap, d_counters, d_bucket_cnt, bucket_shift, stage_bytes);
+                     nreads, hmax, d_cand, cap, d_counters, d_slot_cnt, bucket_shift, stage_bytes);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -533,53 +527,72 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   if (!d_counters) return MG_ERR_NOMEM;
   uint64_t* d_meta = reinterpret_cast<uint64_t*>(d_counters) + 4;
 
-  // ---- bucket path: hash-range buckets of <= ~768 expected candidates, slab of kBucketCap slots each ----
+  // ---- table path: counting hash table partitioned into hash-range buckets ----
+  // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
+  // previous call (x2 for safety) tightens it for steady-state batches.  Under-sizing is detected (a bucket
+  // with no free slot) and handled by the list path.
+  static double distinct_hint = 1.0;
   const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
   const unsigned bits = bit_length(hmax);
+  double distinct_est = (double)expect * distinct_hint;
+  if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) distinct_est = (double)expect * atof(e);  // tests: force overflow
+  if (distinct_est < 4096.0) distinct_est = 4096.0;
   unsigned shift = bits;  // one bucket
-  while (shift > 0 && (double)expect / (double)((hmax >> shift) + 1) > 768.0) --shift;
+  while (shift > 0 && distinct_est / (double)((hmax >> shift) + 1) > (double)kBucketTarget) --shift;
   const uint64_t nbuckets = (hmax >> shift) + 1;
-  if (!force_list && expect >= 32768 && shift < 64 && nbuckets <= (1ull << 26)) {
-    uint64_t* d_slab = (uint64_t*)scratch("sk_slab", nbuckets * kBucketCap * sizeof(uint64_t));
-    uint32_t* d_cnts = (uint32_t*)scratch("sk_slab_cnt", nbuckets * kBucketCap * sizeof(uint32_t));
-    uint32_t* d_bcnt = (uint32_t*)scratch("sk_bucket_cnt", 2 * nbuckets * sizeof(uint32_t));
+  if (!force_list && expect >= 32768 && shift < 64 && nbuckets <= (1ull << 27)) {
+    const uint64_t slots = nbuckets * kBucketSlots;
+    // [keys u64 x slots | counts u32 x slots] zeroed in one memset; staging rows are written sparsely
+    uint8_t* d_tab = (uint8_t*)scratch("sk_table", slots * 12);
+    uint64_t* d_stage_h = (uint64_t*)scratch("sk_stage_h", slots * sizeof(uint64_t));
+    uint32_t* d_stage_c = (uint32_t*)scratch("sk_stage_c", slots * sizeof(uint32_t));
+    uint32_t* d_nuniq = (uint32_t*)scratch("sk_bucket_n", nbuckets * sizeof(uint32_t));
     uint64_t* d_offs = (uint64_t*)scratch("sk_bucket_off", (nbuckets + 1) * sizeof(uint64_t));
-    if (!d_slab || !d_cnts || !d_bcnt || !d_offs) return MG_ERR_NOMEM;
-    uint32_t* d_nuniq = d_bcnt + nbuckets;
+    if (!d_tab || !d_stage_h || !d_stage_c || !d_nuniq || !d_offs) return MG_ERR_NOMEM;
+    uint64_t* d_keys = reinterpret_cast<uint64_t*>(d_tab);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(d_tab + slots * 8);
     MG_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), st));
-    MG_HIP(hipMemsetAsync(d_bcnt, 0, nbuckets * sizeof(uint32_t), st));
+    {
+      ProfScope ps("table_clear");
+      MG_HIP(hipMemsetAsync(d_tab, 0, slots * 12, st));
+    }
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, d_slab, 0, d_counters, d_bcnt, shift, (unsigned)stage);
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, d_keys, 0, d_counters, d_cnt, shift, (unsigned)stage);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
     {
       ProfScope ps("bucket_sort");
-      hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(nbuckets, 1, (unsigned)c.num_cus * 6)), dim3(256), 0, st, d_slab,
-                         d_bcnt, nbuckets, d_cnts, d_nuniq);
+      hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_keys,
+                         d_cnt, nbuckets, d_stage_h, d_stage_c, d_nuniq);
       MG_HIP(hipGetLastError());
     }
-    // distinct hashes <= claimed slots <= expected candidates in the common case; size for the worst case
-    const uint64_t worst = nbuckets * kBucketCap < cap * 4 ? nbuckets * kBucketCap : cap * 4;
+    // the sketch cannot hold more entries than the table has slots
+    const uint64_t worst = slots;
     MG_TRY(sk->hashes.alloc((worst + 1) * sizeof(uint64_t)));
     MG_TRY(sk->counts.alloc((worst + 1) * sizeof(uint32_t)));
     {
       ProfScope ps("bucket_pack");
       hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, d_nuniq, nbuckets, d_offs, d_meta);
-      hipLaunchKernelGGL(k_bucket_compact, dim3(grid_for(nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_slab,
-                         d_cnts, d_nuniq, d_offs, nbuckets, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), worst);
+      hipLaunchKernelGGL(k_bucket_compact, dim3(grid_for(nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+                         d_stage_h, d_stage_c, d_nuniq, d_offs, nbuckets, sk->hashes.as<uint64_t>(),
+                         sk->counts.as<uint32_t>(), worst);
       MG_HIP(hipGetLastError());
     }
     uint64_t h_counters[3] = {0, 0, 0};
     MG_TRY(adopt_runs(sk.get(), d_meta, s, false, 0, d_counters, h_counters));
     sk->kmers_seen = h_counters[1];
     const uint64_t runs = host_words()[4];  // total distinct hashes found (meta[0])
-    if (h_counters[2] == 0 && runs <= worst) {
+    if (h_counters[2] == 0) {
+      double r = 2.0 * (double)runs / (double)(expect ? expect : 1);
+      distinct_hint = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
       *out = sk.release();
       return MG_OK;
     }
-    // a bucket overflowed its slab (heavily repeated k-mer): redo on the list path, which has no such limit
+    // a bucket ran out of slots (more distinct hashes than the hint allowed for): size for the worst case next
+    // time and redo this call on the list path, which has no such limit
+    distinct_hint = 1.0;
     sk.reset(new mg_sketch());
     if (h_counters[0] + 64 > cap) cap = h_counters[0] + 64;
   }

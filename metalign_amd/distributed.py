@@ -62,8 +62,7 @@ class HipEngine:
         self.nref, self.ntax = len(ref2tax), ntax
         self.table = hip.upload_table(dbh, dbo)
         self.ngen_local = len(dbo) - 1
-        self.d_hits = hip.empty(max(self.ngen_local, 1), np.uint32)
-        self.d_sizes = hip.empty(max(self.ngen_local, 1), np.uint32)
+        self.d_hs = hip.empty(2 * max(self.ngen_local, 1), np.uint32)  # [hits | sizes]: one read-back
         # [count T | bases T | first_seen T | scalars 2]
         self.d_acc = hip.empty(3 * ntax + 2, np.uint64)
 
@@ -87,13 +86,19 @@ class HipEngine:
 
     # ---- stage B ----
     def containment(self, sk, ci):
-        self.hip.containment_dev(sk, self.table, ci, self.d_hits.ptr, self.d_sizes.ptr)
-        return self.d_hits.download()[: self.ngen_local], self.d_sizes.download()[: self.ngen_local]
+        g = max(self.ngen_local, 1)
+        self.hip.containment_dev(sk, self.table, ci, self.d_hs.ptr, self.d_hs.ptr + 4 * g)
+        hs = self.d_hs.download()
+        return hs[: self.ngen_local], hs[g: g + self.ngen_local]
 
     # ---- stage C ----
-    def profile_begin(self, pct_id):
+    def profile_begin(self, pct_id, need_map=True):
+        """Pass A of stage C.  The composed state map / read count are only read back (one stream sync) when a
+        neighbouring shard needs them."""
         self.shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
                                                 self.nref, self.ntax, pct_id)
+        if not need_map:
+            return (0, 1), 0
         return self.shard.state_map(), self.shard.ngroups
 
     def profile_commit(self, incoming, first_shard, group_base, want_multimapped=True):
@@ -200,7 +205,7 @@ class ShardJob:
         hits, sizes = eng.containment(sk, self.ci)
         qn = sk.size
         sk.free()
-        (m0, m1), ngroups = eng.profile_begin(self.pct_id)
+        (m0, m1), ngroups = eng.profile_begin(self.pct_id, self.exchange)
         if self.exchange:
             t, dist = self.torch, self.dist
             word = t.as_tensor([m0, m1, ngroups], dtype=t.int64, device=self.device)

@@ -61,7 +61,7 @@ class OracleEngine:
     def containment(self, sk, ci):
         return self.o.containment(sk.h, sk.c, sk.truncated, ci, self.dbh, self.dbo)
 
-    def profile_begin(self, pct_id):
+    def profile_begin(self, pct_id, need_map=True):
         import shard_ref
         self.pct_id = pct_id
         self.nrecs = len(self.recs) - (1 if self.has_look else 0)

@@ -192,7 +192,12 @@ def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch):
         h, c, _, seen = hip.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
         assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
     monkeypatch.delenv("MG_DEBUG_FORCE_LIST", raising=False)
-    # 6000 copies of one read: each of its k-mers occurs 6000x > 2048 slab slots
+    # an undersized table (distinct-count hint far too low) must be detected and redone on the list path
+    monkeypatch.setenv("MG_DEBUG_DISTINCT_HINT", "0.0005")
+    h, c, _, seen = hip.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
+    assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+    monkeypatch.delenv("MG_DEBUG_DISTINCT_HINT", raising=False)
+    # 6000 copies of one read: each of its k-mers occurs 6000x (one table slot, count 6000+)
     rep = np.tile(bases[: 150], 6000)
     b2 = np.concatenate([bases, rep])
     o2 = np.concatenate([offsets, offsets[-1] + (np.arange(1, 6001, dtype=np.uint64) * np.uint64(150))])
