@@ -87,6 +87,8 @@ int mg_sync(void);
 /* Per-kernel timing with HIP events on the library stream (bench.py's
  * roofline leg).  Names are the kernel family names listed in DESIGN.md. */
 int mg_prof_enable(int on);
+/* Restrict timing to one kernel family ("" = all); reset by mg_prof_enable. */
+int mg_prof_only(const char* kernel);
 int mg_prof_reset(void);
 /* Returns number of launches and their summed device time in milliseconds. */
 int mg_prof_get(const char* kernel, uint64_t* launches, double* total_ms);

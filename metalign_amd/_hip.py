@@ -25,7 +25,7 @@ MAX_K = 64
 EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
-    "mg_prof_enable", "mg_prof_reset", "mg_prof_get",
+    "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_size", "mg_sketch_truncated",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
@@ -271,6 +271,9 @@ class Hip:
 
     def prof_enable(self, on=True):
         self._chk(self.lib.mg_prof_enable(ctypes.c_int(1 if on else 0)))
+
+    def prof_only(self, kernel=""):
+        self._chk(self.lib.mg_prof_only(kernel.encode()))
 
     def prof_reset(self):
         self._chk(self.lib.mg_prof_reset())

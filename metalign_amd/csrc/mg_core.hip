@@ -100,6 +100,7 @@ static hipEvent_t prof_event() {
 }
 
 ProfScope::ProfScope(const char* n) : name(n), on(ctx().prof_on) {
+  if (on && ctx().prof_only[0] && strcmp(ctx().prof_only, n) != 0) on = false;
   if (!on) return;
   a = prof_event();
   b = prof_event();
@@ -242,6 +243,13 @@ int mg_sync(void) {
 int mg_prof_enable(int on) {
   MG_REQUIRE_READY();
   ctx().prof_on = on != 0;
+  ctx().prof_only[0] = 0;
+  return MG_OK;
+}
+
+int mg_prof_only(const char* kernel) {
+  MG_REQUIRE_READY();
+  snprintf(ctx().prof_only, sizeof(ctx().prof_only), "%s", kernel ? kernel : "");
   return MG_OK;
 }
 

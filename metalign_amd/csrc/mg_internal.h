@@ -30,6 +30,7 @@ struct Context {
   int num_cus = 256;
   // profiling
   bool prof_on = false;
+  char prof_only[32] = "";  // when set, only this kernel family is timed (keeps the timed region light)
   std::map<std::string, ProfEntry> prof;
   struct Pending { std::string name; hipEvent_t a, b; };
   std::vector<Pending> prof_pending;   // recorded, not yet read (no sync inside the timed region)

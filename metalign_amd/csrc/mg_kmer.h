@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 
 namespace mg {
 
@@ -98,22 +99,33 @@ struct Roller {
   __device__ __forceinline__ uint64_t hash() const {
     const bool fw = forward_is_canonical();
     uint32_t w[ND + 4];
+    if constexpr (ND <= 8) {
 #pragma unroll
-    for (int j = 0; j < ND; ++j) w[j] = fw ? f[j] : r[j];
+      for (int j = 0; j < ND; ++j) w[j] = fw ? f[j] : r[j];
+    } else {
+      // For longer windows the optimiser turns the element-wise select into "select the ARRAY, then load",
+      // which forces f[] and r[] into scratch memory; a bit-field blend (v_bfi_b32) keeps them in registers.
+      const uint32_t m = fw ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) w[j] = (f[j] & m) | (r[j] & ~m);
+    }
 #pragma unroll
     for (int j = ND; j < ND + 4; ++j) w[j] = 0;
     constexpr uint64_t C1 = 0x87c37b91114253d5ULL, C2 = 0x4cf5ad432745937fULL;
     constexpr int NBLK = K / 16, TAIL = K & 15;
     uint64_t h1 = 0, h2 = 0;
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-      uint64_t k1 = (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32);
-      uint64_t k2 = (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32);
+    // 16-byte body blocks, expanded with compile-time indices (a `for` over NBLK >= 2 is unrolled too late
+    // for the register promotion of w[], f[] and r[]: they would live in scratch memory)
+    auto body = [&]<int B>() {
+      uint64_t k1 = (uint64_t)w[4 * B] | ((uint64_t)w[4 * B + 1] << 32);
+      uint64_t k2 = (uint64_t)w[4 * B + 2] | ((uint64_t)w[4 * B + 3] << 32);
       k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
       h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
       k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
       h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
-    }
+    };
+    [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(
+        std::make_integer_sequence<int, NBLK>{});
     if constexpr (TAIL > 8) {
       uint64_t k2 = (uint64_t)w[4 * NBLK + 2] | ((uint64_t)w[4 * NBLK + 3] << 32);
       k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
