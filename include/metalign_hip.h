@@ -120,6 +120,15 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
 int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
                              uint64_t n, uint64_t s, int any_truncated,
                              uint64_t bound, mg_sketch** out);
+/* Positions at which an ascending sketch crosses `nbounds` hash values: out_idx[i] = number of
+ * entries with hash < bounds[i].  Used to cut a sketch into hash-range slices for the multi-GPU
+ * exchange (rank r owns hashes in [bounds[r-1], bounds[r])). */
+int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbounds,
+                    uint64_t* out_idx);
+/* Overrides the completeness bound mg_containment_dev uses for this sketch (a hash-range slice of a
+ * truncated sample sketch is complete up to the SAMPLE's last hash, not its own): hashes above
+ * `bound` are outside the sketch when `truncated` != 0. */
+int mg_sketch_set_bound(mg_sketch* sk, int truncated, uint64_t bound);
 uint64_t mg_sketch_size(const mg_sketch* sk);
 int mg_sketch_truncated(const mg_sketch* sk);
 uint64_t mg_sketch_kmers_seen(const mg_sketch* sk); /* valid k-mer windows hashed */

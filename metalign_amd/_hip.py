@@ -26,7 +26,7 @@ EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_size", "mg_sketch_truncated",
+    "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
@@ -126,6 +126,19 @@ class Sketch:
     @property
     def kmers_seen(self):
         return int(self.hip.lib.mg_sketch_kmers_seen(self.handle))
+
+    def split(self, bounds):
+        """Number of entries below each hash bound (ascending python ints)."""
+        b = np.asarray([int(x) for x in bounds], dtype=np.uint64)
+        out = np.zeros(len(b), dtype=np.uint64)
+        if len(b):
+            self.hip._chk(self.hip.lib.mg_sketch_split(self.handle, _np(b, ctypes.c_uint64), ctypes.c_uint32(len(b)),
+                                                       _np(out, ctypes.c_uint64)))
+        return [int(x) for x in out]
+
+    def set_bound(self, truncated, bound):
+        self.hip._chk(self.hip.lib.mg_sketch_set_bound(self.handle, ctypes.c_int(int(truncated)),
+                                                       ctypes.c_uint64(int(bound))))
 
     def device_ptrs(self):
         h, c = _vp(), _vp()

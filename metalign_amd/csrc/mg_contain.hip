@@ -122,7 +122,8 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   if (db->ngenomes == 0) return MG_OK;
   mg_sketch* sk = const_cast<mg_sketch*>(q);  // the look-up index is a cache inside the handle
   MG_TRY(ensure_index(sk));
-  const uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
+  uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
+  if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
   Context& c = ctx();
   ProfScope ps("containment");
   unsigned grid = grid_for(db->ngenomes, 4, (unsigned)c.num_cus * 8);

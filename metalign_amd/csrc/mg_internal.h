@@ -147,6 +147,8 @@ struct mg_sketch {
   int truncated = 0;
   uint64_t kmers_seen = 0;
   uint64_t last_hash = 0;  // hashes[n-1] when n > 0
+  bool has_bound = false;  // mg_sketch_set_bound: completeness bound of the sample this slice belongs to
+  uint64_t bound = 0;
   // bucket index for containment look-ups (built lazily)
   mg::DevBuf index;    // u32[nbuckets+1]
   unsigned index_shift = 0;

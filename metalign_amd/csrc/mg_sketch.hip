@@ -374,6 +374,19 @@ __global__ __launch_bounds__(256) void k_bucket_compact(const uint64_t* __restri
   }
 }
 
+__global__ void k_sketch_split(const uint64_t* __restrict__ hashes, uint64_t n, const uint64_t* __restrict__ bounds,
+                               uint32_t nbounds, uint64_t* __restrict__ out_idx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbounds) return;
+  const uint64_t key = bounds[i];
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (hashes[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  out_idx[i] = lo;
+}
+
 // meta[0] = runs, then: apply the complete-part bound (entries > bound dropped) and the s cut;
 // meta[1] = kept entries, meta[2] = last kept hash, meta[3] = 1 if anything was cut.
 __global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __restrict__ meta, uint64_t s,
@@ -623,6 +636,31 @@ int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
   rc = adopt_runs(sk, d_meta, s, any_truncated != 0, bound);
   if (rc) return bail(rc);
   *out = sk;
+  return MG_OK;
+}
+
+int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbounds, uint64_t* out_idx) {
+  MG_REQUIRE_READY();
+  if (!sk || !bounds || !out_idx) return fail(MG_ERR_ARG, "null argument");
+  if (nbounds == 0) return MG_OK;
+  if (nbounds > 4096) return fail(MG_ERR_ARG, "too many slice bounds");
+  hipStream_t st = ctx().stream;
+  uint64_t* d_io = (uint64_t*)scratch("sk_split", 2 * (uint64_t)nbounds * sizeof(uint64_t));
+  if (!d_io) return MG_ERR_NOMEM;
+  MG_HIP(hipMemcpyAsync(d_io, bounds, nbounds * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_sketch_split, dim3((nbounds + 63) / 64), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk->n, d_io,
+                     nbounds, d_io + nbounds);
+  MG_HIP(hipGetLastError());
+  MG_HIP(hipMemcpyAsync(out_idx, d_io + nbounds, nbounds * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  return MG_OK;
+}
+
+int mg_sketch_set_bound(mg_sketch* sk, int truncated, uint64_t bound) {
+  if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  sk->has_bound = true;
+  sk->truncated = truncated ? 1 : 0;
+  sk->bound = bound;
   return MG_OK;
 }
 

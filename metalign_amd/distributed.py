@@ -2,14 +2,18 @@
 
 Partitioning
   reads / alignment records   contiguous shards in stream order, cut on read boundaries (rank r holds shard r)
-  genome sketch table         sharded by genome id: rank r holds genomes [G*r/W, G*(r+1)/W)
+  genome sketch table         sharded by HASH RANGE: rank r holds, for every genome, the part of its sketch that
+                              falls in [ (hmax+1)*r/W, (hmax+1)*(r+1)/W ) -- hashes are uniform, so the slices are
+                              equal-sized, and a genome's containment is the SUM of its per-slice hit counts
 Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)
-  1. all-gather of the per-rank read sketches (hash,count runs) -> every rank merges them into the sample
-     sketch (bottom-s of a union = bottom-s of the union of per-shard bottom-s sets; counts add).
+  1. all-to-all of the per-rank read sketches by hash range (each rank sends 1/W of its sketch to every peer; the
+     bytes a rank moves do not grow with W) -> every rank merges what it receives into ITS slice of the sample
+     sketch (counts of equal hashes add; bottom-s is taken over the rank-ordered slices).
   2. all-gather of one tiny word per rank: the shard's 2-bit carried-state map and its read count, so each
      rank can compose the state entering its shard (scripts/map_and_profile.py:229-232 crosses shard edges).
   3. ONE all-reduce(sum, int64) of [containment hits | sizes | per-taxon read counts | bases |
-     per-rank first-seen slots | tot_rds, n_ambig].  <= a few MB: latency-bound on xGMI, not bandwidth-bound.
+     per-rank first-seen slots | tot_rds, n_ambig] -- hits and sizes are true sums over the hash slices.
+     <= a few MB: latency-bound on xGMI, not bandwidth-bound.
 The compute calls go through an `engine` (HipEngine below: libmetalign_hip.so on this rank's GPU).  The
 CPU tests substitute an oracle-backed engine to check the choreography under gloo; product code never does.
 """
@@ -20,8 +24,23 @@ from . import _hip
 U64_MAX = _hip.U64_MAX
 
 
-def genome_shard(ngenomes, rank, world):
-    return (ngenomes * rank) // world, (ngenomes * (rank + 1)) // world
+def _u64(x):
+    """int64 tensor element (two's complement) -> python int in [0, 2^64)."""
+    return int(x) & 0xFFFFFFFFFFFFFFFF
+
+
+def slice_bounds(hmax, world):
+    """Hash-range slices: rank r owns hashes in [b[r], b[r+1]); b[0] = 0, b[world] = hmax + 1."""
+    return [((int(hmax) + 1) * r) // world for r in range(world + 1)]
+
+
+def table_slice(dbh, dbo, lo, hi):
+    """The part of every genome sketch that falls in [lo, hi): (hashes, offsets[G+1]); order preserved."""
+    dbh = np.asarray(dbh)
+    keep = (dbh >= np.uint64(lo)) & (dbh < np.uint64(hi)) if hi <= U64_MAX else (dbh >= np.uint64(lo))
+    csum = np.zeros(len(dbh) + 1, dtype=np.uint64)
+    np.cumsum(keep, out=csum[1:])
+    return dbh[keep], csum[np.asarray(dbo, dtype=np.int64)]
 
 
 def compose_incoming(maps, rank):
@@ -84,6 +103,9 @@ class HipEngine:
         self.keep = [hashes_t, counts_t]
         return self.hip.sketch_from_pairs_dev(hashes_t.data_ptr(), counts_t.data_ptr(), n, k, s, any_truncated, bound)
 
+    def split_sketch(self, sk, bounds):
+        return sk.split(bounds)
+
     # ---- stage B ----
     def containment(self, sk, ci):
         g = max(self.ngen_local, 1)
@@ -92,6 +114,9 @@ class HipEngine:
         return hs[: self.ngen_local], hs[g: g + self.ngen_local]
 
     # ---- stage C ----
+    def set_sketch_bound(self, sk, truncated, bound):
+        sk.set_bound(truncated, bound)
+
     def profile_begin(self, pct_id, need_map=True):
         """Pass A of stage C.  The composed state map / read count are only read back (one stream sync) when a
         neighbouring shard needs them."""
@@ -141,10 +166,11 @@ class ShardJob:
         G = len(dbo) - 1
         self.G = G
         self.T = int(ntax) if ntax is not None else (int(np.max(ref2tax)) + 1 if len(ref2tax) else 0)
-        self.g0, self.g1 = genome_shard(G, self.rank, self.world)
-        lo, hi = int(dbo[self.g0]), int(dbo[self.g1])
         tails = dbo[1:][dbo[1:] > dbo[:-1]] - 1
         self.hmax = int(dbh[tails.astype(np.int64)].max()) if len(tails) else 0
+        self.bounds = slice_bounds(self.hmax, self.world)
+        if self.world > 1:
+            dbh, dbo = table_slice(dbh, dbo, self.bounds[self.rank], self.bounds[self.rank + 1])
         has_look = False
         if self.exchange:
             # the first record of the NEXT non-empty shard closes this shard's last read (:225-226)
@@ -165,37 +191,91 @@ class ShardJob:
                 has_look = True
         else:
             self.nonempty = [len(recs) > 0]
-        self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh[lo:hi], dbo[self.g0:self.g1 + 1] - dbo[self.g0])
+        self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh, dbo)
 
     # ------------------------------------------------------------------
+    def _exchange(self, send_h, send_c, send_counts):
+        """All-to-all of (hash,count) runs: send_counts[q] consecutive entries go to rank q.
+        -> (hashes, counts) received, concatenated in source-rank order."""
+        t, dist, W = self.torch, self.dist, self.world
+        sc = t.as_tensor(np.asarray(send_counts, dtype=np.int64), device=self.device)
+        mat = [t.zeros(W, dtype=t.int64, device=self.device) for _ in range(W)]
+        dist.all_gather(mat, sc)  # mat[p][q] = entries p sends to q
+        recv_counts = [int(mat[p][self.rank].item()) for p in range(W)]
+        rh = t.zeros(sum(recv_counts), dtype=t.int64, device=self.device)
+        rc = t.zeros(sum(recv_counts), dtype=t.int32, device=self.device)
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(rh, send_h, recv_counts, list(send_counts))
+            dist.all_to_all_single(rc, send_c, recv_counts, list(send_counts))
+        else:  # gloo has no all-to-all: point-to-point exchange with the same data movement
+            ops, so, ro = [], np.cumsum([0] + list(send_counts)), np.cumsum([0] + recv_counts)
+            for q in range(W):
+                if q == self.rank:
+                    rh[ro[q]:ro[q + 1]] = send_h[so[q]:so[q + 1]]
+                    rc[ro[q]:ro[q + 1]] = send_c[so[q]:so[q + 1]]
+                    continue
+                if send_counts[q]:
+                    ops.append(dist.P2POp(dist.isend, send_h[so[q]:so[q + 1]].contiguous(), q))
+                    ops.append(dist.P2POp(dist.isend, send_c[so[q]:so[q + 1]].contiguous(), q))
+                if recv_counts[q]:
+                    ops.append(dist.P2POp(dist.irecv, rh[ro[q]:ro[q + 1]], q))
+                    ops.append(dist.P2POp(dist.irecv, rc[ro[q]:ro[q + 1]], q))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        return rh, rc
+
     def _merged_sketch(self):
+        """This rank's hash-range slice of the sample sketch (the whole sketch when not exchanging)."""
         sk = self.engine.sketch_local(self.k, self.hmax, self.s)
         if not self.exchange:
             return sk
-        t, dist = self.torch, self.dist
+        t, dist, W = self.torch, self.dist, self.world
         h, c = self.engine.export_sketch(sk)
         n = int(h.numel())
-        last = int(h[-1].item()) if n else 0
-        meta = t.as_tensor([n, int(sk.truncated), last], dtype=t.int64, device=self.device)
-        metas = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        cuts = [0] + self.engine.split_sketch(sk, self.bounds[1:W]) + [n]
+        send_counts = [cuts[q + 1] - cuts[q] for q in range(W)]
+        rh, rc = self._exchange(h, c, send_counts)
+        # completeness: a source truncated at its s-th hash knows nothing above it
+        meta = t.as_tensor([int(sk.truncated), int(h[-1].item()) if n else 0, n], dtype=t.int64, device=self.device)
+        metas = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(W)]
         dist.all_gather(metas, meta)
-        metas = [m.cpu().numpy() for m in metas]
-        nmax = int(max(m[0] for m in metas))
-        hp = t.zeros(nmax, dtype=t.int64, device=self.device)
-        cp = t.zeros(nmax, dtype=t.int32, device=self.device)
-        hp[:n] = h
-        cp[:n] = c
-        hs = [t.zeros(nmax, dtype=t.int64, device=self.device) for _ in range(self.world)]
-        cs = [t.zeros(nmax, dtype=t.int32, device=self.device) for _ in range(self.world)]
-        dist.all_gather(hs, hp)
-        dist.all_gather(cs, cp)
-        allh = t.cat([hs[r][: int(metas[r][0])] for r in range(self.world)]).contiguous()
-        allc = t.cat([cs[r][: int(metas[r][0])] for r in range(self.world)]).contiguous()
-        any_trunc = any(int(m[1]) for m in metas)
-        bounds = [int(np.uint64(np.int64(m[2]))) for m in metas if int(m[1]) and int(m[0])]
-        bound = min(bounds) if bounds else U64_MAX
-        merged = self.engine.merge_sketches(allh, allc, self.k, self.s, any_trunc, bound)
+        metas = [[int(v) for v in m.cpu().numpy()] for m in metas]
+        lasts = [_u64(m[1]) for m in metas if m[0] and m[2]]
+        complete_to = min(lasts) if lasts else U64_MAX
+        any_trunc = bool(lasts)
         sk.free()
+        merged = self.engine.merge_sketches(rh.contiguous(), rc.contiguous(), self.k, 0, any_trunc, complete_to)
+        if self.s or any_trunc:
+            # bottom-s over the rank-ordered slices: keep the first s entries of the global order
+            sizes = [t.zeros(2, dtype=t.int64, device=self.device) for _ in range(W)]
+            dist.all_gather(sizes, t.as_tensor([merged.size, 0], dtype=t.int64, device=self.device))
+            sizes = [int(x[0].item()) for x in sizes]
+            before = sum(sizes[: self.rank])
+            total = sum(sizes)
+            keep = merged.size
+            truncated = any_trunc
+            if self.s and total > self.s:
+                keep = max(0, min(merged.size, self.s - before))
+                truncated = True
+            if keep < merged.size:
+                mh, mc = self.engine.export_sketch(merged)
+                cut = self.engine.merge_sketches(mh[:keep].contiguous(), mc[:keep].contiguous(), self.k, 0, False, 0)
+                merged.free()
+                merged = cut
+            # the sample sketch's last hash = last kept hash of the last rank that keeps anything
+            mine = 0
+            if merged.size:
+                mh, _ = self.engine.export_sketch(merged)
+                mine = int(mh[-1].item())
+            lasts_t = [t.zeros(2, dtype=t.int64, device=self.device) for _ in range(W)]
+            dist.all_gather(lasts_t, t.as_tensor([merged.size, mine], dtype=t.int64, device=self.device))
+            kept = [(int(x[0].item()), _u64(x[1].item())) for x in lasts_t]
+            sample_last = max((hh for nn, hh in kept if nn), default=0)
+            self.engine.set_sketch_bound(merged, truncated, sample_last)
+            self._sample_size = sum(nn for nn, _ in kept)
+        else:
+            self._sample_size = None
         return merged
 
     def step(self, want_multimapped=False):
@@ -222,9 +302,10 @@ class ShardJob:
         G, T, W = self.G, self.T, self.world
         if self.exchange:
             t, dist = self.torch, self.dist
-            buf = np.zeros(2 * G + 2 * T + W * T + 2, dtype=np.int64)
-            buf[self.g0:self.g1] = hits
-            buf[G + self.g0:G + self.g1] = sizes
+            buf = np.zeros(2 * G + 2 * T + W * T + 3, dtype=np.int64)
+            buf[:G] = hits          # per-slice partial sums: the all-reduce adds them up
+            buf[G:2 * G] = sizes
+            buf[-3] = qn            # sample sketch size = sum of slice sizes
             buf[2 * G:2 * G + T] = count.view(np.int64)
             buf[2 * G + T:2 * G + 2 * T] = bases.view(np.int64)
             o = 2 * G + 2 * T + self.rank * T
@@ -238,6 +319,7 @@ class ShardJob:
             slots = buf[2 * G + 2 * T:2 * G + 2 * T + W * T].view(np.uint64).reshape(W, T)
             first = slots.min(axis=0)  # shards hold disjoint, increasing read-index ranges
             scalars = buf[-2:].view(np.uint64)
+            qn = int(buf[-3])
         out = dict(hits=hits, sizes=sizes, count=count, bases=bases, first_seen=first, tot_rds=int(scalars[0]),
                    n_ambig=int(scalars[1]), sketch_size=qn, multimapped=mm)
         ci_vals = hits / np.maximum(sizes, 1)

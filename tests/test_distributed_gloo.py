@@ -31,9 +31,16 @@ class OracleEngine:
         def __init__(self, h, c, trunc):
             self.h, self.c, self.truncated = h, c, trunc
             self.size = len(h)
+            self.bound = None
 
         def free(self):
             pass
+
+    def split_sketch(self, sk, bounds):
+        return [int(np.searchsorted(sk.h, np.uint64(b), side="left")) for b in bounds]
+
+    def set_sketch_bound(self, sk, truncated, bound):
+        sk.truncated, sk.bound = bool(truncated), int(bound)
 
     def sketch_local(self, k, hmax, s):
         h, c, t, _ = self.o.sketch_reads(self.rb, self.ro, k, hmax=hmax, s=s)
@@ -59,7 +66,16 @@ class OracleEngine:
         return self._Sk(uh, uc, trunc)
 
     def containment(self, sk, ci):
-        return self.o.containment(sk.h, sk.c, sk.truncated, ci, self.dbh, self.dbo)
+        if sk.bound is None:
+            return self.o.containment(sk.h, sk.c, sk.truncated, ci, self.dbh, self.dbo)
+        # slice of a sample sketch: complete up to the SAMPLE's last hash.  Express that for the oracle by
+        # appending the bound as a sentinel entry with count 0 (never a hit) so that it is the "last hash".
+        if sk.truncated:
+            h = np.concatenate([sk.h[sk.h < np.uint64(sk.bound)], [np.uint64(sk.bound)]])
+            c = np.concatenate([sk.c[sk.h < np.uint64(sk.bound)],
+                                sk.c[sk.h == np.uint64(sk.bound)] if (sk.h == np.uint64(sk.bound)).any() else [np.uint32(0)]])
+            return self.o.containment(h, c.astype(np.uint32), True, ci, self.dbh, self.dbo)
+        return self.o.containment(sk.h, sk.c, False, ci, self.dbh, self.dbo)
 
     def profile_begin(self, pct_id, need_map=True):
         import shard_ref
@@ -104,14 +120,14 @@ def _worker(rank, world, port, tmpdir):
     recs["total"] = 100
     recs["matched"] = rng.integers(30, 101, size=nrec)
     recs["flag_len"] = rng.choice([0, 16, 256, 272], size=nrec).astype(np.uint32) | (np.where(rng.random(nrec) < 0.8, 100, 0).astype(np.uint32) << 12)
-    # shard: reads split in half; records cut at the read boundary nearest the middle
+    # shards: reads and records cut into `world` contiguous parts (records on read boundaries)
     starts = np.nonzero(new)[0]
-    cut = int(starts[len(starts) // 2])
-    rcut = 600
-    my_reads = (rb[: int(ro[rcut])], ro[: rcut + 1]) if rank == 0 else (rb[int(ro[rcut]):], ro[rcut:] - ro[rcut])
-    my_recs = recs[:cut] if rank == 0 else recs[cut:]
+    rcuts = [0] + [int(starts[len(starts) * i // world]) for i in range(1, world)] + [nrec]
+    ncuts = [1200 * i // world for i in range(world + 1)]
+    my_reads = (rb[int(ro[ncuts[rank]]): int(ro[ncuts[rank + 1]])], ro[ncuts[rank]: ncuts[rank + 1] + 1] - ro[ncuts[rank]])
+    my_recs = recs[rcuts[rank]: rcuts[rank + 1]]
     res = {}
-    for s in (0, 400):
+    for s in (0, 400, 37):
         job = mgd.ShardJob(None, dist, rank, world, k=k, ci=2, pct_id=0.5, s=s, engine=OracleEngine(torch))
         job.load(my_reads[0], my_reads[1], my_recs, ref2tax, dbh, dbo, ntax=ntax)
         out = job.step()
@@ -134,16 +150,17 @@ def _worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharding_matches_single_process(tmp_path, world):
     import torch.multiprocessing as mp
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
-        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 400: True})
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 400: True, 37: True})
 
 
 def test_shard_reference_equals_c_oracle_unsharded():
