@@ -120,6 +120,12 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
 int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
                              uint64_t n, uint64_t s, int any_truncated,
                              uint64_t bound, mg_sketch** out);
+/* As mg_sketch_from_pairs_dev, for pairs whose hashes all lie in [range_lo, range_hi] (a hash-range slice):
+ * merges through the partitioned counting table instead of a global sort.  Pairs outside the range, or
+ * range_hi < range_lo, select the general path. */
+int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n,
+                        uint64_t range_lo, uint64_t range_hi, uint64_t s, int any_truncated,
+                        uint64_t bound, mg_sketch** out);
 /* Positions at which an ascending sketch crosses `nbounds` hash values: out_idx[i] = number of
  * entries with hash < bounds[i].  Used to cut a sketch into hash-range slices for the multi-GPU
  * exchange (rank r owns hashes in [bounds[r-1], bounds[r])). */
@@ -131,6 +137,7 @@ int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbound
 int mg_sketch_set_bound(mg_sketch* sk, int truncated, uint64_t bound);
 uint64_t mg_sketch_size(const mg_sketch* sk);
 int mg_sketch_truncated(const mg_sketch* sk);
+uint64_t mg_sketch_last_hash(const mg_sketch* sk); /* largest hash in the sketch (0 when empty) */
 uint64_t mg_sketch_kmers_seen(const mg_sketch* sk); /* valid k-mer windows hashed */
 int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes,
                           const uint32_t** d_counts);

@@ -26,7 +26,7 @@ EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated",
+    "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
@@ -61,7 +61,7 @@ def load_library(path=LIB_PATH):
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
     lib = ctypes.CDLL(path)
     lib.mg_last_error.restype = ctypes.c_char_p
-    for name in ("mg_sketch_size", "mg_sketch_kmers_seen", "mg_db_ngenomes", "mg_db_max_hash", "mg_profile_ngroups"):
+    for name in ("mg_sketch_size", "mg_sketch_kmers_seen", "mg_sketch_last_hash", "mg_db_ngenomes", "mg_db_max_hash", "mg_profile_ngroups"):
         getattr(lib, name).restype = ctypes.c_uint64
     lib.mg_sketch_free.restype = None
     lib.mg_db_free.restype = None
@@ -122,6 +122,10 @@ class Sketch:
     @property
     def truncated(self):
         return bool(self.hip.lib.mg_sketch_truncated(self.handle))
+
+    @property
+    def last_hash(self):
+        return int(self.hip.lib.mg_sketch_last_hash(self.handle))
 
     @property
     def kmers_seen(self):
@@ -308,6 +312,14 @@ class Hip:
         self._chk(self.lib.mg_sketch_from_pairs_dev(_vp(d_hashes), _vp(d_counts), ctypes.c_uint64(n),
                                                     ctypes.c_uint64(s), ctypes.c_int(int(any_truncated)),
                                                     ctypes.c_uint64(bound), ctypes.byref(h)))
+        return Sketch(self, h, k)
+
+    def sketch_merge_dev(self, d_hashes, d_counts, n, k, range_lo, range_hi, s=0, any_truncated=False, bound=U64_MAX):
+        h = _vp()
+        self._chk(self.lib.mg_sketch_merge_dev(_vp(d_hashes), _vp(d_counts), ctypes.c_uint64(n),
+                                               ctypes.c_uint64(int(range_lo)), ctypes.c_uint64(int(range_hi)),
+                                               ctypes.c_uint64(s), ctypes.c_int(int(any_truncated)),
+                                               ctypes.c_uint64(bound), ctypes.byref(h)))
         return Sketch(self, h, k)
 
     def sketch_reads(self, bases, offsets, k, hmax=U64_MAX, s=0):

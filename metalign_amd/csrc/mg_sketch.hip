@@ -58,6 +58,21 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
 constexpr uint32_t kBucketTarget = 96;  // expected distinct hashes per bucket (load factor <= 3/8)
 
+// Insert-or-add into the partitioned counting table: keys[bucket][slot] holds hash+1 (0 = empty).
+// Returns false when the bucket has no free slot.
+__device__ __forceinline__ bool table_add(uint64_t* __restrict__ keys, uint32_t* __restrict__ cnts, uint64_t bucket,
+                                          uint64_t h, uint32_t amount) {
+  const unsigned long long v = h + 1;  // hashes are <= 2^64-2, so v is never the empty marker 0
+  const uint64_t base = bucket * kBucketSlots;
+  uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
+  for (uint32_t t = 0; t < kBucketSlots; ++t) {
+    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + base + p), 0ull, v);
+    if (old == 0ull || old == v) { atomicAdd(cnts + base + p, amount); return true; }
+    p = (p + 1) & (kBucketSlots - 1);
+  }
+  return false;
+}
+
 // Wave-level candidate sink: LDS staging, then either one reservation in the flat list (list mode) or an
 // insert-or-increment per candidate in the partitioned counting table (table mode, shift < 64).
 struct CandSink {
@@ -66,7 +81,7 @@ struct CandSink {
   uint64_t cap;       // list mode: entries available in `out`
   unsigned long long* counters;  // [0] candidates produced, [1] k-mers hashed, [2] table overflows
   uint32_t* slot_cnt;            // table mode: occurrence count per slot
-  unsigned shift;                // bucket = hash >> shift; 64 = list mode
+  unsigned shift;                // bucket = hash >> shift; 64 = list mode (read sketches start at hash 0)
   int n;              // entries staged (wave-uniform)
 
   __device__ __forceinline__ void flush(int lane) {
@@ -82,16 +97,7 @@ struct CandSink {
       uint32_t lost = 0;
       for (int i = lane; i < n; i += 64) {
         const uint64_t h = lds[i];
-        const unsigned long long v = h + 1;  // hashes are <= 2^64-2, so v is never the empty marker 0
-        const uint64_t base = (h >> shift) * kBucketSlots;
-        uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
-        uint32_t t = 0;
-        for (; t < kBucketSlots; ++t) {
-          const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(out + base + p), 0ull, v);
-          if (old == 0ull || old == v) { atomicAdd(slot_cnt + base + p, 1u); break; }
-          p = (p + 1) & (kBucketSlots - 1);
-        }
-        if (t == kBucketSlots) ++lost;
+        if (!table_add(out, slot_cnt, h >> shift, h, 1u)) ++lost;
       }
       if (lane == 0) atomicAdd(counters, (unsigned long long)n);
       if (lost) atomicAdd(counters + 2, (unsigned long long)lost);
@@ -272,6 +278,22 @@ static unsigned bit_length(uint64_t v) {
   return b ? b : 1;
 }
 
+// Merge step of the multi-GPU exchange: add (hash,count) pairs into the table; bucket = (hash - lo) >> shift.
+__global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const uint32_t* __restrict__ counts, uint64_t n,
+                                     uint64_t lo, unsigned shift, uint64_t nbuckets, uint64_t* __restrict__ keys,
+                                     uint32_t* __restrict__ cnts, unsigned long long* __restrict__ counters) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t lost = 0;
+  for (; i < n; i += stride) {
+    const uint64_t h = hashes[i];
+    uint64_t b = (h - lo) >> shift;
+    if (h < lo || b >= nbuckets) { ++lost; continue; }  // outside the declared range: caller falls back
+    if (!table_add(keys, cnts, b, h, counts[i])) ++lost;
+  }
+  if (lost) atomicAdd(counters + 2, (unsigned long long)lost);
+}
+
 // One WAVEFRONT per bucket (no workgroup barriers: buckets are independent, four in flight per workgroup):
 // compact the bucket's occupied slots into the wave's LDS region, sort the (hash,count) pairs by hash with a
 // bitonic network (width = next power of two >= n, wave-synchronous steps) and write them to the bucket's
@@ -448,6 +470,75 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   return MG_OK;
 }
 
+// ---- partitioned counting table: plan, buffers, and the table -> sketch tail shared by reads and merges ----
+struct TablePlan {
+  uint64_t lo = 0;       // bucket = (hash - lo) >> shift
+  unsigned shift = 0;
+  uint64_t nbuckets = 0, slots = 0;
+  uint64_t* keys = nullptr;   // [slots], 0 = empty, else hash + 1
+  uint32_t* cnts = nullptr;   // [slots]
+  uint64_t* stage_h = nullptr;
+  uint32_t* stage_c = nullptr;
+  uint32_t* nuniq = nullptr;
+  uint64_t* offs = nullptr;
+};
+
+// Buckets of ~kBucketTarget expected distinct hashes over the key range [lo, hi]; false when the range or the
+// estimate does not suit the table (caller takes the general path).
+static bool plan_table(uint64_t lo, uint64_t hi, double distinct_est, TablePlan& tp) {
+  if (hi < lo) return false;
+  if (distinct_est < 4096.0) distinct_est = 4096.0;
+  const uint64_t span = hi - lo;
+  unsigned shift = bit_length(span);  // one bucket
+  if (shift > 63) shift = 63;
+  while (shift > 0 && distinct_est / (double)((span >> shift) + 1) > (double)kBucketTarget) --shift;
+  tp.lo = lo;
+  tp.shift = shift;
+  tp.nbuckets = (span >> shift) + 1;
+  if (tp.nbuckets > (1ull << 27)) return false;
+  tp.slots = tp.nbuckets * kBucketSlots;
+  return true;
+}
+
+static int alloc_table(TablePlan& tp) {
+  // [keys u64 x slots | counts u32 x slots] zeroed in one memset; staging rows are written sparsely
+  uint8_t* d_tab = (uint8_t*)scratch("sk_table", tp.slots * 12);
+  tp.stage_h = (uint64_t*)scratch("sk_stage_h", tp.slots * sizeof(uint64_t));
+  tp.stage_c = (uint32_t*)scratch("sk_stage_c", tp.slots * sizeof(uint32_t));
+  tp.nuniq = (uint32_t*)scratch("sk_bucket_n", tp.nbuckets * sizeof(uint32_t));
+  tp.offs = (uint64_t*)scratch("sk_bucket_off", (tp.nbuckets + 1) * sizeof(uint64_t));
+  if (!d_tab || !tp.stage_h || !tp.stage_c || !tp.nuniq || !tp.offs) return MG_ERR_NOMEM;
+  tp.keys = reinterpret_cast<uint64_t*>(d_tab);
+  tp.cnts = reinterpret_cast<uint32_t*>(d_tab + tp.slots * 8);
+  ProfScope ps("table_clear");
+  MG_HIP(hipMemsetAsync(d_tab, 0, tp.slots * 12, ctx().stream));
+  return MG_OK;
+}
+
+// Sort every bucket, pack the buckets in order into the sketch's own buffers, apply bound / s, read back.
+static int table_to_sketch(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_bound, uint64_t bound,
+                           const unsigned long long* d_counters, uint64_t* h_counters) {
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  {
+    ProfScope ps("bucket_sort");
+    hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, tp.keys,
+                       tp.cnts, tp.nbuckets, tp.stage_h, tp.stage_c, tp.nuniq);
+    MG_HIP(hipGetLastError());
+  }
+  MG_TRY(sk->hashes.alloc((tp.slots + 1) * sizeof(uint64_t)));  // a sketch cannot outgrow the table
+  MG_TRY(sk->counts.alloc((tp.slots + 1) * sizeof(uint32_t)));
+  {
+    ProfScope ps("bucket_pack");
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, tp.nuniq, tp.nbuckets, tp.offs, d_meta);
+    hipLaunchKernelGGL(k_bucket_compact, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+                       tp.stage_h, tp.stage_c, tp.nuniq, tp.offs, tp.nbuckets, sk->hashes.as<uint64_t>(),
+                       sk->counts.as<uint32_t>(), tp.slots);
+    MG_HIP(hipGetLastError());
+  }
+  return adopt_runs(sk, d_meta, s, use_bound, bound, d_counters, h_counters);
+}
+
 // List path: flat candidate list -> rocPRIM radix sort -> run-length encode (any size, any distribution).
 static int sketch_via_list(mg_sketch* sk, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k,
                            uint64_t hmax, uint64_t s, uint64_t cap, unsigned stage, unsigned long long* d_counters) {
@@ -546,55 +637,21 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   // with no free slot) and handled by the list path.
   static double distinct_hint = 1.0;
   const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
-  const unsigned bits = bit_length(hmax);
   double distinct_est = (double)expect * distinct_hint;
   if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) distinct_est = (double)expect * atof(e);  // tests: force overflow
-  if (distinct_est < 4096.0) distinct_est = 4096.0;
-  unsigned shift = bits;  // one bucket
-  while (shift > 0 && distinct_est / (double)((hmax >> shift) + 1) > (double)kBucketTarget) --shift;
-  const uint64_t nbuckets = (hmax >> shift) + 1;
-  if (!force_list && expect >= 32768 && shift < 64 && nbuckets <= (1ull << 27)) {
-    const uint64_t slots = nbuckets * kBucketSlots;
-    // [keys u64 x slots | counts u32 x slots] zeroed in one memset; staging rows are written sparsely
-    uint8_t* d_tab = (uint8_t*)scratch("sk_table", slots * 12);
-    uint64_t* d_stage_h = (uint64_t*)scratch("sk_stage_h", slots * sizeof(uint64_t));
-    uint32_t* d_stage_c = (uint32_t*)scratch("sk_stage_c", slots * sizeof(uint32_t));
-    uint32_t* d_nuniq = (uint32_t*)scratch("sk_bucket_n", nbuckets * sizeof(uint32_t));
-    uint64_t* d_offs = (uint64_t*)scratch("sk_bucket_off", (nbuckets + 1) * sizeof(uint64_t));
-    if (!d_tab || !d_stage_h || !d_stage_c || !d_nuniq || !d_offs) return MG_ERR_NOMEM;
-    uint64_t* d_keys = reinterpret_cast<uint64_t*>(d_tab);
-    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(d_tab + slots * 8);
+  TablePlan tp;
+  if (!force_list && expect >= 32768 && plan_table(0, hmax, distinct_est, tp)) {
     MG_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), st));
-    {
-      ProfScope ps("table_clear");
-      MG_HIP(hipMemsetAsync(d_tab, 0, slots * 12, st));
-    }
+    MG_TRY(alloc_table(tp));
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, d_keys, 0, d_counters, d_cnt, shift, (unsigned)stage);
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, tp.keys, 0, d_counters, tp.cnts, tp.shift,
+                                  (unsigned)stage);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
-    {
-      ProfScope ps("bucket_sort");
-      hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_keys,
-                         d_cnt, nbuckets, d_stage_h, d_stage_c, d_nuniq);
-      MG_HIP(hipGetLastError());
-    }
-    // the sketch cannot hold more entries than the table has slots
-    const uint64_t worst = slots;
-    MG_TRY(sk->hashes.alloc((worst + 1) * sizeof(uint64_t)));
-    MG_TRY(sk->counts.alloc((worst + 1) * sizeof(uint32_t)));
-    {
-      ProfScope ps("bucket_pack");
-      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, d_nuniq, nbuckets, d_offs, d_meta);
-      hipLaunchKernelGGL(k_bucket_compact, dim3(grid_for(nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
-                         d_stage_h, d_stage_c, d_nuniq, d_offs, nbuckets, sk->hashes.as<uint64_t>(),
-                         sk->counts.as<uint32_t>(), worst);
-      MG_HIP(hipGetLastError());
-    }
     uint64_t h_counters[3] = {0, 0, 0};
-    MG_TRY(adopt_runs(sk.get(), d_meta, s, false, 0, d_counters, h_counters));
+    MG_TRY(table_to_sketch(tp, sk.get(), d_meta, s, false, 0, d_counters, h_counters));
     sk->kmers_seen = h_counters[1];
     const uint64_t runs = host_words()[4];  // total distinct hashes found (meta[0])
     if (h_counters[2] == 0) {
@@ -614,29 +671,61 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   return MG_OK;
 }
 
-int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
-                             int any_truncated, uint64_t bound, mg_sketch** out) {
+// General merge: sort the pairs by hash (rocPRIM) and add the counts of equal hashes.
+static int merge_via_sort(mg_sketch* sk, const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
+                          int any_truncated, uint64_t bound) {
+  uint64_t* d_ks = (uint64_t*)scratch("mp_keys", (n + 1) * sizeof(uint64_t));
+  uint32_t* d_vs = (uint32_t*)scratch("mp_vals", (n + 1) * sizeof(uint32_t));
+  uint64_t* d_meta = (uint64_t*)scratch("mp_meta", 8 * sizeof(uint64_t));
+  if (!d_ks || !d_vs || !d_meta) return MG_ERR_NOMEM;
+  MG_TRY(sk->hashes.alloc((n + 1) * sizeof(uint64_t)));
+  MG_TRY(sk->counts.alloc((n + 1) * sizeof(uint32_t)));
+  {
+    ProfScope ps("merge_sort");
+    MG_TRY(sort_pairs(d_hashes, d_ks, d_counts, d_vs, n));
+    MG_TRY(reduce_pairs(d_ks, d_vs, n, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), d_meta));
+  }
+  return adopt_runs(sk, d_meta, s, any_truncated != 0, bound);
+}
+
+int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t range_lo,
+                        uint64_t range_hi, uint64_t s, int any_truncated, uint64_t bound, mg_sketch** out) {
   MG_REQUIRE_READY();
   if (!out) return fail(MG_ERR_ARG, "null out handle");
   *out = nullptr;
-  mg_sketch* sk = new mg_sketch();
-  auto bail = [&](int rc) { delete sk; return rc; };
-  uint64_t* d_ks = (uint64_t*)scratch("mp_keys", (n + 1) * sizeof(uint64_t));
-  uint32_t* d_vs = (uint32_t*)scratch("mp_vals", (n + 1) * sizeof(uint32_t));
-  uint64_t* d_meta = (uint64_t*)scratch("mp_meta", 4 * sizeof(uint64_t));
-  if (!d_ks || !d_vs || !d_meta) return bail(MG_ERR_NOMEM);
-  int rc = sk->hashes.alloc((n + 1) * sizeof(uint64_t));
-  if (rc) return bail(rc);
-  rc = sk->counts.alloc((n + 1) * sizeof(uint32_t));
-  if (rc) return bail(rc);
-  rc = sort_pairs(d_hashes, d_ks, d_counts, d_vs, n);
-  if (rc) return bail(rc);
-  rc = reduce_pairs(d_ks, d_vs, n, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), d_meta);
-  if (rc) return bail(rc);
-  rc = adopt_runs(sk, d_meta, s, any_truncated != 0, bound);
-  if (rc) return bail(rc);
-  *out = sk;
+  if (n > 0 && (!d_hashes || !d_counts)) return fail(MG_ERR_ARG, "null device input");
+  std::unique_ptr<mg_sketch> sk(new mg_sketch());
+  hipStream_t st = ctx().stream;
+  TablePlan tp;
+  if (n >= 32768 && range_hi >= range_lo && !getenv("MG_DEBUG_FORCE_LIST") && plan_table(range_lo, range_hi, (double)n, tp)) {
+    unsigned long long* d_counters = (unsigned long long*)scratch("mp_meta", 8 * sizeof(uint64_t));
+    if (!d_counters) return MG_ERR_NOMEM;
+    uint64_t* d_meta = reinterpret_cast<uint64_t*>(d_counters) + 4;
+    MG_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), st));
+    MG_TRY(alloc_table(tp));
+    {
+      ProfScope ps("merge_insert");
+      hipLaunchKernelGGL(k_table_insert_pairs, dim3(grid_for(n, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st,
+                         d_hashes, d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, d_counters);
+      MG_HIP(hipGetLastError());
+    }
+    uint64_t h_counters[3] = {0, 0, 0};
+    MG_TRY(table_to_sketch(tp, sk.get(), d_meta, s, any_truncated != 0, bound, d_counters, h_counters));
+    if (h_counters[2] == 0) {
+      *out = sk.release();
+      return MG_OK;
+    }
+    sk.reset(new mg_sketch());  // a pair fell outside the declared range: general path
+  }
+  MG_TRY(merge_via_sort(sk.get(), d_hashes, d_counts, n, s, any_truncated, bound));
+  *out = sk.release();
   return MG_OK;
+}
+
+int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
+                             int any_truncated, uint64_t bound, mg_sketch** out) {
+  // no declared range: range_hi < range_lo selects the general (sorting) merge
+  return mg_sketch_merge_dev(d_hashes, d_counts, n, 1, 0, s, any_truncated, bound, out);
 }
 
 int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbounds, uint64_t* out_idx) {
@@ -666,6 +755,7 @@ int mg_sketch_set_bound(mg_sketch* sk, int truncated, uint64_t bound) {
 
 uint64_t mg_sketch_size(const mg_sketch* sk) { return sk ? sk->n : 0; }
 int mg_sketch_truncated(const mg_sketch* sk) { return sk ? sk->truncated : 0; }
+uint64_t mg_sketch_last_hash(const mg_sketch* sk) { return (sk && sk->n) ? sk->last_hash : 0; }
 uint64_t mg_sketch_kmers_seen(const mg_sketch* sk) { return sk ? sk->kmers_seen : 0; }
 
 int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes, const uint32_t** d_counts) {

@@ -98,10 +98,12 @@ class HipEngine:
         ph, pc = sk.device_ptrs()
         return (t.as_tensor(_CudaView(ph, n, "<i8"), device="cuda"), t.as_tensor(_CudaView(pc, n, "<i4"), device="cuda"))
 
-    def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound):
+    def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound, hash_range=None):
+        """hash_range = (lo, hi) inclusive when every hash is known to lie in it (a hash-range slice)."""
         n = int(hashes_t.numel())
         self.keep = [hashes_t, counts_t]
-        return self.hip.sketch_from_pairs_dev(hashes_t.data_ptr(), counts_t.data_ptr(), n, k, s, any_truncated, bound)
+        lo, hi = hash_range if hash_range is not None else (1, 0)
+        return self.hip.sketch_merge_dev(hashes_t.data_ptr(), counts_t.data_ptr(), n, k, lo, hi, s, any_truncated, bound)
 
     def split_sketch(self, sk, bounds):
         return sk.split(bounds)
@@ -194,110 +196,110 @@ class ShardJob:
         self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh, dbo)
 
     # ------------------------------------------------------------------
-    def _exchange(self, send_h, send_c, send_counts):
-        """All-to-all of (hash,count) runs: send_counts[q] consecutive entries go to rank q.
-        -> (hashes, counts) received, concatenated in source-rank order."""
+    def _all_to_all(self, send_h, send_c, send_counts, recv_counts):
+        """Variable all-to-all of the sketch arrays: send_counts[q] consecutive entries go to rank q; the slices
+        are contiguous ranges of the ascending sketch, so the sketch's own buffers are the send buffers."""
         t, dist, W = self.torch, self.dist, self.world
-        sc = t.as_tensor(np.asarray(send_counts, dtype=np.int64), device=self.device)
-        mat = [t.zeros(W, dtype=t.int64, device=self.device) for _ in range(W)]
-        dist.all_gather(mat, sc)  # mat[p][q] = entries p sends to q
-        recv_counts = [int(mat[p][self.rank].item()) for p in range(W)]
         rh = t.zeros(sum(recv_counts), dtype=t.int64, device=self.device)
         rc = t.zeros(sum(recv_counts), dtype=t.int32, device=self.device)
         if dist.get_backend() == "nccl":
-            dist.all_to_all_single(rh, send_h, recv_counts, list(send_counts))
-            dist.all_to_all_single(rc, send_c, recv_counts, list(send_counts))
-        else:  # gloo has no all-to-all: point-to-point exchange with the same data movement
-            ops, so, ro = [], np.cumsum([0] + list(send_counts)), np.cumsum([0] + recv_counts)
-            for q in range(W):
-                if q == self.rank:
-                    rh[ro[q]:ro[q + 1]] = send_h[so[q]:so[q + 1]]
-                    rc[ro[q]:ro[q + 1]] = send_c[so[q]:so[q + 1]]
-                    continue
-                if send_counts[q]:
-                    ops.append(dist.P2POp(dist.isend, send_h[so[q]:so[q + 1]].contiguous(), q))
-                    ops.append(dist.P2POp(dist.isend, send_c[so[q]:so[q + 1]].contiguous(), q))
-                if recv_counts[q]:
-                    ops.append(dist.P2POp(dist.irecv, rh[ro[q]:ro[q + 1]], q))
-                    ops.append(dist.P2POp(dist.irecv, rc[ro[q]:ro[q + 1]], q))
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+            w1 = dist.all_to_all_single(rh, send_h, list(recv_counts), list(send_counts), async_op=True)
+            w2 = dist.all_to_all_single(rc, send_c, list(recv_counts), list(send_counts), async_op=True)
+            w1.wait()
+            w2.wait()
+            return rh, rc
+        # gloo has no all-to-all: point-to-point exchange with the same data movement
+        so, ro = np.cumsum([0] + list(send_counts)), np.cumsum([0] + list(recv_counts))
+        ops = []
+        for q in range(W):
+            if q == self.rank:
+                rh[ro[q]:ro[q + 1]] = send_h[so[q]:so[q + 1]]
+                rc[ro[q]:ro[q + 1]] = send_c[so[q]:so[q + 1]]
+                continue
+            if send_counts[q]:
+                ops.append(dist.P2POp(dist.isend, send_h[so[q]:so[q + 1]].contiguous(), q))
+                ops.append(dist.P2POp(dist.isend, send_c[so[q]:so[q + 1]].contiguous(), q))
+            if recv_counts[q]:
+                ops.append(dist.P2POp(dist.irecv, rh[ro[q]:ro[q + 1]], q))
+                ops.append(dist.P2POp(dist.irecv, rc[ro[q]:ro[q + 1]], q))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         return rh, rc
 
-    def _merged_sketch(self):
-        """This rank's hash-range slice of the sample sketch (the whole sketch when not exchanging)."""
-        sk = self.engine.sketch_local(self.k, self.hmax, self.s)
-        if not self.exchange:
-            return sk
-        t, dist, W = self.torch, self.dist, self.world
-        h, c = self.engine.export_sketch(sk)
-        n = int(h.numel())
-        cuts = [0] + self.engine.split_sketch(sk, self.bounds[1:W]) + [n]
+    def _exchange_step(self):
+        """Stage A + pass A of stage C locally, then ONE all-gather of per-rank words (slice sizes, sketch
+        completeness, carried-state map) and ONE all-to-all round of sketch slices.
+        -> (this rank's slice of the sample sketch, [(m0, m1, ngroups) per rank])."""
+        eng, t, dist, W = self.engine, self.torch, self.dist, self.world
+        sk = eng.sketch_local(self.k, self.hmax, self.s)
+        (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
+        n = sk.size
+        cuts = [0] + eng.split_sketch(sk, self.bounds[1:W]) + [n]
         send_counts = [cuts[q + 1] - cuts[q] for q in range(W)]
-        rh, rc = self._exchange(h, c, send_counts)
+        last = sk.last_hash  # two's complement into the int64 word
+        word = send_counts + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, m0, m1, ngroups]
+        words = [t.zeros(W + 6, dtype=t.int64, device=self.device) for _ in range(W)]
+        dist.all_gather(words, t.as_tensor(np.asarray(word, dtype=np.int64), device=self.device))
+        words = t.stack(words).cpu().numpy().tolist()
+        recv_counts = [words[p][self.rank] for p in range(W)]
+        h, c = eng.export_sketch(sk)
+        rh, rc = self._all_to_all(h, c, send_counts, recv_counts)
+        sk.free()
         # completeness: a source truncated at its s-th hash knows nothing above it
-        meta = t.as_tensor([int(sk.truncated), int(h[-1].item()) if n else 0, n], dtype=t.int64, device=self.device)
-        metas = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(W)]
-        dist.all_gather(metas, meta)
-        metas = [[int(v) for v in m.cpu().numpy()] for m in metas]
-        lasts = [_u64(m[1]) for m in metas if m[0] and m[2]]
+        lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
         complete_to = min(lasts) if lasts else U64_MAX
         any_trunc = bool(lasts)
-        sk.free()
-        merged = self.engine.merge_sketches(rh.contiguous(), rc.contiguous(), self.k, 0, any_trunc, complete_to)
+        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1] - 1
+        merged = eng.merge_sketches(rh, rc, self.k, 0, any_trunc, complete_to, (lo, hi))
         if self.s or any_trunc:
-            # bottom-s over the rank-ordered slices: keep the first s entries of the global order
-            sizes = [t.zeros(2, dtype=t.int64, device=self.device) for _ in range(W)]
-            dist.all_gather(sizes, t.as_tensor([merged.size, 0], dtype=t.int64, device=self.device))
-            sizes = [int(x[0].item()) for x in sizes]
-            before = sum(sizes[: self.rank])
-            total = sum(sizes)
-            keep = merged.size
-            truncated = any_trunc
-            if self.s and total > self.s:
-                keep = max(0, min(merged.size, self.s - before))
-                truncated = True
-            if keep < merged.size:
-                mh, mc = self.engine.export_sketch(merged)
-                cut = self.engine.merge_sketches(mh[:keep].contiguous(), mc[:keep].contiguous(), self.k, 0, False, 0)
-                merged.free()
-                merged = cut
-            # the sample sketch's last hash = last kept hash of the last rank that keeps anything
-            mine = 0
-            if merged.size:
-                mh, _ = self.engine.export_sketch(merged)
-                mine = int(mh[-1].item())
-            lasts_t = [t.zeros(2, dtype=t.int64, device=self.device) for _ in range(W)]
-            dist.all_gather(lasts_t, t.as_tensor([merged.size, mine], dtype=t.int64, device=self.device))
-            kept = [(int(x[0].item()), _u64(x[1].item())) for x in lasts_t]
-            sample_last = max((hh for nn, hh in kept if nn), default=0)
-            self.engine.set_sketch_bound(merged, truncated, sample_last)
-            self._sample_size = sum(nn for nn, _ in kept)
-        else:
-            self._sample_size = None
+            merged = self._bottom_s(merged, any_trunc)
+        return merged, [(w[W + 3], w[W + 4], w[W + 5]) for w in words]
+
+    def _bottom_s(self, merged, any_trunc):
+        """bottom-s over the rank-ordered slices: keep the first s entries of the global order and tell every
+        slice the sample's completeness bound (two tiny all-gathers; only when s > 0)."""
+        eng, t, dist, W = self.engine, self.torch, self.dist, self.world
+        sizes = [t.zeros(1, dtype=t.int64, device=self.device) for _ in range(W)]
+        dist.all_gather(sizes, t.as_tensor([merged.size], dtype=t.int64, device=self.device))
+        sizes = [int(x[0].item()) for x in sizes]
+        before, total = sum(sizes[: self.rank]), sum(sizes)
+        keep, truncated = merged.size, any_trunc
+        if self.s and total > self.s:
+            keep = max(0, min(merged.size, self.s - before))
+            truncated = True
+        if keep < merged.size:
+            mh, mc = eng.export_sketch(merged)
+            cut = eng.merge_sketches(mh[:keep].contiguous(), mc[:keep].contiguous(), self.k, 0, False, 0, None)
+            merged.free()
+            merged = cut
+        mine = 0
+        if merged.size:
+            mh, _ = eng.export_sketch(merged)
+            mine = int(mh[-1].item())
+        lasts_t = [t.zeros(2, dtype=t.int64, device=self.device) for _ in range(W)]
+        dist.all_gather(lasts_t, t.as_tensor([merged.size, mine], dtype=t.int64, device=self.device))
+        kept = [(int(x[0].item()), _u64(x[1].item())) for x in lasts_t]
+        sample_last = max((hh for nn, hh in kept if nn), default=0)
+        eng.set_sketch_bound(merged, truncated, sample_last)
         return merged
 
     def step(self, want_multimapped=False):
         """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank)."""
         eng = self.engine
-        sk = self._merged_sketch()
+        if self.exchange:
+            sk, words = self._exchange_step()
+            maps = [(w[0], w[1]) for w in words]
+            incoming = compose_incoming(maps, self.rank)
+            group_base = int(sum(w[2] for w in words[: self.rank]))
+            first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
+        else:
+            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            eng.profile_begin(self.pct_id, False)
+            incoming, group_base, first_shard = 1, 0, True
         hits, sizes = eng.containment(sk, self.ci)
         qn = sk.size
         sk.free()
-        (m0, m1), ngroups = eng.profile_begin(self.pct_id, self.exchange)
-        if self.exchange:
-            t, dist = self.torch, self.dist
-            word = t.as_tensor([m0, m1, ngroups], dtype=t.int64, device=self.device)
-            words = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(self.world)]
-            dist.all_gather(words, word)
-            words = [w.cpu().numpy() for w in words]
-            maps = [(int(w[0]), int(w[1])) for w in words]
-            incoming = compose_incoming(maps, self.rank)
-            group_base = int(sum(int(w[2]) for w in words[: self.rank]))
-            first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
-        else:
-            incoming, group_base, first_shard = 1, 0, True
         count, bases, first, scalars, mm = eng.profile_commit(incoming, first_shard, group_base, want_multimapped)
         G, T, W = self.G, self.T, self.world
         if self.exchange:

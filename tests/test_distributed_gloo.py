@@ -31,6 +31,7 @@ class OracleEngine:
         def __init__(self, h, c, trunc):
             self.h, self.c, self.truncated = h, c, trunc
             self.size = len(h)
+            self.last_hash = int(h[-1]) if len(h) else 0
             self.bound = None
 
         def free(self):
@@ -50,7 +51,7 @@ class OracleEngine:
         t = self.torch
         return t.from_numpy(sk.h.view(np.int64).copy()), t.from_numpy(sk.c.view(np.int32).copy())
 
-    def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound):
+    def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound, hash_range=None):
         h = hashes_t.numpy().view(np.uint64)
         c = counts_t.numpy().view(np.uint32).astype(np.uint64)
         order = np.argsort(h, kind="stable")
