@@ -152,6 +152,22 @@ int mg_sketch_reads(const uint8_t* bases, const uint64_t* offsets,
                     uint64_t* out_n, int* out_truncated, uint64_t* out_kmers_seen);
 
 /* ------------------------------------------------------------------------ *
+ * Ingest on the device (text already in HBM -> what stage A consumes).
+ * Replaces the reads parsing inside kmc (scripts/select_db.py:45-52: -fq / -fa).
+ * format 0 = FASTQ (4 lines per record), 1 = FASTA with one sequence line per
+ * record.  Multi-line FASTA is parsed on the host (metalign_amd/formats.py).
+ * Sequences are kept as written (case, N); '\r' before '\n' is dropped.
+ * ------------------------------------------------------------------------ */
+typedef struct mg_reads mg_reads;
+int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_reads** out);
+int mg_reads_parse(const uint8_t* text, uint64_t nbytes, int format, mg_reads** out);
+uint64_t mg_reads_count(const mg_reads* r);
+uint64_t mg_reads_nbases(const mg_reads* r);
+int mg_reads_device_ptrs(const mg_reads* r, const uint8_t** d_bases, const uint64_t** d_offsets);
+int mg_reads_download(const mg_reads* r, uint8_t* bases, uint64_t* offsets);
+void mg_reads_free(mg_reads* r);
+
+/* ------------------------------------------------------------------------ *
  * Stage A' — genome sketch table (the pre-built DB the hot path consumes).
  * Replaces: CMash MakeStreamingDNADatabase.py -n 1000 -k 60
  * (local_tests/retrain_and_test_metalign.sh:49) and the .h5 / KMC-dump / bloom
@@ -239,6 +255,30 @@ int mg_profile_multimapped(const mg_profile* p, uint64_t* mm_offsets,
                            uint32_t* mm_tax, uint64_t* mm_hitlen,
                            uint64_t* mm_read);
 void mg_profile_free(mg_profile* p);
+
+/* SAM text in HBM -> alignment records (mg_aln_rec), one per retained line, in file order.
+ * Replaces, per line, map_and_process's filter ('@', < 6 fields, unmapped, CIGAR '*':
+ * scripts/map_and_profile.py:202-213), parse_flag (:104-111), filter_line's CIGAR walk (:88-95),
+ * RNAME -> accession row (:217) and the `read != prev_read` test (:220).
+ * mg_acc_index: accession names -> row (= index into ref2tax); a repeated name keeps its last row.
+ * prev_qname: QNAME of the last retained line of the previous chunk ("" for the first chunk); chunks
+ * must end on line boundaries.  On a line the reference cannot parse the call fails with MG_ERR_ARG and
+ * reports err_kind (1 KeyError: unknown RNAME, 2 IndexError: < 12 fields, 3 ValueError: FLAG / CIGAR / tag,
+ * 4 ZeroDivisionError: CIGAR without operations, 5 alignment too long for the record) and the 0-based
+ * line number within the chunk, so that the wrapper can raise what the reference raises. */
+typedef struct mg_acc_index mg_acc_index;
+typedef struct mg_sam_batch mg_sam_batch;
+int mg_acc_index_build(const char* names, const uint64_t* name_offsets, uint32_t nacc, mg_acc_index** out);
+void mg_acc_index_free(mg_acc_index* ix);
+int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                        mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+int mg_sam_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                    mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+uint64_t mg_sam_batch_count(const mg_sam_batch* b);
+const char* mg_sam_batch_last_qname(const mg_sam_batch* b);
+int mg_sam_batch_device_ptr(const mg_sam_batch* b, const mg_aln_rec** d_recs);
+int mg_sam_batch_download(const mg_sam_batch* b, mg_aln_rec* recs);
+void mg_sam_batch_free(mg_sam_batch* b);
 
 /* Host-buffer convenience, single shard = whole stream. Capacities: mm_* as
  * above with mm_cap_reads / mm_cap_entries entries available. */

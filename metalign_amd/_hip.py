@@ -28,6 +28,10 @@ EXPORTS = [
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
+    "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
+    "mg_reads_download", "mg_reads_free",
+    "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_sam_batch_count",
+    "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
     "mg_profile_begin_dev", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev",
@@ -61,6 +65,11 @@ def load_library(path=LIB_PATH):
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
     lib = ctypes.CDLL(path)
     lib.mg_last_error.restype = ctypes.c_char_p
+    for name in ("mg_reads_count", "mg_reads_nbases", "mg_sam_batch_count"):
+        getattr(lib, name).restype = ctypes.c_uint64
+    lib.mg_sam_batch_last_qname.restype = ctypes.c_char_p
+    for name in ("mg_reads_free", "mg_acc_index_free", "mg_sam_batch_free"):
+        getattr(lib, name).restype = None
     for name in ("mg_sketch_size", "mg_sketch_kmers_seen", "mg_sketch_last_hash", "mg_db_ngenomes", "mg_db_max_hash", "mg_profile_ngroups"):
         getattr(lib, name).restype = ctypes.c_uint64
     lib.mg_sketch_free.restype = None
@@ -160,6 +169,69 @@ class Sketch:
     def free(self):
         if self.handle:
             self.hip.lib.mg_sketch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class SamParseError(Exception):
+    """A SAM line the reference cannot parse; `kind` follows include/metalign_hip.h, `line` is 0-based in the chunk."""
+
+    def __init__(self, kind, line):
+        super().__init__("SAM parse error kind %d at line %d" % (kind, line))
+        self.kind, self.line = kind, line
+
+
+class Reads:
+    """Device-resident reads (bases + offsets) produced by the on-device FASTQ / FASTA parser."""
+
+    def __init__(self, hip, handle):
+        self.hip, self.handle = hip, handle
+
+    @property
+    def count(self):
+        return int(self.hip.lib.mg_reads_count(self.handle))
+
+    @property
+    def nbases(self):
+        return int(self.hip.lib.mg_reads_nbases(self.handle))
+
+    def device_ptrs(self):
+        b, o = _vp(), _vp()
+        self.hip._chk(self.hip.lib.mg_reads_device_ptrs(self.handle, ctypes.byref(b), ctypes.byref(o)))
+        return b.value, o.value
+
+    def download(self):
+        bases = np.empty(max(self.nbases, 1), dtype=np.uint8)
+        offs = np.empty(self.count + 1, dtype=np.uint64)
+        self.hip._chk(self.hip.lib.mg_reads_download(self.handle, _np(bases, ctypes.c_uint8), _np(offs, ctypes.c_uint64)))
+        return bases[: self.nbases], offs
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_reads_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class AccIndex:
+    """Device-resident accession -> row table for the SAM tokeniser."""
+
+    def __init__(self, hip, handle):
+        self.hip, self.handle = hip, handle
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_acc_index_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -337,6 +409,49 @@ class Hip:
             sk.free()
             d_b.free()
             d_o.free()
+
+    # ---- ingest ----
+    def parse_reads(self, text, fmt):
+        """FASTQ (fmt 'fastq') or one-sequence-line FASTA ('fasta') bytes -> device-resident Reads."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        h = _vp()
+        src = buf if buf.size else np.zeros(1, np.uint8)
+        self._chk(self.lib.mg_reads_parse(_np(src, ctypes.c_uint8), ctypes.c_uint64(buf.size),
+                                          ctypes.c_int(0 if fmt == "fastq" else 1), ctypes.byref(h)))
+        return Reads(self, h)
+
+    def acc_index(self, names):
+        blob = "".join(names).encode()
+        offs = np.zeros(len(names) + 1, dtype=np.uint64)
+        if names:
+            offs[1:] = np.cumsum([len(n.encode()) for n in names])
+        h = _vp()
+        self._chk(self.lib.mg_acc_index_build(ctypes.c_char_p(blob), _np(offs, ctypes.c_uint64),
+                                              ctypes.c_uint32(len(names)), ctypes.byref(h)))
+        return AccIndex(self, h)
+
+    def sam_tokenize(self, text, acc_index, prev_qname=""):
+        """One chunk of SAM text (ending on a line boundary) -> (records REC_DTYPE[], QNAME of its last
+        retained line).  Raises SamParseError for a line the reference cannot parse."""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        h = _vp()
+        kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
+        src = buf if buf.size else np.zeros(1, np.uint8)
+        rc = self.lib.mg_sam_tokenize(_np(src, ctypes.c_uint8), ctypes.c_uint64(buf.size), acc_index.handle,
+                                      ctypes.c_char_p(prev_qname.encode()), ctypes.byref(h), ctypes.byref(kind),
+                                      ctypes.byref(line))
+        if rc != 0 and kind.value:
+            raise SamParseError(kind.value, line.value)
+        self._chk(rc)
+        try:
+            n = int(self.lib.mg_sam_batch_count(h))
+            recs = np.zeros(n, dtype=REC_DTYPE)
+            if n:
+                self._chk(self.lib.mg_sam_batch_download(h, _vp(recs.ctypes.data)))
+            last = self.lib.mg_sam_batch_last_qname(h).decode("utf-8", "replace")
+            return recs, last
+        finally:
+            self.lib.mg_sam_batch_free(h)
 
     # ---- stage A' ----
     def sketch_genomes(self, bases, offsets, k, n):

@@ -1,0 +1,610 @@
+// mg_ingest.hip — device-side ingest: text already in HBM -> the structures the hot
+// path consumes.
+//
+//   FASTQ / single-line FASTA text  -> bases u8[] + offsets u64[R+1]          (mg_reads_parse_dev)
+//     replaces the reads parsing inside kmc (scripts/select_db.py:45-52)
+//   SAM text                        -> 16-byte alignment records              (mg_sam_tokenize_dev)
+//     replaces the per-line Python of map_and_process: '@' / short-line / unmapped filter
+//     (scripts/map_and_profile.py:202-213), parse_flag (:104-111), the CIGAR walk of filter_line
+//     (:88-95), RNAME -> accession row (:217) and the `read != prev_read` test (:220)
+//
+// Both start from a line index (positions of '\n'), built with one counting pass, one scan and one
+// marking pass; everything after is one thread per line.  Byte work, HBM-bound; no rocPRIM in the
+// counting passes besides the exclusive scans.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mg_internal.h"
+
+namespace mg {
+
+constexpr int kIB = 256;          // threads per block
+constexpr int kBytesPerThread = 16;
+
+// ---------------------------------------------------------------------------------------------
+// line index
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, uint64_t nbytes, uint64_t base) {
+  // bit j set <=> text[base + j] == '\n'
+  uint32_t m = 0;
+  if (base + kBytesPerThread <= nbytes && ((reinterpret_cast<uintptr_t>(text) + base) & 15) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(text + base);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) m |= (((w[q] >> (8 * b)) & 0xffu) == 0x0au ? 1u : 0u) << (4 * q + b);
+  } else {
+    for (int j = 0; j < kBytesPerThread; ++j)
+      if (base + j < nbytes && text[base + j] == '\n') m |= 1u << j;
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(kIB) void k_count_newlines(const uint8_t* __restrict__ text, uint64_t nbytes,
+                                                        uint32_t* __restrict__ blk_count) {
+  __shared__ uint32_t wsum[kIB / 64];
+  const uint64_t base = ((uint64_t)blockIdx.x * kIB + threadIdx.x) * kBytesPerThread;
+  uint32_t c = base < nbytes ? __popc(nl_mask16(text, nbytes, base)) : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// line_end[i] = byte offset of the i-th '\n'
+__global__ __launch_bounds__(kIB) void k_mark_newlines(const uint8_t* __restrict__ text, uint64_t nbytes,
+                                                       const uint64_t* __restrict__ blk_base,
+                                                       uint64_t* __restrict__ line_end) {
+  __shared__ uint32_t wsum[kIB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t base = ((uint64_t)blockIdx.x * kIB + threadIdx.x) * kBytesPerThread;
+  const uint32_t m = base < nbytes ? nl_mask16(text, nbytes, base) : 0;
+  const uint32_t c = __popc(m);
+  uint32_t inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t p = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += p;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wave; ++w) before += wsum[w];
+  uint64_t at = blk_base[blockIdx.x] + before + inc - c;
+  uint32_t mm = m;
+  while (mm) {
+    const int j = __ffs(mm) - 1;
+    line_end[at++] = base + j;
+    mm &= mm - 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTQ / FASTA
+// ---------------------------------------------------------------------------------------------
+// Line l spans [l == 0 ? 0 : line_end[l-1] + 1, line_end[l]) ; a trailing '\r' is not part of the line.
+__device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end,
+                                          uint64_t l, uint64_t& beg, uint64_t& end) {
+  beg = l == 0 ? 0 : line_end[l - 1] + 1;
+  end = line_end[l];
+  if (end > beg && text[end - 1] == '\r') --end;
+}
+
+// lines_per_rec = 4 (FASTQ) or 2 (single-line FASTA); sequence = line 1 of each record.
+// err[0] = min record index with a malformed header (UINT64_MAX if none)
+__global__ void k_read_lengths(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end, uint64_t nrec,
+                               int lines_per_rec, uint8_t head, uint32_t* __restrict__ lens,
+                               unsigned long long* __restrict__ err) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; r < nrec; r += stride) {
+    uint64_t hb, he, sb, se;
+    line_span(text, line_end, r * lines_per_rec, hb, he);
+    line_span(text, line_end, r * lines_per_rec + 1, sb, se);
+    bool bad = he == hb || text[hb] != head;
+    if (lines_per_rec == 4) {
+      uint64_t pb, pe;
+      line_span(text, line_end, r * 4 + 2, pb, pe);
+      bad |= pe == pb || text[pb] != '+';
+    }
+    if (bad) atomicMin(err, (unsigned long long)r);
+    lens[r] = (uint32_t)(se - sb);
+  }
+}
+
+// One wavefront per read: copy its sequence line into the compact base buffer.
+__global__ __launch_bounds__(256) void k_gather_reads(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end,
+                                                      uint64_t nrec, int lines_per_rec, const uint64_t* __restrict__ offs,
+                                                      uint8_t* __restrict__ bases) {
+  const int lane = threadIdx.x & 63;
+  uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (; r < nrec; r += nw) {
+    const uint64_t sb = line_end[r * lines_per_rec] + 1;
+    const uint64_t o = offs[r], n = offs[r + 1] - o;
+    for (uint64_t i = lane; i < n; i += 64) bases[o + i] = text[sb + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM
+// ---------------------------------------------------------------------------------------------
+enum SamErr : uint32_t { kErrNone = 0, kErrKey = 1, kErrIndex = 2, kErrValue = 3, kErrZeroDiv = 4, kErrOverflow = 5 };
+
+__device__ __forceinline__ bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+__device__ __forceinline__ bool is_alpha(uint8_t c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
+
+__device__ __forceinline__ uint64_t fnv1a(const uint8_t* p, uint32_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (uint32_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+struct AccTable {
+  const uint64_t* slot_hash;   // 0 = empty
+  const uint32_t* slot_row;
+  uint64_t mask;               // slots - 1
+  const uint8_t* names;        // concatenated accession strings
+  const uint64_t* name_off;    // [nacc + 1]
+};
+
+__device__ __forceinline__ int64_t acc_lookup(const AccTable& t, const uint8_t* s, uint32_t n) {
+  uint64_t h = fnv1a(s, n);
+  if (h == 0) h = 1;
+  for (uint64_t p = h & t.mask;; p = (p + 1) & t.mask) {
+    const uint64_t sh = t.slot_hash[p];
+    if (sh == 0) return -1;
+    if (sh == h) {
+      const uint32_t row = t.slot_row[p];
+      const uint64_t b = t.name_off[row], e = t.name_off[row + 1];
+      if (e - b == n) {
+        bool same = true;
+        for (uint32_t i = 0; i < n && same; ++i) same = t.names[b + i] == s[i];
+        if (same) return row;
+      }
+    }
+  }
+}
+
+struct LineOut {
+  mg_aln_rec rec;      // ref_new without the new-read bit
+  uint64_t qbeg;       // QNAME span in the text
+  uint32_t qlen;
+  uint32_t retained;
+};
+
+// One thread per line: everything except the new-read bit.  err: [0] = first failing line (atomicMin),
+// kinds[line] holds the failure kind for the host to look up.
+__global__ void k_sam_parse(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end, uint64_t nlines,
+                            AccTable acc, LineOut* __restrict__ out, uint32_t* __restrict__ retained,
+                            unsigned long long* __restrict__ err, uint32_t* __restrict__ err_kind) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; l < nlines; l += stride) {
+    LineOut o;
+    o.retained = 0;
+    o.qbeg = 0; o.qlen = 0;
+    o.rec.ref_new = o.rec.matched = o.rec.total = o.rec.flag_len = 0;
+    const uint64_t beg = l == 0 ? 0 : line_end[l - 1] + 1;
+    const uint64_t end = line_end[l];
+    uint32_t kind = kErrNone;
+    if (end > beg && text[beg] != '@') {  // line.startswith('@') is tested BEFORE strip() (:204)
+      // fields of line.strip().split(): maximal runs of non-whitespace; only the first 12 matter
+      uint64_t fb[12], fe[12];
+      int nf = 0;
+      uint64_t p = beg;
+      while (p < end && nf < 12) {
+        while (p < end && is_ws(text[p])) ++p;
+        if (p >= end) break;
+        fb[nf] = p;
+        while (p < end && !is_ws(text[p])) ++p;
+        fe[nf] = p;
+        ++nf;
+      }
+      if (nf >= 6) {
+        // FLAG: int(splits[1])
+        uint64_t flag = 0;
+        bool ok = fe[1] > fb[1], neg = false;
+        uint64_t q = fb[1];
+        if (ok && (text[q] == '+' || text[q] == '-')) { neg = text[q] == '-'; ++q; }
+        ok = ok && q < fe[1];
+        for (; ok && q < fe[1]; ++q) {
+          const uint8_t ch = text[q];
+          if (ch < '0' || ch > '9') ok = false; else flag = (flag * 10 + (ch - '0')) & 0xffffffffffffull;
+        }
+        if (neg) flag = 0 - flag;  // Python's & on a negative int sees two's complement bits
+        if (!ok) {
+          kind = kErrValue;
+        } else {
+          const bool star = fe[5] - fb[5] == 1 && text[fb[5]] == '*';
+          if (!((flag & 4) || star)) {
+            // retained line (:211-213)
+            const int64_t row = acc_lookup(acc, text + fb[2], (uint32_t)(fe[2] - fb[2]));
+            if (row < 0) kind = kErrKey;
+            uint64_t matched = 0, total = 0, cur = 0;
+            for (uint64_t c = fb[5]; c < fe[5] && kind == kErrNone; ++c) {
+              const uint8_t ch = text[c];
+              if (is_alpha(ch)) {
+                if (ch == 'M') matched += cur;
+                total += cur;
+                cur = 0;
+              } else if (ch >= '0' && ch <= '9') {
+                cur = cur * 10 + (ch - '0');
+              } else {
+                kind = kErrValue;  // int(ch) on a non-digit, e.g. '=' (:90-93)
+              }
+            }
+            if (kind == kErrNone && nf < 12) kind = kErrIndex;  // splits[11] (:97)
+            if (kind == kErrNone) {  // int(splits[11][5:])
+              uint64_t t = fb[11] + 5;
+              bool tok = t < fe[11];
+              if (tok && (text[t] == '+' || text[t] == '-')) ++t;
+              tok = tok && t < fe[11];
+              for (; tok && t < fe[11]; ++t) tok = text[t] >= '0' && text[t] <= '9';
+              if (!tok) kind = kErrValue;
+            }
+            if (kind == kErrNone && total == 0) kind = kErrZeroDiv;
+            const uint64_t slen = (fe[9] - fb[9] == 1 && text[fb[9]] == '*') ? 0 : fe[9] - fb[9];
+            if (kind == kErrNone && (slen > MG_REC_MAX_SEQLEN || matched > 0xffffffffull || total > 0xffffffffull))
+              kind = kErrOverflow;
+            if (kind == kErrNone) {
+              o.retained = 1;
+              o.rec.ref_new = (uint32_t)row;
+              o.rec.matched = (uint32_t)matched;
+              o.rec.total = (uint32_t)total;
+              o.rec.flag_len = (uint32_t)(flag & MG_REC_FLAG_MASK) | ((uint32_t)slen << MG_REC_LEN_SHIFT);
+              o.qbeg = fb[0];
+              o.qlen = (uint32_t)(fe[0] - fb[0]);
+            }
+          }
+        }
+      }
+    }
+    if (kind != kErrNone) {
+      atomicMin(err, (unsigned long long)l);
+      err_kind[l] = kind;
+    }
+    out[l] = o;
+    retained[l] = o.retained;
+  }
+}
+
+// rank = exclusive prefix of retained flags: list the retained lines in order
+__global__ void k_sam_list(const uint32_t* __restrict__ retained, const uint64_t* __restrict__ rank, uint64_t nlines,
+                           uint64_t* __restrict__ ret_line) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; l < nlines; l += stride)
+    if (retained[l]) ret_line[rank[l]] = l;
+}
+
+// record r = retained line ret_line[r]; new-read bit = QNAME differs from the previous retained line's
+// (the first one is compared with prev_qname, the QNAME carried over from the previous chunk; empty = none)
+__global__ void k_sam_emit(const uint8_t* __restrict__ text, const LineOut* __restrict__ lines,
+                           const uint64_t* __restrict__ ret_line, uint64_t nret, const uint8_t* __restrict__ prev_qname,
+                           uint32_t prev_len, mg_aln_rec* __restrict__ recs) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; r < nret; r += stride) {
+    const LineOut cur = lines[ret_line[r]];
+    const uint8_t* pq;
+    uint32_t pl;
+    if (r == 0) { pq = prev_qname; pl = prev_len; }
+    else { const LineOut pv = lines[ret_line[r - 1]]; pq = text + pv.qbeg; pl = pv.qlen; }
+    bool same = pl == cur.qlen;
+    for (uint32_t i = 0; same && i < cur.qlen; ++i) same = pq[i] == text[cur.qbeg + i];
+    mg_aln_rec rec = cur.rec;
+    if (!same) rec.ref_new |= MG_REC_NEW_BIT;
+    recs[r] = rec;
+  }
+}
+
+// Shared: build the line index of a text buffer.  If the text does not end in '\n' the last partial
+// line is terminated virtually.  -> d_line_end (scratch "ing_lines"), *nlines.
+static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d_line_end, uint64_t* nlines,
+                            bool* virtual_last) {
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  *nlines = 0;
+  *virtual_last = false;
+  if (nbytes == 0) { *d_line_end = (uint64_t*)scratch("ing_lines", 16); return *d_line_end ? MG_OK : MG_ERR_NOMEM; }
+  const uint64_t per_block = (uint64_t)kIB * kBytesPerThread;
+  const uint64_t nblocks = (nbytes + per_block - 1) / per_block;
+  if (nblocks > 0x7fffffffull) return fail(MG_ERR_ARG, "text too large for one ingest call");
+  uint32_t* d_cnt = (uint32_t*)scratch("ing_blk_cnt", nblocks * sizeof(uint32_t));
+  uint64_t* d_base = (uint64_t*)scratch("ing_blk_base", (nblocks + 1) * sizeof(uint64_t));
+  if (!d_cnt || !d_base) return MG_ERR_NOMEM;
+  uint64_t total = 0;
+  uint8_t last = 0;
+  {
+    ProfScope ps("ingest_lines");
+    hipLaunchKernelGGL(k_count_newlines, dim3((unsigned)nblocks), dim3(kIB), 0, st, d_text, nbytes, d_cnt);
+    MG_HIP(hipGetLastError());
+    MG_TRY(exclusive_sum_u32_to_u64(d_cnt, d_base, nblocks, &total));
+    MG_HIP(hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    *virtual_last = last != '\n';
+    uint64_t* d_le = (uint64_t*)scratch("ing_lines", (total + 2) * sizeof(uint64_t));
+    if (!d_le) return MG_ERR_NOMEM;
+    hipLaunchKernelGGL(k_mark_newlines, dim3((unsigned)nblocks), dim3(kIB), 0, st, d_text, nbytes, d_base, d_le);
+    MG_HIP(hipGetLastError());
+    if (*virtual_last) MG_HIP(hipMemcpyAsync(d_le + total, &nbytes, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    MG_HIP(hipStreamSynchronize(st));
+    *d_line_end = d_le;
+  }
+  *nlines = total + (*virtual_last ? 1 : 0);
+  return MG_OK;
+}
+
+}  // namespace mg
+
+using namespace mg;
+
+struct mg_reads {
+  DevBuf bases, offsets;
+  uint64_t nreads = 0, nbases = 0;
+};
+
+struct mg_acc_index {
+  DevBuf slot_hash, slot_row, names, name_off;
+  uint64_t slots = 0;
+  uint32_t nacc = 0;
+};
+
+struct mg_sam_batch {
+  DevBuf recs;
+  uint64_t nrecs = 0;
+  std::string last_qname;
+};
+
+extern "C" {
+
+int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_reads** out) {
+  MG_REQUIRE_READY();
+  if (!out) return fail(MG_ERR_ARG, "null out handle");
+  *out = nullptr;
+  if (format != 0 && format != 1) return fail(MG_ERR_ARG, "format must be 0 (fastq) or 1 (single-line fasta)");
+  if (nbytes > 0 && !d_text) return fail(MG_ERR_ARG, "null device text");
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  std::unique_ptr<mg_reads> rd(new mg_reads());
+  uint64_t* d_le = nullptr;
+  uint64_t nlines = 0;
+  bool vlast = false;
+  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast));
+  const int lpr = format == 0 ? 4 : 2;
+  const uint64_t nrec = nlines / lpr;
+  const uint64_t left = nlines % lpr;
+  if (left) {  // only blank lines may follow the last whole record
+    uint64_t le[5] = {0, 0, 0, 0, 0};
+    const uint64_t first = nrec * lpr;  // first leftover line
+    const uint64_t from = first ? first - 1 : 0;
+    MG_HIP(hipMemcpyAsync(le, d_le + from, (nlines - from) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    bool blank = true;
+    for (uint64_t l = first; l < nlines; ++l) {
+      const uint64_t end = le[l - from];
+      const uint64_t beg = l == 0 ? 0 : le[l - 1 - from] + 1;
+      blank = blank && end <= beg + 1;  // empty, or a lone '\r'
+    }
+    if (!blank) return fail(MG_ERR_ARG, "reads text: %llu lines is not a whole number of %d-line records",
+                            (unsigned long long)nlines, lpr);
+  }
+  rd->nreads = nrec;
+  MG_TRY(rd->offsets.alloc((nrec + 2) * sizeof(uint64_t)));
+  if (nrec == 0) {
+    MG_HIP(hipMemsetAsync(rd->offsets.p, 0, 2 * sizeof(uint64_t), st));
+    MG_TRY(rd->bases.alloc(16));
+    *out = rd.release();
+    return MG_OK;
+  }
+  uint32_t* d_len = (uint32_t*)scratch("ing_len", nrec * sizeof(uint32_t));
+  unsigned long long* d_err = (unsigned long long*)scratch("ing_err", sizeof(unsigned long long));
+  if (!d_len || !d_err) return MG_ERR_NOMEM;
+  MG_HIP(hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), st));
+  {
+    ProfScope ps("ingest_reads");
+    hipLaunchKernelGGL(k_read_lengths, dim3(grid_for(nrec, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_text, d_le,
+                       nrec, lpr, (uint8_t)(format == 0 ? '@' : '>'), d_len, d_err);
+    MG_HIP(hipGetLastError());
+    MG_TRY(exclusive_sum_u32_to_u64(d_len, rd->offsets.as<uint64_t>(), nrec, &rd->nbases));
+    unsigned long long h_err = 0;
+    MG_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    if (h_err != ~0ull) return fail(MG_ERR_ARG, "reads file: malformed record %llu (header / separator line)", h_err);
+    MG_TRY(rd->bases.alloc(rd->nbases + 16));
+    hipLaunchKernelGGL(k_gather_reads, dim3(grid_for(nrec, 4, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
+                       nrec, lpr, rd->offsets.as<uint64_t>(), rd->bases.as<uint8_t>());
+    MG_HIP(hipGetLastError());
+  }
+  *out = rd.release();
+  return MG_OK;
+}
+
+int mg_reads_parse(const uint8_t* text, uint64_t nbytes, int format, mg_reads** out) {
+  MG_REQUIRE_READY();
+  DevBuf d_text;
+  MG_TRY(d_text.alloc(nbytes + 16));
+  MG_TRY(mg_memcpy_h2d(d_text.p, text, nbytes));
+  return mg_reads_parse_dev(d_text.as<uint8_t>(), nbytes, format, out);
+}
+
+uint64_t mg_reads_count(const mg_reads* r) { return r ? r->nreads : 0; }
+uint64_t mg_reads_nbases(const mg_reads* r) { return r ? r->nbases : 0; }
+
+int mg_reads_device_ptrs(const mg_reads* r, const uint8_t** d_bases, const uint64_t** d_offsets) {
+  if (!r) return fail(MG_ERR_ARG, "null reads");
+  if (d_bases) *d_bases = r->bases.as<uint8_t>();
+  if (d_offsets) *d_offsets = r->offsets.as<uint64_t>();
+  return MG_OK;
+}
+
+int mg_reads_download(const mg_reads* r, uint8_t* bases, uint64_t* offsets) {
+  MG_REQUIRE_READY();
+  if (!r) return fail(MG_ERR_ARG, "null reads");
+  if (bases && r->nbases) MG_TRY(mg_memcpy_d2h(bases, r->bases.p, r->nbases));
+  if (offsets) MG_TRY(mg_memcpy_d2h(offsets, r->offsets.p, (r->nreads + 1) * sizeof(uint64_t)));
+  return MG_OK;
+}
+
+void mg_reads_free(mg_reads* r) { delete r; }
+
+// ---- accession table ----
+static uint64_t host_fnv1a(const char* p, uint64_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (uint64_t i = 0; i < n; ++i) { h ^= (uint8_t)p[i]; h *= 0x100000001b3ull; }
+  return h ? h : 1;
+}
+
+int mg_acc_index_build(const char* names, const uint64_t* name_offsets, uint32_t nacc, mg_acc_index** out) {
+  MG_REQUIRE_READY();
+  if (!out || (nacc && (!names || !name_offsets))) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  std::unique_ptr<mg_acc_index> ix(new mg_acc_index());
+  uint64_t slots = 16;
+  while (slots < 2ull * nacc + 2) slots <<= 1;
+  std::vector<uint64_t> sh(slots, 0);
+  std::vector<uint32_t> sr(slots, 0);
+  for (uint32_t i = 0; i < nacc; ++i) {
+    const uint64_t b = name_offsets[i], e = name_offsets[i + 1];
+    const uint64_t h = host_fnv1a(names + b, e - b);
+    uint64_t p = h & (slots - 1);
+    bool dup = false;
+    while (sh[p] != 0) {
+      if (sh[p] == h) {
+        const uint64_t ob = name_offsets[sr[p]], oe = name_offsets[sr[p] + 1];
+        if (oe - ob == e - b && memcmp(names + ob, names + b, e - b) == 0) { dup = true; break; }
+      }
+      p = (p + 1) & (slots - 1);
+    }
+    // a repeated accession keeps its LAST row, as the reference's dict assignment does (:77)
+    sh[p] = h;
+    sr[p] = i;
+    (void)dup;
+  }
+  const uint64_t nb = nacc ? name_offsets[nacc] : 0;
+  MG_TRY(ix->slot_hash.alloc(slots * sizeof(uint64_t)));
+  MG_TRY(ix->slot_row.alloc(slots * sizeof(uint32_t)));
+  MG_TRY(ix->names.alloc(nb + 16));
+  MG_TRY(ix->name_off.alloc((nacc + 1ull) * sizeof(uint64_t)));
+  MG_TRY(mg_memcpy_h2d(ix->slot_hash.p, sh.data(), slots * sizeof(uint64_t)));
+  MG_TRY(mg_memcpy_h2d(ix->slot_row.p, sr.data(), slots * sizeof(uint32_t)));
+  if (nb) MG_TRY(mg_memcpy_h2d(ix->names.p, names, nb));
+  if (nacc) MG_TRY(mg_memcpy_h2d(ix->name_off.p, name_offsets, (nacc + 1ull) * sizeof(uint64_t)));
+  else { uint64_t z = 0; MG_TRY(mg_memcpy_h2d(ix->name_off.p, &z, sizeof(z))); }
+  ix->slots = slots;
+  ix->nacc = nacc;
+  *out = ix.release();
+  return MG_OK;
+}
+
+void mg_acc_index_free(mg_acc_index* ix) { delete ix; }
+
+int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                        mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  MG_REQUIRE_READY();
+  if (!out || !ix) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (err_kind) *err_kind = 0;
+  if (err_line) *err_line = 0;
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  std::unique_ptr<mg_sam_batch> sb(new mg_sam_batch());
+  if (prev_qname) sb->last_qname = prev_qname;
+  uint64_t* d_le = nullptr;
+  uint64_t nlines = 0;
+  bool vlast = false;
+  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast));
+  if (nlines == 0) {
+    MG_TRY(sb->recs.alloc(16));
+    *out = sb.release();
+    return MG_OK;
+  }
+  LineOut* d_lines = (LineOut*)scratch("sam_lines", nlines * sizeof(LineOut));
+  uint32_t* d_ret = (uint32_t*)scratch("sam_ret", nlines * sizeof(uint32_t));
+  uint64_t* d_rank = (uint64_t*)scratch("sam_rank", (nlines + 1) * sizeof(uint64_t));
+  uint32_t* d_kind = (uint32_t*)scratch("sam_kind", nlines * sizeof(uint32_t));
+  unsigned long long* d_err = (unsigned long long*)scratch("ing_err", sizeof(unsigned long long));
+  const size_t plen = prev_qname ? strlen(prev_qname) : 0;
+  uint8_t* d_prev = (uint8_t*)scratch("sam_prev", plen + 16);
+  if (!d_lines || !d_ret || !d_rank || !d_kind || !d_err || !d_prev) return MG_ERR_NOMEM;
+  MG_HIP(hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), st));
+  if (plen) MG_HIP(hipMemcpyAsync(d_prev, prev_qname, plen, hipMemcpyHostToDevice, st));
+  AccTable at{ix->slot_hash.as<uint64_t>(), ix->slot_row.as<uint32_t>(), ix->slots - 1, ix->names.as<uint8_t>(),
+              ix->name_off.as<uint64_t>()};
+  uint64_t nret = 0;
+  {
+    ProfScope ps("ingest_sam");
+    hipLaunchKernelGGL(k_sam_parse, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
+                       nlines, at, d_lines, d_ret, d_err, d_kind);
+    MG_HIP(hipGetLastError());
+    MG_TRY(exclusive_sum_u32_to_u64(d_ret, d_rank, nlines, &nret));
+    unsigned long long h_err = 0;
+    MG_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    if (h_err != ~0ull) {
+      uint32_t kind = 0;
+      MG_HIP(hipMemcpyAsync(&kind, d_kind + h_err, sizeof(kind), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      if (err_kind) *err_kind = (int)kind;
+      if (err_line) *err_line = h_err;
+      return fail(MG_ERR_ARG, "SAM line %llu: parse error kind %u", h_err, kind);
+    }
+    MG_TRY(sb->recs.alloc((nret + 1) * sizeof(mg_aln_rec)));
+    if (nret) {
+      uint64_t* d_list = (uint64_t*)scratch("sam_list", nret * sizeof(uint64_t));
+      if (!d_list) return MG_ERR_NOMEM;
+      hipLaunchKernelGGL(k_sam_list, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_ret, d_rank,
+                         nlines, d_list);
+      hipLaunchKernelGGL(k_sam_emit, dim3(grid_for(nret, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_lines,
+                         d_list, nret, d_prev, (uint32_t)plen, sb->recs.as<mg_aln_rec>());
+      MG_HIP(hipGetLastError());
+      // QNAME of the last retained line, for the next chunk
+      uint64_t last_line = 0;
+      MG_HIP(hipMemcpyAsync(&last_line, d_list + (nret - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      LineOut lo;
+      MG_HIP(hipMemcpyAsync(&lo, d_lines + last_line, sizeof(LineOut), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      sb->last_qname.resize(lo.qlen);
+      if (lo.qlen) MG_HIP(hipMemcpyAsync(&sb->last_qname[0], d_text + lo.qbeg, lo.qlen, hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+    }
+  }
+  sb->nrecs = nret;
+  *out = sb.release();
+  return MG_OK;
+}
+
+int mg_sam_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                    mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  MG_REQUIRE_READY();
+  DevBuf d_text;
+  MG_TRY(d_text.alloc(nbytes + 16));
+  MG_TRY(mg_memcpy_h2d(d_text.p, text, nbytes));
+  return mg_sam_tokenize_dev(d_text.as<uint8_t>(), nbytes, ix, prev_qname, out, err_kind, err_line);
+}
+
+uint64_t mg_sam_batch_count(const mg_sam_batch* b) { return b ? b->nrecs : 0; }
+const char* mg_sam_batch_last_qname(const mg_sam_batch* b) { return b ? b->last_qname.c_str() : ""; }
+
+int mg_sam_batch_device_ptr(const mg_sam_batch* b, const mg_aln_rec** d_recs) {
+  if (!b || !d_recs) return fail(MG_ERR_ARG, "null argument");
+  *d_recs = b->recs.as<mg_aln_rec>();
+  return MG_OK;
+}
+
+int mg_sam_batch_download(const mg_sam_batch* b, mg_aln_rec* recs) {
+  MG_REQUIRE_READY();
+  if (!b) return fail(MG_ERR_ARG, "null batch");
+  if (b->nrecs) MG_TRY(mg_memcpy_d2h(recs, b->recs.p, b->nrecs * sizeof(mg_aln_rec)));
+  return MG_OK;
+}
+
+void mg_sam_batch_free(mg_sam_batch* b) { delete b; }
+
+}  // extern "C"

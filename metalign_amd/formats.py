@@ -37,6 +37,8 @@ def read_sequences(path, kind):
                 head = fh.readline()
                 if not head:
                     break
+                if not head.strip():  # blank line between / after records
+                    continue
                 seq = fh.readline().rstrip("\r\n")
                 fh.readline()
                 fh.readline()

@@ -164,6 +164,71 @@ def tokenise_sam(lines, acc_index, decode=False):
     return tk.records()
 
 
+_CHUNK_BYTES = 64 << 20
+
+
+def _line_chunks(instream, decode):
+    """The SAM stream as byte chunks that end on line boundaries (a file object is read in bulk)."""
+    if hasattr(instream, 'read') and not decode:
+        carry = b''
+        while True:
+            blk = instream.read(_CHUNK_BYTES)
+            if not blk:
+                break
+            if isinstance(blk, str):
+                blk = blk.encode('utf-8')
+            blk = carry + blk
+            cut = blk.rfind(b'\n') + 1
+            carry = blk[cut:]
+            if cut:
+                yield blk[:cut]
+        if carry:
+            yield carry
+        return
+    buf, size = [], 0
+    for line in instream:
+        if decode:
+            if not line:
+                break
+        else:
+            line = line.encode('utf-8') if isinstance(line, str) else line
+        buf.append(line)
+        size += len(line)
+        if size >= _CHUNK_BYTES:
+            yield b''.join(buf)
+            buf, size = [], 0
+    if buf:
+        yield b''.join(buf)
+
+
+def tokenise_sam_device(instream, acc_index, decode=False):
+    """SAM stream -> records on the MI355X (mg_sam_tokenize).  A line the reference cannot parse is re-run
+    through the host tokeniser so that the very same exception (type and message) surfaces."""
+    hip = _hip.Hip.get()
+    names = [None] * len(acc_index)
+    for a, i in acc_index.items():
+        names[i] = a
+    index = hip.acc_index(names)
+    parts, prev = [], ''
+    try:
+        for chunk in _line_chunks(instream, decode):
+            try:
+                recs, prev = hip.sam_tokenize(chunk, index, prev)
+            except _hip.SamParseError as e:
+                bad = chunk.split(b'\n')[e.line].decode('utf-8', 'replace')
+                _Tokeniser(acc_index).feed(bad)  # raises KeyError / IndexError / ValueError / ZeroDivisionError
+                raise
+            parts.append(recs)
+    finally:
+        index.free()
+    if not parts:
+        return np.zeros(0, dtype=_hip.REC_DTYPE)
+    return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+
+_device_tokenise = tokenise_sam_device
+
+
 def dense_tables(acc2info, taxid2info):
     """Dense ids for the device: accession row -> taxon row."""
     taxids = list(taxid2info)
@@ -214,7 +279,9 @@ def map_and_process(args, instream, acc2info, taxid2info, _assign=None):
     """Reference signature (:193).  `_assign` is a test seam; product code never passes it."""
     acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
     _ = taxid2info['Unmapped']  # KeyError here, as at :197, when db_info lacks the Unmapped row
-    recs = tokenise_sam(instream, acc_index, decode=(args.input_type != 'sam'))
+    # test seam: an injected record-level backend is fed by the host tokeniser; product code never passes one
+    tokenise = _device_tokenise if _assign is None else tokenise_sam
+    recs = tokenise(instream, acc_index, decode=(args.input_type != 'sam'))
     res = (_assign or _device_assign)(recs, ref2tax, len(taxids), float(args.pct_id))
     return assemble_taxids2abs(args, res, taxids, taxid2info)
 

@@ -85,6 +85,38 @@ def write_containment_csv(path, ks, rows):
             fh.write(name + ',' + ','.join(repr(v) for v in vals) + '\n')
 
 
+class _HostParsedReads:
+    """Reads parsed on the host (multi-line FASTA) and uploaded; same surface as _hip.Reads."""
+
+    def __init__(self, hip, bases, offsets):
+        self.count = len(offsets) - 1
+        self._b = hip.array(bases if bases.size else np.zeros(1, np.uint8))
+        self._o = hip.array(offsets)
+
+    def device_ptrs(self):
+        return self._b.ptr, self._o.ptr
+
+    def free(self):
+        self._b.free()
+        self._o.free()
+
+
+def load_reads_device(hip, path, kind):
+    """Reads file -> device-resident bases + offsets.  FASTQ and one-line-per-sequence FASTA are parsed on the
+    GPU from the raw (decompressed) text (mg_reads_parse); multi-line FASTA falls back to the host parser."""
+    import gzip
+    opener = gzip.open if path.endswith('.gz') else open
+    with opener(path, 'rb') as fh:
+        text = fh.read()
+    try:
+        return hip.parse_reads(text, 'fastq' if kind == 'fastq' else 'fasta')
+    except _hip.HipError:
+        if kind == 'fastq':
+            raise
+        bases, offsets, _ = formats.read_sequences(path, kind)
+        return _HostParsedReads(hip, bases, offsets)
+
+
 def run_sketch_steps(args):
     """Stages A+B on the MI355X: reads -> per-k read sketch -> containment of every genome sketch ->
     temp_dir/cmash_query_results.csv.  Replaces run_kmc_steps (:43-65) and the CMash call (:69-76)."""
@@ -93,25 +125,23 @@ def run_sketch_steps(args):
     if table_dir in (None, 'AUTO'):
         table_dir = formats.default_table_dir(args.data)
     table = formats.SketchTable(table_dir)
-    bases, offsets, _ = formats.read_sequences(args.reads, args.input_type)
-    nreads = len(offsets) - 1
-    d_b = hip.array(bases if bases.size else np.zeros(1, np.uint8))
-    d_o = hip.array(offsets)
+    reads = load_reads_device(hip, args.reads, args.input_type)
+    d_b_ptr, d_o_ptr = reads.device_ptrs()
+    nreads = reads.count
     min_count = int(getattr(args, 'min_count', 2))
     s = int(getattr(args, 'sketch_size', 0))
     per_k = []
     for k in table.ks:
         h, o = table.arrays(k)
         dev_table = hip.upload_table(np.asarray(h), o)
-        sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, dev_table.max_hash, s)
+        sk = hip.sketch_reads_dev(d_b_ptr, d_o_ptr, nreads, k, dev_table.max_hash, s)
         hits, sizes = hip.containment(sk, dev_table, min_count)
         with np.errstate(divide='ignore', invalid='ignore'):
             ci = np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0)
         per_k.append(ci)
         sk.free()
         dev_table.free()
-    d_b.free()
-    d_o.free()
+    reads.free()
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
     return out

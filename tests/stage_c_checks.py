@@ -77,6 +77,7 @@ def check_run(sam_path, dbinfo_path, run, assign, monkeypatch, tmp_path, mm_dige
     # whole stage through map_main -> CAMI text
     if assign is not None:
         monkeypatch.setattr(mp, "_device_assign", assign)
+        monkeypatch.setattr(mp, "_device_tokenise", mp.tokenise_sam)
     args = make_args(sam_path, dbinfo_path, out, ov)
     raised = None
     try:
