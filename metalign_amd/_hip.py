@@ -420,6 +420,27 @@ class Hip:
                                           ctypes.c_int(0 if fmt == "fastq" else 1), ctypes.byref(h)))
         return Reads(self, h)
 
+    def parse_reads_dev(self, d_text, nbytes, fmt):
+        """As parse_reads, for text already resident in HBM."""
+        h = _vp()
+        self._chk(self.lib.mg_reads_parse_dev(_vp(d_text), ctypes.c_uint64(nbytes),
+                                              ctypes.c_int(0 if fmt == "fastq" else 1), ctypes.byref(h)))
+        return Reads(self, h)
+
+    def sam_tokenize_dev(self, d_text, nbytes, acc_index, prev_qname=""):
+        """As sam_tokenize, for text already resident in HBM; returns the number of records (left on the device)."""
+        h = _vp()
+        kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
+        rc = self.lib.mg_sam_tokenize_dev(_vp(d_text), ctypes.c_uint64(nbytes), acc_index.handle,
+                                          ctypes.c_char_p(prev_qname.encode()), ctypes.byref(h), ctypes.byref(kind),
+                                          ctypes.byref(line))
+        if rc != 0 and kind.value:
+            raise SamParseError(kind.value, line.value)
+        self._chk(rc)
+        n = int(self.lib.mg_sam_batch_count(h))
+        self.lib.mg_sam_batch_free(h)
+        return n
+
     def acc_index(self, names):
         blob = "".join(names).encode()
         offs = np.zeros(len(names) + 1, dtype=np.uint64)
