@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     p.add_argument("--genomes", type=int, default=1000)
     p.add_argument("--genome_len", type=int, default=50_000)
@@ -182,7 +182,7 @@ def main():
             "config": {"workload": "%d synthetic 150bp reads/GPU vs %d-genome sketch DB (n=%d), k=%d, "
                                    "%d alignment records/GPU, 1 MI355X per rank"
                                    % (args.reads, args.genomes, args.sketch_n, args.k, len(w["recs"])),
-                       "parallelism": "reads sharded x%d, sketch table sharded by genome" % world},
+                       "parallelism": "reads + alignment records sharded x%d, read sketch and sketch table sharded by hash range" % world},
             "roofline": {"kernel": "k_sketch_reads<%d>" % args.k, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                          "avg_launch_ms": k1_avg, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ_K1 * args.reads,
