@@ -164,6 +164,55 @@ def tokenise_sam(lines, acc_index, decode=False):
     return tk.records()
 
 
+def tokenise_paf(lines, acc_index, decode=False):
+    """PAF replay adaptor: minimap2 PAF lines -> the same 16-byte records.
+
+    The reference has no PAF parser (it reads SAM columns, :87,97,142-144,211,217), so this is an adaptor, not a
+    parity path.  Mapping: RNAME <- target name (col 6); FLAG <- 16 if strand '-', + 256 if `tp:A:S`
+    (secondary), + 2048 if `tp:A:I`/`tp:A:i` is absent and the line repeats a primary (not emitted by minimap2);
+    CIGAR totals <- `cg:Z:` when present (matched = sum of M, total = all ops + the query bases outside
+    [qstart, qend), i.e. what SAM writes as clipping), else matched = col 10 (matching bases) and
+    total = col 2 (query length) — without `-c` PAF carries no CIGAR, so filter_line (:86-100) can only be
+    approximated; len(SEQ) <- query length for primaries, 0 for secondaries (SAM writes '*' there).
+    Pair flags do not exist in PAF: every read is treated as single-end."""
+    rows, prev = [], ''
+    for line in lines:
+        if decode:
+            line = line.decode('utf-8')
+            if not line:
+                break
+        f = line.rstrip('\n').split('\t')
+        if len(f) < 12:
+            continue
+        qlen, qs, qe = int(f[1]), int(f[2]), int(f[3])
+        tags = {t[:4]: t[5:] for t in f[12:] if len(t) > 5}
+        flag = 16 if f[4] == '-' else 0
+        secondary = tags.get('tp:A') == 'S'
+        if secondary:
+            flag |= 256
+        if 'cg:Z' in tags:
+            matched = total = num = 0
+            for ch in tags['cg:Z']:
+                if ch.isdigit():
+                    num = num * 10 + int(ch)
+                else:
+                    if ch == 'M':
+                        matched += num
+                    total += num
+                    num = 0
+            total += qlen - (qe - qs)
+        else:
+            matched, total = int(f[9]), qlen
+        if total == 0:
+            raise ZeroDivisionError('float division by zero')
+        seqlen = 0 if secondary else qlen
+        new = f[0] != prev
+        prev = f[0]
+        rows.append((acc_index[f[5]] | (_hip.NEW_BIT if new else 0), matched, total,
+                     flag | (seqlen << _hip.LEN_SHIFT)))
+    return np.array(rows, dtype=_hip.REC_DTYPE) if rows else np.zeros(0, dtype=_hip.REC_DTYPE)
+
+
 _CHUNK_BYTES = 64 << 20
 
 
@@ -281,6 +330,8 @@ def map_and_process(args, instream, acc2info, taxid2info, _assign=None):
     _ = taxid2info['Unmapped']  # KeyError here, as at :197, when db_info lacks the Unmapped row
     # test seam: an injected record-level backend is fed by the host tokeniser; product code never passes one
     tokenise = _device_tokenise if _assign is None else tokenise_sam
+    if getattr(args, 'paf_input', False):
+        tokenise = tokenise_paf
     recs = tokenise(instream, acc_index, decode=(args.input_type != 'sam'))
     res = (_assign or _device_assign)(recs, ref2tax, len(taxids), float(args.pct_id))
     return assemble_taxids2abs(args, res, taxids, taxid2info)
@@ -452,7 +503,7 @@ def map_main(args=None):
         args = profile_parseargs()
     if args.pct_id > 1.0 or args.pct_id < 0.0:
         sys.exit('Error: --pct_id must be between 0.0 and 1.0, inclusive.')
-    if args.db == 'NONE' and not args.infiles[0].endswith('sam'):
+    if args.db == 'NONE' and not args.infiles[0].endswith(('sam', 'paf')):
         sys.exit('Error: --db must be specified unless sam files are provided.')
     if not args.data.endswith('/'):
         args.data += '/'
@@ -464,6 +515,8 @@ def map_main(args=None):
             parts = parts[:-1]
         kind = {'fq': 'fastq', 'fastq': 'fastq', 'fa': 'fasta', 'fna': 'fasta', 'fasta': 'fasta',
                 'sam': 'sam'}.get(parts[-1])
+        if parts[-1] == 'paf':  # build-only: a minimap2 PAF file is replayed like a SAM file
+            kind, args.paf_input = 'sam', True
         if kind is None:
             sys.exit('Could not auto-determine file type. Use --input_type.')
         args.input_type = kind

@@ -107,3 +107,24 @@ def test_fasta_fastq_readers(tmp_path):
         fh.write("@r1 x\nACG\n+\nIII\n@r2\nTTTT\n+\nIIII\n")
     b, o, n = formats.read_sequences(str(fq), "fastq")
     assert n == ["r1", "r2"] and list(o) == [0, 3, 7] and bytes(b) == b"ACGTTTT"
+
+
+def test_paf_adaptor_maps_onto_sam_records():
+    """A SAM stream and its PAF rendering (with cg:Z:) give the same records wherever PAF can express them."""
+    import numpy as np
+
+    from metalign_amd import map_and_profile as mp
+    accs = ["NZ_A.1", "NZ_B.1"]
+    idx = {"Unmapped": 0, "NZ_A.1": 1, "NZ_B.1": 2}
+    sam = ("r1\t0\tNZ_A.1\t10\t60\t5S35M\t*\t0\t0\t" + "A" * 40 + "\t" + "I" * 40 + "\tNM:i:1\n"
+           "r1\t272\tNZ_B.1\t99\t0\t30M2D8M2S\t*\t0\t0\t*\t*\tNM:i:4\n"
+           "r2\t16\tNZ_B.1\t5\t60\t40M\t*\t0\t0\t" + "C" * 40 + "\t" + "I" * 40 + "\tNM:i:0\n")
+    paf = ("r1\t40\t5\t40\t+\tNZ_A.1\t5000\t9\t44\t34\t35\t60\ttp:A:P\tcg:Z:35M\n"
+           "r1\t40\t0\t38\t-\tNZ_B.1\t5000\t98\t138\t36\t40\t0\ttp:A:S\tcg:Z:30M2D8M\n"
+           "r2\t40\t0\t40\t-\tNZ_B.1\t5000\t4\t44\t40\t40\t60\ttp:A:P\tcg:Z:40M\n")
+    a = mp.tokenise_sam(sam.splitlines(True), idx)
+    b = mp.tokenise_paf(paf.splitlines(True), idx)
+    assert np.array_equal(a, b)
+    # without cg:Z: the identity test is approximated by matching bases / query length
+    c = mp.tokenise_paf(["r3\t100\t0\t100\t+\tNZ_A.1\t5000\t0\t100\t90\t100\t60\ttp:A:P\n"], idx)
+    assert (int(c["matched"][0]), int(c["total"][0])) == (90, 100)
