@@ -291,8 +291,21 @@ def _device_assign(recs, ref2tax, ntax, pct_id):
     return _hip.Hip.get().profile_assign(recs, ref2tax, ntax, pct_id)
 
 
-def assemble_taxids2abs(args, res, taxids, taxid2info):
-    """Kernel outputs -> the (taxids2abs, multimapped, low_mem_mmap) triple of the reference (:193-264)."""
+def multimapped_lists(res, taxids):
+    """Multimapped CSR -> the reference's list of [taxid, ..., hitlen] lists (:245-248)."""
+    off, mtax, mlen = res['mm_offsets'], res['mm_tax'], res['mm_hitlen']
+    names = np.asarray(taxids, dtype=object)[mtax] if len(mtax) else []
+    out = []
+    for i in range(len(mlen)):
+        row = list(names[int(off[i]):int(off[i + 1])])
+        row.append(int(mlen[i]))
+        out.append(row)
+    return out
+
+
+def assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=True):
+    """Kernel outputs -> the (taxids2abs, multimapped, low_mem_mmap) triple of the reference (:193-264).
+    want_lists=False leaves `multimapped` as the CSR dict for the vectorised tail (compute_abundances)."""
     taxids2abs = {'Unmapped': [0.0, 0.0] + taxid2info['Unmapped']}
     tot_rds, n_ambig = int(res['tot_rds']), int(res['n_ambig'])
     if not args.no_quantify_unmapped:
@@ -309,14 +322,9 @@ def assemble_taxids2abs(args, res, taxids, taxid2info):
             taxids2abs[taxid][1] += nbases
         else:
             taxids2abs[taxid] = [nreads, nbases] + taxid2info[taxid]
-    off, mtax, mlen = res['mm_offsets'], res['mm_tax'], res['mm_hitlen']
-    if args.low_mem and len(mlen) > 0:
+    if args.low_mem and len(res['mm_hitlen']) > 0:
         raise TypeError("object of type 'int' has no len()")  # what the reference does at :253,255
-    multimapped = []
-    for i in range(len(mlen)):
-        row = [taxids[int(t)] for t in mtax[int(off[i]):int(off[i + 1])]]
-        row.append(int(mlen[i]))
-        multimapped.append(row)
+    multimapped = multimapped_lists(res, taxids) if want_lists else res
     if not args.no_quantify_unmapped:
         if tot_rds == 0:
             sys.exit('No reads mapped. Aborting...')
@@ -324,7 +332,7 @@ def assemble_taxids2abs(args, res, taxids, taxid2info):
     return taxids2abs, multimapped, {}
 
 
-def map_and_process(args, instream, acc2info, taxid2info, _assign=None):
+def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_lists=True):
     """Reference signature (:193).  `_assign` is a test seam; product code never passes it."""
     acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
     _ = taxid2info['Unmapped']  # KeyError here, as at :197, when db_info lacks the Unmapped row
@@ -334,7 +342,9 @@ def map_and_process(args, instream, acc2info, taxid2info, _assign=None):
         tokenise = tokenise_paf
     recs = tokenise(instream, acc_index, decode=(args.input_type != 'sam'))
     res = (_assign or _device_assign)(recs, ref2tax, len(taxids), float(args.pct_id))
-    return assemble_taxids2abs(args, res, taxids, taxid2info)
+    if not _want_lists:
+        res = dict(res, taxids=taxids)
+    return assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=_want_lists)
 
 
 def preprocess_multimapped(args, multimapped, taxids2abs):
@@ -378,6 +388,43 @@ def resolve_multi_prop(args, taxids2abs, multimapped, low_mem_mmap, taxid2info):
             pending[t] = pending[t] + part if t in pending else part
     for t, extra in pending.items():
         taxids2abs[t][1] += extra
+    return taxids2abs
+
+
+def resolve_multi_prop_csr(args, taxids2abs, mm, taxid2info):
+    """resolve_multi_prop (:269-312) straight from the kernel's multimapped CSR, vectorised.
+
+    Same arithmetic in the same order as the list version: per read, the DISTINCT taxa that still have an entry in
+    taxids2abs share the read's hitlen in proportion to their current bases; every taxon's additions are summed
+    in read order (np.bincount adds sequentially) and applied once at the end."""
+    echo('Assigning multimapped reads...', args.verbose)
+    taxids = mm['taxids']
+    T = len(taxids)
+    off = mm['mm_offsets'].astype(np.int64)
+    tax = mm['mm_tax'].astype(np.int64)
+    hitlen = mm['mm_hitlen'].astype(np.float64)
+    if len(hitlen) == 0:
+        return taxids2abs
+    weight = np.full(T, np.nan)
+    index = {t: i for i, t in enumerate(taxids)}
+    for taxid, row in taxids2abs.items():
+        weight[index[taxid]] = row[1]
+    rid = np.repeat(np.arange(len(hitlen), dtype=np.int64), np.diff(off))
+    keep = ~np.isnan(weight[tax])
+    pairs = np.unique(rid[keep] * T + tax[keep])  # distinct (read, taxon), ascending by read
+    r, t = pairs // T, pairs % T
+    w = weight[t]
+    denom = np.bincount(r, weights=w, minlength=len(hitlen))
+    ok = denom[r] != 0.0
+    r, t, w = r[ok], t[ok], w[ok]
+    part = (w / denom[r]) * hitlen[r]
+    if args.length_normalize:
+        part = part / np.array([taxid2info[x][0] for x in taxids], dtype=np.float64)[t]
+    extra = np.bincount(t, weights=part, minlength=T)
+    touched = np.zeros(T, dtype=bool)
+    touched[t] = True
+    for i in np.nonzero(touched)[0]:
+        taxids2abs[taxids[int(i)]][1] += float(extra[i])
     return taxids2abs
 
 
@@ -442,17 +489,17 @@ def compute_abundances(args, infile, acc2info, tax2info):
         mapper = subprocess.Popen(['minimap2', '-ax', 'sr', '-t', str(args.threads), '-2', '-n' '1',
                                    '--secondary=yes', args.db, infile], stdout=subprocess.PIPE, bufsize=1)
         instream = iter(mapper.stdout.readline, b'')
-    taxids2abs, multimapped, low_mem_mmap = map_and_process(args, instream, acc2info, tax2info)
+    # product path: the multimapped reads stay in the kernel's CSR form; preprocess_multimapped (:180-188) is
+    # subsumed by the membership test inside the resolve step (a taxon dropped there is dropped here too)
+    taxids2abs, mm, low_mem_mmap = map_and_process(args, instream, acc2info, tax2info, _want_lists=False)
     if args.input_type == 'sam':
         instream.close()
     else:
         mapper.stdout.close()
         mapper.wait()
-    if len(multimapped) > 0:
-        multimapped = preprocess_multimapped(args, multimapped, taxids2abs)
     taxids2abs = {k: v for k, v in taxids2abs.items() if v[0] > args.read_cutoff}
-    if len(multimapped) > 0 or len(low_mem_mmap) > 0:
-        taxids2abs = resolve_multi_prop(args, taxids2abs, multimapped, low_mem_mmap, tax2info)
+    if len(mm['mm_hitlen']) > 0:
+        taxids2abs = resolve_multi_prop_csr(args, taxids2abs, mm, tax2info)
     return tree_results_cami(args, taxids2abs)
 
 
