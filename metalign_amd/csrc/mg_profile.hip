@@ -307,7 +307,13 @@ __global__ __launch_bounds__(1024) void k_profile_scan_mm(uint64_t* __restrict__
   }
 }
 
-// LDS-privatised histogram when ntax <= hist_cap (dynamic LDS: 3 * hist_cap u64), else global atomics.
+// Per-workgroup privatised histogram in LDS, flushed with global atomics at the end:
+//   use_lds_hist == 1  direct:  ntax <= 2048 bins (dynamic LDS: 3 * ntax u64)
+//   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
+//                      fewer taxa than the table lists); a taxon that finds no bin within kHashProbe steps
+//                      goes to global atomics directly.  Without this a skewed sample serialises millions of
+//                      global atomics on a few hundred addresses (8.6 ms -> see DESIGN.md at 12.5 M records).
+constexpr uint32_t kHashSlots = 2048, kHashProbe = 32;
 __global__ __launch_bounds__(kPB) void k_profile_commit(
     const mg_aln_rec* __restrict__ recs, uint64_t nrecs, uint64_t ntotal, const uint32_t* __restrict__ ref2tax,
     double pct_id, uint8_t* __restrict__ maps, const uint8_t* __restrict__ pre_map,
@@ -320,11 +326,16 @@ __global__ __launch_bounds__(kPB) void k_profile_commit(
   __shared__ uint32_t lds[8];
   __shared__ uint64_t lds64[4];
   __shared__ unsigned long long s_ambig, s_groups;
+  const uint32_t nbins = use_lds_hist == 2 ? kHashSlots : ntax;
   unsigned long long* h_count = hist;
-  unsigned long long* h_bases = hist + ntax;
-  unsigned long long* h_first = hist + 2 * (size_t)ntax;
+  unsigned long long* h_bases = hist + nbins;
+  unsigned long long* h_first = hist + 2 * (size_t)nbins;
+  uint32_t* h_key = reinterpret_cast<uint32_t*>(hist + 3 * (size_t)nbins);  // hashed mode only
   if (use_lds_hist) {
-    for (uint32_t t = threadIdx.x; t < ntax; t += kPB) { h_count[t] = 0; h_bases[t] = 0; h_first[t] = ~0ull; }
+    for (uint32_t t = threadIdx.x; t < nbins; t += kPB) {
+      h_count[t] = 0; h_bases[t] = 0; h_first[t] = ~0ull;
+      if (use_lds_hist == 2) h_key[t] = 0xffffffffu;
+    }
   }
   if (threadIdx.x == 0) { s_ambig = (blockIdx.x == 0 && first_shard) ? 1ull : 0ull; s_groups = 0; }
   __syncthreads();
@@ -352,10 +363,20 @@ __global__ __launch_bounds__(kPB) void k_profile_commit(
           atomicAdd(&s_ambig, 1ull);
         } else if (v.kind == 1) {
           const unsigned long long gidx = group_base + pre_groups[tile] + rank;
-          if (use_lds_hist) {
-            atomicAdd(&h_count[v.tax], 1ull);
-            atomicAdd(&h_bases[v.tax], (unsigned long long)v.hitlen);
-            atomicMin(&h_first[v.tax], gidx);
+          uint32_t bin = v.tax;
+          bool in_lds = use_lds_hist == 1;
+          if (use_lds_hist == 2) {
+            uint32_t p = (v.tax * 2654435761u) >> 21;  // 11 bits: kHashSlots
+            for (uint32_t step = 0; step < kHashProbe; ++step) {
+              const uint32_t old = atomicCAS(&h_key[p], 0xffffffffu, v.tax);
+              if (old == 0xffffffffu || old == v.tax) { bin = p; in_lds = true; break; }
+              p = (p + 1) & (kHashSlots - 1);
+            }
+          }
+          if (in_lds) {
+            atomicAdd(&h_count[bin], 1ull);
+            atomicAdd(&h_bases[bin], (unsigned long long)v.hitlen);
+            atomicMin(&h_first[bin], gidx);
           } else {
             atomicAdd(&g_count[v.tax], 1ull);
             atomicAdd(&g_bases[v.tax], (unsigned long long)v.hitlen);
@@ -375,11 +396,12 @@ __global__ __launch_bounds__(kPB) void k_profile_commit(
   }
   __syncthreads();
   if (use_lds_hist) {
-    for (uint32_t t = threadIdx.x; t < ntax; t += kPB) {
+    for (uint32_t t = threadIdx.x; t < nbins; t += kPB) {
       if (h_count[t]) {
-        atomicAdd(&g_count[t], h_count[t]);
-        atomicAdd(&g_bases[t], h_bases[t]);
-        atomicMin(&g_first[t], h_first[t]);
+        const uint32_t tax = use_lds_hist == 2 ? h_key[t] : t;
+        atomicAdd(&g_count[tax], h_count[t]);
+        atomicAdd(&g_bases[tax], h_bases[t]);
+        atomicMin(&g_first[tax], h_first[t]);
       }
     }
   }
@@ -542,8 +564,9 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
   MG_TRY(p->mm_cnt.alloc(p->nrecs * sizeof(uint32_t)));
   MG_TRY(p->tile_ent.alloc(p->nblocks * sizeof(uint64_t)));
   MG_TRY(p->tile_reads.alloc(p->nblocks * sizeof(uint64_t)));
-  const uint32_t use_lds = p->ntax <= 2048 ? 1u : 0u;
-  const size_t lds = use_lds ? 3 * (size_t)p->ntax * sizeof(unsigned long long) : 0;
+  const uint32_t use_lds = p->ntax <= 2048 ? 1u : 2u;
+  const size_t lds = use_lds == 1 ? 3 * (size_t)p->ntax * sizeof(unsigned long long)
+                                  : kHashSlots * (3 * sizeof(unsigned long long) + sizeof(uint32_t));
   {
     ProfScope ps("profile_commit");
     unsigned grid = grid_for(p->nblocks, 1, (unsigned)c.num_cus * 4);
