@@ -181,7 +181,7 @@ int mgo_sketch_reads(const uint8_t* bases, const uint64_t* offsets, uint64_t nre
       free(acc.v);
       return MG_ERR_NOMEM;
     }
-  qsort(acc.v, acc.n, sizeof(uint64_t), cmp_u64);
+  if (acc.n) qsort(acc.v, acc.n, sizeof(uint64_t), cmp_u64);
   uint64_t n = 0;
   int truncated = 0, rc = MG_OK;
   for (uint64_t i = 0; i < acc.n;) {
@@ -215,7 +215,7 @@ int mgo_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t n
       free(acc.v);
       return MG_ERR_NOMEM;
     }
-    qsort(acc.v, acc.n, sizeof(uint64_t), cmp_u64);
+    if (acc.n) qsort(acc.v, acc.n, sizeof(uint64_t), cmp_u64);
     uint64_t kept = 0;
     for (uint64_t i = 0; i < acc.n && kept < n; ++i)
       if (i == 0 || acc.v[i] != acc.v[i - 1]) { out_hashes[w++] = acc.v[i]; ++kept; }

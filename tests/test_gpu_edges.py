@@ -1,0 +1,83 @@
+"""-m gpu: degenerate inputs through the C ABI (empty, single element, extreme k) against the oracle."""
+import numpy as np
+import pytest
+
+from metalign_amd import _hip
+
+pytestmark = pytest.mark.gpu
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+def test_empty_and_tiny_record_streams(hip, oracle_lib):
+    r2t = np.array([0, 1, 1], dtype=np.uint32)
+    for n in (0, 1, 2, 3):
+        recs = np.zeros(n, dtype=oracle_lib.REC_DTYPE)
+        if n:
+            recs["ref_new"] = np.array([1 | 0x80000000, 2, 1 | 0x80000000][:n], dtype=np.uint32)
+            recs["total"] = 10
+            recs["matched"] = 10
+            recs["flag_len"] = (10 << 12)
+        got = hip.profile_assign(recs, r2t, 2, 0.5)
+        want = oracle_lib.profile_assign(recs, r2t, 2, 0.5)
+        for key in want:
+            assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), (n, key)
+
+
+def test_one_giant_read_group(hip, oracle_lib):
+    """A single read with 5000 alignment lines (one thread walks it; paired-end intersection is quadratic)."""
+    rng = np.random.default_rng(1)
+    n = 5000
+    r2t = rng.integers(0, 7, size=30).astype(np.uint32)
+    for flags in ([0, 256], [99, 147, 355, 403]):
+        recs = np.zeros(n + 2, dtype=oracle_lib.REC_DTYPE)
+        recs["ref_new"] = rng.integers(0, 30, size=n + 2).astype(np.uint32)
+        recs["ref_new"][[0, 1, n + 1]] |= 0x80000000  # starter read (1 line), the giant read, a closing read
+        recs["total"] = 100
+        recs["matched"] = rng.integers(30, 101, size=n + 2)
+        recs["flag_len"] = rng.choice(flags, size=n + 2).astype(np.uint32) | (100 << 12)
+        got = hip.profile_assign(recs, r2t, 7, 0.5)
+        want = oracle_lib.profile_assign(recs, r2t, 7, 0.5)
+        for key in want:
+            assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
+
+
+def test_sketch_degenerate_inputs(hip, oracle_lib):
+    cases = {
+        "all N": ([b"N" * 200] * 70, 21),
+        "k=1": ([b"ACGTTGCAAC", b"", b"T"], 1),
+        "k=64 exact": ([b"ACGT" * 16, b"ACGT" * 16 + b"A"], 64),
+        "one read": ([b"ACGTACGTTGCATGCATGCAAGCTAGCT"], 21),
+        "homopolymer x 5000": ([b"A" * 150] * 5000, 31),
+    }
+    for name, (seqs, k) in cases.items():
+        bases = np.frombuffer(b"".join(seqs), dtype=np.uint8) if any(seqs) else np.zeros(0, np.uint8)
+        offs = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+        h, c, t, seen = hip.sketch_reads(bases, offs, k)
+        oh, oc, ot, oseen = oracle_lib.sketch_reads(bases, offs, k)
+        assert (seen, t) == (oseen, ot), name
+        assert np.array_equal(h, oh) and np.array_equal(c, oc), name
+
+
+def test_containment_with_empty_operands(hip, oracle_lib):
+    dbh = np.array([5, 9, 100, 7], dtype=np.uint64)
+    dbo = np.array([0, 3, 3, 4], dtype=np.uint64)  # genome 1 has an empty sketch
+    table = hip.upload_table(dbh, dbo)
+    assert table.ngenomes == 3 and table.max_hash == 100
+    empty = hip.sketch_reads_dev(hip.array(np.zeros(1, np.uint8)).ptr, hip.array(np.zeros(1, np.uint64)).ptr, 0, 21, U64_MAX, 0)
+    hits, sizes = hip.containment(empty, table, 2)
+    assert list(hits) == [0, 0, 0] and list(sizes) == [3, 0, 1]
+    qh, qc = np.array([7, 9, 50], dtype=np.uint64), np.array([2, 1, 9], dtype=np.uint32)
+    d_h, d_c = hip.array(qh), hip.array(qc)
+    sk = hip.sketch_from_pairs_dev(d_h.ptr, d_c.ptr, 3, 21)
+    hits, sizes = hip.containment(sk, table, 2)
+    oh, os_ = oracle_lib.containment(qh, qc, False, 2, dbh, dbo)
+    assert np.array_equal(hits, oh) and np.array_equal(sizes, os_)
+
+
+def test_bad_arguments_fail_loudly(hip):
+    with pytest.raises(_hip.HipError):
+        hip.sketch_reads(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4], np.uint64), 65)
+    with pytest.raises(_hip.HipError):
+        hip.sketch_reads(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4], np.uint64), 0)
+    with pytest.raises(_hip.HipError):
+        hip.sketch_genomes(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4], np.uint64), 21, 0)
