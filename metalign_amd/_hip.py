@@ -454,7 +454,7 @@ class Hip:
     def sam_tokenize(self, text, acc_index, prev_qname=""):
         """One chunk of SAM text (ending on a line boundary) -> (records REC_DTYPE[], QNAME of its last
         retained line).  Raises SamParseError for a line the reference cannot parse."""
-        buf = np.frombuffer(text, dtype=np.uint8)
+        buf = np.frombuffer(text, dtype=np.uint8)  # bytes or a memoryview slice: no copy
         h = _vp()
         kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
         src = buf if buf.size else np.zeros(1, np.uint8)

@@ -156,9 +156,9 @@ class _Tokeniser:
 def tokenise_sam(lines, acc_index, decode=False):
     tk = _Tokeniser(acc_index)
     for line in lines:
-        if decode:
+        if isinstance(line, (bytes, bytearray)):  # the aligner's pipe, or a SAM file opened in binary mode
             line = line.decode('utf-8')
-            if not line:
+            if decode and not line:
                 break
         tk.feed(line)
     return tk.records()
@@ -213,24 +213,37 @@ def tokenise_paf(lines, acc_index, decode=False):
     return np.array(rows, dtype=_hip.REC_DTYPE) if rows else np.zeros(0, dtype=_hip.REC_DTYPE)
 
 
-_CHUNK_BYTES = 64 << 20
+_CHUNK_BYTES = 256 << 20
 
 
 def _line_chunks(instream, decode):
-    """The SAM stream as byte chunks that end on line boundaries (a file object is read in bulk)."""
+    """The SAM stream as byte chunks that end on line boundaries.  A (binary) file object is read in bulk and
+    sliced without copying; an iterator of lines (the aligner's pipe) is batched."""
     if hasattr(instream, 'read') and not decode:
         carry = b''
         while True:
-            blk = instream.read(_CHUNK_BYTES)
+            blk = instream.read(1 << 30)
             if not blk:
                 break
-            if isinstance(blk, str):
+            if isinstance(blk, str):  # a text-mode handle: the reference opens SAM files that way
                 blk = blk.encode('utf-8')
-            blk = carry + blk
-            cut = blk.rfind(b'\n') + 1
-            carry = blk[cut:]
-            if cut:
-                yield blk[:cut]
+            if carry:
+                blk = carry + blk
+            view = memoryview(blk)
+            pos, n = 0, len(blk)
+            while n - pos > _CHUNK_BYTES:
+                cut = blk.rfind(b'\n', pos, pos + _CHUNK_BYTES) + 1
+                if cut <= pos:  # a single line longer than a chunk
+                    cut = blk.find(b'\n', pos + _CHUNK_BYTES) + 1
+                    if cut <= 0:
+                        break
+                yield view[pos:cut]
+                pos = cut
+            last = blk.rfind(b'\n', pos) + 1
+            if last > pos:
+                yield view[pos:last]
+                pos = last
+            carry = bytes(view[pos:])
         if carry:
             yield carry
         return
@@ -264,7 +277,7 @@ def tokenise_sam_device(instream, acc_index, decode=False):
             try:
                 recs, prev = hip.sam_tokenize(chunk, index, prev)
             except _hip.SamParseError as e:
-                bad = chunk.split(b'\n')[e.line].decode('utf-8', 'replace')
+                bad = bytes(chunk).split(b'\n')[e.line].decode('utf-8', 'replace')
                 _Tokeniser(acc_index).feed(bad)  # raises KeyError / IndexError / ValueError / ZeroDivisionError
                 raise
             parts.append(recs)
@@ -484,7 +497,7 @@ def tree_results_cami(args, taxids2abs):
 def compute_abundances(args, infile, acc2info, tax2info):
     """One input file -> clade abundances (:404-433)."""
     if args.input_type == 'sam':
-        instream = open(infile, 'r')
+        instream = open(infile, 'rb')  # bytes go to the device tokeniser as they are
     else:  # stream minimap2's SAM, exactly the reference's invocation (:413-416)
         mapper = subprocess.Popen(['minimap2', '-ax', 'sr', '-t', str(args.threads), '-2', '-n' '1',
                                    '--secondary=yes', args.db, infile], stdout=subprocess.PIPE, bufsize=1)

@@ -60,7 +60,13 @@ for rep in range(2):
     a2 = argparse.Namespace(infiles=[sam], data=data, db="NONE", dbinfo=sub, input_type="AUTO", length_normalize=False, low_mem=False,
                             min_abundance=1e-4, rank_renormalize=False, output=os.path.join(td, "ab.tsv"), pct_id=0.5,
                             no_quantify_unmapped=False, read_cutoff=1, sampleID="x", threads=4, verbose=False)
-    map_and_profile.map_main(a2)
+    if rep == 1 and os.environ.get("MG_CPROFILE"):
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        map_and_profile.map_main(a2)
+        pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+    else:
+        map_and_profile.map_main(a2)
     t2 = time.perf_counter()
     print("run %d: select_db.select_main (FASTQ %d MB -> subset db) %.3f s = %.2e reads/s;  map_main (SAM %d MB -> CAMI) %.3f s = %.2e reads/s"
           % (rep, os.path.getsize(fq) >> 20, t1 - t0, n / (t1 - t0), os.path.getsize(sam) >> 20, t2 - t1, n / (t2 - t1)))
