@@ -1,12 +1,16 @@
 // mg_contain.hip — Stage B: containment of every genome sketch in the read sketch.
 //
-// K2 `k_containment`: one wavefront per genome.  Both operands are sorted sets
-// (genome sketch ascending, read sketch ascending); the intersection is taken
-// by looking each genome hash up in the read sketch through a bucket index
-// over the hash's leading bits (expected bucket population ~1), 64 genome
-// hashes per step, and counting matches with a wavefront ballot + popcount.
-// The genome table is streamed once, 512 B per wavefront-step, fully coalesced;
-// the read sketch and its index are L2 / Infinity-Cache resident.
+// K2: both operands are sorted sets.  The table is held INVERTED (built once at upload): U = the ascending
+// union of all genome sketches, and for every genome hash its position in U.
+//   k_presence     walks U once, 64 consecutive hashes per wavefront step, and looks each one up in the read
+//                  sketch through a bucket index over the hash's leading bits (~1 entry per bucket).  Because
+//                  consecutive lanes carry increasing hashes, their index / sketch accesses are nearly
+//                  contiguous (the intersection of two sorted lists, without the serial merge); the result is
+//                  one presence bit per U entry, written with a wavefront ballot.
+//   k_genome_hits  one wavefront per genome gathers its bits (positions are streamed coalesced, the bitmap is
+//                  |U|/8 bytes and L2-resident) and counts them with ballot + popcount.
+// A first version looked every genome hash up directly (G*n scattered look-ups): 0.27 ms at 10k genomes; this
+// one streams U and the positions once.
 //
 // Replaces: kmc_tools simple ... intersect (scripts/select_db.py:54-56) and the
 // containment index of StreamingQueryDNADatabase.py (scripts/select_db.py:73-76).
@@ -16,26 +20,56 @@
 
 namespace mg {
 
-// idx[b] = first position whose hash >= b << shift; idx[nbuckets] = n.
+// idx[b] = first position whose hash >= b << shift; idx[nbuckets] = n.  One thread per sketch entry i (and one
+// past the end) writes i into every bucket in (bucket(q[i-1]), bucket(q[i])]: hashes are uniform and there is
+// about one bucket per entry, so that is ~1 store per thread, against a 20-step binary search per bucket.
 __global__ void k_build_index(const uint64_t* __restrict__ q, uint64_t n, unsigned shift, uint64_t nbuckets,
                               uint32_t* __restrict__ idx) {
-  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > nbuckets) return;
-  if (b == nbuckets) { idx[b] = (uint32_t)n; return; }
-  const uint64_t key = b << shift;
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) {
-    uint64_t mid = (lo + hi) >> 1;
-    if (q[mid] < key) lo = mid + 1; else hi = mid;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i <= n; i += stride) {
+    const uint64_t first = i == 0 ? 0 : (q[i - 1] >> shift) + 1;
+    // past the end: only the bucket right after the last hash's is ever read (look-ups stop at q[n-1])
+    const uint64_t last = i == n ? first : (q[i] >> shift);
+    for (uint64_t b = first; b <= last; ++b) idx[b] = (uint32_t)i;
   }
-  idx[b] = (uint32_t)lo;
 }
 
-__global__ __launch_bounds__(256) void k_containment(const uint64_t* __restrict__ q, const uint32_t* __restrict__ qc,
-                                                     uint64_t qn, uint64_t q_last, const uint32_t* __restrict__ idx,
-                                                     unsigned shift, uint64_t bound, uint32_t ci,
-                                                     const uint64_t* __restrict__ db, const uint64_t* __restrict__ offs,
-                                                     uint64_t ngenomes, uint32_t* __restrict__ hits,
+// Pass 1: walk the table's ascending union U; bit i of `present` = U[i] is in the read sketch with count >= ci.
+// Consecutive lanes look up increasing hashes, so their index / sketch accesses are nearly contiguous.
+__global__ __launch_bounds__(256) void k_presence(const uint64_t* __restrict__ q, const uint32_t* __restrict__ qc,
+                                                  uint64_t qn, uint64_t q_last, const uint32_t* __restrict__ idx,
+                                                  unsigned shift, uint32_t ci, const uint64_t* __restrict__ uniq,
+                                                  uint64_t nuniq, unsigned long long* __restrict__ present) {
+  const int lane = threadIdx.x & 63;
+  uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // 64 entries of U per wavefront step
+  const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint64_t nwords = (nuniq + 63) / 64;
+  for (; w < nwords; w += nw) {
+    const uint64_t i = w * 64 + lane;
+    bool found = false;
+    if (i < nuniq && qn > 0) {
+      const uint64_t h = uniq[i];
+      if (h <= q_last) {
+        const uint64_t b = h >> shift;
+        uint32_t lo = idx[b], hi = idx[b + 1];
+        while (lo < hi) {  // lower_bound inside the bucket
+          uint32_t mid = (lo + hi) >> 1;
+          if (q[mid] < h) lo = mid + 1; else hi = mid;
+        }
+        found = lo < qn && q[lo] == h && qc[lo] >= ci;
+      }
+    }
+    const unsigned long long m = __ballot(found);
+    if (lane == 0) present[w] = m;
+  }
+}
+
+// Pass 2: one wavefront per genome gathers its bits.  bound_pos = number of U entries <= the sketch's
+// completeness bound (nuniq when the sketch is complete): positions below it count towards `sizes`.
+__global__ __launch_bounds__(256) void k_genome_hits(const uint32_t* __restrict__ pos, const uint64_t* __restrict__ offs,
+                                                     uint64_t ngenomes, const unsigned long long* __restrict__ present,
+                                                     uint64_t bound_pos, uint32_t* __restrict__ hits,
                                                      uint32_t* __restrict__ sizes) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -47,23 +81,51 @@ __global__ __launch_bounds__(256) void k_containment(const uint64_t* __restrict_
       const uint64_t i = base + lane;
       bool inb = false, found = false;
       if (i < end) {
-        const uint64_t h = db[i];
-        inb = h <= bound;
-        if (inb && qn > 0 && h <= q_last) {
-          const uint64_t b = h >> shift;
-          uint32_t lo = idx[b], hi = idx[b + 1];
-          while (lo < hi) {  // lower_bound inside the bucket
-            uint32_t mid = (lo + hi) >> 1;
-            if (q[mid] < h) lo = mid + 1; else hi = mid;
-          }
-          found = lo < qn && q[lo] == h && qc[lo] >= ci;
-        }
+        const uint32_t p = pos[i];
+        inb = p < bound_pos;
+        found = inb && ((present[p >> 6] >> (p & 63)) & 1ull);
       }
       nh += __popcll(__ballot(found));
       ns += __popcll(__ballot(inb));
     }
     if (lane == 0) { hits[g] = nh; sizes[g] = ns; }
   }
+}
+
+// ---- table upload helpers: U = distinct sorted hashes, pos[original index] = rank in U ----
+__global__ void k_iota_u32(uint32_t* v, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) v[i] = (uint32_t)i;
+}
+
+__global__ void k_head_flags(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t* __restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+}
+
+// rank[i] = exclusive prefix of head flags = (index in U of sorted[i]) + (flag ? 0 : ... ) : inclusive - 1
+__global__ void k_scatter_pos(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ orig,
+                              const uint32_t* __restrict__ flags, const uint64_t* __restrict__ excl, uint64_t n,
+                              uint64_t* __restrict__ uniq, uint32_t* __restrict__ pos) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const uint64_t r = excl[i] + flags[i] - 1;  // inclusive count of heads up to i, minus one
+    if (flags[i]) uniq[r] = sorted[i];
+    pos[orig[i]] = (uint32_t)r;
+  }
+}
+
+__global__ void k_upper_bound_one(const uint64_t* __restrict__ uniq, uint64_t n, uint64_t bound, uint64_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (uniq[mid] <= bound) lo = mid + 1; else hi = mid;
+  }
+  *out = lo;
 }
 
 static int ensure_index(mg_sketch* sk) {
@@ -80,8 +142,9 @@ static int ensure_index(mg_sketch* sk) {
   sk->index_buckets = 1ull << lb;
   MG_TRY(sk->index.alloc((sk->index_buckets + 1) * sizeof(uint32_t)));
   ProfScope ps("contain_index");
-  hipLaunchKernelGGL(k_build_index, dim3((unsigned)((sk->index_buckets + 1 + 255) / 256)), dim3(256), 0, ctx().stream,
-                     sk->hashes.as<uint64_t>(), sk->n, sk->index_shift, sk->index_buckets, sk->index.as<uint32_t>());
+  hipLaunchKernelGGL(k_build_index, dim3(grid_for(sk->n + 1, 256, (unsigned)ctx().num_cus * 16)), dim3(256), 0,
+                     ctx().stream, sk->hashes.as<uint64_t>(), sk->n, sk->index_shift, sk->index_buckets,
+                     sk->index.as<uint32_t>());
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -96,18 +159,45 @@ int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets, uint64_t ngeno
   MG_REQUIRE_READY();
   if (!out || !offsets) return fail(MG_ERR_ARG, "null argument");
   *out = nullptr;
-  std::unique_ptr<mg_db> db(new mg_db());
-  db->ngenomes = ngenomes;
-  db->total = offsets[ngenomes] - offsets[0];
   if (offsets[0] != 0) return fail(MG_ERR_ARG, "db offsets must start at 0");
-  MG_TRY(db->hashes.alloc(db->total * sizeof(uint64_t)));
+  std::unique_ptr<mg_db> db(new mg_db());
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  const uint64_t total = offsets[ngenomes];
+  if (total > 0xfffffff0ull) return fail(MG_ERR_ARG, "sketch table of %llu hashes exceeds the 32-bit position range",
+                                         (unsigned long long)total);
+  db->ngenomes = ngenomes;
+  db->total = total;
   MG_TRY(db->offsets.alloc((ngenomes + 1) * sizeof(uint64_t)));
-  MG_TRY(mg_memcpy_h2d(db->hashes.p, hashes, db->total * sizeof(uint64_t)));
   MG_TRY(mg_memcpy_h2d(db->offsets.p, offsets, (ngenomes + 1) * sizeof(uint64_t)));
   uint64_t mx = 0;  // each genome sketch is ascending: its maximum is its last entry
-  for (uint64_t g = 0; g < ngenomes; ++g)
+  for (uint64_t g = 0; g < ngenomes; ++g) {
+    if (offsets[g + 1] < offsets[g]) return fail(MG_ERR_ARG, "db offsets must be non-decreasing");
     if (offsets[g + 1] > offsets[g] && hashes[offsets[g + 1] - 1] > mx) mx = hashes[offsets[g + 1] - 1];
+  }
   db->max_hash = mx;
+  MG_TRY(db->pos.alloc((total + 1) * sizeof(uint32_t)));
+  MG_TRY(db->uniq.alloc((total + 1) * sizeof(uint64_t)));
+  if (total) {
+    // one-time inversion on the device: sort (hash, original index), mark run heads, scan, scatter
+    uint64_t* d_h = (uint64_t*)scratch("db_h", total * sizeof(uint64_t));
+    uint64_t* d_hs = (uint64_t*)scratch("db_hs", total * sizeof(uint64_t));
+    uint32_t* d_i = (uint32_t*)scratch("db_i", total * sizeof(uint32_t));
+    uint32_t* d_is = (uint32_t*)scratch("db_is", total * sizeof(uint32_t));
+    uint32_t* d_flag = (uint32_t*)scratch("db_flag", total * sizeof(uint32_t));
+    uint64_t* d_excl = (uint64_t*)scratch("db_excl", (total + 1) * sizeof(uint64_t));
+    if (!d_h || !d_hs || !d_i || !d_is || !d_flag || !d_excl) return MG_ERR_NOMEM;
+    MG_HIP(hipMemcpyAsync(d_h, hashes, total * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const unsigned grid = grid_for(total, 256, (unsigned)c.num_cus * 8);
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid), dim3(256), 0, st, d_i, total);
+    MG_TRY(sort_pairs(d_h, d_hs, d_i, d_is, total));
+    hipLaunchKernelGGL(k_head_flags, dim3(grid), dim3(256), 0, st, d_hs, total, d_flag);
+    MG_TRY(exclusive_sum_u32_to_u64(d_flag, d_excl, total, &db->nuniq));
+    hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(256), 0, st, d_hs, d_is, d_flag, d_excl, total,
+                       db->uniq.as<uint64_t>(), db->pos.as<uint32_t>());
+    MG_HIP(hipGetLastError());
+    MG_HIP(hipStreamSynchronize(st));
+  }
   *out = db.release();
   return MG_OK;
 }
@@ -125,11 +215,27 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
   if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
   Context& c = ctx();
+  hipStream_t st = c.stream;
+  const uint64_t nwords = (db->nuniq + 63) / 64;
+  unsigned long long* d_present = (unsigned long long*)scratch("contain_bits", (nwords + 1) * sizeof(unsigned long long));
+  uint64_t* d_bpos = (uint64_t*)scratch("contain_bpos", sizeof(uint64_t));
+  if (!d_present || !d_bpos) return MG_ERR_NOMEM;
   ProfScope ps("containment");
-  unsigned grid = grid_for(db->ngenomes, 4, (unsigned)c.num_cus * 8);
-  hipLaunchKernelGGL(k_containment, dim3(grid), dim3(256), 0, c.stream, sk->hashes.as<uint64_t>(),
-                     sk->counts.as<uint32_t>(), sk->n, sk->last_hash, sk->index.as<uint32_t>(), sk->index_shift, bound,
-                     ci, db->hashes.as<uint64_t>(), db->offsets.as<uint64_t>(), db->ngenomes, d_hits, d_sizes);
+  uint64_t bound_pos = db->nuniq;
+  if (bound != ~0ull) {  // truncated sketch: only table hashes <= bound take part (rare path: one read-back)
+    hipLaunchKernelGGL(k_upper_bound_one, dim3(1), dim3(64), 0, st, db->uniq.as<uint64_t>(), db->nuniq, bound, d_bpos);
+    uint64_t* pin = host_words();
+    MG_HIP(hipMemcpyAsync(pin + 20, d_bpos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    bound_pos = pin[20];
+  }
+  if (nwords)
+    hipLaunchKernelGGL(k_presence, dim3(grid_for(nwords, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+                       sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), sk->n, sk->last_hash,
+                       sk->index.as<uint32_t>(), sk->index_shift, ci, db->uniq.as<uint64_t>(), db->nuniq, d_present);
+  hipLaunchKernelGGL(k_genome_hits, dim3(grid_for(db->ngenomes, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+                     db->pos.as<uint32_t>(), db->offsets.as<uint64_t>(), db->ngenomes, d_present, bound_pos, d_hits,
+                     d_sizes);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }

@@ -134,6 +134,8 @@ int reduce_pairs(const uint64_t* d_keys, const uint32_t* d_vals, uint64_t n, uin
                  uint64_t* d_runs);
 // Sort every segment [offs[i], offs[i+1]) of keys independently.
 int segmented_sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, const uint64_t* d_offsets, uint64_t nseg);
+// Sort (key u64, value u32) pairs by key (all 64 bits); used once per table upload.
+int sort_pairs(const uint64_t* d_kin, uint64_t* d_kout, const uint32_t* d_vin, uint32_t* d_vout, uint64_t n);
 // Exclusive prefix sums; *h_total receives the grand total.
 int exclusive_sum_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* h_total);
 
@@ -156,9 +158,14 @@ struct mg_sketch {
 };
 
 struct mg_db {
-  mg::DevBuf hashes;   // u64[total]
+  // Inverted layout built once at upload (mg_contain.hip): the ascending union U of all genome sketches and, for
+  // every genome hash, its position in U.  Containment then walks U once (coherent look-ups into the read
+  // sketch -> presence bitmap) and gathers bits per genome, instead of G*n scattered look-ups.
+  mg::DevBuf uniq;     // u64[nuniq]   ascending distinct hashes of the whole table
+  mg::DevBuf pos;      // u32[total]   genome hash i -> index into uniq (ascending within a genome)
   mg::DevBuf offsets;  // u64[ngenomes+1]
   uint64_t ngenomes = 0;
   uint64_t total = 0;
+  uint64_t nuniq = 0;
   uint64_t max_hash = 0;
 };
