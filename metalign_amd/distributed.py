@@ -205,9 +205,7 @@ class ShardJob:
         if dist.get_backend() == "nccl":
             w1 = dist.all_to_all_single(rh, send_h, list(recv_counts), list(send_counts), async_op=True)
             w2 = dist.all_to_all_single(rc, send_c, list(recv_counts), list(send_counts), async_op=True)
-            w1.wait()
-            w2.wait()
-            return rh, rc
+            return rh, rc, [w1, w2]  # in flight on RCCL's stream: the caller overlaps stage C's commit with it
         # gloo has no all-to-all: point-to-point exchange with the same data movement
         so, ro = np.cumsum([0] + list(send_counts)), np.cumsum([0] + list(recv_counts))
         ops = []
@@ -225,12 +223,13 @@ class ShardJob:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        return rh, rc
+        return rh, rc, []
 
     def _exchange_step(self):
         """Stage A + pass A of stage C locally, then ONE all-gather of per-rank words (slice sizes, sketch
-        completeness, carried-state map) and ONE all-to-all round of sketch slices.
-        -> (this rank's slice of the sample sketch, [(m0, m1, ngroups) per rank])."""
+        completeness, carried-state map) and ONE all-to-all round of sketch slices, during which stage C's
+        commit runs (it only needs the gathered state maps).
+        -> (this rank's slice of the sample sketch, commit results)."""
         eng, t, dist, W = self.engine, self.torch, self.dist, self.world
         sk = eng.sketch_local(self.k, self.hmax, self.s)
         (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
@@ -244,7 +243,15 @@ class ShardJob:
         words = t.stack(words).cpu().numpy().tolist()
         recv_counts = [words[p][self.rank] for p in range(W)]
         h, c = eng.export_sketch(sk)
-        rh, rc = self._all_to_all(h, c, send_counts, recv_counts)
+        rh, rc, inflight = self._all_to_all(h, c, send_counts, recv_counts)
+        # stage C commit overlaps the all-to-all: it depends on the gathered maps only
+        maps = [(w[W + 3], w[W + 4]) for w in words]
+        incoming = compose_incoming(maps, self.rank)
+        group_base = int(sum(w[W + 5] for w in words[: self.rank]))
+        first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
+        committed = eng.profile_commit(incoming, first_shard, group_base, self._want_mm)
+        for wk in inflight:
+            wk.wait()
         sk.free()
         # completeness: a source truncated at its s-th hash knows nothing above it
         lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
@@ -254,7 +261,7 @@ class ShardJob:
         merged = eng.merge_sketches(rh, rc, self.k, 0, any_trunc, complete_to, (lo, hi))
         if self.s or any_trunc:
             merged = self._bottom_s(merged, any_trunc)
-        return merged, [(w[W + 3], w[W + 4], w[W + 5]) for w in words]
+        return merged, committed
 
     def _bottom_s(self, merged, any_trunc):
         """bottom-s over the rank-ordered slices: keep the first s entries of the global order and tell every
@@ -287,20 +294,19 @@ class ShardJob:
     def step(self, want_multimapped=False):
         """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank)."""
         eng = self.engine
+        self._want_mm = want_multimapped
         if self.exchange:
-            sk, words = self._exchange_step()
-            maps = [(w[0], w[1]) for w in words]
-            incoming = compose_incoming(maps, self.rank)
-            group_base = int(sum(w[2] for w in words[: self.rank]))
-            first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
+            sk, committed = self._exchange_step()
         else:
             sk = eng.sketch_local(self.k, self.hmax, self.s)
             eng.profile_begin(self.pct_id, False)
-            incoming, group_base, first_shard = 1, 0, True
+            committed = None
         hits, sizes = eng.containment(sk, self.ci)
         qn = sk.size
         sk.free()
-        count, bases, first, scalars, mm = eng.profile_commit(incoming, first_shard, group_base, want_multimapped)
+        if committed is None:
+            committed = eng.profile_commit(1, True, 0, want_multimapped)
+        count, bases, first, scalars, mm = committed
         G, T, W = self.G, self.T, self.world
         if self.exchange:
             t, dist = self.torch, self.dist
