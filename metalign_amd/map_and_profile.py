@@ -21,14 +21,13 @@ CAMI file is byte-identical.
 There is no CPU fallback: without libmetalign_hip.so / a GPU, map_and_process
 raises (metalign_amd._hip.HipUnavailable).
 """
-import argparse
 import subprocess
 import sys
 import time
 
 import numpy as np
 
-from . import _hip
+from . import _hip, cli
 
 start = time.time()
 RANKS = ['superkingdom', 'phylum', 'class', 'order', 'family', 'genus', 'species', 'strain']
@@ -43,30 +42,7 @@ def echo(msg, verbose):
 
 
 def profile_parseargs(argv=None):
-    p = argparse.ArgumentParser(description='Compute abundance estimations for species in a sample.')
-    p.add_argument('infiles', nargs='+', help='sam or reads file(s) (space-delimited if multiple). Required.')
-    p.add_argument('data', help='Path to data/ directory with the files from setup_data.sh')
-    p.add_argument('--db', default='NONE', help='Path to database from select_db.py. Required if read files given')
-    p.add_argument('--dbinfo', default='AUTO', help='Location of db_info file. Default: data/db_info.txt')
-    p.add_argument('--input_type', default='AUTO', choices=['fastq', 'fasta', 'sam', 'AUTO'],
-                   help='Type of input file (fastq/fasta/sam). Default: try to automatically determine')
-    p.add_argument('--length_normalize', action='store_true', help='Normalize abundances by genome length.')
-    p.add_argument('--low_mem', action='store_true',
-                   help='Run in low memory mode, with inexact multimapped processing.')
-    p.add_argument('--min_abundance', type=float, default=10**-4,
-                   help='Minimum abundance for a taxa to be included in the results. Default: 10^(-4).')
-    p.add_argument('--rank_renormalize', action='store_true',
-                   help='Renormalize abundances to 100 pct. at each rank, e.g if an organism has a species but not genus label.')
-    p.add_argument('--output', default='abundances.tsv', help='Output abundances file. Default: abundances.txt')
-    p.add_argument('--pct_id', type=float, default=0.5,
-                   help='Minimum percent identity from reference to count a hit.')
-    p.add_argument('--no_quantify_unmapped', action='store_true',
-                   help='Do not factor in unmapped reads in abundance estimation.')
-    p.add_argument('--read_cutoff', type=int, default=1, help='Number of reads to count an organism as present.')
-    p.add_argument('--sampleID', default='NONE', help='Sample ID for output. Defaults to input file name(s).')
-    p.add_argument('--threads', type=int, default=4, help='Number of compute threads for Minimap2. Default: 4')
-    p.add_argument('--verbose', action='store_true', help='Print verbose output.')
-    return p.parse_args(argv)
+    return cli.parser_for('map_and_profile').parse_args(argv)
 
 
 def get_taxid_rank(taxlin):
@@ -565,21 +541,17 @@ def map_main(args=None):
         sys.exit('Error: --pct_id must be between 0.0 and 1.0, inclusive.')
     if args.db == 'NONE' and not args.infiles[0].endswith(('sam', 'paf')):
         sys.exit('Error: --db must be specified unless sam files are provided.')
-    if not args.data.endswith('/'):
-        args.data += '/'
+    args.data = cli.with_slash(args.data)
     if args.dbinfo == 'AUTO':
         args.dbinfo = args.data + 'db_info.txt'
     if args.input_type == 'AUTO':
-        parts = args.infiles[0].split('.')
-        if parts[-1] == 'gz':
-            parts = parts[:-1]
-        kind = {'fq': 'fastq', 'fastq': 'fastq', 'fa': 'fasta', 'fna': 'fasta', 'fasta': 'fasta',
-                'sam': 'sam'}.get(parts[-1])
-        if parts[-1] == 'paf':  # build-only: a minimap2 PAF file is replayed like a SAM file
-            kind, args.paf_input = 'sam', True
-        if kind is None:
-            sys.exit('Could not auto-determine file type. Use --input_type.')
-        args.input_type = kind
+        first = args.infiles[0]
+        if first.endswith('.sam'):
+            args.input_type = 'sam'
+        elif first.endswith('.paf'):  # build-only: a minimap2 PAF file is replayed like a SAM file
+            args.input_type, args.paf_input = 'sam', True
+        else:
+            args.input_type = cli.sniff_reads_type(first)
     open(args.output, 'w').close()
     acc2info, taxid2info = get_acc2info(args)
     rank_results = gather_results(args, acc2info, taxid2info)

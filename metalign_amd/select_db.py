@@ -18,7 +18,6 @@ own k list is used; the stock table is n=1000, k in {30,40,50,60}); containment 
 CSV column, which is the one the cutoff applies to (:85-86).  Parity status of this arithmetic: unpinned by
 the reference (KMC / CMash are not vendored), pinned to oracle/mg_oracle.c bit for bit — see DESIGN.md.
 """
-import argparse
 import os
 import subprocess
 import sys
@@ -26,32 +25,11 @@ import tempfile
 
 import numpy as np
 
-from . import _hip, formats
+from . import _hip, cli, formats
 
 
 def select_parseargs(argv=None):
-    p = argparse.ArgumentParser(description='Run CMash and select a subset of the whole database to align to.')
-    p.add_argument('reads', help='Path to reads file.')
-    p.add_argument('data', help='Path to data/ directory with the files from setup_data.sh')
-    p.add_argument('--cmash_results', default='NONE', help='Give location of CMash query results if already done.')
-    p.add_argument('--cutoff', type=float, default=0.01, help='CMash cutoff value. Default is 0.01.')
-    p.add_argument('--db', default='AUTO', help='Where to write subset database. Default: temp_dir/cmashed_db.fna')
-    p.add_argument('--db_dir', default='AUTO', help='Directory with all organism files in the full database.')
-    p.add_argument('--dbinfo_in', default='AUTO', help='Specify location of db_info file. Default is data/db_info.txt')
-    p.add_argument('--dbinfo_out', default='AUTO',
-                   help='Where to write subset db_info. Default: temp_dir/subset_db_info.txt')
-    p.add_argument('--input_type', default='AUTO', choices=['fastq', 'fasta', 'AUTO'],
-                   help='Type of input file (fastq/fasta). Default: try to auto-determine')
-    p.add_argument('--keep_temp_files', action='store_true', help='Retain KMC files after this script finishes.')
-    p.add_argument('--strain_level', action='store_true',
-                   help='Include all strains above cutoff. Default: 1 strain per species.')
-    p.add_argument('--temp_dir', default='AUTO/', help='Directory to write temporary files to.')
-    p.add_argument('--threads', type=int, default=4, help='How many compute threads for KMC to use. Default: 4')
-    # build-only additions (defaults keep the reference behaviour)
-    p.add_argument('--sketch_table', default='AUTO', help='Genome sketch table directory. Default: data/sketch_table')
-    p.add_argument('--min_count', type=int, default=2, help='k-mer count threshold (kmc -ci). Default: 2')
-    p.add_argument('--sketch_size', type=int, default=0, help='Read sketch size per k; 0 = every hash <= table max.')
-    return p.parse_args(argv)
+    return cli.parser_for('select_db').parse_args(argv)
 
 
 def read_dbinfo(args):
@@ -194,34 +172,20 @@ def select_main(args=None):
     elif args.cutoff < 0.0 or args.cutoff > 1.0:
         print('Error: args.cutoff must be between 0 and 1, inclusive.')
         sys.exit()
-    if not args.data.endswith('/'):
-        args.data += '/'
+    args.data = cli.with_slash(args.data)
     if args.db_dir == 'AUTO':
         args.db_dir = args.data + 'organism_files/'
-    if not args.db_dir.endswith('/'):
-        args.db_dir += '/'
+    args.db_dir = cli.with_slash(args.db_dir)
     if args.temp_dir == 'AUTO/':
         args.temp_dir = tempfile.mkdtemp(prefix=args.data)
-    if not args.temp_dir.endswith('/'):
-        args.temp_dir += '/'
-    if not os.path.exists(args.temp_dir):
-        os.makedirs(args.temp_dir)
-    if args.dbinfo_in == 'AUTO':
-        args.dbinfo_in = args.data + 'db_info.txt'
-    if args.dbinfo_out == 'AUTO':
-        args.dbinfo_out = args.temp_dir + 'subset_db_info.txt'
-    if args.db == 'AUTO':
-        args.db = args.temp_dir + 'cmashed_db.fna'
+    args.temp_dir = cli.with_slash(args.temp_dir)
+    os.makedirs(args.temp_dir, exist_ok=True)
+    for attr, default in (('dbinfo_in', args.data + 'db_info.txt'), ('dbinfo_out', args.temp_dir + 'subset_db_info.txt'),
+                          ('db', args.temp_dir + 'cmashed_db.fna')):
+        if getattr(args, attr) == 'AUTO':
+            setattr(args, attr, default)
     if args.input_type == 'AUTO':
-        parts = args.reads.split('.')
-        if parts[-1] == 'gz':
-            parts = parts[:-1]
-        if parts[-1] in ('fq', 'fastq'):
-            args.input_type = 'fastq'
-        elif parts[-1] in ('fa', 'fna', 'fasta'):
-            args.input_type = 'fasta'
-        else:
-            sys.exit('Could not auto-determine file type. Use --input_type.')
+        args.input_type = cli.sniff_reads_type(args.reads)
 
     taxid2info = read_dbinfo(args)
     if args.cmash_results == 'NONE':
