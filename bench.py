@@ -161,8 +161,8 @@ def main():
         k1_avg = k1_ms / max(nk1, 1)
         achieved = ALGO_BYTES_PER_READ_K1 * args.reads / (k1_avg * 1e-3) / 1e9 if nk1 else 0.0
         kernels = {}
-        for name in ("table_clear", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort", "sketch_rle", "contain_index", "containment", "profile_maps",
-                     "profile_scan", "profile_commit", "profile_scan_mm", "profile_fill_mm"):
+        for name in ("table_clear", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort", "sketch_rle", "contain_index", "containment", "profile_map",
+                     "profile_pass"):
             n, t = hip.prof_get(name)
             if n:
                 kernels[name] = round(t / n, 4)

@@ -1,4 +1,4 @@
-// mg_profile.hip — Stage C: per-read taxon assignment + abundance histogram.
+// mg_profile.hip — Stage C: per-read taxon assignment + abundance histogram, ONE pass over the records.
 //
 // Replaces the loop of map_and_process (scripts/map_and_profile.py:193-264).
 // The reference loop carries one bit across read boundaries: when a read is
@@ -8,25 +8,39 @@
 //     A_g : {first line kept, first line dropped} -> {next kept, next dropped}
 // and the true state of every read is the prefix composition of these maps
 // (associative, not commutative) started from "dropped" (the phantom first
-// boundary, :155-156).  Pipeline:
-//   k_profile_maps     per record: leaders evaluate A_g(0), A_g(1); per-block
-//                      ordered composition (wave shuffles + LDS)
-//   k_profile_scan     one block: exclusive composition over block aggregates
-//   k_profile_commit   per record: in-block ordered scan gives each leader its
-//                      true state; the read is classified once; unique reads go
-//                      to an LDS-privatised histogram (count, bases, first
-//                      seen) flushed with global atomics; multimapped reads
-//                      record their list length
-//   k_profile_scan_mm  one block: exclusive sums of the per-tile multimapped totals
-//   k_profile_fill_mm  writes the multimapped CSR (lists in SAM order)
-// Records are 16 B and are streamed with coalesced 16-byte loads.
+// boundary, :155-156).
+//
+// k_profile_pass is a single-pass chained scan (decoupled look-back) over tiles of 2048 records:
+//   1. the tile's records are loaded once (coalesced 16 B loads), reduced to 8-byte descriptors
+//      {taxon, new-read / rejected / pair bits, len(SEQ)} (the fp64 division of filter_line :96-99 is done once
+//      per record) and parked in LDS;
+//   2. every read leader classifies its read under BOTH hypotheses (process_read :152-176) from LDS; a thread
+//      folds its 8 consecutive records into a function of the state entering it: outgoing state, multimapped
+//      reads and list entries it would emit; an ordered workgroup scan composes these functions;
+//   3. the tile publishes its aggregate AS A FUNCTION of the state entering it (two 64-bit words);
+//   4. one wavefront looks back over the preceding tiles' descriptors, 256 per step, composing them with an
+//      ordered butterfly until it meets an inclusive prefix, and publishes its own inclusive prefix — tiles are
+//      handed out by an atomic ticket, so every predecessor is resident or finished and the look-back cannot
+//      dead-lock;
+//   5. with the incoming state and the exclusive read / multimapped offsets known, the leaders classify once
+//      more (from LDS, true hypothesis only) and commit: unique reads into an LDS-privatised histogram (count,
+//      bases, first-seen) that the workgroup keeps across its tiles and flushes once with global atomics,
+//      multimapped reads straight into the CSR (SAM order).
+// HBM traffic: 16 B per record, once (the previous version read the records three times, wrote and re-read
+// 5 B of scratch per record and ran two single-workgroup scans: 17.2 ms at 125 M records).
+// COMMIT = false is the same chain without step 5: the shard's composed state map and read count, which a
+// multi-GPU job needs from every shard before any of them can commit.
 #include <memory>
 
 #include "mg_internal.h"
 
 namespace mg {
 
-constexpr int kPB = 256;  // threads per block == records per tile
+constexpr int kPB = 256;                 // threads per workgroup
+constexpr int kItems = 8;                // consecutive records per thread
+constexpr int kTile = kPB * kItems;      // records per tile
+constexpr int kHalo = 64;                // descriptors staged past the tile end (a read's lines + its closing line)
+constexpr int kStaged = kTile + kHalo;
 
 struct Verdict {
   uint32_t kind;  // 0 Ambiguous, 1 unique, 2 multimapped
@@ -35,44 +49,73 @@ struct Verdict {
   uint32_t nmm;
 };
 
-__device__ __forceinline__ bool rec_pair1(uint32_t flag) { return (flag & 1u) && (flag & 64u); }   // :106
-__device__ __forceinline__ bool rec_pair2(uint32_t flag) { return (flag & 1u) && (flag & 128u); }  // :107
+// 8-byte digest of one record: all that process_read needs.
+constexpr uint32_t D_NEW = 1u, D_REJ = 2u, D_P1 = 4u, D_P2 = 8u;
+constexpr int D_LEN_SHIFT = 12;
 
-// filter_line (:86-100) or chimeric (:108,135)
-__device__ __forceinline__ bool rec_rejected(const mg_aln_rec& r, double pct_id) {
-  return ((double)r.matched / (double)r.total < pct_id) || (r.flag_len & 2048u);
+__device__ __forceinline__ uint2 make_desc(const mg_aln_rec& r, uint32_t tax, double pct_id) {
+  const uint32_t fl = r.flag_len & MG_REC_FLAG_MASK;
+  const bool a = (fl & 1u) && (fl & 64u);   // parse_flag :106
+  const bool b = (fl & 1u) && (fl & 128u);  // :107
+  // filter_line (:86-100) or chimeric (:108,135)
+  const bool rej = ((double)r.matched / (double)r.total < pct_id) || (fl & 2048u);
+  uint2 d;
+  d.x = tax;
+  d.y = (r.ref_new >> 31) | (rej ? D_REJ : 0u) | (a ? D_P1 : 0u) | (b ? D_P2 : 0u) |
+        ((r.flag_len >> MG_REC_LEN_SHIFT) << D_LEN_SHIFT);
+  return d;
 }
 
-// process_read (:152-176) over the lines [s, e); next_flag = FLAG of the line that closes the read
-// (its pair bits are the `pair1, pair2` passed at :225-226).  mm_out: where to write the taxon list
-// of a multimapped read (nullptr = only count it).
-__device__ Verdict eval_group(const mg_aln_rec* __restrict__ recs, uint64_t s, uint64_t e, uint32_t next_flag,
-                              const uint32_t* __restrict__ ref2tax, double pct_id, uint32_t* mm_out) {
+// LDS slot of the tile-local record index i: one pad slot per kItems, so that the threads' strided
+// accesses (thread t owns records kItems*t ..) fall into distinct banks.
+__device__ __forceinline__ uint32_t slot(uint32_t i) { return i + (i >> 3); }
+constexpr int kSlots = kStaged + (kStaged >> 3) + 1;
+
+// Descriptors of records [t0, t0 + nst) live in LDS; anything past that (a read longer than the halo) is
+// rebuilt from HBM.
+struct DescView {
+  const uint2* lds;
+  uint64_t t0;
+  uint32_t nst;
+  const mg_aln_rec* __restrict__ recs;
+  const uint32_t* __restrict__ ref2tax;
+  double pct_id;
+  __device__ __forceinline__ uint2 operator()(uint64_t i) const {
+    if (i - t0 < nst) return lds[slot((uint32_t)(i - t0))];
+    const mg_aln_rec r = recs[i];
+    return make_desc(r, ref2tax[r.ref_new & MG_REC_REF_MASK], pct_id);
+  }
+};
+
+// process_read (:152-176) over the lines [s, e), any length, any flags; next_paired = the line that closes the
+// read carries pair flags (the `pair1, pair2` passed at :225-226).  mm_out: where to write the taxon list of a
+// multimapped read (nullptr = only count it).  The kernel calls this for the reads its straight-line path does
+// not cover: both mates mapped (set intersection, :115-125) and reads longer than the staged window.
+__device__ __forceinline__ Verdict eval_group(const DescView& at, uint64_t s, uint64_t e, bool next_paired, uint32_t* mm_out) {
   Verdict v{0, 0, 0, 0};
   long p1 = 0, p2 = 0;
   uint64_t nk = 0;
   for (uint64_t i = s; i < e; ++i) {  // appends (:257-258) then clean_read_hits (:130-147)
-    const mg_aln_rec r = recs[i];
-    const uint32_t fl = r.flag_len & MG_REC_FLAG_MASK;
-    const bool a = rec_pair1(fl), b = rec_pair2(fl);
+    const uint2 d = at(i);
+    const bool a = d.y & D_P1, b = d.y & D_P2;
     p1 += (a || !(a || b)) ? 1 : 0;
     p2 += b ? 1 : 0;
-    if (rec_rejected(r, pct_id)) {
+    if (d.y & D_REJ) {
       if (a) p1 -= 1; else if (b) p2 -= 1;
     } else {
-      if (nk == 0) v.tax = ref2tax[r.ref_new & MG_REC_REF_MASK];
+      if (nk == 0) v.tax = d.x;
       ++nk;
     }
-    v.hitlen += r.flag_len >> MG_REC_LEN_SHIFT;
+    v.hitlen += d.y >> D_LEN_SHIFT;
   }
   if (nk == 0) return v;  // :155-156
-  auto kept = [&](uint64_t i) { return !rec_rejected(recs[i], pct_id); };
-  auto tax = [&](uint64_t i) { return ref2tax[recs[i].ref_new & MG_REC_REF_MASK]; };
+  auto kept = [&](uint64_t i) { return !(at(i).y & D_REJ); };
+  auto tax = [&](uint64_t i) { return at(i).x; };
   auto emit = [&](uint32_t t) {
     if (mm_out) mm_out[v.nmm] = t;
     ++v.nmm;
   };
-  if (rec_pair1(next_flag) || rec_pair2(next_flag)) {  // :157
+  if (next_paired) {                                   // :157
     if (p1 + p2 == 1) { v.kind = 1; return v; }         // :158-160
     if (p1 == 0 || p2 == 0) return v;                   // :116-117 -> :164-165
     uint64_t split = p1 < 0 ? 0 : (uint64_t)p1;
@@ -127,184 +170,215 @@ __device__ Verdict eval_group(const mg_aln_rec* __restrict__ recs, uint64_t s, u
   return v;
 }
 
+// Counters of clean_read_hits (:130-147) over staged lines [s, e) (tile-local indices).
+struct Walk {
+  int p1, p2;
+  uint32_t nk, tax;  // kept lines, taxon of the first kept line
+  uint64_t hsum;     // sum of len(SEQ) over all lines
+};
+__device__ __forceinline__ void walk_add(Walk& w, const uint2 d) {
+  const bool a = d.y & D_P1, b = d.y & D_P2, rej = d.y & D_REJ;
+  w.p1 += ((a || !b) ? 1 : 0) - ((rej && a) ? 1 : 0);
+  w.p2 += (b ? 1 : 0) - ((rej && !a && b) ? 1 : 0);
+  if (!rej) {
+    if (w.nk == 0) w.tax = d.x;
+    ++w.nk;
+  }
+  w.hsum += d.y >> D_LEN_SHIFT;
+}
+// process_read's decision from the counters: kind | nmm << 2; kind 3 = needs the set intersection (eval_group).
+__device__ __forceinline__ uint32_t classify(const Walk& w, bool next_paired) {
+  if (w.nk == 0) return 0u;                           // :155-156
+  if (next_paired) {                                  // :157
+    if (w.p1 + w.p2 == 1) return 1u;                  // :158-160
+    if (w.p1 == 0 || w.p2 == 0) return 0u;            // :116-117 -> :164-165
+    return 3u;
+  }
+  if (w.p1 > 1) return 2u | (w.nk << 2);              // :172-173
+  return 1u;                                          // :174-176
+}
+
 // State maps: bit0 = f(0), bit1 = f(1); x = 1 means "first line dropped".
 constexpr uint32_t kIdentity = 2u;
 __device__ __forceinline__ uint32_t map_then(uint32_t first, uint32_t second) {
   return ((second >> (first & 1u)) & 1u) | (((second >> ((first >> 1) & 1u)) & 1u) << 1);
 }
 
-// End of the group led by record i: index of the next record with the new-read bit, or ntotal.
-__device__ __forceinline__ uint64_t group_end(const mg_aln_rec* __restrict__ recs, uint64_t i, uint64_t ntotal) {
-  uint64_t j = i + 1;
-  while (j < ntotal && !(recs[j].ref_new & MG_REC_NEW_BIT)) ++j;
-  return j;
+// A run of records as a function of the state x entering it: outgoing state and what it emits.
+// pk[x] packs multimapped list entries (bits 0..35), multimapped reads (36..49) and reads (50..63) of at most
+// one tile.
+struct RunFn {
+  uint32_t out;
+  uint64_t pk[2];
+};
+__device__ __forceinline__ RunFn run_then(const RunFn& f, const RunFn& s) {
+  RunFn o;
+  o.out = map_then(f.out, s.out);
+  o.pk[0] = f.pk[0] + ((f.out & 1u) ? s.pk[1] : s.pk[0]);  // selects, not indexing: the pair stays in registers
+  o.pk[1] = f.pk[1] + ((f.out & 2u) ? s.pk[1] : s.pk[0]);
+  return o;
 }
+constexpr int kPkMmShift = 36, kPkReadShift = 50;
+constexpr uint64_t kPkOneMm = 1ull << kPkMmShift, kPkOneRead = 1ull << kPkReadShift;
+__device__ __forceinline__ uint64_t pk_ent(uint64_t pk) { return pk & (kPkOneMm - 1); }
+__device__ __forceinline__ uint64_t pk_mm(uint64_t pk) { return (pk >> kPkMmShift) & 0x3fffull; }
+__device__ __forceinline__ uint64_t pk_reads(uint64_t pk) { return pk >> kPkReadShift; }
+static_assert(kTile < (1 << 13), "tile counters are 13-bit fields in the published aggregate");
 
-// Ordered inclusive scan of maps across the block; returns the EXCLUSIVE prefix for this thread
-// and the block aggregate in *total.  lds: 4 words.
-__device__ __forceinline__ uint32_t block_scan_maps(uint32_t m, uint32_t* lds, uint32_t* total) {
+// Ordered inclusive scan of RunFn across the workgroup; returns the EXCLUSIVE prefix of this thread and the
+// workgroup aggregate.  lds: kPB / 64 entries.
+__device__ __forceinline__ RunFn block_scan_runs(const RunFn& mine, RunFn* lds, RunFn* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = m;
+  RunFn inc = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    uint32_t prev = __shfl_up(inc, o, 64);
-    if (lane >= o) inc = map_then(prev, inc);
+    RunFn prev;
+    prev.out = __shfl_up(inc.out, o, 64);
+    prev.pk[0] = __shfl_up(inc.pk[0], o, 64);
+    prev.pk[1] = __shfl_up(inc.pk[1], o, 64);
+    if (lane >= o) inc = run_then(prev, inc);
   }
   if (lane == 63) lds[wave] = inc;
   __syncthreads();
-  uint32_t before = kIdentity, all = kIdentity;
+  RunFn before{kIdentity, {0, 0}}, all{kIdentity, {0, 0}};
 #pragma unroll
   for (int w = 0; w < kPB / 64; ++w) {
-    if (w < wave) before = map_then(before, lds[w]);
-    all = map_then(all, lds[w]);
+    const RunFn t = lds[w];
+    if (w < wave) before = run_then(before, t);
+    all = run_then(all, t);
   }
-  uint32_t excl = __shfl_up(inc, 1, 64);
-  if (lane == 0) excl = kIdentity;
+  RunFn excl;
+  excl.out = __shfl_up(inc.out, 1, 64);
+  excl.pk[0] = __shfl_up(inc.pk[0], 1, 64);
+  excl.pk[1] = __shfl_up(inc.pk[1], 1, 64);
+  if (lane == 0) excl = RunFn{kIdentity, {0, 0}};
   __syncthreads();
   *total = all;
-  return map_then(before, excl);
+  return run_then(before, excl);
 }
 
-// Exclusive count of set flags before this thread within the block, and the block total.
-__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* lds, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long m = __ballot(flag);
-  if (lane == 0) lds[wave] = __popcll(m);
-  __syncthreads();
-  uint32_t before = 0, all = 0;
+// ---- tile descriptors of the chained scan ----
+// Three 64-bit words per tile, each carrying the status in its top two bits, so that a reader needs no fence:
+// it re-reads until the three statuses agree.
+//   AGG     w[x] (x = 0, 1) = status | out(x):1 | reads:13 | mm_reads(x):13 | mm_entries(x):35 ;  w[2] = status
+//   PREFIX  w[0] = status | map:2 | reads (inclusive) ; w[1] = status | mm_reads ; w[2] = status | mm_entries
+constexpr uint64_t ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = 3ull << 62;
+constexpr int kDescWords = 4;  // 32-byte stride
+constexpr int kWin = 4;        // descriptors per lane and look-back step (window = 256 tiles)
+
+struct TileFn {  // aggregate of a run of tiles as a function of the state entering it
+  uint32_t out;  // 2-bit map
+  uint64_t g;    // reads
+  uint64_t r[2], e[2];
+};
+__device__ __forceinline__ TileFn fn_identity() { return TileFn{kIdentity, 0, {0, 0}, {0, 0}}; }
+__device__ __forceinline__ TileFn fn_then(const TileFn& f, const TileFn& s) {
+  TileFn o;
+  o.out = map_then(f.out, s.out);
+  o.g = f.g + s.g;
 #pragma unroll
-  for (int w = 0; w < kPB / 64; ++w) {
-    if (w < wave) before += lds[w];
-    all += lds[w];
+  for (int x = 0; x < 2; ++x) {
+    const uint32_t mid = (f.out >> x) & 1u;
+    o.r[x] = f.r[x] + (mid ? s.r[1] : s.r[0]);
+    o.e[x] = f.e[x] + (mid ? s.e[1] : s.e[0]);
   }
-  __syncthreads();
-  *total = all;
-  return before + __popcll(m & ((1ull << lane) - 1ull));
+  return o;
+}
+__device__ __forceinline__ uint64_t agg_word(uint32_t out_x, uint64_t g, uint64_t r, uint64_t e) {
+  return ST_AGG | ((uint64_t)out_x << 61) | (g << 48) | (r << 35) | e;
+}
+// Descriptor words -> function.  An inclusive prefix is a function of the state entering the SHARD whose
+// counts are those of the true path (the look-back only ever evaluates it there); everything farther back is
+// already folded into it.
+__device__ __forceinline__ TileFn fn_from_words(uint64_t w0, uint64_t w1, uint64_t w2) {
+  TileFn f;
+  if ((w0 & ST_MASK) == ST_PREFIX) {
+    f.out = (uint32_t)(w0 >> 60) & 3u;
+    f.g = w0 & ((1ull << 60) - 1);
+    f.r[0] = f.r[1] = w1 & ~ST_MASK;
+    f.e[0] = f.e[1] = w2 & ~ST_MASK;
+  } else {
+    f.out = (uint32_t)((w0 >> 61) & 1u) | ((uint32_t)((w1 >> 61) & 1u) << 1);
+    f.g = (w0 >> 48) & 0x1fffull;
+    f.r[0] = (w0 >> 35) & 0x1fffull; f.e[0] = w0 & ((1ull << 35) - 1);
+    f.r[1] = (w1 >> 35) & 0x1fffull; f.e[1] = w1 & ((1ull << 35) - 1);
+  }
+  return f;
+}
+__device__ __forceinline__ TileFn fn_shfl_xor(const TileFn& f, int o) {
+  TileFn t;
+  t.out = __shfl_xor(f.out, o, 64);
+  t.g = __shfl_xor(f.g, o, 64);
+  t.r[0] = __shfl_xor(f.r[0], o, 64); t.r[1] = __shfl_xor(f.r[1], o, 64);
+  t.e[0] = __shfl_xor(f.e[0], o, 64); t.e[1] = __shfl_xor(f.e[1], o, 64);
+  return t;
 }
 
-__global__ __launch_bounds__(kPB) void k_profile_maps(const mg_aln_rec* __restrict__ recs, uint64_t nrecs,
-                                                      uint64_t ntotal, const uint32_t* __restrict__ ref2tax,
-                                                      double pct_id, uint8_t* __restrict__ maps,
-                                                      uint8_t* __restrict__ blk_map, uint32_t* __restrict__ blk_groups) {
-  __shared__ uint32_t lds[8];
-  const uint64_t i = (uint64_t)blockIdx.x * kPB + threadIdx.x;
-  uint32_t m = kIdentity;
-  bool leader = false;
-  if (i < nrecs && (recs[i].ref_new & MG_REC_NEW_BIT)) {
-    leader = true;
-    const uint64_t e = group_end(recs, i, ntotal);
-    if (e < ntotal) {  // a following boundary exists: this read IS processed (:225-226)
-      const uint32_t nf = recs[e].flag_len & MG_REC_FLAG_MASK;
-      const uint32_t a0 = eval_group(recs, i, e, nf, ref2tax, pct_id, nullptr).kind == 0;
-      const uint32_t a1 = eval_group(recs, i + 1, e, nf, ref2tax, pct_id, nullptr).kind == 0;
-      m = a0 | (a1 << 1);
+__device__ __forceinline__ uint64_t ld_desc(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_desc(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Incoming {  // what a tile learns from its predecessors
+  uint32_t map;    // composed map from the shard start to the tile start
+  uint64_t g, r, e;
+};
+
+constexpr int kLbWaves = 1;     // wavefronts that look back together: kLbWaves x 64 x kWin tiles per round
+
+// Executed by one whole wavefront: folds the window of 64 * kWin tiles whose nearest member is tile `base`
+// (lane l inspects the tiles base - kWin*l - c, c = 0 .. kWin-1), stopping at the nearest inclusive prefix.
+// Returns once every tile nearer than that prefix (all of them, if there is none) is published.
+__device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc, int64_t base, bool* found) {
+  const int lane = threadIdx.x & 63;
+  TileFn f;
+  int p_lane;
+  uint64_t w[kWin][3];
+  uint32_t have = 0;  // this lane's tiles seen published; only the others are polled again
+  for (;;) {
+#pragma unroll
+    for (int c = 0; c < kWin; ++c) {  // all loads in flight together: one round trip per attempt
+      const int64_t k = base - (lane * kWin + c);
+      if (have & (1u << c)) continue;
+      if (k >= 0) {
+        const uint64_t* d = desc + (uint64_t)k * kDescWords;
+        w[c][0] = ld_desc(d); w[c][1] = ld_desc(d + 1); w[c][2] = ld_desc(d + 2);
+      } else {  // before tile 0: the empty prefix
+        w[c][0] = ST_PREFIX | ((uint64_t)kIdentity << 60); w[c][1] = ST_PREFIX; w[c][2] = ST_PREFIX;
+      }
     }
+    f = fn_identity();
+    bool ok = true, pfx = false;
+#pragma unroll
+    for (int c = 0; c < kWin; ++c) {
+      const uint64_t s0 = w[c][0] & ST_MASK;
+      const bool pub = s0 != 0 && s0 == (w[c][1] & ST_MASK) && s0 == (w[c][2] & ST_MASK);
+      if (pub) have |= 1u << c;
+      if (ok && !pfx) {
+        if (!pub) ok = false;
+        else {
+          f = fn_then(fn_from_words(w[c][0], w[c][1], w[c][2]), f);  // farther tile: prepend
+          pfx = s0 == ST_PREFIX;
+        }
+      }
+    }
+    const unsigned long long pm = __ballot(ok && pfx);
+    p_lane = pm ? __ffsll((long long)pm) - 1 : 64;
+    if (__ballot(lane <= p_lane && !ok) == 0ull) break;
+    if (lane > p_lane) have = (1u << kWin) - 1u;  // beyond the nearest prefix: nothing more to poll
+    __builtin_amdgcn_s_sleep(2);
   }
-  if (i < nrecs) maps[i] = (uint8_t)m;
-  uint32_t total, ngroups;
-  (void)block_scan_maps(m, lds, &total);
-  (void)block_rank(leader, lds + 4, &ngroups);
-  if (threadIdx.x == 0) { blk_map[blockIdx.x] = (uint8_t)total; blk_groups[blockIdx.x] = ngroups; }
-}
-
-// ---- helpers for the single-block (1024 threads) scans over per-tile aggregates ----
-template <int NT>
-__device__ __forceinline__ uint64_t blockN_excl_sum(uint64_t v, uint64_t* lds, uint64_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint64_t inc = v;
+  if (lane > p_lane) f = fn_identity();  // farther than the prefix: already folded into it
+  // ordered butterfly over the lanes (lane 63 is the farthest)
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    uint64_t prev = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += prev;
+    const TileFn t = fn_shfl_xor(f, o);
+    f = (lane & o) ? fn_then(f, t) : fn_then(t, f);
   }
-  if (lane == 63) lds[wave] = inc;
-  __syncthreads();
-  uint64_t before = 0, all = 0;
-#pragma unroll
-  for (int w = 0; w < NT / 64; ++w) {
-    const uint64_t t = lds[w];
-    if (w < wave) before += t;
-    all += t;
-  }
-  __syncthreads();
-  *total = all;
-  return before + inc - v;
-}
-
-template <int NT>
-__device__ __forceinline__ uint32_t blockN_excl_map(uint32_t m, uint32_t* lds, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = m;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t prev = __shfl_up(inc, o, 64);
-    if (lane >= o) inc = map_then(prev, inc);
-  }
-  if (lane == 63) lds[wave] = inc;
-  __syncthreads();
-  uint32_t before = kIdentity, all = kIdentity;
-#pragma unroll
-  for (int w = 0; w < NT / 64; ++w) {
-    const uint32_t t = lds[w];
-    if (w < wave) before = map_then(before, t);
-    all = map_then(all, t);
-  }
-  uint32_t excl = __shfl_up(inc, 1, 64);
-  if (lane == 0) excl = kIdentity;
-  __syncthreads();
-  *total = all;
-  return map_then(before, excl);
-}
-
-// One block.  In: per-tile aggregates.  Out: exclusive prefixes per tile, totals in out_tot[0..1].
-__global__ __launch_bounds__(1024) void k_profile_scan(const uint8_t* __restrict__ blk_map,
-                                                       const uint32_t* __restrict__ blk_groups, uint64_t nblocks,
-                                                       uint8_t* __restrict__ pre_map, uint64_t* __restrict__ pre_groups,
-                                                       uint64_t* __restrict__ out_tot) {
-  __shared__ uint32_t s_map[16];
-  __shared__ uint64_t s_grp[16];
-  const uint64_t per = (nblocks + 1023) / 1024;
-  const uint64_t b0 = (uint64_t)threadIdx.x * per;
-  const uint64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
-  uint32_t m = kIdentity;
-  uint64_t g = 0;
-  for (uint64_t b = b0; b < b1; ++b) { m = map_then(m, blk_map[b]); g += blk_groups[b]; }
-  uint32_t tot_m;
-  uint64_t tot_g;
-  m = blockN_excl_map<1024>(m, s_map, &tot_m);
-  g = blockN_excl_sum<1024>(g, s_grp, &tot_g);
-  if (threadIdx.x == 0) { out_tot[0] = tot_m; out_tot[1] = tot_g; }
-  for (uint64_t b = b0; b < b1; ++b) {
-    pre_map[b] = (uint8_t)m;
-    pre_groups[b] = g;
-    m = map_then(m, blk_map[b]);
-    g += blk_groups[b];
-  }
-}
-
-// One block: exclusive sums of the per-tile multimapped entry / read totals (in place), grand totals out.
-__global__ __launch_bounds__(1024) void k_profile_scan_mm(uint64_t* __restrict__ tile_ent,
-                                                          uint64_t* __restrict__ tile_reads, uint64_t ntiles,
-                                                          uint64_t* __restrict__ out_tot,
-                                                          uint64_t* __restrict__ mm_offsets) {
-  __shared__ uint64_t s_a[16];
-  __shared__ uint64_t s_b[16];
-  const uint64_t per = (ntiles + 1023) / 1024;
-  const uint64_t b0 = (uint64_t)threadIdx.x * per;
-  const uint64_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
-  uint64_t e = 0, r = 0;
-  for (uint64_t b = b0; b < b1; ++b) { e += tile_ent[b]; r += tile_reads[b]; }
-  uint64_t tot_e, tot_r;
-  e = blockN_excl_sum<1024>(e, s_a, &tot_e);
-  r = blockN_excl_sum<1024>(r, s_b, &tot_r);
-  if (threadIdx.x == 0) { out_tot[2] = tot_e; out_tot[3] = tot_r; mm_offsets[tot_r] = tot_e; }
-  for (uint64_t b = b0; b < b1; ++b) {
-    const uint64_t te = tile_ent[b], tr = tile_reads[b];
-    tile_ent[b] = e;
-    tile_reads[b] = r;
-    e += te;
-    r += tr;
-  }
+  *found = p_lane < 64;
+  return f;
 }
 
 // Per-workgroup privatised histogram in LDS, flushed with global atomics at the end:
@@ -312,130 +386,262 @@ __global__ __launch_bounds__(1024) void k_profile_scan_mm(uint64_t* __restrict__
 //   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
 //                      fewer taxa than the table lists); a taxon that finds no bin within kHashProbe steps
 //                      goes to global atomics directly.  Without this a skewed sample serialises millions of
-//                      global atomics on a few hundred addresses (8.6 ms -> see DESIGN.md at 12.5 M records).
+//                      global atomics on a few hundred addresses.
 constexpr uint32_t kHashSlots = 2048, kHashProbe = 32;
-__global__ __launch_bounds__(kPB) void k_profile_commit(
-    const mg_aln_rec* __restrict__ recs, uint64_t nrecs, uint64_t ntotal, const uint32_t* __restrict__ ref2tax,
-    double pct_id, uint8_t* __restrict__ maps, const uint8_t* __restrict__ pre_map,
-    const uint64_t* __restrict__ pre_groups, uint32_t incoming, uint32_t first_shard, uint64_t group_base,
-    uint32_t ntax, uint32_t use_lds_hist, unsigned long long* __restrict__ g_count,
-    unsigned long long* __restrict__ g_bases, unsigned long long* __restrict__ g_first,
-    unsigned long long* __restrict__ g_scalars, uint32_t* __restrict__ mm_cnt, uint64_t* __restrict__ tile_ent,
-    uint64_t* __restrict__ tile_reads, uint64_t ntiles) {
+
+struct PassArgs {
+  const mg_aln_rec* recs;
+  uint64_t nrecs, ntotal;
+  const uint32_t* ref2tax;
+  double pct_id;
+  uint64_t* desc;                 // [ntiles][kDescWords], zeroed
+  unsigned long long* ticket;     // zeroed
+  uint64_t ntiles;
+  uint32_t incoming, first_shard;
+  uint64_t group_base;
+  uint32_t ntax, use_lds_hist;
+  unsigned long long *g_count, *g_bases, *g_first, *g_scalars;
+  uint64_t* mm_offsets; uint32_t* mm_tax; uint64_t* mm_hitlen; uint64_t* mm_read;
+  uint64_t* out_tot;              // [0] composed map, [1] reads, [2] multimapped entries, [3] multimapped reads
+};
+
+template <bool COMMIT>
+__global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
-  __shared__ uint32_t lds[8];
-  __shared__ uint64_t lds64[4];
+  __shared__ uint2 s_desc[kSlots];
+  __shared__ RunFn s_run[kPB / 64];
+  __shared__ uint64_t s_bcast[4];
+  __shared__ TileFn s_lb[kLbWaves];
+  __shared__ uint32_t s_lbf[kLbWaves + 1];
+  __shared__ unsigned long long s_ticket;
   __shared__ unsigned long long s_ambig, s_groups;
-  const uint32_t nbins = use_lds_hist == 2 ? kHashSlots : ntax;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nbins = A.use_lds_hist == 2 ? kHashSlots : A.ntax;
   unsigned long long* h_count = hist;
   unsigned long long* h_bases = hist + nbins;
   unsigned long long* h_first = hist + 2 * (size_t)nbins;
   uint32_t* h_key = reinterpret_cast<uint32_t*>(hist + 3 * (size_t)nbins);  // hashed mode only
-  if (use_lds_hist) {
-    for (uint32_t t = threadIdx.x; t < nbins; t += kPB) {
+  if (COMMIT && A.use_lds_hist) {
+    for (uint32_t t = tid; t < nbins; t += kPB) {
       h_count[t] = 0; h_bases[t] = 0; h_first[t] = ~0ull;
-      if (use_lds_hist == 2) h_key[t] = 0xffffffffu;
+      if (A.use_lds_hist == 2) h_key[t] = 0xffffffffu;
     }
   }
-  if (threadIdx.x == 0) { s_ambig = (blockIdx.x == 0 && first_shard) ? 1ull : 0ull; s_groups = 0; }
+  if (tid == 0) { s_ambig = 0; s_groups = 0; }
   __syncthreads();
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t i = tile * kPB + threadIdx.x;
-    uint32_t m = kIdentity;
-    bool leader = false;
-    if (i < nrecs) {
-      m = maps[i];
-      leader = (recs[i].ref_new & MG_REC_NEW_BIT) != 0;
+
+  for (;;) {
+    if (tid == 0) s_ticket = atomicAdd(A.ticket, 1ull);  // tiles are handed out in order
+    __syncthreads();
+    const uint64_t tile = s_ticket;
+    if (tile >= A.ntiles) break;
+    const uint64_t t0 = tile * kTile;
+    const uint32_t nst = (uint32_t)(A.ntotal - t0 < (uint64_t)kStaged ? A.ntotal - t0 : (uint64_t)kStaged);  // staged
+    const uint32_t nown = (uint32_t)(A.nrecs - t0 < (uint64_t)kTile ? A.nrecs - t0 : (uint64_t)kTile);      // owned
+    // 1. records -> descriptors in LDS (coalesced 16-byte loads, one division per record)
+    for (uint32_t i = tid; i < nst; i += kPB) {
+      const mg_aln_rec r = A.recs[t0 + i];
+      s_desc[slot(i)] = make_desc(r, A.ref2tax[r.ref_new & MG_REC_REF_MASK], A.pct_id);
     }
-    uint32_t blk_total, ngroups;
-    const uint32_t excl = block_scan_maps(m, lds, &blk_total);
-    const uint32_t rank = block_rank(leader, lds + 4, &ngroups);
-    const uint32_t x_b = (pre_map[tile] >> incoming) & 1u;  // state at the start of this tile
-    uint32_t my_cnt = 0;
-    if (leader) {
-      const uint32_t d = (excl >> x_b) & 1u;  // 1: this read's first line was dropped (:232)
-      const uint64_t e = group_end(recs, i, ntotal);
-      maps[i] = (uint8_t)d;
-      if (e < ntotal) {
-        const uint32_t nf = recs[e].flag_len & MG_REC_FLAG_MASK;
-        const Verdict v = eval_group(recs, i + d, e, nf, ref2tax, pct_id, nullptr);
-        if (v.kind == 0) {
-          atomicAdd(&s_ambig, 1ull);
-        } else if (v.kind == 1) {
-          const unsigned long long gidx = group_base + pre_groups[tile] + rank;
-          uint32_t bin = v.tax;
-          bool in_lds = use_lds_hist == 1;
-          if (use_lds_hist == 2) {
-            uint32_t p = (v.tax * 2654435761u) >> 21;  // 11 bits: kHashSlots
+    __syncthreads();
+    const DescView at{s_desc, t0, nst, A.recs, A.ref2tax, A.pct_id};
+
+    // 2. leaders classify their read under both hypotheses; the thread's 8 records fold into one RunFn
+    const uint32_t l0 = (uint32_t)tid * kItems;
+    RunFn mine{kIdentity, {0, 0}};
+    {
+      uint32_t st0 = 0, st1 = 1;  // state after the records seen so far, for the thread entered kept / dropped
+      for (int j = 0; j < kItems; ++j) {
+        const uint32_t li = l0 + j;
+        if (li >= nown) break;
+        const uint2 d = s_desc[slot(li)];
+        if (!(d.y & D_NEW)) continue;
+        mine.pk[0] += kPkOneRead;
+        mine.pk[1] += kPkOneRead;
+        uint32_t e = li + 1;
+        while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
+        uint32_t k0, k1;  // kind | nmm << 2 under "kept" / "dropped"
+        if (e < nst) {
+          const bool np = s_desc[slot(e)].y & (D_P1 | D_P2);
+          Walk w{0, 0, 0, 0, 0}, w1{0, 0, 0, 0, 0};
+          walk_add(w, d);
+          for (uint32_t q = li + 1; q < e; ++q) {  // "dropped" is the same read without its first line
+            const uint2 dq = s_desc[slot(q)];
+            walk_add(w, dq);
+            walk_add(w1, dq);
+          }
+          k0 = classify(w, np);
+          k1 = classify(w1, np);
+          if (k0 == 3u) { const Verdict v = eval_group(at, t0 + li, t0 + e, true, nullptr); k0 = v.kind | (v.nmm << 2); }
+          if (k1 == 3u) { const Verdict v = eval_group(at, t0 + li + 1, t0 + e, true, nullptr); k1 = v.kind | (v.nmm << 2); }
+        } else {  // the read runs past the staged window (or to the end of the shard)
+          uint64_t ge = t0 + e;
+          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
+          if (ge >= A.ntotal) continue;  // no closing line: the read is never processed (:259-264)
+          const bool np = at(ge).y & (D_P1 | D_P2);
+          const Verdict v0 = eval_group(at, t0 + li, ge, np, nullptr);
+          const Verdict v1 = eval_group(at, t0 + li + 1, ge, np, nullptr);
+          k0 = v0.kind | (v0.nmm << 2);
+          k1 = v1.kind | (v1.nmm << 2);
+        }
+        // advance both paths through this read
+        const uint32_t ka = st0 ? k1 : k0, kb = st1 ? k1 : k0;
+        if (COMMIT) {
+          if ((ka & 3u) == 2u) mine.pk[0] += kPkOneMm + (ka >> 2);
+          if ((kb & 3u) == 2u) mine.pk[1] += kPkOneMm + (kb >> 2);
+        }
+        st0 = (ka & 3u) == 0u;
+        st1 = (kb & 3u) == 0u;
+      }
+      mine.out = st0 | (st1 << 1);
+    }
+    // 3. ordered scan over the workgroup; tile aggregate
+    RunFn tile_fn;
+    const RunFn excl = block_scan_runs(mine, s_run, &tile_fn);
+    // 4. publish the aggregate, look back (wavefronts 0 .. kLbWaves-1, 1024 tiles per round), publish the
+    //    inclusive prefix
+    const uint64_t tile_g = pk_reads(tile_fn.pk[0]);
+    uint64_t* const dsc = A.desc + tile * kDescWords;
+    if (tid == 0 && tile + 1 < A.ntiles) {
+      st_desc(dsc, agg_word(tile_fn.out & 1u, tile_g, pk_mm(tile_fn.pk[0]), pk_ent(tile_fn.pk[0])));
+      st_desc(dsc + 1, agg_word((tile_fn.out >> 1) & 1u, tile_g, pk_mm(tile_fn.pk[1]), pk_ent(tile_fn.pk[1])));
+      st_desc(dsc + 2, ST_AGG);
+    }
+    TileFn acc = fn_identity();  // thread 0: everything between the nearest inclusive prefix and this tile
+    if (tile > 0) {
+      for (int64_t base = (int64_t)tile - 1;; base -= kLbWaves * 64 * kWin) {
+        if (wave < kLbWaves) {
+          bool found;
+          const TileFn f = look_window(A.desc, base - (int64_t)wave * 64 * kWin, &found);
+          if (lane == 0) { s_lb[wave] = f; s_lbf[wave] = found ? 1u : 0u; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t done = 0;
+          for (int w = 0; w < kLbWaves && !done; ++w) {  // near -> far
+            acc = fn_then(s_lb[w], acc);
+            done = s_lbf[w];
+          }
+          s_lbf[kLbWaves] = done;
+        }
+        __syncthreads();
+        if (s_lbf[kLbWaves]) break;
+      }
+    }
+    if (tid == 0) {
+      Incoming in{acc.out, acc.g, A.incoming ? acc.r[1] : acc.r[0], A.incoming ? acc.e[1] : acc.e[0]};
+      const uint32_t x_in = (in.map >> A.incoming) & 1u;
+      const uint32_t map_incl = map_then(in.map, tile_fn.out);
+      const uint64_t tpk = x_in ? tile_fn.pk[1] : tile_fn.pk[0];
+      const uint64_t g_incl = in.g + tile_g, r_incl = in.r + pk_mm(tpk), e_incl = in.e + pk_ent(tpk);
+      if (tile + 1 < A.ntiles) {
+        st_desc(dsc, ST_PREFIX | ((uint64_t)map_incl << 60) | g_incl);
+        st_desc(dsc + 1, ST_PREFIX | r_incl);
+        st_desc(dsc + 2, ST_PREFIX | e_incl);
+      } else {  // the last tile closes the shard
+        A.out_tot[0] = map_incl; A.out_tot[1] = g_incl;
+        if (COMMIT) { A.out_tot[2] = e_incl; A.out_tot[3] = r_incl; A.mm_offsets[r_incl] = e_incl; }
+      }
+      s_bcast[0] = x_in; s_bcast[1] = in.g; s_bcast[2] = in.r; s_bcast[3] = in.e;
+    }
+    __syncthreads();
+    if (COMMIT) {
+      // 5. commit with the true state: the thread's exclusive prefix, evaluated at the tile's incoming state
+      const uint32_t x_in = (uint32_t)s_bcast[0];
+      uint32_t st = (excl.out >> x_in) & 1u;
+      const uint64_t ex = x_in ? excl.pk[1] : excl.pk[0];
+      uint64_t eo = s_bcast[3] + pk_ent(ex);
+      uint64_t so = s_bcast[2] + pk_mm(ex);
+      uint64_t gidx = A.group_base + s_bcast[1] + pk_reads(ex);
+      uint32_t ambig = (tid == 0 && tile == 0 && A.first_shard) ? 1u : 0u;  // the phantom first boundary (:155-156)
+      for (int j = 0; j < kItems; ++j) {
+        const uint32_t li = l0 + j;
+        if (li >= nown) break;
+        const uint2 d = s_desc[slot(li)];
+        if (!(d.y & D_NEW)) continue;
+        const uint64_t my_gidx = gidx++;
+        uint32_t e = li + 1;
+        while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
+        uint32_t kind, tax, nmm = 0;
+        uint64_t hitlen, ge = t0 + e;
+        bool np, slow = false;
+        if (e < nst) {
+          np = s_desc[slot(e)].y & (D_P1 | D_P2);
+          Walk w{0, 0, 0, 0, 0};
+          for (uint32_t q = li + st; q < e; ++q) walk_add(w, s_desc[slot(q)]);
+          const uint32_t k = classify(w, np);
+          kind = k & 3u; nmm = k >> 2; tax = w.tax; hitlen = w.hsum;
+          slow = kind == 3u;
+        } else {
+          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
+          if (ge >= A.ntotal) continue;  // never processed
+          np = at(ge).y & (D_P1 | D_P2);
+          slow = true;
+        }
+        if (slow) {
+          const Verdict v = eval_group(at, t0 + li + st, ge, np, nullptr);
+          kind = v.kind; tax = v.tax; nmm = v.nmm; hitlen = v.hitlen;
+        }
+        if (kind == 0) {
+          ++ambig;
+        } else if (kind == 1) {
+          uint32_t bin = tax;
+          bool in_lds = A.use_lds_hist == 1;
+          if (A.use_lds_hist == 2) {
+            uint32_t p = (tax * 2654435761u) >> 21;  // 11 bits: kHashSlots
             for (uint32_t step = 0; step < kHashProbe; ++step) {
-              const uint32_t old = atomicCAS(&h_key[p], 0xffffffffu, v.tax);
-              if (old == 0xffffffffu || old == v.tax) { bin = p; in_lds = true; break; }
+              const uint32_t old = atomicCAS(&h_key[p], 0xffffffffu, tax);
+              if (old == 0xffffffffu || old == tax) { bin = p; in_lds = true; break; }
               p = (p + 1) & (kHashSlots - 1);
             }
           }
           if (in_lds) {
             atomicAdd(&h_count[bin], 1ull);
-            atomicAdd(&h_bases[bin], (unsigned long long)v.hitlen);
-            atomicMin(&h_first[bin], gidx);
+            atomicAdd(&h_bases[bin], (unsigned long long)hitlen);
+            atomicMin(&h_first[bin], (unsigned long long)my_gidx);
           } else {
-            atomicAdd(&g_count[v.tax], 1ull);
-            atomicAdd(&g_bases[v.tax], (unsigned long long)v.hitlen);
-            atomicMin(&g_first[v.tax], gidx);
+            atomicAdd(&A.g_count[tax], 1ull);
+            atomicAdd(&A.g_bases[tax], (unsigned long long)hitlen);
+            atomicMin(&A.g_first[tax], (unsigned long long)my_gidx);
           }
         } else {
-          my_cnt = v.nmm;
+          if (slow) {
+            (void)eval_group(at, t0 + li + st, ge, np, A.mm_tax + eo);  // writes the taxon list (SAM order)
+          } else {
+            uint64_t wpos = eo;
+            for (uint32_t q = li + st; q < e; ++q) {  // every kept line (:172-173)
+              const uint2 dq = s_desc[slot(q)];
+              if (!(dq.y & D_REJ)) A.mm_tax[wpos++] = dq.x;
+            }
+          }
+          A.mm_offsets[so] = eo;
+          A.mm_hitlen[so] = hitlen;
+          A.mm_read[so] = my_gidx;
+          eo += nmm;
+          ++so;
+        }
+        st = kind == 0;
+      }
+      if (ambig) atomicAdd(&s_ambig, (unsigned long long)ambig);
+      if (tid == 0) s_groups += tile_g;
+    }
+    __syncthreads();  // s_desc / s_bcast / s_ticket are reused by the next tile
+  }
+  if (COMMIT) {
+    __syncthreads();
+    if (A.use_lds_hist) {
+      for (uint32_t t = tid; t < nbins; t += kPB) {
+        if (h_count[t]) {
+          const uint32_t tax = A.use_lds_hist == 2 ? h_key[t] : t;
+          atomicAdd(&A.g_count[tax], h_count[t]);
+          atomicAdd(&A.g_bases[tax], h_bases[t]);
+          atomicMin(&A.g_first[tax], h_first[t]);
         }
       }
     }
-    if (i < nrecs) mm_cnt[i] = my_cnt;
-    uint64_t t_ent;
-    uint32_t t_reads;
-    (void)blockN_excl_sum<kPB>((uint64_t)my_cnt, lds64, &t_ent);
-    (void)block_rank(my_cnt != 0, lds + 4, &t_reads);
-    if (threadIdx.x == 0) { s_groups += ngroups; tile_ent[tile] = t_ent; tile_reads[tile] = t_reads; }
-  }
-  __syncthreads();
-  if (use_lds_hist) {
-    for (uint32_t t = threadIdx.x; t < nbins; t += kPB) {
-      if (h_count[t]) {
-        const uint32_t tax = use_lds_hist == 2 ? h_key[t] : t;
-        atomicAdd(&g_count[tax], h_count[t]);
-        atomicAdd(&g_bases[tax], h_bases[t]);
-        atomicMin(&g_first[tax], h_first[t]);
-      }
-    }
-  }
-  if (threadIdx.x == 0) {
-    if (s_groups) atomicAdd(&g_scalars[0], s_groups);
-    if (s_ambig) atomicAdd(&g_scalars[1], s_ambig);
-  }
-}
-
-__global__ __launch_bounds__(kPB) void k_profile_fill_mm(
-    const mg_aln_rec* __restrict__ recs, uint64_t nrecs, uint64_t ntotal, const uint32_t* __restrict__ ref2tax,
-    double pct_id, const uint8_t* __restrict__ dropped, const uint64_t* __restrict__ pre_groups, uint64_t group_base,
-    const uint32_t* __restrict__ mm_cnt, const uint64_t* __restrict__ tile_ent, const uint64_t* __restrict__ tile_reads,
-    uint64_t* __restrict__ mm_offsets, uint32_t* __restrict__ mm_tax, uint64_t* __restrict__ mm_hitlen,
-    uint64_t* __restrict__ mm_read, uint64_t ntiles) {
-  __shared__ uint32_t lds[8];
-  __shared__ uint64_t lds64[4];
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t i = tile * kPB + threadIdx.x;
-    const bool leader = i < nrecs && (recs[i].ref_new & MG_REC_NEW_BIT);
-    const uint32_t cnt = i < nrecs ? mm_cnt[i] : 0;
-    uint32_t ngroups, nreads_t;
-    uint64_t nent_t;
-    const uint32_t rank = block_rank(leader, lds, &ngroups);
-    const uint32_t slot_in = block_rank(cnt != 0, lds + 4, &nreads_t);
-    const uint64_t ent_in = blockN_excl_sum<kPB>((uint64_t)cnt, lds64, &nent_t);
-    if (cnt != 0) {
-      const uint64_t e = group_end(recs, i, ntotal);
-      const uint32_t nf = recs[e].flag_len & MG_REC_FLAG_MASK;
-      const uint64_t eo = tile_ent[tile] + ent_in, so = tile_reads[tile] + slot_in;
-      const Verdict v = eval_group(recs, i + dropped[i], e, nf, ref2tax, pct_id, mm_tax + eo);
-      mm_offsets[so] = eo;
-      mm_hitlen[so] = v.hitlen;
-      mm_read[so] = group_base + pre_groups[tile] + rank;
+    if (tid == 0) {
+      if (s_groups) atomicAdd(&A.g_scalars[0], s_groups);
+      if (s_ambig) atomicAdd(&A.g_scalars[1], s_ambig);
     }
   }
 }
@@ -450,17 +656,90 @@ struct mg_profile {
   const uint32_t* d_ref2tax = nullptr;
   uint32_t nref = 0, ntax = 0;
   double pct_id = 0.5;
-  uint64_t nblocks = 0;
-  DevBuf maps, blk_map, blk_groups, pre_map, pre_groups, tot;
+  uint64_t ntiles = 0;
+  DevBuf desc, tot;          // tile descriptors + ticket (last word); totals of the last pass
   uint8_t map[2] = {0, 1};
   uint64_t ngroups = 0;
-  bool have_map = false;     // totals of pass A read back (lazily: a single shard never needs them)
+  bool have_map = false;     // composed state map / read count known (map-only pass, or read back after commit)
   bool have_mm = false;      // multimapped totals read back (lazily)
   bool committed = false;
   // multimapped CSR (device)
-  DevBuf mm_cnt, tile_ent, tile_reads, mm_offsets, mm_tax, mm_hitlen, mm_read;
+  DevBuf mm_offsets, mm_tax, mm_hitlen, mm_read;
   uint64_t mm_nreads = 0, mm_nentries = 0;
 };
+
+namespace {
+
+// One chained-scan pass over the shard.  commit == false: composed state map + read count only.
+int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_shard, uint64_t group_base,
+                uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  const uint64_t desc_bytes = (p->ntiles * kDescWords + 1) * sizeof(uint64_t);
+  if (!p->desc.p) MG_TRY(p->desc.alloc(desc_bytes));
+  if (!p->tot.p) MG_TRY(p->tot.alloc(4 * sizeof(uint64_t)));
+  MG_HIP(hipMemsetAsync(p->desc.p, 0, desc_bytes, st));
+  PassArgs a{};
+  a.recs = p->d_recs; a.nrecs = p->nrecs; a.ntotal = p->ntotal;
+  a.ref2tax = p->d_ref2tax; a.pct_id = p->pct_id;
+  a.desc = p->desc.as<uint64_t>();
+  a.ticket = reinterpret_cast<unsigned long long*>(p->desc.as<uint64_t>() + p->ntiles * kDescWords);
+  a.ntiles = p->ntiles;
+  a.incoming = incoming; a.first_shard = first_shard; a.group_base = group_base;
+  a.ntax = p->ntax;
+  a.out_tot = p->tot.as<uint64_t>();
+  if (!commit) {
+    ProfScope ps("profile_map");
+    const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * 4);
+    hipLaunchKernelGGL(k_profile_pass<false>, dim3(grid), dim3(kPB), 0, st, a);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+  }
+  a.use_lds_hist = p->ntax <= 2048 ? 1u : 2u;
+  const size_t lds = a.use_lds_hist == 1 ? 3 * (size_t)p->ntax * sizeof(unsigned long long)
+                                         : kHashSlots * (3 * sizeof(unsigned long long) + sizeof(uint32_t));
+  a.g_count = (unsigned long long*)d_count; a.g_bases = (unsigned long long*)d_bases;
+  a.g_first = (unsigned long long*)d_first_seen; a.g_scalars = (unsigned long long*)d_scalars;
+  a.mm_offsets = p->mm_offsets.as<uint64_t>(); a.mm_tax = p->mm_tax.as<uint32_t>();
+  a.mm_hitlen = p->mm_hitlen.as<uint64_t>(); a.mm_read = p->mm_read.as<uint64_t>();
+  ProfScope ps("profile_pass");
+  // every workgroup flushes its private histogram once: few, long-lived workgroups
+  const unsigned per_cu = lds > 40 * 1024 ? 2u : 3u;
+  const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
+  hipLaunchKernelGGL(k_profile_pass<true>, dim3(grid), dim3(kPB), lds, st, a);
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
+// Totals of the last pass ([0] composed map, [1] reads) are fetched on first use.
+int fetch_map(mg_profile* p) {
+  if (p->have_map || p->nrecs == 0) { p->have_map = true; return MG_OK; }
+  hipStream_t st = ctx().stream;
+  if (!p->committed)  // nobody ran over the shard yet: the map-only pass
+    MG_TRY(launch_pass(p, false, 0, 0, 0, nullptr, nullptr, nullptr, nullptr));
+  uint64_t* h_tot = host_words() + 16;
+  MG_HIP(hipMemcpyAsync(h_tot, p->tot.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  p->map[0] = (uint8_t)(h_tot[0] & 1u);
+  p->map[1] = (uint8_t)((h_tot[0] >> 1) & 1u);
+  p->ngroups = h_tot[1];
+  p->have_map = true;
+  return MG_OK;
+}
+
+int fetch_mm(mg_profile* p) {
+  if (p->have_mm || p->nrecs == 0) { p->have_mm = true; return MG_OK; }
+  hipStream_t st = ctx().stream;
+  uint64_t* h_tot = host_words() + 16;
+  MG_HIP(hipMemcpyAsync(h_tot + 2, p->tot.as<uint64_t>() + 2, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  p->mm_nentries = h_tot[2];
+  p->mm_nreads = h_tot[3];
+  p->have_mm = true;
+  return MG_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -478,57 +757,10 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs, int has_looka
   p->nref = nref;
   p->ntax = ntax;
   p->pct_id = pct_id;
-  p->nblocks = (nrecs + kPB - 1) / kPB;
-  if (nrecs == 0) { p->map[0] = 0; p->map[1] = 1; *out = p.release(); return MG_OK; }
-  Context& c = ctx();
-  hipStream_t st = c.stream;
-  MG_TRY(p->maps.alloc(nrecs));
-  MG_TRY(p->blk_map.alloc(p->nblocks));
-  MG_TRY(p->blk_groups.alloc(p->nblocks * sizeof(uint32_t)));
-  MG_TRY(p->pre_map.alloc(p->nblocks));
-  MG_TRY(p->pre_groups.alloc(p->nblocks * sizeof(uint64_t)));
-  MG_TRY(p->tot.alloc(4 * sizeof(uint64_t)));
-  {
-    ProfScope ps("profile_maps");
-    hipLaunchKernelGGL(k_profile_maps, dim3((unsigned)p->nblocks), dim3(kPB), 0, st, d_recs, nrecs, p->ntotal,
-                       d_ref2tax, pct_id, p->maps.as<uint8_t>(), p->blk_map.as<uint8_t>(),
-                       p->blk_groups.as<uint32_t>());
-    MG_HIP(hipGetLastError());
-  }
-  {
-    ProfScope ps("profile_scan");
-    hipLaunchKernelGGL(k_profile_scan, dim3(1), dim3(1024), 0, st, p->blk_map.as<uint8_t>(),
-                       p->blk_groups.as<uint32_t>(), p->nblocks, p->pre_map.as<uint8_t>(),
-                       p->pre_groups.as<uint64_t>(), p->tot.as<uint64_t>());
-    MG_HIP(hipGetLastError());
-  }
+  p->ntiles = (nrecs + kTile - 1) / kTile;
+  // nothing is launched here: a single shard commits in one pass; a shard of a multi-GPU job first asks for its
+  // composed state map (mg_profile_state_map), which runs the map-only pass.
   *out = p.release();
-  return MG_OK;
-}
-
-// Pass-A totals (composed state map, read count) are fetched on first use.
-static int fetch_map(mg_profile* p) {
-  if (p->have_map || p->nrecs == 0) { p->have_map = true; return MG_OK; }
-  hipStream_t st = ctx().stream;
-  uint64_t* h_tot = host_words() + 16;
-  MG_HIP(hipMemcpyAsync(h_tot, p->tot.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipStreamSynchronize(st));
-  p->map[0] = (uint8_t)(h_tot[0] & 1u);
-  p->map[1] = (uint8_t)((h_tot[0] >> 1) & 1u);
-  p->ngroups = h_tot[1];
-  p->have_map = true;
-  return MG_OK;
-}
-
-static int fetch_mm(mg_profile* p) {
-  if (p->have_mm || p->nrecs == 0) { p->have_mm = true; return MG_OK; }
-  hipStream_t st = ctx().stream;
-  uint64_t* h_tot = host_words() + 16;
-  MG_HIP(hipMemcpyAsync(h_tot + 2, p->tot.as<uint64_t>() + 2, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipStreamSynchronize(st));
-  p->mm_nentries = h_tot[2];
-  p->mm_nreads = h_tot[3];
-  p->have_mm = true;
   return MG_OK;
 }
 
@@ -552,55 +784,16 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
   MG_REQUIRE_READY();
   if (!p || !d_count || !d_bases || !d_first_seen || !d_scalars) return fail(MG_ERR_ARG, "null argument");
   if (p->committed) return fail(MG_ERR_STATE, "profile shard already committed");
-  Context& c = ctx();
-  hipStream_t st = c.stream;
   p->committed = true;
-  if (p->nrecs == 0) {
-    if (first_shard) {
-      // the phantom boundary never happens without a first line: nothing to add
-    }
-    return MG_OK;
-  }
-  MG_TRY(p->mm_cnt.alloc(p->nrecs * sizeof(uint32_t)));
-  MG_TRY(p->tile_ent.alloc(p->nblocks * sizeof(uint64_t)));
-  MG_TRY(p->tile_reads.alloc(p->nblocks * sizeof(uint64_t)));
-  const uint32_t use_lds = p->ntax <= 2048 ? 1u : 2u;
-  const size_t lds = use_lds == 1 ? 3 * (size_t)p->ntax * sizeof(unsigned long long)
-                                  : kHashSlots * (3 * sizeof(unsigned long long) + sizeof(uint32_t));
-  {
-    ProfScope ps("profile_commit");
-    unsigned grid = grid_for(p->nblocks, 1, (unsigned)c.num_cus * 4);
-    hipLaunchKernelGGL(k_profile_commit, dim3(grid), dim3(kPB), lds, st, p->d_recs, p->nrecs, p->ntotal, p->d_ref2tax,
-                       p->pct_id, p->maps.as<uint8_t>(), p->pre_map.as<uint8_t>(), p->pre_groups.as<uint64_t>(),
-                       (uint32_t)(incoming_dropped ? 1 : 0), (uint32_t)(first_shard ? 1 : 0), group_base, p->ntax,
-                       use_lds, (unsigned long long*)d_count, (unsigned long long*)d_bases,
-                       (unsigned long long*)d_first_seen, (unsigned long long*)d_scalars, p->mm_cnt.as<uint32_t>(),
-                       p->tile_ent.as<uint64_t>(), p->tile_reads.as<uint64_t>(), p->nblocks);
-    MG_HIP(hipGetLastError());
-  }
+  if (p->nrecs == 0) return MG_OK;  // the phantom boundary never happens without a first line: nothing to add
   // multimapped CSR buffers sized by their upper bounds (pooled), so that nothing has to be read back here:
   // entries <= records, multimapped reads <= records
   MG_TRY(p->mm_offsets.alloc((p->nrecs + 2) * sizeof(uint64_t)));
   MG_TRY(p->mm_tax.alloc((p->nrecs + 1) * sizeof(uint32_t)));
   MG_TRY(p->mm_hitlen.alloc((p->nrecs + 1) * sizeof(uint64_t)));
   MG_TRY(p->mm_read.alloc((p->nrecs + 1) * sizeof(uint64_t)));
-  {
-    ProfScope ps("profile_scan_mm");
-    hipLaunchKernelGGL(k_profile_scan_mm, dim3(1), dim3(1024), 0, st, p->tile_ent.as<uint64_t>(),
-                       p->tile_reads.as<uint64_t>(), p->nblocks, p->tot.as<uint64_t>(), p->mm_offsets.as<uint64_t>());
-    MG_HIP(hipGetLastError());
-  }
-  {
-    ProfScope ps("profile_fill_mm");
-    unsigned grid = grid_for(p->nblocks, 1, (unsigned)c.num_cus * 8);
-    hipLaunchKernelGGL(k_profile_fill_mm, dim3(grid), dim3(kPB), 0, st, p->d_recs, p->nrecs, p->ntotal, p->d_ref2tax,
-                       p->pct_id, p->maps.as<uint8_t>(), p->pre_groups.as<uint64_t>(), group_base,
-                       p->mm_cnt.as<uint32_t>(), p->tile_ent.as<uint64_t>(), p->tile_reads.as<uint64_t>(),
-                       p->mm_offsets.as<uint64_t>(), p->mm_tax.as<uint32_t>(), p->mm_hitlen.as<uint64_t>(),
-                       p->mm_read.as<uint64_t>(), p->nblocks);
-    MG_HIP(hipGetLastError());
-  }
-  return MG_OK;
+  return launch_pass(p, true, incoming_dropped ? 1u : 0u, first_shard ? 1u : 0u, group_base, d_count, d_bases,
+                     d_first_seen, d_scalars);
 }
 
 int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads, uint64_t* nentries) {
