@@ -58,10 +58,13 @@ struct Roller {
     run = 0;
   }
 
-  // Append one valid base with code c (0..3).
+  // Append one base with code c (0..3; anything else only in bits that `run` keeps from being used).
+  // ASCII of the base and of its complement come from one v_perm_b32 each (byte select out of "ACGT" / "TGCA").
   __device__ __forceinline__ void push(uint32_t c) {
-    const uint32_t up = (0x54474341u >> (8 * c)) & 0xffu;  // "ACGT"[c]
-    const uint32_t cu = (0x41434754u >> (8 * c)) & 0xffu;  // complement: "TGCA"[c]
+    const uint32_t sel = c | 0x0c0c0c00u;  // byte 0 <- table[c]; bytes 1..3 <- 0x00
+    const uint32_t up = __builtin_amdgcn_perm(0u, 0x54474341u, sel);  // "ACGT"[c]
+    const uint32_t cu = __builtin_amdgcn_perm(0u, 0x41434754u, sel);  // complement: "TGCA"[c]
+    c &= 3u;
     // forward ASCII window: drop byte 0, append `up` as byte K-1
 #pragma unroll
     for (int j = 0; j + 1 < ND; ++j) f[j] = __builtin_amdgcn_alignbyte(f[j + 1], f[j], 1);
