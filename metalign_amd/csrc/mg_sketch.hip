@@ -141,9 +141,17 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uin
   Roller<K> roll;
   roll.reset();
   uint32_t nk = 0;
+  const uint32_t last = len ? len - 1 : 0;
   auto code_at = [&](uint32_t pos) -> uint32_t {
-    if (pos >= len) return 4u;
-    return CODES ? (uint32_t)src[pos] : encode1(src[pos]);
+    if constexpr (CODES) {
+      // unconditional LDS read + select (a guarded read costs an exec-mask branch and a full wait at its join);
+      // the index is clamped to the read: ragged tiles never read outside the stage
+      const uint32_t c = src[pos < last ? pos : last];
+      return pos < len ? c : 4u;
+    } else {
+      if (pos >= len) return 4u;
+      return encode1(src[pos]);
+    }
   };
   // The first K-1 bases of a read complete no k-mer: roll them in without hashing (every lane starts its read
   // at pos 0, so this is wave-uniform; it is (K-1)/150 of all steps — 13 % at k = 21, 39 % at k = 60).
@@ -154,8 +162,10 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uin
     roll.push(c);
     roll.run = c < 4u ? roll.run : 0;
   }
+  uint32_t c0 = code_at(warm), c1 = code_at(warm + 1);
   for (uint32_t pos = warm; pos < maxlen; pos += 2) {
-    const uint32_t c0 = code_at(pos), c1 = code_at(pos + 1);
+    const uint32_t n0 = code_at(pos + 2), n1 = code_at(pos + 3);  // next iteration's bases: the LDS latency hides
+                                                                   // behind this iteration's two hashes
     roll.push(c0);
     roll.run = c0 < 4u ? roll.run : 0;
     const uint64_t h0 = roll.hash();
@@ -167,6 +177,8 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uin
     nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
     sink.offer(full0 && h0 <= hmax, h0, lane);
     sink.offer(full1 && h1 <= hmax, h1, lane);
+    c0 = n0;
+    c1 = n1;
   }
   kmers += nk;
 }
