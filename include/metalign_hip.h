@@ -82,6 +82,12 @@ int mg_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes);
 int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes);
 /* Asynchronous on the library stream (accumulator reset between batches). */
 int mg_dev_memset(void* d_ptr, int byte_value, uint64_t bytes);
+/* Page-locked host memory and an asynchronous device-to-host copy into it (ordered on the library stream;
+ * the bytes are valid after mg_sync).  Lets a caller queue all of a batch's small read-backs behind the
+ * kernels and pay for one synchronisation. */
+int mg_host_alloc(void** h_ptr, uint64_t bytes);
+int mg_host_free(void* h_ptr);
+int mg_memcpy_d2h_async(void* h_pinned_dst, const void* d_src, uint64_t bytes);
 int mg_sync(void);
 
 /* Per-kernel timing with HIP events on the library stream (bench.py's
@@ -239,6 +245,10 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs,
                          int has_lookahead, const uint32_t* d_ref2tax,
                          uint32_t nref, uint32_t ntax, double pct_id,
                          mg_profile** out);
+/* Resets the accumulators a commit adds into (count = bases = 0, first_seen = UINT64_MAX, scalars = 0);
+ * asynchronous, one launch. */
+int mg_profile_acc_reset(uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen,
+                         uint64_t* d_scalars, uint32_t ntax);
 /* map[0] = outgoing bit if incoming is 0, map[1] = ... if incoming is 1. */
 int mg_profile_state_map(const mg_profile* p, uint8_t map[2]);
 uint64_t mg_profile_ngroups(const mg_profile* p);

@@ -25,6 +25,7 @@ MAX_K = 64
 EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
+    "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
@@ -34,7 +35,7 @@ EXPORTS = [
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
-    "mg_profile_begin_dev", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev",
+    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_free", "mg_profile_assign",
 ]
 
@@ -109,6 +110,38 @@ class DeviceArray:
     def free(self):
         if self.ptr:
             self.hip.lib.mg_dev_free(_vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):  # best effort
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class PinnedArray:
+    """Page-locked host memory (mg_host_alloc) viewed as a numpy array: the target of asynchronous read-backs."""
+
+    def __init__(self, hip, count, dtype):
+        self.hip = hip
+        self.dtype = np.dtype(dtype)
+        self.count = int(count)
+        self.nbytes = self.count * self.dtype.itemsize
+        p = _vp()
+        hip._chk(hip.lib.mg_host_alloc(ctypes.byref(p), ctypes.c_uint64(self.nbytes + 16)))
+        self.ptr = p.value
+        buf = (ctypes.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=self.count)
+
+    def fetch_async(self, d_ptr, nbytes=None):
+        """Queue device -> this buffer on the library stream; valid after hip.sync()."""
+        n = self.nbytes if nbytes is None else int(nbytes)
+        self.hip._chk(self.hip.lib.mg_memcpy_d2h_async(_vp(self.ptr), _vp(d_ptr), ctypes.c_uint64(n)))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.hip.lib.mg_host_free(_vp(self.ptr))
             self.ptr = None
 
     def __del__(self):  # best effort
@@ -354,6 +387,9 @@ class Hip:
     def array(self, host, dtype=None):
         host = np.ascontiguousarray(host, dtype=dtype)
         return DeviceArray(self, host.size, host.dtype).upload(host)
+
+    def pinned(self, count, dtype):
+        return PinnedArray(self, count, dtype)
 
     def empty(self, count, dtype):
         return DeviceArray(self, count, dtype)

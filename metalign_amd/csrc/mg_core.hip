@@ -227,6 +227,27 @@ int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes) {
   return MG_OK;
 }
 
+int mg_host_alloc(void** h_ptr, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (!h_ptr) return fail(MG_ERR_ARG, "null out pointer");
+  hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 16, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(MG_ERR_NOMEM, "hipHostMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+  return MG_OK;
+}
+
+int mg_host_free(void* h_ptr) {
+  MG_REQUIRE_READY();
+  if (h_ptr) MG_HIP(hipHostFree(h_ptr));
+  return MG_OK;
+}
+
+int mg_memcpy_d2h_async(void* h_pinned_dst, const void* d_src, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (bytes == 0) return MG_OK;
+  MG_HIP(hipMemcpyAsync(h_pinned_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+  return MG_OK;
+}
+
 int mg_dev_memset(void* d_ptr, int byte_value, uint64_t bytes) {
   MG_REQUIRE_READY();
   if (bytes == 0) return MG_OK;

@@ -646,6 +646,14 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
   }
 }
 
+// Accumulators of one batch: count = bases = 0, first_seen = UINT64_MAX, scalars = 0 (one launch).
+__global__ void k_acc_reset(uint64_t* __restrict__ count, uint64_t* __restrict__ bases, uint64_t* __restrict__ first,
+                            uint64_t* __restrict__ scalars, uint32_t ntax) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntax; t += stride) { count[t] = 0; bases[t] = 0; first[t] = ~0ull; }
+  if (blockIdx.x == 0 && threadIdx.x < 2) scalars[threadIdx.x] = 0;
+}
+
 }  // namespace mg
 
 using namespace mg;
@@ -761,6 +769,15 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs, int has_looka
   // nothing is launched here: a single shard commits in one pass; a shard of a multi-GPU job first asks for its
   // composed state map (mg_profile_state_map), which runs the map-only pass.
   *out = p.release();
+  return MG_OK;
+}
+
+int mg_profile_acc_reset(uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars, uint32_t ntax) {
+  MG_REQUIRE_READY();
+  if (!d_count || !d_bases || !d_first_seen || !d_scalars) return fail(MG_ERR_ARG, "null argument");
+  hipLaunchKernelGGL(k_acc_reset, dim3(grid_for((uint64_t)ntax + 2, 256, 64)), dim3(256), 0, ctx().stream, d_count, d_bases,
+                     d_first_seen, d_scalars, ntax);
+  MG_HIP(hipGetLastError());
   return MG_OK;
 }
 

@@ -84,6 +84,9 @@ class HipEngine:
         self.d_hs = hip.empty(2 * max(self.ngen_local, 1), np.uint32)  # [hits | sizes]: one read-back
         # [count T | bases T | first_seen T | scalars 2]
         self.d_acc = hip.empty(3 * ntax + 2, np.uint64)
+        # page-locked landing buffers: a step queues both read-backs behind its kernels and syncs once
+        self.h_hs = hip.pinned(2 * max(self.ngen_local, 1), np.uint32)
+        self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
 
     # ---- stage A ----
     def sketch_local(self, k, hmax, s):
@@ -115,6 +118,19 @@ class HipEngine:
         hs = self.d_hs.download()
         return hs[: self.ngen_local], hs[g: g + self.ngen_local]
 
+    def containment_and_commit_results(self, sk, ci, want_multimapped):
+        """Stage B's kernels, then BOTH read-backs (containment counts, stage-C accumulators of a commit queued
+        earlier with profile_commit_launch) behind them: one synchronisation."""
+        g, T = max(self.ngen_local, 1), self.ntax
+        self.hip.containment_dev(sk, self.table, ci, self.d_hs.ptr, self.d_hs.ptr + 4 * g)
+        self.h_hs.fetch_async(self.d_hs.ptr)
+        self.h_acc.fetch_async(self.d_acc.ptr)
+        self.hip.sync()
+        hs, acc = self.h_hs.array.copy(), self.h_acc.array.copy()
+        mm = self.shard.multimapped() if want_multimapped else None
+        self.shard.free()
+        return (hs[: self.ngen_local], hs[g: g + self.ngen_local]), (acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm)
+
     # ---- stage C ----
     def set_sketch_bound(self, sk, truncated, bound):
         sk.set_bound(truncated, bound)
@@ -128,19 +144,26 @@ class HipEngine:
             return (0, 1), 0
         return self.shard.state_map(), self.shard.ngroups
 
-    def profile_commit(self, incoming, first_shard, group_base, want_multimapped=True):
+    def profile_commit_launch(self, incoming, first_shard, group_base):
+        """Asynchronous part of the commit: accumulator reset + the stage-C pass; nothing is read back."""
         T = self.ntax
-        hipl = self.hip.lib
         import ctypes
         base = self.d_acc.ptr
-        self.hip._chk(hipl.mg_dev_memset(ctypes.c_void_p(base), 0, ctypes.c_uint64(2 * T * 8)))
-        self.hip._chk(hipl.mg_dev_memset(ctypes.c_void_p(base + 2 * T * 8), 0xFF, ctypes.c_uint64(T * 8)))
-        self.hip._chk(hipl.mg_dev_memset(ctypes.c_void_p(base + 3 * T * 8), 0, ctypes.c_uint64(16)))
+        vp = ctypes.c_void_p
+        self.hip._chk(self.hip.lib.mg_profile_acc_reset(vp(base), vp(base + T * 8), vp(base + 2 * T * 8), vp(base + 3 * T * 8),
+                                                        ctypes.c_uint32(T)))
         self.shard.commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8)
+
+    def profile_commit_finish(self, want_multimapped=True):
+        T = self.ntax
         acc = self.d_acc.download()
         mm = self.shard.multimapped() if want_multimapped else None
         self.shard.free()
         return acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm
+
+    def profile_commit(self, incoming, first_shard, group_base, want_multimapped=True):
+        self.profile_commit_launch(incoming, first_shard, group_base)
+        return self.profile_commit_finish(want_multimapped)
 
 
 class ShardJob:
@@ -297,15 +320,22 @@ class ShardJob:
         self._want_mm = want_multimapped
         if self.exchange:
             sk, committed = self._exchange_step()
+            hits, sizes = eng.containment(sk, self.ci)
         else:
-            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            # single shard: stage C is queued first and runs to completion behind stage A's one host sync (the
+            # sketch size); its results come back with the containment counts, so the step has two syncs, not three
             eng.profile_begin(self.pct_id, False)
-            committed = None
-        hits, sizes = eng.containment(sk, self.ci)
+            split = hasattr(eng, "profile_commit_launch")
+            if split:
+                eng.profile_commit_launch(1, True, 0)
+            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            if split:
+                (hits, sizes), committed = eng.containment_and_commit_results(sk, self.ci, want_multimapped)
+            else:
+                hits, sizes = eng.containment(sk, self.ci)
+                committed = eng.profile_commit(1, True, 0, want_multimapped)
         qn = sk.size
         sk.free()
-        if committed is None:
-            committed = eng.profile_commit(1, True, 0, want_multimapped)
         count, bases, first, scalars, mm = committed
         G, T, W = self.G, self.T, self.world
         if self.exchange:
