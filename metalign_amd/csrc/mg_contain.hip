@@ -1,16 +1,16 @@
 // mg_contain.hip — Stage B: containment of every genome sketch in the read sketch.
 //
-// K2: both operands are sorted sets.  The table is held INVERTED (built once at upload): U = the ascending
-// union of all genome sketches, and for every genome hash its position in U.
-//   k_presence     walks U once, 64 consecutive hashes per wavefront step, and looks each one up in the read
-//                  sketch through a bucket index over the hash's leading bits (~1 entry per bucket).  Because
-//                  consecutive lanes carry increasing hashes, their index / sketch accesses are nearly
-//                  contiguous (the intersection of two sorted lists, without the serial merge); the result is
-//                  one presence bit per U entry, written with a wavefront ballot.
-//   k_genome_hits  one wavefront per genome gathers its bits (positions are streamed coalesced, the bitmap is
-//                  |U|/8 bytes and L2-resident) and counts them with ballot + popcount.
-// A first version looked every genome hash up directly (G*n scattered look-ups): 0.27 ms at 10k genomes; this
-// one streams U and the positions once.
+// K2: both operands are sorted sets.  The table is held HASH-MAJOR (built once at upload): every (hash, genome)
+// pair of every genome sketch, sorted by hash.  One streaming pass (`k_contain_pairs`):
+//   * a workgroup takes a tile of 2048 consecutive pairs; their hashes span a narrow range, so the part of the
+//     read sketch that can match them is a short contiguous run, found with two look-ups in the sketch's bucket
+//     index and copied to LDS with coalesced loads;
+//   * every pair looks its hash up in that LDS run (binary search) and, when it is present with count >= ci,
+//     adds one to its genome's hit counter — atomics only for the PRESENT pairs, a small fraction of a
+//     metagenome's table.
+// HBM traffic: the table once (12 B per pair) + the read sketch once.  The previous layout (ascending union +
+// per-genome positions: a presence bitmap, then one gather per genome hash) took 3.9 ms at 200 k genomes because
+// the 200 M bit gathers each pulled a 64-byte line out of the Infinity Cache; see DESIGN.md.
 //
 // Replaces: kmc_tools simple ... intersect (scripts/select_db.py:54-56) and the
 // containment index of StreamingQueryDNADatabase.py (scripts/select_db.py:73-76).
@@ -35,87 +35,181 @@ __global__ void k_build_index(const uint64_t* __restrict__ q, uint64_t n, unsign
   }
 }
 
-// Pass 1: walk the table's ascending union U; bit i of `present` = U[i] is in the read sketch with count >= ci.
-// Consecutive lanes look up increasing hashes, so their index / sketch accesses are nearly contiguous.
-__global__ __launch_bounds__(256) void k_presence(const uint64_t* __restrict__ q, const uint32_t* __restrict__ qc,
-                                                  uint64_t qn, uint64_t q_last, const uint32_t* __restrict__ idx,
-                                                  unsigned shift, uint32_t ci, const uint64_t* __restrict__ uniq,
-                                                  uint64_t nuniq, unsigned long long* __restrict__ present) {
-  const int lane = threadIdx.x & 63;
-  uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // 64 entries of U per wavefront step
-  const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  const uint64_t nwords = (nuniq + 63) / 64;
-  for (; w < nwords; w += nw) {
-    const uint64_t i = w * 64 + lane;
-    bool found = false;
-    if (i < nuniq && qn > 0) {
-      const uint64_t h = uniq[i];
-      if (h <= q_last) {
-        const uint64_t b = h >> shift;
-        uint32_t lo = idx[b], hi = idx[b + 1];
-        while (lo < hi) {  // lower_bound inside the bucket
-          uint32_t mid = (lo + hi) >> 1;
-          if (q[mid] < h) lo = mid + 1; else hi = mid;
+constexpr int kCT = 256;                // threads per workgroup
+constexpr int kCTile = 8 * kCT;         // pairs per tile
+constexpr uint32_t kCCap = 2048;        // read-sketch entries staged in LDS per tile (24 KB: six workgroups per CU)
+
+// hits[g] += 1 for every pair (h, g) with h in the read sketch at count >= ci; sizes (optional, truncated
+// sketches only) counts every pair.  npairs = pairs with hash <= the sketch's completeness bound.
+__global__ __launch_bounds__(kCT) void k_contain_pairs(const uint64_t* __restrict__ q, const uint32_t* __restrict__ qc,
+                                                       uint64_t qn, uint64_t q_last, const uint32_t* __restrict__ idx,
+                                                       unsigned shift, uint32_t ci, const uint64_t* __restrict__ ph,
+                                                       const uint32_t* __restrict__ pg, uint64_t npairs,
+                                                       uint32_t* __restrict__ hits_part, uint32_t* __restrict__ sizes_part,
+                                                       uint64_t ngenomes, uint32_t copy_mask) {
+  // counters are replicated (copy = workgroup id modulo the number of copies, see mg_containment_dev): a few
+  // abundant genomes collect most hits, and atomics on one address retire one at a time
+  uint32_t* const hits = hits_part + (uint64_t)(blockIdx.x & copy_mask) * ngenomes;
+  uint32_t* const sizes = sizes_part ? sizes_part + (uint64_t)(blockIdx.x & copy_mask) * ngenomes : nullptr;
+  __shared__ uint64_t s_q[kCCap];
+  __shared__ uint32_t s_c[kCCap];
+  __shared__ uint64_t s_edge[2];
+  constexpr int kPer = kCTile / kCT;
+  const int tid = threadIdx.x;
+  const uint64_t ntiles = (npairs + kCTile - 1) / kCTile;
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t t0 = tile * kCTile;
+    const uint64_t t1 = t0 + kCTile < npairs ? t0 + kCTile : npairs;
+    // this thread's pairs: issued first, they travel while the matching run of the read sketch is located
+    uint64_t h[kPer];
+    uint32_t g[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const uint64_t i = t0 + tid + (uint64_t)j * kCT;
+      h[j] = ~0ull;  // never in a sketch (reserved value): inactive slot
+      g[j] = 0;
+      if (i < t1) { h[j] = ph[i]; g[j] = pg[i]; }
+    }
+    // first / last hash of the tile: already among the loaded pairs (no second round trip)
+    if (tid == 0) s_edge[0] = h[0];
+    {
+      const uint64_t il = t1 - 1 - t0;  // tile-local index of the last pair
+      if ((il % kCT) == (uint64_t)tid) {
+        uint64_t v = h[0];
+#pragma unroll
+        for (int j = 1; j < kPer; ++j) v = (il / kCT) == (uint64_t)j ? h[j] : v;
+        s_edge[1] = v;
+      }
+    }
+    __syncthreads();
+    const uint64_t h_first = s_edge[0], h_last = s_edge[1];
+    uint32_t lo = 0, hi = 0;  // the run of the read sketch that can match this tile
+    if (qn > 0 && h_first <= q_last) {
+      const uint64_t top = h_last < q_last ? h_last : q_last;
+      lo = idx[h_first >> shift];
+      hi = idx[(top >> shift) + 1];
+    }
+    const uint32_t len = hi - lo;
+    const bool staged = len < kCCap;
+    uint32_t pow2 = 1;  // smallest power of two > len: the padded length of the staged run
+    while (pow2 <= len) pow2 <<= 1;
+    if (staged) {
+      // the run's loads are issued four rounds at a time (a plain loop waits for every round trip in turn)
+      for (uint32_t r0 = 0; r0 < len; r0 += 4 * kCT) {
+        uint64_t vq[4];
+        uint32_t vc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t i = r0 + r * kCT + tid;
+          vq[r] = 0; vc[r] = 0;
+          if (i < len) { vq[r] = q[lo + i]; vc[r] = qc[lo + i]; }
         }
-        found = lo < qn && q[lo] == h && qc[lo] >= ci;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t i = r0 + r * kCT + tid;
+          if (i < len) { s_q[i] = vq[r]; s_c[i] = vc[r]; }
+        }
+      }
+      for (uint32_t i = len + tid; i < pow2; i += kCT) { s_q[i] = ~0ull; s_c[i] = 0; }
+    }
+    __syncthreads();
+    if (sizes) {
+#pragma unroll
+      for (int j = 0; j < kPer; ++j)
+        if (h[j] != ~0ull) atomicAdd(&sizes[g[j]], 1u);
+    }
+    if (len && staged) {
+      // Eight lower bounds in lock step over the LDS run, padded with +inf up to a power of two so that a probe
+      // needs neither a bound check nor a branch: the eight loads of a step are independent and pipeline.
+      uint32_t p[kPer];
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) p[j] = 0;
+      for (uint32_t step = pow2 >> 1; step; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+          const uint32_t t = p[j] + step;
+          p[j] = s_q[t - 1] < h[j] ? t : p[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {  // p <= len; s_q[len] is padding, and an inactive slot (h = +inf) stops there
+        if (s_q[p[j]] == h[j] && h[j] != ~0ull && s_c[p[j]] >= ci) atomicAdd(&hits[g[j]], 1u);
+      }
+    } else if (len) {
+      // a dense stretch of the read sketch (longer than the LDS stage): searched where it lies
+      const uint64_t* __restrict__ keys = q + lo;
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        if (h[j] > q_last) continue;
+        uint32_t a = 0, b = len;
+        while (a < b) {
+          const uint32_t mid = (a + b) >> 1;
+          if (keys[mid] < h[j]) a = mid + 1; else b = mid;
+        }
+        if (a < len && keys[a] == h[j] && qc[lo + a] >= ci) atomicAdd(&hits[g[j]], 1u);
       }
     }
-    const unsigned long long m = __ballot(found);
-    if (lane == 0) present[w] = m;
+    __syncthreads();
   }
 }
 
-// Pass 2: one wavefront per genome gathers its bits.  bound_pos = number of U entries <= the sketch's
-// completeness bound (nuniq when the sketch is complete): positions below it count towards `sizes`.
-__global__ __launch_bounds__(256) void k_genome_hits(const uint32_t* __restrict__ pos, const uint64_t* __restrict__ offs,
-                                                     uint64_t ngenomes, const unsigned long long* __restrict__ present,
-                                                     uint64_t bound_pos, uint32_t* __restrict__ hits,
-                                                     uint32_t* __restrict__ sizes) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  for (uint64_t g = wave; g < ngenomes; g += nwaves) {
-    const uint64_t beg = offs[g], end = offs[g + 1];
-    uint32_t nh = 0, ns = 0;
-    for (uint64_t base = beg; base < end; base += 64) {
-      const uint64_t i = base + lane;
-      bool inb = false, found = false;
-      if (i < end) {
-        const uint32_t p = pos[i];
-        inb = p < bound_pos;
-        found = inb && ((present[p >> 6] >> (p & 63)) & 1ull);
+__global__ void k_zero_u32(uint32_t* __restrict__ v, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) v[i] = 0;
+}
+
+// hits[g] = sum over the copies; sizes[g] likewise when they were counted (truncated sketch), else the stored size.
+__global__ void k_contain_reduce(const uint32_t* __restrict__ hits_part, const uint32_t* __restrict__ sizes_part,
+                                 const uint32_t* __restrict__ gsize, uint64_t ngenomes, uint32_t copies,
+                                 uint32_t* __restrict__ hits, uint32_t* __restrict__ sizes) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < ngenomes; g += stride) {
+    uint32_t h = 0, z = 0;
+    for (uint32_t c0 = 0; c0 < copies; c0 += 8) {  // eight independent loads per round trip
+      uint32_t a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t c = c0 + u;
+        a[u] = c < copies ? hits_part[(uint64_t)c * ngenomes + g] : 0u;
+        b[u] = (c < copies && sizes_part) ? sizes_part[(uint64_t)c * ngenomes + g] : 0u;
       }
-      nh += __popcll(__ballot(found));
-      ns += __popcll(__ballot(inb));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { h += a[u]; z += b[u]; }
     }
-    if (lane == 0) { hits[g] = nh; sizes[g] = ns; }
+    hits[g] = h;
+    sizes[g] = sizes_part ? z : gsize[g];
   }
 }
 
-// ---- table upload helpers: U = distinct sorted hashes, pos[original index] = rank in U ----
+// ---- table upload helpers ----
 __global__ void k_iota_u32(uint32_t* v, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) v[i] = (uint32_t)i;
 }
 
-__global__ void k_head_flags(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t* __restrict__ flags) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
-}
-
-// rank[i] = exclusive prefix of head flags = (index in U of sorted[i]) + (flag ? 0 : ... ) : inclusive - 1
-__global__ void k_scatter_pos(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ orig,
-                              const uint32_t* __restrict__ flags, const uint64_t* __restrict__ excl, uint64_t n,
-                              uint64_t* __restrict__ uniq, uint32_t* __restrict__ pos) {
+// pair_gen[j] = genome whose sketch holds original entry orig[j]: last g with offsets[g] <= orig[j].
+__global__ void k_pair_genomes(const uint32_t* __restrict__ orig, uint64_t n, const uint64_t* __restrict__ offsets,
+                               uint64_t ngenomes, uint32_t* __restrict__ pair_gen) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const uint64_t r = excl[i] + flags[i] - 1;  // inclusive count of heads up to i, minus one
-    if (flags[i]) uniq[r] = sorted[i];
-    pos[orig[i]] = (uint32_t)r;
+    const uint64_t o = orig[i];
+    uint64_t lo = 0, hi = ngenomes;  // invariant: offsets[lo] <= o < offsets[hi]
+    while (hi - lo > 1) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (offsets[mid] <= o) lo = mid; else hi = mid;
+    }
+    pair_gen[i] = (uint32_t)lo;
   }
+}
+
+__global__ void k_genome_sizes(const uint64_t* __restrict__ offsets, uint64_t ngenomes, uint32_t* __restrict__ gsize) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < ngenomes; g += stride) gsize[g] = (uint32_t)(offsets[g + 1] - offsets[g]);
 }
 
 __global__ void k_upper_bound_one(const uint64_t* __restrict__ uniq, uint64_t n, uint64_t bound, uint64_t* __restrict__ out) {
@@ -166,6 +260,7 @@ int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets, uint64_t ngeno
   const uint64_t total = offsets[ngenomes];
   if (total > 0xfffffff0ull) return fail(MG_ERR_ARG, "sketch table of %llu hashes exceeds the 32-bit position range",
                                          (unsigned long long)total);
+  if (ngenomes > 0xfffffff0ull) return fail(MG_ERR_ARG, "too many genomes");
   db->ngenomes = ngenomes;
   db->total = total;
   MG_TRY(db->offsets.alloc((ngenomes + 1) * sizeof(uint64_t)));
@@ -176,28 +271,27 @@ int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets, uint64_t ngeno
     if (offsets[g + 1] > offsets[g] && hashes[offsets[g + 1] - 1] > mx) mx = hashes[offsets[g + 1] - 1];
   }
   db->max_hash = mx;
-  MG_TRY(db->pos.alloc((total + 1) * sizeof(uint32_t)));
-  MG_TRY(db->uniq.alloc((total + 1) * sizeof(uint64_t)));
+  MG_TRY(db->pair_hash.alloc((total + 1) * sizeof(uint64_t)));
+  MG_TRY(db->pair_gen.alloc((total + 1) * sizeof(uint32_t)));
+  MG_TRY(db->gsize.alloc((ngenomes + 1) * sizeof(uint32_t)));
+  if (ngenomes)
+    hipLaunchKernelGGL(k_genome_sizes, dim3(grid_for(ngenomes, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st,
+                       db->offsets.as<uint64_t>(), ngenomes, db->gsize.as<uint32_t>());
   if (total) {
-    // one-time inversion on the device: sort (hash, original index), mark run heads, scan, scatter
+    // one-time inversion on the device: sort (hash, original index), then original index -> genome
     uint64_t* d_h = (uint64_t*)scratch("db_h", total * sizeof(uint64_t));
-    uint64_t* d_hs = (uint64_t*)scratch("db_hs", total * sizeof(uint64_t));
     uint32_t* d_i = (uint32_t*)scratch("db_i", total * sizeof(uint32_t));
     uint32_t* d_is = (uint32_t*)scratch("db_is", total * sizeof(uint32_t));
-    uint32_t* d_flag = (uint32_t*)scratch("db_flag", total * sizeof(uint32_t));
-    uint64_t* d_excl = (uint64_t*)scratch("db_excl", (total + 1) * sizeof(uint64_t));
-    if (!d_h || !d_hs || !d_i || !d_is || !d_flag || !d_excl) return MG_ERR_NOMEM;
+    if (!d_h || !d_i || !d_is) return MG_ERR_NOMEM;
     MG_HIP(hipMemcpyAsync(d_h, hashes, total * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     const unsigned grid = grid_for(total, 256, (unsigned)c.num_cus * 8);
     hipLaunchKernelGGL(k_iota_u32, dim3(grid), dim3(256), 0, st, d_i, total);
-    MG_TRY(sort_pairs(d_h, d_hs, d_i, d_is, total));
-    hipLaunchKernelGGL(k_head_flags, dim3(grid), dim3(256), 0, st, d_hs, total, d_flag);
-    MG_TRY(exclusive_sum_u32_to_u64(d_flag, d_excl, total, &db->nuniq));
-    hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(256), 0, st, d_hs, d_is, d_flag, d_excl, total,
-                       db->uniq.as<uint64_t>(), db->pos.as<uint32_t>());
-    MG_HIP(hipGetLastError());
-    MG_HIP(hipStreamSynchronize(st));
+    MG_TRY(sort_pairs(d_h, db->pair_hash.as<uint64_t>(), d_i, d_is, total));
+    hipLaunchKernelGGL(k_pair_genomes, dim3(grid), dim3(256), 0, st, d_is, total, db->offsets.as<uint64_t>(), ngenomes,
+                       db->pair_gen.as<uint32_t>());
   }
+  MG_HIP(hipGetLastError());
+  MG_HIP(hipStreamSynchronize(st));
   *out = db.release();
   return MG_OK;
 }
@@ -216,26 +310,38 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
   Context& c = ctx();
   hipStream_t st = c.stream;
-  const uint64_t nwords = (db->nuniq + 63) / 64;
-  unsigned long long* d_present = (unsigned long long*)scratch("contain_bits", (nwords + 1) * sizeof(unsigned long long));
-  uint64_t* d_bpos = (uint64_t*)scratch("contain_bpos", sizeof(uint64_t));
-  if (!d_present || !d_bpos) return MG_ERR_NOMEM;
   ProfScope ps("containment");
-  uint64_t bound_pos = db->nuniq;
-  if (bound != ~0ull) {  // truncated sketch: only table hashes <= bound take part (rare path: one read-back)
-    hipLaunchKernelGGL(k_upper_bound_one, dim3(1), dim3(64), 0, st, db->uniq.as<uint64_t>(), db->nuniq, bound, d_bpos);
+  uint64_t npairs = db->total;
+  uint32_t* d_count_sizes = nullptr;
+  if (bound != ~0ull) {
+    // truncated sketch: only table hashes <= bound take part, in the sizes too (rare path: one read-back)
+    uint64_t* d_bpos = (uint64_t*)scratch("contain_bpos", sizeof(uint64_t));
+    if (!d_bpos) return MG_ERR_NOMEM;
+    hipLaunchKernelGGL(k_upper_bound_one, dim3(1), dim3(64), 0, st, db->pair_hash.as<uint64_t>(), db->total, bound, d_bpos);
     uint64_t* pin = host_words();
     MG_HIP(hipMemcpyAsync(pin + 20, d_bpos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
-    bound_pos = pin[20];
+    npairs = pin[20];
+    d_count_sizes = d_sizes;
   }
-  if (nwords)
-    hipLaunchKernelGGL(k_presence, dim3(grid_for(nwords, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+  // counter copies: enough to spread a skewed sample's hits, few enough to zero and sum in microseconds
+  uint32_t copies = 1;
+  while (copies < 64 && (uint64_t)copies * 2 * db->ngenomes <= 65536) copies *= 2;
+  const uint64_t part_n = (uint64_t)copies * db->ngenomes;
+  uint32_t* d_part = (uint32_t*)scratch("contain_part", (d_count_sizes ? 2 : 1) * part_n * sizeof(uint32_t));
+  if (!d_part) return MG_ERR_NOMEM;
+  uint32_t* d_part_sizes = d_count_sizes ? d_part + part_n : nullptr;
+  hipLaunchKernelGGL(k_zero_u32, dim3(grid_for((d_count_sizes ? 2 : 1) * part_n, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st,
+                     d_part, (d_count_sizes ? 2 : 1) * part_n);
+  if (npairs) {
+    const uint64_t ntiles = (npairs + kCTile - 1) / kCTile;
+    hipLaunchKernelGGL(k_contain_pairs, dim3(grid_for(ntiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st,
                        sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), sk->n, sk->last_hash,
-                       sk->index.as<uint32_t>(), sk->index_shift, ci, db->uniq.as<uint64_t>(), db->nuniq, d_present);
-  hipLaunchKernelGGL(k_genome_hits, dim3(grid_for(db->ngenomes, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
-                     db->pos.as<uint32_t>(), db->offsets.as<uint64_t>(), db->ngenomes, d_present, bound_pos, d_hits,
-                     d_sizes);
+                       sk->index.as<uint32_t>(), sk->index_shift, ci, db->pair_hash.as<uint64_t>(),
+                       db->pair_gen.as<uint32_t>(), npairs, d_part, d_part_sizes, db->ngenomes, copies - 1);
+  }
+  hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(db->ngenomes, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, d_part,
+                     d_part_sizes, db->gsize.as<uint32_t>(), db->ngenomes, copies, d_hits, d_sizes);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }

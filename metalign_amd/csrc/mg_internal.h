@@ -158,14 +158,14 @@ struct mg_sketch {
 };
 
 struct mg_db {
-  // Inverted layout built once at upload (mg_contain.hip): the ascending union U of all genome sketches and, for
-  // every genome hash, its position in U.  Containment then walks U once (coherent look-ups into the read
-  // sketch -> presence bitmap) and gathers bits per genome, instead of G*n scattered look-ups.
-  mg::DevBuf uniq;     // u64[nuniq]   ascending distinct hashes of the whole table
-  mg::DevBuf pos;      // u32[total]   genome hash i -> index into uniq (ascending within a genome)
-  mg::DevBuf offsets;  // u64[ngenomes+1]
+  // Hash-major layout built once at upload (mg_contain.hip): every (hash, genome) pair of every genome sketch,
+  // sorted by hash.  Containment streams the pairs once against the matching run of the read sketch.
+  mg::DevBuf pair_hash;  // u64[total]   ascending (equal hashes of different genomes are adjacent)
+  mg::DevBuf pair_gen;   // u32[total]   genome of the pair
+  mg::DevBuf gsize;      // u32[ngenomes] sketch size of every genome
+  mg::DevBuf offsets;    // u64[ngenomes+1]
   uint64_t ngenomes = 0;
   uint64_t total = 0;
-  uint64_t nuniq = 0;
   uint64_t max_hash = 0;
 };
+
