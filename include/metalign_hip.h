@@ -118,6 +118,16 @@ typedef struct mg_sketch mg_sketch;
 int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
                         uint64_t nreads, int k, uint64_t hmax, uint64_t s,
                         mg_sketch** out);
+/* As mg_sketch_reads_dev, without the host synchronisation at the end: the sketch's size, last hash and
+ * truncation flag stay on the device until the first call that needs them on the host (any accessor, download,
+ * split, set_bound, or mg_sketch_resolve), so a batch can queue stage B behind stage A and synchronise once.
+ * mg_containment_dev accepts such a sketch as it is when s == 0.  d_bases / d_offsets must stay valid until the
+ * sketch is resolved.  mg_sketch_resolve: *rebuilt = 1 when the sketch had to be recomputed (the counting table
+ * inside stage A overflowed): results derived from it before that are stale and must be recomputed. */
+int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
+                              uint64_t nreads, int k, uint64_t hmax, uint64_t s,
+                              mg_sketch** out);
+int mg_sketch_resolve(mg_sketch* sk, int* rebuilt);
 /* Union of (hash,count) runs, counts of equal hashes summed, then truncated to
  * s: the merge step after an all-gather of per-GPU sketches.  Inputs need not
  * be sorted.  `any_truncated`: OR of the inputs' truncated flags with

@@ -27,7 +27,7 @@ EXPORTS = [
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_sketch_reads_dev", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
+    "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
@@ -172,6 +172,12 @@ class Sketch:
     @property
     def kmers_seen(self):
         return int(self.hip.lib.mg_sketch_kmers_seen(self.handle))
+
+    def resolve(self):
+        """Finalise a deferred sketch; True when it had to be rebuilt (results derived from it are stale)."""
+        rebuilt = ctypes.c_int(0)
+        self.hip._chk(self.hip.lib.mg_sketch_resolve(self.handle, ctypes.byref(rebuilt)))
+        return bool(rebuilt.value)
 
     def split(self, bounds):
         """Number of entries below each hash bound (ascending python ints)."""
@@ -413,6 +419,13 @@ class Hip:
         h = _vp()
         self._chk(self.lib.mg_sketch_reads_dev(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_int(k),
                                                ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.byref(h)))
+        return Sketch(self, h, k)
+
+    def sketch_reads_dev_async(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0):
+        """No host sync: the sketch finalises at its first host-side read (Sketch.resolve / size / download ...)."""
+        h = _vp()
+        self._chk(self.lib.mg_sketch_reads_dev_async(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_int(k),
+                                                     ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.byref(h)))
         return Sketch(self, h, k)
 
     def sketch_from_pairs_dev(self, d_hashes, d_counts, n, k, s=0, any_truncated=False, bound=U64_MAX):

@@ -24,7 +24,8 @@ namespace mg {
 // past the end) writes i into every bucket in (bucket(q[i-1]), bucket(q[i])]: hashes are uniform and there is
 // about one bucket per entry, so that is ~1 store per thread, against a 20-step binary search per bucket.
 __global__ void k_build_index(const uint64_t* __restrict__ q, uint64_t n, unsigned shift, uint64_t nbuckets,
-                              uint32_t* __restrict__ idx) {
+                              uint32_t* __restrict__ idx, const uint64_t* __restrict__ meta) {
+  if (meta) n = meta[1];  // a sketch whose finalisation is deferred: its size is still on the device
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i <= n; i += stride) {
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const uint64_t* __restric
                                                        unsigned shift, uint32_t ci, const uint64_t* __restrict__ ph,
                                                        const uint32_t* __restrict__ pg, uint64_t npairs,
                                                        uint32_t* __restrict__ hits_part, uint32_t* __restrict__ sizes_part,
-                                                       uint64_t ngenomes, uint32_t copy_mask) {
+                                                       uint64_t ngenomes, uint32_t copy_mask,
+                                                       const uint64_t* __restrict__ meta) {
+  if (meta) { qn = meta[1]; q_last = meta[2]; }  // deferred sketch: size and last hash are still on the device
   // counters are replicated (copy = workgroup id modulo the number of copies, see mg_containment_dev): a few
   // abundant genomes collect most hits, and atomics on one address retire one at a time
   uint32_t* const hits = hits_part + (uint64_t)(blockIdx.x & copy_mask) * ngenomes;
@@ -223,22 +226,25 @@ __global__ void k_upper_bound_one(const uint64_t* __restrict__ uniq, uint64_t n,
 }
 
 static int ensure_index(mg_sketch* sk) {
-  if (sk->index.p || sk->n == 0) return MG_OK;
-  if (sk->n > 0xfffffff0ull) return fail(MG_ERR_ARG, "read sketch too large for 32-bit index");
+  if (sk->index.p) return MG_OK;
+  const bool pending = sk->pending;
+  const uint64_t n = pending ? sk->n_bound : sk->n;  // pending: an estimate sizes the index, the kernel reads the true n
+  if (n == 0) return MG_OK;
+  if (n > 0xfffffff0ull) return fail(MG_ERR_ARG, "read sketch too large for 32-bit index");
   unsigned bits = 0;
-  for (uint64_t v = sk->last_hash; v; v >>= 1) ++bits;
+  for (uint64_t v = pending ? sk->hmax : sk->last_hash; v; v >>= 1) ++bits;
   if (bits == 0) bits = 1;
   unsigned lb = 0;  // log2(buckets): about one sketch entry per bucket, at most 2^27 buckets
-  while ((1ull << lb) < sk->n && lb < 27) ++lb;
+  while ((1ull << lb) < n && lb < 27) ++lb;
   if (lb < 1) lb = 1;  // keeps the shift below 64
   if (lb > bits) lb = bits;
   sk->index_shift = bits - lb;
   sk->index_buckets = 1ull << lb;
   MG_TRY(sk->index.alloc((sk->index_buckets + 1) * sizeof(uint32_t)));
   ProfScope ps("contain_index");
-  hipLaunchKernelGGL(k_build_index, dim3(grid_for(sk->n + 1, 256, (unsigned)ctx().num_cus * 16)), dim3(256), 0,
+  hipLaunchKernelGGL(k_build_index, dim3(grid_for(n + 1, 256, (unsigned)ctx().num_cus * 16)), dim3(256), 0,
                      ctx().stream, sk->hashes.as<uint64_t>(), sk->n, sk->index_shift, sk->index_buckets,
-                     sk->index.as<uint32_t>());
+                     sk->index.as<uint32_t>(), pending ? sk->meta.as<uint64_t>() : (const uint64_t*)nullptr);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -305,6 +311,10 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   if (!q || !db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
   if (db->ngenomes == 0) return MG_OK;
   mg_sketch* sk = const_cast<mg_sketch*>(q);  // the look-up index is a cache inside the handle
+  // A sketch whose finalisation is deferred is consumed as it is when no completeness bound can apply (s = 0):
+  // the kernels read its size and last hash from the device, nothing is synchronised here.
+  if (sk->pending && (sk->redo.s > 0 || sk->has_bound)) MG_TRY(sketch_resolve(sk, nullptr));
+  const uint64_t* d_meta = sk->pending ? sk->meta.as<uint64_t>() : nullptr;
   MG_TRY(ensure_index(sk));
   uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
   if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
@@ -338,7 +348,7 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
     hipLaunchKernelGGL(k_contain_pairs, dim3(grid_for(ntiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st,
                        sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), sk->n, sk->last_hash,
                        sk->index.as<uint32_t>(), sk->index_shift, ci, db->pair_hash.as<uint64_t>(),
-                       db->pair_gen.as<uint32_t>(), npairs, d_part, d_part_sizes, db->ngenomes, copies - 1);
+                       db->pair_gen.as<uint32_t>(), npairs, d_part, d_part_sizes, db->ngenomes, copies - 1, d_meta);
   }
   hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(db->ngenomes, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, d_part,
                      d_part_sizes, db->gsize.as<uint32_t>(), db->ngenomes, copies, d_hits, d_sizes);

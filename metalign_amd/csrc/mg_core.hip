@@ -166,6 +166,7 @@ static int init_common(int device, void* stream) {
     c.own_stream = true;
   }
   MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), 64 * sizeof(uint64_t), hipHostMallocDefault));
+  MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pend_pinned), 64 * sizeof(uint64_t), hipHostMallocDefault));
   c.device = device;
   c.ready = true;
   return MG_OK;
@@ -181,6 +182,7 @@ void mg_shutdown(void) {
   mg::scratch_release_all();
   mg::pool_release_all();
   if (c.pinned) (void)hipHostFree(c.pinned);
+  if (c.pend_pinned) (void)hipHostFree(c.pend_pinned);
   mg::prof_collect();
   for (hipEvent_t e : c.prof_pool) (void)hipEventDestroy(e);
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);

@@ -21,6 +21,9 @@ struct ProfEntry {
 };
 
 struct DevBuf;
+}  // namespace mg
+struct mg_sketch;
+namespace mg {
 
 struct Context {
   bool ready = false;
@@ -40,6 +43,10 @@ struct Context {
   std::map<std::string, DevBuf*> scratch;
   std::map<uint64_t, std::vector<void*>> pool;  // size class -> free blocks
   uint64_t* pinned = nullptr;
+  // landing words of sketches whose finalisation is deferred (mg_sketch_reads_dev_async): 8 slots x 8 words
+  uint64_t* pend_pinned = nullptr;
+  struct ::mg_sketch* pend_owner[8] = {};
+  unsigned pend_next = 0;
 };
 
 Context& ctx();
@@ -155,7 +162,31 @@ struct mg_sketch {
   mg::DevBuf index;    // u32[nbuckets+1]
   unsigned index_shift = 0;
   uint64_t index_buckets = 0;
+  // Deferred finalisation (mg_sketch_reads_dev_async): until the first host-side read, n / last_hash /
+  // truncated / kmers_seen live in `meta` on the device ([0] runs, [1] n, [2] last hash, [3] truncated,
+  // [4..6] candidates / k-mers / table overflows) with an asynchronous copy in flight to `h_meta`.
+  bool pending = false;
+  mg::DevBuf meta;
+  uint64_t* h_meta = nullptr;
+  int pend_slot = -1;
+  uint64_t n_bound = 0;    // upper bound of n while pending (sizes the look-up index)
+  uint64_t hmax = 0;
+  double expect = 0.0;     // expected candidates: feeds the distinct-count hint at resolution
+  struct Redo {            // what rebuilds the sketch on the list path if the counting table overflowed
+    const uint8_t* bases = nullptr;
+    const uint64_t* offsets = nullptr;
+    uint64_t nreads = 0, hmax = 0, s = 0, cap = 0;
+    int k = 0;
+    unsigned stage = 0;
+  } redo;
+  ~mg_sketch();
 };
+
+namespace mg {
+// Brings a pending sketch's metadata to the host (one stream sync); *rebuilt = 1 when the counting table had
+// overflowed and the sketch was recomputed on the list path (anything derived from it while pending is stale).
+int sketch_resolve(mg_sketch* sk, int* rebuilt);
+}  // namespace mg
 
 struct mg_db {
   // Hash-major layout built once at upload (mg_contain.hip): every (hash, genome) pair of every genome sketch,

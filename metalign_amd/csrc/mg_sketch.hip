@@ -474,8 +474,9 @@ __global__ void k_sketch_split(const uint64_t* __restrict__ hashes, uint64_t n, 
 // meta[0] = runs, then: apply the complete-part bound (entries > bound dropped) and the s cut;
 // meta[1] = kept entries, meta[2] = last kept hash, meta[3] = 1 if anything was cut.
 __global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __restrict__ meta, uint64_t s,
-                              uint32_t use_bound, uint64_t bound) {
+                              uint32_t use_bound, uint64_t bound, const unsigned long long* __restrict__ counters) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (counters) { meta[4] = counters[0]; meta[5] = counters[1]; meta[6] = counters[2]; }  // one block to read back
   const uint64_t runs = meta[0];
   uint64_t keep = runs;
   uint64_t cut = 0;
@@ -500,7 +501,7 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
                       const unsigned long long* d_counters = nullptr, uint64_t* h_counters = nullptr) {
   hipStream_t st = ctx().stream;
   hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), d_meta, s,
-                     (uint32_t)(use_bound ? 1 : 0), bound);
+                     (uint32_t)(use_bound ? 1 : 0), bound, (const unsigned long long*)nullptr);
   uint64_t* pin = host_words();
   MG_HIP(hipMemcpyAsync(pin + 4, d_meta, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (d_counters) MG_HIP(hipMemcpyAsync(pin + 8, d_counters, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -577,9 +578,8 @@ static int alloc_table(TablePlan& tp) {
   return MG_OK;
 }
 
-// Sort every bucket, pack the buckets in order into the sketch's own buffers, apply bound / s, read back.
-static int table_to_sketch(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_bound, uint64_t bound,
-                           const unsigned long long* d_counters, uint64_t* h_counters) {
+// Sort every bucket and pack the buckets in order into the sketch's own buffers (d_meta[0] = distinct hashes).
+static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta) {
   Context& c = ctx();
   hipStream_t st = c.stream;
   {
@@ -598,6 +598,13 @@ static int table_to_sketch(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta,
                        sk->counts.as<uint32_t>(), tp.slots);
     MG_HIP(hipGetLastError());
   }
+  return MG_OK;
+}
+
+// ... then apply bound / s and read back.
+static int table_to_sketch(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_bound, uint64_t bound,
+                           const unsigned long long* d_counters, uint64_t* h_counters) {
+  MG_TRY(table_pack(tp, sk, d_meta));
   return adopt_runs(sk, d_meta, s, use_bound, bound, d_counters, h_counters);
 }
 
@@ -642,14 +649,55 @@ static int sketch_via_list(mg_sketch* sk, const uint8_t* d_bases, const uint64_t
   return adopt_runs(sk, d_meta, s, false, 0);
 }
 
+static double distinct_hint = 1.0;  // distinct / expected candidates of the previous batch (x2), sizes the counting table
+
+int sketch_resolve(mg_sketch* sk, int* rebuilt) {
+  if (rebuilt) *rebuilt = 0;
+  if (!sk || !sk->pending) return MG_OK;
+  Context& c = ctx();
+  MG_HIP(hipStreamSynchronize(c.stream));
+  const uint64_t* m = sk->h_meta;
+  const uint64_t runs = m[0], candidates = m[4], overflows = m[6];
+  sk->n = m[1];
+  sk->last_hash = m[2];
+  sk->truncated = m[3] ? 1 : 0;
+  sk->kmers_seen = m[5];
+  sk->pending = false;
+  if (sk->pend_slot >= 0 && c.pend_owner[sk->pend_slot] == sk) c.pend_owner[sk->pend_slot] = nullptr;
+  sk->pend_slot = -1;
+  if (overflows == 0) {
+    const double r = 2.0 * (double)runs / sk->expect;
+    distinct_hint = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
+    return MG_OK;
+  }
+  // a bucket ran out of slots (more distinct hashes than the hint allowed for): size for the worst case next
+  // time and redo this sketch on the list path, which has no such limit
+  distinct_hint = 1.0;
+  if (rebuilt) *rebuilt = 1;
+  sk->index.release();
+  sk->hashes.release();
+  sk->counts.release();
+  uint64_t cap = sk->redo.cap;
+  if (candidates + 64 > cap) cap = candidates + 64;
+  unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
+  if (!d_counters) return MG_ERR_NOMEM;
+  return sketch_via_list(sk, sk->redo.bases, sk->redo.offsets, sk->redo.nreads, sk->redo.k, sk->redo.hmax, sk->redo.s, cap,
+                         sk->redo.stage, d_counters);
+}
+
 }  // namespace mg
+
+mg_sketch::~mg_sketch() {
+  mg::Context& c = mg::ctx();
+  if (pend_slot >= 0 && c.pend_owner[pend_slot] == this) c.pend_owner[pend_slot] = nullptr;
+}
 
 using namespace mg;
 
 extern "C" {
 
-int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
-                        uint64_t s, mg_sketch** out) {
+int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
+                              uint64_t s, mg_sketch** out) {
   MG_REQUIRE_READY();
   if (!out) return fail(MG_ERR_ARG, "null out handle");
   *out = nullptr;
@@ -697,9 +745,8 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
   // previous call (x2 for safety) tightens it for steady-state batches.  Under-sizing is detected (a bucket
   // with no free slot) and handled by the list path.
-  static double distinct_hint = 1.0;
   const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
-  double distinct_est = (double)expect * distinct_hint;
+  double distinct_est = (double)expect * mg::distinct_hint;
   if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) distinct_est = (double)expect * atof(e);  // tests: force overflow
   TablePlan tp;
   if (!force_list && expect >= 32768 && plan_table(0, hmax, distinct_est, tp)) {
@@ -712,25 +759,43 @@ int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
-    uint64_t h_counters[3] = {0, 0, 0};
-    MG_TRY(table_to_sketch(tp, sk.get(), d_meta, s, false, 0, d_counters, h_counters));
-    sk->kmers_seen = h_counters[1];
-    const uint64_t runs = host_words()[4];  // total distinct hashes found (meta[0])
-    if (h_counters[2] == 0) {
-      double r = 2.0 * (double)runs / (double)(expect ? expect : 1);
-      distinct_hint = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
-      *out = sk.release();
-      return MG_OK;
-    }
-    // a bucket ran out of slots (more distinct hashes than the hint allowed for): size for the worst case next
-    // time and redo this call on the list path, which has no such limit
-    distinct_hint = 1.0;
-    sk.reset(new mg_sketch());
-    if (h_counters[0] + 64 > cap) cap = h_counters[0] + 64;
+    // Deferred finalisation: the sketch's size, last hash and the table-overflow counter stay on the device with a
+    // copy in flight to pinned memory; sketch_resolve() reads them at the first host-side use.
+    Context& cc = ctx();
+    const unsigned slot = cc.pend_next++ & 7u;
+    if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
+    MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
+    uint64_t* sk_meta = sk->meta.as<uint64_t>();
+    MG_TRY(table_pack(tp, sk.get(), sk_meta));
+    hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
+                       (const unsigned long long*)d_counters);
+    MG_HIP(hipGetLastError());
+    sk->h_meta = cc.pend_pinned + 8 * slot;
+    MG_HIP(hipMemcpyAsync(sk->h_meta, sk_meta, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    sk->pending = true;
+    sk->pend_slot = (int)slot;
+    cc.pend_owner[slot] = sk.get();
+    sk->n_bound = tp.slots;  // a sketch cannot outgrow the table; tightened below
+    if ((uint64_t)distinct_est + 1 < sk->n_bound) sk->n_bound = (uint64_t)distinct_est + 1;
+    if (s > 0 && s < sk->n_bound) sk->n_bound = s;
+    sk->hmax = hmax;
+    sk->expect = (double)(expect ? expect : 1);
+    sk->redo.bases = d_bases; sk->redo.offsets = d_offsets; sk->redo.nreads = nreads; sk->redo.k = k;
+    sk->redo.hmax = hmax; sk->redo.s = s; sk->redo.cap = cap; sk->redo.stage = (unsigned)stage;
+    *out = sk.release();
+    return MG_OK;
   }
   MG_TRY(sketch_via_list(sk.get(), d_bases, d_offsets, nreads, k, hmax, s, cap, (unsigned)stage, d_counters));
   *out = sk.release();
   return MG_OK;
+}
+
+int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
+                        uint64_t s, mg_sketch** out) {
+  MG_TRY(mg_sketch_reads_dev_async(d_bases, d_offsets, nreads, k, hmax, s, out));
+  int rc = sketch_resolve(*out, nullptr);
+  if (rc != MG_OK) { mg_sketch_free(*out); *out = nullptr; }
+  return rc;
 }
 
 // General merge: sort the pairs by hash (rocPRIM) and add the counts of equal hashes.
@@ -793,6 +858,7 @@ int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
 int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbounds, uint64_t* out_idx) {
   MG_REQUIRE_READY();
   if (!sk || !bounds || !out_idx) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(sketch_resolve(const_cast<mg_sketch*>(sk), nullptr));
   if (nbounds == 0) return MG_OK;
   if (nbounds > 4096) return fail(MG_ERR_ARG, "too many slice bounds");
   hipStream_t st = ctx().stream;
@@ -809,19 +875,30 @@ int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbound
 
 int mg_sketch_set_bound(mg_sketch* sk, int truncated, uint64_t bound) {
   if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  MG_TRY(sketch_resolve(sk, nullptr));
   sk->has_bound = true;
   sk->truncated = truncated ? 1 : 0;
   sk->bound = bound;
   return MG_OK;
 }
 
-uint64_t mg_sketch_size(const mg_sketch* sk) { return sk ? sk->n : 0; }
-int mg_sketch_truncated(const mg_sketch* sk) { return sk ? sk->truncated : 0; }
-uint64_t mg_sketch_last_hash(const mg_sketch* sk) { return (sk && sk->n) ? sk->last_hash : 0; }
-uint64_t mg_sketch_kmers_seen(const mg_sketch* sk) { return sk ? sk->kmers_seen : 0; }
+static const mg_sketch* settled(const mg_sketch* sk) {  // accessors see a finalised sketch
+  if (sk && sk->pending) (void)sketch_resolve(const_cast<mg_sketch*>(sk), nullptr);
+  return sk;
+}
+uint64_t mg_sketch_size(const mg_sketch* sk) { return settled(sk) ? sk->n : 0; }
+int mg_sketch_truncated(const mg_sketch* sk) { return settled(sk) ? sk->truncated : 0; }
+uint64_t mg_sketch_last_hash(const mg_sketch* sk) { return (settled(sk) && sk->n) ? sk->last_hash : 0; }
+uint64_t mg_sketch_kmers_seen(const mg_sketch* sk) { return settled(sk) ? sk->kmers_seen : 0; }
+int mg_sketch_resolve(mg_sketch* sk, int* rebuilt) {
+  MG_REQUIRE_READY();
+  if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  return sketch_resolve(sk, rebuilt);
+}
 
 int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes, const uint32_t** d_counts) {
   if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  MG_TRY(sketch_resolve(const_cast<mg_sketch*>(sk), nullptr));  // a rebuild would move the buffers
   if (d_hashes) *d_hashes = sk->hashes.as<uint64_t>();
   if (d_counts) *d_counts = sk->counts.as<uint32_t>();
   return MG_OK;
@@ -830,6 +907,7 @@ int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes, const 
 int mg_sketch_download(const mg_sketch* sk, uint64_t* hashes, uint32_t* counts, uint64_t cap) {
   MG_REQUIRE_READY();
   if (!sk) return fail(MG_ERR_ARG, "null sketch");
+  MG_TRY(sketch_resolve(const_cast<mg_sketch*>(sk), nullptr));
   if (cap < sk->n) return fail(MG_ERR_CAPACITY, "sketch has %llu entries, buffer holds %llu", (unsigned long long)sk->n,
                                (unsigned long long)cap);
   if (sk->n == 0) return MG_OK;

@@ -92,6 +92,9 @@ class HipEngine:
     def sketch_local(self, k, hmax, s):
         return self.hip.sketch_reads_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)
 
+    def sketch_local_async(self, k, hmax, s):
+        return self.hip.sketch_reads_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)
+
     def export_sketch(self, sk):
         """(hashes int64 tensor, counts int32 tensor) on this rank's device, zero-copy."""
         t = self.torch
@@ -126,6 +129,10 @@ class HipEngine:
         self.h_hs.fetch_async(self.d_hs.ptr)
         self.h_acc.fetch_async(self.d_acc.ptr)
         self.hip.sync()
+        if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
+            self.hip.containment_dev(sk, self.table, ci, self.d_hs.ptr, self.d_hs.ptr + 4 * g)
+            self.h_hs.fetch_async(self.d_hs.ptr)
+            self.hip.sync()
         hs, acc = self.h_hs.array.copy(), self.h_acc.array.copy()
         mm = self.shard.multimapped() if want_multimapped else None
         self.shard.free()
@@ -322,13 +329,13 @@ class ShardJob:
             sk, committed = self._exchange_step()
             hits, sizes = eng.containment(sk, self.ci)
         else:
-            # single shard: stage C is queued first and runs to completion behind stage A's one host sync (the
-            # sketch size); its results come back with the containment counts, so the step has two syncs, not three
+            # single shard: stage C is queued first, its results come back with the containment counts ...
             eng.profile_begin(self.pct_id, False)
             split = hasattr(eng, "profile_commit_launch")
             if split:
                 eng.profile_commit_launch(1, True, 0)
-            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            # ... and stage A itself does not synchronise: the whole step is queued, then read back once
+            sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
             if split:
                 (hits, sizes), committed = eng.containment_and_commit_results(sk, self.ci, want_multimapped)
             else:

@@ -205,3 +205,35 @@ def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch):
     h, c, _, seen = hip.sketch_reads(b2, o2, k, hmax=int(0.3 * 2**64))
     assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
     assert c.max() >= 6000
+
+
+def test_deferred_sketch_feeds_containment_without_a_sync(hip, oracle_lib, monkeypatch):
+    """mg_sketch_reads_dev_async: stage B consumes the sketch while its size is still on the device; the results
+    equal the oracle's, and a counting-table overflow discovered at resolve() is reported so that stage B is redone."""
+    rng = np.random.default_rng(77)
+    gb, go = util.random_genomes(rng, 12, 30000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 120000, 150, err=0.02)  # many distinct (erroneous) k-mers
+    k, n = 21, 300
+    dbh, dbo = oracle_lib.sketch_genomes(gb, go, k, n)
+    hmax = int(dbh.max())
+    oh, oc, otr, oseen = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax)
+    ohits, osizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
+    table = hip.upload_table(dbh, dbo)
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    d_h, d_s = hip.empty(12, np.uint32), hip.empty(12, np.uint32)
+    for hint, want_rebuilt in ((None, False), ("0.0005", True)):
+        if hint:
+            monkeypatch.setenv("MG_DEBUG_DISTINCT_HINT", hint)
+        sk = hip.sketch_reads_dev_async(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, 0)
+        hip.containment_dev(sk, table, 2, d_h.ptr, d_s.ptr)  # queued behind stage A, nothing synchronised yet
+        hip.sync()
+        rebuilt = sk.resolve()
+        assert rebuilt or not want_rebuilt  # (the adaptive table sizing may also overflow on its own: same handling)
+        if rebuilt:
+            hip.containment_dev(sk, table, 2, d_h.ptr, d_s.ptr)
+        assert np.array_equal(d_h.download(), ohits) and np.array_equal(d_s.download(), osizes)
+        h, c = sk.download()
+        assert sk.kmers_seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
+        assert not sk.resolve()  # idempotent
+        sk.free()
+        monkeypatch.delenv("MG_DEBUG_DISTINCT_HINT", raising=False)

@@ -32,11 +32,10 @@ hip.sync()
 t_all = time.perf_counter()
 for _ in range(N):
     t = time.perf_counter()
-    eng.profile_begin(0.5, False); eng.profile_commit_launch(1, True, 0); t = tic("stage C queued (async)", t)
-    sk = eng.sketch_local(job.k, job.hmax, 0); t = tic("sketch_local (K1..adopt, 1 sync)", t)
-    hs = eng.containment(sk, 2); t = tic("containment (+download)", t)
+    eng.profile_begin(0.5, False); eng.profile_commit_launch(1, True, 0); t = tic("stage C queued", t)
+    sk = eng.sketch_local_async(job.k, job.hmax, 0); t = tic("stage A queued (no sync)", t)
+    res = eng.containment_and_commit_results(sk, 2, False); t = tic("stage B queued + the step's one sync + read-backs", t)
     n = sk.size; sk.free(); t = tic("sketch size/free", t)
-    r = eng.profile_commit_finish(False); t = tic("stage C results (download)", t)
 hip.sync()
 tot = (time.perf_counter() - t_all) / N
 for k, v in acc.items():
