@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--sketch_n", type=int, default=1000)
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    p.add_argument("--no_kernel_table", action="store_true", help="skip the extra instrumented steps (clean traces)")
     return p.parse_args()
 
 
@@ -146,7 +147,7 @@ def main():
     # per-kernel table from a few extra, untimed steps with every kernel family instrumented
     hip.prof_reset()
     hip.prof_enable(True)
-    for _ in range(min(args.steps, 5)):
+    for _ in range(0 if args.no_kernel_table else min(args.steps, 5)):
         job.step()
     sync()
     hip.prof_enable(False)

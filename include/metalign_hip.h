@@ -266,6 +266,12 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard,
                           uint64_t group_base, uint64_t* d_count,
                           uint64_t* d_bases, uint64_t* d_first_seen,
                           uint64_t* d_scalars);
+/* As mg_profile_commit_dev for a batch of its own: the accumulators are reset (as by mg_profile_acc_reset) in the
+ * launch that prepares the pass, instead of being added to. */
+int mg_profile_commit_reset_dev(mg_profile* p, int incoming_dropped, int first_shard,
+                                uint64_t group_base, uint64_t* d_count,
+                                uint64_t* d_bases, uint64_t* d_first_seen,
+                                uint64_t* d_scalars);
 /* Sizes of the multimapped CSR after commit. */
 int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads,
                                 uint64_t* nentries);

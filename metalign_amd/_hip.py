@@ -35,7 +35,7 @@ EXPORTS = [
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
-    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev",
+    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_free", "mg_profile_assign",
 ]
 
@@ -321,8 +321,10 @@ class ProfileShard:
     def ngroups(self):
         return int(self.hip.lib.mg_profile_ngroups(self.handle))
 
-    def commit(self, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars):
-        self.hip._chk(self.hip.lib.mg_profile_commit_dev(
+    def commit(self, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars, reset=False):
+        """reset=True: the accumulators are reset in the same launch that prepares the pass (a batch of its own)."""
+        fn = self.hip.lib.mg_profile_commit_reset_dev if reset else self.hip.lib.mg_profile_commit_dev
+        self.hip._chk(fn(
             self.handle, ctypes.c_int(int(incoming_dropped)), ctypes.c_int(int(first_shard)),
             ctypes.c_uint64(group_base), _vp(d_count), _vp(d_bases), _vp(d_first_seen), _vp(d_scalars)))
 

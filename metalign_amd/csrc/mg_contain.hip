@@ -24,10 +24,12 @@ namespace mg {
 // past the end) writes i into every bucket in (bucket(q[i-1]), bucket(q[i])]: hashes are uniform and there is
 // about one bucket per entry, so that is ~1 store per thread, against a 20-step binary search per bucket.
 __global__ void k_build_index(const uint64_t* __restrict__ q, uint64_t n, unsigned shift, uint64_t nbuckets,
-                              uint32_t* __restrict__ idx, const uint64_t* __restrict__ meta) {
+                              uint32_t* __restrict__ idx, const uint64_t* __restrict__ meta,
+                              uint32_t* __restrict__ zero, uint64_t nzero) {
   if (meta) n = meta[1];  // a sketch whose finalisation is deferred: its size is still on the device
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t z = i; z < nzero; z += stride) zero[z] = 0;  // the hit-counter copies of the same call (one launch less)
   for (; i <= n; i += stride) {
     const uint64_t first = i == 0 ? 0 : (q[i - 1] >> shift) + 1;
     // past the end: only the bucket right after the last hash's is ever read (look-ups stop at q[n-1])
@@ -225,7 +227,9 @@ __global__ void k_upper_bound_one(const uint64_t* __restrict__ uniq, uint64_t n,
   *out = lo;
 }
 
-static int ensure_index(mg_sketch* sk) {
+// zero / nzero: a buffer to clear in the same launch; *zeroed tells whether that happened.
+static int ensure_index(mg_sketch* sk, uint32_t* zero = nullptr, uint64_t nzero = 0, bool* zeroed = nullptr) {
+  if (zeroed) *zeroed = false;
   if (sk->index.p) return MG_OK;
   const bool pending = sk->pending;
   const uint64_t n = pending ? sk->n_bound : sk->n;  // pending: an estimate sizes the index, the kernel reads the true n
@@ -244,8 +248,9 @@ static int ensure_index(mg_sketch* sk) {
   ProfScope ps("contain_index");
   hipLaunchKernelGGL(k_build_index, dim3(grid_for(n + 1, 256, (unsigned)ctx().num_cus * 16)), dim3(256), 0,
                      ctx().stream, sk->hashes.as<uint64_t>(), sk->n, sk->index_shift, sk->index_buckets,
-                     sk->index.as<uint32_t>(), pending ? sk->meta.as<uint64_t>() : (const uint64_t*)nullptr);
+                     sk->index.as<uint32_t>(), pending ? sk->meta.as<uint64_t>() : (const uint64_t*)nullptr, zero, nzero);
   MG_HIP(hipGetLastError());
+  if (zeroed) *zeroed = true;
   return MG_OK;
 }
 
@@ -315,16 +320,26 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   // the kernels read its size and last hash from the device, nothing is synchronised here.
   if (sk->pending && (sk->redo.s > 0 || sk->has_bound)) MG_TRY(sketch_resolve(sk, nullptr));
   const uint64_t* d_meta = sk->pending ? sk->meta.as<uint64_t>() : nullptr;
-  MG_TRY(ensure_index(sk));
   uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
   if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
+  const bool count_sizes = bound != ~0ull;  // truncated sketch: only table hashes <= bound take part, in the sizes too
   Context& c = ctx();
   hipStream_t st = c.stream;
+  // counter copies: enough to spread a skewed sample's hits, few enough to zero and sum in microseconds
+  uint32_t copies = 1;
+  while (copies < 64 && (uint64_t)copies * 2 * db->ngenomes <= 65536) copies *= 2;
+  const uint64_t part_n = (uint64_t)copies * db->ngenomes;
+  const uint64_t zero_n = (count_sizes ? 2 : 1) * part_n;
+  uint32_t* d_part = (uint32_t*)scratch("contain_part", zero_n * sizeof(uint32_t));
+  if (!d_part) return MG_ERR_NOMEM;
+  uint32_t* d_part_sizes = count_sizes ? d_part + part_n : nullptr;
+  bool zeroed = false;
+  MG_TRY(ensure_index(sk, d_part, zero_n, &zeroed));
   ProfScope ps("containment");
+  if (!zeroed)
+    hipLaunchKernelGGL(k_zero_u32, dim3(grid_for(zero_n, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, d_part, zero_n);
   uint64_t npairs = db->total;
-  uint32_t* d_count_sizes = nullptr;
-  if (bound != ~0ull) {
-    // truncated sketch: only table hashes <= bound take part, in the sizes too (rare path: one read-back)
+  if (count_sizes) {  // rare path: one read-back
     uint64_t* d_bpos = (uint64_t*)scratch("contain_bpos", sizeof(uint64_t));
     if (!d_bpos) return MG_ERR_NOMEM;
     hipLaunchKernelGGL(k_upper_bound_one, dim3(1), dim3(64), 0, st, db->pair_hash.as<uint64_t>(), db->total, bound, d_bpos);
@@ -332,17 +347,7 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
     MG_HIP(hipMemcpyAsync(pin + 20, d_bpos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
     npairs = pin[20];
-    d_count_sizes = d_sizes;
   }
-  // counter copies: enough to spread a skewed sample's hits, few enough to zero and sum in microseconds
-  uint32_t copies = 1;
-  while (copies < 64 && (uint64_t)copies * 2 * db->ngenomes <= 65536) copies *= 2;
-  const uint64_t part_n = (uint64_t)copies * db->ngenomes;
-  uint32_t* d_part = (uint32_t*)scratch("contain_part", (d_count_sizes ? 2 : 1) * part_n * sizeof(uint32_t));
-  if (!d_part) return MG_ERR_NOMEM;
-  uint32_t* d_part_sizes = d_count_sizes ? d_part + part_n : nullptr;
-  hipLaunchKernelGGL(k_zero_u32, dim3(grid_for((d_count_sizes ? 2 : 1) * part_n, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st,
-                     d_part, (d_count_sizes ? 2 : 1) * part_n);
   if (npairs) {
     const uint64_t ntiles = (npairs + kCTile - 1) / kCTile;
     hipLaunchKernelGGL(k_contain_pairs, dim3(grid_for(ntiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st,

@@ -646,6 +646,19 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
   }
 }
 
+// Before a pass: tile descriptors + ticket = 0 and, when asked, the accumulators of a fresh batch (one launch).
+__global__ void k_pass_prepare(uint64_t* __restrict__ desc, uint64_t ndesc, uint64_t* __restrict__ count,
+                               uint64_t* __restrict__ bases, uint64_t* __restrict__ first, uint64_t* __restrict__ scalars,
+                               uint32_t ntax) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t i = i0; i < ndesc; i += stride) desc[i] = 0;
+  if (count) {
+    for (uint64_t t = i0; t < ntax; t += stride) { count[t] = 0; bases[t] = 0; first[t] = ~0ull; }
+    if (i0 < 2) scalars[i0] = 0;
+  }
+}
+
 // Accumulators of one batch: count = bases = 0, first_seen = UINT64_MAX, scalars = 0 (one launch).
 __global__ void k_acc_reset(uint64_t* __restrict__ count, uint64_t* __restrict__ bases, uint64_t* __restrict__ first,
                             uint64_t* __restrict__ scalars, uint32_t ntax) {
@@ -680,13 +693,20 @@ namespace {
 
 // One chained-scan pass over the shard.  commit == false: composed state map + read count only.
 int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_shard, uint64_t group_base,
-                uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
+                uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars, bool reset_acc = false) {
   Context& c = ctx();
   hipStream_t st = c.stream;
   const uint64_t desc_bytes = (p->ntiles * kDescWords + 1) * sizeof(uint64_t);
   if (!p->desc.p) MG_TRY(p->desc.alloc(desc_bytes));
   if (!p->tot.p) MG_TRY(p->tot.alloc(4 * sizeof(uint64_t)));
-  MG_HIP(hipMemsetAsync(p->desc.p, 0, desc_bytes, st));
+  {
+    const uint64_t ndesc = desc_bytes / sizeof(uint64_t);
+    const uint64_t work = ndesc > p->ntax ? ndesc : p->ntax;
+    hipLaunchKernelGGL(k_pass_prepare, dim3(grid_for(work, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st,
+                       p->desc.as<uint64_t>(), ndesc, reset_acc ? d_count : (uint64_t*)nullptr, d_bases, d_first_seen, d_scalars,
+                       p->ntax);
+    MG_HIP(hipGetLastError());
+  }
   PassArgs a{};
   a.recs = p->d_recs; a.nrecs = p->nrecs; a.ntotal = p->ntotal;
   a.ref2tax = p->d_ref2tax; a.pct_id = p->pct_id;
@@ -796,13 +816,16 @@ uint64_t mg_profile_ngroups(const mg_profile* p) {
   return p->ngroups;
 }
 
-int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base, uint64_t* d_count,
-                          uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
+static int commit_impl(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base, uint64_t* d_count,
+                       uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars, bool reset_acc) {
   MG_REQUIRE_READY();
   if (!p || !d_count || !d_bases || !d_first_seen || !d_scalars) return fail(MG_ERR_ARG, "null argument");
   if (p->committed) return fail(MG_ERR_STATE, "profile shard already committed");
   p->committed = true;
-  if (p->nrecs == 0) return MG_OK;  // the phantom boundary never happens without a first line: nothing to add
+  if (p->nrecs == 0) {  // the phantom boundary never happens without a first line: nothing to add
+    if (reset_acc) return mg_profile_acc_reset(d_count, d_bases, d_first_seen, d_scalars, p->ntax);
+    return MG_OK;
+  }
   // multimapped CSR buffers sized by their upper bounds (pooled), so that nothing has to be read back here:
   // entries <= records, multimapped reads <= records
   MG_TRY(p->mm_offsets.alloc((p->nrecs + 2) * sizeof(uint64_t)));
@@ -810,7 +833,17 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
   MG_TRY(p->mm_hitlen.alloc((p->nrecs + 1) * sizeof(uint64_t)));
   MG_TRY(p->mm_read.alloc((p->nrecs + 1) * sizeof(uint64_t)));
   return launch_pass(p, true, incoming_dropped ? 1u : 0u, first_shard ? 1u : 0u, group_base, d_count, d_bases,
-                     d_first_seen, d_scalars);
+                     d_first_seen, d_scalars, reset_acc);
+}
+
+int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base, uint64_t* d_count,
+                          uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
+  return commit_impl(p, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars, false);
+}
+
+int mg_profile_commit_reset_dev(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base,
+                                uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
+  return commit_impl(p, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars, true);
 }
 
 int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads, uint64_t* nentries) {

@@ -474,9 +474,10 @@ __global__ void k_sketch_split(const uint64_t* __restrict__ hashes, uint64_t n, 
 // meta[0] = runs, then: apply the complete-part bound (entries > bound dropped) and the s cut;
 // meta[1] = kept entries, meta[2] = last kept hash, meta[3] = 1 if anything was cut.
 __global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __restrict__ meta, uint64_t s,
-                              uint32_t use_bound, uint64_t bound, const unsigned long long* __restrict__ counters) {
+                              uint32_t use_bound, uint64_t bound, const unsigned long long* __restrict__ counters,
+                              uint64_t* __restrict__ host_mirror) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (counters) { meta[4] = counters[0]; meta[5] = counters[1]; meta[6] = counters[2]; }  // one block to read back
+  if (counters) { meta[4] = counters[0]; meta[5] = counters[1]; meta[6] = counters[2]; }
   const uint64_t runs = meta[0];
   uint64_t keep = runs;
   uint64_t cut = 0;
@@ -493,6 +494,10 @@ __global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __r
   meta[1] = keep;
   meta[2] = keep ? unique[keep - 1] : 0;
   meta[3] = cut;
+  if (host_mirror) {  // page-locked host words, written over the bus: the host reads them after the stream sync
+#pragma unroll
+    for (int i = 0; i < 7; ++i) host_mirror[i] = meta[i];
+  }
 }
 
 // Finalise a sketch whose (hash,count) runs were written straight into its own buffers; d_meta[0] = runs.
@@ -501,7 +506,7 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
                       const unsigned long long* d_counters = nullptr, uint64_t* h_counters = nullptr) {
   hipStream_t st = ctx().stream;
   hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), d_meta, s,
-                     (uint32_t)(use_bound ? 1 : 0), bound, (const unsigned long long*)nullptr);
+                     (uint32_t)(use_bound ? 1 : 0), bound, (const unsigned long long*)nullptr, (uint64_t*)nullptr);
   uint64_t* pin = host_words();
   MG_HIP(hipMemcpyAsync(pin + 4, d_meta, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (d_counters) MG_HIP(hipMemcpyAsync(pin + 8, d_counters, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -563,9 +568,10 @@ static bool plan_table(uint64_t lo, uint64_t hi, double distinct_est, TablePlan&
   return true;
 }
 
-static int alloc_table(TablePlan& tp) {
-  // [keys u64 x slots | counts u32 x slots] zeroed in one memset; staging rows are written sparsely
-  uint8_t* d_tab = (uint8_t*)scratch("sk_table", tp.slots * 12);
+static int alloc_table(TablePlan& tp, unsigned long long** d_counters = nullptr) {
+  // [keys u64 x slots | counts u32 x slots | 4 counter words] zeroed in one memset; staging rows are written sparsely
+  const uint64_t tab_bytes = ((tp.slots * 12 + 7) / 8) * 8;
+  uint8_t* d_tab = (uint8_t*)scratch("sk_table", tab_bytes + 4 * sizeof(unsigned long long));
   tp.stage_h = (uint64_t*)scratch("sk_stage_h", tp.slots * sizeof(uint64_t));
   tp.stage_c = (uint32_t*)scratch("sk_stage_c", tp.slots * sizeof(uint32_t));
   tp.nuniq = (uint32_t*)scratch("sk_bucket_n", tp.nbuckets * sizeof(uint32_t));
@@ -573,8 +579,9 @@ static int alloc_table(TablePlan& tp) {
   if (!d_tab || !tp.stage_h || !tp.stage_c || !tp.nuniq || !tp.offs) return MG_ERR_NOMEM;
   tp.keys = reinterpret_cast<uint64_t*>(d_tab);
   tp.cnts = reinterpret_cast<uint32_t*>(d_tab + tp.slots * 8);
+  if (d_counters) *d_counters = reinterpret_cast<unsigned long long*>(d_tab + tab_bytes);
   ProfScope ps("table_clear");
-  MG_HIP(hipMemsetAsync(d_tab, 0, tp.slots * 12, ctx().stream));
+  MG_HIP(hipMemsetAsync(d_tab, 0, tab_bytes + (d_counters ? 4 * sizeof(unsigned long long) : 0), ctx().stream));
   return MG_OK;
 }
 
@@ -750,11 +757,11 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) distinct_est = (double)expect * atof(e);  // tests: force overflow
   TablePlan tp;
   if (!force_list && expect >= 32768 && plan_table(0, hmax, distinct_est, tp)) {
-    MG_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), st));
-    MG_TRY(alloc_table(tp));
+    unsigned long long* t_counters = nullptr;  // cleared together with the table
+    MG_TRY(alloc_table(tp, &t_counters));
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, tp.keys, 0, d_counters, tp.cnts, tp.shift,
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, tp.keys, 0, t_counters, tp.cnts, tp.shift,
                                   (unsigned)stage);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
@@ -767,11 +774,10 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
     uint64_t* sk_meta = sk->meta.as<uint64_t>();
     MG_TRY(table_pack(tp, sk.get(), sk_meta));
-    hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
-                       (const unsigned long long*)d_counters);
-    MG_HIP(hipGetLastError());
     sk->h_meta = cc.pend_pinned + 8 * slot;
-    MG_HIP(hipMemcpyAsync(sk->h_meta, sk_meta, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
+                       (const unsigned long long*)t_counters, sk->h_meta);
+    MG_HIP(hipGetLastError());
     sk->pending = true;
     sk->pend_slot = (int)slot;
     cc.pend_owner[slot] = sk.get();

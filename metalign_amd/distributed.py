@@ -125,13 +125,12 @@ class HipEngine:
         """Stage B's kernels, then BOTH read-backs (containment counts, stage-C accumulators of a commit queued
         earlier with profile_commit_launch) behind them: one synchronisation."""
         g, T = max(self.ngen_local, 1), self.ntax
-        self.hip.containment_dev(sk, self.table, ci, self.d_hs.ptr, self.d_hs.ptr + 4 * g)
-        self.h_hs.fetch_async(self.d_hs.ptr)
+        # the per-genome counts (8 B per genome) are written by the kernel straight into page-locked host memory
+        self.hip.containment_dev(sk, self.table, ci, self.h_hs.ptr, self.h_hs.ptr + 4 * g)
         self.h_acc.fetch_async(self.d_acc.ptr)
         self.hip.sync()
         if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
-            self.hip.containment_dev(sk, self.table, ci, self.d_hs.ptr, self.d_hs.ptr + 4 * g)
-            self.h_hs.fetch_async(self.d_hs.ptr)
+            self.hip.containment_dev(sk, self.table, ci, self.h_hs.ptr, self.h_hs.ptr + 4 * g)
             self.hip.sync()
         hs, acc = self.h_hs.array.copy(), self.h_acc.array.copy()
         mm = self.shard.multimapped() if want_multimapped else None
@@ -154,12 +153,9 @@ class HipEngine:
     def profile_commit_launch(self, incoming, first_shard, group_base):
         """Asynchronous part of the commit: accumulator reset + the stage-C pass; nothing is read back."""
         T = self.ntax
-        import ctypes
         base = self.d_acc.ptr
-        vp = ctypes.c_void_p
-        self.hip._chk(self.hip.lib.mg_profile_acc_reset(vp(base), vp(base + T * 8), vp(base + 2 * T * 8), vp(base + 3 * T * 8),
-                                                        ctypes.c_uint32(T)))
-        self.shard.commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8)
+        self.shard.commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8,
+                          reset=True)
 
     def profile_commit_finish(self, want_multimapped=True):
         T = self.ntax
