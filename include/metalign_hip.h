@@ -280,6 +280,14 @@ int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads,
 int mg_profile_multimapped(const mg_profile* p, uint64_t* mm_offsets,
                            uint32_t* mm_tax, uint64_t* mm_hitlen,
                            uint64_t* mm_read);
+/* resolve_multi_prop (scripts/map_and_profile.py:269-312) on the device, over the multimapped CSR of a committed
+ * shard, without bringing the CSR to the host.  d_weight[t] = unique bases of taxon t after the read cutoff
+ * (:428), NaN for a taxon that was dropped or never hit uniquely (:180-188); d_genome_len[t] = summed accession
+ * lengths when --length_normalize is on, else NULL.  d_extra[t] (ntax doubles, overwritten) receives what the
+ * reference adds to taxids2abs[t][1] at :310-311.  Sums are floating point and order-dependent: equal to the
+ * host computation to ~1e-15 relative, not bit for bit. */
+int mg_profile_resolve_multimapped_dev(const mg_profile* p, const double* d_weight,
+                                       const double* d_genome_len, double* d_extra);
 void mg_profile_free(mg_profile* p);
 
 /* SAM text in HBM -> alignment records (mg_aln_rec), one per retained line, in file order.

@@ -36,7 +36,7 @@ EXPORTS = [
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
-    "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_free", "mg_profile_assign",
+    "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
 ]
 
 
@@ -340,6 +340,28 @@ class ProfileShard:
                                                           _np(rd, ctypes.c_uint64)))
         return off, tax[: ne.value], hl[: nr.value], rd[: nr.value]
 
+    def multimapped_size(self):
+        nr, ne = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self.hip._chk(self.hip.lib.mg_profile_multimapped_size(self.handle, ctypes.byref(nr), ctypes.byref(ne)))
+        return nr.value, ne.value
+
+    def resolve_multimapped(self, weight, genome_len=None):
+        """resolve_multi_prop on the device: weight[t] = unique bases or NaN; -> extra[t] (host float64 array)."""
+        hip = self.hip
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        d_w = hip.array(weight)
+        d_l = hip.array(np.ascontiguousarray(genome_len, dtype=np.float64)) if genome_len is not None else None
+        d_x = hip.empty(len(weight), np.float64)
+        try:
+            hip._chk(hip.lib.mg_profile_resolve_multimapped_dev(self.handle, _vp(d_w.ptr), _vp(d_l.ptr if d_l else None),
+                                                                _vp(d_x.ptr)))
+            return d_x.download()
+        finally:
+            d_w.free()
+            d_x.free()
+            if d_l:
+                d_l.free()
+
     def free(self):
         if self.handle:
             self.hip.lib.mg_profile_free(self.handle)
@@ -350,6 +372,23 @@ class ProfileShard:
             self.free()
         except Exception:  # noqa: BLE001
             pass
+
+
+class ResidentProfile:
+    """A committed stage-C shard kept on the device together with the buffers it reads (multimapped CSR included)."""
+
+    def __init__(self, shard, buffers):
+        self.shard, self.buffers = shard, buffers
+
+    def resolve_multimapped(self, weight, genome_len=None):
+        return self.shard.resolve_multimapped(weight, genome_len)
+
+    def free(self):
+        if self.shard is not None:
+            self.shard.free()
+            for b in self.buffers:
+                b.free()
+            self.shard, self.buffers = None, []
 
 
 class Hip:
@@ -569,6 +608,30 @@ class Hip:
                                                 _vp(d_ref2tax), ctypes.c_uint32(nref), ctypes.c_uint32(ntax),
                                                 ctypes.c_double(pct_id), ctypes.byref(h)))
         return ProfileShard(self, h)
+
+    def profile_assign_resident(self, recs, ref2tax, ntax, pct_id):
+        """As profile_assign, but the multimapped CSR STAYS on the device: -> (dict without the mm_* arrays, plus
+        'mm_nreads' / 'mm_nentries', and 'resident' = a ResidentProfile to resolve the multimapped reads with)."""
+        recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        ref2tax = np.ascontiguousarray(ref2tax, dtype=np.uint32)
+        T = max(int(ntax), 1)
+        d_recs = self.array(recs if len(recs) else np.zeros(1, REC_DTYPE))
+        d_r2t = self.array(ref2tax if ref2tax.size else np.zeros(1, np.uint32))
+        d_acc = self.empty(3 * T + 2, np.uint64)
+        shard = self.profile_begin_dev(d_recs.ptr, len(recs), False, d_r2t.ptr, len(ref2tax), ntax, pct_id)
+        base = d_acc.ptr
+        if len(recs):
+            shard.commit(True, True, 0, base, base + 8 * T, base + 16 * T, base + 24 * T, reset=True)
+            acc = d_acc.download()
+            nr, ne = shard.multimapped_size()
+        else:  # nothing to run: an empty stream has no boundary at all
+            shard.commit(True, True, 0, base, base + 8 * T, base + 16 * T, base + 24 * T, reset=True)
+            acc = d_acc.download()
+            nr = ne = 0
+        res = dict(count=acc[:ntax].copy(), bases=acc[T:T + ntax].copy(), first_seen=acc[2 * T:2 * T + ntax].copy(),
+                   tot_rds=int(acc[3 * T]), n_ambig=int(acc[3 * T + 1]), mm_nreads=nr, mm_nentries=ne)
+        res['resident'] = ResidentProfile(shard, [d_recs, d_r2t, d_acc])
+        return res
 
     def profile_assign(self, recs, ref2tax, ntax, pct_id):
         """Whole stream on one device: host arrays in, dict of host arrays out (same keys as the oracle)."""

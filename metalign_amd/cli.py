@@ -38,6 +38,8 @@ _OPTIONS = {
     'sketch_table': dict(default='AUTO', help='Genome sketch table directory (default: data/sketch_table).'),
     'min_count': dict(type=int, default=2, help='A read k-mer must occur this often to count (kmc -ci, default 2).'),
     'sketch_size': dict(type=int, default=0, help='Read sketch size per k; 0 keeps every hash up to the table maximum.'),
+    'device_multimap': dict(action='store_true', help='Resolve multimapped reads on the GPU (their lists never leave '
+                            'the device; abundances equal the default path to ~1e-15 relative, not byte for byte).'),
 }
 
 _READ_TYPES = ['fastq', 'fasta', 'AUTO']
@@ -50,7 +52,7 @@ _TOOLS = {
         options=['cutoff', 'db_dir', 'dbinfo_in', 'keep_temp_files', ('input_type', _READ_TYPES), 'length_normalize',
                  'low_mem', 'min_abundance', 'no_quantify_unmapped', 'output', 'pct_id', 'precise', 'rank_renormalize',
                  'read_cutoff', 'sampleID', 'sensitive', 'strain_level', 'temp_dir', 'threads', 'verbose',
-                 'sketch_table', 'min_count', 'sketch_size']),
+                 'sketch_table', 'min_count', 'sketch_size', 'device_multimap']),
     'select_db': dict(
         description='Run CMash and select a subset of the whole database to align to.',
         positionals=[('reads', dict(help='Reads file (FASTA / FASTQ, optionally .gz).')),
@@ -65,7 +67,7 @@ _TOOLS = {
         options=[('db', 'NONE', 'Database FASTA from select_db (needed unless the inputs are SAM files).'), 'dbinfo',
                  ('input_type', ['fastq', 'fasta', 'sam', 'AUTO']), 'length_normalize', 'low_mem', 'min_abundance',
                  'rank_renormalize', 'output', 'pct_id', 'no_quantify_unmapped', 'read_cutoff', 'sampleID', 'threads',
-                 'verbose']),
+                 'verbose', 'device_multimap']),
 }
 
 

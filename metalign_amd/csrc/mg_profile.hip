@@ -667,6 +667,58 @@ __global__ void k_acc_reset(uint64_t* __restrict__ count, uint64_t* __restrict__
   if (blockIdx.x == 0 && threadIdx.x < 2) scalars[threadIdx.x] = 0;
 }
 
+// resolve_multi_prop (scripts/map_and_profile.py:269-312) over the multimapped CSR the pass left on the device:
+// one thread per multimapped read.  The DISTINCT taxa of the read that still have a weight (NaN = dropped by the
+// read cutoff or never seen uniquely, :180-188,:428) share its hitlen in proportion to their weights; the shares are
+// summed per taxon (LDS-privatised for ntax <= 2048, then global f64 atomics).  Floating-point sums are
+// order-dependent: the result equals the host version to ~1e-15 relative, not bit for bit (the reference's own
+// order is a Python set's).
+__global__ __launch_bounds__(256) void k_resolve_multimapped(const uint64_t* __restrict__ mm_offsets,
+                                                             const uint32_t* __restrict__ mm_tax,
+                                                             const uint64_t* __restrict__ mm_hitlen,
+                                                             const uint64_t* __restrict__ tot,
+                                                             const double* __restrict__ weight,
+                                                             const double* __restrict__ genome_len, uint32_t ntax,
+                                                             uint32_t use_lds, double* __restrict__ extra) {
+  extern __shared__ double s_extra[];
+  if (use_lds) {
+    for (uint32_t t = threadIdx.x; t < ntax; t += blockDim.x) s_extra[t] = 0.0;
+    __syncthreads();
+  }
+  const uint64_t nreads = tot[3];
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nreads; i += stride) {
+    const uint64_t o0 = mm_offsets[i], o1 = mm_offsets[i + 1];
+    const double hitlen = (double)mm_hitlen[i];
+    auto first_kept = [&](uint64_t e, uint32_t t, double w) {  // e is the first entry of taxon t, and t has a weight
+      if (w != w) return false;
+      for (uint64_t f = o0; f < e; ++f)
+        if (mm_tax[f] == t) return false;
+      return true;
+    };
+    double denom = 0.0;
+    for (uint64_t e = o0; e < o1; ++e) {
+      const uint32_t t = mm_tax[e];
+      const double w = weight[t];
+      if (first_kept(e, t, w)) denom += w;
+    }
+    if (denom == 0.0) continue;  // no taxon left (:280-281) or all weights zero (:286-287)
+    for (uint64_t e = o0; e < o1; ++e) {
+      const uint32_t t = mm_tax[e];
+      const double w = weight[t];
+      if (!first_kept(e, t, w)) continue;
+      double part = (w / denom) * hitlen;
+      if (genome_len) part /= genome_len[t];
+      if (use_lds) atomicAdd(&s_extra[t], part); else atomicAdd(&extra[t], part);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntax; t += blockDim.x)
+      if (s_extra[t] != 0.0) atomicAdd(&extra[t], s_extra[t]);
+  }
+}
+
 }  // namespace mg
 
 using namespace mg;
@@ -844,6 +896,24 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
 int mg_profile_commit_reset_dev(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base,
                                 uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
   return commit_impl(p, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars, true);
+}
+
+int mg_profile_resolve_multimapped_dev(const mg_profile* p, const double* d_weight, const double* d_genome_len,
+                                       double* d_extra) {
+  MG_REQUIRE_READY();
+  if (!p || !d_weight || !d_extra) return fail(MG_ERR_ARG, "null argument");
+  if (!p->committed) return fail(MG_ERR_STATE, "profile shard not committed");
+  hipStream_t st = ctx().stream;
+  MG_HIP(hipMemsetAsync(d_extra, 0, (uint64_t)p->ntax * sizeof(double), st));
+  if (p->nrecs == 0) return MG_OK;
+  const uint32_t use_lds = p->ntax <= 2048 ? 1u : 0u;
+  ProfScope ps("resolve_multimapped");
+  hipLaunchKernelGGL(k_resolve_multimapped, dim3(grid_for(p->nrecs / 4 + 1, 256, (unsigned)ctx().num_cus * 4)), dim3(256),
+                     use_lds ? (size_t)p->ntax * sizeof(double) : 0, st, p->mm_offsets.as<uint64_t>(),
+                     p->mm_tax.as<uint32_t>(), p->mm_hitlen.as<uint64_t>(), p->tot.as<uint64_t>(), d_weight, d_genome_len,
+                     p->ntax, use_lds, d_extra);
+  MG_HIP(hipGetLastError());
+  return MG_OK;
 }
 
 int mg_profile_multimapped_size(const mg_profile* p, uint64_t* nreads, uint64_t* nentries) {

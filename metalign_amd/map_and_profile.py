@@ -280,6 +280,11 @@ def _device_assign(recs, ref2tax, ntax, pct_id):
     return _hip.Hip.get().profile_assign(recs, ref2tax, ntax, pct_id)
 
 
+def _device_assign_resident(recs, ref2tax, ntax, pct_id):
+    """--device_multimap: the multimapped CSR stays in HBM (res['resident']) for resolve_multi_prop_device."""
+    return _hip.Hip.get().profile_assign_resident(recs, ref2tax, ntax, pct_id)
+
+
 def multimapped_lists(res, taxids):
     """Multimapped CSR -> the reference's list of [taxid, ..., hitlen] lists (:245-248)."""
     off, mtax, mlen = res['mm_offsets'], res['mm_tax'], res['mm_hitlen']
@@ -311,7 +316,7 @@ def assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=True):
             taxids2abs[taxid][1] += nbases
         else:
             taxids2abs[taxid] = [nreads, nbases] + taxid2info[taxid]
-    if args.low_mem and len(res['mm_hitlen']) > 0:
+    if args.low_mem and (res['mm_nreads'] if 'resident' in res else len(res['mm_hitlen'])) > 0:
         raise TypeError("object of type 'int' has no len()")  # what the reference does at :253,255
     multimapped = multimapped_lists(res, taxids) if want_lists else res
     if not args.no_quantify_unmapped:
@@ -321,7 +326,7 @@ def assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=True):
     return taxids2abs, multimapped, {}
 
 
-def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_lists=True):
+def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_lists=True, _resident=False):
     """Reference signature (:193).  `_assign` is a test seam; product code never passes it."""
     acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
     _ = taxid2info['Unmapped']  # KeyError here, as at :197, when db_info lacks the Unmapped row
@@ -330,7 +335,8 @@ def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_li
     if getattr(args, 'paf_input', False):
         tokenise = tokenise_paf
     recs = tokenise(instream, acc_index, decode=(args.input_type != 'sam'))
-    res = (_assign or _device_assign)(recs, ref2tax, len(taxids), float(args.pct_id))
+    res = (_assign or (_device_assign_resident if _resident else _device_assign))(recs, ref2tax, len(taxids),
+                                                                                  float(args.pct_id))
     if not _want_lists:
         res = dict(res, taxids=taxids)
     return assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=_want_lists)
@@ -417,6 +423,22 @@ def resolve_multi_prop_csr(args, taxids2abs, mm, taxid2info):
     return taxids2abs
 
 
+def resolve_multi_prop_device(args, taxids2abs, mm, taxid2info):
+    """resolve_multi_prop (:269-312) by mg_profile_resolve_multimapped_dev: the multimapped lists stay on the GPU,
+    the host sends one weight per taxon (NaN = no entry in taxids2abs) and gets one addition per taxon back."""
+    echo('Assigning multimapped reads...', args.verbose)
+    taxids = mm['taxids']
+    weight = np.full(len(taxids), np.nan)
+    index = {t: i for i, t in enumerate(taxids)}
+    for taxid, row in taxids2abs.items():
+        weight[index[taxid]] = row[1]
+    glen = np.array([taxid2info[x][0] for x in taxids], dtype=np.float64) if args.length_normalize else None
+    extra = mm['resident'].resolve_multimapped(weight, glen)
+    for i in np.nonzero(extra)[0]:
+        taxids2abs[taxids[int(i)]][1] += float(extra[i])
+    return taxids2abs
+
+
 def rank_renormalize(args, clades2abs, only_strains=False):
     """Scale abundances so each rank sums to the mapped percentage (:316-339)."""
     totals = dict.fromkeys(RANKS, 0.0)
@@ -480,14 +502,22 @@ def compute_abundances(args, infile, acc2info, tax2info):
         instream = iter(mapper.stdout.readline, b'')
     # product path: the multimapped reads stay in the kernel's CSR form; preprocess_multimapped (:180-188) is
     # subsumed by the membership test inside the resolve step (a taxon dropped there is dropped here too)
-    taxids2abs, mm, low_mem_mmap = map_and_process(args, instream, acc2info, tax2info, _want_lists=False)
+    on_device = bool(getattr(args, 'device_multimap', False))
+    taxids2abs, mm, low_mem_mmap = map_and_process(args, instream, acc2info, tax2info, _want_lists=False,
+                                                   _resident=on_device)
     if args.input_type == 'sam':
         instream.close()
     else:
         mapper.stdout.close()
         mapper.wait()
     taxids2abs = {k: v for k, v in taxids2abs.items() if v[0] > args.read_cutoff}
-    if len(mm['mm_hitlen']) > 0:
+    if on_device:
+        try:
+            if mm['mm_nreads'] > 0:
+                taxids2abs = resolve_multi_prop_device(args, taxids2abs, mm, tax2info)
+        finally:
+            mm['resident'].free()
+    elif len(mm['mm_hitlen']) > 0:
         taxids2abs = resolve_multi_prop_csr(args, taxids2abs, mm, tax2info)
     return tree_results_cami(args, taxids2abs)
 

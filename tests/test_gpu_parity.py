@@ -237,3 +237,65 @@ def test_deferred_sketch_feeds_containment_without_a_sync(hip, oracle_lib, monke
         assert not sk.resolve()  # idempotent
         sk.free()
         monkeypatch.delenv("MG_DEBUG_DISTINCT_HINT", raising=False)
+
+
+@pytest.mark.parametrize("name", ["single_3k", "paired_2k", "single_100k", "paired_40k"])
+def test_device_multimap_matches_reference_cami(hip, name, tmp_path):
+    """--device_multimap: resolve_multi_prop runs on the GPU over the resident CSR.  The CAMI
+    profile equals the reference's golden text up to the 1e-6 abundance tolerance (sums are order-dependent), and
+    the exceptions the reference raises still surface."""
+    from metalign_amd import map_and_profile as mp
+    spec = sc.load_bulk()[name]
+    sam, dbp = sc.materialise_bulk(name, spec, tmp_path)
+    for run in spec["runs"]:
+        out = str(tmp_path / "abund_dev.tsv")
+        args = sc.make_args(sam, dbp, out, dict(run["args"], device_multimap=True))
+        raised = None
+        try:
+            mp.map_main(args)
+        except SystemExit as e:
+            raised = ["SystemExit", str(e)]
+        except Exception as e:  # noqa: BLE001
+            raised = [type(e).__name__, str(e)]
+        assert raised == run.get("map_main_raises")
+        if raised is None:
+            with open(out) as fh:
+                sc._cami_close(fh.read(), run["cami"])
+
+
+def test_device_multimap_equals_host_resolution(hip, oracle_lib):
+    """mg_profile_resolve_multimapped_dev vs the vectorised host version on random multimapped lists with repeated
+    and dropped taxa, with and without length normalisation (1e-12 relative)."""
+    from metalign_amd import map_and_profile as mp
+    import argparse
+    rng = np.random.default_rng(5)
+    nrec, nref, ntax = 300000, 400, 37
+    recs = np.zeros(nrec, dtype=oracle_lib.REC_DTYPE)
+    new = rng.random(nrec) < 0.45
+    new[0] = True
+    recs["ref_new"] = rng.integers(0, nref, size=nrec).astype(np.uint32) | (new.astype(np.uint32) << 31)
+    recs["total"] = 100
+    recs["matched"] = rng.integers(30, 101, size=nrec)
+    recs["flag_len"] = rng.choice([0, 16, 256, 272], size=nrec).astype(np.uint32) | (np.uint32(100) << 12)
+    ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
+    taxids = ["t%d" % i for i in range(ntax)]
+    res_host = hip.profile_assign(recs, ref2tax, ntax, 0.5)
+    res_dev = hip.profile_assign_resident(recs, ref2tax, ntax, 0.5)
+    assert res_dev["mm_nreads"] == len(res_host["mm_hitlen"]) > 1000
+    for key in ("count", "bases", "first_seen"):
+        assert np.array_equal(res_dev[key], res_host[key])
+    taxid2info = {t: [1000.0 + 13 * i] for i, t in enumerate(taxids)}
+    for norm in (False, True):
+        args = argparse.Namespace(verbose=False, length_normalize=norm, low_mem=False)
+        keep = [i for i in range(ntax) if res_host["count"][i] > 0 and i % 5 != 0]  # some taxa dropped by a cutoff
+        a = {taxids[i]: [int(res_host["count"][i]), float(res_host["bases"][i])] for i in keep}
+        b = {k: list(v) for k, v in a.items()}
+        mp.resolve_multi_prop_csr(args, a, dict(res_host, taxids=taxids), taxid2info)
+        mp.resolve_multi_prop_device(args, b, dict(res_dev, taxids=taxids), taxid2info)
+        assert a.keys() == b.keys()
+        changed = 0
+        for k in a:
+            assert abs(a[k][1] - b[k][1]) <= 1e-12 * max(1.0, abs(a[k][1])), (k, a[k], b[k])
+            changed += a[k][1] != float(res_host["bases"][taxids.index(k)])
+        assert changed > 5
+    res_dev["resident"].free()
