@@ -259,6 +259,9 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs,
  * asynchronous, one launch. */
 int mg_profile_acc_reset(uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen,
                          uint64_t* d_scalars, uint32_t ntax);
+/* Queues the map-only pass behind whatever is on the stream, without synchronising: mg_profile_state_map /
+ * mg_profile_ngroups then only read its two result words back. */
+int mg_profile_map_launch(mg_profile* p);
 /* map[0] = outgoing bit if incoming is 0, map[1] = ... if incoming is 1. */
 int mg_profile_state_map(const mg_profile* p, uint8_t map[2]);
 uint64_t mg_profile_ngroups(const mg_profile* p);

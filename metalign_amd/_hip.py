@@ -35,7 +35,7 @@ EXPORTS = [
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
-    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
+    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
 ]
 
@@ -311,6 +311,10 @@ class ProfileShard:
 
     def __init__(self, hip, handle):
         self.hip, self.handle = hip, handle
+
+    def map_launch(self):
+        """Queue the map-only pass now (no sync); state_map() / ngroups then only read two words back."""
+        self.hip._chk(self.hip.lib.mg_profile_map_launch(self.handle))
 
     def state_map(self):
         m = (ctypes.c_uint8 * 2)()

@@ -734,6 +734,7 @@ struct mg_profile {
   uint8_t map[2] = {0, 1};
   uint64_t ngroups = 0;
   bool have_map = false;     // composed state map / read count known (map-only pass, or read back after commit)
+  bool map_launched = false; // the map-only pass is queued (mg_profile_map_launch); its totals are not read back yet
   bool have_mm = false;      // multimapped totals read back (lazily)
   bool committed = false;
   // multimapped CSR (device)
@@ -795,7 +796,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
 int fetch_map(mg_profile* p) {
   if (p->have_map || p->nrecs == 0) { p->have_map = true; return MG_OK; }
   hipStream_t st = ctx().stream;
-  if (!p->committed)  // nobody ran over the shard yet: the map-only pass
+  if (!p->committed && !p->map_launched)  // nobody ran over the shard yet: the map-only pass
     MG_TRY(launch_pass(p, false, 0, 0, 0, nullptr, nullptr, nullptr, nullptr));
   uint64_t* h_tot = host_words() + 16;
   MG_HIP(hipMemcpyAsync(h_tot, p->tot.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -850,6 +851,15 @@ int mg_profile_acc_reset(uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first
   hipLaunchKernelGGL(k_acc_reset, dim3(grid_for((uint64_t)ntax + 2, 256, 64)), dim3(256), 0, ctx().stream, d_count, d_bases,
                      d_first_seen, d_scalars, ntax);
   MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
+int mg_profile_map_launch(mg_profile* p) {
+  MG_REQUIRE_READY();
+  if (!p) return fail(MG_ERR_ARG, "null profile");
+  if (p->have_map || p->map_launched || p->committed || p->nrecs == 0) return MG_OK;
+  MG_TRY(launch_pass(p, false, 0, 0, 0, nullptr, nullptr, nullptr, nullptr));
+  p->map_launched = true;
   return MG_OK;
 }
 

@@ -150,6 +150,15 @@ class HipEngine:
             return (0, 1), 0
         return self.shard.state_map(), self.shard.ngroups
 
+    def profile_begin_async(self, pct_id):
+        """Pass A of stage C queued without a sync; profile_map() fetches its two words later."""
+        self.shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
+                                                self.nref, self.ntax, pct_id)
+        self.shard.map_launch()
+
+    def profile_map(self):
+        return self.shard.state_map(), self.shard.ngroups
+
     def profile_commit_launch(self, incoming, first_shard, group_base):
         """Asynchronous part of the commit: accumulator reset + the stage-C pass; nothing is read back."""
         T = self.ntax
@@ -257,8 +266,14 @@ class ShardJob:
         commit runs (it only needs the gathered state maps).
         -> (this rank's slice of the sample sketch, commit results)."""
         eng, t, dist, W = self.engine, self.torch, self.dist, self.world
-        sk = eng.sketch_local(self.k, self.hmax, self.s)
-        (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
+        if hasattr(eng, "profile_begin_async"):
+            # stage C's map-only pass is queued first: stage A's one synchronisation covers it too
+            eng.profile_begin_async(self.pct_id)
+            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            (m0, m1), ngroups = eng.profile_map()
+        else:
+            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
         n = sk.size
         cuts = [0] + eng.split_sketch(sk, self.bounds[1:W]) + [n]
         send_counts = [cuts[q + 1] - cuts[q] for q in range(W)]
@@ -275,7 +290,11 @@ class ShardJob:
         incoming = compose_incoming(maps, self.rank)
         group_base = int(sum(w[W + 5] for w in words[: self.rank]))
         first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
-        committed = eng.profile_commit(incoming, first_shard, group_base, self._want_mm)
+        if hasattr(eng, "profile_commit_launch"):
+            eng.profile_commit_launch(incoming, first_shard, group_base)  # read back with stage B's counts (step())
+            committed = None
+        else:
+            committed = eng.profile_commit(incoming, first_shard, group_base, self._want_mm)
         for wk in inflight:
             wk.wait()
         sk.free()
@@ -323,7 +342,10 @@ class ShardJob:
         self._want_mm = want_multimapped
         if self.exchange:
             sk, committed = self._exchange_step()
-            hits, sizes = eng.containment(sk, self.ci)
+            if committed is None:  # commit is in flight: one read-back for stage B's counts and its accumulators
+                (hits, sizes), committed = eng.containment_and_commit_results(sk, self.ci, want_multimapped)
+            else:
+                hits, sizes = eng.containment(sk, self.ci)
         else:
             # single shard: stage C is queued first, its results come back with the containment counts ...
             eng.profile_begin(self.pct_id, False)
