@@ -141,17 +141,23 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const uint64_t* __restric
         if (s_q[p[j]] == h[j] && h[j] != ~0ull && s_c[p[j]] >= ci) atomicAdd(&hits[g[j]], 1u);
       }
     } else if (len) {
-      // a dense stretch of the read sketch (longer than the LDS stage): searched where it lies
-      const uint64_t* __restrict__ keys = q + lo;
+      // A run longer than the LDS stage: either the read sketch is locally much denser than the table (the top of
+      // the hash range, where few genome sketches reach) or simply huge.  Every pair goes through the bucket index
+      // on its own (about one sketch entry per bucket): three dependent loads, the eight pairs' chains independent.
+      uint32_t a[kPer], b[kPer];
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
-        if (h[j] > q_last) continue;
-        uint32_t a = 0, b = len;
-        while (a < b) {
-          const uint32_t mid = (a + b) >> 1;
-          if (keys[mid] < h[j]) a = mid + 1; else b = mid;
+        a[j] = b[j] = 0;
+        if (h[j] <= q_last) { const uint64_t bk = h[j] >> shift; a[j] = idx[bk]; b[j] = idx[bk + 1]; }
+      }
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        uint32_t x = a[j], y = b[j];
+        while (x < y) {  // lower_bound inside the bucket
+          const uint32_t mid = (x + y) >> 1;
+          if (q[mid] < h[j]) x = mid + 1; else y = mid;
         }
-        if (a < len && keys[a] == h[j] && qc[lo + a] >= ci) atomicAdd(&hits[g[j]], 1u);
+        if (x < b[j] && q[x] == h[j] && qc[x] >= ci) atomicAdd(&hits[g[j]], 1u);
       }
     }
     __syncthreads();
