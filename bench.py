@@ -189,6 +189,9 @@ def main():
                          "avg_launch_ms": k1_avg, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ_K1 * args.reads,
                          "note": "integer-ALU bound (MurmurHash3 per k-mer), see DESIGN.md"},
             "kernel_avg_ms": kernels,
+            "kernel_note": "HIP-event time per kernel family from extra instrumented steps; profile_pass runs on the "
+                           "library's second stream concurrently with sketch_reads, so its figure includes waiting for CUs "
+                           "(0.06 ms when it runs alone)",
             "check": {"top_genomes_recovered": out.get("top_ok"), "tot_rds": out.get("tot_rds")},
         }
         if not args.no_cpu_baseline:

@@ -89,6 +89,13 @@ int mg_host_alloc(void** h_ptr, uint64_t bytes);
 int mg_host_free(void* h_ptr);
 int mg_memcpy_d2h_async(void* h_pinned_dst, const void* d_src, uint64_t bytes);
 int mg_sync(void);
+/* Stage C on a second stream of the library (on != 0): its latency-bound pass then overlaps the small kernels
+ * that finish stage A and run stage B instead of queueing behind them.  While enabled, every mg_profile_* launch
+ * goes to that stream; its inputs must be complete when the call is made (they are after any mg_sync / synchronous
+ * copy).  mg_stage_c_join makes the main stream wait for what stage C has queued so far (before reading its
+ * accumulators with mg_memcpy_d2h_async); mg_sync waits for both streams. */
+int mg_stage_c_side_stream(int on);
+int mg_stage_c_join(void);
 
 /* Per-kernel timing with HIP events on the library stream (bench.py's
  * roofline leg).  Names are the kernel family names listed in DESIGN.md. */

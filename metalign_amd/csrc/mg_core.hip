@@ -99,19 +99,19 @@ static hipEvent_t prof_event() {
   return e;
 }
 
-ProfScope::ProfScope(const char* n) : name(n), on(ctx().prof_on) {
+ProfScope::ProfScope(const char* n, hipStream_t st) : name(n), on(ctx().prof_on), stream(st ? st : ctx().stream) {
   if (on && ctx().prof_only[0] && strcmp(ctx().prof_only, n) != 0) on = false;
   if (!on) return;
   a = prof_event();
   b = prof_event();
   if (!a || !b) { on = false; return; }
-  (void)hipEventRecord(a, ctx().stream);
+  (void)hipEventRecord(a, stream);
 }
 
 ProfScope::~ProfScope() {
   if (!on) return;
   Context& c = ctx();
-  (void)hipEventRecord(b, c.stream);
+  (void)hipEventRecord(b, stream);
   c.prof_pending.push_back({name, a, b});
 }
 
@@ -183,6 +183,8 @@ void mg_shutdown(void) {
   mg::pool_release_all();
   if (c.pinned) (void)hipHostFree(c.pinned);
   if (c.pend_pinned) (void)hipHostFree(c.pend_pinned);
+  if (c.stream_c) { (void)hipStreamSynchronize(c.stream_c); (void)hipStreamDestroy(c.stream_c); }
+  if (c.ev_c) (void)hipEventDestroy(c.ev_c);
   mg::prof_collect();
   for (hipEvent_t e : c.prof_pool) (void)hipEventDestroy(e);
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
@@ -224,6 +226,7 @@ int mg_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes) {
 int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes) {
   MG_REQUIRE_READY();
   if (bytes == 0) return MG_OK;
+  if (ctx().c_side) MG_HIP(hipStreamSynchronize(ctx().stream_c));  // a synchronous read sees stage C's results too
   MG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
   MG_HIP(hipStreamSynchronize(ctx().stream));
   return MG_OK;
@@ -259,7 +262,29 @@ int mg_dev_memset(void* d_ptr, int byte_value, uint64_t bytes) {
 
 int mg_sync(void) {
   MG_REQUIRE_READY();
+  if (ctx().c_side) MG_HIP(hipStreamSynchronize(ctx().stream_c));
   MG_HIP(hipStreamSynchronize(ctx().stream));
+  return MG_OK;
+}
+
+int mg_stage_c_side_stream(int on) {
+  MG_REQUIRE_READY();
+  mg::Context& c = ctx();
+  if (on && !c.stream_c) {
+    MG_HIP(hipStreamCreateWithFlags(&c.stream_c, hipStreamNonBlocking));
+    MG_HIP(hipEventCreateWithFlags(&c.ev_c, hipEventDisableTiming));
+  }
+  if (!on && c.c_side) MG_HIP(hipStreamSynchronize(c.stream_c));
+  c.c_side = on != 0;
+  return MG_OK;
+}
+
+int mg_stage_c_join(void) {
+  MG_REQUIRE_READY();
+  mg::Context& c = ctx();
+  if (!c.c_side) return MG_OK;
+  MG_HIP(hipEventRecord(c.ev_c, c.stream_c));
+  MG_HIP(hipStreamWaitEvent(c.stream, c.ev_c, 0));
   return MG_OK;
 }
 

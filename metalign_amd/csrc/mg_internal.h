@@ -30,6 +30,11 @@ struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // optional second stream for stage C (mg_stage_c_side_stream): its latency-bound pass then overlaps the small
+  // kernels that finish stage A and run stage B instead of queueing behind them
+  hipStream_t stream_c = nullptr;
+  hipEvent_t ev_c = nullptr;
+  bool c_side = false;
   int num_cus = 256;
   // profiling
   bool prof_on = false;
@@ -116,10 +121,13 @@ void scratch_release_all();
 struct ProfScope {
   const char* name;
   bool on;
+  hipStream_t stream;
   hipEvent_t a = nullptr, b = nullptr;
-  explicit ProfScope(const char* n);
+  explicit ProfScope(const char* n, hipStream_t st = nullptr);  // nullptr: the library stream
   ~ProfScope();
 };
+// The stream stage C launches on.
+inline hipStream_t stage_c_stream() { return ctx().c_side ? ctx().stream_c : ctx().stream; }
 // Reads every pending event pair (synchronises on them) into ctx().prof.
 void prof_collect();
 

@@ -748,7 +748,7 @@ namespace {
 int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_shard, uint64_t group_base,
                 uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars, bool reset_acc = false) {
   Context& c = ctx();
-  hipStream_t st = c.stream;
+  hipStream_t st = stage_c_stream();
   const uint64_t desc_bytes = (p->ntiles * kDescWords + 1) * sizeof(uint64_t);
   if (!p->desc.p) MG_TRY(p->desc.alloc(desc_bytes));
   if (!p->tot.p) MG_TRY(p->tot.alloc(4 * sizeof(uint64_t)));
@@ -770,7 +770,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   a.ntax = p->ntax;
   a.out_tot = p->tot.as<uint64_t>();
   if (!commit) {
-    ProfScope ps("profile_map");
+    ProfScope ps("profile_map", st);
     const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * 4);
     hipLaunchKernelGGL(k_profile_pass<false>, dim3(grid), dim3(kPB), 0, st, a);
     MG_HIP(hipGetLastError());
@@ -783,7 +783,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   a.g_first = (unsigned long long*)d_first_seen; a.g_scalars = (unsigned long long*)d_scalars;
   a.mm_offsets = p->mm_offsets.as<uint64_t>(); a.mm_tax = p->mm_tax.as<uint32_t>();
   a.mm_hitlen = p->mm_hitlen.as<uint64_t>(); a.mm_read = p->mm_read.as<uint64_t>();
-  ProfScope ps("profile_pass");
+  ProfScope ps("profile_pass", st);
   // every workgroup flushes its private histogram once: few, long-lived workgroups
   const unsigned per_cu = lds > 40 * 1024 ? 2u : 3u;
   const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
@@ -795,7 +795,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
 // Totals of the last pass ([0] composed map, [1] reads) are fetched on first use.
 int fetch_map(mg_profile* p) {
   if (p->have_map || p->nrecs == 0) { p->have_map = true; return MG_OK; }
-  hipStream_t st = ctx().stream;
+  hipStream_t st = stage_c_stream();
   if (!p->committed && !p->map_launched)  // nobody ran over the shard yet: the map-only pass
     MG_TRY(launch_pass(p, false, 0, 0, 0, nullptr, nullptr, nullptr, nullptr));
   uint64_t* h_tot = host_words() + 16;
@@ -810,7 +810,7 @@ int fetch_map(mg_profile* p) {
 
 int fetch_mm(mg_profile* p) {
   if (p->have_mm || p->nrecs == 0) { p->have_mm = true; return MG_OK; }
-  hipStream_t st = ctx().stream;
+  hipStream_t st = stage_c_stream();
   uint64_t* h_tot = host_words() + 16;
   MG_HIP(hipMemcpyAsync(h_tot + 2, p->tot.as<uint64_t>() + 2, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
@@ -848,7 +848,7 @@ int mg_profile_begin_dev(const mg_aln_rec* d_recs, uint64_t nrecs, int has_looka
 int mg_profile_acc_reset(uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars, uint32_t ntax) {
   MG_REQUIRE_READY();
   if (!d_count || !d_bases || !d_first_seen || !d_scalars) return fail(MG_ERR_ARG, "null argument");
-  hipLaunchKernelGGL(k_acc_reset, dim3(grid_for((uint64_t)ntax + 2, 256, 64)), dim3(256), 0, ctx().stream, d_count, d_bases,
+  hipLaunchKernelGGL(k_acc_reset, dim3(grid_for((uint64_t)ntax + 2, 256, 64)), dim3(256), 0, stage_c_stream(), d_count, d_bases,
                      d_first_seen, d_scalars, ntax);
   MG_HIP(hipGetLastError());
   return MG_OK;
@@ -913,11 +913,11 @@ int mg_profile_resolve_multimapped_dev(const mg_profile* p, const double* d_weig
   MG_REQUIRE_READY();
   if (!p || !d_weight || !d_extra) return fail(MG_ERR_ARG, "null argument");
   if (!p->committed) return fail(MG_ERR_STATE, "profile shard not committed");
-  hipStream_t st = ctx().stream;
+  hipStream_t st = stage_c_stream();
   MG_HIP(hipMemsetAsync(d_extra, 0, (uint64_t)p->ntax * sizeof(double), st));
   if (p->nrecs == 0) return MG_OK;
   const uint32_t use_lds = p->ntax <= 2048 ? 1u : 0u;
-  ProfScope ps("resolve_multimapped");
+  ProfScope ps("resolve_multimapped", st);
   hipLaunchKernelGGL(k_resolve_multimapped, dim3(grid_for(p->nrecs / 4 + 1, 256, (unsigned)ctx().num_cus * 4)), dim3(256),
                      use_lds ? (size_t)p->ntax * sizeof(double) : 0, st, p->mm_offsets.as<uint64_t>(),
                      p->mm_tax.as<uint32_t>(), p->mm_hitlen.as<uint64_t>(), p->tot.as<uint64_t>(), d_weight, d_genome_len,
@@ -958,7 +958,7 @@ int mg_profile_assign(const mg_aln_rec* recs, uint64_t nrecs, const uint32_t* re
                       uint64_t* mm_hitlen, uint64_t* mm_read, uint64_t mm_cap_reads, uint64_t mm_cap_entries,
                       uint64_t* mm_nreads, uint64_t* mm_nentries) {
   MG_REQUIRE_READY();
-  hipStream_t st = ctx().stream;
+  hipStream_t st = stage_c_stream();
   DevBuf d_recs, d_r2t, d_acc;
   MG_TRY(d_recs.alloc((nrecs + 1) * sizeof(mg_aln_rec)));
   MG_TRY(d_r2t.alloc((uint64_t)nref * sizeof(uint32_t)));

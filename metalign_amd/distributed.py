@@ -84,6 +84,9 @@ class HipEngine:
         self.d_hs = hip.empty(2 * max(self.ngen_local, 1), np.uint32)  # [hits | sizes]: one read-back
         # [count T | bases T | first_seen T | scalars 2]
         self.d_acc = hip.empty(3 * ntax + 2, np.uint64)
+        # stage C runs on the library's second stream: its latency-bound pass overlaps the small kernels that
+        # finish stage A and run stage B
+        hip.stage_c_side_stream(True)
         # page-locked landing buffers: a step queues both read-backs behind its kernels and syncs once
         self.h_hs = hip.pinned(2 * max(self.ngen_local, 1), np.uint32)
         self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
@@ -127,6 +130,7 @@ class HipEngine:
         g, T = max(self.ngen_local, 1), self.ntax
         # the per-genome counts (8 B per genome) are written by the kernel straight into page-locked host memory
         self.hip.containment_dev(sk, self.table, ci, self.h_hs.ptr, self.h_hs.ptr + 4 * g)
+        self.hip.stage_c_join()  # the accumulators are read on the main stream: it waits for stage C's stream here
         self.h_acc.fetch_async(self.d_acc.ptr)
         self.hip.sync()
         if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
@@ -348,12 +352,13 @@ class ShardJob:
                 hits, sizes = eng.containment(sk, self.ci)
         else:
             # single shard: stage C is queued first, its results come back with the containment counts ...
-            eng.profile_begin(self.pct_id, False)
             split = hasattr(eng, "profile_commit_launch")
+            # stage A does not synchronise: the whole step is queued, then read back once.  Stage A is queued first
+            # (its persistent grid takes the CUs); stage C follows on the second stream and fills in as stage A drains.
+            sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
+            eng.profile_begin(self.pct_id, False)
             if split:
                 eng.profile_commit_launch(1, True, 0)
-            # ... and stage A itself does not synchronise: the whole step is queued, then read back once
-            sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
             if split:
                 (hits, sizes), committed = eng.containment_and_commit_results(sk, self.ci, want_multimapped)
             else:
