@@ -351,14 +351,21 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const uint64_t* __restrict_
   for (uint64_t b = gwave; b < nbuckets; b += nwaves) {
     const uint64_t base = b * kBucketSlots;
     uint32_t n = 0;
+    // all of the bucket's slots are requested before the first is looked at (one round trip, not one per chunk)
+    uint64_t v[kBucketSlots / 64];
+    uint32_t vc[kBucketSlots / 64];
 #pragma unroll
-    for (uint32_t c0 = 0; c0 < kBucketSlots; c0 += 64) {
-      const uint64_t v = tab_keys[base + c0 + lane];
-      const unsigned long long m = __ballot(v != 0);
-      if (v != 0) {
+    for (uint32_t c = 0; c < kBucketSlots / 64; ++c) {
+      v[c] = tab_keys[base + c * 64 + lane];
+      vc[c] = tab_cnt[base + c * 64 + lane];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < kBucketSlots / 64; ++c) {
+      const unsigned long long m = __ballot(v[c] != 0);
+      if (v[c] != 0) {
         const uint32_t d = n + __popcll(m & ((1ull << lane) - 1ull));
-        keys[d] = v - 1;
-        cnt[d] = tab_cnt[base + c0 + lane];
+        keys[d] = v[c] - 1;
+        cnt[d] = vc[c];
       }
       n += __popcll(m);
     }
