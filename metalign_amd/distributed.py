@@ -84,9 +84,6 @@ class HipEngine:
         self.d_hs = hip.empty(2 * max(self.ngen_local, 1), np.uint32)  # [hits | sizes]: one read-back
         # [count T | bases T | first_seen T | scalars 2]
         self.d_acc = hip.empty(3 * ntax + 2, np.uint64)
-        # stage C runs on the library's second stream: its latency-bound pass overlaps the small kernels that
-        # finish stage A and run stage B
-        hip.stage_c_side_stream(True)
         # page-locked landing buffers: a step queues both read-backs behind its kernels and syncs once
         self.h_hs = hip.pinned(2 * max(self.ngen_local, 1), np.uint32)
         self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
@@ -233,6 +230,11 @@ class ShardJob:
         else:
             self.nonempty = [len(recs) > 0]
         self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh, dbo)
+        if hasattr(self.engine, "hip"):
+            # single shard: stage C runs on the library's second stream, its latency-bound pass overlaps the small
+            # kernels that finish stage A and run stage B.  With the exchange in the step the same trick measured
+            # slower (stage C's map-only pass has to come first and delays stage A), so it stays on the main stream.
+            self.engine.hip.stage_c_side_stream(not self.exchange)
 
     # ------------------------------------------------------------------
     def _all_to_all(self, send_h, send_c, send_counts, recv_counts):
