@@ -72,9 +72,12 @@ uint64_t* host_words() { return ctx().pinned; }
 
 void* scratch(const char* name, uint64_t bytes) {
   Context& c = ctx();
-  DevBuf*& b = c.scratch[name];
+  DevBuf*& b = c.scratch[std::string(c.scratch_prefix) + name];
   if (!b) b = new DevBuf();
   if (b->bytes < bytes || !b->p) {
+    // growing frees the old block to the pool: with more than one stream in use, whatever still runs on it has to
+    // finish first (rare: sizes settle after the first batch)
+    if (b->p && (c.a_side || c.c_side)) (void)hipDeviceSynchronize();
     uint64_t want = bytes + bytes / 4 + 256;
     if (b->alloc(want) != MG_OK) return nullptr;
   }
@@ -184,6 +187,8 @@ void mg_shutdown(void) {
   if (c.pinned) (void)hipHostFree(c.pinned);
   if (c.pend_pinned) (void)hipHostFree(c.pend_pinned);
   if (c.stream_c) { (void)hipStreamSynchronize(c.stream_c); (void)hipStreamDestroy(c.stream_c); }
+  if (c.stream_a) { (void)hipStreamSynchronize(c.stream_a); (void)hipStreamDestroy(c.stream_a); }
+  for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
   if (c.ev_c) (void)hipEventDestroy(c.ev_c);
   mg::prof_collect();
   for (hipEvent_t e : c.prof_pool) (void)hipEventDestroy(e);
@@ -276,6 +281,15 @@ int mg_stage_c_side_stream(int on) {
   }
   if (!on && c.c_side) MG_HIP(hipStreamSynchronize(c.stream_c));
   c.c_side = on != 0;
+  return MG_OK;
+}
+
+int mg_stage_a_side_stream(int on) {
+  MG_REQUIRE_READY();
+  mg::Context& c = ctx();
+  if (on && !c.stream_a) MG_HIP(hipStreamCreateWithFlags(&c.stream_a, hipStreamNonBlocking));
+  if (!on && c.a_side) MG_HIP(hipStreamSynchronize(c.stream_a));
+  c.a_side = on != 0;
   return MG_OK;
 }
 

@@ -35,6 +35,12 @@ struct Context {
   hipStream_t stream_c = nullptr;
   hipEvent_t ev_c = nullptr;
   bool c_side = false;
+  // optional stream for stage A (mg_stage_a_side_stream): the heavy sketch pipeline of the NEXT batch then runs
+  // while the current batch's stage B / exchange / read-backs proceed on the main stream
+  hipStream_t stream_a = nullptr;
+  bool a_side = false;
+  const char* scratch_prefix = "";  // scratch buffers are per stream ("a:" while launching on stream_a)
+  std::vector<hipEvent_t> ev_pool;   // recycled completion events of deferred sketches
   int num_cus = 256;
   // profiling
   bool prof_on = false;
@@ -174,6 +180,8 @@ struct mg_sketch {
   // truncated / kmers_seen live in `meta` on the device ([0] runs, [1] n, [2] last hash, [3] truncated,
   // [4..6] candidates / k-mers / table overflows) with an asynchronous copy in flight to `h_meta`.
   bool pending = false;
+  hipEvent_t ev = nullptr;         // recorded behind the sketch's last kernel (on the stream that built it)
+  hipStream_t ev_stream = nullptr;
   mg::DevBuf meta;
   uint64_t* h_meta = nullptr;
   int pend_slot = -1;
@@ -194,6 +202,8 @@ namespace mg {
 // Brings a pending sketch's metadata to the host (one stream sync); *rebuilt = 1 when the counting table had
 // overflowed and the sketch was recomputed on the list path (anything derived from it while pending is stale).
 int sketch_resolve(mg_sketch* sk, int* rebuilt);
+// Makes the library's current stream wait (on the device) for the stream that built the sketch, if it is another.
+int sketch_wait(const mg_sketch* sk);
 }  // namespace mg
 
 struct mg_db {

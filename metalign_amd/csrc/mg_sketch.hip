@@ -663,13 +663,38 @@ static int sketch_via_list(mg_sketch* sk, const uint8_t* d_bases, const uint64_t
   return adopt_runs(sk, d_meta, s, false, 0);
 }
 
+// While alive, the library launches on `st` and uses that stream's own scratch buffers.
+struct StreamGuard {
+  hipStream_t saved;
+  const char* saved_prefix;
+  StreamGuard(hipStream_t st, const char* prefix) : saved(ctx().stream), saved_prefix(ctx().scratch_prefix) {
+    ctx().stream = st;
+    ctx().scratch_prefix = prefix;
+  }
+  ~StreamGuard() { ctx().stream = saved; ctx().scratch_prefix = saved_prefix; }
+};
+
+static hipEvent_t take_event() {
+  Context& c = ctx();
+  if (!c.ev_pool.empty()) { hipEvent_t e = c.ev_pool.back(); c.ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+
+int sketch_wait(const mg_sketch* sk) {
+  if (sk && sk->ev && sk->ev_stream != ctx().stream) MG_HIP(hipStreamWaitEvent(ctx().stream, sk->ev, 0));
+  return MG_OK;
+}
+
 static double distinct_hint = 1.0;  // distinct / expected candidates of the previous batch (x2), sizes the counting table
 
 int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   if (rebuilt) *rebuilt = 0;
   if (!sk || !sk->pending) return MG_OK;
   Context& c = ctx();
-  MG_HIP(hipStreamSynchronize(c.stream));
+  if (sk->ev) MG_HIP(hipEventSynchronize(sk->ev));  // only what built this sketch, not whatever was queued after it
+  else MG_HIP(hipStreamSynchronize(c.stream));
   const uint64_t* m = sk->h_meta;
   const uint64_t runs = m[0], candidates = m[4], overflows = m[6];
   sk->n = m[1];
@@ -693,6 +718,8 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   sk->counts.release();
   uint64_t cap = sk->redo.cap;
   if (candidates + 64 > cap) cap = candidates + 64;
+  // (the rebuild is synchronous on the stream that built the sketch)
+  StreamGuard guard(sk->ev_stream ? sk->ev_stream : c.stream, (sk->ev_stream && sk->ev_stream == c.stream_a) ? "a:" : c.scratch_prefix);
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
   return sketch_via_list(sk, sk->redo.bases, sk->redo.offsets, sk->redo.nreads, sk->redo.k, sk->redo.hmax, sk->redo.s, cap,
@@ -703,6 +730,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
 
 mg_sketch::~mg_sketch() {
   mg::Context& c = mg::ctx();
+  if (ev) c.ev_pool.push_back(ev);
   if (pend_slot >= 0 && c.pend_owner[pend_slot] == this) c.pend_owner[pend_slot] = nullptr;
 }
 
@@ -719,6 +747,8 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   if (nreads > 0 && (!d_bases || !d_offsets)) return fail(MG_ERR_ARG, "null device input");
   if (hmax == kReservedHash) hmax = kReservedHash - 1;
   Context& c = ctx();
+  // with mg_stage_a_side_stream on, the whole sketch pipeline of this call goes to the stage-A stream
+  StreamGuard guard(c.a_side ? c.stream_a : c.stream, c.a_side ? "a:" : c.scratch_prefix);
   hipStream_t st = c.stream;
   std::unique_ptr<mg_sketch> sk(new mg_sketch());
   if (nreads == 0) {
@@ -785,6 +815,8 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
                        (const unsigned long long*)t_counters, sk->h_meta);
     MG_HIP(hipGetLastError());
+    sk->ev = take_event();
+    if (sk->ev) { MG_HIP(hipEventRecord(sk->ev, st)); sk->ev_stream = st; }
     sk->pending = true;
     sk->pend_slot = (int)slot;
     cc.pend_owner[slot] = sk.get();
@@ -799,6 +831,7 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     return MG_OK;
   }
   MG_TRY(sketch_via_list(sk.get(), d_bases, d_offsets, nreads, k, hmax, s, cap, (unsigned)stage, d_counters));
+  MG_HIP(hipStreamSynchronize(st));  // the list path reads back as it goes; nothing is left in flight
   *out = sk.release();
   return MG_OK;
 }
@@ -872,6 +905,7 @@ int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbound
   MG_REQUIRE_READY();
   if (!sk || !bounds || !out_idx) return fail(MG_ERR_ARG, "null argument");
   MG_TRY(sketch_resolve(const_cast<mg_sketch*>(sk), nullptr));
+  MG_TRY(sketch_wait(sk));
   if (nbounds == 0) return MG_OK;
   if (nbounds > 4096) return fail(MG_ERR_ARG, "too many slice bounds");
   hipStream_t st = ctx().stream;
@@ -912,6 +946,7 @@ int mg_sketch_resolve(mg_sketch* sk, int* rebuilt) {
 int mg_sketch_device_ptrs(const mg_sketch* sk, const uint64_t** d_hashes, const uint32_t** d_counts) {
   if (!sk) return fail(MG_ERR_ARG, "null sketch");
   MG_TRY(sketch_resolve(const_cast<mg_sketch*>(sk), nullptr));  // a rebuild would move the buffers
+  MG_TRY(sketch_wait(sk));
   if (d_hashes) *d_hashes = sk->hashes.as<uint64_t>();
   if (d_counts) *d_counts = sk->counts.as<uint32_t>();
   return MG_OK;
@@ -921,6 +956,7 @@ int mg_sketch_download(const mg_sketch* sk, uint64_t* hashes, uint32_t* counts, 
   MG_REQUIRE_READY();
   if (!sk) return fail(MG_ERR_ARG, "null sketch");
   MG_TRY(sketch_resolve(const_cast<mg_sketch*>(sk), nullptr));
+  MG_TRY(sketch_wait(sk));
   if (cap < sk->n) return fail(MG_ERR_CAPACITY, "sketch has %llu entries, buffer holds %llu", (unsigned long long)sk->n,
                                (unsigned long long)cap);
   if (sk->n == 0) return MG_OK;

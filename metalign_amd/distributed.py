@@ -275,7 +275,7 @@ class ShardJob:
         if hasattr(eng, "profile_begin_async"):
             # stage C's map-only pass is queued first: stage A's one synchronisation covers it too
             eng.profile_begin_async(self.pct_id)
-            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            sk = self._given if self._given is not None else eng.sketch_local(self.k, self.hmax, self.s)
             (m0, m1), ngroups = eng.profile_map()
         else:
             sk = eng.sketch_local(self.k, self.hmax, self.s)
@@ -342,10 +342,40 @@ class ShardJob:
         eng.set_sketch_bound(merged, truncated, sample_last)
         return merged
 
-    def step(self, want_multimapped=False):
-        """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank)."""
+    def run(self, nsteps, want_multimapped=False):
+        """`nsteps` passes over the resident batch, software-pipelined: stage A of pass i+1 (the dominant kernel) is
+        queued on the library's stage-A stream BEFORE pass i is finished (the exchange, stage B, the read-backs, all
+        on the main stream), so the GPU does not idle through the collectives' latency (1.34 -> 1.02 ms per pass
+        with every collective in the path on one GPU).  Every pass is complete when this returns; the last pass's
+        results are returned."""
+        eng = self.engine
+        if nsteps < 1:
+            return None
+        # Single shard: no exchange to hide, and the overlap measured slower (0.78 vs 0.745 ms per pass: the next
+        # pass's stage A slows down more, sharing CUs with this pass's stage C and stage B, than the overlap saves).
+        if not hasattr(eng, "sketch_local_async") or not self.exchange:
+            out = None
+            for _ in range(nsteps):
+                out = self.step(want_multimapped)
+            return out
+        eng.hip.stage_a_side_stream(True)
+        try:
+            nxt = eng.sketch_local_async(self.k, self.hmax, self.s)
+            out = None
+            for i in range(nsteps):
+                cur = nxt
+                nxt = eng.sketch_local_async(self.k, self.hmax, self.s) if i + 1 < nsteps else None
+                out = self.step(want_multimapped, _sketch=cur)
+            return out
+        finally:
+            eng.hip.stage_a_side_stream(False)
+
+    def step(self, want_multimapped=False, _sketch=None):
+        """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank).
+        _sketch: this pass's stage A, already queued (run())."""
         eng = self.engine
         self._want_mm = want_multimapped
+        self._given = _sketch
         if self.exchange:
             sk, committed = self._exchange_step()
             if committed is None:  # commit is in flight: one read-back for stage B's counts and its accumulators
@@ -357,7 +387,10 @@ class ShardJob:
             split = hasattr(eng, "profile_commit_launch")
             # stage A does not synchronise: the whole step is queued, then read back once.  Stage A is queued first
             # (its persistent grid takes the CUs); stage C follows on the second stream and fills in as stage A drains.
-            sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
+            if _sketch is not None:
+                sk = _sketch
+            else:
+                sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
             eng.profile_begin(self.pct_id, False)
             if split:
                 eng.profile_commit_launch(1, True, 0)

@@ -81,3 +81,43 @@ def test_bad_arguments_fail_loudly(hip):
         hip.sketch_reads(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4], np.uint64), 0)
     with pytest.raises(_hip.HipError):
         hip.sketch_genomes(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4], np.uint64), 21, 0)
+
+
+def test_pipelined_run_equals_single_steps(hip, oracle_lib):
+    """ShardJob.run(n): stage A of pass i+1 is queued on its own stream before pass i is finished; every pass gives
+    what a stand-alone step gives (and what the oracle gives)."""
+    from metalign_amd import synth
+    from metalign_amd.distributed import ShardJob
+    gb, go = synth.make_genomes(40, 20000)
+    rb, ro, src = synth.make_reads(gb, go, 60000, npresent=7)
+    recs = synth.make_alignment_records(src + 1, 41)
+    ref2tax = np.arange(41, dtype=np.uint32)
+    k, n = 21, 200
+    dbh, dbo = hip.sketch_genomes(gb, go, k, n)
+    job = ShardJob(hip, None, 0, 1, k=k)
+    job.load(rb, ro, recs, ref2tax, dbh, dbo)
+    one = job.step(want_multimapped=True)
+    job.exchange = True  # run() pipelines only when there is an exchange to hide; ...
+    run_step, job.step = job.step, (lambda want_multimapped=False, _sketch=None: run_step_plain(want_multimapped, _sketch))
+
+    def run_step_plain(want_multimapped, _sketch):  # ... here the passes themselves stay single-shard
+        job.exchange = False
+        try:
+            return run_step(want_multimapped, _sketch=_sketch)
+        finally:
+            job.exchange = True
+    piped = job.run(4, want_multimapped=True)
+    job.exchange, job.step = False, run_step
+    again = job.step(want_multimapped=True)
+    oh, oc, otr, _ = oracle_lib.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
+    ohits, osizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
+    want_c = oracle_lib.profile_assign(recs, ref2tax, 41, 0.5)
+    for got in (one, piped, again):
+        assert np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)
+        assert got["sketch_size"] == len(oh)
+        for key in ("count", "bases", "first_seen"):
+            assert np.array_equal(got[key], want_c[key]), key
+        assert got["tot_rds"] == want_c["tot_rds"] and got["n_ambig"] == want_c["n_ambig"]
+        off, tax, hl, rd = got["multimapped"]
+        assert np.array_equal(off, want_c["mm_offsets"]) and np.array_equal(tax, want_c["mm_tax"])
+        assert np.array_equal(hl, want_c["mm_hitlen"]) and np.array_equal(rd, want_c["mm_read"])
