@@ -345,14 +345,14 @@ class ShardJob:
     def run(self, nsteps, want_multimapped=False):
         """`nsteps` passes over the resident batch, software-pipelined: stage A of pass i+1 (the dominant kernel) is
         queued on the library's stage-A stream BEFORE pass i is finished (the exchange, stage B, the read-backs, all
-        on the main stream), so the GPU does not idle through the collectives' latency (1.34 -> 1.02 ms per pass
+        on the main stream), so the GPU does not idle through the collectives' latency (1.34 -> 0.87 ms per pass
         with every collective in the path on one GPU).  Every pass is complete when this returns; the last pass's
         results are returned."""
         eng = self.engine
         if nsteps < 1:
             return None
-        # Single shard: no exchange to hide, and the overlap measured slower (0.78 vs 0.745 ms per pass: the next
-        # pass's stage A slows down more, sharing CUs with this pass's stage C and stage B, than the overlap saves).
+        # Single shard: no exchange to hide; pipelined it measured the same 0.75 ms per pass (stage A gives up a
+        # third of its LDS-limited occupancy to let the rest overlap, and loses what the overlap saves).
         if not hasattr(eng, "sketch_local_async") or not self.exchange:
             out = None
             for _ in range(nsteps):
