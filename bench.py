@@ -112,9 +112,12 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        # an explicit stream shared by torch (collectives synchronise with it) and the library's main stream
+        torch_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(torch_stream)
         dist.init_process_group("nccl", rank=rank, world_size=world)
         from metalign_amd._hip import Hip
-        hip = Hip.get(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        hip = Hip.get(local_rank, stream=torch_stream.cuda_stream)
     else:
         from metalign_amd._hip import Hip
         hip = Hip.get(0)

@@ -70,7 +70,9 @@ int mg_abi_version(void);
 int mg_device_count(void);
 /* Binds the calling process to `device` and creates the library stream. */
 int mg_init(int device);
-/* As mg_init, but launches on a caller-owned hipStream_t (e.g. torch's). */
+/* As mg_init, but launches on a caller-owned hipStream_t, so that the library's kernels are ordered with the
+ * caller's own work on that stream (collectives included).  The stream must be an explicit one: the legacy default
+ * stream (handle 0, which is what torch.cuda.current_stream() is unless a stream was set) is refused. */
 int mg_init_on_stream(int device, void* hip_stream);
 void mg_shutdown(void);
 const char* mg_last_error(void);

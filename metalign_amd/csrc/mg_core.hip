@@ -176,7 +176,12 @@ static int init_common(int device, void* stream) {
 }
 
 int mg_init(int device) { return init_common(device, nullptr); }
-int mg_init_on_stream(int device, void* hip_stream) { return init_common(device, hip_stream); }
+int mg_init_on_stream(int device, void* hip_stream) {
+  // The legacy default stream has the handle 0: accepting it here would silently give the library a stream of its
+  // own, unordered with the caller's work (torch's default stream is exactly that).
+  if (!hip_stream) return fail(MG_ERR_ARG, "mg_init_on_stream needs an explicit stream (not the default stream, handle 0)");
+  return init_common(device, hip_stream);
+}
 
 void mg_shutdown(void) {
   mg::Context& c = ctx();

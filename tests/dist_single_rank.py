@@ -1,0 +1,54 @@
+"""Helper of tests/test_pipeline_gpu.py: ONE rank, every collective of the multi-GPU exchange in the path (RCCL,
+world size 1), pipelined ShardJob.run against the plain single-shard step and the oracle.  Run as a script."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+
+import torch  # noqa: E402  (first: the library then binds to the same HIP runtime)
+import torch.distributed as dist  # noqa: E402
+
+import oracle  # noqa: E402
+from metalign_amd import synth  # noqa: E402
+from metalign_amd._hip import Hip  # noqa: E402
+from metalign_amd.distributed import ShardJob  # noqa: E402
+
+torch.cuda.set_device(0)
+stream = torch.cuda.Stream()  # explicit: the default stream's handle is 0 and is refused by mg_init_on_stream
+torch.cuda.set_stream(stream)
+dist.init_process_group("nccl", rank=0, world_size=1)
+hip = Hip.get(0, stream=stream.cuda_stream)
+oracle.build()
+gb, go = synth.make_genomes(60, 20000)
+rb, ro, src = synth.make_reads(gb, go, 80000, npresent=9)
+recs = synth.make_alignment_records(src + 1, 61)
+ref2tax = np.arange(61, dtype=np.uint32)
+k, n = 21, 200
+dbh, dbo = hip.sketch_genomes(gb, go, k, n)
+job = ShardJob(hip, dist, 0, 1, k=k, always_exchange=True)
+job.load(rb, ro, recs, ref2tax, dbh, dbo)
+outs = [job.step(want_multimapped=True), job.run(4, want_multimapped=True), job.step(want_multimapped=True)]
+oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
+ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
+want = oracle.profile_assign(recs, ref2tax, 61, 0.5)
+for idx, got in enumerate(outs):
+    if not (np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)):
+        bad = np.nonzero(got["hits"] != ohits)[0]
+        print("MISMATCH in output", idx, "hits differ at", len(bad), "genomes; sizes equal:", np.array_equal(got["sizes"], osizes),
+              "sketch", got["sketch_size"], len(oh), "sample", [(int(g), int(got["hits"][g]), int(ohits[g])) for g in bad[:6]])
+    assert np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)
+    assert got["sketch_size"] == len(oh), (got["sketch_size"], len(oh))
+    for key in ("count", "bases", "first_seen"):
+        assert np.array_equal(got[key], want[key]), key
+    assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
+    off, tax, hl, rd = got["multimapped"]
+    assert np.array_equal(off, want["mm_offsets"]) and np.array_equal(tax, want["mm_tax"])
+    assert np.array_equal(hl, want["mm_hitlen"]) and np.array_equal(rd, want["mm_read"])
+dist.barrier()
+dist.destroy_process_group()
+print("dist-single-rank ok")

@@ -117,3 +117,15 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
     strains = [ln.split("\t") for ln in text.splitlines() if "\tstrain\t" in ln]
     assert {s[0] for s in strains} >= {"1001.2.1", "1004.1.1"}
     assert abs(sum(float(s[4]) for s in strains) - 100.0) < 1.0
+
+
+def test_exchange_path_on_one_gpu_under_rccl():
+    """The multi-GPU choreography (all-gather, all-to-all, all-reduce over RCCL) with world size 1, plain steps and the
+    software-pipelined run(), against the oracle.  A child process: torch.distributed state stays out of this one."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(here, "dist_single_rank.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

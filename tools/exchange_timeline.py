@@ -15,10 +15,12 @@ from metalign_amd import distributed as mgd  # noqa: E402
 from metalign_amd._hip import Hip  # noqa: E402
 
 torch.cuda.set_device(0)
+_stream = torch.cuda.Stream()
+torch.cuda.set_stream(_stream)
 dist.init_process_group("nccl", rank=0, world_size=1)
 sys.argv = sys.argv[:1]
 args = bench.parse()
-hip = Hip.get(0, stream=torch.cuda.current_stream().cuda_stream)
+hip = Hip.get(0, stream=_stream.cuda_stream)
 w = bench.build_workload(args, 0, hip)
 job = mgd.ShardJob(hip, dist, 0, 1, k=args.k, always_exchange=True)
 job.load(w["rb"], w["ro"], w["recs"], w["ref2tax"], w["dbh"], w["dbo"])
