@@ -121,3 +121,57 @@ def test_pipelined_run_equals_single_steps(hip, oracle_lib):
         off, tax, hl, rd = got["multimapped"]
         assert np.array_equal(off, want_c["mm_offsets"]) and np.array_equal(tax, want_c["mm_tax"])
         assert np.array_equal(hl, want_c["mm_hitlen"]) and np.array_equal(rd, want_c["mm_read"])
+
+
+@pytest.mark.parametrize("flags", [[0, 16, 256, 272], [99, 147, 355, 403, 65, 129, 73, 137, 2048]])
+def test_stage_c_reads_longer_than_a_tile(hip, oracle_lib, flags):
+    """Reads with hundreds to thousands of alignment lines: they outrun the 64-descriptor halo that a tile stages
+    past its end (the walk continues in HBM) and can span several 2048-record tiles; single-end and paired flags."""
+    rng = np.random.default_rng(len(flags))
+    nref, ntax = 300, 23
+    ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
+    lens = np.concatenate([rng.integers(1, 4, size=3000), rng.integers(60, 200, size=40), [2047, 2048, 2049, 5000, 70, 1]])
+    rng.shuffle(lens)
+    n = int(lens.sum())
+    recs = np.zeros(n, dtype=oracle_lib.REC_DTYPE)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    new = np.zeros(n, dtype=np.uint32)
+    new[starts] = 1
+    # long reads hit few taxa (so that paired intersections are non-trivial), short ones anything
+    ref = rng.integers(0, nref, size=n)
+    recs["ref_new"] = ref.astype(np.uint32) | (new << 31)
+    recs["total"] = 100
+    recs["matched"] = rng.integers(20, 101, size=n)
+    recs["flag_len"] = rng.choice(flags, size=n).astype(np.uint32) | (np.where(rng.random(n) < 0.8, 100, 0).astype(np.uint32) << 12)
+    got = hip.profile_assign(recs, ref2tax, ntax, 0.5)
+    want = oracle_lib.profile_assign(recs, ref2tax, ntax, 0.5)
+    for key in want:
+        assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
+    assert len(want["mm_hitlen"]) > 50
+
+
+def test_containment_dense_read_sketch_sparse_table(hip, oracle_lib):
+    """A read sketch far denser than the table: the run that matches a tile of (hash, genome) pairs exceeds the LDS
+    stage, so every pair goes through the bucket index on its own.  Exact against the oracle, ci = 1 and 2, with
+    hashes shared between genomes."""
+    rng = np.random.default_rng(11)
+    top = 1 << 40
+    pool = np.unique(rng.integers(1, top, size=120000, dtype=np.uint64))
+    qh = pool[rng.random(len(pool)) < 0.6]                      # ~70 k entries in [1, 2^40)
+    qc = rng.integers(1, 4, size=len(qh)).astype(np.uint32)
+    genomes = []
+    shared = rng.choice(pool, size=60, replace=False)
+    for g in range(5):
+        own = rng.choice(pool, size=240, replace=False)
+        genomes.append(np.unique(np.concatenate([own, shared])))
+    genomes.append(np.zeros(0, dtype=np.uint64))               # an empty genome sketch
+    dbh = np.concatenate(genomes).astype(np.uint64)
+    dbo = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.uint64)
+    d_h, d_c = hip.array(qh), hip.array(qc)
+    sk = hip.sketch_from_pairs_dev(d_h.ptr, d_c.ptr, len(qh), 21)
+    table = hip.upload_table(dbh, dbo)
+    for ci in (1, 2):
+        hits, sizes = hip.containment(sk, table, ci)
+        ohits, osizes = oracle_lib.containment(qh, qc, False, ci, dbh, dbo)
+        assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes)
+        assert hits[:5].min() > 50 and hits[5] == 0 and sizes[5] == 0
