@@ -231,10 +231,9 @@ class ShardJob:
             self.nonempty = [len(recs) > 0]
         self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh, dbo)
         if hasattr(self.engine, "hip"):
-            # single shard: stage C runs on the library's second stream, its latency-bound pass overlaps the small
-            # kernels that finish stage A and run stage B.  With the exchange in the step the same trick measured
-            # slower (stage C's map-only pass has to come first and delays stage A), so it stays on the main stream.
-            self.engine.hip.stage_c_side_stream(not self.exchange)
+            # stage C runs on the library's second stream: its latency-bound passes overlap stage A's tail, stage B
+            # and (with the exchange) the collectives
+            self.engine.hip.stage_c_side_stream(True)
 
     # ------------------------------------------------------------------
     def _all_to_all(self, send_h, send_c, send_counts, recv_counts):
