@@ -195,7 +195,7 @@ def main():
                            "(0.06 ms when it runs alone)",
             "check": {"top_genomes_recovered": out.get("top_ok"), "tot_rds": out.get("tot_rds")},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
             res["cpu_baseline"] = cpu_baseline(args, w)
         print(json.dumps(res))
     if dist is not None:

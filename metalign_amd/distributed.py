@@ -153,9 +153,15 @@ class HipEngine:
 
     def profile_begin_async(self, pct_id):
         """Pass A of stage C queued without a sync; profile_map() fetches its two words later."""
-        self.shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
-                                                self.nref, self.ntax, pct_id)
-        self.shard.map_launch()
+        self.shard = self.new_shard_async(pct_id)
+
+    def new_shard_async(self, pct_id):
+        """A stage-C handle over the resident records with its map-only pass already queued (a pipelined job starts
+        the NEXT pass's handle while the current pass is still being finished)."""
+        shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
+                                           self.nref, self.ntax, pct_id)
+        shard.map_launch()
+        return shard
 
     def profile_map(self):
         return self.shard.state_map(), self.shard.ngroups
@@ -273,8 +279,11 @@ class ShardJob:
         eng, t, dist, W = self.engine, self.torch, self.dist, self.world
         if hasattr(eng, "profile_begin_async"):
             # stage C's map-only pass is queued first: stage A's one synchronisation covers it too
-            eng.profile_begin_async(self.pct_id)
-            sk = self._given if self._given is not None else eng.sketch_local(self.k, self.hmax, self.s)
+            if self._given is not None:
+                sk, eng.shard = self._given  # queued a pass ahead by run()
+            else:
+                eng.profile_begin_async(self.pct_id)
+                sk = eng.sketch_local(self.k, self.hmax, self.s)
             (m0, m1), ngroups = eng.profile_map()
         else:
             sk = eng.sketch_local(self.k, self.hmax, self.s)
@@ -359,11 +368,13 @@ class ShardJob:
             return out
         eng.hip.stage_a_side_stream(True)
         try:
-            nxt = eng.sketch_local_async(self.k, self.hmax, self.s)
+            def front():  # what does not depend on the other ranks: stage A and stage C's map-only pass
+                return eng.sketch_local_async(self.k, self.hmax, self.s), eng.new_shard_async(self.pct_id)
+            nxt = front()
             out = None
             for i in range(nsteps):
                 cur = nxt
-                nxt = eng.sketch_local_async(self.k, self.hmax, self.s) if i + 1 < nsteps else None
+                nxt = front() if i + 1 < nsteps else None
                 out = self.step(want_multimapped, _sketch=cur)
             return out
         finally:
@@ -387,7 +398,8 @@ class ShardJob:
             # stage A does not synchronise: the whole step is queued, then read back once.  Stage A is queued first
             # (its persistent grid takes the CUs); stage C follows on the second stream and fills in as stage A drains.
             if _sketch is not None:
-                sk = _sketch
+                sk, ahead = _sketch
+                ahead.free()  # (a single shard needs no map-only pass; its handle is created below)
             else:
                 sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
             eng.profile_begin(self.pct_id, False)
