@@ -787,7 +787,6 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   if (stage > 14336) stage = 14336;
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
-  uint64_t* d_meta = reinterpret_cast<uint64_t*>(d_counters) + 4;
 
   // ---- table path: counting hash table partitioned into hash-range buckets ----
   // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
