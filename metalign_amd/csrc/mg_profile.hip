@@ -264,6 +264,8 @@ __device__ __forceinline__ RunFn block_scan_runs(const RunFn& mine, RunFn* lds, 
 //   PREFIX  w[0] = status | map:2 | reads (inclusive) ; w[1] = status | mm_reads ; w[2] = status | mm_entries
 constexpr uint64_t ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = 3ull << 62;
 constexpr int kDescWords = 4;  // 32-byte stride
+constexpr int kTicketLanes = 16;    // interleaved ticket counters ...
+constexpr int kTicketStride = 16;   // ... 128 bytes apart
 constexpr int kWin = 4;        // descriptors per lane and look-back step (window = 256 tiles)
 
 struct TileFn {  // aggregate of a run of tiles as a function of the state entering it
@@ -328,38 +330,75 @@ struct Incoming {  // what a tile learns from its predecessors
 
 constexpr int kLbWaves = 1;     // wavefronts that look back together: kLbWaves x 64 x kWin tiles per round
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kWinTiles = 64 * kWin;             // tiles per look-back window
+constexpr int kWinChunks = kWinTiles * 2 / 64;   // 16-byte chunks per lane and window (a descriptor = 2 chunks)
+static_assert(kWinChunks == 8, "the batched load below is written for 8 chunks per lane");
+
+// 8 x 16 bytes per lane, L2-bypassing (sc0 sc1: another XCD wrote them), all in flight before one wait.  Chunk j
+// of lane l sits at p + (j * 64 + l) * 16 bytes: every instruction reads one contiguous KB.
+__device__ __forceinline__ void load_window(const u32x4* p, u32x4 (&v)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %8, off offset:2048 sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %8, off offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %9, off sc0 sc1\n\t"
+      "global_load_dwordx4 %5, %9, off offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %9, off offset:2048 sc0 sc1\n\t"
+      "global_load_dwordx4 %7, %9, off offset:3072 sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p), "v"(p + 256)
+      : "memory");
+}
+
 // Executed by one whole wavefront: folds the window of 64 * kWin tiles whose nearest member is tile `base`
-// (lane l inspects the tiles base - kWin*l - c, c = 0 .. kWin-1), stopping at the nearest inclusive prefix.
+// (lane l folds the tiles base - kWin*l - c, c = 0 .. kWin-1), stopping at the nearest inclusive prefix.
 // Returns once every tile nearer than that prefix (all of them, if there is none) is published.
-__device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc, int64_t base, bool* found) {
+// The window's descriptors (8 KB, contiguous) are read with coalesced 16-byte loads and handed to their lanes
+// through LDS: per-word atomic loads made every look-back ~770 separate 8-byte requests to the memory side, and
+// the fabric's request rate, not its latency, bounded the pass at ~80 ns per tile whatever the window or tile size.
+// A 16-byte load may tear between its two words; every word carries the status, torn reads fail the check below.
+__device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc, int64_t base, bool* found,
+                                              u32x4* __restrict__ lbuf) {
   const int lane = threadIdx.x & 63;
   TileFn f;
   int p_lane;
-  uint64_t w[kWin][3];
-  uint32_t have = 0;  // this lane's tiles seen published; only the others are polled again
+  const int64_t lo = base - (kWinTiles - 1);  // tile of chunk 0 (may be negative: before the first tile)
   for (;;) {
+    {
+      // chunks of tiles outside [0, base] are not read (the window is clamped into the descriptor array and the
+      // lanes below substitute the empty prefix for tiles before 0)
+      const int64_t lo_c = lo < 0 ? 0 : lo;
+      u32x4 v[8];
+      load_window(reinterpret_cast<const u32x4*>(desc + (uint64_t)lo_c * kDescWords) + lane, v);
 #pragma unroll
-    for (int c = 0; c < kWin; ++c) {  // all loads in flight together: one round trip per attempt
-      const int64_t k = base - (lane * kWin + c);
-      if (have & (1u << c)) continue;
-      if (k >= 0) {
-        const uint64_t* d = desc + (uint64_t)k * kDescWords;
-        w[c][0] = ld_desc(d); w[c][1] = ld_desc(d + 1); w[c][2] = ld_desc(d + 2);
-      } else {  // before tile 0: the empty prefix
-        w[c][0] = ST_PREFIX | ((uint64_t)kIdentity << 60); w[c][1] = ST_PREFIX; w[c][2] = ST_PREFIX;
-      }
+      for (int j = 0; j < 8; ++j) lbuf[j * 64 + lane] = v[j];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     f = fn_identity();
     bool ok = true, pfx = false;
+    const int64_t shift = lo < 0 ? -lo : 0;  // the staged window starts at tile max(lo, 0)
 #pragma unroll
     for (int c = 0; c < kWin; ++c) {
-      const uint64_t s0 = w[c][0] & ST_MASK;
-      const bool pub = s0 != 0 && s0 == (w[c][1] & ST_MASK) && s0 == (w[c][2] & ST_MASK);
-      if (pub) have |= 1u << c;
+      const int64_t k = base - (lane * kWin + c);
+      uint64_t w0 = ST_PREFIX | ((uint64_t)kIdentity << 60), w1 = ST_PREFIX, w2 = ST_PREFIX;  // before tile 0
+      if (k >= 0) {
+        const int64_t slot = (k - lo) - shift;  // index of tile k in the staged window
+        const u32x4 a = lbuf[slot * 2], b2 = lbuf[slot * 2 + 1];
+        w0 = (uint64_t)a.x | ((uint64_t)a.y << 32);
+        w1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+        w2 = (uint64_t)b2.x | ((uint64_t)b2.y << 32);
+      }
+      const uint64_t s0 = w0 & ST_MASK;
+      const bool pub = s0 != 0 && s0 == (w1 & ST_MASK) && s0 == (w2 & ST_MASK);
       if (ok && !pfx) {
         if (!pub) ok = false;
         else {
-          f = fn_then(fn_from_words(w[c][0], w[c][1], w[c][2]), f);  // farther tile: prepend
+          f = fn_then(fn_from_words(w0, w1, w2), f);  // farther tile: prepend
           pfx = s0 == ST_PREFIX;
         }
       }
@@ -367,7 +406,6 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
     const unsigned long long pm = __ballot(ok && pfx);
     p_lane = pm ? __ffsll((long long)pm) - 1 : 64;
     if (__ballot(lane <= p_lane && !ok) == 0ull) break;
-    if (lane > p_lane) have = (1u << kWin) - 1u;  // beyond the nearest prefix: nothing more to poll
     __builtin_amdgcn_s_sleep(2);
   }
   if (lane > p_lane) f = fn_identity();  // farther than the prefix: already folded into it
@@ -382,7 +420,7 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 }
 
 // Per-workgroup privatised histogram in LDS, flushed with global atomics at the end:
-//   use_lds_hist == 1  direct:  ntax <= 2048 bins (dynamic LDS: 3 * ntax u64)
+//   use_lds_hist == 1  direct:  ntax <= 2048 bins (dynamic LDS: 20 B per bin)
 //   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
 //                      fewer taxa than the table lists); a taxon that finds no bin within kHashProbe steps
 //                      goes to global atomics directly.  Without this a skewed sample serialises millions of
@@ -395,7 +433,8 @@ struct PassArgs {
   const uint32_t* ref2tax;
   double pct_id;
   uint64_t* desc;                 // [ntiles][kDescWords], zeroed
-  unsigned long long* ticket;     // zeroed
+  unsigned long long* ticket;     // [ticket_lanes][kTicketStride], zeroed
+  uint32_t ticket_lanes;
   uint64_t ntiles;
   uint32_t incoming, first_shard;
   uint64_t group_base;
@@ -412,15 +451,17 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
   __shared__ RunFn s_run[kPB / 64];
   __shared__ uint64_t s_bcast[4];
   __shared__ TileFn s_lb[kLbWaves];
+  __shared__ u32x4 s_lbuf[kLbWaves][kWinTiles * 2];  // look-back windows staged for their wavefronts (8 KB each)
   __shared__ uint32_t s_lbf[kLbWaves + 1];
   __shared__ unsigned long long s_ticket;
   __shared__ unsigned long long s_ambig, s_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nbins = A.use_lds_hist == 2 ? kHashSlots : A.ntax;
-  unsigned long long* h_count = hist;
-  unsigned long long* h_bases = hist + nbins;
-  unsigned long long* h_first = hist + 2 * (size_t)nbins;
-  uint32_t* h_key = reinterpret_cast<uint32_t*>(hist + 3 * (size_t)nbins);  // hashed mode only
+  // per bin: bases u64, first-seen u64, count u32 (a workgroup sees far fewer than 2^32 reads), key u32 (hashed mode)
+  unsigned long long* h_bases = hist;
+  unsigned long long* h_first = hist + nbins;
+  uint32_t* h_count = reinterpret_cast<uint32_t*>(hist + 2 * (size_t)nbins);
+  uint32_t* h_key = h_count + nbins;  // hashed mode only
   if (COMMIT && A.use_lds_hist) {
     for (uint32_t t = tid; t < nbins; t += kPB) {
       h_count[t] = 0; h_bases[t] = 0; h_first[t] = ~0ull;
@@ -431,9 +472,13 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
   __syncthreads();
 
   for (;;) {
-    if (tid == 0) s_ticket = atomicAdd(A.ticket, 1ull);  // tiles are handed out in order
+    // Tiles are handed out in order, by kTicketLanes interleaved counters (tile = ticket * lanes + lane, a workgroup
+    // always draws from lane blockIdx % lanes): returning atomics on ONE address retire at ~12 M/s on this part,
+    // which capped the whole pass at ~80 ns per tile whatever its size.  The smallest unfinished tile is always
+    // either being processed or next in its lane's queue, so the look-back still cannot dead-lock.
+    if (tid == 0) s_ticket = atomicAdd(A.ticket + (size_t)(blockIdx.x % A.ticket_lanes) * kTicketStride, 1ull);
     __syncthreads();
-    const uint64_t tile = s_ticket;
+    const uint64_t tile = s_ticket * A.ticket_lanes + (blockIdx.x % A.ticket_lanes);
     if (tile >= A.ntiles) break;
     const uint64_t t0 = tile * kTile;
     const uint32_t nst = (uint32_t)(A.ntotal - t0 < (uint64_t)kStaged ? A.ntotal - t0 : (uint64_t)kStaged);  // staged
@@ -512,7 +557,7 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
       for (int64_t base = (int64_t)tile - 1;; base -= kLbWaves * 64 * kWin) {
         if (wave < kLbWaves) {
           bool found;
-          const TileFn f = look_window(A.desc, base - (int64_t)wave * 64 * kWin, &found);
+          const TileFn f = look_window(A.desc, base - (int64_t)wave * 64 * kWin, &found, s_lbuf[wave]);
           if (lane == 0) { s_lb[wave] = f; s_lbf[wave] = found ? 1u : 0u; }
         }
         __syncthreads();
@@ -596,7 +641,7 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
             }
           }
           if (in_lds) {
-            atomicAdd(&h_count[bin], 1ull);
+            atomicAdd(&h_count[bin], 1u);
             atomicAdd(&h_bases[bin], (unsigned long long)hitlen);
             atomicMin(&h_first[bin], (unsigned long long)my_gidx);
           } else {
@@ -633,7 +678,7 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
       for (uint32_t t = tid; t < nbins; t += kPB) {
         if (h_count[t]) {
           const uint32_t tax = A.use_lds_hist == 2 ? h_key[t] : t;
-          atomicAdd(&A.g_count[tax], h_count[t]);
+          atomicAdd(&A.g_count[tax], (unsigned long long)h_count[t]);
           atomicAdd(&A.g_bases[tax], h_bases[t]);
           atomicMin(&A.g_first[tax], h_first[t]);
         }
@@ -749,8 +794,9 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
                 uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars, bool reset_acc = false) {
   Context& c = ctx();
   hipStream_t st = stage_c_stream();
-  const uint64_t desc_bytes = (p->ntiles * kDescWords + 1) * sizeof(uint64_t);
-  if (!p->desc.p) MG_TRY(p->desc.alloc(desc_bytes));
+  const uint64_t desc_bytes = (p->ntiles * kDescWords + (uint64_t)kTicketLanes * kTicketStride) * sizeof(uint64_t);
+  // (+ one look-back window of slack: a window clamped to the start of a short array is read in full)
+  if (!p->desc.p) MG_TRY(p->desc.alloc(desc_bytes + (uint64_t)kWinTiles * kDescWords * sizeof(uint64_t)));
   if (!p->tot.p) MG_TRY(p->tot.alloc(4 * sizeof(uint64_t)));
   {
     const uint64_t ndesc = desc_bytes / sizeof(uint64_t);
@@ -766,19 +812,21 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   a.desc = p->desc.as<uint64_t>();
   a.ticket = reinterpret_cast<unsigned long long*>(p->desc.as<uint64_t>() + p->ntiles * kDescWords);
   a.ntiles = p->ntiles;
+  a.ticket_lanes = kTicketLanes;  // (lowered below to the grid size: every lane needs a workgroup drawing from it)
   a.incoming = incoming; a.first_shard = first_shard; a.group_base = group_base;
   a.ntax = p->ntax;
   a.out_tot = p->tot.as<uint64_t>();
   if (!commit) {
     ProfScope ps("profile_map", st);
     const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * 4);
+    if (grid < a.ticket_lanes) a.ticket_lanes = grid;
     hipLaunchKernelGGL(k_profile_pass<false>, dim3(grid), dim3(kPB), 0, st, a);
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
   a.use_lds_hist = p->ntax <= 2048 ? 1u : 2u;
-  const size_t lds = a.use_lds_hist == 1 ? 3 * (size_t)p->ntax * sizeof(unsigned long long)
-                                         : kHashSlots * (3 * sizeof(unsigned long long) + sizeof(uint32_t));
+  const size_t lds = a.use_lds_hist == 1 ? (size_t)p->ntax * (2 * sizeof(unsigned long long) + sizeof(uint32_t))
+                                         : kHashSlots * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t));
   a.g_count = (unsigned long long*)d_count; a.g_bases = (unsigned long long*)d_bases;
   a.g_first = (unsigned long long*)d_first_seen; a.g_scalars = (unsigned long long*)d_scalars;
   a.mm_offsets = p->mm_offsets.as<uint64_t>(); a.mm_tax = p->mm_tax.as<uint32_t>();
@@ -787,6 +835,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   // every workgroup flushes its private histogram once: few, long-lived workgroups
   const unsigned per_cu = lds > 40 * 1024 ? 2u : 3u;
   const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
+  if (grid < a.ticket_lanes) a.ticket_lanes = grid;
   hipLaunchKernelGGL(k_profile_pass<true>, dim3(grid), dim3(kPB), lds, st, a);
   MG_HIP(hipGetLastError());
   return MG_OK;
