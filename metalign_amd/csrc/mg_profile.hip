@@ -445,7 +445,7 @@ struct PassArgs {
 };
 
 template <bool COMMIT>
-__global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
+__device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
   __shared__ uint2 s_desc[kSlots];
   __shared__ RunFn s_run[kPB / 64];
@@ -689,6 +689,19 @@ __global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
       if (s_ambig) atomicAdd(&A.g_scalars[1], s_ambig);
     }
   }
+}
+
+// The two instantiations as kernels.  The map-only pass fits 128 VGPRs (4 wavefronts per SIMD: four workgroups
+// per CU instead of three); the commit pass keeps its 154 rather than spill.
+template <bool COMMIT>
+__global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A);
+template <>
+__global__ __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(4))) void k_profile_pass<false>(const PassArgs A) {
+  profile_pass_body<false>(A);
+}
+template <>
+__global__ __launch_bounds__(kPB) void k_profile_pass<true>(const PassArgs A) {
+  profile_pass_body<true>(A);
 }
 
 // Before a pass: tile descriptors + ticket = 0 and, when asked, the accumulators of a fresh batch (one launch).
