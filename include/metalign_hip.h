@@ -84,6 +84,13 @@ int mg_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes);
 int mg_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes);
 /* Asynchronous on the library stream (accumulator reset between batches). */
 int mg_dev_memset(void* d_ptr, int byte_value, uint64_t bytes);
+/* A marker on the library's main stream: mg_event_synchronize returns when everything queued there before
+ * mg_event_record has finished — unlike mg_sync, not what was queued after it, so a caller can queue the next
+ * batch before it reads the current one back. */
+int mg_event_create(void** ev);
+int mg_event_record(void* ev);
+int mg_event_synchronize(void* ev);
+int mg_event_destroy(void* ev);
 /* Page-locked host memory and an asynchronous device-to-host copy into it (ordered on the library stream;
  * the bytes are valid after mg_sync).  Lets a caller queue all of a batch's small read-backs behind the
  * kernels and pay for one synchronisation. */

@@ -25,7 +25,8 @@ MAX_K = 64
 EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
-    "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_c_join",
+    "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async",
+    "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
@@ -143,6 +144,33 @@ class PinnedArray:
             self.array = None
             self.hip.lib.mg_host_free(_vp(self.ptr))
             self.ptr = None
+
+    def __del__(self):  # best effort
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Event:
+    """A marker on the library's main stream (mg_event_*)."""
+
+    def __init__(self, hip):
+        self.hip = hip
+        p = _vp()
+        hip._chk(hip.lib.mg_event_create(ctypes.byref(p)))
+        self.handle = p
+
+    def record(self):
+        self.hip._chk(self.hip.lib.mg_event_record(self.handle))
+
+    def synchronize(self):
+        self.hip._chk(self.hip.lib.mg_event_synchronize(self.handle))
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_event_destroy(self.handle)
+            self.handle = None
 
     def __del__(self):  # best effort
         try:
@@ -447,6 +475,9 @@ class Hip:
 
     def stage_c_join(self):
         self._chk(self.lib.mg_stage_c_join())
+
+    def event(self):
+        return Event(self)
 
     def pinned(self, count, dtype):
         return PinnedArray(self, count, dtype)

@@ -298,6 +298,34 @@ int mg_stage_a_side_stream(int on) {
   return MG_OK;
 }
 
+int mg_event_create(void** ev) {
+  MG_REQUIRE_READY();
+  if (!ev) return fail(MG_ERR_ARG, "null out pointer");
+  hipEvent_t e = nullptr;
+  MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *ev = e;
+  return MG_OK;
+}
+
+int mg_event_record(void* ev) {
+  MG_REQUIRE_READY();
+  if (!ev) return fail(MG_ERR_ARG, "null event");
+  MG_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), ctx().stream));
+  return MG_OK;
+}
+
+int mg_event_synchronize(void* ev) {
+  MG_REQUIRE_READY();
+  if (!ev) return fail(MG_ERR_ARG, "null event");
+  MG_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
+  return MG_OK;
+}
+
+int mg_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev));
+  return MG_OK;
+}
+
 int mg_stage_c_join(void) {
   MG_REQUIRE_READY();
   mg::Context& c = ctx();

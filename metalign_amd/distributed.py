@@ -166,6 +166,45 @@ class HipEngine:
     def profile_map(self):
         return self.shard.state_map(), self.shard.ngroups
 
+    # ---- queue-ahead passes (single shard): everything of a pass is queued, a marker is recorded behind it, and
+    # the pass is read back later — after the NEXT pass has been queued, so the GPU runs pass after pass without
+    # waiting for the host in between.  Two result sets alternate.
+    def _result_sets(self):
+        if not hasattr(self, "_sets"):
+            hip, g, T = self.hip, max(self.ngen_local, 1), self.ntax
+            self._sets = [dict(d_acc=self.d_acc, h_acc=self.h_acc, h_hs=self.h_hs, ev=hip.event()),
+                          dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
+                               h_hs=hip.pinned(2 * g, np.uint32), ev=hip.event())]
+        return self._sets
+
+    def queue_pass(self, slot, k, hmax, s, ci, pct_id):
+        rs = self._result_sets()[slot]
+        g, T = max(self.ngen_local, 1), self.ntax
+        sk = self.hip.sketch_reads_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)  # stage A (main)
+        shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
+                                           self.nref, self.ntax, pct_id)
+        base = rs["d_acc"].ptr
+        shard.commit(True, True, 0, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8, reset=True)  # stage C (2nd stream)
+        self.hip.containment_dev(sk, self.table, ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)      # stage B (main)
+        self.hip.stage_c_join()
+        rs["h_acc"].fetch_async(base)
+        rs["ev"].record()
+        return dict(slot=slot, sk=sk, shard=shard, ci=ci)
+
+    def finish_pass(self, q, want_multimapped):
+        rs = self._result_sets()[q["slot"]]
+        g, T = max(self.ngen_local, 1), self.ntax
+        rs["ev"].synchronize()  # this pass only: the next one may already be running
+        sk, shard = q["sk"], q["shard"]
+        if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
+            self.hip.sync()
+            self.hip.containment_dev(sk, self.table, q["ci"], rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
+            self.hip.sync()
+        hs, acc = rs["h_hs"].array.copy(), rs["h_acc"].array.copy()
+        mm = shard.multimapped() if want_multimapped else None
+        shard.free()
+        return sk, (hs[: self.ngen_local], hs[g: g + self.ngen_local]), (acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm)
+
     def profile_commit_launch(self, incoming, first_shard, group_base):
         """Asynchronous part of the commit: accumulator reset + the stage-C pass; nothing is read back."""
         T = self.ntax
@@ -359,12 +398,22 @@ class ShardJob:
         eng = self.engine
         if nsteps < 1:
             return None
-        # Single shard: no exchange to hide; pipelined it measured the same 0.75 ms per pass (stage A gives up a
-        # third of its LDS-limited occupancy to let the rest overlap, and loses what the overlap saves).
-        if not hasattr(eng, "sketch_local_async") or not self.exchange:
+        if not hasattr(eng, "sketch_local_async"):
             out = None
             for _ in range(nsteps):
                 out = self.step(want_multimapped)
+            return out
+        if not self.exchange:
+            # Single shard: no exchange to hide, and overlapping the next pass's stage A with this pass's tail
+            # measured no gain (it costs stage A what it saves).  What does pay is not letting the GPU wait for the
+            # host between passes: pass i+1 is queued (same streams, behind pass i) BEFORE pass i is read back.
+            q = eng.queue_pass(0, self.k, self.hmax, self.s, self.ci, self.pct_id)
+            out = None
+            for i in range(nsteps):
+                nxt = eng.queue_pass((i + 1) & 1, self.k, self.hmax, self.s, self.ci, self.pct_id) if i + 1 < nsteps else None
+                sk, (hits, sizes), committed = eng.finish_pass(q, want_multimapped)
+                out = self._results(sk, hits, sizes, committed)
+                q = nxt
             return out
         eng.hip.stage_a_side_stream(True)
         try:
@@ -410,6 +459,10 @@ class ShardJob:
             else:
                 hits, sizes = eng.containment(sk, self.ci)
                 committed = eng.profile_commit(1, True, 0, want_multimapped)
+        return self._results(sk, hits, sizes, committed)
+
+    def _results(self, sk, hits, sizes, committed):
+        """Sample-wide results from this rank's stage B counts and stage C accumulators (the all-reduce when sharded)."""
         qn = sk.size
         sk.free()
         count, bases, first, scalars, mm = committed

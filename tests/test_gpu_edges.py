@@ -84,8 +84,9 @@ def test_bad_arguments_fail_loudly(hip):
 
 
 def test_pipelined_run_equals_single_steps(hip, oracle_lib):
-    """ShardJob.run(n): stage A of pass i+1 is queued on its own stream before pass i is finished; every pass gives
-    what a stand-alone step gives (and what the oracle gives)."""
+    """ShardJob.run(n) on a single shard: pass i+1 is queued before pass i is read back (two result sets, one marker
+    per pass); every pass gives what a stand-alone step gives (and what the oracle gives).  The exchange-path
+    pipelining (stage A on its own stream) is covered by tests/dist_single_rank.py."""
     from metalign_amd import synth
     from metalign_amd.distributed import ShardJob
     gb, go = synth.make_genomes(40, 20000)
@@ -97,17 +98,7 @@ def test_pipelined_run_equals_single_steps(hip, oracle_lib):
     job = ShardJob(hip, None, 0, 1, k=k)
     job.load(rb, ro, recs, ref2tax, dbh, dbo)
     one = job.step(want_multimapped=True)
-    job.exchange = True  # run() pipelines only when there is an exchange to hide; ...
-    run_step, job.step = job.step, (lambda want_multimapped=False, _sketch=None: run_step_plain(want_multimapped, _sketch))
-
-    def run_step_plain(want_multimapped, _sketch):  # ... here the passes themselves stay single-shard
-        job.exchange = False
-        try:
-            return run_step(want_multimapped, _sketch=_sketch)
-        finally:
-            job.exchange = True
-    piped = job.run(4, want_multimapped=True)
-    job.exchange, job.step = False, run_step
+    piped = job.run(4, want_multimapped=True)  # single shard: every pass is queued before the previous one is read back
     again = job.step(want_multimapped=True)
     oh, oc, otr, _ = oracle_lib.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
     ohits, osizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
