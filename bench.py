@@ -49,7 +49,10 @@ def build_workload(args, rank, hip):
     """Synthetic inputs, generated on the host once and left resident in HBM."""
     from metalign_amd import synth
     gb, go = synth.make_genomes(args.genomes, args.genome_len)
-    rb, ro, src = synth.make_reads(gb, go, args.reads, seed=synth.SEED + 1 + 1000 * rank)
+    # 50 present genomes at configs[1] (1k genomes); one genome in 20 for the larger tables, so that the coverage per
+    # present genome stays in a metagenome's range instead of growing into the thousands
+    npresent = max(50, args.genomes // 20)
+    rb, ro, src = synth.make_reads(gb, go, args.reads, npresent=npresent, seed=synth.SEED + 1 + 1000 * rank)
     # accession rows: 0 = 'Unmapped', 1..G = one accession per genome; taxon row == accession row
     recs = synth.make_alignment_records(src + 1, args.genomes + 1, seed=synth.SEED + 2 + 1000 * rank)
     ref2tax = np.arange(args.genomes + 1, dtype=np.uint32)
