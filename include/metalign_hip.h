@@ -151,6 +151,26 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
                               uint64_t nreads, int k, uint64_t hmax, uint64_t s,
                               mg_sketch** out);
 int mg_sketch_resolve(mg_sketch* sk, int* rebuilt);
+/* ------------------------------------------------------------------------ *
+ * Membership pre-filter over the genome table's hashes — the role of the bloom pre-filter the reference hands
+ * to CMash (`-f cmash_db_n1000_k60_30-60-10.bf`, scripts/select_db.py:70,75).  One bit per hash: bit (h mod
+ * 2^b), 2^b = the power of two >= 16 x the number of hashes (2^16 <= 2^b <= 2^30: at most 128 MB, inside the
+ * Infinity Cache).  No false negatives, ~6 % false positives (more for tables beyond 64 M hashes).  The FILTERED read sketch is the sketch defined above restricted to the hashes whose bit is
+ * set (truncation to s applies after the filter): every table hash stays in, so containment is unchanged, and a
+ * table whose largest hash does not filter much (tiny genomes) no longer turns every read k-mer into a table
+ * insert.  Build it from ALL hashes of the table (every k has its own), also on a rank that holds a slice.
+ * The filter must outlive the sketches built with it until they are resolved.
+ * ------------------------------------------------------------------------ */
+typedef struct mg_filter mg_filter;
+int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out);
+unsigned mg_filter_log2_bits(const mg_filter* f);
+void mg_filter_free(mg_filter* f);
+int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
+                                 uint64_t nreads, int k, uint64_t hmax, uint64_t s,
+                                 const mg_filter* filter, mg_sketch** out);
+int mg_sketch_reads_filtered_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
+                                       uint64_t nreads, int k, uint64_t hmax, uint64_t s,
+                                       const mg_filter* filter, mg_sketch** out);
 /* Union of (hash,count) runs, counts of equal hashes summed, then truncated to
  * s: the merge step after an all-gather of per-GPU sketches.  Inputs need not
  * be sorted.  `any_truncated`: OR of the inputs' truncated flags with

@@ -28,7 +28,8 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
+    "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
+    "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
@@ -75,6 +76,8 @@ def load_library(path=LIB_PATH):
     for name in ("mg_sketch_size", "mg_sketch_kmers_seen", "mg_sketch_last_hash", "mg_db_ngenomes", "mg_db_max_hash", "mg_profile_ngroups"):
         getattr(lib, name).restype = ctypes.c_uint64
     lib.mg_sketch_free.restype = None
+    lib.mg_filter_free.restype = None
+    lib.mg_filter_log2_bits.restype = ctypes.c_uint
     lib.mg_db_free.restype = None
     lib.mg_profile_free.restype = None
     lib.mg_shutdown.restype = None
@@ -308,6 +311,28 @@ class AccIndex:
             pass
 
 
+class Filter:
+    """Membership pre-filter over a genome table's hashes (mg_filter): bit (h mod 2^b) per hash."""
+
+    def __init__(self, hip, handle):
+        self.hip, self.handle = hip, handle
+
+    @property
+    def log2_bits(self):
+        return int(self.hip.lib.mg_filter_log2_bits(self.handle))
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_filter_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class SketchTable:
     """Device-resident genome sketch table for one k (opaque mg_db handle)."""
 
@@ -500,18 +525,42 @@ class Hip:
         return n.value, ms.value
 
     # ---- stage A ----
-    def sketch_reads_dev(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0):
+    def filter_build(self, hashes):
+        """Membership pre-filter over ALL hashes of a genome table (one k)."""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         h = _vp()
-        self._chk(self.lib.mg_sketch_reads_dev(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_int(k),
-                                               ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.byref(h)))
-        return Sketch(self, h, k)
+        self._chk(self.lib.mg_filter_build(_np(hashes if hashes.size else np.zeros(1, np.uint64), ctypes.c_uint64),
+                                           ctypes.c_uint64(hashes.size), ctypes.byref(h)))
+        return Filter(self, h)
 
-    def sketch_reads_dev_async(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0):
+    def sketch_reads_dev(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0, filt=None):
+        """filt: a Filter (the table's): the sketch is restricted to hashes that may be in the table."""
+        h = _vp()
+        if filt is None:
+            self._chk(self.lib.mg_sketch_reads_dev(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_int(k),
+                                                   ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.byref(h)))
+        else:
+            self._chk(self.lib.mg_sketch_reads_filtered_dev(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads),
+                                                            ctypes.c_int(k), ctypes.c_uint64(hmax), ctypes.c_uint64(s),
+                                                            filt.handle, ctypes.byref(h)))
+        sk = Sketch(self, h, k)
+        sk.filt = filt  # keeps the filter alive as long as the sketch may still be rebuilt with it
+        return sk
+
+    def sketch_reads_dev_async(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0, filt=None):
         """No host sync: the sketch finalises at its first host-side read (Sketch.resolve / size / download ...)."""
         h = _vp()
-        self._chk(self.lib.mg_sketch_reads_dev_async(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_int(k),
-                                                     ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.byref(h)))
-        return Sketch(self, h, k)
+        if filt is None:
+            self._chk(self.lib.mg_sketch_reads_dev_async(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads),
+                                                         ctypes.c_int(k), ctypes.c_uint64(hmax), ctypes.c_uint64(s),
+                                                         ctypes.byref(h)))
+        else:
+            self._chk(self.lib.mg_sketch_reads_filtered_dev_async(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads),
+                                                                  ctypes.c_int(k), ctypes.c_uint64(hmax), ctypes.c_uint64(s),
+                                                                  filt.handle, ctypes.byref(h)))
+        sk = Sketch(self, h, k)
+        sk.filt = filt
+        return sk
 
     def sketch_from_pairs_dev(self, d_hashes, d_counts, n, k, s=0, any_truncated=False, bound=U64_MAX):
         h = _vp()

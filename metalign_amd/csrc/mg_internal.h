@@ -194,6 +194,7 @@ struct mg_sketch {
     uint64_t nreads = 0, hmax = 0, s = 0, cap = 0;
     int k = 0;
     unsigned stage = 0;
+    const mg_filter* filter = nullptr;
   } redo;
   ~mg_sketch();
 };
@@ -205,6 +206,14 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt);
 // Makes the library's current stream wait (on the device) for the stream that built the sketch, if it is another.
 int sketch_wait(const mg_sketch* sk);
 }  // namespace mg
+
+struct mg_filter {
+  // Membership pre-filter over a set of hashes (the genome table's): one bit per hash value modulo the size,
+  // nbits = power of two >= 16 x the number of hashes.  No false negatives; ~6 % false positives.
+  mg::DevBuf bits;      // u32[nbits / 32]
+  uint64_t mask = 0;    // nbits - 1
+  unsigned log2_bits = 0;
+};
 
 struct mg_db {
   // Hash-major layout built once at upload (mg_contain.hip): every (hash, genome) pair of every genome sketch,

@@ -82,24 +82,52 @@ struct CandSink {
   unsigned long long* counters;  // [0] candidates produced, [1] k-mers hashed, [2] table overflows
   uint32_t* slot_cnt;            // table mode: occurrence count per slot
   unsigned shift;                // bucket = hash >> shift; 64 = list mode (read sketches start at hash 0)
+  const uint32_t* fbits;         // optional membership pre-filter (mg_filter): bit (h & fmask) set <=> h may be in the table
+  uint64_t fmask;
   int n;              // entries staged (wave-uniform)
+  unsigned long long produced = 0;  // table mode: this lane's candidates inserted so far
 
+  __device__ __forceinline__ bool passes(uint64_t h) const {
+    return !fbits || ((fbits[(h & fmask) >> 5] >> (h & 31u)) & 1u);
+  }
+
+  // The filter is probed here, a buffer at a time with every lane busy, not in the hashing loop.
   __device__ __forceinline__ void flush(int lane) {
     if (n == 0) return;
     wave_lds_sync();
     if (shift >= 64) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(counters, (unsigned long long)n);
-      base = __shfl(base, 0, 64);
-      for (int i = lane; i < n; i += 64)
-        if (base + i < cap) out[base + i] = lds[i];
-    } else {
-      uint32_t lost = 0;
-      for (int i = lane; i < n; i += 64) {
-        const uint64_t h = lds[i];
-        if (!table_add(out, slot_cnt, h >> shift, h, 1u)) ++lost;
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t h = i < n ? lds[i] : 0;
+        const bool keep = i < n && passes(h);
+        const unsigned long long m = __ballot(keep);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counters, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0, 64) + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && base < cap) out[base] = h;
       }
-      if (lane == 0) atomicAdd(counters, (unsigned long long)n);
+    } else {
+      uint32_t lost = 0, kept = 0;
+      // this lane's candidates and their filter words first, all in flight together; then the inserts
+      uint64_t hh[kCandBuf / 64];
+      uint32_t fw[kCandBuf / 64];
+#pragma unroll
+      for (int j = 0; j < kCandBuf / 64; ++j) {
+        const int i = lane + 64 * j;
+        hh[j] = i < n ? lds[i] : kReservedHash;
+        fw[j] = 0xffffffffu;
+        if (fbits && hh[j] != kReservedHash) fw[j] = fbits[(hh[j] & fmask) >> 5];
+      }
+#pragma unroll
+      for (int j = 0; j < kCandBuf / 64; ++j) {
+        if (hh[j] == kReservedHash || !((fw[j] >> (hh[j] & 31u)) & 1u)) continue;
+        ++kept;
+        if (!table_add(out, slot_cnt, hh[j] >> shift, hh[j], 1u)) ++lost;
+      }
+      // (counted per lane and added to counters[0] once, at the end of the kernel: an atomic per flush on that one
+      // address is what bounded the kernel when the threshold filters little — 1.3 M flushes per 10 M reads at ~24 ns)
+      produced += kept;
       if (lost) atomicAdd(counters + 2, (unsigned long long)lost);
     }
     wave_lds_sync();
@@ -190,12 +218,13 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
                                                          uint64_t hmax, uint64_t* __restrict__ cand, uint64_t cand_cap,
                                                          unsigned long long* __restrict__ counters,
                                                          uint32_t* __restrict__ slot_cnt, unsigned bucket_shift,
-                                                         unsigned stage_bytes) {
+                                                         unsigned stage_bytes, const uint32_t* __restrict__ fbits,
+                                                         uint64_t fmask) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
-  CandSink sink{cbuf, cand, cand_cap, counters, slot_cnt, bucket_shift, 0};
+  CandSink sink{cbuf, cand, cand_cap, counters, slot_cnt, bucket_shift, fbits, fmask, 0};
   uint64_t kmers = 0;
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -230,6 +259,8 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
   sink.flush(lane);
   kmers = wave_sum_u64(kmers);
   if (lane == 0 && kmers) atomicAdd(counters + 1, (unsigned long long)kmers);
+  const uint64_t produced = wave_sum_u64(sink.produced);
+  if (lane == 0 && produced) atomicAdd(counters, (unsigned long long)produced);
 }
 
 // Stage A': hash of the k-mer ENDING at every base position of a batch of genomes
@@ -528,7 +559,7 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
 template <int K>
 static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t hmax,
                                uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, uint32_t* d_slot_cnt,
-                               unsigned bucket_shift, unsigned stage_bytes) {
+                               unsigned bucket_shift, unsigned stage_bytes, const mg_filter* filter = nullptr) {
   Context& c = ctx();
   size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
   if (const char* pad = getenv("MG_DEBUG_LDS_PAD")) lds += (size_t)atol(pad);  // occupancy experiments only
@@ -544,7 +575,8 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
-                     nreads, hmax, d_cand, cap, d_counters, d_slot_cnt, bucket_shift, stage_bytes);
+                     nreads, hmax, d_cand, cap, d_counters, d_slot_cnt, bucket_shift, stage_bytes,
+                     filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr, filter ? filter->mask : 0ull);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -628,7 +660,8 @@ static int table_to_sketch(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta,
 
 // List path: flat candidate list -> rocPRIM radix sort -> run-length encode (any size, any distribution).
 static int sketch_via_list(mg_sketch* sk, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k,
-                           uint64_t hmax, uint64_t s, uint64_t cap, unsigned stage, unsigned long long* d_counters) {
+                           uint64_t hmax, uint64_t s, uint64_t cap, unsigned stage, unsigned long long* d_counters,
+                           const mg_filter* filter = nullptr) {
   hipStream_t st = ctx().stream;
   uint64_t* pin = host_words();
   uint64_t ncand = 0;
@@ -638,7 +671,7 @@ static int sketch_via_list(mg_sketch* sk, const uint8_t* d_bases, const uint64_t
     MG_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), st));
     int rc = MG_ERR_ARG;
     dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, d_cand, cap, d_counters, nullptr, 64u, stage);
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, d_cand, cap, d_counters, nullptr, 64u, stage, filter);
     });
     if (rc) return rc;
     MG_HIP(hipMemcpyAsync(pin + 2, d_counters, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -727,7 +760,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
   return sketch_via_list(sk, sk->redo.bases, sk->redo.offsets, sk->redo.nreads, sk->redo.k, sk->redo.hmax, sk->redo.s, cap,
-                         sk->redo.stage, d_counters);
+                         sk->redo.stage, d_counters, sk->redo.filter);
 }
 
 }  // namespace mg
@@ -740,10 +773,18 @@ mg_sketch::~mg_sketch() {
 
 using namespace mg;
 
-extern "C" {
+// Membership pre-filter: bit (h mod nbits) for every hash of the set.
+__global__ void k_filter_set(const uint64_t* __restrict__ hashes, uint64_t n, uint32_t* __restrict__ bits, uint64_t mask) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const uint64_t b = hashes[i] & mask;
+    atomicOr(&bits[b >> 5], 1u << (b & 31u));
+  }
+}
 
-int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
-                              uint64_t s, mg_sketch** out) {
+static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
+                              uint64_t s, const mg_filter* filter, mg_sketch** out) {
   MG_REQUIRE_READY();
   if (!out) return fail(MG_ERR_ARG, "null out handle");
   *out = nullptr;
@@ -802,7 +843,7 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
       rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, tp.keys, 0, t_counters, tp.cnts, tp.shift,
-                                  (unsigned)stage);
+                                  (unsigned)stage, filter);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
@@ -830,14 +871,65 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     sk->expect = (double)(expect ? expect : 1);
     sk->redo.bases = d_bases; sk->redo.offsets = d_offsets; sk->redo.nreads = nreads; sk->redo.k = k;
     sk->redo.hmax = hmax; sk->redo.s = s; sk->redo.cap = cap; sk->redo.stage = (unsigned)stage;
+    sk->redo.filter = filter;
     *out = sk.release();
     return MG_OK;
   }
-  MG_TRY(sketch_via_list(sk.get(), d_bases, d_offsets, nreads, k, hmax, s, cap, (unsigned)stage, d_counters));
+  MG_TRY(sketch_via_list(sk.get(), d_bases, d_offsets, nreads, k, hmax, s, cap, (unsigned)stage, d_counters, filter));
   MG_HIP(hipStreamSynchronize(st));  // the list path reads back as it goes; nothing is left in flight
   *out = sk.release();
   return MG_OK;
 }
+
+extern "C" {
+
+int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
+                              uint64_t s, mg_sketch** out) {
+  return sketch_reads_async(d_bases, d_offsets, nreads, k, hmax, s, nullptr, out);
+}
+
+int mg_sketch_reads_filtered_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k,
+                                       uint64_t hmax, uint64_t s, const mg_filter* filter, mg_sketch** out) {
+  if (!filter) return fail(MG_ERR_ARG, "null filter");
+  return sketch_reads_async(d_bases, d_offsets, nreads, k, hmax, s, filter, out);
+}
+
+int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
+                                 uint64_t s, const mg_filter* filter, mg_sketch** out) {
+  MG_TRY(mg_sketch_reads_filtered_dev_async(d_bases, d_offsets, nreads, k, hmax, s, filter, out));
+  int rc = sketch_resolve(*out, nullptr);
+  if (rc != MG_OK) { mg_sketch_free(*out); *out = nullptr; }
+  return rc;
+}
+
+int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out) {
+  MG_REQUIRE_READY();
+  if (!out || (n && !hashes)) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  std::unique_ptr<mg_filter> f(new mg_filter());
+  unsigned lb = 16;  // 16 bits per hash, between 2^16 and 2^30 bits (128 MB: still inside the Infinity Cache)
+  while (lb < 30 && (1ull << lb) < 16 * n) ++lb;
+  f->log2_bits = lb;
+  f->mask = (1ull << lb) - 1;
+  const uint64_t bytes = (1ull << lb) / 8;
+  MG_TRY(f->bits.alloc(bytes));
+  hipStream_t st = ctx().stream;
+  MG_HIP(hipMemsetAsync(f->bits.p, 0, bytes, st));
+  if (n) {
+    uint64_t* d_h = (uint64_t*)scratch("filter_h", n * sizeof(uint64_t));
+    if (!d_h) return MG_ERR_NOMEM;
+    MG_HIP(hipMemcpyAsync(d_h, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_filter_set, dim3(grid_for(n, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st, d_h, n,
+                       f->bits.as<uint32_t>(), f->mask);
+    MG_HIP(hipGetLastError());
+  }
+  MG_HIP(hipStreamSynchronize(st));
+  *out = f.release();
+  return MG_OK;
+}
+
+unsigned mg_filter_log2_bits(const mg_filter* f) { return f ? f->log2_bits : 0; }
+void mg_filter_free(mg_filter* f) { delete f; }
 
 int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
                         uint64_t s, mg_sketch** out) {

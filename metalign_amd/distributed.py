@@ -89,11 +89,18 @@ class HipEngine:
         self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
 
     # ---- stage A ----
+    filter = None
+
+    def set_filter(self, table_hashes):
+        """Membership pre-filter over ALL hashes of the genome table (also on a rank that holds a slice of it): the
+        read sketch keeps only hashes that may be in the table — the reference's `-f ...bf` (select_db.py:70,75)."""
+        self.filter = self.hip.filter_build(table_hashes)
+
     def sketch_local(self, k, hmax, s):
-        return self.hip.sketch_reads_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)
+        return self.hip.sketch_reads_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s, filt=self.filter)
 
     def sketch_local_async(self, k, hmax, s):
-        return self.hip.sketch_reads_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)
+        return self.hip.sketch_reads_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s, filt=self.filter)
 
     def export_sketch(self, sk):
         """(hashes int64 tensor, counts int32 tensor) on this rank's device, zero-copy."""
@@ -180,7 +187,7 @@ class HipEngine:
     def queue_pass(self, slot, k, hmax, s, ci, pct_id):
         rs = self._result_sets()[slot]
         g, T = max(self.ngen_local, 1), self.ntax
-        sk = self.hip.sketch_reads_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s)  # stage A (main)
+        sk = self.sketch_local_async(k, hmax, s)                                                  # stage A (main)
         shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
                                            self.nref, self.ntax, pct_id)
         base = rs["d_acc"].ptr
@@ -252,6 +259,8 @@ class ShardJob:
         tails = dbo[1:][dbo[1:] > dbo[:-1]] - 1
         self.hmax = int(dbh[tails.astype(np.int64)].max()) if len(tails) else 0
         self.bounds = slice_bounds(self.hmax, self.world)
+        if hasattr(self.engine, "set_filter"):
+            self.engine.set_filter(dbh)  # from the FULL table, before it is sliced
         if self.world > 1:
             dbh, dbo = table_slice(dbh, dbo, self.bounds[self.rank], self.bounds[self.rank + 1])
         has_look = False

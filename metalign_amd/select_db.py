@@ -112,12 +112,14 @@ def run_sketch_steps(args):
     for k in table.ks:
         h, o = table.arrays(k)
         dev_table = hip.upload_table(np.asarray(h), o)
-        sk = hip.sketch_reads_dev(d_b_ptr, d_o_ptr, nreads, k, dev_table.max_hash, s)
+        filt = hip.filter_build(np.asarray(h))  # the role of the reference's bloom pre-filter (-f ...bf, :70,75)
+        sk = hip.sketch_reads_dev(d_b_ptr, d_o_ptr, nreads, k, dev_table.max_hash, s, filt=filt)
         hits, sizes = hip.containment(sk, dev_table, min_count)
         with np.errstate(divide='ignore', invalid='ignore'):
             ci = np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0)
         per_k.append(ci)
         sk.free()
+        filt.free()
         dev_table.free()
     reads.free()
     out = args.temp_dir + 'cmash_query_results.csv'

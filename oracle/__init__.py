@@ -85,6 +85,31 @@ def sketch_reads(bases, offsets, k, hmax=U64_MAX, s=0, cap=None):
     return h[: n.value].copy(), c[: n.value].copy(), bool(trunc.value), int(seen.value)
 
 
+def filter_bits(hashes):
+    """Membership pre-filter of include/metalign_hip.h (mg_filter_build): -> (bool array of 2^b bits, mask)."""
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    lb = 16
+    while lb < 30 and (1 << lb) < 16 * len(hashes):
+        lb += 1
+    bits = np.zeros(1 << lb, dtype=bool)
+    mask = np.uint64((1 << lb) - 1)
+    bits[(hashes & mask).astype(np.int64)] = True
+    return bits, mask
+
+
+def sketch_reads_filtered(bases, offsets, k, table_hashes, hmax=U64_MAX, s=0):
+    """The filtered read sketch: the sketch of sketch_reads restricted to hashes whose filter bit is set, THEN cut to
+    the s smallest.  -> (hashes, counts, truncated, kmers_seen)."""
+    h, c, _, seen = sketch_reads(bases, offsets, k, hmax=hmax, s=0)
+    bits, mask = filter_bits(table_hashes)
+    keep = bits[(h & mask).astype(np.int64)] if len(h) else np.zeros(0, dtype=bool)
+    h, c = h[keep], c[keep]
+    truncated = bool(s) and len(h) > s
+    if truncated:
+        h, c = h[:s], c[:s]
+    return h, c, truncated, seen
+
+
 def sketch_genomes(bases, offsets, k, n):
     """-> (hashes u64[*], offsets u64[G+1])."""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)

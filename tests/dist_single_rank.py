@@ -34,15 +34,16 @@ job = ShardJob(hip, dist, 0, 1, k=k, always_exchange=True)
 job.load(rb, ro, recs, ref2tax, dbh, dbo)
 outs = [job.step(want_multimapped=True), job.run(4, want_multimapped=True), job.step(want_multimapped=True)]
 oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
+nfiltered = len(oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])  # the job sketches through the table's filter
 ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
 want = oracle.profile_assign(recs, ref2tax, 61, 0.5)
 for idx, got in enumerate(outs):
     if not (np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)):
         bad = np.nonzero(got["hits"] != ohits)[0]
         print("MISMATCH in output", idx, "hits differ at", len(bad), "genomes; sizes equal:", np.array_equal(got["sizes"], osizes),
-              "sketch", got["sketch_size"], len(oh), "sample", [(int(g), int(got["hits"][g]), int(ohits[g])) for g in bad[:6]])
+              "sketch", got["sketch_size"], nfiltered, "sample", [(int(g), int(got["hits"][g]), int(ohits[g])) for g in bad[:6]])
     assert np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)
-    assert got["sketch_size"] == len(oh), (got["sketch_size"], len(oh))
+    assert got["sketch_size"] == nfiltered, (got["sketch_size"], nfiltered)
     for key in ("count", "bases", "first_seen"):
         assert np.array_equal(got[key], want[key]), key
     assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]

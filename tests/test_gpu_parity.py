@@ -299,3 +299,49 @@ def test_device_multimap_equals_host_resolution(hip, oracle_lib):
             changed += a[k][1] != float(res_host["bases"][taxids.index(k)])
         assert changed > 5
     res_dev["resident"].free()
+
+
+@pytest.mark.parametrize("k,s", [(21, 0), (31, 0), (21, 500)])
+def test_filtered_sketch_matches_oracle_and_keeps_containment(hip, oracle_lib, k, s):
+    """mg_sketch_reads_filtered_dev: the sketch restricted to hashes whose bit is set in the table's membership
+    filter (the reference's `-f ...bf` role).  Bit-exact against the oracle's restatement, sync and deferred; and
+    containment is what the unfiltered sketch gives, because every table hash passes its own filter."""
+    rng = np.random.default_rng(31 + k + s)
+    gb, go = util.random_genomes(rng, 10, 4000)          # tiny genomes: the threshold alone filters little
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 20000, 150, err=0.01)
+    n = 800
+    dbh, dbo = oracle_lib.sketch_genomes(gb, go, k, n)
+    hmax = int(dbh.max())
+    filt = hip.filter_build(dbh)
+    assert filt.log2_bits == 17  # 8000 hashes x 16 = 128000 -> 2^17
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    table = hip.upload_table(dbh, dbo)
+    oh, oc, otr, oseen = oracle_lib.sketch_reads_filtered(bases, offsets, k, dbh, hmax=hmax, s=s)
+    uh, uc, utr, _ = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax, s=0)
+    assert len(oh) < 0.5 * len(uh)                        # the filter does remove most of the sketch here
+    for deferred in (False, True):
+        fn = hip.sketch_reads_dev_async if deferred else hip.sketch_reads_dev
+        sk = fn(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, s, filt=filt)
+        h, c = sk.download()
+        assert np.array_equal(h, oh) and np.array_equal(c, oc)
+        assert sk.truncated == otr and sk.kmers_seen == oseen
+        if s == 0:
+            hits, sizes = hip.containment(sk, table, 2)
+            ohits, osizes = oracle_lib.containment(uh, uc, utr, 2, dbh, dbo)   # from the UNFILTERED oracle sketch
+            assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes)
+        sk.free()
+    # the list path (small / forced) applies the same filter
+    import os
+    os.environ["MG_DEBUG_FORCE_LIST"] = "1"
+    try:
+        sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, s, filt=filt)
+        h, c = sk.download()
+        assert np.array_equal(h, oh) and np.array_equal(c, oc)
+        sk.free()
+    finally:
+        del os.environ["MG_DEBUG_FORCE_LIST"]
+    # an empty table: nothing passes
+    empty = hip.filter_build(np.zeros(0, dtype=np.uint64))
+    sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, 0, filt=empty)
+    assert sk.size == 0
+    sk.free()
