@@ -73,15 +73,22 @@ constexpr int kSlots = kStaged + (kStaged >> 3) + 1;
 
 // Descriptors of records [t0, t0 + nst) live in LDS; anything past that (a read longer than the halo) is
 // rebuilt from HBM.
+// The LDS pointer keeps its address space in the type: as a generic pointer inside a struct the compiler fell back
+// to FLAT loads in eval_group, and with a FLAT access possibly in flight every wait in the commit loop became
+// vmcnt(0) — each read then waited for its own multimapped-list stores to reach memory.
+typedef const __attribute__((address_space(3))) unsigned long long* LdsDescPtr;  // a uint2 as one 64-bit word
 struct DescView {
-  const uint2* lds;
+  LdsDescPtr lds;
   uint64_t t0;
   uint32_t nst;
   const mg_aln_rec* __restrict__ recs;
   const uint32_t* __restrict__ ref2tax;
   double pct_id;
   __device__ __forceinline__ uint2 operator()(uint64_t i) const {
-    if (i - t0 < nst) return lds[slot((uint32_t)(i - t0))];
+    if (i - t0 < nst) {
+      const unsigned long long w = lds[slot((uint32_t)(i - t0))];
+      return make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+    }
     const mg_aln_rec r = recs[i];
     return make_desc(r, ref2tax[r.ref_new & MG_REC_REF_MASK], pct_id);
   }
@@ -419,13 +426,21 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
   return f;
 }
 
-// Per-workgroup privatised histogram in LDS, flushed with global atomics at the end:
-//   use_lds_hist == 1  direct:  ntax <= 2048 bins (dynamic LDS: 20 B per bin)
+// Per-workgroup privatised histogram in LDS, flushed with global atomics every kFlushTiles tiles and at the end:
+//   use_lds_hist == 1  direct:  ntax <= 2048 bins (dynamic LDS: 12 B per bin)
 //   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
 //                      fewer taxa than the table lists); a taxon that finds no bin within kHashProbe steps
 //                      goes to global atomics directly.  Without this a skewed sample serialises millions of
 //                      global atomics on a few hundred addresses.
-constexpr uint32_t kHashSlots = 2048, kHashProbe = 32;
+//   use_lds_hist == 0  global atomics only (shards of 2^32 reads or more: the bins hold 32-bit read indices).
+// A bin is ONE packed 64-bit word (count << 40 | bases) plus the 32-bit shard-relative index of the first read
+// seen: one LDS atomic per unique read (the minimum is only attempted when a plain read says it would change
+// something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
+// had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
+// pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
+constexpr uint32_t kHashSlots = 2048, kHashProbe = 32, kFlushTiles = 256;
+constexpr uint32_t kBinLenLimit = 1u << 20;
+constexpr int kBinCountShift = 40;
 
 struct PassArgs {
   const mg_aln_rec* recs;
@@ -444,8 +459,27 @@ struct PassArgs {
   uint64_t* out_tot;              // [0] composed map, [1] reads, [2] multimapped entries, [3] multimapped reads
 };
 
+// Phase timing (make K3_PHASES=1; tools/k3_phases.py): thread 0's shader-clock time between the phase boundaries
+// of every tile, summed per kernel variant.  Compiled out of the normal build.
+#ifdef MG_K3_PHASES
+__device__ unsigned long long g_ph[16];
+extern "C" int mg_debug_k3_phases(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ph), sizeof(g_ph)) != hipSuccess) return MG_ERR_HIP;
+  unsigned long long z[16] = {0};
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ph), z, sizeof(z)) != hipSuccess) return MG_ERR_HIP;
+  return MG_OK;
+}
+#define PH_DECL __shared__ unsigned long long s_ph[8]; unsigned long long tprev = clock64(); if (threadIdx.x < 8) s_ph[threadIdx.x] = 0
+#define PH(i) do { if (tid == 0) { const unsigned long long now_ = clock64(); s_ph[i] += now_ - tprev; tprev = now_; } } while (0)
+#define PH_FLUSH(c) do { if (tid == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ph[i_ + ((c) ? 8 : 0)], s_ph[i_]); } while (0)
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH(c)
+#endif
 template <bool COMMIT>
 __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
+  PH_DECL;
   extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
   __shared__ uint2 s_desc[kSlots];
   __shared__ RunFn s_run[kPB / 64];
@@ -457,14 +491,25 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   __shared__ unsigned long long s_ambig, s_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nbins = A.use_lds_hist == 2 ? kHashSlots : A.ntax;
-  // per bin: bases u64, first-seen u64, count u32 (a workgroup sees far fewer than 2^32 reads), key u32 (hashed mode)
-  unsigned long long* h_bases = hist;
-  unsigned long long* h_first = hist + nbins;
-  uint32_t* h_count = reinterpret_cast<uint32_t*>(hist + 2 * (size_t)nbins);
-  uint32_t* h_key = h_count + nbins;  // hashed mode only
+  unsigned long long* h_pack = hist;                                     // count << 40 | bases
+  uint32_t* h_first = reinterpret_cast<uint32_t*>(hist + nbins);         // first read seen, relative to the shard
+  uint32_t* h_key = h_first + nbins;                                     // hashed mode only
+  auto flush_bins = [&](bool reset) {
+    for (uint32_t t = tid; t < nbins; t += kPB) {
+      const unsigned long long pk = h_pack[t];
+      if (pk) {
+        const uint32_t tax = A.use_lds_hist == 2 ? h_key[t] : t;
+        atomicAdd(&A.g_count[tax], pk >> kBinCountShift);
+        atomicAdd(&A.g_bases[tax], pk & ((1ull << kBinCountShift) - 1));
+        atomicMin(&A.g_first[tax], (unsigned long long)(A.group_base + h_first[t]));
+        if (reset) { h_pack[t] = 0; h_first[t] = 0xffffffffu; }
+      }
+    }
+  };
+  uint32_t tiles_binned = 0;
   if (COMMIT && A.use_lds_hist) {
     for (uint32_t t = tid; t < nbins; t += kPB) {
-      h_count[t] = 0; h_bases[t] = 0; h_first[t] = ~0ull;
+      h_pack[t] = 0; h_first[t] = 0xffffffffu;
       if (A.use_lds_hist == 2) h_key[t] = 0xffffffffu;
     }
   }
@@ -476,10 +521,12 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
     // always draws from lane blockIdx % lanes): returning atomics on ONE address retire at ~12 M/s on this part,
     // which capped the whole pass at ~80 ns per tile whatever its size.  The smallest unfinished tile is always
     // either being processed or next in its lane's queue, so the look-back still cannot dead-lock.
+    PH(7);
     if (tid == 0) s_ticket = atomicAdd(A.ticket + (size_t)(blockIdx.x % A.ticket_lanes) * kTicketStride, 1ull);
     __syncthreads();
     const uint64_t tile = s_ticket * A.ticket_lanes + (blockIdx.x % A.ticket_lanes);
     if (tile >= A.ntiles) break;
+    PH(0);
     const uint64_t t0 = tile * kTile;
     const uint32_t nst = (uint32_t)(A.ntotal - t0 < (uint64_t)kStaged ? A.ntotal - t0 : (uint64_t)kStaged);  // staged
     const uint32_t nown = (uint32_t)(A.nrecs - t0 < (uint64_t)kTile ? A.nrecs - t0 : (uint64_t)kTile);      // owned
@@ -489,7 +536,8 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       s_desc[slot(i)] = make_desc(r, A.ref2tax[r.ref_new & MG_REC_REF_MASK], A.pct_id);
     }
     __syncthreads();
-    const DescView at{s_desc, t0, nst, A.recs, A.ref2tax, A.pct_id};
+    PH(1);
+    const DescView at{(LdsDescPtr)s_desc, t0, nst, A.recs, A.ref2tax, A.pct_id};
 
     // 2. leaders classify their read under both hypotheses; the thread's 8 records fold into one RunFn
     const uint32_t l0 = (uint32_t)tid * kItems;
@@ -541,8 +589,10 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       mine.out = st0 | (st1 << 1);
     }
     // 3. ordered scan over the workgroup; tile aggregate
+    PH(2);
     RunFn tile_fn;
     const RunFn excl = block_scan_runs(mine, s_run, &tile_fn);
+    PH(3);
     // 4. publish the aggregate, look back (wavefronts 0 .. kLbWaves-1, 1024 tiles per round), publish the
     //    inclusive prefix
     const uint64_t tile_g = pk_reads(tile_fn.pk[0]);
@@ -573,6 +623,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         if (s_lbf[kLbWaves]) break;
       }
     }
+    PH(4);
     if (tid == 0) {
       Incoming in{acc.out, acc.g, A.incoming ? acc.r[1] : acc.r[0], A.incoming ? acc.e[1] : acc.e[0]};
       const uint32_t x_in = (in.map >> A.incoming) & 1u;
@@ -590,6 +641,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       s_bcast[0] = x_in; s_bcast[1] = in.g; s_bcast[2] = in.r; s_bcast[3] = in.e;
     }
     __syncthreads();
+    PH(5);
     if (COMMIT) {
       // 5. commit with the true state: the thread's exclusive prefix, evaluated at the tile's incoming state
       const uint32_t x_in = (uint32_t)s_bcast[0];
@@ -635,19 +687,22 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           if (A.use_lds_hist == 2) {
             uint32_t p = (tax * 2654435761u) >> 21;  // 11 bits: kHashSlots
             for (uint32_t step = 0; step < kHashProbe; ++step) {
-              const uint32_t old = atomicCAS(&h_key[p], 0xffffffffu, tax);
+              uint32_t old = h_key[p];  // keys never change once set: a plain look settles the common case
+              if (old == 0xffffffffu) old = atomicCAS(&h_key[p], 0xffffffffu, tax);
               if (old == 0xffffffffu || old == tax) { bin = p; in_lds = true; break; }
               p = (p + 1) & (kHashSlots - 1);
             }
           }
-          if (in_lds) {
-            atomicAdd(&h_count[bin], 1u);
-            atomicAdd(&h_bases[bin], (unsigned long long)hitlen);
-            atomicMin(&h_first[bin], (unsigned long long)my_gidx);
+          if (in_lds && hitlen < kBinLenLimit) {
+            const uint32_t rel = (uint32_t)(my_gidx - A.group_base);
+            atomicAdd(&h_pack[bin], (1ull << kBinCountShift) + hitlen);
+            if (h_first[bin] > rel) atomicMin(&h_first[bin], rel);
           } else {
             atomicAdd(&A.g_count[tax], 1ull);
             atomicAdd(&A.g_bases[tax], (unsigned long long)hitlen);
-            atomicMin(&A.g_first[tax], (unsigned long long)my_gidx);
+            // first_seen only ever decreases: a (possibly stale) value at or below ours means nothing to do
+            if (__atomic_load_n(&A.g_first[tax], __ATOMIC_RELAXED) > my_gidx)
+              atomicMin(&A.g_first[tax], (unsigned long long)my_gidx);
           }
         } else {
           if (slow) {
@@ -669,21 +724,19 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       }
       if (ambig) atomicAdd(&s_ambig, (unsigned long long)ambig);
       if (tid == 0) s_groups += tile_g;
-    }
-    __syncthreads();  // s_desc / s_bcast / s_ticket are reused by the next tile
-  }
-  if (COMMIT) {
-    __syncthreads();
-    if (A.use_lds_hist) {
-      for (uint32_t t = tid; t < nbins; t += kPB) {
-        if (h_count[t]) {
-          const uint32_t tax = A.use_lds_hist == 2 ? h_key[t] : t;
-          atomicAdd(&A.g_count[tax], (unsigned long long)h_count[t]);
-          atomicAdd(&A.g_bases[tax], h_bases[t]);
-          atomicMin(&A.g_first[tax], h_first[t]);
-        }
+      if (A.use_lds_hist && ++tiles_binned == kFlushTiles) {  // before a packed field can overflow
+        __syncthreads();
+        flush_bins(true);
+        tiles_binned = 0;
       }
     }
+    __syncthreads();  // s_desc / s_bcast / s_ticket are reused by the next tile
+    PH(6);
+  }
+  PH_FLUSH(COMMIT);
+  if (COMMIT) {
+    __syncthreads();
+    if (A.use_lds_hist) flush_bins(false);
     if (tid == 0) {
       if (s_groups) atomicAdd(&A.g_scalars[0], s_groups);
       if (s_ambig) atomicAdd(&A.g_scalars[1], s_ambig);
@@ -837,9 +890,10 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
-  a.use_lds_hist = p->ntax <= 2048 ? 1u : 2u;
-  const size_t lds = a.use_lds_hist == 1 ? (size_t)p->ntax * (2 * sizeof(unsigned long long) + sizeof(uint32_t))
-                                         : kHashSlots * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t));
+  a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 2048 ? 1u : 2u;
+  const size_t lds = a.use_lds_hist == 0 ? 0
+                   : a.use_lds_hist == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t))
+                                         : kHashSlots * (sizeof(unsigned long long) + 2 * sizeof(uint32_t));
   a.g_count = (unsigned long long*)d_count; a.g_bases = (unsigned long long*)d_bases;
   a.g_first = (unsigned long long*)d_first_seen; a.g_scalars = (unsigned long long*)d_scalars;
   a.mm_offsets = p->mm_offsets.as<uint64_t>(); a.mm_tax = p->mm_tax.as<uint32_t>();

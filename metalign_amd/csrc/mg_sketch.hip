@@ -66,7 +66,11 @@ __device__ __forceinline__ bool table_add(uint64_t* __restrict__ keys, uint32_t*
   const uint64_t base = bucket * kBucketSlots;
   uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
   for (uint32_t t = 0; t < kBucketSlots; ++t) {
-    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + base + p), 0ull, v);
+    // A plain look first: a slot's key never changes once set, so a (possibly stale, per-XCD cached) read can only
+    // err towards "empty", and then the CAS decides.  At 50x coverage most candidates are repeats of a key that is
+    // already there: they cost this read and one add instead of a returning CAS and an add.
+    unsigned long long old = keys[base + p];
+    if (old == 0ull) old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + base + p), 0ull, v);
     if (old == 0ull || old == v) { atomicAdd(cnts + base + p, amount); return true; }
     p = (p + 1) & (kBucketSlots - 1);
   }
