@@ -104,13 +104,18 @@ int mg_sync(void);
  * copy).  mg_stage_c_join makes the main stream wait for what stage C has queued so far (before reading its
  * accumulators with mg_memcpy_d2h_async); mg_sync waits for both streams. */
 int mg_stage_c_side_stream(int on);
-/* Stage A on its own stream (on != 0): mg_sketch_reads_dev_async then queues its whole pipeline (table clear,
+/* Stage A on its own stream (on = 1 or 2: which of two such streams the NEXT sketch goes to; 0 = back to the main
+ * stream, after waiting for both): mg_sketch_reads_dev_async then queues its whole pipeline (table clear,
  * k_sketch_reads, bucket sort / pack) there, and a caller that processes batch after batch can start the NEXT
  * batch's stage A before it finishes the current batch (stage B, exchange, read-backs on the main stream): the
- * GPU stays on the dominant kernel.  Consumers of such a sketch (mg_containment_dev, mg_sketch_split,
- * mg_sketch_device_ptrs, mg_sketch_download) make the main stream wait for it on the device; mg_sketch_resolve
- * waits for that sketch only.  mg_sync does NOT wait for the stage-A stream. */
+ * GPU stays on the dominant kernel.  Alternating 1 / 2 between consecutive batches also lets batch i+1's
+ * k_sketch_reads overlap batch i's sort / pack tail.  Consumers of such a sketch (mg_containment_dev,
+ * mg_sketch_split, mg_sketch_device_ptrs, mg_sketch_download) make the main stream wait for it on the device;
+ * mg_sketch_resolve waits for that sketch only.  mg_sync does NOT wait for the stage-A streams. */
 int mg_stage_a_side_stream(int on);
+/* Resident k_sketch_reads workgroups per CU while on a stage-A stream: 0 = as many as LDS allows, default 2 (leaves
+ * issue slots to the small dependent kernels of a multi-GPU exchange running beside it). */
+int mg_stage_a_workgroups_per_cu(int n);
 int mg_stage_c_join(void);
 
 /* Per-kernel timing with HIP events on the library stream (bench.py's

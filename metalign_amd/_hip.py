@@ -26,7 +26,7 @@ EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async",
-    "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_c_join",
+    "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
@@ -496,7 +496,11 @@ class Hip:
         self._chk(self.lib.mg_stage_c_side_stream(ctypes.c_int(int(on))))
 
     def stage_a_side_stream(self, on=True):
+        """0 / False: main stream (waits for the stage-A streams); 1 / True or 2: which stage-A stream is next."""
         self._chk(self.lib.mg_stage_a_side_stream(ctypes.c_int(int(on))))
+
+    def stage_a_workgroups_per_cu(self, n):
+        self._chk(self.lib.mg_stage_a_workgroups_per_cu(ctypes.c_int(int(n))))
 
     def stage_c_join(self):
         self._chk(self.lib.mg_stage_c_join())

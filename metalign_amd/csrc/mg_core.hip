@@ -193,6 +193,7 @@ void mg_shutdown(void) {
   if (c.pend_pinned) (void)hipHostFree(c.pend_pinned);
   if (c.stream_c) { (void)hipStreamSynchronize(c.stream_c); (void)hipStreamDestroy(c.stream_c); }
   if (c.stream_a) { (void)hipStreamSynchronize(c.stream_a); (void)hipStreamDestroy(c.stream_a); }
+  if (c.stream_a2) { (void)hipStreamSynchronize(c.stream_a2); (void)hipStreamDestroy(c.stream_a2); }
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
   if (c.ev_c) (void)hipEventDestroy(c.ev_c);
   mg::prof_collect();
@@ -292,9 +293,14 @@ int mg_stage_c_side_stream(int on) {
 int mg_stage_a_side_stream(int on) {
   MG_REQUIRE_READY();
   mg::Context& c = ctx();
-  if (on && !c.stream_a) MG_HIP(hipStreamCreateWithFlags(&c.stream_a, hipStreamNonBlocking));
-  if (!on && c.a_side) MG_HIP(hipStreamSynchronize(c.stream_a));
-  c.a_side = on != 0;
+  if (on < 0 || on > 2) return fail(MG_ERR_ARG, "stage-A stream selector %d outside [0,2]", on);
+  if (on == 1 && !c.stream_a) MG_HIP(hipStreamCreateWithFlags(&c.stream_a, hipStreamNonBlocking));
+  if (on == 2 && !c.stream_a2) MG_HIP(hipStreamCreateWithFlags(&c.stream_a2, hipStreamNonBlocking));
+  if (!on && c.a_side) {
+    if (c.stream_a) MG_HIP(hipStreamSynchronize(c.stream_a));
+    if (c.stream_a2) MG_HIP(hipStreamSynchronize(c.stream_a2));
+  }
+  c.a_side = on;
   return MG_OK;
 }
 
@@ -323,6 +329,13 @@ int mg_event_synchronize(void* ev) {
 
 int mg_event_destroy(void* ev) {
   if (ev) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev));
+  return MG_OK;
+}
+
+int mg_stage_a_workgroups_per_cu(int n) {
+  MG_REQUIRE_READY();
+  if (n < 0 || n > 8) return fail(MG_ERR_ARG, "workgroups per CU %d outside [0,8]", n);
+  ctx().a_side_wg_per_cu = (unsigned)n;
   return MG_OK;
 }
 

@@ -37,8 +37,11 @@ struct Context {
   bool c_side = false;
   // optional stream for stage A (mg_stage_a_side_stream): the heavy sketch pipeline of the NEXT batch then runs
   // while the current batch's stage B / exchange / read-backs proceed on the main stream
-  hipStream_t stream_a = nullptr;
-  bool a_side = false;
+  hipStream_t stream_a = nullptr, stream_a2 = nullptr;  // two, so that consecutive batches' stage A can overlap
+  int a_side = 0;                                        // 0 off, 1 / 2 = which of them the next sketch goes to
+  unsigned a_side_wg_per_cu = 2;                         // k_sketch_reads workgroups per CU on those streams (0 = LDS limit)
+  bool is_stage_a(hipStream_t st) const { return st && (st == stream_a || st == stream_a2); }
+  const char* stage_a_prefix(hipStream_t st) const { return st == stream_a2 ? "b:" : "a:"; }
   const char* scratch_prefix = "";  // scratch buffers are per stream ("a:" while launching on stream_a)
   std::vector<hipEvent_t> ev_pool;   // recycled completion events of deferred sketches
   int num_cus = 256;

@@ -158,6 +158,40 @@ __device__ __forceinline__ uint32_t encode4(uint32_t x) {
   return c | (nz >> 5);
 }
 
+// Four code bytes -> four nibbles (bits 0..15).
+__device__ __forceinline__ uint32_t pack4(uint32_t c) {
+  const uint32_t p = (c | (c >> 4)) & 0x00ff00ffu;
+  return (p | (p >> 8)) & 0xffffu;
+}
+
+// A lane's view of its read in the nibble-packed LDS stage: eight codes per 32-bit word.  The read starts at any
+// nibble, so the window of eight codes is a funnel shift of two consecutive words (one v_alignbit per eight bases);
+// the word after next is requested a group ahead.  Positions advance in lock step across the wavefront, which makes
+// the group changes scalar branches and the nibble offsets scalar operands.
+struct CodeStream {
+  const uint32_t* d;   // word holding the read's first code
+  uint32_t sh;         // bit offset of that code in the word
+  uint32_t lo, hi, nxt, w;
+  uint32_t g;          // group (pos / 8) that w holds
+  __device__ __forceinline__ void open(const uint8_t* stage, uint32_t start) {
+    d = reinterpret_cast<const uint32_t*>(stage) + (start >> 3);
+    sh = (start & 7u) * 4u;
+    lo = d[0]; hi = d[1]; nxt = d[2];
+    w = __builtin_amdgcn_alignbit(hi, lo, sh);
+    g = 0;
+  }
+  // pos: wave-uniform, non-decreasing, advancing by at most one group between calls
+  __device__ __forceinline__ uint32_t at(uint32_t pos) {
+    if ((pos >> 3) != g) {
+      g = pos >> 3;
+      lo = hi; hi = nxt;
+      nxt = d[g + 2];  // may run past the tile into whatever follows in LDS: such positions are >= len and masked
+      w = __builtin_amdgcn_alignbit(hi, lo, sh);
+    }
+    return (w >> ((pos & 7u) * 4u)) & 15u;
+  }
+};
+
 // Code byte of one base read from HBM (the path for tiles that do not fit the LDS stage).
 __device__ __forceinline__ uint32_t encode1(uint32_t b) {
   uint32_t c;
@@ -166,19 +200,20 @@ __device__ __forceinline__ uint32_t encode1(uint32_t b) {
 
 // One lane walks its read two bases per iteration.  Straight-line body (invalid bases and
 // positions past the end are folded into the run counter instead of branches) so that the two
-// independent MurmurHash3 chains of an iteration interleave in the VALU.  CODES: src holds code bytes (encode4).
+// independent MurmurHash3 chains of an iteration interleave in the VALU.  CODES: src is the wavefront's
+// nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise src points at the read's
+// ASCII bases in HBM.
 template <int K, bool CODES>
-__device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uint32_t maxlen, uint64_t hmax,
-                                           CandSink& sink, uint64_t& kmers, int lane) {
+__device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen,
+                                           uint64_t hmax, CandSink& sink, uint64_t& kmers, int lane) {
   Roller<K> roll;
   roll.reset();
   uint32_t nk = 0;
-  const uint32_t last = len ? len - 1 : 0;
+  CodeStream cs;
+  if constexpr (CODES) cs.open(src, start);
   auto code_at = [&](uint32_t pos) -> uint32_t {
     if constexpr (CODES) {
-      // unconditional LDS read + select (a guarded read costs an exec-mask branch and a full wait at its join);
-      // the index is clamped to the read: ragged tiles never read outside the stage
-      const uint32_t c = src[pos < last ? pos : last];
+      const uint32_t c = cs.at(pos);
       return pos < len ? c : 4u;
     } else {
       if (pos >= len) return 4u;
@@ -194,10 +229,8 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uin
     roll.push(c);
     roll.run = c < 4u ? roll.run : 0;
   }
-  uint32_t c0 = code_at(warm), c1 = code_at(warm + 1);
   for (uint32_t pos = warm; pos < maxlen; pos += 2) {
-    const uint32_t n0 = code_at(pos + 2), n1 = code_at(pos + 3);  // next iteration's bases: the LDS latency hides
-                                                                   // behind this iteration's two hashes
+    const uint32_t c0 = code_at(pos), c1 = code_at(pos + 1);
     roll.push(c0);
     roll.run = c0 < 4u ? roll.run : 0;
     const uint64_t h0 = roll.hash();
@@ -209,8 +242,6 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t len, uin
     nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
     sink.offer(full0 && h0 <= hmax, h0, lane);
     sink.offer(full1 && h1 <= hmax, h1, lane);
-    c0 = n0;
-    c1 = n1;
   }
   kmers += nk;
 }
@@ -245,19 +276,21 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
     const uintptr_t a0 = a_first & ~(uintptr_t)15;
     const uint64_t shift = a_first - a0;
     const uint64_t nbytes = shift + (t_end - t_beg);
-    if (nbytes <= stage_bytes) {
-      // coalesced HBM -> LDS copy of the whole tile (16 B per lane per step), bases -> code bytes on the way
+    if (nbytes <= 2ull * stage_bytes) {
+      // coalesced HBM -> LDS copy of the whole tile (16 B per lane per step), bases -> 4-bit codes on the way:
+      // half a byte per base, 30 KB per workgroup instead of 52 — what lets a second grid of this kernel (the next
+      // batch's) and the small kernels of the other streams live beside it on the CU
       const uint4* g = reinterpret_cast<const uint4*>(a0);
-      uint4* s = reinterpret_cast<uint4*>(stage);
+      uint2* s = reinterpret_cast<uint2*>(stage);
       for (uint64_t i = lane; i * 16 < nbytes; i += 64) {
         const uint4 v = g[i];
-        s[i] = uint4{encode4(v.x), encode4(v.y), encode4(v.z), encode4(v.w)};
+        s[i] = uint2{pack4(encode4(v.x)) | (pack4(encode4(v.y)) << 16), pack4(encode4(v.z)) | (pack4(encode4(v.w)) << 16)};
       }
       wave_lds_sync();
-      walk_reads<K, true>(stage + shift + (beg - t_beg), (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      walk_reads<K, true>(stage, (uint32_t)(shift + (beg - t_beg)), (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
       wave_lds_sync();
     } else {
-      walk_reads<K, false>(bases + beg, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      walk_reads<K, false>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
     }
   }
   sink.flush(lane);
@@ -572,10 +605,11 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   unsigned per_cu = (unsigned)(160 * 1024 / (lds ? lds : 1));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
-  // On the stage-A stream (a pipelined job): two workgroups per CU instead of the LDS limit of three, so that the
-  // other streams' kernels (stage B, stage C, merges: 12-48 KB of LDS each) find room beside this persistent grid.
-  // Costs this kernel ~12 %, lets the rest of the pass overlap it: 0.99 -> 0.84 ms per pass with the exchange.
-  if (c.a_side && c.stream == c.stream_a && per_cu > 2) per_cu = 2;
+  // On a stage-A stream (a pipelined job) the caller may cap the resident workgroups per CU
+  // (mg_stage_a_workgroups_per_cu): a job whose pass has a long chain of small dependent kernels and host round
+  // trips beside this kernel (the multi-GPU exchange) wants them to get issue slots — two per CU cost this kernel
+  // ~12 % and took the exchange pass from 0.99 to 0.73 ms; a single-shard job leaves it at the LDS limit.
+  if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
@@ -760,7 +794,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   uint64_t cap = sk->redo.cap;
   if (candidates + 64 > cap) cap = candidates + 64;
   // (the rebuild is synchronous on the stream that built the sketch)
-  StreamGuard guard(sk->ev_stream ? sk->ev_stream : c.stream, (sk->ev_stream && sk->ev_stream == c.stream_a) ? "a:" : c.scratch_prefix);
+  StreamGuard guard(sk->ev_stream ? sk->ev_stream : c.stream, c.is_stage_a(sk->ev_stream) ? c.stage_a_prefix(sk->ev_stream) : c.scratch_prefix);
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
   return sketch_via_list(sk, sk->redo.bases, sk->redo.offsets, sk->redo.nreads, sk->redo.k, sk->redo.hmax, sk->redo.s, cap,
@@ -797,7 +831,8 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   if (hmax == kReservedHash) hmax = kReservedHash - 1;
   Context& c = ctx();
   // with mg_stage_a_side_stream on, the whole sketch pipeline of this call goes to the stage-A stream
-  StreamGuard guard(c.a_side ? c.stream_a : c.stream, c.a_side ? "a:" : c.scratch_prefix);
+  hipStream_t side = c.a_side == 2 ? c.stream_a2 : c.stream_a;
+  StreamGuard guard(c.a_side ? side : c.stream, c.a_side ? c.stage_a_prefix(side) : c.scratch_prefix);
   hipStream_t st = c.stream;
   std::unique_ptr<mg_sketch> sk(new mg_sketch());
   if (nreads == 0) {
@@ -825,11 +860,12 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   const uint64_t expect = (uint64_t)((double)nbases * frac);
   uint64_t cap = expect + expect / 4 + (1u << 16);
   if (cap > nbases + 64) cap = nbases + 64;
-  // LDS tile: 64 reads of average length, 12.5 % slack, 16-byte granules, at most 14 KiB per wavefront
+  // LDS tile: 64 reads of average length at half a byte per base, 12.5 % slack, 16-byte granules, at most
+  // 8 KiB (16 k bases) per wavefront
   uint64_t avg = (nbases + nreads - 1) / nreads;
-  uint64_t stage = ((64 * avg * 9 / 8 + 64 + 15) / 16) * 16;
-  if (stage < 2048) stage = 2048;
-  if (stage > 14336) stage = 14336;
+  uint64_t stage = (((64 * avg * 9 / 8 + 64) / 2 + 15) / 16) * 16;
+  if (stage < 1024) stage = 1024;
+  if (stage > 8192) stage = 8192;
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
 

@@ -17,6 +17,8 @@ Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "g
 The compute calls go through an `engine` (HipEngine below: libmetalign_hip.so on this rank's GPU).  The
 CPU tests substitute an oracle-backed engine to check the choreography under gloo; product code never does.
 """
+import os
+
 import numpy as np
 
 from . import _hip
@@ -184,10 +186,12 @@ class HipEngine:
                                h_hs=hip.pinned(2 * g, np.uint32), ev=hip.event())]
         return self._sets
 
-    def queue_pass(self, slot, k, hmax, s, ci, pct_id):
+    def queue_pass(self, slot, k, hmax, s, ci, pct_id, side=False):
         rs = self._result_sets()[slot]
         g, T = max(self.ngen_local, 1), self.ntax
-        sk = self.sketch_local_async(k, hmax, s)                                                  # stage A (main)
+        if side:  # stage A of consecutive passes on alternating streams: pass i+1's overlaps pass i's tail
+            self.hip.stage_a_side_stream(1 + (slot & 1))
+        sk = self.sketch_local_async(k, hmax, s)                                                  # stage A
         shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
                                            self.nref, self.ntax, pct_id)
         base = rs["d_acc"].ptr
@@ -416,14 +420,24 @@ class ShardJob:
             # Single shard: no exchange to hide, and overlapping the next pass's stage A with this pass's tail
             # measured no gain (it costs stage A what it saves).  What does pay is not letting the GPU wait for the
             # host between passes: pass i+1 is queued (same streams, behind pass i) BEFORE pass i is read back.
-            q = eng.queue_pass(0, self.k, self.hmax, self.s, self.ci, self.pct_id)
-            out = None
-            for i in range(nsteps):
-                nxt = eng.queue_pass((i + 1) & 1, self.k, self.hmax, self.s, self.ci, self.pct_id) if i + 1 < nsteps else None
-                sk, (hits, sizes), committed = eng.finish_pass(q, want_multimapped)
-                out = self._results(sk, hits, sizes, committed)
-                q = nxt
+            # ... and stage A of consecutive passes goes to two alternating streams at full occupancy: pass i+1's
+            # k_sketch_reads fills the GPU while pass i's sort / pack / stage B tail (small kernels) drains.
+            side = True
+            eng.hip.stage_a_workgroups_per_cu(0)
+            try:
+                q = eng.queue_pass(0, self.k, self.hmax, self.s, self.ci, self.pct_id, side)
+                out = None
+                for i in range(nsteps):
+                    nxt = (eng.queue_pass((i + 1) & 1, self.k, self.hmax, self.s, self.ci, self.pct_id, side)
+                           if i + 1 < nsteps else None)
+                    sk, (hits, sizes), committed = eng.finish_pass(q, want_multimapped)
+                    out = self._results(sk, hits, sizes, committed)
+                    q = nxt
+            finally:
+                if side:
+                    eng.hip.stage_a_side_stream(0)
             return out
+        eng.hip.stage_a_workgroups_per_cu(2)
         eng.hip.stage_a_side_stream(True)
         try:
             def front():  # what does not depend on the other ranks: stage A and stage C's map-only pass
