@@ -97,6 +97,8 @@ int mg_event_destroy(void* ev);
 int mg_host_alloc(void** h_ptr, uint64_t bytes);
 int mg_host_free(void* h_ptr);
 int mg_memcpy_d2h_async(void* h_pinned_dst, const void* d_src, uint64_t bytes);
+/* The other direction, from page-locked host memory (which must not be rewritten before the copy has run). */
+int mg_memcpy_h2d_async(void* d_dst, const void* h_pinned_src, uint64_t bytes);
 int mg_sync(void);
 /* Stage C on a second stream of the library (on != 0): its latency-bound pass then overlaps the small kernels
  * that finish stage A and run stage B instead of queueing behind them.  While enabled, every mg_profile_* launch
@@ -190,11 +192,22 @@ int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts,
 int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n,
                         uint64_t range_lo, uint64_t range_hi, uint64_t s, int any_truncated,
                         uint64_t bound, mg_sketch** out);
+/* The same merge queued without a host synchronisation: the handle comes back PENDING, like one from
+ * mg_sketch_reads_dev_async (mg_containment_dev consumes it on the device; mg_sketch_resolve settles it and reports
+ * a redo).  d_hashes / d_counts must stay valid until it is resolved.  Small inputs or inputs without a declared
+ * hash range are merged synchronously. */
+int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t range_lo,
+                              uint64_t range_hi, uint64_t s, int any_truncated, uint64_t bound, mg_sketch** out);
 /* Positions at which an ascending sketch crosses `nbounds` hash values: out_idx[i] = number of
  * entries with hash < bounds[i].  Used to cut a sketch into hash-range slices for the multi-GPU
  * exchange (rank r owns hashes in [bounds[r-1], bounds[r])). */
 int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbounds,
                     uint64_t* out_idx);
+/* The device-side form for a multi-GPU exchange that never stops for the host: entries per slice (nbounds + 1 of
+ * them) followed by truncated, last hash, n and the counting table's overflow count (non-zero: the sketch will be
+ * rebuilt at mg_sketch_resolve and these words are stale), as int64 words at d_out[0 .. nbounds + 4].  d_bounds:
+ * ascending hash bounds in device memory.  Works on a sketch whose finalisation is still deferred. */
+int mg_sketch_slice_words_dev(const mg_sketch* sk, const uint64_t* d_bounds, uint32_t nbounds, int64_t* d_out);
 /* Overrides the completeness bound mg_containment_dev uses for this sketch (a hash-range slice of a
  * truncated sample sketch is complete up to the SAMPLE's last hash, not its own): hashes above
  * `bound` are outside the sketch when `truncated` != 0. */
@@ -312,6 +325,9 @@ int mg_profile_acc_reset(uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first
 int mg_profile_map_launch(mg_profile* p);
 /* map[0] = outgoing bit if incoming is 0, map[1] = ... if incoming is 1. */
 int mg_profile_state_map(const mg_profile* p, uint8_t map[2]);
+/* The same three numbers (map[0], map[1], reads) written as int64 words to device memory behind the map-only pass,
+ * without a synchronisation (scripts/map_and_profile.py:229-232 carried state; see mg_profile_state_map). */
+int mg_profile_map_words_dev(mg_profile* p, int64_t* d_out3);
 uint64_t mg_profile_ngroups(const mg_profile* p);
 int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard,
                           uint64_t group_base, uint64_t* d_count,

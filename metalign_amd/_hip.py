@@ -25,11 +25,11 @@ MAX_K = 64
 EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
-    "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async",
+    "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
-    "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_split", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
+    "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
@@ -37,7 +37,7 @@ EXPORTS = [
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
-    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
+    "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
 ]
 
@@ -142,6 +142,11 @@ class PinnedArray:
         n = self.nbytes if nbytes is None else int(nbytes)
         self.hip._chk(self.hip.lib.mg_memcpy_d2h_async(_vp(self.ptr), _vp(d_ptr), ctypes.c_uint64(n)))
 
+    def push_async(self, d_ptr, nbytes=None):
+        """Queue this buffer -> device on the library stream; do not rewrite it before that has run."""
+        n = self.nbytes if nbytes is None else int(nbytes)
+        self.hip._chk(self.hip.lib.mg_memcpy_h2d_async(_vp(d_ptr), _vp(self.ptr), ctypes.c_uint64(n)))
+
     def free(self):
         if self.ptr:
             self.array = None
@@ -218,6 +223,11 @@ class Sketch:
             self.hip._chk(self.hip.lib.mg_sketch_split(self.handle, _np(b, ctypes.c_uint64), ctypes.c_uint32(len(b)),
                                                        _np(out, ctypes.c_uint64)))
         return [int(x) for x in out]
+
+    def slice_words_dev(self, d_bounds, nbounds, d_out):
+        """Slice sizes + (truncated, last hash, n, overflows) as int64 words on the device; no synchronisation."""
+        self.hip._chk(self.hip.lib.mg_sketch_slice_words_dev(self.handle, _vp(d_bounds), ctypes.c_uint32(int(nbounds)),
+                                                             _vp(d_out)))
 
     def set_bound(self, truncated, bound):
         self.hip._chk(self.hip.lib.mg_sketch_set_bound(self.handle, ctypes.c_int(int(truncated)),
@@ -368,6 +378,10 @@ class ProfileShard:
     def map_launch(self):
         """Queue the map-only pass now (no sync); state_map() / ngroups then only read two words back."""
         self.hip._chk(self.hip.lib.mg_profile_map_launch(self.handle))
+
+    def map_words_dev(self, d_out3):
+        """(map[0], map[1], reads) as int64 words on the device behind the map-only pass; no synchronisation."""
+        self.hip._chk(self.hip.lib.mg_profile_map_words_dev(self.handle, _vp(d_out3)))
 
     def state_map(self):
         m = (ctypes.c_uint8 * 2)()
@@ -579,6 +593,15 @@ class Hip:
                                                ctypes.c_uint64(int(range_lo)), ctypes.c_uint64(int(range_hi)),
                                                ctypes.c_uint64(s), ctypes.c_int(int(any_truncated)),
                                                ctypes.c_uint64(bound), ctypes.byref(h)))
+        return Sketch(self, h, k)
+
+    def sketch_merge_dev_async(self, d_hashes, d_counts, n, k, range_lo, range_hi, s=0, any_truncated=False, bound=U64_MAX):
+        """Queued without a host sync; the inputs must outlive Sketch.resolve()."""
+        h = _vp()
+        self._chk(self.lib.mg_sketch_merge_dev_async(_vp(d_hashes), _vp(d_counts), ctypes.c_uint64(n),
+                                                     ctypes.c_uint64(int(range_lo)), ctypes.c_uint64(int(range_hi)),
+                                                     ctypes.c_uint64(s), ctypes.c_int(int(any_truncated)),
+                                                     ctypes.c_uint64(bound), ctypes.byref(h)))
         return Sketch(self, h, k)
 
     def sketch_reads(self, bases, offsets, k, hmax=U64_MAX, s=0):

@@ -324,7 +324,7 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   mg_sketch* sk = const_cast<mg_sketch*>(q);  // the look-up index is a cache inside the handle
   // A sketch whose finalisation is deferred is consumed as it is when no completeness bound can apply (s = 0):
   // the kernels read its size and last hash from the device, nothing is synchronised here.
-  if (sk->pending && (sk->redo.s > 0 || sk->has_bound)) MG_TRY(sketch_resolve(sk, nullptr));
+  if (sk->pending && (sk->redo.s > 0 || sk->has_bound || sk->redo.use_bound)) MG_TRY(sketch_resolve(sk, nullptr));
   MG_TRY(sketch_wait(sk));  // built on another stream: this one waits for it on the device
   const uint64_t* d_meta = sk->pending ? sk->meta.as<uint64_t>() : nullptr;
   uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;

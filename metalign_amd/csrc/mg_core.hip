@@ -257,6 +257,13 @@ int mg_host_free(void* h_ptr) {
   return MG_OK;
 }
 
+int mg_memcpy_h2d_async(void* d_dst, const void* h_pinned_src, uint64_t bytes) {
+  MG_REQUIRE_READY();
+  if (bytes == 0) return MG_OK;
+  MG_HIP(hipMemcpyAsync(d_dst, h_pinned_src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  return MG_OK;
+}
+
 int mg_memcpy_d2h_async(void* h_pinned_dst, const void* d_src, uint64_t bytes) {
   MG_REQUIRE_READY();
   if (bytes == 0) return MG_OK;

@@ -198,6 +198,11 @@ struct mg_sketch {
     int k = 0;
     unsigned stage = 0;
     const mg_filter* filter = nullptr;
+    // a deferred MERGE (mg_sketch_merge_dev_async) is redone by the sorting merge over its own inputs instead
+    bool is_merge = false, use_bound = false;
+    const uint64_t* m_hashes = nullptr;
+    const uint32_t* m_counts = nullptr;
+    uint64_t m_n = 0, m_bound = 0;
   } redo;
   ~mg_sketch();
 };

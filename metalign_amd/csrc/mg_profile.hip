@@ -979,6 +979,29 @@ int mg_profile_map_launch(mg_profile* p) {
   return MG_OK;
 }
 
+// out[0], out[1] = the shard's composed state map, out[2] = its read count — from the totals the map-only pass left
+// on the device (tot == nullptr: an empty shard, the identity map).
+__global__ void k_map_words(const uint64_t* __restrict__ tot, long long* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const uint64_t m = tot ? tot[0] : 2ull;  // bit x = f(x); identity = 0b10
+  out[0] = (long long)(m & 1ull);
+  out[1] = (long long)((m >> 1) & 1ull);
+  out[2] = tot ? (long long)tot[1] : 0;
+}
+
+int mg_profile_map_words_dev(mg_profile* p, int64_t* d_out3) {
+  MG_REQUIRE_READY();
+  if (!p || !d_out3) return fail(MG_ERR_ARG, "null argument");
+  if (p->committed) return fail(MG_ERR_STATE, "the commit pass has overwritten the map-only totals");
+  MG_TRY(mg_profile_map_launch(p));
+  MG_TRY(mg_stage_c_join());  // the map-only pass runs on stage C's stream; the words are written on the main one
+  hipLaunchKernelGGL(k_map_words, dim3(1), dim3(64), 0, ctx().stream,
+                     p->nrecs ? (const uint64_t*)p->tot.as<uint64_t>() : (const uint64_t*)nullptr,
+                     reinterpret_cast<long long*>(d_out3));
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
 int mg_profile_state_map(const mg_profile* p, uint8_t map[2]) {
   if (!p || !map) return fail(MG_ERR_ARG, "null argument");
   MG_REQUIRE_READY();

@@ -27,6 +27,10 @@
 #include "mg_internal.h"
 #include "mg_kmer.h"
 
+// (defined with the merge entry points below; sketch_resolve redoes a deferred merge with it)
+static int merge_via_sort(mg_sketch* sk, const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
+                          int any_truncated, uint64_t bound);
+
 namespace mg {
 
 constexpr int kWavesPerBlock = 4;
@@ -780,8 +784,19 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   if (sk->pend_slot >= 0 && c.pend_owner[sk->pend_slot] == sk) c.pend_owner[sk->pend_slot] = nullptr;
   sk->pend_slot = -1;
   if (overflows == 0) {
-    const double r = 2.0 * (double)runs / sk->expect;
-    distinct_hint = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
+    if (!sk->redo.is_merge) {
+      const double r = 2.0 * (double)runs / sk->expect;
+      distinct_hint = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
+    }
+    return MG_OK;
+  }
+  if (sk->redo.is_merge) {  // a pair outside the declared range, or a full bucket: the general (sorting) merge
+    if (rebuilt) *rebuilt = 1;
+    sk->index.release();
+    sk->hashes.release();
+    sk->counts.release();
+    MG_TRY(::merge_via_sort(sk, sk->redo.m_hashes, sk->redo.m_counts, sk->redo.m_n, sk->redo.s, sk->redo.use_bound ? 1 : 0,
+                          sk->redo.m_bound));
     return MG_OK;
   }
   // a bucket ran out of slots (more distinct hashes than the hint allowed for): size for the worst case next
@@ -1030,6 +1045,56 @@ int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint
   return MG_OK;
 }
 
+// The same merge without a host synchronisation: the table path is queued and the sketch is handed back pending
+// (its size / last hash / overflow counter land in pinned words behind an event), exactly like a deferred read
+// sketch.  The inputs must stay alive until mg_sketch_resolve (they are what a redo reads).  Inputs the table path
+// does not take (few pairs, no declared range) are merged synchronously.
+int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t range_lo,
+                              uint64_t range_hi, uint64_t s, int any_truncated, uint64_t bound, mg_sketch** out) {
+  MG_REQUIRE_READY();
+  if (!out) return fail(MG_ERR_ARG, "null out handle");
+  *out = nullptr;
+  if (n > 0 && (!d_hashes || !d_counts)) return fail(MG_ERR_ARG, "null device input");
+  TablePlan tp;
+  if (!(n >= 32768 && range_hi >= range_lo && !getenv("MG_DEBUG_FORCE_LIST") && plan_table(range_lo, range_hi, (double)n, tp)))
+    return mg_sketch_merge_dev(d_hashes, d_counts, n, range_lo, range_hi, s, any_truncated, bound, out);
+  std::unique_ptr<mg_sketch> sk(new mg_sketch());
+  Context& cc = ctx();
+  hipStream_t st = cc.stream;
+  unsigned long long* t_counters = nullptr;  // cleared together with the table
+  MG_TRY(alloc_table(tp, &t_counters));
+  {
+    ProfScope ps("merge_insert");
+    hipLaunchKernelGGL(k_table_insert_pairs, dim3(grid_for(n, 256, (unsigned)cc.num_cus * 8)), dim3(256), 0, st, d_hashes,
+                       d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, t_counters);
+    MG_HIP(hipGetLastError());
+  }
+  const unsigned slot = cc.pend_next++ & 7u;
+  if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
+  MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
+  uint64_t* sk_meta = sk->meta.as<uint64_t>();
+  MG_TRY(table_pack(tp, sk.get(), sk_meta));
+  sk->h_meta = cc.pend_pinned + 8 * slot;
+  hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s,
+                     (uint32_t)(any_truncated ? 1 : 0), bound, (const unsigned long long*)t_counters, sk->h_meta);
+  MG_HIP(hipGetLastError());
+  sk->ev = take_event();
+  if (sk->ev) { MG_HIP(hipEventRecord(sk->ev, st)); sk->ev_stream = st; }
+  sk->pending = true;
+  sk->pend_slot = (int)slot;
+  cc.pend_owner[slot] = sk.get();
+  sk->n_bound = n < tp.slots ? n : tp.slots;
+  if (s > 0 && s < sk->n_bound) sk->n_bound = s;
+  sk->hmax = range_hi;
+  sk->expect = (double)(n ? n : 1);
+  sk->redo.is_merge = true;
+  sk->redo.use_bound = any_truncated != 0;
+  sk->redo.s = s;
+  sk->redo.m_hashes = d_hashes; sk->redo.m_counts = d_counts; sk->redo.m_n = n; sk->redo.m_bound = bound;
+  *out = sk.release();
+  return MG_OK;
+}
+
 int mg_sketch_from_pairs_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
                              int any_truncated, uint64_t bound, mg_sketch** out) {
   // no declared range: range_hi < range_lo selects the general (sorting) merge
@@ -1052,6 +1117,47 @@ int mg_sketch_split(const mg_sketch* sk, const uint64_t* bounds, uint32_t nbound
   MG_HIP(hipGetLastError());
   MG_HIP(hipMemcpyAsync(out_idx, d_io + nbounds, nbounds * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
+  return MG_OK;
+}
+
+// Slice sizes of a sketch cut at ascending hash bounds, and its size / last hash / truncation / table-overflow
+// count, written to device words — also for a sketch whose finalisation is still deferred (nothing is synchronised):
+// out[0 .. nbounds] = entries per slice, then truncated, last hash, n, overflows.
+__global__ __launch_bounds__(256) void k_slice_words(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ meta,
+                                                     uint64_t n_host, uint64_t last_host, uint32_t trunc_host,
+                                                     const uint64_t* __restrict__ bounds, uint32_t nbounds,
+                                                     long long* __restrict__ out) {
+  __shared__ uint64_t cuts[4098];
+  const uint64_t n = meta ? meta[1] : n_host;
+  for (uint32_t i = threadIdx.x; i < nbounds; i += blockDim.x) {
+    const uint64_t key = bounds[i];
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (hashes[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    cuts[i + 1] = lo;
+  }
+  if (threadIdx.x == 0) { cuts[0] = 0; cuts[nbounds + 1] = n; }
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q <= nbounds; q += blockDim.x) out[q] = (long long)(cuts[q + 1] - cuts[q]);
+  if (threadIdx.x == 0) {
+    out[nbounds + 1] = meta ? (long long)meta[3] : (long long)trunc_host;
+    out[nbounds + 2] = (long long)(meta ? meta[2] : last_host);
+    out[nbounds + 3] = (long long)n;
+    out[nbounds + 4] = meta ? (long long)meta[6] : 0;
+  }
+}
+
+int mg_sketch_slice_words_dev(const mg_sketch* sk, const uint64_t* d_bounds, uint32_t nbounds, int64_t* d_out) {
+  MG_REQUIRE_READY();
+  if (!sk || !d_out || (nbounds && !d_bounds)) return fail(MG_ERR_ARG, "null argument");
+  if (nbounds > 4096) return fail(MG_ERR_ARG, "too many slice bounds");
+  MG_TRY(sketch_wait(sk));  // built on another stream: this one waits for it on the device
+  hipLaunchKernelGGL(k_slice_words, dim3(1), dim3(256), 0, ctx().stream, sk->hashes.as<uint64_t>(),
+                     sk->pending ? sk->meta.as<uint64_t>() : (const uint64_t*)nullptr, sk->n, sk->n ? sk->last_hash : 0,
+                     (uint32_t)sk->truncated, d_bounds, nbounds, reinterpret_cast<long long*>(d_out));
+  MG_HIP(hipGetLastError());
   return MG_OK;
 }
 

@@ -363,13 +363,15 @@ class ShardJob:
             committed = eng.profile_commit(incoming, first_shard, group_base, self._want_mm)
         for wk in inflight:
             wk.wait()
-        sk.free()
         # completeness: a source truncated at its s-th hash knows nothing above it
         lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
         complete_to = min(lasts) if lasts else U64_MAX
         any_trunc = bool(lasts)
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1] - 1
         merged = eng.merge_sketches(rh, rc, self.k, 0, any_trunc, complete_to, (lo, hi))
+        # the sketch's buffers were the all-to-all's send buffers: they go back to the pool only now that the merge
+        # (which read what the all-to-all delivered, and synchronised) is done
+        sk.free()
         if self.s or any_trunc:
             merged = self._bottom_s(merged, any_trunc)
         return merged, committed
@@ -437,6 +439,8 @@ class ShardJob:
                 if side:
                     eng.hip.stage_a_side_stream(0)
             return out
+        if hasattr(eng, "queue_pass") and os.environ.get("MG_EXCHANGE_PIPELINE", "1") != "0":
+            return self._run_exchange_pipelined(nsteps, want_multimapped)
         eng.hip.stage_a_workgroups_per_cu(2)
         eng.hip.stage_a_side_stream(True)
         try:
@@ -451,6 +455,171 @@ class ShardJob:
             return out
         finally:
             eng.hip.stage_a_side_stream(False)
+
+    # ---- the exchange path with several passes in flight -------------------------------------------------------
+    # A pass with an exchange is a chain: local sketch -> [sync] split -> all-gather -> [sync] all-to-all -> merge
+    # [sync] -> stage B + stage-C commit -> [sync] all-reduce -> [sync] results.  Run one pass at a time and every
+    # one of those waits — each a collective's latency on a real node — is dead time on the host, and the pass rate
+    # is 1 / (length of the chain) however fast the kernels are.  Passes are independent of each other, so the chain
+    # is cut into four phases that each START by waiting for what the previous phase of the same pass queued and END
+    # by queueing asynchronous work; a tick runs phase D of pass t-3, C of t-2, A of t, B of t-1 (the same order on
+    # every rank, so the collectives match up), stage A of passes t+1 and t+2 is already queued on the stage-A
+    # stream.  By the time a phase looks at its inputs a whole tick has passed: the waits find finished work.
+    def _run_exchange_pipelined(self, nsteps, want_multimapped):
+        eng, t, dist, W = self.engine, self.torch, self.dist, self.world
+        hip = eng.hip
+        G, T = self.G, self.T
+        g = max(eng.ngen_local, 1)
+        NSLOT, NW = 4, W + 7  # per-rank words: W slice sizes | truncated | last hash | n | overflows | m0 | m1 | reads
+        nred = 2 * G + 2 * T + W * T + 3
+        if not hasattr(self, "_xslots"):
+            self._xslots = [dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
+                                 h_hs=hip.pinned(2 * g, np.uint32), h_words=hip.pinned(W * NW, np.int64),
+                                 h_red=hip.pinned(nred, np.int64), h_red_in=hip.pinned(nred, np.int64),
+                                 d_red=hip.empty(nred, np.int64), ev=hip.event()) for _ in range(NSLOT)]
+            self._d_bounds = hip.array(np.asarray(self.bounds[1:W] if W > 1 else [0], dtype=np.uint64))
+        # four of the hashing kernel's five workgroups per CU: with no host wait left in the chain the small kernels
+        # need fewer issue slots than on the one-pass-at-a-time path (two), but not none (measured on one GPU with
+        # every collective in the path: 2 -> 0.735 ms per pass, 3 -> 0.68, 4 -> 0.665, 5 -> 0.71; alternating two
+        # stage-A streams here: worse at every setting)
+        hip.stage_a_workgroups_per_cu(4)
+        hip.stage_a_side_stream(True)
+
+        def front():
+            return dict(sk=eng.sketch_local_async(self.k, self.hmax, self.s), shard=eng.new_shard_async(self.pct_id))
+
+        def gather_words(P, word_t):
+            rs = P["rs"]
+            words = t.empty((W, NW), dtype=t.int64, device=self.device)
+            dist.all_gather_into_tensor(words, word_t)
+            P["words_t"] = (words, word_t)
+            rs["h_words"].fetch_async(words.data_ptr())
+            rs["ev"].record()
+
+        def phase_a(P, slot):  # this rank's words, assembled on the device, into the all-gather: no host wait at all
+            P["rs"] = self._xslots[slot]
+            word_t = t.empty(NW, dtype=t.int64, device=self.device)
+            P["sk"].slice_words_dev(self._d_bounds.ptr, W - 1, word_t.data_ptr())
+            P["shard"].map_words_dev(word_t.data_ptr() + 8 * (W + 4))
+            gather_words(P, word_t)
+
+        def read_words(P):
+            rs = P["rs"]
+            rs["ev"].synchronize()
+            words = rs["h_words"].array.reshape(W, NW).tolist()
+            P["words_t"] = None
+            return words
+
+        def phase_b(P):  # all-to-all of the slices, stage-C commit, merge, stage B
+            rs = P["rs"]
+            words = read_words(P)
+            sk = P["sk"]
+            if any(w[W + 3] for w in words):
+                # some rank's counting table overflowed (a sample unlike the previous one): its words are stale.  Every
+                # rank sees the same flags, so every rank repeats the all-gather once that sketch has been rebuilt.
+                self.words_redone = getattr(self, "words_redone", 0) + 1
+                sk.resolve()
+                n = sk.size
+                cuts = [0] + eng.split_sketch(sk, self.bounds[1:W]) + [n]
+                last = sk.last_hash
+                word = ([cuts[q + 1] - cuts[q] for q in range(W)]
+                        + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, 0] + words[self.rank][W + 4:])
+                gather_words(P, t.as_tensor(np.asarray(word, dtype=np.int64), device=self.device))
+                words = read_words(P)
+            sc = [int(x) for x in words[self.rank][:W]]
+            recv_counts = [words[p][self.rank] for p in range(W)]
+            h, c = eng.export_sketch(sk)
+            rh, rc, inflight = self._all_to_all(h, c, sc, recv_counts)
+            maps = [(w[W + 4], w[W + 5]) for w in words]
+            incoming = compose_incoming(maps, self.rank)
+            group_base = int(sum(w[W + 6] for w in words[: self.rank]))
+            first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
+            base = rs["d_acc"].ptr
+            P["shard"].commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8,
+                              reset=True)
+            for wk in inflight:
+                wk.wait()
+            lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
+            complete_to = min(lasts) if lasts else U64_MAX
+            any_trunc = bool(lasts)
+            lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1] - 1
+            P["keep"] = (rh, rc)
+            # queued, not waited for: the merged slice is consumed on the device by stage B; phase C settles it
+            merged = hip.sketch_merge_dev_async(rh.data_ptr(), rc.data_ptr(), int(rh.numel()), self.k, lo, hi, 0,
+                                                any_trunc, complete_to)
+            if self.s or any_trunc:
+                merged = self._bottom_s(merged, any_trunc)
+            P["merged"] = merged
+            hip.containment_dev(merged, eng.table, self.ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
+            hip.stage_c_join()
+            rs["h_acc"].fetch_async(base)
+            rs["ev"].record()
+
+        def phase_c(P):  # this rank's counts -> THE all-reduce
+            rs = P["rs"]
+            rs["ev"].synchronize()
+            merged = P["merged"]
+            P["sk"].free()  # its buffers were the all-to-all's send buffers: back to the pool only now
+            if merged.resolve():
+                hip.sync()
+                hip.containment_dev(merged, eng.table, self.ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
+                hip.sync()
+            hs, acc = rs["h_hs"].array, rs["h_acc"].array
+            buf = rs["h_red_in"].array
+            buf[:] = 0
+            buf[:G] = hs[:G]
+            buf[G:2 * G] = hs[g:g + G]
+            buf[-3] = merged.size
+            buf[2 * G:2 * G + 2 * T] = acc[:2 * T].view(np.int64)
+            o = 2 * G + 2 * T + self.rank * T
+            buf[o:o + T] = acc[2 * T:3 * T].view(np.int64)
+            buf[-2:] = acc[3 * T:].view(np.int64)
+            P["mm"] = P["shard"].multimapped() if want_multimapped else None
+            P["shard"].free()
+            merged.free()
+            P["keep"] = None
+            rs["h_red_in"].push_async(rs["d_red"].ptr)
+            tb = t.as_tensor(_CudaView(rs["d_red"].ptr, nred, "<i8"), device="cuda")
+            dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+            P["tb"] = tb
+            rs["h_red"].fetch_async(rs["d_red"].ptr)
+            rs["ev"].record()
+
+        def phase_d(P):
+            rs = P["rs"]
+            rs["ev"].synchronize()
+            buf = rs["h_red"].array.copy()
+            P["tb"] = None
+            hits, sizes = buf[:G].astype(np.uint32), buf[G:2 * G].astype(np.uint32)
+            count, bases = buf[2 * G:2 * G + T].view(np.uint64), buf[2 * G + T:2 * G + 2 * T].view(np.uint64)
+            first = buf[2 * G + 2 * T:2 * G + 2 * T + W * T].view(np.uint64).reshape(W, T).min(axis=0)
+            scalars = buf[-2:].view(np.uint64)
+            out = dict(hits=hits, sizes=sizes, count=count, bases=bases, first_seen=first, tot_rds=int(scalars[0]),
+                       n_ambig=int(scalars[1]), sketch_size=int(buf[-3]), multimapped=P["mm"])
+            ci_vals = hits / np.maximum(sizes, 1)
+            out["containment"] = ci_vals
+            out["top_ok"] = bool(ci_vals.max() > 0.5) if len(ci_vals) else None
+            return out
+
+        try:
+            AHEAD = 2
+            fronts = [front() for _ in range(min(AHEAD, nsteps))]
+            passes, out = {}, None
+            for tick in range(nsteps + 3):
+                if 0 <= tick - 3 < nsteps:
+                    out = phase_d(passes.pop(tick - 3))
+                if 0 <= tick - 2 < nsteps:
+                    phase_c(passes[tick - 2])
+                if tick < nsteps:
+                    passes[tick] = P = fronts.pop(0)
+                    phase_a(P, tick % NSLOT)
+                    if tick + AHEAD < nsteps:
+                        fronts.append(front())
+                if 0 <= tick - 1 < nsteps:
+                    phase_b(passes[tick - 1])
+            return out
+        finally:
+            hip.stage_a_side_stream(False)
 
     def step(self, want_multimapped=False, _sketch=None):
         """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank).

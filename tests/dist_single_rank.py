@@ -28,7 +28,7 @@ gb, go = synth.make_genomes(60, 20000)
 rb, ro, src = synth.make_reads(gb, go, 80000, npresent=9)
 recs = synth.make_alignment_records(src + 1, 61)
 ref2tax = np.arange(61, dtype=np.uint32)
-k, n = 21, 200
+k, n = 21, (1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200)  # forced-overflow run: enough distinct hashes to fill a minimum-size table
 dbh, dbo = hip.sketch_genomes(gb, go, k, n)
 job = ShardJob(hip, dist, 0, 1, k=k, always_exchange=True)
 job.load(rb, ro, recs, ref2tax, dbh, dbo)
@@ -50,6 +50,8 @@ for idx, got in enumerate(outs):
     off, tax, hl, rd = got["multimapped"]
     assert np.array_equal(off, want["mm_offsets"]) and np.array_equal(tax, want["mm_tax"])
     assert np.array_equal(hl, want["mm_hitlen"]) and np.array_equal(rd, want["mm_read"])
+if os.environ.get("MG_DEBUG_DISTINCT_HINT"):  # the forced-overflow run must have taken the repeat-the-all-gather path
+    assert getattr(job, "words_redone", 0) >= 4, getattr(job, "words_redone", 0)
 dist.barrier()
 dist.destroy_process_group()
 print("dist-single-rank ok")

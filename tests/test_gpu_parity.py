@@ -130,6 +130,49 @@ def test_sketch_merge_equals_single_pass(hip, oracle_lib):
         assert merged.truncated == otrunc
 
 
+def test_deferred_merge_equals_merge(hip):
+    """mg_sketch_merge_dev_async (nothing synchronised, handle pending) == mg_sketch_merge_dev == numpy: the table
+    path, its consumption by stage B while pending, and the redo when a pair lies outside the declared hash range."""
+    rng = np.random.default_rng(5)
+    lo, hi = 1 << 40, (1 << 58) - 1
+    n = 300_000
+    pool = rng.integers(lo, hi, size=120_000, dtype=np.uint64)
+    h = pool[rng.integers(0, len(pool), size=n)]
+    c = rng.integers(1, 5, size=n).astype(np.uint32)
+    want_h, inv = np.unique(h, return_inverse=True)
+    want_c = np.bincount(inv, weights=c).astype(np.uint32)
+    d_h, d_c = hip.array(h), hip.array(c)
+    # a small table to run stage B against while the merged sketch is still pending
+    G, per = 40, 500
+    dbh = np.sort(rng.choice(want_h, size=(G, per)), axis=1).reshape(-1)
+    dbo = np.arange(G + 1, dtype=np.uint64) * np.uint64(per)
+    table = hip.upload_table(dbh, dbo)
+    d_hits, d_sizes = hip.empty(G, np.uint32), hip.empty(G, np.uint32)
+    for declared, redo in (((lo, hi), False), ((lo, (lo + hi) // 2), True)):
+        sk = hip.sketch_merge_dev_async(d_h.ptr, d_c.ptr, n, 21, declared[0], declared[1])
+        hip.containment_dev(sk, table, 2, d_hits.ptr, d_sizes.ptr)  # consumed on the device, nothing settled yet
+        rebuilt = sk.resolve()
+        assert bool(rebuilt) == redo
+        if rebuilt:  # what was derived from the pending handle is stale by contract: again
+            hip.containment_dev(sk, table, 2, d_hits.ptr, d_sizes.ptr)
+        hip.sync()
+        gh, gc = sk.download()
+        assert np.array_equal(gh, want_h) and np.array_equal(gc, want_c)
+        good = set(want_h[want_c >= 2].tolist())
+        hits = d_hits.download()
+        for g in (0, 7, 39):
+            assert hits[g] == len({x for x in dbh[g * per:(g + 1) * per].tolist() if x in good} ) or \
+                hits[g] == sum(1 for x in dbh[g * per:(g + 1) * per].tolist() if x in good)
+        ref = hip.sketch_merge_dev(d_h.ptr, d_c.ptr, n, 21, declared[0], declared[1])
+        rh, rc = ref.download()
+        assert np.array_equal(rh, gh) and np.array_equal(rc, gc)
+        ref.free()
+        sk.free()
+    for b in (d_h, d_c, d_hits, d_sizes):
+        b.free()
+    table.free()
+
+
 @pytest.mark.parametrize("name,idx,run", sc.hand_cases(), ids=lambda v: str(v) if not isinstance(v, dict) else "")
 def test_stage_c_hand_cases_hip(hip, name, idx, run, monkeypatch, tmp_path):
     sc.check_hand_case(name, run, None, monkeypatch, tmp_path)

@@ -129,3 +129,9 @@ def test_exchange_path_on_one_gpu_under_rccl():
     r = subprocess.run([sys.executable, os.path.join(here, "dist_single_rank.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    # the same with stage A's counting table forced to overflow on every pass: the words a rank publishes from its
+    # pending sketch are then stale, every rank sees the flag and the all-gather is repeated after the rebuild
+    env["MG_DEBUG_DISTINCT_HINT"] = "0.0005"
+    r = subprocess.run([sys.executable, os.path.join(here, "dist_single_rank.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
