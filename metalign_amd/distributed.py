@@ -235,6 +235,121 @@ class HipEngine:
         return self.profile_commit_finish(want_multimapped)
 
 
+    # ---- the device side of ShardJob._run_exchange_pipelined (four passes in flight): every method queues work and
+    # returns, except the x_wait_* / x_collect ones, which wait for ONE event recorded a tick earlier.
+    def x_setup(self, W, G, T, bounds, nslot):
+        hip, g = self.hip, max(self.ngen_local, 1)
+        self._xW, self._xNW, self._xnred = W, W + 7, 2 * G + 2 * T + W * T + 3
+        if not hasattr(self, "_xs"):
+            self._xs = [dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
+                             h_hs=hip.pinned(2 * g, np.uint32), h_words=hip.pinned(W * self._xNW, np.int64),
+                             h_red=hip.pinned(self._xnred, np.int64), h_red_in=hip.pinned(self._xnred, np.int64),
+                             d_red=hip.empty(self._xnred, np.int64), ev=hip.event()) for _ in range(nslot)]
+            self._xbounds = hip.array(np.asarray(bounds[1:W] if W > 1 else [0], dtype=np.uint64))
+
+    def x_begin(self):
+        # four of the hashing kernel's five workgroups per CU: with no host wait left in the chain the small kernels
+        # need fewer issue slots than on the one-pass-at-a-time path (two), but not none (measured on one GPU with
+        # every collective in the path: 2 -> 0.735 ms per pass, 3 -> 0.68, 4 -> 0.665, 5 -> 0.71; alternating two
+        # stage-A streams here: worse at every setting)
+        self.hip.stage_a_workgroups_per_cu(4)
+        self.hip.stage_a_side_stream(True)
+
+    def x_end(self):
+        self.hip.stage_a_side_stream(False)
+
+    def x_front(self, k, hmax, s, pct_id):
+        return dict(sk=self.sketch_local_async(k, hmax, s), shard=self.new_shard_async(pct_id))
+
+    def x_words(self, P, slot):
+        """This rank's words, assembled on the device from the still pending sketch and the map-only pass."""
+        P["rs"] = self._xs[slot]
+        W, t = self._xW, self.torch
+        word_t = t.empty(self._xNW, dtype=t.int64, device="cuda")
+        P["sk"].slice_words_dev(self._xbounds.ptr, W - 1, word_t.data_ptr())
+        P["shard"].map_words_dev(word_t.data_ptr() + 8 * (W + 4))
+        return word_t
+
+    def x_redo_words(self, P, bounds, tail):
+        """Host path, after a table overflow made the published words stale: settle the sketch and cut it again."""
+        sk, W = P["sk"], self._xW
+        sk.resolve()
+        n = sk.size
+        cuts = [0] + self.split_sketch(sk, bounds[1:W]) + [n]
+        last = sk.last_hash
+        word = ([cuts[q + 1] - cuts[q] for q in range(W)]
+                + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, 0] + list(tail))
+        return self.torch.as_tensor(np.asarray(word, dtype=np.int64), device="cuda")
+
+    def x_fetch_words(self, P, words_t, hold):
+        rs = P["rs"]
+        P["hold"] = (words_t, hold)
+        rs["h_words"].fetch_async(words_t.data_ptr())
+        rs["ev"].record()
+
+    def x_wait_words(self, P):
+        rs = P["rs"]
+        rs["ev"].synchronize()
+        P["hold"] = None
+        return rs["h_words"].array.reshape(self._xW, self._xNW).tolist()
+
+    def x_commit(self, P, incoming, first_shard, group_base):
+        T, base = self.ntax, P["rs"]["d_acc"].ptr
+        P["shard"].commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8,
+                          reset=True)
+
+    def x_merge(self, P, rh, rc, k, lo, hi, any_trunc, bound):
+        P["keep"] = (rh, rc)  # a deferred merge reads its inputs again if it has to be redone
+        return self.hip.sketch_merge_dev_async(rh.data_ptr(), rc.data_ptr(), int(rh.numel()), k, lo, hi, 0, any_trunc, bound)
+
+    def x_stage_b(self, P, merged, ci):
+        rs, g = P["rs"], max(self.ngen_local, 1)
+        P["merged"] = merged
+        self.hip.containment_dev(merged, self.table, ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
+        self.hip.stage_c_join()
+        rs["h_acc"].fetch_async(rs["d_acc"].ptr)
+        rs["ev"].record()
+
+    def x_collect(self, P, ci, want_multimapped):
+        rs, g, T, G = P["rs"], max(self.ngen_local, 1), self.ntax, self.ngen_local
+        rs["ev"].synchronize()
+        merged = P["merged"]
+        P["sk"].free()  # its buffers were the all-to-all's send buffers: back to the pool only now
+        if merged.resolve():
+            self.hip.sync()
+            self.hip.containment_dev(merged, self.table, ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
+            self.hip.sync()
+        hs, acc = rs["h_hs"].array, rs["h_acc"].array
+        mm = P["shard"].multimapped() if want_multimapped else None
+        qn = merged.size
+        P["shard"].free()
+        merged.free()
+        P["keep"] = None
+        return hs[:G], hs[g:g + G], acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm, qn
+
+    def x_reduce_buffer(self, P):
+        buf = P["rs"]["h_red_in"].array
+        buf[:] = 0
+        return buf
+
+    def x_reduce_tensor(self, P):
+        rs = P["rs"]
+        rs["h_red_in"].push_async(rs["d_red"].ptr)
+        return self.torch.as_tensor(_CudaView(rs["d_red"].ptr, self._xnred, "<i8"), device="cuda")
+
+    def x_fetch_reduced(self, P, tb):
+        rs = P["rs"]
+        P["hold"] = tb
+        rs["h_red"].fetch_async(rs["d_red"].ptr)
+        rs["ev"].record()
+
+    def x_wait_reduced(self, P):
+        rs = P["rs"]
+        rs["ev"].synchronize()
+        P["hold"] = None
+        return rs["h_red"].array.copy()
+
+
 class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 
@@ -405,23 +520,21 @@ class ShardJob:
         return merged
 
     def run(self, nsteps, want_multimapped=False):
-        """`nsteps` passes over the resident batch, software-pipelined: stage A of pass i+1 (the dominant kernel) is
-        queued on the library's stage-A stream BEFORE pass i is finished (the exchange, stage B, the read-backs, all
-        on the main stream), so the GPU does not idle through the collectives' latency (1.34 -> 0.87 ms per pass
-        with every collective in the path on one GPU).  Every pass is complete when this returns; the last pass's
-        results are returned."""
+        """`nsteps` passes over the resident batch with several passes in flight (see the two schedules below).  Every
+        pass is complete when this returns; the last pass's results are returned."""
         eng = self.engine
         if nsteps < 1:
             return None
+        if self.exchange and hasattr(eng, "x_front") and os.environ.get("MG_EXCHANGE_PIPELINE", "1") != "0":
+            return self._run_exchange_pipelined(nsteps, want_multimapped)
         if not hasattr(eng, "sketch_local_async"):
             out = None
             for _ in range(nsteps):
                 out = self.step(want_multimapped)
             return out
         if not self.exchange:
-            # Single shard: no exchange to hide, and overlapping the next pass's stage A with this pass's tail
-            # measured no gain (it costs stage A what it saves).  What does pay is not letting the GPU wait for the
-            # host between passes: pass i+1 is queued (same streams, behind pass i) BEFORE pass i is read back.
+            # Single shard: no exchange to hide.  The GPU is not left waiting for the host between passes: pass i+1 is
+            # queued (behind pass i) BEFORE pass i is read back ...
             # ... and stage A of consecutive passes goes to two alternating streams at full occupancy: pass i+1's
             # k_sketch_reads fills the GPU while pass i's sort / pack / stage B tail (small kernels) drains.
             side = True
@@ -439,8 +552,7 @@ class ShardJob:
                 if side:
                     eng.hip.stage_a_side_stream(0)
             return out
-        if hasattr(eng, "queue_pass") and os.environ.get("MG_EXCHANGE_PIPELINE", "1") != "0":
-            return self._run_exchange_pipelined(nsteps, want_multimapped)
+        # (MG_EXCHANGE_PIPELINE=0: the older schedule, one pass at a time with stage A a pass ahead)
         eng.hip.stage_a_workgroups_per_cu(2)
         eng.hip.stage_a_side_stream(True)
         try:
@@ -467,129 +579,64 @@ class ShardJob:
     # stream.  By the time a phase looks at its inputs a whole tick has passed: the waits find finished work.
     def _run_exchange_pipelined(self, nsteps, want_multimapped):
         eng, t, dist, W = self.engine, self.torch, self.dist, self.world
-        hip = eng.hip
         G, T = self.G, self.T
-        g = max(eng.ngen_local, 1)
         NSLOT, NW = 4, W + 7  # per-rank words: W slice sizes | truncated | last hash | n | overflows | m0 | m1 | reads
-        nred = 2 * G + 2 * T + W * T + 3
-        if not hasattr(self, "_xslots"):
-            self._xslots = [dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
-                                 h_hs=hip.pinned(2 * g, np.uint32), h_words=hip.pinned(W * NW, np.int64),
-                                 h_red=hip.pinned(nred, np.int64), h_red_in=hip.pinned(nred, np.int64),
-                                 d_red=hip.empty(nred, np.int64), ev=hip.event()) for _ in range(NSLOT)]
-            self._d_bounds = hip.array(np.asarray(self.bounds[1:W] if W > 1 else [0], dtype=np.uint64))
-        # four of the hashing kernel's five workgroups per CU: with no host wait left in the chain the small kernels
-        # need fewer issue slots than on the one-pass-at-a-time path (two), but not none (measured on one GPU with
-        # every collective in the path: 2 -> 0.735 ms per pass, 3 -> 0.68, 4 -> 0.665, 5 -> 0.71; alternating two
-        # stage-A streams here: worse at every setting)
-        hip.stage_a_workgroups_per_cu(4)
-        hip.stage_a_side_stream(True)
-
-        def front():
-            return dict(sk=eng.sketch_local_async(self.k, self.hmax, self.s), shard=eng.new_shard_async(self.pct_id))
+        eng.x_setup(W, G, T, self.bounds, NSLOT)
 
         def gather_words(P, word_t):
-            rs = P["rs"]
-            words = t.empty((W, NW), dtype=t.int64, device=self.device)
-            dist.all_gather_into_tensor(words, word_t)
-            P["words_t"] = (words, word_t)
-            rs["h_words"].fetch_async(words.data_ptr())
-            rs["ev"].record()
+            words = t.empty((W, NW), dtype=t.int64, device=word_t.device)
+            dist.all_gather(list(words.unbind(0)), word_t)
+            eng.x_fetch_words(P, words, word_t)
 
-        def phase_a(P, slot):  # this rank's words, assembled on the device, into the all-gather: no host wait at all
-            P["rs"] = self._xslots[slot]
-            word_t = t.empty(NW, dtype=t.int64, device=self.device)
-            P["sk"].slice_words_dev(self._d_bounds.ptr, W - 1, word_t.data_ptr())
-            P["shard"].map_words_dev(word_t.data_ptr() + 8 * (W + 4))
-            gather_words(P, word_t)
-
-        def read_words(P):
-            rs = P["rs"]
-            rs["ev"].synchronize()
-            words = rs["h_words"].array.reshape(W, NW).tolist()
-            P["words_t"] = None
-            return words
+        def phase_a(P, slot):  # this rank's words into the all-gather: no host wait at all
+            gather_words(P, eng.x_words(P, slot))
 
         def phase_b(P):  # all-to-all of the slices, stage-C commit, merge, stage B
-            rs = P["rs"]
-            words = read_words(P)
-            sk = P["sk"]
+            words = eng.x_wait_words(P)
             if any(w[W + 3] for w in words):
                 # some rank's counting table overflowed (a sample unlike the previous one): its words are stale.  Every
                 # rank sees the same flags, so every rank repeats the all-gather once that sketch has been rebuilt.
                 self.words_redone = getattr(self, "words_redone", 0) + 1
-                sk.resolve()
-                n = sk.size
-                cuts = [0] + eng.split_sketch(sk, self.bounds[1:W]) + [n]
-                last = sk.last_hash
-                word = ([cuts[q + 1] - cuts[q] for q in range(W)]
-                        + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, 0] + words[self.rank][W + 4:])
-                gather_words(P, t.as_tensor(np.asarray(word, dtype=np.int64), device=self.device))
-                words = read_words(P)
+                gather_words(P, eng.x_redo_words(P, self.bounds, words[self.rank][W + 4:]))
+                words = eng.x_wait_words(P)
             sc = [int(x) for x in words[self.rank][:W]]
-            recv_counts = [words[p][self.rank] for p in range(W)]
-            h, c = eng.export_sketch(sk)
+            recv_counts = [int(words[p][self.rank]) for p in range(W)]
+            h, c = eng.export_sketch(P["sk"])
             rh, rc, inflight = self._all_to_all(h, c, sc, recv_counts)
             maps = [(w[W + 4], w[W + 5]) for w in words]
             incoming = compose_incoming(maps, self.rank)
             group_base = int(sum(w[W + 6] for w in words[: self.rank]))
             first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
-            base = rs["d_acc"].ptr
-            P["shard"].commit(incoming, first_shard, group_base, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8,
-                              reset=True)
+            eng.x_commit(P, incoming, first_shard, group_base)  # runs during the all-to-all: it needs the maps only
             for wk in inflight:
                 wk.wait()
             lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
             complete_to = min(lasts) if lasts else U64_MAX
             any_trunc = bool(lasts)
             lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1] - 1
-            P["keep"] = (rh, rc)
             # queued, not waited for: the merged slice is consumed on the device by stage B; phase C settles it
-            merged = hip.sketch_merge_dev_async(rh.data_ptr(), rc.data_ptr(), int(rh.numel()), self.k, lo, hi, 0,
-                                                any_trunc, complete_to)
+            merged = eng.x_merge(P, rh, rc, self.k, lo, hi, any_trunc, complete_to)
             if self.s or any_trunc:
                 merged = self._bottom_s(merged, any_trunc)
-            P["merged"] = merged
-            hip.containment_dev(merged, eng.table, self.ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
-            hip.stage_c_join()
-            rs["h_acc"].fetch_async(base)
-            rs["ev"].record()
+            eng.x_stage_b(P, merged, self.ci)
 
         def phase_c(P):  # this rank's counts -> THE all-reduce
-            rs = P["rs"]
-            rs["ev"].synchronize()
-            merged = P["merged"]
-            P["sk"].free()  # its buffers were the all-to-all's send buffers: back to the pool only now
-            if merged.resolve():
-                hip.sync()
-                hip.containment_dev(merged, eng.table, self.ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
-                hip.sync()
-            hs, acc = rs["h_hs"].array, rs["h_acc"].array
-            buf = rs["h_red_in"].array
-            buf[:] = 0
-            buf[:G] = hs[:G]
-            buf[G:2 * G] = hs[g:g + G]
-            buf[-3] = merged.size
-            buf[2 * G:2 * G + 2 * T] = acc[:2 * T].view(np.int64)
+            hits, sizes, count, bases, first, scalars, P["mm"], qn = eng.x_collect(P, self.ci, want_multimapped)
+            buf = eng.x_reduce_buffer(P)
+            buf[:G] = hits
+            buf[G:2 * G] = sizes
+            buf[-3] = qn
+            buf[2 * G:2 * G + T] = count.view(np.int64)
+            buf[2 * G + T:2 * G + 2 * T] = bases.view(np.int64)
             o = 2 * G + 2 * T + self.rank * T
-            buf[o:o + T] = acc[2 * T:3 * T].view(np.int64)
-            buf[-2:] = acc[3 * T:].view(np.int64)
-            P["mm"] = P["shard"].multimapped() if want_multimapped else None
-            P["shard"].free()
-            merged.free()
-            P["keep"] = None
-            rs["h_red_in"].push_async(rs["d_red"].ptr)
-            tb = t.as_tensor(_CudaView(rs["d_red"].ptr, nred, "<i8"), device="cuda")
+            buf[o:o + T] = first.view(np.int64)
+            buf[-2:] = scalars.view(np.int64)
+            tb = eng.x_reduce_tensor(P)
             dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-            P["tb"] = tb
-            rs["h_red"].fetch_async(rs["d_red"].ptr)
-            rs["ev"].record()
+            eng.x_fetch_reduced(P, tb)
 
         def phase_d(P):
-            rs = P["rs"]
-            rs["ev"].synchronize()
-            buf = rs["h_red"].array.copy()
-            P["tb"] = None
+            buf = eng.x_wait_reduced(P)
             hits, sizes = buf[:G].astype(np.uint32), buf[G:2 * G].astype(np.uint32)
             count, bases = buf[2 * G:2 * G + T].view(np.uint64), buf[2 * G + T:2 * G + 2 * T].view(np.uint64)
             first = buf[2 * G + 2 * T:2 * G + 2 * T + W * T].view(np.uint64).reshape(W, T).min(axis=0)
@@ -601,8 +648,12 @@ class ShardJob:
             out["top_ok"] = bool(ci_vals.max() > 0.5) if len(ci_vals) else None
             return out
 
+        eng.x_begin()
         try:
             AHEAD = 2
+
+            def front():
+                return eng.x_front(self.k, self.hmax, self.s, self.pct_id)
             fronts = [front() for _ in range(min(AHEAD, nsteps))]
             passes, out = {}, None
             for tick in range(nsteps + 3):
@@ -619,7 +670,7 @@ class ShardJob:
                     phase_b(passes[tick - 1])
             return out
         finally:
-            hip.stage_a_side_stream(False)
+            eng.x_end()
 
     def step(self, want_multimapped=False, _sketch=None):
         """One pass of the hot path over the resident batch.  Returns the sample-wide results (every rank).

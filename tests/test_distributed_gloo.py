@@ -95,6 +95,80 @@ class OracleEngine:
         return r["count"], r["bases"], r["first_seen"], scal, r["mm"]
 
 
+class PipelinedOracleEngine(OracleEngine):
+    """OracleEngine + the x_* methods of the four-passes-in-flight schedule (ShardJob._run_exchange_pipelined), served on
+    the host: what is under test is the schedule — words layout, the order of the collectives across ranks with several
+    passes in flight, slot reuse, the repeat-the-all-gather path — not the compute."""
+    force_stale_words = False  # publish an overflow count once: every rank must then repeat the all-gather
+
+    def x_setup(self, W, G, T, bounds, nslot):
+        self._xW, self._xNW, self._xnred, self._xbounds_list = W, W + 7, 2 * G + 2 * T + W * T + 3, list(bounds)
+
+    def x_begin(self):
+        pass
+
+    def x_end(self):
+        pass
+
+    def x_front(self, k, hmax, s, pct_id):
+        sk = self.sketch_local(k, hmax, s)
+        maps, ngroups = self.profile_begin(pct_id)
+        return dict(sk=sk, maps=maps, ngroups=ngroups)
+
+    def _word(self, P, overflow):
+        sk, W = P["sk"], self._xW
+        cuts = [0] + self.split_sketch(sk, self._xbounds_list[1:W]) + [sk.size]
+        last = sk.last_hash
+        return ([cuts[q + 1] - cuts[q] for q in range(W)]
+                + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, sk.size, overflow,
+                   P["maps"][0], P["maps"][1], P["ngroups"]])
+
+    def x_words(self, P, slot):
+        stale = 1 if (self.force_stale_words and not getattr(self, "_staled", False)) else 0
+        self._staled = True
+        word = self._word(P, stale)
+        if stale:  # a stale word really is wrong: all slice sizes but the first zeroed
+            word[1:self._xW] = [0] * (self._xW - 1)
+        return self.torch.as_tensor(np.asarray(word, dtype=np.int64))
+
+    def x_redo_words(self, P, bounds, tail):
+        return self.torch.as_tensor(np.asarray(self._word(P, 0), dtype=np.int64))
+
+    def x_fetch_words(self, P, words_t, hold):
+        P["words"] = words_t
+
+    def x_wait_words(self, P):
+        return P["words"].numpy().reshape(self._xW, self._xNW).tolist()
+
+    def x_commit(self, P, incoming, first_shard, group_base):
+        P["commit"] = (incoming, first_shard, group_base)
+
+    def x_merge(self, P, rh, rc, k, lo, hi, any_trunc, bound):
+        return self.merge_sketches(rh, rc, k, 0, any_trunc, bound, (lo, hi))
+
+    def x_stage_b(self, P, merged, ci):
+        P["merged"] = merged
+        P["hs"] = self.containment(merged, ci)
+
+    def x_collect(self, P, ci, want_multimapped):
+        count, bases, first, scal, mm = self.profile_commit(*P["commit"], want_multimapped)
+        hits, sizes = P["hs"]
+        return hits, sizes, count, bases, first, scal, mm, P["merged"].size
+
+    def x_reduce_buffer(self, P):
+        P["buf"] = np.zeros(self._xnred, dtype=np.int64)
+        return P["buf"]
+
+    def x_reduce_tensor(self, P):
+        return self.torch.from_numpy(P["buf"])
+
+    def x_fetch_reduced(self, P, tb):
+        P["red"] = tb
+
+    def x_wait_reduced(self, P):
+        return P["red"].numpy().copy()
+
+
 def _worker(rank, world, port, tmpdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -141,6 +215,18 @@ def _worker(rank, world, port, tmpdir):
                       first=np.array_equal(out["first_seen"], want["first_seen"]),
                       tot=out["tot_rds"] == want["tot_rds"], ambig=out["n_ambig"] == want["n_ambig"],
                       qn=out["sketch_size"] == len(qh))
+        # the four-passes-in-flight schedule (run()) must give the same sample-wide results, also when a rank's words
+        # turn out stale and the all-gather is repeated
+        pe = PipelinedOracleEngine(torch)
+        pe.force_stale_words = (s == 0 and rank == world - 1)
+        pjob = mgd.ShardJob(None, dist, rank, world, k=k, ci=2, pct_id=0.5, s=s, engine=pe)
+        pjob.load(my_reads[0], my_reads[1], my_recs, ref2tax, dbh, dbo, ntax=ntax)
+        pout = pjob.run(5)
+        for key in ("hits", "sizes", "count", "bases", "first_seen"):
+            checks["run_" + key] = np.array_equal(pout[key], out[key])
+        checks["run_scalars"] = (pout["tot_rds"], pout["n_ambig"], pout["sketch_size"]) == (out["tot_rds"], out["n_ambig"], out["sketch_size"])
+        if s == 0:
+            checks["run_repeated_gather"] = getattr(pjob, "words_redone", 0) == 1
         ok = all(checks.values())
         if not ok:
             print("rank", rank, "s", s, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
