@@ -357,6 +357,14 @@ int mg_stage_c_join(void) {
 
 int mg_prof_enable(int on) {
   MG_REQUIRE_READY();
+  if (on) {  // event creation costs tens of microseconds apiece: not inside somebody's timed region
+    mg::Context& c = ctx();
+    while (c.prof_pool.size() < 512) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      c.prof_pool.push_back(e);
+    }
+  }
   ctx().prof_on = on != 0;
   ctx().prof_only[0] = 0;
   return MG_OK;
