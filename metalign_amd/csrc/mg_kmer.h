@@ -91,6 +91,14 @@ struct Roller {
     ++run;
   }
 
+  // The same for a base known to be one of ACGT, in a stretch where nobody looks at `run` (a tile of equally long
+  // reads without a single invalid base: whether a k-mer is complete is then a function of the position alone).
+  __device__ __forceinline__ void push_clean(uint32_t c) {
+    const int keep = run;
+    push(c);      // (the code is 0..3: the compiler drops the mask; the counter is restored, i.e. never computed)
+    run = keep;
+  }
+
   __device__ __forceinline__ bool full() const { return run >= K; }
 
   __device__ __forceinline__ bool forward_is_canonical() const {

@@ -207,14 +207,41 @@ __device__ __forceinline__ uint32_t encode1(uint32_t b) {
 // independent MurmurHash3 chains of an iteration interleave in the VALU.  CODES: src is the wavefront's
 // nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise src points at the read's
 // ASCII bases in HBM.
-template <int K, bool CODES>
-__device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen,
+template <int K, bool CODES, bool CLEAN = false>
+__device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
                                            uint64_t hmax, CandSink& sink, uint64_t& kmers, int lane) {
   Roller<K> roll;
   roll.reset();
   uint32_t nk = 0;
   CodeStream cs;
   if constexpr (CODES) cs.open(src, start);
+  // the tile's longest read, as a SCALAR: the position counter, the stream's group changes and nibble offsets and
+  // the "is this k-mer complete" tests of the clean walk then live in SGPRs instead of costing VALU issue slots
+  const uint32_t maxlen = __builtin_amdgcn_readfirstlane(maxlen_v);
+  // The first K-1 bases of a read complete no k-mer: roll them in without hashing (every lane starts its read
+  // at pos 0, so this is wave-uniform; it is (K-1)/150 of all steps — 13 % at k = 21, 39 % at k = 60).
+  constexpr uint32_t kWarm = (uint32_t)(K - 1) & ~1u;
+  const uint32_t warm = kWarm < maxlen ? kWarm : (maxlen & ~1u);
+  if constexpr (CLEAN) {
+    // Every read of the tile has maxlen bases and none of them is invalid (the usual tile): no length test, no run
+    // counter — "this position completes a k-mer" is a scalar condition.
+    static_assert(CODES, "the clean walk reads the LDS stage");
+    for (uint32_t pos = 0; pos < warm; ++pos) roll.push_clean(cs.at(pos) & 3u);
+    for (uint32_t pos = warm; pos < maxlen; pos += 2) {
+      const uint32_t c0 = cs.at(pos) & 3u, c1 = cs.at(pos + 1) & 3u;  // (c1 past the end: hashed, never offered)
+      roll.push_clean(c0);
+      const uint64_t h0 = roll.hash();
+      const bool full0 = pos + 1 >= (uint32_t)K;
+      roll.push_clean(c1);
+      const uint64_t h1 = roll.hash();
+      const bool full1 = pos + 2 >= (uint32_t)K && pos + 1 < maxlen;
+      nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
+      sink.offer(full0 && h0 <= hmax, h0, lane);
+      sink.offer(full1 && h1 <= hmax, h1, lane);
+    }
+    kmers += nk;
+    return;
+  }
   auto code_at = [&](uint32_t pos) -> uint32_t {
     if constexpr (CODES) {
       const uint32_t c = cs.at(pos);
@@ -224,10 +251,6 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
       return encode1(src[pos]);
     }
   };
-  // The first K-1 bases of a read complete no k-mer: roll them in without hashing (every lane starts its read
-  // at pos 0, so this is wave-uniform; it is (K-1)/150 of all steps — 13 % at k = 21, 39 % at k = 60).
-  constexpr uint32_t kWarm = (uint32_t)(K - 1) & ~1u;
-  const uint32_t warm = kWarm < maxlen ? kWarm : (maxlen & ~1u);
   for (uint32_t pos = 0; pos < warm; ++pos) {
     const uint32_t c = code_at(pos);
     roll.push(c);
@@ -286,12 +309,19 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
       // batch's) and the small kernels of the other streams live beside it on the CU
       const uint4* g = reinterpret_cast<const uint4*>(a0);
       uint2* s = reinterpret_cast<uint2*>(stage);
+      uint32_t bad = 0;  // an invalid base anywhere in what this lane staged (the 16-byte slop of the neighbours included)
       for (uint64_t i = lane; i * 16 < nbytes; i += 64) {
         const uint4 v = g[i];
-        s[i] = uint2{pack4(encode4(v.x)) | (pack4(encode4(v.y)) << 16), pack4(encode4(v.z)) | (pack4(encode4(v.w)) << 16)};
+        const uint2 p{pack4(encode4(v.x)) | (pack4(encode4(v.y)) << 16), pack4(encode4(v.z)) | (pack4(encode4(v.w)) << 16)};
+        bad |= (p.x | p.y) & 0x44444444u;
+        s[i] = p;
       }
       wave_lds_sync();
-      walk_reads<K, true>(stage, (uint32_t)(shift + (beg - t_beg)), (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
+      if (__ballot(bad != 0 || len != maxlen) == 0ull)
+        walk_reads<K, true, true>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      else
+        walk_reads<K, true>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
       wave_lds_sync();
     } else {
       walk_reads<K, false>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
