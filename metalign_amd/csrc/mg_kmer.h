@@ -68,7 +68,8 @@ struct Roller {
     // forward ASCII window: drop byte 0, append `up` as byte K-1
 #pragma unroll
     for (int j = 0; j + 1 < ND; ++j) f[j] = __builtin_amdgcn_alignbyte(f[j + 1], f[j], 1);
-    f[ND - 1] = (f[ND - 1] >> 8) | (up << (8 * (NB - 1)));
+    if constexpr (NB == 1) f[ND - 1] = up;  // the last dword holds one byte: nothing to keep of it
+    else f[ND - 1] = (f[ND - 1] >> 8) | (up << (8 * (NB - 1)));
     // reverse-complement ASCII window: prepend `cu` as byte 0, drop byte K-1
 #pragma unroll
     for (int j = ND - 1; j >= 1; --j) r[j] = __builtin_amdgcn_alignbyte(r[j], r[j - 1], 3);

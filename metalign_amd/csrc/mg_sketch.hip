@@ -143,7 +143,8 @@ struct CandSink {
   }
 
   __device__ __forceinline__ void offer(bool hit, uint64_t h, int lane) {
-    const unsigned long long m = __ballot(hit);
+    // (the builtin takes the condition mask as it is; __ballot() first materialises the predicate as an integer)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
     if (m == 0) return;
     if (hit) lds[n + __popcll(m & ((1ull << lane) - 1ull))] = h;
     n += __popcll(m);
@@ -184,9 +185,10 @@ struct CodeStream {
     w = __builtin_amdgcn_alignbit(hi, lo, sh);
     g = 0;
   }
-  // pos: wave-uniform, non-decreasing, advancing by at most one group between calls
+  // pos: wave-uniform; called for 0, 1, 2, ... or (from an even position on) for pairs pos, pos + 1: a group starts
+  // at a multiple of 8, which only the first of a pair can be — the test is then a scalar one
   __device__ __forceinline__ uint32_t at(uint32_t pos) {
-    if ((pos >> 3) != g) {
+    if ((pos & 7u) == 0 && pos != 0) {
       g = pos >> 3;
       lo = hi; hi = nxt;
       nxt = d[g + 2];  // may run past the tile into whatever follows in LDS: such positions are >= len and masked
@@ -236,8 +238,8 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
       const uint64_t h1 = roll.hash();
       const bool full1 = pos + 2 >= (uint32_t)K && pos + 1 < maxlen;
       nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
-      sink.offer(full0 && h0 <= hmax, h0, lane);
-      sink.offer(full1 && h1 <= hmax, h1, lane);
+      if (full0) sink.offer(h0 <= hmax, h0, lane);  // (scalar branches: the ballot then is the compare itself)
+      if (full1) sink.offer(h1 <= hmax, h1, lane);
     }
     kmers += nk;
     return;
