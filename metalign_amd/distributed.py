@@ -537,8 +537,11 @@ class ShardJob:
             # queued (behind pass i) BEFORE pass i is read back ...
             # ... and stage A of consecutive passes goes to two alternating streams at full occupancy: pass i+1's
             # k_sketch_reads fills the GPU while pass i's sort / pack / stage B tail (small kernels) drains.
+            import gc
             side = True
             eng.hip.stage_a_workgroups_per_cu(0)
+            gc_was_on = gc.isenabled()
+            gc.disable()  # (a cyclic collection in the loop is a hole of milliseconds in the GPU's queue)
             try:
                 q = eng.queue_pass(0, self.k, self.hmax, self.s, self.ci, self.pct_id, side)
                 out = None
@@ -551,6 +554,8 @@ class ShardJob:
             finally:
                 if side:
                     eng.hip.stage_a_side_stream(0)
+                if gc_was_on:
+                    gc.enable()
             return out
         # (MG_EXCHANGE_PIPELINE=0: the older schedule, one pass at a time with stage A a pass ahead)
         eng.hip.stage_a_workgroups_per_cu(2)
