@@ -445,6 +445,22 @@ class ProfileShard:
             pass
 
 
+class SamBatch:
+    """Alignment records left in HBM by the device tokeniser (mg_sam_tokenize_dev)."""
+
+    def __init__(self, hip, handle):
+        self.hip, self.handle = hip, handle
+        self.count = int(hip.lib.mg_sam_batch_count(handle))
+        p = _vp()
+        hip._chk(hip.lib.mg_sam_batch_device_ptr(handle, ctypes.byref(p)))
+        self.ptr = p.value or 0
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_sam_batch_free(self.handle)
+            self.handle = None
+
+
 class ResidentProfile:
     """A committed stage-C shard kept on the device together with the buffers it reads (multimapped CSR included)."""
 
@@ -505,6 +521,43 @@ class Hip:
     def array(self, host, dtype=None):
         host = np.ascontiguousarray(host, dtype=dtype)
         return DeviceArray(self, host.size, host.dtype).upload(host)
+
+    def upload_file(self, path, chunk=32 << 20):
+        """A file's bytes -> HBM through two page-locked chunks: the read of chunk i+1 (page cache -> pinned buffer,
+        one copy) overlaps the DMA of chunk i.  Against read() + a pageable upload this halves the time a large
+        FASTQ / SAM needs to reach the device.  -> (DeviceArray of uint8, size)."""
+        size = os.path.getsize(path)
+        dev = self.empty(max(size, 1), np.uint8)
+        if size == 0:
+            return dev, 0
+        chunk = int(min(chunk, size))
+        bufs = [self.pinned(chunk, np.uint8) for _ in range(2)]
+        evs = [self.event() for _ in range(2)]
+        try:
+            with open(path, "rb", buffering=0) as fh:
+                off, i = 0, 0
+                while off < size:
+                    b, ev = bufs[i & 1], evs[i & 1]
+                    if i >= 2:
+                        ev.synchronize()  # this buffer's previous DMA has run
+                    want = min(chunk, size - off)
+                    view, got = memoryview(b.array)[:want], 0
+                    while got < want:
+                        n = fh.readinto(view[got:])
+                        if not n:
+                            raise HipError("%s: short read at byte %d of %d" % (path, off + got, size))
+                        got += n
+                    b.push_async(dev.ptr + off, want)
+                    ev.record()
+                    off += want
+                    i += 1
+            self.sync()
+        finally:
+            for b in bufs:
+                b.free()
+            for ev in evs:
+                ev.free()
+        return dev, size
 
     def stage_c_side_stream(self, on=True):
         self._chk(self.lib.mg_stage_c_side_stream(ctypes.c_int(int(on))))
@@ -651,6 +704,18 @@ class Hip:
         self.lib.mg_sam_batch_free(h)
         return n
 
+    def sam_tokenize_dev_batch(self, d_text, nbytes, acc_index, prev_qname=""):
+        """SAM text resident in HBM -> SamBatch (records stay on the device).  SamParseError as sam_tokenize."""
+        h = _vp()
+        kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
+        rc = self.lib.mg_sam_tokenize_dev(_vp(d_text), ctypes.c_uint64(nbytes), acc_index.handle,
+                                          ctypes.c_char_p(prev_qname.encode()), ctypes.byref(h), ctypes.byref(kind),
+                                          ctypes.byref(line))
+        if rc != 0 and kind.value:
+            raise SamParseError(kind.value, line.value)
+        self._chk(rc)
+        return SamBatch(self, h)
+
     def acc_index(self, names):
         blob = "".join(names).encode()
         offs = np.zeros(len(names) + 1, dtype=np.uint64)
@@ -751,6 +816,39 @@ class Hip:
         res = dict(count=acc[:ntax].copy(), bases=acc[T:T + ntax].copy(), first_seen=acc[2 * T:2 * T + ntax].copy(),
                    tot_rds=int(acc[3 * T]), n_ambig=int(acc[3 * T + 1]), mm_nreads=nr, mm_nentries=ne)
         res['resident'] = ResidentProfile(shard, [d_recs, d_r2t, d_acc])
+        return res
+
+    def profile_assign_dev_records(self, d_recs_ptr, n, ref2tax, ntax, pct_id, owners, resident=False):
+        """Stage C over records ALREADY in HBM (the device tokeniser's batch).  owners: objects to free with the
+        result (they hold the records).  resident=False: the multimapped CSR is downloaded (same dict as
+        profile_assign); True: it stays on the device (same dict as profile_assign_resident)."""
+        ref2tax = np.ascontiguousarray(ref2tax, dtype=np.uint32)
+        T = max(int(ntax), 1)
+        d_r2t = self.array(ref2tax if ref2tax.size else np.zeros(1, np.uint32))
+        d_acc = self.empty(3 * T + 2, np.uint64)
+        pad = None
+        if not n:  # a handle needs a valid pointer even for an empty stream
+            pad = self.array(np.zeros(1, REC_DTYPE))
+            d_recs_ptr = pad.ptr
+        shard = self.profile_begin_dev(d_recs_ptr, n, False, d_r2t.ptr, len(ref2tax), ntax, pct_id)
+        base = d_acc.ptr
+        shard.commit(True, True, 0, base, base + 8 * T, base + 16 * T, base + 24 * T, reset=True)
+        acc = d_acc.download()
+        res = dict(count=acc[:ntax].copy(), bases=acc[T:T + ntax].copy(), first_seen=acc[2 * T:2 * T + ntax].copy(),
+                   tot_rds=int(acc[3 * T]), n_ambig=int(acc[3 * T + 1]))
+        keep = list(owners) + [d_r2t, d_acc] + ([pad] if pad is not None else [])
+        if resident:
+            nr, ne = shard.multimapped_size() if n else (0, 0)
+            res.update(mm_nreads=nr, mm_nentries=ne, resident=ResidentProfile(shard, keep))
+            return res
+        try:
+            off, tax, hl, rd = shard.multimapped() if n else (np.zeros(1, np.uint64), np.zeros(0, np.uint32),
+                                                             np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+        finally:
+            shard.free()
+            for b in keep:
+                b.free()
+        res.update(mm_offsets=off, mm_tax=tax, mm_hitlen=hl, mm_read=rd)
         return res
 
     def profile_assign(self, recs, ref2tax, ntax, pct_id):

@@ -280,6 +280,9 @@ def _device_assign(recs, ref2tax, ntax, pct_id):
     return _hip.Hip.get().profile_assign(recs, ref2tax, ntax, pct_id)
 
 
+_DEVICE_ASSIGN = _device_assign
+
+
 def _device_assign_resident(recs, ref2tax, ntax, pct_id):
     """--device_multimap: the multimapped CSR stays in HBM (res['resident']) for resolve_multi_prop_device."""
     return _hip.Hip.get().profile_assign_resident(recs, ref2tax, ntax, pct_id)
@@ -324,6 +327,39 @@ def assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=True):
             sys.exit('No reads mapped. Aborting...')
         taxids2abs['Unmapped'][1] = taxids2abs['Unmapped'][0] / float(tot_rds)
     return taxids2abs, multimapped, {}
+
+
+def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _resident=False):
+    """map_and_process for a plain SAM FILE, without the text or the records ever being host arrays: the file goes up
+    through page-locked chunks (Hip.upload_file), is tokenised where it lands and stage C runs on the records the
+    tokeniser left in HBM.  A line the reference cannot parse makes this return None: the caller then takes the
+    streaming path, which reproduces the reference's exception for that line."""
+    acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
+    _ = taxid2info['Unmapped']  # KeyError here, as at :197, when db_info lacks the Unmapped row
+    hip = _hip.Hip.get()
+    names = [None] * len(acc_index)
+    for a, i in acc_index.items():
+        names[i] = a
+    index = hip.acc_index(names)
+    d_text = batch = None
+    try:
+        d_text, size = hip.upload_file(path)
+        try:
+            batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '')
+        except _hip.SamParseError:
+            return None
+        finally:
+            d_text.free()
+        res = hip.profile_assign_dev_records(batch.ptr, batch.count, ref2tax, len(taxids), float(args.pct_id), [batch],
+                                             resident=_resident)
+        batch = None  # owned by the result now
+    finally:
+        index.free()
+        if batch is not None:
+            batch.free()
+    if not _want_lists:
+        res = dict(res, taxids=taxids)
+    return assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=_want_lists)
 
 
 def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_lists=True, _resident=False):
@@ -503,8 +539,14 @@ def compute_abundances(args, infile, acc2info, tax2info):
     # product path: the multimapped reads stay in the kernel's CSR form; preprocess_multimapped (:180-188) is
     # subsumed by the membership test inside the resolve step (a taxon dropped there is dropped here too)
     on_device = bool(getattr(args, 'device_multimap', False))
-    taxids2abs, mm, low_mem_mmap = map_and_process(args, instream, acc2info, tax2info, _want_lists=False,
-                                                   _resident=on_device)
+    done = None
+    seams_untouched = _device_tokenise is tokenise_sam_device and _device_assign is _DEVICE_ASSIGN  # (tests reroute them)
+    if args.input_type == 'sam' and not getattr(args, 'paf_input', False) and seams_untouched:
+        # a plain file: all the way on the device
+        done = map_and_process_file(args, infile, acc2info, tax2info, _want_lists=False, _resident=on_device)
+    if done is None:
+        done = map_and_process(args, instream, acc2info, tax2info, _want_lists=False, _resident=on_device)
+    taxids2abs, mm, low_mem_mmap = done
     if args.input_type == 'sam':
         instream.close()
     else:

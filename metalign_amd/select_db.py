@@ -83,11 +83,17 @@ def load_reads_device(hip, path, kind):
     """Reads file -> device-resident bases + offsets.  FASTQ and one-line-per-sequence FASTA are parsed on the
     GPU from the raw (decompressed) text (mg_reads_parse); multi-line FASTA falls back to the host parser."""
     import gzip
-    opener = gzip.open if path.endswith('.gz') else open
-    with opener(path, 'rb') as fh:
-        text = fh.read()
+    fmt = 'fastq' if kind == 'fastq' else 'fasta'
     try:
-        return hip.parse_reads(text, 'fastq' if kind == 'fastq' else 'fasta')
+        if path.endswith('.gz'):
+            with gzip.open(path, 'rb') as fh:
+                return hip.parse_reads(fh.read(), fmt)
+        # plain text goes up through page-locked chunks (the file read overlaps the DMA) and is parsed where it lands
+        d_text, size = hip.upload_file(path)
+        try:
+            return hip.parse_reads_dev(d_text.ptr, size, fmt)
+        finally:
+            d_text.free()
     except _hip.HipError:
         if kind == 'fastq':
             raise
