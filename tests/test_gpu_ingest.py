@@ -117,3 +117,19 @@ def test_sam_tokeniser_raises_what_the_reference_raises(hip):
     # unmapped / header / short lines are skipped before any field is parsed
     text = "@HD\tx\n" + "u\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII\n" + "a b c\n" + ok
     assert np.array_equal(mp.tokenise_sam_device(iter(text.splitlines(True)), idx), mp.tokenise_sam(text.splitlines(True), idx))
+
+
+@pytest.mark.gpu
+def test_upload_file_chunks(hip, tmp_path):
+    """Hip.upload_file: a file through two page-locked chunks (several rounds of both buffers, a ragged tail, the
+    empty file) == its bytes."""
+    rng = np.random.default_rng(3)
+    for size, chunk in ((0, 1 << 16), (1, 1 << 16), (300_001, 1 << 16), (1 << 16, 1 << 16), (5 * (1 << 16) + 7, 1 << 16)):
+        data = rng.integers(0, 256, size=size, dtype=np.uint8)
+        path = tmp_path / ("f%d.bin" % size)
+        path.write_bytes(data.tobytes())
+        dev, n = hip.upload_file(str(path), chunk=chunk)
+        assert n == size
+        if size:
+            assert np.array_equal(dev.download()[:size], data)
+        dev.free()
