@@ -232,7 +232,10 @@ int mg_sketch_reads(const uint8_t* bases, const uint64_t* offsets,
  * Ingest on the device (text already in HBM -> what stage A consumes).
  * Replaces the reads parsing inside kmc (scripts/select_db.py:45-52: -fq / -fa).
  * format 0 = FASTQ (4 lines per record), 1 = FASTA with one sequence line per
- * record.  Multi-line FASTA is parsed on the host (metalign_amd/formats.py).
+ * record (malformed records are an error), 2 = FASTA with sequences over any
+ * number of lines: a line starting with '>' opens a record, every other line
+ * after the first header is stripped of white space at both ends and appended,
+ * lines in front of the first header are ignored.
  * Sequences are kept as written (case, N); '\r' before '\n' is dropped.
  * ------------------------------------------------------------------------ */
 typedef struct mg_reads mg_reads;

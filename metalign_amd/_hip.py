@@ -84,6 +84,9 @@ def load_library(path=LIB_PATH):
     return lib
 
 
+_READS_FORMAT = {"fastq": 0, "fasta": 1, "fasta_ml": 2}
+
+
 class DeviceArray:
     """A caller-owned HBM allocation (mg_dev_malloc) with a numpy-like shape/dtype."""
 
@@ -675,19 +678,19 @@ class Hip:
 
     # ---- ingest ----
     def parse_reads(self, text, fmt):
-        """FASTQ (fmt 'fastq') or one-sequence-line FASTA ('fasta') bytes -> device-resident Reads."""
+        """FASTQ (fmt 'fastq'), one-sequence-line FASTA ('fasta') or any FASTA ('fasta_ml') bytes -> device-resident Reads."""
         buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
         h = _vp()
         src = buf if buf.size else np.zeros(1, np.uint8)
         self._chk(self.lib.mg_reads_parse(_np(src, ctypes.c_uint8), ctypes.c_uint64(buf.size),
-                                          ctypes.c_int(0 if fmt == "fastq" else 1), ctypes.byref(h)))
+                                          ctypes.c_int(_READS_FORMAT[fmt]), ctypes.byref(h)))
         return Reads(self, h)
 
     def parse_reads_dev(self, d_text, nbytes, fmt):
         """As parse_reads, for text already resident in HBM."""
         h = _vp()
         self._chk(self.lib.mg_reads_parse_dev(_vp(d_text), ctypes.c_uint64(nbytes),
-                                              ctypes.c_int(0 if fmt == "fastq" else 1), ctypes.byref(h)))
+                                              ctypes.c_int(_READS_FORMAT[fmt]), ctypes.byref(h)))
         return Reads(self, h)
 
     def sam_tokenize_dev(self, d_text, nbytes, acc_index, prev_qname=""):

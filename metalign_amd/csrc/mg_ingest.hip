@@ -130,6 +130,71 @@ __global__ __launch_bounds__(256) void k_gather_reads(const uint8_t* __restrict_
   }
 }
 
+// ---- FASTA with sequences over any number of lines (format 2) ----
+// The host parser's rules (metalign_amd/formats.py::read_sequences): a line that starts with '>' opens a record;
+// every other line after the first header is stripped of white space at both ends and appended; lines before the
+// first header are ignored.
+__device__ __forceinline__ bool is_space(uint8_t ch) {
+  return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n' || ch == '\v' || ch == '\f';
+}
+__device__ __forceinline__ void stripped_span(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end,
+                                              uint64_t l, uint64_t& beg, uint64_t& end) {
+  beg = l == 0 ? 0 : line_end[l - 1] + 1;
+  end = line_end[l];
+  while (end > beg && is_space(text[end - 1])) --end;
+  while (beg < end && is_space(text[beg])) ++beg;
+}
+
+__global__ void k_fasta_lines(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end, uint64_t nlines,
+                              uint32_t* __restrict__ flags, uint32_t* __restrict__ lens) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; l < nlines; l += stride) {
+    const uint64_t raw = l == 0 ? 0 : line_end[l - 1] + 1;
+    const bool head = raw < line_end[l] && text[raw] == '>';
+    uint64_t b, e;
+    stripped_span(text, line_end, l, b, e);
+    flags[l] = head ? 1u : 0u;
+    lens[l] = head ? 0u : (uint32_t)(e - b);
+  }
+}
+
+// sequence lines in front of the first header belong to no record
+__global__ void k_fasta_orphans(const uint32_t* __restrict__ flags, const uint64_t* __restrict__ rank, uint64_t nlines,
+                                uint32_t* __restrict__ lens) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; l < nlines; l += stride)
+    if (!flags[l] && rank[l] == 0) lens[l] = 0;
+}
+
+__global__ void k_fasta_offsets(const uint32_t* __restrict__ flags, const uint64_t* __restrict__ rank,
+                                const uint64_t* __restrict__ pos, uint64_t nlines, uint64_t nrec, uint64_t nbases,
+                                uint64_t* __restrict__ offsets) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  if (l == 0) offsets[nrec] = nbases;
+  for (; l < nlines; l += stride)
+    if (flags[l]) offsets[rank[l]] = pos[l];
+}
+
+// One wavefront per line: its stripped bytes go to the record's place in the compact base buffer.
+__global__ __launch_bounds__(256) void k_fasta_gather(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end,
+                                                      const uint32_t* __restrict__ lens, const uint64_t* __restrict__ pos,
+                                                      uint64_t nlines, uint8_t* __restrict__ bases) {
+  const int lane = threadIdx.x & 63;
+  uint64_t l = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (; l < nlines; l += nw) {
+    const uint32_t n = lens[l];
+    if (!n) continue;
+    uint64_t b, e;
+    stripped_span(text, line_end, l, b, e);
+    const uint64_t o = pos[l];
+    for (uint32_t i = lane; i < n; i += 64) bases[o + i] = text[b + i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SAM
 // ---------------------------------------------------------------------------------------------
@@ -367,7 +432,7 @@ int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_re
   MG_REQUIRE_READY();
   if (!out) return fail(MG_ERR_ARG, "null out handle");
   *out = nullptr;
-  if (format != 0 && format != 1) return fail(MG_ERR_ARG, "format must be 0 (fastq) or 1 (single-line fasta)");
+  if (format < 0 || format > 2) return fail(MG_ERR_ARG, "format must be 0 (fastq), 1 (single-line fasta) or 2 (fasta)");
   if (nbytes > 0 && !d_text) return fail(MG_ERR_ARG, "null device text");
   Context& c = ctx();
   hipStream_t st = c.stream;
@@ -376,6 +441,39 @@ int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_re
   uint64_t nlines = 0;
   bool vlast = false;
   MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast));
+  if (format == 2) {  // sequences over any number of lines
+    uint32_t* d_flag = (uint32_t*)scratch("ing_fa_flag", (nlines + 1) * sizeof(uint32_t));
+    uint32_t* d_llen = (uint32_t*)scratch("ing_fa_len", (nlines + 1) * sizeof(uint32_t));
+    uint64_t* d_rank = (uint64_t*)scratch("ing_fa_rank", (nlines + 1) * sizeof(uint64_t));
+    uint64_t* d_pos = (uint64_t*)scratch("ing_fa_pos", (nlines + 1) * sizeof(uint64_t));
+    if (!d_flag || !d_llen || !d_rank || !d_pos) return MG_ERR_NOMEM;
+    uint64_t nrec = 0, nbases = 0;
+    ProfScope ps("ingest_reads");
+    if (nlines) {
+      const unsigned grid = grid_for(nlines, 256, (unsigned)c.num_cus * 8);
+      hipLaunchKernelGGL(k_fasta_lines, dim3(grid), dim3(256), 0, st, d_text, d_le, nlines, d_flag, d_llen);
+      MG_HIP(hipGetLastError());
+      MG_TRY(exclusive_sum_u32_to_u64(d_flag, d_rank, nlines, &nrec));
+      hipLaunchKernelGGL(k_fasta_orphans, dim3(grid), dim3(256), 0, st, d_flag, d_rank, nlines, d_llen);
+      MG_HIP(hipGetLastError());
+      MG_TRY(exclusive_sum_u32_to_u64(d_llen, d_pos, nlines, &nbases));
+    }
+    rd->nreads = nrec;
+    rd->nbases = nbases;
+    MG_TRY(rd->offsets.alloc((nrec + 2) * sizeof(uint64_t)));
+    MG_TRY(rd->bases.alloc(nbases + 16));
+    if (nrec == 0) {
+      MG_HIP(hipMemsetAsync(rd->offsets.p, 0, 2 * sizeof(uint64_t), st));
+    } else {
+      hipLaunchKernelGGL(k_fasta_offsets, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_flag,
+                         d_rank, d_pos, nlines, nrec, nbases, rd->offsets.as<uint64_t>());
+      hipLaunchKernelGGL(k_fasta_gather, dim3(grid_for(nlines, 4, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
+                         d_llen, d_pos, nlines, rd->bases.as<uint8_t>());
+      MG_HIP(hipGetLastError());
+    }
+    *out = rd.release();
+    return MG_OK;
+  }
   const int lpr = format == 0 ? 4 : 2;
   const uint64_t nrec = nlines / lpr;
   const uint64_t left = nlines % lpr;

@@ -80,10 +80,10 @@ class _HostParsedReads:
 
 
 def load_reads_device(hip, path, kind):
-    """Reads file -> device-resident bases + offsets.  FASTQ and one-line-per-sequence FASTA are parsed on the
-    GPU from the raw (decompressed) text (mg_reads_parse); multi-line FASTA falls back to the host parser."""
+    """Reads file -> device-resident bases + offsets.  FASTQ and FASTA are parsed on the GPU from the raw
+    (decompressed) text (mg_reads_parse_dev); the host parser is only the fallback for text the device rejects."""
     import gzip
-    fmt = 'fastq' if kind == 'fastq' else 'fasta'
+    fmt = 'fastq' if kind == 'fastq' else 'fasta_ml'  # (FASTA: sequences over any number of lines)
     try:
         if path.endswith('.gz'):
             with gzip.open(path, 'rb') as fh:

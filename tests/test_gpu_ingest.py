@@ -133,3 +133,35 @@ def test_upload_file_chunks(hip, tmp_path):
         if size:
             assert np.array_equal(dev.download()[:size], data)
         dev.free()
+
+
+@pytest.mark.gpu
+def test_multiline_fasta_on_device_equals_host_parser(hip, tmp_path):
+    """mg_reads_parse_dev format 2 == formats.read_sequences on FASTA with wrapped sequences, CRLF, blank and indented
+    lines, an empty record, junk in front of the first header and no newline at the end."""
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    for trial, (nl, tail) in enumerate((("\n", "\n"), ("\r\n", ""), ("\n", ""))):
+        lines = ["junk before any header", ""] if trial != 2 else []
+        for r in range(60):
+            lines.append(">seq%d some description" % r)
+            n = 0 if r == 7 else int(rng.integers(1, 400))
+            seq = alphabet[rng.integers(0, len(alphabet), size=n)].tobytes().decode()
+            width = int(rng.integers(1, 80))
+            for i in range(0, n, width):
+                pad = "  " if rng.random() < 0.1 else ""
+                lines.append(pad + seq[i:i + width] + ("\t" if rng.random() < 0.1 else ""))
+            if rng.random() < 0.2:
+                lines.append("")
+        text = nl.join(lines) + tail
+        path = tmp_path / ("ml%d.fa" % trial)
+        path.write_bytes(text.encode())
+        want_b, want_o, _ = formats.read_sequences(str(path), "fasta")
+        reads = hip.parse_reads(text.encode(), "fasta_ml")
+        got_b, got_o = reads.download()
+        assert reads.count == len(want_o) - 1
+        assert np.array_equal(got_o, want_o) and np.array_equal(got_b[: int(want_o[-1])], want_b)
+        reads.free()
+    empty = hip.parse_reads(b"", "fasta_ml")
+    assert empty.count == 0
+    empty.free()
