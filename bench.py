@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     p.add_argument("--genomes", type=int, default=1000)
     p.add_argument("--genome_len", type=int, default=50_000)
