@@ -150,6 +150,16 @@ struct CandSink {
     n += __popcll(m);
     if (n > kCandBuf - 64) flush(lane);
   }
+
+  // hit = a && b with each condition balloted by its own compare (the ballot of a conjunction is lowered through a
+  // materialised integer: two more VALU instructions per base)
+  __device__ __forceinline__ void offer2(bool a, bool b, uint64_t h, int lane) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b);
+    if (m == 0) return;
+    if (a && b) lds[n + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    n += __popcll(m);
+    if (n > kCandBuf - 64) flush(lane);
+  }
 };
 
 // Four ASCII bases -> four code bytes: 0..3 = A C G T (either case), 4 = anything else.  SWAR on the dword, done
@@ -209,7 +219,8 @@ __device__ __forceinline__ uint32_t encode1(uint32_t b) {
 // independent MurmurHash3 chains of an iteration interleave in the VALU.  CODES: src is the wavefront's
 // nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise src points at the read's
 // ASCII bases in HBM.
-template <int K, bool CODES, bool CLEAN = false>
+// MODE 0: any tile.  1: a clean tile (no invalid base in it) of equally long reads.  2: a clean tile of ragged reads.
+template <int K, bool CODES, int MODE = 0>
 __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
                                            uint64_t hmax, CandSink& sink, uint64_t& kmers, int lane) {
   Roller<K> roll;
@@ -224,24 +235,28 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
   // at pos 0, so this is wave-uniform; it is (K-1)/150 of all steps — 13 % at k = 21, 39 % at k = 60).
   constexpr uint32_t kWarm = (uint32_t)(K - 1) & ~1u;
   const uint32_t warm = kWarm < maxlen ? kWarm : (maxlen & ~1u);
-  if constexpr (CLEAN) {
-    // Every read of the tile has maxlen bases and none of them is invalid (the usual tile): no length test, no run
-    // counter — "this position completes a k-mer" is a scalar condition.
-    static_assert(CODES, "the clean walk reads the LDS stage");
+  if constexpr (MODE != 0) {
+    // No invalid base anywhere in the tile: no run counter — "this position completes a k-mer" is a scalar condition,
+    // the k-mers of a read are counted in closed form.  Equally long reads (MODE 1, the usual tile) need no length
+    // test either; ragged reads (MODE 2: trimmed data) pay one compare per base, and a lane past its read's end
+    // hashes the next read's bases and offers nothing.
+    static_assert(CODES, "the clean walks read the LDS stage");
+    constexpr bool RAGGED = MODE == 2;
     for (uint32_t pos = 0; pos < warm; ++pos) roll.push_clean(cs.at(pos) & 3u);
     for (uint32_t pos = warm; pos < maxlen; pos += 2) {
       const uint32_t c0 = cs.at(pos) & 3u, c1 = cs.at(pos + 1) & 3u;  // (c1 past the end: hashed, never offered)
       roll.push_clean(c0);
       const uint64_t h0 = roll.hash();
-      const bool full0 = pos + 1 >= (uint32_t)K;
       roll.push_clean(c1);
       const uint64_t h1 = roll.hash();
-      const bool full1 = pos + 2 >= (uint32_t)K && pos + 1 < maxlen;
-      nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
-      if (full0) sink.offer(h0 <= hmax, h0, lane);  // (scalar branches: the ballot then is the compare itself)
-      if (full1) sink.offer(h1 <= hmax, h1, lane);
+      if (pos + 1 >= (uint32_t)K) {  // (scalar branches: the ballot then is the compare itself)
+        if constexpr (RAGGED) sink.offer2(pos < len, h0 <= hmax, h0, lane); else sink.offer(h0 <= hmax, h0, lane);
+      }
+      if (pos + 2 >= (uint32_t)K && pos + 1 < maxlen) {
+        if constexpr (RAGGED) sink.offer2(pos + 1 < len, h1 <= hmax, h1, lane); else sink.offer(h1 <= hmax, h1, lane);
+      }
     }
-    kmers += nk;
+    kmers += len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u;
     return;
   }
   auto code_at = [&](uint32_t pos) -> uint32_t {
@@ -320,13 +335,15 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
       }
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
-      if (__ballot(bad != 0 || len != maxlen) == 0ull)
-        walk_reads<K, true, true>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      if (__ballot(bad != 0) != 0ull)
+        walk_reads<K, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      else if (__ballot(len != maxlen) == 0ull)
+        walk_reads<K, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
       else
-        walk_reads<K, true>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+        walk_reads<K, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
       wave_lds_sync();
     } else {
-      walk_reads<K, false>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      walk_reads<K, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
     }
   }
   sink.flush(lane);
