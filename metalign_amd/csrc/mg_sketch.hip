@@ -2,9 +2,10 @@
 //
 // K1 `k_sketch_reads<K>`: one lane per read, one wavefront per tile of 64
 // consecutive reads.  The tile's bases (contiguous in the concatenated read
-// buffer) are copied HBM -> LDS with 16-byte coalesced loads, then every lane
-// rolls its own read out of LDS (mg_kmer.h) and hashes one canonical k-mer per
-// base.  Hashes <= hmax are compacted per wavefront (ballot + popcount) into an
+// buffer) are copied HBM -> LDS with 16-byte coalesced loads and packed to 4-bit
+// codes on the way, then every lane rolls its own read out of LDS (mg_kmer.h,
+// CodeStream below) and hashes one canonical k-mer per base; tiles without an
+// invalid base take a walk whose position bookkeeping is scalar.  Hashes <= hmax are compacted per wavefront (ballot + popcount) into an
 // LDS candidate buffer.  A flush inserts its candidates into a COUNTING HASH
 // TABLE in HBM that is partitioned by hash range: bucket = leading bits of the
 // hash, kBucketSlots open-addressed slots per bucket (atomicCAS to claim a slot,
