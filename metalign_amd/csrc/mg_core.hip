@@ -169,7 +169,7 @@ static int init_common(int device, void* stream) {
     c.own_stream = true;
   }
   MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), 64 * sizeof(uint64_t), hipHostMallocDefault));
-  MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pend_pinned), 64 * sizeof(uint64_t), hipHostMallocDefault));
+  MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pend_pinned), mg::Context::kPendSlots * 8 * sizeof(uint64_t), hipHostMallocDefault));
   c.device = device;
   c.ready = true;
   return MG_OK;

@@ -57,9 +57,10 @@ struct Context {
   std::map<std::string, DevBuf*> scratch;
   std::map<uint64_t, std::vector<void*>> pool;  // size class -> free blocks
   uint64_t* pinned = nullptr;
-  // landing words of sketches whose finalisation is deferred (mg_sketch_reads_dev_async): 8 slots x 8 words
+  // landing words of sketches whose finalisation is deferred (mg_sketch_reads_dev_async): kPendSlots x 8 words
   uint64_t* pend_pinned = nullptr;
-  struct ::mg_sketch* pend_owner[8] = {};
+  static constexpr unsigned kPendSlots = 16;  // (a pipelined exchange keeps up to ~8 pending: fronts + merged slices)
+  struct ::mg_sketch* pend_owner[kPendSlots] = {};
   unsigned pend_next = 0;
 };
 

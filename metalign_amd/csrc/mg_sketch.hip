@@ -955,7 +955,7 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     // Deferred finalisation: the sketch's size, last hash and the table-overflow counter stay on the device with a
     // copy in flight to pinned memory; sketch_resolve() reads them at the first host-side use.
     Context& cc = ctx();
-    const unsigned slot = cc.pend_next++ & 7u;
+    const unsigned slot = cc.pend_next++ % Context::kPendSlots;
     if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
     MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
     uint64_t* sk_meta = sk->meta.as<uint64_t>();
@@ -1119,7 +1119,7 @@ int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts
                        d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, t_counters);
     MG_HIP(hipGetLastError());
   }
-  const unsigned slot = cc.pend_next++ & 7u;
+  const unsigned slot = cc.pend_next++ % Context::kPendSlots;
   if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
   MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
   uint64_t* sk_meta = sk->meta.as<uint64_t>();

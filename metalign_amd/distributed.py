@@ -579,7 +579,7 @@ class ShardJob:
     # one of those waits — each a collective's latency on a real node — is dead time on the host, and the pass rate
     # is 1 / (length of the chain) however fast the kernels are.  Passes are independent of each other, so the chain
     # is cut into four phases that each START by waiting for what the previous phase of the same pass queued and END
-    # by queueing asynchronous work; a tick runs phase D of pass t-3, C of t-2, A of t, B of t-1 (the same order on
+    # by queueing asynchronous work; a tick runs phase D of pass t-3, C of t-2, B of t-1, A of t (the same order on
     # every rank, so the collectives match up), stage A of passes t+1 and t+2 is already queued on the stage-A
     # stream.  By the time a phase looks at its inputs a whole tick has passed: the waits find finished work.
     def _run_exchange_pipelined(self, nsteps, want_multimapped):
@@ -658,7 +658,7 @@ class ShardJob:
         gc.disable()  # a generation-2 collection in the middle of a tick is a 2-3 ms hole in the GPU's queue (measured:
         eng.x_begin()  # one per ~160 passes); nothing cyclic is created here, reference counting frees what a pass drops
         try:
-            AHEAD = 2
+            AHEAD = 3  # stage A queued this many passes ahead: the GPU keeps hashing through a host stall of a millisecond or two
 
             def front():
                 return eng.x_front(self.k, self.hmax, self.s, self.pct_id)
@@ -669,13 +669,15 @@ class ShardJob:
                     out = phase_d(passes.pop(tick - 3))
                 if 0 <= tick - 2 < nsteps:
                     phase_c(passes[tick - 2])
+                if 0 <= tick - 1 < nsteps:
+                    phase_b(passes[tick - 1])
+                # phase A last: it makes the main stream wait (on the device) for the NEWEST sketch, and whatever is
+                # queued behind that wait only runs once that hashing kernel is through
                 if tick < nsteps:
                     passes[tick] = P = fronts.pop(0)
                     phase_a(P, tick % NSLOT)
                     if tick + AHEAD < nsteps:
                         fronts.append(front())
-                if 0 <= tick - 1 < nsteps:
-                    phase_b(passes[tick - 1])
             return out
         finally:
             eng.x_end()
