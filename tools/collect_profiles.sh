@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 CMD="python3 bench.py --steps 5 --warmup 2 --no_cpu_baseline"
-python3 bench.py --steps 20 --warmup 4 > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o run -- $CMD > "$OUT/stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --output-format csv --pmc $c --kernel-trace -d "$OUT/pmc_$c" -o run -- $CMD > "$OUT/pmc_$c.log" 2>&1
