@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+import util
 from metalign_amd import _hip
 
 pytestmark = pytest.mark.gpu
@@ -167,3 +168,32 @@ def test_containment_dense_read_sketch_sparse_table(hip, oracle_lib):
         ohits, osizes = oracle_lib.containment(qh, qc, False, ci, dbh, dbo)
         assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes)
         assert hits[:5].min() > 50 and hits[5] == 0 and sizes[5] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [21, 32, 60])
+def test_sketch_three_walks_of_a_tile(hip, oracle_lib, k):
+    """k_sketch_reads picks one of three walks per tile of 64 reads: equally long reads without an invalid base, ragged
+    reads without one (incl. reads shorter than k and empty ones), and tiles holding an invalid base.  Each against the
+    oracle — hashes, counts and the number of k-mers seen — with both the table path and the list path."""
+    rng = np.random.default_rng(100 + k)
+    gb, go = util.random_genomes(rng, 5, 30000)
+    hmax = int(0.05 * 2**64)
+    uniform = util.sample_reads(rng, gb, go, 6000, 150, err=0.01)[:2]
+    ragged_b, ragged_o, _ = util.sample_reads(rng, gb, go, 6000, 150, err=0.01, ragged=True, lower=True)
+    lens = np.diff(ragged_o).astype(np.int64)
+    lens[::97] = 0            # empty reads
+    lens[5::101] = k - 1      # reads one base too short for a k-mer
+    keep = np.concatenate([np.arange(int(ragged_o[i]), int(ragged_o[i]) + lens[i]) for i in range(len(lens))])
+    ragged = (ragged_b[keep], np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64))
+    dirty_b = uniform[0].copy()
+    dirty_b[rng.integers(0, dirty_b.size, size=40)] = ord("N")  # a few tiles with an invalid base, most without
+    dirty = (dirty_b, uniform[1])
+    for name, (b, o) in (("uniform", uniform), ("ragged", ragged), ("dirty", dirty)):
+        oh, oc, otr, oseen = oracle_lib.sketch_reads(b, o, k, hmax=hmax)
+        d_b, d_o = hip.array(b if b.size else np.zeros(1, np.uint8)), hip.array(o)
+        sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(o) - 1, k, hmax, 0)
+        gh, gc = sk.download()
+        assert np.array_equal(gh, oh) and np.array_equal(gc, oc), name
+        assert sk.kmers_seen == oseen, (name, sk.kmers_seen, oseen)
+        sk.free(); d_b.free(); d_o.free()
