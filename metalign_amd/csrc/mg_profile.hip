@@ -427,7 +427,7 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 }
 
 // Per-workgroup privatised histogram in LDS, flushed with global atomics every kFlushTiles tiles and at the end:
-//   use_lds_hist == 1  direct:  ntax <= 2048 bins (dynamic LDS: 12 B per bin)
+//   use_lds_hist == 1  direct:  ntax <= 4096 bins (dynamic LDS: 12 B per bin; above 2048 taxa two workgroups per CU, like the hashed form)
 //   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
 //                      fewer taxa than the table lists); a taxon that finds no bin within kHashProbe steps
 //                      goes to global atomics directly.  Without this a skewed sample serialises millions of
@@ -890,7 +890,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
-  a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 2048 ? 1u : 2u;
+  a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 4096 ? 1u : 2u;
   const size_t lds = a.use_lds_hist == 0 ? 0
                    : a.use_lds_hist == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t))
                                          : kHashSlots * (sizeof(unsigned long long) + 2 * sizeof(uint32_t));
