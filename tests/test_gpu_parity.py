@@ -187,9 +187,10 @@ def test_stage_c_bulk_hip(hip, name, monkeypatch, tmp_path):
 
 
 def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib):
-    """Random record streams straight into the C ABI: >2048 taxa forces the global-atomic histogram path."""
+    """Random record streams straight into the C ABI: direct LDS bins at three, then two workgroups per CU (37 / 3500
+    taxa) and, beyond 4096 taxa, hashed bins that overflow into global atomics."""
     rng = np.random.default_rng(9)
-    for ntax, nref in ((37, 90), (5000, 9000)):
+    for ntax, nref in ((37, 90), (3500, 7000), (5000, 9000)):
         n = 300000
         ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
         recs = np.zeros(n, dtype=oracle_lib.REC_DTYPE)
