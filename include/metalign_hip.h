@@ -140,10 +140,17 @@ int mg_prof_get(const char* kernel, uint64_t* launches, double* total_ms);
  * replaced by the lexicographically smaller of itself and its reverse
  * complement, and hashed with MurmurHash3_x64_128(ASCII k-mer, seed 0), first
  * 64 bits.  The sketch is the ascending list of DISTINCT hashes <= hmax with
- * their occurrence counts (saturating at 2^32-1), truncated to the s smallest
- * when s > 0 (`truncated` reports whether entries were cut).
+ * their occurrence counts, truncated to the s smallest when s > 0 (`truncated`
+ * reports whether entries were cut).  Counts SATURATE at cs = 3 by default,
+ * KMC's `-cs3` (scripts/select_db.py:50): count = min(occurrences, cs).  The
+ * only thing downstream reads from a count is `>= ci` with ci = 2 (`-ci2`), and
+ * merging per-GPU sketches keeps it exact: min(sum of min(c_r, cs), cs) =
+ * min(sum of c_r, cs).  mg_set_count_saturation(0) selects exact counts
+ * (saturating at 2^32-1); it applies to sketches built afterwards.
  * ------------------------------------------------------------------------ */
 typedef struct mg_sketch mg_sketch;
+int mg_set_count_saturation(uint32_t cs);
+uint32_t mg_count_saturation(void);
 
 int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
                         uint64_t nreads, int k, uint64_t hmax, uint64_t s,

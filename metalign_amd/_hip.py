@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
+    "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
@@ -47,7 +47,14 @@ class HipUnavailable(RuntimeError):
 
 
 class HipError(RuntimeError):
-    pass
+    """A failed library call; `code` is the mg_status value (include/metalign_hip.h), None when raised on the host side."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_HIP, ERR_ARG, ERR_CAPACITY, ERR_STATE, ERR_NOMEM = -1, -2, -3, -4, -5
 
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -78,6 +85,7 @@ def load_library(path=LIB_PATH):
     lib.mg_sketch_free.restype = None
     lib.mg_filter_free.restype = None
     lib.mg_filter_log2_bits.restype = ctypes.c_uint
+    lib.mg_count_saturation.restype = ctypes.c_uint32
     lib.mg_db_free.restype = None
     lib.mg_profile_free.restype = None
     lib.mg_shutdown.restype = None
@@ -497,10 +505,24 @@ class Hip:
         self.device = device
 
     @classmethod
-    def get(cls, device=0, stream=None):
+    def get(cls, device=None, stream=None):
+        """The process-wide instance.  device / stream = None: whatever the live instance is bound to (device 0 and
+        a stream of the library's own for the first call).  Asking for a device or a main stream OTHER than the live
+        instance's raises: torch / RCCL collectives only order against the stream the library was initialised on
+        (distributed.py), and a silently ignored argument would let them race with the library's kernels."""
         if cls._instance is None:
-            cls._instance = cls(device, stream)
-        return cls._instance
+            cls._instance = cls(0 if device is None else device, stream)
+            cls._instance.main_stream = stream
+            return cls._instance
+        inst = cls._instance
+        if device is not None and int(device) != inst.device:
+            raise HipError("libmetalign_hip is bound to device %d; Hip.get(device=%d) asked for another "
+                           "(Hip.reset() first)" % (inst.device, int(device)))
+        if stream is not None and stream != inst.main_stream:
+            raise HipError("libmetalign_hip's main stream is %r; Hip.get(stream=%r) asked for another (Hip.reset() "
+                           "first): collectives would not be ordered against the library's kernels"
+                           % (inst.main_stream, stream))
+        return inst
 
     @classmethod
     def reset(cls):
@@ -510,7 +532,7 @@ class Hip:
 
     def _chk(self, rc):
         if rc != 0:
-            raise HipError("libmetalign_hip rc=%d: %s" % (rc, self.lib.mg_last_error().decode("utf-8", "replace")))
+            raise HipError("libmetalign_hip rc=%d: %s" % (rc, self.lib.mg_last_error().decode("utf-8", "replace")), rc)
 
     # ---- misc ----
     def device_name(self):
@@ -599,6 +621,13 @@ class Hip:
         return n.value, ms.value
 
     # ---- stage A ----
+    def count_saturation(self, cs=None):
+        """Occurrence counters of read sketches saturate at cs (default 3 = kmc -cs3, select_db.py:50; 0 = exact).
+        With an argument: set it for sketches built from now on.  -> the value in force."""
+        if cs is not None:
+            self._chk(self.lib.mg_set_count_saturation(ctypes.c_uint32(int(cs))))
+        return int(self.lib.mg_count_saturation())
+
     def filter_build(self, hashes):
         """Membership pre-filter over ALL hashes of a genome table (one k)."""
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)

@@ -321,6 +321,9 @@ int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_
   MG_REQUIRE_READY();
   if (!q || !db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
   if (db->ngenomes == 0) return MG_OK;
+  if (ctx().count_sat && ci > ctx().count_sat)
+    return fail(MG_ERR_ARG, "count threshold ci=%u above the counters' saturation cs=%u: nothing could ever match", ci,
+                ctx().count_sat);
   mg_sketch* sk = const_cast<mg_sketch*>(q);  // the look-up index is a cache inside the handle
   // A sketch whose finalisation is deferred is consumed as it is when no completeness bound can apply (s = 0):
   // the kernels read its size and last hash from the device, nothing is synchronised here.

@@ -45,6 +45,8 @@ struct Context {
   const char* scratch_prefix = "";  // scratch buffers are per stream ("a:" while launching on stream_a)
   std::vector<hipEvent_t> ev_pool;   // recycled completion events of deferred sketches
   int num_cus = 256;
+  // occurrence counters of read sketches saturate here (kmc -cs3, scripts/select_db.py:50); 0 = exact counts
+  uint32_t count_sat = 3;
   // profiling
   bool prof_on = false;
   char prof_only[32] = "";  // when set, only this kernel family is timed (keeps the timed region light)

@@ -65,8 +65,12 @@ constexpr uint32_t kBucketTarget = 96;  // expected distinct hashes per bucket (
 
 // Insert-or-add into the partitioned counting table: keys[bucket][slot] holds hash+1 (0 = empty).
 // Returns false when the bucket has no free slot.
+// cs > 0: counters SATURATE at cs (kmc -cs3, scripts/select_db.py:50): a counter that is seen at cs or above is
+// left alone (counters only grow, so a stale look can only cost an unnecessary add), and whoever reads the table
+// afterwards takes min(counter, cs).  At 50x coverage nearly every candidate is a repeat of a key whose counter is
+// saturated already: it costs two reads and no memory-side read-modify-write.
 __device__ __forceinline__ bool table_add(uint64_t* __restrict__ keys, uint32_t* __restrict__ cnts, uint64_t bucket,
-                                          uint64_t h, uint32_t amount) {
+                                          uint64_t h, uint32_t amount, uint32_t cs) {
   const unsigned long long v = h + 1;  // hashes are <= 2^64-2, so v is never the empty marker 0
   const uint64_t base = bucket * kBucketSlots;
   uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
@@ -75,8 +79,14 @@ __device__ __forceinline__ bool table_add(uint64_t* __restrict__ keys, uint32_t*
     // err towards "empty", and then the CAS decides.  At 50x coverage most candidates are repeats of a key that is
     // already there: they cost this read and one add instead of a returning CAS and an add.
     unsigned long long old = keys[base + p];
+    const bool seen = old == v;
     if (old == 0ull) old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + base + p), 0ull, v);
-    if (old == 0ull || old == v) { atomicAdd(cnts + base + p, amount); return true; }
+    if (old == 0ull || old == v) {
+      // (the look goes to the memory side like the atomics do: an L2 of another XCD may hold the line from before)
+      if (cs && seen && __hip_atomic_load(cnts + base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cs) return true;
+      atomicAdd(cnts + base + p, amount);
+      return true;
+    }
     p = (p + 1) & (kBucketSlots - 1);
   }
   return false;
@@ -93,6 +103,7 @@ struct CandSink {
   unsigned shift;                // bucket = hash >> shift; 64 = list mode (read sketches start at hash 0)
   const uint32_t* fbits;         // optional membership pre-filter (mg_filter): bit (h & fmask) set <=> h may be in the table
   uint64_t fmask;
+  uint32_t cs;        // table mode: counters saturate at cs (0 = exact)
   int n;              // entries staged (wave-uniform)
   unsigned long long produced = 0;  // table mode: this lane's candidates inserted so far
 
@@ -132,7 +143,7 @@ struct CandSink {
       for (int j = 0; j < kCandBuf / 64; ++j) {
         if (hh[j] == kReservedHash || !((fw[j] >> (hh[j] & 31u)) & 1u)) continue;
         ++kept;
-        if (!table_add(out, slot_cnt, hh[j] >> shift, hh[j], 1u)) ++lost;
+        if (!table_add(out, slot_cnt, hh[j] >> shift, hh[j], 1u, cs)) ++lost;
       }
       // (counted per lane and added to counters[0] once, at the end of the kernel: an atomic per flush on that one
       // address is what bounded the kernel when the threshold filters little — 1.3 M flushes per 10 M reads at ~24 ns)
@@ -299,12 +310,12 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
                                                          unsigned long long* __restrict__ counters,
                                                          uint32_t* __restrict__ slot_cnt, unsigned bucket_shift,
                                                          unsigned stage_bytes, const uint32_t* __restrict__ fbits,
-                                                         uint64_t fmask) {
+                                                         uint64_t fmask, uint32_t cs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
-  CandSink sink{cbuf, cand, cand_cap, counters, slot_cnt, bucket_shift, fbits, fmask, 0};
+  CandSink sink{cbuf, cand, cand_cap, counters, slot_cnt, bucket_shift, fbits, fmask, cs, 0};
   uint64_t kmers = 0;
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -443,7 +454,7 @@ static unsigned bit_length(uint64_t v) {
 // Merge step of the multi-GPU exchange: add (hash,count) pairs into the table; bucket = (hash - lo) >> shift.
 __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const uint32_t* __restrict__ counts, uint64_t n,
                                      uint64_t lo, unsigned shift, uint64_t nbuckets, uint64_t* __restrict__ keys,
-                                     uint32_t* __restrict__ cnts, unsigned long long* __restrict__ counters) {
+                                     uint32_t* __restrict__ cnts, unsigned long long* __restrict__ counters, uint32_t cs) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint32_t lost = 0;
@@ -451,7 +462,7 @@ __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const 
     const uint64_t h = hashes[i];
     uint64_t b = (h - lo) >> shift;
     if (h < lo || b >= nbuckets) { ++lost; continue; }  // outside the declared range: caller falls back
-    if (!table_add(keys, cnts, b, h, counts[i])) ++lost;
+    if (!table_add(keys, cnts, b, h, counts[i], cs)) ++lost;
   }
   if (lost) atomicAdd(counters + 2, (unsigned long long)lost);
 }
@@ -463,7 +474,7 @@ __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const 
 __global__ __launch_bounds__(256) void k_bucket_sort(const uint64_t* __restrict__ tab_keys,
                                                      const uint32_t* __restrict__ tab_cnt, uint64_t nbuckets,
                                                      uint64_t* __restrict__ stage_h, uint32_t* __restrict__ stage_c,
-                                                     uint32_t* __restrict__ nuniq) {
+                                                     uint32_t* __restrict__ nuniq, uint32_t cs) {
   __shared__ uint64_t s_keys[4][kBucketSlots];
   __shared__ uint32_t s_cnt[4][kBucketSlots];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const uint64_t* __restrict_
       if (v[c] != 0) {
         const uint32_t d = n + __popcll(m & ((1ull << lane) - 1ull));
         keys[d] = v[c] - 1;
-        cnt[d] = vc[c];
+        cnt[d] = (cs && vc[c] > cs) ? cs : vc[c];  // saturating counters: concurrent adds may have overshot
       }
       n += __popcll(m);
     }
@@ -629,11 +640,23 @@ __global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __r
   }
 }
 
+// counts[i] = min(counts[i], cs) for the meta[0] runs a run-length / reduce-by-key pass just wrote (the list path and
+// the sorting merge count exactly; the sketch's counters saturate at cs).
+__global__ void k_clamp_counts(uint32_t* __restrict__ counts, const uint64_t* __restrict__ meta, uint32_t cs) {
+  const uint64_t n = meta[0];
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (counts[i] > cs) counts[i] = cs;
+}
+
 // Finalise a sketch whose (hash,count) runs were written straight into its own buffers; d_meta[0] = runs.
 // One read-back: [meta 0..3 | counters 0..2] -> pinned words 4..10.
 static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_bound, uint64_t bound,
                       const unsigned long long* d_counters = nullptr, uint64_t* h_counters = nullptr) {
   hipStream_t st = ctx().stream;
+  if (ctx().count_sat)  // (after the table path the counts are clamped already; this pass then changes nothing)
+    hipLaunchKernelGGL(k_clamp_counts, dim3(ctx().num_cus * 4), dim3(256), 0, st, sk->counts.as<uint32_t>(), d_meta,
+                       ctx().count_sat);
   hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), d_meta, s,
                      (uint32_t)(use_bound ? 1 : 0), bound, (const unsigned long long*)nullptr, (uint64_t*)nullptr);
   uint64_t* pin = host_words();
@@ -668,7 +691,8 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   ProfScope ps("sketch_reads");
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
                      nreads, hmax, d_cand, cap, d_counters, d_slot_cnt, bucket_shift, stage_bytes,
-                     filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr, filter ? filter->mask : 0ull);
+                     filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr, filter ? filter->mask : 0ull,
+                     c.count_sat);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -727,7 +751,7 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta) {
   {
     ProfScope ps("bucket_sort");
     hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, tp.keys,
-                       tp.cnts, tp.nbuckets, tp.stage_h, tp.stage_c, tp.nuniq);
+                       tp.cnts, tp.nbuckets, tp.stage_h, tp.stage_c, tp.nuniq, c.count_sat);
     MG_HIP(hipGetLastError());
   }
   MG_TRY(sk->hashes.alloc((tp.slots + 1) * sizeof(uint64_t)));  // a sketch cannot outgrow the table
@@ -1033,6 +1057,13 @@ int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out) {
   return MG_OK;
 }
 
+int mg_set_count_saturation(uint32_t cs) {
+  MG_REQUIRE_READY();
+  ctx().count_sat = cs;
+  return MG_OK;
+}
+uint32_t mg_count_saturation(void) { return ctx().count_sat; }
+
 unsigned mg_filter_log2_bits(const mg_filter* f) { return f ? f->log2_bits : 0; }
 void mg_filter_free(mg_filter* f) { delete f; }
 
@@ -1079,7 +1110,7 @@ int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint
     {
       ProfScope ps("merge_insert");
       hipLaunchKernelGGL(k_table_insert_pairs, dim3(grid_for(n, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st,
-                         d_hashes, d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, d_counters);
+                         d_hashes, d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, d_counters, ctx().count_sat);
       MG_HIP(hipGetLastError());
     }
     uint64_t h_counters[3] = {0, 0, 0};
@@ -1116,7 +1147,7 @@ int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts
   {
     ProfScope ps("merge_insert");
     hipLaunchKernelGGL(k_table_insert_pairs, dim3(grid_for(n, 256, (unsigned)cc.num_cus * 8)), dim3(256), 0, st, d_hashes,
-                       d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, t_counters);
+                       d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, t_counters, cc.count_sat);
     MG_HIP(hipGetLastError());
   }
   const unsigned slot = cc.pend_next++ % Context::kPendSlots;

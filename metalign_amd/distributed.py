@@ -366,6 +366,15 @@ class ShardJob:
             if dist is not None:
                 import torch as tm  # noqa: F811
             self.torch = tm
+            if tm is not None and self.exchange:
+                # torch / RCCL collectives order against torch's CURRENT stream only: it must be the stream the library
+                # launches on (mg_init_on_stream), or the all-gather / all-to-all / all-reduce race with its kernels
+                cur = tm.cuda.current_stream().cuda_stream
+                if getattr(hip, "main_stream", None) != cur:
+                    raise _hip.HipError("ShardJob: the library's main stream (%r) is not torch's current stream (%r); "
+                                        "create a torch.cuda.Stream, make it current and pass it to Hip.get(device, "
+                                        "stream=...) before anything else initialises the library"
+                                        % (getattr(hip, "main_stream", None), cur))
             self.engine = HipEngine(hip, tm)
         self.device = getattr(self.engine, "device", "cuda")
 

@@ -153,11 +153,11 @@ def tokenise_paf(lines, acc_index, decode=False):
     Pair flags do not exist in PAF: every read is treated as single-end."""
     rows, prev = [], ''
     for line in lines:
-        if decode:
+        if isinstance(line, (bytes, bytearray)):  # a file opened in binary mode (map_main does), or the aligner's pipe
             line = line.decode('utf-8')
-            if not line:
+            if decode and not line:
                 break
-        f = line.rstrip('\n').split('\t')
+        f = line.rstrip('\r\n').split('\t')
         if len(f) < 12:
             continue
         qlen, qs, qe = int(f[1]), int(f[2]), int(f[3])
@@ -343,13 +343,20 @@ def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _re
     index = hip.acc_index(names)
     d_text = batch = None
     try:
-        d_text, size = hip.upload_file(path)
         try:
+            d_text, size = hip.upload_file(path)
             batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '')
         except _hip.SamParseError:
             return None
+        except _hip.HipError as e:
+            # the whole file as ONE batch did not fit (hipMalloc failed, or the text exceeds what one ingest call
+            # takes): the streaming path tokenises it in 256 MB chunks instead
+            if e.code in (_hip.ERR_NOMEM, _hip.ERR_ARG):
+                return None
+            raise
         finally:
-            d_text.free()
+            if d_text is not None:
+                d_text.free()
         res = hip.profile_assign_dev_records(batch.ptr, batch.count, ref2tax, len(taxids), float(args.pct_id), [batch],
                                              resident=_resident)
         batch = None  # owned by the result now

@@ -63,8 +63,11 @@ def kmer_hashes(seq: bytes, k: int):
     return out, valid.astype(bool)
 
 
-def sketch_reads(bases, offsets, k, hmax=U64_MAX, s=0, cap=None):
-    """-> (hashes u64[n], counts u32[n], truncated, kmers_seen)."""
+DEFAULT_CS = 3  # kmc -cs3 (scripts/select_db.py:50): occurrence counters saturate at 3; the library's default too
+
+
+def sketch_reads(bases, offsets, k, hmax=U64_MAX, s=0, cap=None, cs=DEFAULT_CS):
+    """-> (hashes u64[n], counts u32[n], truncated, kmers_seen); counts = min(occurrences, cs) (cs = 0: exact)."""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     nreads = len(offsets) - 1
@@ -77,7 +80,7 @@ def sketch_reads(bases, offsets, k, hmax=U64_MAX, s=0, cap=None):
     seen = ctypes.c_uint64(0)
     bptr = _p(bases, ctypes.c_uint8) if bases.size else ctypes.POINTER(ctypes.c_uint8)()
     rc = lib().mgo_sketch_reads(bptr, _p(offsets, ctypes.c_uint64), ctypes.c_uint64(nreads), ctypes.c_int(k),
-                                ctypes.c_uint64(hmax), ctypes.c_uint64(s), _p(h, ctypes.c_uint64),
+                                ctypes.c_uint64(hmax), ctypes.c_uint64(s), ctypes.c_uint32(cs), _p(h, ctypes.c_uint64),
                                 _p(c, ctypes.c_uint32), ctypes.c_uint64(cap), ctypes.byref(n),
                                 ctypes.byref(trunc), ctypes.byref(seen))
     if rc != 0:
@@ -97,10 +100,10 @@ def filter_bits(hashes):
     return bits, mask
 
 
-def sketch_reads_filtered(bases, offsets, k, table_hashes, hmax=U64_MAX, s=0):
+def sketch_reads_filtered(bases, offsets, k, table_hashes, hmax=U64_MAX, s=0, cs=DEFAULT_CS):
     """The filtered read sketch: the sketch of sketch_reads restricted to hashes whose filter bit is set, THEN cut to
     the s smallest.  -> (hashes, counts, truncated, kmers_seen)."""
-    h, c, _, seen = sketch_reads(bases, offsets, k, hmax=hmax, s=0)
+    h, c, _, seen = sketch_reads(bases, offsets, k, hmax=hmax, s=0, cs=cs)
     bits, mask = filter_bits(table_hashes)
     keep = bits[(h & mask).astype(np.int64)] if len(h) else np.zeros(0, dtype=bool)
     h, c = h[keep], c[keep]

@@ -168,9 +168,10 @@ static int collect_hashes(const uint8_t* seq, uint64_t len, int k, uint64_t hmax
   return 0;
 }
 
-/* Stage A.  See include/metalign_hip.h (mg_sketch_reads) for the definition. */
+/* Stage A.  See include/metalign_hip.h (mg_sketch_reads) for the definition.
+ * cs: occurrence counters saturate at cs (kmc -cs3, scripts/select_db.py:50); 0 = exact counts. */
 int mgo_sketch_reads(const uint8_t* bases, const uint64_t* offsets, uint64_t nreads,
-                     int k, uint64_t hmax, uint64_t s, uint64_t* out_hashes,
+                     int k, uint64_t hmax, uint64_t s, uint32_t cs, uint64_t* out_hashes,
                      uint32_t* out_counts, uint64_t out_cap, uint64_t* out_n,
                      int* out_truncated, uint64_t* out_kmers_seen) {
   if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
@@ -190,6 +191,7 @@ int mgo_sketch_reads(const uint8_t* bases, const uint64_t* offsets, uint64_t nre
     if (s > 0 && n == s) { truncated = 1; break; }
     if (n == out_cap) { rc = MG_ERR_CAPACITY; break; }
     uint64_t c = j - i;
+    if (cs && c > cs) c = cs;
     out_hashes[n] = acc.v[i];
     out_counts[n] = c > 0xffffffffULL ? 0xffffffffu : (uint32_t)c;
     ++n;

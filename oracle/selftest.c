@@ -11,7 +11,7 @@
 
 void mgo_murmur3_x64_128(const void*, int, uint32_t, uint64_t[2]);
 uint64_t mgo_kmer_hashes(const uint8_t*, uint64_t, int, uint64_t*, uint8_t*);
-int mgo_sketch_reads(const uint8_t*, const uint64_t*, uint64_t, int, uint64_t, uint64_t, uint64_t*, uint32_t*, uint64_t,
+int mgo_sketch_reads(const uint8_t*, const uint64_t*, uint64_t, int, uint64_t, uint64_t, uint32_t, uint64_t*, uint32_t*, uint64_t,
                      uint64_t*, int*, uint64_t*);
 int mgo_sketch_genomes(const uint8_t*, const uint64_t*, uint64_t, int, uint64_t, uint64_t*, uint64_t*);
 int mgo_containment(const uint64_t*, const uint32_t*, uint64_t, int, uint32_t, const uint64_t*, const uint64_t*, uint64_t,
@@ -46,9 +46,9 @@ int main(void) {
     uint32_t* c = (uint32_t*)malloc((total + 1) * 4);
     uint64_t n = 0, seen = 0;
     int trunc = 0;
-    if (mgo_sketch_reads(bases, offs, nreads, k, UINT64_MAX, 0, h, c, total + 1, &n, &trunc, &seen)) return 1;
+    if (mgo_sketch_reads(bases, offs, nreads, k, UINT64_MAX, 0, 0, h, c, total + 1, &n, &trunc, &seen)) return 1;
     uint64_t n2 = 0;
-    if (mgo_sketch_reads(bases, offs, nreads, k, UINT64_MAX / 3, 7, h, c, total + 1, &n2, &trunc, &seen)) return 2;
+    if (mgo_sketch_reads(bases, offs, nreads, k, UINT64_MAX / 3, 7, 3, h, c, total + 1, &n2, &trunc, &seen)) return 2;
     if (n2 > 7) return 3;
     uint64_t* gh = (uint64_t*)malloc((size_t)nreads * 5 * 8 + 8);
     uint64_t go[41];

@@ -1,0 +1,125 @@
+"""A SECOND, independent restatement of stage A / A' / B (test infrastructure only).
+
+oracle/mg_oracle.c is the normative statement of the sketch / containment arithmetic (KMC 3 and CMash are not
+vendored by the reference: /root/reference/.gitignore:5-13), which made one C file the only
+definition of truth for the dominant kernel.  This module states the same definitions again, from the prose of
+DESIGN.md §2 and NOT from the C source, in a deliberately different style so that the two can only agree by
+both being right:
+
+  * MurmurHash3_x64_128 on Python integers (masking to 64 bits), reading the key with int.from_bytes;
+  * sequences split into maximal [ACGTacgt] stretches by a regular expression, upper-cased as strings;
+  * canonical k-mer = min(kmer, reverse_complement(kmer)) on Python strings (str.translate + slicing);
+  * occurrence counting in a dict, saturating at `cs` (kmc -cs<cs>, /root/reference/scripts/select_db.py:50);
+  * containment by set membership.
+
+tests/test_oracle_independent.py checks the C oracle against this on seeded inputs (CPU suite).
+"""
+import re
+
+M64 = (1 << 64) - 1
+_C1 = 0x87C37B91114253D5
+_C2 = 0x4CF5AD432745937F
+RESERVED = M64  # never a sketch member
+
+_RUNS = re.compile(rb"[ACGTacgt]+")
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _rotl(x, r):
+    return ((x << r) | (x >> (64 - r))) & M64
+
+
+def _fmix(v):
+    v ^= v >> 33
+    v = (v * 0xFF51AFD7ED558CCD) & M64
+    v ^= v >> 33
+    v = (v * 0xC4CEB9FE1A85EC53) & M64
+    v ^= v >> 33
+    return v
+
+
+def murmur3_x64_128(key: bytes, seed: int = 0):
+    """(h1, h2) of Appleby's MurmurHash3_x64_128, from the published description of the algorithm."""
+    h1 = h2 = seed & 0xFFFFFFFF
+    n = len(key)
+    full = n - (n % 16)
+    for off in range(0, full, 16):
+        k1 = int.from_bytes(key[off:off + 8], "little")
+        k2 = int.from_bytes(key[off + 8:off + 16], "little")
+        k1 = (_rotl((k1 * _C1) & M64, 31) * _C2) & M64
+        h1 ^= k1
+        h1 = (_rotl(h1, 27) + h2) & M64
+        h1 = (h1 * 5 + 0x52DCE729) & M64
+        k2 = (_rotl((k2 * _C2) & M64, 33) * _C1) & M64
+        h2 ^= k2
+        h2 = (_rotl(h2, 31) + h1) & M64
+        h2 = (h2 * 5 + 0x38495AB5) & M64
+    tail = key[full:]
+    if len(tail) > 8:
+        k2 = int.from_bytes(tail[8:], "little")
+        h2 ^= (_rotl((k2 * _C2) & M64, 33) * _C1) & M64
+    if tail:
+        k1 = int.from_bytes(tail[:8], "little")
+        h1 ^= (_rotl((k1 * _C1) & M64, 31) * _C2) & M64
+    h1 ^= n
+    h2 ^= n
+    h1 = (h1 + h2) & M64
+    h2 = (h2 + h1) & M64
+    h1, h2 = _fmix(h1), _fmix(h2)
+    h1 = (h1 + h2) & M64
+    h2 = (h2 + h1) & M64
+    return h1, h2
+
+
+def canonical_kmers(seq: bytes, k: int):
+    """Every canonical k-mer of `seq` (upper case), in order of occurrence; windows never span a non-ACGT symbol."""
+    for m in _RUNS.finditer(seq):
+        run = m.group().upper()
+        for i in range(len(run) - k + 1):
+            kmer = run[i:i + k]
+            rc = kmer.translate(_COMP)[::-1]
+            yield kmer if kmer <= rc else rc
+
+
+def kmer_hash(kmer: bytes) -> int:
+    return murmur3_x64_128(kmer, 0)[0]
+
+
+def sketch_reads(reads, k, hmax=M64, s=0, cs=0, member=None):
+    """reads: iterable of bytes.  -> (ascending [(hash, count)], truncated, kmers_seen).
+    count = occurrences, saturating at cs when cs > 0; member: optional predicate (the membership pre-filter)."""
+    occ, seen = {}, 0
+    for r in reads:
+        for km in canonical_kmers(r, k):
+            seen += 1
+            h = kmer_hash(km)
+            if h > hmax or h == RESERVED:
+                continue
+            if member is not None and not member(h):
+                continue
+            occ[h] = occ.get(h, 0) + 1
+    items = sorted(occ.items())
+    truncated = bool(s) and len(items) > s
+    if truncated:
+        items = items[:s]
+    if cs:
+        items = [(h, min(c, cs)) for h, c in items]
+    return items, truncated, seen
+
+
+def sketch_genome(seq: bytes, k: int, n: int):
+    """Bottom-n distinct canonical k-mer hashes of one genome, ascending."""
+    hs = {kmer_hash(km) for km in canonical_kmers(seq, k)}
+    hs.discard(RESERVED)
+    return sorted(hs)[:n]
+
+
+def containment(sketch_items, truncated, ci, genome_sketches):
+    """-> [(hits, size)] per genome: size = genome hashes <= bound, hits = those present in the sample at count >= ci."""
+    bound = sketch_items[-1][0] if (truncated and sketch_items) else M64
+    present = {h for h, c in sketch_items if c >= ci}
+    out = []
+    for g in genome_sketches:
+        inb = [h for h in g if h <= bound]
+        out.append((sum(1 for h in inb if h in present), len(inb)))
+    return out

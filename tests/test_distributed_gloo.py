@@ -57,7 +57,8 @@ class OracleEngine:
         order = np.argsort(h, kind="stable")
         h, c = h[order], c[order]
         uh, start = np.unique(h, return_index=True)
-        uc = np.minimum(np.add.reduceat(c, start), 0xFFFFFFFF).astype(np.uint32) if len(h) else np.zeros(0, np.uint32)
+        # counters saturate at cs (the sketch definition): min(sum of min(c_r, cs), cs) == min(sum of c_r, cs)
+        uc = np.minimum(np.add.reduceat(c, start), self.o.DEFAULT_CS).astype(np.uint32) if len(h) else np.zeros(0, np.uint32)
         trunc = bool(any_truncated)
         if any_truncated:
             keep = uh <= np.uint64(bound)

@@ -1,0 +1,117 @@
+"""CPU suite: the C oracle (oracle/mg_oracle.c) against the independent pure-Python restatement (tests/indep_sketch.py).
+
+Stage A/B parity is "unpinned" (KMC 3 / CMash are absent from the reference tree): nothing here makes
+it green.  What this removes is single-implementation risk: the two restatements were written from the same prose
+ in different styles and must agree bit for bit, MurmurHash3 included.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import indep_sketch as ind
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_independent_murmur3_matches_the_known_answers():
+    with open(os.path.join(HERE, "golden", "murmur3_kat.json")) as fh:
+        kat = json.load(fh)
+    assert len(kat) >= 56
+    for v in kat:
+        assert ind.murmur3_x64_128(bytes.fromhex(v["hex"]), v["seed"]) == (v["h1"], v["h2"]), v["hex"]
+    # the one value published in mmh3's README: mmh3.hash64("foo") == (-2129773440516405919, 9128664383759220103)
+    h1, h2 = ind.murmur3_x64_128(b"foo", 0)
+    assert (h1 - (1 << 64), h2) == (-2129773440516405919, 9128664383759220103)
+
+
+def _reads(rng, n, lo, hi, p_n=0.01, p_lower=0.1):
+    out = []
+    for _ in range(n):
+        ln = int(rng.integers(lo, hi + 1))
+        b = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=ln).astype(np.uint8)
+        b[rng.random(ln) < p_n] = ord("N")
+        m = rng.random(ln) < p_lower
+        b[m] |= 0x20
+        out.append(b.tobytes())
+    return out
+
+
+def _flat(reads):
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return np.frombuffer(b"".join(reads), dtype=np.uint8), offs
+
+
+@pytest.mark.parametrize("k", [1, 4, 21, 32, 33, 51, 60, 64])
+@pytest.mark.parametrize("cs", [0, 3])
+def test_read_sketch_c_oracle_equals_independent(oracle_lib, k, cs):
+    rng = np.random.default_rng(1000 + k)
+    # ragged reads incl. shorter than k and empty, N and lower case; a repeated read so that counts exceed cs
+    reads = _reads(rng, 60, 0, 150) + [b"", b"ACGT", b"N" * 70]
+    reads += [reads[3]] * 5
+    bases, offs = _flat(reads)
+    for hmax, s in ((ind.M64, 0), (int(0.3 * 2 ** 64), 0), (ind.M64, 37)):
+        oh, oc, otr, oseen = oracle_lib.sketch_reads(bases, offs, k, hmax=hmax, s=s, cs=cs)
+        items, tr, seen = ind.sketch_reads(reads, k, hmax=hmax, s=s, cs=cs)
+        assert [int(x) for x in oh] == [h for h, _ in items]
+        assert [int(x) for x in oc] == [c for _, c in items]
+        assert (otr, oseen) == (tr, seen)
+
+
+def test_strand_and_case_invariance_of_both(oracle_lib):
+    rng = np.random.default_rng(5)
+    reads = _reads(rng, 20, 80, 120, p_n=0.0, p_lower=0.0)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    flipped = [r.translate(comp)[::-1].lower() for r in reads]
+    a, _, _ = ind.sketch_reads(reads, 31)
+    b, _, _ = ind.sketch_reads(flipped, 31)
+    assert a == b
+    bb, bo = _flat(flipped)
+    oh, oc, _, _ = oracle_lib.sketch_reads(bb, bo, 31, cs=0)
+    assert [int(x) for x in oh] == [h for h, _ in a] and [int(x) for x in oc] == [c for _, c in a]
+
+
+@pytest.mark.parametrize("k", [21, 33, 60])
+def test_genome_sketch_and_containment_c_oracle_equals_independent(oracle_lib, k):
+    rng = np.random.default_rng(77 + k)
+    genomes = _reads(rng, 6, 1500, 2500, p_n=0.002, p_lower=0.05) + [b"ACGT" * 3]  # the last one shorter than most k
+    n = 120
+    gb, go = _flat(genomes)
+    dbh, dbo = oracle_lib.sketch_genomes(gb, go, k, n)
+    want = [ind.sketch_genome(g, k, n) for g in genomes]
+    for g, w in enumerate(want):
+        assert [int(x) for x in dbh[int(dbo[g]):int(dbo[g + 1])]] == w
+    # reads from genomes 1 and 4, twice each so that ci = 2 is met, plus noise
+    reads = []
+    for g in (1, 4):
+        src = genomes[g]
+        for _ in range(40):
+            a = int(rng.integers(0, len(src) - 150))
+            reads += [src[a:a + 150]] * 2
+    reads += _reads(rng, 30, 100, 150)
+    rb, ro = _flat(reads)
+    hmax = int(dbh.max())
+    for s in (0, 150):
+        oh, oc, otr, _ = oracle_lib.sketch_reads(rb, ro, k, hmax=hmax, s=s)
+        items, tr, _ = ind.sketch_reads(reads, k, hmax=hmax, s=s, cs=oracle_lib.DEFAULT_CS)
+        assert [int(x) for x in oh] == [h for h, _ in items] and otr == tr
+        hits, sizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
+        assert [(int(h), int(z)) for h, z in zip(hits, sizes)] == ind.containment(items, tr, 2, want)
+    assert hits[1] > hits[0] and hits[4] > hits[0]
+
+
+def test_filtered_sketch_c_oracle_equals_independent(oracle_lib):
+    rng = np.random.default_rng(9)
+    k = 21
+    genomes = _reads(rng, 4, 3000, 3000, p_n=0.0, p_lower=0.0)
+    gb, go = _flat(genomes)
+    dbh, _ = oracle_lib.sketch_genomes(gb, go, k, 200)
+    reads = [genomes[2][i:i + 100] for i in range(0, 2900, 7)] + _reads(rng, 50, 100, 100)
+    rb, ro = _flat(reads)
+    hmax = int(dbh.max())
+    oh, oc, otr, _ = oracle_lib.sketch_reads_filtered(rb, ro, k, dbh, hmax=hmax)
+    bits, mask = oracle_lib.filter_bits(dbh)
+    items, tr, _ = ind.sketch_reads(reads, k, hmax=hmax, cs=oracle_lib.DEFAULT_CS, member=lambda h: bool(bits[h & int(mask)]))
+    assert [int(x) for x in oh] == [h for h, _ in items] and [int(x) for x in oc] == [c for _, c in items]
