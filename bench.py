@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — 150 bp reads/s end-to-end (CMash-style filter + profile) on N MI355X.
+"""bench.py — 150 bp reads/s through the hot path (CMash-style filter + profile) on N MI355X, inputs resident in HBM.
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-    stage A  read sketch        (k_sketch_reads + sort + run-length)      scripts/select_db.py:50-52,73-76
-    stage B  containment        (k_containment vs the genome sketch table) scripts/select_db.py:54-56,73-76
-    stage C  assign + histogram (k_profile_*)                              scripts/map_and_profile.py:193-264
-N = 1 runs BASELINE.json configs[1]: 1M synthetic 150 bp reads vs a 1k-genome sketch DB, k = 21.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds its own 1M reads and
-alignment records (weak scaling), the genome sketch table is sharded by genome, read sketches are
-all-gathered and merged, and one all-reduce carries containment hits and per-taxon counts
-(metalign_amd/distributed.py).
+    stage A  read sketch, every k of the config (k_sketch_reads* + bucket sort / pack)   scripts/select_db.py:50-52,73-76
+    stage B  containment per k (k_contain_pairs vs the genome sketch table of that k)     scripts/select_db.py:54-56,73-76
+    stage C  assign + histogram (k_profile_pass), once                                    scripts/map_and_profile.py:193-264
+File I/O, PCIe, on-device ingest and the host CAMI tail are NOT in the timed region; `with_ingest` reports the kept
+command line end to end (files on disk -> subset DB / CAMI profile) on a 1M-read sample as a secondary figure.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_sketch_reads; `cpu_baseline` is the
-CPU oracle (oracle/, a scalar C port) timed on this host's cores (one contiguous share of a bounded sample per
-thread, up to 64) — a baseline, not the target.
+Workloads = BASELINE.json configs:
+  --config 1   1M reads vs 1k genomes (50 kb), k = 21                                  (the reference-sized case)
+  --config 2   10M reads vs 10k genomes (50 kb), K = {21,31,51}, 12.5M alignment records, 10 001 taxa
+               = the largest single-GPU configuration: the DEFAULT at N = 1
+  --config 3   12.5M reads PER GPU vs a 200k-genome table (5 kb genomes: the dense regime), K = {21,31,51}, the table
+               and the sample sketch sharded by hash range over the N ranks; at N = 8 this is configs[3]
+               (100M reads): the DEFAULT at N > 1 (weak scaling in reads, the table is fixed)
+  --config 4   config 3 + the CAMI profile of the reduced counts written once after the timed region (configs[4])
+N > 1 is launched by torch.distributed.run, one rank per GPU (metalign_amd/distributed.py: reads and records sharded
+contiguously, sketch tables AND sample sketches sharded by hash range; per pass one all-gather of a few words, one
+all-to-all round of sketch slices, one all-reduce(sum, int64) of hits / sizes / per-taxon counts).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel family (k_sketch_reads*) against HBM with the
+algorithmic bytes of SURVEY.md §8(d) — 158 B per read, ONE pass for all k — and, because that kernel is integer-VALU
+bound, also gives `valu_frac` (VALU issue cycles / all SIMD cycles of the launch); `kernels` does the same for stage B
+and stage C.  `cpu_baseline` is the C oracle (oracle/, a scalar port) on this host's cores over a bounded sample; the
+same sample goes through the GPU path once more, untimed, and `check.oracle_equal` says whether every containment
+count and every per-taxon accumulator came out identical.
 """
 import argparse
 import json
@@ -26,61 +38,110 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_READ_K1 = 158  # 150 B of bases + 8 B offset, one pass
+ALGO_BYTES_PER_READ_K1 = 158  # 150 B of bases + 8 B offset, one pass for all k
+ALGO_BYTES_PER_RECORD_K3 = 16
 HBM_PEAK_GBS = 8000.0
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+
+PRESETS = {
+    1: dict(reads=1_000_000, genomes=1000, genome_len=50_000, ks=[21], ntax=None,
+            name="configs[1]: 1M synthetic 150bp reads vs 1k-genome sketch DB, k=21"),
+    2: dict(reads=10_000_000, genomes=10_000, genome_len=50_000, ks=[21, 31, 51], ntax=None,
+            name="configs[2]: 10M reads vs 10k-genome DB, multi-k {21,31,51} containment"),
+    3: dict(reads=12_500_000, genomes=200_000, genome_len=5_000, ks=[21, 31, 51], ntax=10_001,
+            name="configs[3]: 12.5M reads/GPU (100M at 8 GPUs) vs RefSeq-scale 200k-genome sketch DB sharded by hash range"),
+    4: dict(reads=12_500_000, genomes=200_000, genome_len=5_000, ks=[21, 31, 51], ntax=10_001,
+            name="configs[4]: configs[3] + alignment replay -> full CAMI profile"),
+}
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
-    p.add_argument("--genomes", type=int, default=1000)
-    p.add_argument("--genome_len", type=int, default=50_000)
-    p.add_argument("--k", type=int, default=21)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json config (0: 2 at N=1, 3 at N>1)")
+    p.add_argument("--reads", type=int, default=0, help="reads per GPU (overrides the preset)")
+    p.add_argument("--genomes", type=int, default=0)
+    p.add_argument("--genome_len", type=int, default=0)
+    p.add_argument("--ks", type=str, default="", help="comma-separated k-mer sizes (overrides the preset)")
     p.add_argument("--sketch_n", type=int, default=1000)
-    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_cpu_baseline", action="store_true", help="also skips the oracle check (it shares the sample)")
     p.add_argument("--cpu_seconds", type=float, default=15.0, help="target CPU-baseline duration")
     p.add_argument("--no_kernel_table", action="store_true", help="skip the extra instrumented steps (clean traces)")
-    return p.parse_args()
+    p.add_argument("--no_secondary", action="store_true", help="skip the configs[1] secondary line and the with-ingest figure")
+    a = p.parse_args()
+    return a
 
 
-def build_workload(args, rank, hip):
+def resolve_config(args, world):
+    cfg = args.config or (2 if max(world, args.gpus) == 1 else 3)
+    pre = dict(PRESETS[cfg])
+    if args.reads:
+        pre["reads"] = args.reads
+    if args.genomes:
+        pre["genomes"] = args.genomes
+    if args.genome_len:
+        pre["genome_len"] = args.genome_len
+    if args.ks:
+        pre["ks"] = [int(x) for x in args.ks.split(",")]
+    pre["custom"] = bool(args.reads or args.genomes or args.genome_len or args.ks)
+    pre["config"] = cfg
+    return pre
+
+
+def build_workload(cfg, sketch_n, rank, hip):
     """Synthetic inputs, generated on the host once and left resident in HBM."""
     from metalign_amd import synth
-    gb, go = synth.make_genomes(args.genomes, args.genome_len)
+    G = cfg["genomes"]
+    gb, go = synth.make_genomes(G, cfg["genome_len"])  # the same table on every rank
     # 50 present genomes at configs[1] (1k genomes); one genome in 20 for the larger tables, so that the coverage per
     # present genome stays in a metagenome's range instead of growing into the thousands
-    npresent = max(50, args.genomes // 20)
-    rb, ro, src = synth.make_reads(gb, go, args.reads, npresent=npresent, seed=synth.SEED + 1 + 1000 * rank)
-    # accession rows: 0 = 'Unmapped', 1..G = one accession per genome; taxon row == accession row
-    recs = synth.make_alignment_records(src + 1, args.genomes + 1, seed=synth.SEED + 2 + 1000 * rank)
-    ref2tax = np.arange(args.genomes + 1, dtype=np.uint32)
-    dbh, dbo = hip.sketch_genomes(gb, go, args.k, args.sketch_n)  # stage A' on the GPU (not timed)
-    return dict(gb=gb, go=go, rb=rb, ro=ro, src=src, recs=recs, ref2tax=ref2tax, dbh=dbh, dbo=dbo)
+    npresent = max(50, G // 20)
+    rb, ro, src = synth.make_reads(gb, go, cfg["reads"], npresent=npresent, seed=synth.SEED + 1 + 1000 * rank)
+    # accession rows: 0 = 'Unmapped', 1..G = one accession per genome
+    recs = synth.make_alignment_records(src + 1, G + 1, seed=synth.SEED + 2 + 1000 * rank)
+    if cfg["ntax"] is None:
+        ref2tax = np.arange(G + 1, dtype=np.uint32)  # taxon row == accession row
+    else:
+        # the aligner runs against the SUBSET db that the pre-filter selected (10^2..10^4 taxa, SURVEY.md §8): dense ids
+        ref2tax = (np.arange(G + 1, dtype=np.uint64) % np.uint64(cfg["ntax"])).astype(np.uint32)
+    tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in cfg["ks"]]  # stage A' on the GPU (not timed)
+    return dict(rb=rb, ro=ro, src=src, recs=recs, ref2tax=ref2tax, ntax=int(ref2tax.max()) + 1,
+                dbh=[t[0] for t in tables], dbo=[t[1] for t in tables])
 
 
-def cpu_baseline(args, w):
-    """The CPU oracle on a bounded sample of the same workload, on every host core: the sample is cut into one
-    contiguous share of reads (+ their alignment records) per thread — the same sharding the GPUs use, without the
-    edge fix-up of the carried state, which a timing does not need — then merged and run against the full table.
-    (ctypes releases the GIL inside the C oracle; threads, not processes: this process has initialised the GPU.)
-    The single-core rate of the same code is reported beside it."""
+def make_job(hip, dist, rank, world, cfg, w, force_dist=False, sub=None):
+    from metalign_amd import distributed as mgd
+    job = mgd.ShardJob(hip, dist, rank, world, k=cfg["ks"], ci=2, pct_id=0.5, always_exchange=force_dist)
+    rb, ro, recs = (w["rb"], w["ro"], w["recs"]) if sub is None else sub
+    job.load(rb, ro, recs, w["ref2tax"], w["dbh"], w["dbo"], ntax=w["ntax"])
+    return job
+
+
+def cpu_baseline_and_check(args, cfg, w, hip):
+    """The CPU oracle on a bounded sample of the same workload (the first n reads and their alignment records) on every
+    host core: the sample is cut into one contiguous share per thread (ctypes releases the GIL inside the C oracle;
+    threads, not processes: this process has initialised the GPU); per share the read sketch of every k and stage C
+    (the additive part: a timing does not need the edge fix-up of the carried state); then the shares' sketches are
+    merged per k and run against the full tables.  The single-core rate of the same code is reported beside it.
+    The SAME sample then goes through the GPU path once (untimed) and everything is compared: hits and sizes of every
+    genome for every k, count / bases / first_seen of every taxon, tot_rds, n_ambig."""
     import oracle
     from concurrent.futures import ThreadPoolExecutor
     oracle.build()
-    hmax = int(w["dbh"].max())
+    ks = cfg["ks"]
+    hmaxs = [int(h.max()) for h in w["dbh"]]
     leaders = np.cumsum(w["recs"]["ref_new"] >> 31)
-    ntax = len(w["ref2tax"])
+    nreads_all = len(w["ro"]) - 1
 
     def share(lo, hi):  # reads [lo, hi) and their records
         b0, b1 = int(w["ro"][lo]), int(w["ro"][hi])
         r0 = int(np.searchsorted(leaders, lo, side="right"))
         r1 = int(np.searchsorted(leaders, hi, side="right"))
-        qh, qc, _, _ = oracle.sketch_reads(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo], args.k, hmax=hmax)
-        prof = oracle.profile_assign(w["recs"][r0:r1], w["ref2tax"], ntax, 0.5) if r1 > r0 else None
-        return qh, qc, prof
+        sk = [oracle.sketch_reads(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo], k, hmax=hm)[:2] for k, hm in zip(ks, hmaxs)]
+        prof = oracle.profile_assign(w["recs"][r0:r1], w["ref2tax"], w["ntax"], 0.5) if r1 > r0 else None
+        return sk, prof
 
     def run(nreads, cores):
         t0 = time.perf_counter()
@@ -90,41 +151,80 @@ def cpu_baseline(args, w):
         else:
             with ThreadPoolExecutor(cores) as ex:
                 parts = list(ex.map(lambda i: share(cuts[i], cuts[i + 1]), range(cores)))
-        allh = np.concatenate([p[0] for p in parts])
-        allc = np.concatenate([p[1] for p in parts]).astype(np.uint64)
-        uh, inv = np.unique(allh, return_inverse=True)
-        uc = np.minimum(np.bincount(inv, weights=allc, minlength=len(uh)), 0xFFFFFFFF).astype(np.uint32)
-        oracle.containment(uh, uc, False, 2, w["dbh"], w["dbo"])
-        count = sum(p[2]["count"] for p in parts if p[2] is not None)  # the additive part of stage C
-        del count
-        return time.perf_counter() - t0
+        res = []
+        for ki in range(len(ks)):
+            allh = np.concatenate([p[0][ki][0] for p in parts])
+            allc = np.concatenate([p[0][ki][1] for p in parts]).astype(np.uint64)
+            uh, inv = np.unique(allh, return_inverse=True)
+            uc = np.minimum(np.bincount(inv, weights=allc, minlength=len(uh)), oracle.DEFAULT_CS).astype(np.uint32)
+            res.append(oracle.containment(uh, uc, False, 2, w["dbh"][ki], w["dbo"][ki]))
+        return time.perf_counter() - t0, res
 
     cores = max(1, min(os.cpu_count() or 1, 64))
-    probe = min(20000, args.reads)
-    t1 = run(probe, 1)
+    probe = min(20000, nreads_all)
+    t1, _ = run(probe, 1)
     single = probe / t1
-    n = int(min(args.reads, max(probe, single * cores * 0.7 * args.cpu_seconds)))
-    t = run(n, cores)
-    return {"value": n / t, "unit": "reads/s", "cores": cores, "kind": "port",
-            "single_core_value": single,
-            "sample": "%d of the %d reads (+ their alignment records) in %d contiguous shares, one thread each, merged "
-                      "and run against the full %d-genome table; C oracle, %.1f s" % (n, args.reads, cores, args.genomes, t)}
+    n = int(min(nreads_all, max(probe, single * cores * 0.7 * args.cpu_seconds)))
+    t, want_hs = run(n, cores)
+    base = {"value": n / t, "unit": "reads/s", "cores": cores, "kind": "port", "single_core_value": single,
+            "sample": "the first %d of the %d reads (%.1f %%) + their alignment records in %d contiguous shares, one thread "
+                      "each: read sketches for k in %s, merged, containment against the full %d-genome tables, stage C; "
+                      "C oracle, %.1f s" % (n, nreads_all, 100.0 * n / nreads_all, cores, ks, cfg["genomes"], t)}
+    # ---- the same sample through the GPU path (one job, one step), against the oracle ----
+    b1 = int(w["ro"][n])
+    r1 = int(np.searchsorted(leaders, n, side="right"))
+    sub = (w["rb"][:b1], w["ro"][: n + 1], w["recs"][:r1])
+    want_c = oracle.profile_assign(sub[2], w["ref2tax"], w["ntax"], 0.5)  # exact (sequential) stage C of the sample
+    job = make_job(hip, None, 0, 1, cfg, w, sub=sub)
+    got = job.step()
+    bad = []
+    for ki, k in enumerate(ks):
+        if not np.array_equal(got["hits_k"][ki], want_hs[ki][0]):
+            bad.append("hits k=%d" % k)
+        if not np.array_equal(got["sizes_k"][ki], want_hs[ki][1]):
+            bad.append("sizes k=%d" % k)
+    for key in ("count", "bases", "first_seen"):
+        if not np.array_equal(got[key], want_c[key]):
+            bad.append(key)
+    if (got["tot_rds"], got["n_ambig"]) != (want_c["tot_rds"], want_c["n_ambig"]):
+        bad.append("tot_rds/n_ambig")
+    check = {"oracle_equal": not bad, "mismatch": bad,
+             "compared": "hits and sizes of all %d genomes for k in %s; count / bases / first_seen of all %d taxa; tot_rds; "
+                         "n_ambig — GPU path vs C oracle on the cpu_baseline sample (%d reads, %d records)"
+                         % (cfg["genomes"], ks, w["ntax"], n, r1)}
+    return base, check
 
 
-def pmc_traffic(args):
-    """HBM bytes per k_sketch_reads launch from the committed rocprofv3 PMC passes (a benchmark cannot profile
-    itself): profiles/<round>/pmc_traffic.json, newest round whose workload matches this run; else None."""
+def committed_profile(name, cfg):
+    """Per-launch counters of the committed rocprofv3 PMC passes (a benchmark cannot profile itself):
+    profiles/<round>/<name>, newest round whose workload matches this run; else None."""
     pdir = os.path.join(ROOT, "profiles")
     best = None
     for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, rnd, "pmc_traffic.json")
+        f = os.path.join(pdir, rnd, name)
         if os.path.exists(f):
             with open(f) as fh:
                 d = json.load(fh)
             wl = d.get("workload", {})
-            if (wl.get("reads"), wl.get("genomes"), wl.get("k")) == (args.reads, args.genomes, args.k):
-                best = d["k_sketch_reads"]["hbm_bytes_per_launch"]
+            if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")])) == (cfg["reads"], cfg["genomes"], cfg["ks"]):
+                best = d
     return best
+
+
+def secondary_config1(hip, args):
+    """configs[1] (1M reads, 1k genomes, k = 21) in the same process: reads/s of the pipelined passes."""
+    cfg = dict(PRESETS[1], config=1)
+    w = build_workload(cfg, args.sketch_n, 0, hip)
+    job = make_job(hip, None, 0, 1, cfg, w)
+    job.run(60)
+    hip.sync()
+    steps = 200
+    t0 = time.perf_counter()
+    job.run(steps)
+    hip.sync()
+    dt = time.perf_counter() - t0
+    return {"workload": cfg["name"], "value": cfg["reads"] / (dt / steps), "unit": "reads/s", "ms_per_step": 1e3 * dt / steps,
+            "steps": steps}
 
 
 def main():
@@ -149,10 +249,10 @@ def main():
         from metalign_amd._hip import Hip
         hip = Hip.get(0)
 
-    w = build_workload(args, rank, hip)
-    from metalign_amd import distributed as mgd
-    job = mgd.ShardJob(hip, dist, rank, world, k=args.k, ci=2, pct_id=0.5, always_exchange=force_dist)
-    job.load(w["rb"], w["ro"], w["recs"], w["ref2tax"], w["dbh"], w["dbo"])
+    cfg = resolve_config(args, world)
+    w = build_workload(cfg, args.sketch_n, rank, hip)
+    job = make_job(hip, dist, rank, world, cfg, w, force_dist)
+    nreads, nrecs, K = cfg["reads"], len(w["recs"]), len(cfg["ks"])
 
     def sync():
         hip.sync()
@@ -163,9 +263,9 @@ def main():
             torch.cuda.synchronize()
 
     # The GPU has idled through the workload generation above and takes tens of milliseconds of work to come back to
-    # full clocks (measured: 20 timed passes after 4 warm-up passes 0.624 ms each, after 50 warm-up passes 0.580):
-    # untimed ramp-up passes first, so that the figure does not depend on how small W is; then the W warm-up passes.
-    job.run(max(0, 60 - args.warmup))
+    # full clocks: untimed ramp-up passes first (about 0.1 s of GPU time), so that the figure does not depend on how
+    # small W is; then the W warm-up passes.
+    job.run(max(2, int(2e6 * 60 / max(nreads * K, 1))))
     sync()
     job.run(args.warmup)
     sync()
@@ -177,12 +277,22 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     nk1, k1_ms = hip.prof_get("sketch_reads")
-    # per-kernel table from a few extra, untimed steps with every kernel family instrumented
-    hip.prof_reset()
-    hip.prof_enable(True)
-    for _ in range(0 if args.no_kernel_table else min(args.steps, 5)):
-        job.step()
-    sync()
+    # per-kernel table from a few extra, untimed steps on ONE stream (nothing overlaps: clean per-family times)
+    kernels_ms = {}
+    if not args.no_kernel_table:
+        hip.prof_reset()
+        hip.prof_enable(True)
+        hip.stage_c_side_stream(False)
+        nt = min(args.steps, 3)
+        for _ in range(nt):
+            job.step()
+        sync()
+        hip.stage_c_side_stream(True)
+        for name in ("table_clear", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort",
+                     "sketch_rle", "contain_index", "containment", "profile_map", "profile_pass"):
+            n, t = hip.prof_get(name)
+            if n:
+                kernels_ms[name] = {"ms_per_pass": round(t / nt, 4), "launches_per_pass": n / nt}
     hip.prof_enable(False)
     if dist is not None:
         import torch
@@ -192,17 +302,37 @@ def main():
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
-        k1_avg = k1_ms / max(nk1, 1)
-        achieved = ALGO_BYTES_PER_READ_K1 * args.reads / (k1_avg * 1e-3) / 1e9 if nk1 else 0.0
-        kernels = {}
-        for name in ("table_clear", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort", "sketch_rle", "contain_index", "containment", "profile_map",
-                     "profile_pass"):
-            n, t = hip.prof_get(name)
-            if n:
-                kernels[name] = round(t / n, 4)
+        k1_per_pass_ms = k1_ms / max(args.steps, 1)  # all k of one pass (one fused launch, or one launch per k)
+        launches_per_pass = nk1 / max(args.steps, 1)
+        algo_k1 = ALGO_BYTES_PER_READ_K1 * nreads
+        achieved = algo_k1 / (k1_per_pass_ms * 1e-3) / 1e9 if nk1 else 0.0
+        traffic = committed_profile("pmc_traffic.json", cfg)
+        sq = committed_profile("pmc_sq_summary.json", cfg)
+        valu_insts = sq["k_sketch_reads"]["SQ_INSTS_VALU_per_pass"] if sq else None
+        roof = {"kernel": "k_sketch_reads* (stage A, all k of the pass: %.0f launch(es) per pass)" % launches_per_pass,
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic["k_sketch_reads"]["hbm_bytes_per_pass"] if traffic else None,
+                "avg_launch_ms": k1_ms / max(nk1, 1), "ms_per_pass": k1_per_pass_ms,
+                "algorithmic_bytes_per_pass": algo_k1,
+                "valu_frac": (valu_insts * 4.0 / (SIMDS * CLOCK_HZ * k1_per_pass_ms * 1e-3)) if (valu_insts and nk1) else None,
+                "valu_insts_per_pass": valu_insts,
+                "note": "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU (committed SQ pass "
+                        "of this workload) x 4 cycles / (1024 SIMDs x 2.4 GHz x the live launch time) is the figure that "
+                        "describes it; frac prices 158 B/read, one pass for all k, against 8 TB/s"}
+        kern = []
+        if "containment" in kernels_ms:
+            t_b = kernels_ms["containment"]["ms_per_pass"] + kernels_ms.get("contain_index", {}).get("ms_per_pass", 0.0)
+            algo = sum(int(len(h)) for h in w["dbh"]) * 8 // max(world, 1)
+            kern.append({"kernel": "k_contain_pairs (+ index, reduce), all k", "algorithmic_bytes_per_pass": algo, "ms_per_pass": t_b,
+                         "achieved_GBs": algo / (t_b * 1e-3) / 1e9, "frac": algo / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm"})
+        if "profile_pass" in kernels_ms:
+            t_c = kernels_ms["profile_pass"]["ms_per_pass"]
+            algo = ALGO_BYTES_PER_RECORD_K3 * nrecs
+            kern.append({"kernel": "k_profile_pass", "algorithmic_bytes_per_pass": algo, "ms_per_pass": t_c,
+                         "achieved_GBs": algo / (t_c * 1e-3) / 1e9, "frac": algo / (t_c * 1e-3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm"})
         res = {
             "metric": "150bp reads/s end-to-end (CMash filter + profile)",
-            "value": args.reads * world / (dt / args.steps),
+            "value": nreads * world / (dt / args.steps),
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -213,22 +343,31 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%d synthetic 150bp reads/GPU vs %d-genome sketch DB (n=%d), k=%d, "
-                                   "%d alignment records/GPU, 1 MI355X per rank"
-                                   % (args.reads, args.genomes, args.sketch_n, args.k, len(w["recs"])),
-                       "parallelism": "reads + alignment records sharded x%d, read sketch and sketch table sharded by hash range" % world},
-            "roofline": {"kernel": "k_sketch_reads<%d>" % args.k, "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
-                         "avg_launch_ms": k1_avg, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ_K1 * args.reads,
-                         "note": "integer-ALU bound (MurmurHash3 per k-mer), see DESIGN.md"},
-            "kernel_avg_ms": kernels,
-            "kernel_note": "HIP-event time per kernel family from extra instrumented steps; profile_pass runs on the "
-                           "library's second stream concurrently with sketch_reads, so its figure includes waiting for CUs "
-                           "(0.06 ms when it runs alone)",
-            "check": {"top_genomes_recovered": out.get("top_ok"), "tot_rds": out.get("tot_rds")},
+            "config": {"workload": "%s%s — %d synthetic 150bp reads/GPU vs %d-genome sketch DB (%d bp genomes, n=%d), "
+                                   "k in %s, %d alignment records/GPU, %d taxa, 1 MI355X per rank; inputs resident in HBM"
+                                   % (cfg["name"], " [custom sizes]" if cfg["custom"] else "", nreads, cfg["genomes"],
+                                      cfg["genome_len"], args.sketch_n, cfg["ks"], nrecs, w["ntax"]),
+                       "baseline_config": cfg["config"],
+                       "parallelism": "reads + alignment records sharded x%d, read sketches and sketch tables sharded by hash range" % world},
+            "roofline": roof,
+            "kernels": kern,
+            "kernel_ms_per_pass": kernels_ms,
+            "kernel_note": "HIP-event time per kernel family from extra untimed steps with everything on ONE stream (nothing "
+                           "overlaps); the timed passes themselves are pipelined over three streams",
+            "sanity": {"top_genomes_recovered": out.get("top_ok"), "tot_rds": out.get("tot_rds"),
+                       "sketch_sizes": out.get("sketch_sizes")},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
-            res["cpu_baseline"] = cpu_baseline(args, w)
+            res["cpu_baseline"], res["check"] = cpu_baseline_and_check(args, cfg, w, hip)
+        if not args.no_secondary and world == 1 and cfg["config"] != 1:
+            del job
+            res["secondary"] = secondary_config1(hip, args)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_cli
+                res["with_ingest"] = bench_cli.measure(1_000_000)
+            except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline down)
+                res["with_ingest"] = {"error": repr(e)}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -665,6 +665,12 @@ class Hip:
         sk.filt = filt
         return sk
 
+    def sketch_reads_multi_dev_async(self, d_bases, d_offsets, nreads, ks, hmaxs, s=0, filts=None):
+        """The read sketches for several k from ONE pass over the reads (the reference's query is multi-k: `30-60-10`,
+        select_db.py:75): -> [Sketch per k], every one pending like sketch_reads_dev_async's."""
+        filts = list(filts) if filts is not None else [None] * len(ks)
+        return [self.sketch_reads_dev_async(d_bases, d_offsets, nreads, k, hm, s, filt=f) for k, hm, f in zip(ks, hmaxs, filts)]
+
     def sketch_from_pairs_dev(self, d_hashes, d_counts, n, k, s=0, any_truncated=False, bound=U64_MAX):
         h = _vp()
         self._chk(self.lib.mg_sketch_from_pairs_dev(_vp(d_hashes), _vp(d_counts), ctypes.c_uint64(n),

@@ -61,7 +61,7 @@ struct Context {
   uint64_t* pinned = nullptr;
   // landing words of sketches whose finalisation is deferred (mg_sketch_reads_dev_async): kPendSlots x 8 words
   uint64_t* pend_pinned = nullptr;
-  static constexpr unsigned kPendSlots = 16;  // (a pipelined exchange keeps up to ~8 pending: fronts + merged slices)
+  static constexpr unsigned kPendSlots = 64;  // (a pipelined multi-k exchange keeps ~8 per k pending: fronts + merged slices)
   struct ::mg_sketch* pend_owner[kPendSlots] = {};
   unsigned pend_next = 0;
 };

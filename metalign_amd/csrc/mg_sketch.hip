@@ -840,7 +840,16 @@ int sketch_wait(const mg_sketch* sk) {
   return MG_OK;
 }
 
-static double distinct_hint = 1.0;  // distinct / expected candidates of the previous batch (x2), sizes the counting table
+// distinct / expected candidates of the previous batch of the same k (x2): sizes the counting table
+static double distinct_hint_k[MG_MAX_K + 1];
+static bool distinct_hint_init = false;
+static double& distinct_hint_for(int k) {
+  if (!distinct_hint_init) {
+    for (double& v : distinct_hint_k) v = 1.0;
+    distinct_hint_init = true;
+  }
+  return distinct_hint_k[(k >= 0 && k <= MG_MAX_K) ? k : 0];
+}
 
 int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   if (rebuilt) *rebuilt = 0;
@@ -860,7 +869,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   if (overflows == 0) {
     if (!sk->redo.is_merge) {
       const double r = 2.0 * (double)runs / sk->expect;
-      distinct_hint = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
+      distinct_hint_for(sk->redo.k) = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
     }
     return MG_OK;
   }
@@ -875,7 +884,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   }
   // a bucket ran out of slots (more distinct hashes than the hint allowed for): size for the worst case next
   // time and redo this sketch on the list path, which has no such limit
-  distinct_hint = 1.0;
+  distinct_hint_for(sk->redo.k) = 1.0;
   if (rebuilt) *rebuilt = 1;
   sk->index.release();
   sk->hashes.release();
@@ -963,7 +972,7 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   // previous call (x2 for safety) tightens it for steady-state batches.  Under-sizing is detected (a bucket
   // with no free slot) and handled by the list path.
   const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
-  double distinct_est = (double)expect * mg::distinct_hint;
+  double distinct_est = (double)expect * mg::distinct_hint_for(k);
   if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) distinct_est = (double)expect * atof(e);  // tests: force overflow
   TablePlan tp;
   if (!force_list && expect >= 32768 && plan_table(0, hmax, distinct_est, tp)) {

@@ -14,6 +14,11 @@ Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "g
   3. ONE all-reduce(sum, int64) of [containment hits | sizes | per-taxon read counts | bases |
      per-rank first-seen slots | tot_rds, n_ambig] -- hits and sizes are true sums over the hash slices.
      <= a few MB: latency-bound on xGMI, not bandwidth-bound.
+Several k (the reference's query is multi-k: `30-60-10`, scripts/select_db.py:75): every k has its own sketch table,
+membership filter, hash-range bounds and sample sketch; ONE pass hashes the reads for all of them (stage A, fused
+into one launch when the library has the k set instantiated), runs stage B per k and stage C once.  The exchanges
+carry all k together: the per-rank words of every k travel in the one all-gather, the slices of every k in one
+all-to-all round, and the one all-reduce holds [hits | sizes] for every k.
 The compute calls go through an `engine` (HipEngine below: libmetalign_hip.so on this rank's GPU).  The
 CPU tests substitute an oracle-backed engine to check the choreography under gloo; product code never does.
 """
@@ -69,9 +74,12 @@ class HipEngine:
         self.hip = hip
         self.torch = torch_mod  # None in single-process mode: results are returned as numpy arrays
         self.keep = []
+        self.filters = []  # one membership pre-filter per k (set_filter), None = unfiltered
 
     # ---- inputs ----
-    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, dbh, dbo):
+    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables):
+        """tables: one (hashes, offsets[G+1]) per k — this rank's hash-range slice of each sketch table — or, for a
+        table already laid out hash-major on disk (formats.SketchTable.pairs), a dict(pair_hash=, pair_gen=, gsize=)."""
         hip = self.hip
         self.nreads = len(roffsets) - 1
         self.d_rb = hip.array(rbases if len(rbases) else np.zeros(1, np.uint8))
@@ -81,28 +89,37 @@ class HipEngine:
         self.d_recs = hip.array(recs if len(recs) else np.zeros(1, _hip.REC_DTYPE))
         self.d_r2t = hip.array(ref2tax)
         self.nref, self.ntax = len(ref2tax), ntax
-        self.table = hip.upload_table(dbh, dbo)
-        self.ngen_local = len(dbo) - 1
-        self.d_hs = hip.empty(2 * max(self.ngen_local, 1), np.uint32)  # [hits | sizes]: one read-back
+        self.tables = [hip.upload_table_sorted(**t) if isinstance(t, dict) else hip.upload_table(t[0], t[1]) for t in tables]
+        self.nk = len(tables)
+        self.ngen_local = self.tables[0].ngenomes
+        g = self.gpad = max(self.ngen_local, 1)
+        # per k: [hits g | sizes g], all k in one buffer: one read-back
+        self.d_hs = hip.empty(2 * g * self.nk, np.uint32)
         # [count T | bases T | first_seen T | scalars 2]
         self.d_acc = hip.empty(3 * ntax + 2, np.uint64)
         # page-locked landing buffers: a step queues both read-backs behind its kernels and syncs once
-        self.h_hs = hip.pinned(2 * max(self.ngen_local, 1), np.uint32)
+        self.h_hs = hip.pinned(2 * g * self.nk, np.uint32)
         self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
+        self.filters += [None] * (self.nk - len(self.filters))
 
     # ---- stage A ----
-    filter = None
+    def set_filter(self, ki, table_hashes):
+        """Membership pre-filter over ALL hashes of the genome table of k number ki (also on a rank that holds a slice
+        of it): the read sketch keeps only hashes that may be in the table — the reference's `-f ...bf`
+        (select_db.py:70,75)."""
+        self.filters += [None] * (ki + 1 - len(self.filters))
+        self.filters[ki] = self.hip.filter_build(table_hashes)
 
-    def set_filter(self, table_hashes):
-        """Membership pre-filter over ALL hashes of the genome table (also on a rank that holds a slice of it): the
-        read sketch keeps only hashes that may be in the table — the reference's `-f ...bf` (select_db.py:70,75)."""
-        self.filter = self.hip.filter_build(table_hashes)
+    def sketch_local(self, ks, hmaxs, s):
+        sks = self.sketch_local_async(ks, hmaxs, s)
+        for sk in sks:
+            sk.resolve()
+        return sks
 
-    def sketch_local(self, k, hmax, s):
-        return self.hip.sketch_reads_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s, filt=self.filter)
-
-    def sketch_local_async(self, k, hmax, s):
-        return self.hip.sketch_reads_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, k, hmax, s, filt=self.filter)
+    def sketch_local_async(self, ks, hmaxs, s):
+        """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set)."""
+        return self.hip.sketch_reads_multi_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, ks, hmaxs, s,
+                                                     self.filters[: len(ks)])
 
     def export_sketch(self, sk):
         """(hashes int64 tensor, counts int32 tensor) on this rank's device, zero-copy."""
@@ -116,7 +133,7 @@ class HipEngine:
     def merge_sketches(self, hashes_t, counts_t, k, s, any_truncated, bound, hash_range=None):
         """hash_range = (lo, hi) inclusive when every hash is known to lie in it (a hash-range slice)."""
         n = int(hashes_t.numel())
-        self.keep = [hashes_t, counts_t]
+        self.keep.append((hashes_t, counts_t))
         lo, hi = hash_range if hash_range is not None else (1, 0)
         return self.hip.sketch_merge_dev(hashes_t.data_ptr(), counts_t.data_ptr(), n, k, lo, hi, s, any_truncated, bound)
 
@@ -124,28 +141,39 @@ class HipEngine:
         return sk.split(bounds)
 
     # ---- stage B ----
-    def containment(self, sk, ci):
-        g = max(self.ngen_local, 1)
-        self.hip.containment_dev(sk, self.table, ci, self.d_hs.ptr, self.d_hs.ptr + 4 * g)
-        hs = self.d_hs.download()
-        return hs[: self.ngen_local], hs[g: g + self.ngen_local]
+    def _hs_ptrs(self, base_ptr, ki):
+        g = self.gpad
+        return base_ptr + 4 * (2 * g * ki), base_ptr + 4 * (2 * g * ki + g)
 
-    def containment_and_commit_results(self, sk, ci, want_multimapped):
+    def _hs_split(self, hs):
+        g, G = self.gpad, self.ngen_local
+        hs = np.asarray(hs).reshape(self.nk, 2, g)
+        return hs[:, 0, :G].copy(), hs[:, 1, :G].copy()
+
+    def containment(self, sks, ci):
+        """-> (hits[K][G], sizes[K][G]) of this rank's table slices."""
+        for ki, sk in enumerate(sks):
+            self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(self.d_hs.ptr, ki))
+        return self._hs_split(self.d_hs.download())
+
+    def containment_and_commit_results(self, sks, ci, want_multimapped):
         """Stage B's kernels, then BOTH read-backs (containment counts, stage-C accumulators of a commit queued
         earlier with profile_commit_launch) behind them: one synchronisation."""
-        g, T = max(self.ngen_local, 1), self.ntax
+        T = self.ntax
         # the per-genome counts (8 B per genome) are written by the kernel straight into page-locked host memory
-        self.hip.containment_dev(sk, self.table, ci, self.h_hs.ptr, self.h_hs.ptr + 4 * g)
+        for ki, sk in enumerate(sks):
+            self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(self.h_hs.ptr, ki))
         self.hip.stage_c_join()  # the accumulators are read on the main stream: it waits for stage C's stream here
         self.h_acc.fetch_async(self.d_acc.ptr)
         self.hip.sync()
-        if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
-            self.hip.containment_dev(sk, self.table, ci, self.h_hs.ptr, self.h_hs.ptr + 4 * g)
-            self.hip.sync()
-        hs, acc = self.h_hs.array.copy(), self.h_acc.array.copy()
+        for ki, sk in enumerate(sks):
+            if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
+                self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(self.h_hs.ptr, ki))
+                self.hip.sync()
+        hs, acc = self._hs_split(self.h_hs.array), self.h_acc.array.copy()
         mm = self.shard.multimapped() if want_multimapped else None
         self.shard.free()
-        return (hs[: self.ngen_local], hs[g: g + self.ngen_local]), (acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm)
+        return hs, (acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm)
 
     # ---- stage C ----
     def set_sketch_bound(self, sk, truncated, bound):
@@ -180,41 +208,43 @@ class HipEngine:
     # waiting for the host in between.  Two result sets alternate.
     def _result_sets(self):
         if not hasattr(self, "_sets"):
-            hip, g, T = self.hip, max(self.ngen_local, 1), self.ntax
+            hip, g, T = self.hip, self.gpad, self.ntax
             self._sets = [dict(d_acc=self.d_acc, h_acc=self.h_acc, h_hs=self.h_hs, ev=hip.event()),
                           dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
-                               h_hs=hip.pinned(2 * g, np.uint32), ev=hip.event())]
+                               h_hs=hip.pinned(2 * g * self.nk, np.uint32), ev=hip.event())]
         return self._sets
 
-    def queue_pass(self, slot, k, hmax, s, ci, pct_id, side=False):
+    def queue_pass(self, slot, ks, hmaxs, s, ci, pct_id, side=False):
         rs = self._result_sets()[slot]
-        g, T = max(self.ngen_local, 1), self.ntax
+        T = self.ntax
         if side:  # stage A of consecutive passes on alternating streams: pass i+1's overlaps pass i's tail
             self.hip.stage_a_side_stream(1 + (slot & 1))
-        sk = self.sketch_local_async(k, hmax, s)                                                  # stage A
+        sks = self.sketch_local_async(ks, hmaxs, s)                                               # stage A
         shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
                                            self.nref, self.ntax, pct_id)
         base = rs["d_acc"].ptr
         shard.commit(True, True, 0, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8, reset=True)  # stage C (2nd stream)
-        self.hip.containment_dev(sk, self.table, ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)      # stage B (main)
+        for ki, sk in enumerate(sks):                                                             # stage B (main)
+            self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(rs["h_hs"].ptr, ki))
         self.hip.stage_c_join()
         rs["h_acc"].fetch_async(base)
         rs["ev"].record()
-        return dict(slot=slot, sk=sk, shard=shard, ci=ci)
+        return dict(slot=slot, sks=sks, shard=shard, ci=ci)
 
     def finish_pass(self, q, want_multimapped):
         rs = self._result_sets()[q["slot"]]
-        g, T = max(self.ngen_local, 1), self.ntax
+        T = self.ntax
         rs["ev"].synchronize()  # this pass only: the next one may already be running
-        sk, shard = q["sk"], q["shard"]
-        if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
-            self.hip.sync()
-            self.hip.containment_dev(sk, self.table, q["ci"], rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
-            self.hip.sync()
-        hs, acc = rs["h_hs"].array.copy(), rs["h_acc"].array.copy()
+        sks, shard = q["sks"], q["shard"]
+        for ki, sk in enumerate(sks):
+            if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
+                self.hip.sync()
+                self.hip.containment_dev(sk, self.tables[ki], q["ci"], *self._hs_ptrs(rs["h_hs"].ptr, ki))
+                self.hip.sync()
+        hs, acc = self._hs_split(rs["h_hs"].array), rs["h_acc"].array.copy()
         mm = shard.multimapped() if want_multimapped else None
         shard.free()
-        return sk, (hs[: self.ngen_local], hs[g: g + self.ngen_local]), (acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm)
+        return sks, hs, (acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm)
 
     def profile_commit_launch(self, incoming, first_shard, group_base):
         """Asynchronous part of the commit: accumulator reset + the stage-C pass; nothing is read back."""
@@ -234,18 +264,18 @@ class HipEngine:
         self.profile_commit_launch(incoming, first_shard, group_base)
         return self.profile_commit_finish(want_multimapped)
 
-
     # ---- the device side of ShardJob._run_exchange_pipelined (four passes in flight): every method queues work and
     # returns, except the x_wait_* / x_collect ones, which wait for ONE event recorded a tick earlier.
     def x_setup(self, W, G, T, bounds, nslot):
-        hip, g = self.hip, max(self.ngen_local, 1)
-        self._xW, self._xNW, self._xnred = W, W + 7, 2 * G + 2 * T + W * T + 3
+        """bounds: per k, the W+1 hash-range bounds."""
+        hip, g, K = self.hip, self.gpad, self.nk
+        self._xW, self._xNW, self._xnred = W, K * (W + 4) + 3, 2 * K * G + 2 * T + W * T + K + 2
         if not hasattr(self, "_xs"):
             self._xs = [dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
-                             h_hs=hip.pinned(2 * g, np.uint32), h_words=hip.pinned(W * self._xNW, np.int64),
+                             h_hs=hip.pinned(2 * g * K, np.uint32), h_words=hip.pinned(W * self._xNW, np.int64),
                              h_red=hip.pinned(self._xnred, np.int64), h_red_in=hip.pinned(self._xnred, np.int64),
                              d_red=hip.empty(self._xnred, np.int64), ev=hip.event()) for _ in range(nslot)]
-            self._xbounds = hip.array(np.asarray(bounds[1:W] if W > 1 else [0], dtype=np.uint64))
+            self._xbounds = [hip.array(np.asarray(b[1:W] if W > 1 else [0], dtype=np.uint64)) for b in bounds]
 
     def x_begin(self):
         # four of the hashing kernel's five workgroups per CU: with no host wait left in the chain the small kernels
@@ -258,27 +288,29 @@ class HipEngine:
     def x_end(self):
         self.hip.stage_a_side_stream(False)
 
-    def x_front(self, k, hmax, s, pct_id):
-        return dict(sk=self.sketch_local_async(k, hmax, s), shard=self.new_shard_async(pct_id))
+    def x_front(self, ks, hmaxs, s, pct_id):
+        return dict(sks=self.sketch_local_async(ks, hmaxs, s), shard=self.new_shard_async(pct_id))
 
     def x_words(self, P, slot):
-        """This rank's words, assembled on the device from the still pending sketch and the map-only pass."""
+        """This rank's words, assembled on the device from the still pending sketches and the map-only pass."""
         P["rs"] = self._xs[slot]
         W, t = self._xW, self.torch
         word_t = t.empty(self._xNW, dtype=t.int64, device="cuda")
-        P["sk"].slice_words_dev(self._xbounds.ptr, W - 1, word_t.data_ptr())
-        P["shard"].map_words_dev(word_t.data_ptr() + 8 * (W + 4))
+        for ki, sk in enumerate(P["sks"]):
+            sk.slice_words_dev(self._xbounds[ki].ptr, W - 1, word_t.data_ptr() + 8 * ki * (W + 4))
+        P["shard"].map_words_dev(word_t.data_ptr() + 8 * self.nk * (W + 4))
         return word_t
 
     def x_redo_words(self, P, bounds, tail):
-        """Host path, after a table overflow made the published words stale: settle the sketch and cut it again."""
-        sk, W = P["sk"], self._xW
-        sk.resolve()
-        n = sk.size
-        cuts = [0] + self.split_sketch(sk, bounds[1:W]) + [n]
-        last = sk.last_hash
-        word = ([cuts[q + 1] - cuts[q] for q in range(W)]
-                + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, 0] + list(tail))
+        """Host path, after a table overflow made the published words stale: settle the sketches and cut them again."""
+        W, word = self._xW, []
+        for ki, sk in enumerate(P["sks"]):
+            sk.resolve()
+            n = sk.size
+            cuts = [0] + self.split_sketch(sk, bounds[ki][1:W]) + [n]
+            last = sk.last_hash
+            word += [cuts[q + 1] - cuts[q] for q in range(W)] + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, 0]
+        word += list(tail)
         return self.torch.as_tensor(np.asarray(word, dtype=np.int64), device="cuda")
 
     def x_fetch_words(self, P, words_t, hold):
@@ -299,33 +331,37 @@ class HipEngine:
                           reset=True)
 
     def x_merge(self, P, rh, rc, k, lo, hi, any_trunc, bound):
-        P["keep"] = (rh, rc)  # a deferred merge reads its inputs again if it has to be redone
+        P.setdefault("keep", []).append((rh, rc))  # a deferred merge reads its inputs again if it has to be redone
         return self.hip.sketch_merge_dev_async(rh.data_ptr(), rc.data_ptr(), int(rh.numel()), k, lo, hi, 0, any_trunc, bound)
 
     def x_stage_b(self, P, merged, ci):
-        rs, g = P["rs"], max(self.ngen_local, 1)
+        rs = P["rs"]
         P["merged"] = merged
-        self.hip.containment_dev(merged, self.table, ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
+        for ki, m in enumerate(merged):
+            self.hip.containment_dev(m, self.tables[ki], ci, *self._hs_ptrs(rs["h_hs"].ptr, ki))
         self.hip.stage_c_join()
         rs["h_acc"].fetch_async(rs["d_acc"].ptr)
         rs["ev"].record()
 
     def x_collect(self, P, ci, want_multimapped):
-        rs, g, T, G = P["rs"], max(self.ngen_local, 1), self.ntax, self.ngen_local
+        rs, T = P["rs"], self.ntax
         rs["ev"].synchronize()
         merged = P["merged"]
-        P["sk"].free()  # its buffers were the all-to-all's send buffers: back to the pool only now
-        if merged.resolve():
-            self.hip.sync()
-            self.hip.containment_dev(merged, self.table, ci, rs["h_hs"].ptr, rs["h_hs"].ptr + 4 * g)
-            self.hip.sync()
-        hs, acc = rs["h_hs"].array, rs["h_acc"].array
+        for sk in P["sks"]:
+            sk.free()  # their buffers were the all-to-all's send buffers: back to the pool only now
+        for ki, m in enumerate(merged):
+            if m.resolve():
+                self.hip.sync()
+                self.hip.containment_dev(m, self.tables[ki], ci, *self._hs_ptrs(rs["h_hs"].ptr, ki))
+                self.hip.sync()
+        (hits, sizes), acc = self._hs_split(rs["h_hs"].array), rs["h_acc"].array
         mm = P["shard"].multimapped() if want_multimapped else None
-        qn = merged.size
+        qn = [m.size for m in merged]
         P["shard"].free()
-        merged.free()
+        for m in merged:
+            m.free()
         P["keep"] = None
-        return hs[:G], hs[g:g + G], acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm, qn
+        return hits, sizes, acc[:T], acc[T:2 * T], acc[2 * T:3 * T], acc[3 * T:], mm, qn
 
     def x_reduce_buffer(self, P):
         buf = P["rs"]["h_red_in"].array
@@ -350,14 +386,25 @@ class HipEngine:
         return rs["h_red"].array.copy()
 
 
+def table_max_hash(dbh, dbo):
+    """Largest hash of a genome-major table (every genome sketch is ascending: its maximum is its last entry)."""
+    dbo = np.asarray(dbo)
+    tails = dbo[1:][dbo[1:] > dbo[:-1]] - 1
+    return int(np.asarray(dbh)[tails.astype(np.int64)].max()) if len(tails) else 0
+
+
 class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 
     def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None, always_exchange=False):
+        """k: one k-mer size or a sequence of them (ascending; the reference's cutoff reads the largest)."""
         self.dist, self.rank, self.world = dist, rank, world
         # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
         self.exchange = dist is not None and (world > 1 or always_exchange)
-        self.k, self.ci, self.pct_id, self.s = k, ci, pct_id, s
+        self.single_k = np.isscalar(k)
+        self.ks = [int(k)] if self.single_k else [int(x) for x in k]
+        self.k = self.ks[-1]
+        self.ci, self.pct_id, self.s = ci, pct_id, s
         if engine is not None:
             self.engine = engine
             self.torch = engine.torch
@@ -378,19 +425,41 @@ class ShardJob:
             self.engine = HipEngine(hip, tm)
         self.device = getattr(self.engine, "device", "cuda")
 
-    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo, ntax=None):
-        """recs: this rank's shard (starts on a read boundary).  dbh/dbo: the FULL table; sliced here.
+    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo=None, ntax=None):
+        """recs: this rank's shard (starts on a read boundary).
+        Tables, one per k (a single k takes them bare): either dbh / dbo = the FULL genome-major table (hashes,
+        offsets[G+1]), sliced here by hash range; or dbh = a formats.SketchTable whose files are hash-major — then only
+        this rank's hash range [bounds[r], bounds[r+1]) of every k is read from disk (dbo stays None).
         ntax: number of dense taxon ids (default: max(ref2tax) + 1)."""
-        G = len(dbo) - 1
-        self.G = G
+        K = len(self.ks)
         self.T = int(ntax) if ntax is not None else (int(np.max(ref2tax)) + 1 if len(ref2tax) else 0)
-        tails = dbo[1:][dbo[1:] > dbo[:-1]] - 1
-        self.hmax = int(dbh[tails.astype(np.int64)].max()) if len(tails) else 0
-        self.bounds = slice_bounds(self.hmax, self.world)
-        if hasattr(self.engine, "set_filter"):
-            self.engine.set_filter(dbh)  # from the FULL table, before it is sliced
-        if self.world > 1:
-            dbh, dbo = table_slice(dbh, dbo, self.bounds[self.rank], self.bounds[self.rank + 1])
+        tables, self.hmaxs, self.bounds = [], [], []
+        if hasattr(dbh, "pairs"):  # an on-disk hash-major table (formats.SketchTable, version 2)
+            disk = dbh
+            self.G = disk.ngenomes
+            for ki, k in enumerate(self.ks):
+                hmax = disk.max_hash(k)
+                b = slice_bounds(hmax, self.world)
+                self.hmaxs.append(hmax)
+                self.bounds.append(b)
+                if hasattr(self.engine, "set_filter"):
+                    self.engine.set_filter(ki, disk.pairs(k)["pair_hash"])  # ALL hashes of the table (streamed from the map)
+                tables.append(disk.pairs(k, b[self.rank], b[self.rank + 1]))
+        else:
+            per_k = [(dbh, dbo)] if self.single_k else list(zip(dbh, dbo))
+            assert len(per_k) == K, "one (hashes, offsets) table per k"
+            self.G = len(per_k[0][1]) - 1
+            for ki, (h, o) in enumerate(per_k):
+                hmax = table_max_hash(h, o)
+                b = slice_bounds(hmax, self.world)
+                self.hmaxs.append(hmax)
+                self.bounds.append(b)
+                if hasattr(self.engine, "set_filter"):
+                    self.engine.set_filter(ki, h)  # from the FULL table, before it is sliced
+                if self.world > 1:
+                    h, o = table_slice(h, o, b[self.rank], b[self.rank + 1])
+                tables.append((h, o))
+        self.hmax = self.hmaxs[-1]
         has_look = False
         if self.exchange:
             # the first record of the NEXT non-empty shard closes this shard's last read (:225-226)
@@ -411,11 +480,12 @@ class ShardJob:
                 has_look = True
         else:
             self.nonempty = [len(recs) > 0]
-        self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, dbh, dbo)
+        self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
         if hasattr(self.engine, "hip"):
             # stage C runs on the library's second stream: its latency-bound passes overlap stage A's tail, stage B
-            # and (with the exchange) the collectives
-            self.engine.hip.stage_c_side_stream(True)
+            # and (with the exchange) the collectives  (MG_SINGLE_STREAM=1: everything on one stream, for profiles in
+            # which no two kernels overlap)
+            self.engine.hip.stage_c_side_stream(os.environ.get("MG_SINGLE_STREAM", "0") != "1")
 
     # ------------------------------------------------------------------
     def _all_to_all(self, send_h, send_c, send_counts, recv_counts):
@@ -447,38 +517,57 @@ class ShardJob:
                 req.wait()
         return rh, rc, []
 
+    def _merge_args(self, words, ki):
+        """From the gathered words of k number ki: (any source truncated?, the completeness bound, this rank's range)."""
+        W, o = self.world, ki * (self.world + 4)
+        # completeness: a source truncated at its s-th hash knows nothing above it
+        lasts = [_u64(w[o + W + 1]) for w in words if w[o + W] and w[o + W + 2]]
+        complete_to = min(lasts) if lasts else U64_MAX
+        b = self.bounds[ki]
+        return bool(lasts), complete_to, b[self.rank], b[self.rank + 1] - 1
+
     def _exchange_step(self):
-        """Stage A + pass A of stage C locally, then ONE all-gather of per-rank words (slice sizes, sketch
-        completeness, carried-state map) and ONE all-to-all round of sketch slices, during which stage C's
+        """Stage A + pass A of stage C locally, then ONE all-gather of per-rank words (slice sizes and sketch
+        completeness of every k, carried-state map) and ONE all-to-all round of sketch slices, during which stage C's
         commit runs (it only needs the gathered state maps).
-        -> (this rank's slice of the sample sketch, commit results)."""
-        eng, t, dist, W = self.engine, self.torch, self.dist, self.world
+        -> (this rank's slice of the sample sketch for every k, commit results)."""
+        eng, t, dist, W, K = self.engine, self.torch, self.dist, self.world, len(self.ks)
         if hasattr(eng, "profile_begin_async"):
             # stage C's map-only pass is queued first: stage A's one synchronisation covers it too
             if self._given is not None:
-                sk, eng.shard = self._given  # queued a pass ahead by run()
+                sks, eng.shard = self._given  # queued a pass ahead by run()
             else:
                 eng.profile_begin_async(self.pct_id)
-                sk = eng.sketch_local(self.k, self.hmax, self.s)
+                sks = eng.sketch_local(self.ks, self.hmaxs, self.s)
             (m0, m1), ngroups = eng.profile_map()
         else:
-            sk = eng.sketch_local(self.k, self.hmax, self.s)
+            sks = eng.sketch_local(self.ks, self.hmaxs, self.s)
             (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
-        n = sk.size
-        cuts = [0] + eng.split_sketch(sk, self.bounds[1:W]) + [n]
-        send_counts = [cuts[q + 1] - cuts[q] for q in range(W)]
-        last = sk.last_hash  # two's complement into the int64 word
-        word = send_counts + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, m0, m1, ngroups]
-        words = [t.zeros(W + 6, dtype=t.int64, device=self.device) for _ in range(W)]
+        word, send_counts = [], []
+        for ki, sk in enumerate(sks):
+            n = sk.size
+            cuts = [0] + eng.split_sketch(sk, self.bounds[ki][1:W]) + [n]
+            sc = [cuts[q + 1] - cuts[q] for q in range(W)]
+            send_counts.append(sc)
+            last = sk.last_hash  # two's complement into the int64 word
+            word += sc + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, n, 0]
+        word += [m0, m1, ngroups]
+        NW = K * (W + 4) + 3
+        words = [t.zeros(NW, dtype=t.int64, device=self.device) for _ in range(W)]
         dist.all_gather(words, t.as_tensor(np.asarray(word, dtype=np.int64), device=self.device))
         words = t.stack(words).cpu().numpy().tolist()
-        recv_counts = [words[p][self.rank] for p in range(W)]
-        h, c = eng.export_sketch(sk)
-        rh, rc, inflight = self._all_to_all(h, c, send_counts, recv_counts)
+        received, inflight = [], []
+        for ki, sk in enumerate(sks):
+            recv_counts = [words[p][ki * (W + 4) + self.rank] for p in range(W)]
+            h, c = eng.export_sketch(sk)
+            rh, rc, fl = self._all_to_all(h, c, send_counts[ki], recv_counts)
+            received.append((rh, rc))
+            inflight += fl
         # stage C commit overlaps the all-to-all: it depends on the gathered maps only
-        maps = [(w[W + 3], w[W + 4]) for w in words]
+        tail = K * (W + 4)
+        maps = [(w[tail], w[tail + 1]) for w in words]
         incoming = compose_incoming(maps, self.rank)
-        group_base = int(sum(w[W + 5] for w in words[: self.rank]))
+        group_base = int(sum(w[tail + 2] for w in words[: self.rank]))
         first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
         if hasattr(eng, "profile_commit_launch"):
             eng.profile_commit_launch(incoming, first_shard, group_base)  # read back with stage B's counts (step())
@@ -487,20 +576,22 @@ class ShardJob:
             committed = eng.profile_commit(incoming, first_shard, group_base, self._want_mm)
         for wk in inflight:
             wk.wait()
-        # completeness: a source truncated at its s-th hash knows nothing above it
-        lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
-        complete_to = min(lasts) if lasts else U64_MAX
-        any_trunc = bool(lasts)
-        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1] - 1
-        merged = eng.merge_sketches(rh, rc, self.k, 0, any_trunc, complete_to, (lo, hi))
-        # the sketch's buffers were the all-to-all's send buffers: they go back to the pool only now that the merge
-        # (which read what the all-to-all delivered, and synchronised) is done
-        sk.free()
-        if self.s or any_trunc:
-            merged = self._bottom_s(merged, any_trunc)
+        merged = []
+        for ki, (rh, rc) in enumerate(received):
+            any_trunc, complete_to, lo, hi = self._merge_args(words, ki)
+            m = eng.merge_sketches(rh, rc, self.ks[ki], 0, any_trunc, complete_to, (lo, hi))
+            if self.s or any_trunc:
+                m = self._bottom_s(m, any_trunc, self.ks[ki])
+            merged.append(m)
+        # the sketches' buffers were the all-to-all's send buffers: they go back to the pool only now that the merges
+        # (which read what the all-to-all delivered, and synchronised) are done
+        for sk in sks:
+            sk.free()
+        if hasattr(eng, "keep"):
+            eng.keep = []
         return merged, committed
 
-    def _bottom_s(self, merged, any_trunc):
+    def _bottom_s(self, merged, any_trunc, k):
         """bottom-s over the rank-ordered slices: keep the first s entries of the global order and tell every
         slice the sample's completeness bound (two tiny all-gathers; only when s > 0)."""
         eng, t, dist, W = self.engine, self.torch, self.dist, self.world
@@ -514,7 +605,7 @@ class ShardJob:
             truncated = True
         if keep < merged.size:
             mh, mc = eng.export_sketch(merged)
-            cut = eng.merge_sketches(mh[:keep].contiguous(), mc[:keep].contiguous(), self.k, 0, False, 0, None)
+            cut = eng.merge_sketches(mh[:keep].contiguous(), mc[:keep].contiguous(), k, 0, False, 0, None)
             merged.free()
             merged = cut
         mine = 0
@@ -547,18 +638,18 @@ class ShardJob:
             # ... and stage A of consecutive passes goes to two alternating streams at full occupancy: pass i+1's
             # k_sketch_reads fills the GPU while pass i's sort / pack / stage B tail (small kernels) drains.
             import gc
-            side = True
+            side = os.environ.get("MG_SINGLE_STREAM", "0") != "1"  # (=1: everything on one stream, for clean profiles)
             eng.hip.stage_a_workgroups_per_cu(0)
             gc_was_on = gc.isenabled()
             gc.disable()  # (a cyclic collection in the loop is a hole of milliseconds in the GPU's queue)
             try:
-                q = eng.queue_pass(0, self.k, self.hmax, self.s, self.ci, self.pct_id, side)
+                q = eng.queue_pass(0, self.ks, self.hmaxs, self.s, self.ci, self.pct_id, side)
                 out = None
                 for i in range(nsteps):
-                    nxt = (eng.queue_pass((i + 1) & 1, self.k, self.hmax, self.s, self.ci, self.pct_id, side)
+                    nxt = (eng.queue_pass((i + 1) & 1, self.ks, self.hmaxs, self.s, self.ci, self.pct_id, side)
                            if i + 1 < nsteps else None)
-                    sk, (hits, sizes), committed = eng.finish_pass(q, want_multimapped)
-                    out = self._results(sk, hits, sizes, committed)
+                    sks, (hits, sizes), committed = eng.finish_pass(q, want_multimapped)
+                    out = self._results(sks, hits, sizes, committed)
                     q = nxt
             finally:
                 if side:
@@ -571,7 +662,7 @@ class ShardJob:
         eng.hip.stage_a_side_stream(True)
         try:
             def front():  # what does not depend on the other ranks: stage A and stage C's map-only pass
-                return eng.sketch_local_async(self.k, self.hmax, self.s), eng.new_shard_async(self.pct_id)
+                return eng.sketch_local_async(self.ks, self.hmaxs, self.s), eng.new_shard_async(self.pct_id)
             nxt = front()
             out = None
             for i in range(nsteps):
@@ -591,10 +682,49 @@ class ShardJob:
     # by queueing asynchronous work; a tick runs phase D of pass t-3, C of t-2, B of t-1, A of t (the same order on
     # every rank, so the collectives match up), stage A of passes t+1 and t+2 is already queued on the stage-A
     # stream.  By the time a phase looks at its inputs a whole tick has passed: the waits find finished work.
+    def _red_layout(self):
+        G, T, W, K = self.G, self.T, self.world, len(self.ks)
+        o_sizes, o_count = K * G, 2 * K * G
+        o_bases, o_first = o_count + T, o_count + 2 * T
+        o_qn = o_first + W * T
+        return o_sizes, o_count, o_bases, o_first, o_qn, o_qn + K, o_qn + K + 2  # ..., scalars, total
+
+    def _fill_reduce(self, buf, hits, sizes, count, bases, first, scalars, qn):
+        G, T, K = self.G, self.T, len(self.ks)
+        o_sizes, o_count, o_bases, o_first, o_qn, o_scal, _ = self._red_layout()
+        buf[:K * G] = np.asarray(hits).reshape(-1)  # per-slice partial sums: the all-reduce adds them up
+        buf[o_sizes:o_sizes + K * G] = np.asarray(sizes).reshape(-1)
+        buf[o_count:o_count + T] = count.view(np.int64)
+        buf[o_bases:o_bases + T] = bases.view(np.int64)
+        o = o_first + self.rank * T
+        buf[o:o + T] = first.view(np.int64)
+        buf[o_qn:o_qn + K] = qn  # sample sketch size = sum of slice sizes
+        buf[o_scal:o_scal + 2] = scalars.view(np.int64)
+
+    def _read_reduce(self, buf, mm):
+        G, T, W, K = self.G, self.T, self.world, len(self.ks)
+        o_sizes, o_count, o_bases, o_first, o_qn, o_scal, _ = self._red_layout()
+        hits = buf[:K * G].astype(np.uint32).reshape(K, G)
+        sizes = buf[o_sizes:o_sizes + K * G].astype(np.uint32).reshape(K, G)
+        count, bases = buf[o_count:o_count + T].view(np.uint64), buf[o_bases:o_bases + T].view(np.uint64)
+        first = buf[o_first:o_first + W * T].view(np.uint64).reshape(W, T).min(axis=0)  # shards hold disjoint, increasing read-index ranges
+        scalars = buf[o_scal:o_scal + 2].view(np.uint64)
+        return self._pack_out(hits, sizes, count, bases, first, scalars, [int(x) for x in buf[o_qn:o_qn + K]], mm)
+
+    def _pack_out(self, hits, sizes, count, bases, first, scalars, qn, mm):
+        out = dict(hits_k=hits, sizes_k=sizes, hits=hits[-1], sizes=sizes[-1], count=count, bases=bases, first_seen=first,
+                   tot_rds=int(scalars[0]), n_ambig=int(scalars[1]), sketch_sizes=qn, sketch_size=qn[-1], multimapped=mm,
+                   ks=list(self.ks))
+        ci_vals = hits / np.maximum(sizes, 1)
+        out["containment_k"] = ci_vals
+        out["containment"] = ci_vals[-1]  # the largest k: the column the cutoff reads (select_db.py:85-86)
+        out["top_ok"] = bool(ci_vals[-1].max() > 0.5) if ci_vals.shape[1] else None
+        return out
+
     def _run_exchange_pipelined(self, nsteps, want_multimapped):
-        eng, t, dist, W = self.engine, self.torch, self.dist, self.world
+        eng, t, dist, W, K = self.engine, self.torch, self.dist, self.world, len(self.ks)
         G, T = self.G, self.T
-        NSLOT, NW = 4, W + 7  # per-rank words: W slice sizes | truncated | last hash | n | overflows | m0 | m1 | reads
+        NSLOT, NW = 4, K * (W + 4) + 3  # per rank, per k: W slice sizes | truncated | last hash | n | overflows; then m0 | m1 | reads
         eng.x_setup(W, G, T, self.bounds, NSLOT)
 
         def gather_words(P, word_t):
@@ -607,60 +737,49 @@ class ShardJob:
 
         def phase_b(P):  # all-to-all of the slices, stage-C commit, merge, stage B
             words = eng.x_wait_words(P)
-            if any(w[W + 3] for w in words):
+            tail = K * (W + 4)
+            if any(w[ki * (W + 4) + W + 3] for w in words for ki in range(K)):
                 # some rank's counting table overflowed (a sample unlike the previous one): its words are stale.  Every
                 # rank sees the same flags, so every rank repeats the all-gather once that sketch has been rebuilt.
                 self.words_redone = getattr(self, "words_redone", 0) + 1
-                gather_words(P, eng.x_redo_words(P, self.bounds, words[self.rank][W + 4:]))
+                gather_words(P, eng.x_redo_words(P, self.bounds, words[self.rank][tail:]))
                 words = eng.x_wait_words(P)
-            sc = [int(x) for x in words[self.rank][:W]]
-            recv_counts = [int(words[p][self.rank]) for p in range(W)]
-            h, c = eng.export_sketch(P["sk"])
-            rh, rc, inflight = self._all_to_all(h, c, sc, recv_counts)
-            maps = [(w[W + 4], w[W + 5]) for w in words]
+            received, inflight = [], []
+            for ki, sk in enumerate(P["sks"]):
+                o = ki * (W + 4)
+                sc = [int(x) for x in words[self.rank][o:o + W]]
+                recv_counts = [int(words[p][o + self.rank]) for p in range(W)]
+                h, c = eng.export_sketch(sk)
+                rh, rc, fl = self._all_to_all(h, c, sc, recv_counts)
+                received.append((rh, rc))
+                inflight += fl
+            maps = [(w[tail], w[tail + 1]) for w in words]
             incoming = compose_incoming(maps, self.rank)
-            group_base = int(sum(w[W + 6] for w in words[: self.rank]))
+            group_base = int(sum(w[tail + 2] for w in words[: self.rank]))
             first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
             eng.x_commit(P, incoming, first_shard, group_base)  # runs during the all-to-all: it needs the maps only
             for wk in inflight:
                 wk.wait()
-            lasts = [_u64(w[W + 1]) for w in words if w[W] and w[W + 2]]
-            complete_to = min(lasts) if lasts else U64_MAX
-            any_trunc = bool(lasts)
-            lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1] - 1
-            # queued, not waited for: the merged slice is consumed on the device by stage B; phase C settles it
-            merged = eng.x_merge(P, rh, rc, self.k, lo, hi, any_trunc, complete_to)
-            if self.s or any_trunc:
-                merged = self._bottom_s(merged, any_trunc)
+            merged = []
+            for ki, (rh, rc) in enumerate(received):
+                any_trunc, complete_to, lo, hi = self._merge_args(words, ki)
+                # queued, not waited for: the merged slice is consumed on the device by stage B; phase C settles it
+                m = eng.x_merge(P, rh, rc, self.ks[ki], lo, hi, any_trunc, complete_to)
+                if self.s or any_trunc:
+                    m = self._bottom_s(m, any_trunc, self.ks[ki])
+                merged.append(m)
             eng.x_stage_b(P, merged, self.ci)
 
         def phase_c(P):  # this rank's counts -> THE all-reduce
             hits, sizes, count, bases, first, scalars, P["mm"], qn = eng.x_collect(P, self.ci, want_multimapped)
             buf = eng.x_reduce_buffer(P)
-            buf[:G] = hits
-            buf[G:2 * G] = sizes
-            buf[-3] = qn
-            buf[2 * G:2 * G + T] = count.view(np.int64)
-            buf[2 * G + T:2 * G + 2 * T] = bases.view(np.int64)
-            o = 2 * G + 2 * T + self.rank * T
-            buf[o:o + T] = first.view(np.int64)
-            buf[-2:] = scalars.view(np.int64)
+            self._fill_reduce(buf, hits, sizes, count, bases, first, scalars, qn)
             tb = eng.x_reduce_tensor(P)
             dist.all_reduce(tb, op=dist.ReduceOp.SUM)
             eng.x_fetch_reduced(P, tb)
 
         def phase_d(P):
-            buf = eng.x_wait_reduced(P)
-            hits, sizes = buf[:G].astype(np.uint32), buf[G:2 * G].astype(np.uint32)
-            count, bases = buf[2 * G:2 * G + T].view(np.uint64), buf[2 * G + T:2 * G + 2 * T].view(np.uint64)
-            first = buf[2 * G + 2 * T:2 * G + 2 * T + W * T].view(np.uint64).reshape(W, T).min(axis=0)
-            scalars = buf[-2:].view(np.uint64)
-            out = dict(hits=hits, sizes=sizes, count=count, bases=bases, first_seen=first, tot_rds=int(scalars[0]),
-                       n_ambig=int(scalars[1]), sketch_size=int(buf[-3]), multimapped=P["mm"])
-            ci_vals = hits / np.maximum(sizes, 1)
-            out["containment"] = ci_vals
-            out["top_ok"] = bool(ci_vals.max() > 0.5) if len(ci_vals) else None
-            return out
+            return self._read_reduce(eng.x_wait_reduced(P), P["mm"])
 
         import gc
         gc_was_on = gc.isenabled()
@@ -670,7 +789,7 @@ class ShardJob:
             AHEAD = 3  # stage A queued this many passes ahead: the GPU keeps hashing through a host stall of a millisecond or two
 
             def front():
-                return eng.x_front(self.k, self.hmax, self.s, self.pct_id)
+                return eng.x_front(self.ks, self.hmaxs, self.s, self.pct_id)
             fronts = [front() for _ in range(min(AHEAD, nsteps))]
             passes, out = {}, None
             for tick in range(nsteps + 3):
@@ -700,60 +819,44 @@ class ShardJob:
         self._want_mm = want_multimapped
         self._given = _sketch
         if self.exchange:
-            sk, committed = self._exchange_step()
+            sks, committed = self._exchange_step()
             if committed is None:  # commit is in flight: one read-back for stage B's counts and its accumulators
-                (hits, sizes), committed = eng.containment_and_commit_results(sk, self.ci, want_multimapped)
+                (hits, sizes), committed = eng.containment_and_commit_results(sks, self.ci, want_multimapped)
             else:
-                hits, sizes = eng.containment(sk, self.ci)
+                hits, sizes = eng.containment(sks, self.ci)
         else:
             # single shard: stage C is queued first, its results come back with the containment counts ...
             split = hasattr(eng, "profile_commit_launch")
             # stage A does not synchronise: the whole step is queued, then read back once.  Stage A is queued first
             # (its persistent grid takes the CUs); stage C follows on the second stream and fills in as stage A drains.
             if _sketch is not None:
-                sk, ahead = _sketch
+                sks, ahead = _sketch
                 ahead.free()  # (a single shard needs no map-only pass; its handle is created below)
             else:
-                sk = eng.sketch_local_async(self.k, self.hmax, self.s) if split else eng.sketch_local(self.k, self.hmax, self.s)
+                sks = (eng.sketch_local_async(self.ks, self.hmaxs, self.s) if split
+                       else eng.sketch_local(self.ks, self.hmaxs, self.s))
             eng.profile_begin(self.pct_id, False)
             if split:
                 eng.profile_commit_launch(1, True, 0)
             if split:
-                (hits, sizes), committed = eng.containment_and_commit_results(sk, self.ci, want_multimapped)
+                (hits, sizes), committed = eng.containment_and_commit_results(sks, self.ci, want_multimapped)
             else:
-                hits, sizes = eng.containment(sk, self.ci)
+                hits, sizes = eng.containment(sks, self.ci)
                 committed = eng.profile_commit(1, True, 0, want_multimapped)
-        return self._results(sk, hits, sizes, committed)
+        return self._results(sks, hits, sizes, committed)
 
-    def _results(self, sk, hits, sizes, committed):
+    def _results(self, sks, hits, sizes, committed):
         """Sample-wide results from this rank's stage B counts and stage C accumulators (the all-reduce when sharded)."""
-        qn = sk.size
-        sk.free()
+        qn = [sk.size for sk in sks]
+        for sk in sks:
+            sk.free()
         count, bases, first, scalars, mm = committed
-        G, T, W = self.G, self.T, self.world
+        hits, sizes = np.asarray(hits), np.asarray(sizes)
         if self.exchange:
             t, dist = self.torch, self.dist
-            buf = np.zeros(2 * G + 2 * T + W * T + 3, dtype=np.int64)
-            buf[:G] = hits          # per-slice partial sums: the all-reduce adds them up
-            buf[G:2 * G] = sizes
-            buf[-3] = qn            # sample sketch size = sum of slice sizes
-            buf[2 * G:2 * G + T] = count.view(np.int64)
-            buf[2 * G + T:2 * G + 2 * T] = bases.view(np.int64)
-            o = 2 * G + 2 * T + self.rank * T
-            buf[o:o + T] = first.view(np.int64)
-            buf[-2:] = scalars.view(np.int64)
+            buf = np.zeros(self._red_layout()[-1], dtype=np.int64)
+            self._fill_reduce(buf, hits, sizes, count, bases, first, scalars, qn)
             tb = t.as_tensor(buf, device=self.device)
             dist.all_reduce(tb, op=dist.ReduceOp.SUM)  # THE all-reduce
-            buf = tb.cpu().numpy()
-            hits, sizes = buf[:G].astype(np.uint32), buf[G:2 * G].astype(np.uint32)
-            count, bases = buf[2 * G:2 * G + T].view(np.uint64), buf[2 * G + T:2 * G + 2 * T].view(np.uint64)
-            slots = buf[2 * G + 2 * T:2 * G + 2 * T + W * T].view(np.uint64).reshape(W, T)
-            first = slots.min(axis=0)  # shards hold disjoint, increasing read-index ranges
-            scalars = buf[-2:].view(np.uint64)
-            qn = int(buf[-3])
-        out = dict(hits=hits, sizes=sizes, count=count, bases=bases, first_seen=first, tot_rds=int(scalars[0]),
-                   n_ambig=int(scalars[1]), sketch_size=qn, multimapped=mm)
-        ci_vals = hits / np.maximum(sizes, 1)
-        out["containment"] = ci_vals
-        out["top_ok"] = bool(ci_vals.max() > 0.5) if len(ci_vals) else None
-        return out
+            return self._read_reduce(tb.cpu().numpy(), mm)
+        return self._pack_out(hits.astype(np.uint32), sizes.astype(np.uint32), count, bases, first, scalars, qn, mm)

@@ -21,11 +21,11 @@ class OracleEngine:
         self.o = oracle
         self.torch = torch_mod
 
-    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, dbh, dbo):
+    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables):
         self.rb, self.ro = rbases, roffsets
         self.recs, self.has_look = recs, has_lookahead
         self.ref2tax, self.ntax = ref2tax, ntax
-        self.dbh, self.dbo = dbh, dbo
+        self.tables = tables  # one (hashes, offsets) per k: this rank's hash-range slice
 
     class _Sk:
         def __init__(self, h, c, trunc):
@@ -43,9 +43,14 @@ class OracleEngine:
     def set_sketch_bound(self, sk, truncated, bound):
         sk.truncated, sk.bound = bool(truncated), int(bound)
 
-    def sketch_local(self, k, hmax, s):
-        h, c, t, _ = self.o.sketch_reads(self.rb, self.ro, k, hmax=hmax, s=s)
-        return self._Sk(h, c, t)
+    def sketch_local(self, ks, hmaxs, s):
+        out = []
+        for ki, (k, hmax) in enumerate(zip(ks, hmaxs)):
+            h, c, t, _ = self.o.sketch_reads(self.rb, self.ro, k, hmax=hmax, s=s)
+            sk = self._Sk(h, c, t)
+            sk.ki = ki
+            out.append(sk)
+        return out
 
     def export_sketch(self, sk):
         t = self.torch
@@ -67,17 +72,21 @@ class OracleEngine:
             uh, uc, trunc = uh[:s], uc[:s], True
         return self._Sk(uh, uc, trunc)
 
-    def containment(self, sk, ci):
+    def containment(self, sks, ci):
+        res = [self._containment_one(sk, ci, *self.tables[ki]) for ki, sk in enumerate(sks)]
+        return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+
+    def _containment_one(self, sk, ci, dbh, dbo):
         if sk.bound is None:
-            return self.o.containment(sk.h, sk.c, sk.truncated, ci, self.dbh, self.dbo)
+            return self.o.containment(sk.h, sk.c, sk.truncated, ci, dbh, dbo)
         # slice of a sample sketch: complete up to the SAMPLE's last hash.  Express that for the oracle by
         # appending the bound as a sentinel entry with count 0 (never a hit) so that it is the "last hash".
         if sk.truncated:
             h = np.concatenate([sk.h[sk.h < np.uint64(sk.bound)], [np.uint64(sk.bound)]])
             c = np.concatenate([sk.c[sk.h < np.uint64(sk.bound)],
                                 sk.c[sk.h == np.uint64(sk.bound)] if (sk.h == np.uint64(sk.bound)).any() else [np.uint32(0)]])
-            return self.o.containment(h, c.astype(np.uint32), True, ci, self.dbh, self.dbo)
-        return self.o.containment(sk.h, sk.c, False, ci, self.dbh, self.dbo)
+            return self.o.containment(h, c.astype(np.uint32), True, ci, dbh, dbo)
+        return self.o.containment(sk.h, sk.c, False, ci, dbh, dbo)
 
     def profile_begin(self, pct_id, need_map=True):
         import shard_ref
@@ -103,7 +112,8 @@ class PipelinedOracleEngine(OracleEngine):
     force_stale_words = False  # publish an overflow count once: every rank must then repeat the all-gather
 
     def x_setup(self, W, G, T, bounds, nslot):
-        self._xW, self._xNW, self._xnred, self._xbounds_list = W, W + 7, 2 * G + 2 * T + W * T + 3, list(bounds)
+        K = len(bounds)
+        self._xW, self._xNW, self._xnred, self._xbounds_list = W, K * (W + 4) + 3, 2 * K * G + 2 * T + W * T + K + 2, [list(b) for b in bounds]
 
     def x_begin(self):
         pass
@@ -111,18 +121,19 @@ class PipelinedOracleEngine(OracleEngine):
     def x_end(self):
         pass
 
-    def x_front(self, k, hmax, s, pct_id):
-        sk = self.sketch_local(k, hmax, s)
+    def x_front(self, ks, hmaxs, s, pct_id):
+        sks = self.sketch_local(ks, hmaxs, s)
         maps, ngroups = self.profile_begin(pct_id)
-        return dict(sk=sk, maps=maps, ngroups=ngroups)
+        return dict(sks=sks, maps=maps, ngroups=ngroups)
 
     def _word(self, P, overflow):
-        sk, W = P["sk"], self._xW
-        cuts = [0] + self.split_sketch(sk, self._xbounds_list[1:W]) + [sk.size]
-        last = sk.last_hash
-        return ([cuts[q + 1] - cuts[q] for q in range(W)]
-                + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, sk.size, overflow,
-                   P["maps"][0], P["maps"][1], P["ngroups"]])
+        W, word = self._xW, []
+        for ki, sk in enumerate(P["sks"]):
+            cuts = [0] + self.split_sketch(sk, self._xbounds_list[ki][1:W]) + [sk.size]
+            last = sk.last_hash
+            word += ([cuts[q + 1] - cuts[q] for q in range(W)]
+                     + [int(sk.truncated), last - (1 << 64) if last >= (1 << 63) else last, sk.size, overflow])
+        return word + [P["maps"][0], P["maps"][1], P["ngroups"]]
 
     def x_words(self, P, slot):
         stale = 1 if (self.force_stale_words and not getattr(self, "_staled", False)) else 0
@@ -154,7 +165,7 @@ class PipelinedOracleEngine(OracleEngine):
     def x_collect(self, P, ci, want_multimapped):
         count, bases, first, scal, mm = self.profile_commit(*P["commit"], want_multimapped)
         hits, sizes = P["hs"]
-        return hits, sizes, count, bases, first, scal, mm, P["merged"].size
+        return hits, sizes, count, bases, first, scal, mm, [m.size for m in P["merged"]]
 
     def x_reduce_buffer(self, P):
         P["buf"] = np.zeros(self._xnred, dtype=np.int64)
@@ -183,8 +194,8 @@ def _worker(rank, world, port, tmpdir):
     from metalign_amd import distributed as mgd
     rng = np.random.default_rng(5)
     gb, go = util.random_genomes(rng, 10, 4000)
-    k, n = 21, 200
-    dbh, dbo = oracle.sketch_genomes(gb, go, k, n)
+    n = 200
+    tables = {k: oracle.sketch_genomes(gb, go, k, n) for k in (15, 21, 31)}
     rb, ro, src = util.sample_reads(rng, gb, go, 1200, 100, err=0.01, present=[2, 6])
     nref, ntax = 30, 9
     ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
@@ -202,36 +213,45 @@ def _worker(rank, world, port, tmpdir):
     ncuts = [1200 * i // world for i in range(world + 1)]
     my_reads = (rb[int(ro[ncuts[rank]]): int(ro[ncuts[rank + 1]])], ro[ncuts[rank]: ncuts[rank + 1] + 1] - ro[ncuts[rank]])
     my_recs = recs[rcuts[rank]: rcuts[rank + 1]]
+    want = oracle.profile_assign(recs, ref2tax, ntax, 0.5)
     res = {}
-    for s in (0, 400, 37):
-        job = mgd.ShardJob(None, dist, rank, world, k=k, ci=2, pct_id=0.5, s=s, engine=OracleEngine(torch))
+    # (k, s): one k given bare (the single-k surface), and several k in one pass (the reference's query is multi-k)
+    for case, (kspec, s) in enumerate([(21, 0), ([15, 21, 31], 0), (21, 400), ([21, 31], 37)]):
+        ks = [kspec] if np.isscalar(kspec) else list(kspec)
+        dbh = tables[kspec][0] if np.isscalar(kspec) else [tables[k][0] for k in ks]
+        dbo = tables[kspec][1] if np.isscalar(kspec) else [tables[k][1] for k in ks]
+        job = mgd.ShardJob(None, dist, rank, world, k=kspec, ci=2, pct_id=0.5, s=s, engine=OracleEngine(torch))
         job.load(my_reads[0], my_reads[1], my_recs, ref2tax, dbh, dbo, ntax=ntax)
         out = job.step()
         # single-process truth
-        qh, qc, tr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()), s=s)
-        hits, sizes = oracle.containment(qh, qc, tr, 2, dbh, dbo)
-        want = oracle.profile_assign(recs, ref2tax, ntax, 0.5)
-        checks = dict(hits=np.array_equal(out["hits"], hits), sizes=np.array_equal(out["sizes"], sizes),
-                      count=np.array_equal(out["count"], want["count"]), bases=np.array_equal(out["bases"], want["bases"]),
+        checks = dict(count=np.array_equal(out["count"], want["count"]), bases=np.array_equal(out["bases"], want["bases"]),
                       first=np.array_equal(out["first_seen"], want["first_seen"]),
                       tot=out["tot_rds"] == want["tot_rds"], ambig=out["n_ambig"] == want["n_ambig"],
-                      qn=out["sketch_size"] == len(qh))
+                      shape=out["hits_k"].shape == (len(ks), 10))
+        for ki, k in enumerate(ks):
+            th, to = tables[k]
+            qh, qc, tr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(th.max()), s=s)
+            hits, sizes = oracle.containment(qh, qc, tr, 2, th, to)
+            checks["hits%d" % k] = np.array_equal(out["hits_k"][ki], hits)
+            checks["sizes%d" % k] = np.array_equal(out["sizes_k"][ki], sizes)
+            checks["qn%d" % k] = out["sketch_sizes"][ki] == len(qh)
+        checks["last_k_alias"] = np.array_equal(out["hits"], out["hits_k"][-1]) and out["sketch_size"] == out["sketch_sizes"][-1]
         # the four-passes-in-flight schedule (run()) must give the same sample-wide results, also when a rank's words
         # turn out stale and the all-gather is repeated
         pe = PipelinedOracleEngine(torch)
         pe.force_stale_words = (s == 0 and rank == world - 1)
-        pjob = mgd.ShardJob(None, dist, rank, world, k=k, ci=2, pct_id=0.5, s=s, engine=pe)
+        pjob = mgd.ShardJob(None, dist, rank, world, k=kspec, ci=2, pct_id=0.5, s=s, engine=pe)
         pjob.load(my_reads[0], my_reads[1], my_recs, ref2tax, dbh, dbo, ntax=ntax)
         pout = pjob.run(5)
-        for key in ("hits", "sizes", "count", "bases", "first_seen"):
+        for key in ("hits_k", "sizes_k", "count", "bases", "first_seen"):
             checks["run_" + key] = np.array_equal(pout[key], out[key])
-        checks["run_scalars"] = (pout["tot_rds"], pout["n_ambig"], pout["sketch_size"]) == (out["tot_rds"], out["n_ambig"], out["sketch_size"])
+        checks["run_scalars"] = (pout["tot_rds"], pout["n_ambig"], pout["sketch_sizes"]) == (out["tot_rds"], out["n_ambig"], out["sketch_sizes"])
         if s == 0:
             checks["run_repeated_gather"] = getattr(pjob, "words_redone", 0) == 1
         ok = all(checks.values())
         if not ok:
-            print("rank", rank, "s", s, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
-        res[s] = bool(ok)
+            print("rank", rank, "case", case, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
+        res[case] = bool(ok)
     with open(os.path.join(tmpdir, "rank%d.txt" % rank), "w") as fh:
         fh.write(repr(res))
     dist.barrier()
@@ -248,7 +268,7 @@ def test_sharding_matches_single_process(tmp_path, world):
     s.close()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 400: True, 37: True})
+        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 1: True, 2: True, 3: True})
 
 
 def test_shard_reference_equals_c_oracle_unsharded():

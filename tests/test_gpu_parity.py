@@ -4,6 +4,7 @@ import pytest
 
 import stage_c_checks as sc
 import util
+from metalign_amd import _hip
 
 pytestmark = pytest.mark.gpu
 
@@ -106,6 +107,40 @@ def test_containment_matches_oracle(hip, oracle_lib, k, s, ci):
         assert ci_vals[[1, 5, 9, 33]].min() > 0.5 and np.delete(ci_vals, [1, 5, 9, 33]).max() < 0.1
 
 
+@pytest.mark.parametrize("cs", [0, 1, 3, 7])
+def test_count_saturation_matches_oracle(hip, oracle_lib, cs):
+    """Counters saturate at cs (kmc -cs3, select_db.py:50): count = min(occurrences, cs), on the counting-table path
+    (look before add, clamp at pack), on the list path and through a merge; cs = 0 keeps exact counts."""
+    rng = np.random.default_rng(11)
+    gb, go = util.random_genomes(rng, 3, 6000)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 9000, 150, err=0.005)  # ~75x coverage: most counts far above cs
+    k = 21
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    hip.count_saturation(cs)
+    try:
+        assert hip.count_saturation() == cs
+        for hmax in (U64_MAX, int(0.01 * 2 ** 64)):  # the table path, and few enough candidates for the list path
+            sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, 0)
+            qh, qc = sk.download()
+            oh, oc, _, _ = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax, cs=cs)
+            assert np.array_equal(qh, oh) and np.array_equal(qc, oc)
+            assert int(qc.max()) == (cs if cs else int(oc.max())) and (cs == 0 or int(oc.max()) == cs)
+            # merged with itself: min(2 c, cs)
+            both_h, both_c = np.concatenate([qh, qh]), np.concatenate([qc, qc])
+            d_h, d_c = hip.array(both_h), hip.array(both_c)
+            for lo, hi in ((0, int(qh[-1])), (1, 0)):  # through the counting table / through the sorting merge
+                m = hip.sketch_merge_dev(d_h.ptr, d_c.ptr, both_h.size, k, lo, hi)
+                mh, mc = m.download()
+                want = 2 * qc.astype(np.uint64)
+                assert np.array_equal(mh, qh) and np.array_equal(mc, np.minimum(want, cs) if cs else want)
+        if cs:
+            table = hip.upload_table(np.sort(rng.choice(qh, size=50, replace=False)), np.array([0, 50], dtype=np.uint64))
+            with pytest.raises(_hip.HipError):
+                hip.containment(sk, table, cs + 1)  # a threshold above the saturation could never be met
+    finally:
+        hip.count_saturation(3)
+
+
 def test_sketch_merge_equals_single_pass(hip, oracle_lib):
     """Two read shards sketched separately and merged == one pass over all reads (the multi-GPU merge)."""
     rng = np.random.default_rng(77)
@@ -140,7 +175,8 @@ def test_deferred_merge_equals_merge(hip):
     h = pool[rng.integers(0, len(pool), size=n)]
     c = rng.integers(1, 5, size=n).astype(np.uint32)
     want_h, inv = np.unique(h, return_inverse=True)
-    want_c = np.bincount(inv, weights=c).astype(np.uint32)
+    want_exact = np.bincount(inv, weights=c).astype(np.uint32)
+    want_c = np.minimum(want_exact, hip.count_saturation())  # counters saturate at cs = 3 (kmc -cs3), sums included
     d_h, d_c = hip.array(h), hip.array(c)
     # a small table to run stage B against while the merged sketch is still pending
     G, per = 40, 500
