@@ -149,6 +149,7 @@ int mg_prof_get(const char* kernel, uint64_t* launches, double* total_ms);
  * (saturating at 2^32-1); it applies to sketches built afterwards.
  * ------------------------------------------------------------------------ */
 typedef struct mg_sketch mg_sketch;
+typedef struct mg_filter mg_filter;
 int mg_set_count_saturation(uint32_t cs);
 uint32_t mg_count_saturation(void);
 
@@ -165,6 +166,16 @@ int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets,
                               uint64_t nreads, int k, uint64_t hmax, uint64_t s,
                               mg_sketch** out);
 int mg_sketch_resolve(mg_sketch* sk, int* rebuilt);
+/* Every k of a multi-k query from ONE pass over the reads — the reference's containment query is multi-k (CMash
+ * k-range `30-60-10`, scripts/select_db.py:75; BASELINE configs use {21,31,51}).  ks[nk] ascending, hmaxs[nk] the
+ * per-k thresholds, filters[nk] the per-k membership pre-filters (NULL, or NULL entries, = unfiltered).  out[i]
+ * receives the sketch of ks[i], pending like one from mg_sketch_reads_dev_async and bit-identical to it.  For the
+ * k sets {21,31,51} and {30,40,50,60} a fused kernel stages and rolls the reads once and derives every smaller k's
+ * k-mer from the window at the largest k; any other set (or a k whose candidates are few enough for the list path)
+ * is served by one launch per k. */
+int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int nk,
+                                    const int* ks, const uint64_t* hmaxs, uint64_t s,
+                                    const mg_filter* const* filters, mg_sketch** out);
 /* ------------------------------------------------------------------------ *
  * Membership pre-filter over the genome table's hashes — the role of the bloom pre-filter the reference hands
  * to CMash (`-f cmash_db_n1000_k60_30-60-10.bf`, scripts/select_db.py:70,75).  One bit per hash: bit (h mod
@@ -175,7 +186,6 @@ int mg_sketch_resolve(mg_sketch* sk, int* rebuilt);
  * insert.  Build it from ALL hashes of the table (every k has its own), also on a rank that holds a slice.
  * The filter must outlive the sketches built with it until they are resolved.
  * ------------------------------------------------------------------------ */
-typedef struct mg_filter mg_filter;
 int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out);
 unsigned mg_filter_log2_bits(const mg_filter* f);
 void mg_filter_free(mg_filter* f);

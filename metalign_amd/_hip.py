@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
+    "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
@@ -669,7 +669,19 @@ class Hip:
         """The read sketches for several k from ONE pass over the reads (the reference's query is multi-k: `30-60-10`,
         select_db.py:75): -> [Sketch per k], every one pending like sketch_reads_dev_async's."""
         filts = list(filts) if filts is not None else [None] * len(ks)
-        return [self.sketch_reads_dev_async(d_bases, d_offsets, nreads, k, hm, s, filt=f) for k, hm, f in zip(ks, hmaxs, filts)]
+        nk = len(ks)
+        c_ks = (ctypes.c_int * nk)(*[int(k) for k in ks])
+        c_hm = (ctypes.c_uint64 * nk)(*[int(h) for h in hmaxs])
+        c_f = (_vp * nk)(*[(f.handle if f is not None else None) for f in filts])
+        c_out = (_vp * nk)()
+        self._chk(self.lib.mg_sketch_reads_multi_dev_async(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads),
+                                                           ctypes.c_int(nk), c_ks, c_hm, ctypes.c_uint64(s), c_f, c_out))
+        out = []
+        for i in range(nk):
+            sk = Sketch(self, _vp(c_out[i]), int(ks[i]))
+            sk.filt = filts[i]  # keeps the filter alive as long as the sketch may still be rebuilt with it
+            out.append(sk)
+        return out
 
     def sketch_from_pairs_dev(self, d_hashes, d_counts, n, k, s=0, any_truncated=False, bound=U64_MAX):
         h = _vp()

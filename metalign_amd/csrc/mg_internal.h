@@ -23,6 +23,7 @@ struct ProfEntry {
 struct DevBuf;
 }  // namespace mg
 struct mg_sketch;
+struct mg_filter;
 namespace mg {
 
 struct Context {
@@ -211,6 +212,19 @@ struct mg_sketch {
 };
 
 namespace mg {
+// ---- the fused multi-k stage-A launch (mg_sketch_multi.hip) ----
+struct MultiKTable {  // one k of the launch: its threshold, counting table (already zeroed), counters and pre-filter
+  uint64_t hmax;
+  uint64_t* keys;
+  uint32_t* cnts;
+  unsigned long long* counters;
+  unsigned shift;
+  const mg_filter* filter;
+};
+bool sketch_reads_multi_supported(const int* ks, int nk);
+int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
+                              const MultiKTable* tabs, unsigned stage_bytes);
+
 // Brings a pending sketch's metadata to the host (one stream sync); *rebuilt = 1 when the counting table had
 // overflowed and the sketch was recomputed on the list path (anything derived from it while pending is stale).
 int sketch_resolve(mg_sketch* sk, int* rebuilt);

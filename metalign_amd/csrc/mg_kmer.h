@@ -154,6 +154,87 @@ struct Roller {
   }
 };
 
+// MurmurHash3_x64_128(the K bytes held in w[0 .. (K+3)/4), zero padded up to NDW dwords; seed 0) -> first 64 bits.
+template <int K, int NDW>
+__device__ __forceinline__ uint64_t murmur3_h1_words(const uint32_t (&w)[NDW]) {
+  static_assert(NDW >= (K + 3) / 4 + 4, "the tail reads up to four dwords past the last byte");
+  constexpr uint64_t C1 = 0x87c37b91114253d5ULL, C2 = 0x4cf5ad432745937fULL;
+  constexpr int NBLK = K / 16, TAIL = K & 15;
+  uint64_t h1 = 0, h2 = 0;
+  auto body = [&]<int B>() {
+    uint64_t k1 = (uint64_t)w[4 * B] | ((uint64_t)w[4 * B + 1] << 32);
+    uint64_t k2 = (uint64_t)w[4 * B + 2] | ((uint64_t)w[4 * B + 3] << 32);
+    k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+    k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+  };
+  [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(
+      std::make_integer_sequence<int, NBLK>{});
+  if constexpr (TAIL > 8) {
+    uint64_t k2 = (uint64_t)w[4 * NBLK + 2] | ((uint64_t)w[4 * NBLK + 3] << 32);
+    k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+  }
+  if constexpr (TAIL > 0) {
+    uint64_t k1 = (uint64_t)w[4 * NBLK] | ((uint64_t)w[4 * NBLK + 1] << 32);
+    k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+  }
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2;
+  return h1;
+}
+
+// Hash of the canonical K-mer that ENDS at the newest base of a Roller<KMAX>, K <= KMAX: one roller at the largest
+// k of a multi-k query serves every smaller k.  The K-mer is the SUFFIX of the forward window (bytes KMAX-K ..
+// KMAX-1: a byte-granular funnel shift of the forward ASCII words; the low 2K bits of the forward 2-bit form) and
+// its reverse complement is the PREFIX of the reverse-complement window (its first K bytes as they are; the top 2K
+// bits of the reverse 2-bit form).
+template <int K, int KMAX>
+__device__ __forceinline__ uint64_t hash_suffix(const Roller<KMAX>& R) {
+  static_assert(K >= 1 && K <= KMAX, "sub-k must not exceed the roller's k");
+  if constexpr (K == KMAX) {
+    return R.hash();
+  } else {
+    constexpr int ND = (K + 3) / 4, NB = K - 4 * (ND - 1);
+    constexpr uint32_t LAST = NB == 4 ? 0xffffffffu : ((1u << (8 * NB)) - 1u);
+    constexpr int OFF = KMAX - K, OD = OFF / 4, OB = OFF % 4;
+    constexpr int NDM = Roller<KMAX>::ND;
+    // canonical choice on the 2-bit forms (as 128-bit values hi:lo)
+    constexpr int S = 2 * (KMAX - K);  // the reverse form's K-mer sits S bits up
+    uint64_t f_lo = R.pf_lo, f_hi = KMAX > 32 ? R.pf_hi : 0ull;
+    uint64_t r_lo, r_hi;
+    {
+      const uint64_t p_lo = R.pr_lo, p_hi = KMAX > 32 ? R.pr_hi : 0ull;
+      if constexpr (S >= 64) { r_lo = S == 64 ? p_hi : (p_hi >> (S - 64)); r_hi = 0; }
+      else { r_lo = (p_lo >> S) | (p_hi << (64 - S)); r_hi = p_hi >> S; }  // (S > 0 here: K < KMAX)
+    }
+    if constexpr (K <= 32) {
+      constexpr uint64_t M = K == 32 ? ~0ull : ((1ull << (2 * K)) - 1ull);
+      f_lo &= M; r_lo &= M; f_hi = 0; r_hi = 0;
+    } else {
+      constexpr uint64_t MH = (1ull << (2 * (K - 32))) - 1ull;  // K < KMAX <= 64: at most 62 bits
+      f_hi &= MH; r_hi &= MH;
+    }
+    const bool fw = K <= 32 ? (f_lo <= r_lo) : (f_hi < r_hi || (f_hi == r_hi && f_lo <= r_lo));
+    const uint32_t m = fw ? 0xffffffffu : 0u;
+    uint32_t w[ND + 4];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const uint32_t a = R.f[OD + j];
+      const uint32_t b = (OD + j + 1 < NDM) ? R.f[OD + j + 1] : 0u;
+      uint32_t fwd = OB == 0 ? a : __builtin_amdgcn_alignbyte(b, a, OB);
+      uint32_t rev = R.r[j];
+      if (j == ND - 1) { fwd &= LAST; rev &= LAST; }
+      w[j] = (fwd & m) | (rev & ~m);
+    }
+#pragma unroll
+    for (int j = ND; j < ND + 4; ++j) w[j] = 0;
+    return murmur3_h1_words<K, ND + 4>(w);
+  }
+}
+
 // Calls F.template operator()<K>() for the runtime k; false when k is unsupported.
 template <class F, int K = 1>
 inline bool dispatch_k(int k, F&& fn) {

@@ -27,70 +27,13 @@
 
 #include "mg_internal.h"
 #include "mg_kmer.h"
+#include "mg_sketch_dev.h"
 
 // (defined with the merge entry points below; sketch_resolve redoes a deferred merge with it)
 static int merge_via_sort(mg_sketch* sk, const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
                           int any_truncated, uint64_t bound);
 
 namespace mg {
-
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlock = 64 * kWavesPerBlock;
-constexpr int kCandBuf = 256;  // u64 entries per wavefront
-
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS traffic of one wavefront is executed in order; this only pins the compiler.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    uint64_t t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
-constexpr uint32_t kBucketTarget = 96;  // expected distinct hashes per bucket (load factor <= 3/8)
-
-// Insert-or-add into the partitioned counting table: keys[bucket][slot] holds hash+1 (0 = empty).
-// Returns false when the bucket has no free slot.
-// cs > 0: counters SATURATE at cs (kmc -cs3, scripts/select_db.py:50): a counter that is seen at cs or above is
-// left alone (counters only grow, so a stale look can only cost an unnecessary add), and whoever reads the table
-// afterwards takes min(counter, cs).  At 50x coverage nearly every candidate is a repeat of a key whose counter is
-// saturated already: it costs two reads and no memory-side read-modify-write.
-__device__ __forceinline__ bool table_add(uint64_t* __restrict__ keys, uint32_t* __restrict__ cnts, uint64_t bucket,
-                                          uint64_t h, uint32_t amount, uint32_t cs) {
-  const unsigned long long v = h + 1;  // hashes are <= 2^64-2, so v is never the empty marker 0
-  const uint64_t base = bucket * kBucketSlots;
-  uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
-  for (uint32_t t = 0; t < kBucketSlots; ++t) {
-    // A plain look first: a slot's key never changes once set, so a (possibly stale, per-XCD cached) read can only
-    // err towards "empty", and then the CAS decides.  At 50x coverage most candidates are repeats of a key that is
-    // already there: they cost this read and one add instead of a returning CAS and an add.
-    unsigned long long old = keys[base + p];
-    const bool seen = old == v;
-    if (old == 0ull) old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + base + p), 0ull, v);
-    if (old == 0ull || old == v) {
-      // (the look goes to the memory side like the atomics do: an L2 of another XCD may hold the line from before)
-      if (cs && seen && __hip_atomic_load(cnts + base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cs) return true;
-      atomicAdd(cnts + base + p, amount);
-      return true;
-    }
-    p = (p + 1) & (kBucketSlots - 1);
-  }
-  return false;
-}
 
 // Wave-level candidate sink: LDS staging, then either one reservation in the flat list (list mode) or an
 // insert-or-increment per candidate in the partitioned counting table (table mode, shift < 64).
@@ -173,58 +116,6 @@ struct CandSink {
     if (n > kCandBuf - 64) flush(lane);
   }
 };
-
-// Four ASCII bases -> four code bytes: 0..3 = A C G T (either case), 4 = anything else.  SWAR on the dword, done
-// once per base while the tile is copied into LDS (14 instructions per 4 bases instead of 9 per base in the walk).
-__device__ __forceinline__ uint32_t encode4(uint32_t x) {
-  const uint32_t u = x & 0xDFDFDFDFu;                       // upper case
-  const uint32_t t = (x >> 1) & 0x03030303u;                // A:0 C:1 T:2 G:3
-  const uint32_t c = t ^ ((t >> 1) & 0x01010101u);          // A:0 C:1 G:2 T:3
-  const uint32_t d = __builtin_amdgcn_perm(0u, 0x54474341u, c) ^ u;  // "ACGT"[c] != the byte <=> not a base
-  const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
-  return c | (nz >> 5);
-}
-
-// Four code bytes -> four nibbles (bits 0..15).
-__device__ __forceinline__ uint32_t pack4(uint32_t c) {
-  const uint32_t p = (c | (c >> 4)) & 0x00ff00ffu;
-  return (p | (p >> 8)) & 0xffffu;
-}
-
-// A lane's view of its read in the nibble-packed LDS stage: eight codes per 32-bit word.  The read starts at any
-// nibble, so the window of eight codes is a funnel shift of two consecutive words (one v_alignbit per eight bases);
-// the word after next is requested a group ahead.  Positions advance in lock step across the wavefront, which makes
-// the group changes scalar branches and the nibble offsets scalar operands.
-struct CodeStream {
-  const uint32_t* d;   // word holding the read's first code
-  uint32_t sh;         // bit offset of that code in the word
-  uint32_t lo, hi, nxt, w;
-  uint32_t g;          // group (pos / 8) that w holds
-  __device__ __forceinline__ void open(const uint8_t* stage, uint32_t start) {
-    d = reinterpret_cast<const uint32_t*>(stage) + (start >> 3);
-    sh = (start & 7u) * 4u;
-    lo = d[0]; hi = d[1]; nxt = d[2];
-    w = __builtin_amdgcn_alignbit(hi, lo, sh);
-    g = 0;
-  }
-  // pos: wave-uniform; called for 0, 1, 2, ... or (from an even position on) for pairs pos, pos + 1: a group starts
-  // at a multiple of 8, which only the first of a pair can be — the test is then a scalar one
-  __device__ __forceinline__ uint32_t at(uint32_t pos) {
-    if ((pos & 7u) == 0 && pos != 0) {
-      g = pos >> 3;
-      lo = hi; hi = nxt;
-      nxt = d[g + 2];  // may run past the tile into whatever follows in LDS: such positions are >= len and masked
-      w = __builtin_amdgcn_alignbit(hi, lo, sh);
-    }
-    return (w >> ((pos & 7u) * 4u)) & 15u;
-  }
-};
-
-// Code byte of one base read from HBM (the path for tiles that do not fit the LDS stage).
-__device__ __forceinline__ uint32_t encode1(uint32_t b) {
-  uint32_t c;
-  return decode_base(b, c) ? c : 4u;
-}
 
 // One lane walks its read two bases per iteration.  Straight-line body (invalid bases and
 // positions past the end are folded into the run counter instead of branches) so that the two
@@ -727,21 +618,35 @@ static bool plan_table(uint64_t lo, uint64_t hi, double distinct_est, TablePlan&
   return true;
 }
 
-static int alloc_table(TablePlan& tp, unsigned long long** d_counters = nullptr) {
-  // [keys u64 x slots | counts u32 x slots | 4 counter words] zeroed in one memset; staging rows are written sparsely
+// The table proper of k number `ki` of a fused launch (0 for everybody else): [keys u64 x slots | counts u32 x slots |
+// 4 counter words], zeroed in one memset.
+static int alloc_table_core(TablePlan& tp, unsigned long long** d_counters, int ki) {
+  char name[24];
+  snprintf(name, sizeof(name), ki ? "sk_table#%d" : "sk_table", ki);
   const uint64_t tab_bytes = ((tp.slots * 12 + 7) / 8) * 8;
-  uint8_t* d_tab = (uint8_t*)scratch("sk_table", tab_bytes + 4 * sizeof(unsigned long long));
-  tp.stage_h = (uint64_t*)scratch("sk_stage_h", tp.slots * sizeof(uint64_t));
-  tp.stage_c = (uint32_t*)scratch("sk_stage_c", tp.slots * sizeof(uint32_t));
-  tp.nuniq = (uint32_t*)scratch("sk_bucket_n", tp.nbuckets * sizeof(uint32_t));
-  tp.offs = (uint64_t*)scratch("sk_bucket_off", (tp.nbuckets + 1) * sizeof(uint64_t));
-  if (!d_tab || !tp.stage_h || !tp.stage_c || !tp.nuniq || !tp.offs) return MG_ERR_NOMEM;
+  uint8_t* d_tab = (uint8_t*)scratch(name, tab_bytes + 4 * sizeof(unsigned long long));
+  if (!d_tab) return MG_ERR_NOMEM;
   tp.keys = reinterpret_cast<uint64_t*>(d_tab);
   tp.cnts = reinterpret_cast<uint32_t*>(d_tab + tp.slots * 8);
   if (d_counters) *d_counters = reinterpret_cast<unsigned long long*>(d_tab + tab_bytes);
   ProfScope ps("table_clear");
   MG_HIP(hipMemsetAsync(d_tab, 0, tab_bytes + (d_counters ? 4 * sizeof(unsigned long long) : 0), ctx().stream));
   return MG_OK;
+}
+
+// The staging rows table_pack sorts the buckets into (written sparsely, shared by consecutive tables of a stream).
+static int alloc_table_staging(TablePlan& tp) {
+  tp.stage_h = (uint64_t*)scratch("sk_stage_h", tp.slots * sizeof(uint64_t));
+  tp.stage_c = (uint32_t*)scratch("sk_stage_c", tp.slots * sizeof(uint32_t));
+  tp.nuniq = (uint32_t*)scratch("sk_bucket_n", tp.nbuckets * sizeof(uint32_t));
+  tp.offs = (uint64_t*)scratch("sk_bucket_off", (tp.nbuckets + 1) * sizeof(uint64_t));
+  if (!tp.stage_h || !tp.stage_c || !tp.nuniq || !tp.offs) return MG_ERR_NOMEM;
+  return MG_OK;
+}
+
+static int alloc_table(TablePlan& tp, unsigned long long** d_counters = nullptr) {
+  MG_TRY(alloc_table_staging(tp));
+  return alloc_table_core(tp, d_counters, 0);
 }
 
 // Sort every bucket and pack the buckets in order into the sketch's own buffers (d_meta[0] = distinct hashes).
@@ -919,6 +824,90 @@ __global__ void k_filter_set(const uint64_t* __restrict__ hashes, uint64_t n, ui
   }
 }
 
+// Sizes derived from the read buffer: total bases (one read-back, cached per input buffer: a stale value only
+// mis-sizes buffers, and every mis-sizing is detected and retried) and the LDS tile of a wavefront.
+struct ReadPlan {
+  uint64_t nbases = 0;
+  unsigned stage = 0;
+};
+static int plan_reads(const uint64_t* d_offsets, uint64_t nreads, hipStream_t st, ReadPlan& rp) {
+  uint64_t* pin = host_words();
+  static const uint64_t* cached_off = nullptr;
+  static uint64_t cached_nreads = 0, cached_nbases = 0;
+  if (cached_off == d_offsets && cached_nreads == nreads) {
+    rp.nbases = cached_nbases;
+  } else {
+    MG_HIP(hipMemcpyAsync(pin + 0, d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipMemcpyAsync(pin + 1, d_offsets + nreads, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    rp.nbases = pin[1] - pin[0];
+    cached_off = d_offsets; cached_nreads = nreads; cached_nbases = rp.nbases;
+  }
+  // LDS tile: 64 reads of average length at half a byte per base, 12.5 % slack, 16-byte granules, at most
+  // 8 KiB (16 k bases) per wavefront
+  const uint64_t avg = (rp.nbases + nreads - 1) / nreads;
+  uint64_t stage = (((64 * avg * 9 / 8 + 64) / 2 + 15) / 16) * 16;
+  if (stage < 1024) stage = 1024;
+  if (stage > 8192) stage = 8192;
+  rp.stage = (unsigned)stage;
+  return MG_OK;
+}
+
+struct KPlan {  // one k of a sketch call
+  uint64_t hmax = 0, expect = 0, cap = 0;
+  double distinct_est = 0.0;
+  bool table = false;
+  TablePlan tp;
+};
+static void plan_k(const ReadPlan& rp, int k, uint64_t hmax, KPlan& kp) {
+  kp.hmax = hmax;
+  const double frac = ((double)hmax + 1.0) / 18446744073709551616.0;
+  kp.expect = (uint64_t)((double)rp.nbases * frac);
+  kp.cap = kp.expect + kp.expect / 4 + (1u << 16);
+  if (kp.cap > rp.nbases + 64) kp.cap = rp.nbases + 64;
+  // ---- table path: counting hash table partitioned into hash-range buckets ----
+  // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
+  // previous call of the same k (x2 for safety) tightens it for steady-state batches.  Under-sizing is detected (a
+  // bucket with no free slot) and handled by the list path.
+  const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
+  kp.distinct_est = (double)kp.expect * mg::distinct_hint_for(k);
+  if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) kp.distinct_est = (double)kp.expect * atof(e);  // tests: force overflow
+  kp.table = !force_list && kp.expect >= 32768 && plan_table(0, hmax, kp.distinct_est, kp.tp);
+}
+
+// Deferred finalisation of a sketch whose counting table has just been filled: bucket sort / pack, then the sketch's
+// size, last hash and the table-overflow counter stay on the device with a copy in flight to pinned memory;
+// sketch_resolve() reads them at the first host-side use.
+static int finish_pending(mg_sketch* sk, const KPlan& kp, const ReadPlan& rp, unsigned long long* t_counters, int k,
+                          uint64_t s, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
+                          const mg_filter* filter) {
+  Context& cc = ctx();
+  hipStream_t st = cc.stream;
+  const unsigned slot = cc.pend_next++ % Context::kPendSlots;
+  if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
+  MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
+  uint64_t* sk_meta = sk->meta.as<uint64_t>();
+  MG_TRY(table_pack(kp.tp, sk, sk_meta));
+  sk->h_meta = cc.pend_pinned + 8 * slot;
+  hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
+                     (const unsigned long long*)t_counters, sk->h_meta);
+  MG_HIP(hipGetLastError());
+  sk->ev = take_event();
+  if (sk->ev) { MG_HIP(hipEventRecord(sk->ev, st)); sk->ev_stream = st; }
+  sk->pending = true;
+  sk->pend_slot = (int)slot;
+  cc.pend_owner[slot] = sk;
+  sk->n_bound = kp.tp.slots;  // a sketch cannot outgrow the table; tightened below
+  if ((uint64_t)kp.distinct_est + 1 < sk->n_bound) sk->n_bound = (uint64_t)kp.distinct_est + 1;
+  if (s > 0 && s < sk->n_bound) sk->n_bound = s;
+  sk->hmax = kp.hmax;
+  sk->expect = (double)(kp.expect ? kp.expect : 1);
+  sk->redo.bases = d_bases; sk->redo.offsets = d_offsets; sk->redo.nreads = nreads; sk->redo.k = k;
+  sk->redo.hmax = kp.hmax; sk->redo.s = s; sk->redo.cap = kp.cap; sk->redo.stage = rp.stage;
+  sk->redo.filter = filter;
+  return MG_OK;
+}
+
 static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
                               uint64_t s, const mg_filter* filter, mg_sketch** out) {
   MG_REQUIRE_READY();
@@ -939,87 +928,93 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     *out = sk.release();
     return MG_OK;
   }
-  // total bases -> candidate capacity estimate and LDS tile size (one read-back, cached per input buffer:
-  // a stale value only mis-sizes buffers, and every mis-sizing is detected and retried)
-  uint64_t* pin = host_words();
-  static const uint64_t* cached_off = nullptr;
-  static uint64_t cached_nreads = 0, cached_nbases = 0;
-  uint64_t nbases;
-  if (cached_off == d_offsets && cached_nreads == nreads) {
-    nbases = cached_nbases;
-  } else {
-    MG_HIP(hipMemcpyAsync(pin + 0, d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipMemcpyAsync(pin + 1, d_offsets + nreads, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
-    nbases = pin[1] - pin[0];
-    cached_off = d_offsets; cached_nreads = nreads; cached_nbases = nbases;
-  }
-  const double frac = ((double)hmax + 1.0) / 18446744073709551616.0;
-  const uint64_t expect = (uint64_t)((double)nbases * frac);
-  uint64_t cap = expect + expect / 4 + (1u << 16);
-  if (cap > nbases + 64) cap = nbases + 64;
-  // LDS tile: 64 reads of average length at half a byte per base, 12.5 % slack, 16-byte granules, at most
-  // 8 KiB (16 k bases) per wavefront
-  uint64_t avg = (nbases + nreads - 1) / nreads;
-  uint64_t stage = (((64 * avg * 9 / 8 + 64) / 2 + 15) / 16) * 16;
-  if (stage < 1024) stage = 1024;
-  if (stage > 8192) stage = 8192;
+  ReadPlan rp;
+  MG_TRY(plan_reads(d_offsets, nreads, st, rp));
+  KPlan kp;
+  plan_k(rp, k, hmax, kp);
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
-
-  // ---- table path: counting hash table partitioned into hash-range buckets ----
-  // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
-  // previous call (x2 for safety) tightens it for steady-state batches.  Under-sizing is detected (a bucket
-  // with no free slot) and handled by the list path.
-  const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
-  double distinct_est = (double)expect * mg::distinct_hint_for(k);
-  if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) distinct_est = (double)expect * atof(e);  // tests: force overflow
-  TablePlan tp;
-  if (!force_list && expect >= 32768 && plan_table(0, hmax, distinct_est, tp)) {
+  if (kp.table) {
     unsigned long long* t_counters = nullptr;  // cleared together with the table
-    MG_TRY(alloc_table(tp, &t_counters));
+    MG_TRY(alloc_table(kp.tp, &t_counters));
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, tp.keys, 0, t_counters, tp.cnts, tp.shift,
-                                  (unsigned)stage, filter);
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, kp.tp.keys, 0, t_counters, kp.tp.cnts, kp.tp.shift,
+                                  rp.stage, filter);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
-    // Deferred finalisation: the sketch's size, last hash and the table-overflow counter stay on the device with a
-    // copy in flight to pinned memory; sketch_resolve() reads them at the first host-side use.
-    Context& cc = ctx();
-    const unsigned slot = cc.pend_next++ % Context::kPendSlots;
-    if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
-    MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
-    uint64_t* sk_meta = sk->meta.as<uint64_t>();
-    MG_TRY(table_pack(tp, sk.get(), sk_meta));
-    sk->h_meta = cc.pend_pinned + 8 * slot;
-    hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
-                       (const unsigned long long*)t_counters, sk->h_meta);
-    MG_HIP(hipGetLastError());
-    sk->ev = take_event();
-    if (sk->ev) { MG_HIP(hipEventRecord(sk->ev, st)); sk->ev_stream = st; }
-    sk->pending = true;
-    sk->pend_slot = (int)slot;
-    cc.pend_owner[slot] = sk.get();
-    sk->n_bound = tp.slots;  // a sketch cannot outgrow the table; tightened below
-    if ((uint64_t)distinct_est + 1 < sk->n_bound) sk->n_bound = (uint64_t)distinct_est + 1;
-    if (s > 0 && s < sk->n_bound) sk->n_bound = s;
-    sk->hmax = hmax;
-    sk->expect = (double)(expect ? expect : 1);
-    sk->redo.bases = d_bases; sk->redo.offsets = d_offsets; sk->redo.nreads = nreads; sk->redo.k = k;
-    sk->redo.hmax = hmax; sk->redo.s = s; sk->redo.cap = cap; sk->redo.stage = (unsigned)stage;
-    sk->redo.filter = filter;
+    MG_TRY(finish_pending(sk.get(), kp, rp, t_counters, k, s, d_bases, d_offsets, nreads, filter));
     *out = sk.release();
     return MG_OK;
   }
-  MG_TRY(sketch_via_list(sk.get(), d_bases, d_offsets, nreads, k, hmax, s, cap, (unsigned)stage, d_counters, filter));
+  MG_TRY(sketch_via_list(sk.get(), d_bases, d_offsets, nreads, k, hmax, s, kp.cap, rp.stage, d_counters, filter));
   MG_HIP(hipStreamSynchronize(st));  // the list path reads back as it goes; nothing is left in flight
   *out = sk.release();
   return MG_OK;
 }
 
+// Every k of a multi-k query from ONE pass over the reads (mg_sketch_multi.hip) when the k set has a fused kernel and
+// every k takes the counting-table path; otherwise one launch per k.  out[i] = the sketch of ks[i], pending.
+static int sketch_reads_multi_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int nk, const int* ks,
+                                    const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters, mg_sketch** out) {
+  MG_REQUIRE_READY();
+  if (!out || !ks || !hmaxs || nk < 1) return fail(MG_ERR_ARG, "null argument");
+  for (int i = 0; i < nk; ++i) out[i] = nullptr;
+  auto per_k = [&]() -> int {
+    for (int i = 0; i < nk; ++i) {
+      int rc = sketch_reads_async(d_bases, d_offsets, nreads, ks[i], hmaxs[i], s, filters ? filters[i] : nullptr, &out[i]);
+      if (rc != MG_OK) {
+        for (int j = 0; j < i; ++j) { mg_sketch_free(out[j]); out[j] = nullptr; }
+        return rc;
+      }
+    }
+    return MG_OK;
+  };
+  if (nreads == 0 || nk == 1 || nk > 4 || !sketch_reads_multi_supported(ks, nk) || getenv("MG_DEBUG_NO_FUSED")) return per_k();
+  if (!d_bases || !d_offsets) return fail(MG_ERR_ARG, "null device input");
+  Context& c = ctx();
+  hipStream_t side = c.a_side == 2 ? c.stream_a2 : c.stream_a;
+  StreamGuard guard(c.a_side ? side : c.stream, c.a_side ? c.stage_a_prefix(side) : c.scratch_prefix);
+  hipStream_t st = c.stream;
+  ReadPlan rp;
+  MG_TRY(plan_reads(d_offsets, nreads, st, rp));
+  KPlan kp[4];
+  uint64_t hm[4];
+  for (int i = 0; i < nk; ++i) {
+    hm[i] = hmaxs[i] == kReservedHash ? kReservedHash - 1 : hmaxs[i];
+    plan_k(rp, ks[i], hm[i], kp[i]);
+    if (!kp[i].table) return per_k();  // few candidates (list path) for some k: nothing to fuse
+  }
+  MultiKTable tabs[4];
+  unsigned long long* t_counters[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < nk; ++i) {
+    MG_TRY(alloc_table_core(kp[i].tp, &t_counters[i], i));
+    tabs[i] = MultiKTable{hm[i], kp[i].tp.keys, kp[i].tp.cnts, t_counters[i], kp[i].tp.shift, filters ? filters[i] : nullptr};
+  }
+  MG_TRY(launch_sketch_reads_multi(ks, nk, d_bases, d_offsets, nreads, tabs, rp.stage));
+  for (int i = 0; i < nk; ++i) {
+    std::unique_ptr<mg_sketch> sk(new mg_sketch());
+    int rc = alloc_table_staging(kp[i].tp);
+    if (rc == MG_OK)
+      rc = finish_pending(sk.get(), kp[i], rp, t_counters[i], ks[i], s, d_bases, d_offsets, nreads, filters ? filters[i] : nullptr);
+    if (rc != MG_OK) {
+      for (int j = 0; j < i; ++j) { mg_sketch_free(out[j]); out[j] = nullptr; }
+      return rc;
+    }
+    out[i] = sk.release();
+  }
+  return MG_OK;
+}
+
 extern "C" {
+
+int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int nk, const int* ks,
+                                    const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters, mg_sketch** out) {
+  for (int i = 0; ks && i < nk; ++i)
+    if (ks[i] < 1 || ks[i] > MG_MAX_K) return fail(MG_ERR_ARG, "k=%d outside [1,%d]", ks[i], MG_MAX_K);
+  return sketch_reads_multi_async(d_bases, d_offsets, nreads, nk, ks, hmaxs, s, filters, out);
+}
 
 int mg_sketch_reads_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int k, uint64_t hmax,
                               uint64_t s, mg_sketch** out) {

@@ -1,0 +1,279 @@
+// mg_sketch_multi.hip — Stage A for EVERY k of a multi-k query in one launch.
+//
+// The reference's containment query is multi-k (`30-60-10`, scripts/select_db.py:75; BASELINE configs use
+// {21,31,51}).  One launch per k streams, stages, encodes and rolls the reads |K| times; here a tile is staged and
+// encoded once, each lane rolls ONE window at the largest k (mg_kmer.h: Roller<KMAX>) and every smaller k's
+// canonical k-mer is read out of it (hash_suffix: its forward ASCII is a byte-granular funnel shift of the big
+// window's, its reverse complement is the first K bytes of the big reverse window, the 2-bit forms are bit fields
+// of the big ones) — what remains per k is its MurmurHash3 and its threshold test.  Candidates of all k share one
+// LDS buffer per wavefront (entries tagged with the k's index) and go to per-k counting tables
+// (mg_sketch_dev.h: table_add) exactly as in the single-k kernel; the host side turns every table into that k's
+// sketch with the same tail (mg_sketch.hip: table_pack), so the sketches are bit-identical to single-k launches.
+//
+// Replaces: kmc -k60 -ci2 -cs3 (scripts/select_db.py:50-52) + k-mer hashing in CMash's streaming multi-k query
+// (scripts/select_db.py:73-76).
+#include "mg_sketch_dev.h"
+
+namespace mg {
+
+constexpr int kMaxMultiK = 4;
+
+struct MultiArgs {
+  uint64_t hmax[kMaxMultiK];
+  uint64_t* keys[kMaxMultiK];            // counting table of k number i: [nbuckets][kBucketSlots], 0 = empty, else hash + 1
+  uint32_t* cnts[kMaxMultiK];
+  unsigned long long* counters[kMaxMultiK];  // [0] candidates produced, [1] k-mers hashed, [2] table overflows
+  const uint32_t* fbits[kMaxMultiK];     // optional membership pre-filter of k number i
+  uint64_t fmask[kMaxMultiK];
+  unsigned shift[kMaxMultiK];
+  uint32_t cs;
+};
+
+// Wave-level candidate sink shared by all k: (hash, k index) pairs staged in LDS, flushed into the per-k tables.
+struct MultiSink {
+  uint64_t* lds_h;   // this wave's kCandBuf hashes
+  uint8_t* lds_k;    // ... and the index of the k each belongs to
+  const MultiArgs* A;  // in LDS
+  int n;             // entries staged (wave-uniform)
+  unsigned long long produced[kMaxMultiK];
+
+  __device__ __forceinline__ void flush(int lane) {
+    if (n == 0) return;
+    wave_lds_sync();
+    uint64_t hh[kCandBuf / 64];
+    uint32_t kk[kCandBuf / 64], fw[kCandBuf / 64];
+    // this lane's candidates and their filter words first, all in flight together; then the inserts
+#pragma unroll
+    for (int j = 0; j < kCandBuf / 64; ++j) {
+      const int i = lane + 64 * j;
+      hh[j] = i < n ? lds_h[i] : kReservedHash;
+      kk[j] = i < n ? lds_k[i] : 0u;
+      fw[j] = 0xffffffffu;
+      if (hh[j] != kReservedHash) {
+        const uint32_t* fb = A->fbits[kk[j]];
+        if (fb) fw[j] = fb[(hh[j] & A->fmask[kk[j]]) >> 5];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kCandBuf / 64; ++j) {
+      if (hh[j] == kReservedHash || !((fw[j] >> (hh[j] & 31u)) & 1u)) continue;
+      const uint32_t ki = kk[j];
+#pragma unroll
+      for (int q = 0; q < kMaxMultiK; ++q) produced[q] += ki == (uint32_t)q ? 1u : 0u;
+      if (!table_add(A->keys[ki], A->cnts[ki], hh[j] >> A->shift[ki], hh[j], 1u, A->cs))
+        atomicAdd(A->counters[ki] + 2, 1ull);
+    }
+    wave_lds_sync();
+    n = 0;
+  }
+
+  template <int KI>
+  __device__ __forceinline__ void offer(bool hit, uint64_t h, int lane) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if (m == 0) return;
+    if (hit) {
+      const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+      lds_h[at] = h;
+      lds_k[at] = (uint8_t)KI;
+    }
+    n += __popcll(m);
+    if (n > kCandBuf - 64) flush(lane);
+  }
+  template <int KI>
+  __device__ __forceinline__ void offer2(bool a, bool b, uint64_t h, int lane) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b);
+    if (m == 0) return;
+    if (a && b) {
+      const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+      lds_h[at] = h;
+      lds_k[at] = (uint8_t)KI;
+    }
+    n += __popcll(m);
+    if (n > kCandBuf - 64) flush(lane);
+  }
+};
+
+template <int... KS>
+struct KList {
+  static constexpr int N = sizeof...(KS);
+  static constexpr int v[sizeof...(KS)] = {KS...};
+  static constexpr int kmax = v[N - 1];
+  static constexpr int kmin = v[0];
+};
+
+// One lane walks its read; per base it pushes into the roller at the largest k and hashes the k-mer of every k that
+// can be complete at this position.  MODE as in mg_sketch.hip: 0 any tile, 1 clean tile of equally long reads,
+// 2 clean tile of ragged reads.
+// CODES: src is the wavefront's nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise
+// src points at the read's ASCII bases in HBM (a tile that does not fit the stage; MODE 0 only).
+template <class KL, bool CODES, int MODE>
+__device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
+                                                 const MultiArgs* A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane) {
+  constexpr int KMAX = KL::kmax;
+  static_assert(CODES || MODE == 0, "the clean walks read the LDS stage");
+  Roller<KMAX> roll;
+  roll.reset();
+  CodeStream cs;
+  if constexpr (CODES) cs.open(src, start);
+  const uint32_t maxlen = __builtin_amdgcn_readfirstlane(maxlen_v);
+  uint64_t hmax[KL::N];
+#pragma unroll
+  for (int i = 0; i < KL::N; ++i) hmax[i] = A->hmax[i];
+  // positions [0, kmin - 1): no k-mer of any k is complete — rolled in without hashing (wave-uniform)
+  constexpr uint32_t kWarm = (uint32_t)(KL::kmin - 1);
+  const uint32_t warm = kWarm < maxlen ? kWarm : maxlen;
+  if constexpr (MODE != 0) {
+    constexpr bool RAGGED = MODE == 2;
+    for (uint32_t pos = 0; pos < warm; ++pos) roll.push_clean(cs.at(pos) & 3u);
+    for (uint32_t pos = warm; pos < maxlen; ++pos) {
+      roll.push_clean(cs.at(pos) & 3u);
+      // k number I is complete from position K_I - 1 on: a scalar condition per k (the ks ascend, so the tests nest)
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((pos + 1 >= (uint32_t)KL::v[I]
+              ? (RAGGED ? sink.template offer2<I>(pos < len, hash_suffix<KL::v[I], KMAX>(roll) <= hmax[I],
+                                                  hash_suffix<KL::v[I], KMAX>(roll), lane)
+                        : sink.template offer<I>(hash_suffix<KL::v[I], KMAX>(roll) <= hmax[I],
+                                                 hash_suffix<KL::v[I], KMAX>(roll), lane))
+              : (void)0),
+         ...);
+      }(std::make_integer_sequence<int, KL::N>{});
+    }
+#pragma unroll
+    for (int i = 0; i < KL::N; ++i) kmers[i] += len >= (uint32_t)KL::v[i] ? len - (uint32_t)KL::v[i] + 1u : 0u;
+    return;
+  }
+  uint32_t nk[KL::N];
+#pragma unroll
+  for (int i = 0; i < KL::N; ++i) nk[i] = 0;
+  for (uint32_t pos = 0; pos < maxlen; ++pos) {
+    uint32_t c;
+    if constexpr (CODES) { c = cs.at(pos); c = pos < len ? c : 4u; }
+    else c = pos < len ? encode1(src[pos]) : 4u;
+    roll.push(c);
+    roll.run = c < 4u ? roll.run : 0;
+    if (pos < warm) continue;  // (scalar)
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ((pos + 1 >= (uint32_t)KL::v[I]
+            ? (nk[I] += roll.run >= KL::v[I] ? 1u : 0u,
+               sink.template offer2<I>(roll.run >= KL::v[I], hash_suffix<KL::v[I], KMAX>(roll) <= hmax[I],
+                                       hash_suffix<KL::v[I], KMAX>(roll), lane))
+            : (void)0),
+       ...);
+    }(std::make_integer_sequence<int, KL::N>{});
+  }
+#pragma unroll
+  for (int i = 0; i < KL::N; ++i) kmers[i] += nk[i];
+}
+
+template <class KL>
+__global__ __launch_bounds__(kBlock) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
+                                                               const uint64_t* __restrict__ offsets, uint64_t nreads,
+                                                               const MultiArgs args, unsigned stage_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ MultiArgs s_args;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) s_args = args;
+  __syncthreads();
+  uint8_t* stage = smem + (size_t)wave * stage_bytes;
+  uint8_t* cand = smem + (size_t)kWavesPerBlock * stage_bytes;
+  uint64_t* cbuf = reinterpret_cast<uint64_t*>(cand) + wave * kCandBuf;
+  uint8_t* kbuf = cand + (size_t)kWavesPerBlock * kCandBuf * sizeof(uint64_t) + wave * kCandBuf;
+  MultiSink sink{cbuf, kbuf, &s_args, 0, {0, 0, 0, 0}};
+  uint64_t kmers[kMaxMultiK] = {0, 0, 0, 0};
+  const uint64_t ntiles = (nreads + 63) / 64;
+  for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
+       tile += (uint64_t)gridDim.x * kWavesPerBlock) {
+    const uint64_t r = tile * 64 + lane;
+    uint64_t beg = 0, end = 0;
+    if (r < nreads) { beg = offsets[r]; end = offsets[r + 1]; }
+    const uint64_t len = end - beg;
+    const uint64_t maxlen = wave_max_u64(len);
+    const uint64_t t_beg = __shfl(beg, 0, 64);
+    const uint64_t t_end = wave_max_u64(end);
+    const uintptr_t a_first = reinterpret_cast<uintptr_t>(bases) + t_beg;
+    const uintptr_t a0 = a_first & ~(uintptr_t)15;
+    const uint64_t shift = a_first - a0;
+    const uint64_t nbytes = shift + (t_end - t_beg);
+    if (nbytes <= 2ull * stage_bytes) {
+      // coalesced HBM -> LDS copy of the whole tile (16 B per lane per step), bases -> 4-bit codes on the way
+      const uint4* g = reinterpret_cast<const uint4*>(a0);
+      uint2* s = reinterpret_cast<uint2*>(stage);
+      uint32_t bad = 0;
+      for (uint64_t i = lane; i * 16 < nbytes; i += 64) {
+        const uint4 v = g[i];
+        const uint2 p{pack4(encode4(v.x)) | (pack4(encode4(v.y)) << 16), pack4(encode4(v.z)) | (pack4(encode4(v.w)) << 16)};
+        bad |= (p.x | p.y) & 0x44444444u;
+        s[i] = p;
+      }
+      wave_lds_sync();
+      const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
+      if (__ballot(bad != 0) != 0ull)
+        walk_reads_multi<KL, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+      else if (__ballot(len != maxlen) == 0ull)
+        walk_reads_multi<KL, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+      else
+        walk_reads_multi<KL, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+      wave_lds_sync();
+    } else {
+      walk_reads_multi<KL, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+    }
+  }
+  sink.flush(lane);
+#pragma unroll
+  for (int i = 0; i < KL::N; ++i) {
+    const uint64_t km = wave_sum_u64(kmers[i]);
+    if (lane == 0 && km) atomicAdd(s_args.counters[i] + 1, (unsigned long long)km);
+    const uint64_t pr = wave_sum_u64(sink.produced[i]);
+    if (lane == 0 && pr) atomicAdd(s_args.counters[i], (unsigned long long)pr);
+  }
+}
+
+template <class KL>
+static int launch_multi(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, const MultiArgs& a,
+                        unsigned stage_bytes) {
+  Context& c = ctx();
+  const size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * (sizeof(uint64_t) + 1));
+  const uint64_t ntiles = (nreads + 63) / 64;
+  unsigned per_cu = (unsigned)(160 * 1024 / (lds + sizeof(MultiArgs) + 64));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
+  const unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
+  ProfScope ps("sketch_reads");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi<KL>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
+                     nreads, a, stage_bytes);
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
+bool sketch_reads_multi_supported(const int* ks, int nk) {
+  auto is = [&](std::initializer_list<int> want) {
+    if ((int)want.size() != nk) return false;
+    int i = 0;
+    for (int k : want)
+      if (ks[i++] != k) return false;
+    return true;
+  };
+  return is({21, 31, 51}) || is({30, 40, 50, 60});
+}
+
+// One launch for all k; `tables` etc. are per k (ascending k).  MG_ERR_ARG when the k set has no instantiation.
+int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
+                              const MultiKTable* tabs, unsigned stage_bytes) {
+  if (nk < 1 || nk > kMaxMultiK) return fail(MG_ERR_ARG, "between 1 and %d k per fused launch", kMaxMultiK);
+  MultiArgs a{};
+  for (int i = 0; i < nk; ++i) {
+    a.hmax[i] = tabs[i].hmax; a.keys[i] = tabs[i].keys; a.cnts[i] = tabs[i].cnts; a.counters[i] = tabs[i].counters;
+    a.fbits[i] = tabs[i].filter ? tabs[i].filter->bits.as<uint32_t>() : nullptr;
+    a.fmask[i] = tabs[i].filter ? tabs[i].filter->mask : 0ull;
+    a.shift[i] = tabs[i].shift;
+  }
+  a.cs = ctx().count_sat;
+  if (nk == 3 && ks[0] == 21 && ks[1] == 31 && ks[2] == 51)
+    return launch_multi<KList<21, 31, 51>>(d_bases, d_offsets, nreads, a, stage_bytes);
+  if (nk == 4 && ks[0] == 30 && ks[1] == 40 && ks[2] == 50 && ks[3] == 60)
+    return launch_multi<KList<30, 40, 50, 60>>(d_bases, d_offsets, nreads, a, stage_bytes);
+  return fail(MG_ERR_ARG, "no fused stage-A kernel for this k set");
+}
+
+}  // namespace mg
