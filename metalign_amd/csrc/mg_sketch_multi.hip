@@ -12,6 +12,8 @@
 //
 // Replaces: kmc -k60 -ci2 -cs3 (scripts/select_db.py:50-52) + k-mer hashing in CMash's streaming multi-k query
 // (scripts/select_db.py:73-76).
+#include <cstdlib>
+
 #include "mg_sketch_dev.h"
 
 namespace mg {
@@ -35,7 +37,7 @@ struct MultiSink {
   uint8_t* lds_k;    // ... and the index of the k each belongs to
   const MultiArgs* A;  // in LDS
   int n;             // entries staged (wave-uniform)
-  unsigned long long produced[kMaxMultiK];
+  unsigned long long produced[kMaxMultiK];  // candidates inserted per k by this WAVEFRONT (wave-uniform: scalar registers)
 
   __device__ __forceinline__ void flush(int lane) {
     if (n == 0) return;
@@ -56,10 +58,11 @@ struct MultiSink {
     }
 #pragma unroll
     for (int j = 0; j < kCandBuf / 64; ++j) {
-      if (hh[j] == kReservedHash || !((fw[j] >> (hh[j] & 31u)) & 1u)) continue;
+      const bool go = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
       const uint32_t ki = kk[j];
 #pragma unroll
-      for (int q = 0; q < kMaxMultiK; ++q) produced[q] += ki == (uint32_t)q ? 1u : 0u;
+      for (int q = 0; q < kMaxMultiK; ++q) produced[q] += (unsigned)__popcll(__ballot(go && ki == (uint32_t)q));
+      if (!go) continue;
       if (!table_add(A->keys[ki], A->cnts[ki], hh[j] >> A->shift[ki], hh[j], 1u, A->cs))
         atomicAdd(A->counters[ki] + 2, 1ull);
     }
@@ -108,7 +111,7 @@ struct KList {
 // src points at the read's ASCII bases in HBM (a tile that does not fit the stage; MODE 0 only).
 template <class KL, bool CODES, int MODE>
 __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
-                                                 const MultiArgs* A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane) {
+                                                 const MultiArgs& A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane) {
   constexpr int KMAX = KL::kmax;
   static_assert(CODES || MODE == 0, "the clean walks read the LDS stage");
   Roller<KMAX> roll;
@@ -116,9 +119,9 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
   CodeStream cs;
   if constexpr (CODES) cs.open(src, start);
   const uint32_t maxlen = __builtin_amdgcn_readfirstlane(maxlen_v);
-  uint64_t hmax[KL::N];
+  uint64_t hmax[KL::N];  // (A is the kernel argument itself: these are scalar registers)
 #pragma unroll
-  for (int i = 0; i < KL::N; ++i) hmax[i] = A->hmax[i];
+  for (int i = 0; i < KL::N; ++i) hmax[i] = A.hmax[i];
   // positions [0, kmin - 1): no k-mer of any k is complete — rolled in without hashing (wave-uniform)
   constexpr uint32_t kWarm = (uint32_t)(KL::kmin - 1);
   const uint32_t warm = kWarm < maxlen ? kWarm : maxlen;
@@ -139,7 +142,8 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
       }(std::make_integer_sequence<int, KL::N>{});
     }
 #pragma unroll
-    for (int i = 0; i < KL::N; ++i) kmers[i] += len >= (uint32_t)KL::v[i] ? len - (uint32_t)KL::v[i] + 1u : 0u;
+    for (int i = 0; i < KL::N; ++i)  // the tile's k-mers in closed form, summed over the wavefront into a scalar
+      kmers[i] += wave_sum_u64(len >= (uint32_t)KL::v[i] ? len - (uint32_t)KL::v[i] + 1u : 0u);
     return;
   }
   uint32_t nk[KL::N];
@@ -162,13 +166,12 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
     }(std::make_integer_sequence<int, KL::N>{});
   }
 #pragma unroll
-  for (int i = 0; i < KL::N; ++i) kmers[i] += nk[i];
+  for (int i = 0; i < KL::N; ++i) kmers[i] += wave_sum_u64(nk[i]);
 }
 
 template <class KL>
-__global__ __launch_bounds__(kBlock) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
-                                                               const uint64_t* __restrict__ offsets, uint64_t nreads,
-                                                               const MultiArgs args, unsigned stage_bytes) {
+__device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                        uint64_t nreads, const MultiArgs& args, unsigned stage_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ MultiArgs s_args;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -208,24 +211,31 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads_multi(const uint8_t* __
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
       if (__ballot(bad != 0) != 0ull)
-        walk_reads_multi<KL, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+        walk_reads_multi<KL, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
       else if (__ballot(len != maxlen) == 0ull)
-        walk_reads_multi<KL, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+        walk_reads_multi<KL, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
       else
-        walk_reads_multi<KL, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+        walk_reads_multi<KL, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
       wave_lds_sync();
     } else {
-      walk_reads_multi<KL, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, &s_args, sink, kmers, lane);
+      walk_reads_multi<KL, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
     }
   }
   sink.flush(lane);
 #pragma unroll
-  for (int i = 0; i < KL::N; ++i) {
-    const uint64_t km = wave_sum_u64(kmers[i]);
-    if (lane == 0 && km) atomicAdd(s_args.counters[i] + 1, (unsigned long long)km);
-    const uint64_t pr = wave_sum_u64(sink.produced[i]);
-    if (lane == 0 && pr) atomicAdd(s_args.counters[i], (unsigned long long)pr);
+  for (int i = 0; i < KL::N; ++i) {  // (wave totals already: every lane holds the same value)
+    if (lane == 0 && kmers[i]) atomicAdd(args.counters[i] + 1, (unsigned long long)kmers[i]);
+    if (lane == 0 && sink.produced[i]) atomicAdd(args.counters[i], (unsigned long long)sink.produced[i]);
   }
+}
+
+// 137 VGPRs for {21,31,51}: three wavefronts per SIMD.  Held to 128 (four per SIMD, ten spilled registers) the kernel
+// takes the same time (16.03 against 16.01 ms per 10M reads): it is bound by VALU issue, not by latency.
+template <class KL>
+__global__ __launch_bounds__(kBlock) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
+                                                               const uint64_t* __restrict__ offsets, uint64_t nreads,
+                                                               const MultiArgs args, unsigned stage_bytes) {
+  sketch_reads_multi_body<KL>(bases, offsets, nreads, args, stage_bytes);
 }
 
 template <class KL>
