@@ -3,8 +3,8 @@
 Partitioning
   reads / alignment records   contiguous shards in stream order, cut on read boundaries (rank r holds shard r)
   genome sketch table         sharded by HASH RANGE: rank r holds, for every genome, the part of its sketch that
-                              falls in [ (hmax+1)*r/W, (hmax+1)*(r+1)/W ) -- hashes are uniform, so the slices are
-                              equal-sized, and a genome's containment is the SUM of its per-slice hit counts
+                              falls in [ b[r], b[r+1] ), b = the r/W quantiles of the table's hashes (table_bounds:
+                              equal-sized slices), and a genome's containment is the SUM of its per-slice hit counts
 Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)
   1. all-to-all of the per-rank read sketches by hash range (each rank sends 1/W of its sketch to every peer; the
      bytes a rank moves do not grow with W) -> every rank merges what it receives into ITS slice of the sample
@@ -37,8 +37,31 @@ def _u64(x):
 
 
 def slice_bounds(hmax, world):
-    """Hash-range slices: rank r owns hashes in [b[r], b[r+1]); b[0] = 0, b[world] = hmax + 1."""
+    """Equal-WIDTH hash-range slices: rank r owns hashes in [b[r], b[r+1]); b[0] = 0, b[world] = hmax + 1."""
     return [((int(hmax) + 1) * r) // world for r in range(world + 1)]
+
+
+def table_bounds(table_hashes, world, hmax=None, presorted=False):
+    """Equal-LOAD hash-range slices of a sketch table: b[r] = the r/world quantile of the table's hashes, b[0] = 0,
+    b[world] = hmax + 1.  A bottom-n sketch of genome g is uniform on [0, its own n-th smallest hash], and hmax is the
+    MAXIMUM of those over all genomes, so the table thins out towards hmax: with equal-width slices the top one held
+    3 M of a 200k-genome table's 200 M hashes and the others 28 M each (stage B and the sketch merge of seven ranks
+    12 % over the mean, one rank idle).  Quantiles make the slices equal-sized whatever the genome sizes; every rank
+    derives the same bounds from the same table."""
+    h = np.asarray(table_hashes)
+    total = len(h)
+    if hmax is None:
+        hmax = int(h.max()) if total else 0
+    if world <= 1:
+        return [0, int(hmax) + 1]
+    if total == 0:
+        return [0] + [int(hmax) + 1] * world
+    kth = [total * r // world for r in range(1, world)]
+    cut = h[kth] if presorted else np.partition(h, kth)[kth]
+    b = [0] + [int(x) for x in cut] + [int(hmax) + 1]
+    for r in range(1, world + 1):  # never decreasing (tiny tables with repeated hashes)
+        b[r] = max(b[r], b[r - 1])
+    return b
 
 
 def table_slice(dbh, dbo, lo, hi):
@@ -439,7 +462,7 @@ class ShardJob:
             self.G = disk.ngenomes
             for ki, k in enumerate(self.ks):
                 hmax = disk.max_hash(k)
-                b = slice_bounds(hmax, self.world)
+                b = table_bounds(disk.pairs(k)["pair_hash"], self.world, hmax, presorted=True)
                 self.hmaxs.append(hmax)
                 self.bounds.append(b)
                 if hasattr(self.engine, "set_filter"):
@@ -451,7 +474,7 @@ class ShardJob:
             self.G = len(per_k[0][1]) - 1
             for ki, (h, o) in enumerate(per_k):
                 hmax = table_max_hash(h, o)
-                b = slice_bounds(hmax, self.world)
+                b = table_bounds(h, self.world, hmax)
                 self.hmaxs.append(hmax)
                 self.bounds.append(b)
                 if hasattr(self.engine, "set_filter"):
