@@ -360,11 +360,11 @@ __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const 
 
 // One WAVEFRONT per bucket (no workgroup barriers: buckets are independent, four in flight per workgroup):
 // compact the bucket's occupied slots into the wave's LDS region, sort the (hash,count) pairs by hash with a
-// bitonic network (width = next power of two >= n, wave-synchronous steps) and write them to the bucket's
-// staging rows: stage_h[b][r], stage_c[b][r], r < nuniq[b].  Every hash of the bucket is distinct already.
-__global__ __launch_bounds__(256) void k_bucket_sort(const uint64_t* __restrict__ tab_keys,
-                                                     const uint32_t* __restrict__ tab_cnt, uint64_t nbuckets,
-                                                     uint64_t* __restrict__ stage_h, uint32_t* __restrict__ stage_c,
+// bitonic network (width = next power of two >= n, wave-synchronous steps) and write them back IN PLACE: the
+// bucket's first nuniq[b] slots then hold its hashes (no longer hash + 1) ascending, with their counts.  (The whole
+// bucket is in registers / LDS before the first store, and a bucket belongs to one wavefront; separate staging
+// rows cost 12 B per slot, 13 GB for a dense 400 M-candidate table.)  Every hash of the bucket is distinct already.
+__global__ __launch_bounds__(256) void k_bucket_sort(uint64_t* tab_keys, uint32_t* tab_cnt, uint64_t nbuckets,
                                                      uint32_t* __restrict__ nuniq, uint32_t cs) {
   __shared__ uint64_t s_keys[4][kBucketSlots];
   __shared__ uint32_t s_cnt[4][kBucketSlots];
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const uint64_t* __restrict_
         wave_lds_sync();
       }
     }
-    for (uint32_t i = lane; i < n; i += 64) { stage_h[base + i] = keys[i]; stage_c[base + i] = cnt[i]; }
+    for (uint32_t i = lane; i < n; i += 64) { tab_keys[base + i] = keys[i]; tab_cnt[base + i] = cnt[i]; }
     wave_lds_sync();
   }
 }
@@ -504,12 +504,19 @@ __global__ void k_sketch_split(const uint64_t* __restrict__ hashes, uint64_t n, 
 
 // meta[0] = runs, then: apply the complete-part bound (entries > bound dropped) and the s cut;
 // meta[1] = kept entries, meta[2] = last kept hash, meta[3] = 1 if anything was cut.
+// cap > 0: the sketch's buffers hold cap entries; a table with more distinct hashes than that (its size was an
+// estimate) is reported like a table overflow (meta[6]) and the sketch is redone by whoever resolves it.
 __global__ void k_sketch_meta(const uint64_t* __restrict__ unique, uint64_t* __restrict__ meta, uint64_t s,
                               uint32_t use_bound, uint64_t bound, const unsigned long long* __restrict__ counters,
-                              uint64_t* __restrict__ host_mirror) {
+                              uint64_t* __restrict__ host_mirror, uint64_t cap) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (counters) { meta[4] = counters[0]; meta[5] = counters[1]; meta[6] = counters[2]; }
-  const uint64_t runs = meta[0];
+  uint64_t runs = meta[0];
+  if (cap && runs > cap) {  // k_bucket_compact dropped what did not fit
+    meta[6] = (counters ? meta[6] : 0) + 1;
+    runs = cap;
+    meta[0] = cap;
+  }
   uint64_t keep = runs;
   uint64_t cut = 0;
   if (use_bound) {  // upper_bound(unique, bound)
@@ -549,7 +556,7 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
     hipLaunchKernelGGL(k_clamp_counts, dim3(ctx().num_cus * 4), dim3(256), 0, st, sk->counts.as<uint32_t>(), d_meta,
                        ctx().count_sat);
   hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), d_meta, s,
-                     (uint32_t)(use_bound ? 1 : 0), bound, (const unsigned long long*)nullptr, (uint64_t*)nullptr);
+                     (uint32_t)(use_bound ? 1 : 0), bound, (const unsigned long long*)nullptr, (uint64_t*)nullptr, (uint64_t)0);
   uint64_t* pin = host_words();
   MG_HIP(hipMemcpyAsync(pin + 4, d_meta, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (d_counters) MG_HIP(hipMemcpyAsync(pin + 8, d_counters, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -595,8 +602,6 @@ struct TablePlan {
   uint64_t nbuckets = 0, slots = 0;
   uint64_t* keys = nullptr;   // [slots], 0 = empty, else hash + 1
   uint32_t* cnts = nullptr;   // [slots]
-  uint64_t* stage_h = nullptr;
-  uint32_t* stage_c = nullptr;
   uint32_t* nuniq = nullptr;
   uint64_t* offs = nullptr;
 };
@@ -634,13 +639,11 @@ static int alloc_table_core(TablePlan& tp, unsigned long long** d_counters, int 
   return MG_OK;
 }
 
-// The staging rows table_pack sorts the buckets into (written sparsely, shared by consecutive tables of a stream).
+// Per-bucket counts and offsets of table_pack (shared by consecutive tables of a stream).
 static int alloc_table_staging(TablePlan& tp) {
-  tp.stage_h = (uint64_t*)scratch("sk_stage_h", tp.slots * sizeof(uint64_t));
-  tp.stage_c = (uint32_t*)scratch("sk_stage_c", tp.slots * sizeof(uint32_t));
   tp.nuniq = (uint32_t*)scratch("sk_bucket_n", tp.nbuckets * sizeof(uint32_t));
   tp.offs = (uint64_t*)scratch("sk_bucket_off", (tp.nbuckets + 1) * sizeof(uint64_t));
-  if (!tp.stage_h || !tp.stage_c || !tp.nuniq || !tp.offs) return MG_ERR_NOMEM;
+  if (!tp.nuniq || !tp.offs) return MG_ERR_NOMEM;
   return MG_OK;
 }
 
@@ -649,24 +652,26 @@ static int alloc_table(TablePlan& tp, unsigned long long** d_counters = nullptr)
   return alloc_table_core(tp, d_counters, 0);
 }
 
-// Sort every bucket and pack the buckets in order into the sketch's own buffers (d_meta[0] = distinct hashes).
-static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta) {
+// Sort every bucket and pack the buckets in order into the sketch's own buffers of `cap` entries (d_meta[0] = distinct
+// hashes; what exceeds cap is dropped and must be detected by the caller: k_sketch_meta's cap).
+static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint64_t cap) {
   Context& c = ctx();
   hipStream_t st = c.stream;
+  if (cap > tp.slots) cap = tp.slots;  // a sketch cannot outgrow the table
   {
     ProfScope ps("bucket_sort");
     hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, tp.keys,
-                       tp.cnts, tp.nbuckets, tp.stage_h, tp.stage_c, tp.nuniq, c.count_sat);
+                       tp.cnts, tp.nbuckets, tp.nuniq, c.count_sat);
     MG_HIP(hipGetLastError());
   }
-  MG_TRY(sk->hashes.alloc((tp.slots + 1) * sizeof(uint64_t)));  // a sketch cannot outgrow the table
-  MG_TRY(sk->counts.alloc((tp.slots + 1) * sizeof(uint32_t)));
+  MG_TRY(sk->hashes.alloc((cap + 1) * sizeof(uint64_t)));
+  MG_TRY(sk->counts.alloc((cap + 1) * sizeof(uint32_t)));
   {
     ProfScope ps("bucket_pack");
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, tp.nuniq, tp.nbuckets, tp.offs, d_meta);
     hipLaunchKernelGGL(k_bucket_compact, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
-                       tp.stage_h, tp.stage_c, tp.nuniq, tp.offs, tp.nbuckets, sk->hashes.as<uint64_t>(),
-                       sk->counts.as<uint32_t>(), tp.slots);
+                       tp.keys, tp.cnts, tp.nuniq, tp.offs, tp.nbuckets, sk->hashes.as<uint64_t>(),
+                       sk->counts.as<uint32_t>(), cap);
     MG_HIP(hipGetLastError());
   }
   return MG_OK;
@@ -674,8 +679,8 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta) {
 
 // ... then apply bound / s and read back.
 static int table_to_sketch(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_bound, uint64_t bound,
-                           const unsigned long long* d_counters, uint64_t* h_counters) {
-  MG_TRY(table_pack(tp, sk, d_meta));
+                           const unsigned long long* d_counters, uint64_t* h_counters, uint64_t cap) {
+  MG_TRY(table_pack(tp, sk, d_meta, cap));
   return adopt_runs(sk, d_meta, s, use_bound, bound, d_counters, h_counters);
 }
 
@@ -887,18 +892,22 @@ static int finish_pending(mg_sketch* sk, const KPlan& kp, const ReadPlan& rp, un
   if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
   MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
   uint64_t* sk_meta = sk->meta.as<uint64_t>();
-  MG_TRY(table_pack(kp.tp, sk, sk_meta));
+  // the sketch's buffers are sized from the distinct-count estimate (which is the candidate count itself until a
+  // first batch has been seen, and twice the observed ratio afterwards), not from the table's slots (2.7 per
+  // expected entry): 12 B instead of 32 per expected entry and sketch in flight
+  uint64_t cap = (uint64_t)kp.distinct_est + 1024;
+  if (cap > kp.tp.slots) cap = kp.tp.slots;
+  MG_TRY(table_pack(kp.tp, sk, sk_meta, cap));
   sk->h_meta = cc.pend_pinned + 8 * slot;
   hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s, 0u, (uint64_t)0,
-                     (const unsigned long long*)t_counters, sk->h_meta);
+                     (const unsigned long long*)t_counters, sk->h_meta, cap);
   MG_HIP(hipGetLastError());
   sk->ev = take_event();
   if (sk->ev) { MG_HIP(hipEventRecord(sk->ev, st)); sk->ev_stream = st; }
   sk->pending = true;
   sk->pend_slot = (int)slot;
   cc.pend_owner[slot] = sk;
-  sk->n_bound = kp.tp.slots;  // a sketch cannot outgrow the table; tightened below
-  if ((uint64_t)kp.distinct_est + 1 < sk->n_bound) sk->n_bound = (uint64_t)kp.distinct_est + 1;
+  sk->n_bound = cap;
   if (s > 0 && s < sk->n_bound) sk->n_bound = s;
   sk->hmax = kp.hmax;
   sk->expect = (double)(kp.expect ? kp.expect : 1);
@@ -1118,7 +1127,7 @@ int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint
       MG_HIP(hipGetLastError());
     }
     uint64_t h_counters[3] = {0, 0, 0};
-    MG_TRY(table_to_sketch(tp, sk.get(), d_meta, s, any_truncated != 0, bound, d_counters, h_counters));
+    MG_TRY(table_to_sketch(tp, sk.get(), d_meta, s, any_truncated != 0, bound, d_counters, h_counters, n));  // a union of n pairs has <= n entries
     if (h_counters[2] == 0) {
       *out = sk.release();
       return MG_OK;
@@ -1158,10 +1167,10 @@ int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts
   if (cc.pend_owner[slot]) MG_TRY(sketch_resolve(cc.pend_owner[slot], nullptr));  // ring full: settle the oldest
   MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
   uint64_t* sk_meta = sk->meta.as<uint64_t>();
-  MG_TRY(table_pack(tp, sk.get(), sk_meta));
+  MG_TRY(table_pack(tp, sk.get(), sk_meta, n));  // (the union has at most n entries: no capacity check needed)
   sk->h_meta = cc.pend_pinned + 8 * slot;
   hipLaunchKernelGGL(k_sketch_meta, dim3(1), dim3(64), 0, st, sk->hashes.as<uint64_t>(), sk_meta, s,
-                     (uint32_t)(any_truncated ? 1 : 0), bound, (const unsigned long long*)t_counters, sk->h_meta);
+                     (uint32_t)(any_truncated ? 1 : 0), bound, (const unsigned long long*)t_counters, sk->h_meta, (uint64_t)0);
   MG_HIP(hipGetLastError());
   sk->ev = take_event();
   if (sk->ev) { MG_HIP(hipEventRecord(sk->ev, st)); sk->ev_stream = st; }

@@ -139,6 +139,14 @@ class HipEngine:
             sk.resolve()
         return sks
 
+    def prime(self, ks, hmaxs, s):
+        """One stage-A pass over the resident reads, settled and dropped: the library sizes its counting tables and sketch
+        buffers from the distinct-to-candidate ratio of the PREVIOUS batch of the same k and has none yet — without this,
+        every pass a pipelined job queues before its first read-back is sized for the worst case (a dense 200k-genome
+        table: 13 GB of table and 5 GB of sketch per k and pass in flight, against 1-2 GB once the ratio is known)."""
+        for sk in self.sketch_local(ks, hmaxs, s):
+            sk.free()
+
     def sketch_local_async(self, ks, hmaxs, s):
         """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set)."""
         return self.hip.sketch_reads_multi_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, ks, hmaxs, s,
@@ -504,6 +512,8 @@ class ShardJob:
         else:
             self.nonempty = [len(recs) > 0]
         self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
+        if hasattr(self.engine, "prime") and len(roffsets) > 1:
+            self.engine.prime(self.ks, self.hmaxs, self.s)
         if hasattr(self.engine, "hip"):
             # stage C runs on the library's second stream: its latency-bound passes overlap stage A's tail, stage B
             # and (with the exchange) the collectives  (MG_SINGLE_STREAM=1: everything on one stream, for profiles in
