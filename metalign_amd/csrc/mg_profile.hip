@@ -30,6 +30,7 @@
 // 5 B of scratch per record and ran two single-workgroup scans: 17.2 ms at 125 M records).
 // COMMIT = false is the same chain without step 5: the shard's composed state map and read count, which a
 // multi-GPU job needs from every shard before any of them can commit.
+#include <cstdlib>
 #include <memory>
 
 #include "mg_internal.h"
@@ -71,14 +72,16 @@ __device__ __forceinline__ uint2 make_desc(const mg_aln_rec& r, uint32_t tax, do
 __device__ __forceinline__ uint32_t slot(uint32_t i) { return i + (i >> 3); }
 constexpr int kSlots = kStaged + (kStaged >> 3) + 1;
 
-// Descriptors of records [t0, t0 + nst) live in LDS; anything past that (a read longer than the halo) is
-// rebuilt from HBM.
-// The LDS pointer keeps its address space in the type: as a generic pointer inside a struct the compiler fell back
-// to FLAT loads in eval_group, and with a FLAT access possibly in flight every wait in the commit loop became
-// vmcnt(0) — each read then waited for its own multimapped-list stores to reach memory.
-typedef const __attribute__((address_space(3))) unsigned long long* LdsDescPtr;  // a uint2 as one 64-bit word
+// What the tile staged in LDS for 64 consecutive records: four bit planes (new read / pair-1 flag / pair-2 flag /
+// rejected), next to a taxon and a running length sum per record.
+struct Planes { uint64_t nw, a, b, r; };
+
+// The general evaluator's view of the records: those of [t0, t0 + nst) come out of the tile's LDS stage, anything
+// past that (a read longer than the halo) is rebuilt from HBM.
 struct DescView {
-  LdsDescPtr lds;
+  const Planes* pl;          // LDS
+  const uint32_t* tax;       // LDS
+  const uint32_t* pfx;       // LDS: inclusive sum of len(SEQ) within the record's 64-block
   uint64_t t0;
   uint32_t nst;
   const mg_aln_rec* __restrict__ recs;
@@ -86,8 +89,12 @@ struct DescView {
   double pct_id;
   __device__ __forceinline__ uint2 operator()(uint64_t i) const {
     if (i - t0 < nst) {
-      const unsigned long long w = lds[slot((uint32_t)(i - t0))];
-      return make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+      const uint32_t x = (uint32_t)(i - t0), b = x & 63u;
+      const Planes P = pl[x >> 6];
+      const uint32_t len = pfx[x] - (b ? pfx[x - 1] : 0u);
+      return make_uint2(tax[x], (uint32_t)((P.nw >> b) & 1ull) | ((uint32_t)((P.r >> b) & 1ull) << 1) |
+                                    ((uint32_t)((P.a >> b) & 1ull) << 2) | ((uint32_t)((P.b >> b) & 1ull) << 3) |
+                                    (len << D_LEN_SHIFT));
     }
     const mg_aln_rec r = recs[i];
     return make_desc(r, ref2tax[r.ref_new & MG_REC_REF_MASK], pct_id);
@@ -426,19 +433,20 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
   return f;
 }
 
-// Per-workgroup privatised histogram in LDS, flushed with global atomics every kFlushTiles tiles and at the end:
-//   use_lds_hist == 1  direct:  ntax <= 4096 bins (dynamic LDS: 12 B per bin; above 2048 taxa two workgroups per CU, like the hashed form)
-//   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
-//                      fewer taxa than the table lists); a taxon that finds no bin within kHashProbe steps
-//                      goes to global atomics directly.  Without this a skewed sample serialises millions of
-//                      global atomics on a few hundred addresses.
-//   use_lds_hist == 0  global atomics only (shards of 2^32 reads or more: the bins hold 32-bit read indices).
-// A bin is ONE packed 64-bit word (count << 40 | bases) plus the 32-bit shard-relative index of the first read
-// seen: one LDS atomic per unique read (the minimum is only attempted when a plain read says it would change
-// something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
-// had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
-// pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
-constexpr uint32_t kHashSlots = 2048, kHashProbe = 32, kFlushTiles = 256;
+// Per-workgroup privatised histogram, flushed every kFlushTiles tiles and at the end:
+//   hist_mode == 1  LDS, direct: ntax <= 4096 bins of 12 B (dynamic LDS; above 2048 taxa two workgroups per CU).  A bin
+//                   is ONE packed 64-bit word (count << 40 | bases) plus the 32-bit shard-relative index of the first
+//                   read seen: one LDS atomic per unique read (the minimum is only attempted when a plain read says it
+//                   would change something).  Flushed into the global accumulators with device-scope atomics.
+//   hist_mode == 2  any ntax: the same bins PRIVATE TO THE WORKGROUP IN GLOBAL MEMORY, updated with WORKGROUP-scope
+//                   atomics — executed in the L2 of the XCD the workgroup runs on, not at the memory side like the
+//                   device-scope ones (which retire at ~14 G/s on this multi-XCD part and made the 10 001-taxa case 4x
+//                   slower than the 2 001-taxa one when a hashed LDS table of 2048 bins overflowed into them).  Nothing
+//                   else touches a workgroup's copy while the kernel runs; k_bins_reduce sums the copies afterwards.
+//   hist_mode == 0  global device-scope atomics only (shards of 2^32 reads or more: the bins hold 32-bit read indices).
+// Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a packed field.
+constexpr uint32_t kFlushTiles = 256;
+constexpr uint32_t kMapOnly = 3;  // hist_mode of the map-only pass: nothing is committed
 constexpr uint32_t kBinLenLimit = 1u << 20;
 constexpr int kBinCountShift = 40;
 
@@ -453,8 +461,10 @@ struct PassArgs {
   uint64_t ntiles;
   uint32_t incoming, first_shard;
   uint64_t group_base;
-  uint32_t ntax, use_lds_hist;
+  uint32_t ntax, hist_mode;
   unsigned long long *g_count, *g_bases, *g_first, *g_scalars;
+  unsigned long long* priv_pack;  // hist_mode 2: [gridDim.x][ntax] packed bins ...
+  uint32_t* priv_first;           // ... and first-seen words, zeroed / 0xffffffff by k_pass_prepare
   uint64_t* mm_offsets; uint32_t* mm_tax; uint64_t* mm_hitlen; uint64_t* mm_read;
   uint64_t* out_tot;              // [0] composed map, [1] reads, [2] multimapped entries, [3] multimapped reads
 };
@@ -477,12 +487,104 @@ extern "C" int mg_debug_k3_phases(unsigned long long* out, int reset) {
 #define PH(i)
 #define PH_FLUSH(c)
 #endif
+
+// ---- lane-per-record evaluation ----
+// A tile's records are reduced to four BIT PLANES (one 64-bit word per 64 consecutive records: new read / pair-1
+// flag / pair-2 flag / rejected) plus a taxon and a running length sum per record, all in LDS.  A read leader then
+// sees its whole read as 64-bit windows of those planes (a funnel shift of two words), and process_read's counters
+// (:130-147,:152-176) are popcounts over the read's segment of the window — for both hypotheses at once, since
+// "first line dropped" is the same segment without its lowest bit.  No per-read loop, no divergence between reads
+// of different line counts; reads of 64 lines or more, or running past the staged halo, take eval_group over HBM.
+constexpr int kWords = kStaged / 64;  // 33: 32 words of the tile + one of halo
+static_assert(kStaged % 64 == 0 && kTile / 64 == 32, "one word-level scan lane per word of the tile");
+
+__device__ __forceinline__ uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t s) {
+  return s ? (lo >> s) | (hi << (64u - s)) : lo;
+}
+__device__ __forceinline__ uint64_t lt_mask(uint32_t i) { return i >= 64u ? ~0ull : ((1ull << i) - 1ull); }  // bits below i
+__device__ __forceinline__ uint32_t parity64(uint64_t v) { return (uint32_t)__popcll(v) & 1u; }
+
+// What a leader keeps between the evaluation and the commit: per hypothesis the kind (2 bits), the multimapped
+// entries it would emit (7 bits) and the window offset of its first kept line (6 bits); bit 31 = slow path.
+constexpr uint32_t kEvSlow = 1u << 31;
+__device__ __forceinline__ uint32_t ev_pack(uint32_t kind, uint32_t nmm, uint32_t first) { return kind | (nmm << 2) | (first << 9); }
+__device__ __forceinline__ uint32_t ev_kind(uint32_t e) { return e & 3u; }
+__device__ __forceinline__ uint32_t ev_nmm(uint32_t e) { return (e >> 2) & 127u; }
+__device__ __forceinline__ uint32_t ev_first(uint32_t e) { return (e >> 9) & 63u; }
+
+// intersect_read_hits (:115-125) + the paired branch of process_read (:157-169) for a read whose kept lines are the
+// set bits of `kept` (window offsets from the tile-local position p0): the first `split` kept lines are read 1's,
+// the rest read 2's.  Returns kind | entries << 2; out != nullptr: writes the taxon list of a multimapped read.
+__device__ __forceinline__ uint32_t intersect_lds(const uint32_t* __restrict__ tax, uint32_t p0, uint64_t kept, int split,
+                                                  uint32_t* out) {
+  const int nk = __popcll(kept);
+  if (split < 0) split = 0;
+  if (split > nk) split = nk;
+  uint64_t first_set = 0, m = kept;  // the first `split` kept lines
+  for (int o = 0; o < split; ++o) { first_set |= m & (~m + 1ull); m &= m - 1ull; }
+  const uint64_t second_set = kept & ~first_set;
+  auto in_set = [&](uint64_t set, uint32_t t) {
+    for (uint64_t q = set; q; q &= q - 1ull)
+      if (tax[p0 + (uint32_t)__builtin_ctzll(q)] == t) return true;
+    return false;
+  };
+  uint32_t ndistinct = 0;
+  for (uint64_t q = first_set; q; q &= q - 1ull) {  // |set(pair1refs) & set(pair2refs)| (:121-122)
+    const uint32_t o = (uint32_t)__builtin_ctzll(q);
+    const uint32_t t = tax[p0 + o];
+    if (!in_set(second_set, t)) continue;
+    if (!in_set(first_set & lt_mask(o), t)) ++ndistinct;  // first occurrence in read 1's lines
+  }
+  if (ndistinct == 0) return 0u;   // :164-165
+  if (ndistinct == 1) return 1u;   // :166-167 (taxon of the FIRST kept line)
+  uint32_t n = 0;                  // :168-169
+  for (uint64_t q = kept; q; q &= q - 1ull) {
+    const uint32_t t = tax[p0 + (uint32_t)__builtin_ctzll(q)];
+    if (in_set(first_set, t) && in_set(second_set, t)) {
+      if (out) out[n] = t;
+      ++n;
+    }
+  }
+  return 2u | (n << 2);
+}
+
+// process_read's decision for the segment `seg` of the windows (aw, bw, rw): kind | entries << 2 | first kept << 9.
+// kind 2 with more than 127 entries cannot be packed: the caller takes the slow path for such a read (>= 64 lines
+// never gets here, so this cannot happen; the field is simply wide enough).
+__device__ __forceinline__ uint32_t eval_seg(uint64_t seg, uint64_t aw, uint64_t bw, uint64_t rw, bool np,
+                                             const uint32_t* __restrict__ tax, uint32_t p0) {
+  const uint64_t kept = seg & ~rw;
+  const int nk = __popcll(kept);
+  if (nk == 0) return 0u;                                                     // :155-156
+  const int p1 = __popcll(seg & (aw | ~bw)) - __popcll(seg & rw & aw);      // clean_read_hits :137-138
+  const int p2 = __popcll(seg & bw) - __popcll(seg & rw & ~aw & bw);        // :139-140
+  const uint32_t first = (uint32_t)__builtin_ctzll(kept);
+  if (np) {                                                                   // :157
+    if (p1 + p2 == 1) return ev_pack(1u, 0u, first);                          // :158-160
+    if (p1 == 0 || p2 == 0) return 0u;                                        // :116-117 -> :164-165
+    const uint32_t k = intersect_lds(tax, p0, kept, p1, nullptr);
+    return ev_pack(k & 3u, k >> 2, first);
+  }
+  if (p1 > 1) return ev_pack(2u, (uint32_t)nk, first);                        // :172-173
+  return ev_pack(1u, 0u, first);                                              // :174-176
+}
+
 template <bool COMMIT>
 __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   PH_DECL;
   extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
-  __shared__ uint2 s_desc[kSlots];
-  __shared__ RunFn s_run[kPB / 64];
+  __shared__ Planes s_pl[kWords + 1];
+  __shared__ uint32_t s_tax[kStaged];
+  __shared__ uint32_t s_pfx[kStaged];            // inclusive sum of len(SEQ) within the record's 64-block
+  __shared__ uint64_t s_ab[2][kTile / 64];       // per word of the tile: state-map planes (a: depends on the state, b: value)
+  __shared__ uint32_t s_wmm[2][kTile / 64], s_went[2][kTile / 64];  // per word, per tile-incoming state: multimapped reads / entries
+  // reads that do not fit a window (64 lines or more, or running into the end of the staged records): at most one per 64
+  // records of the tile + one; evaluated by a loop of their own (ONE copy of the general evaluator, not one per round)
+  constexpr int kSlowCap = kTile / 64 + 8;
+  __shared__ uint32_t s_nslow;
+  __shared__ uint32_t s_slow_p[kSlowCap], s_slow_e[2][kSlowCap];   // position; kind | entries << 2 per hypothesis
+  __shared__ uint64_t s_slow_so[kSlowCap], s_slow_eo[kSlowCap], s_slow_gidx[kSlowCap];
+  __shared__ uint32_t s_slow_st[kSlowCap];
   __shared__ uint64_t s_bcast[4];
   __shared__ TileFn s_lb[kLbWaves];
   __shared__ u32x4 s_lbuf[kLbWaves][kWinTiles * 2];  // look-back windows staged for their wavefronts (8 KB each)
@@ -490,30 +592,28 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   __shared__ unsigned long long s_ticket;
   __shared__ unsigned long long s_ambig, s_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t nbins = A.use_lds_hist == 2 ? kHashSlots : A.ntax;
+  constexpr int kRounds = kTile / kPB;
+  const uint32_t nbins = A.ntax;
   unsigned long long* h_pack = hist;                                     // count << 40 | bases
   uint32_t* h_first = reinterpret_cast<uint32_t*>(hist + nbins);         // first read seen, relative to the shard
-  uint32_t* h_key = h_first + nbins;                                     // hashed mode only
+  unsigned long long* const p_pack = A.priv_pack ? A.priv_pack + (size_t)blockIdx.x * A.ntax : nullptr;
+  uint32_t* const p_first = A.priv_first ? A.priv_first + (size_t)blockIdx.x * A.ntax : nullptr;
   auto flush_bins = [&](bool reset) {
     for (uint32_t t = tid; t < nbins; t += kPB) {
       const unsigned long long pk = h_pack[t];
       if (pk) {
-        const uint32_t tax = A.use_lds_hist == 2 ? h_key[t] : t;
-        atomicAdd(&A.g_count[tax], pk >> kBinCountShift);
-        atomicAdd(&A.g_bases[tax], pk & ((1ull << kBinCountShift) - 1));
-        atomicMin(&A.g_first[tax], (unsigned long long)(A.group_base + h_first[t]));
+        atomicAdd(&A.g_count[t], pk >> kBinCountShift);
+        atomicAdd(&A.g_bases[t], pk & ((1ull << kBinCountShift) - 1));
+        atomicMin(&A.g_first[t], (unsigned long long)(A.group_base + h_first[t]));
         if (reset) { h_pack[t] = 0; h_first[t] = 0xffffffffu; }
       }
     }
   };
   uint32_t tiles_binned = 0;
-  if (COMMIT && A.use_lds_hist) {
-    for (uint32_t t = tid; t < nbins; t += kPB) {
-      h_pack[t] = 0; h_first[t] = 0xffffffffu;
-      if (A.use_lds_hist == 2) h_key[t] = 0xffffffffu;
-    }
+  if (COMMIT && A.hist_mode == 1) {
+    for (uint32_t t = tid; t < nbins; t += kPB) { h_pack[t] = 0; h_first[t] = 0xffffffffu; }
   }
-  if (tid == 0) { s_ambig = 0; s_groups = 0; }
+  if (tid == 0) { s_ambig = 0; s_groups = 0; s_nslow = 0; s_pl[kWords] = Planes{0, 0, 0, 0}; }
   __syncthreads();
 
   for (;;) {
@@ -530,71 +630,191 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
     const uint64_t t0 = tile * kTile;
     const uint32_t nst = (uint32_t)(A.ntotal - t0 < (uint64_t)kStaged ? A.ntotal - t0 : (uint64_t)kStaged);  // staged
     const uint32_t nown = (uint32_t)(A.nrecs - t0 < (uint64_t)kTile ? A.nrecs - t0 : (uint64_t)kTile);      // owned
-    // 1. records -> descriptors in LDS (coalesced 16-byte loads, one division per record)
-    for (uint32_t i = tid; i < nst; i += kPB) {
-      const mg_aln_rec r = A.recs[t0 + i];
-      s_desc[slot(i)] = make_desc(r, A.ref2tax[r.ref_new & MG_REC_REF_MASK], A.pct_id);
+    // 1. records -> bit planes + taxon + length prefix in LDS (coalesced 16-byte loads, one division per record);
+    //    a wavefront holds 64 consecutive records per round: its ballots ARE the plane words
+#pragma unroll
+    for (int it = 0; it < (kStaged + kPB - 1) / kPB; ++it) {
+      const uint32_t i = (uint32_t)it * kPB + tid;
+      if (it == kStaged / kPB && wave != 0) break;  // the halo is one word: wavefront 0's
+      const bool valid = i < nst;
+      mg_aln_rec r{0, 0, 1, 0};
+      if (valid) r = A.recs[t0 + i];
+      const uint32_t tx = valid ? A.ref2tax[r.ref_new & MG_REC_REF_MASK] : 0u;
+      const uint32_t fl = r.flag_len & MG_REC_FLAG_MASK;
+      const bool pa = (fl & 1u) && (fl & 64u);   // parse_flag :106
+      const bool pb = (fl & 1u) && (fl & 128u);  // :107
+      // filter_line (:86-100) or chimeric (:108,135)
+      const bool rej = ((double)r.matched / (double)r.total < A.pct_id) || (fl & 2048u);
+      const uint32_t len = valid ? (r.flag_len >> MG_REC_LEN_SHIFT) : 0u;
+      uint32_t inc = len;  // inclusive sum over the 64-block
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      const uint64_t mn = __ballot(valid && (r.ref_new >> 31)), ma = __ballot(valid && pa), mb = __ballot(valid && pb),
+                     mr = __ballot(valid && rej);
+      if (i < (uint32_t)kStaged) { s_tax[i] = tx; s_pfx[i] = inc; }
+      if (lane == 0) s_pl[i >> 6] = Planes{mn, ma, mb, mr};
     }
     __syncthreads();
     PH(1);
-    const DescView at{(LdsDescPtr)s_desc, t0, nst, A.recs, A.ref2tax, A.pct_id};
+    const DescView at{s_pl, s_tax, s_pfx, t0, nst, A.recs, A.ref2tax, A.pct_id};  // (for the reads that do not fit a window)
 
-    // 2. leaders classify their read under both hypotheses; the thread's 8 records fold into one RunFn
-    const uint32_t l0 = (uint32_t)tid * kItems;
-    RunFn mine{kIdentity, {0, 0}};
-    {
-      uint32_t st0 = 0, st1 = 1;  // state after the records seen so far, for the thread entered kept / dropped
-      for (int j = 0; j < kItems; ++j) {
-        const uint32_t li = l0 + j;
-        if (li >= nown) break;
-        const uint2 d = s_desc[slot(li)];
-        if (!(d.y & D_NEW)) continue;
-        mine.pk[0] += kPkOneRead;
-        mine.pk[1] += kPkOneRead;
-        uint32_t e = li + 1;
-        while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
-        uint32_t k0, k1;  // kind | nmm << 2 under "kept" / "dropped"
-        if (e < nst) {
-          const bool np = s_desc[slot(e)].y & (D_P1 | D_P2);
-          Walk w{0, 0, 0, 0, 0}, w1{0, 0, 0, 0, 0};
-          walk_add(w, d);
-          for (uint32_t q = li + 1; q < e; ++q) {  // "dropped" is the same read without its first line
-            const uint2 dq = s_desc[slot(q)];
-            walk_add(w, dq);
-            walk_add(w1, dq);
-          }
-          k0 = classify(w, np);
-          k1 = classify(w1, np);
-          if (k0 == 3u) { const Verdict v = eval_group(at, t0 + li, t0 + e, true, nullptr); k0 = v.kind | (v.nmm << 2); }
-          if (k1 == 3u) { const Verdict v = eval_group(at, t0 + li + 1, t0 + e, true, nullptr); k1 = v.kind | (v.nmm << 2); }
-        } else {  // the read runs past the staged window (or to the end of the shard)
-          uint64_t ge = t0 + e;
-          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
-          if (ge >= A.ntotal) continue;  // no closing line: the read is never processed (:259-264)
-          const bool np = at(ge).y & (D_P1 | D_P2);
-          const Verdict v0 = eval_group(at, t0 + li, ge, np, nullptr);
-          const Verdict v1 = eval_group(at, t0 + li + 1, ge, np, nullptr);
-          k0 = v0.kind | (v0.nmm << 2);
-          k1 = v1.kind | (v1.nmm << 2);
+    // 2. every leader evaluates its read under both hypotheses from the windows
+    uint32_t ev0[kRounds], ev1[kRounds], hs[kRounds];
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const uint32_t p = (uint32_t)j * kPB + tid;
+      const uint32_t w = p >> 6, sft = p & 63u;
+      const Planes P0 = s_pl[w], P1 = s_pl[w + 1];
+      const bool leader = p < nown && ((P0.nw >> sft) & 1ull);
+      uint32_t e0 = 0, e1 = 0, hsum = 0;
+      bool amb0 = false, amb1 = false;  // identity for non-leaders: a = 1, b = 0
+      bool processed = false, slow_here = false;
+      if (leader) {
+        const uint64_t nwin = funnel(P0.nw, P1.nw, sft) & ~1ull;
+        if (nwin) {
+          const uint32_t nxt = (uint32_t)__builtin_ctzll(nwin);  // 1..63: the closing line is staged
+          const uint64_t seg = lt_mask(nxt);
+          const uint64_t aw = funnel(P0.a, P1.a, sft), bw = funnel(P0.b, P1.b, sft), rw = funnel(P0.r, P1.r, sft);
+          const bool np = ((aw | bw) >> nxt) & 1ull;
+          e0 = eval_seg(seg, aw, bw, rw, np, s_tax, p);
+          e1 = eval_seg(seg & ~1ull, aw, bw, rw, np, s_tax, p);
+          const uint32_t end = p + nxt - 1;
+          const uint32_t pfx_p = s_pfx[p], len_p = pfx_p - (sft ? s_pfx[p - 1] : 0u);
+          const uint32_t before = pfx_p - len_p;  // sum of the block's lengths below p
+          hsum = (end >> 6) == w ? s_pfx[end] - before : (s_pfx[(w << 6) + 63] - before) + s_pfx[end];
+          processed = true;
+        } else {
+          // the read runs past the staged window (64 lines or more, or to the end of the shard): registered here,
+          // evaluated below; until then the position counts as an identity
+          const uint32_t idx = atomicAdd(&s_nslow, 1u);
+          s_slow_p[idx] = p;
+          e0 = e1 = kEvSlow | idx;
+          slow_here = true;
         }
-        // advance both paths through this read
-        const uint32_t ka = st0 ? k1 : k0, kb = st1 ? k1 : k0;
-        if (COMMIT) {
-          if ((ka & 3u) == 2u) mine.pk[0] += kPkOneMm + (ka >> 2);
-          if ((kb & 3u) == 2u) mine.pk[1] += kPkOneMm + (kb >> 2);
-        }
-        st0 = (ka & 3u) == 0u;
-        st1 = (kb & 3u) == 0u;
+        if (processed) { amb0 = ev_kind(e0) == 0u; amb1 = ev_kind(e1) == 0u; }
       }
-      mine.out = st0 | (st1 << 1);
+      ev0[j] = (processed || slow_here) ? e0 : 0xffffffffu;  // 0xffffffff: nothing to commit at this position
+      ev1[j] = e1;
+      hs[j] = hsum;
+      // state map of the position: out(s) = a s ^ b; a = out0 ^ out1, b = out0; positions without a processed read: identity
+      const uint64_t ma = __ballot(!(processed && (amb0 == amb1))), mb = __ballot(processed && amb0);
+      if (lane == 0) { s_ab[0][j * (kPB / 64) + wave] = ma; s_ab[1][j * (kPB / 64) + wave] = mb; }
+      asm volatile("" ::: "memory");  // one round's windows at a time: hoisting all eight rounds' LDS reads costs 128 VGPRs
     }
-    // 3. ordered scan over the workgroup; tile aggregate
+    __syncthreads();
+    if (s_nslow) {  // (uniform)
+      for (uint32_t idx = tid; idx < s_nslow; idx += kPB) {
+        const uint32_t p = s_slow_p[idx];
+        const uint64_t ge = [&] { uint64_t g = t0 + p + 1; while (g < A.ntotal && !(A.recs[g].ref_new & MG_REC_NEW_BIT)) ++g; return g; }();
+        uint32_t k0 = 3u, k1 = 3u;  // kind 3: no closing line — the read is never processed (:259-264), the position stays an identity
+        if (ge < A.ntotal) {
+          const bool np = at(ge).y & (D_P1 | D_P2);
+          const Verdict v0 = eval_group(at, t0 + p, ge, np, nullptr);
+          const Verdict v1 = eval_group(at, t0 + p + 1, ge, np, nullptr);
+          k0 = (v0.kind & 3u) | (v0.nmm << 2);
+          k1 = (v1.kind & 3u) | (v1.nmm << 2);
+          const bool amb0 = v0.kind == 0u, amb1 = v1.kind == 0u;
+          const uint64_t bit = 1ull << (p & 63u);
+          if (amb0 == amb1) atomicAnd((unsigned long long*)&s_ab[0][p >> 6], ~bit);  // a = 0: a constant map
+          if (amb0) atomicOr((unsigned long long*)&s_ab[1][p >> 6], bit);
+        }
+        s_slow_e[0][idx] = k0;
+        s_slow_e[1][idx] = k1;
+      }
+      __syncthreads();
+    }
     PH(2);
-    RunFn tile_fn;
-    const RunFn excl = block_scan_runs(mine, s_run, &tile_fn);
+
+    // 3. state entering every word, for the tile entered kept (s = 0) / dropped (s = 1): every 2-state map is affine
+    //    over GF(2), so a run of maps composes by "last reset + parity of the b bits since" — on 64-bit masks.  Lane l
+    //    (< 32) summarises word l; the same trick one level up gives every word's incoming state.  All wavefronts do
+    //    this redundantly (no barrier, no broadcast).
+    uint32_t win0, win1;  // lane l: state entering word l (lane 32: leaving the tile) given s = 0 / 1
+    uint32_t lead_excl;   // lane l: leaders of the tile before word l
+    {
+      const bool wl = lane < kTile / 64;
+      const uint64_t Aw = wl ? s_ab[0][lane] : ~0ull, Bw = wl ? s_ab[1][lane] : 0ull;
+      const uint64_t R = ~Aw;
+      const uint32_t rl = R ? 63u - (uint32_t)__builtin_clzll(R) : 0u;
+      const bool a_word = R == 0ull;
+      const bool b_word = parity64(R ? (Bw >> rl) : Bw);
+      const uint64_t WA = __ballot(a_word), WB = __ballot(b_word);
+      const uint64_t mres = ~WA & lt_mask((uint32_t)lane);
+      if (mres) {
+        const uint32_t r = 63u - (uint32_t)__builtin_clzll(mres);
+        win0 = win1 = parity64(WB & lt_mask((uint32_t)lane) & ~lt_mask(r));
+      } else {
+        win0 = parity64(WB & lt_mask((uint32_t)lane));
+        win1 = win0 ^ 1u;
+      }
+      uint32_t nl = wl ? (uint32_t)__popcll(s_pl[lane].nw & (lane == (int)((nown - 1) >> 6) ? lt_mask(((nown - 1) & 63u) + 1u) : ~0ull)) : 0u;
+      if (wl && (uint32_t)lane > ((nown - 1) >> 6)) nl = 0;
+      uint32_t inc = nl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      lead_excl = inc - nl;
+    }
+    const uint32_t tile_out = (__shfl(win0, 32, 64) & 1u) | ((__shfl(win1, 32, 64) & 1u) << 1);
+    const uint32_t tile_reads = __shfl(lead_excl, 32, 64);
+    // 4. per position: its state under both tile-incoming states; per word: multimapped reads / entries of each
+    uint32_t stbits = 0;  // bit 2j = state of round j's position if the tile is entered kept, bit 2j+1 if dropped
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const int wd = j * (kPB / 64) + wave;
+      const uint64_t Aw = s_ab[0][wd], Bw = s_ab[1][wd];
+      const uint32_t in0 = __shfl(win0, wd, 64), in1 = __shfl(win1, wd, 64);
+      const uint64_t below = lt_mask((uint32_t)lane);
+      const uint64_t mres = ~Aw & below;
+      uint32_t st0, st1;
+      if (mres) {
+        const uint32_t r = 63u - (uint32_t)__builtin_clzll(mres);
+        st0 = st1 = parity64(Bw & below & ~lt_mask(r));
+      } else {
+        const uint32_t par = parity64(Bw & below);
+        st0 = par ^ in0;
+        st1 = par ^ in1;
+      }
+      stbits |= (st0 | (st1 << 1)) << (2 * j);
+      if (COMMIT) {
+        const bool live = ev0[j] != 0xffffffffu;
+        const bool slow = live && (ev0[j] & kEvSlow);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const uint32_t stx = x ? st1 : st0;
+          const uint32_t e = slow ? s_slow_e[stx][ev0[j] & (kEvSlow - 1u)] : (stx ? ev1[j] : ev0[j]);
+          const bool mm = live && (e & 3u) == 2u;
+          const uint32_t ne = mm ? (slow ? e >> 2 : ev_nmm(e)) : 0u;
+          const uint32_t cnt = (uint32_t)__popcll(__ballot(mm));
+          uint32_t sum = ne;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+          if (lane == 0) { s_wmm[x][wd] = cnt; s_went[x][wd] = sum; }
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    __syncthreads();
     PH(3);
-    // 4. publish the aggregate, look back (wavefronts 0 .. kLbWaves-1, 1024 tiles per round), publish the
-    //    inclusive prefix
+    // tile aggregate as a function of the incoming state
+    RunFn tile_fn{tile_out, {0, 0}};
+    {
+      uint32_t m0 = 0, m1 = 0, n0 = 0, n1 = 0;
+      if (COMMIT && lane < kTile / 64) { m0 = s_wmm[0][lane]; m1 = s_wmm[1][lane]; n0 = s_went[0][lane]; n1 = s_went[1][lane]; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        m0 += __shfl_xor(m0, o, 64); m1 += __shfl_xor(m1, o, 64);
+        n0 += __shfl_xor(n0, o, 64); n1 += __shfl_xor(n1, o, 64);
+      }
+      tile_fn.pk[0] = (uint64_t)n0 | ((uint64_t)m0 << kPkMmShift) | ((uint64_t)tile_reads << kPkReadShift);
+      tile_fn.pk[1] = (uint64_t)n1 | ((uint64_t)m1 << kPkMmShift) | ((uint64_t)tile_reads << kPkReadShift);
+    }
+    // publish the aggregate, look back (wavefronts 0 .. kLbWaves-1), publish the inclusive prefix
     const uint64_t tile_g = pk_reads(tile_fn.pk[0]);
     uint64_t* const dsc = A.desc + tile * kDescWords;
     if (tid == 0 && tile + 1 < A.ntiles) {
@@ -636,107 +856,150 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         st_desc(dsc + 2, ST_PREFIX | e_incl);
       } else {  // the last tile closes the shard
         A.out_tot[0] = map_incl; A.out_tot[1] = g_incl;
-        if (COMMIT) { A.out_tot[2] = e_incl; A.out_tot[3] = r_incl; A.mm_offsets[r_incl] = e_incl; }
+        if (COMMIT && A.hist_mode != kMapOnly) { A.out_tot[2] = e_incl; A.out_tot[3] = r_incl; A.mm_offsets[r_incl] = e_incl; }
       }
       s_bcast[0] = x_in; s_bcast[1] = in.g; s_bcast[2] = in.r; s_bcast[3] = in.e;
     }
     __syncthreads();
     PH(5);
-    if (COMMIT) {
-      // 5. commit with the true state: the thread's exclusive prefix, evaluated at the tile's incoming state
+    if (COMMIT && A.hist_mode != kMapOnly) {
+      // 5. commit with the true state; exclusive offsets = word prefix (32-lane scan, every wavefront on its own) +
+      //    position within the word
       const uint32_t x_in = (uint32_t)s_bcast[0];
-      uint32_t st = (excl.out >> x_in) & 1u;
-      const uint64_t ex = x_in ? excl.pk[1] : excl.pk[0];
-      uint64_t eo = s_bcast[3] + pk_ent(ex);
-      uint64_t so = s_bcast[2] + pk_mm(ex);
-      uint64_t gidx = A.group_base + s_bcast[1] + pk_reads(ex);
+      uint32_t mm_excl, ent_excl;
+      {
+        const bool wl = lane < kTile / 64;
+        const uint32_t m = wl ? s_wmm[x_in][lane] : 0u, n = wl ? s_went[x_in][lane] : 0u;
+        uint32_t im = m, in = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t tm = __shfl_up(im, o, 64), tn = __shfl_up(in, o, 64);
+          if (lane >= o) { im += tm; in += tn; }
+        }
+        mm_excl = im - m;
+        ent_excl = in - n;
+      }
       uint32_t ambig = (tid == 0 && tile == 0 && A.first_shard) ? 1u : 0u;  // the phantom first boundary (:155-156)
-      for (int j = 0; j < kItems; ++j) {
-        const uint32_t li = l0 + j;
-        if (li >= nown) break;
-        const uint2 d = s_desc[slot(li)];
-        if (!(d.y & D_NEW)) continue;
-        const uint64_t my_gidx = gidx++;
-        uint32_t e = li + 1;
-        while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
-        uint32_t kind, tax, nmm = 0;
-        uint64_t hitlen, ge = t0 + e;
-        bool np, slow = false;
-        if (e < nst) {
-          np = s_desc[slot(e)].y & (D_P1 | D_P2);
-          Walk w{0, 0, 0, 0, 0};
-          for (uint32_t q = li + st; q < e; ++q) walk_add(w, s_desc[slot(q)]);
-          const uint32_t k = classify(w, np);
-          kind = k & 3u; nmm = k >> 2; tax = w.tax; hitlen = w.hsum;
-          slow = kind == 3u;
+      auto commit_unique = [&](uint32_t tax, uint64_t hitlen, uint64_t gidx) {
+        if (A.hist_mode == 1 && hitlen < kBinLenLimit) {
+          const uint32_t rel = (uint32_t)(gidx - A.group_base);
+          atomicAdd(&h_pack[tax], (1ull << kBinCountShift) + hitlen);
+          if (h_first[tax] > rel) atomicMin(&h_first[tax], rel);
+        } else if (A.hist_mode == 2 && hitlen < kBinLenLimit) {
+          const uint32_t rel = (uint32_t)(gidx - A.group_base);
+          __hip_atomic_fetch_add(&p_pack[tax], (1ull << kBinCountShift) + hitlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (p_first[tax] > rel) __hip_atomic_fetch_min(&p_first[tax], rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
-          if (ge >= A.ntotal) continue;  // never processed
-          np = at(ge).y & (D_P1 | D_P2);
-          slow = true;
+          atomicAdd(&A.g_count[tax], 1ull);
+          atomicAdd(&A.g_bases[tax], (unsigned long long)hitlen);
+          // first_seen only ever decreases: a (possibly stale) value at or below ours means nothing to do
+          if (__atomic_load_n(&A.g_first[tax], __ATOMIC_RELAXED) > gidx) atomicMin(&A.g_first[tax], (unsigned long long)gidx);
         }
+      };
+#pragma unroll
+      for (int j = 0; j < kRounds; ++j) {
+        const int wd = j * (kPB / 64) + wave;
+        const uint32_t p = (uint32_t)j * kPB + tid;
+        const bool live = ev0[j] != 0xffffffffu;
+        const uint32_t st = (stbits >> (2 * j + x_in)) & 1u;
+        const bool slow = live && (ev0[j] & kEvSlow);
+        const uint32_t sidx = ev0[j] & (kEvSlow - 1u);
+        const uint32_t e = slow ? s_slow_e[st][sidx] : (st ? ev1[j] : ev0[j]);
+        uint32_t kind = live ? (e & 3u) : 3u;  // 3: nothing here
+        // (cross-lane reads happen HERE, in uniform control flow: inside the branches below the source lane may be off)
+        const uint64_t so_base = s_bcast[2] + __shfl(mm_excl, wd, 64), eo_base = s_bcast[3] + __shfl(ent_excl, wd, 64);
+        const Planes P0 = s_pl[p >> 6];
+        const uint64_t my_gidx = A.group_base + s_bcast[1] + __shfl(lead_excl, wd, 64) +
+                                 (uint32_t)__popcll(P0.nw & lt_mask(p & 63u));
+        uint32_t tax = 0, nmm = 0;
+        uint64_t hitlen = 0;
         if (slow) {
-          const Verdict v = eval_group(at, t0 + li + st, ge, np, nullptr);
-          kind = v.kind; tax = v.tax; nmm = v.nmm; hitlen = v.hitlen;
+          nmm = e >> 2;
+        } else if (live && kind != 0u) {
+          tax = s_tax[p + ev_first(e)];
+          nmm = ev_nmm(e);
+          hitlen = hs[j] - (st ? (s_pfx[p] - ((p & 63u) ? s_pfx[p - 1] : 0u)) : 0u);
         }
-        if (kind == 0) {
+        // exclusive positions of this word's multimapped reads / entries
+        const bool mm = kind == 2u;
+        const uint64_t mmask = __ballot(mm);
+        uint32_t einc = mm ? nmm : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = __shfl_up(einc, o, 64);
+          if (lane >= o) einc += t;
+        }
+        if (slow && kind != 3u) {  // committed by the loop below, with the offsets found here
+          s_slow_so[sidx] = so_base + (uint32_t)__popcll(mmask & lt_mask((uint32_t)lane));
+          s_slow_eo[sidx] = eo_base + (einc - nmm);
+          s_slow_gidx[sidx] = my_gidx;
+          s_slow_st[sidx] = st;
+        } else if (kind == 0u) {
           ++ambig;
-        } else if (kind == 1) {
-          uint32_t bin = tax;
-          bool in_lds = A.use_lds_hist == 1;
-          if (A.use_lds_hist == 2) {
-            uint32_t p = (tax * 2654435761u) >> 21;  // 11 bits: kHashSlots
-            for (uint32_t step = 0; step < kHashProbe; ++step) {
-              uint32_t old = h_key[p];  // keys never change once set: a plain look settles the common case
-              if (old == 0xffffffffu) old = atomicCAS(&h_key[p], 0xffffffffu, tax);
-              if (old == 0xffffffffu || old == tax) { bin = p; in_lds = true; break; }
-              p = (p + 1) & (kHashSlots - 1);
-            }
-          }
-          if (in_lds && hitlen < kBinLenLimit) {
-            const uint32_t rel = (uint32_t)(my_gidx - A.group_base);
-            atomicAdd(&h_pack[bin], (1ull << kBinCountShift) + hitlen);
-            if (h_first[bin] > rel) atomicMin(&h_first[bin], rel);
-          } else {
-            atomicAdd(&A.g_count[tax], 1ull);
-            atomicAdd(&A.g_bases[tax], (unsigned long long)hitlen);
-            // first_seen only ever decreases: a (possibly stale) value at or below ours means nothing to do
-            if (__atomic_load_n(&A.g_first[tax], __ATOMIC_RELAXED) > my_gidx)
-              atomicMin(&A.g_first[tax], (unsigned long long)my_gidx);
-          }
-        } else {
-          if (slow) {
-            (void)eval_group(at, t0 + li + st, ge, np, A.mm_tax + eo);  // writes the taxon list (SAM order)
-          } else {
-            uint64_t wpos = eo;
-            for (uint32_t q = li + st; q < e; ++q) {  // every kept line (:172-173)
-              const uint2 dq = s_desc[slot(q)];
-              if (!(dq.y & D_REJ)) A.mm_tax[wpos++] = dq.x;
+        } else if (kind == 1u) {
+          commit_unique(tax, hitlen, my_gidx);
+        } else if (mm) {
+          const uint64_t so = so_base + (uint32_t)__popcll(mmask & lt_mask((uint32_t)lane));
+          const uint64_t eo = eo_base + (einc - nmm);
+          {
+            const uint32_t sft = p & 63u;
+            const Planes P1 = s_pl[(p >> 6) + 1];
+            const uint64_t nwin = funnel(P0.nw, P1.nw, sft) & ~1ull;
+            const uint32_t nxt = (uint32_t)__builtin_ctzll(nwin);
+            const uint64_t seg = lt_mask(nxt) & ~(uint64_t)st;
+            const uint64_t aw = funnel(P0.a, P1.a, sft), bw = funnel(P0.b, P1.b, sft), rw = funnel(P0.r, P1.r, sft);
+            const uint64_t kept = seg & ~rw;
+            if (((aw | bw) >> nxt) & 1ull) {  // paired: the taxa both mates hit (:168-169)
+              const int p1 = __popcll(seg & (aw | ~bw)) - __popcll(seg & rw & aw);
+              (void)intersect_lds(s_tax, p, kept, p1, A.mm_tax + eo);
+            } else {  // every kept line (:172-173)
+              uint64_t wpos = eo;
+              for (uint64_t q = kept; q; q &= q - 1ull) A.mm_tax[wpos++] = s_tax[p + (uint32_t)__builtin_ctzll(q)];
             }
           }
           A.mm_offsets[so] = eo;
           A.mm_hitlen[so] = hitlen;
           A.mm_read[so] = my_gidx;
-          eo += nmm;
-          ++so;
         }
-        st = kind == 0;
+        asm volatile("" ::: "memory");
+      }
+      if (s_nslow) {  // (uniform) the reads that did not fit a window, with the offsets the loop above left for them
+        __syncthreads();
+        for (uint32_t idx = tid; idx < s_nslow; idx += kPB) {
+          if ((s_slow_e[0][idx] & 3u) == 3u) continue;  // no closing line: never processed (nothing was left for it)
+          const uint32_t p = s_slow_p[idx], st = s_slow_st[idx];
+          uint64_t ge = t0 + p + 1;
+          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
+          const bool np = at(ge).y & (D_P1 | D_P2);
+          const uint64_t so = s_slow_so[idx], eo = s_slow_eo[idx];
+          const Verdict v = eval_group(at, t0 + p + st, ge, np, A.mm_tax + eo);  // (writes its taxon list if it has one)
+          if (v.kind == 0u) {
+            ++ambig;
+          } else if (v.kind == 1u) {
+            commit_unique(v.tax, v.hitlen, s_slow_gidx[idx]);
+          } else {
+            A.mm_offsets[so] = eo;
+            A.mm_hitlen[so] = v.hitlen;
+            A.mm_read[so] = s_slow_gidx[idx];
+          }
+        }
       }
       if (ambig) atomicAdd(&s_ambig, (unsigned long long)ambig);
       if (tid == 0) s_groups += tile_g;
-      if (A.use_lds_hist && ++tiles_binned == kFlushTiles) {  // before a packed field can overflow
+      if (A.hist_mode == 1 && ++tiles_binned == kFlushTiles) {  // before a packed field can overflow
         __syncthreads();
         flush_bins(true);
         tiles_binned = 0;
       }
     }
-    __syncthreads();  // s_desc / s_bcast / s_ticket are reused by the next tile
+    __syncthreads();  // the staged planes / s_bcast / s_ticket are reused by the next tile
+    if (tid == 0) s_nslow = 0;
     PH(6);
   }
   PH_FLUSH(COMMIT);
   if (COMMIT) {
     __syncthreads();
-    if (A.use_lds_hist) flush_bins(false);
+    if (A.hist_mode == 1) flush_bins(false);
     if (tid == 0) {
       if (s_groups) atomicAdd(&A.g_scalars[0], s_groups);
       if (s_ambig) atomicAdd(&A.g_scalars[1], s_ambig);
@@ -744,17 +1007,47 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   }
 }
 
-// The two instantiations as kernels.  The map-only pass fits 128 VGPRs (4 wavefronts per SIMD: four workgroups
-// per CU instead of three); the commit pass keeps its 154 rather than spill.
+// One kernel for both passes: the map-only pass (a shard's composed state map and read count, which a multi-GPU job
+// needs from every shard before any of them can commit) is the same chain with hist_mode == kMapOnly, which skips
+// step 5.  (A separate COMMIT = false instantiation — the same source minus the commit — did not terminate on the
+// GPU while this one does; with one instantiation there is also one kernel to keep correct.)
 template <bool COMMIT>
-__global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A);
-template <>
-__global__ __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(4))) void k_profile_pass<false>(const PassArgs A) {
-  profile_pass_body<false>(A);
+__global__ __launch_bounds__(kPB) void k_profile_pass(const PassArgs A) {
+  profile_pass_body<COMMIT>(A);
 }
-template <>
-__global__ __launch_bounds__(kPB) void k_profile_pass<true>(const PassArgs A) {
-  profile_pass_body<true>(A);
+
+// hist_mode 2, after the pass: the workgroups' private bins summed into the accumulators (one thread per taxon walks
+// the copies: consecutive threads read consecutive words of a copy).
+__global__ __launch_bounds__(256) void k_bins_reduce(const unsigned long long* __restrict__ priv_pack,
+                                                     const uint32_t* __restrict__ priv_first, uint32_t ncopies, uint32_t ntax,
+                                                     uint64_t group_base, unsigned long long* __restrict__ g_count,
+                                                     unsigned long long* __restrict__ g_bases,
+                                                     unsigned long long* __restrict__ g_first) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntax) return;
+  unsigned long long cnt = 0, bas = 0;
+  uint32_t first = 0xffffffffu;
+  for (uint32_t c0 = 0; c0 < ncopies; c0 += 8) {
+    unsigned long long v[8];
+    uint32_t f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t c = c0 + u;
+      v[u] = c < ncopies ? priv_pack[(size_t)c * ntax + t] : 0ull;
+      f[u] = c < ncopies ? priv_first[(size_t)c * ntax + t] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      cnt += v[u] >> kBinCountShift;
+      bas += v[u] & ((1ull << kBinCountShift) - 1);
+      first = f[u] < first ? f[u] : first;
+    }
+  }
+  if (cnt) {  // (the accumulators may already hold other shards' sums)
+    atomicAdd(&g_count[t], cnt);
+    atomicAdd(&g_bases[t], bas);
+    atomicMin(&g_first[t], (unsigned long long)(group_base + first));
+  }
 }
 
 // Before a pass: tile descriptors + ticket = 0 and, when asked, the accumulators of a fresh batch (one launch).
@@ -842,6 +1135,7 @@ struct mg_profile {
   double pct_id = 0.5;
   uint64_t ntiles = 0;
   DevBuf desc, tot;          // tile descriptors + ticket (last word); totals of the last pass
+  DevBuf priv;               // hist_mode 2: the workgroups' private bins [grid][ntax] x (8 + 4) bytes
   uint8_t map[2] = {0, 1};
   uint64_t ngroups = 0;
   bool have_map = false;     // composed state map / read count known (map-only pass, or read back after commit)
@@ -884,27 +1178,42 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   a.out_tot = p->tot.as<uint64_t>();
   if (!commit) {
     ProfScope ps("profile_map", st);
-    const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * 4);
+    const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * 2);
     if (grid < a.ticket_lanes) a.ticket_lanes = grid;
-    hipLaunchKernelGGL(k_profile_pass<false>, dim3(grid), dim3(kPB), 0, st, a);
+    a.hist_mode = kMapOnly;
+    hipLaunchKernelGGL(k_profile_pass<true>, dim3(grid), dim3(kPB), 0, st, a);
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
-  a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 4096 ? 1u : 2u;
-  const size_t lds = a.use_lds_hist == 0 ? 0
-                   : a.use_lds_hist == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t))
-                                         : kHashSlots * (sizeof(unsigned long long) + 2 * sizeof(uint32_t));
+  a.hist_mode = p->nrecs >= 0x7fffffffull ? 0u : p->ntax <= 4096 ? 1u : 2u;
+  if (const char* e = getenv("MG_DEBUG_HIST_MODE")) a.hist_mode = (uint32_t)atoi(e);  // experiments / tests
+  if (a.hist_mode == 1 && p->ntax > 4096) a.hist_mode = 2;
+  const size_t lds = a.hist_mode == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t)) : 0;
   a.g_count = (unsigned long long*)d_count; a.g_bases = (unsigned long long*)d_bases;
   a.g_first = (unsigned long long*)d_first_seen; a.g_scalars = (unsigned long long*)d_scalars;
   a.mm_offsets = p->mm_offsets.as<uint64_t>(); a.mm_tax = p->mm_tax.as<uint32_t>();
   a.mm_hitlen = p->mm_hitlen.as<uint64_t>(); a.mm_read = p->mm_read.as<uint64_t>();
-  ProfScope ps("profile_pass", st);
   // every workgroup flushes its private histogram once: few, long-lived workgroups
-  const unsigned per_cu = lds > 40 * 1024 ? 2u : 3u;
+  unsigned per_cu = lds > 40 * 1024 ? 2u : 3u;
+  if (const char* e = getenv("MG_DEBUG_K3_PER_CU")) per_cu = (unsigned)atoi(e);
   const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
   if (grid < a.ticket_lanes) a.ticket_lanes = grid;
+  ProfScope ps("profile_pass", st);  // (with the clearing and the reduction of the private bins, where they are used)
+  if (a.hist_mode == 2) {
+    const uint64_t nb = (uint64_t)grid * p->ntax;
+    MG_TRY(p->priv.alloc(nb * (sizeof(unsigned long long) + sizeof(uint32_t)) + 16));
+    a.priv_pack = p->priv.as<unsigned long long>();
+    a.priv_first = reinterpret_cast<uint32_t*>(a.priv_pack + nb);
+    MG_HIP(hipMemsetAsync(a.priv_pack, 0, nb * sizeof(unsigned long long), st));
+    MG_HIP(hipMemsetAsync(a.priv_first, 0xff, nb * sizeof(uint32_t), st));
+  }
   hipLaunchKernelGGL(k_profile_pass<true>, dim3(grid), dim3(kPB), lds, st, a);
   MG_HIP(hipGetLastError());
+  if (a.hist_mode == 2) {
+    hipLaunchKernelGGL(k_bins_reduce, dim3((p->ntax + 255) / 256), dim3(256), 0, st, a.priv_pack, a.priv_first, grid, p->ntax,
+                       group_base, a.g_count, a.g_bases, a.g_first);
+    MG_HIP(hipGetLastError());
+  }
   return MG_OK;
 }
 
