@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmetalign_hip.so")
+LIB_PATH = os.environ.get("MG_LIB_PATH") or os.path.join(_HERE, "libmetalign_hip.so")  # (MG_LIB_PATH: instrumented builds of the same library)
 
 REC_DTYPE = np.dtype([("ref_new", "<u4"), ("matched", "<u4"), ("total", "<u4"), ("flag_len", "<u4")])
 NEW_BIT = 0x80000000

@@ -46,6 +46,9 @@ struct Context {
   const char* scratch_prefix = "";  // scratch buffers are per stream ("a:" while launching on stream_a)
   std::vector<hipEvent_t> ev_pool;   // recycled completion events of deferred sketches
   int num_cus = 256;
+  // stage C's private overflow bins (mg_profile.hip): which block / partition is known to be all-zero
+  void* k3_priv_ptr = nullptr;
+  uint64_t k3_priv_nb = 0;
   // occurrence counters of read sketches saturate here (kmc -cs3, scripts/select_db.py:50); 0 = exact counts
   uint32_t count_sat = 3;
   // profiling

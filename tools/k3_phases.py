@@ -1,8 +1,8 @@
 """Where a stage-C tile spends its time: thread 0's shader clock between the phase boundaries of k_profile_pass,
 averaged per tile, for the commit pass and the map-only pass.  Needs the instrumented build:
-    make -C metalign_amd/csrc clean && make -C metalign_amd/csrc K3_PHASES=1
-    python tools/k3_phases.py
-(and a clean rebuild afterwards: the shipped library has no clocks in it)."""
+    make -C metalign_amd/csrc phases
+    MG_LIB_PATH=metalign_amd/libmetalign_hip_phases.so python tools/k3_phases.py
+(a second library next to the shipped one, which has no clocks in it)."""
 import os, sys, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ lib = hip.lib
 if not hasattr(lib, "mg_debug_k3_phases"):
     sys.exit("build with K3_PHASES=1 first (see the docstring)")
 names = ["ticket", "load+desc", "walk", "blockscan", "lookback", "publish", "commit", "looptop/exit"]
-for R, G, present in [(1000000, 1000, 50), (12500000, 2000, 2000), (20000000, 10000, 10000)]:
+for R, G, present in [(12500000, 2000, 2000), (10000000, 10000, 500)]:
     rng = np.random.default_rng(1)
     pres = rng.choice(np.arange(1, G + 1), size=present, replace=False)
     src = pres[rng.integers(0, present, size=R)]
