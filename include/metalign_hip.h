@@ -187,6 +187,11 @@ int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_of
  * The filter must outlive the sketches built with it until they are resolved.
  * ------------------------------------------------------------------------ */
 int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out);
+/* The filter's bit array to the host (2^log2_bits / 8 bytes) and back: the table builder stores it next to the table
+ * (the reference ships its pre-filter as a file too, ..._30-60-10.bf, scripts/select_db.py:70), so that a rank that
+ * loads 1/W of the table does not have to stream the other W-1 parts just to set their bits. */
+int mg_filter_download(const mg_filter* f, uint32_t* bits, uint64_t nbytes);
+int mg_filter_from_bits(const uint32_t* bits, unsigned log2_bits, mg_filter** out);
 unsigned mg_filter_log2_bits(const mg_filter* f);
 void mg_filter_free(mg_filter* f);
 int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
@@ -280,6 +285,13 @@ int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets,
 typedef struct mg_db mg_db;
 int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets,
                  uint64_t ngenomes, mg_db** out);
+/* The same table from its HASH-MAJOR form (metalign_amd/formats.py, table version 2: what mg_db_upload builds on the
+ * device is what the builder already wrote to disk): pair_hash[npairs] ascending, pair_gen[npairs] the genome of every
+ * pair, gsize[ngenomes] the number of pairs of every genome IN THIS ARRAY — so a rank of a multi-GPU job uploads only
+ * the contiguous run of pairs that falls in its hash range, and nothing is sorted at upload.  Replaces the load of
+ * data/cmash_db_n1000_k60.h5 + its KMC dump (scripts/select_db.py:44,69-70).  max_hash: of the WHOLE table. */
+int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uint64_t npairs, const uint32_t* gsize,
+                        uint64_t ngenomes, uint64_t max_hash, mg_db** out);
 uint64_t mg_db_ngenomes(const mg_db* db);
 uint64_t mg_db_max_hash(const mg_db* db); /* the hmax to sketch reads with */
 void mg_db_free(mg_db* db);

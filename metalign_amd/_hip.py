@@ -28,14 +28,14 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_log2_bits", "mg_filter_free",
+    "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
-    "mg_sketch_genomes", "mg_db_upload", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
+    "mg_sketch_genomes", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
@@ -342,6 +342,12 @@ class Filter:
     def log2_bits(self):
         return int(self.hip.lib.mg_filter_log2_bits(self.handle))
 
+    def download(self):
+        """The bit array (uint32 words), as the table builder stores it next to the table."""
+        bits = np.empty((1 << self.log2_bits) // 32, dtype=np.uint32)
+        self.hip._chk(self.hip.lib.mg_filter_download(self.handle, _np(bits, ctypes.c_uint32), ctypes.c_uint64(bits.nbytes)))
+        return bits
+
     def free(self):
         if self.handle:
             self.hip.lib.mg_filter_free(self.handle)
@@ -636,6 +642,14 @@ class Hip:
                                            ctypes.c_uint64(hashes.size), ctypes.byref(h)))
         return Filter(self, h)
 
+    def filter_from_bits(self, bits):
+        """A stored filter (Filter.download) back onto the device."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint32)
+        lb = int(bits.size * 32).bit_length() - 1
+        h = _vp()
+        self._chk(self.lib.mg_filter_from_bits(_np(bits, ctypes.c_uint32), ctypes.c_uint(lb), ctypes.byref(h)))
+        return Filter(self, h)
+
     def sketch_reads_dev(self, d_bases, d_offsets, nreads, k, hmax=U64_MAX, s=0, filt=None):
         """filt: a Filter (the table's): the sketch is restricted to hashes that may be in the table."""
         h = _vp()
@@ -819,6 +833,20 @@ class Hip:
         h = _vp()
         self._chk(self.lib.mg_db_upload(_np(hashes, ctypes.c_uint64), _np(offsets, ctypes.c_uint64),
                                         ctypes.c_uint64(len(offsets) - 1), ctypes.byref(h)))
+        return SketchTable(self, h)
+
+    def upload_table_sorted(self, pair_hash, pair_gen, gsize, max_hash):
+        """A table (or a hash-range slice of one) that is hash-major already (formats.SketchTable.pairs): no sort."""
+        pair_hash = np.ascontiguousarray(pair_hash, dtype=np.uint64)
+        pair_gen = np.ascontiguousarray(pair_gen, dtype=np.uint32)
+        gsize = np.ascontiguousarray(gsize, dtype=np.uint32)
+        n = pair_hash.size
+        h = _vp()
+        ph = pair_hash if n else np.zeros(1, np.uint64)
+        pg = pair_gen if n else np.zeros(1, np.uint32)
+        self._chk(self.lib.mg_db_upload_sorted(_np(ph, ctypes.c_uint64), _np(pg, ctypes.c_uint32), ctypes.c_uint64(n),
+                                               _np(gsize, ctypes.c_uint32), ctypes.c_uint64(gsize.size),
+                                               ctypes.c_uint64(int(max_hash)), ctypes.byref(h)))
         return SketchTable(self, h)
 
     # ---- stage B ----

@@ -53,7 +53,12 @@ def build(paths, out_dir, ks, n, batch_bases=1 << 27):
             os_.extend(int(v) + base for v in o[1:])
     final = {k: (np.concatenate(per_k[k][0]) if per_k[k][0] else np.zeros(0, np.uint64),
                  np.asarray(per_k[k][1], dtype=np.uint64)) for k in ks}
-    formats.write_sketch_table(out_dir, names, ks, n, final)
+    filters = {}
+    for k in ks:  # the membership pre-filter of every k, stored next to the table (the reference's ...bf file)
+        f = hip.filter_build(final[k][0])
+        filters[k] = f.download()
+        f.free()
+    formats.write_sketch_table(out_dir, names, ks, n, final, filters)
     return final
 
 

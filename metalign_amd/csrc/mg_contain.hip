@@ -313,6 +313,34 @@ int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets, uint64_t ngeno
   return MG_OK;
 }
 
+int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uint64_t npairs, const uint32_t* gsize,
+                        uint64_t ngenomes, uint64_t max_hash, mg_db** out) {
+  MG_REQUIRE_READY();
+  if (!out || !gsize || (npairs && (!pair_hash || !pair_gen))) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (npairs > 0xfffffff0ull) return fail(MG_ERR_ARG, "sketch table of %llu hashes exceeds the 32-bit position range",
+                                          (unsigned long long)npairs);
+  if (ngenomes > 0xfffffff0ull) return fail(MG_ERR_ARG, "too many genomes");
+  if (npairs && (pair_hash[0] > pair_hash[npairs - 1] || pair_hash[npairs - 1] > max_hash))
+    return fail(MG_ERR_ARG, "pair list is not ascending within [0, max_hash]");
+  std::unique_ptr<mg_db> db(new mg_db());
+  hipStream_t st = ctx().stream;
+  db->ngenomes = ngenomes;
+  db->total = npairs;
+  db->max_hash = max_hash;
+  MG_TRY(db->pair_hash.alloc((npairs + 1) * sizeof(uint64_t)));
+  MG_TRY(db->pair_gen.alloc((npairs + 1) * sizeof(uint32_t)));
+  MG_TRY(db->gsize.alloc((ngenomes + 1) * sizeof(uint32_t)));
+  if (npairs) {
+    MG_HIP(hipMemcpyAsync(db->pair_hash.p, pair_hash, npairs * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemcpyAsync(db->pair_gen.p, pair_gen, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  if (ngenomes) MG_HIP(hipMemcpyAsync(db->gsize.p, gsize, ngenomes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  MG_HIP(hipStreamSynchronize(st));
+  *out = db.release();
+  return MG_OK;
+}
+
 uint64_t mg_db_ngenomes(const mg_db* db) { return db ? db->ngenomes : 0; }
 uint64_t mg_db_max_hash(const mg_db* db) { return db ? db->max_hash : 0; }
 void mg_db_free(mg_db* db) { delete db; }

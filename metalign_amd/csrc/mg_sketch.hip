@@ -1077,6 +1077,28 @@ int mg_set_count_saturation(uint32_t cs) {
 }
 uint32_t mg_count_saturation(void) { return ctx().count_sat; }
 
+int mg_filter_download(const mg_filter* f, uint32_t* bits, uint64_t nbytes) {
+  MG_REQUIRE_READY();
+  if (!f || !bits) return fail(MG_ERR_ARG, "null argument");
+  if (nbytes != (1ull << f->log2_bits) / 8) return fail(MG_ERR_CAPACITY, "the filter holds %llu bytes", (unsigned long long)((1ull << f->log2_bits) / 8));
+  return mg_memcpy_d2h(bits, f->bits.p, nbytes);
+}
+
+int mg_filter_from_bits(const uint32_t* bits, unsigned log2_bits, mg_filter** out) {
+  MG_REQUIRE_READY();
+  if (!bits || !out) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (log2_bits < 16 || log2_bits > 30) return fail(MG_ERR_ARG, "filter size 2^%u outside [2^16, 2^30] bits", log2_bits);
+  std::unique_ptr<mg_filter> f(new mg_filter());
+  f->log2_bits = log2_bits;
+  f->mask = (1ull << log2_bits) - 1;
+  const uint64_t bytes = (1ull << log2_bits) / 8;
+  MG_TRY(f->bits.alloc(bytes));
+  MG_TRY(mg_memcpy_h2d(f->bits.p, bits, bytes));
+  *out = f.release();
+  return MG_OK;
+}
+
 unsigned mg_filter_log2_bits(const mg_filter* f) { return f ? f->log2_bits : 0; }
 void mg_filter_free(mg_filter* f) { delete f; }
 

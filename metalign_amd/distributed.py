@@ -133,6 +133,11 @@ class HipEngine:
         self.filters += [None] * (ki + 1 - len(self.filters))
         self.filters[ki] = self.hip.filter_build(table_hashes)
 
+    def set_filter_bits(self, ki, bits):
+        """The same from the bit array the table builder stored (formats.SketchTable.filter_bits)."""
+        self.filters += [None] * (ki + 1 - len(self.filters))
+        self.filters[ki] = self.hip.filter_from_bits(bits)
+
     def sketch_local(self, ks, hmaxs, s):
         sks = self.sketch_local_async(ks, hmaxs, s)
         for sk in sks:
@@ -474,7 +479,11 @@ class ShardJob:
                 self.hmaxs.append(hmax)
                 self.bounds.append(b)
                 if hasattr(self.engine, "set_filter"):
-                    self.engine.set_filter(ki, disk.pairs(k)["pair_hash"])  # ALL hashes of the table (streamed from the map)
+                    bits = disk.filter_bits(k)  # stored by the builder: the rank does not stream the other ranks' slices
+                    if bits is not None and hasattr(self.engine, "set_filter_bits"):
+                        self.engine.set_filter_bits(ki, bits)
+                    else:
+                        self.engine.set_filter(ki, disk.pairs(k)["pair_hash"])
                 tables.append(disk.pairs(k, b[self.rank], b[self.rank + 1]))
         else:
             per_k = [(dbh, dbo)] if self.single_k else list(zip(dbh, dbo))

@@ -2,15 +2,22 @@
 on-disk genome sketch table that replaces the reference's CMash artefacts.
 
 Sketch table directory (replaces data/cmash_db_n1000_k60.h5, ..._dump.kmc_{pre,suf} and
-..._30-60-10.bf, /root/reference/scripts/select_db.py:44,69-70):
+..._30-60-10.bf, /root/reference/scripts/select_db.py:44,69-70), version 2 — HASH-MAJOR, the layout stage B streams
+(mg_contain.hip), so that nothing is sorted at load time and a rank of a multi-GPU job maps only its hash range:
 
-    <dir>/meta.json           {"format": "metalign_amd.sketch_table", "version": 1, "n": 1000,
-                               "ks": [21, 31, 51], "ngenomes": G, "hash": "murmur3_x64_128.h1(canonical ASCII k-mer)"}
-    <dir>/names.txt           one organism file name per line (taxid_<a>_<b>_genomic.fna.gz,
-                               /root/reference/utils/ncbi2db.py:160-186), row order == genome id
-    <dir>/k<K>.hashes.u64     little-endian u64, every genome's ascending sketch back to back
-    <dir>/k<K>.offsets.u64    little-endian u64[G+1]
-Flat files so that a RefSeq-scale table (1.6 GB per k) is np.memmap'ed and uploaded shard by shard.
+    <dir>/meta.json             {"format": "metalign_amd.sketch_table", "version": 2, "n": 1000,
+                                 "ks": [21, 31, 51], "ngenomes": G, "hash": "murmur3_x64_128.h1(canonical ASCII k-mer)"}
+    <dir>/names.txt             one organism file name per line (taxid_<a>_<b>_genomic.fna.gz,
+                                 /root/reference/utils/ncbi2db.py:160-186), row order == genome id
+    <dir>/k<K>.pair_hash.u64    little-endian u64: every (hash, genome) pair of every genome sketch, ascending by hash
+                                 (equal hashes of different genomes adjacent, in genome order)
+    <dir>/k<K>.pair_gen.u32     little-endian u32: the genome of every pair
+    <dir>/k<K>.gsize.u32        little-endian u32[G]: sketch size of every genome
+    <dir>/k<K>.filter.u32       the membership pre-filter over all hashes of the table (one bit per hash value modulo
+                                 the size, include/metalign_hip.h: mg_filter) — the reference's ..._30-60-10.bf
+Version 1 (genome-major k<K>.hashes.u64 + k<K>.offsets.u64: every genome's ascending sketch back to back) is still
+read; it is inverted on the host when it is opened.
+Flat files so that a RefSeq-scale table (2.4 GB per k) is np.memmap'ed and uploaded slice by slice.
 """
 import gzip
 import json
@@ -69,7 +76,7 @@ def read_sequences(path, kind):
 
 
 class SketchTable:
-    """Host view of a sketch table directory."""
+    """Host view of a sketch table directory (version 2: hash-major; version 1: genome-major)."""
 
     def __init__(self, path):
         self.path = path
@@ -77,25 +84,105 @@ class SketchTable:
             self.meta = json.load(fh)
         if self.meta.get("format") != TABLE_FORMAT:
             raise ValueError("%s is not a %s directory" % (path, TABLE_FORMAT))
+        self.version = int(self.meta.get("version", 1))
         self.ks = [int(k) for k in self.meta["ks"]]
         self.n = int(self.meta["n"])
         with open(os.path.join(path, "names.txt")) as fh:
             self.names = [ln.rstrip("\n") for ln in fh]
         self.ngenomes = len(self.names)
+        self._maps = {}
+
+    def _f(self, k, what):
+        return os.path.join(self.path, "k%d.%s" % (k, what))
+
+    def _pair_maps(self, k):
+        if k not in self._maps:
+            if self.version >= 2:
+                ph = np.memmap(self._f(k, "pair_hash.u64"), dtype="<u8", mode="r")
+                pg = np.memmap(self._f(k, "pair_gen.u32"), dtype="<u4", mode="r")
+                gs = np.fromfile(self._f(k, "gsize.u32"), dtype="<u4")
+            else:  # version 1: invert on the host (once per process)
+                h, o = self.arrays(k)
+                ph, pg, gs = pairs_from_genome_major(np.asarray(h), o)
+            assert len(ph) == len(pg) and len(gs) == self.ngenomes
+            self._maps[k] = (ph, pg, gs)
+        return self._maps[k]
+
+    def max_hash(self, k):
+        ph = self._pair_maps(k)[0]
+        return int(ph[-1]) if len(ph) else 0
+
+    def pairs(self, k, lo=None, hi=None):
+        """The hash-major table of k restricted to hashes in [lo, hi) (default: all of it), as the keyword arguments of
+        Hip.upload_table_sorted: pair_hash / pair_gen are views of the memory maps (only the slice is read from disk),
+        gsize counts the pairs of every genome WITHIN the slice (a genome's containment is the sum over the slices)."""
+        ph, pg, gs = self._pair_maps(k)
+        mx = self.max_hash(k)
+        if lo is None and hi is None:
+            return dict(pair_hash=ph, pair_gen=pg, gsize=gs, max_hash=mx)
+        a = int(np.searchsorted(ph, np.uint64(lo or 0), side="left"))
+        b = len(ph) if hi is None or hi > 0xFFFFFFFFFFFFFFFF else int(np.searchsorted(ph, np.uint64(hi), side="left"))
+        sl = np.bincount(np.asarray(pg[a:b]), minlength=self.ngenomes).astype(np.uint32)
+        return dict(pair_hash=ph[a:b], pair_gen=pg[a:b], gsize=sl, max_hash=mx)
+
+    def filter_bits(self, k):
+        """The stored membership pre-filter of k (None for a table without one)."""
+        f = self._f(k, "filter.u32")
+        return np.fromfile(f, dtype="<u4") if os.path.exists(f) else None
 
     def arrays(self, k):
-        h = np.memmap(os.path.join(self.path, "k%d.hashes.u64" % k), dtype="<u8", mode="r")
-        o = np.fromfile(os.path.join(self.path, "k%d.offsets.u64" % k), dtype="<u8")
+        """Genome-major view (hashes, offsets[G+1]): every genome's ascending sketch back to back."""
+        if self.version >= 2:
+            ph, pg, gs = self._pair_maps(k)
+            order = np.argsort(np.asarray(pg), kind="stable")  # stable: ascending hash within a genome
+            o = np.zeros(self.ngenomes + 1, dtype=np.uint64)
+            o[1:] = np.cumsum(gs, dtype=np.uint64)
+            return np.asarray(ph)[order], o
+        h = np.memmap(self._f(k, "hashes.u64"), dtype="<u8", mode="r")
+        o = np.fromfile(self._f(k, "offsets.u64"), dtype="<u8")
         assert len(o) == self.ngenomes + 1 and int(o[-1]) == len(h)
         return h, o
 
 
-def write_sketch_table(path, names, ks, n, per_k):
-    """per_k: {k: (hashes u64[], offsets u64[G+1])}."""
+def pairs_from_genome_major(hashes, offsets):
+    """(hashes, offsets[G+1]) genome-major -> (pair_hash ascending, pair_gen, gsize): the inversion mg_db_upload does on
+    the device, on the host for the table builder."""
+    hashes = np.asarray(hashes, dtype=np.uint64)
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    g = len(offsets) - 1
+    gsize = np.diff(offsets).astype(np.uint32)
+    gen = np.repeat(np.arange(g, dtype=np.uint32), gsize)
+    order = np.argsort(hashes, kind="stable")  # stable: equal hashes stay in genome order
+    return hashes[order], gen[order], gsize
+
+
+def _write_common(path, names):
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "names.txt"), "w") as fh:
         for nm in names:
             fh.write(nm + "\n")
+
+
+def write_sketch_table(path, names, ks, n, per_k, filters=None):
+    """per_k: {k: (hashes u64[], offsets u64[G+1])} genome-major, as mg_sketch_genomes returns it; written hash-major.
+    filters: optional {k: uint32 bit array} (Filter.download)."""
+    _write_common(path, names)
+    for k in ks:
+        ph, pg, gs = pairs_from_genome_major(*per_k[k])
+        np.ascontiguousarray(ph, dtype="<u8").tofile(os.path.join(path, "k%d.pair_hash.u64" % k))
+        np.ascontiguousarray(pg, dtype="<u4").tofile(os.path.join(path, "k%d.pair_gen.u32" % k))
+        np.ascontiguousarray(gs, dtype="<u4").tofile(os.path.join(path, "k%d.gsize.u32" % k))
+        if filters and filters.get(k) is not None:
+            np.ascontiguousarray(filters[k], dtype="<u4").tofile(os.path.join(path, "k%d.filter.u32" % k))
+    meta = {"format": TABLE_FORMAT, "version": 2, "n": int(n), "ks": [int(k) for k in ks], "ngenomes": len(names),
+            "layout": "hash-major pairs", "hash": "murmur3_x64_128.h1(canonical ASCII k-mer), seed 0"}
+    with open(os.path.join(path, "meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
+def write_sketch_table_v1(path, names, ks, n, per_k):
+    """The genome-major layout of version 1 (kept for tables already on disk and for the tests of the reader)."""
+    _write_common(path, names)
     for k in ks:
         h, o = per_k[k]
         np.ascontiguousarray(h, dtype="<u8").tofile(os.path.join(path, "k%d.hashes.u64" % k))

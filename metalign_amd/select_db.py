@@ -114,19 +114,26 @@ def run_sketch_steps(args):
     nreads = reads.count
     min_count = int(getattr(args, 'min_count', 2))
     s = int(getattr(args, 'sketch_size', 0))
-    per_k = []
+    # every k of the table: the hash-major pairs go up as they lie on disk (no sort), the stored pre-filter with them
+    # (the role of the reference's bloom pre-filter, -f ...bf, :70,75) ...
+    dev_tables, filts = [], []
     for k in table.ks:
-        h, o = table.arrays(k)
-        dev_table = hip.upload_table(np.asarray(h), o)
-        filt = hip.filter_build(np.asarray(h))  # the role of the reference's bloom pre-filter (-f ...bf, :70,75)
-        sk = hip.sketch_reads_dev(d_b_ptr, d_o_ptr, nreads, k, dev_table.max_hash, s, filt=filt)
+        dev_tables.append(hip.upload_table_sorted(**table.pairs(k)))
+        bits = table.filter_bits(k)
+        filts.append(hip.filter_from_bits(bits) if bits is not None
+                     else hip.filter_build(np.asarray(table.pairs(k)['pair_hash'])))
+    # ... then ONE pass over the reads for all k (the reference's query is multi-k too: 30-60-10, :75), and stage B per k
+    sks = hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, nreads, table.ks, [t.max_hash for t in dev_tables], s, filts)
+    per_k = []
+    for sk, dev_table in zip(sks, dev_tables):
         hits, sizes = hip.containment(sk, dev_table, min_count)
+        if sk.resolve():  # the counting table had overflowed and the sketch was rebuilt: stage B again
+            hits, sizes = hip.containment(sk, dev_table, min_count)
         with np.errstate(divide='ignore', invalid='ignore'):
             ci = np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0)
         per_k.append(ci)
-        sk.free()
-        filt.free()
-        dev_table.free()
+    for h in sks + filts + dev_tables:
+        h.free()
     reads.free()
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))

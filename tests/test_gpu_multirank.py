@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 
 import util
-from metalign_amd import synth
+from metalign_amd import formats, synth
 from metalign_amd.distributed import table_bounds, table_max_hash, table_slice
 from test_gpu_fullsize import _stage_c_sharded
 
@@ -201,3 +201,45 @@ def test_config4_one_rank_stage_c_full_size(hip, oracle_lib):
     sharded = _stage_c_sharded(hip, recs, ref2tax, T, cuts)
     for key in want:
         assert np.array_equal(np.asarray(sharded[key]), np.asarray(want[key])), key
+
+
+def test_hash_major_table_on_disk_sliced_loads(hip, oracle_lib, tmp_path):
+    """The table as the builder writes it (formats version 2: hash-major pairs + the membership filter): uploaded without
+    a sort (mg_db_upload_sorted) it gives the containment of the genome-major upload; a rank of a W-rank job maps only
+    its hash range [bounds[r], bounds[r+1]) — 1/W of the pair files — and the per-range counts add up to the whole."""
+    rng = np.random.default_rng(12)
+    G, n, ks, W = 200, 300, (21, 31), 4
+    gb, go = util.random_genomes(rng, G, 5000)
+    rb, ro, _ = util.sample_reads(rng, gb, go, 8000, 150, err=0.01, present=rng.choice(G, size=12, replace=False))
+    d_b, d_o = hip.array(rb), hip.array(ro)
+    per_k, filters = {}, {}
+    for k in ks:
+        per_k[k] = hip.sketch_genomes(gb, go, k, n)
+        f = hip.filter_build(per_k[k][0])
+        filters[k] = f.download()
+        f.free()
+    formats.write_sketch_table(str(tmp_path / "t"), ["g%d" % g for g in range(G)], list(ks), n, per_k, filters)
+    disk = formats.SketchTable(str(tmp_path / "t"))
+    for k in ks:
+        dbh, dbo = per_k[k]
+        full = disk.pairs(k)
+        filt = hip.filter_from_bits(disk.filter_bits(k))
+        assert np.array_equal(filt.download(), filters[k])
+        sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(ro) - 1, k, full["max_hash"], 0, filt=filt)
+        want_h, want_s = hip.containment(sk, hip.upload_table(dbh, dbo), 2)   # genome-major upload: sorted on the device
+        got_h, got_s = hip.containment(sk, hip.upload_table_sorted(**full), 2)
+        assert np.array_equal(got_h, want_h) and np.array_equal(got_s, want_s)
+        qh, qc, tr, _ = oracle_lib.sketch_reads_filtered(rb, ro, k, dbh, hmax=full["max_hash"])
+        oh, osz = oracle_lib.containment(qh, qc, tr, 2, dbh, dbo)
+        assert np.array_equal(got_h, oh) and np.array_equal(got_s, osz)
+        b = table_bounds(full["pair_hash"], W, full["max_hash"], presorted=True)
+        assert b == table_bounds(dbh, W, full["max_hash"])  # the same cut points from either layout
+        hits, sizes, touched = np.zeros(G, np.uint64), np.zeros(G, np.uint64), 0
+        for r in range(W):
+            part = disk.pairs(k, b[r], b[r + 1])
+            touched += len(part["pair_hash"])
+            assert abs(len(part["pair_hash"]) - len(dbh) / W) <= 0.02 * len(dbh) / W + G  # 1/W of the table per rank
+            hr, sr = hip.containment(sk, hip.upload_table_sorted(**part), 2)
+            hits += hr
+            sizes += sr
+        assert touched == len(dbh) and np.array_equal(hits, oh) and np.array_equal(sizes, osz)

@@ -128,3 +128,43 @@ def test_paf_adaptor_maps_onto_sam_records():
     # without cg:Z: the identity test is approximated by matching bases / query length
     c = mp.tokenise_paf(["r3\t100\t0\t100\t+\tNZ_A.1\t5000\t0\t100\t90\t100\t60\ttp:A:P\n"], idx)
     assert (int(c["matched"][0]), int(c["total"][0])) == (90, 100)
+
+
+def test_sketch_table_v2_hash_major_round_trip(tmp_path):
+    """formats: the hash-major table (version 2) — what the builder writes is what stage B streams; slices by hash range
+    touch only their part and add up; the genome-major view and version-1 directories still read the same table."""
+    import numpy as np
+    from metalign_amd import formats
+    rng = np.random.default_rng(4)
+    G, n = 7, 50
+    per_k = {}
+    for k in (21, 31):
+        sk = [np.sort(rng.choice(1 << 40, size=int(rng.integers(0, n + 1)), replace=False).astype(np.uint64)) for _ in range(G)]
+        sk[3] = sk[2][: len(sk[2]) // 2].copy()  # shared hashes between genomes
+        o = np.zeros(G + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(x) for x in sk])
+        per_k[k] = (np.concatenate(sk), o)
+    names = ["taxid_%d_1_genomic.fna.gz" % g for g in range(G)]
+    filters = {21: np.arange(2048, dtype=np.uint32)}
+    formats.write_sketch_table(str(tmp_path / "v2"), names, [21, 31], n, per_k, filters)
+    formats.write_sketch_table_v1(str(tmp_path / "v1"), names, [21, 31], n, per_k)
+    for d in ("v2", "v1"):
+        t = formats.SketchTable(str(tmp_path / d))
+        assert t.ks == [21, 31] and t.ngenomes == G and t.names == names
+        for k in (21, 31):
+            h, o = t.arrays(k)
+            assert np.array_equal(h, per_k[k][0]) and np.array_equal(o, per_k[k][1])
+            full = t.pairs(k)
+            ph, pg = np.asarray(full["pair_hash"]), np.asarray(full["pair_gen"])
+            assert np.all(ph[1:] >= ph[:-1]) and len(ph) == len(per_k[k][0]) and full["max_hash"] == int(per_k[k][0].max())
+            assert np.array_equal(full["gsize"], np.diff(per_k[k][1]).astype(np.uint32))
+            same = ph[1:] == ph[:-1]
+            assert np.all(pg[1:][same] > pg[:-1][same])  # equal hashes: genome order
+            for g in range(G):  # every genome's pairs are its sketch
+                assert np.array_equal(ph[pg == g], per_k[k][0][int(per_k[k][1][g]):int(per_k[k][1][g + 1])])
+            bounds = [0, int(ph[len(ph) // 3]), int(ph[2 * len(ph) // 3]), full["max_hash"] + 1]
+            parts = [t.pairs(k, bounds[i], bounds[i + 1]) for i in range(3)]
+            assert np.array_equal(np.concatenate([np.asarray(q["pair_hash"]) for q in parts]), ph)
+            assert np.array_equal(sum(q["gsize"].astype(np.int64) for q in parts), full["gsize"])
+    t2 = formats.SketchTable(str(tmp_path / "v2"))
+    assert np.array_equal(t2.filter_bits(21), filters[21]) and t2.filter_bits(31) is None
