@@ -407,6 +407,16 @@ int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_ind
                         mg_sam_batch** out, int* err_kind, uint64_t* err_line);
 int mg_sam_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
                     mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+/* PAF replay adaptor (minimap2 PAF instead of SAM).  The reference has no PAF reader — it parses SAM
+ * columns (scripts/map_and_profile.py:87,97,142-144,211,217) — so this maps PAF onto the same records: fields split on
+ * TAB, lines with fewer than 12 fields skipped, RNAME <- column 6, FLAG <- 16 for strand '-' (+ 256 when the last
+ * `tp:A:` tag is S), CIGAR totals from the last `cg:Z:` tag (matched = sum of M, total = all operations + the query
+ * bases outside [qstart, qend), which SAM writes as clipping) or, without one, matched = column 10 and total = column 2;
+ * len(SEQ) <- query length (0 for secondaries).  Same batch handle, same err_kind / err_line contract as the SAM call. */
+int mg_paf_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                        mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+int mg_paf_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                    mg_sam_batch** out, int* err_kind, uint64_t* err_line);
 uint64_t mg_sam_batch_count(const mg_sam_batch* b);
 const char* mg_sam_batch_last_qname(const mg_sam_batch* b);
 int mg_sam_batch_device_ptr(const mg_sam_batch* b, const mg_aln_rec** d_recs);

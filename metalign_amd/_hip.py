@@ -33,7 +33,7 @@ EXPORTS = [
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
-    "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_sam_batch_count",
+    "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
@@ -768,11 +768,13 @@ class Hip:
         self.lib.mg_sam_batch_free(h)
         return n
 
-    def sam_tokenize_dev_batch(self, d_text, nbytes, acc_index, prev_qname=""):
-        """SAM text resident in HBM -> SamBatch (records stay on the device).  SamParseError as sam_tokenize."""
+    def sam_tokenize_dev_batch(self, d_text, nbytes, acc_index, prev_qname="", paf=False):
+        """SAM (or, paf=True, PAF) text resident in HBM -> SamBatch (records stay on the device).  SamParseError as
+        sam_tokenize."""
         h = _vp()
         kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
-        rc = self.lib.mg_sam_tokenize_dev(_vp(d_text), ctypes.c_uint64(nbytes), acc_index.handle,
+        fn = self.lib.mg_paf_tokenize_dev if paf else self.lib.mg_sam_tokenize_dev
+        rc = fn(_vp(d_text), ctypes.c_uint64(nbytes), acc_index.handle,
                                           ctypes.c_char_p(prev_qname.encode()), ctypes.byref(h), ctypes.byref(kind),
                                           ctypes.byref(line))
         if rc != 0 and kind.value:
@@ -790,14 +792,15 @@ class Hip:
                                               ctypes.c_uint32(len(names)), ctypes.byref(h)))
         return AccIndex(self, h)
 
-    def sam_tokenize(self, text, acc_index, prev_qname=""):
-        """One chunk of SAM text (ending on a line boundary) -> (records REC_DTYPE[], QNAME of its last
+    def sam_tokenize(self, text, acc_index, prev_qname="", paf=False):
+        """One chunk of SAM (paf=True: PAF) text (ending on a line boundary) -> (records REC_DTYPE[], QNAME of its last
         retained line).  Raises SamParseError for a line the reference cannot parse."""
         buf = np.frombuffer(text, dtype=np.uint8)  # bytes or a memoryview slice: no copy
         h = _vp()
         kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
         src = buf if buf.size else np.zeros(1, np.uint8)
-        rc = self.lib.mg_sam_tokenize(_np(src, ctypes.c_uint8), ctypes.c_uint64(buf.size), acc_index.handle,
+        fn = self.lib.mg_paf_tokenize if paf else self.lib.mg_sam_tokenize
+        rc = fn(_np(src, ctypes.c_uint8), ctypes.c_uint64(buf.size), acc_index.handle,
                                       ctypes.c_char_p(prev_qname.encode()), ctypes.byref(h), ctypes.byref(kind),
                                       ctypes.byref(line))
         if rc != 0 and kind.value:

@@ -338,6 +338,121 @@ __global__ void k_sam_parse(const uint8_t* __restrict__ text, const uint64_t* __
   }
 }
 
+// PAF replay adaptor, one thread per line: minimap2 PAF -> the same records, by the rules of
+// metalign_amd/map_and_profile.py::tokenise_paf (the reference itself reads SAM, scripts/map_and_profile.py:87,97,
+// 142-144,211,217: this is an adaptor, not a parity path).  Fields are split on TAB only (the trailing CR / LF
+// stripped); lines with fewer than 12 fields are skipped; RNAME <- column 6; FLAG <- 16 if strand '-', + 256 if the
+// LAST `tp:A:` tag is S; with a `cg:Z:` tag (the last one) matched = sum of M, total = all ops + the query bases outside
+// [qstart, qend); without, matched = column 10 and total = column 2; len(SEQ) <- query length, 0 for secondaries.
+__device__ __forceinline__ bool paf_int(const uint8_t* t, uint64_t b, uint64_t e, int64_t* v) {  // int(field): [+-]digits
+  bool neg = false;
+  if (b < e && (t[b] == '+' || t[b] == '-')) { neg = t[b] == '-'; ++b; }
+  if (b >= e) return false;
+  int64_t x = 0;
+  for (; b < e; ++b) {
+    if (t[b] < '0' || t[b] > '9') return false;
+    x = x * 10 + (t[b] - '0');
+    if (x > (1ll << 40)) return false;  // (reported as overflow by the caller's range checks anyway)
+  }
+  *v = neg ? -x : x;
+  return true;
+}
+
+__global__ void k_paf_parse(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end, uint64_t nlines,
+                            AccTable acc, LineOut* __restrict__ out, uint32_t* __restrict__ retained,
+                            unsigned long long* __restrict__ err, uint32_t* __restrict__ err_kind) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; l < nlines; l += stride) {
+    LineOut o;
+    o.retained = 0;
+    o.qbeg = 0; o.qlen = 0;
+    o.rec.ref_new = o.rec.matched = o.rec.total = o.rec.flag_len = 0;
+    const uint64_t beg = l == 0 ? 0 : line_end[l - 1] + 1;
+    uint64_t end = line_end[l];
+    while (end > beg && (text[end - 1] == '\r' || text[end - 1] == '\n')) --end;  // rstrip('\r\n')
+    uint32_t kind = kErrNone;
+    // the first 12 fields; the tags after them are scanned in place
+    uint64_t fb[12], fe[12];
+    int nf = 0;
+    uint64_t p = beg;
+    while (nf < 12) {
+      fb[nf] = p;
+      while (p < end && text[p] != '\t') ++p;
+      fe[nf] = p;
+      ++nf;
+      if (p >= end) break;
+      ++p;  // the TAB
+    }
+    const bool more = nf == 12 && fe[11] < end;  // a TAB follows the 12th field: tags
+    if (nf == 12) {
+      int64_t qlen = 0, qs = 0, qe = 0, nmatch = 0;
+      if (!paf_int(text, fb[1], fe[1], &qlen) || !paf_int(text, fb[2], fe[2], &qs) || !paf_int(text, fb[3], fe[3], &qe))
+        kind = kErrValue;
+      uint32_t flag = (fe[4] - fb[4] == 1 && text[fb[4]] == '-') ? 16u : 0u;
+      // tags: the LAST tp:A: and the LAST cg:Z: win (a dict built left to right)
+      bool secondary = false, have_cg = false;
+      uint64_t cgb = 0, cge = 0;
+      if (more) {
+        uint64_t t = fe[11] + 1;
+        while (t <= end) {
+          uint64_t te = t;
+          while (te < end && text[te] != '\t') ++te;
+          if (te - t > 5) {
+            if (text[t] == 't' && text[t + 1] == 'p' && text[t + 2] == ':' && text[t + 3] == 'A')
+              secondary = te - t == 6 && text[t + 5] == 'S';
+            if (text[t] == 'c' && text[t + 1] == 'g' && text[t + 2] == ':' && text[t + 3] == 'Z') { have_cg = true; cgb = t + 5; cge = te; }
+          }
+          if (te >= end) break;
+          t = te + 1;
+        }
+      }
+      if (secondary) flag |= 256u;
+      int64_t matched = 0, total = 0;
+      if (kind == kErrNone) {
+        if (have_cg) {
+          int64_t cur = 0;
+          for (uint64_t c = cgb; c < cge; ++c) {
+            const uint8_t ch = text[c];
+            if (ch >= '0' && ch <= '9') { cur = cur * 10 + (ch - '0'); if (cur > (1ll << 40)) cur = 1ll << 40; }
+            else { if (ch == 'M') matched += cur; total += cur; cur = 0; }
+          }
+          total += qlen - (qe - qs);
+        } else {
+          if (!paf_int(text, fb[9], fe[9], &nmatch)) kind = kErrValue;
+          matched = nmatch;
+          total = qlen;
+        }
+      }
+      if (kind == kErrNone && total == 0) kind = kErrZeroDiv;
+      const int64_t slen = secondary ? 0 : qlen;
+      int64_t row = -1;
+      if (kind == kErrNone) {
+        row = acc_lookup(acc, text + fb[5], (uint32_t)(fe[5] - fb[5]));
+        if (row < 0) kind = kErrKey;
+      }
+      if (kind == kErrNone && (slen < 0 || slen > (int64_t)MG_REC_MAX_SEQLEN || matched < 0 || matched > 0xffffffffll ||
+                               total < 0 || total > 0xffffffffll))
+        kind = kErrOverflow;
+      if (kind == kErrNone) {
+        o.retained = 1;
+        o.rec.ref_new = (uint32_t)row;
+        o.rec.matched = (uint32_t)matched;
+        o.rec.total = (uint32_t)total;
+        o.rec.flag_len = flag | ((uint32_t)slen << MG_REC_LEN_SHIFT);
+        o.qbeg = fb[0];
+        o.qlen = (uint32_t)(fe[0] - fb[0]);
+      }
+    }
+    if (kind != kErrNone) {
+      atomicMin(err, (unsigned long long)l);
+      err_kind[l] = kind;
+    }
+    out[l] = o;
+    retained[l] = o.retained;
+  }
+}
+
 // rank = exclusive prefix of retained flags: list the retained lines in order
 __global__ void k_sam_list(const uint32_t* __restrict__ retained, const uint64_t* __restrict__ rank, uint64_t nlines,
                            uint64_t* __restrict__ ret_line) {
@@ -602,8 +717,8 @@ int mg_acc_index_build(const char* names, const uint64_t* name_offsets, uint32_t
 
 void mg_acc_index_free(mg_acc_index* ix) { delete ix; }
 
-int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
-                        mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+static int aln_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                            bool paf, mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
   MG_REQUIRE_READY();
   if (!out || !ix) return fail(MG_ERR_ARG, "null argument");
   *out = nullptr;
@@ -637,8 +752,12 @@ int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_ind
   uint64_t nret = 0;
   {
     ProfScope ps("ingest_sam");
-    hipLaunchKernelGGL(k_sam_parse, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
-                       nlines, at, d_lines, d_ret, d_err, d_kind);
+    if (paf)
+      hipLaunchKernelGGL(k_paf_parse, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
+                         nlines, at, d_lines, d_ret, d_err, d_kind);
+    else
+      hipLaunchKernelGGL(k_sam_parse, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
+                         nlines, at, d_lines, d_ret, d_err, d_kind);
     MG_HIP(hipGetLastError());
     MG_TRY(exclusive_sum_u32_to_u64(d_ret, d_rank, nlines, &nret));
     unsigned long long h_err = 0;
@@ -650,7 +769,7 @@ int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_ind
       MG_HIP(hipStreamSynchronize(st));
       if (err_kind) *err_kind = (int)kind;
       if (err_line) *err_line = h_err;
-      return fail(MG_ERR_ARG, "SAM line %llu: parse error kind %u", h_err, kind);
+      return fail(MG_ERR_ARG, "%s line %llu: parse error kind %u", paf ? "PAF" : "SAM", h_err, kind);
     }
     MG_TRY(sb->recs.alloc((nret + 1) * sizeof(mg_aln_rec)));
     if (nret) {
@@ -676,6 +795,25 @@ int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_ind
   sb->nrecs = nret;
   *out = sb.release();
   return MG_OK;
+}
+
+int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                        mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  return aln_tokenize_dev(d_text, nbytes, ix, prev_qname, false, out, err_kind, err_line);
+}
+
+int mg_paf_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                        mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  return aln_tokenize_dev(d_text, nbytes, ix, prev_qname, true, out, err_kind, err_line);
+}
+
+int mg_paf_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                    mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  MG_REQUIRE_READY();
+  DevBuf d_text;
+  MG_TRY(d_text.alloc(nbytes + 16));
+  MG_TRY(mg_memcpy_h2d(d_text.p, text, nbytes));
+  return mg_paf_tokenize_dev(d_text.as<uint8_t>(), nbytes, ix, prev_qname, out, err_kind, err_line);
 }
 
 int mg_sam_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,

@@ -239,9 +239,9 @@ def _line_chunks(instream, decode):
         yield b''.join(buf)
 
 
-def tokenise_sam_device(instream, acc_index, decode=False):
-    """SAM stream -> records on the MI355X (mg_sam_tokenize).  A line the reference cannot parse is re-run
-    through the host tokeniser so that the very same exception (type and message) surfaces."""
+def tokenise_sam_device(instream, acc_index, decode=False, paf=False):
+    """SAM (paf=True: PAF) stream -> records on the MI355X (mg_sam_tokenize / mg_paf_tokenize).  A line the reference
+    cannot parse is re-run through the host tokeniser so that the very same exception (type and message) surfaces."""
     hip = _hip.Hip.get()
     names = [None] * len(acc_index)
     for a, i in acc_index.items():
@@ -251,10 +251,13 @@ def tokenise_sam_device(instream, acc_index, decode=False):
     try:
         for chunk in _line_chunks(instream, decode):
             try:
-                recs, prev = hip.sam_tokenize(chunk, index, prev)
+                recs, prev = hip.sam_tokenize(chunk, index, prev, paf=paf)
             except _hip.SamParseError as e:
                 bad = bytes(chunk).split(b'\n')[e.line].decode('utf-8', 'replace')
-                _Tokeniser(acc_index).feed(bad)  # raises KeyError / IndexError / ValueError / ZeroDivisionError
+                if paf:
+                    tokenise_paf([bad], acc_index)  # raises KeyError / ValueError / ZeroDivisionError
+                else:
+                    _Tokeniser(acc_index).feed(bad)  # raises KeyError / IndexError / ValueError / ZeroDivisionError
                 raise
             parts.append(recs)
     finally:
@@ -265,6 +268,14 @@ def tokenise_sam_device(instream, acc_index, decode=False):
 
 
 _device_tokenise = tokenise_sam_device
+
+
+def tokenise_paf_device(instream, acc_index, decode=False):
+    """PAF replay on the device (mg_paf_tokenize): the same records as tokenise_paf."""
+    return tokenise_sam_device(instream, acc_index, decode=decode, paf=True)
+
+
+_device_tokenise_paf = tokenise_paf_device
 
 
 def dense_tables(acc2info, taxid2info):
@@ -329,7 +340,7 @@ def assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=True):
     return taxids2abs, multimapped, {}
 
 
-def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _resident=False):
+def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _resident=False, _paf=False):
     """map_and_process for a plain SAM FILE, without the text or the records ever being host arrays: the file goes up
     through page-locked chunks (Hip.upload_file), is tokenised where it lands and stage C runs on the records the
     tokeniser left in HBM.  A line the reference cannot parse makes this return None: the caller then takes the
@@ -345,7 +356,7 @@ def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _re
     try:
         try:
             d_text, size = hip.upload_file(path)
-            batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '')
+            batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '', paf=_paf)
         except _hip.SamParseError:
             return None
         except _hip.HipError as e:
@@ -376,7 +387,7 @@ def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_li
     # test seam: an injected record-level backend is fed by the host tokeniser; product code never passes one
     tokenise = _device_tokenise if _assign is None else tokenise_sam
     if getattr(args, 'paf_input', False):
-        tokenise = tokenise_paf
+        tokenise = _device_tokenise_paf if _assign is None else tokenise_paf
     recs = tokenise(instream, acc_index, decode=(args.input_type != 'sam'))
     res = (_assign or (_device_assign_resident if _resident else _device_assign))(recs, ref2tax, len(taxids),
                                                                                   float(args.pct_id))
@@ -548,9 +559,10 @@ def compute_abundances(args, infile, acc2info, tax2info):
     on_device = bool(getattr(args, 'device_multimap', False))
     done = None
     seams_untouched = _device_tokenise is tokenise_sam_device and _device_assign is _DEVICE_ASSIGN  # (tests reroute them)
-    if args.input_type == 'sam' and not getattr(args, 'paf_input', False) and seams_untouched:
-        # a plain file: all the way on the device
-        done = map_and_process_file(args, infile, acc2info, tax2info, _want_lists=False, _resident=on_device)
+    if args.input_type == 'sam' and seams_untouched:
+        # a plain file (SAM, or a PAF replay): all the way on the device
+        done = map_and_process_file(args, infile, acc2info, tax2info, _want_lists=False, _resident=on_device,
+                                    _paf=bool(getattr(args, 'paf_input', False)))
     if done is None:
         done = map_and_process(args, instream, acc2info, tax2info, _want_lists=False, _resident=on_device)
     taxids2abs, mm, low_mem_mmap = done

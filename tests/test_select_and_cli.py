@@ -168,3 +168,18 @@ def test_sketch_table_v2_hash_major_round_trip(tmp_path):
             assert np.array_equal(sum(q["gsize"].astype(np.int64) for q in parts), full["gsize"])
     t2 = formats.SketchTable(str(tmp_path / "v2"))
     assert np.array_equal(t2.filter_bits(21), filters[21]) and t2.filter_bits(31) is None
+
+
+def test_tokenise_paf_takes_bytes_lines_like_the_stream_code_hands_them(tmp_path):
+    """compute_abundances opens replay files in binary mode: PAF lines arrive as bytes (this crashed with TypeError)."""
+    import numpy as np
+    from metalign_amd import map_and_profile as mp
+    idx = {"Unmapped": 0, "NZ_A.1": 1}
+    line = "r1\t40\t5\t40\t+\tNZ_A.1\t5000\t9\t44\t34\t35\t60\ttp:A:P\tcg:Z:35M\n"
+    a = mp.tokenise_paf([line], idx)
+    b = mp.tokenise_paf([line.encode()], idx)
+    p = tmp_path / "x.paf"
+    p.write_text(line * 3)
+    with open(str(p), "rb") as fh:
+        c = mp.tokenise_paf(fh, idx, decode=False)
+    assert np.array_equal(a, b) and len(c) == 3 and np.array_equal(c[:1], a)
