@@ -201,9 +201,10 @@ def committed_profile(name, cfg):
     pdir = os.path.join(ROOT, "profiles")
     best = None
     for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, rnd, name)
-        if os.path.exists(f):
-            with open(f) as fh:
+        for fn in sorted(os.listdir(os.path.join(pdir, rnd))):  # <name> itself or <workload tag>_<name>
+            if not fn.endswith(name):
+                continue
+            with open(os.path.join(pdir, rnd, fn)) as fh:
                 d = json.load(fh)
             wl = d.get("workload", {})
             if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")])) == (cfg["reads"], cfg["genomes"], cfg["ks"]):
@@ -308,10 +309,11 @@ def main():
         achieved = algo_k1 / (k1_per_pass_ms * 1e-3) / 1e9 if nk1 else 0.0
         traffic = committed_profile("pmc_traffic.json", cfg)
         sq = committed_profile("pmc_sq_summary.json", cfg)
-        valu_insts = sq["k_sketch_reads"]["SQ_INSTS_VALU_per_pass"] if sq else None
+        valu_insts = sq["k_sketch_reads"].get("SQ_INSTS_VALU_per_pass") if sq else None
         roof = {"kernel": "k_sketch_reads* (stage A, all k of the pass: %.0f launch(es) per pass)" % launches_per_pass,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic["k_sketch_reads"]["hbm_bytes_per_pass"] if traffic else None,
+                "traffic": (traffic["k_sketch_reads"].get("hbm_bytes_per_pass", traffic["k_sketch_reads"].get("hbm_bytes_per_launch"))
+                            if traffic else None),
                 "avg_launch_ms": k1_ms / max(nk1, 1), "ms_per_pass": k1_per_pass_ms,
                 "algorithmic_bytes_per_pass": algo_k1,
                 "valu_frac": (valu_insts * 4.0 / (SIMDS * CLOCK_HZ * k1_per_pass_ms * 1e-3)) if (valu_insts and nk1) else None,

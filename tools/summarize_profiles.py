@@ -1,7 +1,9 @@
 """Condenses the rocprofv3 outputs of tools/collect_profiles.sh into small files fit for profiles/<round>/:
-kernel_stats.csv (library kernels only, names shortened), pmc_traffic.json (HBM bytes per launch per kernel,
-corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
-FETCH_SIZE counts half of a wide coalesced read) and pmc_sq.json (VALU issue statistics of the dominant kernel).
+kernel_stats.csv (library kernels only, names shortened), pmc_traffic.json (HBM bytes per launch and per PASS, corrected
+as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts
+half of a wide coalesced read) and pmc_sq_summary.json (VALU instruction counts per launch and per pass).  "Per pass" for
+stage A = the sum over the k of one pass (one fused launch, or one launch per k).  bench.py reads the two JSON files of
+the newest round whose workload matches its own.
 Usage: python tools/summarize_profiles.py gpurun_out/prof_<tag>"""
 import csv
 import glob
@@ -12,11 +14,12 @@ import sys
 
 
 def short(name):
-    m = re.search(r"mg::(k_\w+(?:<[^>]*>)?)", name)
+    m = re.search(r"mg::(k_\w+(?:<.*>)?)", name)
     if m:
-        return m.group(1)
+        return m.group(1).replace("mg::", "").replace(" ", "")
     if "rocprim" in name:
-        return "rocprim::" + (re.search(r"detail::(\w+)", name).group(1) if re.search(r"detail::(\w+)", name) else "kernel")
+        m = re.search(r"detail::(\w+)", name)
+        return "rocprim::" + (m.group(1) if m else "kernel")
     return name.split("(")[0][:60]
 
 
@@ -25,7 +28,38 @@ def one(pattern):
     return f[0] if f else None
 
 
+def per_kernel(csvfile, counters):
+    acc = {}
+    for r in csv.DictReader(open(csvfile)):
+        if r["Counter_Name"] not in counters:
+            continue
+        k = short(r["Kernel_Name"])
+        a = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: {c: {"launches": n, "avg": tot / n} for c, (n, tot) in d.items()} for k, d in acc.items()}
+
+
+def stage_a_per_pass(d, key):
+    """Sum over the stage-A kernels of one pass: the fused kernel if it ran, else one k_sketch_reads<K> per k."""
+    fused = [k for k in d if k.startswith("k_sketch_reads_multi")]
+    names = fused if fused else [k for k in d if re.match(r"k_sketch_reads<\d+>", k)]
+    return names, sum(d[k][key] for k in names)
+
+
 def main(out):
+    bench = {}
+    for f in ("bench_under_rocprof.json", "bench.json"):
+        p = os.path.join(out, f)
+        if os.path.exists(p):
+            lines = [ln for ln in open(p) if ln.startswith('{"metric"')]
+            if lines:
+                bench = json.loads(lines[-1])
+                break
+    wl = {}
+    m = re.search(r"(\d+) synthetic 150bp reads/GPU vs (\d+)-genome .*k in \[([\d, ]+)\]", bench.get("config", {}).get("workload", ""))
+    if m:
+        wl = {"reads": int(m.group(1)), "genomes": int(m.group(2)), "ks": [int(x) for x in m.group(3).split(",")]}
     res = {}
     f = one(os.path.join(out, "stats", "**", "*kernel_stats.csv"))
     if f:
@@ -35,49 +69,42 @@ def main(out):
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-        res["kernel_stats"] = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+        res["kernel_stats_avg_ns"] = {short(r["Name"]): float(r["AverageNs"]) for r in rows if short(r["Name"]).startswith("k_")}
     traffic = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(os.path.join(out, "pmc_" + c, "**", "*counter_collection.csv"))
         if not f:
             continue
-        acc = {}
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != c:
-                continue
-            k = short(r["Kernel_Name"])
-            a = acc.setdefault(k, [0, 0.0])
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
-        for k, (n, tot) in acc.items():
-            kb = tot / n
-            scale = 2048.0 if c == "FETCH_SIZE" else 1024.0  # KB -> bytes; FETCH_SIZE x2 on gfx950 (guide, HBM section)
-            traffic.setdefault(k, {"launches": n})[c.lower() + "_bytes"] = kb * scale
+        scale = 2048.0 if c == "FETCH_SIZE" else 1024.0  # KB -> bytes; FETCH_SIZE x2 on gfx950 (guide, HBM section)
+        for k, d in per_kernel(f, {c}).items():
+            t = traffic.setdefault(k, {"launches": d[c]["launches"]})
+            t[c.lower().replace("_size", "") + "_bytes"] = d[c]["avg"] * scale
     for k, d in traffic.items():
-        d["hbm_bytes_per_launch"] = d.get("fetch_size_bytes", 0.0) + d.get("write_size_bytes", 0.0)
+        d["hbm_bytes_per_launch"] = d.get("fetch_bytes", 0.0) + d.get("write_bytes", 0.0)
     if traffic:
-        json.dump({"correction": "FETCH_SIZE KB x1024 x2 (gfx950 counts half of wide coalesced reads), WRITE_SIZE KB x1024; "
-                                 "atomics are read-modify-writes at the memory side and show up in WRITE_SIZE",
-                   "kernels": {k: v for k, v in traffic.items() if k.startswith("k_")}},
-                  open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+        names, tot = stage_a_per_pass(traffic, "hbm_bytes_per_launch")
+        doc = {"workload": wl,
+               "correction": "FETCH_SIZE KB x1024 x2 (gfx950 counts half of wide coalesced reads), WRITE_SIZE KB x1024; atomics are "
+                             "read-modify-writes at the memory side and show up in WRITE_SIZE; two separate --pmc passes",
+               "k_sketch_reads": {"kernels": names, "hbm_bytes_per_pass": tot,
+                                  "fetch_bytes_per_pass": sum(traffic[k].get("fetch_bytes", 0.0) for k in names),
+                                  "write_bytes_per_pass": sum(traffic[k].get("write_bytes", 0.0) for k in names),
+                                  "algorithmic_bytes_per_pass": 158 * wl.get("reads", 0)},
+               "kernels": {k: v for k, v in traffic.items() if k.startswith("k_")}}
+        json.dump(doc, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+        res["stage_a_hbm_bytes_per_pass"] = tot
     f = one(os.path.join(out, "pmc_SQ", "**", "*counter_collection.csv"))
     if f:
-        acc = {}
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            if not k.startswith("k_"):
-                continue
-            d = acc.setdefault(k, {})
-            a = d.setdefault(r["Counter_Name"], [0, 0.0])
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
-        sq = {k: {c: tot / n for c, (n, tot) in d.items()} for k, d in acc.items()}
-        for k, d in sq.items():
-            if d.get("SQ_BUSY_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
-                d["valu_busy_frac_of_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / max(d.get("SQ_WAVE_CYCLES", 1.0), 1.0)
-        json.dump(sq, open(os.path.join(out, "pmc_sq.json"), "w"), indent=1)
-    print(json.dumps({k: v for k, v in res.get("kernel_stats", {}).items() if k.startswith("k_")}, indent=1))
-    print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in traffic.items() if k.startswith("k_")}, indent=1))
+        sq = {k: {c: v["avg"] for c, v in d.items()} | {"launches": max(v["launches"] for v in d.values())}
+              for k, d in per_kernel(f, {"SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"}).items()
+              if k.startswith("k_")}
+        names, tot = stage_a_per_pass(sq, "SQ_INSTS_VALU")
+        doc = {"workload": wl, "k_sketch_reads": {"kernels": names, "SQ_INSTS_VALU_per_pass": tot,
+                                                  "per_wave_step": tot / max(wl.get("reads", 1) * 150 / 64.0, 1.0)},
+               "kernels": sq}
+        json.dump(doc, open(os.path.join(out, "pmc_sq_summary.json"), "w"), indent=1)
+        res["stage_a_valu_insts_per_pass"] = tot
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
