@@ -203,6 +203,29 @@ enum SamErr : uint32_t { kErrNone = 0, kErrKey = 1, kErrIndex = 2, kErrValue = 3
 __device__ __forceinline__ bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 __device__ __forceinline__ bool is_alpha(uint8_t c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
 
+// First whitespace byte in [p, end), or end.  A SAM line is mostly SEQ and QUAL (2 x 150 of ~370 bytes) that only have
+// to be stepped over: eight bytes per load once p is aligned, with a SWAR test for "some byte below 0x21" (the classic
+// has-less-than; bytes >= 0x80 never match); a candidate is then checked against the exact whitespace set of
+// str.split().  One byte per load made the one-thread-per-line parser latency-bound at 106 GB/s of text.
+__device__ __forceinline__ uint64_t scan_to_ws(const uint8_t* __restrict__ text, uint64_t p, uint64_t end) {
+  while (p < end && ((reinterpret_cast<uintptr_t>(text) + p) & 7u)) {
+    if (is_ws(text[p])) return p;
+    ++p;
+  }
+  while (p + 8 <= end) {
+    const uint64_t x = *reinterpret_cast<const uint64_t*>(text + p);
+    uint64_t m = (x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull;
+    while (m) {  // candidates in ascending order (a borrow can only flag bytes ABOVE a true one: checked like the rest)
+      const uint32_t b = (uint32_t)__builtin_ctzll(m) >> 3;
+      if (is_ws((uint8_t)(x >> (8 * b)))) return p + b;
+      m &= m - 1;
+    }
+    p += 8;
+  }
+  while (p < end && !is_ws(text[p])) ++p;
+  return p;
+}
+
 __device__ __forceinline__ uint64_t fnv1a(const uint8_t* p, uint32_t n) {
   uint64_t h = 0xcbf29ce484222325ull;
   for (uint32_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
@@ -266,7 +289,7 @@ __global__ void k_sam_parse(const uint8_t* __restrict__ text, const uint64_t* __
         while (p < end && is_ws(text[p])) ++p;
         if (p >= end) break;
         fb[nf] = p;
-        while (p < end && !is_ws(text[p])) ++p;
+        p = scan_to_ws(text, p, end);
         fe[nf] = p;
         ++nf;
       }
