@@ -31,10 +31,18 @@ static uint64_t size_class(uint64_t n) {
   return p;
 }
 
+static void seal_open_batch();
+static void release_completed_batches();
+
 void* pool_alloc(uint64_t bytes, uint64_t* got) {
   Context& c = ctx();
   const uint64_t cls = size_class(bytes);
+  if (!c.fence_sealed.empty()) release_completed_batches();
   auto& fl = c.pool[cls];
+  if (fl.empty() && !c.fence_open.empty()) {  // (lazily: one set of events per batch of frees, not per free)
+    seal_open_batch();
+    release_completed_batches();
+  }
   if (!fl.empty()) {
     void* p = fl.back();
     fl.pop_back();
@@ -55,14 +63,70 @@ void* pool_alloc(uint64_t bytes, uint64_t* got) {
   return p;
 }
 
+// With the library's side streams in use (stage A x2, stage C) a block freed by the host may still be read or written
+// by a kernel queued on ANOTHER stream than the one that will reuse it — the free list knows nothing about streams, and
+// a handle destructor (an exception in the middle of a pipelined run, a __del__) does not synchronise.  Such blocks
+// are fenced: frees are collected into a batch; when an allocation finds its free list empty, the open batch is
+// SEALED — one event recorded on every stream of the library — and sealed batches whose events have all completed
+// hand their blocks to the free lists.  With only the main stream in use nothing is fenced (stream order is enough).
+static hipEvent_t fence_event() {
+  Context& c = ctx();
+  if (!c.fence_events.empty()) { hipEvent_t e = c.fence_events.back(); c.fence_events.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+
+static void seal_open_batch() {
+  Context& c = ctx();
+  if (c.fence_open.empty()) return;
+  Context::FenceBatch b;
+  b.blocks.swap(c.fence_open);
+  hipStream_t streams[4] = {c.stream, c.stream_a, c.stream_a2, c.stream_c};
+  for (hipStream_t st : streams) {
+    if (!st) continue;
+    hipEvent_t e = fence_event();
+    if (!e || hipEventRecord(e, st) != hipSuccess) {  // cannot fence: wait for everything instead
+      (void)hipDeviceSynchronize();
+      if (e) c.fence_events.push_back(e);
+      continue;
+    }
+    b.events.push_back(e);
+  }
+  c.fence_sealed.push_back(std::move(b));
+}
+
+static void release_completed_batches() {
+  Context& c = ctx();
+  for (size_t i = 0; i < c.fence_sealed.size();) {
+    Context::FenceBatch& b = c.fence_sealed[i];
+    bool done = true;
+    for (hipEvent_t e : b.events)
+      if (hipEventQuery(e) != hipSuccess) { done = false; break; }
+    if (!done) { ++i; continue; }
+    for (auto& blk : b.blocks) c.pool[blk.second].push_back(blk.first);
+    for (hipEvent_t e : b.events) c.fence_events.push_back(e);
+    c.fence_sealed.erase(c.fence_sealed.begin() + (long)i);
+  }
+}
+
 void pool_free(void* p, uint64_t bytes) {
   Context& c = ctx();
   if (!c.ready) { (void)hipFree(p); return; }
-  c.pool[bytes].push_back(p);
+  if (c.a_side || c.c_side) c.fence_open.emplace_back(p, bytes);  // side streams in use: reusable once they have passed
+  else c.pool[bytes].push_back(p);
 }
 
 void pool_release_all() {
   Context& c = ctx();
+  if (!c.fence_open.empty() || !c.fence_sealed.empty()) (void)hipDeviceSynchronize();
+  for (auto& blk : c.fence_open) (void)hipFree(blk.first);
+  c.fence_open.clear();
+  for (auto& b : c.fence_sealed) {
+    for (auto& blk : b.blocks) (void)hipFree(blk.first);
+    for (hipEvent_t e : b.events) c.fence_events.push_back(e);
+  }
+  c.fence_sealed.clear();
   for (auto& kv : c.pool)
     for (void* p : kv.second) (void)hipFree(p);
   c.pool.clear();
@@ -195,6 +259,7 @@ void mg_shutdown(void) {
   if (c.stream_a) { (void)hipStreamSynchronize(c.stream_a); (void)hipStreamDestroy(c.stream_a); }
   if (c.stream_a2) { (void)hipStreamSynchronize(c.stream_a2); (void)hipStreamDestroy(c.stream_a2); }
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c.fence_events) (void)hipEventDestroy(e);
   if (c.ev_c) (void)hipEventDestroy(c.ev_c);
   mg::prof_collect();
   for (hipEvent_t e : c.prof_pool) (void)hipEventDestroy(e);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/metalign_hip.h"
@@ -62,6 +63,11 @@ struct Context {
   // steady-state calls do not hipMalloc/hipFree (hipFree synchronises the device)
   std::map<std::string, DevBuf*> scratch;
   std::map<uint64_t, std::vector<void*>> pool;  // size class -> free blocks
+  // blocks freed while side streams were in use wait here until every stream has passed the point of the free
+  struct FenceBatch { std::vector<std::pair<void*, uint64_t>> blocks; std::vector<hipEvent_t> events; };
+  std::vector<std::pair<void*, uint64_t>> fence_open;
+  std::vector<FenceBatch> fence_sealed;
+  std::vector<hipEvent_t> fence_events;
   uint64_t* pinned = nullptr;
   // landing words of sketches whose finalisation is deferred (mg_sketch_reads_dev_async): kPendSlots x 8 words
   uint64_t* pend_pinned = nullptr;
