@@ -222,10 +222,10 @@ struct mg_sketch {
 
 namespace mg {
 // ---- the fused multi-k stage-A launch (mg_sketch_multi.hip) ----
+struct Slot;          // mg_sketch_dev.h: one 16-byte slot of the counting table
 struct MultiKTable {  // one k of the launch: its threshold, counting table (already zeroed), counters and pre-filter
   uint64_t hmax;
-  uint64_t* keys;
-  uint32_t* cnts;
+  Slot* tab;
   unsigned long long* counters;
   unsigned shift;
   const mg_filter* filter;

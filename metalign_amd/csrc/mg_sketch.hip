@@ -39,10 +39,10 @@ namespace mg {
 // insert-or-increment per candidate in the partitioned counting table (table mode, shift < 64).
 struct CandSink {
   uint64_t* lds;      // this wave's kCandBuf entries
-  uint64_t* out;      // list mode: candidate list; table mode: keys [nbuckets][kBucketSlots], 0 = empty, else hash+1
+  uint64_t* out;      // list mode: candidate list
   uint64_t cap;       // list mode: entries available in `out`
   unsigned long long* counters;  // [0] candidates produced, [1] k-mers hashed, [2] table overflows
-  uint32_t* slot_cnt;            // table mode: occurrence count per slot
+  Slot* tab;                     // table mode: [nbuckets][kBucketSlots] slots (key = hash + 1, 0 = empty; counter)
   unsigned shift;                // bucket = hash >> shift; 64 = list mode (read sketches start at hash 0)
   const uint32_t* fbits;         // optional membership pre-filter (mg_filter): bit (h & fmask) set <=> h may be in the table
   uint64_t fmask;
@@ -82,11 +82,28 @@ struct CandSink {
         fw[j] = 0xffffffffu;
         if (fbits && hh[j] != kReservedHash) fw[j] = fbits[(hh[j] & fmask) >> 5];
       }
+      // ... then every surviving candidate's home slot, key and counter in ONE 16-byte access, again all in flight
+      // together (one candidate after the other — key, then counter, then the next candidate — a flush was nine
+      // dependent round trips to memory; now it is two, and a tenth of the kernel's time went with them)
+      uint4 sv[kCandBuf / 64];
+      bool go[kCandBuf / 64];
 #pragma unroll
       for (int j = 0; j < kCandBuf / 64; ++j) {
-        if (hh[j] == kReservedHash || !((fw[j] >> (hh[j] & 31u)) & 1u)) continue;
+        go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+        sv[j] = make_uint4(0, 0, 0, 0);
+        if (go[j]) sv[j] = *reinterpret_cast<const uint4*>(tab + (hh[j] >> shift) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1)));
+      }
+#pragma unroll
+      for (int j = 0; j < kCandBuf / 64; ++j) {
+        if (!go[j]) continue;
         ++kept;
-        if (!table_add(out, slot_cnt, hh[j] >> shift, hh[j], 1u, cs)) ++lost;
+        const unsigned long long v = hh[j] + 1, key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
+        if (key == v) {  // the usual case at metagenomic coverage: a repeat
+          if (!(cs && sv[j].z >= cs))
+            atomicAdd(&tab[(hh[j] >> shift) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1))].cnt, 1u);
+        } else if (!table_add(tab, hh[j] >> shift, hh[j], 1u, cs, key == 0ull ? 0u : 1u)) {  // empty: claim it; taken: probe on
+          ++lost;
+        }
       }
       // (counted per lane and added to counters[0] once, at the end of the kernel: an atomic per flush on that one
       // address is what bounded the kernel when the threshold filters little — 1.3 M flushes per 10 M reads at ~24 ns)
@@ -199,14 +216,14 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
                                                          const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                          uint64_t hmax, uint64_t* __restrict__ cand, uint64_t cand_cap,
                                                          unsigned long long* __restrict__ counters,
-                                                         uint32_t* __restrict__ slot_cnt, unsigned bucket_shift,
+                                                         Slot* __restrict__ tab, unsigned bucket_shift,
                                                          unsigned stage_bytes, const uint32_t* __restrict__ fbits,
                                                          uint64_t fmask, uint32_t cs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
-  CandSink sink{cbuf, cand, cand_cap, counters, slot_cnt, bucket_shift, fbits, fmask, cs, 0};
+  CandSink sink{cbuf, cand, cand_cap, counters, tab, bucket_shift, fbits, fmask, cs, 0};
   uint64_t kmers = 0;
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -344,8 +361,8 @@ static unsigned bit_length(uint64_t v) {
 
 // Merge step of the multi-GPU exchange: add (hash,count) pairs into the table; bucket = (hash - lo) >> shift.
 __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const uint32_t* __restrict__ counts, uint64_t n,
-                                     uint64_t lo, unsigned shift, uint64_t nbuckets, uint64_t* __restrict__ keys,
-                                     uint32_t* __restrict__ cnts, unsigned long long* __restrict__ counters, uint32_t cs) {
+                                     uint64_t lo, unsigned shift, uint64_t nbuckets, Slot* __restrict__ tab,
+                                     unsigned long long* __restrict__ counters, uint32_t cs) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint32_t lost = 0;
@@ -353,7 +370,7 @@ __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const 
     const uint64_t h = hashes[i];
     uint64_t b = (h - lo) >> shift;
     if (h < lo || b >= nbuckets) { ++lost; continue; }  // outside the declared range: caller falls back
-    if (!table_add(keys, cnts, b, h, counts[i], cs)) ++lost;
+    if (!table_add(tab, b, h, counts[i], cs)) ++lost;
   }
   if (lost) atomicAdd(counters + 2, (unsigned long long)lost);
 }
@@ -364,8 +381,7 @@ __global__ void k_table_insert_pairs(const uint64_t* __restrict__ hashes, const 
 // bucket's first nuniq[b] slots then hold its hashes (no longer hash + 1) ascending, with their counts.  (The whole
 // bucket is in registers / LDS before the first store, and a bucket belongs to one wavefront; separate staging
 // rows cost 12 B per slot, 13 GB for a dense 400 M-candidate table.)  Every hash of the bucket is distinct already.
-__global__ __launch_bounds__(256) void k_bucket_sort(uint64_t* tab_keys, uint32_t* tab_cnt, uint64_t nbuckets,
-                                                     uint32_t* __restrict__ nuniq, uint32_t cs) {
+__global__ __launch_bounds__(256) void k_bucket_sort(Slot* tab, uint64_t nbuckets, uint32_t* __restrict__ nuniq, uint32_t cs) {
   __shared__ uint64_t s_keys[4][kBucketSlots];
   __shared__ uint32_t s_cnt[4][kBucketSlots];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -380,8 +396,9 @@ __global__ __launch_bounds__(256) void k_bucket_sort(uint64_t* tab_keys, uint32_
     uint32_t vc[kBucketSlots / 64];
 #pragma unroll
     for (uint32_t c = 0; c < kBucketSlots / 64; ++c) {
-      v[c] = tab_keys[base + c * 64 + lane];
-      vc[c] = tab_cnt[base + c * 64 + lane];
+      const uint4 raw = *reinterpret_cast<const uint4*>(tab + base + c * 64 + lane);
+      v[c] = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+      vc[c] = raw.z;
     }
 #pragma unroll
     for (uint32_t c = 0; c < kBucketSlots / 64; ++c) {
@@ -415,7 +432,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(uint64_t* tab_keys, uint32_
         wave_lds_sync();
       }
     }
-    for (uint32_t i = lane; i < n; i += 64) { tab_keys[base + i] = keys[i]; tab_cnt[base + i] = cnt[i]; }
+    for (uint32_t i = lane; i < n; i += 64) { tab[base + i].key = keys[i]; tab[base + i].cnt = cnt[i]; }
     wave_lds_sync();
   }
 }
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(const uint32_t* __restrict
 }
 
 // Pack every bucket's distinct hashes / counts at its offset: the concatenation is ascending.
-__global__ __launch_bounds__(256) void k_bucket_compact(const uint64_t* __restrict__ slab, const uint32_t* __restrict__ cnts,
+__global__ __launch_bounds__(256) void k_bucket_compact(const Slot* __restrict__ tab,
                                                         const uint32_t* __restrict__ nuniq, const uint64_t* __restrict__ offs,
                                                         uint64_t nbuckets, uint64_t* __restrict__ out_hashes,
                                                         uint32_t* __restrict__ out_counts, uint64_t out_cap) {
@@ -483,8 +500,9 @@ __global__ __launch_bounds__(256) void k_bucket_compact(const uint64_t* __restri
     const uint32_t n = nuniq[b];
     const uint64_t o = offs[b];
     for (uint32_t i = lane; i < n && o + i < out_cap; i += 64) {  // out_cap: see the size check on the host
-      out_hashes[o + i] = slab[b * kBucketSlots + i];
-      out_counts[o + i] = cnts[b * kBucketSlots + i];
+      const uint4 raw = *reinterpret_cast<const uint4*>(tab + b * kBucketSlots + i);
+      out_hashes[o + i] = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+      out_counts[o + i] = raw.z;
     }
   }
 }
@@ -570,7 +588,7 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
 
 template <int K>
 static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t hmax,
-                               uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, uint32_t* d_slot_cnt,
+                               uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, Slot* d_tab,
                                unsigned bucket_shift, unsigned stage_bytes, const mg_filter* filter = nullptr) {
   Context& c = ctx();
   size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
@@ -588,7 +606,7 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
-                     nreads, hmax, d_cand, cap, d_counters, d_slot_cnt, bucket_shift, stage_bytes,
+                     nreads, hmax, d_cand, cap, d_counters, d_tab, bucket_shift, stage_bytes,
                      filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr, filter ? filter->mask : 0ull,
                      c.count_sat);
   MG_HIP(hipGetLastError());
@@ -600,8 +618,7 @@ struct TablePlan {
   uint64_t lo = 0;       // bucket = (hash - lo) >> shift
   unsigned shift = 0;
   uint64_t nbuckets = 0, slots = 0;
-  uint64_t* keys = nullptr;   // [slots], 0 = empty, else hash + 1
-  uint32_t* cnts = nullptr;   // [slots]
+  Slot* tab = nullptr;        // [slots]: key = hash + 1 (0 = empty) and its counter
   uint32_t* nuniq = nullptr;
   uint64_t* offs = nullptr;
 };
@@ -623,16 +640,15 @@ static bool plan_table(uint64_t lo, uint64_t hi, double distinct_est, TablePlan&
   return true;
 }
 
-// The table proper of k number `ki` of a fused launch (0 for everybody else): [keys u64 x slots | counts u32 x slots |
+// The table proper of k number `ki` of a fused launch (0 for everybody else): [16-byte slots x slots |
 // 4 counter words], zeroed in one memset.
 static int alloc_table_core(TablePlan& tp, unsigned long long** d_counters, int ki) {
   char name[24];
   snprintf(name, sizeof(name), ki ? "sk_table#%d" : "sk_table", ki);
-  const uint64_t tab_bytes = ((tp.slots * 12 + 7) / 8) * 8;
+  const uint64_t tab_bytes = tp.slots * sizeof(Slot);
   uint8_t* d_tab = (uint8_t*)scratch(name, tab_bytes + 4 * sizeof(unsigned long long));
   if (!d_tab) return MG_ERR_NOMEM;
-  tp.keys = reinterpret_cast<uint64_t*>(d_tab);
-  tp.cnts = reinterpret_cast<uint32_t*>(d_tab + tp.slots * 8);
+  tp.tab = reinterpret_cast<Slot*>(d_tab);
   if (d_counters) *d_counters = reinterpret_cast<unsigned long long*>(d_tab + tab_bytes);
   ProfScope ps("table_clear");
   MG_HIP(hipMemsetAsync(d_tab, 0, tab_bytes + (d_counters ? 4 * sizeof(unsigned long long) : 0), ctx().stream));
@@ -660,8 +676,8 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint
   if (cap > tp.slots) cap = tp.slots;  // a sketch cannot outgrow the table
   {
     ProfScope ps("bucket_sort");
-    hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, tp.keys,
-                       tp.cnts, tp.nbuckets, tp.nuniq, c.count_sat);
+    hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, tp.tab,
+                       tp.nbuckets, tp.nuniq, c.count_sat);
     MG_HIP(hipGetLastError());
   }
   MG_TRY(sk->hashes.alloc((cap + 1) * sizeof(uint64_t)));
@@ -670,7 +686,7 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint
     ProfScope ps("bucket_pack");
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, tp.nuniq, tp.nbuckets, tp.offs, d_meta);
     hipLaunchKernelGGL(k_bucket_compact, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
-                       tp.keys, tp.cnts, tp.nuniq, tp.offs, tp.nbuckets, sk->hashes.as<uint64_t>(),
+                       tp.tab, tp.nuniq, tp.offs, tp.nbuckets, sk->hashes.as<uint64_t>(),
                        sk->counts.as<uint32_t>(), cap);
     MG_HIP(hipGetLastError());
   }
@@ -948,7 +964,7 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     MG_TRY(alloc_table(kp.tp, &t_counters));
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, kp.tp.keys, 0, t_counters, kp.tp.cnts, kp.tp.shift,
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, nullptr, 0, t_counters, kp.tp.tab, kp.tp.shift,
                                   rp.stage, filter);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
@@ -999,7 +1015,7 @@ static int sketch_reads_multi_async(const uint8_t* d_bases, const uint64_t* d_of
   unsigned long long* t_counters[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < nk; ++i) {
     MG_TRY(alloc_table_core(kp[i].tp, &t_counters[i], i));
-    tabs[i] = MultiKTable{hm[i], kp[i].tp.keys, kp[i].tp.cnts, t_counters[i], kp[i].tp.shift, filters ? filters[i] : nullptr};
+    tabs[i] = MultiKTable{hm[i], kp[i].tp.tab, t_counters[i], kp[i].tp.shift, filters ? filters[i] : nullptr};
   }
   MG_TRY(launch_sketch_reads_multi(ks, nk, d_bases, d_offsets, nreads, tabs, rp.stage));
   for (int i = 0; i < nk; ++i) {
@@ -1145,7 +1161,7 @@ int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint
     {
       ProfScope ps("merge_insert");
       hipLaunchKernelGGL(k_table_insert_pairs, dim3(grid_for(n, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st,
-                         d_hashes, d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, d_counters, ctx().count_sat);
+                         d_hashes, d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.tab, d_counters, ctx().count_sat);
       MG_HIP(hipGetLastError());
     }
     uint64_t h_counters[3] = {0, 0, 0};
@@ -1182,7 +1198,7 @@ int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts
   {
     ProfScope ps("merge_insert");
     hipLaunchKernelGGL(k_table_insert_pairs, dim3(grid_for(n, 256, (unsigned)cc.num_cus * 8)), dim3(256), 0, st, d_hashes,
-                       d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.keys, tp.cnts, t_counters, cc.count_sat);
+                       d_counts, n, tp.lo, tp.shift, tp.nbuckets, tp.tab, t_counters, cc.count_sat);
     MG_HIP(hipGetLastError());
   }
   const unsigned slot = cc.pend_next++ % Context::kPendSlots;

@@ -36,28 +36,38 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
 constexpr uint32_t kBucketTarget = 96;  // expected distinct hashes per bucket (load factor <= 3/8)
 
-// Insert-or-add into the partitioned counting table: keys[bucket][slot] holds hash+1 (0 = empty).
+// One slot of the partitioned counting table: key = hash + 1 (0 = empty) and its occurrence counter side by side, so
+// that ONE 16-byte access answers both "is it this key" and "is its counter saturated" (round 1 kept keys and counters
+// in two arrays: two dependent random accesses per candidate, each a 128-byte line out of HBM).
+struct __attribute__((aligned(16))) Slot {
+  unsigned long long key;
+  uint32_t cnt;
+  uint32_t pad;
+};
+static_assert(sizeof(Slot) == 16, "slots are loaded with one 16-byte access");
+
+// Insert-or-add into the partitioned counting table: tab[bucket][slot].key holds hash+1 (0 = empty).
 // Returns false when the bucket has no free slot.
 // cs > 0: counters SATURATE at cs (kmc -cs3, scripts/select_db.py:50): a counter that is seen at cs or above is
 // left alone (counters only grow, so a stale look can only cost an unnecessary add), and whoever reads the table
 // afterwards takes min(counter, cs).  At 50x coverage nearly every candidate is a repeat of a key whose counter is
-// saturated already: it costs two reads and no memory-side read-modify-write.
-__device__ __forceinline__ bool table_add(uint64_t* __restrict__ keys, uint32_t* __restrict__ cnts, uint64_t bucket,
-                                          uint64_t h, uint32_t amount, uint32_t cs) {
+// saturated already: it costs one read and no memory-side read-modify-write.
+__device__ __forceinline__ bool table_add(Slot* __restrict__ tab, uint64_t bucket, uint64_t h, uint32_t amount, uint32_t cs,
+                                          uint32_t first_probe = 0) {
   const unsigned long long v = h + 1;  // hashes are <= 2^64-2, so v is never the empty marker 0
   const uint64_t base = bucket * kBucketSlots;
-  uint32_t p = (uint32_t)h & (kBucketSlots - 1);  // low bits: independent of the bucket id
-  for (uint32_t t = 0; t < kBucketSlots; ++t) {
+  uint32_t p = ((uint32_t)h + first_probe) & (kBucketSlots - 1);  // low bits: independent of the bucket id
+  for (uint32_t t = first_probe; t < kBucketSlots; ++t) {
     // A plain look first: a slot's key never changes once set, so a (possibly stale, per-XCD cached) read can only
     // err towards "empty", and then the CAS decides.  At 50x coverage most candidates are repeats of a key that is
-    // already there: they cost this read and one add instead of a returning CAS and an add.
-    unsigned long long old = keys[base + p];
+    // already there: they cost this read and at most one add instead of a returning CAS and an add.
+    const uint4 raw = *reinterpret_cast<const uint4*>(tab + base + p);
+    unsigned long long old = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
     const bool seen = old == v;
-    if (old == 0ull) old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + base + p), 0ull, v);
+    if (old == 0ull) old = atomicCAS(&tab[base + p].key, 0ull, v);
     if (old == 0ull || old == v) {
-      // (the look goes to the memory side like the atomics do: an L2 of another XCD may hold the line from before)
-      if (cs && seen && __hip_atomic_load(cnts + base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cs) return true;
-      atomicAdd(cnts + base + p, amount);
+      if (cs && seen && raw.z >= cs) return true;
+      atomicAdd(&tab[base + p].cnt, amount);
       return true;
     }
     p = (p + 1) & (kBucketSlots - 1);

@@ -22,8 +22,7 @@ constexpr int kMaxMultiK = 4;
 
 struct MultiArgs {
   uint64_t hmax[kMaxMultiK];
-  uint64_t* keys[kMaxMultiK];            // counting table of k number i: [nbuckets][kBucketSlots], 0 = empty, else hash + 1
-  uint32_t* cnts[kMaxMultiK];
+  Slot* tab[kMaxMultiK];                 // counting table of k number i: [nbuckets][kBucketSlots] slots
   unsigned long long* counters[kMaxMultiK];  // [0] candidates produced, [1] k-mers hashed, [2] table overflows
   const uint32_t* fbits[kMaxMultiK];     // optional membership pre-filter of k number i
   uint64_t fmask[kMaxMultiK];
@@ -56,15 +55,29 @@ struct MultiSink {
         if (fb) fw[j] = fb[(hh[j] & A->fmask[kk[j]]) >> 5];
       }
     }
+    // ... then every surviving candidate's home slot (key and counter in one 16-byte access), again all in flight
+    Slot* home[kCandBuf / 64];
+    uint4 sv[kCandBuf / 64];
+    bool go[kCandBuf / 64];
 #pragma unroll
     for (int j = 0; j < kCandBuf / 64; ++j) {
-      const bool go = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+      go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+      home[j] = A->tab[kk[j]] + (hh[j] >> A->shift[kk[j]]) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1));
+      sv[j] = make_uint4(0, 0, 0, 0);
+      if (go[j]) sv[j] = *reinterpret_cast<const uint4*>(home[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kCandBuf / 64; ++j) {
       const uint32_t ki = kk[j];
 #pragma unroll
-      for (int q = 0; q < kMaxMultiK; ++q) produced[q] += (unsigned)__popcll(__ballot(go && ki == (uint32_t)q));
-      if (!go) continue;
-      if (!table_add(A->keys[ki], A->cnts[ki], hh[j] >> A->shift[ki], hh[j], 1u, A->cs))
+      for (int q = 0; q < kMaxMultiK; ++q) produced[q] += (unsigned)__popcll(__ballot(go[j] && ki == (uint32_t)q));
+      if (!go[j]) continue;
+      const unsigned long long v = hh[j] + 1, key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
+      if (key == v) {  // a repeat: nothing to do once its counter is saturated
+        if (!(A->cs && sv[j].z >= A->cs)) atomicAdd(&home[j]->cnt, 1u);
+      } else if (!table_add(A->tab[ki], hh[j] >> A->shift[ki], hh[j], 1u, A->cs, key == 0ull ? 0u : 1u)) {
         atomicAdd(A->counters[ki] + 2, 1ull);
+      }
     }
     wave_lds_sync();
     n = 0;
@@ -273,7 +286,7 @@ int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, con
   if (nk < 1 || nk > kMaxMultiK) return fail(MG_ERR_ARG, "between 1 and %d k per fused launch", kMaxMultiK);
   MultiArgs a{};
   for (int i = 0; i < nk; ++i) {
-    a.hmax[i] = tabs[i].hmax; a.keys[i] = tabs[i].keys; a.cnts[i] = tabs[i].cnts; a.counters[i] = tabs[i].counters;
+    a.hmax[i] = tabs[i].hmax; a.tab[i] = tabs[i].tab; a.counters[i] = tabs[i].counters;
     a.fbits[i] = tabs[i].filter ? tabs[i].filter->bits.as<uint32_t>() : nullptr;
     a.fmask[i] = tabs[i].filter ? tabs[i].filter->mask : 0ull;
     a.shift[i] = tabs[i].shift;
