@@ -1,6 +1,6 @@
 """Stage A alone on configs[2]'s reads: the fused launch with the real thresholds / filters, and with thresholds that let
 nothing through (no candidate handling at all: what the kernel costs as pure hashing).
-python tools/k1_probe.py [nreads] [ngenomes] [genome_len]"""
+python tools/k1_probe.py [nreads] [ngenomes] [genome_len] [ks, comma separated]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from metalign_amd._hip import Hip
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000
-ks = [21, 31, 51]
+ks = [int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [21, 31, 51]
 hip = Hip.get(0)
 gb, go = synth.make_genomes(G, L)
 rb, ro, _ = synth.make_reads(gb, go, R, npresent=max(50, G // 20))
@@ -29,4 +29,4 @@ def run(hm, fl, label):
     print("%-46s stage A %.3f ms per pass (%d launch(es) per pass), sketch sizes %s" % (label, t / 2, c // 2, n), flush=True)
 run(hmaxs, filts, "thresholds + filters of the table:")
 run(hmaxs, None, "thresholds, no filter:")
-run([int(3e-5 * 2 ** 64)] * 3, None, "thresholds that pass ~45 k k-mers per k (pure hashing):")
+run([int(3e-5 * 2 ** 64)] * len(ks), None, "thresholds that pass ~45 k k-mers per k (pure hashing):")
