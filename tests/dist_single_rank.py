@@ -28,30 +28,42 @@ gb, go = synth.make_genomes(60, 20000)
 rb, ro, src = synth.make_reads(gb, go, 80000, npresent=9)
 recs = synth.make_alignment_records(src + 1, 61)
 ref2tax = np.arange(61, dtype=np.uint32)
-k, n = 21, (1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200)  # forced-overflow run: enough distinct hashes to fill a minimum-size table
-dbh, dbo = hip.sketch_genomes(gb, go, k, n)
-job = ShardJob(hip, dist, 0, 1, k=k, always_exchange=True)
-job.load(rb, ro, recs, ref2tax, dbh, dbo)
-outs = [job.step(want_multimapped=True), job.run(4, want_multimapped=True), job.step(want_multimapped=True)]
-oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
-nfiltered = len(oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])  # the job sketches through the table's filter
-ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
+n = 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200  # forced-overflow run: enough distinct hashes to fill a minimum-size table
 want = oracle.profile_assign(recs, ref2tax, 61, 0.5)
-for idx, got in enumerate(outs):
-    if not (np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)):
-        bad = np.nonzero(got["hits"] != ohits)[0]
-        print("MISMATCH in output", idx, "hits differ at", len(bad), "genomes; sizes equal:", np.array_equal(got["sizes"], osizes),
-              "sketch", got["sketch_size"], nfiltered, "sample", [(int(g), int(got["hits"][g]), int(ohits[g])) for g in bad[:6]])
-    assert np.array_equal(got["hits"], ohits) and np.array_equal(got["sizes"], osizes)
-    assert got["sketch_size"] == nfiltered, (got["sketch_size"], nfiltered)
-    for key in ("count", "bases", "first_seen"):
-        assert np.array_equal(got[key], want[key]), key
-    assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
-    off, tax, hl, rd = got["multimapped"]
-    assert np.array_equal(off, want["mm_offsets"]) and np.array_equal(tax, want["mm_tax"])
-    assert np.array_equal(hl, want["mm_hitlen"]) and np.array_equal(rd, want["mm_read"])
-if os.environ.get("MG_DEBUG_DISTINCT_HINT"):  # the forced-overflow run must have taken the repeat-the-all-gather path
-    assert getattr(job, "words_redone", 0) >= 4, getattr(job, "words_redone", 0)
+# one k given bare (the single-k surface), then the k set of BASELINE configs[2] (the fused stage-A launch): every k's
+# words in the one all-gather, its slices in the all-to-all round, its hits / sizes in the one all-reduce
+for kspec in (21, [21, 31, 51]):
+    ks = [kspec] if np.isscalar(kspec) else kspec
+    tabs = [hip.sketch_genomes(gb, go, k, n) for k in ks]
+    job = ShardJob(hip, dist, 0, 1, k=kspec, always_exchange=True)
+    if np.isscalar(kspec):
+        job.load(rb, ro, recs, ref2tax, tabs[0][0], tabs[0][1])
+    else:
+        job.load(rb, ro, recs, ref2tax, [t[0] for t in tabs], [t[1] for t in tabs])
+    outs = [job.step(want_multimapped=True), job.run(4, want_multimapped=True), job.step(want_multimapped=True)]
+    for idx, got in enumerate(outs):
+        assert got["hits_k"].shape == (len(ks), 60)
+        for ki, k in enumerate(ks):
+            dbh, dbo = tabs[ki]
+            oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
+            nfiltered = len(oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])  # the job sketches through the table's filter
+            ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
+            if not (np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes)):
+                bad = np.nonzero(got["hits_k"][ki] != ohits)[0]
+                print("MISMATCH in output", idx, "k", k, "hits differ at", len(bad), "genomes; sizes equal:",
+                      np.array_equal(got["sizes_k"][ki], osizes), "sketch", got["sketch_sizes"][ki], nfiltered,
+                      "sample", [(int(g), int(got["hits_k"][ki][g]), int(ohits[g])) for g in bad[:6]])
+            assert np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes)
+            assert got["sketch_sizes"][ki] == nfiltered, (k, got["sketch_sizes"][ki], nfiltered)
+        assert np.array_equal(got["hits"], got["hits_k"][-1])
+        for key in ("count", "bases", "first_seen"):
+            assert np.array_equal(got[key], want[key]), key
+        assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
+        off, tax, hl, rd = got["multimapped"]
+        assert np.array_equal(off, want["mm_offsets"]) and np.array_equal(tax, want["mm_tax"])
+        assert np.array_equal(hl, want["mm_hitlen"]) and np.array_equal(rd, want["mm_read"])
+    if os.environ.get("MG_DEBUG_DISTINCT_HINT"):  # the forced-overflow run must have taken the repeat-the-all-gather path
+        assert getattr(job, "words_redone", 0) >= 4, getattr(job, "words_redone", 0)
 dist.barrier()
 dist.destroy_process_group()
 print("dist-single-rank ok")

@@ -117,6 +117,16 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
     strains = [ln.split("\t") for ln in text.splitlines() if "\tstrain\t" in ln]
     assert {s[0] for s in strains} >= {"1001.2.1", "1004.1.1"}
     assert abs(sum(float(s[4]) for s in strains) - 100.0) < 1.0
+    # the same table as a version-1 directory (genome-major files, no stored filter: inverted on the host when opened,
+    # the filter built from the hashes): select_db writes the same CSV
+    from metalign_amd import select_db
+    v1 = tmp_path / "table_v1"
+    formats.write_sketch_table_v1(str(v1), names, ks, n, {k: table.arrays(k) for k in ks})
+    assert formats.SketchTable(str(v1)).version == 1 and table.version == 2
+    tmp1 = tmp_path / "tmp_v1"
+    args = select_db.select_parseargs([str(fq), str(data), "--temp_dir", str(tmp1), "--keep_temp_files", "--sketch_table", str(v1)])
+    select_db.select_main(args)
+    assert (tmp1 / "cmash_query_results.csv").read_text().splitlines() == csv
 
 
 def test_exchange_path_on_one_gpu_under_rccl():
