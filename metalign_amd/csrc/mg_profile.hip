@@ -443,7 +443,7 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 // something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
 // had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
 // pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
-constexpr uint32_t kHashSlots = 2048, kHashProbe = 16, kFlushTiles = 256;  // (a miss costs kHashProbe LDS reads before the private bins take it; per 125M records over 10 001 uniform taxa: 32 probes 7.9 ms, 8: 5.6, 2: 5.1, but below 16 a sample of 500 hot taxa starts to overflow and pays the reduction: 0.52 -> 0.56 ms per 12.5M)
+constexpr uint32_t kHashSlots = 1024, kHashProbe = 16, kFlushTiles = 256;  // (a miss costs kHashProbe LDS reads before the private bins take it; per 125M records over 10 001 uniform taxa: 32 probes 7.9 ms, 8: 5.6, 2: 5.1, but below 16 a sample of 500 hot taxa starts to overflow and pays the reduction: 0.52 -> 0.56 ms per 12.5M)
 constexpr uint32_t kBinLenLimit = 1u << 20;
 constexpr int kBinCountShift = 40;
 
@@ -694,7 +694,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           uint32_t bin = tax;
           bool in_lds = A.use_lds_hist == 1;
           if (A.use_lds_hist == 2) {
-            uint32_t p = (tax * 2654435761u) >> 21;  // 11 bits: kHashSlots
+            uint32_t p = (tax * 2654435761u) >> 22;  // 10 bits: kHashSlots
             for (uint32_t step = 0; step < kHashProbe; ++step) {
               uint32_t old = h_key[p];  // keys never change once set: a plain look settles the common case
               if (old == 0xffffffffu) old = atomicCAS(&h_key[p], 0xffffffffu, tax);
