@@ -192,6 +192,28 @@ def test_multi_k_sketch_matches_oracle_per_k(hip, oracle_lib, ks, kind, monkeypa
         assert np.array_equal(h, oh) and np.array_equal(c, oc), k
 
 
+@pytest.mark.parametrize("ks", [(21, 31, 51), (30, 40, 50, 60)])
+def test_multi_k_sketch_long_reads_take_the_hbm_walk(hip, oracle_lib, ks):
+    """Tiles that do not fit the LDS stage (contigs instead of reads) are walked straight out of HBM by the fused kernel
+    too; mixed with ordinary reads, N runs and lower case."""
+    rng = np.random.default_rng(len(ks))
+    lens = np.concatenate([rng.integers(30_000, 90_000, size=5), rng.integers(0, 200, size=300), [70_000]])
+    rng.shuffle(lens)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    bases = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(offsets[-1])).astype(np.uint8)
+    bases[rng.integers(0, bases.size, size=bases.size // 400)] = ord("N")
+    low = rng.random(bases.size) < 0.05
+    bases[low] |= 0x20
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    hmaxs = [int(0.25 * 2 ** 64)] * len(ks)
+    sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, len(lens), list(ks), hmaxs, 0, None)
+    for i, k in enumerate(ks):
+        h, c = sks[i].download()
+        oh, oc, _, oseen = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmaxs[i])
+        assert np.array_equal(h, oh) and np.array_equal(c, oc) and sks[i].kmers_seen == oseen, k
+
+
 def test_sketch_merge_equals_single_pass(hip, oracle_lib):
     """Two read shards sketched separately and merged == one pass over all reads (the multi-GPU merge)."""
     rng = np.random.default_rng(77)
