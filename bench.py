@@ -212,6 +212,27 @@ def committed_profile(name, cfg):
     return best
 
 
+def committed_run(name, cfg):
+    """value / ms_per_step of a committed bench line (profiles/<round>/<name>, newest round) if it ran this per-GPU
+    workload; else None."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        fn = os.path.join(pdir, rnd, name)
+        if not os.path.isfile(fn):
+            continue
+        with open(fn) as fh:
+            d = json.loads(fh.read().strip().splitlines()[-1])
+        wl = d.get("config", {}).get("workload", "")
+        if ("%d synthetic 150bp reads/GPU vs %d-genome" % (cfg["reads"], cfg["genomes"])) in wl and ("k in %s" % cfg["ks"]) in wl:
+            best = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"],
+                    "source": "profiles/%s/%s" % (rnd, name),
+                    "note": "bench.py --config %d at world size 1 with the exchange path forced (MG_FORCE_DIST=1): the "
+                            "denominator for weak-scaling efficiency of this workload; bench.py's DEFAULT at N = 1 is "
+                            "configs[2], a different workload" % cfg["config"]}
+    return best
+
+
 def secondary_config1(hip, args):
     """configs[1] (1M reads, 1k genomes, k = 21) in the same process: reads/s of the pipelined passes."""
     cfg = dict(PRESETS[1], config=1)
@@ -367,6 +388,12 @@ def main():
             "sanity": {"top_genomes_recovered": out.get("top_ok"), "tot_rds": out.get("tot_rds"),
                        "sketch_sizes": out.get("sketch_sizes")},
         }
+        if world > 1:
+            # the default workload differs between N = 1 (configs[2]) and N > 1 (configs[3] shapes): the figure this
+            # line's per-GPU workload gives on ONE GPU (world 1, same collectives in the path), as committed
+            ref = committed_run("config3_world1_forced_dist_bench.json", cfg)
+            if ref:
+                res["same_workload_n1"] = ref
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
             res["cpu_baseline"], res["check"] = cpu_baseline_and_check(args, cfg, w, hip)
         if not args.no_secondary and world == 1 and cfg["config"] != 1:
