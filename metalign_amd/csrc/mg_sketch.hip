@@ -49,6 +49,7 @@ struct CandSink {
   uint32_t cs;        // table mode: counters saturate at cs (0 = exact)
   int n;              // entries staged (wave-uniform)
   unsigned long long produced = 0;  // table mode: this lane's candidates inserted so far
+  bool slot_first = false;          // table mode: the order of the two look-ups of a flush (wave-uniform)
 
   __device__ __forceinline__ bool passes(uint64_t h) const {
     return !fbits || ((fbits[(h & fmask) >> 5] >> (h & 31u)) & 1u);
@@ -72,32 +73,52 @@ struct CandSink {
       }
     } else {
       uint32_t lost = 0, kept = 0;
-      // this lane's candidates and their filter words first, all in flight together; then the inserts
-      uint64_t hh[kCandBuf / 64];
-      uint32_t fw[kCandBuf / 64];
+      // this lane's candidates; then — all in flight together — either their filter words and after those the home
+      // slots of the survivors, or the home slots and after those the filter words of the candidates their slot does
+      // not hold (same result either way: what is in the table has passed the filter; see MultiSink::flush in
+      // mg_sketch_multi.hip for which order a wavefront takes).  A home slot is key and counter in ONE 16-byte access
+      // (one candidate after the other — key, then counter, then the next candidate — a flush was nine dependent round
+      // trips to memory; now it is two, and a tenth of the kernel's time went with them).
+      constexpr int J = kCandBuf / 64;
+      uint64_t hh[J];
+      uint32_t fw[J];
+      uint4 sv[J];
+      bool go[J];
 #pragma unroll
-      for (int j = 0; j < kCandBuf / 64; ++j) {
+      for (int j = 0; j < J; ++j) {
         const int i = lane + 64 * j;
         hh[j] = i < n ? lds[i] : kReservedHash;
         fw[j] = 0xffffffffu;
-        if (fbits && hh[j] != kReservedHash) fw[j] = fbits[(hh[j] & fmask) >> 5];
-      }
-      // ... then every surviving candidate's home slot, key and counter in ONE 16-byte access, again all in flight
-      // together (one candidate after the other — key, then counter, then the next candidate — a flush was nine
-      // dependent round trips to memory; now it is two, and a tenth of the kernel's time went with them)
-      uint4 sv[kCandBuf / 64];
-      bool go[kCandBuf / 64];
-#pragma unroll
-      for (int j = 0; j < kCandBuf / 64; ++j) {
-        go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
         sv[j] = make_uint4(0, 0, 0, 0);
-        if (go[j]) sv[j] = *reinterpret_cast<const uint4*>(tab + (hh[j] >> shift) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1)));
       }
+      if (slot_first) {
 #pragma unroll
-      for (int j = 0; j < kCandBuf / 64; ++j) {
+        for (int j = 0; j < J; ++j)
+          if (hh[j] != kReservedHash) sv[j] = *reinterpret_cast<const uint4*>(tab + (hh[j] >> shift) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1)));
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const unsigned long long key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
+          if (fbits && hh[j] != kReservedHash && key != hh[j] + 1) fw[j] = fbits[(hh[j] & fmask) >> 5];
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+      } else {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if (fbits && hh[j] != kReservedHash) fw[j] = fbits[(hh[j] & fmask) >> 5];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+          if (go[j]) sv[j] = *reinterpret_cast<const uint4*>(tab + (hh[j] >> shift) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1)));
+        }
+      }
+      int found = 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const unsigned long long v = hh[j] + 1, key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
+        found += __popcll(__ballot(go[j] && key == v));
         if (!go[j]) continue;
         ++kept;
-        const unsigned long long v = hh[j] + 1, key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
         if (key == v) {  // the usual case at metagenomic coverage: a repeat
           if (!(cs && sv[j].z >= cs))
             atomicAdd(&tab[(hh[j] >> shift) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1))].cnt, 1u);
@@ -105,6 +126,7 @@ struct CandSink {
           ++lost;
         }
       }
+      slot_first = 2 * found > n;
       // (counted per lane and added to counters[0] once, at the end of the kernel: an atomic per flush on that one
       // address is what bounded the kernel when the threshold filters little — 1.3 M flushes per 10 M reads at ~24 ns)
       produced += kept;

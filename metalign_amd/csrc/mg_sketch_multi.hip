@@ -38,47 +38,83 @@ struct MultiSink {
   int n;             // entries staged (wave-uniform)
   unsigned long long produced[kMaxMultiK];  // candidates inserted per k by this WAVEFRONT (wave-uniform: scalar registers)
 
+  // A flush costs its candidates RANDOM accesses (one 128-byte line each): a word of the membership filter and the
+  // home slot of the counting table.  Which of the two is looked at first does not change the result — whatever is in
+  // the table has passed the filter — but it decides how many lines a candidate costs: filter first, 1 + (share that
+  // passes); slot first, 1 + (share whose home slot does not hold it yet).  A sample that covers its genomes many
+  // times over (or a dense table: BASELINE configs[3], 20 % of all k-mers are candidates) finds nearly every candidate
+  // in its home slot; a sample of mostly unknown organisms has nearly every candidate rejected by the filter.  The
+  // wavefront keeps to the order that was cheaper for its previous flush.
+  bool slot_first;  // wave-uniform
+
   __device__ __forceinline__ void flush(int lane) {
     if (n == 0) return;
     wave_lds_sync();
-    uint64_t hh[kCandBuf / 64];
-    uint32_t kk[kCandBuf / 64], fw[kCandBuf / 64];
-    // this lane's candidates and their filter words first, all in flight together; then the inserts
+    constexpr int J = kCandBuf / 64;
+    uint64_t hh[J];
+    uint32_t kk[J];
+    Slot* home[J];
+    uint4 sv[J];
+    bool go[J];
 #pragma unroll
-    for (int j = 0; j < kCandBuf / 64; ++j) {
+    for (int j = 0; j < J; ++j) {
       const int i = lane + 64 * j;
       hh[j] = i < n ? lds_h[i] : kReservedHash;
       kk[j] = i < n ? lds_k[i] : 0u;
-      fw[j] = 0xffffffffu;
-      if (hh[j] != kReservedHash) {
-        const uint32_t* fb = A->fbits[kk[j]];
-        if (fb) fw[j] = fb[(hh[j] & A->fmask[kk[j]]) >> 5];
-      }
-    }
-    // ... then every surviving candidate's home slot (key and counter in one 16-byte access), again all in flight
-    Slot* home[kCandBuf / 64];
-    uint4 sv[kCandBuf / 64];
-    bool go[kCandBuf / 64];
-#pragma unroll
-    for (int j = 0; j < kCandBuf / 64; ++j) {
-      go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
       home[j] = A->tab[kk[j]] + (hh[j] >> A->shift[kk[j]]) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1));
       sv[j] = make_uint4(0, 0, 0, 0);
-      if (go[j]) sv[j] = *reinterpret_cast<const uint4*>(home[j]);
     }
+    if (slot_first) {
+      // every candidate's home slot (key and counter in one 16-byte access), all in flight together; then the filter
+      // words of those it does not hold
 #pragma unroll
-    for (int j = 0; j < kCandBuf / 64; ++j) {
+      for (int j = 0; j < J; ++j)
+        if (hh[j] != kReservedHash) sv[j] = *reinterpret_cast<const uint4*>(home[j]);
+      uint32_t fw[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const unsigned long long key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
+        fw[j] = 0xffffffffu;
+        if (hh[j] != kReservedHash && key != hh[j] + 1) {
+          const uint32_t* fb = A->fbits[kk[j]];
+          if (fb) fw[j] = fb[(hh[j] & A->fmask[kk[j]]) >> 5];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+    } else {
+      // every candidate's filter word, all in flight together; then the home slots of the survivors
+      uint32_t fw[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        fw[j] = 0xffffffffu;
+        if (hh[j] != kReservedHash) {
+          const uint32_t* fb = A->fbits[kk[j]];
+          if (fb) fw[j] = fb[(hh[j] & A->fmask[kk[j]]) >> 5];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        go[j] = hh[j] != kReservedHash && ((fw[j] >> (hh[j] & 31u)) & 1u);
+        if (go[j]) sv[j] = *reinterpret_cast<const uint4*>(home[j]);
+      }
+    }
+    int found = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
       const uint32_t ki = kk[j];
 #pragma unroll
       for (int q = 0; q < kMaxMultiK; ++q) produced[q] += (unsigned)__popcll(__ballot(go[j] && ki == (uint32_t)q));
-      if (!go[j]) continue;
       const unsigned long long v = hh[j] + 1, key = (unsigned long long)sv[j].x | ((unsigned long long)sv[j].y << 32);
+      found += __popcll(__ballot(go[j] && key == v));
+      if (!go[j]) continue;
       if (key == v) {  // a repeat: nothing to do once its counter is saturated
         if (!(A->cs && sv[j].z >= A->cs)) atomicAdd(&home[j]->cnt, 1u);
       } else if (!table_add(A->tab[ki], hh[j] >> A->shift[ki], hh[j], 1u, A->cs, key == 0ull ? 0u : 1u)) {
         atomicAdd(A->counters[ki] + 2, 1ull);
       }
     }
+    slot_first = 2 * found > n;
     wave_lds_sync();
     n = 0;
   }
