@@ -264,7 +264,20 @@ def main():
         # an explicit stream shared by torch (collectives synchronise with it) and the library's main stream
         torch_stream = torch.cuda.Stream()
         torch.cuda.set_stream(torch_stream)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL prints its version banner on stdout when the first communicator comes up: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         from metalign_amd._hip import Hip
         hip = Hip.get(local_rank, stream=torch_stream.cuda_stream)
     else:
@@ -405,7 +418,7 @@ def main():
                 res["with_ingest"] = bench_cli.measure(1_000_000)
             except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline down)
                 res["with_ingest"] = {"error": repr(e)}
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -789,6 +789,10 @@ int sketch_wait(const mg_sketch* sk) {
 }
 
 // distinct / expected candidates of the previous batch of the same k (x2): sizes the counting table
+// The next table of the same k is sized for this many times the distinct hashes the last one held (a bucket then
+// expects at most kBucketTarget / kHintSafety of them; 256 slots are 12 standard deviations away, and a sample twice
+// as diverse as its predecessor is caught by the overflow counter and redone on the list path).
+constexpr double kHintSafety = 1.25;
 static double distinct_hint_k[MG_MAX_K + 1];
 static bool distinct_hint_init = false;
 static double& distinct_hint_for(int k) {
@@ -816,7 +820,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   sk->pend_slot = -1;
   if (overflows == 0) {
     if (!sk->redo.is_merge) {
-      const double r = 2.0 * (double)runs / sk->expect;
+      const double r = kHintSafety * (double)runs / sk->expect;
       distinct_hint_for(sk->redo.k) = r < 0.02 ? 0.02 : (r > 1.0 ? 1.0 : r);
     }
     return MG_OK;
@@ -910,7 +914,7 @@ static void plan_k(const ReadPlan& rp, int k, uint64_t hmax, KPlan& kp) {
   if (kp.cap > rp.nbases + 64) kp.cap = rp.nbases + 64;
   // ---- table path: counting hash table partitioned into hash-range buckets ----
   // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
-  // previous call of the same k (x2 for safety) tightens it for steady-state batches.  Under-sizing is detected (a
+  // previous call of the same k (x kHintSafety) tightens it for steady-state batches.  Under-sizing is detected (a
   // bucket with no free slot) and handled by the list path.
   const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
   kp.distinct_est = (double)kp.expect * mg::distinct_hint_for(k);
@@ -931,8 +935,8 @@ static int finish_pending(mg_sketch* sk, const KPlan& kp, const ReadPlan& rp, un
   MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
   uint64_t* sk_meta = sk->meta.as<uint64_t>();
   // the sketch's buffers are sized from the distinct-count estimate (which is the candidate count itself until a
-  // first batch has been seen, and twice the observed ratio afterwards), not from the table's slots (2.7 per
-  // expected entry): 12 B instead of 32 per expected entry and sketch in flight
+  // first batch has been seen, and kHintSafety times the observed ratio afterwards), not from the table's slots
+  // (2 to 4 per expected entry): 12 B instead of 32 to 64 per expected entry and sketch in flight
   uint64_t cap = (uint64_t)kp.distinct_est + 1024;
   if (cap > kp.tp.slots) cap = kp.tp.slots;
   MG_TRY(table_pack(kp.tp, sk, sk_meta, cap));

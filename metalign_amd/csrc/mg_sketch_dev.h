@@ -34,7 +34,7 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
-constexpr uint32_t kBucketTarget = 96;  // expected distinct hashes per bucket (load factor <= 3/8)
+constexpr uint32_t kBucketTarget = 128;  // expected distinct hashes per bucket at most (load factor <= 1/2; the shift rounds it down by up to 2x)
 
 // One slot of the partitioned counting table: key = hash + 1 (0 = empty) and its occurrence counter side by side, so
 // that ONE 16-byte access answers both "is it this key" and "is its counter saturated" (round 1 kept keys and counters
