@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -78,6 +79,13 @@ struct Context {
 
 Context& ctx();
 int fail(int code, const char* fmt, ...);
+
+// The stage-A kernels' cs word (mg_sketch_dev.h: kCsMask): count saturation + the tests' flush-order pin.
+inline uint32_t stage_a_cs_word() {
+  uint32_t order = 0;
+  if (const char* e = getenv("MG_DEBUG_FLUSH_ORDER")) order = e[0] == 'f' ? 1u : (e[0] == 's' ? 2u : 0u);
+  return ctx().count_sat | (order << 30);
+}
 
 #define MG_HIP(call)                                                                          \
   do {                                                                                        \

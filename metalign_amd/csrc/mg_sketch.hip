@@ -50,6 +50,7 @@ struct CandSink {
   int n;              // entries staged (wave-uniform)
   unsigned long long produced = 0;  // table mode: this lane's candidates inserted so far
   bool slot_first = false;          // table mode: the order of the two look-ups of a flush (wave-uniform)
+  uint32_t order = 0;               // 0: adapt; 1 / 2: pinned (tests)
 
   __device__ __forceinline__ bool passes(uint64_t h) const {
     return !fbits || ((fbits[(h & fmask) >> 5] >> (h & 31u)) & 1u);
@@ -126,7 +127,7 @@ struct CandSink {
           ++lost;
         }
       }
-      slot_first = 2 * found > n;
+      slot_first = order ? order == 2u : 2 * found > n;
       // (counted per lane and added to counters[0] once, at the end of the kernel: an atomic per flush on that one
       // address is what bounded the kernel when the threshold filters little — 1.3 M flushes per 10 M reads at ~24 ns)
       produced += kept;
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
-  CandSink sink{cbuf, cand, cand_cap, counters, tab, bucket_shift, fbits, fmask, cs, 0};
+  CandSink sink{cbuf, cand, cand_cap, counters, tab, bucket_shift, fbits, fmask, cs & kCsMask, 0};
+  sink.order = cs >> 30;
+  sink.slot_first = sink.order == 2u;
   uint64_t kmers = 0;
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -630,7 +633,7 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
                      nreads, hmax, d_cand, cap, d_counters, d_tab, bucket_shift, stage_bytes,
                      filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr, filter ? filter->mask : 0ull,
-                     c.count_sat);
+                     stage_a_cs_word());
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -1114,6 +1117,7 @@ int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out) {
 
 int mg_set_count_saturation(uint32_t cs) {
   MG_REQUIRE_READY();
+  if (cs > mg::kCsMask) return fail(MG_ERR_ARG, "count saturation %u above %u", cs, mg::kCsMask);
   ctx().count_sat = cs;
   return MG_OK;
 }

@@ -33,6 +33,9 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
+// The kernels' `cs` word: the saturation value in the low 30 bits; the top two pin the order of a flush's two look-ups
+// for the tests (0: each wavefront adapts, 1: filter first, 2: home slot first) — MG_DEBUG_FLUSH_ORDER=filter|slot.
+constexpr uint32_t kCsMask = 0x3fffffffu;
 constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
 constexpr uint32_t kBucketTarget = 128;  // expected distinct hashes per bucket at most (load factor <= 1/2; the shift rounds it down by up to 2x)
 

@@ -27,7 +27,8 @@ struct MultiArgs {
   const uint32_t* fbits[kMaxMultiK];     // optional membership pre-filter of k number i
   uint64_t fmask[kMaxMultiK];
   unsigned shift[kMaxMultiK];
-  uint32_t cs;
+  uint32_t cs;     // saturation value (low 30 bits of the cs word)
+  uint32_t order;  // its top two bits
 };
 
 // Wave-level candidate sink shared by all k: (hash, k index) pairs staged in LDS, flushed into the per-k tables.
@@ -46,6 +47,7 @@ struct MultiSink {
   // in its home slot; a sample of mostly unknown organisms has nearly every candidate rejected by the filter.  The
   // wavefront keeps to the order that was cheaper for its previous flush.
   bool slot_first;  // wave-uniform
+  uint32_t order;   // 0: adapt; 1 / 2: pinned (tests; see kCsMask)
 
   __device__ __forceinline__ void flush(int lane) {
     if (n == 0) return;
@@ -114,7 +116,7 @@ struct MultiSink {
         atomicAdd(A->counters[ki] + 2, 1ull);
       }
     }
-    slot_first = 2 * found > n;
+    slot_first = order ? order == 2u : 2 * found > n;
     wave_lds_sync();
     n = 0;
   }
@@ -230,7 +232,7 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
   uint8_t* cand = smem + (size_t)kWavesPerBlock * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(cand) + wave * kCandBuf;
   uint8_t* kbuf = cand + (size_t)kWavesPerBlock * kCandBuf * sizeof(uint64_t) + wave * kCandBuf;
-  MultiSink sink{cbuf, kbuf, &s_args, 0, {0, 0, 0, 0}};
+  MultiSink sink{cbuf, kbuf, &s_args, 0, {0, 0, 0, 0}, args.order == 2u, args.order};
   uint64_t kmers[kMaxMultiK] = {0, 0, 0, 0};
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -327,7 +329,8 @@ int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, con
     a.fmask[i] = tabs[i].filter ? tabs[i].filter->mask : 0ull;
     a.shift[i] = tabs[i].shift;
   }
-  a.cs = ctx().count_sat;
+  a.cs = stage_a_cs_word() & kCsMask;
+  a.order = stage_a_cs_word() >> 30;
   if (nk == 3 && ks[0] == 21 && ks[1] == 31 && ks[2] == 51)
     return launch_multi<KList<21, 31, 51>>(d_bases, d_offsets, nreads, a, stage_bytes);
   if (nk == 4 && ks[0] == 30 && ks[1] == 40 && ks[2] == 50 && ks[3] == 60)

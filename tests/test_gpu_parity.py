@@ -192,6 +192,40 @@ def test_multi_k_sketch_matches_oracle_per_k(hip, oracle_lib, ks, kind, monkeypa
         assert np.array_equal(h, oh) and np.array_equal(c, oc), k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["filter", "slot"])
+def test_flush_order_does_not_change_the_sketch(hip, oracle_lib, order, monkeypatch):
+    """A flush of stage A's candidate buffer looks at the membership filter and at the candidate's home slot in the
+    counting table; each wavefront takes whichever order was cheaper for its previous flush (mg_sketch_multi.hip:
+    MultiSink::flush).  Pinned to either order (MG_DEBUG_FLUSH_ORDER, a test hook) the sketches are the oracle's, bit for
+    bit, at high coverage (nearly every candidate is a repeat) and at none (every candidate is new), with error k-mers
+    the filter rejects, for the single-k kernel and the fused one."""
+    monkeypatch.setenv("MG_DEBUG_FLUSH_ORDER", order)
+    rng = np.random.default_rng(5 + len(order))
+    gb, go = util.random_genomes(rng, 10, 8000)
+    ks = (21, 31, 51)
+    tables = [oracle_lib.sketch_genomes(gb, go, k, 800)[0] for k in ks]
+    filts = [hip.filter_build(t) for t in tables]
+    hmaxs = [int(t.max()) for t in tables]
+    for nreads, present in ((12000, 2), (600, 10)):  # ~110x coverage of two genomes; 1x of all ten
+        pick = np.sort(rng.choice(10, size=present, replace=False))
+        bases, offsets, _ = util.sample_reads(rng, gb, go, nreads, 150, err=0.02, present=pick)
+        d_b, d_o = hip.array(bases), hip.array(offsets)
+        sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, nreads, list(ks), hmaxs, 0, filts)
+        for i, k in enumerate(ks):
+            h, c = sks[i].download()
+            oh, oc, _, oseen = oracle_lib.sketch_reads_filtered(bases, offsets, k, tables[i], hmax=hmaxs[i])
+            assert np.array_equal(h, oh) and np.array_equal(c, oc) and sks[i].kmers_seen == oseen, (k, nreads)
+            one = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, hmaxs[i], 0, filt=filts[i])
+            h1, c1 = one.download()
+            assert np.array_equal(h1, oh) and np.array_equal(c1, oc), (k, nreads)
+        # and without a filter (the order then only decides when the slot is read)
+        one = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, 21, hmaxs[0], 0)
+        h1, c1 = one.download()
+        oh, oc, _, _ = oracle_lib.sketch_reads(bases, offsets, 21, hmax=hmaxs[0])
+        assert np.array_equal(h1, oh) and np.array_equal(c1, oc)
+
+
 @pytest.mark.parametrize("ks", [(21, 31, 51), (30, 40, 50, 60)])
 def test_multi_k_sketch_long_reads_take_the_hbm_walk(hip, oracle_lib, ks):
     """Tiles that do not fit the LDS stage (contigs instead of reads) are walked straight out of HBM by the fused kernel
