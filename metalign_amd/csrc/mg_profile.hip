@@ -443,7 +443,13 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 // something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
 // had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
 // pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
-constexpr uint32_t kHashSlots = 1024, kHashProbe = 16, kFlushTiles = 256;  // (a miss costs kHashProbe LDS reads before the private bins take it; per 125M records over 10 001 uniform taxa: 32 probes 7.9 ms, 8: 5.6, 2: 5.1, but below 16 a sample of 500 hot taxa starts to overflow and pays the reduction: 0.52 -> 0.56 ms per 12.5M)
+// kHashProbe slots = kHashProbe / 4 buckets of four keys (one 16-byte LDS read each) are looked at before the private
+// bins take a record.  Per 125M records over 10 001 uniform taxa (keys probed one by one): 32 probes 7.9 ms, 8: 5.6,
+// 2: 5.1, but below 16 a sample of 500 hot taxa starts to overflow and pays the reduction (0.52 -> 0.56 ms per
+// 12.5M); with the buckets of four: 4.73 ms and 0.49 ms.  (Measured, and not understood: on the SAME records the
+// hashed bins cost 0.15 ms more than direct ones — 0.55 against 0.40 ms at 500 taxa, MG_DEBUG_K3_HASHED — although a
+// record takes 1.09 bucket reads on average and 0.6 % overflow; tools/experiments/README.md has the counters.)
+constexpr uint32_t kHashSlots = 1024, kHashProbe = 16, kFlushTiles = 256;
 constexpr uint32_t kBinLenLimit = 1u << 20;
 constexpr int kBinCountShift = 40;
 
@@ -562,6 +568,8 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         uint32_t e = li + 1;
         while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
         uint32_t k0, k1;  // kind | nmm << 2 under "kept" / "dropped"
+        uint64_t ge = t0 + e;
+        bool npx;  // what the general evaluator is told about the next read
         if (e < nst) {
           const bool np = s_desc[slot(e)].y & (D_P1 | D_P2);
           Walk w{0, 0, 0, 0, 0}, w1{0, 0, 0, 0, 0};
@@ -573,17 +581,21 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           }
           k0 = classify(w, np);
           k1 = classify(w1, np);
-          if (k0 == 3u) { const Verdict v = eval_group(at, t0 + li, t0 + e, true, nullptr); k0 = v.kind | (v.nmm << 2); }
-          if (k1 == 3u) { const Verdict v = eval_group(at, t0 + li + 1, t0 + e, true, nullptr); k1 = v.kind | (v.nmm << 2); }
+          npx = true;
         } else {  // the read runs past the staged window (or to the end of the shard)
-          uint64_t ge = t0 + e;
           while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
           if (ge >= A.ntotal) continue;  // no closing line: the read is never processed (:259-264)
-          const bool np = at(ge).y & (D_P1 | D_P2);
-          const Verdict v0 = eval_group(at, t0 + li, ge, np, nullptr);
-          const Verdict v1 = eval_group(at, t0 + li + 1, ge, np, nullptr);
-          k0 = v0.kind | (v0.nmm << 2);
-          k1 = v1.kind | (v1.nmm << 2);
+          npx = at(ge).y & (D_P1 | D_P2);
+          k0 = k1 = 3u;
+        }
+        // the general evaluator for what the straight-line walk does not cover — ONE inlined copy for both hypotheses
+        // (every copy is ~3 KB of code in the tile loop; the kernel was 42 KB with six of them)
+#pragma unroll 1
+        for (uint32_t hyp = 0; hyp < 2; ++hyp) {
+          if ((hyp ? k1 : k0) != 3u) continue;
+          const Verdict v = eval_group(at, t0 + li + hyp, ge, npx, nullptr);
+          const uint32_t kk = v.kind | (v.nmm << 2);
+          if (hyp) k1 = kk; else k0 = kk;
         }
         // advance both paths through this read
         const uint32_t ka = st0 ? k1 : k0, kb = st1 ? k1 : k0;
@@ -684,9 +696,15 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           np = at(ge).y & (D_P1 | D_P2);
           slow = true;
         }
-        if (slow) {
-          const Verdict v = eval_group(at, t0 + li + st, ge, np, nullptr);
-          kind = v.kind; tax = v.tax; nmm = v.nmm; hitlen = v.hitlen;
+        if (slow) {  // verdict first; a multimapped read's taxon list (SAM order) in a second round of the same code
+          uint32_t* out = nullptr;
+#pragma unroll 1
+          for (int round = 0; round < 2; ++round) {
+            const Verdict v = eval_group(at, t0 + li + st, ge, np, out);
+            kind = v.kind; tax = v.tax; nmm = v.nmm; hitlen = v.hitlen;
+            if (kind != 2u) break;
+            out = A.mm_tax + eo;
+          }
         }
         if (kind == 0) {
           ++ambig;
@@ -694,12 +712,23 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           uint32_t bin = tax;
           bool in_lds = A.use_lds_hist == 1;
           if (A.use_lds_hist == 2) {
-            uint32_t p = (tax * 2654435761u) >> 22;  // 10 bits: kHashSlots
-            for (uint32_t step = 0; step < kHashProbe; ++step) {
-              uint32_t old = h_key[p];  // keys never change once set: a plain look settles the common case
-              if (old == 0xffffffffu) old = atomicCAS(&h_key[p], 0xffffffffu, tax);
-              if (old == 0xffffffffu || old == tax) { bin = p; in_lds = true; break; }
-              p = (p + 1) & (kHashSlots - 1);
+            // kHashSlots / 4 buckets of four keys, one 16-byte LDS read each: with the keys probed one at a time the
+            // slowest lane of the wavefront set the pace (~10 dependent LDS reads per record at half load; 28 k of
+            // the commit's 63 k clocks per tile at 10 001 taxa).  A key never changes once set and every lane scans
+            // the slots in the same order, so a taxon cannot end up in two of them.
+            uint32_t b = (tax * 2654435761u) >> 24;  // 8 bits
+            static_assert(kHashSlots == 1024, "bucket index width");
+            for (uint32_t step = 0; step < kHashProbe / 4 && !in_lds; ++step) {
+              const uint4 kq = *reinterpret_cast<const uint4*>(&h_key[b * 4]);
+              const uint32_t kv[4] = {kq.x, kq.y, kq.z, kq.w};
+#pragma unroll
+              for (uint32_t q = 0; q < 4; ++q) {
+                if (in_lds) break;
+                uint32_t old = kv[q];
+                if (old == 0xffffffffu) old = atomicCAS(&h_key[b * 4 + q], 0xffffffffu, tax);
+                if (old == 0xffffffffu || old == tax) { bin = b * 4 + q; in_lds = true; }
+              }
+              b = (b + 1) & (kHashSlots / 4 - 1);
             }
           }
           if (in_lds && hitlen < kBinLenLimit) {
@@ -721,9 +750,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
               atomicMin(&A.g_first[tax], (unsigned long long)my_gidx);
           }
         } else {
-          if (slow) {
-            (void)eval_group(at, t0 + li + st, ge, np, A.mm_tax + eo);  // writes the taxon list (SAM order)
-          } else {
+          if (!slow) {
             uint64_t wpos = eo;
             for (uint32_t q = li + st; q < e; ++q) {  // every kept line (:172-173)
               const uint2 dq = s_desc[slot(q)];
@@ -955,6 +982,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     return MG_OK;
   }
   a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 4096 ? 1u : 2u;
+  if (a.use_lds_hist == 1 && getenv("MG_DEBUG_K3_HASHED")) a.use_lds_hist = 2;  // tests: the hashed bins on a small taxonomy
   const size_t lds = a.use_lds_hist == 0 ? 0
                    : a.use_lds_hist == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t))
                                          : kHashSlots * (sizeof(unsigned long long) + 2 * sizeof(uint32_t));

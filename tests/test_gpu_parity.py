@@ -329,9 +329,14 @@ def test_stage_c_bulk_hip(hip, name, monkeypatch, tmp_path):
         sc.check_run(sam, dbp, run, None, monkeypatch, tmp_path, mm_digest_only=True)
 
 
-def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib):
+@pytest.mark.parametrize("force_hashed", [False, True])
+def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib, force_hashed, monkeypatch):
     """Random record streams straight into the C ABI: direct LDS bins at three, then two workgroups per CU (37 / 3500
-    taxa) and, beyond 4096 taxa, hashed bins that overflow into global atomics."""
+    taxa) and, beyond 4096 taxa, hashed bins (buckets of four keys) that overflow into the workgroups' private bins;
+    and the hashed bins on the small taxonomies too (MG_DEBUG_K3_HASHED, a test hook): few taxa — every bucket probe
+    hits at once — and 3500 — most of them overflow."""
+    if force_hashed:
+        monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
     rng = np.random.default_rng(9)
     for ntax, nref in ((37, 90), (3500, 7000), (5000, 9000)):
         n = 300000
