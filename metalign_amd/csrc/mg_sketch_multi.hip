@@ -182,14 +182,15 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
     for (uint32_t pos = warm; pos < maxlen; ++pos) {
       roll.push_clean(cs.at(pos) & 3u);
       // k number I is complete from position K_I - 1 on: a scalar condition per k (the ks ascend, so the tests nest)
+      // (the hash is computed ONCE, into a variable: written twice — as the threshold test and as the value offered —
+      // the four-k kernel ended up with 1.6 x the multiplies, the optimiser no longer merging the two)
+      auto one = [&]<int I>() {
+        const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll);
+        if constexpr (RAGGED) sink.template offer2<I>(pos < len, h <= hmax[I], h, lane);
+        else sink.template offer<I>(h <= hmax[I], h, lane);
+      };
       [&]<int... I>(std::integer_sequence<int, I...>) {
-        ((pos + 1 >= (uint32_t)KL::v[I]
-              ? (RAGGED ? sink.template offer2<I>(pos < len, hash_suffix<KL::v[I], KMAX>(roll) <= hmax[I],
-                                                  hash_suffix<KL::v[I], KMAX>(roll), lane)
-                        : sink.template offer<I>(hash_suffix<KL::v[I], KMAX>(roll) <= hmax[I],
-                                                 hash_suffix<KL::v[I], KMAX>(roll), lane))
-              : (void)0),
-         ...);
+        ((pos + 1 >= (uint32_t)KL::v[I] ? one.template operator()<I>() : (void)0), ...);
       }(std::make_integer_sequence<int, KL::N>{});
     }
 #pragma unroll
@@ -207,13 +208,13 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
     roll.push(c);
     roll.run = c < 4u ? roll.run : 0;
     if (pos < warm) continue;  // (scalar)
+    auto one = [&]<int I>() {
+      const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll);
+      nk[I] += roll.run >= KL::v[I] ? 1u : 0u;
+      sink.template offer2<I>(roll.run >= KL::v[I], h <= hmax[I], h, lane);
+    };
     [&]<int... I>(std::integer_sequence<int, I...>) {
-      ((pos + 1 >= (uint32_t)KL::v[I]
-            ? (nk[I] += roll.run >= KL::v[I] ? 1u : 0u,
-               sink.template offer2<I>(roll.run >= KL::v[I], hash_suffix<KL::v[I], KMAX>(roll) <= hmax[I],
-                                       hash_suffix<KL::v[I], KMAX>(roll), lane))
-            : (void)0),
-       ...);
+      ((pos + 1 >= (uint32_t)KL::v[I] ? one.template operator()<I>() : (void)0), ...);
     }(std::make_integer_sequence<int, KL::N>{});
   }
 #pragma unroll
@@ -283,7 +284,7 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
 // 137 VGPRs for {21,31,51}: three wavefronts per SIMD.  Held to 128 (four per SIMD, ten spilled registers) the kernel
 // takes the same time (16.03 against 16.01 ms per 10M reads): it is bound by VALU issue, not by latency.
 template <class KL>
-__global__ __launch_bounds__(kBlock) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
                                                                const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                                const MultiArgs args, unsigned stage_bytes) {
   sketch_reads_multi_body<KL>(bases, offsets, nreads, args, stage_bytes);
