@@ -720,13 +720,23 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
             static_assert(kHashSlots == 1024, "bucket index width");
             for (uint32_t step = 0; step < kHashProbe / 4 && !in_lds; ++step) {
               const uint4 kq = *reinterpret_cast<const uint4*>(&h_key[b * 4]);
-              const uint32_t kv[4] = {kq.x, kq.y, kq.z, kq.w};
+              // the usual case without a branch: the key is one of the four
+              const uint32_t at = kq.x == tax ? 0u : kq.y == tax ? 1u : kq.z == tax ? 2u : kq.w == tax ? 3u : 4u;
+              if (at < 4u) {
+                bin = b * 4 + at; in_lds = true;
+              } else if (kq.w == 0xffffffffu) {  // room in this bucket (slots fill in order): claim the first free one
+                const uint32_t kv[4] = {kq.x, kq.y, kq.z, kq.w};
 #pragma unroll
-              for (uint32_t q = 0; q < 4; ++q) {
-                if (in_lds) break;
-                uint32_t old = kv[q];
-                if (old == 0xffffffffu) old = atomicCAS(&h_key[b * 4 + q], 0xffffffffu, tax);
-                if (old == 0xffffffffu || old == tax) { bin = b * 4 + q; in_lds = true; }
+                for (uint32_t q = 0; q < 4; ++q) {
+                  if (in_lds || kv[q] != 0xffffffffu) continue;
+                  const uint32_t old = atomicCAS(&h_key[b * 4 + q], 0xffffffffu, tax);
+                  if (old == 0xffffffffu || old == tax) { bin = b * 4 + q; in_lds = true; }
+                }
+                if (!in_lds) {  // lost every free slot of the snapshot to other taxa: look again (rare)
+                  const uint4 k2 = *reinterpret_cast<const uint4*>(&h_key[b * 4]);
+                  const uint32_t a2 = k2.x == tax ? 0u : k2.y == tax ? 1u : k2.z == tax ? 2u : k2.w == tax ? 3u : 4u;
+                  if (a2 < 4u) { bin = b * 4 + a2; in_lds = true; }
+                }
               }
               b = (b + 1) & (kHashSlots / 4 - 1);
             }
