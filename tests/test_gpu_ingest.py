@@ -121,10 +121,11 @@ def test_sam_tokeniser_raises_what_the_reference_raises(hip):
 
 @pytest.mark.gpu
 def test_upload_file_chunks(hip, tmp_path):
-    """Hip.upload_file: a file through two page-locked chunks (several rounds of both buffers, a ragged tail, the
-    empty file) == its bytes."""
+    """Hip.upload_file: a file through page-locked chunks filled by reader threads (several rounds of two buffers, of
+    four above eight chunks, a ragged tail, the empty file, chunks kept from one call to the next) == its bytes."""
     rng = np.random.default_rng(3)
-    for size, chunk in ((0, 1 << 16), (1, 1 << 16), (300_001, 1 << 16), (1 << 16, 1 << 16), (5 * (1 << 16) + 7, 1 << 16)):
+    for size, chunk in ((0, 1 << 16), (1, 1 << 16), (300_001, 1 << 16), (1 << 16, 1 << 16), (5 * (1 << 16) + 7, 1 << 16),
+                        (19 * (1 << 16) + 123, 1 << 16), (3 * (1 << 16), 1 << 16), (40_000, 1 << 16)):
         data = rng.integers(0, 256, size=size, dtype=np.uint8)
         path = tmp_path / ("f%d.bin" % size)
         path.write_bytes(data.tobytes())
