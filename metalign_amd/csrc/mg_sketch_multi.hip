@@ -281,8 +281,9 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
   }
 }
 
-// 137 VGPRs for {21,31,51}: three wavefronts per SIMD.  Held to 128 (four per SIMD, ten spilled registers) the kernel
-// takes the same time (16.03 against 16.01 ms per 10M reads): it is bound by VALU issue, not by latency.
+// 157 VGPRs for {21,31,51}: three wavefronts per SIMD (held to 128 — four per SIMD, fifty spilled registers — 16.9
+// against 15.9 ms per 10M reads at configs[2], 49 against 39 ms in the dense regime).  {30,40,50,60} wants 179: held to
+// 168 (eleven spilled) for three wavefronts per SIMD, 22.6 against 23.9 ms.
 template <class KL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
                                                                const uint64_t* __restrict__ offsets, uint64_t nreads,
