@@ -567,16 +567,17 @@ class Hip:
         dev = self.empty(max(size, 1), np.uint8)
         if size == 0:
             return dev, 0
-        nbufs = 2 if size <= 8 * chunk else 4
         kept = getattr(self, "_upload_bufs", None) or []
-        if not kept or kept[0].count < min(chunk, size):
+        if kept and kept[0].count < min(chunk, size):  # kept for smaller files: start over
             for b in kept:
                 b.free()
             kept = []
+        bufsize = kept[0].count if kept else int(chunk if size > chunk // 4 else size)  # (every kept chunk has this size)
+        chunk = int(min(bufsize, size))
+        nbufs = 2 if size <= 8 * chunk else 4
         while len(kept) < nbufs:
-            kept.append(self.pinned(int(chunk if (kept or size > chunk // 4) else size), np.uint8))
+            kept.append(self.pinned(bufsize, np.uint8))
         self._upload_bufs = bufs = kept
-        chunk = int(min(bufs[0].count, size))
         nchunks = (size + chunk - 1) // chunk
         evs = [self.event() for _ in range(nbufs)]
         fd = os.open(path, os.O_RDONLY)

@@ -1,5 +1,5 @@
 """Soak: many passes of the pipelined single-shard job; device memory in use must not creep and the last pass must
-equal the first.  Usage: python tools/soak.py [passes]"""
+equal the first.  Usage: python tools/soak.py [passes] [config]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,13 +7,13 @@ import bench
 from metalign_amd import distributed as mgd
 from metalign_amd._hip import Hip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-sys.argv = sys.argv[:1]
-args = bench.parse()
+config = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # BASELINE configs[1] by default (configs[2]: python tools/soak.py 300 2)
 hip = Hip.get(0)
-w = bench.build_workload(args, 0, hip)
-job = mgd.ShardJob(hip, None, 0, 1, k=args.k)
-job.load(w["rb"], w["ro"], w["recs"], w["ref2tax"], w["dbh"], w["dbo"])
-first = job.run(10, want_multimapped=True)
+cfg = dict(bench.PRESETS[config], config=config)
+w = bench.build_workload(cfg, 1000, 0, hip)
+job = bench.make_job(hip, None, 0, 1, cfg, w)
+MM = os.environ.get("SOAK_MM", "1") == "1"
+first = job.run(10, want_multimapped=MM)
 hip.sync()
 import subprocess
 def used():
@@ -24,10 +24,13 @@ def used():
         return -1
 m0 = used()
 t0 = time.perf_counter()
-last = job.run(n, want_multimapped=True)
-hip.sync()
+trace = []
+for part in range(6):  # VRAM in use along the way: a plateau is the pool filling up, a slope is a leak
+    last = job.run(max(n // 6, 1), want_multimapped=MM)
+    hip.sync()
+    trace.append(round(used()))
 dt = time.perf_counter() - t0
 m1 = used()
-same = all(np.array_equal(first[k], last[k]) for k in ("hits", "sizes", "count", "bases", "first_seen")) and \
-    all(np.array_equal(a, b) for a, b in zip(first["multimapped"], last["multimapped"]))
-print("passes %d  %.4f ms/pass  VRAM used %.0f -> %.0f MiB  identical results: %s" % (n, dt / n * 1e3, m0, m1, same))
+same = all(np.array_equal(first[k], last[k]) for k in ("hits_k", "sizes_k", "count", "bases", "first_seen")) and \
+    (not MM or all(np.array_equal(a, b) for a, b in zip(first["multimapped"], last["multimapped"])))
+print("passes %d  %.4f ms/pass  VRAM used %.0f -> %.0f MiB (along the way: %s)  identical results: %s" % (n, dt / n * 1e3, m0, m1, trace, same))
