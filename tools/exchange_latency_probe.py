@@ -21,11 +21,10 @@ _stream = torch.cuda.Stream()
 torch.cuda.set_stream(_stream)
 dist.init_process_group("nccl", rank=0, world_size=1)
 sys.argv = sys.argv[:1]
-args = bench.parse()
+cfg = dict(bench.PRESETS[1], config=1)  # BASELINE configs[1]
 hip = Hip.get(0, stream=_stream.cuda_stream)
-w = bench.build_workload(args, 0, hip)
-job = mgd.ShardJob(hip, dist, 0, 1, k=args.k, always_exchange=True)
-job.load(w["rb"], w["ro"], w["recs"], w["ref2tax"], w["dbh"], w["dbo"])
+w = bench.build_workload(cfg, 1000, 0, hip)
+job = bench.make_job(hip, dist, 0, 1, cfg, w, force_dist=True)
 
 # cycles per microsecond of the spin kernel's clock
 torch.cuda.synchronize()

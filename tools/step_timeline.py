@@ -10,11 +10,10 @@ import bench  # noqa: E402
 from metalign_amd import distributed as mgd  # noqa: E402
 from metalign_amd._hip import Hip  # noqa: E402
 
-args = bench.parse()
+cfg = dict(bench.PRESETS[1], config=1)  # BASELINE configs[1]
 hip = Hip.get(0)
-w = bench.build_workload(args, 0, hip)
-job = mgd.ShardJob(hip, None, 0, 1, k=args.k)
-job.load(w["rb"], w["ro"], w["recs"], w["ref2tax"], w["dbh"], w["dbo"])
+w = bench.build_workload(cfg, 1000, 0, hip)
+job = bench.make_job(hip, None, 0, 1, cfg, w)
 eng = job.engine
 for _ in range(3):
     job.step()
@@ -30,12 +29,10 @@ def tic(name, t0):
 N = 20
 hip.sync()
 t_all = time.perf_counter()
-for _ in range(N):
+for _ in range(N):  # one pass at a time (bench.py keeps two in flight): host time of the two halves of a pass
     t = time.perf_counter()
-    eng.profile_begin(0.5, False); eng.profile_commit_launch(1, True, 0); t = tic("stage C queued", t)
-    sk = eng.sketch_local_async(job.k, job.hmax, 0); t = tic("stage A queued (no sync)", t)
-    res = eng.containment_and_commit_results(sk, 2, False); t = tic("stage B queued + the step's one sync + read-backs", t)
-    n = sk.size; sk.free(); t = tic("sketch size/free", t)
+    q = eng.queue_pass(0, job.ks, job.hmaxs, job.s, job.ci, job.pct_id, False); t = tic("pass queued (stage A, B, C; no sync)", t)
+    sks, (hits, sizes), committed = eng.finish_pass(q, False); t = tic("the pass's one sync + read-backs", t)
 hip.sync()
 tot = (time.perf_counter() - t_all) / N
 for k, v in acc.items():
