@@ -77,6 +77,11 @@ int mg_init_on_stream(int device, void* hip_stream);
 void mg_shutdown(void);
 const char* mg_last_error(void);
 int mg_device_name(char* buf, int cap);
+/* Free and total bytes of the device's memory as the runtime reports them (hipMemGetInfo) and the bytes the library's
+ * caching allocator holds for reuse — what a caller sizes a batch against (the whole-file ingest of
+ * metalign_amd/map_and_profile.py falls back to chunks when the text does not fit) and what tests/ and tools/soak.py
+ * watch for growth over thousands of passes.  No counterpart in the reference (host memory is Python's). */
+int mg_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* pooled_bytes);
 
 int mg_dev_malloc(void** d_ptr, uint64_t bytes);
 int mg_dev_free(void* d_ptr);

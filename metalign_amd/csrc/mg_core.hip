@@ -277,6 +277,24 @@ void mg_shutdown(void) {
 
 const char* mg_last_error(void) { return mg::g_err; }
 
+int mg_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* pooled_bytes) {
+  MG_REQUIRE_READY();
+  size_t f = 0, t = 0;
+  MG_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  if (pooled_bytes) {
+    mg::Context& c = mg::ctx();
+    uint64_t held = 0;
+    for (auto& kv : c.pool) held += kv.first * kv.second.size();
+    for (auto& blk : c.fence_open) held += blk.second;
+    for (auto& b : c.fence_sealed)
+      for (auto& blk : b.blocks) held += blk.second;
+    *pooled_bytes = held;
+  }
+  return MG_OK;
+}
+
 int mg_device_name(char* buf, int cap) {
   MG_REQUIRE_READY();
   hipDeviceProp_t prop;

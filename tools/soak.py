@@ -15,13 +15,9 @@ job = bench.make_job(hip, None, 0, 1, cfg, w)
 MM = os.environ.get("SOAK_MM", "1") == "1"
 first = job.run(10, want_multimapped=MM)
 hip.sync()
-import subprocess
-def used():
-    out = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--csv"], capture_output=True, text=True).stdout
-    try:
-        return int(out.strip().splitlines()[1].split(",")[2]) / 2**20
-    except Exception:
-        return -1
+def used():  # MiB of device memory in use, as the runtime reports it
+    free, total, _ = hip.mem_info()
+    return (total - free) / 2**20
 m0 = used()
 t0 = time.perf_counter()
 trace = []

@@ -22,12 +22,9 @@ first = job.run(10)
 torch.cuda.synchronize()
 
 
-def used():
-    out = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--csv"], capture_output=True, text=True).stdout
-    try:
-        return int(out.strip().splitlines()[1].split(",")[2]) / 2**20
-    except Exception:
-        return -1
+def used():  # MiB of device memory in use, as the runtime reports it
+    free, total, _ = hip.mem_info()
+    return (total - free) / 2**20
 
 
 m0 = used()
