@@ -21,6 +21,7 @@ CAMI file is byte-identical.
 There is no CPU fallback: without libmetalign_hip.so / a GPU, map_and_process
 raises (metalign_amd._hip.HipUnavailable).
 """
+import os
 import subprocess
 import sys
 import time
@@ -354,6 +355,11 @@ def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _re
     index = hip.acc_index(names)
     d_text = batch = None
     try:
+        # the text plus ~60 B per line of line index and tokeniser output must fit beside what is resident already:
+        # otherwise straight to the streaming path (256 MB chunks), without first filling the device and failing
+        free, _, pooled = hip.mem_info()
+        if 2 * os.path.getsize(path) > free + pooled:
+            return None
         try:
             d_text, size = hip.upload_file(path)
             batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '', paf=_paf)
