@@ -101,6 +101,60 @@ def load_reads_device(hip, path, kind):
         return _HostParsedReads(hip, bases, offsets)
 
 
+def _record_cut(data, kind):
+    """Index just past the last COMPLETE record of a piece of FASTQ / FASTA text (0: none yet)."""
+    arr = np.frombuffer(data, dtype=np.uint8)
+    if kind == 'fastq':  # four lines per record (what the device parser takes)
+        nl = np.flatnonzero(arr == 10)
+        whole = (len(nl) // 4) * 4
+        return int(nl[whole - 1]) + 1 if whole else 0
+    at = data.rfind(b'\n>')  # FASTA: a record ends where the next header begins
+    return at + 1 if at >= 0 else 0
+
+
+def iter_read_batches(hip, path, kind, batch_bytes):
+    """Device-resident batches of the reads file: the whole file when it fits `batch_bytes` (plain text goes up through
+    page-locked chunks and is parsed where it lands), otherwise record-aligned pieces of about that size — a sample
+    larger than the device's free memory is sketched piece by piece and the sketches are merged (run_sketch_steps);
+    the reference's kmc spills to disk instead (scripts/select_db.py:50-52)."""
+    import gzip
+    gz = path.endswith('.gz')
+    if not gz and os.path.getsize(path) <= batch_bytes:
+        yield load_reads_device(hip, path, kind)
+        return
+    fmt = 'fastq' if kind == 'fastq' else 'fasta_ml'
+    carry = b''
+    with (gzip.open(path, 'rb') if gz else open(path, 'rb')) as fh:
+        while True:
+            buf = fh.read(batch_bytes)
+            data = carry + buf
+            if not buf:  # end of file: what is left is the last record (with or without a final newline)
+                if data.strip():
+                    yield hip.parse_reads(data, fmt)
+                return
+            cut = _record_cut(data, kind)
+            if cut:
+                yield hip.parse_reads(data[:cut], fmt)
+            carry = data[cut:]
+
+
+def _merge_two(hip, a, b, k, hmax, s):
+    """Union of two read sketches of the same k with saturating count sums (mg_sketch_merge_dev: the multi-GPU merge,
+    here for the pieces of one sample).  Frees both inputs."""
+    (ha, ca), (hb, cb) = a.download(), b.download()
+    trunc = [(sk.truncated, sk.last_hash) for sk in (a, b)]
+    any_trunc = any(t for t, _ in trunc)
+    bound = min([lh for t, lh in trunc if t] or [_hip.U64_MAX])
+    a.free()
+    b.free()
+    d_h, d_c = hip.array(np.concatenate([ha, hb])), hip.array(np.concatenate([ca, cb]))
+    try:
+        return hip.sketch_merge_dev(d_h.ptr, d_c.ptr, len(ha) + len(hb), k, 0, hmax, s, any_trunc, bound)
+    finally:
+        d_h.free()
+        d_c.free()
+
+
 def run_sketch_steps(args):
     """Stages A+B on the MI355X: reads -> per-k read sketch -> containment of every genome sketch ->
     temp_dir/cmash_query_results.csv.  Replaces run_kmc_steps (:43-65) and the CMash call (:69-76)."""
@@ -109,9 +163,6 @@ def run_sketch_steps(args):
     if table_dir in (None, 'AUTO'):
         table_dir = formats.default_table_dir(args.data)
     table = formats.SketchTable(table_dir)
-    reads = load_reads_device(hip, args.reads, args.input_type)
-    d_b_ptr, d_o_ptr = reads.device_ptrs()
-    nreads = reads.count
     min_count = int(getattr(args, 'min_count', 2))
     s = int(getattr(args, 'sketch_size', 0))
     # every k of the table: the hash-major pairs go up as they lie on disk (no sort), the stored pre-filter with them
@@ -123,18 +174,33 @@ def run_sketch_steps(args):
         filts.append(hip.filter_from_bits(bits) if bits is not None
                      else hip.filter_build(np.asarray(table.pairs(k)['pair_hash'])))
     # ... then ONE pass over the reads for all k (the reference's query is multi-k too: 30-60-10, :75), and stage B per k
-    sks = hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, nreads, table.ks, [t.max_hash for t in dev_tables], s, filts)
+    # (a reads file larger than a quarter of the free device memory — or MG_READ_BATCH_BYTES — goes through in
+    # record-aligned pieces whose sketches are merged: saturating counters add up to the same clamped counts)
+    free, _, pooled = hip.mem_info()
+    batch_bytes = int(os.environ.get('MG_READ_BATCH_BYTES', 0)) or max((free + pooled) // 4, 1 << 26)
+    hmaxs = [t.max_hash for t in dev_tables]
+    sks = None
+    for reads in iter_read_batches(hip, args.reads, args.input_type, batch_bytes):
+        d_b_ptr, d_o_ptr = reads.device_ptrs()
+        part = hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, reads.count, table.ks, hmaxs, s, filts)
+        for sk in part:
+            sk.resolve()  # (a sketch whose counting table overflowed is redone from the reads: before they go)
+        reads.free()
+        sks = part if sks is None else [_merge_two(hip, a, b, k, hm, s) for a, b, k, hm in zip(sks, part, table.ks, hmaxs)]
+    if sks is None:  # an empty reads file
+        empty = _HostParsedReads(hip, np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        sks = hip.sketch_reads_multi_dev_async(*empty.device_ptrs(), 0, table.ks, hmaxs, s, filts)
+        for sk in sks:
+            sk.resolve()
+        empty.free()
     per_k = []
     for sk, dev_table in zip(sks, dev_tables):
         hits, sizes = hip.containment(sk, dev_table, min_count)
-        if sk.resolve():  # the counting table had overflowed and the sketch was rebuilt: stage B again
-            hits, sizes = hip.containment(sk, dev_table, min_count)
         with np.errstate(divide='ignore', invalid='ignore'):
             ci = np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0)
         per_k.append(ci)
     for h in sks + filts + dev_tables:
         h.free()
-    reads.free()
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
     return out

@@ -127,6 +127,26 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
     args = select_db.select_parseargs([str(fq), str(data), "--temp_dir", str(tmp1), "--keep_temp_files", "--sketch_table", str(v1)])
     select_db.select_main(args)
     assert (tmp1 / "cmash_query_results.csv").read_text().splitlines() == csv
+    # a reads file that does not fit the device goes through in record-aligned pieces whose sketches are merged
+    # (MG_READ_BATCH_BYTES forces it here: ~40 pieces of the 1 MB file; a piece boundary falls inside records); .gz is
+    # inflated on the host and cut the same way; FASTA pieces are cut at headers.  Same CSV every time.
+    import gzip
+    monkeypatch.setenv("MG_READ_BATCH_BYTES", "25000")
+    gzq = tmp_path / "sample_gz.fq.gz"
+    with open(fq, "rb") as src_fh, gzip.open(gzq, "wb") as dst:
+        dst.write(src_fh.read())
+    fa = tmp_path / "sample.fa"
+    with open(fa, "w") as fh:
+        for i in range(len(ro) - 1):
+            seq = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
+            fh.write(">r%d\n%s\n%s\n" % (i, seq[:70], seq[70:]))  # sequences over two lines
+    for j, reads_file in enumerate((fq, gzq, fa)):
+        tmpj = tmp_path / ("tmp_batched%d" % j)
+        args = select_db.select_parseargs([str(reads_file), str(data), "--temp_dir", str(tmpj), "--keep_temp_files",
+                                           "--sketch_table", str(data / "sketch_table")])
+        select_db.select_main(args)
+        assert (tmpj / "cmash_query_results.csv").read_text().splitlines() == csv, reads_file
+    monkeypatch.delenv("MG_READ_BATCH_BYTES")
 
 
 def test_exchange_path_on_one_gpu_under_rccl():
