@@ -101,6 +101,177 @@ def load_reads_device(hip, path, kind):
         return _HostParsedReads(hip, bases, offsets)
 
 
+# ---- one process per GPU (python -m torch.distributed.run ... -m metalign_amd.select_db ...) ----------------------------
+# Every rank takes a byte range of the reads file, moved to RECORD boundaries exactly: FASTQ records are four lines, so
+# a rank needs the number of newlines in front of its range (every rank counts its own range, one all-gather); FASTA
+# records begin at a '>' that follows a newline.  A record belongs to the rank in whose raw range its first line
+# STARTS.  The sketch tables are read by hash range (format 2), the exchange is distributed.ShardJob's.
+
+def _scan(path, pos, size, fn, block=1 << 20):
+    """fn(bytes, file offset of the block) -> file offset or None, over blocks from pos on; None at the end of file."""
+    with open(path, 'rb') as fh:
+        while pos < size:
+            fh.seek(pos)
+            buf = fh.read(block)
+            if not buf:
+                return None
+            r = fn(buf, pos)
+            if r is not None:
+                return r
+            pos += len(buf)
+    return None
+
+
+def count_newlines(path, lo, hi, block=1 << 24):
+    n = 0
+    with open(path, 'rb') as fh:
+        fh.seek(lo)
+        left = hi - lo
+        while left > 0:
+            buf = fh.read(min(block, left))
+            if not buf:
+                break
+            n += int(np.count_nonzero(np.frombuffer(buf, dtype=np.uint8) == 10))
+            left -= len(buf)
+    return n
+
+
+def fastq_record_start(path, pos, lines_before, size):
+    """File offset of the first FASTQ record whose first line starts at or after byte `pos`, given the number of
+    newlines in front of `pos`; `size` (end of file) when there is none."""
+    if pos >= size:
+        return size
+    if pos == 0:
+        line_start, idx = 0, 0
+    else:
+        with open(path, 'rb') as fh:
+            fh.seek(pos - 1)
+            prev = fh.read(1)
+        if prev == b'\n':
+            line_start, idx = pos, lines_before
+        else:  # in the middle of line number `lines_before`: the next line is the first to start in here
+            nl = _scan(path, pos, size, lambda buf, off: (off + buf.find(b'\n')) if b'\n' in buf else None)
+            if nl is None:
+                return size
+            line_start, idx = nl + 1, lines_before + 1
+    skip = (-idx) % 4  # lines to step over to the next record's '@' line
+    while skip and line_start < size:
+        nl = _scan(path, line_start, size, lambda buf, off: (off + buf.find(b'\n')) if b'\n' in buf else None)
+        if nl is None:
+            return size
+        line_start = nl + 1
+        skip -= 1
+    return min(line_start, size)
+
+
+def fasta_record_start(path, pos, size):
+    """File offset of the first FASTA header line that starts at or after byte `pos` (0 for pos 0: what precedes the first
+    header travels with the first range and is ignored by the parser, as on one GPU)."""
+    if pos == 0:
+        return 0
+    if pos >= size:
+        return size
+
+    def find(buf, off):
+        at = buf.find(b'\n>')
+        if at >= 0:
+            return off + at + 1
+        return None
+    # (blocks overlap by one byte so that a '\n' at a block's end and the '>' after it are seen together)
+    p = pos - 1
+    with open(path, 'rb') as fh:
+        while p < size:
+            fh.seek(p)
+            buf = fh.read((1 << 20) + 1)
+            if len(buf) < 2:
+                return size
+            r = find(buf, p)
+            if r is not None:
+                return r
+            p += len(buf) - 1
+    return size
+
+
+def read_range_of_rank(path, kind, rank, world, all_gather_ints):
+    """(start, end) byte offsets of the records of `path` that rank `rank` of `world` owns.  all_gather_ints(x) -> the
+    list of every rank's x (torch.distributed in the launcher, a plain list in the tests)."""
+    size = os.path.getsize(path)
+    raw = [size * r // world for r in range(world + 1)]
+    if kind != 'fastq':
+        return fasta_record_start(path, raw[rank], size), fasta_record_start(path, raw[rank + 1], size)
+    counts = all_gather_ints(count_newlines(path, raw[rank], raw[rank + 1]))
+    before = [0]
+    for c in counts:
+        before.append(before[-1] + int(c))
+    return (fastq_record_start(path, raw[rank], before[rank], size),
+            fastq_record_start(path, raw[rank + 1], before[rank + 1], size))
+
+
+_dist_keep = []  # (the torch stream the library launches on must outlive the job)
+
+
+def dist_context():
+    """(torch.distributed, rank, world, Hip) when this process is one rank of a torch.distributed.run launch (WORLD_SIZE
+    in the environment; MG_FORCE_DIST=1: also at world size 1), else None."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 and os.environ.get('MG_FORCE_DIST') != '1':
+        return None
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        stream = torch.cuda.Stream()  # explicit: collectives are ordered with the library's kernels on it
+        torch.cuda.set_stream(stream)
+        _dist_keep.append(stream)
+        dist.init_process_group('nccl')
+    hip = _hip.Hip.get(local, stream=torch.cuda.current_stream().cuda_stream)
+    return dist, dist.get_rank(), dist.get_world_size(), hip
+
+
+def run_sketch_steps_dist(args, ctx):
+    """run_sketch_steps with one process per GPU: reads sharded by byte range, sketch tables and read sketches sharded by
+    hash range (distributed.ShardJob); rank 0 writes the CSV."""
+    import torch
+    from .distributed import ShardJob
+    dist, rank, world, hip = ctx
+    if args.reads.endswith('.gz'):
+        sys.exit('Error: a .gz reads file cannot be split by byte range; inflate it first for a multi-GPU run.')
+    table_dir = getattr(args, 'sketch_table', 'AUTO')
+    if table_dir in (None, 'AUTO'):
+        table_dir = formats.default_table_dir(args.data)
+    table = formats.SketchTable(table_dir)
+
+    def gather(x):
+        t = torch.tensor([int(x)], dtype=torch.int64, device='cuda')
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [int(o.item()) for o in out]
+
+    start, end = read_range_of_rank(args.reads, args.input_type, rank, world, gather)
+    with open(args.reads, 'rb') as fh:
+        fh.seek(start)
+        text = fh.read(end - start)
+    reads = hip.parse_reads(text, 'fastq' if args.input_type == 'fastq' else 'fasta_ml')
+    rb, ro = reads.download()
+    reads.free()
+    job = ShardJob(hip, dist, rank, world, k=list(table.ks), ci=int(getattr(args, 'min_count', 2)),
+                   s=int(getattr(args, 'sketch_size', 0)), always_exchange=True)
+    # (a format-2 table is hash-major on disk: the rank maps only its hash range; a format-1 table is inverted on the host
+    # first, by every rank)
+    job.load(rb, ro, np.zeros(0, dtype=_hip.REC_DTYPE), np.zeros(1, dtype=np.uint32), table, ntax=1)
+    got = job.step()
+    out = args.temp_dir + 'cmash_query_results.csv'
+    if rank == 0:
+        per_k = []
+        for hits, sizes in zip(got['hits_k'], got['sizes_k']):
+            with np.errstate(divide='ignore', invalid='ignore'):
+                per_k.append(np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0))
+        write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
+    dist.barrier()
+    return out
+
+
 def _record_cut(data, kind):
     """Index just past the last COMPLETE record of a piece of FASTQ / FASTA text (0: none yet)."""
     arr = np.frombuffer(data, dtype=np.uint8)
@@ -270,7 +441,12 @@ def select_main(args=None):
         args.input_type = cli.sniff_reads_type(args.reads)
 
     taxid2info = read_dbinfo(args)
-    if args.cmash_results == 'NONE':
+    ctx = dist_context() if args.cmash_results == 'NONE' else None
+    if ctx is not None:  # one process per GPU: all ranks sketch, rank 0 goes on alone
+        run_sketch_steps_dist(args, ctx)
+        if ctx[1] != 0:
+            return
+    elif args.cmash_results == 'NONE':
         run_sketch_steps(args)
     organisms = run_cmash_and_cutoff(args, taxid2info)
     make_db_and_dbinfo(args, organisms, taxid2info)

@@ -147,6 +147,22 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
         select_db.select_main(args)
         assert (tmpj / "cmash_query_results.csv").read_text().splitlines() == csv, reads_file
     monkeypatch.delenv("MG_READ_BATCH_BYTES")
+    # the same command as ONE RANK of a torch.distributed.run launch (world size 1, every collective in the path:
+    # MG_FORCE_DIST=1): reads taken by record-aligned byte range, table by hash range, distributed.ShardJob's exchange;
+    # rank 0 writes the same CSV and the same subset db_info.  A child process: torch.distributed stays out of this one.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for j, reads_file in enumerate((fq, fa)):
+        tmpd2 = tmp_path / ("tmp_dist%d" % j)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29551 + j), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                   MG_FORCE_DIST="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-m", "metalign_amd.select_db", str(reads_file), str(data), "--temp_dir", str(tmpd2),
+                            "--keep_temp_files", "--sketch_table", str(data / "sketch_table")],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert (tmpd2 / "cmash_query_results.csv").read_text().splitlines() == csv, reads_file
+        assert (tmpd2 / "subset_db_info.txt").read_text().splitlines() == sub
 
 
 def test_exchange_path_on_one_gpu_under_rccl():

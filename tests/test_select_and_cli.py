@@ -183,3 +183,50 @@ def test_tokenise_paf_takes_bytes_lines_like_the_stream_code_hands_them(tmp_path
     with open(str(p), "rb") as fh:
         c = mp.tokenise_paf(fh, idx, decode=False)
     assert np.array_equal(a, b) and len(c) == 3 and np.array_equal(c[:1], a)
+
+
+def test_record_aligned_byte_ranges_of_a_multi_gpu_launch(tmp_path):
+    """select_db.read_range_of_rank: the byte ranges the ranks of a torch.distributed.run launch take of the reads file
+    tile it at RECORD boundaries — FASTQ with quality lines that begin with '@' and '+' (a byte-pattern guess would be
+    fooled; the ranges come from newline counts), reads of very different lengths, no final newline; FASTA with wrapped
+    sequences and junk in front of the first header — for every world size, every record exactly once."""
+    import numpy as np
+    from metalign_amd import select_db
+    rng = np.random.default_rng(12)
+    recs = []
+    for i in range(257):
+        n = int(rng.integers(1, 400))
+        seq = "".join(rng.choice(list("ACGTN"), size=n))
+        qual = "".join(rng.choice(list("@+I#>"), size=n))
+        if i % 3 == 0:
+            qual = "@" + qual[1:]
+        if i % 5 == 0:
+            qual = "+" + qual[1:]
+        recs.append("@r%d +x\n%s\n+\n%s\n" % (i, seq, qual))
+    for tail in ("", "strip"):
+        text = "".join(recs)
+        if tail:
+            text = text[:-1]  # no newline at the end of the file
+        fq = tmp_path / ("r%s.fq" % tail)
+        fq.write_text(text)
+        size = len(text)
+        for world in range(1, 9):
+            raw = [size * r // world for r in range(world + 1)]
+            counts = [select_db.count_newlines(str(fq), raw[r], raw[r + 1]) for r in range(world)]
+            ranges = [select_db.read_range_of_rank(str(fq), "fastq", r, world, lambda x: counts) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == size
+            assert all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+            starts = set(np.cumsum([0] + [len(x) for x in recs[:-1]]).tolist()) | {size}
+            assert all(a in starts and b in starts and a <= b for a, b in ranges), (world, ranges)
+    fa_recs = [">s%d desc > not a header\n%s\n" % (i, "\n".join("".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 61))))
+                                                              for _ in range(int(rng.integers(0, 6))))) for i in range(120)]
+    text = "junk in front\n\n" + "".join(fa_recs)
+    fa = tmp_path / "r.fa"
+    fa.write_text(text)
+    size = len(text)
+    hdr = set((len("junk in front\n\n") + np.cumsum([0] + [len(x) for x in fa_recs[:-1]])).tolist()) | {0, size}
+    for world in range(1, 9):
+        ranges = [select_db.read_range_of_rank(str(fa), "fasta", r, world, None) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == size
+        assert all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+        assert all(a in hdr and b in hdr and a <= b for a, b in ranges), (world, ranges)
