@@ -472,6 +472,11 @@ class SamBatch:
         hip._chk(hip.lib.mg_sam_batch_device_ptr(handle, ctypes.byref(p)))
         self.ptr = p.value or 0
 
+    @property
+    def last_qname(self):
+        """QNAME of the last retained line ('' when there is none): what the next piece of the text is tokenised after."""
+        return self.hip.lib.mg_sam_batch_last_qname(self.handle).decode("utf-8", "replace")
+
     def free(self):
         if self.handle:
             self.hip.lib.mg_sam_batch_free(self.handle)
@@ -563,14 +568,15 @@ class Hip:
         host = np.ascontiguousarray(host, dtype=dtype)
         return DeviceArray(self, host.size, host.dtype).upload(host)
 
-    def upload_file(self, path, chunk=32 << 20):
+    def upload_file(self, path, chunk=32 << 20, offset=0, length=None):
         """A file's bytes -> HBM through page-locked chunks: reader threads fill chunks (page cache -> pinned buffer, one
         copy, positional reads, the GIL released) while the DMA of earlier chunks runs; this thread alone talks to the
         library.  Two chunks for files up to 256 MB, four above (one thread copies ~14 GB/s out of the page cache,
         PCIe takes ~50).  The chunks stay with the instance: page-locking 32 MB costs ~5 ms each time.
+        offset / length: a byte range of the file (a rank's share of a multi-GPU launch).
         -> (DeviceArray of uint8, size)."""
         from concurrent.futures import ThreadPoolExecutor
-        size = os.path.getsize(path)
+        size = os.path.getsize(path) - offset if length is None else int(length)
         dev = self.empty(max(size, 1), np.uint8)
         if size == 0:
             return dev, 0
@@ -593,9 +599,9 @@ class Hip:
             off, want = i * chunk, min(chunk, size - i * chunk)
             view, got = memoryview(bufs[i % nbufs].array)[:want], 0
             while got < want:
-                n = os.preadv(fd, [view[got:]], off + got)
+                n = os.preadv(fd, [view[got:]], offset + off + got)
                 if not n:
-                    raise HipError("%s: short read at byte %d of %d" % (path, off + got, size))
+                    raise HipError("%s: short read at byte %d of %d" % (path, offset + off + got, offset + size))
                 got += n
             return want
 

@@ -386,6 +386,169 @@ def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _re
     return assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=_want_lists)
 
 
+# ---- one process per GPU (python -m torch.distributed.run ... -m metalign_amd.map_and_profile ...) ---------------------
+# What costs time in this stage is getting tens of gigabytes of SAM text tokenised; stage C itself takes milliseconds
+# for 10^8 records.  So the ranks share the TEXT — every rank uploads and tokenises a line-aligned byte range of the
+# file on its GPU — and the 16-byte records (1/20 of the text) are gathered on rank 0, which runs stage C and the tail
+# exactly as a single process does, on exactly the record stream a single process sees: the only thing a rank cannot
+# know alone, whether its first retained line continues the previous range's last read, is settled from the first /
+# last QNAMEs the ranks exchange.
+
+def sam_range_of_rank(path, rank, world):
+    """(start, end) byte offsets of the lines that START in rank `rank`'s share of the file."""
+    size = os.path.getsize(path)
+
+    def line_start(pos):
+        if pos <= 0:
+            return 0
+        if pos >= size:
+            return size
+        with open(path, 'rb') as fh:
+            p = pos - 1  # (a newline at pos - 1 makes pos itself a line start)
+            while p < size:
+                fh.seek(p)
+                buf = fh.read(1 << 20)
+                if not buf:
+                    return size
+                at = buf.find(b'\n')
+                if at >= 0:
+                    return min(p + at + 1, size)
+                p += len(buf)
+        return size
+    return line_start(size * rank // world), line_start(size * (rank + 1) // world)
+
+
+def first_retained_qname(path, start, end):
+    """QNAME of the first line in [start, end) that the line filter of :201-217 keeps (None when there is none)."""
+    with open(path, 'rb') as fh:
+        fh.seek(start)
+        left, carry = end - start, b''
+        while left > 0:
+            buf = fh.read(min(1 << 20, left))
+            if not buf:
+                break
+            left -= len(buf)
+            lines = (carry + buf).split(b'\n')
+            carry = lines.pop() if left > 0 else b''
+            for ln in lines:
+                if ln.startswith(b'@'):
+                    continue
+                f = ln.strip().split()
+                if len(f) < 6:
+                    continue
+                try:
+                    flag = int(f[1])
+                except ValueError:
+                    return None  # (the tokeniser reports the line)
+                if (flag & 4) or f[5] == b'*':
+                    continue
+                return f[0].decode('utf-8', 'replace')
+    return None
+
+
+def clear_continued_heads(first_word_of, counts, firsts, lasts):
+    """The pieces of one record stream, tokenised independently (every piece's first record has its new-read bit set):
+    for every non-empty piece whose first retained QNAME equals the last retained QNAME in front of it, call
+    first_word_of(record index) to clear that bit.  -> the record offsets of the pieces."""
+    offs, prev = [0], None
+    for n, fq, lq in zip(counts, firsts, lasts):
+        if n and prev is not None and fq == prev:
+            first_word_of(offs[-1])
+        if n:
+            prev = lq
+        offs.append(offs[-1] + n)
+    return offs
+
+
+class _TensorOwner:
+    def __init__(self, t):
+        self.t = t
+
+    def free(self):
+        self.t = None
+
+
+def map_and_process_file_dist(args, path, acc2info, taxid2info, ctx, _want_lists=True, _resident=False):
+    """map_and_process_file with one process per GPU.  Rank 0 returns what map_and_process_file returns (None: a line
+    the reference cannot parse somewhere — it then takes the streaming path over the whole file, which reproduces the
+    reference's exception); the other ranks return 'done'."""
+    import torch
+    dist, rank, world, hip = ctx
+    acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
+    _ = taxid2info['Unmapped']
+    names = [None] * len(acc_index)
+    for a, i in acc_index.items():
+        names[i] = a
+    index = hip.acc_index(names)
+    start, end = sam_range_of_rank(path, rank, world)
+    d_text = batch = None
+    bad = 0
+    try:
+        try:
+            d_text, size = hip.upload_file(path, offset=start, length=end - start)
+            batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '')
+        except (_hip.SamParseError, _hip.HipError):
+            bad = 1
+        finally:
+            if d_text is not None:
+                d_text.free()
+        n = batch.count if batch is not None else 0
+        fq = (first_retained_qname(path, start, end) or '') if n else ''
+        lq = batch.last_qname if n else ''
+        # every rank learns every piece's size, state and boundary names (two small all-gathers)
+        word = torch.tensor([n, bad], dtype=torch.int64, device='cuda')
+        words = [torch.zeros_like(word) for _ in range(world)]
+        dist.all_gather(words, word)
+        counts = [int(w[0].item()) for w in words]
+        if any(int(w[1].item()) for w in words):
+            return None if rank == 0 else 'done'
+        nm = torch.zeros(2, 512, dtype=torch.uint8, device='cuda')
+        for row, q in enumerate((fq, lq)):
+            b = q.encode('utf-8')[:511]
+            if b:
+                nm[row, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+        nms = [torch.zeros_like(nm) for _ in range(world)]
+        dist.all_gather(nms, nm)
+        as_str = lambda t: bytes(t.cpu().numpy().tobytes()).split(b'\0', 1)[0].decode('utf-8', 'replace')
+        firsts, lasts = [as_str(t[0]) for t in nms], [as_str(t[1]) for t in nms]
+        mine = None
+        if n:
+            mine = torch.as_tensor(_CudaWords(batch.ptr, 4 * n), device='cuda')
+        if rank != 0:
+            if n:
+                dist.send(mine, dst=0)
+            return 'done'
+        total = sum(counts)
+        buf = torch.zeros(max(4 * total, 4), dtype=torch.int32, device='cuda')
+        offs = clear_continued_heads(lambda i: None, counts, firsts, lasts)  # (offsets first; the bits after the pieces are in)
+        if n:
+            buf[: 4 * n] = mine
+        for r in range(1, world):
+            if counts[r]:
+                dist.recv(buf[4 * offs[r]: 4 * offs[r + 1]], src=r)
+
+        def clear(i):
+            buf[4 * i] &= 0x7FFFFFFF  # ref_new is the record's first word; NEW is its top bit
+        clear_continued_heads(clear, counts, firsts, lasts)
+        torch.cuda.current_stream().synchronize()
+        res = hip.profile_assign_dev_records(buf.data_ptr(), total, ref2tax, len(taxids), float(args.pct_id),
+                                             [_TensorOwner(buf)], resident=_resident)
+    finally:
+        index.free()
+        if batch is not None:
+            batch.free()
+    if not _want_lists:
+        res = dict(res, taxids=taxids)
+    return assemble_taxids2abs(args, res, taxids, taxid2info, want_lists=_want_lists)
+
+
+class _CudaWords:
+    """n int32 words of device memory, for torch.as_tensor (zero-copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<i4', 'data': (int(ptr), False), 'version': 2}
+
+
 def map_and_process(args, instream, acc2info, taxid2info, _assign=None, _want_lists=True, _resident=False):
     """Reference signature (:193).  `_assign` is a test seam; product code never passes it."""
     acc_index, taxids, ref2tax = dense_tables(acc2info, taxid2info)
@@ -565,10 +728,19 @@ def compute_abundances(args, infile, acc2info, tax2info):
     on_device = bool(getattr(args, 'device_multimap', False))
     done = None
     seams_untouched = _device_tokenise is tokenise_sam_device and _device_assign is _DEVICE_ASSIGN  # (tests reroute them)
-    if args.input_type == 'sam' and seams_untouched:
+    paf = bool(getattr(args, 'paf_input', False))
+    if args.input_type == 'sam' and seams_untouched and not paf:
+        from .select_db import dist_context
+        ctx = dist_context()
+        if ctx is not None:  # one process per GPU: the ranks tokenise the text between them, rank 0 does the rest
+            done = map_and_process_file_dist(args, infile, acc2info, tax2info, ctx, _want_lists=False, _resident=on_device)
+            if done == 'done':
+                instream.close()
+                return None
+            seams_untouched = seams_untouched and done is not None  # (None: rank 0 streams the file, alone)
+    if args.input_type == 'sam' and seams_untouched and done is None:
         # a plain file (SAM, or a PAF replay): all the way on the device
-        done = map_and_process_file(args, infile, acc2info, tax2info, _want_lists=False, _resident=on_device,
-                                    _paf=bool(getattr(args, 'paf_input', False)))
+        done = map_and_process_file(args, infile, acc2info, tax2info, _want_lists=False, _resident=on_device, _paf=paf)
     if done is None:
         done = map_and_process(args, instream, acc2info, tax2info, _want_lists=False, _resident=on_device)
     taxids2abs, mm, low_mem_mmap = done
@@ -594,7 +766,11 @@ def gather_results(args, acc2info, taxid2info):
     merged = {}
     for infile in args.infiles:
         echo('Computing abundances for input file: ' + infile, args.verbose)
-        for clade, row in compute_abundances(args, infile, acc2info, taxid2info).items():
+        clades = compute_abundances(args, infile, acc2info, taxid2info)
+        if clades is None:  # a rank other than 0 of a multi-GPU launch: its share of the work is done
+            args._not_root = True
+            continue
+        for clade, row in clades.items():
             if clade in merged:
                 merged[clade][-1] += row[-1]
             else:
@@ -649,10 +825,12 @@ def map_main(args=None):
             args.input_type, args.paf_input = 'sam', True
         else:
             args.input_type = cli.sniff_reads_type(first)
-    open(args.output, 'w').close()
+    if int(os.environ.get('RANK', '0')) == 0:
+        open(args.output, 'w').close()
     acc2info, taxid2info = get_acc2info(args)
     rank_results = gather_results(args, acc2info, taxid2info)
-    write_results(args, rank_results)
+    if not getattr(args, '_not_root', False):
+        write_results(args, rank_results)
 
 
 if __name__ == '__main__':

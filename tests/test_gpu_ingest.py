@@ -95,6 +95,47 @@ def test_sam_tokeniser_matches_host(hip, monkeypatch, kind, seed, n):
     assert np.array_equal(got3, want)
 
 
+@pytest.mark.parametrize("kind,seed,n", [("single", 5, 6000), ("paired", 6, 4000)])
+def test_sam_pieces_tokenised_on_the_device_give_the_whole_files_records(hip, tmp_path, kind, seed, n):
+    """What the ranks of a multi-GPU map_and_profile do, on one GPU: line-aligned byte ranges of the SAM file go up
+    (Hip.upload_file with offset / length) and are tokenised independently; with the new-read bit cleared wherever a
+    piece's first retained QNAME equals the last retained QNAME in front of it, the concatenation is the record stream
+    of the whole file (what rank 0 then runs stage C on) — for several world sizes, with multi-line reads across cuts."""
+    dbtext, accs, taxids = samgen.make_dbinfo(seed=8, n_species=25)
+    text = (samgen.make_sam_single if kind == "single" else samgen.make_sam_paired)(seed, n, accs, taxids)
+    path = tmp_path / "x.sam"
+    path.write_text(text)
+    idx = _acc_index(accs)
+    want = mp.tokenise_sam(text.splitlines(True), idx)
+    names = [None] * len(idx)
+    for a, i in idx.items():
+        names[i] = a
+    index = hip.acc_index(names)
+    try:
+        for world in (1, 2, 3, 7, 40):
+            pieces, firsts, lasts = [], [], []
+            for r in range(world):
+                a, b = mp.sam_range_of_rank(str(path), r, world)
+                d_text, size = hip.upload_file(str(path), offset=a, length=b - a)
+                batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, "")
+                recs = np.zeros(batch.count, dtype=mp._hip.REC_DTYPE)
+                if batch.count:
+                    hip._chk(hip.lib.mg_sam_batch_download(batch.handle, recs.ctypes.data_as(__import__("ctypes").c_void_p)))
+                pieces.append(recs)
+                firsts.append((mp.first_retained_qname(str(path), a, b) or "") if batch.count else "")
+                lasts.append(batch.last_qname if batch.count else "")
+                batch.free()
+                d_text.free()
+            got = np.concatenate(pieces)
+
+            def clear(i):
+                got["ref_new"][i] &= 0x7FFFFFFF
+            mp.clear_continued_heads(clear, [len(p) for p in pieces], firsts, lasts)
+            assert np.array_equal(got, want), world
+    finally:
+        index.free()
+
+
 def test_sam_tokeniser_raises_what_the_reference_raises(hip):
     dbtext, accs, taxids = samgen.make_dbinfo(seed=8, n_species=5)
     idx = _acc_index(accs)

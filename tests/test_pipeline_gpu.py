@@ -163,6 +163,16 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert (tmpd2 / "cmash_query_results.csv").read_text().splitlines() == csv, reads_file
         assert (tmpd2 / "subset_db_info.txt").read_text().splitlines() == sub
+    # ... and stage C the same way: the ranks tokenise the SAM text between them, rank 0 gathers the records and writes
+    # the same CAMI file as the single process (which got these lines from the stub aligner)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MG_FORCE_DIST="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out2 = tmp_path / "abundances_dist.tsv"
+    r = subprocess.run([sys.executable, "-m", "metalign_amd.map_and_profile", str(sam), str(data), "--dbinfo",
+                        str(tmpd / "subset_db_info.txt"), "--output", str(out2), "--sampleID", "s1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert out2.read_text() == text
 
 
 def test_exchange_path_on_one_gpu_under_rccl():

@@ -230,3 +230,52 @@ def test_record_aligned_byte_ranges_of_a_multi_gpu_launch(tmp_path):
         assert ranges[0][0] == 0 and ranges[-1][1] == size
         assert all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
         assert all(a in hdr and b in hdr and a <= b for a, b in ranges), (world, ranges)
+
+
+def test_sam_pieces_of_a_multi_gpu_launch_give_the_same_record_stream(tmp_path):
+    """map_and_profile under torch.distributed.run: the ranks tokenise line-aligned byte ranges of the SAM file
+    independently (every piece's first record gets its new-read bit) and rank 0 clears that bit wherever a piece's
+    first retained QNAME equals the last retained QNAME in front of it (clear_continued_heads).  Emulated here with the
+    host tokeniser on the pieces: for every world size the concatenation equals the tokenisation of the whole file —
+    with reads of several lines straddling the cuts, header and unmapped lines at the cuts, empty pieces."""
+    import numpy as np
+    from metalign_amd import _hip
+    from metalign_amd import map_and_profile as mp
+    rng = np.random.default_rng(5)
+    accs = ["ACC%03d.1" % i for i in range(20)]
+    idx = {a: i for i, a in enumerate(accs)}
+    lines = ["@HD\tVN:1.6", "@SQ\tSN:ACC000.1\tLN:1000"]
+    for r in range(400):
+        nl = int(rng.integers(1, 6))
+        for j in range(nl):
+            flag = 0 if j == 0 else 256
+            if rng.random() < 0.1:
+                lines.append("q%d\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII" % r)  # unmapped: filtered, same QNAME
+            seq = "ACGT" * int(rng.integers(5, 40)) if j == 0 else "*"
+            lines.append("\t".join(["q%d" % r, str(flag), accs[int(rng.integers(0, 20))], "1", "60", "%dM" % (len(seq) if j == 0 else 50),
+                                     "*", "0", "0", seq, "I" * len(seq) if j == 0 else "*", "NM:i:0"]))
+        if r % 50 == 7:
+            lines.append("@CO\ta comment in the middle")
+    text = "\n".join(lines) + "\n"
+    path = tmp_path / "a.sam"
+    path.write_text(text)
+    whole = mp.tokenise_sam(text.splitlines(True), idx)
+    size = len(text)
+    for world in (1, 2, 3, 5, 8, 64, 900):
+        ranges = [mp.sam_range_of_rank(str(path), r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == size and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+        assert all(a == 0 or text[a - 1] == "\n" for a, _ in ranges)
+        pieces, firsts, lasts = [], [], []
+        for a, b in ranges:
+            tk = mp._Tokeniser(idx)
+            for ln in text[a:b].splitlines(True):
+                tk.feed(ln)
+            pieces.append(tk.records())
+            firsts.append(mp.first_retained_qname(str(path), a, b) or "")
+            lasts.append(tk.prev)
+        got = np.concatenate(pieces) if pieces else np.zeros(0, dtype=_hip.REC_DTYPE)
+
+        def clear(i):
+            got["ref_new"][i] &= 0x7FFFFFFF
+        offs = mp.clear_continued_heads(clear, [len(p) for p in pieces], firsts, lasts)
+        assert offs[-1] == len(whole) and np.array_equal(got, whole), world
