@@ -52,6 +52,12 @@ def main(argv=None):
     _apply_modes(args)
     _wire_stages(args)
     select.select_main(args)
+    import os
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and int(os.environ.get('RANK', '0')) != 0:
+        # a multi-GPU launch (torch.distributed.run): the ranks share stages A + B; rank 0 aligns and profiles
+        if not args.keep_temp_files:
+            shutil.rmtree(args.temp_dir, ignore_errors=True)
+        return
     mapper.map_main(args)
     if not args.keep_temp_files:
         shutil.rmtree(args.temp_dir, ignore_errors=True)
