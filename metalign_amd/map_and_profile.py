@@ -517,6 +517,7 @@ def map_and_process_file_dist(args, path, acc2info, taxid2info, ctx, _want_lists
         if rank != 0:
             if n:
                 dist.send(mine, dst=0)
+                torch.cuda.current_stream().synchronize()  # (the records are freed on the way out)
             return 'done'
         total = sum(counts)
         buf = torch.zeros(max(4 * total, 4), dtype=torch.int32, device='cuda')
