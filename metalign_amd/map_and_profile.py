@@ -826,6 +826,8 @@ def map_main(args=None):
             args.input_type, args.paf_input = 'sam', True
         else:
             args.input_type = cli.sniff_reads_type(first)
+    if int(os.environ.get('RANK', '0')) != 0 and (args.input_type != 'sam' or getattr(args, 'paf_input', False)):
+        return  # a multi-GPU launch shares only SAM files between the ranks; anything else is rank 0's alone
     if int(os.environ.get('RANK', '0')) == 0:
         open(args.output, 'w').close()
     acc2info, taxid2info = get_acc2info(args)
