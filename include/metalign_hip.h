@@ -82,6 +82,11 @@ int mg_device_name(char* buf, int cap);
  * metalign_amd/map_and_profile.py falls back to chunks when the text does not fit) and what tests/ and tools/soak.py
  * watch for growth over thousands of passes.  No counterpart in the reference (host memory is Python's). */
 int mg_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* pooled_bytes);
+/* Gives the blocks the caching allocator holds for reuse, and the library's grow-only scratch buffers (counting tables
+ * among them), back to the runtime (after waiting for the device; they are allocated again on demand).  Worth
+ * calling once after a first, worst-case-sized pass: the first stage-A pass of a k has no distinct-count ratio yet and
+ * sizes its tables for the worst case (tens of GB against a dense table), which the allocator would otherwise keep. */
+int mg_mem_trim(void);
 
 int mg_dev_malloc(void** d_ptr, uint64_t bytes);
 int mg_dev_free(void* d_ptr);

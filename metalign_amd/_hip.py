@@ -24,7 +24,7 @@ MAX_K = 64
 # every symbol include/metalign_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
-    "mg_device_name", "mg_mem_info", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
+    "mg_device_name", "mg_mem_info", "mg_mem_trim", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
@@ -560,6 +560,10 @@ class Hip:
         f, t, p = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         self._chk(self.lib.mg_mem_info(ctypes.byref(f), ctypes.byref(t), ctypes.byref(p)))
         return f.value, t.value, p.value
+
+    def mem_trim(self):
+        """Cached (free) blocks of the library's allocator back to the runtime."""
+        self._chk(self.lib.mg_mem_trim())
 
     def sync(self):
         self._chk(self.lib.mg_sync())

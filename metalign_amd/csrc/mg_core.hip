@@ -295,6 +295,16 @@ int mg_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* pooled_by
   return MG_OK;
 }
 
+int mg_mem_trim(void) {
+  MG_REQUIRE_READY();
+  MG_HIP(hipDeviceSynchronize());  // nothing is in flight: the grow-only scratch buffers can go as well
+  mg::scratch_release_all();
+  mg::ctx().k3_priv_ptr = nullptr;  // (stage C's private bins are scratch: their all-zero invariant goes with them)
+  mg::ctx().k3_priv_nb = 0;
+  mg::pool_release_all();
+  return MG_OK;
+}
+
 int mg_device_name(char* buf, int cap) {
   MG_REQUIRE_READY();
   hipDeviceProp_t prop;

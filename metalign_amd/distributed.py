@@ -523,6 +523,10 @@ class ShardJob:
         self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
         if hasattr(self.engine, "prime") and len(roffsets) > 1:
             self.engine.prime(self.ks, self.hmaxs, self.s)
+            # the priming pass was sized for the worst case (no distinct-count ratio yet: tens of GB against a dense
+            # table); its blocks would stay cached for the life of the process
+            if hasattr(self.engine, "hip"):
+                self.engine.hip.mem_trim()
         if hasattr(self.engine, "hip"):
             # stage C runs on the library's second stream: its latency-bound passes overlap stage A's tail, stage B
             # and (with the exchange) the collectives  (MG_SINGLE_STREAM=1: everything on one stream, for profiles in
