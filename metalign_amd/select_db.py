@@ -353,10 +353,11 @@ def run_sketch_steps(args):
     sks = None
     for reads in iter_read_batches(hip, args.reads, args.input_type, batch_bytes):
         d_b_ptr, d_o_ptr = reads.device_ptrs()
-        if sks is None and reads.count > 4_000_000:
+        if sks is None and reads.count > int(os.environ.get('MG_PRIME_READS', 4_000_000)):
             # the library sizes a k's counting table from the distinct-to-candidate ratio of its previous call and has
             # none yet (worst case: tens of GB to clear and sort against a dense table): the first million reads tell it
-            for sk in hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, 1_000_000, table.ks, hmaxs, s, filts):
+            for sk in hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, min(1_000_000, max(reads.count // 4, 1)), table.ks,
+                                                       hmaxs, s, filts):
                 sk.resolve()
                 sk.free()
         part = hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, reads.count, table.ks, hmaxs, s, filts)

@@ -132,6 +132,7 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
     # inflated on the host and cut the same way; FASTA pieces are cut at headers.  Same CSV every time.
     import gzip
     monkeypatch.setenv("MG_READ_BATCH_BYTES", "25000")
+    monkeypatch.setenv("MG_PRIME_READS", "10")  # (and the table-sizing pass over a prefix of the first piece, which only large inputs take)
     gzq = tmp_path / "sample_gz.fq.gz"
     with open(fq, "rb") as src_fh, gzip.open(gzq, "wb") as dst:
         dst.write(src_fh.read())
@@ -147,6 +148,7 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
         select_db.select_main(args)
         assert (tmpj / "cmash_query_results.csv").read_text().splitlines() == csv, reads_file
     monkeypatch.delenv("MG_READ_BATCH_BYTES")
+    monkeypatch.delenv("MG_PRIME_READS")
     # the same command as ONE RANK of a torch.distributed.run launch (world size 1, every collective in the path:
     # MG_FORCE_DIST=1): reads taken by record-aligned byte range, table by hash range, distributed.ShardJob's exchange;
     # rank 0 writes the same CSV and the same subset db_info.  A child process: torch.distributed stays out of this one.
