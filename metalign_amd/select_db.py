@@ -295,9 +295,10 @@ def iter_read_batches(hip, path, kind, batch_bytes):
         return
     fmt = 'fastq' if kind == 'fastq' else 'fasta_ml'
     carry = b''
+    piece = min(batch_bytes, 2 << 30)  # (a piece passes through host memory: bounded whatever the device could take)
     with (gzip.open(path, 'rb') if gz else open(path, 'rb')) as fh:
         while True:
-            buf = fh.read(batch_bytes)
+            buf = fh.read(piece)
             data = carry + buf
             if not buf:  # end of file: what is left is the last record (with or without a final newline)
                 if data.strip():
