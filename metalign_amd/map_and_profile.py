@@ -460,6 +460,47 @@ def clear_continued_heads(first_word_of, counts, firsts, lasts):
     return offs
 
 
+def gather_record_pieces(torch, dist, rank, world, mine, n, first_q, last_q, bad, device):
+    """The exchange of map_and_process_file_dist, on whatever device the process group runs (cuda under RCCL, cpu under
+    gloo in the tests).  mine: this rank's n records as 4 n int32 words (None when n == 0).  Rank 0 gets
+    (all records in rank order with the new-read bits at the cuts settled, total); the others 'done'; None (rank 0) when
+    some rank could not tokenise its piece."""
+    # every rank learns every piece's size, state and boundary names (two small all-gathers)
+    word = torch.tensor([n, bad], dtype=torch.int64, device=device)
+    words = [torch.zeros_like(word) for _ in range(world)]
+    dist.all_gather(words, word)
+    counts = [int(w[0].item()) for w in words]
+    if any(int(w[1].item()) for w in words):
+        return None if rank == 0 else 'done'
+    nm = torch.zeros(2, 512, dtype=torch.uint8)
+    for row, q in enumerate((first_q, last_q)):
+        b = q.encode('utf-8')[:511]
+        if b:
+            nm[row, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+    nm = nm.to(device)
+    nms = [torch.zeros_like(nm) for _ in range(world)]
+    dist.all_gather(nms, nm)
+    as_str = lambda t: bytes(t.cpu().numpy().tobytes()).split(b'\0', 1)[0].decode('utf-8', 'replace')
+    firsts, lasts = [as_str(t[0]) for t in nms], [as_str(t[1]) for t in nms]
+    if rank != 0:
+        if n:
+            dist.send(mine, dst=0)
+        return 'done'
+    total = sum(counts)
+    buf = torch.zeros(max(4 * total, 4), dtype=torch.int32, device=device)
+    offs = clear_continued_heads(lambda i: None, counts, firsts, lasts)  # (offsets first; the bits after the pieces are in)
+    if n:
+        buf[: 4 * n] = mine
+    for r in range(1, world):
+        if counts[r]:
+            dist.recv(buf[4 * offs[r]: 4 * offs[r + 1]], src=r)
+
+    def clear(i):
+        buf[4 * i] &= 0x7FFFFFFF  # ref_new is the record's first word; NEW is its top bit
+    clear_continued_heads(clear, counts, firsts, lasts)
+    return buf, total
+
+
 class _TensorOwner:
     def __init__(self, t):
         self.t = t
@@ -495,42 +536,13 @@ def map_and_process_file_dist(args, path, acc2info, taxid2info, ctx, _want_lists
         n = batch.count if batch is not None else 0
         fq = (first_retained_qname(path, start, end) or '') if n else ''
         lq = batch.last_qname if n else ''
-        # every rank learns every piece's size, state and boundary names (two small all-gathers)
-        word = torch.tensor([n, bad], dtype=torch.int64, device='cuda')
-        words = [torch.zeros_like(word) for _ in range(world)]
-        dist.all_gather(words, word)
-        counts = [int(w[0].item()) for w in words]
-        if any(int(w[1].item()) for w in words):
-            return None if rank == 0 else 'done'
-        nm = torch.zeros(2, 512, dtype=torch.uint8, device='cuda')
-        for row, q in enumerate((fq, lq)):
-            b = q.encode('utf-8')[:511]
-            if b:
-                nm[row, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
-        nms = [torch.zeros_like(nm) for _ in range(world)]
-        dist.all_gather(nms, nm)
-        as_str = lambda t: bytes(t.cpu().numpy().tobytes()).split(b'\0', 1)[0].decode('utf-8', 'replace')
-        firsts, lasts = [as_str(t[0]) for t in nms], [as_str(t[1]) for t in nms]
-        mine = None
-        if n:
-            mine = torch.as_tensor(_CudaWords(batch.ptr, 4 * n), device='cuda')
-        if rank != 0:
-            if n:
-                dist.send(mine, dst=0)
+        mine = torch.as_tensor(_CudaWords(batch.ptr, 4 * n), device='cuda') if n else None
+        got = gather_record_pieces(torch, dist, rank, world, mine, n, fq, lq, bad, 'cuda')
+        if got is None or got == 'done':
+            if rank != 0 and n:
                 torch.cuda.current_stream().synchronize()  # (the records are freed on the way out)
-            return 'done'
-        total = sum(counts)
-        buf = torch.zeros(max(4 * total, 4), dtype=torch.int32, device='cuda')
-        offs = clear_continued_heads(lambda i: None, counts, firsts, lasts)  # (offsets first; the bits after the pieces are in)
-        if n:
-            buf[: 4 * n] = mine
-        for r in range(1, world):
-            if counts[r]:
-                dist.recv(buf[4 * offs[r]: 4 * offs[r + 1]], src=r)
-
-        def clear(i):
-            buf[4 * i] &= 0x7FFFFFFF  # ref_new is the record's first word; NEW is its top bit
-        clear_continued_heads(clear, counts, firsts, lasts)
+            return got
+        buf, total = got
         torch.cuda.current_stream().synchronize()
         res = hip.profile_assign_dev_records(buf.data_ptr(), total, ref2tax, len(taxids), float(args.pct_id),
                                              [_TensorOwner(buf)], resident=_resident)

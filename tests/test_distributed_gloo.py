@@ -271,6 +271,69 @@ def test_sharding_matches_single_process(tmp_path, world):
         assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 1: True, 2: True, 3: True})
 
 
+def _sam_worker(rank, world, port, tmpdir):
+    """One rank of map_and_profile's multi-GPU launch, on the CPU over gloo: its line-aligned byte range of the SAM file
+    tokenised (host tokeniser here), then map_and_profile.gather_record_pieces — the all-gathers, send / recv, the
+    new-read bits at the cuts — exactly as map_and_process_file_dist calls it with device tensors under RCCL."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from metalign_amd import map_and_profile as mp
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    path = os.path.join(tmpdir, "a.sam")
+    text = open(path).read()
+    idx = {"ACC%03d.1" % i: i for i in range(20)}
+    res = {}
+    for case in ("records", "one rank cannot tokenise its piece"):
+        a, b = mp.sam_range_of_rank(path, rank, world)
+        tk = mp._Tokeniser(idx)
+        for ln in text[a:b].splitlines(True):
+            tk.feed(ln)
+        recs = tk.records()
+        n = len(recs)
+        mine = torch.from_numpy(np.ascontiguousarray(recs).view(np.int32).copy()) if n else None
+        bad = int(case != "records" and rank == world - 1)
+        got = mp.gather_record_pieces(torch, dist, rank, world, mine, n, (mp.first_retained_qname(path, a, b) or "") if n else "",
+                                      tk.prev if n else "", bad, "cpu")
+        if case != "records":
+            res[case] = got is None if rank == 0 else got == "done"
+        elif rank != 0:
+            res[case] = got == "done"
+        else:
+            buf, total = got
+            whole = mp.tokenise_sam(text.splitlines(True), idx)
+            res[case] = total == len(whole) and np.array_equal(buf[: 4 * total].numpy().view(whole.dtype), whole)
+    with open(os.path.join(tmpdir, "sam_rank%d.txt" % rank), "w") as fh:
+        fh.write(repr(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sam_record_pieces_gathered_over_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    import socket
+    rng = np.random.default_rng(world)
+    lines = ["@HD\tVN:1.6"]
+    for r in range(300):
+        for j in range(int(rng.integers(1, 5))):
+            seq = "ACGT" * int(rng.integers(5, 30)) if j == 0 else "*"
+            lines.append("\t".join(["q%d" % r, "0" if j == 0 else "256", "ACC%03d.1" % int(rng.integers(0, 20)), "1", "60",
+                                     "%dM" % (len(seq) if j == 0 else 40), "*", "0", "0", seq, "I" * len(seq) if j == 0 else "*",
+                                     "NM:i:0"]))
+    (tmp_path / "a.sam").write_text("\n".join(lines) + "\n")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sam_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / ("sam_rank%d.txt" % r)).read_text() == repr({"records": True, "one rank cannot tokenise its piece": True})
+
+
 def test_shard_reference_equals_c_oracle_unsharded():
     """The shard-aware Python restatement used by the engine above == the pinned C oracle on whole streams."""
     import oracle
