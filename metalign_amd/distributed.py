@@ -429,6 +429,50 @@ def table_max_hash(dbh, dbo):
     return int(np.asarray(dbh)[tails.astype(np.int64)].max()) if len(tails) else 0
 
 
+class _HostStagedGloo:
+    """torch.distributed over GLOO for tensors that live on the GPU, staged through host memory (gloo moves CPU tensors).
+    RCCL is the product's transport; this exists so that the multi-rank path can run with the REAL kernels where RCCL
+    cannot — two ranks on one GPU ("Duplicate GPU detected") — i.e. for tests on single-GPU machines."""
+
+    def __init__(self, dist, torch):
+        self._d, self._t = dist, torch
+
+    def __getattr__(self, name):  # get_backend, barrier, ReduceOp, get_rank, ...
+        return getattr(self._d, name)
+
+    def all_gather(self, outs, t):
+        cin = t.cpu()
+        couts = [self._t.empty(o.shape, dtype=o.dtype) for o in outs]
+        self._d.all_gather(couts, cin)
+        for o, c in zip(outs, couts):
+            o.copy_(c)
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        self._d.all_reduce(c, op=op if op is not None else self._d.ReduceOp.SUM)
+        t.copy_(c)
+
+    class _Op:
+        def __init__(self, fn, tensor, peer):
+            self.fn, self.tensor, self.peer = fn, tensor, peer
+
+    def P2POp(self, fn, tensor, peer):
+        return self._Op(fn, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        staged = []
+        for op in ops:
+            c = op.tensor.cpu() if op.fn is self._d.isend else self._t.empty(op.tensor.shape, dtype=op.tensor.dtype)
+            staged.append((op, c))
+        reqs = self._d.batch_isend_irecv([self._d.P2POp(op.fn, c, op.peer) for op, c in staged])
+        for r in reqs:
+            r.wait()
+        for op, c in staged:
+            if op.fn is self._d.irecv:
+                op.tensor.copy_(c)
+        return []
+
+
 class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 
@@ -460,6 +504,8 @@ class ShardJob:
                                         % (getattr(hip, "main_stream", None), cur))
             self.engine = HipEngine(hip, tm)
         self.device = getattr(self.engine, "device", "cuda")
+        if dist is not None and self.device != "cpu" and dist.get_backend() == "gloo":
+            self.dist = _HostStagedGloo(dist, self.torch)  # (tests: several ranks on one GPU)
 
     def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo=None, ntax=None):
         """recs: this rank's shard (starts on a read boundary).

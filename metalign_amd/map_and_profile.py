@@ -536,16 +536,24 @@ def map_and_process_file_dist(args, path, acc2info, taxid2info, ctx, _want_lists
         n = batch.count if batch is not None else 0
         fq = (first_retained_qname(path, start, end) or '') if n else ''
         lq = batch.last_qname if n else ''
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'  # (gloo — tests: staged through the host)
         mine = torch.as_tensor(_CudaWords(batch.ptr, 4 * n), device='cuda') if n else None
-        got = gather_record_pieces(torch, dist, rank, world, mine, n, fq, lq, bad, 'cuda')
+        if mine is not None and dev == 'cpu':
+            mine = mine.cpu()
+        got = gather_record_pieces(torch, dist, rank, world, mine, n, fq, lq, bad, dev)
         if got is None or got == 'done':
             if rank != 0 and n:
                 torch.cuda.current_stream().synchronize()  # (the records are freed on the way out)
             return got
         buf, total = got
-        torch.cuda.current_stream().synchronize()
-        res = hip.profile_assign_dev_records(buf.data_ptr(), total, ref2tax, len(taxids), float(args.pct_id),
-                                             [_TensorOwner(buf)], resident=_resident)
+        if dev == 'cpu':
+            d_all = hip.array(buf[: max(4 * total, 4)].numpy())
+            ptr, owner = d_all.ptr, d_all
+        else:
+            torch.cuda.current_stream().synchronize()
+            ptr, owner = buf.data_ptr(), _TensorOwner(buf)
+        res = hip.profile_assign_dev_records(ptr, total, ref2tax, len(taxids), float(args.pct_id), [owner],
+                                             resident=_resident)
     finally:
         index.free()
         if batch is not None:

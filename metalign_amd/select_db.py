@@ -218,13 +218,15 @@ def dist_context():
         return None
     import torch
     import torch.distributed as dist
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    # (MG_DIST_BACKEND=gloo — tests: several ranks on ONE GPU, which RCCL refuses; the ranks then share device
+    # LOCAL_RANK modulo the device count and the collectives are staged through the host)
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if not dist.is_initialized():
         stream = torch.cuda.Stream()  # explicit: collectives are ordered with the library's kernels on it
         torch.cuda.set_stream(stream)
         _dist_keep.append(stream)
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('MG_DIST_BACKEND', 'nccl'))
     hip = _hip.Hip.get(local, stream=torch.cuda.current_stream().cuda_stream)
     return dist, dist.get_rank(), dist.get_world_size(), hip
 
@@ -242,8 +244,10 @@ def run_sketch_steps_dist(args, ctx):
         table_dir = formats.default_table_dir(args.data)
     table = formats.SketchTable(table_dir)
 
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+
     def gather(x):
-        t = torch.tensor([int(x)], dtype=torch.int64, device='cuda')
+        t = torch.tensor([int(x)], dtype=torch.int64, device=dev)
         out = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(out, t)
         return [int(o.item()) for o in out]

@@ -1,0 +1,79 @@
+"""Helper of tests/test_pipeline_gpu.py: TWO ranks (torch.distributed.run --nproc-per-node 2) sharing ONE GPU, every
+kernel of the multi-GPU path real (stage A per read shard, slicing by hash range, the exchange of slices, the merge of
+slices from two different ranks, stage B on a table slice, stage C with the carried state across the shard edge), the
+collectives over gloo with the tensors staged through the host (RCCL refuses two ranks on one device).  Plain steps and
+the four-passes-in-flight schedule, single k and the fused multi-k launch, against the oracle on the unsharded input."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import oracle  # noqa: E402
+from metalign_amd import synth  # noqa: E402
+from metalign_amd._hip import Hip  # noqa: E402
+from metalign_amd.distributed import ShardJob  # noqa: E402
+
+torch.cuda.set_device(0)
+stream = torch.cuda.Stream()
+torch.cuda.set_stream(stream)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+hip = Hip.get(0, stream=stream.cuda_stream)
+oracle.build()
+G = 60
+gb, go = synth.make_genomes(G, 20000)
+rb, ro, src = synth.make_reads(gb, go, 80000, npresent=9)
+recs = synth.make_alignment_records(src + 1, G + 1)
+ref2tax = np.arange(G + 1, dtype=np.uint32)
+want = oracle.profile_assign(recs, ref2tax, G + 1, 0.5)
+# shards: reads and records in `world` contiguous parts (records cut on read boundaries)
+nreads = len(ro) - 1
+ncuts = [nreads * i // world for i in range(world + 1)]
+starts = np.nonzero(recs["ref_new"] >> 31)[0]
+rcuts = [0] + [int(starts[len(starts) * i // world]) for i in range(1, world)] + [len(recs)]
+my_rb = rb[int(ro[ncuts[rank]]): int(ro[ncuts[rank + 1]])]
+my_ro = ro[ncuts[rank]: ncuts[rank + 1] + 1] - ro[ncuts[rank]]
+my_recs = recs[rcuts[rank]: rcuts[rank + 1]]
+for kspec in (21, [21, 31, 51]):
+    ks = [kspec] if np.isscalar(kspec) else kspec
+    tabs = [hip.sketch_genomes(gb, go, k, 200) for k in ks]
+    job = ShardJob(hip, dist, rank, world, k=kspec)
+    if np.isscalar(kspec):
+        job.load(my_rb, my_ro, my_recs, ref2tax, tabs[0][0], tabs[0][1])
+    else:
+        job.load(my_rb, my_ro, my_recs, ref2tax, [t[0] for t in tabs], [t[1] for t in tabs])
+    outs = [job.step(want_multimapped=True), job.run(4, want_multimapped=True), job.step(want_multimapped=True)]
+    for idx, got in enumerate(outs):
+        for ki, k in enumerate(ks):
+            dbh, dbo = tabs[ki]
+            oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
+            ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
+            assert np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes), (rank, idx, k)
+            nfiltered = len(oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])
+            assert got["sketch_sizes"][ki] == nfiltered, (rank, k, got["sketch_sizes"][ki], nfiltered)
+        for key in ("count", "bases", "first_seen"):
+            assert np.array_equal(got[key], want[key]), (rank, idx, key)
+        assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
+        # every rank holds the multimapped reads of ITS shard (global read indices): in rank order they are the stream's
+        parts = [None] * world
+        dist.all_gather_object(parts, tuple(np.asarray(x) for x in got["multimapped"]))
+        tax = np.concatenate([p[1] for p in parts])
+        hl = np.concatenate([p[2] for p in parts])
+        rd = np.concatenate([p[3] for p in parts])
+        off, base = [np.zeros(1, dtype=np.uint64)], 0
+        for p in parts:
+            off.append(np.asarray(p[0][1:], dtype=np.uint64) + np.uint64(base))
+            base += int(p[0][-1])
+        off = np.concatenate(off)
+        assert np.array_equal(tax, want["mm_tax"]) and np.array_equal(hl, want["mm_hitlen"]), (rank, idx)
+        assert np.array_equal(rd, want["mm_read"]) and np.array_equal(off, want["mm_offsets"]), (rank, idx)
+dist.barrier()
+dist.destroy_process_group()
+print("two-ranks-one-gpu ok (rank %d)" % rank, flush=True)

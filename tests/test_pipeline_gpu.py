@@ -175,6 +175,25 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert out2.read_text() == text
+    # ... and both command lines with TWO and THREE ranks sharing this GPU (torch.distributed.run; gloo staged through
+    # the host, since RCCL refuses several ranks on one device): the same CSV, subset db_info and CAMI file
+    for world in (2, 3):
+        env = dict(os.environ, MG_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                  "--master-addr", "127.0.0.1", "--master-port", str(29560 + world)]
+        tmpw = tmp_path / ("tmp_world%d" % world)
+        r = subprocess.run(launch + ["-m", "metalign_amd.select_db", str(fq), str(data), "--temp_dir", str(tmpw), "--keep_temp_files",
+                                     "--sketch_table", str(data / "sketch_table")],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert (tmpw / "cmash_query_results.csv").read_text().splitlines() == csv, world
+        assert (tmpw / "subset_db_info.txt").read_text().splitlines() == sub
+        outw = tmp_path / ("abundances_world%d.tsv" % world)
+        r = subprocess.run(launch + ["-m", "metalign_amd.map_and_profile", str(sam), str(data), "--dbinfo",
+                                     str(tmpd / "subset_db_info.txt"), "--output", str(outw), "--sampleID", "s1"],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert outw.read_text() == text, world
 
 
 def test_exchange_path_on_one_gpu_under_rccl():
@@ -193,3 +212,23 @@ def test_exchange_path_on_one_gpu_under_rccl():
     r = subprocess.run([sys.executable, os.path.join(here, "dist_single_rank.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_several_ranks_on_one_gpu_with_the_real_kernels(world):
+    """The multi-GPU path at world size > 1 with every kernel real: `world` processes share this GPU (stage A per read
+    shard, slices by hash range, the merge of slices that come from different ranks, stage B on table slices, stage C
+    with the carried state across shard edges; plain steps and four passes in flight; one k and the fused multi-k
+    launch) and must give the oracle's unsharded results on every rank.  The collectives go over gloo with the tensors
+    staged through the host (distributed._HostStagedGloo): RCCL refuses two ranks on one device, so its transport is the
+    one thing this does not exercise (tests/dist_single_rank.py runs it at world size 1)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29590 + world),
+                        os.path.join(here, "dist_two_ranks_one_gpu.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    for rank in range(world):
+        assert "two-ranks-one-gpu ok (rank %d)" % rank in r.stdout
+
