@@ -260,6 +260,7 @@ def main():
         # torch first: the library then binds to the same HIP runtime and launches on torch's stream
         import torch
         import torch.distributed as dist
+        local_rank %= max(torch.cuda.device_count(), 1)  # (MG_DIST_BACKEND=gloo: several ranks on one GPU, for validation)
         torch.cuda.set_device(local_rank)
         # an explicit stream shared by torch (collectives synchronise with it) and the library's main stream
         torch_stream = torch.cuda.Stream()
@@ -269,7 +270,7 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world)
+            dist.init_process_group(os.environ.get("MG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize()
         finally:

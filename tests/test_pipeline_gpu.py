@@ -232,3 +232,23 @@ def test_several_ranks_on_one_gpu_with_the_real_kernels(world):
     for rank in range(world):
         assert "two-ranks-one-gpu ok (rank %d)" % rank in r.stdout
 
+
+def test_bench_command_of_the_driver_at_two_ranks_on_one_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`, the driver's multi-GPU command, with
+    both ranks on this GPU (MG_DIST_BACKEND=gloo): rank 0 prints exactly ONE JSON line on stdout, whole-job value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MG_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29597", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "1",
+                        "--reads", "200000", "--genomes", "200", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 200000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
