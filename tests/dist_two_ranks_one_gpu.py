@@ -43,7 +43,8 @@ my_ro = ro[ncuts[rank]: ncuts[rank + 1] + 1] - ro[ncuts[rank]]
 my_recs = recs[rcuts[rank]: rcuts[rank + 1]]
 for kspec in (21, [21, 31, 51]):
     ks = [kspec] if np.isscalar(kspec) else kspec
-    tabs = [hip.sketch_genomes(gb, go, k, 200) for k in ks]
+    # (MG_DEBUG_DISTINCT_HINT: every counting table undersized -> sketches redone, words stale, the all-gather repeated)
+    tabs = [hip.sketch_genomes(gb, go, k, 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200) for k in ks]
     job = ShardJob(hip, dist, rank, world, k=kspec)
     if np.isscalar(kspec):
         job.load(my_rb, my_ro, my_recs, ref2tax, tabs[0][0], tabs[0][1])
@@ -74,6 +75,8 @@ for kspec in (21, [21, 31, 51]):
         off = np.concatenate(off)
         assert np.array_equal(tax, want["mm_tax"]) and np.array_equal(hl, want["mm_hitlen"]), (rank, idx)
         assert np.array_equal(rd, want["mm_read"]) and np.array_equal(off, want["mm_offsets"]), (rank, idx)
+    if os.environ.get("MG_DEBUG_DISTINCT_HINT"):
+        assert getattr(job, "words_redone", 0) >= 1, getattr(job, "words_redone", 0)
 dist.barrier()
 dist.destroy_process_group()
 print("two-ranks-one-gpu ok (rank %d)" % rank, flush=True)

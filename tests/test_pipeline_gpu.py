@@ -214,8 +214,8 @@ def test_exchange_path_on_one_gpu_under_rccl():
     assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_several_ranks_on_one_gpu_with_the_real_kernels(world):
+@pytest.mark.parametrize("world,overflow", [(2, False), (3, False), (2, True)])
+def test_several_ranks_on_one_gpu_with_the_real_kernels(world, overflow):
     """The multi-GPU path at world size > 1 with every kernel real: `world` processes share this GPU (stage A per read
     shard, slices by hash range, the merge of slices that come from different ranks, stage B on table slices, stage C
     with the carried state across shard edges; plain steps and four passes in flight; one k and the fused multi-k
@@ -225,9 +225,12 @@ def test_several_ranks_on_one_gpu_with_the_real_kernels(world):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    if overflow:  # every counting table undersized: sketches redone on the list path, the words all-gather repeated
+        env["MG_DEBUG_DISTINCT_HINT"] = "0.0005"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                        "--master-addr", "127.0.0.1", "--master-port", str(29590 + world),
-                        os.path.join(here, "dist_two_ranks_one_gpu.py")], capture_output=True, text=True, timeout=900)
+                        "--master-addr", "127.0.0.1", "--master-port", str(29590 + world + (5 if overflow else 0)),
+                        os.path.join(here, "dist_two_ranks_one_gpu.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     for rank in range(world):
         assert "two-ranks-one-gpu ok (rank %d)" % rank in r.stdout
