@@ -41,11 +41,12 @@ rcuts = [0] + [int(starts[len(starts) * i // world]) for i in range(1, world)] +
 my_rb = rb[int(ro[ncuts[rank]]): int(ro[ncuts[rank + 1]])]
 my_ro = ro[ncuts[rank]: ncuts[rank + 1] + 1] - ro[ncuts[rank]]
 my_recs = recs[rcuts[rank]: rcuts[rank + 1]]
-for kspec in (21, [21, 31, 51]):
+# (k set, s): one k given bare, the fused multi-k launch, and bottom-s sketches (the sample-wide cut over the ranks' slices)
+for kspec, s_cut in ((21, 0), ([21, 31, 51], 0), (21, 500), ([21, 31, 51], 700)):
     ks = [kspec] if np.isscalar(kspec) else kspec
     # (MG_DEBUG_DISTINCT_HINT: every counting table undersized -> sketches redone, words stale, the all-gather repeated)
     tabs = [hip.sketch_genomes(gb, go, k, 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200) for k in ks]
-    job = ShardJob(hip, dist, rank, world, k=kspec)
+    job = ShardJob(hip, dist, rank, world, k=kspec, s=s_cut)
     if np.isscalar(kspec):
         job.load(my_rb, my_ro, my_recs, ref2tax, tabs[0][0], tabs[0][1])
     else:
@@ -54,11 +55,11 @@ for kspec in (21, [21, 31, 51]):
     for idx, got in enumerate(outs):
         for ki, k in enumerate(ks):
             dbh, dbo = tabs[ki]
-            oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
-            ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
-            assert np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes), (rank, idx, k)
-            nfiltered = len(oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])
-            assert got["sketch_sizes"][ki] == nfiltered, (rank, k, got["sketch_sizes"][ki], nfiltered)
+            fh, fc, ftr, _ = oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()), s=s_cut)  # the job's sketch
+            ohits, osizes = oracle.containment(fh, fc, ftr, 2, dbh, dbo)
+            assert np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes), (rank, idx, k, s_cut)
+            assert got["sketch_sizes"][ki] == len(fh), (rank, k, s_cut, got["sketch_sizes"][ki], len(fh))
+            assert not s_cut or (ftr and len(fh) == s_cut), (k, s_cut, len(fh))  # (the cut is exercised)
         for key in ("count", "bases", "first_seen"):
             assert np.array_equal(got[key], want[key]), (rank, idx, key)
         assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
