@@ -175,9 +175,9 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert out2.read_text() == text
-    # ... and both command lines with TWO and THREE ranks sharing this GPU (torch.distributed.run; gloo staged through
+    # ... and both command lines with two, three and eight ranks sharing this GPU (torch.distributed.run; gloo staged through
     # the host, since RCCL refuses several ranks on one device): the same CSV, subset db_info and CAMI file
-    for world in (2, 3):
+    for world in (2, 3, 8):
         env = dict(os.environ, MG_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
         launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                   "--master-addr", "127.0.0.1", "--master-port", str(29560 + world)]
@@ -214,7 +214,7 @@ def test_exchange_path_on_one_gpu_under_rccl():
     assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-@pytest.mark.parametrize("world,overflow", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,overflow", [(2, False), (3, False), (8, False), (2, True)])
 def test_several_ranks_on_one_gpu_with_the_real_kernels(world, overflow):
     """The multi-GPU path at world size > 1 with every kernel real: `world` processes share this GPU (stage A per read
     shard, slices by hash range, the merge of slices that come from different ranks, stage B on table slices, stage C
