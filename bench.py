@@ -70,6 +70,10 @@ def parse():
     p.add_argument("--cpu_seconds", type=float, default=15.0, help="target CPU-baseline duration")
     p.add_argument("--no_kernel_table", action="store_true", help="skip the extra instrumented steps (clean traces)")
     p.add_argument("--no_secondary", action="store_true", help="skip the configs[1] secondary line and the with-ingest figure")
+    p.add_argument("--no_same_workload_n1", action="store_true",
+                   help="N > 1: do not measure this workload on one GPU first (rank 0 alone, same collectives in the path)")
+    p.add_argument("--dry_run", action="store_true",
+                   help="plumbing check only: rendezvous + the known-answer collectives, one JSON line, no GPU work")
     a = p.parse_args()
     return a
 
@@ -249,15 +253,113 @@ def secondary_config1(hip, args):
             "steps": steps}
 
 
+_LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+               "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT",
+               "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+               "TORCHELASTIC_ERROR_FILE")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _relay(cmd, env, timeout=None):
+    """Runs a child bench, passes its stderr through, returns (rc, the LAST JSON line it printed or None).  The caller
+    has not touched the GPU (a process that has must not be the parent of a launcher on this pool)."""
+    import subprocess
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+    for ln in (out or "").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    return proc.returncode, line
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` as a plain command (no WORLD_SIZE in the environment): start the N ranks ourselves —
+    python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 — BEFORE anything in this process
+    touches the GPU, and relay rank 0's one JSON line.  Under torchrun (the driver's N > 1 command) this is not taken."""
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    rc, line = _relay(cmd, env)
+    if line:
+        print(line, flush=True)
+    return rc if rc else (0 if line else 1)
+
+
+def same_workload_on_one_gpu(args, cfg):
+    """The per-GPU workload of this N > 1 run on ONE GPU of this node, in this run: a child process (rank 0's GPU, world
+    size 1, MG_FORCE_DIST=1: every collective of the N-rank pass stays in the path, the table is whole), started by rank 0
+    BEFORE it initialises its GPU while the other ranks wait in the rendezvous.  Weak-scaling efficiency at N is
+    value(N) / (N x this value); bench.py's own N = 1 default is configs[2], a different workload."""
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
+    env.update(MG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg["config"]), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--sketch_n", str(args.sketch_n), "--no_cpu_baseline", "--no_secondary", "--no_kernel_table"]
+    for flag, val in (("--reads", args.reads), ("--genomes", args.genomes), ("--genome_len", args.genome_len), ("--ks", args.ks)):
+        if val:
+            cmd += [flag, str(val)]
+    t0 = time.perf_counter()
+    rc, line = _relay(cmd, env, timeout=900)
+    if rc or not line:
+        return {"error": "the one-GPU run of this workload failed (rc %r)" % rc}
+    d = json.loads(line)
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "n_gpus": 1, "steps": d["steps"],
+            "source": "this run: rank 0's GPU alone before the group run, world size 1 with the exchange path forced "
+                      "(MG_FORCE_DIST=1), %.0f s wall" % (time.perf_counter() - t0),
+            "workload": d["config"]["workload"]}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     force_dist = os.environ.get("MG_FORCE_DIST") == "1"  # single-GPU validation of the torch/RCCL path
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d ranks: reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
+    n1 = None
+    if world > 1 and rank == 0 and not args.no_same_workload_n1 and not args.dry_run:
+        n1 = same_workload_on_one_gpu(args, resolve_config(args, world))  # before this process touches the GPU
+    if args.dry_run:
+        import datetime
+        import torch
+        import torch.distributed as dist
+        from metalign_amd import distributed as mgd
+        backend = os.environ.get("MG_DIST_BACKEND", "nccl")
+        if world > 1 or force_dist:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+            dev = "cpu"
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+                dev = "cuda"
+            mgd.selfcheck_collectives(dist, torch, rank, world, dev)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "150bp reads/s end-to-end (CMash filter + profile)", "value": None, "unit": "reads/s",
+                              "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
+                              "collective_selfcheck": "ok" if (world > 1 or force_dist) else "skipped (one rank)",
+                              "backend": backend}), flush=True)
+        return
     if world > 1 or args.gpus > 1 or force_dist:
         # torch first: the library then binds to the same HIP runtime and launches on torch's stream
+        import datetime
         import torch
         import torch.distributed as dist
         local_rank %= max(torch.cuda.device_count(), 1)  # (MG_DIST_BACKEND=gloo: several ranks on one GPU, for validation)
@@ -270,9 +372,14 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(os.environ.get("MG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+            # (the timeout covers rank 0's one-GPU run of the workload, during which the other ranks wait here)
+            dist.init_process_group(os.environ.get("MG_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(minutes=30))
             dist.barrier()
             torch.cuda.synchronize()
+            if world > 1:  # known-answer collectives (uneven all-to-all, int64 all-reduce): fail loudly at start-up
+                from metalign_amd import distributed as mgd
+                mgd.selfcheck_collectives(dist, torch, rank, world, "cuda")
         finally:
             sys.stdout.flush()
             import ctypes
@@ -405,9 +512,12 @@ def main():
         if world > 1:
             # the default workload differs between N = 1 (configs[2]) and N > 1 (configs[3] shapes): the figure this
             # line's per-GPU workload gives on ONE GPU (world 1, same collectives in the path), as committed
-            ref = committed_run("config3_world1_forced_dist_bench.json", cfg)
+            ref = n1 if (n1 and "error" not in n1) else committed_run("config3_world1_forced_dist_bench.json", cfg)
             if ref:
                 res["same_workload_n1"] = ref
+                if n1 and "error" in n1:
+                    res["same_workload_n1"]["note_in_run"] = n1["error"] + "; the committed figure is quoted instead"
+            res["collective_selfcheck"] = "ok"
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
             res["cpu_baseline"], res["check"] = cpu_baseline_and_check(args, cfg, w, hip)
         if not args.no_secondary and world == 1 and cfg["config"] != 1:

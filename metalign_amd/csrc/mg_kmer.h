@@ -1,16 +1,34 @@
 // mg_kmer.h — device-side k-mer roller + MurmurHash3_x64_128 specialised on k.
 //
-// One lane walks one sequence and keeps, in registers,
-//   * the forward k-mer and its reverse complement as ASCII bytes (what
-//     MurmurHash3 consumes), rolled one byte per base with v_alignbyte, and
-//   * both strands 2-bit packed (first base most significant) so that the
-//     canonical choice "lexicographically smaller of k-mer and revcomp" is one
-//     integer compare.
-// The hash is MurmurHash3_x64_128(seed 0), first 64 bits, of the canonical
-// ASCII k-mer: block/tail structure is resolved at compile time from K.
-// Normative statement: oracle/mg_oracle.c (canonical_hash).
+// One lane walks one sequence and keeps, in registers, both strands of the current window 2-bit packed (first base most
+// significant): the canonical choice "lexicographically smaller of k-mer and reverse complement" is one integer
+// compare, and the canonical k-mer is the selected packed word.
+//
+// The hash is MurmurHash3_x64_128(seed 0), first 64 bits, of the canonical k-mer's ASCII bytes (normative statement:
+// oracle/mg_oracle.c, canonical_hash).  Its ASCII is never materialised: the only thing MurmurHash3 does with a key
+// word (8 bytes) before anything non-linear is multiply it by a constant — k1 *= C1, k2 *= C2 — and a dword of four
+// ASCII bases takes 256 values, so
+//     (lo + hi * 2^32) * C  mod 2^64  =  T[g_lo]  +  (low32(T[g_hi]) << 32),        T[g] = ASCII4(g) * C mod 2^64,
+// g = the 8-bit packed code of the four bases: one 8-byte and one 4-byte LDS read and one 32-bit add replace a 64-bit
+// multiply (two v_mul_lo_u32 + v_mad_u64_u32 + v_add3_u32 = 17 issue cycles on gfx950, profiles/r03/valu_classes.json)
+// AND the two rolling ASCII windows, the per-k byte funnel shifts and the per-dword strand selects that fed it (round
+// 2's design, kept under tools/experiments/mg_kmer_ascii_windows.h.txt: 26 + 6 v_alignbyte_b32 + 27 v_cndmask_b32 per
+// step of the fused {21,31,51} kernel).  14 of that kernel's 40 multiplies per position are such first multiplies.
+// Key words that end inside a group of four (K mod 4 != 0) use tables of 4, 16 and 64 entries for groups of 1, 2 and 3
+// bases.  A workgroup builds the tables (2 constants x 340 entries x 8 B = 5.4 KB) when it starts: fill_hash_tables().
 #pragma once
+#ifndef MG_HOST_CHECK
 #include <hip/hip_runtime.h>
+#else
+// tests/host_kmer_check.cpp compiles this header with g++ (no GPU in the build container): the roller and the
+// table-driven MurmurHash3 below then run on the host, against the oracle, for every k (tests/test_kmer_header_host.py)
+#define __device__
+#define __host__
+#define __forceinline__ inline
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned s) {
+  return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (s & 31u));
+}
+#endif
 
 #include <cstdint>
 #include <utility>
@@ -28,6 +46,8 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t v) {
   return v;
 }
 
+constexpr uint64_t kMurmurC1 = 0x87c37b91114253d5ULL, kMurmurC2 = 0x4cf5ad432745937fULL;
+
 // Base decode: A,C,G,T (either case) -> 0..3 (lexicographic order), anything else -> invalid.
 // idx = (b & 0xDF) - 'A'; valid letters sit at idx 0 (A), 2 (C), 6 (G), 19 (T).
 __device__ __forceinline__ bool decode_base(uint32_t b, uint32_t& code) {
@@ -38,44 +58,131 @@ __device__ __forceinline__ bool decode_base(uint32_t b, uint32_t& code) {
   return ok;
 }
 
+// ---- the first-multiply tables -------------------------------------------------------------------------------------
+// Per constant: [0, 256) groups of four bases, then groups of 1 (4 entries), 2 (16) and 3 (64) bases.
+constexpr int kHashTabPer = 256 + 4 + 16 + 64;
+constexpr int kHashTabEntries = 2 * kHashTabPer;  // C1's tables, then C2's
+__host__ __device__ constexpr int hash_tab_part(int nbases) { return nbases == 4 ? 0 : nbases == 1 ? 256 : nbases == 2 ? 260 : 276; }
+
+// Entry e of the tables: the ASCII of its group (first base = byte 0 = the group's most significant code) times its constant.
+__device__ __forceinline__ uint64_t hash_tab_entry(int e) {
+  const uint64_t c = e >= kHashTabPer ? kMurmurC2 : kMurmurC1;
+  e = e >= kHashTabPer ? e - kHashTabPer : e;
+  int m = 4, g = e;
+  if (e >= 276) { m = 3; g = e - 276; }
+  else if (e >= 260) { m = 2; g = e - 260; }
+  else if (e >= 256) { m = 1; g = e - 256; }
+  uint64_t ascii = 0;
+  for (int b = 0; b < m; ++b) {
+    const uint32_t code = (uint32_t)(g >> (2 * (m - 1 - b))) & 3u;
+    ascii |= (uint64_t)((0x54474341u >> (8 * code)) & 0xffu) << (8 * b);  // "ACGT"[code]
+  }
+  return ascii * c;
+}
+
+#ifndef MG_HOST_CHECK
+// The workgroup's tables (static LDS of whatever kernel calls this: the address space stays visible to the optimiser,
+// so every look-up is a ds_read with the table's offset as its immediate).
+__device__ __forceinline__ const uint64_t* hash_tables() {
+  __shared__ __attribute__((aligned(16))) uint64_t s_hash_tab[kHashTabEntries];
+  return s_hash_tab;
+}
+
+// Every thread of the workgroup calls this once before its first hash (ends in a workgroup barrier).
+__device__ __forceinline__ const uint64_t* fill_hash_tables() {
+  uint64_t* t = const_cast<uint64_t*>(hash_tables());
+  for (int e = (int)threadIdx.x; e < kHashTabEntries; e += (int)blockDim.x) t[e] = hash_tab_entry(e);
+  __syncthreads();
+  return t;
+}
+#endif
+
+// A canonical k-mer, 2-bit packed (first base most significant), as up to four dwords (d[0] least significant).
+struct Packed {
+  uint32_t d[4];
+};
+__device__ __forceinline__ Packed make_packed(uint64_t lo, uint64_t hi) {
+  return Packed{{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)}};
+}
+
+// 8 x the W-bit field at bit LB of p: the byte offset of an 8-byte table entry.
+template <int LB, int W>
+__device__ __forceinline__ uint32_t field_x8(const Packed& p) {
+  static_assert(W >= 2 && W <= 8 && LB >= 0 && LB + W <= 128, "field out of range");
+  constexpr uint32_t M = ((1u << W) - 1u) << 3;
+  constexpr int S = LB - 3;  // the shift that leaves the field at bit 3
+  if constexpr (S < 0) {
+    return (p.d[0] << (-S)) & M;
+  } else {
+    constexpr int Q = S / 32, R = S % 32;
+    if constexpr (R == 0) return p.d[Q] & M;
+    else if constexpr (R + W + 3 <= 32) return (p.d[Q] >> R) & M;
+    else return __builtin_amdgcn_alignbit(Q + 1 < 4 ? p.d[Q + 1] : 0u, p.d[Q], R) & M;
+  }
+}
+
+// Key word number WORD (bytes 8*WORD .. of the K-byte key) times C1 (CI = 0) or C2 (CI = 1), mod 2^64.
+template <int K, int WORD, int CI>
+__device__ __forceinline__ uint64_t key_word_times_c(const Packed& p, const uint64_t* tab) {
+  constexpr int S = 8 * WORD, E = K < S + 8 ? K : S + 8;
+  static_assert(E > S, "no such key word");
+  constexpr int NLO = E - S < 4 ? E - S : 4, NHI = E - S - NLO;
+  const uint8_t* base = reinterpret_cast<const uint8_t*>(tab + CI * kHashTabPer);
+  uint64_t v = *reinterpret_cast<const uint64_t*>(base + 8 * hash_tab_part(NLO) + field_x8<2 * (K - S - NLO), 2 * NLO>(p));
+  if constexpr (NHI > 0) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(base + 8 * hash_tab_part(NHI) + field_x8<2 * (K - S - NLO - NHI), 2 * NHI>(p));
+    v = (uint64_t)(uint32_t)v | ((uint64_t)((uint32_t)(v >> 32) + u) << 32);  // one 32-bit add on the high dword
+  }
+  return v;
+}
+
+// MurmurHash3_x64_128(ASCII of the packed K-mer p, seed 0) -> first 64 bits.
+template <int K>
+__device__ __forceinline__ uint64_t murmur3_h1_packed(const Packed& p, const uint64_t* tab) {
+  constexpr uint64_t C1 = kMurmurC1, C2 = kMurmurC2;
+  constexpr int NBLK = K / 16, TAIL = K & 15;
+  uint64_t h1 = 0, h2 = 0;
+  // 16-byte body blocks, expanded with compile-time indices
+  auto body = [&]<int B>() {
+    uint64_t k1 = key_word_times_c<K, 2 * B, 0>(p, tab);
+    uint64_t k2 = key_word_times_c<K, 2 * B + 1, 1>(p, tab);
+    k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+    k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+  };
+  [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(std::make_integer_sequence<int, NBLK>{});
+  if constexpr (TAIL > 8) {
+    uint64_t k2 = key_word_times_c<K, 2 * NBLK + 1, 1>(p, tab);
+    k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+  }
+  if constexpr (TAIL > 0) {
+    uint64_t k1 = key_word_times_c<K, 2 * NBLK, 0>(p, tab);
+    k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+  }
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2;
+  return h1;
+}
+
 template <int K>
 struct Roller {
   static_assert(K >= 1 && K <= 64, "k out of range");
-  static constexpr int ND = (K + 3) / 4;       // dwords holding K ASCII bytes
-  static constexpr int NB = K - 4 * (ND - 1);  // valid bytes in the last dword, 1..4
-  static constexpr int NW = (K + 31) / 32;     // 64-bit words of the 2-bit form
-  static constexpr uint32_t LAST_MASK = NB == 4 ? 0xffffffffu : ((1u << (8 * NB)) - 1u);
+  static constexpr int NW = (K + 31) / 32;  // 64-bit words of the 2-bit form
 
-  uint32_t f[ND];  // forward strand, ASCII, byte j of the string at bits 8*(j%4) of f[j/4]
-  uint32_t r[ND];  // reverse complement, ASCII
   uint64_t pf_lo, pf_hi, pr_lo, pr_hi;  // 2-bit packed strands (hi unused when K <= 32)
   int run;                              // consecutive valid bases seen
 
   __device__ __forceinline__ void reset() {
-#pragma unroll
-    for (int j = 0; j < ND; ++j) { f[j] = 0; r[j] = 0; }
     pf_lo = pf_hi = pr_lo = pr_hi = 0;
     run = 0;
   }
 
   // Append one base with code c (0..3; anything else only in bits that `run` keeps from being used).
-  // ASCII of the base and of its complement come from one v_perm_b32 each (byte select out of "ACGT" / "TGCA").
   __device__ __forceinline__ void push(uint32_t c) {
-    const uint32_t sel = c | 0x0c0c0c00u;  // byte 0 <- table[c]; bytes 1..3 <- 0x00
-    const uint32_t up = __builtin_amdgcn_perm(0u, 0x54474341u, sel);  // "ACGT"[c]
-    const uint32_t cu = __builtin_amdgcn_perm(0u, 0x41434754u, sel);  // complement: "TGCA"[c]
     c &= 3u;
-    // forward ASCII window: drop byte 0, append `up` as byte K-1
-#pragma unroll
-    for (int j = 0; j + 1 < ND; ++j) f[j] = __builtin_amdgcn_alignbyte(f[j + 1], f[j], 1);
-    if constexpr (NB == 1) f[ND - 1] = up;  // the last dword holds one byte: nothing to keep of it
-    else f[ND - 1] = (f[ND - 1] >> 8) | (up << (8 * (NB - 1)));
-    // reverse-complement ASCII window: prepend `cu` as byte 0, drop byte K-1
-#pragma unroll
-    for (int j = ND - 1; j >= 1; --j) r[j] = __builtin_amdgcn_alignbyte(r[j], r[j - 1], 3);
-    r[0] = (r[0] << 8) | cu;
-    r[ND - 1] &= LAST_MASK;
-    // 2-bit packed strands
     const uint64_t cc = 3u - c;
     if constexpr (NW == 1) {
       constexpr uint64_t M = K == 32 ? ~0ull : ((1ull << (2 * K)) - 1ull);
@@ -107,101 +214,24 @@ struct Roller {
     return pf_hi < pr_hi || (pf_hi == pr_hi && pf_lo <= pr_lo);
   }
 
-  // MurmurHash3_x64_128(canonical ASCII k-mer, seed 0) -> first 64 bits.
-  __device__ __forceinline__ uint64_t hash() const {
+  // MurmurHash3_x64_128(canonical ASCII k-mer, seed 0) -> first 64 bits.  tab: fill_hash_tables().
+  __device__ __forceinline__ uint64_t hash(const uint64_t* tab) const {
     const bool fw = forward_is_canonical();
-    uint32_t w[ND + 4];
-    if constexpr (ND <= 8) {
-#pragma unroll
-      for (int j = 0; j < ND; ++j) w[j] = fw ? f[j] : r[j];
-    } else {
-      // For longer windows the optimiser turns the element-wise select into "select the ARRAY, then load",
-      // which forces f[] and r[] into scratch memory; a bit-field blend (v_bfi_b32) keeps them in registers.
-      const uint32_t m = fw ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int j = 0; j < ND; ++j) w[j] = (f[j] & m) | (r[j] & ~m);
-    }
-#pragma unroll
-    for (int j = ND; j < ND + 4; ++j) w[j] = 0;
-    constexpr uint64_t C1 = 0x87c37b91114253d5ULL, C2 = 0x4cf5ad432745937fULL;
-    constexpr int NBLK = K / 16, TAIL = K & 15;
-    uint64_t h1 = 0, h2 = 0;
-    // 16-byte body blocks, expanded with compile-time indices (a `for` over NBLK >= 2 is unrolled too late
-    // for the register promotion of w[], f[] and r[]: they would live in scratch memory)
-    auto body = [&]<int B>() {
-      uint64_t k1 = (uint64_t)w[4 * B] | ((uint64_t)w[4 * B + 1] << 32);
-      uint64_t k2 = (uint64_t)w[4 * B + 2] | ((uint64_t)w[4 * B + 3] << 32);
-      k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
-      h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
-      k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
-      h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
-    };
-    [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(
-        std::make_integer_sequence<int, NBLK>{});
-    if constexpr (TAIL > 8) {
-      uint64_t k2 = (uint64_t)w[4 * NBLK + 2] | ((uint64_t)w[4 * NBLK + 3] << 32);
-      k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
-    }
-    if constexpr (TAIL > 0) {
-      uint64_t k1 = (uint64_t)w[4 * NBLK] | ((uint64_t)w[4 * NBLK + 1] << 32);
-      k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
-    }
-    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
-    h1 += h2; h2 += h1;
-    h1 = fmix64(h1); h2 = fmix64(h2);
-    h1 += h2;
-    return h1;
+    const uint64_t lo = fw ? pf_lo : pr_lo, hi = NW == 1 ? 0ull : (fw ? pf_hi : pr_hi);
+    return murmur3_h1_packed<K>(make_packed(lo, hi), tab);
   }
 };
 
-// MurmurHash3_x64_128(the K bytes held in w[0 .. (K+3)/4), zero padded up to NDW dwords; seed 0) -> first 64 bits.
-template <int K, int NDW>
-__device__ __forceinline__ uint64_t murmur3_h1_words(const uint32_t (&w)[NDW]) {
-  static_assert(NDW >= (K + 3) / 4 + 4, "the tail reads up to four dwords past the last byte");
-  constexpr uint64_t C1 = 0x87c37b91114253d5ULL, C2 = 0x4cf5ad432745937fULL;
-  constexpr int NBLK = K / 16, TAIL = K & 15;
-  uint64_t h1 = 0, h2 = 0;
-  auto body = [&]<int B>() {
-    uint64_t k1 = (uint64_t)w[4 * B] | ((uint64_t)w[4 * B + 1] << 32);
-    uint64_t k2 = (uint64_t)w[4 * B + 2] | ((uint64_t)w[4 * B + 3] << 32);
-    k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
-    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
-    k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
-    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
-  };
-  [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(
-      std::make_integer_sequence<int, NBLK>{});
-  if constexpr (TAIL > 8) {
-    uint64_t k2 = (uint64_t)w[4 * NBLK + 2] | ((uint64_t)w[4 * NBLK + 3] << 32);
-    k2 *= C2; k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
-  }
-  if constexpr (TAIL > 0) {
-    uint64_t k1 = (uint64_t)w[4 * NBLK] | ((uint64_t)w[4 * NBLK + 1] << 32);
-    k1 *= C1; k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
-  }
-  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
-  h1 += h2; h2 += h1;
-  h1 = fmix64(h1); h2 = fmix64(h2);
-  h1 += h2;
-  return h1;
-}
-
 // Hash of the canonical K-mer that ENDS at the newest base of a Roller<KMAX>, K <= KMAX: one roller at the largest
-// k of a multi-k query serves every smaller k.  The K-mer is the SUFFIX of the forward window (bytes KMAX-K ..
-// KMAX-1: a byte-granular funnel shift of the forward ASCII words; the low 2K bits of the forward 2-bit form) and
-// its reverse complement is the PREFIX of the reverse-complement window (its first K bytes as they are; the top 2K
-// bits of the reverse 2-bit form).
+// k of a multi-k query serves every smaller k.  The K-mer is the SUFFIX of the forward window (the low 2K bits of the
+// forward 2-bit form) and its reverse complement is the PREFIX of the reverse-complement window (the top 2K bits of
+// the reverse 2-bit form).
 template <int K, int KMAX>
-__device__ __forceinline__ uint64_t hash_suffix(const Roller<KMAX>& R) {
+__device__ __forceinline__ uint64_t hash_suffix(const Roller<KMAX>& R, const uint64_t* tab) {
   static_assert(K >= 1 && K <= KMAX, "sub-k must not exceed the roller's k");
   if constexpr (K == KMAX) {
-    return R.hash();
+    return R.hash(tab);
   } else {
-    constexpr int ND = (K + 3) / 4, NB = K - 4 * (ND - 1);
-    constexpr uint32_t LAST = NB == 4 ? 0xffffffffu : ((1u << (8 * NB)) - 1u);
-    constexpr int OFF = KMAX - K, OD = OFF / 4, OB = OFF % 4;
-    constexpr int NDM = Roller<KMAX>::ND;
-    // canonical choice on the 2-bit forms (as 128-bit values hi:lo)
     constexpr int S = 2 * (KMAX - K);  // the reverse form's K-mer sits S bits up
     uint64_t f_lo = R.pf_lo, f_hi = KMAX > 32 ? R.pf_hi : 0ull;
     uint64_t r_lo, r_hi;
@@ -218,23 +248,13 @@ __device__ __forceinline__ uint64_t hash_suffix(const Roller<KMAX>& R) {
       f_hi &= MH; r_hi &= MH;
     }
     const bool fw = K <= 32 ? (f_lo <= r_lo) : (f_hi < r_hi || (f_hi == r_hi && f_lo <= r_lo));
-    const uint32_t m = fw ? 0xffffffffu : 0u;
-    uint32_t w[ND + 4];
-#pragma unroll
-    for (int j = 0; j < ND; ++j) {
-      const uint32_t a = R.f[OD + j];
-      const uint32_t b = (OD + j + 1 < NDM) ? R.f[OD + j + 1] : 0u;
-      uint32_t fwd = OB == 0 ? a : __builtin_amdgcn_alignbyte(b, a, OB);
-      uint32_t rev = R.r[j];
-      if (j == ND - 1) { fwd &= LAST; rev &= LAST; }
-      w[j] = (fwd & m) | (rev & ~m);
-    }
-#pragma unroll
-    for (int j = ND; j < ND + 4; ++j) w[j] = 0;
-    return murmur3_h1_words<K, ND + 4>(w);
+    return murmur3_h1_packed<K>(make_packed(fw ? f_lo : r_lo, fw ? f_hi : r_hi), tab);
   }
 }
 
+#ifndef MG_MAX_K
+#define MG_MAX_K 64
+#endif
 // Calls F.template operator()<K>() for the runtime k; false when k is unsupported.
 template <class F, int K = 1>
 inline bool dispatch_k(int k, F&& fn) {

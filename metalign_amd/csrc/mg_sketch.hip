@@ -165,7 +165,7 @@ struct CandSink {
 // MODE 0: any tile.  1: a clean tile (no invalid base in it) of equally long reads.  2: a clean tile of ragged reads.
 template <int K, bool CODES, int MODE = 0>
 __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
-                                           uint64_t hmax, CandSink& sink, uint64_t& kmers, int lane) {
+                                           uint64_t hmax, CandSink& sink, uint64_t& kmers, int lane, const uint64_t* htab) {
   Roller<K> roll;
   roll.reset();
   uint32_t nk = 0;
@@ -189,9 +189,9 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
     for (uint32_t pos = warm; pos < maxlen; pos += 2) {
       const uint32_t c0 = cs.at(pos) & 3u, c1 = cs.at(pos + 1) & 3u;  // (c1 past the end: hashed, never offered)
       roll.push_clean(c0);
-      const uint64_t h0 = roll.hash();
+      const uint64_t h0 = roll.hash(htab);
       roll.push_clean(c1);
-      const uint64_t h1 = roll.hash();
+      const uint64_t h1 = roll.hash(htab);
       if (pos + 1 >= (uint32_t)K) {  // (scalar branches: the ballot then is the compare itself)
         if constexpr (RAGGED) sink.offer2(pos < len, h0 <= hmax, h0, lane); else sink.offer(h0 <= hmax, h0, lane);
       }
@@ -220,11 +220,11 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
     const uint32_t c0 = code_at(pos), c1 = code_at(pos + 1);
     roll.push(c0);
     roll.run = c0 < 4u ? roll.run : 0;
-    const uint64_t h0 = roll.hash();
+    const uint64_t h0 = roll.hash(htab);
     const bool full0 = roll.run >= K;
     roll.push(c1);
     roll.run = c1 < 4u ? roll.run : 0;
-    const uint64_t h1 = roll.hash();
+    const uint64_t h1 = roll.hash(htab);
     const bool full1 = roll.run >= K;
     nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
     sink.offer(full0 && h0 <= hmax, h0, lane);
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
                                                          unsigned stage_bytes, const uint32_t* __restrict__ fbits,
                                                          uint64_t fmask, uint32_t cs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint64_t* htab = fill_hash_tables();  // MurmurHash3's first multiplies (mg_kmer.h)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
@@ -281,14 +282,14 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
       if (__ballot(bad != 0) != 0ull)
-        walk_reads<K, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+        walk_reads<K, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
       else if (__ballot(len != maxlen) == 0ull)
-        walk_reads<K, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+        walk_reads<K, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
       else
-        walk_reads<K, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+        walk_reads<K, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
       wave_lds_sync();
     } else {
-      walk_reads<K, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane);
+      walk_reads<K, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
     }
   }
   sink.flush(lane);
@@ -306,6 +307,7 @@ template <int K>
 __global__ __launch_bounds__(256) void k_hash_positions(const uint8_t* __restrict__ bases,
                                                         const uint64_t* __restrict__ offsets, uint64_t nseq,
                                                         uint64_t nbases, uint64_t* __restrict__ out) {
+  const uint64_t* htab = fill_hash_tables();
   const uint64_t nchunks = (nbases + kChunk - 1) / kChunk;
   for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
        ch += (uint64_t)gridDim.x * blockDim.x) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void k_hash_positions(const uint8_t* __restric
       uint64_t h = kReservedHash;
       if (decode_base(bases[p], c)) {
         roll.push(c);
-        if (roll.full()) h = roll.hash();
+        if (roll.full()) h = roll.hash(htab);
       } else {
         roll.run = 0;
       }
@@ -620,7 +622,7 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   if (const char* pad = getenv("MG_DEBUG_LDS_PAD")) lds += (size_t)atol(pad);  // occupancy experiments only
   const uint64_t ntiles = (nreads + 63) / 64;
   // enough resident blocks to fill every CU at the LDS-limited occupancy, grid-stride over the rest
-  unsigned per_cu = (unsigned)(160 * 1024 / (lds ? lds : 1));
+  unsigned per_cu = (unsigned)(160 * 1024 / (lds + kHashTabEntries * sizeof(uint64_t)));  // (+ the static hash tables)
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   // On a stage-A stream (a pipelined job) the caller may cap the resident workgroups per CU

@@ -162,7 +162,8 @@ struct KList {
 // src points at the read's ASCII bases in HBM (a tile that does not fit the stage; MODE 0 only).
 template <class KL, bool CODES, int MODE>
 __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
-                                                 const MultiArgs& A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane) {
+                                                 const MultiArgs& A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane,
+                                                 const uint64_t* htab) {
   constexpr int KMAX = KL::kmax;
   static_assert(CODES || MODE == 0, "the clean walks read the LDS stage");
   Roller<KMAX> roll;
@@ -185,7 +186,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
       // (the hash is computed ONCE, into a variable: written twice — as the threshold test and as the value offered —
       // the four-k kernel ended up with 1.6 x the multiplies, the optimiser no longer merging the two)
       auto one = [&]<int I>() {
-        const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll);
+        const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll, htab);
         if constexpr (RAGGED) sink.template offer2<I>(pos < len, h <= hmax[I], h, lane);
         else sink.template offer<I>(h <= hmax[I], h, lane);
       };
@@ -209,7 +210,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
     roll.run = c < 4u ? roll.run : 0;
     if (pos < warm) continue;  // (scalar)
     auto one = [&]<int I>() {
-      const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll);
+      const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll, htab);
       nk[I] += roll.run >= KL::v[I] ? 1u : 0u;
       sink.template offer2<I>(roll.run >= KL::v[I], h <= hmax[I], h, lane);
     };
@@ -228,7 +229,7 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
   __shared__ MultiArgs s_args;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_args = args;
-  __syncthreads();
+  const uint64_t* htab = fill_hash_tables();  // MurmurHash3's first multiplies (mg_kmer.h); ends in the workgroup barrier
   uint8_t* stage = smem + (size_t)wave * stage_bytes;
   uint8_t* cand = smem + (size_t)kWavesPerBlock * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(cand) + wave * kCandBuf;
@@ -263,14 +264,14 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
       if (__ballot(bad != 0) != 0ull)
-        walk_reads_multi<KL, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
+        walk_reads_multi<KL, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       else if (__ballot(len != maxlen) == 0ull)
-        walk_reads_multi<KL, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
+        walk_reads_multi<KL, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       else
-        walk_reads_multi<KL, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
+        walk_reads_multi<KL, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       wave_lds_sync();
     } else {
-      walk_reads_multi<KL, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane);
+      walk_reads_multi<KL, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
     }
   }
   sink.flush(lane);
@@ -297,7 +298,7 @@ static int launch_multi(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   Context& c = ctx();
   const size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * (sizeof(uint64_t) + 1));
   const uint64_t ntiles = (nreads + 63) / 64;
-  unsigned per_cu = (unsigned)(160 * 1024 / (lds + sizeof(MultiArgs) + 64));
+  unsigned per_cu = (unsigned)(160 * 1024 / (lds + sizeof(MultiArgs) + 64 + kHashTabEntries * sizeof(uint64_t)));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;

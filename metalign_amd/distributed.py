@@ -473,6 +473,53 @@ class _HostStagedGloo:
         return []
 
 
+def selfcheck_collectives(dist, torch, rank, world, device):
+    """Known-answer run of every collective a pass uses, in the shapes it uses them, before any real work: an
+    all-gather of a few int64 words, an all-to-all with UNEVEN splits (rank r sends q + 1 + (r + q) % 3 entries to
+    rank q; gloo: the same movement as point-to-point operations, exactly as ShardJob._all_to_all does), an
+    all-reduce(sum, int64).  Raises RuntimeError naming the collective whose result is wrong — a transport that
+    delivers wrong or misplaced data must stop the job at start-up, not show up as a wrong containment index.
+    (scripts/select_db.py:73-76 and scripts/map_and_profile.py:193-264 are single-process; the collectives are this
+    build's own and so is their check.)"""
+    d = _HostStagedGloo(dist, torch) if (str(device) != "cpu" and dist.get_backend() == "gloo") else dist
+    t, W = torch, world
+    # all-gather
+    mine = t.as_tensor([rank, 1000 + rank, -(rank + 1)], dtype=t.int64, device=device)
+    got = [t.zeros(3, dtype=t.int64, device=device) for _ in range(W)]
+    d.all_gather(got, mine)
+    for q in range(W):
+        if got[q].cpu().tolist() != [q, 1000 + q, -(q + 1)]:
+            raise RuntimeError("collective self-check: all_gather delivered %r for rank %d on rank %d" % (got[q].cpu().tolist(), q, rank))
+    # all-to-all, uneven splits: entry j of the slice r -> q carries r * 10^6 + q * 10^3 + j
+    n = lambda r, q: q + 1 + (r + q) % 3  # noqa: E731
+    send_counts = [n(rank, q) for q in range(W)]
+    recv_counts = [n(q, rank) for q in range(W)]
+    send = t.as_tensor(np.concatenate([np.arange(n(rank, q)) + rank * 10**6 + q * 10**3 for q in range(W)]).astype(np.int64), device=device)
+    recv = t.zeros(sum(recv_counts), dtype=t.int64, device=device)
+    if d.get_backend() == "nccl":
+        d.all_to_all_single(recv, send, list(recv_counts), list(send_counts))
+    else:
+        so, ro = np.cumsum([0] + send_counts), np.cumsum([0] + recv_counts)
+        ops = []
+        for q in range(W):
+            if q == rank:
+                recv[ro[q]:ro[q + 1]] = send[so[q]:so[q + 1]]
+                continue
+            ops.append(d.P2POp(d.isend, send[so[q]:so[q + 1]].contiguous(), q))
+            ops.append(d.P2POp(d.irecv, recv[ro[q]:ro[q + 1]], q))
+        if ops:
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
+    want = np.concatenate([np.arange(n(q, rank)) + q * 10**6 + rank * 10**3 for q in range(W)])
+    if not np.array_equal(recv.cpu().numpy(), want):
+        raise RuntimeError("collective self-check: all-to-all with uneven splits delivered wrong data on rank %d" % rank)
+    # all-reduce(sum, int64), values above 2^32 so that a 32-bit reduction would show
+    v = t.as_tensor([(rank + 1) * (1 << 33), rank, 1], dtype=t.int64, device=device)
+    d.all_reduce(v, op=d.ReduceOp.SUM)
+    if v.cpu().tolist() != [W * (W + 1) // 2 * (1 << 33), W * (W - 1) // 2, W]:
+        raise RuntimeError("collective self-check: all_reduce(sum, int64) gave %r on rank %d" % (v.cpu().tolist(), rank))
+
+
 class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 

@@ -12,6 +12,10 @@ mkdir -p "$OUT"
 ARGS="--steps 5 --warmup 2 --no_cpu_baseline --no_secondary --no_kernel_table $*"
 timeout -s KILL 600 python3 bench.py --no_secondary "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 MG_SINGLE_STREAM=1 timeout -s KILL 600 python3 bench.py --no_cpu_baseline --no_secondary "$@" > "$OUT/bench_single_stream.json" 2>> "$OUT/bench.err"
+# the DEFAULT schedule (stage A of consecutive passes on two alternating streams, stage C on a third): the trace that
+# evidences the driver-timed step; kernels of different passes overlap here, so averages are NOT a kernel's own time
+timeout -s KILL 900 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_pipelined" -o run -- python3 bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_secondary --no_kernel_table "$@" > "$OUT/bench_pipelined_under_rocprof.json" 2> "$OUT/stats_pipelined.log"
+python3 tools/trace_timeline.py "$OUT/stats_pipelined" "$OUT/pipelined_timeline.json" > "$OUT/pipelined_timeline.txt" 2>&1
 export MG_SINGLE_STREAM=1
 timeout -s KILL 900 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o run -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -20,5 +24,5 @@ done
 timeout -s KILL 900 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
   --kernel-trace -d "$OUT/pmc_SQ" -o run -- python3 bench.py $ARGS > "$OUT/pmc_SQ.log" 2>&1
 python3 tools/summarize_profiles.py "$OUT" > "$OUT/summary.log" 2>&1
-for d in stats pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do rm -rf "$OUT/$d"; done
+for d in stats stats_pipelined pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do rm -rf "$OUT/$d"; done
 tail -n 30 "$OUT/summary.log"

@@ -70,6 +70,13 @@ def main(out):
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
         res["kernel_stats_avg_ns"] = {short(r["Name"]): float(r["AverageNs"]) for r in rows if short(r["Name"]).startswith("k_")}
+    f = one(os.path.join(out, "stats_pipelined", "**", "*kernel_stats.csv"))
+    if f:  # the default multi-stream schedule: kernels of consecutive passes overlap, averages are not a kernel's own time
+        with open(os.path.join(out, "pipelined_kernel_stats.csv"), "w") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+            for r in csv.DictReader(open(f)):
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     traffic = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(os.path.join(out, "pmc_" + c, "**", "*counter_collection.csv"))
