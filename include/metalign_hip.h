@@ -186,6 +186,36 @@ int mg_sketch_resolve(mg_sketch* sk, int* rebuilt);
 int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int nk,
                                     const int* ks, const uint64_t* hmaxs, uint64_t s,
                                     const mg_filter* const* filters, mg_sketch** out);
+/* A sample that arrives in PIECES — a reads file streamed through page-locked chunks while the next chunk is in
+ * flight, or a file larger than the device: every piece is hashed into the SAME per-k counting tables (the tables are
+ * what dedupes and counts), so nothing is sketched per piece and nothing merged.  Replaces kmc reading the whole reads
+ * file, scripts/select_db.py:45-52 (`.gz` included, :146-148).
+ *   begin:   ks[nk] ascending (1..4 of them), thresholds, bottom-s and pre-filters as for mg_sketch_reads_multi_dev_async;
+ *            expect_bases = the sample's total bases, roughly (sizes the tables together with the library's
+ *            distinct-count hint; an estimate that proves too small is reported at resolution, see below).
+ *   add_dev: one batch of reads already in HBM (bases + offsets[nreads + 1]; nbases = their total, 0 = unknown).
+ *            Asynchronous; the batch may be freed as soon as the call returns (stream-ordered).
+ *   finish:  out[i] = the sketch of ks[i], pending like one from mg_sketch_reads_dev_async and bit-identical to the
+ *            sketch of the concatenated batches.  mg_sketch_resolve returns MG_ERR_CAPACITY when a table overflowed
+ *            (the reads are gone: the hint is reset to the worst case, stream the sample again).
+ *   add_file / add_gzip: the file -> HBM -> parse -> add pipeline inside the library (mg_stream.hip): reader threads
+ *            fill page-locked chunks (plain files: positional reads in parallel; gzip: zlib inflate, BGZF blocks in
+ *            parallel), one DMA stream uploads chunk i + 1 while chunk i is parsed on the device (mg_reads_parse
+ *            rules; record-aligned: the incomplete last record of a chunk is carried to the front of the next ON THE
+ *            DEVICE) and hashed into the tables.  format as mg_reads_parse; offset / length: a byte range of the
+ *            file that begins on a record boundary (a rank's share; length 0 = to the end).  chunk_bytes / nthreads:
+ *            0 = defaults (64 MB, up to 8 readers). */
+typedef struct mg_sketch_stream mg_sketch_stream;
+int mg_sketch_stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters,
+                           uint64_t expect_bases, mg_sketch_stream** out);
+int mg_sketch_stream_add_dev(mg_sketch_stream* ss, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
+                             uint64_t nbases);
+int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format, uint64_t offset, uint64_t length,
+                              uint64_t chunk_bytes, int nthreads);
+int mg_sketch_stream_finish(mg_sketch_stream* ss, mg_sketch** out);
+uint64_t mg_sketch_stream_nreads(const mg_sketch_stream* ss);
+uint64_t mg_sketch_stream_nbases(const mg_sketch_stream* ss);
+void mg_sketch_stream_free(mg_sketch_stream* ss);
 /* ------------------------------------------------------------------------ *
  * Membership pre-filter over the genome table's hashes — the role of the bloom pre-filter the reference hands
  * to CMash (`-f cmash_db_n1000_k60_30-60-10.bf`, scripts/select_db.py:70,75).  One bit per hash: bit (h mod
@@ -272,6 +302,10 @@ int mg_sketch_reads(const uint8_t* bases, const uint64_t* offsets,
  * ------------------------------------------------------------------------ */
 typedef struct mg_reads mg_reads;
 int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_reads** out);
+/* A PIECE of a reads file that begins on a record boundary (final = 0): the whole records in it are parsed and
+ * *consumed = the byte where the first incomplete record begins — the caller carries [consumed, nbytes) to the front of
+ * the next piece (mg_sketch_stream_add_file does, on the device).  final != 0: mg_reads_parse_dev. */
+int mg_reads_parse_prefix_dev(const uint8_t* d_text, uint64_t nbytes, int format, int final, uint64_t* consumed, mg_reads** out);
 int mg_reads_parse(const uint8_t* text, uint64_t nbytes, int format, mg_reads** out);
 uint64_t mg_reads_count(const mg_reads* r);
 uint64_t mg_reads_nbases(const mg_reads* r);
@@ -427,6 +461,14 @@ int mg_paf_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_ind
                         mg_sam_batch** out, int* err_kind, uint64_t* err_line);
 int mg_paf_tokenize(const uint8_t* text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
                     mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+/* The alignment FILE (SAM, paf = 0; PAF, paf = 1; plain, gzip or BGZF) -> records on the device through the pipeline of
+ * mg_stream.hip: reader threads fill page-locked chunks, chunk i + 1 goes up while chunk i — cut at its last newline, the
+ * rest carried to the front of the next chunk on the device — is tokenised, the previous retained QNAME carried along.
+ * The batch equals mg_sam_tokenize_dev's of the whole text.  offset / length: a line-aligned byte range of a plain file
+ * (length 0 = to the end); chunk_bytes / nthreads: 0 = defaults.  Replaces the line loop of map_and_process,
+ * scripts/map_and_profile.py:201-217.  err_line is relative to the piece the line fell into. */
+int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64_t offset, uint64_t length,
+                       uint64_t chunk_bytes, int nthreads, mg_sam_batch** out, int* err_kind, uint64_t* err_line);
 uint64_t mg_sam_batch_count(const mg_sam_batch* b);
 const char* mg_sam_batch_last_qname(const mg_sam_batch* b);
 int mg_sam_batch_device_ptr(const mg_sam_batch* b, const mg_aln_rec** d_recs);

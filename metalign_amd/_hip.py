@@ -31,9 +31,10 @@ EXPORTS = [
     "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
-    "mg_reads_parse_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
+    "mg_sketch_stream_begin", "mg_sketch_stream_add_dev", "mg_sketch_stream_add_file", "mg_sketch_stream_finish", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases", "mg_sketch_stream_free",
+    "mg_reads_parse_dev", "mg_reads_parse_prefix_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
-    "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_batch_count",
+    "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment",
@@ -75,7 +76,7 @@ def load_library(path=LIB_PATH):
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
     lib = ctypes.CDLL(path)
     lib.mg_last_error.restype = ctypes.c_char_p
-    for name in ("mg_reads_count", "mg_reads_nbases", "mg_sam_batch_count"):
+    for name in ("mg_reads_count", "mg_reads_nbases", "mg_sam_batch_count", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases"):
         getattr(lib, name).restype = ctypes.c_uint64
     lib.mg_sam_batch_last_qname.restype = ctypes.c_char_p
     for name in ("mg_reads_free", "mg_acc_index_free", "mg_sam_batch_free"):
@@ -83,6 +84,7 @@ def load_library(path=LIB_PATH):
     for name in ("mg_sketch_size", "mg_sketch_kmers_seen", "mg_sketch_last_hash", "mg_db_ngenomes", "mg_db_max_hash", "mg_profile_ngroups"):
         getattr(lib, name).restype = ctypes.c_uint64
     lib.mg_sketch_free.restype = None
+    lib.mg_sketch_stream_free.restype = None
     lib.mg_filter_free.restype = None
     lib.mg_filter_log2_bits.restype = ctypes.c_uint
     lib.mg_count_saturation.restype = ctypes.c_uint32
@@ -275,6 +277,62 @@ class SamParseError(Exception):
     def __init__(self, kind, line):
         super().__init__("SAM parse error kind %d at line %d" % (kind, line))
         self.kind, self.line = kind, line
+
+
+class SketchStream:
+    """mg_sketch_stream_*: every piece of a sample is hashed into the SAME per-k counting tables; finish() gives the
+    sketches (pending, like sketch_reads_multi_dev_async's) of the concatenated pieces."""
+
+    def __init__(self, hip, ks, hmaxs, s=0, filters=None, expect_bases=0):
+        self.hip, self.ks = hip, [int(k) for k in ks]
+        nk = len(self.ks)
+        self.filts = list(filters) if filters is not None else [None] * nk
+        c_ks = (ctypes.c_int * nk)(*self.ks)
+        c_hm = (ctypes.c_uint64 * nk)(*[int(h) for h in hmaxs])
+        c_f = (_vp * nk)(*[(f.handle if f is not None else None) for f in self.filts])
+        h = _vp()
+        hip._chk(hip.lib.mg_sketch_stream_begin(ctypes.c_int(nk), c_ks, c_hm, ctypes.c_uint64(int(s)), c_f,
+                                                ctypes.c_uint64(int(expect_bases)), ctypes.byref(h)))
+        self.handle = h
+
+    def add_dev(self, d_bases, d_offsets, nreads, nbases=0):
+        self.hip._chk(self.hip.lib.mg_sketch_stream_add_dev(self.handle, _vp(d_bases), _vp(d_offsets), ctypes.c_uint64(int(nreads)),
+                                                            ctypes.c_uint64(int(nbases))))
+
+    def add_reads(self, reads):
+        d_b, d_o = reads.device_ptrs()
+        self.add_dev(d_b, d_o, reads.count, getattr(reads, "nbases", 0))
+
+    def add_file(self, path, fmt, offset=0, length=0, chunk_bytes=0, nthreads=0):
+        """The file (plain, gzip or BGZF) -> page-locked chunks -> HBM -> device parser -> the tables, pipelined inside the
+        library (mg_stream.hip).  offset / length: a record-aligned byte range of a plain file."""
+        self.hip._chk(self.hip.lib.mg_sketch_stream_add_file(self.handle, os.fsencode(path), ctypes.c_int(_READS_FORMAT[fmt]),
+                                                             ctypes.c_uint64(int(offset)), ctypes.c_uint64(int(length)),
+                                                             ctypes.c_uint64(int(chunk_bytes)), ctypes.c_int(int(nthreads))))
+
+    @property
+    def nreads(self):
+        return int(self.hip.lib.mg_sketch_stream_nreads(self.handle))
+
+    @property
+    def nbases(self):
+        return int(self.hip.lib.mg_sketch_stream_nbases(self.handle))
+
+    def finish(self):
+        nk = len(self.ks)
+        c_out = (_vp * nk)()
+        self.hip._chk(self.hip.lib.mg_sketch_stream_finish(self.handle, c_out))
+        out = []
+        for i in range(nk):
+            sk = Sketch(self.hip, _vp(c_out[i]), self.ks[i])
+            sk.filt = self.filts[i]
+            out.append(sk)
+        return out
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_sketch_stream_free(self.handle)
+            self.handle = None
 
 
 class Reads:
@@ -783,6 +841,10 @@ class Hip:
                                           ctypes.c_int(_READS_FORMAT[fmt]), ctypes.byref(h)))
         return Reads(self, h)
 
+    def sketch_stream(self, ks, hmaxs, s=0, filters=None, expect_bases=0):
+        """A streamed read sketch: one set of counting tables for a sample that arrives in pieces (SketchStream)."""
+        return SketchStream(self, ks, hmaxs, s, filters, expect_bases)
+
     def parse_reads_dev(self, d_text, nbytes, fmt):
         """As parse_reads, for text already resident in HBM."""
         h = _vp()
@@ -813,6 +875,20 @@ class Hip:
         rc = fn(_vp(d_text), ctypes.c_uint64(nbytes), acc_index.handle,
                                           ctypes.c_char_p(prev_qname.encode()), ctypes.byref(h), ctypes.byref(kind),
                                           ctypes.byref(line))
+        if rc != 0 and kind.value:
+            raise SamParseError(kind.value, line.value)
+        self._chk(rc)
+        return SamBatch(self, h)
+
+    def sam_stream_file(self, path, acc_index, paf=False, offset=0, length=0, chunk_bytes=0, nthreads=0):
+        """The alignment file (SAM; paf=True: PAF; plain, gzip or BGZF) -> SamBatch, streamed through page-locked chunks
+        inside the library (mg_sam_stream_file): the file read, the upload and the tokeniser overlap, and the text never
+        exists as a host array.  SamParseError for a line the reference cannot parse."""
+        h = _vp()
+        kind, line = ctypes.c_int(0), ctypes.c_uint64(0)
+        rc = self.lib.mg_sam_stream_file(os.fsencode(path), ctypes.c_int(1 if paf else 0), acc_index.handle,
+                                         ctypes.c_uint64(int(offset)), ctypes.c_uint64(int(length)), ctypes.c_uint64(int(chunk_bytes)),
+                                         ctypes.c_int(int(nthreads)), ctypes.byref(h), ctypes.byref(kind), ctypes.byref(line))
         if rc != 0 and kind.value:
             raise SamParseError(kind.value, line.value)
         self._chk(rc)

@@ -313,6 +313,23 @@ int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets, uint64_t ngeno
   return MG_OK;
 }
 
+// A stored hash-major table is trusted for nothing: one streaming pass over what was uploaded counts the pairs that are
+// out of order, above max_hash, or name a genome that does not exist (stage B adds into hits[genome] with atomics — a
+// corrupt or mismatched k*.pair_gen.u32 would write out of bounds).  bad[0] order, bad[1] range, bad[2] genome id.
+__global__ void k_check_pairs(const uint64_t* __restrict__ pair_hash, const uint32_t* __restrict__ pair_gen, uint64_t npairs,
+                              uint64_t ngenomes, uint64_t max_hash, unsigned long long* __restrict__ bad) {
+  unsigned o = 0, r = 0, g = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t h = pair_hash[i];
+    o += (i > 0 && pair_hash[i - 1] > h) ? 1u : 0u;
+    r += h > max_hash ? 1u : 0u;
+    g += pair_gen[i] >= ngenomes ? 1u : 0u;
+  }
+  if (o) atomicAdd(bad + 0, (unsigned long long)o);
+  if (r) atomicAdd(bad + 1, (unsigned long long)r);
+  if (g) atomicAdd(bad + 2, (unsigned long long)g);
+}
+
 int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uint64_t npairs, const uint32_t* gsize,
                         uint64_t ngenomes, uint64_t max_hash, mg_db** out) {
   MG_REQUIRE_READY();
@@ -336,6 +353,20 @@ int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uin
     MG_HIP(hipMemcpyAsync(db->pair_gen.p, pair_gen, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   }
   if (ngenomes) MG_HIP(hipMemcpyAsync(db->gsize.p, gsize, ngenomes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  if (npairs) {
+    unsigned long long* d_bad = (unsigned long long*)scratch("db_check", 4 * sizeof(unsigned long long));
+    if (!d_bad) return MG_ERR_NOMEM;
+    MG_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_check_pairs, dim3(grid_for(npairs, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st,
+                       db->pair_hash.as<uint64_t>(), db->pair_gen.as<uint32_t>(), npairs, ngenomes, max_hash, d_bad);
+    MG_HIP(hipGetLastError());
+    uint64_t* pin = host_words();
+    MG_HIP(hipMemcpyAsync(pin, d_bad, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    if (pin[0] || pin[1] || pin[2])
+      return fail(MG_ERR_ARG, "hash-major sketch table is corrupt: %llu pairs out of order, %llu above max_hash, %llu with a genome id >= %llu",
+                  (unsigned long long)pin[0], (unsigned long long)pin[1], (unsigned long long)pin[2], (unsigned long long)ngenomes);
+  }
   MG_HIP(hipStreamSynchronize(st));
   *out = db.release();
   return MG_OK;

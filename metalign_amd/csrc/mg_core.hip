@@ -259,6 +259,7 @@ void mg_shutdown(void) {
   mg::Context& c = ctx();
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
+  mg::stream_release_all();
   mg::scratch_release_all();
   mg::pool_release_all();
   if (c.pinned) (void)hipHostFree(c.pinned);

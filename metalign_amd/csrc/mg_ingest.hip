@@ -159,6 +159,16 @@ __global__ void k_fasta_lines(const uint8_t* __restrict__ text, const uint64_t* 
   }
 }
 
+// 1 + the index of the last header line (0: none) — where a piece of a streamed FASTA file is cut
+__global__ void k_fasta_last_header(const uint32_t* __restrict__ flags, uint64_t nlines, unsigned long long* __restrict__ out) {
+  uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long best = 0;
+  for (; l < nlines; l += stride)
+    if (flags[l]) best = l + 1;
+  if (best) atomicMax(out, best);
+}
+
 // sequence lines in front of the first header belong to no record
 __global__ void k_fasta_orphans(const uint32_t* __restrict__ flags, const uint64_t* __restrict__ rank, uint64_t nlines,
                                 uint32_t* __restrict__ lens) {
@@ -509,7 +519,7 @@ __global__ void k_sam_emit(const uint8_t* __restrict__ text, const LineOut* __re
 // Shared: build the line index of a text buffer.  If the text does not end in '\n' the last partial
 // line is terminated virtually.  -> d_line_end (scratch "ing_lines"), *nlines.
 static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d_line_end, uint64_t* nlines,
-                            bool* virtual_last) {
+                            bool* virtual_last, bool allow_virtual = true) {
   Context& c = ctx();
   hipStream_t st = c.stream;
   *nlines = 0;
@@ -530,7 +540,7 @@ static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d
     MG_TRY(exclusive_sum_u32_to_u64(d_cnt, d_base, nblocks, &total));
     MG_HIP(hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
-    *virtual_last = last != '\n';
+    *virtual_last = allow_virtual && last != '\n';  // (a piece of a stream: what follows the last newline is not a line yet)
     uint64_t* d_le = (uint64_t*)scratch("ing_lines", (total + 2) * sizeof(uint64_t));
     if (!d_le) return MG_ERR_NOMEM;
     hipLaunchKernelGGL(k_mark_newlines, dim3((unsigned)nblocks), dim3(kIB), 0, st, d_text, nbytes, d_base, d_le);
@@ -547,29 +557,18 @@ static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d
 
 using namespace mg;
 
-struct mg_reads {
-  DevBuf bases, offsets;
-  uint64_t nreads = 0, nbases = 0;
-};
-
-struct mg_acc_index {
-  DevBuf slot_hash, slot_row, names, name_off;
-  uint64_t slots = 0;
-  uint32_t nacc = 0;
-};
-
-struct mg_sam_batch {
-  DevBuf recs;
-  uint64_t nrecs = 0;
-  std::string last_qname;
-};
+// (mg_reads, mg_acc_index, mg_sam_batch: mg_internal.h)
 
 extern "C" {
 
-int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_reads** out) {
+// final: the text is a whole file (or the last piece of one).  Otherwise it is a piece of a stream that BEGINS on a record
+// boundary: the whole records in it are parsed and *consumed = the byte where the first incomplete record begins (the
+// caller carries [consumed, nbytes) to the front of the next piece).
+static int reads_parse_impl(const uint8_t* d_text, uint64_t nbytes, int format, bool final, uint64_t* consumed, mg_reads** out) {
   MG_REQUIRE_READY();
   if (!out) return fail(MG_ERR_ARG, "null out handle");
   *out = nullptr;
+  if (consumed) *consumed = final ? nbytes : 0;
   if (format < 0 || format > 2) return fail(MG_ERR_ARG, "format must be 0 (fastq), 1 (single-line fasta) or 2 (fasta)");
   if (nbytes > 0 && !d_text) return fail(MG_ERR_ARG, "null device text");
   Context& c = ctx();
@@ -578,7 +577,7 @@ int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_re
   uint64_t* d_le = nullptr;
   uint64_t nlines = 0;
   bool vlast = false;
-  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast));
+  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast, final));
   if (format == 2) {  // sequences over any number of lines
     uint32_t* d_flag = (uint32_t*)scratch("ing_fa_flag", (nlines + 1) * sizeof(uint32_t));
     uint32_t* d_llen = (uint32_t*)scratch("ing_fa_len", (nlines + 1) * sizeof(uint32_t));
@@ -591,6 +590,33 @@ int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_re
       const unsigned grid = grid_for(nlines, 256, (unsigned)c.num_cus * 8);
       hipLaunchKernelGGL(k_fasta_lines, dim3(grid), dim3(256), 0, st, d_text, d_le, nlines, d_flag, d_llen);
       MG_HIP(hipGetLastError());
+      if (!final) {
+        // a record ends where the next header line begins: everything from the LAST header line on waits for the next piece
+        unsigned long long* d_last = (unsigned long long*)scratch("ing_fa_last", 2 * sizeof(unsigned long long));
+        if (!d_last) return MG_ERR_NOMEM;
+        MG_HIP(hipMemsetAsync(d_last, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_fasta_last_header, dim3(grid), dim3(256), 0, st, d_flag, nlines, d_last);
+        MG_HIP(hipGetLastError());
+        uint64_t* pin = host_words();
+        MG_HIP(hipMemcpyAsync(pin + 12, d_last, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+        const uint64_t last = pin[12];  // 1 + line index, 0 = none
+        // (no header in the piece at all: a record longer than the piece, or junk in front of the first header —
+        // nothing is consumed and the caller, whose carry then outgrows its room, takes the whole-file path)
+        const uint64_t use = last ? last - 1 : 0;
+        const uint64_t cut_line = use;  // consumed = the start of line `use` (= the end of line use - 1, + 1)
+        if (cut_line == 0) {
+          if (consumed) *consumed = 0;
+        } else {
+          MG_HIP(hipMemcpyAsync(pin + 12, d_le + (cut_line - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+          MG_HIP(hipStreamSynchronize(st));
+          if (consumed) *consumed = pin[12] + 1;
+        }
+        nlines = use;
+      }
+    }
+    if (nlines) {
+      const unsigned grid = grid_for(nlines, 256, (unsigned)c.num_cus * 8);
       MG_TRY(exclusive_sum_u32_to_u64(d_flag, d_rank, nlines, &nrec));
       hipLaunchKernelGGL(k_fasta_orphans, dim3(grid), dim3(256), 0, st, d_flag, d_rank, nlines, d_llen);
       MG_HIP(hipGetLastError());
@@ -614,7 +640,16 @@ int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_re
   }
   const int lpr = format == 0 ? 4 : 2;
   const uint64_t nrec = nlines / lpr;
-  const uint64_t left = nlines % lpr;
+  const uint64_t left = final ? nlines % lpr : 0;  // (a piece: the lines of an incomplete record are the next piece's)
+  if (!final && consumed) {
+    *consumed = 0;
+    if (nrec) {
+      uint64_t* pin = host_words();
+      MG_HIP(hipMemcpyAsync(pin + 12, d_le + (nrec * lpr - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      *consumed = pin[12] + 1;
+    }
+  }
   if (left) {  // only blank lines may follow the last whole record
     uint64_t le[5] = {0, 0, 0, 0, 0};
     const uint64_t first = nrec * lpr;  // first leftover line
@@ -659,6 +694,15 @@ int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_re
   }
   *out = rd.release();
   return MG_OK;
+}
+
+int mg_reads_parse_dev(const uint8_t* d_text, uint64_t nbytes, int format, mg_reads** out) {
+  return reads_parse_impl(d_text, nbytes, format, true, nullptr, out);
+}
+
+int mg_reads_parse_prefix_dev(const uint8_t* d_text, uint64_t nbytes, int format, int final, uint64_t* consumed, mg_reads** out) {
+  if (!consumed) return fail(MG_ERR_ARG, "null consumed");
+  return reads_parse_impl(d_text, nbytes, format, final != 0, consumed, out);
 }
 
 int mg_reads_parse(const uint8_t* text, uint64_t nbytes, int format, mg_reads** out) {
@@ -742,6 +786,15 @@ void mg_acc_index_free(mg_acc_index* ix) { delete ix; }
 
 static int aln_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
                             bool paf, mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  return mg::aln_tokenize_prefix_dev(d_text, nbytes, ix, prev_qname, paf, true, nullptr, out, err_kind, err_line);
+}
+
+}  // extern "C"
+
+// final = false: a PIECE of the text that begins at a line start; the complete lines in it are tokenised and *consumed =
+// the byte after the last newline (what follows is carried to the next piece by the caller, mg_stream.hip).
+int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
+                                bool paf, bool final, uint64_t* consumed, mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
   MG_REQUIRE_READY();
   if (!out || !ix) return fail(MG_ERR_ARG, "null argument");
   *out = nullptr;
@@ -754,11 +807,18 @@ static int aln_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc
   uint64_t* d_le = nullptr;
   uint64_t nlines = 0;
   bool vlast = false;
-  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast));
+  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast, final));
+  if (consumed) *consumed = final ? nbytes : 0;
   if (nlines == 0) {
     MG_TRY(sb->recs.alloc(16));
     *out = sb.release();
     return MG_OK;
+  }
+  if (!final && consumed) {
+    uint64_t* pin = host_words();
+    MG_HIP(hipMemcpyAsync(pin + 12, d_le + (nlines - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    *consumed = pin[12] + 1;
   }
   LineOut* d_lines = (LineOut*)scratch("sam_lines", nlines * sizeof(LineOut));
   uint32_t* d_ret = (uint32_t*)scratch("sam_ret", nlines * sizeof(uint32_t));
@@ -819,6 +879,8 @@ static int aln_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc
   *out = sb.release();
   return MG_OK;
 }
+
+extern "C" {
 
 int mg_sam_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
                         mg_sam_batch** out, int* err_kind, uint64_t* err_line) {

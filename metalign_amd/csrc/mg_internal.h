@@ -146,6 +146,8 @@ struct DevBuf {
 // Grow-only scratch buffer `name` of at least `bytes` bytes; nullptr (and error text set) on failure.
 void* scratch(const char* name, uint64_t bytes);
 void scratch_release_all();
+// mg_stream.hip: the page-locked slots, DMA stream and events of the file pipelines (kept between calls).
+void stream_release_all();
 
 // Times one kernel family with HIP events on the library stream when profiling is on.
 struct ProfScope {
@@ -248,6 +250,29 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt);
 // Makes the library's current stream wait (on the device) for the stream that built the sketch, if it is another.
 int sketch_wait(const mg_sketch* sk);
 }  // namespace mg
+
+// ---- ingest handles (mg_ingest.hip; mg_stream.hip builds them piece by piece) ----
+struct mg_reads {
+  mg::DevBuf bases, offsets;
+  uint64_t nreads = 0, nbases = 0;
+};
+
+struct mg_acc_index {
+  mg::DevBuf slot_hash, slot_row, names, name_off;
+  uint64_t slots = 0;
+  uint32_t nacc = 0;
+};
+
+struct mg_sam_batch {
+  mg::DevBuf recs;
+  uint64_t nrecs = 0;
+  std::string last_qname;
+};
+
+namespace mg {
+int aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname, bool paf,
+                            bool final, uint64_t* consumed, mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+}
 
 struct mg_filter {
   // Membership pre-filter over a set of hashes (the genome table's): one bit per hash value modulo the size,

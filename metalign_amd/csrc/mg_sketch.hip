@@ -842,6 +842,10 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   // a bucket ran out of slots (more distinct hashes than the hint allowed for): size for the worst case next
   // time and redo this sketch on the list path, which has no such limit
   distinct_hint_for(sk->redo.k) = 1.0;
+  if (!sk->redo.bases)  // a streamed sketch (mg_sketch_stream_*): its reads are gone; the caller streams them again
+    return fail(MG_ERR_CAPACITY, "streamed read sketch (k = %d): a counting-table bucket overflowed (%llu candidates for %llu "
+                "expected); the table hint is reset — stream the reads again", sk->redo.k, (unsigned long long)candidates,
+                (unsigned long long)sk->expect);
   if (rebuilt) *rebuilt = 1;
   sk->index.release();
   sk->hashes.release();
@@ -1063,7 +1067,144 @@ static int sketch_reads_multi_async(const uint8_t* d_bases, const uint64_t* d_of
   return MG_OK;
 }
 
+// ---- streamed read sketch: one set of counting tables, any number of read batches ---------------------------------
+// A sample that arrives in pieces (a file streamed through page-locked chunks while the next chunk is in flight, or a
+// file larger than the device) hashes every piece into the SAME per-k counting tables — the tables are what dedupes and
+// counts, so nothing is sketched per piece and nothing is merged (round 2 made a sketch per piece and merged pairs of
+// them through the host).  Replaces: kmc reading the whole reads file (scripts/select_db.py:45-52).
+struct mg_sketch_stream {
+  int nk = 0;
+  int ks[4] = {0, 0, 0, 0};
+  uint64_t hmax[4] = {0, 0, 0, 0};
+  uint64_t s = 0;
+  const mg_filter* filters[4] = {nullptr, nullptr, nullptr, nullptr};
+  KPlan kp[4];
+  DevBuf tab[4];                           // [slots x 16 B | 4 counter words] per k, zeroed at begin
+  unsigned long long* t_counters[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool fused = false;
+  uint64_t nreads = 0, nbases = 0, expect_bases = 0;
+};
+
+static unsigned stage_bytes_for(uint64_t nbases, uint64_t nreads) {
+  const uint64_t avg = nreads ? (nbases + nreads - 1) / nreads : 0;
+  uint64_t stage = (((64 * avg * 9 / 8 + 64) / 2 + 15) / 16) * 16;
+  if (stage < 1024) stage = 1024;
+  if (stage > 8192) stage = 8192;
+  return (unsigned)stage;
+}
+
+static int stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters,
+                        uint64_t expect_bases, mg_sketch_stream** out) {
+  MG_REQUIRE_READY();
+  if (!out || !ks || !hmaxs) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (nk < 1 || nk > 4) return fail(MG_ERR_ARG, "between 1 and 4 k per streamed sketch");
+  std::unique_ptr<mg_sketch_stream> ss(new mg_sketch_stream());
+  ss->nk = nk;
+  ss->s = s;
+  ss->expect_bases = expect_bases ? expect_bases : 1;
+  ReadPlan rp;
+  rp.nbases = ss->expect_bases;
+  hipStream_t st = ctx().stream;
+  for (int i = 0; i < nk; ++i) {
+    if (ks[i] < 1 || ks[i] > MG_MAX_K) return fail(MG_ERR_ARG, "k=%d outside [1,%d]", ks[i], MG_MAX_K);
+    if (i && ks[i] <= ks[i - 1]) return fail(MG_ERR_ARG, "the k of a streamed sketch must ascend");
+    ss->ks[i] = ks[i];
+    ss->hmax[i] = hmaxs[i] == kReservedHash ? kReservedHash - 1 : hmaxs[i];
+    ss->filters[i] = filters ? filters[i] : nullptr;
+    KPlan& kp = ss->kp[i];
+    plan_k(rp, ks[i], ss->hmax[i], kp);
+    // A table that proves too small costs a second pass over the whole FILE here (the reads are gone), not a redo from
+    // resident reads: twice the room the one-shot path takes (the hint is the previous sample's ratio x 1.25; a sample
+    // up to 2.5 x as diverse as its predecessor still fits), never more than one slot pair per expected candidate.
+    kp.distinct_est = 2.0 * kp.distinct_est < (double)kp.expect ? 2.0 * kp.distinct_est : (double)kp.expect;
+    kp.table = kp.table && plan_table(0, ss->hmax[i], kp.distinct_est, kp.tp);
+    // always the table path here (the list path wants all candidates of the sample in one buffer): a sample too small
+    // for plan_k's threshold gets the smallest table
+    if (!kp.table && !plan_table(0, ss->hmax[i], kp.distinct_est, kp.tp))
+      return fail(MG_ERR_ARG, "k=%d: no counting table for this threshold", ks[i]);
+    kp.table = true;
+    const uint64_t tab_bytes = kp.tp.slots * sizeof(Slot);
+    MG_TRY(ss->tab[i].alloc(tab_bytes + 4 * sizeof(unsigned long long)));
+    kp.tp.tab = ss->tab[i].as<Slot>();
+    ss->t_counters[i] = reinterpret_cast<unsigned long long*>(ss->tab[i].as<uint8_t>() + tab_bytes);
+    ProfScope ps("table_clear");
+    MG_HIP(hipMemsetAsync(ss->tab[i].p, 0, tab_bytes + 4 * sizeof(unsigned long long), st));
+  }
+  ss->fused = nk > 1 && sketch_reads_multi_supported(ss->ks, nk) && !getenv("MG_DEBUG_NO_FUSED");
+  *out = ss.release();
+  return MG_OK;
+}
+
+static int stream_add(mg_sketch_stream* ss, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t nbases) {
+  MG_REQUIRE_READY();
+  if (!ss) return fail(MG_ERR_ARG, "null stream");
+  if (nreads == 0) return MG_OK;
+  if (!d_bases || !d_offsets) return fail(MG_ERR_ARG, "null device input");
+  if (nbases == 0) {  // not told: read the offsets' ends back (one small sync)
+    ReadPlan rp;
+    MG_TRY(plan_reads(d_offsets, nreads, ctx().stream, rp));
+    nbases = rp.nbases;
+  }
+  const unsigned stage = stage_bytes_for(nbases, nreads);
+  if (ss->fused) {
+    MultiKTable tabs[4];
+    for (int i = 0; i < ss->nk; ++i)
+      tabs[i] = MultiKTable{ss->hmax[i], ss->kp[i].tp.tab, ss->t_counters[i], ss->kp[i].tp.shift, ss->filters[i]};
+    MG_TRY(launch_sketch_reads_multi(ss->ks, ss->nk, d_bases, d_offsets, nreads, tabs, stage));
+  } else {
+    for (int i = 0; i < ss->nk; ++i) {
+      int rc = MG_ERR_ARG;
+      dispatch_k(ss->ks[i], [&]<int K>() {
+        rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, ss->hmax[i], nullptr, 0, ss->t_counters[i], ss->kp[i].tp.tab,
+                                    ss->kp[i].tp.shift, stage, ss->filters[i]);
+      });
+      if (rc) return rc;
+    }
+  }
+  ss->nreads += nreads;
+  ss->nbases += nbases;
+  return MG_OK;
+}
+
+static int stream_finish(mg_sketch_stream* ss, mg_sketch** out) {
+  MG_REQUIRE_READY();
+  if (!ss || !out) return fail(MG_ERR_ARG, "null argument");
+  for (int i = 0; i < ss->nk; ++i) out[i] = nullptr;
+  ReadPlan rp;
+  rp.nbases = ss->nbases;
+  rp.stage = stage_bytes_for(ss->nbases, ss->nreads);
+  for (int i = 0; i < ss->nk; ++i) {
+    std::unique_ptr<mg_sketch> sk(new mg_sketch());
+    KPlan& kp = ss->kp[i];
+    // (the hint update at resolution divides the distinct hashes by the candidates EXPECTED: of what was streamed)
+    const double frac = ((double)kp.hmax + 1.0) / 18446744073709551616.0;
+    kp.expect = (uint64_t)((double)ss->nbases * frac);
+    int rc = alloc_table_staging(kp.tp);
+    if (rc == MG_OK) rc = finish_pending(sk.get(), kp, rp, ss->t_counters[i], ss->ks[i], ss->s, nullptr, nullptr, 0, ss->filters[i]);
+    if (rc != MG_OK) {
+      for (int j = 0; j < i; ++j) { mg_sketch_free(out[j]); out[j] = nullptr; }
+      return rc;
+    }
+    out[i] = sk.release();
+  }
+  return MG_OK;
+}
+
 extern "C" {
+
+int mg_sketch_stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters,
+                           uint64_t expect_bases, mg_sketch_stream** out) {
+  return stream_begin(nk, ks, hmaxs, s, filters, expect_bases, out);
+}
+int mg_sketch_stream_add_dev(mg_sketch_stream* ss, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
+                             uint64_t nbases) {
+  return stream_add(ss, d_bases, d_offsets, nreads, nbases);
+}
+int mg_sketch_stream_finish(mg_sketch_stream* ss, mg_sketch** out) { return stream_finish(ss, out); }
+uint64_t mg_sketch_stream_nreads(const mg_sketch_stream* ss) { return ss ? ss->nreads : 0; }
+uint64_t mg_sketch_stream_nbases(const mg_sketch_stream* ss) { return ss ? ss->nbases : 0; }
+void mg_sketch_stream_free(mg_sketch_stream* ss) { delete ss; }
 
 int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, int nk, const int* ks,
                                     const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters, mg_sketch** out) {

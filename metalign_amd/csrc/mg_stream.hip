@@ -1,0 +1,505 @@
+// mg_stream.hip — files -> HBM -> the stages, pipelined inside the library.
+//
+// The reference hands its reads file to `kmc` and its SAM text to a Python loop (scripts/select_db.py:43-52, `.gz` is
+// expected input :146-148; scripts/map_and_profile.py:201-217).  Here the text goes through in PIECES:
+//
+//   reader threads      page cache -> page-locked slots (plain file: positional reads, any number of threads in
+//                       parallel; gzip: zlib inflate straight into the slots — one thread for a plain gzip stream,
+//                       which cannot be entered in the middle, all threads for BGZF, whose blocks say how long they are)
+//   DMA stream          slot i -> device text buffer (i mod 3), behind a HEADROOM in front of which the unfinished
+//                       last record (line) of piece i - 1 is placed ON THE DEVICE — so the upload of piece i + 1 does not
+//                       depend on where piece i was cut and runs while piece i is parsed
+//   library stream      [carry | piece] -> mg_reads_parse_prefix_dev / the SAM tokeniser -> the consumer
+//                       (mg_sketch_stream_add_dev: ONE set of counting tables for the whole file)
+//
+// Nothing of the text ever exists as a host array beyond the slots; the host never looks at a byte of it.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mg_internal.h"
+
+namespace mg {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// byte sources
+// ---------------------------------------------------------------------------------------------------------------------
+struct Source {
+  std::string error;  // set by fill() on failure (a reader thread must not touch the library's error text)
+  virtual ~Source() {}
+  // Piece i of the byte stream into dst (at most cap bytes).  *last = this is the stream's final piece (possibly empty).
+  // Returns the bytes written, -1 on error.  Called for i = 0, 1, 2, ... — by ANY thread in any order when parallel(),
+  // else by one thread in order.
+  virtual int64_t fill(uint64_t i, uint8_t* dst, uint64_t cap, bool* last) = 0;
+  virtual bool parallel() const = 0;
+};
+
+struct PlainSource : Source {
+  int fd = -1;
+  uint64_t off = 0, len = 0, cap_ = 0;
+  ~PlainSource() override { if (fd >= 0) close(fd); }
+  bool parallel() const override { return true; }
+  int64_t fill(uint64_t i, uint8_t* dst, uint64_t cap, bool* last) override {
+    const uint64_t at = i * cap;
+    const uint64_t want = at >= len ? 0 : (len - at < cap ? len - at : cap);
+    *last = at + want >= len;
+    uint64_t got = 0;
+    while (got < want) {
+      const ssize_t n = pread(fd, dst + got, want - got, (off_t)(off + at + got));
+      if (n < 0) { error = std::string("read failed: ") + strerror(errno); return -1; }
+      if (n == 0) { error = "file is shorter than its size said"; return -1; }
+      got += (uint64_t)n;
+    }
+    return (int64_t)got;
+  }
+};
+
+// A gzip (or zlib) stream, members concatenated or not: inflated in order by ONE thread, straight into the slots.
+struct GzipSource : Source {
+  int fd = -1;
+  z_stream zs;
+  bool zs_live = false, ended = false, in_member = false;
+  std::vector<uint8_t> in;
+  uint64_t in_off = 0;  // file offset of the next compressed byte to read
+  GzipSource() { memset(&zs, 0, sizeof(zs)); in.resize(4u << 20); }
+  ~GzipSource() override { if (zs_live) inflateEnd(&zs); if (fd >= 0) close(fd); }
+  bool parallel() const override { return false; }
+  int64_t fill(uint64_t, uint8_t* dst, uint64_t cap, bool* last) override {
+    *last = false;
+    if (ended) { *last = true; return 0; }
+    if (!zs_live) {
+      if (inflateInit2(&zs, 15 + 32) != Z_OK) { error = "inflateInit2 failed"; return -1; }  // gzip or zlib header, detected
+      zs_live = true;
+    }
+    zs.next_out = dst;
+    uint64_t room = cap;
+    while (room > 0) {
+      if (zs.avail_in == 0) {
+        const ssize_t n = pread(fd, in.data(), in.size(), (off_t)in_off);
+        if (n < 0) { error = std::string("read failed: ") + strerror(errno); return -1; }
+        if (n == 0) {  // end of the file
+          if (in_member) { error = "the gzip stream ends in the middle of a member (truncated file)"; return -1; }
+          ended = true;
+          break;
+        }
+        in_off += (uint64_t)n;
+        zs.next_in = in.data();
+        zs.avail_in = (uInt)n;
+      }
+      zs.avail_out = (uInt)(room > 0x40000000ull ? 0x40000000ull : room);
+      const uInt before = zs.avail_out;
+      in_member = true;
+      const int rc = inflate(&zs, Z_NO_FLUSH);
+      room -= before - zs.avail_out;
+      if (rc == Z_STREAM_END) {
+        in_member = false;  // a member ended: another may follow (bgzip, cat a.gz b.gz, pigz -i)
+        if (inflateReset(&zs) != Z_OK) { error = "inflateReset failed"; return -1; }
+      } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+        error = std::string("inflate failed: ") + (zs.msg ? zs.msg : "corrupt gzip data");
+        return -1;
+      }
+    }
+    if (ended) *last = true;
+    return (int64_t)(cap - room);
+  }
+};
+
+// BGZF (bgzip / htslib): gzip members of at most 64 KB that carry their own compressed size (extra field 'BC'), so the
+// file can be indexed without inflating anything and every block inflated independently — by all reader threads.
+struct BgzfSource : Source {
+  struct Block { uint64_t coff; uint32_t csize, isize; };
+  struct Group { uint64_t first, count, bytes; };
+  int fd = -1;
+  std::vector<Block> blocks;
+  std::vector<Group> groups;  // consecutive blocks of at most one piece together
+  ~BgzfSource() override { if (fd >= 0) close(fd); }
+  bool parallel() const override { return true; }
+
+  // true when the file is BGZF from its first to its last byte (every member has the BC field); builds the index
+  static bool is_bgzf_header(const uint8_t* h) {
+    return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' &&
+           h[14] == 2 && h[15] == 0;
+  }
+  bool index(uint64_t fsize, uint64_t cap) {
+    uint64_t at = 0;
+    uint8_t h[18], tail[4];
+    while (at < fsize) {
+      if (fsize - at < 28 || pread(fd, h, 18, (off_t)at) != 18 || !is_bgzf_header(h)) return false;
+      const uint32_t csize = (uint32_t)(h[16] | (h[17] << 8)) + 1u;
+      if (csize < 26 || at + csize > fsize) return false;
+      if (pread(fd, tail, 4, (off_t)(at + csize - 4)) != 4) return false;
+      const uint32_t isize = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+      if (isize > 65536u) return false;
+      blocks.push_back(Block{at, csize, isize});
+      at += csize;
+    }
+    Group g{0, 0, 0};
+    for (uint64_t b = 0; b < blocks.size(); ++b) {
+      if (g.count && g.bytes + blocks[b].isize > cap) { groups.push_back(g); g = Group{b, 0, 0}; }
+      ++g.count;
+      g.bytes += blocks[b].isize;
+    }
+    groups.push_back(g);  // (an empty file has one empty group: the final piece)
+    return true;
+  }
+  int64_t fill(uint64_t i, uint8_t* dst, uint64_t cap, bool* last) override {
+    *last = i + 1 >= groups.size();
+    if (i >= groups.size()) return 0;
+    const Group& g = groups[i];
+    if (g.bytes > cap) { error = "BGZF group larger than a slot"; return -1; }
+    std::vector<uint8_t> cbuf(65536 + 64);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) { error = "inflateInit2 failed"; return -1; }  // raw deflate: the header is skipped by hand
+    uint64_t out = 0;
+    for (uint64_t b = g.first; b < g.first + g.count; ++b) {
+      const Block& blk = blocks[b];
+      if (pread(fd, cbuf.data(), blk.csize, (off_t)blk.coff) != (ssize_t)blk.csize) { error = "short read of a BGZF block"; inflateEnd(&zs); return -1; }
+      const uint32_t xlen = (uint32_t)(cbuf[10] | (cbuf[11] << 8));
+      const uint32_t hdr = 12 + xlen;
+      if (hdr + 8 > blk.csize) { error = "corrupt BGZF block header"; inflateEnd(&zs); return -1; }
+      zs.next_in = cbuf.data() + hdr;
+      zs.avail_in = blk.csize - hdr - 8;
+      zs.next_out = dst + out;
+      zs.avail_out = blk.isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) {
+        error = std::string("inflate of a BGZF block failed: ") + (zs.msg ? zs.msg : "size mismatch");
+        inflateEnd(&zs);
+        return -1;
+      }
+      out += blk.isize;
+      inflateReset(&zs);
+    }
+    inflateEnd(&zs);
+    return (int64_t)out;
+  }
+};
+
+static bool looks_gzip(int fd) {
+  uint8_t h[2];
+  return pread(fd, h, 2, 0) == 2 && h[0] == 0x1f && h[1] == 0x8b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// resources kept between calls (page-locking a slot costs milliseconds: the slots stay)
+// ---------------------------------------------------------------------------------------------------------------------
+struct StreamRes {
+  hipStream_t copy = nullptr;
+  std::vector<uint8_t*> slots;
+  uint64_t slot_bytes = 0;
+  std::vector<hipEvent_t> ev_slot;   // the DMA out of slot s has run
+  hipEvent_t ev_h2d[3] = {nullptr, nullptr, nullptr};     // device buffer b holds its piece
+  hipEvent_t ev_parsed[3] = {nullptr, nullptr, nullptr};  // ... and nothing reads it any more
+};
+static StreamRes g_res;
+
+void stream_release_all() {
+  StreamRes& r = g_res;
+  if (r.copy) { (void)hipStreamSynchronize(r.copy); (void)hipStreamDestroy(r.copy); }
+  for (uint8_t* p : r.slots) (void)hipHostFree(p);
+  for (hipEvent_t e : r.ev_slot) (void)hipEventDestroy(e);
+  for (int b = 0; b < 3; ++b) {
+    if (r.ev_h2d[b]) (void)hipEventDestroy(r.ev_h2d[b]);
+    if (r.ev_parsed[b]) (void)hipEventDestroy(r.ev_parsed[b]);
+  }
+  r = StreamRes();
+}
+
+static int ensure_res(uint64_t slot_bytes, size_t nslots) {
+  StreamRes& r = g_res;
+  if (!r.copy) MG_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+  if (r.slot_bytes != slot_bytes) {
+    for (uint8_t* p : r.slots) (void)hipHostFree(p);
+    r.slots.clear();
+    r.slot_bytes = slot_bytes;
+  }
+  while (r.slots.size() < nslots) {
+    uint8_t* p = nullptr;
+    MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), slot_bytes, hipHostMallocDefault));
+    r.slots.push_back(p);
+  }
+  while (r.ev_slot.size() < nslots) {
+    hipEvent_t e = nullptr;
+    MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    r.ev_slot.push_back(e);
+  }
+  for (int b = 0; b < 3; ++b) {
+    if (!r.ev_h2d[b]) MG_HIP(hipEventCreateWithFlags(&r.ev_h2d[b], hipEventDisableTiming));
+    if (!r.ev_parsed[b]) MG_HIP(hipEventCreateWithFlags(&r.ev_parsed[b], hipEventDisableTiming));
+  }
+  return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the pipeline
+// ---------------------------------------------------------------------------------------------------------------------
+// consumer(d_text, nbytes, final, &consumed): the library-stream side of one piece; [consumed, nbytes) is carried.
+using Consumer = std::function<int(const uint8_t*, uint64_t, bool, uint64_t*)>;
+
+struct SlotState {
+  std::mutex m;
+  std::condition_variable cv;
+  int64_t filled = -1;        // piece number the slot holds (ready for the DMA)
+  int64_t dma_queued = -1;    // piece number whose DMA out of the slot has been queued (ev_slot recorded behind it)
+  int64_t bytes = 0;
+  bool last = false;
+};
+
+static int run_pipeline(Source& src, uint64_t chunk_bytes, int nthreads, const Consumer& consume, uint64_t* pieces_out) {
+  Context& c = ctx();
+  if (chunk_bytes < (1u << 16)) chunk_bytes = 1u << 16;
+  chunk_bytes = (chunk_bytes + 4095) & ~4095ull;
+  const uint64_t headroom = chunk_bytes / 4 > (4u << 20) ? chunk_bytes / 4 : (chunk_bytes < (4u << 20) ? chunk_bytes : (4u << 20));
+  if (nthreads < 1) nthreads = 1;
+  if (!src.parallel()) nthreads = 1;
+  const size_t nslots = (size_t)nthreads + 2;
+  MG_TRY(ensure_res(chunk_bytes, nslots));
+  StreamRes& r = g_res;
+  DevBuf dtext[3];
+  for (int b = 0; b < 3; ++b) MG_TRY(dtext[b].alloc(headroom + chunk_bytes + 64));
+  std::vector<std::unique_ptr<SlotState>> st(nslots);
+  for (auto& p : st) p.reset(new SlotState());
+  std::atomic<uint64_t> next_piece{0};
+  std::atomic<bool> stop{false}, failed{false};
+  std::atomic<int64_t> last_piece{-1};  // known once some reader has seen the end of the stream
+
+  auto reader = [&]() {
+    (void)hipSetDevice(c.device);
+    for (;;) {
+      const uint64_t i = next_piece.fetch_add(1);
+      const int64_t lp = last_piece.load();
+      if (stop.load() || (lp >= 0 && (int64_t)i > lp)) return;
+      const size_t s = i % nslots;
+      SlotState& ss = *st[s];
+      if (i >= nslots) {  // the slot's previous piece must have left it
+        std::unique_lock<std::mutex> lk(ss.m);
+        ss.cv.wait(lk, [&] { return stop.load() || ss.dma_queued == (int64_t)(i - nslots); });
+        if (stop.load()) return;
+        lk.unlock();
+        (void)hipEventSynchronize(r.ev_slot[s]);
+      }
+      bool last = false;
+      const int64_t n = src.fill(i, r.slots[s], chunk_bytes, &last);
+      {
+        std::lock_guard<std::mutex> lk(ss.m);
+        if (n < 0) { failed.store(true); ss.bytes = 0; ss.last = true; }
+        else { ss.bytes = n; ss.last = last; }
+        ss.filled = (int64_t)i;
+      }
+      if (last || n < 0) {
+        int64_t expect = -1;
+        last_piece.compare_exchange_strong(expect, (int64_t)i);
+      }
+      ss.cv.notify_all();
+      if (n < 0) return;
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int t = 0; t < nthreads; ++t) threads.emplace_back(reader);
+  auto shut = [&]() {
+    stop.store(true);
+    for (auto& p : st) { std::lock_guard<std::mutex> lk(p->m); p->cv.notify_all(); }
+    for (auto& t : threads) if (t.joinable()) t.join();
+  };
+
+  int rc = MG_OK;
+  uint64_t carry = 0, npieces = 0;
+  hipStream_t main_st = c.stream;
+  // piece j's DMA is queued BEFORE piece j - 1 is parsed: the copy engine works while this thread waits in the parser
+  auto queue_dma = [&](uint64_t j, int64_t* bytes, bool* last) -> int {
+    const size_t s = j % nslots;
+    const int b = (int)(j % 3);
+    SlotState& ss = *st[s];
+    {
+      std::unique_lock<std::mutex> lk(ss.m);
+      ss.cv.wait(lk, [&] { return ss.filled == (int64_t)j; });
+      *bytes = ss.bytes;
+      *last = ss.last;
+    }
+    if (failed.load()) return fail(MG_ERR_ARG, "%s", src.error.empty() ? "reading the input failed" : src.error.c_str());
+    if (j >= 3) MG_HIP(hipStreamWaitEvent(r.copy, r.ev_parsed[b], 0));  // the buffer's previous piece has been parsed
+    if (*bytes > 0)
+      MG_HIP(hipMemcpyAsync(dtext[b].as<uint8_t>() + headroom, r.slots[s], (size_t)*bytes, hipMemcpyHostToDevice, r.copy));
+    MG_HIP(hipEventRecord(r.ev_slot[s], r.copy));
+    MG_HIP(hipEventRecord(r.ev_h2d[b], r.copy));
+    {
+      std::lock_guard<std::mutex> lk(ss.m);
+      ss.dma_queued = (int64_t)j;
+    }
+    ss.cv.notify_all();
+    return MG_OK;
+  };
+
+  int64_t cur_bytes = 0, nxt_bytes = 0;
+  bool cur_last = false, nxt_last = false;
+  rc = queue_dma(0, &cur_bytes, &cur_last);
+  for (uint64_t j = 0; rc == MG_OK; ++j) {
+    if (!cur_last) rc = queue_dma(j + 1, &nxt_bytes, &nxt_last);
+    if (rc != MG_OK) break;
+    const int b = (int)(j % 3);
+    rc = hipStreamWaitEvent(main_st, r.ev_h2d[b], 0) == hipSuccess ? MG_OK : fail(MG_ERR_HIP, "hipStreamWaitEvent failed");
+    if (rc != MG_OK) break;
+    const uint8_t* text = dtext[b].as<uint8_t>() + headroom - carry;
+    const uint64_t nbytes = carry + (uint64_t)cur_bytes;
+    uint64_t consumed = 0;
+    rc = consume(text, nbytes, cur_last, &consumed);
+    if (rc != MG_OK) break;
+    ++npieces;
+    if (cur_last) break;
+    if (consumed > nbytes) consumed = nbytes;
+    const uint64_t left = nbytes - consumed;
+    if (left > headroom) {
+      rc = fail(MG_ERR_CAPACITY, "a record of more than %llu bytes does not fit the streaming pieces", (unsigned long long)headroom);
+      break;
+    }
+    if (left) {
+      const int nb = (int)((j + 1) % 3);
+      if (hipMemcpyAsync(dtext[nb].as<uint8_t>() + headroom - left, text + consumed, (size_t)left, hipMemcpyDeviceToDevice, main_st) != hipSuccess) {
+        rc = fail(MG_ERR_HIP, "carry copy failed");
+        break;
+      }
+    }
+    carry = left;
+    if (hipEventRecord(r.ev_parsed[b], main_st) != hipSuccess) { rc = fail(MG_ERR_HIP, "hipEventRecord failed"); break; }
+    cur_bytes = nxt_bytes;
+    cur_last = nxt_last;
+  }
+  shut();
+  (void)hipStreamSynchronize(r.copy);
+  if (rc != MG_OK) (void)hipStreamSynchronize(main_st);  // (what was queued may still read the buffers released below)
+  if (pieces_out) *pieces_out = npieces;
+  return rc;
+}
+
+// *chunk_bytes: 0 = the default of the source's kind (64 MB; BGZF 16 MB: many inflating threads, each with a slot).
+static int open_source(const char* path, uint64_t offset, uint64_t length, uint64_t* chunk_bytes, std::unique_ptr<Source>* out, bool* gz) {
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(MG_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return fail(MG_ERR_ARG, "cannot stat %s", path); }
+  const uint64_t fsize = (uint64_t)sb.st_size;
+  *gz = looks_gzip(fd);
+  if (*gz) {
+    if (offset || length) { close(fd); return fail(MG_ERR_ARG, "a byte range of a gzip file cannot be streamed"); }
+    std::unique_ptr<BgzfSource> bz(new BgzfSource());
+    bz->fd = fd;
+    uint64_t bc = *chunk_bytes ? *chunk_bytes : (16ull << 20);
+    if (bc < (1u << 16)) bc = 1u << 16;
+    if (bz->index(fsize, bc)) { *chunk_bytes = bc; *out = std::move(bz); return MG_OK; }
+    bz->fd = -1;  // not BGZF: one inflate stream
+    if (!*chunk_bytes) *chunk_bytes = 64ull << 20;
+    std::unique_ptr<GzipSource> g(new GzipSource());
+    g->fd = fd;
+    *out = std::move(g);
+    return MG_OK;
+  }
+  if (offset > fsize) { close(fd); return fail(MG_ERR_ARG, "offset beyond the end of %s", path); }
+  if (!*chunk_bytes) *chunk_bytes = 64ull << 20;
+  std::unique_ptr<PlainSource> p(new PlainSource());
+  p->fd = fd;
+  p->off = offset;
+  p->len = length ? (offset + length > fsize ? fsize - offset : length) : fsize - offset;
+  *out = std::move(p);
+  return MG_OK;
+}
+
+static int default_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  if (const char* e = getenv("MG_STREAM_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+  return (int)(hw > 8 ? 8 : hw);
+}
+
+}  // namespace mg
+
+using namespace mg;
+
+extern "C" {
+
+int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format, uint64_t offset, uint64_t length,
+                              uint64_t chunk_bytes, int nthreads) {
+  MG_REQUIRE_READY();
+  if (!ss || !path) return fail(MG_ERR_ARG, "null argument");
+  if (format < 0 || format > 2) return fail(MG_ERR_ARG, "format must be 0 (fastq), 1 (single-line fasta) or 2 (fasta)");
+  std::unique_ptr<Source> src;
+  bool gz = false;
+  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz));
+  if (nthreads <= 0) nthreads = default_threads();
+  if (gz && src->parallel()) {  // BGZF: inflating is the work — every core the box has
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!getenv("MG_STREAM_THREADS") && hw > (unsigned)nthreads) nthreads = (int)(hw > 32 ? 32 : hw);
+  }
+  Consumer consume = [&](const uint8_t* d_text, uint64_t nbytes, bool final, uint64_t* consumed) -> int {
+    mg_reads* rd = nullptr;
+    MG_TRY(mg_reads_parse_prefix_dev(d_text, nbytes, format, final ? 1 : 0, consumed, &rd));
+    const uint8_t* d_b = nullptr;
+    const uint64_t* d_o = nullptr;
+    int rc = mg_reads_device_ptrs(rd, &d_b, &d_o);
+    if (rc == MG_OK) rc = mg_sketch_stream_add_dev(ss, d_b, d_o, mg_reads_count(rd), mg_reads_nbases(rd));
+    mg_reads_free(rd);  // (stream-ordered: the hashing kernel queued above still reads it; the pool hands it out behind that)
+    return rc;
+  };
+  return run_pipeline(*src, chunk_bytes, nthreads, consume, nullptr);
+}
+
+// SAM (paf = 0) or PAF text file -> alignment records on the device, through the same pipeline: every piece is cut at its
+// last newline, tokenised (mg_sam_tokenize_dev's rules; the previous retained QNAME carried from piece to piece so that
+// the new-read bit is the whole file's) and its records appended.  Replaces the per-line Python of map_and_process,
+// scripts/map_and_profile.py:201-217.  A line the reference cannot parse: MG_ERR_ARG with err_kind (the caller streams
+// the file through the host tokeniser, which raises what the reference raises).
+int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64_t offset, uint64_t length,
+                       uint64_t chunk_bytes, int nthreads, mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+  MG_REQUIRE_READY();
+  if (!path || !ix || !out) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (err_kind) *err_kind = 0;
+  if (err_line) *err_line = 0;
+  std::unique_ptr<Source> src;
+  bool gz = false;
+  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz));
+  if (nthreads <= 0) nthreads = default_threads();
+  std::vector<std::unique_ptr<mg_sam_batch>> parts;
+  std::string prev;
+  uint64_t total = 0;
+  Consumer consume = [&](const uint8_t* d_text, uint64_t nbytes, bool final, uint64_t* consumed) -> int {
+    mg_sam_batch* b = nullptr;
+    MG_TRY(aln_tokenize_prefix_dev(d_text, nbytes, ix, prev.c_str(), paf != 0, final, consumed, &b, err_kind, err_line));
+    prev = b->last_qname;
+    total += b->nrecs;
+    parts.emplace_back(b);
+    return MG_OK;
+  };
+  MG_TRY(run_pipeline(*src, chunk_bytes, nthreads, consume, nullptr));
+  std::unique_ptr<mg_sam_batch> all(new mg_sam_batch());
+  all->last_qname = prev;
+  all->nrecs = total;
+  if (parts.size() == 1) {
+    all->recs = std::move(parts[0]->recs);
+  } else {
+    MG_TRY(all->recs.alloc((total + 1) * sizeof(mg_aln_rec)));
+    uint64_t at = 0;
+    hipStream_t st = ctx().stream;
+    for (auto& p : parts) {
+      if (p->nrecs)
+        MG_HIP(hipMemcpyAsync(all->recs.as<mg_aln_rec>() + at, p->recs.p, p->nrecs * sizeof(mg_aln_rec), hipMemcpyDeviceToDevice, st));
+      at += p->nrecs;
+    }
+    MG_HIP(hipStreamSynchronize(st));
+  }
+  *out = all.release();
+  return MG_OK;
+}
+
+}  // extern "C"

@@ -17,8 +17,9 @@ Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "g
 Several k (the reference's query is multi-k: `30-60-10`, scripts/select_db.py:75): every k has its own sketch table,
 membership filter, hash-range bounds and sample sketch; ONE pass hashes the reads for all of them (stage A, fused
 into one launch when the library has the k set instantiated), runs stage B per k and stage C once.  The exchanges
-carry all k together: the per-rank words of every k travel in the one all-gather, the slices of every k in one
-all-to-all round, and the one all-reduce holds [hits | sizes] for every k.
+carry all k together: the per-rank words of every k travel in the one all-gather, and the one all-reduce holds
+[hits | sizes] for every k; the sketch slices move in one all-to-all round PER k (two all_to_all_single calls each:
+hashes and counts), all of them queued before the first is waited for.
 The compute calls go through an `engine` (HipEngine below: libmetalign_hip.so on this rank's GPU).  The
 CPU tests substitute an oracle-backed engine to check the choreography under gloo; product code never does.
 """

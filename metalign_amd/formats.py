@@ -104,7 +104,9 @@ class SketchTable:
             else:  # version 1: invert on the host (once per process)
                 h, o = self.arrays(k)
                 ph, pg, gs = pairs_from_genome_major(np.asarray(h), o)
-            assert len(ph) == len(pg) and len(gs) == self.ngenomes
+            if len(ph) != len(pg) or len(gs) != self.ngenomes:
+                raise ValueError("sketch table %s, k = %d: %d hashes, %d genome ids, %d genome sizes for %d genomes — the files do "
+                                 "not belong together" % (self.path, k, len(ph), len(pg), len(gs), self.ngenomes))
             self._maps[k] = (ph, pg, gs)
         return self._maps[k]
 
@@ -123,6 +125,8 @@ class SketchTable:
         a = int(np.searchsorted(ph, np.uint64(lo or 0), side="left"))
         b = len(ph) if hi is None or hi > 0xFFFFFFFFFFFFFFFF else int(np.searchsorted(ph, np.uint64(hi), side="left"))
         sl = np.bincount(np.asarray(pg[a:b]), minlength=self.ngenomes).astype(np.uint32)
+        if len(sl) != self.ngenomes:  # (a genome id >= ngenomes in the slice: bincount grew)
+            raise ValueError("sketch table %s, k = %d: genome id %d in a table of %d genomes" % (self.path, k, len(sl) - 1, self.ngenomes))
         return dict(pair_hash=ph[a:b], pair_gen=pg[a:b], gsize=sl, max_hash=mx)
 
     def filter_bits(self, k):
@@ -195,3 +199,31 @@ def write_sketch_table_v1(path, names, ks, n, per_k):
 
 def default_table_dir(data_dir):
     return os.path.join(data_dir, "sketch_table")
+
+
+def is_gzip(path):
+    with open(path, 'rb') as fh:
+        return fh.read(2) == b'\x1f\x8b'
+
+
+def inflate_file(path, block=16 << 20):
+    """A gzip file's text (every member of it: bgzip, `cat a.gz b.gz`), inflated with zlib on large blocks — the gzip
+    module's file object spends most of its time in small reads.  OSError for a stream that ends inside a member."""
+    import zlib
+    out = []
+    with open(path, 'rb') as fh:
+        d, fed = zlib.decompressobj(47), False
+        while True:
+            buf = fh.read(block)
+            if not buf:
+                break
+            while buf:
+                fed = True
+                out.append(d.decompress(buf))
+                if d.eof:  # a member ended: another may follow
+                    buf, d, fed = d.unused_data, zlib.decompressobj(47), False
+                else:
+                    buf = b''
+        if fed:
+            raise OSError('%s: the gzip stream ends in the middle of a member' % path)
+    return b''.join(out)

@@ -152,7 +152,12 @@ def tokenise_paf(lines, acc_index, decode=False):
     total = col 2 (query length) — without `-c` PAF carries no CIGAR, so filter_line (:86-100) can only be
     approximated; len(SEQ) <- query length for primaries, 0 for secondaries (SAM writes '*' there).
     Pair flags do not exist in PAF: every read is treated as single-end."""
-    rows, prev = [], ''
+    return _tokenise_paf_from(lines, acc_index, '', decode)[0]
+
+
+def _tokenise_paf_from(lines, acc_index, prev, decode=False):
+    """tokenise_paf with the previous retained QNAME handed in and out: (records, last retained QNAME)."""
+    rows = []
     for line in lines:
         if isinstance(line, (bytes, bytearray)):  # a file opened in binary mode (map_main does), or the aligner's pipe
             line = line.decode('utf-8')
@@ -187,7 +192,7 @@ def tokenise_paf(lines, acc_index, decode=False):
         prev = f[0]
         rows.append((acc_index[f[5]] | (_hip.NEW_BIT if new else 0), matched, total,
                      flag | (seqlen << _hip.LEN_SHIFT)))
-    return np.array(rows, dtype=_hip.REC_DTYPE) if rows else np.zeros(0, dtype=_hip.REC_DTYPE)
+    return (np.array(rows, dtype=_hip.REC_DTYPE) if rows else np.zeros(0, dtype=_hip.REC_DTYPE)), prev
 
 
 _CHUNK_BYTES = 256 << 20
@@ -254,12 +259,25 @@ def tokenise_sam_device(instream, acc_index, decode=False, paf=False):
             try:
                 recs, prev = hip.sam_tokenize(chunk, index, prev, paf=paf)
             except _hip.SamParseError as e:
-                bad = bytes(chunk).split(b'\n')[e.line].decode('utf-8', 'replace')
+                lines = bytes(chunk).split(b'\n')
+                bad = lines[e.line].decode('utf-8', 'replace')
                 if paf:
                     tokenise_paf([bad], acc_index)  # raises KeyError / ValueError / ZeroDivisionError
                 else:
                     _Tokeniser(acc_index).feed(bad)  # raises KeyError / IndexError / ValueError / ZeroDivisionError
-                raise
+                # The host statement takes the line: the device parser is the stricter of the two (Python's int() accepts
+                # surrounding blanks, '_' between digits and values of any size; the kernel does not).  The host
+                # tokeniser is the definition — this chunk goes through it, carrying the previous QNAME in and out.
+                if lines and not lines[-1]:
+                    lines.pop()  # (the chunk ends in a newline)
+                if paf:
+                    recs, prev = _tokenise_paf_from(lines, acc_index, prev)
+                else:
+                    tk = _Tokeniser(acc_index)
+                    tk.prev = prev
+                    for ln in lines:
+                        tk.feed(ln.decode('utf-8'))
+                    recs, prev = tk.records(), tk.prev
             parts.append(recs)
     finally:
         index.free()
@@ -358,17 +376,23 @@ def map_and_process_file(args, path, acc2info, taxid2info, _want_lists=True, _re
         # the text plus ~60 B per line of line index and tokeniser output must fit beside what is resident already:
         # otherwise straight to the streaming path (256 MB chunks), without first filling the device and failing
         free, _, pooled = hip.mem_info()
-        if 2 * os.path.getsize(path) > free + pooled:
+        streamed = os.environ.get('MG_NO_STREAM') != '1'
+        # (streamed: only the 16-byte records — ~1/20 of the text — and three chunks of text are ever resident)
+        if (os.path.getsize(path) // 8 if streamed else 2 * os.path.getsize(path)) > free + pooled:
             return None
         try:
-            d_text, size = hip.upload_file(path)
-            batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '', paf=_paf)
+            if not streamed:  # the whole text up, then one tokeniser call (round 2's path)
+                d_text, size = hip.upload_file(path)
+                batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '', paf=_paf)
+            else:
+                # reader threads -> page-locked chunks -> HBM -> tokeniser, chunk i + 1 in flight while chunk i is tokenised
+                batch = hip.sam_stream_file(path, index, paf=_paf, chunk_bytes=int(os.environ.get('MG_STREAM_CHUNK_BYTES', 0)))
         except _hip.SamParseError:
             return None
         except _hip.HipError as e:
             # the whole file as ONE batch did not fit (hipMalloc failed, or the text exceeds what one ingest call
             # takes): the streaming path tokenises it in 256 MB chunks instead
-            if e.code in (_hip.ERR_NOMEM, _hip.ERR_ARG):
+            if e.code in (_hip.ERR_NOMEM, _hip.ERR_ARG, _hip.ERR_CAPACITY):  # (capacity: a line longer than a chunk's headroom)
                 return None
             raise
         finally:
@@ -526,8 +550,8 @@ def map_and_process_file_dist(args, path, acc2info, taxid2info, ctx, _want_lists
     bad = 0
     try:
         try:
-            d_text, size = hip.upload_file(path, offset=start, length=end - start)
-            batch = hip.sam_tokenize_dev_batch(d_text.ptr, size, index, '')
+            if end > start:
+                batch = hip.sam_stream_file(path, index, offset=start, length=end - start)
         except (_hip.SamParseError, _hip.HipError):
             bad = 1
         finally:
@@ -748,7 +772,8 @@ def compute_abundances(args, infile, acc2info, tax2info):
     # subsumed by the membership test inside the resolve step (a taxon dropped there is dropped here too)
     on_device = bool(getattr(args, 'device_multimap', False))
     done = None
-    seams_untouched = _device_tokenise is tokenise_sam_device and _device_assign is _DEVICE_ASSIGN  # (tests reroute them)
+    seams_untouched = (_device_tokenise is tokenise_sam_device and _device_tokenise_paf is tokenise_paf_device
+                       and _device_assign is _DEVICE_ASSIGN)  # (tests reroute them)
     paf = bool(getattr(args, 'paf_input', False))
     if args.input_type == 'sam' and seams_untouched and not paf:
         from .select_db import dist_context

@@ -40,7 +40,8 @@ def _wire_stages(args):
 def main(argv=None):
     args = metalign_parseargs(argv)
     args.data = cli.with_slash(args.data)
-    if args.temp_dir == 'AUTO/':
+    own_temp = args.temp_dir == 'AUTO/'  # a directory of this process's own making (one per rank in a multi-GPU launch)
+    if own_temp:
         args.temp_dir = tempfile.mkdtemp(prefix=args.data)
     args.temp_dir = cli.with_slash(args.temp_dir)
     if args.dbinfo_in == 'AUTO':
@@ -54,8 +55,11 @@ def main(argv=None):
     select.select_main(args)
     import os
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and int(os.environ.get('RANK', '0')) != 0:
-        # a multi-GPU launch (torch.distributed.run): the ranks share stages A + B; rank 0 aligns and profiles
-        if not args.keep_temp_files:
+        # a multi-GPU launch (torch.distributed.run): the ranks share stages A + B; rank 0 aligns and profiles.
+        # An explicit --temp_dir is ONE directory for all ranks: rank 0 is still reading the CSV from it, writing the
+        # subset database into it and aligning against it — only rank 0 removes it, after map_main.  A rank's own
+        # mkdtemp (AUTO) holds nothing anybody else reads.
+        if own_temp and not args.keep_temp_files:
             shutil.rmtree(args.temp_dir, ignore_errors=True)
         return
     mapper.map_main(args)

@@ -237,8 +237,6 @@ def run_sketch_steps_dist(args, ctx):
     import torch
     from .distributed import ShardJob
     dist, rank, world, hip = ctx
-    if args.reads.endswith('.gz'):
-        sys.exit('Error: a .gz reads file cannot be split by byte range; inflate it first for a multi-GPU run.')
     table_dir = getattr(args, 'sketch_table', 'AUTO')
     if table_dir in (None, 'AUTO'):
         table_dir = formats.default_table_dir(args.data)
@@ -252,10 +250,16 @@ def run_sketch_steps_dist(args, ctx):
         dist.all_gather(out, t)
         return [int(o.item()) for o in out]
 
-    start, end = read_range_of_rank(args.reads, args.input_type, rank, world, gather)
-    with open(args.reads, 'rb') as fh:
-        fh.seek(start)
-        text = fh.read(end - start)
+    if formats.is_gzip(args.reads):
+        # a gzip stream cannot be entered in the middle: rank 0 inflates it (zlib, members one after the other) and
+        # sketches all of it; the other ranks bring empty shards to the exchange and their table slices to stage B.
+        # Inflating — ~0.3 GB/s of text per core — is what such a run waits for, not the hashing (one GPU takes 200 GB/s).
+        text = formats.inflate_file(args.reads) if rank == 0 else b''
+    else:
+        start, end = read_range_of_rank(args.reads, args.input_type, rank, world, gather)
+        with open(args.reads, 'rb') as fh:
+            fh.seek(start)
+            text = fh.read(end - start)
     reads = hip.parse_reads(text, 'fastq' if args.input_type == 'fastq' else 'fasta_ml')
     rb, ro = reads.download()
     reads.free()
@@ -314,6 +318,51 @@ def iter_read_batches(hip, path, kind, batch_bytes):
             carry = data[cut:]
 
 
+def expected_bases(path, kind):
+    """Roughly the bases in a reads file, from its size: sizes the streamed sketch's counting tables (an estimate that
+    proves too small is caught — a table overflow — and the file streamed again).  FASTQ: half the bytes are bases;
+    gzip: DNA text deflates about 4 x."""
+    size = os.path.getsize(path)
+    if path.endswith('.gz'):
+        size *= 4
+    return int(size * (0.5 if kind == 'fastq' else 1.0)) + 1
+
+
+def stream_reads_file(hip, path, kind, ks, hmaxs, s, filts, offset=0, length=0):
+    """The reads file -> read sketches of every k, streamed: reader threads fill page-locked chunks (plain files by
+    positional reads in parallel, `.gz` inflated by zlib inside the library — BGZF blocks in parallel), chunk i + 1 goes up
+    while chunk i is parsed ON THE DEVICE and hashed into ONE set of counting tables (mg_sketch_stream_add_file): no
+    per-chunk sketch, no merge, and the text never exists as a host array.  What kmc does with the reads file,
+    scripts/select_db.py:45-52 (`.gz` expected: :146-148).
+    None when the file does not suit the pipeline (a record larger than a chunk's headroom; FASTA text the device parser
+    rejects): the caller takes the piece-wise path, whose host parser decides."""
+    fmt = 'fastq' if kind == 'fastq' else 'fasta_ml'
+    expect = expected_bases(path, kind) if not length else int(length * (0.5 if kind == 'fastq' else 1.0)) + 1
+    chunk = int(os.environ.get('MG_STREAM_CHUNK_BYTES', 0))
+    for attempt in range(2):
+        stream = hip.sketch_stream(ks, hmaxs, s, filts, expect)
+        sks = []
+        try:
+            stream.add_file(path, fmt, offset=offset, length=length, chunk_bytes=chunk)
+            sks = stream.finish()
+            for sk in sks:
+                sk.resolve()
+            return sks
+        except _hip.HipError as e:
+            for sk in sks:
+                sk.free()
+            if e.code == _hip.ERR_CAPACITY and attempt == 0 and stream.nbases:
+                # a counting table overflowed: the library has reset its hint to the worst case; size for what was seen
+                expect = max(expect, int(stream.nbases * 1.25))
+                continue
+            if e.code == _hip.ERR_CAPACITY or (e.code == _hip.ERR_ARG and kind != 'fastq'):
+                return None
+            raise
+        finally:
+            stream.free()
+    return None
+
+
 def _merge_two(hip, a, b, k, hmax, s):
     """Union of two read sketches of the same k with saturating count sums (mg_sketch_merge_dev: the multi-GPU merge,
     here for the pieces of one sample).  Frees both inputs."""
@@ -352,11 +401,11 @@ def run_sketch_steps(args):
     # ... then ONE pass over the reads for all k (the reference's query is multi-k too: 30-60-10, :75), and stage B per k
     # (a reads file larger than a quarter of the free device memory — or MG_READ_BATCH_BYTES — goes through in
     # record-aligned pieces whose sketches are merged: saturating counters add up to the same clamped counts)
+    hmaxs = [t.max_hash for t in dev_tables]
+    sks = None if os.environ.get('MG_NO_STREAM') == '1' else stream_reads_file(hip, args.reads, args.input_type, table.ks, hmaxs, s, filts)
     free, _, pooled = hip.mem_info()
     batch_bytes = int(os.environ.get('MG_READ_BATCH_BYTES', 0)) or max((free + pooled) // 4, 1 << 26)
-    hmaxs = [t.max_hash for t in dev_tables]
-    sks = None
-    for reads in iter_read_batches(hip, args.reads, args.input_type, batch_bytes):
+    for reads in (iter_read_batches(hip, args.reads, args.input_type, batch_bytes) if sks is None else ()):
         d_b_ptr, d_o_ptr = reads.device_ptrs()
         if sks is None and reads.count > int(os.environ.get('MG_PRIME_READS', 4_000_000)):
             # the library sizes a k's counting table from the distinct-to-candidate ratio of its previous call and has
@@ -370,7 +419,7 @@ def run_sketch_steps(args):
             sk.resolve()  # (a sketch whose counting table overflowed is redone from the reads: before they go)
         reads.free()
         sks = part if sks is None else [_merge_two(hip, a, b, k, hm, s) for a, b, k, hm in zip(sks, part, table.ks, hmaxs)]
-    if sks is None:  # an empty reads file
+    if sks is None:  # an empty reads file (on the piece-wise path)
         empty = _HostParsedReads(hip, np.zeros(0, np.uint8), np.zeros(1, np.uint64))
         sks = hip.sketch_reads_multi_dev_async(*empty.device_ptrs(), 0, table.ks, hmaxs, s, filts)
         for sk in sks:
@@ -458,6 +507,10 @@ def select_main(args=None):
         run_sketch_steps_dist(args, ctx)
         if ctx[1] != 0:
             return
+    elif int(os.environ.get('WORLD_SIZE', '1')) > 1 and int(os.environ.get('RANK', '0')) != 0:
+        # a multi-GPU launch with --cmash_results given: nothing to sketch, and the host-only tail below writes
+        # args.db / args.dbinfo_out — ONE writer, rank 0 (W ranks appending zcat output to the same file interleave)
+        return
     elif args.cmash_results == 'NONE':
         run_sketch_steps(args)
     organisms = run_cmash_and_cutoff(args, taxid2info)

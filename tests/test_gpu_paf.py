@@ -110,3 +110,28 @@ def test_paf_device_tokeniser_edges(hip):
             mp.tokenise_paf(bad.splitlines(True), acc_index)
         with pytest.raises(exc):
             mp.tokenise_paf_device([good.encode() + b"\n" + bad.encode()], acc_index)
+
+
+def test_lines_the_host_accepts_but_the_device_parser_does_not_go_through_the_host(hip):
+    """Python's int() takes surrounding blanks, '_' between digits and numbers of any size; the kernel's integer
+    parser takes digits.  The host tokeniser is the definition: a chunk with such a line is tokenised on the host,
+    with the previous QNAME carried in and out, instead of failing (the bare re-raise)."""
+    acc_index = {"Unmapped": 0, "NZ_A.1": 1, "NZ_B.1": 2}
+    text = ("r1\t40\t5\t40\t+\tNZ_A.1\t5000\t9\t44\t34\t35\t60\ttp:A:P\tcg:Z:35M\n"
+            "r1\t 40 \t0\t3_8\t-\tNZ_B.1\t5000\t98\t138\t36\t40\t0\ttp:A:S\tcg:Z:30M2D8M\n"   # ' 40 ' and '3_8': int() takes both
+            "r2\t100\t0\t100\t+\tNZ_A.1\t5000\t0\t100\t90\t100\t60\n"
+            "r2\t100\t0\t100\t+\tNZ_B.1\t5000\t0\t100\t0090\t100\t60\ttp:A:S\n")
+    want = mp.tokenise_paf(text.splitlines(True), acc_index)
+    got = mp.tokenise_paf_device([text.encode()], acc_index)
+    assert len(want) == 4 and np.array_equal(got, want)
+    # two chunks: the second starts in the middle of read r2 — the carried QNAME keeps its new-read bit clear
+    lines = text.splitlines(True)
+    got2 = mp.tokenise_paf_device(iter([l.encode() for l in lines]), acc_index)  # (an iterator of lines is batched into one chunk)
+    assert np.array_equal(got2, want)
+    old = mp._CHUNK_BYTES
+    mp._CHUNK_BYTES = 64
+    try:
+        got3 = mp.tokenise_paf_device(iter([l.encode() for l in lines]), acc_index)
+    finally:
+        mp._CHUNK_BYTES = old
+    assert np.array_equal(got3, want)

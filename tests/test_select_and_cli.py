@@ -279,3 +279,71 @@ def test_sam_pieces_of_a_multi_gpu_launch_give_the_same_record_stream(tmp_path):
             got["ref_new"][i] &= 0x7FFFFFFF
         offs = mp.clear_continued_heads(clear, [len(p) for p in pieces], firsts, lasts)
         assert offs[-1] == len(whole) and np.array_equal(got, whole), world
+
+
+def test_only_rank_0_writes_the_subset_database_when_cmash_results_is_given(tmp_path, monkeypatch):
+    """A torch.distributed.run launch with --cmash_results: nothing to sketch, and the host-only tail
+    (run_cmash_and_cutoff + make_db_and_dbinfo, reference scripts/select_db.py:80-117) has ONE writer — W ranks
+    appending zcat output to the same args.db would interleave."""
+    def args_for(sub):
+        d = tmp_path / sub
+        d.mkdir()
+        return argparse.Namespace(reads="reads.fq", data=SEL + "/", cmash_results=os.path.join(SEL, "basic.csv"), cutoff=0.01,
+                                  db=str(d / "db.fna"), db_dir="AUTO", dbinfo_in="AUTO", dbinfo_out=str(d / "sub.txt"),
+                                  input_type="fastq", keep_temp_files=False, strain_level=False, temp_dir=str(d) + "/", threads=1)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "2")
+    a = args_for("rank2")
+    select_db.select_main(a)
+    assert not os.path.exists(a.db) and not os.path.exists(a.dbinfo_out)
+    monkeypatch.setenv("RANK", "0")
+    a = args_for("rank0")
+    select_db.select_main(a)
+    assert os.path.getsize(a.db) > 0 and os.path.getsize(a.dbinfo_out) > 0
+
+
+def test_other_ranks_leave_a_shared_temp_dir_alone(tmp_path, monkeypatch):
+    """metalign.py under torch.distributed.run with an explicit --temp_dir: the directory is shared by all ranks and
+    rank 0 is still working in it (CSV, subset database, the aligner) when the others are done — only rank 0 removes
+    it, after map_main; with the AUTO default every rank removes the directory it made itself."""
+    calls = []
+    monkeypatch.setattr(select_db, "select_main", lambda args: calls.append(("select", args.temp_dir)))
+    monkeypatch.setattr(map_and_profile, "map_main", lambda args: calls.append(("map", args.temp_dir)))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    (shared / "cmash_query_results.csv").write_text("x")
+    data = tmp_path / "data"
+    data.mkdir()
+    argv = ["reads.fq", str(data), "--temp_dir", str(shared), "--input_type", "fastq"]
+    monkeypatch.setenv("RANK", "1")
+    metalign.main(argv)
+    assert shared.exists() and (shared / "cmash_query_results.csv").exists() and [c[0] for c in calls] == ["select"]
+    monkeypatch.setenv("RANK", "0")
+    metalign.main(argv)
+    assert not shared.exists() and [c[0] for c in calls] == ["select", "select", "map"]
+    # AUTO: a rank's own mkdtemp goes away with the rank
+    calls.clear()
+    monkeypatch.setenv("RANK", "1")
+    metalign.main(["reads.fq", str(data), "--input_type", "fastq"])
+    assert calls and not os.path.exists(calls[0][1])
+
+
+def test_inflate_file_takes_every_member_and_refuses_a_truncated_stream(tmp_path):
+    """`.gz` reads are expected input (reference scripts/select_db.py:146-148): formats.inflate_file is what rank 0 of a
+    multi-GPU launch inflates them with."""
+    import gzip
+
+    from metalign_amd import formats
+    data = bytes(range(256)) * 4000 + b"ACGT" * 50000
+    one, two, cut, empty = (tmp_path / n for n in ("one.gz", "two.gz", "cut.gz", "empty.gz"))
+    one.write_bytes(gzip.compress(data, 1))
+    two.write_bytes(gzip.compress(data[:300000], 1) + gzip.compress(data[300000:], 9))
+    cut.write_bytes(gzip.compress(data, 1)[:-3000])
+    empty.write_bytes(gzip.compress(b""))
+    assert formats.is_gzip(str(one)) and not formats.is_gzip(__file__)
+    assert formats.inflate_file(str(one)) == data
+    assert formats.inflate_file(str(two), block=70001) == data
+    assert formats.inflate_file(str(empty)) == b""
+    with pytest.raises(OSError):
+        formats.inflate_file(str(cut))
