@@ -6,7 +6,7 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
     stage B  containment per k (k_contain_pairs vs the genome sketch table of that k)     scripts/select_db.py:54-56,73-76
     stage C  assign + histogram (k_profile_pass), once                                    scripts/map_and_profile.py:193-264
 File I/O, PCIe, on-device ingest and the host CAMI tail are NOT in the timed region; `with_ingest` reports the kept
-command line end to end (files on disk -> subset DB / CAMI profile) on a 1M-read sample as a secondary figure.
+command line end to end (files on disk -> subset DB / CAMI profile) on the SAME workload as a secondary figure.
 
 Workloads = BASELINE.json configs:
   --config 1   1M reads vs 1k genomes (50 kb), k = 21                                  (the reference-sized case)
@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_READ_K1 = 158  # 150 B of bases + 8 B offset, one pass for all k
 ALGO_BYTES_PER_RECORD_K3 = 16
 HBM_PEAK_GBS = 8000.0
-SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+SIMDS, XCDS = 1024, 8  # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
 
 PRESETS = {
     1: dict(reads=1_000_000, genomes=1000, genome_len=50_000, ks=[21], ntax=None,
@@ -112,7 +112,7 @@ def build_workload(cfg, sketch_n, rank, hip):
         ref2tax = (np.arange(G + 1, dtype=np.uint64) % np.uint64(cfg["ntax"])).astype(np.uint32)
     tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in cfg["ks"]]  # stage A' on the GPU (not timed)
     return dict(rb=rb, ro=ro, src=src, recs=recs, ref2tax=ref2tax, ntax=int(ref2tax.max()) + 1,
-                dbh=[t[0] for t in tables], dbo=[t[1] for t in tables])
+                dbh=[t[0] for t in tables], dbo=[t[1] for t in tables], gb=gb, go=go)
 
 
 def make_job(hip, dist, rank, world, cfg, w, force_dist=False, sub=None):
@@ -214,6 +214,35 @@ def committed_profile(name, cfg):
             if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")])) == (cfg["reads"], cfg["genomes"], cfg["ks"]):
                 best = d
     return best
+
+
+def valu_roofline(sq, ms_alone_live):
+    """valu_frac and what it was computed from; {} of Nones when a piece is missing."""
+    out = {"valu_frac": None, "valu_model": None}
+    if not sq:
+        return out
+    names = sq["k_sketch_reads"]["kernels"]
+    insts = sq["k_sketch_reads"].get("SQ_INSTS_VALU_per_pass")
+    gui = sum(sq["kernels"][k].get("GRBM_GUI_ACTIVE", 0.0) for k in names)
+    model = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        fn = os.path.join(pdir, rnd, "k1_valu_roofline.json")
+        if os.path.isfile(fn):
+            with open(fn) as fh:
+                model = dict(json.load(fh), source="profiles/%s/k1_valu_roofline.json" % rnd)
+    fused = len(names) == 1 and "multi" in names[0]
+    if not (insts and gui and model and fused):
+        return out  # (the per-opcode table is the fused {21,31,51} kernel's)
+    simd_cycles = gui / XCDS * SIMDS
+    cpi = model["cycles_per_valu_instruction"]
+    out["valu_frac"] = insts * cpi / simd_cycles
+    out["valu_model"] = {"cycles_per_valu_instruction": cpi, "valu_instructions_per_wave_step_static": model["valu_instructions_per_wave_step"],
+                         "source": model["source"], "SQ_INSTS_VALU": insts, "GRBM_GUI_ACTIVE": gui,
+                         "simd_cycles_of_the_launch": simd_cycles,
+                         "engine_clock_GHz_in_that_pass": (gui / XCDS) / (sq["kernels"][names[0]].get("duration_ns", 0.0) or float("nan")) if sq["kernels"][names[0]].get("duration_ns") else None,
+                         "ms_per_pass_alone_live": ms_alone_live}
+    return out
 
 
 def committed_run(name, cfg):
@@ -458,19 +487,19 @@ def main():
                             if traffic else None),
                 "avg_launch_ms": k1_ms / max(nk1, 1), "ms_per_pass": k1_per_pass_ms,
                 "algorithmic_bytes_per_pass": algo_k1,
-                # VALU roofline: in the timed region two launches of consecutive passes are co-resident (alternating
-                # streams), so a launch's own duration there is longer than the kernel needs; the fraction is priced with
-                # the launch ALONE (the single-stream steps behind the timed region) and, for the record, with the timed
-                # region's average as well
-                "valu_frac": ((valu_insts * 4.0 / (SIMDS * CLOCK_HZ * kernels_ms["sketch_reads"]["ms_per_pass"] * 1e-3))
-                              if (valu_insts and "sketch_reads" in kernels_ms) else None),
-                "valu_frac_timed_region": (valu_insts * 4.0 / (SIMDS * CLOCK_HZ * k1_per_pass_ms * 1e-3)) if (valu_insts and nk1) else None,
+                # VALU roofline (the kernel is integer-VALU bound), calibrated: every opcode of the hot loop priced with its
+                # measured issue cost (tools/ubench_valu.hip -> profiles/<round>/valu_classes.json; tools/valu_roofline.py
+                # -> k1_valu_roofline.json: cycles per VALU instruction of this kernel's mix), times the VALU instructions the
+                # launch executed, over the SIMD cycles the launch had — both from the SAME committed PMC pass
+                # (SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), the kernel running alone on one stream
+                **valu_roofline(sq, kernels_ms.get("sketch_reads", {}).get("ms_per_pass")),
                 "ms_per_pass_alone": kernels_ms.get("sketch_reads", {}).get("ms_per_pass"),
                 "valu_insts_per_pass": valu_insts,
-                "note": "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU (committed SQ pass "
-                        "of this workload) x 4 cycles / (1024 SIMDs x 2.4 GHz x the live time of the launch running alone) is "
-                        "the figure that describes it; achieved / frac price 158 B/read, one pass for all k, with the average "
-                        "launch duration of the (pipelined) timed region against 8 TB/s"}
+                "note": "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
+                        "cycles per VALU instruction of this kernel's opcode mix / the SIMD cycles of the launch (GRBM_GUI_ACTIVE "
+                        "/ 8 x 1024), all from the committed PMC pass of this workload, is the figure that describes it; achieved "
+                        "/ frac price 158 B/read, one pass for all k, with the average launch duration of the (pipelined) timed "
+                        "region against 8 TB/s"}
         kern = []
         if "containment" in kernels_ms:
             t_b = kernels_ms["containment"]["ms_per_pass"] + kernels_ms.get("contain_index", {}).get("ms_per_pass", 0.0)
@@ -524,9 +553,12 @@ def main():
             del job
             res["secondary"] = secondary_config1(hip, args)
             try:
+                # the kept command line on THIS workload from files on disk (page cache): the same reads as a FASTQ file,
+                # the same tables as a stored sketch table, 1.25 SAM lines per read
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_cli
-                res["with_ingest"] = bench_cli.measure(1_000_000)
+                res["with_ingest"] = bench_cli.measure(nreads, G=cfg["genomes"], ks=tuple(cfg["ks"]), glen=cfg["genome_len"],
+                                                       sketch_n=args.sketch_n, workload=w)
             except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline down)
                 res["with_ingest"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -353,6 +353,11 @@ void mg_db_free(mg_db* db);
  * ------------------------------------------------------------------------ */
 int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci,
                        uint32_t* d_hits, uint32_t* d_sizes);
+/* The same for every k of a pass in ONE launch of each of the three kernels (bucket index, pairs, reduction) — at 10k
+ * genomes a launch is a few tens of microseconds of mostly latency, and a three-k pass had nine of them.  qs[i] against
+ * dbs[i] into d_hits[i] / d_sizes[i], i < nk <= 4. */
+int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* const* dbs, uint32_t ci, uint32_t* const* d_hits,
+                             uint32_t* const* d_sizes);
 int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts,
                    uint64_t qn, int q_truncated, uint32_t ci,
                    const uint64_t* db_hashes, const uint64_t* db_offsets,

@@ -37,7 +37,7 @@ EXPORTS = [
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
-    "mg_containment_dev", "mg_containment",
+    "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
 ]
@@ -968,6 +968,15 @@ class Hip:
     def containment_dev(self, sketch, table, ci, d_hits, d_sizes):
         self._chk(self.lib.mg_containment_dev(sketch.handle, table.handle, ctypes.c_uint32(ci), _vp(d_hits),
                                               _vp(d_sizes)))
+
+    def containment_multi_dev(self, sketches, tables, ci, d_hits, d_sizes):
+        """Stage B of every k of a pass: one launch of each kernel for all of them (mg_containment_multi_dev)."""
+        nk = len(sketches)
+        c_q = (_vp * nk)(*[s.handle for s in sketches])
+        c_t = (_vp * nk)(*[t.handle for t in tables])
+        c_h = (_vp * nk)(*[_vp(p) for p in d_hits])
+        c_s = (_vp * nk)(*[_vp(p) for p in d_sizes])
+        self._chk(self.lib.mg_containment_multi_dev(ctypes.c_int(nk), c_q, c_t, ctypes.c_uint32(ci), c_h, c_s))
 
     def containment(self, sketch, table, ci=2):
         g = table.ngenomes

@@ -20,21 +20,58 @@
 
 namespace mg {
 
+// One k of a stage-B call (every k of a pass goes through ONE launch of each kernel: at 10k genomes a launch is 5-50 us
+// of mostly latency, and a pass had nine of them).
+struct ContainK {
+  // the read sketch and its bucket index
+  const uint64_t* q;
+  const uint32_t* qc;
+  uint64_t qn, q_last;
+  const uint64_t* meta;   // a sketch whose finalisation is deferred: [1] size, [2] last hash still on the device
+  uint32_t* idx;
+  unsigned shift;
+  uint64_t idx_buckets;
+  uint32_t build_index;   // 1: this call builds idx
+  // the table
+  const uint64_t* ph;
+  const uint32_t* pg;
+  const uint32_t* gsize;
+  uint64_t npairs, ngenomes;
+  uint64_t tile0;         // first tile of this k among the tiles of the call
+  // counters
+  uint32_t* hits_part;
+  uint32_t* sizes_part;   // null unless the sketch is truncated
+  uint32_t* hits;
+  uint32_t* sizes;
+};
+constexpr int kMaxContainK = 4;
+struct ContainArgs {
+  ContainK k[kMaxContainK];
+  int nk;
+  uint32_t ci, copies;
+  uint64_t ntiles;        // of all k together
+  uint32_t* zero;         // the hit-counter copies of the call, zeroed by the index kernel (one launch less)
+  uint64_t nzero;
+};
+
 // idx[b] = first position whose hash >= b << shift; idx[nbuckets] = n.  One thread per sketch entry i (and one
 // past the end) writes i into every bucket in (bucket(q[i-1]), bucket(q[i])]: hashes are uniform and there is
 // about one bucket per entry, so that is ~1 store per thread, against a 20-step binary search per bucket.
-__global__ void k_build_index(const uint64_t* __restrict__ q, uint64_t n, unsigned shift, uint64_t nbuckets,
-                              uint32_t* __restrict__ idx, const uint64_t* __restrict__ meta,
-                              uint32_t* __restrict__ zero, uint64_t nzero) {
-  if (meta) n = meta[1];  // a sketch whose finalisation is deferred: its size is still on the device
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_build_index(const ContainArgs a) {
+  const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t z = i; z < nzero; z += stride) zero[z] = 0;  // the hit-counter copies of the same call (one launch less)
-  for (; i <= n; i += stride) {
-    const uint64_t first = i == 0 ? 0 : (q[i - 1] >> shift) + 1;
-    // past the end: only the bucket right after the last hash's is ever read (look-ups stop at q[n-1])
-    const uint64_t last = i == n ? first : (q[i] >> shift);
-    for (uint64_t b = first; b <= last; ++b) idx[b] = (uint32_t)i;
+  for (uint64_t z = i0; z < a.nzero; z += stride) a.zero[z] = 0;
+  for (int ki = 0; ki < a.nk; ++ki) {
+    const ContainK& K = a.k[ki];
+    if (!K.build_index) continue;
+    const uint64_t* __restrict__ q = K.q;
+    const uint64_t n = K.meta ? K.meta[1] : K.qn;
+    for (uint64_t i = i0; i <= n; i += stride) {
+      const uint64_t first = i == 0 ? 0 : (q[i - 1] >> K.shift) + 1;
+      // past the end: only the bucket right after the last hash's is ever read (look-ups stop at q[n-1])
+      const uint64_t last = i == n ? first : (q[i] >> K.shift);
+      for (uint64_t b = first; b <= last; ++b) K.idx[b] = (uint32_t)i;
+    }
   }
 }
 
@@ -44,25 +81,33 @@ constexpr uint32_t kCCap = 2048;        // read-sketch entries staged in LDS per
 
 // hits[g] += 1 for every pair (h, g) with h in the read sketch at count >= ci; sizes (optional, truncated
 // sketches only) counts every pair.  npairs = pairs with hash <= the sketch's completeness bound.
-__global__ __launch_bounds__(kCT) void k_contain_pairs(const uint64_t* __restrict__ q, const uint32_t* __restrict__ qc,
-                                                       uint64_t qn, uint64_t q_last, const uint32_t* __restrict__ idx,
-                                                       unsigned shift, uint32_t ci, const uint64_t* __restrict__ ph,
-                                                       const uint32_t* __restrict__ pg, uint64_t npairs,
-                                                       uint32_t* __restrict__ hits_part, uint32_t* __restrict__ sizes_part,
-                                                       uint64_t ngenomes, uint32_t copy_mask,
-                                                       const uint64_t* __restrict__ meta) {
-  if (meta) { qn = meta[1]; q_last = meta[2]; }  // deferred sketch: size and last hash are still on the device
-  // counters are replicated (copy = workgroup id modulo the number of copies, see mg_containment_dev): a few
-  // abundant genomes collect most hits, and atomics on one address retire one at a time
-  uint32_t* const hits = hits_part + (uint64_t)(blockIdx.x & copy_mask) * ngenomes;
-  uint32_t* const sizes = sizes_part ? sizes_part + (uint64_t)(blockIdx.x & copy_mask) * ngenomes : nullptr;
+__global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
   __shared__ uint64_t s_q[kCCap];
   __shared__ uint32_t s_c[kCCap];
   __shared__ uint64_t s_edge[2];
   constexpr int kPer = kCTile / kCT;
   const int tid = threadIdx.x;
-  const uint64_t ntiles = (npairs + kCTile - 1) / kCTile;
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (uint64_t gtile = blockIdx.x; gtile < a.ntiles; gtile += gridDim.x) {
+    // which k this tile belongs to (tiles of the ks follow each other; block-uniform)
+    int ki = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxContainK; ++j) ki += (j < a.nk && gtile >= a.k[j].tile0) ? 1 : 0;
+    const ContainK& K = a.k[ki];
+    const uint64_t* __restrict__ q = K.q;
+    const uint32_t* __restrict__ qc = K.qc;
+    const uint32_t* __restrict__ idx = K.idx;
+    const uint64_t* __restrict__ ph = K.ph;
+    const uint32_t* __restrict__ pg = K.pg;
+    const unsigned shift = K.shift;
+    const uint32_t ci = a.ci;
+    const uint64_t npairs = K.npairs;
+    const uint64_t qn = K.meta ? K.meta[1] : K.qn;          // deferred sketch: size and last hash are still on the device
+    const uint64_t q_last = K.meta ? K.meta[2] : K.q_last;
+    // counters are replicated (copy = workgroup id modulo the number of copies, see mg_containment_dev): a few
+    // abundant genomes collect most hits, and atomics on one address retire one at a time
+    uint32_t* const hits = K.hits_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes;
+    uint32_t* const sizes = K.sizes_part ? K.sizes_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes : nullptr;
+    const uint64_t tile = gtile - K.tile0;
     const uint64_t t0 = tile * kCTile;
     const uint64_t t1 = t0 + kCTile < npairs ? t0 + kCTile : npairs;
     // this thread's pairs: issued first, they travel while the matching run of the read sketch is located
@@ -171,26 +216,30 @@ __global__ void k_zero_u32(uint32_t* __restrict__ v, uint64_t n) {
 }
 
 // hits[g] = sum over the copies; sizes[g] likewise when they were counted (truncated sketch), else the stored size.
-__global__ void k_contain_reduce(const uint32_t* __restrict__ hits_part, const uint32_t* __restrict__ sizes_part,
-                                 const uint32_t* __restrict__ gsize, uint64_t ngenomes, uint32_t copies,
-                                 uint32_t* __restrict__ hits, uint32_t* __restrict__ sizes) {
-  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_contain_reduce(const ContainArgs a) {
+  const uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; g < ngenomes; g += stride) {
-    uint32_t h = 0, z = 0;
-    for (uint32_t c0 = 0; c0 < copies; c0 += 8) {  // eight independent loads per round trip
-      uint32_t a[8], b[8];
+  for (int ki = 0; ki < a.nk; ++ki) {
+    const ContainK& K = a.k[ki];
+    const uint32_t* __restrict__ hits_part = K.hits_part;
+    const uint32_t* __restrict__ sizes_part = K.sizes_part;
+    const uint64_t ngenomes = K.ngenomes;
+    for (uint64_t g = g0; g < ngenomes; g += stride) {
+      uint32_t h = 0, z = 0;
+      for (uint32_t c0 = 0; c0 < a.copies; c0 += 8) {  // eight independent loads per round trip
+        uint32_t x[8], y[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t c = c0 + u;
-        a[u] = c < copies ? hits_part[(uint64_t)c * ngenomes + g] : 0u;
-        b[u] = (c < copies && sizes_part) ? sizes_part[(uint64_t)c * ngenomes + g] : 0u;
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t c = c0 + u;
+          x[u] = c < a.copies ? hits_part[(uint64_t)c * ngenomes + g] : 0u;
+          y[u] = (c < a.copies && sizes_part) ? sizes_part[(uint64_t)c * ngenomes + g] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { h += x[u]; z += y[u]; }
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { h += a[u]; z += b[u]; }
+      K.hits[g] = h;
+      K.sizes[g] = sizes_part ? z : K.gsize[g];
     }
-    hits[g] = h;
-    sizes[g] = sizes_part ? z : gsize[g];
   }
 }
 
@@ -234,8 +283,9 @@ __global__ void k_upper_bound_one(const uint64_t* __restrict__ uniq, uint64_t n,
 }
 
 // zero / nzero: a buffer to clear in the same launch; *zeroed tells whether that happened.
-static int ensure_index(mg_sketch* sk, uint32_t* zero = nullptr, uint64_t nzero = 0, bool* zeroed = nullptr) {
-  if (zeroed) *zeroed = false;
+// Sizes and allocates the sketch's bucket index if it has none; *build = the index kernel of this call must fill it.
+static int plan_index(mg_sketch* sk, bool* build) {
+  *build = false;
   if (sk->index.p) return MG_OK;
   const bool pending = sk->pending;
   const uint64_t n = pending ? sk->n_bound : sk->n;  // pending: an estimate sizes the index, the kernel reads the true n
@@ -251,12 +301,7 @@ static int ensure_index(mg_sketch* sk, uint32_t* zero = nullptr, uint64_t nzero 
   sk->index_shift = bits - lb;
   sk->index_buckets = 1ull << lb;
   MG_TRY(sk->index.alloc((sk->index_buckets + 1) * sizeof(uint32_t)));
-  ProfScope ps("contain_index");
-  hipLaunchKernelGGL(k_build_index, dim3(grid_for(n + 1, 256, (unsigned)ctx().num_cus * 16)), dim3(256), 0,
-                     ctx().stream, sk->hashes.as<uint64_t>(), sk->n, sk->index_shift, sk->index_buckets,
-                     sk->index.as<uint32_t>(), pending ? sk->meta.as<uint64_t>() : (const uint64_t*)nullptr, zero, nzero);
-  MG_HIP(hipGetLastError());
-  if (zeroed) *zeroed = true;
+  *build = true;
   return MG_OK;
 }
 
@@ -376,58 +421,109 @@ uint64_t mg_db_ngenomes(const mg_db* db) { return db ? db->ngenomes : 0; }
 uint64_t mg_db_max_hash(const mg_db* db) { return db ? db->max_hash : 0; }
 void mg_db_free(mg_db* db) { delete db; }
 
-int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_t* d_hits, uint32_t* d_sizes) {
+// Stage B for every k of a pass: ONE index launch, ONE pairs launch over the tiles of all tables, ONE reduction.
+int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* const* dbs, uint32_t ci, uint32_t* const* d_hits,
+                             uint32_t* const* d_sizes) {
   MG_REQUIRE_READY();
-  if (!q || !db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
-  if (db->ngenomes == 0) return MG_OK;
+  if (nk < 1 || nk > kMaxContainK) return fail(MG_ERR_ARG, "between 1 and %d k per stage-B call", kMaxContainK);
+  if (!qs || !dbs || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
   if (ctx().count_sat && ci > ctx().count_sat)
     return fail(MG_ERR_ARG, "count threshold ci=%u above the counters' saturation cs=%u: nothing could ever match", ci,
                 ctx().count_sat);
-  mg_sketch* sk = const_cast<mg_sketch*>(q);  // the look-up index is a cache inside the handle
-  // A sketch whose finalisation is deferred is consumed as it is when no completeness bound can apply (s = 0):
-  // the kernels read its size and last hash from the device, nothing is synchronised here.
-  if (sk->pending && (sk->redo.s > 0 || sk->has_bound || sk->redo.use_bound)) MG_TRY(sketch_resolve(sk, nullptr));
-  MG_TRY(sketch_wait(sk));  // built on another stream: this one waits for it on the device
-  const uint64_t* d_meta = sk->pending ? sk->meta.as<uint64_t>() : nullptr;
-  uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
-  if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
-  const bool count_sizes = bound != ~0ull;  // truncated sketch: only table hashes <= bound take part, in the sizes too
   Context& c = ctx();
   hipStream_t st = c.stream;
+  ContainArgs a{};
+  a.ci = ci;
+  uint64_t gmax = 0, part_total = 0, index_work = 0, reduce_work = 0;
+  int m = 0;
+  bool any_index = false;
+  struct Pend { mg_sketch* sk; const mg_db* db; bool count_sizes; uint64_t bound; };
+  Pend pend[kMaxContainK];
+  for (int i = 0; i < nk; ++i) {
+    if (!qs[i] || !dbs[i] || !d_hits[i] || !d_sizes[i]) return fail(MG_ERR_ARG, "null argument");
+    if (dbs[i]->ngenomes == 0) continue;
+    mg_sketch* sk = const_cast<mg_sketch*>(qs[i]);  // the look-up index is a cache inside the handle
+    // A sketch whose finalisation is deferred is consumed as it is when no completeness bound can apply (s = 0):
+    // the kernels read its size and last hash from the device, nothing is synchronised here.
+    if (sk->pending && (sk->redo.s > 0 || sk->has_bound || sk->redo.use_bound)) MG_TRY(sketch_resolve(sk, nullptr));
+    MG_TRY(sketch_wait(sk));  // built on another stream: this one waits for it on the device
+    uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
+    if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
+    pend[m] = Pend{sk, dbs[i], bound != ~0ull, bound};  // truncated sketch: only table hashes <= bound take part, in the sizes too
+    ContainK& K = a.k[m];
+    K.hits = d_hits[i];
+    K.sizes = d_sizes[i];
+    if (dbs[i]->ngenomes > gmax) gmax = dbs[i]->ngenomes;
+    ++m;
+  }
+  if (m == 0) return MG_OK;
+  a.nk = m;
   // counter copies: enough to spread a skewed sample's hits, few enough to zero and sum in microseconds
   uint32_t copies = 1;
-  while (copies < 64 && (uint64_t)copies * 2 * db->ngenomes <= 65536) copies *= 2;
-  const uint64_t part_n = (uint64_t)copies * db->ngenomes;
-  const uint64_t zero_n = (count_sizes ? 2 : 1) * part_n;
-  uint32_t* d_part = (uint32_t*)scratch("contain_part", zero_n * sizeof(uint32_t));
+  while (copies < 64 && (uint64_t)copies * 2 * gmax <= 65536) copies *= 2;
+  a.copies = copies;
+  for (int i = 0; i < m; ++i) part_total += (pend[i].count_sizes ? 2 : 1) * (uint64_t)copies * pend[i].db->ngenomes;
+  uint32_t* d_part = (uint32_t*)scratch("contain_part", part_total * sizeof(uint32_t));
   if (!d_part) return MG_ERR_NOMEM;
-  uint32_t* d_part_sizes = count_sizes ? d_part + part_n : nullptr;
-  bool zeroed = false;
-  MG_TRY(ensure_index(sk, d_part, zero_n, &zeroed));
+  a.zero = d_part;
+  a.nzero = part_total;
+  uint64_t at = 0, tiles = 0;
+  for (int i = 0; i < m; ++i) {
+    mg_sketch* sk = pend[i].sk;
+    const mg_db* db = pend[i].db;
+    ContainK& K = a.k[i];
+    bool build = false;
+    MG_TRY(plan_index(sk, &build));
+    any_index = any_index || build;
+    K.q = sk->hashes.as<uint64_t>();
+    K.qc = sk->counts.as<uint32_t>();
+    K.qn = sk->n;
+    K.q_last = sk->last_hash;
+    K.meta = sk->pending ? sk->meta.as<uint64_t>() : nullptr;
+    K.idx = sk->index.as<uint32_t>();
+    K.shift = sk->index_shift;
+    K.idx_buckets = sk->index_buckets;
+    K.build_index = build ? 1u : 0u;
+    if (build) { const uint64_t n = sk->pending ? sk->n_bound : sk->n; if (n + 1 > index_work) index_work = n + 1; }
+    K.ph = db->pair_hash.as<uint64_t>();
+    K.pg = db->pair_gen.as<uint32_t>();
+    K.gsize = db->gsize.as<uint32_t>();
+    K.ngenomes = db->ngenomes;
+    K.hits_part = d_part + at;
+    at += (uint64_t)copies * db->ngenomes;
+    K.sizes_part = nullptr;
+    if (pend[i].count_sizes) { K.sizes_part = d_part + at; at += (uint64_t)copies * db->ngenomes; }
+    K.npairs = db->total;
+    if (pend[i].count_sizes) {  // rare path: one read-back
+      uint64_t* d_bpos = (uint64_t*)scratch("contain_bpos", sizeof(uint64_t));
+      if (!d_bpos) return MG_ERR_NOMEM;
+      hipLaunchKernelGGL(k_upper_bound_one, dim3(1), dim3(64), 0, st, db->pair_hash.as<uint64_t>(), db->total, pend[i].bound, d_bpos);
+      uint64_t* pin = host_words();
+      MG_HIP(hipMemcpyAsync(pin + 20, d_bpos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      K.npairs = pin[20];
+    }
+    K.tile0 = tiles;
+    tiles += (K.npairs + kCTile - 1) / kCTile;
+    if (db->ngenomes > reduce_work) reduce_work = db->ngenomes;
+  }
+  a.ntiles = tiles;
+  {
+    ProfScope ps("contain_index");
+    const uint64_t work = index_work > part_total ? index_work : part_total;
+    hipLaunchKernelGGL(k_build_index, dim3(grid_for(work ? work : 1, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, a);
+    MG_HIP(hipGetLastError());
+  }
   ProfScope ps("containment");
-  if (!zeroed)
-    hipLaunchKernelGGL(k_zero_u32, dim3(grid_for(zero_n, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, d_part, zero_n);
-  uint64_t npairs = db->total;
-  if (count_sizes) {  // rare path: one read-back
-    uint64_t* d_bpos = (uint64_t*)scratch("contain_bpos", sizeof(uint64_t));
-    if (!d_bpos) return MG_ERR_NOMEM;
-    hipLaunchKernelGGL(k_upper_bound_one, dim3(1), dim3(64), 0, st, db->pair_hash.as<uint64_t>(), db->total, bound, d_bpos);
-    uint64_t* pin = host_words();
-    MG_HIP(hipMemcpyAsync(pin + 20, d_bpos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
-    npairs = pin[20];
-  }
-  if (npairs) {
-    const uint64_t ntiles = (npairs + kCTile - 1) / kCTile;
-    hipLaunchKernelGGL(k_contain_pairs, dim3(grid_for(ntiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st,
-                       sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), sk->n, sk->last_hash,
-                       sk->index.as<uint32_t>(), sk->index_shift, ci, db->pair_hash.as<uint64_t>(),
-                       db->pair_gen.as<uint32_t>(), npairs, d_part, d_part_sizes, db->ngenomes, copies - 1, d_meta);
-  }
-  hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(db->ngenomes, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, d_part,
-                     d_part_sizes, db->gsize.as<uint32_t>(), db->ngenomes, copies, d_hits, d_sizes);
+  if (tiles)
+    hipLaunchKernelGGL(k_contain_pairs, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st, a);
+  hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(reduce_work, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, a);
   MG_HIP(hipGetLastError());
   return MG_OK;
+}
+
+int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_t* d_hits, uint32_t* d_sizes) {
+  return mg_containment_multi_dev(1, &q, &db, ci, &d_hits, &d_sizes);
 }
 
 int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts, uint64_t qn, int q_truncated, uint32_t ci,

@@ -180,11 +180,18 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
   if constexpr (MODE != 0) {
     constexpr bool RAGGED = MODE == 2;
     for (uint32_t pos = 0; pos < warm; ++pos) roll.push_clean(cs.at(pos) & 3u);
-    for (uint32_t pos = warm; pos < maxlen; ++pos) {
+    // positions [kmin - 1, kmax - 1): only the smaller k are complete — a scalar condition per k (the ks ascend, so the
+    // tests nest)
+    // (the hash is computed ONCE, into a variable: written twice — as the threshold test and as the value offered —
+    // the four-k kernel ended up with 1.6 x the multiplies, the optimiser no longer merging the two)
+#ifdef MG_K1_SEQUENTIAL  // (A/B builds: every position through the per-k conditional form)
+    constexpr uint32_t kAll = 0xffffffffu;
+#else
+    constexpr uint32_t kAll = (uint32_t)(KMAX - 1);
+#endif
+    const uint32_t some_end = kAll < maxlen ? kAll : maxlen;
+    for (uint32_t pos = warm; pos < some_end; ++pos) {
       roll.push_clean(cs.at(pos) & 3u);
-      // k number I is complete from position K_I - 1 on: a scalar condition per k (the ks ascend, so the tests nest)
-      // (the hash is computed ONCE, into a variable: written twice — as the threshold test and as the value offered —
-      // the four-k kernel ended up with 1.6 x the multiplies, the optimiser no longer merging the two)
       auto one = [&]<int I>() {
         const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll, htab);
         if constexpr (RAGGED) sink.template offer2<I>(pos < len, h <= hmax[I], h, lane);
@@ -193,6 +200,34 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
       [&]<int... I>(std::integer_sequence<int, I...>) {
         ((pos + 1 >= (uint32_t)KL::v[I] ? one.template operator()<I>() : (void)0), ...);
       }(std::make_integer_sequence<int, KL::N>{});
+    }
+    // positions [kmax - 1, maxlen): EVERY k is complete (100 of a 150-base read's positions at {21,31,51}).  Two hashes
+    // of the position at a time in one straight line — their table look-ups (mg_kmer.h) are issued together and the two
+    // independent MurmurHash3 chains interleave, instead of each k's look-ups being waited for just before its own
+    // multiplies — then their threshold tests and the (branchy) candidate hand-over
+    for (uint32_t pos = some_end; pos < maxlen; ++pos) {
+      roll.push_clean(cs.at(pos) & 3u);
+#ifndef MG_K1_ALL  // the hashes two at a time (MG_K1_ALL, A/B builds: all of them at once)
+      auto pair = [&]<int I0>() {
+        constexpr int I1 = I0 + 1 < KL::N ? I0 + 1 : I0;
+        const uint64_t ha = hash_suffix<KL::v[I0], KMAX>(roll, htab);
+        const uint64_t hb = I1 != I0 ? hash_suffix<KL::v[I1], KMAX>(roll, htab) : 0ull;
+        if constexpr (RAGGED) sink.template offer2<I0>(pos < len, ha <= hmax[I0], ha, lane); else sink.template offer<I0>(ha <= hmax[I0], ha, lane);
+        if constexpr (I1 != I0) {
+          if constexpr (RAGGED) sink.template offer2<I1>(pos < len, hb <= hmax[I1], hb, lane); else sink.template offer<I1>(hb <= hmax[I1], hb, lane);
+        }
+      };
+      pair.template operator()<0>();
+      if constexpr (KL::N > 2) pair.template operator()<2>();
+#else
+      uint64_t h[KL::N];
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((h[I] = hash_suffix<KL::v[I], KMAX>(roll, htab)), ...);
+      }(std::make_integer_sequence<int, KL::N>{});
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((RAGGED ? sink.template offer2<I>(pos < len, h[I] <= hmax[I], h[I], lane) : sink.template offer<I>(h[I] <= hmax[I], h[I], lane)), ...);
+      }(std::make_integer_sequence<int, KL::N>{});
+#endif
     }
 #pragma unroll
     for (int i = 0; i < KL::N; ++i)  // the tile's k-mers in closed form, summed over the wavefront into a scalar
@@ -285,8 +320,17 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
 // 157 VGPRs for {21,31,51}: three wavefronts per SIMD (held to 128 — four per SIMD, fifty spilled registers — 16.9
 // against 15.9 ms per 10M reads at configs[2], 49 against 39 ms in the dense regime).  {30,40,50,60} wants 179: held to
 // 168 (eleven spilled) for three wavefronts per SIMD, 22.6 against 23.9 ms.
+// Measured on configs[2] (10M reads; tools/ab_k1.sh, profiles/r03/k1_variants.txt): per-k conditional form at 127 VGPRs
+// 14.60 ms alone / 21.72 ms for {30,40,50,60} / 12.91 ms per pipelined pass; all hashes of a position in one straight
+// line (157 VGPRs, three wavefronts per SIMD) 14.59 / 20.78 / 13.61 — faster alone, slower beside the next pass's
+// launch; two hashes at a time held to 128 VGPRs (11 and 41 spilled registers) 14.52 / 20.79 / 12.90: the default.
+#if defined(MG_K1_SEQUENTIAL) || defined(MG_K1_ALL)
+#define MG_K1_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#else
+#define MG_K1_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 template <class KL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock) MG_K1_WAVES_ATTR void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
                                                                const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                                const MultiArgs args, unsigned stage_bytes) {
   sketch_reads_multi_body<KL>(bases, offsets, nreads, args, stage_bytes);

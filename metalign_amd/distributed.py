@@ -182,6 +182,11 @@ class HipEngine:
         g = self.gpad
         return base_ptr + 4 * (2 * g * ki), base_ptr + 4 * (2 * g * ki + g)
 
+    def _stage_b(self, sks, ci, base_ptr):
+        """Stage B of every k: one launch of each kernel for all of them (mg_containment_multi_dev)."""
+        ptrs = [self._hs_ptrs(base_ptr, ki) for ki in range(len(sks))]
+        self.hip.containment_multi_dev(sks, self.tables[:len(sks)], ci, [p[0] for p in ptrs], [p[1] for p in ptrs])
+
     def _hs_split(self, hs):
         g, G = self.gpad, self.ngen_local
         hs = np.asarray(hs).reshape(self.nk, 2, g)
@@ -189,8 +194,7 @@ class HipEngine:
 
     def containment(self, sks, ci):
         """-> (hits[K][G], sizes[K][G]) of this rank's table slices."""
-        for ki, sk in enumerate(sks):
-            self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(self.d_hs.ptr, ki))
+        self._stage_b(sks, ci, self.d_hs.ptr)
         return self._hs_split(self.d_hs.download())
 
     def containment_and_commit_results(self, sks, ci, want_multimapped):
@@ -198,8 +202,7 @@ class HipEngine:
         earlier with profile_commit_launch) behind them: one synchronisation."""
         T = self.ntax
         # the per-genome counts (8 B per genome) are written by the kernel straight into page-locked host memory
-        for ki, sk in enumerate(sks):
-            self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(self.h_hs.ptr, ki))
+        self._stage_b(sks, ci, self.h_hs.ptr)
         self.hip.stage_c_join()  # the accumulators are read on the main stream: it waits for stage C's stream here
         self.h_acc.fetch_async(self.d_acc.ptr)
         self.hip.sync()
@@ -261,8 +264,7 @@ class HipEngine:
                                            self.nref, self.ntax, pct_id)
         base = rs["d_acc"].ptr
         shard.commit(True, True, 0, base, base + T * 8, base + 2 * T * 8, base + 3 * T * 8, reset=True)  # stage C (2nd stream)
-        for ki, sk in enumerate(sks):                                                             # stage B (main)
-            self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(rs["h_hs"].ptr, ki))
+        self._stage_b(sks, ci, rs["h_hs"].ptr)                                                    # stage B (main)
         self.hip.stage_c_join()
         rs["h_acc"].fetch_async(base)
         rs["ev"].record()
@@ -374,8 +376,7 @@ class HipEngine:
     def x_stage_b(self, P, merged, ci):
         rs = P["rs"]
         P["merged"] = merged
-        for ki, m in enumerate(merged):
-            self.hip.containment_dev(m, self.tables[ki], ci, *self._hs_ptrs(rs["h_hs"].ptr, ki))
+        self._stage_b(merged, ci, rs["h_hs"].ptr)
         self.hip.stage_c_join()
         rs["h_acc"].fetch_async(rs["d_acc"].ptr)
         rs["ev"].record()

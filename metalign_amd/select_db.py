@@ -380,9 +380,14 @@ def _merge_two(hip, a, b, k, hmax, s):
         d_c.free()
 
 
+run_timings = {}  # seconds of the last select_main's parts (tools/bench_cli.py reads them; nothing else does)
+
+
 def run_sketch_steps(args):
     """Stages A+B on the MI355X: reads -> per-k read sketch -> containment of every genome sketch ->
     temp_dir/cmash_query_results.csv.  Replaces run_kmc_steps (:43-65) and the CMash call (:69-76)."""
+    import time
+    t_start = time.perf_counter()
     hip = _hip.Hip.get()
     table_dir = getattr(args, 'sketch_table', 'AUTO')
     if table_dir in (None, 'AUTO'):
@@ -402,6 +407,8 @@ def run_sketch_steps(args):
     # (a reads file larger than a quarter of the free device memory — or MG_READ_BATCH_BYTES — goes through in
     # record-aligned pieces whose sketches are merged: saturating counters add up to the same clamped counts)
     hmaxs = [t.max_hash for t in dev_tables]
+    run_timings['table_load_s'] = time.perf_counter() - t_start
+    t_start = time.perf_counter()
     sks = None if os.environ.get('MG_NO_STREAM') == '1' else stream_reads_file(hip, args.reads, args.input_type, table.ks, hmaxs, s, filts)
     free, _, pooled = hip.mem_info()
     batch_bytes = int(os.environ.get('MG_READ_BATCH_BYTES', 0)) or max((free + pooled) // 4, 1 << 26)
@@ -425,6 +432,8 @@ def run_sketch_steps(args):
         for sk in sks:
             sk.resolve()
         empty.free()
+    run_timings['stream_s'] = time.perf_counter() - t_start
+    t_start = time.perf_counter()
     per_k = []
     for sk, dev_table in zip(sks, dev_tables):
         hits, sizes = hip.containment(sk, dev_table, min_count)
@@ -435,6 +444,7 @@ def run_sketch_steps(args):
         h.free()
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
+    run_timings['containment_s'] = time.perf_counter() - t_start
     return out
 
 
@@ -513,8 +523,11 @@ def select_main(args=None):
         return
     elif args.cmash_results == 'NONE':
         run_sketch_steps(args)
+    import time
+    t_tail = time.perf_counter()
     organisms = run_cmash_and_cutoff(args, taxid2info)
     make_db_and_dbinfo(args, organisms, taxid2info)
+    run_timings['host_tail_s'] = time.perf_counter() - t_tail
     # the reference removes its KMC intermediates here (:161-167); this path creates none.
     # cmash_query_results.csv stays in temp_dir, as it does in the reference.
 

@@ -166,3 +166,30 @@ def test_config2_full_size_properties(hip):
     sharded = _stage_c_sharded(hip, recs, ref2tax, 10_001, cuts)
     for key in ("count", "bases", "first_seen", "tot_rds", "n_ambig", "mm_read", "mm_tax", "mm_hitlen", "mm_offsets"):
         assert np.array_equal(np.asarray(sharded[key]), np.asarray(res[key])), key
+
+
+def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib):
+    """BASELINE.json configs[2] EXACTLY as bench.py runs it at N = 1 (bench.build_workload: 10M reads of 500 present 50 kb
+    genomes among 10 000, K = {21,31,51}, 12.5M alignment records, 10 001 taxa): ShardJob.step() — the fused stage-A
+    launch, stage B per k, stage C — on a >= 2M-read sample against the C oracle on every host core: hits and sizes of
+    all 10 000 genomes for every k, count / bases / first_seen of every taxon, tot_rds, n_ambig.  (bench.py prints the
+    same comparison as `check.oracle_equal`; here it is the driver's GPU test tier that holds it.)"""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cfg = dict(bench.PRESETS[2], config=2, custom=False)
+    w = bench.build_workload(cfg, 1000, 0, hip)
+    assert len(w["ro"]) - 1 == 10_000_000 and len(w["dbh"]) == 3 and w["ntax"] == 10_001
+    args = argparse.Namespace(cpu_seconds=20.0)
+    base, check = bench.cpu_baseline_and_check(args, cfg, w, hip)
+    nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
+    assert nsample >= 2_000_000 or nsample == 10_000_000, check["compared"]
+    assert check["oracle_equal"], check["mismatch"]
+    # and the pipelined passes the benchmark times give the same sketches as single steps
+    job = bench.make_job(hip, None, 0, 1, cfg, w)
+    one = job.step()
+    out = job.run(3)
+    assert out["sketch_sizes"] == one["sketch_sizes"] and out["tot_rds"] == one["tot_rds"]

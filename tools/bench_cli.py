@@ -1,6 +1,11 @@
 """Wall-clock of the kept command line on synthetic reads (files on disk -> subset DB / CAMI profile), i.e. ingest
 INCLUDED: file read, PCIe, on-device parsing / tokenising, the kernels, the host CAMI tail.
-python tools/bench_cli.py [nreads]        (bench.py imports measure() for its `with_ingest` field)"""
+
+    python tools/bench_cli.py [nreads] [ngenomes] [ks]       e.g.  python tools/bench_cli.py 10000000 10000 21,31,51
+
+bench.py imports measure() for its `with_ingest` field and hands it the workload it has in memory already (BASELINE
+configs[2]: 10M reads, the 10k-genome multi-k table, 12.5M SAM lines), so the headline workload is the one measured with
+ingest.  The files are written with numpy (fixed-width records: 10M reads in seconds, not minutes of Python loops)."""
 import argparse
 import gzip
 import os
@@ -8,58 +13,154 @@ import shutil
 import sys
 import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+ACC = "NZ_SYN%06d.1"
 
-def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False):
-    from metalign_amd import build_db, map_and_profile, select_db, synth
+
+def _digits(idx, width):
+    """(len(idx), width) uint8 ASCII decimal digits, zero padded."""
+    idx = np.asarray(idx, dtype=np.int64)
+    out = np.empty((len(idx), width), dtype=np.uint8)
+    for p in range(width):
+        out[:, width - 1 - p] = (idx // (10 ** p)) % 10 + 48
+    return out
+
+
+def write_fastq(path, rb, n, L=150, block=1_000_000):
+    """@r<9 digits>\\n<seq>\\n+\\n<qual>\\n per read."""
+    seqs = rb.reshape(n, L)
+    w = 2 + 9 + 1 + L + 3 + L + 1
+    with open(path, "wb") as fh:
+        for a in range(0, n, block):
+            b = min(a + block, n)
+            rec = np.empty((b - a, w), dtype=np.uint8)
+            rec[:, 0], rec[:, 1] = ord("@"), ord("r")
+            rec[:, 2:11] = _digits(np.arange(a, b), 9)
+            rec[:, 11] = 10
+            rec[:, 12:12 + L] = seqs[a:b]
+            rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+            rec[:, 15 + L:15 + 2 * L] = ord("I")
+            rec[:, 15 + 2 * L] = 10
+            rec.tofile(fh)
+    return n * w
+
+
+def write_sam(path, rb, src, n, G, L=150, block=1_000_000):
+    """One primary line per read (strand from the read's parity) + a secondary (SEQ '*') to the next genome for every
+    fourth read: 1.25 lines per read, fixed-width fields, written four reads at a time."""
+    assert n % 4 == 0 and block % 4 == 0
+    seqs = rb.reshape(n, L)
+    tail = b"\t1000\t60\t%dM\t*\t0\t0\t" % L
+    p_len = {0: None, 16: None}
+
+    def primary(idx, flag):
+        m = len(idx)
+        head = b"r" + b"0" * 9 + b"\t" + (b"%d" % flag) + b"\t" + (ACC % 0).encode() + tail
+        w = len(head) + L + 1 + L + len(b"\tNM:i:1\n")
+        rec = np.empty((m, w), dtype=np.uint8)
+        rec[:, :len(head)] = np.frombuffer(head, dtype=np.uint8)
+        rec[:, 1:10] = _digits(idx, 9)
+        acc0 = 10 + 1 + len(b"%d" % flag) + 1
+        rec[:, acc0 + 6: acc0 + 12] = _digits(src[idx], 6)
+        rec[:, len(head): len(head) + L] = seqs[idx]
+        rec[:, len(head) + L] = 9
+        rec[:, len(head) + L + 1: len(head) + 2 * L + 1] = ord("I")
+        rec[:, len(head) + 2 * L + 1:] = np.frombuffer(b"\tNM:i:1\n", dtype=np.uint8)
+        p_len[flag] = w
+        return rec
+
+    def secondary(idx):
+        line = b"r" + b"0" * 9 + b"\t256\t" + (ACC % 0).encode() + b"\t1000\t0\t%dM10S\t*\t0\t0\t*\t*\tNM:i:5\n" % (L - 10)
+        rec = np.empty((len(idx), len(line)), dtype=np.uint8)
+        rec[:] = np.frombuffer(line, dtype=np.uint8)
+        rec[:, 1:10] = _digits(idx, 9)
+        rec[:, 15 + 6: 15 + 12] = _digits((src[idx] + 1) % G, 6)
+        return rec
+
+    total = 0
+    with open(path, "wb") as fh:
+        for a in range(0, n, block):
+            b = min(a + block, n)
+            i0 = np.arange(a, b, 4)
+            parts = [primary(i0, 0), secondary(i0), primary(i0 + 1, 16), primary(i0 + 2, 0), primary(i0 + 3, 16)]
+            out = np.concatenate(parts, axis=1)
+            out.tofile(fh)
+            total += out.size
+    return total, n + n // 4
+
+
+def write_data_dir(data, gb, go, G, glen, threads=16):
+    """organism_files/*.fna.gz (one accession per genome), db_info.txt; -> (organism file names, accessions, subset db_info text)."""
+    os.makedirs(os.path.join(data, "organism_files"))
+    rows = ["Accession\tLength\tTaxID\tLineage\tTaxID_Lineage\n", "Unmapped\t0\tUnmapped\t|||||||Unmapped\t|||||||Unmapped\n"]
+    accs, names = [], []
+    for g in range(G):
+        taxid = "%d.1" % (1000 + g)
+        names.append("taxid_%s_genomic.fna.gz" % taxid.replace(".", "_"))
+        accs.append(ACC % g)
+        rows.append("\t".join([accs[g], str(glen), taxid, "Bacteria|P|C|O|F|G|S%d|S%d str" % (g, g), "2|1|2|3|4|5|%d|%s" % (1000 + g, taxid)]) + "\n")
+
+    def one(g):
+        blob = (">%s\n" % accs[g]).encode() + gb[int(go[g]):int(go[g + 1])].tobytes() + b"\n"
+        with open(os.path.join(data, "organism_files", names[g]), "wb") as fh:
+            fh.write(gzip.compress(blob, 1))
+
+    with ThreadPoolExecutor(threads) as ex:  # (zlib releases the GIL)
+        list(ex.map(one, range(G)))
+    with open(os.path.join(data, "db_info.txt"), "w") as fh:
+        fh.write("".join(rows[:1] + rows[2:]))
+    return names, accs, "".join(rows)
+
+
+def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, glen=50_000, sketch_n=1000):
+    """workload: dict(gb, go, rb, src, dbh, dbo) — genomes, reads, source genome of every read, the per-k genome-major
+    sketch table — as bench.py builds them; None: generated here."""
+    from metalign_amd import formats, map_and_profile, select_db, synth
     from metalign_amd._hip import Hip
-    Hip.get()
+    hip = Hip.get()
     td = tempfile.mkdtemp(prefix="mg_cli_")
     try:
-        gb, go = synth.make_genomes(G, 50_000)
-        rb, ro, src = synth.make_reads(gb, go, n, npresent=40)
-        seqs = rb.reshape(n, 150)
+        t_gen = time.perf_counter()
+        if workload is None:
+            gb, go = synth.make_genomes(G, glen)
+            rb, ro, src = synth.make_reads(gb, go, n, npresent=max(40, G // 20))
+            tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in ks]
+            dbh, dbo = [t[0] for t in tables], [t[1] for t in tables]
+        else:
+            gb, go, rb, src, dbh, dbo = (workload[x] for x in ("gb", "go", "rb", "src", "dbh", "dbo"))
+        n -= n % 4
         data = os.path.join(td, "data")
-        os.makedirs(os.path.join(data, "organism_files"))
-        rows = ["Accession\tLength\tTaxID\tLineage\tTaxID_Lineage\n", "Unmapped\t0\tUnmapped\t|||||||Unmapped\t|||||||Unmapped\n"]
-        accs, names = [], []
-        for g in range(G):
-            taxid = "%d.1" % (1000 + g)
-            nm = "taxid_%s_genomic.fna.gz" % taxid.replace(".", "_")
-            acc = "NZ_SYN%06d.1" % g
-            with gzip.open(os.path.join(data, "organism_files", nm), "wb", compresslevel=1) as fh:
-                fh.write((">%s\n" % acc).encode() + gb[int(go[g]):int(go[g + 1])].tobytes() + b"\n")
-            rows.append("\t".join([acc, "50000", taxid, "Bacteria|P|C|O|F|G|S%d|S%d str" % (g, g), "2|1|2|3|4|5|%d|%s" % (1000 + g, taxid)]) + "\n")
-            accs.append(acc)
-            names.append(nm)
-        with open(os.path.join(data, "db_info.txt"), "w") as fh:
-            fh.write("".join(rows[:1] + rows[2:]))
+        names, accs, sub_text = write_data_dir(data, gb, go, G, glen)
+        filters = {}
+        for k, h in zip(ks, dbh):
+            f = hip.filter_build(h)
+            filters[k] = f.download()
+            f.free()
+        formats.write_sketch_table(os.path.join(data, "sketch_table"), names, list(ks), sketch_n,
+                                   {k: (h, o) for k, h, o in zip(ks, dbh, dbo)}, filters)
         sub = os.path.join(td, "subset_db_info.txt")
         with open(sub, "w") as fh:
-            fh.write("".join(rows))
-        t0 = time.perf_counter()
-        build_db.build([os.path.join(data, "organism_files", x) for x in names], os.path.join(data, "sketch_table"), list(ks), 1000)
-        t_build = time.perf_counter() - t0
+            fh.write(sub_text)
         fq = os.path.join(td, "reads.fq")
-        with open(fq, "wb") as fh:
-            qual = b"\n+\n" + b"I" * 150 + b"\n"
-            fh.write(b"".join(b"@r%d\n" % i + seqs[i].tobytes() + qual for i in range(n)))
+        fq_bytes = write_fastq(fq, rb[: n * 150], n)
         sam = os.path.join(td, "aln.sam")
-        qs = "I" * 150
-        with open(sam, "w") as fh:
-            for i in range(n):
-                fh.write("r%d\t%d\t%s\t1000\t60\t150M\t*\t0\t0\t%s\t%s\tNM:i:1\n" % (i, 16 * (i & 1), accs[src[i]], seqs[i].tobytes().decode(), qs))
-                if i % 4 == 0:
-                    fh.write("r%d\t256\t%s\t1000\t0\t140M10S\t*\t0\t0\t*\t*\tNM:i:5\n" % (i, accs[(src[i] + 1) % G]))
+        sam_bytes, sam_lines = write_sam(sam, rb[: n * 150], np.asarray(src[:n], dtype=np.int64), n, G)
+        t_gen = time.perf_counter() - t_gen
         best = None
         for rep in range(reps):
             tmpd = os.path.join(td, "tmp%d" % rep)
             args = argparse.Namespace(reads=fq, data=data, cmash_results="NONE", cutoff=0.01, db="AUTO", db_dir="AUTO", dbinfo_in="AUTO",
                                       dbinfo_out="AUTO", input_type="AUTO", keep_temp_files=True, strain_level=False, temp_dir=tmpd,
                                       threads=4, sketch_table="AUTO", min_count=2, sketch_size=0)
+            hip.prof_reset()
             t0 = time.perf_counter()
+            sk_t0 = time.perf_counter()
+            select_db.run_timings = {}
             select_db.select_main(args)
             t1 = time.perf_counter()
             a2 = argparse.Namespace(infiles=[sam], data=data, db="NONE", dbinfo=sub, input_type="AUTO", length_normalize=False, low_mem=False,
@@ -67,23 +168,38 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False):
                                     no_quantify_unmapped=False, read_cutoff=1, sampleID="x", threads=4, verbose=False)
             map_and_profile.map_main(a2)
             t2 = time.perf_counter()
+            tm = dict(getattr(select_db, "run_timings", {}))
             if verbose:
-                print("run %d: select_main %.3f s, map_main %.3f s" % (rep, t1 - t0, t2 - t1))
+                print("run %d: select_main %.3f s %s, map_main %.3f s" % (rep, t1 - t0, {k: round(v, 3) for k, v in tm.items()}, t2 - t1), flush=True)
             if best is None or (t2 - t0) < best[0] + best[1]:
-                best = (t1 - t0, t2 - t1)
-        sel, mp = best
-        return {"reads": n, "genomes": G, "ks": list(ks), "fastq_mb": os.path.getsize(fq) >> 20, "sam_mb": os.path.getsize(sam) >> 20,
-                "select_main_s": sel, "map_main_s": mp, "build_db_s": t_build,
-                "select_main_reads_per_s": n / sel, "map_main_reads_per_s": n / mp,
-                "value": n / (sel + mp), "unit": "reads/s",
-                "what": "metalign_amd.select_db.select_main (FASTQ file -> upload, parse on device, sketch, containment, CSV, "
-                        "cutoff, zcat of the selected genomes) + map_and_profile.map_main (SAM file -> upload, tokenise on device, "
-                        "assign, multimapped resolution, CAMI file), files in the page cache, best of %d" % reps}
+                best = (t1 - t0, t2 - t1, tm)
+            del sk_t0
+        sel, mp, tm = best
+        nsel = sum(1 for _ in open(os.path.join(td, "tmp0", "subset_db_info.txt"))) - 2
+        res = {"reads": n, "genomes": G, "ks": list(ks), "fastq_mb": fq_bytes >> 20, "sam_mb": sam_bytes >> 20, "sam_lines": sam_lines,
+               "select_main_s": sel, "map_main_s": mp, "generate_s": t_gen, "selected_genomes": nsel,
+               "select_main_reads_per_s": n / sel, "map_main_reads_per_s": n / mp,
+               "value": n / (sel + mp), "unit": "reads/s",
+               "what": "metalign_amd.select_db.select_main (FASTQ file -> reader threads -> page-locked chunks -> HBM -> parse on "
+                       "device -> ONE set of counting tables for all k, containment, CSV, cutoff, zcat of the selected genomes) + "
+                       "map_and_profile.map_main (SAM file streamed the same way -> tokenise on device, assign, multimapped "
+                       "resolution, CAMI file), files in the page cache, best of %d" % reps}
+        if tm.get("stream_s"):
+            res["stage_a_b_from_file"] = {"seconds": tm["stream_s"] + tm.get("containment_s", 0.0),
+                                         "reads_per_s": n / (tm["stream_s"] + tm.get("containment_s", 0.0)),
+                                         "fastq_GBs": fq_bytes / tm["stream_s"] / 1e9, "stream_s": tm["stream_s"],
+                                         "containment_s": tm.get("containment_s"), "table_load_s": tm.get("table_load_s"),
+                                         "host_tail_s": tm.get("host_tail_s"),
+                                         "what": "reads file -> read sketches of every k (the pipeline of mg_stream.hip) + stage B per k: "
+                                                 "the part of select_main between the sketch table's load and the CSV"}
+        return res
     finally:
         shutil.rmtree(td, ignore_errors=True)
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    ks = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (21,)
     import json
-    print(json.dumps(measure(n, verbose=True), indent=1))
+    print(json.dumps(measure(n, G=G, ks=ks, verbose=True), indent=1))

@@ -105,6 +105,16 @@ def main(out):
         sq = {k: {c: v["avg"] for c, v in d.items()} | {"launches": max(v["launches"] for v in d.values())}
               for k, d in per_kernel(f, {"SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"}).items()
               if k.startswith("k_")}
+        tr = one(os.path.join(out, "pmc_SQ", "**", "*kernel_trace.csv"))
+        if tr:  # the launches' own durations in the SAME pass (for the engine clock: GRBM_GUI_ACTIVE / 8 / duration)
+            acc = {}
+            for r in csv.DictReader(open(tr)):
+                a = acc.setdefault(short(r["Kernel_Name"]), [0, 0.0])
+                a[0] += 1
+                a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            for k in sq:
+                if k in acc:
+                    sq[k]["duration_ns"] = acc[k][1] / acc[k][0]
         names, tot = stage_a_per_pass(sq, "SQ_INSTS_VALU")
         doc = {"workload": wl, "k_sketch_reads": {"kernels": names, "SQ_INSTS_VALU_per_pass": tot,
                                                   "per_wave_step": tot / max(wl.get("reads", 1) * 150 / 64.0, 1.0)},
