@@ -162,6 +162,17 @@ typedef struct mg_sketch mg_sketch;
 typedef struct mg_filter mg_filter;
 int mg_set_count_saturation(uint32_t cs);
 uint32_t mg_count_saturation(void);
+/* Which definition of a k-mer's hash stage A / A' compute (sketches and tables of different modes do not mix; the table
+ * on disk records its mode, metalign_amd/formats.py):
+ *   0  MurmurHash3_x64_128(the lexicographically smaller of k-mer and reverse complement)[0:64] — KMC's canonical k-mer,
+ *      one hash, the full 64 bits.  Default; what every figure of this build is measured with.
+ *   1  min(MurmurHash3(k-mer), MurmurHash3(reverse complement)) mod 9999999999971 — CMash's MinHash.CountEstimator as
+ *      SURVEY.md §8(c) recollects it (two hashes per k-mer).  UNVERIFIED: CMash is not under /root/reference and the
+ *      reference pins no version and holds no vectors at this seam (scripts/select_db.py:69-76,
+ *      local_tests/dump_kmers.py:2-7); the mode exists so that a table built here and one built by CMash could be
+ *      compared at all. */
+int mg_set_hash_mode(int mode);
+int mg_hash_mode(void);
 
 int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
                         uint64_t nreads, int k, uint64_t hmax, uint64_t s,

@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_set_count_saturation", "mg_count_saturation", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_free",
+    "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_sketch_stream_begin", "mg_sketch_stream_add_dev", "mg_sketch_stream_add_file", "mg_sketch_stream_finish", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases", "mg_sketch_stream_free",
@@ -840,6 +840,15 @@ class Hip:
         self._chk(self.lib.mg_reads_parse(_np(src, ctypes.c_uint8), ctypes.c_uint64(buf.size),
                                           ctypes.c_int(_READS_FORMAT[fmt]), ctypes.byref(h)))
         return Reads(self, h)
+
+    def set_hash_mode(self, mode):
+        """0: hash of the canonical k-mer (default); 1: min(hash(kmer), hash(revcomp)) % 9999999999971 — CMash as SURVEY.md
+        §8(c) recollects it (include/metalign_hip.h: mg_set_hash_mode)."""
+        self._chk(self.lib.mg_set_hash_mode(ctypes.c_int(int(mode))))
+
+    @property
+    def hash_mode(self):
+        return int(self.lib.mg_hash_mode())
 
     def sketch_stream(self, ks, hmaxs, s=0, filters=None, expect_bases=0):
         """A streamed read sketch: one set of counting tables for a sample that arrives in pieces (SketchStream)."""

@@ -30,8 +30,20 @@ def genome_bases(path):
     return np.concatenate(parts)
 
 
-def build(paths, out_dir, ks, n, batch_bases=1 << 27):
+def build(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0):
+    """hash_mode: 0 = MurmurHash3 of the canonical k-mer (default); 1 = min(hash(kmer), hash(revcomp)) % 9999999999971,
+    CMash's CountEstimator as SURVEY.md §8(c) recollects it (unverified; include/metalign_hip.h: mg_set_hash_mode).  The
+    table records its mode and select_db sketches the reads in the same one."""
     hip = _hip.Hip.get()
+    previous = hip.hash_mode
+    hip.set_hash_mode(hash_mode)
+    try:
+        return _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode)
+    finally:
+        hip.set_hash_mode(previous)
+
+
+def _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode):
     names = [os.path.basename(p) for p in paths]
     per_k = {k: ([], [0]) for k in ks}
     i = 0
@@ -58,7 +70,7 @@ def build(paths, out_dir, ks, n, batch_bases=1 << 27):
         f = hip.filter_build(final[k][0])
         filters[k] = f.download()
         f.free()
-    formats.write_sketch_table(out_dir, names, ks, n, final, filters)
+    formats.write_sketch_table(out_dir, names, ks, n, final, filters, hash_mode=hash_mode)
     return final
 
 
@@ -68,6 +80,9 @@ def main(argv=None):
     p.add_argument('out_dir', help='Sketch table directory to write (default location: data/sketch_table).')
     p.add_argument('-n', '--num_hashes', type=int, default=1000, help='Sketch size per genome. Default: 1000')
     p.add_argument('-k', '--ks', default='30,40,50,60', help='Comma-separated k-mer sizes. Default: 30,40,50,60')
+    p.add_argument('--hash_mode', choices=['canonical', 'cmash'], default='canonical',
+                   help="canonical: MurmurHash3 of the lexicographically smaller strand, 64 bits (default). cmash: "
+                        "min(hash(kmer), hash(revcomp)) %% 9999999999971, CMash's definition as recollected (unverified).")
     a = p.parse_args(argv)
     if os.path.isdir(a.genomes):
         paths = sorted(os.path.join(a.genomes, f) for f in os.listdir(a.genomes)
@@ -75,7 +90,7 @@ def main(argv=None):
     else:
         with open(a.genomes) as fh:
             paths = [ln.strip() for ln in fh if ln.strip()]
-    build(paths, a.out_dir, [int(x) for x in a.ks.split(',')], a.num_hashes)
+    build(paths, a.out_dir, [int(x) for x in a.ks.split(',')], a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0)
 
 
 if __name__ == '__main__':

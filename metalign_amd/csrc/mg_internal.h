@@ -53,6 +53,8 @@ struct Context {
   uint64_t k3_priv_nb = 0;
   // occurrence counters of read sketches saturate here (kmc -cs3, scripts/select_db.py:50); 0 = exact counts
   uint32_t count_sat = 3;
+  // which definition of a k-mer's hash the stage-A / A' kernels compute (mg_set_hash_mode; mg_kmer.h)
+  int hash_mode = 0;
   // profiling
   bool prof_on = false;
   char prof_only[32] = "";  // when set, only this kernel family is timed (keeps the timed region light)

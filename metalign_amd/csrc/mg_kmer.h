@@ -48,6 +48,13 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t v) {
 
 constexpr uint64_t kMurmurC1 = 0x87c37b91114253d5ULL, kMurmurC2 = 0x4cf5ad432745937fULL;
 
+// Which definition of a k-mer's hash a kernel is instantiated for (mg_set_hash_mode; oracle/mg_oracle.c: g_hash_mode):
+//   kHashCanonical  MurmurHash3 of the lexicographically smaller strand, the full 64 bits (KMC's canonical k-mer; default)
+//   kHashCmash      min(MurmurHash3(kmer), MurmurHash3(revcomp)) mod 9999999999971 — CMash's CountEstimator as SURVEY.md
+//                   §8(c) recollects it (unverified: its source is not under /root/reference); two hashes per k-mer
+constexpr int kHashCanonical = 0, kHashCmash = 1;
+constexpr uint64_t kCmashPrime = 9999999999971ULL;
+
 // Base decode: A,C,G,T (either case) -> 0..3 (lexicographic order), anything else -> invalid.
 // idx = (b & 0xDF) - 'A'; valid letters sit at idx 0 (A), 2 (C), 6 (G), 19 (T).
 __device__ __forceinline__ bool decode_base(uint32_t b, uint32_t& code) {
@@ -214,8 +221,14 @@ struct Roller {
     return pf_hi < pr_hi || (pf_hi == pr_hi && pf_lo <= pr_lo);
   }
 
-  // MurmurHash3_x64_128(canonical ASCII k-mer, seed 0) -> first 64 bits.  tab: fill_hash_tables().
+  // The k-mer's hash under definition HM.  tab: fill_hash_tables().
+  template <int HM = kHashCanonical>
   __device__ __forceinline__ uint64_t hash(const uint64_t* tab) const {
+    if constexpr (HM == kHashCmash) {
+      const uint64_t a = murmur3_h1_packed<K>(make_packed(pf_lo, NW == 1 ? 0ull : pf_hi), tab);
+      const uint64_t b = murmur3_h1_packed<K>(make_packed(pr_lo, NW == 1 ? 0ull : pr_hi), tab);
+      return (a < b ? a : b) % kCmashPrime;
+    }
     const bool fw = forward_is_canonical();
     const uint64_t lo = fw ? pf_lo : pr_lo, hi = NW == 1 ? 0ull : (fw ? pf_hi : pr_hi);
     return murmur3_h1_packed<K>(make_packed(lo, hi), tab);
@@ -226,11 +239,11 @@ struct Roller {
 // k of a multi-k query serves every smaller k.  The K-mer is the SUFFIX of the forward window (the low 2K bits of the
 // forward 2-bit form) and its reverse complement is the PREFIX of the reverse-complement window (the top 2K bits of
 // the reverse 2-bit form).
-template <int K, int KMAX>
+template <int K, int KMAX, int HM = kHashCanonical>
 __device__ __forceinline__ uint64_t hash_suffix(const Roller<KMAX>& R, const uint64_t* tab) {
   static_assert(K >= 1 && K <= KMAX, "sub-k must not exceed the roller's k");
   if constexpr (K == KMAX) {
-    return R.hash(tab);
+    return R.template hash<HM>(tab);
   } else {
     constexpr int S = 2 * (KMAX - K);  // the reverse form's K-mer sits S bits up
     uint64_t f_lo = R.pf_lo, f_hi = KMAX > 32 ? R.pf_hi : 0ull;
@@ -246,6 +259,11 @@ __device__ __forceinline__ uint64_t hash_suffix(const Roller<KMAX>& R, const uin
     } else {
       constexpr uint64_t MH = (1ull << (2 * (K - 32))) - 1ull;  // K < KMAX <= 64: at most 62 bits
       f_hi &= MH; r_hi &= MH;
+    }
+    if constexpr (HM == kHashCmash) {
+      const uint64_t a = murmur3_h1_packed<K>(make_packed(f_lo, f_hi), tab);
+      const uint64_t b = murmur3_h1_packed<K>(make_packed(r_lo, r_hi), tab);
+      return (a < b ? a : b) % kCmashPrime;
     }
     const bool fw = K <= 32 ? (f_lo <= r_lo) : (f_hi < r_hi || (f_hi == r_hi && f_lo <= r_lo));
     return murmur3_h1_packed<K>(make_packed(fw ? f_lo : r_lo, fw ? f_hi : r_hi), tab);

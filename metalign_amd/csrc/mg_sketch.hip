@@ -163,7 +163,7 @@ struct CandSink {
 // nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise src points at the read's
 // ASCII bases in HBM.
 // MODE 0: any tile.  1: a clean tile (no invalid base in it) of equally long reads.  2: a clean tile of ragged reads.
-template <int K, bool CODES, int MODE = 0>
+template <int K, bool CODES, int MODE = 0, int HM = kHashCanonical>
 __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
                                            uint64_t hmax, CandSink& sink, uint64_t& kmers, int lane, const uint64_t* htab) {
   Roller<K> roll;
@@ -189,9 +189,9 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
     for (uint32_t pos = warm; pos < maxlen; pos += 2) {
       const uint32_t c0 = cs.at(pos) & 3u, c1 = cs.at(pos + 1) & 3u;  // (c1 past the end: hashed, never offered)
       roll.push_clean(c0);
-      const uint64_t h0 = roll.hash(htab);
+      const uint64_t h0 = roll.template hash<HM>(htab);
       roll.push_clean(c1);
-      const uint64_t h1 = roll.hash(htab);
+      const uint64_t h1 = roll.template hash<HM>(htab);
       if (pos + 1 >= (uint32_t)K) {  // (scalar branches: the ballot then is the compare itself)
         if constexpr (RAGGED) sink.offer2(pos < len, h0 <= hmax, h0, lane); else sink.offer(h0 <= hmax, h0, lane);
       }
@@ -220,11 +220,11 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
     const uint32_t c0 = code_at(pos), c1 = code_at(pos + 1);
     roll.push(c0);
     roll.run = c0 < 4u ? roll.run : 0;
-    const uint64_t h0 = roll.hash(htab);
+    const uint64_t h0 = roll.template hash<HM>(htab);
     const bool full0 = roll.run >= K;
     roll.push(c1);
     roll.run = c1 < 4u ? roll.run : 0;
-    const uint64_t h1 = roll.hash(htab);
+    const uint64_t h1 = roll.template hash<HM>(htab);
     const bool full1 = roll.run >= K;
     nk += (full0 ? 1u : 0u) + (full1 ? 1u : 0u);
     sink.offer(full0 && h0 <= hmax, h0, lane);
@@ -234,7 +234,7 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
 }
 
 // counters[0] = candidates produced (may exceed cap: overflow => caller retries), counters[1] = k-mers hashed
-template <int K>
+template <int K, int HM>
 __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restrict__ bases,
                                                          const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                          uint64_t hmax, uint64_t* __restrict__ cand, uint64_t cand_cap,
@@ -282,14 +282,14 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
       if (__ballot(bad != 0) != 0ull)
-        walk_reads<K, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
+        walk_reads<K, true, 0, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
       else if (__ballot(len != maxlen) == 0ull)
-        walk_reads<K, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
+        walk_reads<K, true, 1, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
       else
-        walk_reads<K, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
+        walk_reads<K, true, 2, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
       wave_lds_sync();
     } else {
-      walk_reads<K, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
+      walk_reads<K, false, 0, HM>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, hmax, sink, kmers, lane, htab);
     }
   }
   sink.flush(lane);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
 // (kReservedHash where there is none).  One lane per run of kChunk positions.
 constexpr int kChunk = 64;
 
-template <int K>
+template <int K, int HM>
 __global__ __launch_bounds__(256) void k_hash_positions(const uint8_t* __restrict__ bases,
                                                         const uint64_t* __restrict__ offsets, uint64_t nseq,
                                                         uint64_t nbases, uint64_t* __restrict__ out) {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void k_hash_positions(const uint8_t* __restric
       uint64_t h = kReservedHash;
       if (decode_base(bases[p], c)) {
         roll.push(c);
-        if (roll.full()) h = roll.hash(htab);
+        if (roll.full()) h = roll.template hash<HM>(htab);
       } else {
         roll.run = 0;
       }
@@ -632,10 +632,14 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
-                     nreads, hmax, d_cand, cap, d_counters, d_tab, bucket_shift, stage_bytes,
-                     filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr, filter ? filter->mask : 0ull,
-                     stage_a_cs_word());
+  const uint32_t* fb = filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr;
+  const uint64_t fm = filter ? filter->mask : 0ull;
+  if (c.hash_mode == kHashCmash)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K, kHashCmash>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
+                       nreads, hmax, d_cand, cap, d_counters, d_tab, bucket_shift, stage_bytes, fb, fm, stage_a_cs_word());
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads<K, kHashCanonical>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases,
+                       d_offsets, nreads, hmax, d_cand, cap, d_counters, d_tab, bucket_shift, stage_bytes, fb, fm, stage_a_cs_word());
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -1266,6 +1270,14 @@ int mg_set_count_saturation(uint32_t cs) {
 }
 uint32_t mg_count_saturation(void) { return ctx().count_sat; }
 
+int mg_set_hash_mode(int mode) {
+  MG_REQUIRE_READY();
+  if (mode != mg::kHashCanonical && mode != mg::kHashCmash) return fail(MG_ERR_ARG, "hash mode %d: 0 (canonical k-mer) or 1 (CMash recollection)", mode);
+  ctx().hash_mode = mode;
+  return MG_OK;
+}
+int mg_hash_mode(void) { return ctx().hash_mode; }
+
 int mg_filter_download(const mg_filter* f, uint32_t* bits, uint64_t nbytes) {
   MG_REQUIRE_READY();
   if (!f || !bits) return fail(MG_ERR_ARG, "null argument");
@@ -1571,7 +1583,11 @@ int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ng
       const uint64_t nchunks = (nb + kChunk - 1) / kChunk;
       unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
       bool ok = dispatch_k(k, [&]<int K>() {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
+        if (ctx().hash_mode == kHashCmash)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCmash>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
+                           d_pos);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCanonical>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
                            d_pos);
       });
       if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);

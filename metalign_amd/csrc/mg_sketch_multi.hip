@@ -160,7 +160,7 @@ struct KList {
 // 2 clean tile of ragged reads.
 // CODES: src is the wavefront's nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise
 // src points at the read's ASCII bases in HBM (a tile that does not fit the stage; MODE 0 only).
-template <class KL, bool CODES, int MODE>
+template <class KL, bool CODES, int MODE, int HM>
 __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
                                                  const MultiArgs& A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane,
                                                  const uint64_t* htab) {
@@ -193,7 +193,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
     for (uint32_t pos = warm; pos < some_end; ++pos) {
       roll.push_clean(cs.at(pos) & 3u);
       auto one = [&]<int I>() {
-        const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll, htab);
+        const uint64_t h = hash_suffix<KL::v[I], KMAX, HM>(roll, htab);
         if constexpr (RAGGED) sink.template offer2<I>(pos < len, h <= hmax[I], h, lane);
         else sink.template offer<I>(h <= hmax[I], h, lane);
       };
@@ -210,8 +210,8 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
 #ifndef MG_K1_ALL  // the hashes two at a time (MG_K1_ALL, A/B builds: all of them at once)
       auto pair = [&]<int I0>() {
         constexpr int I1 = I0 + 1 < KL::N ? I0 + 1 : I0;
-        const uint64_t ha = hash_suffix<KL::v[I0], KMAX>(roll, htab);
-        const uint64_t hb = I1 != I0 ? hash_suffix<KL::v[I1], KMAX>(roll, htab) : 0ull;
+        const uint64_t ha = hash_suffix<KL::v[I0], KMAX, HM>(roll, htab);
+        const uint64_t hb = I1 != I0 ? hash_suffix<KL::v[I1], KMAX, HM>(roll, htab) : 0ull;
         if constexpr (RAGGED) sink.template offer2<I0>(pos < len, ha <= hmax[I0], ha, lane); else sink.template offer<I0>(ha <= hmax[I0], ha, lane);
         if constexpr (I1 != I0) {
           if constexpr (RAGGED) sink.template offer2<I1>(pos < len, hb <= hmax[I1], hb, lane); else sink.template offer<I1>(hb <= hmax[I1], hb, lane);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
 #else
       uint64_t h[KL::N];
       [&]<int... I>(std::integer_sequence<int, I...>) {
-        ((h[I] = hash_suffix<KL::v[I], KMAX>(roll, htab)), ...);
+        ((h[I] = hash_suffix<KL::v[I], KMAX, HM>(roll, htab)), ...);
       }(std::make_integer_sequence<int, KL::N>{});
       [&]<int... I>(std::integer_sequence<int, I...>) {
         ((RAGGED ? sink.template offer2<I>(pos < len, h[I] <= hmax[I], h[I], lane) : sink.template offer<I>(h[I] <= hmax[I], h[I], lane)), ...);
@@ -245,7 +245,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
     roll.run = c < 4u ? roll.run : 0;
     if (pos < warm) continue;  // (scalar)
     auto one = [&]<int I>() {
-      const uint64_t h = hash_suffix<KL::v[I], KMAX>(roll, htab);
+      const uint64_t h = hash_suffix<KL::v[I], KMAX, HM>(roll, htab);
       nk[I] += roll.run >= KL::v[I] ? 1u : 0u;
       sink.template offer2<I>(roll.run >= KL::v[I], h <= hmax[I], h, lane);
     };
@@ -257,7 +257,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
   for (int i = 0; i < KL::N; ++i) kmers[i] += wave_sum_u64(nk[i]);
 }
 
-template <class KL>
+template <class KL, int HM>
 __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                         uint64_t nreads, const MultiArgs& args, unsigned stage_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -299,14 +299,14 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
       if (__ballot(bad != 0) != 0ull)
-        walk_reads_multi<KL, true, 0>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+        walk_reads_multi<KL, true, 0, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       else if (__ballot(len != maxlen) == 0ull)
-        walk_reads_multi<KL, true, 1>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+        walk_reads_multi<KL, true, 1, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       else
-        walk_reads_multi<KL, true, 2>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+        walk_reads_multi<KL, true, 2, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       wave_lds_sync();
     } else {
-      walk_reads_multi<KL, false, 0>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+      walk_reads_multi<KL, false, 0, HM>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
     }
   }
   sink.flush(lane);
@@ -329,11 +329,11 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
 #else
 #define MG_K1_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-template <class KL>
+template <class KL, int HM>
 __global__ __launch_bounds__(kBlock) MG_K1_WAVES_ATTR void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
                                                                const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                                const MultiArgs args, unsigned stage_bytes) {
-  sketch_reads_multi_body<KL>(bases, offsets, nreads, args, stage_bytes);
+  sketch_reads_multi_body<KL, HM>(bases, offsets, nreads, args, stage_bytes);
 }
 
 template <class KL>
@@ -348,8 +348,12 @@ static int launch_multi(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi<KL>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases, d_offsets,
-                     nreads, a, stage_bytes);
+  if (c.hash_mode == kHashCmash)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi<KL, kHashCmash>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases,
+                       d_offsets, nreads, a, stage_bytes);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi<KL, kHashCanonical>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases,
+                       d_offsets, nreads, a, stage_bytes);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }

@@ -87,6 +87,9 @@ class SketchTable:
         self.version = int(self.meta.get("version", 1))
         self.ks = [int(k) for k in self.meta["ks"]]
         self.n = int(self.meta["n"])
+        # which definition of a k-mer's hash the table was sketched with (include/metalign_hip.h: mg_set_hash_mode);
+        # tables written before the field existed are mode 0
+        self.hash_mode = int(self.meta.get("hash_mode", 0))
         with open(os.path.join(path, "names.txt")) as fh:
             self.names = [ln.rstrip("\n") for ln in fh]
         self.ngenomes = len(self.names)
@@ -167,7 +170,7 @@ def _write_common(path, names):
             fh.write(nm + "\n")
 
 
-def write_sketch_table(path, names, ks, n, per_k, filters=None):
+def write_sketch_table(path, names, ks, n, per_k, filters=None, hash_mode=0):
     """per_k: {k: (hashes u64[], offsets u64[G+1])} genome-major, as mg_sketch_genomes returns it; written hash-major.
     filters: optional {k: uint32 bit array} (Filter.download)."""
     _write_common(path, names)
@@ -178,7 +181,7 @@ def write_sketch_table(path, names, ks, n, per_k, filters=None):
         np.ascontiguousarray(gs, dtype="<u4").tofile(os.path.join(path, "k%d.gsize.u32" % k))
         if filters and filters.get(k) is not None:
             np.ascontiguousarray(filters[k], dtype="<u4").tofile(os.path.join(path, "k%d.filter.u32" % k))
-    meta = {"format": TABLE_FORMAT, "version": 2, "n": int(n), "ks": [int(k) for k in ks], "ngenomes": len(names),
+    meta = {"format": TABLE_FORMAT, "version": 2, "n": int(n), "ks": [int(k) for k in ks], "ngenomes": len(names), "hash_mode": int(hash_mode),
             "layout": "hash-major pairs", "hash": "murmur3_x64_128.h1(canonical ASCII k-mer), seed 0"}
     with open(os.path.join(path, "meta.json"), "w") as fh:
         json.dump(meta, fh, indent=1)

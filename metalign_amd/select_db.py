@@ -241,6 +241,7 @@ def run_sketch_steps_dist(args, ctx):
     if table_dir in (None, 'AUTO'):
         table_dir = formats.default_table_dir(args.data)
     table = formats.SketchTable(table_dir)
+    hip.set_hash_mode(table.hash_mode)
 
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
 
@@ -393,6 +394,7 @@ def run_sketch_steps(args):
     if table_dir in (None, 'AUTO'):
         table_dir = formats.default_table_dir(args.data)
     table = formats.SketchTable(table_dir)
+    hip.set_hash_mode(table.hash_mode)  # the reads are hashed by the definition the table was sketched with
     min_count = int(getattr(args, 'min_count', 2))
     s = int(getattr(args, 'sketch_size', 0))
     # every k of the table: the hash-major pairs go up as they lie on disk (no sort), the stored pre-filter with them

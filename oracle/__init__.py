@@ -63,6 +63,19 @@ def kmer_hashes(seq: bytes, k: int):
     return out, valid.astype(bool)
 
 
+CMASH_PRIME = 9999999999971
+
+
+def set_hash_mode(mode):
+    """0: hash(min(kmer, revcomp)), 64 bits (default); 1: min(hash(kmer), hash(revcomp)) % CMASH_PRIME (CMash as
+    SURVEY.md §8c recollects it, unverified).  Process-wide, like the library's mg_set_hash_mode."""
+    lib().mgo_set_hash_mode(ctypes.c_int(int(mode)))
+
+
+def hash_mode():
+    return int(lib().mgo_hash_mode())
+
+
 DEFAULT_CS = 3  # kmc -cs3 (scripts/select_db.py:50): occurrence counters saturate at 3; the library's default too
 
 

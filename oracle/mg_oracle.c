@@ -95,7 +95,20 @@ static inline int base_code(uint8_t b) { /* A,C,G,T (either case) -> 0..3, else 
 
 static const char kUpper[4] = {'A', 'C', 'G', 'T'};
 
-/* Hash of the canonical form of the k-mer seq[0..k) (all symbols valid). */
+/* Which definition of a k-mer's hash is in force (the library's mg_set_hash_mode):
+ *   0  hash(min(kmer, revcomp)): MurmurHash3 of the lexicographically smaller strand — KMC's canonical k-mer, ONE hash,
+ *      the full 64 bits.  The default.
+ *   1  min(hash(kmer), hash(revcomp)) mod p, p = 9999999999971: CMash's MinHash.CountEstimator AS SURVEY.md §8(c) RECOLLECTS
+ *      it (khmer's hash_no_rc_murmur3 on both strands, the smaller value kept, `% p` with p = get_prime_lt_x(9999999999971.)
+ *      = 9999999999971, itself prime) — UNVERIFIED: CMash's source is not under /root/reference, the reference pins no
+ *      version and holds no vectors at this seam (scripts/select_db.py:69-76; local_tests/dump_kmers.py:2-7).  It exists
+ *      so that a table built by this definition and CMash's own could be compared at all. */
+static int g_hash_mode = 0;
+#define MGO_CMASH_PRIME 9999999999971ULL
+void mgo_set_hash_mode(int mode) { g_hash_mode = mode ? 1 : 0; }
+int mgo_hash_mode(void) { return g_hash_mode; }
+
+/* Hash of the k-mer seq[0..k) (all symbols valid) under the mode in force. */
 static uint64_t canonical_hash(const uint8_t* seq, int k) {
   char fwd[MG_MAX_K], rc[MG_MAX_K];
   for (int i = 0; i < k; ++i) {
@@ -103,8 +116,16 @@ static uint64_t canonical_hash(const uint8_t* seq, int k) {
     fwd[i] = kUpper[c];
     rc[k - 1 - i] = kUpper[3 - c];
   }
-  const char* pick = memcmp(fwd, rc, (size_t)k) <= 0 ? fwd : rc;
   uint64_t out[2];
+  if (g_hash_mode == 1) {
+    uint64_t a, b;
+    mgo_murmur3_x64_128(fwd, k, 0, out);
+    a = out[0];
+    mgo_murmur3_x64_128(rc, k, 0, out);
+    b = out[0];
+    return (a < b ? a : b) % MGO_CMASH_PRIME;
+  }
+  const char* pick = memcmp(fwd, rc, (size_t)k) <= 0 ? fwd : rc;
   mgo_murmur3_x64_128(pick, k, 0, out);
   return out[0];
 }

@@ -3,9 +3,9 @@
 // device builtin, v_alignbit, is restated in the header's MG_HOST_CHECK section), so that the build container — which has
 // no GPU — can hold them against the oracle for every k.  Test infrastructure: tests/test_kmer_header_host.py.
 //
-// stdin: one sequence of [ACGTacgtN...] per line.  stdout, per line and per k in 1..64: "k" then the hash of the k-mer
-// ENDING at every position (hex; '-' where there is none), as Roller<k>::hash gives it; then, for the fused kernels' k
-// sets, "s k kmax" lines with hash_suffix<k, kmax> of a Roller<kmax>.
+// stdin: one sequence of [ACGTacgtN...] per line.  stdout, per line, per hash definition ("mode 0" / "mode 1" lines) and
+// per k in 1..64: "k" then the hash of the k-mer ENDING at every position (hex; '-' where there is none), as
+// Roller<k>::hash gives it; then, for the fused kernels' k sets, "s k kmax" lines with hash_suffix<k, kmax> of a Roller<kmax>.
 #define MG_HOST_CHECK 1
 #include "../metalign_amd/csrc/mg_kmer.h"
 
@@ -16,7 +16,7 @@
 
 static std::vector<uint64_t> tab;
 
-template <int K>
+template <int K, int HM>
 static void one_k(const std::string& seq) {
   mg::Roller<K> r;
   r.reset();
@@ -25,7 +25,7 @@ static void one_k(const std::string& seq) {
     uint32_t c;
     if (mg::decode_base((unsigned char)ch, c)) {
       r.push(c);
-      if (r.full()) { std::printf(" %016llx", (unsigned long long)r.hash(tab.data())); continue; }
+      if (r.full()) { std::printf(" %016llx", (unsigned long long)r.template hash<HM>(tab.data())); continue; }
     } else {
       r.run = 0;
     }
@@ -34,7 +34,7 @@ static void one_k(const std::string& seq) {
   std::printf("\n");
 }
 
-template <int K, int KMAX>
+template <int K, int KMAX, int HM>
 static void one_suffix(const std::string& seq) {
   mg::Roller<KMAX> r;
   r.reset();
@@ -43,7 +43,7 @@ static void one_suffix(const std::string& seq) {
     uint32_t c;
     if (mg::decode_base((unsigned char)ch, c)) {
       r.push(c);
-      if (r.run >= K) { std::printf(" %016llx", (unsigned long long)mg::hash_suffix<K, KMAX>(r, tab.data())); continue; }
+      if (r.run >= K) { std::printf(" %016llx", (unsigned long long)mg::hash_suffix<K, KMAX, HM>(r, tab.data())); continue; }
     } else {
       r.run = 0;
     }
@@ -52,8 +52,17 @@ static void one_suffix(const std::string& seq) {
   std::printf("\n");
 }
 
-template <int... K>
-static void all_k(const std::string& seq, std::integer_sequence<int, K...>) { (one_k<K + 1>(seq), ...); }
+template <int HM, int... K>
+static void all_k(const std::string& seq, std::integer_sequence<int, K...>) { (one_k<K + 1, HM>(seq), ...); }
+
+template <int HM>
+static void one_mode(const std::string& line) {
+  std::printf("mode %d\n", HM);
+  all_k<HM>(line, std::make_integer_sequence<int, 64>{});
+  one_suffix<21, 51, HM>(line); one_suffix<31, 51, HM>(line); one_suffix<51, 51, HM>(line);
+  one_suffix<30, 60, HM>(line); one_suffix<40, 60, HM>(line); one_suffix<50, 60, HM>(line); one_suffix<60, 60, HM>(line);
+  one_suffix<1, 64, HM>(line); one_suffix<32, 64, HM>(line); one_suffix<33, 64, HM>(line); one_suffix<17, 33, HM>(line); one_suffix<4, 5, HM>(line);
+}
 
 int main() {
   tab.resize(mg::kHashTabEntries);
@@ -61,10 +70,8 @@ int main() {
   std::string line;
   while (std::getline(std::cin, line)) {
     std::printf("seq %zu\n", line.size());
-    all_k(line, std::make_integer_sequence<int, 64>{});
-    one_suffix<21, 51>(line); one_suffix<31, 51>(line); one_suffix<51, 51>(line);
-    one_suffix<30, 60>(line); one_suffix<40, 60>(line); one_suffix<50, 60>(line); one_suffix<60, 60>(line);
-    one_suffix<1, 64>(line); one_suffix<32, 64>(line); one_suffix<33, 64>(line); one_suffix<17, 33>(line); one_suffix<4, 5>(line);
+    one_mode<mg::kHashCanonical>(line);
+    one_mode<mg::kHashCmash>(line);
   }
   return 0;
 }

@@ -71,17 +71,27 @@ def murmur3_x64_128(key: bytes, seed: int = 0):
     return h1, h2
 
 
+CMASH_PRIME = 9999999999971  # CMash: get_prime_lt_x(9999999999971.) — the number is itself prime
+HASH_MODE = 0  # 0: hash(min(kmer, revcomp)), 64 bits; 1: min(hash(kmer), hash(revcomp)) % CMASH_PRIME
+
+
 def canonical_kmers(seq: bytes, k: int):
-    """Every canonical k-mer of `seq` (upper case), in order of occurrence; windows never span a non-ACGT symbol."""
+    """Every k-mer of `seq` (upper case) in order of occurrence, as what kmer_hash takes: the lexicographically smaller
+    strand (mode 0) or the pair of strands (mode 1); windows never span a non-ACGT symbol."""
     for m in _RUNS.finditer(seq):
         run = m.group().upper()
         for i in range(len(run) - k + 1):
             kmer = run[i:i + k]
             rc = kmer.translate(_COMP)[::-1]
-            yield kmer if kmer <= rc else rc
+            if HASH_MODE == 1:
+                yield (kmer, rc)
+            else:
+                yield kmer if kmer <= rc else rc
 
 
-def kmer_hash(kmer: bytes) -> int:
+def kmer_hash(kmer) -> int:
+    if isinstance(kmer, tuple):  # mode 1: both strands hashed, the smaller value kept, modulo the prime
+        return min(murmur3_x64_128(kmer[0], 0)[0], murmur3_x64_128(kmer[1], 0)[0]) % CMASH_PRIME
     return murmur3_x64_128(kmer, 0)[0]
 
 

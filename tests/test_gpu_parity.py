@@ -544,3 +544,58 @@ def test_filtered_sketch_matches_oracle_and_keeps_containment(hip, oracle_lib, k
     sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, 0, filt=empty)
     assert sk.size == 0
     sk.free()
+
+
+@pytest.fixture
+def cmash_mode(hip, oracle_lib):
+    """Hash definition 1 in the library AND the oracle (min(hash(kmer), hash(revcomp)) % 9999999999971: CMash as SURVEY.md
+    §8(c) recollects it, unverified); back to the default afterwards."""
+    hip.set_hash_mode(1)
+    oracle_lib.set_hash_mode(1)
+    yield
+    hip.set_hash_mode(0)
+    oracle_lib.set_hash_mode(0)
+
+
+def test_cmash_recollection_mode_matches_the_oracle(hip, oracle_lib, cmash_mode):
+    """Stage A', A (one k and the fused launches, table and list paths, the three tile walks) and B under hash mode 1 ==
+    the oracle under the same mode; and the two modes give different sketches of the same reads."""
+    rng = np.random.default_rng(4242)
+    gb, go = util.random_genomes(rng, 12, 4000, with_n=True)
+    for ks in ([21], [21, 31, 51], [30, 40, 50, 60], [1], [32, 33], [64]):
+        tabs = []
+        for k in ks:
+            dbh, dbo = hip.sketch_genomes(gb, go, k, 150)
+            odbh, odbo = oracle_lib.sketch_genomes(gb, go, k, 150)
+            assert np.array_equal(dbh, odbh) and np.array_equal(dbo, odbo), k
+            assert int(dbh.max()) < oracle_lib.CMASH_PRIME
+            tabs.append((dbh, dbo))
+        for ragged, with_n in ((False, False), (True, False), (False, True)):
+            rb, ro, _ = util.sample_reads(rng, gb, go, 9000, 150, ragged=ragged, lower=True, present=[2, 7])
+            if with_n:
+                rb[rng.integers(0, rb.size, size=50)] = ord("N")
+            d_b, d_o = hip.array(rb), hip.array(ro)
+            hmaxs = [int(t[0].max()) for t in tabs]
+            sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, len(ro) - 1, ks, hmaxs, 0, None)
+            for k, sk, (dbh, dbo), hm in zip(ks, sks, tabs, hmaxs):
+                sk.resolve()
+                qh, qc = sk.download()
+                oh, oc, otr, _ = oracle_lib.sketch_reads(rb, ro, k, hmax=hm)
+                assert np.array_equal(qh, oh) and np.array_equal(qc, oc), (ks, k, ragged, with_n)
+                table = hip.upload_table(dbh, dbo)
+                hits, sizes = hip.containment(sk, table, 2)
+                ohits, osizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
+                assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes)
+                table.free()
+                sk.free()
+            d_b.free()
+            d_o.free()
+    # the list path (tiny input) and a different sketch than mode 0's
+    rb, ro, _ = util.sample_reads(rng, gb, go, 40, 150, present=[2])
+    h1, c1, _, _ = hip.sketch_reads(rb, ro, 21)
+    oh, oc, _, _ = oracle_lib.sketch_reads(rb, ro, 21)
+    assert np.array_equal(h1, oh) and np.array_equal(c1, oc)
+    hip.set_hash_mode(0)
+    h0, _, _, _ = hip.sketch_reads(rb, ro, 21)
+    hip.set_hash_mode(1)
+    assert len(h0) == len(h1) and not np.array_equal(h0, h1)

@@ -52,13 +52,19 @@ def test_every_k_and_every_fused_suffix_equals_the_oracle(checker):
     seqs = sequences()
     out = subprocess.run([checker], input=b"\n".join(seqs) + b"\n", capture_output=True, check=True).stdout.decode().splitlines()
     it = iter(out)
-    for seq in seqs:
-        assert next(it) == "seq %d" % len(seq)
-        for k in range(1, 65):
-            got = next(it).split()
-            assert got[0] == str(k)
-            assert got[1:] == expected(seq, k), "k = %d, sequence of %d" % (k, len(seq))
-        for k, kmax in SUFFIXES:
-            got = next(it).split()
-            assert got[:3] == ["s", str(k), str(kmax)]
-            assert got[3:] == expected(seq, k), "suffix k = %d of a %d-roller, sequence of %d" % (k, kmax, len(seq))
+    try:
+        for seq in seqs:
+            assert next(it) == "seq %d" % len(seq)
+            for mode in (0, 1):  # hash(min(kmer, revcomp)) | min(hash(kmer), hash(revcomp)) % p  
+                assert next(it) == "mode %d" % mode
+                oracle.set_hash_mode(mode)
+                for k in range(1, 65):
+                    got = next(it).split()
+                    assert got[0] == str(k)
+                    assert got[1:] == expected(seq, k), "mode %d, k = %d, sequence of %d" % (mode, k, len(seq))
+                for k, kmax in SUFFIXES:
+                    got = next(it).split()
+                    assert got[:3] == ["s", str(k), str(kmax)]
+                    assert got[3:] == expected(seq, k), "mode %d, suffix k = %d of a %d-roller, sequence of %d" % (mode, k, kmax, len(seq))
+    finally:
+        oracle.set_hash_mode(0)

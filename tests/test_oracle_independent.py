@@ -15,6 +15,17 @@ import indep_sketch as ind
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+@pytest.fixture(params=[0, 1], ids=["canonical_kmer_hash", "cmash_recollection"])
+def hash_mode(request, oracle_lib):
+    """Both definitions of a k-mer's hash: 0 = hash(min(kmer, revcomp)), 64 bits — the default; 1 =
+    min(hash(kmer), hash(revcomp)) % 9999999999971, CMash as SURVEY.md §8(c) recollects it (unverified)."""
+    oracle_lib.set_hash_mode(request.param)
+    ind.HASH_MODE = request.param
+    yield request.param
+    oracle_lib.set_hash_mode(0)
+    ind.HASH_MODE = 0
+
+
 def test_independent_murmur3_matches_the_known_answers():
     with open(os.path.join(HERE, "golden", "murmur3_kat.json")) as fh:
         kat = json.load(fh)
@@ -46,13 +57,14 @@ def _flat(reads):
 
 @pytest.mark.parametrize("k", [1, 4, 21, 32, 33, 51, 60, 64])
 @pytest.mark.parametrize("cs", [0, 3])
-def test_read_sketch_c_oracle_equals_independent(oracle_lib, k, cs):
+def test_read_sketch_c_oracle_equals_independent(oracle_lib, hash_mode, k, cs):
     rng = np.random.default_rng(1000 + k)
     # ragged reads incl. shorter than k and empty, N and lower case; a repeated read so that counts exceed cs
     reads = _reads(rng, 60, 0, 150) + [b"", b"ACGT", b"N" * 70]
     reads += [reads[3]] * 5
     bases, offs = _flat(reads)
-    for hmax, s in ((ind.M64, 0), (int(0.3 * 2 ** 64), 0), (ind.M64, 37)):
+    top = ind.CMASH_PRIME if hash_mode else 2 ** 64
+    for hmax, s in ((ind.M64, 0), (int(0.3 * top), 0), (ind.M64, 37)):
         oh, oc, otr, oseen = oracle_lib.sketch_reads(bases, offs, k, hmax=hmax, s=s, cs=cs)
         items, tr, seen = ind.sketch_reads(reads, k, hmax=hmax, s=s, cs=cs)
         assert [int(x) for x in oh] == [h for h, _ in items]
@@ -60,7 +72,7 @@ def test_read_sketch_c_oracle_equals_independent(oracle_lib, k, cs):
         assert (otr, oseen) == (tr, seen)
 
 
-def test_strand_and_case_invariance_of_both(oracle_lib):
+def test_strand_and_case_invariance_of_both(oracle_lib, hash_mode):
     rng = np.random.default_rng(5)
     reads = _reads(rng, 20, 80, 120, p_n=0.0, p_lower=0.0)
     comp = bytes.maketrans(b"ACGT", b"TGCA")
@@ -74,7 +86,7 @@ def test_strand_and_case_invariance_of_both(oracle_lib):
 
 
 @pytest.mark.parametrize("k", [21, 33, 60])
-def test_genome_sketch_and_containment_c_oracle_equals_independent(oracle_lib, k):
+def test_genome_sketch_and_containment_c_oracle_equals_independent(oracle_lib, hash_mode, k):
     rng = np.random.default_rng(77 + k)
     genomes = _reads(rng, 6, 1500, 2500, p_n=0.002, p_lower=0.05) + [b"ACGT" * 3]  # the last one shorter than most k
     n = 120
@@ -115,3 +127,21 @@ def test_filtered_sketch_c_oracle_equals_independent(oracle_lib):
     bits, mask = oracle_lib.filter_bits(dbh)
     items, tr, _ = ind.sketch_reads(reads, k, hmax=hmax, cs=oracle_lib.DEFAULT_CS, member=lambda h: bool(bits[h & int(mask)]))
     assert [int(x) for x in oh] == [h for h, _ in items] and [int(x) for x in oc] == [c for _, c in items]
+
+
+def test_the_cmash_recollection_is_what_its_words_say(oracle_lib):
+    """Mode 1 spelled out on one k-mer: both strands hashed, the smaller VALUE kept, modulo the prime — and the two modes
+    differ (the smaller strand's hash is not the smaller hash)."""
+    kmer, rc = b"ACGTTGCAAGGCTTAAACCCG", b"CGGGTTTAAGCCTTGCAACGT"
+    a, b = ind.murmur3_x64_128(kmer)[0], ind.murmur3_x64_128(rc)[0]
+    assert ind.CMASH_PRIME == 9999999999971 and all(ind.CMASH_PRIME % p for p in range(2, 10000))
+    oracle_lib.set_hash_mode(1)
+    try:
+        h, v = oracle_lib.kmer_hashes(kmer, 21)
+        assert v[0] and int(h[0]) == min(a, b) % ind.CMASH_PRIME
+        h2, _ = oracle_lib.kmer_hashes(rc.lower(), 21)
+        assert int(h2[0]) == int(h[0])
+    finally:
+        oracle_lib.set_hash_mode(0)
+    h0, _ = oracle_lib.kmer_hashes(kmer, 21)
+    assert int(h0[0]) == a and a != min(a, b) % ind.CMASH_PRIME  # (ACGTT... < CGGGT...: mode 0 hashes the forward strand)
