@@ -242,6 +242,13 @@ struct MultiKTable {  // one k of the launch: its threshold, counting table (alr
   unsigned shift;
   const mg_filter* filter;
 };
+// mg_sketch_cmash.hip: the one-k kernels instantiated for hash definition 1 (mg_set_hash_mode)
+int launch_sketch_reads_cmash(int k, unsigned grid, size_t lds, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets,
+                              uint64_t nreads, uint64_t hmax, uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters,
+                              Slot* d_tab, unsigned bucket_shift, unsigned stage_bytes, const uint32_t* fbits, uint64_t fmask,
+                              uint32_t cs_word);
+int launch_hash_positions_cmash(int k, unsigned grid, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nseq,
+                                uint64_t nbases, uint64_t* d_out);
 bool sketch_reads_multi_supported(const int* ks, int nk);
 int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
                               const MultiKTable* tabs, unsigned stage_bytes);
