@@ -37,11 +37,33 @@ namespace mg {
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
+// x * C mod 2^64 for a 64-bit constant as three chained v_mad_u64_u32 (lo x lo in full; + lo x hi; + hi x lo): 13.7 issue
+// cycles + two register moves (the chain's 64-bit addends want register pairs) against 17.3 for the compiler's form — v_mad_u64_u32 + 2 x v_mul_lo_u32 (the cross terms) + v_add3_u32
+// (profiles/r03/valu_classes.json).  One dependent chain instead of three independent multiplies: rounds 1 and 2 measured
+// no gain from it; with the ASCII windows gone and two hashes of a position interleaved (mg_sketch_multi.hip) the fused
+// kernel alone takes 14.28 against 14.39 ms per 10M reads and the pipelined pass 12.24 against 13.04 ms (round 3).
+// MG_MUL64_COMPILER (A/B builds) keeps the compiler's form.
+template <uint64_t C>
+__device__ __forceinline__ uint64_t mul64c(uint64_t x) {
+#if !defined(MG_MUL64_COMPILER) && !defined(MG_HOST_CHECK)
+  const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+  constexpr uint32_t cl = (uint32_t)C, ch = (uint32_t)(C >> 32);
+  uint64_t p, t, u, c0, c1, c2;  // (c*: the carry-outs nobody reads; any SGPR pair)
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(c0) : "v"(xl), "s"(cl));
+  const uint64_t hi0 = p >> 32;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(c1) : "v"(xl), "s"(ch), "v"(hi0));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(u), "=s"(c2) : "v"(xh), "s"(cl), "v"(t));
+  return (uint64_t)(uint32_t)p | (u << 32);
+#else
+  return x * C;
+#endif
+}
+
 __device__ __forceinline__ uint64_t fmix64(uint64_t v) {
   v ^= v >> 33;
-  v *= 0xff51afd7ed558ccdULL;
+  v = mul64c<0xff51afd7ed558ccdULL>(v);
   v ^= v >> 33;
-  v *= 0xc4ceb9fe1a85ec53ULL;
+  v = mul64c<0xc4ceb9fe1a85ec53ULL>(v);
   v ^= v >> 33;
   return v;
 }
@@ -153,19 +175,19 @@ __device__ __forceinline__ uint64_t murmur3_h1_packed(const Packed& p, const uin
   auto body = [&]<int B>() {
     uint64_t k1 = key_word_times_c<K, 2 * B, 0>(p, tab);
     uint64_t k2 = key_word_times_c<K, 2 * B + 1, 1>(p, tab);
-    k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+    k1 = rotl64(k1, 31); k1 = mul64c<C2>(k1); h1 ^= k1;
     h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
-    k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+    k2 = rotl64(k2, 33); k2 = mul64c<C1>(k2); h2 ^= k2;
     h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
   };
   [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(std::make_integer_sequence<int, NBLK>{});
   if constexpr (TAIL > 8) {
     uint64_t k2 = key_word_times_c<K, 2 * NBLK + 1, 1>(p, tab);
-    k2 = rotl64(k2, 33); k2 *= C1; h2 ^= k2;
+    k2 = rotl64(k2, 33); k2 = mul64c<C1>(k2); h2 ^= k2;
   }
   if constexpr (TAIL > 0) {
     uint64_t k1 = key_word_times_c<K, 2 * NBLK, 0>(p, tab);
-    k1 = rotl64(k1, 31); k1 *= C2; h1 ^= k1;
+    k1 = rotl64(k1, 31); k1 = mul64c<C2>(k1); h1 ^= k1;
   }
   h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
   h1 += h2; h2 += h1;

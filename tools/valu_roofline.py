@@ -89,7 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm")
     ap.add_argument("classes")
-    ap.add_argument("--kernel", default="KListIJLi21ELi31ELi51")
+    ap.add_argument("--kernel", default="KListIJLi21ELi31ELi51EEEELi0E")
     ap.add_argument("--waves", type=int, default=8, help="column of the ubench table (8: issue cost with latencies covered)")
     ap.add_argument("--read_len", type=int, default=150)
     ap.add_argument("--ks", default="21,31,51")
@@ -101,21 +101,29 @@ def main():
     idx = {b: i for i, b in enumerate(order)}
     # the walk loops: back edges whose body holds multiplies; per loop, the blocks with multiplies are the hashes (one per
     # k, in ascending k) — the clean equal-length walk (MODE 1) is the loop without a per-lane length compare in its hashes
-    cands, paired = [], []
+    # the walk loops: back edges whose body holds multiplies.  A loop over the positions where EVERY k is complete holds all
+    # the multiplies of a position (whatever the number of blocks: the shipped kernel hashes two k per block there); a loop
+    # over the positions where the largest k is not complete yet holds fewer, one block per k.  There is one of each per
+    # tile walk; the clean equal-length walk (MODE 1) is the one with the fewest 32-bit compares (no `pos < len`, no run
+    # counter).
+    def nmul(bs):
+        return sum(1 for b in bs for o in blocks[b] if ih.classify(o) in ("valu_mul32", "valu_mad64"))
+    loops = []
     for head, tail, body in ih.loops(blocks, order, succ):
-        hot = [b for b in body if any(ih.classify(o) == "valu_mul32" for o in blocks[b])]
-        if len(hot) == len(ks) and len(body) < 400:
-            cands.append((head, tail, body, hot))
-        elif len(hot) == len(ks) - 1 and len(ks) > 1 and len(body) < 400:
-            paired.append((head, tail, body, hot))  # the loop over the positions where the largest k is not complete yet
-    if not cands:
+        hot = [b for b in body if any(ih.classify(o) in ("valu_mul32", "valu_mad64") for o in blocks[b])]
+        if hot and len(body) < 400 and nmul(hot) > 30:
+            loops.append((head, tail, body, hot))
+    if not loops:
         sys.exit("no walk loop found")
+    top = max(nmul(c[3]) for c in loops)
+    cands = [c for c in loops if nmul(c[3]) == top]
+    paired = [c for c in loops if nmul(c[3]) < top and len(c[3]) == len(ks) - 1]
     lines_all = {}
     for head, tail, body, hot in cands:
         lines_all[head] = block_lines(a.asm, a.kernel, [head] + hot)
     # MODE 1 = the candidate with the fewest v_cmp on 32 bits in its hash blocks (no `pos < len`)
-    def ncmp32(c):
-        return sum(1 for b in c[3] for op, _ in lines_all[c[0]][b] if op.startswith("v_cmp") and "u32" in op)
+    def ncmp32(c):  # (the clean walk has neither the per-lane length compare nor the run-counter tests)
+        return sum(1 for b in c[3] for op, _ in lines_all[c[0]][b] if op.startswith("v_cmp") and ("32" in op))
     head, tail, body, hot = min(cands, key=ncmp32)
     lines = lines_all[head]
     per_block = {}
@@ -139,7 +147,7 @@ def main():
     if paired:
         def ncmp32p(c):
             ls = block_lines(a.asm, a.kernel, [c[0]] + c[3])
-            return sum(1 for b in c[3] for op, _ in ls[b] if op.startswith("v_cmp") and "u32" in op)
+            return sum(1 for b in c[3] for op, _ in ls[b] if op.startswith("v_cmp") and ("32" in op))
         ph, pt, pb, phot = min(paired, key=ncmp32p)
         pl = block_lines(a.asm, a.kernel, [ph] + phot)
         part = {}
@@ -162,7 +170,7 @@ def main():
             tot_instr += npos[i] * n_i
             tot_cyc += npos[i] * c_i
             continue
-        for b in [head] + hot[: i + 1]:
+        for b in [head] + (hot if i == len(ks) - 1 else hot[: i + 1]):
             for (op, how), (n, c) in per_block[b].items():
                 n_i += n
                 c_i += n * c
