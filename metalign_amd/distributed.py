@@ -92,6 +92,8 @@ class _CudaView:
 
 
 class HipEngine:
+    wg_per_cu_exchange = 3  # the hashing kernel's workgroups per CU beside the exchange chain (x_begin)
+
     """Compute side of one rank: device-resident inputs + calls into libmetalign_hip.so."""
 
     def __init__(self, hip, torch_mod=None):
@@ -321,7 +323,10 @@ class HipEngine:
         # need fewer issue slots than on the one-pass-at-a-time path (two), but not none (measured on one GPU with
         # every collective in the path: 2 -> 0.735 ms per pass, 3 -> 0.68, 4 -> 0.665, 5 -> 0.71; alternating two
         # stage-A streams here: worse at every setting)
-        self.hip.stage_a_workgroups_per_cu(4)
+        # (round 3: the fused multi-k kernel is held to 128 VGPRs — four of its workgroups per CU take the WHOLE register
+        # file and every other kernel of the tick waits for one of them to retire: three per CU.  configs[3] shapes at world
+        # size 1, ms per pass: 4 -> 54.1, 3 -> 52.2, 2 -> 61.1.  MG_STAGE_A_WG_PER_CU overrides, for measurements)
+        self.hip.stage_a_workgroups_per_cu(int(os.environ.get("MG_STAGE_A_WG_PER_CU", self.wg_per_cu_exchange)))
         self.hip.stage_a_side_stream(True)
 
     def x_end(self):
