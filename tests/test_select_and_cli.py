@@ -347,3 +347,21 @@ def test_inflate_file_takes_every_member_and_refuses_a_truncated_stream(tmp_path
     assert formats.inflate_file(str(empty)) == b""
     with pytest.raises(OSError):
         formats.inflate_file(str(cut))
+
+
+def test_subset_database_is_what_zcat_would_write(tmp_path, capsys):
+    """make_db_and_dbinfo appends `zcat <organism file>` per selected genome (reference scripts/select_db.py:103-105, exit
+    codes ignored): gzip files — every member — inflated in order; a file zcat refuses contributes nothing but a message."""
+    import gzip
+
+    org = tmp_path / "org"
+    org.mkdir()
+    (org / "a.fna.gz").write_bytes(gzip.compress(b">a\nACGT\n"))
+    (org / "b.fna.gz").write_bytes(gzip.compress(b">b1\nAA\n") + gzip.compress(b">b2\nCC\n"))
+    (org / "c.fna.gz").write_bytes(b">not gzip\nGG\n")
+    (org / "d.fna.gz").write_bytes(gzip.compress(b">d\nTT\n"))
+    out = tmp_path / "db.fna"
+    with open(out, "wb") as fh:
+        select_db._zcat_into(fh, [str(org / n) for n in ("a.fna.gz", "b.fna.gz", "c.fna.gz", "d.fna.gz")], threads=3, batch=2)
+    assert out.read_bytes() == b">a\nACGT\n>b1\nAA\n>b2\nCC\n>d\nTT\n"
+    assert "c.fna.gz" in capsys.readouterr().err

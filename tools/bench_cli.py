@@ -158,6 +158,11 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, 
                                       dbinfo_out="AUTO", input_type="AUTO", keep_temp_files=True, strain_level=False, temp_dir=tmpd,
                                       threads=4, sketch_table="AUTO", min_count=2, sketch_size=0)
             hip.prof_reset()
+            prof = None
+            if os.environ.get("MG_CLI_PROFILE") == "1" and rep == reps - 1:  # cProfile of the last repetition's two stages
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             t0 = time.perf_counter()
             sk_t0 = time.perf_counter()
             select_db.run_timings = {}
@@ -168,6 +173,13 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, 
                                     no_quantify_unmapped=False, read_cutoff=1, sampleID="x", threads=4, verbose=False)
             map_and_profile.map_main(a2)
             t2 = time.perf_counter()
+            if prof is not None:
+                import io
+                import pstats
+                prof.disable()
+                buf = io.StringIO()
+                pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(40)
+                print(buf.getvalue()[:8000], flush=True)
             tm = dict(getattr(select_db, "run_timings", {}))
             if verbose:
                 print("run %d: select_main %.3f s %s, map_main %.3f s" % (rep, t1 - t0, {k: round(v, 3) for k, v in tm.items()}, t2 - t1), flush=True)
