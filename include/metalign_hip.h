@@ -215,7 +215,7 @@ int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_of
  *            rules; record-aligned: the incomplete last record of a chunk is carried to the front of the next ON THE
  *            DEVICE) and hashed into the tables.  format as mg_reads_parse; offset / length: a byte range of the
  *            file that begins on a record boundary (a rank's share; length 0 = to the end).  chunk_bytes / nthreads:
- *            0 = defaults (64 MB, up to 8 readers). */
+ *            0 = defaults (32 MB, up to 8 readers). */
 typedef struct mg_sketch_stream mg_sketch_stream;
 int mg_sketch_stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters,
                            uint64_t expect_bases, mg_sketch_stream** out);
