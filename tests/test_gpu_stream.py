@@ -299,3 +299,32 @@ def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch):
             csv, sub, _ = select(q, "st_%s_%s" % (chunk, name.replace(".", "_")))
             assert (csv, sub) == (want_csv, want_sub), (name, chunk)
         assert profile(sam, sub_path, "st" + chunk) == want_cami
+
+
+def test_repeated_streams_hold_no_more_memory(hip, tmp_path):
+    """Forty streams of the same file (alternating piece sizes, so that the page-locked slots are re-made; a refused file in
+    between): the sketches stay the same and the device memory in use does not grow."""
+    ks = [21, 31, 51]
+    gb, go, rb, ro = _sample(5, nreads=8000)
+    tabs, hmaxs, filts = _tables(hip, gb, go, ks)
+    p = tmp_path / "x.fq"
+    p.write_bytes(_fastq(rb, ro))
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r\nACGT\nnot a plus line\nIIII\n" * 50)
+    want = None
+    used = []
+    for i in range(40):
+        got, counts = _streamed(hip, ks, hmaxs, filts, rb.size, lambda st: st.add_file(str(p), "fastq", chunk_bytes=(1 << 16) << (i % 3), nthreads=1 + i % 4))
+        assert counts == (len(ro) - 1, rb.size)
+        if want is None:
+            want = got
+        _same(got, want)
+        if i % 10 == 5:
+            st = hip.sketch_stream(ks, hmaxs, 0, filts, expect_bases=1000)
+            with pytest.raises(_hip.HipError):
+                st.add_file(str(bad), "fastq", chunk_bytes=1 << 16)
+            st.free()
+        hip.sync()
+        free, total, pooled = hip.mem_info()
+        used.append(total - free - pooled)
+    assert max(used[20:]) <= max(used[5:20]) + (8 << 20), used

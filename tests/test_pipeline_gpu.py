@@ -182,7 +182,9 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
         launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                   "--master-addr", "127.0.0.1", "--master-port", str(29560 + world)]
         tmpw = tmp_path / ("tmp_world%d" % world)
-        r = subprocess.run(launch + ["-m", "metalign_amd.select_db", str(fa if world == 3 else fq), str(data), "--temp_dir", str(tmpw), "--keep_temp_files",
+        # (world 2 is handed the GZIPPED reads — rank 0 inflates and sketches them, the other rank brings an empty shard and
+        # its table slices; round 2 exited with an error there — world 3 the FASTA file, world 8 the FASTQ file)
+        r = subprocess.run(launch + ["-m", "metalign_amd.select_db", str({2: gzq, 3: fa}.get(world, fq)), str(data), "--temp_dir", str(tmpw), "--keep_temp_files",
                                      "--sketch_table", str(data / "sketch_table")],
                            capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
