@@ -343,21 +343,27 @@ def stream_reads_file(hip, path, kind, ks, hmaxs, s, filts, offset=0, length=0):
         stream = hip.sketch_stream(ks, hmaxs, s, filts, expect)
         sks = []
         try:
-            stream.add_file(path, fmt, offset=offset, length=length, chunk_bytes=chunk)
+            try:
+                stream.add_file(path, fmt, offset=offset, length=length, chunk_bytes=chunk)
+            except _hip.HipError as e:
+                # a record longer than a piece's headroom (capacity), or FASTA text the device parser refuses: not for
+                # this pipeline; a malformed FASTQ record is the caller's error, as on the whole-file path
+                if e.code == _hip.ERR_CAPACITY or (e.code == _hip.ERR_ARG and kind != 'fastq'):
+                    return None
+                raise
             sks = stream.finish()
-            for sk in sks:
-                sk.resolve()
-            return sks
-        except _hip.HipError as e:
-            for sk in sks:
-                sk.free()
-            if e.code == _hip.ERR_CAPACITY and attempt == 0 and stream.nbases:
-                # a counting table overflowed: the library has reset its hint to the worst case; size for what was seen
+            try:
+                for sk in sks:
+                    sk.resolve()
+                return sks
+            except _hip.HipError as e:
+                for sk in sks:
+                    sk.free()
+                if e.code != _hip.ERR_CAPACITY:
+                    raise
+                # a counting table overflowed: the library has reset its hint to the worst case; size the second pass
+                # for the bases the first one counted
                 expect = max(expect, int(stream.nbases * 1.25))
-                continue
-            if e.code == _hip.ERR_CAPACITY or (e.code == _hip.ERR_ARG and kind != 'fastq'):
-                return None
-            raise
         finally:
             stream.free()
     return None

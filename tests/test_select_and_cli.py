@@ -365,3 +365,66 @@ def test_subset_database_is_what_zcat_would_write(tmp_path, capsys):
         select_db._zcat_into(fh, [str(org / n) for n in ("a.fna.gz", "b.fna.gz", "c.fna.gz", "d.fna.gz")], threads=3, batch=2)
     assert out.read_bytes() == b">a\nACGT\n>b1\nAA\n>b2\nCC\n>d\nTT\n"
     assert "c.fna.gz" in capsys.readouterr().err
+
+
+class _FakeSketch:
+    def __init__(self, fail_with=None):
+        self.fail_with, self.freed = fail_with, False
+
+    def resolve(self):
+        if self.fail_with is not None:
+            raise self.fail_with
+
+    def free(self):
+        self.freed = True
+
+
+class _FakeStreamHip:
+    """Stands in for _hip.Hip in select_db.stream_reads_file: records what it is asked and fails as scripted."""
+
+    def __init__(self, script):
+        self.script, self.calls = list(script), []
+
+    def sketch_stream(self, ks, hmaxs, s, filts, expect):
+        hip = self
+        step = self.script.pop(0)
+
+        class S:
+            nbases = 123_456_789
+
+            def add_file(self, path, fmt, offset=0, length=0, chunk_bytes=0):
+                hip.calls.append(("add_file", fmt, expect))
+                if step.get("add"):
+                    raise step["add"]
+
+            def finish(self):
+                return [_FakeSketch(step.get("resolve")) for _ in ks]
+
+            def free(self):
+                hip.calls.append(("free",))
+        return S()
+
+
+def test_stream_reads_file_retries_and_falls_back(tmp_path):
+    """The host logic around mg_sketch_stream_*: a counting table that proved too small (MG_ERR_CAPACITY at resolution) ->
+    the file is streamed ONCE more, sized for what was seen; a record too long for the pieces, or FASTA text the device
+    parser refuses -> None (the caller's piece-wise path); a malformed FASTQ record -> the error surfaces."""
+    from metalign_amd import _hip
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"@r\nACGT\n+\nIIII\n" * 10)
+    cap = _hip.HipError("overflow", _hip.ERR_CAPACITY)
+    arg = _hip.HipError("malformed", _hip.ERR_ARG)
+    hip = _FakeStreamHip([{"resolve": cap}, {}])
+    sks = select_db.stream_reads_file(hip, str(fq), "fastq", [21], [1], 0, [None])
+    assert len(sks) == 1 and [c[0] for c in hip.calls] == ["add_file", "free", "add_file", "free"]
+    assert hip.calls[2][2] >= int(123_456_789 * 1.25)  # the second pass is sized for the bases the first one counted
+    hip = _FakeStreamHip([{"resolve": cap}, {"resolve": cap}])
+    assert select_db.stream_reads_file(hip, str(fq), "fastq", [21], [1], 0, [None]) is None
+    hip = _FakeStreamHip([{"add": cap}])
+    assert select_db.stream_reads_file(hip, str(fq), "fastq", [21], [1], 0, [None]) is None
+    hip = _FakeStreamHip([{"add": arg}])
+    assert select_db.stream_reads_file(hip, str(fq), "fasta", [21], [1], 0, [None]) is None and hip.calls[0][1] == "fasta_ml"
+    hip = _FakeStreamHip([{"add": arg}])
+    with pytest.raises(_hip.HipError):
+        select_db.stream_reads_file(hip, str(fq), "fastq", [21], [1], 0, [None])
+    assert select_db.expected_bases(str(fq), "fastq") == os.path.getsize(fq) // 2 + 1
