@@ -78,6 +78,8 @@ __global__ void k_build_index(const ContainArgs a) {
 constexpr int kCT = 256;                // threads per workgroup
 constexpr int kCTile = 8 * kCT;         // pairs per tile
 constexpr uint32_t kCCap = 2048;        // read-sketch entries staged in LDS per tile (24 KB: six workgroups per CU)
+// (round 3, measured again and dropped: a 1024-entry stage and eight workgroups per CU whenever a tile's run is expected under
+// 512 entries — the filtered sketch of a metagenome against any table: 0.140 against 0.127 ms per three-k pass at configs[2])
 
 // hits[g] += 1 for every pair (h, g) with h in the read sketch at count >= ci; sizes (optional, truncated
 // sketches only) counts every pair.  npairs = pairs with hash <= the sketch's completeness bound.
