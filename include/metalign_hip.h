@@ -337,6 +337,15 @@ int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets,
                       uint64_t ngenomes, int k, uint64_t n,
                       uint64_t* out_hashes, uint64_t* out_offsets);
 
+/* The k < kmax table of hash mode 1 (CMash as SURVEY.md §8(c) recollects it, UNVERIFIED: the smaller-k columns are
+ * containments of the k-PREFIXES of the sketched kmax-mers): per genome the bottom-n sketch at kmax under mode 1, every
+ * sketched kmax-mer oriented as CMash keeps it (the strand with the smaller hash, the reverse complement on a tie), the
+ * mode-1 hash of its first k bases; the genome's entry = its distinct keys, ascending.  Same output layout as
+ * mg_sketch_genomes; independent of mg_set_hash_mode.  Replaces (in that mode) the prefix tree of
+ * MakeStreamingDNADatabase.py (local_tests/retrain_and_test_metalign.sh:49). */
+int mg_sketch_genomes_prefix(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int kmax, int k, uint64_t n,
+                             uint64_t* out_hashes, uint64_t* out_offsets);
+
 typedef struct mg_db mg_db;
 int mg_db_upload(const uint64_t* hashes, const uint64_t* offsets,
                  uint64_t ngenomes, mg_db** out);

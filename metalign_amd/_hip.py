@@ -36,7 +36,7 @@ EXPORTS = [
     "mg_reads_download", "mg_reads_free",
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
-    "mg_sketch_genomes", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
+    "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
@@ -947,6 +947,19 @@ class Hip:
         self._chk(self.lib.mg_sketch_genomes(_np(bases, ctypes.c_uint8), _np(offsets, ctypes.c_uint64),
                                              ctypes.c_uint64(g), ctypes.c_int(k), ctypes.c_uint64(n),
                                              _np(out_h, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
+        return out_h[: int(out_o[-1])].copy(), out_o
+
+    def sketch_genomes_prefix(self, bases, offsets, kmax, k, n):
+        """The k < kmax table of hash mode 1: per genome the distinct mode-1 hashes of the k-prefixes of its sketched kmax-mers
+        (mg_sketch_genomes_prefix; CMash as SURVEY.md §8(c) recollects it, unverified)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        g = len(offsets) - 1
+        out_h = np.zeros(max(g * n, 1), dtype=np.uint64)
+        out_o = np.zeros(g + 1, dtype=np.uint64)
+        self._chk(self.lib.mg_sketch_genomes_prefix(_np(bases, ctypes.c_uint8), _np(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                                                    ctypes.c_int(kmax), ctypes.c_int(k), ctypes.c_uint64(n),
+                                                    _np(out_h, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
         return out_h[: int(out_o[-1])].copy(), out_o
 
     def upload_table(self, hashes, offsets):

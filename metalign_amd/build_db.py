@@ -30,20 +30,23 @@ def genome_bases(path):
     return np.concatenate(parts)
 
 
-def build(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0):
+def build(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0, prefix_tables=False):
     """hash_mode: 0 = MurmurHash3 of the canonical k-mer (default); 1 = min(hash(kmer), hash(revcomp)) % 9999999999971,
     CMash's CountEstimator as SURVEY.md §8(c) recollects it (unverified; include/metalign_hip.h: mg_set_hash_mode).  The
-    table records its mode and select_db sketches the reads in the same one."""
+    table records its mode and select_db sketches the reads in the same one.  prefix_tables (mode 1 only): the tables of the
+    k below the largest hold the k-PREFIXES of the sketched k_max-mers (CMash's smaller-k columns as recollected), not
+    sketches of their own; select_db then runs those k without a hash threshold (the table's largest key is near the
+    prime), the stored membership filter doing the rejecting."""
     hip = _hip.Hip.get()
     previous = hip.hash_mode
     hip.set_hash_mode(hash_mode)
     try:
-        return _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode)
+        return _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode, prefix_tables)
     finally:
         hip.set_hash_mode(previous)
 
 
-def _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode):
+def _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode, prefix_tables):
     names = [os.path.basename(p) for p in paths]
     per_k = {k: ([], [0]) for k in ks}
     i = 0
@@ -58,7 +61,11 @@ def _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode):
         offs[1:] = np.cumsum([len(s) for s in seqs])
         bases = np.concatenate(seqs) if total else np.zeros(1, np.uint8)
         for k in ks:
-            h, o = hip.sketch_genomes(bases, offs, k, n)
+            # hash mode 1 with prefix tables: the k < k_max tables hold the k-prefixes of the sketched k_max-mers
+            if hash_mode == 1 and prefix_tables and k < max(ks):
+                h, o = hip.sketch_genomes_prefix(bases, offs, max(ks), k, n)
+            else:
+                h, o = hip.sketch_genomes(bases, offs, k, n)
             hs, os_ = per_k[k]
             base = os_[-1]
             hs.append(h)
@@ -70,7 +77,7 @@ def _build(hip, paths, out_dir, ks, n, batch_bases, hash_mode):
         f = hip.filter_build(final[k][0])
         filters[k] = f.download()
         f.free()
-    formats.write_sketch_table(out_dir, names, ks, n, final, filters, hash_mode=hash_mode)
+    formats.write_sketch_table(out_dir, names, ks, n, final, filters, hash_mode=hash_mode, prefix_tables=bool(prefix_tables and hash_mode == 1))
     return final
 
 
@@ -83,14 +90,19 @@ def main(argv=None):
     p.add_argument('--hash_mode', choices=['canonical', 'cmash'], default='canonical',
                    help="canonical: MurmurHash3 of the lexicographically smaller strand, 64 bits (default). cmash: "
                         "min(hash(kmer), hash(revcomp)) %% 9999999999971, CMash's definition as recollected (unverified).")
+    p.add_argument('--prefix_tables', action='store_true',
+                   help="with --hash_mode cmash: the k < k_max tables hold the k-prefixes of the sketched k_max-mers (CMash's "
+                        "smaller-k columns as recollected) instead of a sketch per k.")
     a = p.parse_args(argv)
+    if a.prefix_tables and a.hash_mode != 'cmash':
+        p.error('--prefix_tables needs --hash_mode cmash')
     if os.path.isdir(a.genomes):
         paths = sorted(os.path.join(a.genomes, f) for f in os.listdir(a.genomes)
                        if '.fna' in f or f.endswith(('.fa', '.fa.gz', '.fasta', '.fasta.gz')))
     else:
         with open(a.genomes) as fh:
             paths = [ln.strip() for ln in fh if ln.strip()]
-    build(paths, a.out_dir, [int(x) for x in a.ks.split(',')], a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0)
+    build(paths, a.out_dir, [int(x) for x in a.ks.split(',')], a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0, prefix_tables=a.prefix_tables)
 
 
 if __name__ == '__main__':

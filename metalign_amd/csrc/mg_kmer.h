@@ -75,6 +75,9 @@ constexpr uint64_t kMurmurC1 = 0x87c37b91114253d5ULL, kMurmurC2 = 0x4cf5ad432745
 //   kHashCmash      min(MurmurHash3(kmer), MurmurHash3(revcomp)) mod 9999999999971 — CMash's CountEstimator as SURVEY.md
 //                   §8(c) recollects it (unverified: its source is not under /root/reference); two hashes per k-mer
 constexpr int kHashCanonical = 0, kHashCmash = 1;
+// (table builder only: kHashCmash with the kept strand in bit 63 — set when the reverse complement's hash is the smaller or
+// equal one, the strand CMash's CountEstimator.add keeps; mode-1 hashes are below 2^44)
+constexpr int kHashCmashTagged = 2;
 constexpr uint64_t kCmashPrime = 9999999999971ULL;
 
 // Base decode: A,C,G,T (either case) -> 0..3 (lexicographic order), anything else -> invalid.
@@ -246,10 +249,12 @@ struct Roller {
   // The k-mer's hash under definition HM.  tab: fill_hash_tables().
   template <int HM = kHashCanonical>
   __device__ __forceinline__ uint64_t hash(const uint64_t* tab) const {
-    if constexpr (HM == kHashCmash) {
+    if constexpr (HM == kHashCmash || HM == kHashCmashTagged) {
       const uint64_t a = murmur3_h1_packed<K>(make_packed(pf_lo, NW == 1 ? 0ull : pf_hi), tab);
       const uint64_t b = murmur3_h1_packed<K>(make_packed(pr_lo, NW == 1 ? 0ull : pr_hi), tab);
-      return (a < b ? a : b) % kCmashPrime;
+      const uint64_t h = (a < b ? a : b) % kCmashPrime;
+      if constexpr (HM == kHashCmashTagged) return h | (b <= a ? 1ull << 63 : 0ull);
+      return h;
     }
     const bool fw = forward_is_canonical();
     const uint64_t lo = fw ? pf_lo : pr_lo, hi = NW == 1 ? 0ull : (fw ? pf_hi : pr_hi);

@@ -610,9 +610,18 @@ struct KPlan {  // one k of a sketch call
   bool table = false;
   TablePlan tp;
 };
+// The share of all k-mers whose hash is <= hmax: hashes are uniform over 2^64 under definition 0 and over [0, 9999999999971)
+// under definition 1 (mg_set_hash_mode) — where a table of k-prefixes (build_db --prefix_tables) has its largest key near
+// the prime and EVERY k-mer is a candidate.
+static double hash_fraction(uint64_t hmax) {
+  const double range = ctx().hash_mode == kHashCmash ? (double)kCmashPrime : 18446744073709551616.0;
+  const double f = ((double)hmax + 1.0) / range;
+  return f < 1.0 ? f : 1.0;
+}
+
 static void plan_k(const ReadPlan& rp, int k, uint64_t hmax, KPlan& kp) {
   kp.hmax = hmax;
-  const double frac = ((double)hmax + 1.0) / 18446744073709551616.0;
+  const double frac = hash_fraction(hmax);
   kp.expect = (uint64_t)((double)rp.nbases * frac);
   kp.cap = kp.expect + kp.expect / 4 + (1u << 16);
   if (kp.cap > rp.nbases + 64) kp.cap = rp.nbases + 64;
@@ -873,7 +882,7 @@ static int stream_finish(mg_sketch_stream* ss, mg_sketch** out) {
     std::unique_ptr<mg_sketch> sk(new mg_sketch());
     KPlan& kp = ss->kp[i];
     // (the hint update at resolution divides the distinct hashes by the candidates EXPECTED: of what was streamed)
-    const double frac = ((double)kp.hmax + 1.0) / 18446744073709551616.0;
+    const double frac = hash_fraction(kp.hmax);
     kp.expect = (uint64_t)((double)ss->nbases * frac);
     int rc = alloc_table_staging(kp.tp);
     if (rc == MG_OK) rc = finish_pending(sk.get(), kp, rp, ss->t_counters[i], ss->ks[i], ss->s, nullptr, nullptr, 0, ss->filters[i]);
@@ -1237,6 +1246,140 @@ int mg_sketch_reads(const uint8_t* bases, const uint64_t* offsets, uint64_t nrea
   int rc = mg_sketch_download(sk, out_hashes, out_counts, out_cap);
   mg_sketch_free(sk);
   return rc;
+}
+
+// ---- the k < k_max tables of hash mode 1: k-prefixes of the sketched k_max-mers (oracle: mgo_sketch_genomes_prefix) ----
+}  // extern "C"
+
+namespace mg {
+
+constexpr uint64_t kTagBit = 1ull << 63;
+
+// the tagged position hashes without their tag (what the sketch is made of); the reserved value stays
+__global__ void k_clear_tags(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i] == kReservedHash ? kReservedHash : (in[i] & ~kTagBit);
+}
+
+__global__ void k_fill_u64(uint64_t* __restrict__ v, uint64_t n, uint64_t value) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) v[i] = value;
+}
+
+// Every position p that ends a valid k_max-mer whose hash is in its genome's sketch: the key of that k_max-mer's k-prefix
+// (in the kept strand's orientation) = the mode-1 hash of the k-mer ending at p - kmax + k (kept strand = forward) or at p
+// (kept strand = reverse complement: the prefix of the reverse complement is the reverse complement of the SUFFIX, and the
+// hash is symmetric in the strand).  keys[g * n + slot] = the smallest key among the k_max-mers that share the slot's hash.
+__global__ __launch_bounds__(256) void k_prefix_keys(const uint64_t* __restrict__ tagged, const uint64_t* __restrict__ hk,
+                                                     const uint64_t* __restrict__ offsets, uint64_t nseq, uint64_t nbases,
+                                                     const uint64_t* __restrict__ sketch, const uint32_t* __restrict__ cnt, uint64_t n,
+                                                     int kmax, int k, unsigned long long* __restrict__ keys) {
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; p < nbases; p += stride) {
+    const uint64_t t = tagged[p];
+    if (t == kReservedHash) continue;
+    const uint64_t h = t & ~kTagBit;
+    uint64_t lo = 0, hi = nseq;  // genome of p: offsets[lo] <= p < offsets[hi]
+    while (hi - lo > 1) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint64_t g = lo;
+    const uint64_t* sk = sketch + g * n;
+    uint32_t a = 0, b = cnt[g];
+    while (a < b) {
+      const uint32_t mid = (a + b) >> 1;
+      if (sk[mid] < h) a = mid + 1; else b = mid;
+    }
+    if (a >= cnt[g] || sk[a] != h) continue;
+    const uint64_t e = (t & kTagBit) ? p : p - (uint64_t)kmax + (uint64_t)k;
+    atomicMin(&keys[g * n + a], (unsigned long long)hk[e]);
+  }
+}
+
+}  // namespace mg
+
+extern "C" {
+
+int mg_sketch_genomes_prefix(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int kmax, int k, uint64_t n,
+                             uint64_t* out_hashes, uint64_t* out_offsets) {
+  MG_REQUIRE_READY();
+  if (!offsets || !out_offsets) return fail(MG_ERR_ARG, "null argument");
+  if (kmax < 1 || kmax > MG_MAX_K || k < 1 || k > kmax) return fail(MG_ERR_ARG, "need 1 <= k=%d <= kmax=%d <= %d", k, kmax, MG_MAX_K);
+  if (n == 0) return fail(MG_ERR_ARG, "n must be positive");
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  out_offsets[0] = 0;
+  const uint64_t kBatchBases = 1ull << 27;
+  uint64_t g0 = 0, written = 0;
+  std::vector<uint64_t> h_slots, rel, seg;
+  std::vector<uint32_t> h_cnt;
+  while (g0 < ngenomes) {
+    uint64_t g1 = g0 + 1;
+    while (g1 < ngenomes && offsets[g1 + 1] - offsets[g0] <= kBatchBases && g1 - g0 < (1u << 20)) ++g1;
+    const uint64_t ng = g1 - g0, nb = offsets[g1] - offsets[g0];
+    if (nb > 0xffffffffull) return fail(MG_ERR_ARG, "single genome of %llu bases exceeds 2^32-1", (unsigned long long)nb);
+    rel.resize(ng + 1);
+    seg.resize(ng + 1);
+    for (uint64_t i = 0; i <= ng; ++i) { rel[i] = offsets[g0 + i] - offsets[g0]; seg[i] = i * n; }
+    uint8_t* d_bases = (uint8_t*)scratch("g_bases", nb + 16);
+    uint64_t* d_off = (uint64_t*)scratch("g_off", (ng + 1) * sizeof(uint64_t));
+    uint64_t* d_seg = (uint64_t*)scratch("gp_seg", (ng + 1) * sizeof(uint64_t));
+    uint64_t* d_tag = (uint64_t*)scratch("gp_tag", (nb + 1) * sizeof(uint64_t));
+    uint64_t* d_hk = (uint64_t*)scratch("gp_hk", (nb + 1) * sizeof(uint64_t));
+    uint64_t* d_pos = (uint64_t*)scratch("g_pos", (nb + 1) * sizeof(uint64_t));
+    uint64_t* d_sorted = (uint64_t*)scratch("g_sorted", (nb + 1) * sizeof(uint64_t));
+    uint64_t* d_out = (uint64_t*)scratch("g_out", ng * n * sizeof(uint64_t));
+    uint32_t* d_cnt = (uint32_t*)scratch("g_cnt", ng * sizeof(uint32_t));
+    unsigned long long* d_keys = (unsigned long long*)scratch("gp_keys", ng * n * sizeof(uint64_t));
+    uint64_t* d_keys_sorted = (uint64_t*)scratch("gp_keys_sorted", ng * n * sizeof(uint64_t));
+    uint64_t* d_out2 = (uint64_t*)scratch("gp_out", ng * n * sizeof(uint64_t));
+    uint32_t* d_cnt2 = (uint32_t*)scratch("gp_cnt", ng * sizeof(uint32_t));
+    if (!d_bases || !d_off || !d_seg || !d_tag || !d_hk || !d_pos || !d_sorted || !d_out || !d_cnt || !d_keys || !d_keys_sorted ||
+        !d_out2 || !d_cnt2)
+      return MG_ERR_NOMEM;
+    if (nb) MG_HIP(hipMemcpyAsync(d_bases, bases + offsets[g0], nb, hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemcpyAsync(d_off, rel.data(), (ng + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemcpyAsync(d_seg, seg.data(), (ng + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const unsigned g256 = grid_for(nb ? nb : 1, 256, (unsigned)c.num_cus * 8);
+    if (nb) {
+      ProfScope ps("hash_positions");
+      const uint64_t nchunks = (nb + kChunk - 1) / kChunk;
+      const unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
+      MG_TRY(launch_hash_positions_cmash(kmax, grid, st, d_bases, d_off, ng, nb, d_tag, true));
+      MG_TRY(launch_hash_positions_cmash(k, grid, st, d_bases, d_off, ng, nb, d_hk, false));
+      hipLaunchKernelGGL(k_clear_tags, dim3(g256), dim3(256), 0, st, d_tag, nb, d_pos);
+      MG_HIP(hipGetLastError());
+    }
+    MG_TRY(segmented_sort_keys(d_pos, d_sorted, nb, d_off, ng));
+    hipLaunchKernelGGL(k_take_bottom_n, dim3(grid_for(ng, 1, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_sorted, d_off, ng, n,
+                       d_out, d_cnt);
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(ng * n, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+                       reinterpret_cast<uint64_t*>(d_keys), ng * n, kReservedHash);
+    if (nb)
+      hipLaunchKernelGGL(k_prefix_keys, dim3(g256), dim3(256), 0, st, d_tag, d_hk, d_off, ng, nb, d_out, d_cnt, n, kmax, k, d_keys);
+    MG_HIP(hipGetLastError());
+    // per genome: its keys ascending, distinct (unfilled slots hold the reserved value, which k_take_bottom_n skips)
+    MG_TRY(segmented_sort_keys(reinterpret_cast<uint64_t*>(d_keys), d_keys_sorted, ng * n, d_seg, ng));
+    hipLaunchKernelGGL(k_take_bottom_n, dim3(grid_for(ng, 1, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_keys_sorted, d_seg, ng,
+                       n, d_out2, d_cnt2);
+    MG_HIP(hipGetLastError());
+    h_slots.resize(ng * n);
+    h_cnt.resize(ng);
+    MG_HIP(hipMemcpyAsync(h_slots.data(), d_out2, ng * n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt2, ng * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < ng; ++i) {
+      for (uint32_t j = 0; j < h_cnt[i]; ++j) out_hashes[written + j] = h_slots[i * n + j];
+      written += h_cnt[i];
+      out_offsets[g0 + i + 1] = written;
+    }
+    g0 = g1;
+  }
+  return MG_OK;
 }
 
 int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,

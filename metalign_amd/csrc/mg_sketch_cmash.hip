@@ -20,10 +20,14 @@ int launch_sketch_reads_cmash(int k, unsigned grid, size_t lds, hipStream_t st, 
 }
 
 int launch_hash_positions_cmash(int k, unsigned grid, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nseq,
-                                uint64_t nbases, uint64_t* d_out) {
+                                uint64_t nbases, uint64_t* d_out, bool tagged) {
   const bool ok = dispatch_k(k, [&]<int K>() {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCmash>), dim3(grid), dim3(256), 0, st, d_bases, d_offsets, nseq, nbases,
-                       d_out);
+    if (tagged)  // the kept strand in bit 63 (the prefix-table builder, mg_sketch_genomes_prefix)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCmashTagged>), dim3(grid), dim3(256), 0, st, d_bases, d_offsets, nseq,
+                         nbases, d_out);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCmash>), dim3(grid), dim3(256), 0, st, d_bases, d_offsets, nseq, nbases,
+                         d_out);
   });
   return ok ? MG_OK : fail(MG_ERR_ARG, "unsupported k=%d", k);
 }

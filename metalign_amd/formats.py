@@ -90,6 +90,7 @@ class SketchTable:
         # which definition of a k-mer's hash the table was sketched with (include/metalign_hip.h: mg_set_hash_mode);
         # tables written before the field existed are mode 0
         self.hash_mode = int(self.meta.get("hash_mode", 0))
+        self.prefix_tables = bool(self.meta.get("prefix_tables", False))  # mode 1: k < k_max tables of k-prefixes (build_db)
         with open(os.path.join(path, "names.txt")) as fh:
             self.names = [ln.rstrip("\n") for ln in fh]
         self.ngenomes = len(self.names)
@@ -170,7 +171,7 @@ def _write_common(path, names):
             fh.write(nm + "\n")
 
 
-def write_sketch_table(path, names, ks, n, per_k, filters=None, hash_mode=0):
+def write_sketch_table(path, names, ks, n, per_k, filters=None, hash_mode=0, prefix_tables=False):
     """per_k: {k: (hashes u64[], offsets u64[G+1])} genome-major, as mg_sketch_genomes returns it; written hash-major.
     filters: optional {k: uint32 bit array} (Filter.download)."""
     _write_common(path, names)
@@ -181,7 +182,7 @@ def write_sketch_table(path, names, ks, n, per_k, filters=None, hash_mode=0):
         np.ascontiguousarray(gs, dtype="<u4").tofile(os.path.join(path, "k%d.gsize.u32" % k))
         if filters and filters.get(k) is not None:
             np.ascontiguousarray(filters[k], dtype="<u4").tofile(os.path.join(path, "k%d.filter.u32" % k))
-    meta = {"format": TABLE_FORMAT, "version": 2, "n": int(n), "ks": [int(k) for k in ks], "ngenomes": len(names), "hash_mode": int(hash_mode),
+    meta = {"format": TABLE_FORMAT, "version": 2, "n": int(n), "ks": [int(k) for k in ks], "ngenomes": len(names), "hash_mode": int(hash_mode), "prefix_tables": bool(prefix_tables),
             "layout": "hash-major pairs", "hash": "murmur3_x64_128.h1(canonical ASCII k-mer), seed 0"}
     with open(os.path.join(path, "meta.json"), "w") as fh:
         json.dump(meta, fh, indent=1)

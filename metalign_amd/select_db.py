@@ -399,6 +399,7 @@ def run_sketch_steps(args):
     if table_dir in (None, 'AUTO'):
         table_dir = formats.default_table_dir(args.data)
     table = formats.SketchTable(table_dir)
+    previous_mode = hip.hash_mode
     hip.set_hash_mode(table.hash_mode)  # the reads are hashed by the definition the table was sketched with
     min_count = int(getattr(args, 'min_count', 2))
     s = int(getattr(args, 'sketch_size', 0))
@@ -452,6 +453,7 @@ def run_sketch_steps(args):
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
     run_timings['containment_s'] = time.perf_counter() - t_start
+    hip.set_hash_mode(previous_mode)
     return out
 
 

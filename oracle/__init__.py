@@ -141,6 +141,22 @@ def sketch_genomes(bases, offsets, k, n):
     return h[: int(o[-1])].copy(), o
 
 
+def sketch_genomes_prefix(bases, offsets, kmax, k, n):
+    """The k < kmax table of hash mode 1: per genome the distinct mode-1 hashes of the k-prefixes of its sketched kmax-mers
+    (oracle/mg_oracle.c: mgo_sketch_genomes_prefix).  -> (hashes u64[*], offsets u64[G+1])."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    g = len(offsets) - 1
+    h = np.zeros(max(g * n, 1), dtype=np.uint64)
+    o = np.zeros(g + 1, dtype=np.uint64)
+    rc = lib().mgo_sketch_genomes_prefix(_p(bases, ctypes.c_uint8), _p(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                                         ctypes.c_int(kmax), ctypes.c_int(k), ctypes.c_uint64(n), _p(h, ctypes.c_uint64),
+                                         _p(o, ctypes.c_uint64))
+    if rc != 0:
+        raise RuntimeError("mgo_sketch_genomes_prefix rc=%d" % rc)
+    return h[: int(o[-1])].copy(), o
+
+
 def containment(q_hashes, q_counts, q_truncated, ci, db_hashes, db_offsets):
     """-> (hits u32[G], sizes u32[G])."""
     q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)

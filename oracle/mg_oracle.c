@@ -248,6 +248,68 @@ int mgo_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t n
   return MG_OK;
 }
 
+/* The k < k_max tables of hash mode 1 (CMash as SURVEY.md §8(c) recollects it: the smaller-k columns are containments of
+ * the k-PREFIXES of the sketched k_max-mers, stored in a ternary search tree; UNVERIFIED like the rest of the mode).  Per
+ * genome: the bottom-n sketch at k_max under mode 1; every sketched k_max-mer oriented as CMash's CountEstimator.add keeps
+ * it (the strand whose hash is the smaller one; the reverse complement on a tie); its first k bases; the key of that
+ * k-prefix = its own mode-1 hash (symmetric in the strand, so a read k-mer matches the prefix or its reverse complement, as
+ * the streaming query does); the genome's table entry for k = its DISTINCT keys, ascending.  Two different k_max-mers with
+ * the same hash value (a collision modulo the prime) share one sketch slot: the smaller key is kept.  The mode in force
+ * does not matter to this function (it is mode 1 by definition). */
+typedef struct { uint64_t h, key; } hk_pair;
+static int cmp_hk(const void* a, const void* b) {
+  const hk_pair* x = (const hk_pair*)a; const hk_pair* y = (const hk_pair*)b;
+  if (x->h != y->h) return x->h < y->h ? -1 : 1;
+  return x->key < y->key ? -1 : (x->key > y->key ? 1 : 0);
+}
+int mgo_sketch_genomes_prefix(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int kmax, int k, uint64_t n,
+                              uint64_t* out_hashes, uint64_t* out_offsets) {
+  if (k < 1 || k > kmax || kmax > MG_MAX_K) return MG_ERR_ARG;
+  const int saved = g_hash_mode;
+  uint64_t w = 0;
+  out_offsets[0] = 0;
+  for (uint64_t g = 0; g < ngenomes; ++g) {
+    const uint8_t* seq = bases + offsets[g];
+    const uint64_t len = offsets[g + 1] - offsets[g];
+    hk_pair* v = (hk_pair*)malloc((len + 1) * sizeof(hk_pair));
+    if (!v) return MG_ERR_NOMEM;
+    uint64_t nv = 0, run = 0;
+    for (uint64_t j = 0; j < len; ++j) {
+      run = base_code(seq[j]) >= 0 ? run + 1 : 0;
+      if (run < (uint64_t)kmax) continue;
+      const uint8_t* win = seq + (j + 1 - (uint64_t)kmax);
+      char fwd[MG_MAX_K], rc[MG_MAX_K];
+      for (int i = 0; i < kmax; ++i) {
+        int c = base_code(win[i]);
+        fwd[i] = kUpper[c];
+        rc[kmax - 1 - i] = kUpper[3 - c];
+      }
+      uint64_t o[2], hf, hr;
+      mgo_murmur3_x64_128(fwd, kmax, 0, o); hf = o[0];
+      mgo_murmur3_x64_128(rc, kmax, 0, o); hr = o[0];
+      const char* kept = hr <= hf ? rc : fwd;  /* CountEstimator.add: `if h == h2: kmer = rc` */
+      g_hash_mode = 1;
+      v[nv].h = (hf < hr ? hf : hr) % MGO_CMASH_PRIME;
+      v[nv].key = canonical_hash((const uint8_t*)kept, k);  /* the k-prefix of the kept strand, hashed under mode 1 */
+      g_hash_mode = saved;
+      ++nv;
+    }
+    if (nv) qsort(v, nv, sizeof(hk_pair), cmp_hk);
+    uint64_t* keys = (uint64_t*)malloc((n + 1) * sizeof(uint64_t));
+    if (!keys) { free(v); return MG_ERR_NOMEM; }
+    uint64_t kept_n = 0;
+    for (uint64_t i = 0; i < nv && kept_n < n; ++i)
+      if (i == 0 || v[i].h != v[i - 1].h) keys[kept_n++] = v[i].key;  /* first of a run of equal h: the smallest key */
+    free(v);
+    if (kept_n) qsort(keys, kept_n, sizeof(uint64_t), cmp_u64);
+    for (uint64_t i = 0; i < kept_n; ++i)
+      if (i == 0 || keys[i] != keys[i - 1]) out_hashes[w++] = keys[i];
+    free(keys);
+    out_offsets[g + 1] = w;
+  }
+  return MG_OK;
+}
+
 /* Stage B.  See include/metalign_hip.h (mg_containment). */
 int mgo_containment(const uint64_t* q_hashes, const uint32_t* q_counts, uint64_t qn,
                     int q_truncated, uint32_t ci, const uint64_t* db_hashes,

@@ -124,6 +124,29 @@ def sketch_genome(seq: bytes, k: int, n: int):
     return sorted(hs)[:n]
 
 
+def sketch_genome_prefix(seq: bytes, kmax: int, k: int, n: int):
+    """The k < kmax table entry of one genome under hash mode 1: sketch the genome at kmax keeping, per hash
+    value, the k-mer as CMash's CountEstimator.add keeps it (the strand with the smaller hash, the reverse complement on a
+    tie); the table holds the distinct mode-1 hashes of the first k bases of those k-mers.  Written from the prose, on Python
+    strings and dicts; independent of HASH_MODE."""
+    best = {}  # hash value -> smallest prefix key among the kmax-mers that have it
+    for m in _RUNS.finditer(seq):
+        run = m.group().upper()
+        for i in range(len(run) - kmax + 1):
+            kmer = run[i:i + kmax]
+            rc = kmer.translate(_COMP)[::-1]
+            hf, hr = murmur3_x64_128(kmer, 0)[0], murmur3_x64_128(rc, 0)[0]
+            kept = rc if hr <= hf else kmer
+            pre = kept[:k]
+            prc = pre.translate(_COMP)[::-1]
+            key = min(murmur3_x64_128(pre, 0)[0], murmur3_x64_128(prc, 0)[0]) % CMASH_PRIME
+            h = min(hf, hr) % CMASH_PRIME
+            if h not in best or key < best[h]:
+                best[h] = key
+    chosen = [best[h] for h in sorted(best)[:n]]
+    return sorted(set(chosen))
+
+
 def containment(sketch_items, truncated, ci, genome_sketches):
     """-> [(hits, size)] per genome: size = genome hashes <= bound, hits = those present in the sample at count >= ci."""
     bound = sketch_items[-1][0] if (truncated and sketch_items) else M64

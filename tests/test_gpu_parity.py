@@ -599,3 +599,42 @@ def test_cmash_recollection_mode_matches_the_oracle(hip, oracle_lib, cmash_mode)
     h0, _, _, _ = hip.sketch_reads(rb, ro, 21)
     hip.set_hash_mode(1)
     assert len(h0) == len(h1) and not np.array_equal(h0, h1)
+
+
+def test_cmash_prefix_tables_match_the_oracle(hip, oracle_lib, cmash_mode):
+    """The k < k_max tables of hash mode 1 — the k-prefixes of the sketched k_max-mers (mg_sketch_genomes_prefix) — against
+    the oracle, and a query against them: every read k-mer is a candidate there (the table's largest key is near the prime),
+    the membership filter does the rejecting, and the containment counts equal the oracle's."""
+    rng = np.random.default_rng(777)
+    gb, go = util.random_genomes(rng, 10, 3000, with_n=True)
+    n = 120
+    for kmax, ks in ((60, [30, 40, 50]), (51, [21, 31]), (33, [32]), (64, [1, 64])):
+        for k in ks:
+            h, o = hip.sketch_genomes_prefix(gb, go, kmax, k, n)
+            oh, oo = oracle_lib.sketch_genomes_prefix(gb, go, kmax, k, n)
+            assert np.array_equal(h, oh) and np.array_equal(o, oo), (kmax, k)
+    # the stock query shape: K = {30,40,50,60}, prefix tables for 30 / 40 / 50, the sketch itself at 60
+    ks, kmax = [30, 40, 50, 60], 60
+    tabs = [hip.sketch_genomes_prefix(gb, go, kmax, k, n) if k < kmax else hip.sketch_genomes(gb, go, k, n) for k in ks]
+    want_last = oracle_lib.sketch_genomes(gb, go, kmax, n)
+    assert np.array_equal(tabs[-1][0], want_last[0])
+    rb, ro, _ = util.sample_reads(rng, gb, go, 6000, 150, lower=True, present=[1, 6])
+    d_b, d_o = hip.array(rb), hip.array(ro)
+    hmaxs = [int(t[0].max()) for t in tabs]
+    assert hmaxs[0] > oracle_lib.CMASH_PRIME // 2 > hmaxs[-1]  # prefix keys are not bottom-n values: no threshold to speak of
+    filts = [hip.filter_build(t[0]) for t in tabs]
+    sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, len(ro) - 1, ks, hmaxs, 0, filts)
+    for k, sk, (dbh, dbo), hm in zip(ks, sks, tabs, hmaxs):
+        sk.resolve()
+        qh, qc = sk.download()
+        oh, oc, otr, _ = oracle_lib.sketch_reads_filtered(rb, ro, k, dbh, hmax=hm)
+        assert np.array_equal(qh, oh) and np.array_equal(qc, oc), k
+        table = hip.upload_table(dbh, dbo)
+        hits, sizes = hip.containment(sk, table, 2)
+        ohits, osizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
+        assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes), k
+        assert hits[1] > 0.5 * sizes[1] and hits[6] > 0.5 * sizes[6] and hits[0] < 0.2 * max(sizes[0], 1)
+        table.free()
+        sk.free()
+    d_b.free()
+    d_o.free()

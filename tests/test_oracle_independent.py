@@ -145,3 +145,23 @@ def test_the_cmash_recollection_is_what_its_words_say(oracle_lib):
         oracle_lib.set_hash_mode(0)
     h0, _ = oracle_lib.kmer_hashes(kmer, 21)
     assert int(h0[0]) == a and a != min(a, b) % ind.CMASH_PRIME  # (ACGTT... < CGGGT...: mode 0 hashes the forward strand)
+
+
+@pytest.mark.parametrize("kmax,k", [(60, 30), (51, 21), (33, 32), (21, 21), (9, 4)])
+def test_prefix_tables_of_the_cmash_recollection(oracle_lib, kmax, k):
+    """The k < k_max tables of hash mode 1 (k-prefixes of the sketched k_max-mers): C oracle == independent restatement;
+    with k == k_max the table is the mode-1 sketch itself."""
+    rng = np.random.default_rng(31 * kmax + k)
+    genomes = _reads(rng, 5, 900, 1600, p_n=0.003, p_lower=0.05) + [b"ACGT" * 4, b"A" * 200]
+    n = 90
+    gb, go = _flat(genomes)
+    h, o = oracle_lib.sketch_genomes_prefix(gb, go, kmax, k, n)
+    for g, seq in enumerate(genomes):
+        assert [int(x) for x in h[int(o[g]):int(o[g + 1])]] == ind.sketch_genome_prefix(seq, kmax, k, n), g
+    if k == kmax:
+        oracle_lib.set_hash_mode(1)
+        try:
+            dbh, dbo = oracle_lib.sketch_genomes(gb, go, kmax, n)
+        finally:
+            oracle_lib.set_hash_mode(0)
+        assert np.array_equal(h, dbh) and np.array_equal(o, dbo)

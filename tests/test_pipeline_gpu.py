@@ -257,3 +257,60 @@ def test_bench_command_of_the_driver_at_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 200000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
+
+
+def test_select_main_on_a_cmash_mode_table_with_prefix_columns(hip, oracle_lib, tmp_path):
+    """build_db --hash_mode cmash --prefix_tables, then select_main on it: the table records its mode, the reads are hashed by
+    the same definition, and the CSV equals what the oracle computes under that definition (mode-1 sketch at k_max, k-prefix
+    tables below it; DESIGN.md §2 — CMash as recollected, unverified)."""
+    from metalign_amd import build_db, formats, select_db
+    rng = np.random.default_rng(99)
+    data, gb, go, names, accs = _make_data_dir(tmp_path, rng)
+    ks, n = [21, 31, 41], 120
+    paths = [str(data / "organism_files" / nm) for nm in names]
+    build_db.build(paths, str(data / "sketch_table"), ks, n, hash_mode=1, prefix_tables=True)
+    assert hip.hash_mode == 0  # (the builder puts the library's mode back)
+    table = formats.SketchTable(str(data / "sketch_table"))
+    assert table.hash_mode == 1 and table.prefix_tables
+    # the same contigs as the builder sketches them: joined by 'N'
+    joined, offs = [], [0]
+    for g in range(len(names)):
+        s = gb[int(go[g]):int(go[g + 1])]
+        half = len(s) // 2
+        j = np.concatenate([s[:half], np.frombuffer(b"N", np.uint8), s[half:]])
+        joined.append(j)
+        offs.append(offs[-1] + len(j))
+    jb, jo = np.concatenate(joined), np.asarray(offs, dtype=np.uint64)
+    oracle_lib.set_hash_mode(1)
+    try:
+        want_tabs = [oracle_lib.sketch_genomes_prefix(jb, jo, ks[-1], k, n) if k < ks[-1] else oracle_lib.sketch_genomes(jb, jo, k, n) for k in ks]
+        for k, (oh, oo) in zip(ks, want_tabs):
+            h, o = table.arrays(k)
+            assert np.array_equal(np.asarray(h), oh) and np.array_equal(o, oo), k
+        rb, ro, src = util.sample_reads(rng, gb, go, 3000, 150, err=0.005, present=[3, 8])
+        fq = tmp_path / "sample.fq"
+        with open(fq, "w") as fh:
+            for i in range(len(ro) - 1):
+                s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
+                fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+        tmpd = tmp_path / "tmp"
+        args = select_db.select_parseargs([str(fq), str(data), "--temp_dir", str(tmpd), "--keep_temp_files", "--sketch_table",
+                                           str(data / "sketch_table")])
+        select_db.select_main(args)
+        csv = (tmpd / "cmash_query_results.csv").read_text().splitlines()
+        assert csv[0] == ",k=21,k=31,k=41"
+        per_k = []
+        for k, (oh, oo) in zip(ks, want_tabs):
+            qh, qc, tr, _ = oracle_lib.sketch_reads_filtered(rb, ro, k, oh, hmax=int(oh.max()))
+            hits, sizes = oracle_lib.containment(qh, qc, tr, 2, oh, oo)
+            per_k.append(hits / np.maximum(sizes, 1))
+    finally:
+        oracle_lib.set_hash_mode(0)
+        hip.set_hash_mode(0)
+    got = {ln.split(",")[0]: [float(x) for x in ln.split(",")[1:]] for ln in csv[1:]}
+    for g, nm in enumerate(names):
+        if per_k[0][g] > 0:
+            assert got[nm] == [float(c[g]) for c in per_k], nm
+        else:
+            assert nm not in got
+    assert csv[1].split(",")[0] in (names[3], names[8])
