@@ -244,6 +244,16 @@ int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out);
 int mg_filter_download(const mg_filter* f, uint32_t* bits, uint64_t nbytes);
 int mg_filter_from_bits(const uint32_t* bits, unsigned log2_bits, mg_filter** out);
 unsigned mg_filter_log2_bits(const mg_filter* f);
+/* The RESIDENT INDEX of a table whose largest hash filters little (genomes of a few kb, or viruses beside bacteria: the
+ * bloom pre-filter's other job, scripts/select_db.py:70,75): a counting table seeded ONCE with every hash of the table
+ * (hashes[0..n), duplicates welcome, all <= hmax) and never cleared — counters carry the epoch of the sketch call that
+ * wrote them.  Sketch calls given this filter then cost a candidate ONE random 16-byte access (found: counted; not
+ * found: not a hash of the table, dropped) instead of a home slot plus a filter word, and no table clear; the sketch
+ * holds exactly the read k-mers that are hashes of the table (the bit filter lets ~6 % of the others through), so
+ * containment is unchanged.  16 bytes x 2 to 4 slots per hash, once per stream that sketches with it.
+ * MG_ERR_CAPACITY: the hashes crowd some range (a bucket without a free slot) — the filter stays a bit filter. */
+int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, uint64_t hmax);
+uint64_t mg_filter_resident_bytes(const mg_filter* f);
 void mg_filter_free(mg_filter* f);
 int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
                                  uint64_t nreads, int k, uint64_t hmax, uint64_t s,

@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
-    "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_free",
+    "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_resident_bytes", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_sketch_stream_begin", "mg_sketch_stream_add_dev", "mg_sketch_stream_add_file", "mg_sketch_stream_finish", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases", "mg_sketch_stream_free",
@@ -87,6 +87,7 @@ def load_library(path=LIB_PATH):
     lib.mg_sketch_stream_free.restype = None
     lib.mg_filter_free.restype = None
     lib.mg_filter_log2_bits.restype = ctypes.c_uint
+    lib.mg_filter_resident_bytes.restype = ctypes.c_uint64
     lib.mg_count_saturation.restype = ctypes.c_uint32
     lib.mg_db_free.restype = None
     lib.mg_profile_free.restype = None
@@ -405,6 +406,22 @@ class Filter:
         bits = np.empty((1 << self.log2_bits) // 32, dtype=np.uint32)
         self.hip._chk(self.hip.lib.mg_filter_download(self.handle, _np(bits, ctypes.c_uint32), ctypes.c_uint64(bits.nbytes)))
         return bits
+
+    def make_resident(self, hashes, hmax):
+        """Seed the table's RESIDENT INDEX from all its hashes (mg_filter_make_resident): sketch calls given this filter then
+        count in it — one random access per candidate, no filter word, no table clear.  False when the hashes crowd some
+        range (the filter stays a bit filter); raises on anything else."""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        rc = self.hip.lib.mg_filter_make_resident(self.handle, _np(hashes if hashes.size else np.zeros(1, np.uint64), ctypes.c_uint64),
+                                                  ctypes.c_uint64(hashes.size), ctypes.c_uint64(int(hmax)))
+        if rc == ERR_CAPACITY:
+            return False
+        self.hip._chk(rc)
+        return True
+
+    @property
+    def resident_bytes(self):
+        return int(self.hip.lib.mg_filter_resident_bytes(self.handle))
 
     def free(self):
         if self.handle:

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -55,6 +56,8 @@ struct Context {
   uint32_t count_sat = 3;
   // which definition of a k-mer's hash the stage-A / A' kernels compute (mg_set_hash_mode; mg_kmer.h)
   int hash_mode = 0;
+  // the last epoch handed to a call that counts in a resident index (mg_filter::Resident): unique across filters and copies
+  uint32_t resident_epoch = 0;
   // profiling
   bool prof_on = false;
   char prof_only[32] = "";  // when set, only this kernel family is timed (keeps the timed region light)
@@ -219,7 +222,7 @@ struct mg_sketch {
   struct Redo {            // what rebuilds the sketch on the list path if the counting table overflowed
     const uint8_t* bases = nullptr;
     const uint64_t* offsets = nullptr;
-    uint64_t nreads = 0, hmax = 0, s = 0, cap = 0;
+    uint64_t nreads = 0, hmax = 0, s = 0, cap = 0, nbases = 0;
     int k = 0;
     unsigned stage = 0;
     const mg_filter* filter = nullptr;
@@ -241,6 +244,9 @@ struct MultiKTable {  // one k of the launch: its threshold, counting table (alr
   unsigned long long* counters;
   unsigned shift;
   const mg_filter* filter;
+  uint32_t epoch = 0;  // != 0: tab is a copy of the filter's resident index and this the epoch of the call
+  uint64_t* list = nullptr;  // ... and the list the kernel leaves the touched hashes in (filled with kReservedHash)
+  uint64_t listcap = 0;
 };
 // mg_sketch_cmash.hip: the one-k kernels instantiated for hash definition 1 (mg_set_hash_mode)
 int launch_sketch_reads_cmash(int k, unsigned grid, size_t lds, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets,
@@ -289,6 +295,19 @@ struct mg_filter {
   mg::DevBuf bits;      // u32[nbits / 32]
   uint64_t mask = 0;    // nbits - 1
   unsigned log2_bits = 0;
+  // Optional RESIDENT INDEX over the same hashes (mg_filter_make_resident; mg_sketch_dev.h: resident_count): a counting
+  // table seeded once with every hash and never cleared, its counters tagged with the epoch of the call that wrote them.
+  // A read sketch made with it holds exactly the read k-mers that ARE hashes of the table (the bit filter lets ~6 % of
+  // the others through); containment is the same either way.  One copy per stream that sketches with it (the counters of
+  // two passes in flight on two streams must not share slots), made on first use.
+  struct Resident {
+    unsigned shift = 0;
+    uint64_t nbuckets = 0, slots = 0, distinct = 0, hmax = 0;
+    struct Copy { hipStream_t stream = nullptr; void* slots = nullptr; };
+    std::vector<Copy> copies;  // [0]: the seeded one
+    ~Resident();
+  };
+  mutable std::unique_ptr<Resident> resident;
 };
 
 struct mg_db {

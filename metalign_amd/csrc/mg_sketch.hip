@@ -31,6 +31,7 @@
 #include "mg_sketch_kernel.h"
 
 // (defined with the merge entry points below; sketch_resolve redoes a deferred merge with it)
+static int redo_resident(mg_sketch* sk);
 static int merge_via_sort(mg_sketch* sk, const uint64_t* d_hashes, const uint32_t* d_counts, uint64_t n, uint64_t s,
                           int any_truncated, uint64_t bound);
 
@@ -225,6 +226,159 @@ __global__ __launch_bounds__(256) void k_bucket_compact(const Slot* __restrict__
   }
 }
 
+// ---- resident index (mg_filter_make_resident) ----
+// Seed: every hash gets its slot (key = hash + 1; counter 0, epoch 0).  counters[0] += distinct hashes placed,
+// counters[1] += hashes without a slot (outside the range, or a full bucket: the index is then not built).
+__global__ void k_index_seed(const uint64_t* __restrict__ hashes, uint64_t n, unsigned shift, uint64_t nbuckets,
+                             Slot* __restrict__ tab, unsigned long long* __restrict__ counters) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t placed = 0, lost = 0;
+  for (; i < n; i += stride) {
+    const uint64_t h = hashes[i];
+    const uint64_t b = h >> shift;
+    if (b >= nbuckets || h == kReservedHash) { ++lost; continue; }
+    // its home slot or the first free one after it; a hash that is not at home leaves kMovedOn there (mg_sketch_dev.h)
+    const unsigned long long v = h + 1;
+    const uint64_t base = b * kBucketSlots;
+    const uint32_t home = (uint32_t)h & (kBucketSlots - 1);
+    uint32_t t = 0;
+    for (; t <= kMaxHops; ++t) {
+      const unsigned long long old = atomicCAS(&tab[base + ((home + t) & (kBucketSlots - 1))].key, 0ull, v);
+      if (old == 0ull) { ++placed; break; }
+      if (old == v) break;  // the same hash in another genome's sketch
+    }
+    if (t > kMaxHops) ++lost;
+    else if (t > 0) atomicOr(&tab[base + home].cnt, kMovedOn);
+  }
+  if (placed) atomicAdd(counters, (unsigned long long)placed);
+  if (lost) atomicAdd(counters + 1, (unsigned long long)lost);
+}
+
+// A slot of a resident index counts in this pass: seeded, written in this epoch.
+__device__ __forceinline__ bool resident_live(const uint4& raw, uint32_t epoch) {
+  return (raw.x | raw.y) != 0u && raw.w == epoch && (raw.z & ~kMovedOn) != 0u;
+}
+
+// nuniq[b] = slots of bucket b that count in this pass (one wavefront per bucket).
+__global__ __launch_bounds__(256) void k_resident_count(const Slot* __restrict__ tab, uint64_t nbuckets, uint32_t epoch,
+                                                        uint32_t* __restrict__ nuniq) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t b = gwave; b < nbuckets; b += nwaves) {
+    uint4 raw[kBucketSlots / 64];
+#pragma unroll
+    for (uint32_t c = 0; c < kBucketSlots / 64; ++c) raw[c] = *reinterpret_cast<const uint4*>(tab + b * kBucketSlots + c * 64 + lane);
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kBucketSlots / 64; ++c) n += __popcll(__ballot(resident_live(raw[c], epoch)));
+    if (lane == 0) nuniq[b] = n;
+  }
+}
+
+// k_bucket_sort for a resident index: the slots stay where they are (the next pass finds them there); the bucket's
+// live (hash, count) pairs are sorted in LDS and written straight to their place in the sketch (offs from
+// k_resident_count + k_bucket_scan).
+__global__ __launch_bounds__(256) void k_resident_sort_out(const Slot* __restrict__ tab, uint64_t nbuckets, uint32_t epoch,
+                                                           const uint64_t* __restrict__ offs, uint32_t cs,
+                                                           uint64_t* __restrict__ out_hashes, uint32_t* __restrict__ out_counts,
+                                                           uint64_t out_cap) {
+  __shared__ uint64_t s_keys[4][kBucketSlots];
+  __shared__ uint32_t s_cnt[4][kBucketSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t* keys = s_keys[wave];
+  uint32_t* cnt = s_cnt[wave];
+  const uint64_t gwave = (uint64_t)blockIdx.x * 4 + wave, nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t b = gwave; b < nbuckets; b += nwaves) {
+    uint4 raw[kBucketSlots / 64];
+#pragma unroll
+    for (uint32_t c = 0; c < kBucketSlots / 64; ++c) raw[c] = *reinterpret_cast<const uint4*>(tab + b * kBucketSlots + c * 64 + lane);
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kBucketSlots / 64; ++c) {
+      const bool live = resident_live(raw[c], epoch);
+      const unsigned long long m = __ballot(live);
+      if (live) {
+        const uint32_t d = n + __popcll(m & ((1ull << lane) - 1ull));
+        keys[d] = ((uint64_t)raw[c].x | ((uint64_t)raw[c].y << 32)) - 1;
+        const uint32_t seen = raw[c].z & ~kMovedOn;
+        cnt[d] = (cs && seen > cs) ? cs : seen;
+      }
+      n += __popcll(m);
+    }
+    if (n == 0) continue;
+    uint32_t N = 64;
+    while (N < n) N <<= 1;
+    for (uint32_t i = n + lane; i < N; i += 64) keys[i] = kReservedHash;
+    wave_lds_sync();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = lane; t < N / 2; t += 64) {
+          const uint32_t ix = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const uint32_t px = ix | j;
+          const uint64_t x = keys[ix], y = keys[px];
+          const bool up = (ix & k) == 0;
+          if ((x > y) == up) {
+            keys[ix] = y; keys[px] = x;
+            const uint32_t cx = cnt[ix], cy = cnt[px];
+            cnt[ix] = cy; cnt[px] = cx;
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+    const uint64_t o = offs[b];
+    for (uint32_t i = lane; i < n && o + i < out_cap; i += 64) { out_hashes[o + i] = keys[i]; out_counts[o + i] = cnt[i]; }
+    wave_lds_sync();
+  }
+}
+
+// ---- ... and the sketch from the LIST of hashes the pass touched (mg_sketch_dev.h: resident_list_append), sorted ----
+// An entry counts if it is a hash (the unused part of the list is kReservedHash, sorted to the end) and differs from its
+// predecessor (two lanes may have listed one hash).  nuniq[b] = such entries among the 256 of block b.
+__device__ __forceinline__ bool list_entry_counts(const uint64_t* __restrict__ sorted, uint64_t n, uint64_t i) {
+  if (i >= n) return false;
+  const uint64_t h = sorted[i];
+  return h != kReservedHash && (i == 0 || sorted[i - 1] != h);
+}
+__global__ __launch_bounds__(256) void k_list_count(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t* __restrict__ nuniq) {
+  __shared__ uint32_t s_n[4];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(list_entry_counts(sorted, n, i));
+  if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) nuniq[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+// ... written to its place in the sketch with its counter out of the index (found where the kernel found it: home slot,
+// or the slots after it).
+__global__ __launch_bounds__(256) void k_list_gather(const uint64_t* __restrict__ sorted, uint64_t n, const uint64_t* __restrict__ offs,
+                                                     const Slot* __restrict__ tab, unsigned shift, uint32_t epoch, uint32_t cs,
+                                                     uint64_t* __restrict__ out_hashes, uint32_t* __restrict__ out_counts,
+                                                     uint64_t out_cap) {
+  __shared__ uint32_t s_n[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool mine = list_entry_counts(sorted, n, i);
+  const unsigned long long m = __ballot(mine);
+  if (lane == 0) s_n[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (!mine) return;
+  uint64_t at = offs[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) at += s_n[w];
+  if (at >= out_cap) return;  // (reported by k_sketch_meta's cap)
+  const uint64_t h = sorted[i];
+  const Slot* bucket = tab + (h >> shift) * kBucketSlots;
+  uint32_t seen = 0;
+  for (uint32_t t = 0; t <= kMaxHops; ++t) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(bucket + (((uint32_t)h + t) & (kBucketSlots - 1)));
+    const unsigned long long key = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
+    if (key == h + 1) { seen = raw.w == epoch ? raw.z & ~kMovedOn : 0u; break; }
+    if (key == 0ull) break;
+  }
+  out_hashes[at] = h;
+  out_counts[at] = (cs && seen > cs) ? cs : seen;
+}
+
 __global__ void k_sketch_split(const uint64_t* __restrict__ hashes, uint64_t n, const uint64_t* __restrict__ bounds,
                                uint32_t nbounds, uint64_t* __restrict__ out_idx) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,7 +461,8 @@ static int adopt_runs(mg_sketch* sk, uint64_t* d_meta, uint64_t s, bool use_boun
 template <int K>
 static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t hmax,
                                uint64_t* d_cand, uint64_t cap, unsigned long long* d_counters, Slot* d_tab,
-                               unsigned bucket_shift, unsigned stage_bytes, const mg_filter* filter = nullptr) {
+                               unsigned bucket_shift, unsigned stage_bytes, const mg_filter* filter = nullptr,
+                               uint32_t epoch = 0) {
   Context& c = ctx();
   size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
   if (const char* pad = getenv("MG_DEBUG_LDS_PAD")) lds += (size_t)atol(pad);  // occupancy experiments only
@@ -323,8 +478,9 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
-  const uint32_t* fb = filter ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr;
-  const uint64_t fm = filter ? filter->mask : 0ull;
+  // (epoch != 0: d_tab is a resident index — the kernel takes "no filter words, a mask" as that and the mask as the epoch)
+  const uint32_t* fb = filter && !epoch ? filter->bits.as<uint32_t>() : (const uint32_t*)nullptr;
+  const uint64_t fm = epoch ? (uint64_t)epoch : (filter ? filter->mask : 0ull);
   if (c.hash_mode == kHashCmash)  // (instantiated in mg_sketch_cmash.hip)
     MG_TRY(launch_sketch_reads_cmash(K, grid, lds, c.stream, d_bases, d_offsets, nreads, hmax, d_cand, cap, d_counters, d_tab,
                                      bucket_shift, stage_bytes, fb, fm, stage_a_cs_word()));
@@ -343,6 +499,9 @@ struct TablePlan {
   Slot* tab = nullptr;        // [slots]: key = hash + 1 (0 = empty) and its counter
   uint32_t* nuniq = nullptr;
   uint64_t* offs = nullptr;
+  uint32_t epoch = 0;         // != 0: tab is a resident index (seeded, never cleared; live slots carry this epoch)
+  uint64_t* list = nullptr;   // ... and the kernel lists the hashes it touches here (listcap entries, kReservedHash = unused)
+  uint64_t listcap = 0;
 };
 
 // Buckets of ~kBucketTarget expected distinct hashes over the key range [lo, hi]; false when the range or the
@@ -396,6 +555,44 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint
   Context& c = ctx();
   hipStream_t st = c.stream;
   if (cap > tp.slots) cap = tp.slots;  // a sketch cannot outgrow the table
+  if (tp.epoch && tp.list) {
+    // the sketch = the listed hashes in order, once each, with their counters: the work is the pass's distinct hashes',
+    // not the table's (a sample covers a few per cent of a 200k-genome table: 1.7 against 15 ms for three k)
+    MG_TRY(sk->hashes.alloc((cap + 1) * sizeof(uint64_t)));
+    MG_TRY(sk->counts.alloc((cap + 1) * sizeof(uint32_t)));
+    const uint64_t nblocks = (tp.listcap + 255) / 256;
+    uint64_t* sorted = (uint64_t*)scratch("sk_rsorted", tp.listcap * sizeof(uint64_t));
+    uint32_t* nuniq = (uint32_t*)scratch("sk_rlist_n", nblocks * sizeof(uint32_t));
+    uint64_t* offs = (uint64_t*)scratch("sk_rlist_off", (nblocks + 1) * sizeof(uint64_t));
+    if (!sorted || !nuniq || !offs) return MG_ERR_NOMEM;
+    {
+      ProfScope ps("bucket_sort");
+      MG_TRY(sort_keys(tp.list, sorted, tp.listcap, 64));
+    }
+    ProfScope ps("bucket_pack");
+    hipLaunchKernelGGL(k_list_count, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, tp.listcap, nuniq);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, nuniq, nblocks, offs, d_meta);
+    hipLaunchKernelGGL(k_list_gather, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, tp.listcap, offs, tp.tab, tp.shift, tp.epoch,
+                       c.count_sat, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), cap);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+  }
+  if (tp.epoch) {  // (MG_DEBUG_RESIDENT_SCAN: the same sketch from a walk over every slot of the index)
+    const unsigned grid = grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8);
+    MG_TRY(sk->hashes.alloc((cap + 1) * sizeof(uint64_t)));
+    MG_TRY(sk->counts.alloc((cap + 1) * sizeof(uint32_t)));
+    {
+      ProfScope ps("bucket_sort");
+      hipLaunchKernelGGL(k_resident_count, dim3(grid), dim3(256), 0, st, tp.tab, tp.nbuckets, tp.epoch, tp.nuniq);
+      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, tp.nuniq, tp.nbuckets, tp.offs, d_meta);
+      MG_HIP(hipGetLastError());
+    }
+    ProfScope ps("bucket_pack");
+    hipLaunchKernelGGL(k_resident_sort_out, dim3(grid), dim3(256), 0, st, tp.tab, tp.nbuckets, tp.epoch, tp.offs, c.count_sat,
+                       sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), cap);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+  }
   {
     ProfScope ps("bucket_sort");
     hipLaunchKernelGGL(k_bucket_sort, dim3(grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8)), dim3(256), 0, st, tp.tab,
@@ -545,6 +742,13 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   sk->index.release();
   sk->hashes.release();
   sk->counts.release();
+  if (sk->redo.filter && sk->redo.filter->resident && !getenv("MG_DEBUG_NO_RESIDENT")) {
+    // made against a resident index, whose sketch is the exact intersection (the list path's filter lets ~6 % of the
+    // other hashes through): the list of touched hashes, or the sketch's buffers, were too small — again, with room for
+    // every hash of the index (the hint has just been reset)
+    StreamGuard guard(sk->ev_stream ? sk->ev_stream : c.stream, c.is_stage_a(sk->ev_stream) ? c.stage_a_prefix(sk->ev_stream) : c.scratch_prefix);
+    return ::redo_resident(sk);
+  }
   uint64_t cap = sk->redo.cap;
   if (candidates + 64 > cap) cap = candidates + 64;
   // (the rebuild is synchronous on the stream that built the sketch)
@@ -556,6 +760,11 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
 }
 
 }  // namespace mg
+
+mg_filter::Resident::~Resident() {
+  for (auto& cp : copies)
+    if (cp.slots) (void)hipFree(cp.slots);  // (synchronises the device: nothing is still counting in them afterwards)
+}
 
 mg_sketch::~mg_sketch() {
   mg::Context& c = mg::ctx();
@@ -635,6 +844,97 @@ static void plan_k(const ReadPlan& rp, int k, uint64_t hmax, KPlan& kp) {
   kp.table = !force_list && kp.expect >= 32768 && plan_table(0, hmax, kp.distinct_est, kp.tp);
 }
 
+// A call that sketches against the filter's RESIDENT INDEX (mg_internal.h: mg_filter::Resident): no table to size or
+// clear — this stream's copy of the seeded slots (made on its first use: two passes in flight on two streams must not
+// count in the same slots) and an epoch nobody has used on any copy.  The threshold is the table's own largest hash at
+// most: nothing above it can be in the index, whose buckets end there.
+static uint32_t next_resident_epoch() {
+  Context& c = ctx();
+  if (++c.resident_epoch == 0) ++c.resident_epoch;  // (0 = "not resident"; a wrap after 2^32 passes is not handled)
+  return c.resident_epoch;
+}
+static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t hmax, uint32_t epoch, KPlan& kp,
+                         unsigned long long** t_counters, int ki, bool full = false) {
+  mg_filter::Resident& R = *f->resident;
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  void* slots = nullptr;
+  for (auto& cp : R.copies)
+    if (cp.stream == st) slots = cp.slots;
+  if (!slots && R.copies[0].stream == nullptr) { R.copies[0].stream = st; slots = R.copies[0].slots; }
+  if (!slots) {
+    mg_filter::Resident::Copy cp;
+    MG_HIP(hipDeviceSynchronize());  // (counters of passes in flight elsewhere may be copied torn: their epochs are never reused)
+    if (hipMalloc(&cp.slots, R.slots * sizeof(Slot)) != hipSuccess) {
+      pool_release_all();
+      MG_HIP(hipMalloc(&cp.slots, R.slots * sizeof(Slot)));
+    }
+    cp.stream = st;
+    R.copies.push_back(cp);
+    MG_HIP(hipMemcpyAsync(cp.slots, R.copies[0].slots, R.slots * sizeof(Slot), hipMemcpyDeviceToDevice, st));
+    slots = cp.slots;
+  }
+  if (hmax > R.hmax) hmax = R.hmax;
+  kp.hmax = hmax;
+  kp.expect = (uint64_t)((double)rp.nbases * hash_fraction(hmax));
+  kp.cap = kp.expect + kp.expect / 4 + (1u << 16);
+  if (kp.cap > rp.nbases + 64) kp.cap = rp.nbases + 64;
+  // the sketch cannot hold a hash the index does not; fewer when the previous sketch of this k held fewer (an estimate: a
+  // list or a sketch too small is reported like a table overflow, and the sketch made again with room for every hash)
+  kp.distinct_est = (double)kp.expect * mg::distinct_hint_for(k);
+  if (full || kp.distinct_est > (double)R.distinct || getenv("MG_DEBUG_RESIDENT_SCAN")) kp.distinct_est = (double)R.distinct;
+  const char* tight = full ? nullptr : getenv("MG_DEBUG_DISTINCT_HINT");  // tests: force the overflow
+  if (tight) kp.distinct_est = (double)kp.expect * atof(tight);
+  kp.table = true;
+  kp.tp.lo = 0;
+  kp.tp.shift = R.shift;
+  kp.tp.nbuckets = R.nbuckets;
+  kp.tp.slots = R.slots;
+  kp.tp.tab = reinterpret_cast<Slot*>(slots);
+  kp.tp.epoch = epoch;
+  char name[24];
+  snprintf(name, sizeof(name), "sk_rcounters#%d", ki);
+  *t_counters = (unsigned long long*)scratch(name, 4 * sizeof(unsigned long long));
+  if (!*t_counters) return MG_ERR_NOMEM;
+  MG_HIP(hipMemsetAsync(*t_counters, 0, 4 * sizeof(unsigned long long), st));
+  if (!getenv("MG_DEBUG_RESIDENT_SCAN")) {
+    // room for the estimate, the few hashes two lanes list, and a last chunk per wavefront of the largest grid
+    kp.tp.listcap = (uint64_t)kp.distinct_est + (uint64_t)kp.distinct_est / 16 + (uint64_t)c.num_cus * 8 * kWavesPerBlock * kListChunk + 4096;
+    if (tight) kp.tp.listcap = (uint64_t)kp.distinct_est + 16 * kListChunk;  // (tests: ... of the list too)
+    snprintf(name, sizeof(name), "sk_rlist#%d", ki);
+    kp.tp.list = (uint64_t*)scratch(name, kp.tp.listcap * sizeof(uint64_t));
+    if (!kp.tp.list) return MG_ERR_NOMEM;
+    MG_HIP(hipMemsetAsync(kp.tp.list, 0xff, kp.tp.listcap * sizeof(uint64_t), st));
+  }
+  return MG_OK;
+}
+static bool use_resident(const mg_filter* f) { return f && f->resident && !getenv("MG_DEBUG_NO_RESIDENT"); }
+
+// sketch_resolve's way out when the list of touched hashes (or the sketch's buffers) of a resident sketch was too small:
+// the one-k kernel again, synchronously, sized for every hash of the index.
+static int redo_resident(mg_sketch* sk) {
+  ReadPlan rp;
+  rp.nbases = sk->redo.nbases;
+  rp.stage = sk->redo.stage;
+  KPlan kp;
+  unsigned long long* t_counters = nullptr;
+  MG_TRY(plan_resident(sk->redo.filter, rp, sk->redo.k, sk->redo.hmax, next_resident_epoch(), kp, &t_counters, 0, true));
+  MG_TRY(alloc_table_staging(kp.tp));
+  int rc = MG_ERR_ARG;
+  const bool ok = dispatch_k(sk->redo.k, [&]<int K>() {
+    rc = launch_sketch_reads<K>(sk->redo.bases, sk->redo.offsets, sk->redo.nreads, kp.hmax, kp.tp.list, kp.tp.listcap, t_counters,
+                                kp.tp.tab, kp.tp.shift, rp.stage, sk->redo.filter, kp.tp.epoch);
+  });
+  if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", sk->redo.k);
+  if (rc) return rc;
+  MG_TRY(sk->meta.alloc(8 * sizeof(uint64_t)));
+  uint64_t h_counters[3] = {0, 0, 0};
+  MG_TRY(table_to_sketch(kp.tp, sk, sk->meta.as<uint64_t>(), sk->redo.s, false, 0, t_counters, h_counters,
+                         sk->redo.filter->resident->distinct + 1024));
+  if (h_counters[2]) return fail(MG_ERR_CAPACITY, "resident sketch (k = %d): the list of touched hashes overflowed at full size", sk->redo.k);
+  return MG_OK;
+}
+
 // Deferred finalisation of a sketch whose counting table has just been filled: bucket sort / pack, then the sketch's
 // size, last hash and the table-overflow counter stay on the device with a copy in flight to pinned memory;
 // sketch_resolve() reads them at the first host-side use.
@@ -667,7 +967,7 @@ static int finish_pending(mg_sketch* sk, const KPlan& kp, const ReadPlan& rp, un
   sk->hmax = kp.hmax;
   sk->expect = (double)(kp.expect ? kp.expect : 1);
   sk->redo.bases = d_bases; sk->redo.offsets = d_offsets; sk->redo.nreads = nreads; sk->redo.k = k;
-  sk->redo.hmax = kp.hmax; sk->redo.s = s; sk->redo.cap = kp.cap; sk->redo.stage = rp.stage;
+  sk->redo.hmax = kp.hmax; sk->redo.s = s; sk->redo.cap = kp.cap; sk->redo.stage = rp.stage; sk->redo.nbases = rp.nbases;
   sk->redo.filter = filter;
   return MG_OK;
 }
@@ -695,16 +995,18 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   ReadPlan rp;
   MG_TRY(plan_reads(d_offsets, nreads, st, rp));
   KPlan kp;
-  plan_k(rp, k, hmax, kp);
+  unsigned long long* t_counters = nullptr;  // cleared together with the table
+  if (use_resident(filter)) MG_TRY(plan_resident(filter, rp, k, hmax, next_resident_epoch(), kp, &t_counters, 0));
+  else plan_k(rp, k, hmax, kp);
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
   if (kp.table) {
-    unsigned long long* t_counters = nullptr;  // cleared together with the table
-    MG_TRY(alloc_table(kp.tp, &t_counters));
+    if (kp.tp.epoch) MG_TRY(alloc_table_staging(kp.tp));
+    else MG_TRY(alloc_table(kp.tp, &t_counters));
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, hmax, nullptr, 0, t_counters, kp.tp.tab, kp.tp.shift,
-                                  rp.stage, filter);
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, kp.hmax, kp.tp.list, kp.tp.listcap, t_counters, kp.tp.tab,
+                                  kp.tp.shift, rp.stage, filter, kp.tp.epoch);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
@@ -745,16 +1047,25 @@ static int sketch_reads_multi_async(const uint8_t* d_bases, const uint64_t* d_of
   MG_TRY(plan_reads(d_offsets, nreads, st, rp));
   KPlan kp[4];
   uint64_t hm[4];
-  for (int i = 0; i < nk; ++i) {
-    hm[i] = hmaxs[i] == kReservedHash ? kReservedHash - 1 : hmaxs[i];
-    plan_k(rp, ks[i], hm[i], kp[i]);
-    if (!kp[i].table) return per_k();  // few candidates (list path) for some k: nothing to fuse
-  }
+  bool resident = filters != nullptr;  // every k against its table's resident index, or none
+  for (int i = 0; i < nk && resident; ++i) resident = use_resident(filters[i]);
   MultiKTable tabs[4];
   unsigned long long* t_counters[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < nk; ++i) {
-    MG_TRY(alloc_table_core(kp[i].tp, &t_counters[i], i));
-    tabs[i] = MultiKTable{hm[i], kp[i].tp.tab, t_counters[i], kp[i].tp.shift, filters ? filters[i] : nullptr};
+    hm[i] = hmaxs[i] == kReservedHash ? kReservedHash - 1 : hmaxs[i];
+    if (resident) continue;
+    plan_k(rp, ks[i], hm[i], kp[i]);
+    if (!kp[i].table) return per_k();  // few candidates (list path) for some k: nothing to fuse
+  }
+  const uint32_t epoch = resident ? next_resident_epoch() : 0u;  // one for all k of the launch
+  for (int i = 0; i < nk; ++i) {
+    if (resident) {
+      MG_TRY(plan_resident(filters[i], rp, ks[i], hm[i], epoch, kp[i], &t_counters[i], i));
+    } else {
+      MG_TRY(alloc_table_core(kp[i].tp, &t_counters[i], i));
+    }
+    tabs[i] = MultiKTable{kp[i].hmax, kp[i].tp.tab, t_counters[i], kp[i].tp.shift, filters ? filters[i] : nullptr, kp[i].tp.epoch,
+                          kp[i].tp.list, kp[i].tp.listcap};
   }
   MG_TRY(launch_sketch_reads_multi(ks, nk, d_bases, d_offsets, nreads, tabs, rp.stage));
   for (int i = 0; i < nk; ++i) {
@@ -960,6 +1271,57 @@ int mg_filter_build(const uint64_t* hashes, uint64_t n, mg_filter** out) {
   MG_HIP(hipStreamSynchronize(st));
   *out = f.release();
   return MG_OK;
+}
+
+// The filter's resident index (mg_internal.h: mg_filter::Resident): every one of the n hashes (duplicates welcome; all
+// <= hmax) seeded into a counting table of buckets of <= kBucketTarget expected hashes over [0, hmax].  A table whose
+// hashes crowd some range — a bucket without a free slot — gets MG_ERR_CAPACITY and stays a bit filter.
+int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, uint64_t hmax) {
+  MG_REQUIRE_READY();
+  if (!f || (n && !hashes)) return fail(MG_ERR_ARG, "null argument");
+  if (hmax == kReservedHash) hmax = kReservedHash - 1;
+  f->resident.reset();
+  TablePlan tp;
+  if (n == 0 || !plan_table(0, hmax, (double)n, tp)) return fail(MG_ERR_ARG, "no resident index for %llu hashes up to %llu", (unsigned long long)n, (unsigned long long)hmax);
+  std::unique_ptr<mg_filter::Resident> R(new mg_filter::Resident());
+  R->shift = tp.shift; R->nbuckets = tp.nbuckets; R->slots = tp.slots; R->hmax = hmax;
+  mg_filter::Resident::Copy cp;
+  if (hipMalloc(&cp.slots, tp.slots * sizeof(Slot)) != hipSuccess) {
+    pool_release_all();
+    if (hipMalloc(&cp.slots, tp.slots * sizeof(Slot)) != hipSuccess)
+      return fail(MG_ERR_NOMEM, "resident index: hipMalloc(%llu) failed", (unsigned long long)(tp.slots * sizeof(Slot)));
+  }
+  R->copies.push_back(cp);
+  hipStream_t st = ctx().stream;
+  MG_HIP(hipMemsetAsync(cp.slots, 0, tp.slots * sizeof(Slot), st));
+  unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
+  if (!d_counters) return MG_ERR_NOMEM;
+  MG_HIP(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
+  const uint64_t chunk = 1ull << 26;  // 512 MB of hashes at a time
+  uint64_t* d_h = (uint64_t*)scratch("filter_h", (n < chunk ? n : chunk) * sizeof(uint64_t));
+  if (!d_h) return MG_ERR_NOMEM;
+  for (uint64_t at = 0; at < n; at += chunk) {
+    const uint64_t m = n - at < chunk ? n - at : chunk;
+    MG_HIP(hipMemcpyAsync(d_h, hashes + at, m * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_index_seed, dim3(grid_for(m, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st, d_h, m, tp.shift,
+                       tp.nbuckets, reinterpret_cast<Slot*>(cp.slots), d_counters);
+    MG_HIP(hipGetLastError());
+    MG_HIP(hipStreamSynchronize(st));  // (pageable source: the copy is synchronous anyway; d_h is reused)
+  }
+  uint64_t* pin = host_words();
+  MG_HIP(hipMemcpyAsync(pin, d_counters, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  R->distinct = pin[0];
+  if (pin[1])
+    return fail(MG_ERR_CAPACITY, "resident index: %llu of %llu hashes found no slot (above hmax, or a crowded hash range)",
+                (unsigned long long)pin[1], (unsigned long long)n);
+  f->resident = std::move(R);
+  return MG_OK;
+}
+
+// Bytes of HBM the filter's resident index holds (every copy), 0 without one.
+uint64_t mg_filter_resident_bytes(const mg_filter* f) {
+  return f && f->resident ? f->resident->slots * sizeof(mg::Slot) * f->resident->copies.size() : 0;
 }
 
 int mg_set_count_saturation(uint32_t cs) {

@@ -78,6 +78,84 @@ __device__ __forceinline__ bool table_add(Slot* __restrict__ tab, uint64_t bucke
   return false;
 }
 
+// RESIDENT INDEX (mg_filter_make_resident): the same slots, but seeded ONCE with every hash of the genome table and never
+// cleared.  A candidate is then either found and counted, or it is not a hash of the table and dropped: no filter word,
+// no insert.  What a flush costs is (a) its DEPENDENT round trips to memory and (b) the number of loads its lanes issue,
+// each to a line of its own — not bytes (tools/k1_probe.py, 12.5M reads against the 200k-genome table: no look-up at all
+// 19.3 ms, every home slot loaded and nothing else 24.8, two slots of one line per candidate 33.0, the counting table's
+// slot -> filter word -> compare-and-swap -> add 35.2).  So the index answers with ONE 16-byte load, once:
+//  * open addressing as in the counting table (home slot = the hash's low bits, then the slots after it), but the set is
+//    static, so the HOME slot knows whether any hash whose home it is lives further on (kMovedOn, set at seeding).  A
+//    candidate that is not in its home slot and finds the mark clear is not a hash of the table — 90 % of the misses end
+//    there, where probing would go on until an empty slot.  Otherwise it goes back into the wavefront's buffer tagged "one
+//    slot on" and is looked at again by the NEXT flush (found / an empty slot / on again): never a second round trip.
+//  * `pad` holds the EPOCH the counter belongs to: a sketch call has its own, larger than any before it; a counter of
+//    another epoch reads as zero.  Counting never waits for memory either: {cnt, pad} is one 64-bit word, epoch high —
+//    atomicMax(word, epoch << 32 | mark) starts the epoch's count at zero unless it has started, atomicAdd(word, 1) counts;
+//    both without a return value, same address, program order.  A lane that saw a stale word (another XCD's L2) does the
+//    same two and nothing is lost; one that saw the counter at cs does neither.
+constexpr uint32_t kMovedOn = 0x80000000u;  // in cnt of a hash's home slot: a hash with this home is not in it
+constexpr uint32_t kMaxHops = 63;           // slots a hash may live from home (the fused kernel's tag has six bits)
+
+// J candidates of a lane (hh[j] == kReservedHash: none), hop[j] slots from home.  hit[j]: found and counted; fresh[j]: ... and
+// this lane saw no count of this epoch there (for a list of the hashes a pass has touched: several lanes may, for one hash);
+// on[j]: not found, and it may be one slot on.
+template <int J>
+__device__ __forceinline__ void resident_lookup(Slot* const (&bucket)[J], const uint64_t (&hh)[J], const uint32_t (&hop)[J],
+                                                uint32_t epoch, uint32_t cs, bool (&hit)[J], bool (&fresh)[J], bool (&on)[J],
+                                                bool count = true) {
+  uint4 raw[J];
+  Slot* at[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    raw[j] = make_uint4(0, 0, 0, 0);
+    at[j] = bucket[j] + (((uint32_t)hh[j] + hop[j]) & (kBucketSlots - 1));
+    if (hh[j] != kReservedHash) raw[j] = *reinterpret_cast<const uint4*>(at[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const unsigned long long key = (unsigned long long)raw[j].x | ((unsigned long long)raw[j].y << 32);
+    const uint32_t mark = raw[j].z & kMovedOn, cnt = raw[j].z & ~kMovedOn, ep = raw[j].w;
+    hit[j] = hh[j] != kReservedHash && key == hh[j] + 1;
+    on[j] = hh[j] != kReservedHash && !hit[j] && (hop[j] == 0 ? mark != 0 : key != 0ull);
+    fresh[j] = hit[j] && ep != epoch;
+    if (count && hit[j] && !(ep == epoch && cs && cnt >= cs)) {
+      unsigned long long* word = reinterpret_cast<unsigned long long*>(&at[j]->cnt);  // {cnt, pad}: cnt is the low half
+      if (ep != epoch) atomicMax(word, ((unsigned long long)epoch << 32) | mark);
+      atomicAdd(word, 1ull);
+    }
+  }
+}
+
+// The hashes a pass has touched in a resident index, as a LIST (what turns the index into the pass's sketch without a
+// walk over all of its slots: sort, drop the few repeats, read the counters).  A wavefront appends what its lanes saw
+// `fresh` to a chunk of its own (one atomic on the list's cursor, counters[3], per kListChunk entries); the list is filled
+// with kReservedHash before the launch, so what a wavefront leaves of its last chunk sorts to the end.  A full list is
+// reported like a table overflow (counters[2]): whoever resolves the sketch makes it again with room for every hash.
+constexpr uint32_t kListChunk = 256;
+__device__ __forceinline__ void resident_list_append(bool mine, uint64_t h, uint64_t* __restrict__ list, uint64_t cap,
+                                                     unsigned long long* __restrict__ counters, uint64_t*& lbase, uint32_t& lfill,
+                                                     int lane) {
+  const unsigned long long m = __ballot(mine);
+  if (m == 0) return;
+  const uint32_t c = (uint32_t)__popcll(m);
+  if (!lbase || lfill + c > kListChunk) {
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(counters + 3, (unsigned long long)kListChunk);
+    off = (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)off) |
+          ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(off >> 32)) << 32);
+    if (off + kListChunk > cap) {
+      if (lane == 0) atomicAdd(counters + 2, 1ull);
+      lbase = nullptr;
+      return;
+    }
+    lbase = list + off;
+    lfill = 0;
+  }
+  if (mine) lbase[lfill + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
+  lfill += c;
+}
+
 // Four ASCII bases -> four code bytes: 0..3 = A C G T (either case), 4 = anything else.  SWAR on the dword, done
 // once per base while the tile is copied into LDS (14 instructions per 4 bases instead of 9 per base in the walk).
 __device__ __forceinline__ uint32_t encode4(uint32_t x) {

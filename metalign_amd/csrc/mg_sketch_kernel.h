@@ -25,6 +25,9 @@ struct CandSink {
   unsigned long long produced = 0;  // table mode: this lane's candidates inserted so far
   bool slot_first = false;          // table mode: the order of the two look-ups of a flush (wave-uniform)
   uint32_t order = 0;               // 0: adapt; 1 / 2: pinned (tests)
+  uint32_t epoch = 0;               // table mode, != 0: `tab` is a resident index (mg_sketch_dev.h) and out / cap the list of hashes touched
+  uint64_t* lbase = nullptr;        // ... this wavefront's chunk of that list
+  uint32_t lfill = 0;
 
   __device__ __forceinline__ bool passes(uint64_t h) const {
     return !fbits || ((fbits[(h & fmask) >> 5] >> (h & 31u)) & 1u);
@@ -45,6 +48,33 @@ struct CandSink {
         if (lane == 0) base = atomicAdd(counters, (unsigned long long)__popcll(m));
         base = __shfl(base, 0, 64) + __popcll(m & ((1ull << lane) - 1ull));
         if (keep && base < cap) out[base] = h;
+      }
+    } else if (epoch) {
+      // resident index (mg_sketch_dev.h).  This sink's buffer has no room for a "one slot on" tag: the candidates that have
+      // to look further do so here, round after round (the fused kernel defers them to its next flush).
+      constexpr int J = kCandBuf / 64;
+      uint64_t hh[J];
+      uint32_t hop[J];
+      Slot* bucket[J];
+      bool hit[J], fresh[J], on[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int i = lane + 64 * j;
+        hh[j] = i < n ? lds[i] : kReservedHash;
+        hop[j] = 0;
+        bucket[j] = tab + (hh[j] != kReservedHash ? hh[j] >> shift : 0ull) * kBucketSlots;
+      }
+      for (;;) {
+        resident_lookup<J>(bucket, hh, hop, epoch, cs, hit, fresh, on);
+        bool more = false;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          produced += hit[j];
+          if (out) resident_list_append(fresh[j], hh[j], out, cap, counters, lbase, lfill, lane);
+          if (on[j] && hop[j] < kMaxHops) { ++hop[j]; more = true; }
+          else hh[j] = kReservedHash;
+        }
+        if (__ballot(more) == 0ull) break;
       }
     } else {
       uint32_t lost = 0, kept = 0;
@@ -224,6 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restri
   CandSink sink{cbuf, cand, cand_cap, counters, tab, bucket_shift, fbits, fmask, cs & kCsMask, 0};
   sink.order = cs >> 30;
   sink.slot_first = sink.order == 2u;
+  if (!fbits) sink.epoch = (uint32_t)fmask;  // no filter words and a "mask": the table is a resident index, this its epoch
   uint64_t kmers = 0;
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;

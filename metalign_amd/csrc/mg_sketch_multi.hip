@@ -29,9 +29,14 @@ struct MultiArgs {
   unsigned shift[kMaxMultiK];
   uint32_t cs;     // saturation value (low 30 bits of the cs word)
   uint32_t order;  // its top two bits
+  uint64_t* list[kMaxMultiK];            // resident indexes: the list of hashes the pass has touched in index i (or null)
+  uint64_t listcap[kMaxMultiK];
+  uint32_t epoch;  // != 0: the tables are resident indexes (mg_sketch_dev.h: resident_count) and this the pass's epoch
+  uint32_t ablate; // resident kernel only, MG_DEBUG_RESIDENT_ABLATE (tools/k1_probe.py): 1 = a flush drops its candidates (what the kernel costs without any look-up)
 };
 
 // Wave-level candidate sink shared by all k: (hash, k index) pairs staged in LDS, flushed into the per-k tables.
+template <bool RESIDENT>  // the tables are resident indexes: a kernel of its own, so that the usual one carries none of it
 struct MultiSink {
   uint64_t* lds_h;   // this wave's kCandBuf hashes
   uint8_t* lds_k;    // ... and the index of the k each belongs to
@@ -48,6 +53,7 @@ struct MultiSink {
   // wavefront keeps to the order that was cheaper for its previous flush.
   bool slot_first;  // wave-uniform
   uint32_t order;   // 0: adapt; 1 / 2: pinned (tests; see kCsMask)
+  uint64_t* lst = nullptr;  // RESIDENT, in LDS (registers are the hashing loop's): this wavefront's chunk of A->list[i], i < 4, then how full each is
 
   __device__ __forceinline__ void flush(int lane) {
     if (n == 0) return;
@@ -63,8 +69,57 @@ struct MultiSink {
       const int i = lane + 64 * j;
       hh[j] = i < n ? lds_h[i] : kReservedHash;
       kk[j] = i < n ? lds_k[i] : 0u;
-      home[j] = A->tab[kk[j]] + (hh[j] >> A->shift[kk[j]]) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1));
+      if constexpr (!RESIDENT)
+        home[j] = A->tab[kk[j]] + (hh[j] >> A->shift[kk[j]]) * kBucketSlots + ((uint32_t)hh[j] & (kBucketSlots - 1));
       sv[j] = make_uint4(0, 0, 0, 0);
+    }
+    if constexpr (RESIDENT) {
+      // resident indexes (mg_sketch_dev.h): one 16-byte load per candidate, all in flight together — one round trip; a
+      // candidate that has to look one slot on goes back into the buffer (its k byte counts the slots above bit 1)
+      if (A->ablate == 1u) { wave_lds_sync(); n = 0; return; }
+      Slot* bucket[J];
+      uint32_t hop[J];
+      bool hit[J], fresh[J], on[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const uint32_t ki = kk[j] & 3u;
+        hop[j] = kk[j] >> 2;
+        bucket[j] = A->tab[ki] + (hh[j] != kReservedHash ? hh[j] >> A->shift[ki] : 0ull) * kBucketSlots;
+      }
+      resident_lookup<J>(bucket, hh, hop, A->epoch, A->cs, hit, fresh, on, A->ablate < 2u);  // (2, 3: nothing is counted)
+      if (A->ablate == 2u) { wave_lds_sync(); n = 0; return; }                               // (2: ... and nothing goes round again)
+      wave_lds_sync();  // (every lane holds its entries in registers: the buffer's front is free for what goes round again)
+      int back = 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int q = 0; q < kMaxMultiK; ++q) produced[q] += (unsigned)__popcll(__ballot(hit[j] && (kk[j] & 3u) == (uint32_t)q));
+        if (A->ablate == 0u && __ballot(fresh[j]) != 0ull) {
+#pragma unroll
+          for (int q = 0; q < kMaxMultiK; ++q) {
+            if (!A->list[q]) continue;
+            uint32_t* fills = reinterpret_cast<uint32_t*>(lst + kMaxMultiK);
+            uint64_t* lbase = reinterpret_cast<uint64_t*>(lst[q]);
+            uint32_t lfill = fills[q];
+            resident_list_append(fresh[j] && (kk[j] & 3u) == (uint32_t)q, hh[j], A->list[q], A->listcap[q], A->counters[q], lbase,
+                                 lfill, lane);
+            lst[q] = reinterpret_cast<uint64_t>(lbase);  // (every lane the same value)
+            fills[q] = lfill;
+          }
+        }
+        const bool again = on[j] && hop[j] < kMaxHops;
+        const unsigned long long m = __ballot(again);
+        if (m == 0) continue;
+        if (again) {
+          const int at = back + __popcll(m & ((1ull << lane) - 1ull));
+          lds_h[at] = hh[j];
+          lds_k[at] = (uint8_t)(kk[j] + 4u);
+        }
+        back += __popcll(m);
+      }
+      wave_lds_sync();
+      n = back;
+      return;
     }
     if (slot_first) {
       // every candidate's home slot (key and counter in one 16-byte access), all in flight together; then the filter
@@ -160,9 +215,9 @@ struct KList {
 // 2 clean tile of ragged reads.
 // CODES: src is the wavefront's nibble-packed LDS stage and `start` the nibble index of this lane's read; otherwise
 // src points at the read's ASCII bases in HBM (a tile that does not fit the stage; MODE 0 only).
-template <class KL, bool CODES, int MODE, int HM>
+template <class KL, bool CODES, int MODE, int HM, class SINK>
 __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t start, uint32_t len, uint32_t maxlen_v,
-                                                 const MultiArgs& A, MultiSink& sink, uint64_t (&kmers)[kMaxMultiK], int lane,
+                                                 const MultiArgs& A, SINK& sink, uint64_t (&kmers)[kMaxMultiK], int lane,
                                                  const uint64_t* htab) {
   constexpr int KMAX = KL::kmax;
   static_assert(CODES || MODE == 0, "the clean walks read the LDS stage");
@@ -257,7 +312,7 @@ __device__ __forceinline__ void walk_reads_multi(const uint8_t* src, uint32_t st
   for (int i = 0; i < KL::N; ++i) kmers[i] += wave_sum_u64(nk[i]);
 }
 
-template <class KL, int HM>
+template <class KL, int HM, bool RESIDENT>
 __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                         uint64_t nreads, const MultiArgs& args, unsigned stage_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -269,7 +324,13 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
   uint8_t* cand = smem + (size_t)kWavesPerBlock * stage_bytes;
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(cand) + wave * kCandBuf;
   uint8_t* kbuf = cand + (size_t)kWavesPerBlock * kCandBuf * sizeof(uint64_t) + wave * kCandBuf;
-  MultiSink sink{cbuf, kbuf, &s_args, 0, {0, 0, 0, 0}, args.order == 2u, args.order};
+  MultiSink<RESIDENT> sink{cbuf, kbuf, &s_args, 0, {0, 0, 0, 0}, args.order == 2u, args.order};
+  if constexpr (RESIDENT) {
+    __shared__ uint64_t s_lst[kWavesPerBlock][kMaxMultiK + kMaxMultiK / 2];
+    sink.lst = s_lst[wave];
+    if (lane < kMaxMultiK + kMaxMultiK / 2) sink.lst[lane] = 0;  // no chunk yet
+    wave_lds_sync();
+  }
   uint64_t kmers[kMaxMultiK] = {0, 0, 0, 0};
   const uint64_t ntiles = (nreads + 63) / 64;
   for (uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
@@ -299,17 +360,19 @@ __device__ __forceinline__ void sketch_reads_multi_body(const uint8_t* __restric
       wave_lds_sync();
       const uint32_t nstart = (uint32_t)(shift + (beg - t_beg));
       if (__ballot(bad != 0) != 0ull)
-        walk_reads_multi<KL, true, 0, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+        walk_reads_multi<KL, true, 0, HM, MultiSink<RESIDENT>>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       else if (__ballot(len != maxlen) == 0ull)
-        walk_reads_multi<KL, true, 1, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+        walk_reads_multi<KL, true, 1, HM, MultiSink<RESIDENT>>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       else
-        walk_reads_multi<KL, true, 2, HM>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+        walk_reads_multi<KL, true, 2, HM, MultiSink<RESIDENT>>(stage, nstart, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
       wave_lds_sync();
     } else {
-      walk_reads_multi<KL, false, 0, HM>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
+      walk_reads_multi<KL, false, 0, HM, MultiSink<RESIDENT>>(bases + beg, 0u, (uint32_t)len, (uint32_t)maxlen, args, sink, kmers, lane, htab);
     }
   }
   sink.flush(lane);
+  if constexpr (RESIDENT)
+    while (sink.n) sink.flush(lane);  // (candidates that went round again: at most kMaxHops times)
 #pragma unroll
   for (int i = 0; i < KL::N; ++i) {  // (wave totals already: every lane holds the same value)
     if (lane == 0 && kmers[i]) atomicAdd(args.counters[i] + 1, (unsigned long long)kmers[i]);
@@ -333,7 +396,14 @@ template <class KL, int HM>
 __global__ __launch_bounds__(kBlock) MG_K1_WAVES_ATTR void k_sketch_reads_multi(const uint8_t* __restrict__ bases,
                                                                const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                                const MultiArgs args, unsigned stage_bytes) {
-  sketch_reads_multi_body<KL, HM>(bases, offsets, nreads, args, stage_bytes);
+  sketch_reads_multi_body<KL, HM, false>(bases, offsets, nreads, args, stage_bytes);
+}
+// ... against resident indexes (args.epoch != 0)
+template <class KL, int HM>
+__global__ __launch_bounds__(kBlock) MG_K1_WAVES_ATTR void k_sketch_reads_multi_resident(const uint8_t* __restrict__ bases,
+                                                               const uint64_t* __restrict__ offsets, uint64_t nreads,
+                                                               const MultiArgs args, unsigned stage_bytes) {
+  sketch_reads_multi_body<KL, HM, true>(bases, offsets, nreads, args, stage_bytes);
 }
 
 template <class KL>
@@ -342,13 +412,19 @@ static int launch_multi(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
   Context& c = ctx();
   const size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * (sizeof(uint64_t) + 1));
   const uint64_t ntiles = (nreads + 63) / 64;
-  unsigned per_cu = (unsigned)(160 * 1024 / (lds + sizeof(MultiArgs) + 64 + kHashTabEntries * sizeof(uint64_t)));
+  unsigned per_cu = (unsigned)(160 * 1024 / (lds + sizeof(MultiArgs) + 64 + 256 + kHashTabEntries * sizeof(uint64_t)));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const unsigned grid = grid_for(ntiles, kWavesPerBlock, (unsigned)c.num_cus * per_cu);
   ProfScope ps("sketch_reads");
-  if (c.hash_mode == kHashCmash)
+  if (a.epoch && c.hash_mode == kHashCmash)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi_resident<KL, kHashCmash>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases,
+                       d_offsets, nreads, a, stage_bytes);
+  else if (a.epoch)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi_resident<KL, kHashCanonical>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases,
+                       d_offsets, nreads, a, stage_bytes);
+  else if (c.hash_mode == kHashCmash)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sketch_reads_multi<KL, kHashCmash>), dim3(grid), dim3(kBlock), lds, c.stream, d_bases,
                        d_offsets, nreads, a, stage_bytes);
   else
@@ -379,7 +455,12 @@ int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, con
     a.fbits[i] = tabs[i].filter ? tabs[i].filter->bits.as<uint32_t>() : nullptr;
     a.fmask[i] = tabs[i].filter ? tabs[i].filter->mask : 0ull;
     a.shift[i] = tabs[i].shift;
+    if (tabs[i].epoch) {  // (all of a call's k or none)
+      a.fbits[i] = nullptr; a.fmask[i] = 0; a.epoch = tabs[i].epoch;
+      a.list[i] = tabs[i].list; a.listcap[i] = tabs[i].listcap;
+    }
   }
+  if (const char* e = getenv("MG_DEBUG_RESIDENT_ABLATE")) a.ablate = (uint32_t)atoi(e);
   a.cs = stage_a_cs_word() & kCsMask;
   a.order = stage_a_cs_word() >> 30;
   if (nk == 3 && ks[0] == 21 && ks[1] == 31 && ks[2] == 51)

@@ -135,6 +135,25 @@ class HipEngine:
         (select_db.py:70,75)."""
         self.filters += [None] * (ki + 1 - len(self.filters))
         self.filters[ki] = self.hip.filter_build(table_hashes)
+        if len(table_hashes) and self.wants_resident_index(int(np.max(table_hashes)), len(table_hashes)):
+            # a table whose largest hash filters little: its hashes seeded once into a resident counting table — a candidate
+            # then costs one random access instead of a home slot plus a filter word, and no table is cleared per pass
+            # (False: the hashes crowd some range and the bit filter stays)
+            self.filters[ki].make_resident(table_hashes, int(np.max(table_hashes)))
+
+    def wants_resident_index(self, hmax, nhashes):
+        """MG_RESIDENT_INDEX=1 / 0 forces it on / off; otherwise: when at least 5 % of all k-mers pass the table's threshold
+        (genomes of a few kb, or a mixed table: stage A is then bound by its random look-ups, not by its hashing) and
+        three copies of the index (one per stream that sketches: up to 64 bytes per hash each) fit a quarter of the
+        free HBM together with the other k's."""
+        e = os.environ.get("MG_RESIDENT_INDEX", "auto")
+        if e in ("0", "1"):
+            return e == "1"
+        hash_range = 9999999999971.0 if self.hip.hash_mode == 1 else 2.0 ** 64
+        if (hmax + 1) / hash_range < 0.05:
+            return False
+        free, _, pooled = self.hip.mem_info()
+        return 3 * 64 * nhashes * max(getattr(self, "nk", 1), 1) <= (free + pooled) // 4
 
     def set_filter_bits(self, ki, bits):
         """The same from the bit array the table builder stored (formats.SketchTable.filter_bits)."""
@@ -568,6 +587,8 @@ class ShardJob:
         this rank's hash range [bounds[r], bounds[r+1]) of every k is read from disk (dbo stays None).
         ntax: number of dense taxon ids (default: max(ref2tax) + 1)."""
         K = len(self.ks)
+        if hasattr(self.engine, "wants_resident_index"):
+            self.engine.nk = K  # (its memory estimate covers every k's index)
         self.T = int(ntax) if ntax is not None else (int(np.max(ref2tax)) + 1 if len(ref2tax) else 0)
         tables, self.hmaxs, self.bounds = [], [], []
         if hasattr(dbh, "pairs"):  # an on-disk hash-major table (formats.SketchTable, version 2)
@@ -580,6 +601,9 @@ class ShardJob:
                 self.bounds.append(b)
                 if hasattr(self.engine, "set_filter"):
                     bits = disk.filter_bits(k)  # stored by the builder: the rank does not stream the other ranks' slices
+                    if hasattr(self.engine, "wants_resident_index") and \
+                            self.engine.wants_resident_index(hmax, len(disk.pairs(k)["pair_hash"])):
+                        bits = None  # the resident index wants every hash of the table on every rank
                     if bits is not None and hasattr(self.engine, "set_filter_bits"):
                         self.engine.set_filter_bits(ki, bits)
                     else:

@@ -638,3 +638,109 @@ def test_cmash_prefix_tables_match_the_oracle(hip, oracle_lib, cmash_mode):
         sk.free()
     d_b.free()
     d_o.free()
+
+
+def _exact_sketch(oracle_lib, bases, offsets, k, table_hashes, hmax, cs=3):
+    """What a sketch made against a table's RESIDENT INDEX holds: the read k-mers that are hashes of the table."""
+    uh, uc, _, seen = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmax, s=0)
+    keep = np.isin(uh, table_hashes)
+    return uh[keep], uc[keep], seen
+
+
+@pytest.mark.parametrize("ks", [(21, 31, 51), (30, 40, 50, 60), (25, 33)])
+def test_resident_index_sketches_are_the_exact_intersection(hip, oracle_lib, ks):
+    """mg_filter_make_resident: the counting table seeded once with every hash of the genome table, counters tagged with
+    the epoch of the call.  A sketch made with it is the oracle's unfiltered sketch restricted to the table's hashes
+    (counts saturating at 3 as ever) — for the fused launch, the one-k kernel and a k set without a fused kernel, call
+    after call on DIFFERENT reads (a counter of an earlier epoch reads as zero), and containment is what the
+    unfiltered sketch gives."""
+    rng = np.random.default_rng(sum(ks))
+    gb, go = util.random_genomes(rng, 12, 6000)
+    tabs = [oracle_lib.sketch_genomes(gb, go, k, 900) for k in ks]
+    hmaxs = [int(t[0].max()) for t in tabs]
+    filts = [hip.filter_build(t[0]) for t in tabs]
+    for f, t, hm in zip(filts, tabs, hmaxs):
+        assert f.resident_bytes == 0
+        assert f.make_resident(t[0], hm)
+        assert f.resident_bytes > 0
+    tables = [hip.upload_table(*t) for t in tabs]
+    for rep, (nreads, present, err) in enumerate(((9000, 3, 0.02), (700, 12, 0.0), (9000, 5, 0.03), (64, 1, 0.0))):
+        pick = np.sort(rng.choice(12, size=present, replace=False))
+        bases, offsets, _ = util.sample_reads(rng, gb, go, nreads, 150, err=err, present=pick)
+        d_b, d_o = hip.array(bases), hip.array(offsets)
+        sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, nreads, list(ks), hmaxs, 0, filts)
+        for i, k in enumerate(ks):
+            eh, ec, seen = _exact_sketch(oracle_lib, bases, offsets, k, tabs[i][0], hmaxs[i])
+            h, c = sks[i].download()
+            assert np.array_equal(h, eh) and np.array_equal(c, ec) and sks[i].kmers_seen == seen, (k, rep)
+            one = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, hmaxs[i], 0, filt=filts[i])
+            h1, c1 = one.download()
+            assert np.array_equal(h1, eh) and np.array_equal(c1, ec), (k, rep)
+            # a threshold above the table's largest hash changes nothing; bottom-s cuts after the intersection
+            cut = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, (1 << 64) - 1, 50, filt=filts[i])
+            h2, c2 = cut.download()
+            assert np.array_equal(h2, eh[:50]) and np.array_equal(c2, ec[:50]) and cut.truncated == int(len(eh) > 50)
+            hits, sizes = hip.containment(sks[i], tables[i], 2)
+            uh, uc, utr, _ = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmaxs[i], s=0)
+            ohits, osizes = oracle_lib.containment(uh, uc, utr, 2, *tabs[i])
+            assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes), (k, rep)
+            for x in (one, cut):
+                x.free()
+        for x in sks:
+            x.free()
+    # exact counts (saturation off): the epoch's first candidate starts the counter at one
+    hip.count_saturation(0)
+    try:
+        bases, offsets, _ = util.sample_reads(rng, gb, go, 20000, 150, err=0.0, present=np.array([4]))
+        d_b, d_o = hip.array(bases), hip.array(offsets)
+        for _ in range(2):
+            sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, 20000, ks[0], hmaxs[0], 0, filt=filts[0])
+            h, c = sk.download()
+            uh, uc, _, _ = oracle_lib.sketch_reads(bases, offsets, ks[0], hmax=hmaxs[0], s=0, cs=0)
+            keep = np.isin(uh, tabs[0][0])
+            assert np.array_equal(h, uh[keep]) and np.array_equal(c, uc[keep]) and c.max() > 50
+            sk.free()
+    finally:
+        hip.count_saturation(3)
+    # hashes that crowd one range: no index, the filter stays what it was
+    crowded = hip.filter_build(tabs[0][0])
+    assert not crowded.make_resident(np.arange(5000, dtype=np.uint64), (1 << 63))
+    assert crowded.resident_bytes == 0
+    for f in filts + [crowded]:
+        f.free()
+
+
+@pytest.mark.parametrize("hook", ["MG_DEBUG_DISTINCT_HINT", "MG_DEBUG_RESIDENT_SCAN"])
+def test_resident_index_list_overflow_and_slot_walk(hip, oracle_lib, hook, monkeypatch):
+    """The sketch of a resident index is made from the LIST of hashes the kernel touched.  A list (or sketch buffer) sized for
+    far fewer hashes than the sample has (MG_DEBUG_DISTINCT_HINT, a test hook) is reported like a table overflow and the
+    sketch made again at full size when it is resolved — exact either way; and a walk over every slot of the index
+    (MG_DEBUG_RESIDENT_SCAN) gives the same sketch as the list."""
+    monkeypatch.setenv(hook, "0.0001" if hook.endswith("HINT") else "1")
+    rng = np.random.default_rng(77)
+    ks = (21, 31, 51)
+    gb, go = util.random_genomes(rng, 40, 6000)
+    tabs = [oracle_lib.sketch_genomes(gb, go, k, 900) for k in ks]
+    hmaxs = [int(t[0].max()) for t in tabs]
+    filts = [hip.filter_build(t[0]) for t in tabs]
+    for f, t, hm in zip(filts, tabs, hmaxs):
+        assert f.make_resident(t[0], hm)
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 30000, 150, err=0.01)
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    for _ in range(2):
+        sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, 30000, list(ks), hmaxs, 0, filts)
+        for i, k in enumerate(ks):
+            eh, ec, seen = _exact_sketch(oracle_lib, bases, offsets, k, tabs[i][0], hmaxs[i])
+            rebuilt = sks[i].resolve()
+            if hook.endswith("HINT"):
+                assert rebuilt
+            h, c = sks[i].download()
+            assert len(eh) > 20000 and np.array_equal(h, eh) and np.array_equal(c, ec), k
+            one = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, 30000, k, hmaxs[i], 0, filt=filts[i])
+            h1, c1 = one.download()
+            assert np.array_equal(h1, eh) and np.array_equal(c1, ec), k
+            one.free()
+        for x in sks:
+            x.free()
+    for f in filts:
+        f.free()

@@ -11,6 +11,8 @@ G = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000
 ks = [int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [21, 31, 51]
 hip = Hip.get(0)
+if os.environ.get("MG_PROBE_CS"):  # counters saturate here (default 3): fewer memory-side atomics per distinct hash at 1
+    hip.count_saturation(int(os.environ["MG_PROBE_CS"]))
 gb, go = synth.make_genomes(G, L)
 rb, ro, _ = synth.make_reads(gb, go, R, npresent=max(50, G // 20))
 d_b, d_o = hip.array(rb), hip.array(ro)
@@ -26,7 +28,19 @@ def run(hm, fl, label):
         for sk in sks: sk.free()
     hip.sync(); hip.prof_enable(False)
     c, t = hip.prof_get("sketch_reads")
-    print("%-46s stage A %.3f ms per pass (%d launch(es) per pass), sketch sizes %s" % (label, t / 2, c // 2, n), flush=True)
+    tail = " + ".join("%s %.2f" % (nm, hip.prof_get(nm)[1] / 2) for nm in ("table_clear", "bucket_sort", "bucket_pack"))
+    print("%-46s stage A %.3f ms per pass (%d launch(es) per pass; %s ms), sketch sizes %s" % (label, t / 2, c // 2, tail, n), flush=True)
 run(hmaxs, filts, "thresholds + filters of the table:")
+if os.environ.get("MG_PROBE_RESIDENT", "1") != "0":
+    res = [hip.filter_build(t) for t in tables]
+    ok = [f.make_resident(t, hm) for f, t, hm in zip(res, tables, hmaxs)]
+    print("resident indexes: %s, %.2f GB" % (ok, sum(f.resident_bytes for f in res) / 1e9), flush=True)
+    run(hmaxs, res, "thresholds + resident indexes of the table:")
+    for ab, what in ((1, "a flush drops its candidates"), (2, "looks them up, counts nothing, none goes round again"),
+                     (3, "looks them up, counts nothing")):
+        os.environ["MG_DEBUG_RESIDENT_ABLATE"] = str(ab)
+        run(hmaxs, res, "resident, %s:" % what)
+    del os.environ["MG_DEBUG_RESIDENT_ABLATE"]
+    for f in res: f.free()
 run(hmaxs, None, "thresholds, no filter:")
 run([int(3e-5 * 2 ** 64)] * len(ks), None, "thresholds that pass ~45 k k-mers per k (pure hashing):")
