@@ -742,7 +742,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   sk->index.release();
   sk->hashes.release();
   sk->counts.release();
-  if (sk->redo.filter && sk->redo.filter->resident && !getenv("MG_DEBUG_NO_RESIDENT")) {
+  if (sk->redo.s == 0 && sk->redo.filter && sk->redo.filter->resident && !getenv("MG_DEBUG_NO_RESIDENT")) {
     // made against a resident index, whose sketch is the exact intersection (the list path's filter lets ~6 % of the
     // other hashes through): the list of touched hashes, or the sketch's buffers, were too small — again, with room for
     // every hash of the index (the hint has just been reset)
@@ -908,7 +908,9 @@ static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t
   }
   return MG_OK;
 }
-static bool use_resident(const mg_filter* f) { return f && f->resident && !getenv("MG_DEBUG_NO_RESIDENT"); }
+// (a bottom-s sketch keeps the bit filter's definition — the s smallest of what passes the FILTER — so that the cut does
+// not depend on whether the table has an index)
+static bool use_resident(const mg_filter* f, uint64_t s) { return s == 0 && f && f->resident && !getenv("MG_DEBUG_NO_RESIDENT"); }
 
 // sketch_resolve's way out when the list of touched hashes (or the sketch's buffers) of a resident sketch was too small:
 // the one-k kernel again, synchronously, sized for every hash of the index.
@@ -996,7 +998,7 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
   MG_TRY(plan_reads(d_offsets, nreads, st, rp));
   KPlan kp;
   unsigned long long* t_counters = nullptr;  // cleared together with the table
-  if (use_resident(filter)) MG_TRY(plan_resident(filter, rp, k, hmax, next_resident_epoch(), kp, &t_counters, 0));
+  if (use_resident(filter, s)) MG_TRY(plan_resident(filter, rp, k, hmax, next_resident_epoch(), kp, &t_counters, 0));
   else plan_k(rp, k, hmax, kp);
   unsigned long long* d_counters = (unsigned long long*)scratch("sk_counters", 8 * sizeof(unsigned long long));
   if (!d_counters) return MG_ERR_NOMEM;
@@ -1048,7 +1050,7 @@ static int sketch_reads_multi_async(const uint8_t* d_bases, const uint64_t* d_of
   KPlan kp[4];
   uint64_t hm[4];
   bool resident = filters != nullptr;  // every k against its table's resident index, or none
-  for (int i = 0; i < nk && resident; ++i) resident = use_resident(filters[i]);
+  for (int i = 0; i < nk && resident; ++i) resident = use_resident(filters[i], s);
   MultiKTable tabs[4];
   unsigned long long* t_counters[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < nk; ++i) {

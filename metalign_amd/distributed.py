@@ -144,8 +144,8 @@ class HipEngine:
     def wants_resident_index(self, hmax, nhashes):
         """MG_RESIDENT_INDEX=1 / 0 forces it on / off; otherwise: when at least 5 % of all k-mers pass the table's threshold
         (genomes of a few kb, or a mixed table: stage A is then bound by its random look-ups, not by its hashing) and
-        three copies of the index (one per stream that sketches: up to 64 bytes per hash each) fit a quarter of the
-        free HBM together with the other k's."""
+        the indexes of all k (32 to 64 bytes per hash, once per stream that sketches: two for a pipelined job) fit half of
+        the free HBM."""
         e = os.environ.get("MG_RESIDENT_INDEX", "auto")
         if e in ("0", "1"):
             return e == "1"
@@ -153,7 +153,7 @@ class HipEngine:
         if (hmax + 1) / hash_range < 0.05:
             return False
         free, _, pooled = self.hip.mem_info()
-        return 3 * 64 * nhashes * max(getattr(self, "nk", 1), 1) <= (free + pooled) // 4
+        return 2 * 48 * nhashes * max(getattr(self, "nk", 1), 1) <= (free + pooled) // 2
 
     def set_filter_bits(self, ki, bits):
         """The same from the bit array the table builder stored (formats.SketchTable.filter_bits)."""

@@ -7,6 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 
@@ -14,6 +15,7 @@ import torch  # noqa: E402  (first: the library then binds to the same HIP runti
 import torch.distributed as dist  # noqa: E402
 
 import oracle  # noqa: E402
+import util  # noqa: E402
 from metalign_amd import synth  # noqa: E402
 from metalign_amd._hip import Hip  # noqa: E402
 from metalign_amd.distributed import ShardJob  # noqa: E402
@@ -46,7 +48,7 @@ for kspec in (21, [21, 31, 51]):
         for ki, k in enumerate(ks):
             dbh, dbo = tabs[ki]
             oh, oc, otr, _ = oracle.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
-            nfiltered = len(oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])  # the job sketches through the table's filter
+            nfiltered = util.job_sketch_size(oracle, job, ki, rb, ro, k, dbh)  # the job sketches through the table's filter or index
             ohits, osizes = oracle.containment(oh, oc, otr, 2, dbh, dbo)
             if not (np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes)):
                 bad = np.nonzero(got["hits_k"][ki] != ohits)[0]

@@ -16,6 +16,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import oracle  # noqa: E402
+import util  # noqa: E402
 from metalign_amd import synth  # noqa: E402
 from metalign_amd._hip import Hip  # noqa: E402
 from metalign_amd.distributed import ShardJob  # noqa: E402
@@ -58,7 +59,8 @@ for kspec, s_cut in ((21, 0), ([21, 31, 51], 0), (21, 500), ([21, 31, 51], 700))
             fh, fc, ftr, _ = oracle.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()), s=s_cut)  # the job's sketch
             ohits, osizes = oracle.containment(fh, fc, ftr, 2, dbh, dbo)
             assert np.array_equal(got["hits_k"][ki], ohits) and np.array_equal(got["sizes_k"][ki], osizes), (rank, idx, k, s_cut)
-            assert got["sketch_sizes"][ki] == len(fh), (rank, k, s_cut, got["sketch_sizes"][ki], len(fh))
+            nsk = util.job_sketch_size(oracle, job, ki, rb, ro, k, dbh, s_cut)  # (the table's filter, or its resident index)
+            assert got["sketch_sizes"][ki] == nsk, (rank, k, s_cut, got["sketch_sizes"][ki], nsk, len(fh))
             assert not s_cut or (ftr and len(fh) == s_cut), (k, s_cut, len(fh))  # (the cut is exercised)
         for key in ("count", "bases", "first_seen"):
             assert np.array_equal(got[key], want[key]), (rank, idx, key)

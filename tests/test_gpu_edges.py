@@ -125,7 +125,7 @@ def test_pipelined_run_equals_single_steps(hip, oracle_lib):
     piped = job.run(4, want_multimapped=True)  # single shard: every pass is queued before the previous one is read back
     again = job.step(want_multimapped=True)
     oh, oc, otr, _ = oracle_lib.sketch_reads(rb, ro, k, hmax=int(dbh.max()))
-    nfiltered = len(oracle_lib.sketch_reads_filtered(rb, ro, k, dbh, hmax=int(dbh.max()))[0])  # the job's sketch
+    nfiltered = util.job_sketch_size(oracle_lib, job, 0, rb, ro, k, dbh)  # the job's sketch
     ohits, osizes = oracle_lib.containment(oh, oc, otr, 2, dbh, dbo)
     want_c = oracle_lib.profile_assign(recs, ref2tax, 41, 0.5)
     for got in (one, piped, again):

@@ -676,10 +676,15 @@ def test_resident_index_sketches_are_the_exact_intersection(hip, oracle_lib, ks)
             one = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, hmaxs[i], 0, filt=filts[i])
             h1, c1 = one.download()
             assert np.array_equal(h1, eh) and np.array_equal(c1, ec), (k, rep)
-            # a threshold above the table's largest hash changes nothing; bottom-s cuts after the intersection
-            cut = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, (1 << 64) - 1, 50, filt=filts[i])
+            # a threshold above the table's largest hash changes nothing; a bottom-s sketch keeps the bit filter's definition
+            cut = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, (1 << 64) - 1, 0, filt=filts[i])
             h2, c2 = cut.download()
-            assert np.array_equal(h2, eh[:50]) and np.array_equal(c2, ec[:50]) and cut.truncated == int(len(eh) > 50)
+            assert np.array_equal(h2, eh) and np.array_equal(c2, ec)
+            cut.free()
+            cut = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, hmaxs[i], 50, filt=filts[i])
+            h2, c2 = cut.download()
+            fh, fc, ftr, _ = oracle_lib.sketch_reads_filtered(bases, offsets, k, tabs[i][0], hmax=hmaxs[i], s=50)
+            assert np.array_equal(h2, fh) and np.array_equal(c2, fc) and cut.truncated == ftr
             hits, sizes = hip.containment(sks[i], tables[i], 2)
             uh, uc, utr, _ = oracle_lib.sketch_reads(bases, offsets, k, hmax=hmaxs[i], s=0)
             ohits, osizes = oracle_lib.containment(uh, uc, utr, 2, *tabs[i])

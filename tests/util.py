@@ -42,3 +42,14 @@ def sample_reads(rng, gbases, goffsets, nreads, readlen, err=0.01, ragged=False,
         m = rng.random(out.size) < 0.1
         out[m] = out[m] | 0x20
     return out, offsets, src
+
+
+def job_sketch_size(oracle, job, ki, bases, offsets, k, table_hashes, s=0):
+    """How many hashes the read sketch of a ShardJob holds for its k number ki: what passes the table's bit filter — or, when
+    the job has built the table's resident index (dense tables, s = 0), exactly the read k-mers that are hashes of the table."""
+    filt = job.engine.filters[ki] if ki < len(job.engine.filters) else None
+    hmax = int(table_hashes.max())
+    if s == 0 and filt is not None and filt.resident_bytes > 0:
+        h = oracle.sketch_reads(bases, offsets, k, hmax=hmax)[0]
+        return int(np.isin(h, table_hashes).sum())
+    return len(oracle.sketch_reads_filtered(bases, offsets, k, table_hashes, hmax=hmax, s=s)[0])

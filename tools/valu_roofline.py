@@ -89,7 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm")
     ap.add_argument("classes")
-    ap.add_argument("--kernel", default="KListIJLi21ELi31ELi51EEEELi0E")
+    ap.add_argument("--kernel", default="20k_sketch_reads_multiINS_5KListIJLi21ELi31ELi51EEEELi0E")  # (not ..._resident)
     ap.add_argument("--waves", type=int, default=8, help="column of the ubench table (8: issue cost with latencies covered)")
     ap.add_argument("--read_len", type=int, default=150)
     ap.add_argument("--ks", default="21,31,51")
