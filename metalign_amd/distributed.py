@@ -344,7 +344,8 @@ class HipEngine:
         # stage-A streams here: worse at every setting)
         # (round 3: the fused multi-k kernel is held to 128 VGPRs — four of its workgroups per CU take the WHOLE register
         # file and every other kernel of the tick waits for one of them to retire: three per CU.  configs[3] shapes at world
-        # size 1, ms per pass: 4 -> 54.1, 3 -> 52.2, 2 -> 61.1.  MG_STAGE_A_WG_PER_CU overrides, for measurements)
+        # size 1, ms per pass: 4 -> 54.1, 3 -> 52.2, 2 -> 61.1; with the table's resident index 3 -> 39.5, 4 -> 39.1, and the two
+        # stage-A streams in turn 39.6 / 39.0: still no better.  MG_STAGE_A_WG_PER_CU overrides, for measurements)
         self.hip.stage_a_workgroups_per_cu(int(os.environ.get("MG_STAGE_A_WG_PER_CU", self.wg_per_cu_exchange)))
         self.hip.stage_a_side_stream(True)
 

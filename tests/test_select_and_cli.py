@@ -428,3 +428,33 @@ def test_stream_reads_file_retries_and_falls_back(tmp_path):
     with pytest.raises(_hip.HipError):
         select_db.stream_reads_file(hip, str(fq), "fastq", [21], [1], 0, [None])
     assert select_db.expected_bases(str(fq), "fastq") == os.path.getsize(fq) // 2 + 1
+
+
+def test_when_a_job_builds_the_resident_index(monkeypatch):
+    """HipEngine.wants_resident_index: forced by MG_RESIDENT_INDEX, otherwise for tables whose largest hash lets at least
+    5 % of all k-mers through (under either hash definition) and whose indexes fit half of the free HBM."""
+    from metalign_amd import distributed
+
+    class FakeHip:
+        hash_mode = 0
+
+        def __init__(self, free):
+            self.free = free
+
+        def mem_info(self):
+            return self.free, 288 << 30, 0
+
+    eng = distributed.HipEngine(FakeHip(200 << 30))
+    eng.nk = 3
+    monkeypatch.delenv("MG_RESIDENT_INDEX", raising=False)
+    dense, sparse = int(0.22 * 2 ** 64), int(0.02 * 2 ** 64)
+    assert eng.wants_resident_index(dense, 200_000_000)
+    assert not eng.wants_resident_index(sparse, 200_000_000)
+    assert not eng.wants_resident_index(dense, 2_000_000_000)      # 3 k x 2 copies x 48 B x 2e9 hashes do not fit
+    eng.hip.hash_mode = 1                                          # hashes below 9999999999971: the same share of them
+    assert eng.wants_resident_index(int(0.22 * 9999999999971), 1000)
+    assert not eng.wants_resident_index(int(0.01 * 9999999999971), 1000)
+    monkeypatch.setenv("MG_RESIDENT_INDEX", "0")
+    assert not eng.wants_resident_index(dense, 1000)
+    monkeypatch.setenv("MG_RESIDENT_INDEX", "1")
+    assert eng.wants_resident_index(sparse, 1000)
