@@ -171,8 +171,14 @@ class HipEngine:
         buffers from the distinct-to-candidate ratio of the PREVIOUS batch of the same k and has none yet — without this,
         every pass a pipelined job queues before its first read-back is sized for the worst case (a dense 200k-genome
         table: 13 GB of table and 5 GB of sketch per k and pass in flight, against 1-2 GB once the ratio is known)."""
-        for sk in self.sketch_local(ks, hmaxs, s):
-            sk.free()
+        # (on the first stage-A stream, where a pipelined job's passes run: a table's resident index keeps one copy per
+        # stream that has sketched with it, 8 GB per k at 200k genomes — the main stream need not own one)
+        self.hip.stage_a_side_stream(True)
+        try:
+            for sk in self.sketch_local(ks, hmaxs, s):
+                sk.free()
+        finally:
+            self.hip.stage_a_side_stream(False)
 
     def sketch_local_async(self, ks, hmaxs, s):
         """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set)."""
@@ -345,7 +351,8 @@ class HipEngine:
         # (round 3: the fused multi-k kernel is held to 128 VGPRs — four of its workgroups per CU take the WHOLE register
         # file and every other kernel of the tick waits for one of them to retire: three per CU.  configs[3] shapes at world
         # size 1, ms per pass: 4 -> 54.1, 3 -> 52.2, 2 -> 61.1; with the table's resident index 3 -> 39.5, 4 -> 39.1, and the two
-        # stage-A streams in turn 39.6 / 39.0: still no better.  MG_STAGE_A_WG_PER_CU overrides, for measurements)
+        # stage-A streams in turn 39.6 / 39.0: still no better (traced: two hashing kernels side by side take 41 ms each and
+        # starve the radix sort of the touched-hash lists, 16 ms).  MG_STAGE_A_WG_PER_CU overrides, for measurements)
         self.hip.stage_a_workgroups_per_cu(int(os.environ.get("MG_STAGE_A_WG_PER_CU", self.wg_per_cu_exchange)))
         self.hip.stage_a_side_stream(True)
 

@@ -749,3 +749,38 @@ def test_resident_index_list_overflow_and_slot_walk(hip, oracle_lib, hook, monke
             x.free()
     for f in filts:
         f.free()
+
+
+def test_resident_index_with_passes_in_flight_on_two_streams(hip, oracle_lib):
+    """Two sketch calls in flight on the library's two stage-A streams count in two COPIES of the index (the second made on
+    that stream's first use), each call under an epoch of its own; a third call reuses the first stream's copy while the
+    other stream's sketch is still unresolved.  Every sketch is the exact intersection of ITS reads with the table."""
+    rng = np.random.default_rng(2025)
+    ks = (21, 31, 51)
+    gb, go = util.random_genomes(rng, 30, 6000)
+    tabs = [oracle_lib.sketch_genomes(gb, go, k, 900) for k in ks]
+    hmaxs = [int(t[0].max()) for t in tabs]
+    filts = [hip.filter_build(t[0]) for t in tabs]
+    for f, t, hm in zip(filts, tabs, hmaxs):
+        assert f.make_resident(t[0], hm)
+    one_copy = [f.resident_bytes for f in filts]
+    samples = []
+    for present in (np.arange(0, 10), np.arange(10, 30), np.arange(5, 12)):
+        bases, offsets, _ = util.sample_reads(rng, gb, go, 40000, 150, err=0.01, present=present)
+        samples.append((bases, offsets, hip.array(bases), hip.array(offsets)))
+    try:
+        queued = []
+        for which, (bases, offsets, d_b, d_o) in zip((1, 2, 1), samples):
+            hip.stage_a_side_stream(which)
+            queued.append(hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, 40000, list(ks), hmaxs, 0, filts))
+    finally:
+        hip.stage_a_side_stream(0)
+    assert [f.resident_bytes for f in filts] == [2 * b for b in one_copy]
+    for (bases, offsets, _, _), sks in zip(samples, queued):
+        for i, k in enumerate(ks):
+            eh, ec, seen = _exact_sketch(oracle_lib, bases, offsets, k, tabs[i][0], hmaxs[i])
+            h, c = sks[i].download()
+            assert np.array_equal(h, eh) and np.array_equal(c, ec) and sks[i].kmers_seen == seen, k
+            sks[i].free()
+    for f in filts:
+        f.free()
