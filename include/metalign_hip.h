@@ -250,9 +250,10 @@ unsigned mg_filter_log2_bits(const mg_filter* f);
  * wrote them.  Sketch calls given this filter then cost a candidate ONE random 16-byte access (found: counted; not
  * found: not a hash of the table, dropped) instead of a home slot plus a filter word, and no table clear; the sketch
  * holds exactly the read k-mers that are hashes of the table (the bit filter lets ~6 % of the others through), so
- * containment is unchanged.  16 bytes x 2 to 4 slots per hash, once per stream that sketches with it.
+ * containment is unchanged.  16 bytes x 2 to 4 slots per hash (x 2^spread, spread in [0,3]: at a lower load fewer
+ * candidates have to look a slot further), once per stream that sketches with it.
  * MG_ERR_CAPACITY: the hashes crowd some range (a bucket without a free slot) — the filter stays a bit filter. */
-int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, uint64_t hmax);
+int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, uint64_t hmax, unsigned spread);
 uint64_t mg_filter_resident_bytes(const mg_filter* f);
 void mg_filter_free(mg_filter* f);
 int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets,

@@ -407,13 +407,13 @@ class Filter:
         self.hip._chk(self.hip.lib.mg_filter_download(self.handle, _np(bits, ctypes.c_uint32), ctypes.c_uint64(bits.nbytes)))
         return bits
 
-    def make_resident(self, hashes, hmax):
+    def make_resident(self, hashes, hmax, spread=0):
         """Seed the table's RESIDENT INDEX from all its hashes (mg_filter_make_resident): sketch calls given this filter then
         count in it — one random access per candidate, no filter word, no table clear.  False when the hashes crowd some
-        range (the filter stays a bit filter); raises on anything else."""
+        range (the filter stays a bit filter); raises on anything else.  spread = 1: half the load, twice the memory."""
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         rc = self.hip.lib.mg_filter_make_resident(self.handle, _np(hashes if hashes.size else np.zeros(1, np.uint64), ctypes.c_uint64),
-                                                  ctypes.c_uint64(hashes.size), ctypes.c_uint64(int(hmax)))
+                                                  ctypes.c_uint64(hashes.size), ctypes.c_uint64(int(hmax)), ctypes.c_uint(int(spread)))
         if rc == ERR_CAPACITY:
             return False
         self.hip._chk(rc)

@@ -454,6 +454,13 @@ def test_when_a_job_builds_the_resident_index(monkeypatch):
     eng.hip.hash_mode = 1                                          # hashes below 9999999999971: the same share of them
     assert eng.wants_resident_index(int(0.22 * 9999999999971), 1000)
     assert not eng.wants_resident_index(int(0.01 * 9999999999971), 1000)
+    # ... at half the load (twice the memory) when that fits too
+    monkeypatch.delenv("MG_RESIDENT_SPREAD", raising=False)
+    assert eng.resident_spread(1000) == 1 and eng.resident_spread(200_000_000) == 0
+    eng.hip.free = 280 << 30
+    assert eng.resident_spread(200_000_000) == 1
+    monkeypatch.setenv("MG_RESIDENT_SPREAD", "0")
+    assert eng.resident_spread(1000) == 0
     monkeypatch.setenv("MG_RESIDENT_INDEX", "0")
     assert not eng.wants_resident_index(dense, 1000)
     monkeypatch.setenv("MG_RESIDENT_INDEX", "1")

@@ -33,7 +33,7 @@ def run(hm, fl, label):
 run(hmaxs, filts, "thresholds + filters of the table:")
 if os.environ.get("MG_PROBE_RESIDENT", "1") != "0":
     res = [hip.filter_build(t) for t in tables]
-    ok = [f.make_resident(t, hm) for f, t, hm in zip(res, tables, hmaxs)]
+    ok = [f.make_resident(t, hm, int(os.environ.get("MG_PROBE_SPREAD", "0"))) for f, t, hm in zip(res, tables, hmaxs)]
     print("resident indexes: %s, %.2f GB" % (ok, sum(f.resident_bytes for f in res) / 1e9), flush=True)
     run(hmaxs, res, "thresholds + resident indexes of the table:")
     for ab, what in ((1, "a flush drops its candidates"), (2, "looks them up, counts nothing, none goes round again"),
