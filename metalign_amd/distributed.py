@@ -363,7 +363,9 @@ class HipEngine:
         # size 1, ms per pass: 4 -> 54.1, 3 -> 52.2, 2 -> 61.1; with the table's resident index 3 -> 39.5, 4 -> 39.1, and the two
         # stage-A streams in turn 39.6 / 39.0: still no better (traced: two hashing kernels side by side take 41 ms each and
         # starve the radix sort of the touched-hash lists, 16 ms).  MG_STAGE_A_WG_PER_CU overrides, for measurements)
-        self.hip.stage_a_workgroups_per_cu(int(os.environ.get("MG_STAGE_A_WG_PER_CU", self.wg_per_cu_exchange)))
+        # (... and with the index at half load 3 -> 36.7, 4 -> 35.6, 5 -> 35.7: four for a job that counts in resident indexes)
+        resident = any(f is not None and f.resident_bytes for f in self.filters)
+        self.hip.stage_a_workgroups_per_cu(int(os.environ.get("MG_STAGE_A_WG_PER_CU", 4 if resident else self.wg_per_cu_exchange)))
         self.hip.stage_a_side_stream(True)
 
     def x_end(self):
