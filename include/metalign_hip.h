@@ -467,6 +467,13 @@ int mg_profile_multimapped(const mg_profile* p, uint64_t* mm_offsets,
  * host computation to ~1e-15 relative, not bit for bit. */
 int mg_profile_resolve_multimapped_dev(const mg_profile* p, const double* d_weight,
                                        const double* d_genome_len, double* d_extra);
+/* The same on the HOST, from the CSR mg_profile_multimapped returned, in the reference's order of additions — per read the
+ * distinct taxa that still have a weight, ascending, share the read's hitlen in proportion to their weights; a taxon's
+ * additions are summed read after read (:290-311) — so the result is the host tail's own, bit for bit (the default tail;
+ * the device version above is the option).  weight[t] NaN = no entry; genome_len NULL unless --length_normalize;
+ * extra[ntax] and touched[ntax] are overwritten.  Plain host code: needs no device and no mg_init. */
+int mg_multimapped_shares(const uint64_t* mm_offsets, uint64_t nreads, const uint32_t* mm_tax, const uint64_t* mm_hitlen,
+                          const double* weight, uint32_t ntax, const double* genome_len, double* extra, uint8_t* touched);
 void mg_profile_free(mg_profile* p);
 
 /* SAM text in HBM -> alignment records (mg_aln_rec), one per retained line, in file order.

@@ -39,7 +39,7 @@ EXPORTS = [
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
-    "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_profile_free", "mg_profile_assign",
+    "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_multimapped_shares", "mg_profile_free", "mg_profile_assign",
 ]
 
 
@@ -96,6 +96,32 @@ def load_library(path=LIB_PATH):
 
 
 _READS_FORMAT = {"fastq": 0, "fasta": 1, "fasta_ml": 2}
+
+_host_lib = None
+
+
+def multimapped_shares(mm_offsets, mm_tax, mm_hitlen, weight, genome_len=None):
+    """mg_multimapped_shares: resolve_multi_prop's additions per taxon from the multimapped CSR, in the reference's order of
+    additions (host code of the library: no device involved).  -> (extra float64[ntax], touched bool[ntax])."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    off = np.ascontiguousarray(mm_offsets, dtype=np.uint64)
+    tax = np.ascontiguousarray(mm_tax, dtype=np.uint32)
+    hl = np.ascontiguousarray(mm_hitlen, dtype=np.uint64)
+    w = np.ascontiguousarray(weight, dtype=np.float64)
+    gl = np.ascontiguousarray(genome_len, dtype=np.float64) if genome_len is not None else None
+    extra = np.zeros(len(w), dtype=np.float64)
+    touched = np.zeros(len(w), dtype=np.uint8)
+    one = np.zeros(1, dtype=np.uint64)
+    rc = _host_lib.mg_multimapped_shares(_np(off if off.size else one, ctypes.c_uint64), ctypes.c_uint64(len(hl)),
+                                         _np(tax if tax.size else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                         _np(hl if hl.size else one, ctypes.c_uint64), _np(w, ctypes.c_double),
+                                         ctypes.c_uint32(len(w)), _np(gl, ctypes.c_double) if gl is not None else None,
+                                         _np(extra, ctypes.c_double), _np(touched, ctypes.c_uint8))
+    if rc != 0:
+        raise HipError("libmetalign_hip rc=%d: %s" % (rc, _host_lib.mg_last_error().decode("utf-8", "replace")), rc)
+    return extra, touched.astype(bool)
 
 
 class DeviceArray:

@@ -32,6 +32,9 @@
 // multi-GPU job needs from every shard before any of them can commit.
 #include <memory>
 
+#include <algorithm>
+#include <vector>
+
 #include "mg_internal.h"
 
 namespace mg {
@@ -1173,6 +1176,38 @@ int mg_profile_commit_dev(mg_profile* p, int incoming_dropped, int first_shard, 
 int mg_profile_commit_reset_dev(mg_profile* p, int incoming_dropped, int first_shard, uint64_t group_base,
                                 uint64_t* d_count, uint64_t* d_bases, uint64_t* d_first_seen, uint64_t* d_scalars) {
   return commit_impl(p, incoming_dropped, first_shard, group_base, d_count, d_bases, d_first_seen, d_scalars, true);
+}
+
+// (host code: every rounding is the reference's — no fused multiply-add between the share and the sum it goes into)
+#pragma clang fp contract(off)
+int mg_multimapped_shares(const uint64_t* mm_offsets, uint64_t nreads, const uint32_t* mm_tax, const uint64_t* mm_hitlen,
+                          const double* weight, uint32_t ntax, const double* genome_len, double* extra, uint8_t* touched) {
+  if (!extra || !touched || !weight || (nreads && (!mm_offsets || !mm_tax || !mm_hitlen)))
+    return fail(MG_ERR_ARG, "null argument");
+  for (uint32_t t = 0; t < ntax; ++t) { extra[t] = 0.0; touched[t] = 0; }
+  std::vector<uint32_t> taxa;
+  for (uint64_t i = 0; i < nreads; ++i) {
+    taxa.clear();
+    for (uint64_t e = mm_offsets[i]; e < mm_offsets[i + 1]; ++e) {
+      const uint32_t t = mm_tax[e];
+      if (t >= ntax) return fail(MG_ERR_ARG, "multimapped taxon %u outside [0,%u)", t, ntax);
+      if (weight[t] == weight[t]) taxa.push_back(t);  // (not NaN: the taxon still has an entry)
+    }
+    if (taxa.empty()) continue;
+    std::sort(taxa.begin(), taxa.end());
+    taxa.erase(std::unique(taxa.begin(), taxa.end()), taxa.end());
+    double denom = 0.0;
+    for (uint32_t t : taxa) denom += weight[t];
+    if (denom == 0.0) continue;
+    const double hitlen = (double)mm_hitlen[i];
+    for (uint32_t t : taxa) {
+      double part = (weight[t] / denom) * hitlen;
+      if (genome_len) part = part / genome_len[t];
+      extra[t] += part;
+      touched[t] = 1;
+    }
+  }
+  return MG_OK;
 }
 
 int mg_profile_resolve_multimapped_dev(const mg_profile* p, const double* d_weight, const double* d_genome_len,

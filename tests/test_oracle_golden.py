@@ -83,3 +83,34 @@ def test_vectorised_multimap_resolution_equals_list_version(tmp_path):
                 assert abs(want[k][1] - got[k][1]) <= 1e-12 * max(1.0, abs(want[k][1]))
             else:
                 assert want[k] == got[k], k
+
+
+def test_library_multimap_resolution_equals_numpy_bit_for_bit():
+    """mg_multimapped_shares (the library's host routine behind resolve_multi_prop_csr) against the numpy version it
+    replaced, on random CSRs: repeated taxa within a read, taxa without an entry (NaN), reads left empty, zero weights,
+    fractional weights (length-normalised runs) and genome lengths — every taxon's sum bit for bit."""
+    import argparse
+    import copy
+    from metalign_amd import map_and_profile as mp
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        T = int(rng.integers(3, 60))
+        taxids = ["t%d" % i for i in range(T)]
+        nreads = int(rng.integers(0, 4000))
+        lens = rng.integers(0, 7, size=nreads)
+        off = np.zeros(nreads + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        tax = rng.integers(0, T, size=int(off[-1])).astype(np.uint32)
+        hitlen = rng.integers(30, 151, size=nreads).astype(np.uint64)
+        t2a, t2i = {}, {}
+        for i, t in enumerate(taxids):
+            t2i[t] = [float(rng.integers(1000, 9000)), "strain", "x|y"]
+            if rng.random() < 0.7:
+                w = 0.0 if rng.random() < 0.1 else (float(rng.integers(1, 10**6)) if trial % 2 == 0 else float(rng.random() * 1e3))
+                t2a[t] = [int(rng.integers(1, 100)), w] + t2i[t]
+        mm = dict(taxids=taxids, mm_offsets=off, mm_tax=tax, mm_hitlen=hitlen)
+        for ln in (False, True):
+            args = argparse.Namespace(verbose=False, length_normalize=ln)
+            got = mp.resolve_multi_prop_csr(args, copy.deepcopy(t2a), mm, t2i)
+            want = mp.resolve_multi_prop_csr_numpy(args, copy.deepcopy(t2a), mm, t2i)
+            assert got == want, (trial, ln)
