@@ -436,11 +436,11 @@ class Filter:
     def make_resident(self, hashes, hmax, spread=0):
         """Seed the table's RESIDENT INDEX from all its hashes (mg_filter_make_resident): sketch calls given this filter then
         count in it — one random access per candidate, no filter word, no table clear.  False when the hashes crowd some
-        range (the filter stays a bit filter); raises on anything else.  spread = 1: half the load, twice the memory."""
+        range or the device has no room for it (the filter stays a bit filter); raises on anything else.  spread = 1: half the load, twice the memory."""
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         rc = self.hip.lib.mg_filter_make_resident(self.handle, _np(hashes if hashes.size else np.zeros(1, np.uint64), ctypes.c_uint64),
                                                   ctypes.c_uint64(hashes.size), ctypes.c_uint64(int(hmax)), ctypes.c_uint(int(spread)))
-        if rc == ERR_CAPACITY:
+        if rc in (ERR_CAPACITY, ERR_NOMEM):  # (no room for the index either: the filter stays what it was)
             return False
         self.hip._chk(rc)
         return True
