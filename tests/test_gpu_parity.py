@@ -785,3 +785,34 @@ def test_resident_index_with_passes_in_flight_on_two_streams(hip, oracle_lib):
             sks[i].free()
     for f in filts:
         f.free()
+
+
+def test_resident_index_under_the_cmash_hash_definition(hip, oracle_lib, cmash_mode):
+    """Hash definition 1 (hashes below 9999999999971) with PREFIX tables for the smaller k — every read k-mer is a candidate
+    there, the regime the resident index is for: the fused launch, the one-k kernel and a k set without a fused kernel
+    against the exact intersection of the oracle's sketch (same definition) with the table."""
+    rng = np.random.default_rng(1971)
+    gb, go = util.random_genomes(rng, 10, 5000)
+    for ks in ((21, 31, 51), (24, 36)):
+        full = oracle_lib.sketch_genomes(gb, go, ks[-1], 400)
+        tabs = [oracle_lib.sketch_genomes_prefix(gb, go, ks[-1], k, 400) for k in ks[:-1]] + [full]
+        hmaxs = [int(t[0].max()) for t in tabs]
+        assert hmaxs[0] > 0.5 * oracle_lib.CMASH_PRIME  # (a prefix table's largest key is near the prime)
+        filts = [hip.filter_build(t[0]) for t in tabs]
+        for f, t, hm in zip(filts, tabs, hmaxs):
+            assert f.make_resident(t[0], hm, 1)
+        for nreads, present in ((8000, [1, 4]), (500, list(range(10)))):
+            bases, offsets, _ = util.sample_reads(rng, gb, go, nreads, 150, err=0.01, present=present)
+            d_b, d_o = hip.array(bases), hip.array(offsets)
+            sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, nreads, list(ks), hmaxs, 0, filts)
+            for i, k in enumerate(ks):
+                eh, ec, seen = _exact_sketch(oracle_lib, bases, offsets, k, tabs[i][0], hmaxs[i])
+                h, c = sks[i].download()
+                assert len(eh) > 0 and np.array_equal(h, eh) and np.array_equal(c, ec) and sks[i].kmers_seen == seen, (ks, k)
+                one = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, nreads, k, hmaxs[i], 0, filt=filts[i])
+                h1, c1 = one.download()
+                assert np.array_equal(h1, eh) and np.array_equal(c1, ec), (ks, k)
+                one.free()
+                sks[i].free()
+        for f in filts:
+            f.free()
