@@ -156,6 +156,8 @@ class HipEngine:
         (genomes of a few kb, or a mixed table: stage A is then bound by its random look-ups, not by its hashing) and
         the indexes of all k (32 to 64 bytes per hash, once per stream that sketches: two for a pipelined job) fit half of
         the free HBM."""
+        if getattr(self, "bottom_s", 0):
+            return False  # (the library would not use it: bottom-s sketches are cut from what passes the FILTER)
         e = os.environ.get("MG_RESIDENT_INDEX", "auto")
         if e in ("0", "1"):
             return e == "1"
@@ -609,6 +611,7 @@ class ShardJob:
         K = len(self.ks)
         if hasattr(self.engine, "wants_resident_index"):
             self.engine.nk = K  # (its memory estimate covers every k's index)
+            self.engine.bottom_s = self.s  # (a bottom-s sketch keeps the bit filter's definition: no index then)
         self.T = int(ntax) if ntax is not None else (int(np.max(ref2tax)) + 1 if len(ref2tax) else 0)
         tables, self.hmaxs, self.bounds = [], [], []
         if hasattr(dbh, "pairs"):  # an on-disk hash-major table (formats.SketchTable, version 2)

@@ -465,3 +465,5 @@ def test_when_a_job_builds_the_resident_index(monkeypatch):
     assert not eng.wants_resident_index(dense, 1000)
     monkeypatch.setenv("MG_RESIDENT_INDEX", "1")
     assert eng.wants_resident_index(sparse, 1000)
+    eng.bottom_s = 500                                             # a bottom-s job: the library would not use the index
+    assert not eng.wants_resident_index(dense, 1000)
