@@ -538,6 +538,11 @@ def main():
             "sanity": {"top_genomes_recovered": out.get("top_ok"), "tot_rds": out.get("tot_rds"),
                        "sketch_sizes": out.get("sketch_sizes")},
         }
+        # a dense table (>= 5 % of all k-mers pass its threshold: configs[3]'s 5 kb genomes) gets a resident index at load
+        # (DESIGN.md §4): stage A then counts in it, and the sketch is the exact intersection with the table
+        resident = sum(f.resident_bytes for f in getattr(job.engine, "filters", []) if f is not None)
+        res["config"]["stage_a_tables"] = ("resident index of the genome table, %.1f GB in HBM" % (resident / 1e9)) if resident \
+            else "counting tables per pass + the table's membership filter"
         if world > 1:
             # the default workload differs between N = 1 (configs[2]) and N > 1 (configs[3] shapes): the figure this
             # line's per-GPU workload gives on ONE GPU (world 1, same collectives in the path), as committed
