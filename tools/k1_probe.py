@@ -11,6 +11,8 @@ G = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000
 ks = [int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [21, 31, 51]
 hip = Hip.get(0)
+if os.environ.get("MG_PROBE_HASH_MODE"):  # 1: min(hash(kmer), hash(revcomp)) % 9999999999971 — two hashes per k-mer
+    hip.set_hash_mode(int(os.environ["MG_PROBE_HASH_MODE"]))
 if os.environ.get("MG_PROBE_CS"):  # counters saturate here (default 3): fewer memory-side atomics per distinct hash at 1
     hip.count_saturation(int(os.environ["MG_PROBE_CS"]))
 gb, go = synth.make_genomes(G, L)
@@ -43,4 +45,5 @@ if os.environ.get("MG_PROBE_RESIDENT", "1") != "0":
     del os.environ["MG_DEBUG_RESIDENT_ABLATE"]
     for f in res: f.free()
 run(hmaxs, None, "thresholds, no filter:")
-run([int(3e-5 * 2 ** 64)] * len(ks), None, "thresholds that pass ~45 k k-mers per k (pure hashing):")
+span = 9999999999971 if os.environ.get("MG_PROBE_HASH_MODE") == "1" else 2 ** 64
+run([int(3e-5 * span)] * len(ks), None, "thresholds that pass ~45 k k-mers per k (pure hashing):")
