@@ -254,6 +254,7 @@ unsigned mg_filter_log2_bits(const mg_filter* f);
  * candidates have to look a slot further), once per stream that sketches with it.
  * MG_ERR_CAPACITY: the hashes crowd some range (a bucket without a free slot) — the filter stays a bit filter. */
 int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, uint64_t hmax, unsigned spread);
+int mg_filter_drop_resident(mg_filter* f);   /* back to a bit filter (sketches made with it must have been resolved) */
 uint64_t mg_filter_resident_bytes(const mg_filter* f);
 void mg_filter_free(mg_filter* f);
 int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets,

@@ -1324,6 +1324,15 @@ int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, ui
   return MG_OK;
 }
 
+// The filter back to a bit filter: its resident index (every copy) is freed.
+int mg_filter_drop_resident(mg_filter* f) {
+  MG_REQUIRE_READY();
+  if (!f) return fail(MG_ERR_ARG, "null argument");
+  if (f->resident) MG_HIP(hipDeviceSynchronize());  // (sketches in flight may still be counting in it)
+  f->resident.reset();
+  return MG_OK;
+}
+
 // Bytes of HBM the filter's resident index holds (every copy), 0 without one.
 uint64_t mg_filter_resident_bytes(const mg_filter* f) {
   return f && f->resident ? f->resident->slots * sizeof(mg::Slot) * f->resident->copies.size() : 0;

@@ -185,12 +185,39 @@ class HipEngine:
         table: 13 GB of table and 5 GB of sketch per k and pass in flight, against 1-2 GB once the ratio is known)."""
         # (on the first stage-A stream, where a pipelined job's passes run: a table's resident index keeps one copy per
         # stream that has sketched with it, 8 GB per k at 200k genomes — the main stream need not own one)
-        self.hip.stage_a_side_stream(True)
-        try:
+        import time
+
+        def one_pass():
+            self.hip.sync()
+            t0 = time.perf_counter()
             for sk in self.sketch_local(ks, hmaxs, s):
                 sk.free()
+            return time.perf_counter() - t0
+        self.hip.stage_a_side_stream(True)
+        try:
+            one_pass()
+            if any(f is not None and f.resident_bytes for f in self.filters[: len(ks)]) and \
+                    os.environ.get("MG_RESIDENT_INDEX", "auto") != "1":
+                # The index pays when most candidates ARE hashes of the table (a sample of the table's genomes, thresholds
+                # near the genomes' own); when most are not — hash definition 1's prefix tables, where every k-mer is a
+                # candidate and 2 % of a present genome's are members — the bit filter's one cached word rejects them for
+                # less.  Which it is depends on the sample: measured, stage A once more each way (the caller drops the loser).
+                with_index = one_pass()
+                os.environ["MG_DEBUG_NO_RESIDENT"] = "1"  # (read by the library at every call)
+                try:
+                    one_pass()  # (the first pass of this form sizes its tables for the worst case)
+                    with_filter = one_pass()
+                finally:
+                    del os.environ["MG_DEBUG_NO_RESIDENT"]
+                return with_index, with_filter
         finally:
             self.hip.stage_a_side_stream(False)
+        return None
+
+    def drop_resident_indexes(self):
+        for f in self.filters:
+            if f is not None and f.resident_bytes:
+                f.drop_resident()
 
     def sketch_local_async(self, ks, hmaxs, s):
         """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set)."""
@@ -668,8 +695,24 @@ class ShardJob:
         else:
             self.nonempty = [len(recs) > 0]
         self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
-        if hasattr(self.engine, "prime") and len(roffsets) > 1:
-            self.engine.prime(self.ks, self.hmaxs, self.s)
+        if hasattr(self.engine, "prime") and (len(roffsets) > 1 or self.exchange):
+            choice = self.engine.prime(self.ks, self.hmaxs, self.s) if len(roffsets) > 1 else None
+            resident = any(f is not None and f.resident_bytes for f in getattr(self.engine, "filters", []))
+            drop = resident and choice is not None and choice[1] < choice[0]
+            if self.exchange and self.world > 1:
+                # every rank takes the same side (the ranks' sketches are slices of ONE sketch): an index everywhere or
+                # nowhere (a rank may have had no room for it), and the SUM of the ranks' timings decides
+                t = self.torch
+                v = t.as_tensor([1.0 if resident else 0.0] + (list(choice) if choice else [0.0, 0.0]), dtype=t.float64,
+                                device=self.device)
+                self.dist.all_reduce(v)
+                have, with_index, with_filter = (float(x) for x in v.cpu())
+                drop = have < self.world or with_filter < with_index
+                choice = (with_index, with_filter) if have else None
+            if choice is not None:
+                self.resident_choice = dict(with_index_s=choice[0], with_filter_s=choice[1])
+            if drop and resident:
+                self.engine.drop_resident_indexes()
             # the priming pass was sized for the worst case (no distinct-count ratio yet: tens of GB against a dense
             # table); its blocks would stay cached for the life of the process
             if hasattr(self.engine, "hip"):

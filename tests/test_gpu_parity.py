@@ -816,3 +816,31 @@ def test_resident_index_under_the_cmash_hash_definition(hip, oracle_lib, cmash_m
                 sks[i].free()
         for f in filts:
             f.free()
+
+
+def test_dropping_a_resident_index_leaves_the_bit_filter(hip, oracle_lib):
+    """mg_filter_drop_resident (a job drops the index when its priming passes measure the bit filter faster — a sample most of
+    whose candidates are NOT hashes of the table): the memory is given back and sketches are the filter's again."""
+    rng = np.random.default_rng(31337)
+    gb, go = util.random_genomes(rng, 10, 6000)
+    k = 31
+    dbh, dbo = oracle_lib.sketch_genomes(gb, go, k, 900)
+    hmax = int(dbh.max())
+    bases, offsets, _ = util.sample_reads(rng, gb, go, 20000, 150, err=0.01)
+    d_b, d_o = hip.array(bases), hip.array(offsets)
+    filt = hip.filter_build(dbh)
+    assert filt.make_resident(dbh, hmax)
+    eh, ec, _ = _exact_sketch(oracle_lib, bases, offsets, k, dbh, hmax)
+    sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, 20000, k, hmax, 0, filt=filt)
+    h, c = sk.download()
+    assert np.array_equal(h, eh) and np.array_equal(c, ec)
+    sk.free()
+    filt.drop_resident()
+    assert filt.resident_bytes == 0
+    fh, fc, _, _ = oracle_lib.sketch_reads_filtered(bases, offsets, k, dbh, hmax=hmax)
+    sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, 20000, k, hmax, 0, filt=filt)
+    h, c = sk.download()
+    assert len(fh) > len(eh) and np.array_equal(h, fh) and np.array_equal(c, fc)
+    sk.free()
+    filt.drop_resident()  # (nothing to drop: fine)
+    filt.free()

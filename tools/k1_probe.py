@@ -19,6 +19,8 @@ gb, go = synth.make_genomes(G, L)
 rb, ro, _ = synth.make_reads(gb, go, R, npresent=max(50, G // 20))
 d_b, d_o = hip.array(rb), hip.array(ro)
 tables = [hip.sketch_genomes(gb, go, k, 1000)[0] for k in ks]
+if os.environ.get("MG_PROBE_PREFIX") == "1":  # hash definition 1's prefix tables for k < kmax: every read k-mer is a candidate
+    tables = [hip.sketch_genomes_prefix(gb, go, ks[-1], k, 1000)[0] for k in ks[:-1]] + tables[-1:]
 filts = [hip.filter_build(t) for t in tables]
 hmaxs = [int(t.max()) for t in tables]
 def run(hm, fl, label):
