@@ -178,6 +178,7 @@ inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks
 // ---- internal services implemented in mg_sort.hip (rocPRIM-backed plain library ops) ----
 // Sorts n u64 keys ascending using bits [0,end_bit). out may not alias in.
 int sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, unsigned end_bit);
+int sort_keys_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n);
 int sort_pairs(const uint64_t* d_kin, uint64_t* d_kout, const uint32_t* d_vin, uint32_t* d_vout, uint64_t n);
 // Run-length encode sorted keys -> (unique, counts, *d_runs); asynchronous, run count stays on the device.
 int rle_keys(const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* d_runs);
@@ -245,7 +246,7 @@ struct MultiKTable {  // one k of the launch: its threshold, counting table (alr
   unsigned shift;
   const mg_filter* filter;
   uint32_t epoch = 0;  // != 0: tab is a copy of the filter's resident index and this the epoch of the call
-  uint64_t* list = nullptr;  // ... and the list the kernel leaves the touched hashes in (filled with kReservedHash)
+  uint32_t* list = nullptr;  // ... and the list the kernel leaves the touched SLOTS in (filled with 0xffffffff)
   uint64_t listcap = 0;
 };
 // mg_sketch_cmash.hip: the one-k kernels instantiated for hash definition 1 (mg_set_hash_mode)

@@ -333,15 +333,18 @@ __global__ __launch_bounds__(256) void k_resident_sort_out(const Slot* __restric
   }
 }
 
-// ---- ... and the sketch from the LIST of hashes the pass touched (mg_sketch_dev.h: resident_list_append), sorted ----
-// An entry counts if it is a hash (the unused part of the list is kReservedHash, sorted to the end) and differs from its
-// predecessor (two lanes may have listed one hash).  nuniq[b] = such entries among the 256 of block b.
-__device__ __forceinline__ bool list_entry_counts(const uint64_t* __restrict__ sorted, uint64_t n, uint64_t i) {
+// ---- ... and the sketch from the LIST of slots the pass touched (mg_sketch_dev.h: resident_list_append), sorted ----
+// Sorted slot numbers are in hash order bucket by bucket (a bucket is a hash range) but not within a bucket (a slot is the
+// hash's low bits): k_list_keys fetches every listed slot's hash and counter, k_list_place puts the few entries of a bucket
+// in hash order.  An entry counts if it is a slot (the unused part of the list is kNoSlot, sorted to the end) and differs
+// from its predecessor (two lanes may have listed one slot).
+__device__ __forceinline__ bool list_entry_counts(const uint32_t* __restrict__ sorted, uint64_t n, uint64_t i) {
   if (i >= n) return false;
-  const uint64_t h = sorted[i];
-  return h != kReservedHash && (i == 0 || sorted[i - 1] != h);
+  const uint32_t s = sorted[i];
+  return s != kNoSlot && (i == 0 || sorted[i - 1] != s);
 }
-__global__ __launch_bounds__(256) void k_list_count(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t* __restrict__ nuniq) {
+// nuniq[b] = entries that count among the 256 of block b.
+__global__ __launch_bounds__(256) void k_list_count(const uint32_t* __restrict__ sorted, uint64_t n, uint32_t* __restrict__ nuniq) {
   __shared__ uint32_t s_n[4];
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const unsigned long long m = __ballot(list_entry_counts(sorted, n, i));
@@ -349,12 +352,12 @@ __global__ __launch_bounds__(256) void k_list_count(const uint64_t* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) nuniq[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
 }
-// ... written to its place in the sketch with its counter out of the index (found where the kernel found it: home slot,
-// or the slots after it).
-__global__ __launch_bounds__(256) void k_list_gather(const uint64_t* __restrict__ sorted, uint64_t n, const uint64_t* __restrict__ offs,
-                                                     const Slot* __restrict__ tab, unsigned shift, uint32_t epoch, uint32_t cs,
-                                                     uint64_t* __restrict__ out_hashes, uint32_t* __restrict__ out_counts,
-                                                     uint64_t out_cap) {
+// Per entry: how many entries before it count (before[i]), and the hash and counter of its slot (kReservedHash for an
+// entry that does not count).
+__global__ __launch_bounds__(256) void k_list_keys(const uint32_t* __restrict__ sorted, uint64_t n, const uint64_t* __restrict__ offs,
+                                                   const Slot* __restrict__ tab, uint32_t epoch, uint32_t cs,
+                                                   uint32_t* __restrict__ before, uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ cnts) {
   __shared__ uint32_t s_n[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -362,21 +365,43 @@ __global__ __launch_bounds__(256) void k_list_gather(const uint64_t* __restrict_
   const unsigned long long m = __ballot(mine);
   if (lane == 0) s_n[wave] = (uint32_t)__popcll(m);
   __syncthreads();
-  if (!mine) return;
+  if (i >= n) return;
   uint64_t at = offs[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   for (int w = 0; w < wave; ++w) at += s_n[w];
-  if (at >= out_cap) return;  // (reported by k_sketch_meta's cap)
-  const uint64_t h = sorted[i];
-  const Slot* bucket = tab + (h >> shift) * kBucketSlots;
+  before[i] = (uint32_t)at;
+  uint64_t key = kReservedHash;
   uint32_t seen = 0;
-  for (uint32_t t = 0; t <= kMaxHops; ++t) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(bucket + (((uint32_t)h + t) & (kBucketSlots - 1)));
-    const unsigned long long key = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
-    if (key == h + 1) { seen = raw.w == epoch ? raw.z & ~kMovedOn : 0u; break; }
-    if (key == 0ull) break;
+  if (mine) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(tab + sorted[i]);
+    key = ((uint64_t)raw.x | ((uint64_t)raw.y << 32)) - 1;
+    seen = raw.w == epoch ? raw.z & ~kMovedOn : 0u;
+    if (cs && seen > cs) seen = cs;
   }
-  out_hashes[at] = h;
-  out_counts[at] = (cs && seen > cs) ? cs : seen;
+  keys[i] = key;
+  cnts[i] = seen;
+}
+// An entry's place in the sketch: behind everything of earlier buckets (before[first entry of its bucket]) and behind the
+// entries of its own bucket with smaller hashes.
+__global__ __launch_bounds__(256) void k_list_place(const uint32_t* __restrict__ sorted, uint64_t n, const uint32_t* __restrict__ before,
+                                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cnts,
+                                                    uint64_t* __restrict__ out_hashes, uint32_t* __restrict__ out_counts,
+                                                    uint64_t out_cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == kReservedHash) return;
+  const uint32_t bucket = sorted[i] / kBucketSlots;
+  uint64_t first = i;
+  uint32_t smaller = 0;
+  while (first > 0 && sorted[first - 1] / kBucketSlots == bucket) {
+    --first;
+    smaller += keys[first] < key;  // (an entry that does not count holds kReservedHash: never smaller)
+  }
+  for (uint64_t j = i + 1; j < n && sorted[j] / kBucketSlots == bucket; ++j) smaller += keys[j] < key;
+  const uint64_t at = (uint64_t)before[first] + smaller;
+  if (at >= out_cap) return;  // (reported by k_sketch_meta's cap)
+  out_hashes[at] = key;
+  out_counts[at] = cnts[i];
 }
 
 __global__ void k_sketch_split(const uint64_t* __restrict__ hashes, uint64_t n, const uint64_t* __restrict__ bounds,
@@ -500,7 +525,7 @@ struct TablePlan {
   uint32_t* nuniq = nullptr;
   uint64_t* offs = nullptr;
   uint32_t epoch = 0;         // != 0: tab is a resident index (seeded, never cleared; live slots carry this epoch)
-  uint64_t* list = nullptr;   // ... and the kernel lists the hashes it touches here (listcap entries, kReservedHash = unused)
+  uint32_t* list = nullptr;   // ... and the kernel lists the SLOTS it touches here (listcap entries, kNoSlot = unused)
   uint64_t listcap = 0;
 };
 
@@ -556,24 +581,29 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint
   hipStream_t st = c.stream;
   if (cap > tp.slots) cap = tp.slots;  // a sketch cannot outgrow the table
   if (tp.epoch && tp.list) {
-    // the sketch = the listed hashes in order, once each, with their counters: the work is the pass's distinct hashes',
-    // not the table's (a sample covers a few per cent of a 200k-genome table: 1.7 against 15 ms for three k)
+    // the sketch = the listed slots' hashes in order, once each, with their counters: the work is the pass's distinct
+    // hashes', not the table's (a sample covers a few per cent of a 200k-genome table: 1.7 against 15 ms for three k)
     MG_TRY(sk->hashes.alloc((cap + 1) * sizeof(uint64_t)));
     MG_TRY(sk->counts.alloc((cap + 1) * sizeof(uint32_t)));
-    const uint64_t nblocks = (tp.listcap + 255) / 256;
-    uint64_t* sorted = (uint64_t*)scratch("sk_rsorted", tp.listcap * sizeof(uint64_t));
+    const uint64_t nl = tp.listcap, nblocks = (nl + 255) / 256;
+    uint32_t* sorted = (uint32_t*)scratch("sk_rsorted", nl * sizeof(uint32_t));
     uint32_t* nuniq = (uint32_t*)scratch("sk_rlist_n", nblocks * sizeof(uint32_t));
     uint64_t* offs = (uint64_t*)scratch("sk_rlist_off", (nblocks + 1) * sizeof(uint64_t));
-    if (!sorted || !nuniq || !offs) return MG_ERR_NOMEM;
+    uint32_t* before = (uint32_t*)scratch("sk_rlist_before", nl * sizeof(uint32_t));
+    uint64_t* keys = (uint64_t*)scratch("sk_rlist_keys", nl * sizeof(uint64_t));
+    uint32_t* cnts = (uint32_t*)scratch("sk_rlist_cnts", nl * sizeof(uint32_t));
+    if (!sorted || !nuniq || !offs || !before || !keys || !cnts) return MG_ERR_NOMEM;
     {
       ProfScope ps("bucket_sort");
-      MG_TRY(sort_keys(tp.list, sorted, tp.listcap, 64));
+      MG_TRY(sort_keys_u32(tp.list, sorted, nl));
     }
     ProfScope ps("bucket_pack");
-    hipLaunchKernelGGL(k_list_count, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, tp.listcap, nuniq);
+    hipLaunchKernelGGL(k_list_count, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, nl, nuniq);
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, nuniq, nblocks, offs, d_meta);
-    hipLaunchKernelGGL(k_list_gather, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, tp.listcap, offs, tp.tab, tp.shift, tp.epoch,
-                       c.count_sat, sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), cap);
+    hipLaunchKernelGGL(k_list_keys, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, nl, offs, tp.tab, tp.epoch, c.count_sat, before,
+                       keys, cnts);
+    hipLaunchKernelGGL(k_list_place, dim3((unsigned)nblocks), dim3(256), 0, st, sorted, nl, before, keys, cnts,
+                       sk->hashes.as<uint64_t>(), sk->counts.as<uint32_t>(), cap);
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
@@ -902,9 +932,9 @@ static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t
     kp.tp.listcap = (uint64_t)kp.distinct_est + (uint64_t)kp.distinct_est / 16 + (uint64_t)c.num_cus * 8 * kWavesPerBlock * kListChunk + 4096;
     if (tight) kp.tp.listcap = (uint64_t)kp.distinct_est + 16 * kListChunk;  // (tests: ... of the list too)
     snprintf(name, sizeof(name), "sk_rlist#%d", ki);
-    kp.tp.list = (uint64_t*)scratch(name, kp.tp.listcap * sizeof(uint64_t));
+    kp.tp.list = (uint32_t*)scratch(name, kp.tp.listcap * sizeof(uint32_t));
     if (!kp.tp.list) return MG_ERR_NOMEM;
-    MG_HIP(hipMemsetAsync(kp.tp.list, 0xff, kp.tp.listcap * sizeof(uint64_t), st));
+    MG_HIP(hipMemsetAsync(kp.tp.list, 0xff, kp.tp.listcap * sizeof(uint32_t), st));
   }
   return MG_OK;
 }
@@ -924,8 +954,8 @@ static int redo_resident(mg_sketch* sk) {
   MG_TRY(alloc_table_staging(kp.tp));
   int rc = MG_ERR_ARG;
   const bool ok = dispatch_k(sk->redo.k, [&]<int K>() {
-    rc = launch_sketch_reads<K>(sk->redo.bases, sk->redo.offsets, sk->redo.nreads, kp.hmax, kp.tp.list, kp.tp.listcap, t_counters,
-                                kp.tp.tab, kp.tp.shift, rp.stage, sk->redo.filter, kp.tp.epoch);
+    rc = launch_sketch_reads<K>(sk->redo.bases, sk->redo.offsets, sk->redo.nreads, kp.hmax, reinterpret_cast<uint64_t*>(kp.tp.list),
+                                kp.tp.listcap, t_counters, kp.tp.tab, kp.tp.shift, rp.stage, sk->redo.filter, kp.tp.epoch);
   });
   if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", sk->redo.k);
   if (rc) return rc;
@@ -1007,8 +1037,8 @@ static int sketch_reads_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     else MG_TRY(alloc_table(kp.tp, &t_counters));
     int rc = MG_ERR_ARG;
     bool ok = dispatch_k(k, [&]<int K>() {
-      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, kp.hmax, kp.tp.list, kp.tp.listcap, t_counters, kp.tp.tab,
-                                  kp.tp.shift, rp.stage, filter, kp.tp.epoch);
+      rc = launch_sketch_reads<K>(d_bases, d_offsets, nreads, kp.hmax, reinterpret_cast<uint64_t*>(kp.tp.list), kp.tp.listcap,
+                                  t_counters, kp.tp.tab, kp.tp.shift, rp.stage, filter, kp.tp.epoch);
     });
     if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
     if (rc) return rc;
@@ -1288,6 +1318,8 @@ int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, ui
   // (spread s: buckets planned for 2^s times the hashes — at s = 1 half as many hashes live away from their home slot and
   // half as many candidates go round again, 28.5 against 29.7 ms per 12.5M reads at 200k genomes, for twice the memory)
   if (n == 0 || !plan_table(0, hmax, (double)n * (double)(1u << spread), tp)) return fail(MG_ERR_ARG, "no resident index for %llu hashes up to %llu", (unsigned long long)n, (unsigned long long)hmax);
+  if (tp.slots >= (1ull << 32))  // (a pass lists the slots it touches as 32-bit numbers)
+    return fail(MG_ERR_CAPACITY, "resident index: %llu slots do not fit 32-bit slot numbers", (unsigned long long)tp.slots);
   std::unique_ptr<mg_filter::Resident> R(new mg_filter::Resident());
   R->shift = tp.shift; R->nbuckets = tp.nbuckets; R->slots = tp.slots; R->hmax = hmax;
   mg_filter::Resident::Copy cp;

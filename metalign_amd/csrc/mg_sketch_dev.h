@@ -103,13 +103,14 @@ constexpr uint32_t kMaxHops = 63;           // slots a hash may live from home (
 template <int J>
 __device__ __forceinline__ void resident_lookup(Slot* const (&bucket)[J], const uint64_t (&hh)[J], const uint32_t (&hop)[J],
                                                 uint32_t epoch, uint32_t cs, bool (&hit)[J], bool (&fresh)[J], bool (&on)[J],
-                                                bool count = true) {
+                                                uint32_t (&pos)[J], bool count = true) {
   uint4 raw[J];
   Slot* at[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     raw[j] = make_uint4(0, 0, 0, 0);
-    at[j] = bucket[j] + (((uint32_t)hh[j] + hop[j]) & (kBucketSlots - 1));
+    pos[j] = ((uint32_t)hh[j] + hop[j]) & (kBucketSlots - 1);  // (the slot within its bucket: what a fresh hit is listed by)
+    at[j] = bucket[j] + pos[j];
     if (hh[j] != kReservedHash) raw[j] = *reinterpret_cast<const uint4*>(at[j]);
   }
 #pragma unroll
@@ -127,14 +128,17 @@ __device__ __forceinline__ void resident_lookup(Slot* const (&bucket)[J], const 
   }
 }
 
-// The hashes a pass has touched in a resident index, as a LIST (what turns the index into the pass's sketch without a
-// walk over all of its slots: sort, drop the few repeats, read the counters).  A wavefront appends what its lanes saw
-// `fresh` to a chunk of its own (one atomic on the list's cursor, counters[3], per kListChunk entries); the list is filled
-// with kReservedHash before the launch, so what a wavefront leaves of its last chunk sorts to the end.  A full list is
-// reported like a table overflow (counters[2]): whoever resolves the sketch makes it again with room for every hash.
+// What a pass has touched in a resident index, as a LIST (what turns the index into the pass's sketch without a walk over
+// all of its slots) — of SLOT NUMBERS, bucket x 256 + slot: 32-bit keys sort in half the passes and a quarter of the bytes
+// of 64-bit hashes, buckets are hash ranges, and the handful of slots a pass touches in one bucket are put in hash order
+// when the counters are read (mg_sketch.hip: k_list_*).  A wavefront appends what its lanes saw `fresh` to a chunk of its
+// own (one atomic on the list's cursor, counters[3], per kListChunk entries); the list is filled with kNoSlot before the
+// launch, so what a wavefront leaves of its last chunk sorts to the end.  A full list is reported like a table overflow
+// (counters[2]): whoever resolves the sketch makes it again with room for every hash.
+constexpr uint32_t kNoSlot = 0xffffffffu;
 constexpr uint32_t kListChunk = 256;
-__device__ __forceinline__ void resident_list_append(bool mine, uint64_t h, uint64_t* __restrict__ list, uint64_t cap,
-                                                     unsigned long long* __restrict__ counters, uint64_t*& lbase, uint32_t& lfill,
+__device__ __forceinline__ void resident_list_append(bool mine, uint32_t h, uint32_t* __restrict__ list, uint64_t cap,
+                                                     unsigned long long* __restrict__ counters, uint32_t*& lbase, uint32_t& lfill,
                                                      int lane) {
   const unsigned long long m = __ballot(mine);
   if (m == 0) return;

@@ -26,7 +26,7 @@ struct CandSink {
   bool slot_first = false;          // table mode: the order of the two look-ups of a flush (wave-uniform)
   uint32_t order = 0;               // 0: adapt; 1 / 2: pinned (tests)
   uint32_t epoch = 0;               // table mode, != 0: `tab` is a resident index (mg_sketch_dev.h) and out / cap the list of hashes touched
-  uint64_t* lbase = nullptr;        // ... this wavefront's chunk of that list
+  uint32_t* lbase = nullptr;        // ... this wavefront's chunk of that list (slot numbers: `out`, there, is a uint32_t array)
   uint32_t lfill = 0;
 
   __device__ __forceinline__ bool passes(uint64_t h) const {
@@ -57,6 +57,7 @@ struct CandSink {
       uint32_t hop[J];
       Slot* bucket[J];
       bool hit[J], fresh[J], on[J];
+      uint32_t pos[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int i = lane + 64 * j;
@@ -65,12 +66,14 @@ struct CandSink {
         bucket[j] = tab + (hh[j] != kReservedHash ? hh[j] >> shift : 0ull) * kBucketSlots;
       }
       for (;;) {
-        resident_lookup<J>(bucket, hh, hop, epoch, cs, hit, fresh, on);
+        resident_lookup<J>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos);
         bool more = false;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           produced += hit[j];
-          if (out) resident_list_append(fresh[j], hh[j], out, cap, counters, lbase, lfill, lane);
+          if (out)
+            resident_list_append(fresh[j], (uint32_t)(hh[j] >> shift) * kBucketSlots + pos[j], reinterpret_cast<uint32_t*>(out), cap,
+                                 counters, lbase, lfill, lane);
           if (on[j] && hop[j] < kMaxHops) { ++hop[j]; more = true; }
           else hh[j] = kReservedHash;
         }

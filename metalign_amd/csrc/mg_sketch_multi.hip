@@ -29,7 +29,7 @@ struct MultiArgs {
   unsigned shift[kMaxMultiK];
   uint32_t cs;     // saturation value (low 30 bits of the cs word)
   uint32_t order;  // its top two bits
-  uint64_t* list[kMaxMultiK];            // resident indexes: the list of hashes the pass has touched in index i (or null)
+  uint32_t* list[kMaxMultiK];            // resident indexes: the list of slots the pass has touched in index i (or null)
   uint64_t listcap[kMaxMultiK];
   uint32_t epoch;  // != 0: the tables are resident indexes (mg_sketch_dev.h: resident_count) and this the pass's epoch
   uint32_t ablate; // resident kernel only, MG_DEBUG_RESIDENT_ABLATE (tools/k1_probe.py): 1 = a flush drops its candidates (what the kernel costs without any look-up)
@@ -86,7 +86,8 @@ struct MultiSink {
         hop[j] = kk[j] >> 2;
         bucket[j] = A->tab[ki] + (hh[j] != kReservedHash ? hh[j] >> A->shift[ki] : 0ull) * kBucketSlots;
       }
-      resident_lookup<J>(bucket, hh, hop, A->epoch, A->cs, hit, fresh, on, A->ablate < 2u);  // (2, 3: nothing is counted)
+      uint32_t pos[J];
+      resident_lookup<J>(bucket, hh, hop, A->epoch, A->cs, hit, fresh, on, pos, A->ablate < 2u);  // (2, 3: nothing is counted)
       if (A->ablate == 2u) { wave_lds_sync(); n = 0; return; }                               // (2: ... and nothing goes round again)
       wave_lds_sync();  // (every lane holds its entries in registers: the buffer's front is free for what goes round again)
       int back = 0;
@@ -99,10 +100,10 @@ struct MultiSink {
           for (int q = 0; q < kMaxMultiK; ++q) {
             if (!A->list[q]) continue;
             uint32_t* fills = reinterpret_cast<uint32_t*>(lst + kMaxMultiK);
-            uint64_t* lbase = reinterpret_cast<uint64_t*>(lst[q]);
+            uint32_t* lbase = reinterpret_cast<uint32_t*>(lst[q]);
             uint32_t lfill = fills[q];
-            resident_list_append(fresh[j] && (kk[j] & 3u) == (uint32_t)q, hh[j], A->list[q], A->listcap[q], A->counters[q], lbase,
-                                 lfill, lane);
+            resident_list_append(fresh[j] && (kk[j] & 3u) == (uint32_t)q, (uint32_t)(hh[j] >> A->shift[q]) * kBucketSlots + pos[j],
+                                 A->list[q], A->listcap[q], A->counters[q], lbase, lfill, lane);
             lst[q] = reinterpret_cast<uint64_t>(lbase);  // (every lane the same value)
             fills[q] = lfill;
           }

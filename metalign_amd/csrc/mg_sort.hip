@@ -44,6 +44,17 @@ int sort_keys(const uint64_t* d_in, uint64_t* d_out, uint64_t n, unsigned end_bi
   return MG_OK;
 }
 
+int sort_keys_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n) {
+  if (n == 0) return MG_OK;
+  hipStream_t st = ctx().stream;
+  size_t tmp = 0;
+  MG_HIP(rocprim::radix_sort_keys(nullptr, tmp, d_in, d_out, n, 0u, 32u, st));
+  void* t = scratch("sort_tmp", tmp);
+  if (!t) return MG_ERR_NOMEM;
+  MG_HIP(rocprim::radix_sort_keys(t, tmp, d_in, d_out, n, 0u, 32u, st));
+  return MG_OK;
+}
+
 int sort_pairs(const uint64_t* d_kin, uint64_t* d_kout, const uint32_t* d_vin, uint32_t* d_vout, uint64_t n) {
   if (n == 0) return MG_OK;
   hipStream_t st = ctx().stream;
