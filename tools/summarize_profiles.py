@@ -43,6 +43,8 @@ def per_kernel(csvfile, counters):
 def stage_a_per_pass(d, key):
     """Sum over the stage-A kernels of one pass: the fused kernel if it ran, else one k_sketch_reads<K> per k."""
     fused = [k for k in d if k.startswith("k_sketch_reads_multi")]
+    if len(fused) > 1:  # a job that measured index against filter at load ran both forms: the one its passes run
+        fused = [max(fused, key=lambda k: d[k].get("launches", 0))]
     names = fused if fused else [k for k in d if re.match(r"k_sketch_reads<\d+>", k)]
     return names, sum(d[k][key] for k in names)
 
