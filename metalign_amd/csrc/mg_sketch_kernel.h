@@ -50,34 +50,28 @@ struct CandSink {
         if (keep && base < cap) out[base] = h;
       }
     } else if (epoch) {
-      // resident index (mg_sketch_dev.h).  This sink's buffer has no room for a "one slot on" tag: the candidates that have
-      // to look further do so here, round after round (the fused kernel defers them to its next flush).
-      constexpr int J = kCandBuf / 64;
-      uint64_t hh[J];
-      uint32_t hop[J];
-      Slot* bucket[J];
-      bool hit[J], fresh[J], on[J];
-      uint32_t pos[J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int i = lane + 64 * j;
-        hh[j] = i < n ? lds[i] : kReservedHash;
-        hop[j] = 0;
-        bucket[j] = tab + (hh[j] != kReservedHash ? hh[j] >> shift : 0ull) * kBucketSlots;
-      }
-      for (;;) {
-        resident_lookup<J>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos);
-        bool more = false;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          produced += hit[j];
+      // resident index (mg_sketch_dev.h).  The one-k kernel serves the k sets without a fused kernel and the rare sketch that
+      // is made again: its flush takes the buffer 64 candidates at a time, each lane's candidate round after round until it is
+      // found or known absent — four to a lane in one round trip, as the fused kernel does it, costs every one-k kernel 35
+      // registers (100 -> 135: three wavefronts per SIMD instead of four) whether it ever sees an index or not.
+#pragma unroll 1
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        uint64_t hh[1] = {i < n ? lds[i] : kReservedHash};
+        uint32_t hop[1] = {0}, pos[1];
+        Slot* bucket[1] = {tab + (hh[0] != kReservedHash ? hh[0] >> shift : 0ull) * kBucketSlots};
+        bool hit[1], fresh[1], on[1];
+        for (;;) {
+          resident_lookup<1>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos);
+          produced += hit[0];
           if (out)
-            resident_list_append(fresh[j], (uint32_t)(hh[j] >> shift) * kBucketSlots + pos[j], reinterpret_cast<uint32_t*>(out), cap,
+            resident_list_append(fresh[0], (uint32_t)(hh[0] >> shift) * kBucketSlots + pos[0], reinterpret_cast<uint32_t*>(out), cap,
                                  counters, lbase, lfill, lane);
-          if (on[j] && hop[j] < kMaxHops) { ++hop[j]; more = true; }
-          else hh[j] = kReservedHash;
+          bool more = false;
+          if (on[0] && hop[0] < kMaxHops) { ++hop[0]; more = true; }
+          else hh[0] = kReservedHash;
+          if (__ballot(more) == 0ull) break;
         }
-        if (__ballot(more) == 0ull) break;
       }
     } else {
       uint32_t lost = 0, kept = 0;
