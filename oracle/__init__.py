@@ -157,6 +157,96 @@ def sketch_genomes_prefix(bases, offsets, kmax, k, n):
     return h[: int(o[-1])].copy(), o
 
 
+def sketch_genomes_kmers(bases, offsets, k, n):
+    """Stage A' with the k-mers kept (oracle/mg_oracle.c: mgo_sketch_genomes_kmers), under the mode in force.
+    -> (hashes u64[*], kmer_hi u64[*], kmer_lo u64[*], offsets u64[G+1]); the k-mer 2-bit packed, first base most significant."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    g = len(offsets) - 1
+    h = np.zeros(max(g * n, 1), dtype=np.uint64)
+    hi = np.zeros(max(g * n, 1), dtype=np.uint64)
+    lo = np.zeros(max(g * n, 1), dtype=np.uint64)
+    o = np.zeros(g + 1, dtype=np.uint64)
+    rc = lib().mgo_sketch_genomes_kmers(_p(bases, ctypes.c_uint8), _p(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                                        ctypes.c_int(k), ctypes.c_uint64(n), _p(h, ctypes.c_uint64), _p(hi, ctypes.c_uint64),
+                                        _p(lo, ctypes.c_uint64), _p(o, ctypes.c_uint64))
+    if rc != 0:
+        raise RuntimeError("mgo_sketch_genomes_kmers rc=%d" % rc)
+    e = int(o[-1])
+    return h[:e].copy(), hi[:e].copy(), lo[:e].copy(), o
+
+
+def refpipe_build(hashes, kmer_hi, kmer_lo, offsets, ks):
+    """The table of the reference pipeline (oracle/mg_oracle.c, "THE REFERENCE'S OWN WIRING"): from the genome-major
+    entries of the largest k (sketch_genomes_kmers) -> dict(ks, ngenomes, pair_hash, pair_gen, gsize, kmer_hi, kmer_lo (pair
+    order), small = {k: dict(pa, pb, cid, cgen, gsize, nprefix)} for every k below the largest)."""
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ks = [int(k) for k in ks]
+    kmax, g, e = ks[-1], len(offsets) - 1, len(hashes)
+    ph = np.zeros(max(e, 1), dtype=np.uint64)
+    pg = np.zeros(max(e, 1), dtype=np.uint32)
+    perm = np.zeros(max(e, 1), dtype=np.uint64)
+    rc = lib().mgo_refpipe_pairs(_p(hashes, ctypes.c_uint64), _p(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                                 _p(ph, ctypes.c_uint64), _p(pg, ctypes.c_uint32), _p(perm, ctypes.c_uint64))
+    if rc != 0:
+        raise RuntimeError("mgo_refpipe_pairs rc=%d" % rc)
+    ph, pg, perm = ph[:e], pg[:e], perm[:e].astype(np.int64)
+    khi = np.ascontiguousarray(np.asarray(kmer_hi, dtype=np.uint64)[perm])
+    klo = np.ascontiguousarray(np.asarray(kmer_lo, dtype=np.uint64)[perm])
+    out = dict(ks=ks, ngenomes=g, pair_hash=ph, pair_gen=pg, gsize=np.diff(offsets).astype(np.uint32), kmer_hi=khi,
+               kmer_lo=klo, small={})
+    for k in ks[:-1]:
+        pa, pb = np.zeros(max(e, 1), np.uint32), np.zeros(max(e, 1), np.uint32)
+        cid, cgen = np.zeros(max(e, 1), np.uint32), np.zeros(max(e, 1), np.uint32)
+        gs = np.zeros(max(g, 1), np.uint32)
+        nc, npre = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = lib().mgo_refpipe_build_k(_p(khi if e else np.zeros(1, np.uint64), ctypes.c_uint64),
+                                       _p(klo if e else np.zeros(1, np.uint64), ctypes.c_uint64),
+                                       _p(np.ascontiguousarray(pg) if e else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                       ctypes.c_uint64(e), ctypes.c_uint64(g), ctypes.c_int(kmax), ctypes.c_int(k),
+                                       _p(pa, ctypes.c_uint32), _p(pb, ctypes.c_uint32), _p(cid, ctypes.c_uint32),
+                                       _p(cgen, ctypes.c_uint32), ctypes.byref(nc), _p(gs, ctypes.c_uint32), ctypes.byref(npre))
+        if rc != 0:
+            raise RuntimeError("mgo_refpipe_build_k rc=%d" % rc)
+        out["small"][k] = dict(pa=pa[:e].copy(), pb=pb[:e].copy(), cid=cid[:nc.value].copy(), cgen=cgen[:nc.value].copy(),
+                               gsize=gs[:g].copy(), nprefix=int(npre.value))
+    return out
+
+
+def refpipe_containment(q_hashes, q_counts, ci, table):
+    """The query of the reference pipeline against refpipe_build's table: q = the read sketch of the LARGEST k.
+    -> (hits u32[K][G], sizes u32[K][G]), k ascending (the largest k last: the column the cutoff reads)."""
+    q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)
+    q_counts = np.ascontiguousarray(q_counts, dtype=np.uint32)
+    ph, pg, g = table["pair_hash"], table["pair_gen"], table["ngenomes"]
+    e = len(ph)
+    matched = np.zeros(max(e, 1), dtype=np.uint8)
+    lib().mgo_refpipe_matched(_p(q_hashes if len(q_hashes) else np.zeros(1, np.uint64), ctypes.c_uint64),
+                              _p(q_counts if len(q_counts) else np.zeros(1, np.uint32), ctypes.c_uint32),
+                              ctypes.c_uint64(len(q_hashes)), ctypes.c_uint32(ci),
+                              _p(np.ascontiguousarray(ph) if e else np.zeros(1, np.uint64), ctypes.c_uint64), ctypes.c_uint64(e),
+                              _p(matched, ctypes.c_uint8))
+    hits, sizes = [], []
+    for k in table["ks"][:-1]:
+        t = table["small"][k]
+        out = np.zeros(max(g, 1), dtype=np.uint32)
+        rc = lib().mgo_refpipe_hits_k(_p(matched, ctypes.c_uint8),
+                                      _p(t["pa"] if e else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                      _p(t["pb"] if e else np.zeros(1, np.uint32), ctypes.c_uint32), ctypes.c_uint64(e),
+                                      ctypes.c_uint64(t["nprefix"]),
+                                      _p(t["cid"] if len(t["cid"]) else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                      _p(t["cgen"] if len(t["cgen"]) else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                      ctypes.c_uint64(len(t["cid"])), ctypes.c_uint64(g), _p(out, ctypes.c_uint32))
+        if rc != 0:
+            raise RuntimeError("mgo_refpipe_hits_k rc=%d" % rc)
+        hits.append(out[:g].copy())
+        sizes.append(t["gsize"].copy())
+    hits.append(np.bincount(pg[matched[:e] != 0], minlength=g).astype(np.uint32)[:g] if e else np.zeros(g, np.uint32))
+    sizes.append(table["gsize"].copy())
+    return np.asarray(hits, dtype=np.uint32).reshape(len(table["ks"]), g), np.asarray(sizes, dtype=np.uint32).reshape(len(table["ks"]), g)
+
+
 def containment(q_hashes, q_counts, q_truncated, ci, db_hashes, db_offsets):
     """-> (hits u32[G], sizes u32[G])."""
     q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)

@@ -18,6 +18,9 @@
  *            vendored nor version-pinned by the reference and absent from this
  *            image.  This file is the normative statement of what the build
  *            computes for those stages; the GPU must match it bit for bit.
+ *            That includes the "reference pipeline" below (mgo_refpipe_*): the
+ *            reference's own wiring of those tools (k_max-mers only on the read
+ *            side, smaller-k columns from prefixes of the matched k_max-mers).
  *
  * All paths below are relative to /root/reference.
  */
@@ -307,6 +310,234 @@ int mgo_sketch_genomes_prefix(const uint8_t* bases, const uint64_t* offsets, uin
     free(keys);
     out_offsets[g + 1] = w;
   }
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------- *
+ * THE REFERENCE'S OWN WIRING OF STAGE A/B ("reference pipeline").
+ *
+ * scripts/select_db.py counts ONLY k_max-mers of the reads (`kmc -k60 -ci2 -cs3`, :50-52), intersects them with the k_max-mers
+ * of all genome sketches (`kmc_tools simple ... intersect`, :54-56), dumps the survivors as FASTA (:58-65) and hands THAT to
+ * CMash's streaming query with the k range 30-60-10 (:73-76).  The query [UPSTREAM-RECOLLECTION, SURVEY.md §8c: CMash is not
+ * under /root/reference] walks every k_max-mer x of its input and the reverse complement of x, and for every k of the range
+ * looks the k-PREFIX up in a prefix tree of the sketched k_max-mers (each stored in the orientation CountEstimator.add kept);
+ * a genome's column for k is (distinct k-prefixes of its sketched k_max-mers that were found) / (distinct k-prefixes of its
+ * sketched k_max-mers).  So the read side is ONE k, and every smaller-k column is a function of WHICH SKETCHED k_max-MERS
+ * MATCHED — derived here on the table side:
+ *
+ *   table (mgo_sketch_genomes_kmers + mgo_refpipe_build_k)
+ *     entry  = one sketched k_max-mer of one genome: its hash under the mode in force (the identity the read side matches
+ *              on) and the k-mer as the table keeps it, 2-bit packed (first base most significant): mode 0 the
+ *              lexicographically smaller strand, mode 1 the strand with the smaller MurmurHash3 (the reverse complement on a
+ *              tie) — of the FIRST window of the genome that has the hash (CountEstimator.add keeps the first k-mer of a hash)
+ *     pairs  = all entries sorted by (hash, genome): the hash-major table of k_max as everywhere else in this build
+ *     for k < k_max:  D_k = the distinct k-prefixes of all entries' kept k-mers, numbered in ascending (lexicographic) order
+ *              pa[pair] = number of the kept k-mer's k-prefix;  pb[pair] = number of its REVERSE COMPLEMENT's k-prefix when
+ *              that string is in D_k, else 0xffffffff (the query tries both strands, :73-76)
+ *              count list = the distinct (prefix number, genome) combinations, ascending; gsize_k[g] = how many genome g has
+ *   query (mgo_refpipe_matched + mgo_refpipe_hits_k)
+ *     matched[pair] = the pair's hash is in the read sketch of k_max with count >= ci                      (:50-56)
+ *     k_max column  = matched pairs of the genome / sketch size                         (what mgo_containment computes)
+ *     marked_k      = { pa[pair], pb[pair] : matched[pair] }
+ *     k column      = #{(p, g) in the count list : p in marked_k} / gsize_k[g]                              (:73-76)
+ *
+ * PARITY UNPINNED like the rest of stage A/B; tests/indep_sketch.py states the same on STRINGS (dicts of k-mers and
+ * prefixes, no hash on the query side at all) and tests/test_oracle_independent.py holds the two together.
+ * ---------------------------------------------------------------------- */
+
+/* codes c[0..k) (0..3 = ACGT) -> the 2k-bit number with the first base most significant, as (hi, lo) */
+static void pack_codes(const uint8_t* c, int k, uint64_t* hi, uint64_t* lo) {
+  uint64_t h = 0, l = 0;
+  for (int i = 0; i < k; ++i) {
+    h = (h << 2) | (l >> 62);
+    l = (l << 2) | (uint64_t)(c[i] & 3);
+  }
+  *hi = h; *lo = l;
+}
+
+static void unpack_codes(uint64_t hi, uint64_t lo, int k, uint8_t* c) {
+  for (int i = k - 1; i >= 0; --i) {
+    c[i] = (uint8_t)(lo & 3);
+    lo = (lo >> 2) | (hi << 62);
+    hi >>= 2;
+  }
+}
+
+typedef struct { uint64_t h, pos; int use_rc; } hp_entry;
+static int cmp_hp(const void* a, const void* b) {
+  const hp_entry* x = (const hp_entry*)a; const hp_entry* y = (const hp_entry*)b;
+  if (x->h != y->h) return x->h < y->h ? -1 : 1;
+  return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+
+/* Stage A' with the k-mers kept (CMash's database holds _mins AND _kmers per genome: local_tests/dump_kmers.py:7-14).
+ * As mgo_sketch_genomes under the mode in force; out_khi/out_klo[i] = the kept k-mer of out_hashes[i], packed. */
+int mgo_sketch_genomes_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                             uint64_t* out_hashes, uint64_t* out_khi, uint64_t* out_klo, uint64_t* out_offsets) {
+  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
+  uint64_t w = 0;
+  out_offsets[0] = 0;
+  for (uint64_t g = 0; g < ngenomes; ++g) {
+    const uint8_t* seq = bases + offsets[g];
+    const uint64_t len = offsets[g + 1] - offsets[g];
+    hp_entry* v = (hp_entry*)malloc((len + 1) * sizeof(hp_entry));
+    if (!v) return MG_ERR_NOMEM;
+    uint64_t nv = 0, run = 0;
+    for (uint64_t j = 0; j < len; ++j) {
+      run = base_code(seq[j]) >= 0 ? run + 1 : 0;
+      if (run < (uint64_t)k) continue;
+      const uint8_t* win = seq + (j + 1 - (uint64_t)k);
+      char fwd[MG_MAX_K], rc[MG_MAX_K];
+      for (int i = 0; i < k; ++i) {
+        int c = base_code(win[i]);
+        fwd[i] = kUpper[c];
+        rc[k - 1 - i] = kUpper[3 - c];
+      }
+      uint64_t o[2];
+      if (g_hash_mode == 1) {
+        uint64_t hf, hr;
+        mgo_murmur3_x64_128(fwd, k, 0, o); hf = o[0];
+        mgo_murmur3_x64_128(rc, k, 0, o); hr = o[0];
+        v[nv].h = (hf < hr ? hf : hr) % MGO_CMASH_PRIME;
+        v[nv].use_rc = hr <= hf;  /* CountEstimator.add: the strand with the smaller hash, the reverse complement on a tie */
+      } else {
+        v[nv].use_rc = memcmp(fwd, rc, (size_t)k) > 0;  /* KMC's canonical k-mer */
+        mgo_murmur3_x64_128(v[nv].use_rc ? rc : fwd, k, 0, o);
+        v[nv].h = o[0];
+      }
+      if (v[nv].h == UINT64_MAX) continue;  /* reserved: never a sketch member */
+      v[nv].pos = j + 1 - (uint64_t)k;
+      ++nv;
+    }
+    if (nv) qsort(v, nv, sizeof(hp_entry), cmp_hp);
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < nv && kept < n; ++i) {
+      if (i > 0 && v[i].h == v[i - 1].h) continue;  /* a hash seen before: its first window stays */
+      uint8_t codes[MG_MAX_K];
+      const uint8_t* win = seq + v[i].pos;
+      for (int t = 0; t < k; ++t) {
+        int c = base_code(win[t]);
+        if (v[i].use_rc) codes[k - 1 - t] = (uint8_t)(3 - c); else codes[t] = (uint8_t)c;
+      }
+      out_hashes[w] = v[i].h;
+      pack_codes(codes, k, &out_khi[w], &out_klo[w]);
+      ++w; ++kept;
+    }
+    free(v);
+    out_offsets[g + 1] = w;
+  }
+  return MG_OK;
+}
+
+typedef struct { uint64_t h; uint32_t g; uint64_t e; } pair_ent;   /* e: index of the entry in the genome-major arrays */
+static int cmp_pair_ent(const void* a, const void* b) {
+  const pair_ent* x = (const pair_ent*)a; const pair_ent* y = (const pair_ent*)b;
+  if (x->h != y->h) return x->h < y->h ? -1 : 1;
+  if (x->g != y->g) return x->g < y->g ? -1 : 1;
+  return x->e < y->e ? -1 : (x->e > y->e ? 1 : 0);
+}
+typedef struct { uint64_t hi, lo; } u128;
+static int cmp_u128(const void* a, const void* b) {
+  const u128* x = (const u128*)a; const u128* y = (const u128*)b;
+  if (x->hi != y->hi) return x->hi < y->hi ? -1 : 1;
+  return x->lo < y->lo ? -1 : (x->lo > y->lo ? 1 : 0);
+}
+
+/* The hash-major pairs of the k_max table: entries sorted by (hash, genome).  perm[i] = genome-major index of pair i. */
+int mgo_refpipe_pairs(const uint64_t* hashes, const uint64_t* offsets, uint64_t ngenomes, uint64_t* pair_hash,
+                      uint32_t* pair_gen, uint64_t* perm) {
+  const uint64_t E = offsets[ngenomes];
+  pair_ent* p = (pair_ent*)malloc((E + 1) * sizeof(pair_ent));
+  if (!p) return MG_ERR_NOMEM;
+  for (uint64_t g = 0; g < ngenomes; ++g)
+    for (uint64_t e = offsets[g]; e < offsets[g + 1]; ++e) { p[e].h = hashes[e]; p[e].g = (uint32_t)g; p[e].e = e; }
+  if (E) qsort(p, E, sizeof(pair_ent), cmp_pair_ent);
+  for (uint64_t i = 0; i < E; ++i) { pair_hash[i] = p[i].h; pair_gen[i] = p[i].g; perm[i] = p[i].e; }
+  free(p);
+  return MG_OK;
+}
+
+/* One k < kmax of the table, from the entries in PAIR order (khi/klo/gen[npairs]: the kept kmax-mers and genomes of the
+ * pairs).  pa, pb: [npairs]; cid, cgen: [npairs] capacity, *ncount filled; gsize: [ngenomes]; *nprefix = |D_k|. */
+int mgo_refpipe_build_k(const uint64_t* khi, const uint64_t* klo, const uint32_t* gen, uint64_t npairs, uint64_t ngenomes,
+                        int kmax, int k, uint32_t* pa, uint32_t* pb, uint32_t* cid, uint32_t* cgen, uint64_t* ncount,
+                        uint32_t* gsize, uint64_t* nprefix) {
+  if (k < 1 || k >= kmax || kmax > MG_MAX_K) return MG_ERR_ARG;
+  u128* a = (u128*)malloc((npairs + 1) * sizeof(u128));  /* prefix of the kept strand */
+  u128* b = (u128*)malloc((npairs + 1) * sizeof(u128));  /* prefix of the other strand */
+  u128* d = (u128*)malloc((npairs + 1) * sizeof(u128));
+  uint64_t* cg = (uint64_t*)malloc((npairs + 1) * sizeof(uint64_t));
+  if (!a || !b || !d || !cg) { free(a); free(b); free(d); free(cg); return MG_ERR_NOMEM; }
+  for (uint64_t i = 0; i < npairs; ++i) {
+    uint8_t c[MG_MAX_K], r[MG_MAX_K];
+    unpack_codes(khi[i], klo[i], kmax, c);
+    for (int t = 0; t < kmax; ++t) r[kmax - 1 - t] = (uint8_t)(3 - c[t]);
+    pack_codes(c, k, &a[i].hi, &a[i].lo);
+    pack_codes(r, k, &b[i].hi, &b[i].lo);
+    d[i] = a[i];
+  }
+  if (npairs) qsort(d, npairs, sizeof(u128), cmp_u128);
+  uint64_t nd = 0;
+  for (uint64_t i = 0; i < npairs; ++i)
+    if (i == 0 || cmp_u128(&d[i], &d[i - 1]) != 0) d[nd++] = d[i];
+  *nprefix = nd;
+  for (uint64_t i = 0; i < npairs; ++i) {
+    for (int which = 0; which < 2; ++which) {
+      const u128* key = which ? &b[i] : &a[i];
+      uint64_t lo = 0, hi = nd;
+      while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (cmp_u128(&d[mid], key) < 0) lo = mid + 1; else hi = mid;
+      }
+      const int found = lo < nd && cmp_u128(&d[lo], key) == 0;
+      if (which) pb[i] = found ? (uint32_t)lo : 0xffffffffu; else pa[i] = (uint32_t)lo;
+    }
+    cg[i] = ((uint64_t)pa[i] << 32) | gen[i];
+  }
+  if (npairs) qsort(cg, npairs, sizeof(uint64_t), cmp_u64);
+  for (uint64_t g = 0; g < ngenomes; ++g) gsize[g] = 0;
+  uint64_t nc = 0;
+  for (uint64_t i = 0; i < npairs; ++i) {
+    if (i > 0 && cg[i] == cg[i - 1]) continue;
+    cid[nc] = (uint32_t)(cg[i] >> 32);
+    cgen[nc] = (uint32_t)cg[i];
+    gsize[cgen[nc]] += 1;
+    ++nc;
+  }
+  *ncount = nc;
+  free(a); free(b); free(d); free(cg);
+  return MG_OK;
+}
+
+/* matched[i] = 1 when pair i's hash is in the read sketch with count >= ci (kmc -ci2 + kmc_tools intersect, :50-56) */
+int mgo_refpipe_matched(const uint64_t* q_hashes, const uint32_t* q_counts, uint64_t qn, uint32_t ci,
+                        const uint64_t* pair_hash, uint64_t npairs, uint8_t* matched) {
+  for (uint64_t i = 0; i < npairs; ++i) {
+    const uint64_t h = pair_hash[i];
+    uint64_t lo = 0, hi = qn;
+    while (lo < hi) {
+      uint64_t mid = lo + (hi - lo) / 2;
+      if (q_hashes[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    matched[i] = (uint8_t)(lo < qn && q_hashes[lo] == h && q_counts[lo] >= ci);
+  }
+  return MG_OK;
+}
+
+/* The column of one k < kmax: hits[g] = #{(p, g) in the count list : p marked by a matched pair's pa / pb} (:73-76) */
+int mgo_refpipe_hits_k(const uint8_t* matched, const uint32_t* pa, const uint32_t* pb, uint64_t npairs, uint64_t nprefix,
+                       const uint32_t* cid, const uint32_t* cgen, uint64_t ncount, uint64_t ngenomes, uint32_t* out_hits) {
+  uint8_t* marked = (uint8_t*)calloc(nprefix + 1, 1);
+  if (!marked) return MG_ERR_NOMEM;
+  for (uint64_t i = 0; i < npairs; ++i) {
+    if (!matched[i]) continue;
+    marked[pa[i]] = 1;
+    if (pb[i] != 0xffffffffu) marked[pb[i]] = 1;
+  }
+  for (uint64_t g = 0; g < ngenomes; ++g) out_hits[g] = 0;
+  for (uint64_t i = 0; i < ncount; ++i)
+    if (marked[cid[i]]) out_hits[cgen[i]] += 1;
+  free(marked);
   return MG_OK;
 }
 

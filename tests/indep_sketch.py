@@ -156,3 +156,68 @@ def containment(sketch_items, truncated, ci, genome_sketches):
         inb = [h for h in g if h <= bound]
         out.append((sum(1 for h in inb if h in present), len(inb)))
     return out
+
+
+# ---- the reference's own wiring of stage A/B ("the reference pipeline"), on STRINGS ---------------------------
+# Written from /root/reference/scripts/select_db.py:43-76 and the prose, not from oracle/mg_oracle.c: KMC counts the reads'
+# k_max-mers (canonical = the lexicographically smaller strand, count >= ci), kmc_tools intersects them with the k_max-mers of
+# the genome sketches, and the streaming query looks the k-prefixes of every surviving k_max-mer AND of its reverse complement up
+# among the sketched k_max-mers (kept in the orientation the sketch stored them).  No hash on the query side at all: k-mers are
+# matched as strings, prefixes live in Python sets.  (The oracle matches k_max-mers by their hash value; the two can differ only
+# by a hash collision.)
+
+def _revcomp(s: bytes) -> bytes:
+    return s.translate(_COMP)[::-1]
+
+
+def refpipe_genome_kmers(seq: bytes, kmax: int, n: int):
+    """The sketched kmax-mers of one genome as the table keeps them: bottom-n by hash (the definition HASH_MODE selects), per hash
+    the first window that has it, oriented as the sketch stores it — mode 0: the lexicographically smaller strand; mode 1: the
+    strand with the smaller MurmurHash3, the reverse complement on a tie (CMash's CountEstimator.add, as recollected)."""
+    first = {}
+    for m in _RUNS.finditer(seq):
+        run = m.group().upper()
+        for i in range(len(run) - kmax + 1):
+            kmer = run[i:i + kmax]
+            rc = _revcomp(kmer)
+            if HASH_MODE == 1:
+                hf, hr = murmur3_x64_128(kmer, 0)[0], murmur3_x64_128(rc, 0)[0]
+                h, kept = min(hf, hr) % CMASH_PRIME, (rc if hr <= hf else kmer)
+            else:
+                kept = kmer if kmer <= rc else rc
+                h = murmur3_x64_128(kept, 0)[0]
+            if h != RESERVED and h not in first:
+                first[h] = kept
+    return [first[h] for h in sorted(first)[:n]]
+
+
+def refpipe_query(reads, genome_kmers, ks, ci):
+    """reads: iterable of bytes; genome_kmers: per genome the list refpipe_genome_kmers returned; ks ascending, ks[-1] = kmax.
+    -> per k a list of (hits, size) per genome."""
+    kmax = ks[-1]
+    counts = {}
+    for r in reads:  # kmc -k<kmax> -ci<ci>: canonical k-mers of the reads with their occurrence counts (:50-52)
+        for m in _RUNS.finditer(r):
+            run = m.group().upper()
+            for i in range(len(run) - kmax + 1):
+                kmer = run[i:i + kmax]
+                rc = _revcomp(kmer)
+                c = kmer if kmer <= rc else rc
+                counts[c] = counts.get(c, 0) + 1
+    db = set()  # the KMC database of the sketches' k-mers (local_tests/retrain_and_test_metalign.sh:59-66): canonical forms
+    for g in genome_kmers:
+        for y in g:
+            db.add(min(y, _revcomp(y)))
+    survivors = [x for x, c in counts.items() if c >= ci and x in db]  # kmc_tools simple ... intersect (:54-56) -> the FASTA (:58-65)
+    out = []
+    for k in ks:  # the streaming query, k range (:73-76): both strands of every query k-mer, k-prefixes against the tree
+        seen = set()
+        for x in survivors:
+            seen.add(x[:k])
+            seen.add(_revcomp(x)[:k])
+        col = []
+        for g in genome_kmers:
+            prefixes = {y[:k] for y in g}
+            col.append((len(prefixes & seen), len(prefixes)))
+        out.append(col)
+    return out

@@ -165,3 +165,106 @@ def test_prefix_tables_of_the_cmash_recollection(oracle_lib, kmax, k):
         finally:
             oracle_lib.set_hash_mode(0)
         assert np.array_equal(h, dbh) and np.array_equal(o, dbo)
+
+
+# ---- the reference's own wiring of stage A/B: k_max-mers only on the read side, prefix columns from the table side -------------
+def _unpack(hi, lo, k):
+    v = (int(hi) << 64) | int(lo)
+    return bytes(b"ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def _refpipe_case(rng, strains=True):
+    """Genomes that SHARE k-mers (a strain = a mutated copy; a repeat inside one genome; a reverse-complemented copy), N runs,
+    lower case; reads from three of them, both strands, each twice so that ci = 2 is met, plus reads of nothing."""
+    genomes = _reads(rng, 5, 1200, 2000, p_n=0.002, p_lower=0.05)
+    if strains:
+        g0 = bytearray(genomes[0].upper())
+        for p in rng.integers(0, len(g0), size=12):
+            g0[int(p)] = b"ACGT"[int(rng.integers(0, 4))]
+        genomes.append(bytes(g0))                                                   # a strain of genome 0
+        genomes.append(genomes[1][:600] + genomes[1][100:700])                      # repeats inside one genome
+        genomes.append(genomes[2].upper().translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])  # the other strand of genome 2
+    genomes += [b"ACGT" * 5, b"", b"A" * 300]
+    reads = []
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    for g in (0, 2, 4):
+        src = genomes[g]
+        for _ in range(60):
+            a = int(rng.integers(0, len(src) - 150))
+            r = src[a:a + 150]
+            if rng.random() < 0.5:
+                r = r.translate(comp)[::-1]
+            reads += [r, r]
+    reads += _reads(rng, 40, 60, 150) + [b"", b"ACG"]
+    return genomes, reads
+
+
+@pytest.mark.parametrize("ks", [[21, 31, 51], [30, 40, 50, 60], [4, 6, 9], [5, 33, 64], [32], [8, 16, 32]], ids=str)
+def test_reference_pipeline_c_oracle_equals_the_string_restatement(oracle_lib, hash_mode, ks):
+    rng = np.random.default_rng(4000 + 7 * sum(ks) + hash_mode)
+    genomes, reads = _refpipe_case(rng)
+    kmax, n = ks[-1], 150
+    gb, go = _flat(genomes)
+    h, khi, klo, o = oracle_lib.sketch_genomes_kmers(gb, go, kmax, n)
+    # the table's k-mers: the same hashes as the plain sketch, the kept k-mers as the string restatement keeps them
+    ph, po = oracle_lib.sketch_genomes(gb, go, kmax, n)
+    assert np.array_equal(h, ph) and np.array_equal(o, po)
+    want_kmers = [ind.refpipe_genome_kmers(g, kmax, n) for g in genomes]
+    for g, w in enumerate(want_kmers):
+        got = [_unpack(khi[e], klo[e], kmax) for e in range(int(o[g]), int(o[g + 1]))]
+        assert got == w, g
+    table = oracle_lib.refpipe_build(h, khi, klo, o, ks)
+    assert np.all(np.diff(table["pair_hash"].astype(object)) >= 0)
+    for k in ks[:-1]:
+        t = table["small"][k]
+        d = sorted({y[:k] for g in want_kmers for y in g})
+        assert t["nprefix"] == len(d)
+        # pa / pb name the prefixes they should (checked through the kept k-mers in pair order)
+        for i in rng.integers(0, len(table["pair_hash"]), size=min(200, len(table["pair_hash"]))):
+            y = _unpack(table["kmer_hi"][i], table["kmer_lo"][i], kmax)
+            assert d[int(t["pa"][i])] == y[:k]
+            other = ind._revcomp(y)[:k]
+            assert (d[int(t["pb"][i])] == other) if t["pb"][i] != 0xFFFFFFFF else (other not in set(d))
+        assert [int(x) for x in t["gsize"]] == [len({y[:k] for y in g}) for g in want_kmers]
+    rb, ro = _flat(reads)
+    for ci in (1, 2):
+        qh, qc, _, _ = oracle_lib.sketch_reads(rb, ro, kmax, hmax=int(h.max()) if len(h) else 0)
+        hits, sizes = oracle_lib.refpipe_containment(qh, qc, ci, table)
+        want = ind.refpipe_query(reads, want_kmers, ks, ci)
+        for ki in range(len(ks)):
+            assert [(int(a), int(b)) for a, b in zip(hits[ki], sizes[ki])] == want[ki], (ks[ki], ci)
+        # the largest k's column is the plain containment of the k_max table
+        ph_hits, ph_sizes = oracle_lib.containment(qh, qc, False, ci, h, o)
+        assert np.array_equal(hits[-1], ph_hits) and np.array_equal(sizes[-1], ph_sizes)
+    # genomes that were sampled stand out at every k; a k-prefix column is never below the k_max column's hits / never above its size
+    for ki in range(len(ks)):
+        assert hits[ki][0] > 0 and hits[ki][2] > 0 and hits[ki][4] > 0
+        assert np.all(hits[ki] <= sizes[ki])
+
+
+def test_reference_pipeline_smaller_k_columns_are_not_independent_sketches(oracle_lib):
+    """What separates the reference's wiring from a sketch per k: a read that holds a genome's 21-mers but none of its 51-mers
+    (every 51-mer is broken by an error) contributes NOTHING to the k = 21 column."""
+    rng = np.random.default_rng(5)
+    genome = _reads(rng, 1, 3000, 3000, p_n=0.0, p_lower=0.0)[0]
+    ks, n = [21, 51], 400
+    gb, go = _flat([genome])
+    h, khi, klo, o = oracle_lib.sketch_genomes_kmers(gb, go, 51, n)
+    table = oracle_lib.refpipe_build(h, khi, klo, o, ks)
+    reads = []
+    for a in range(0, 2800, 50):  # 100-base reads with a substitution every 40 bases: 21-mers survive, 51-mers do not
+        r = bytearray(genome[a:a + 100])
+        for p in range(20, 100, 40):
+            r[p] = ord("A") if r[p] != ord("A") else ord("C")
+        reads += [bytes(r)] * 2
+    rb, ro = _flat(reads)
+    qh, qc, _, _ = oracle_lib.sketch_reads(rb, ro, 51, hmax=int(h.max()))
+    hits, _ = oracle_lib.refpipe_containment(qh, qc, 2, table)
+    assert hits[1][0] == 0 and hits[0][0] == 0
+    want = ind.refpipe_query(reads, [ind.refpipe_genome_kmers(genome, 51, n)], ks, 2)
+    assert want[0][0][0] == 0 and want[1][0][0] == 0
+    # ... while an independent 21-mer sketch of the same reads does find the genome
+    g21, _ = oracle_lib.sketch_genomes(gb, go, 21, n)
+    q21, c21, _, _ = oracle_lib.sketch_reads(rb, ro, 21, hmax=int(g21.max()))
+    hh, _ = oracle_lib.containment(q21, c21, False, 2, g21, np.asarray([0, len(g21)], dtype=np.uint64))
+    assert hh[0] > 50
