@@ -396,6 +396,73 @@ int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts,
                    uint64_t ngenomes, uint32_t* out_hits, uint32_t* out_sizes);
 
 /* ------------------------------------------------------------------------ *
+ * THE REFERENCE PIPELINE — stages A' / B wired the way scripts/select_db.py wires KMC and CMash.
+ * Replaces, together: `kmc -k60 -ci2 -cs3` over the reads (:50-52), `kmc_tools simple <db dump> <reads> intersect` (:54-56),
+ * kmc_dump + the FASTA rewrite (:58-65) and StreamingQueryDNADatabase.py <60-mers.fa> <db.h5> <csv> 30-60-10 (:73-76).
+ *
+ * The reference counts ONLY k_max-mers of the reads, keeps those that occur >= ci times AND are k_max-mers of some genome
+ * sketch, and hands that set to the streaming query, which derives the column of every k of its range from the
+ * k-PREFIXES of those k_max-mers and of their reverse complements, looked up among the sketched k_max-mers [CMash: upstream
+ * recollection, SURVEY.md §8c — parity unpinned like the rest of stage A/B; normative statement: oracle/mg_oracle.c,
+ * mgo_refpipe_*; a second statement on strings: tests/indep_sketch.py].  So the read side is stage A at ONE k
+ * (mg_sketch_reads_* / mg_sketch_stream_* with k = k_max and the table's threshold / pre-filter), and every smaller k's
+ * column is a function of WHICH sketched k_max-mers matched:
+ *   containment_k(g) = #{distinct k-prefixes of g's sketched k_max-mers that are the k-prefix of a MATCHED sketched
+ *                        k_max-mer (of any genome) or of its reverse complement}
+ *                      / #{distinct k-prefixes of g's sketched k_max-mers};
+ *   containment_kmax(g) = mg_containment_dev's.
+ * A k_max-mer "matches" when its hash (the mode in force, mg_set_hash_mode) is in the read sketch with count >= ci.
+ *
+ * mg_sketch_genomes_kmers: mg_sketch_genomes plus the k-mer of every sketch entry as the table keeps it (CMash's database
+ *   holds the sketches' k-mers beside their hashes: local_tests/dump_kmers.py:7-14), 2-bit packed, first base most
+ *   significant, right-aligned in (hi, lo): mode 0 the lexicographically smaller strand, mode 1 the strand with the smaller
+ *   MurmurHash3 (the reverse complement on a tie); of the FIRST window of the genome that has the hash.
+ * mg_refdb_build: from those genome-major entries of the LARGEST k (ks[nk-1]; ks ascending, nk <= 4), on the device: the
+ *   hash-major pairs of k_max and, per k below it, pa / pb per pair (the number — rank among the table's distinct
+ *   k-prefixes — of the kept k-mer's k-prefix / of its reverse complement's, 0xffffffff when that is no prefix of the
+ *   table) and the count list (distinct (prefix number, genome), ascending) with gsize_k[g] = entries of genome g.
+ * mg_refdb_upload: the same handle from stored arrays (metalign_amd/formats.py, table version 3) — or from a rank's share:
+ *   any contiguous run of the pairs with its pa / pb, any contiguous run of a count list with gsize counted within it;
+ *   nprefix is always the whole table's.  mg_refdb_download_*: what the builder stores.
+ * ------------------------------------------------------------------------ */
+typedef struct mg_refdb mg_refdb;
+int mg_sketch_genomes_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                            uint64_t* out_hashes, uint64_t* out_kmer_hi, uint64_t* out_kmer_lo, uint64_t* out_offsets);
+int mg_refdb_build(const uint64_t* hashes, const uint64_t* kmer_hi, const uint64_t* kmer_lo, const uint64_t* offsets,
+                   uint64_t ngenomes, int nk, const int* ks, mg_refdb** out);
+int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash,
+                    const uint32_t* pair_gen, const uint32_t* gsize_kmax, uint64_t max_hash, const uint32_t* const* pa,
+                    const uint32_t* const* pb, const uint64_t* nprefix, const uint32_t* const* cid,
+                    const uint32_t* const* cgen, const uint64_t* ncount, const uint32_t* const* gsize, mg_refdb** out);
+/* npairs; nprefix[nk-1], ncount[nk-1] (any may be NULL) */
+int mg_refdb_sizes(const mg_refdb* db, uint64_t* npairs, uint64_t* nprefix, uint64_t* ncount);
+/* any pointer may be NULL; kmer_hi / kmer_lo (pair order) only from a table built here */
+int mg_refdb_download_kmax(const mg_refdb* db, uint64_t* pair_hash, uint32_t* pair_gen, uint32_t* gsize, uint64_t* kmer_hi,
+                           uint64_t* kmer_lo);
+int mg_refdb_download_k(const mg_refdb* db, int ki, uint32_t* pa, uint32_t* pb, uint32_t* cid, uint32_t* cgen,
+                        uint32_t* gsize);
+int mg_refdb_nk(const mg_refdb* db);
+uint64_t mg_refdb_ngenomes(const mg_refdb* db);
+uint64_t mg_refdb_max_hash(const mg_refdb* db); /* the hmax to sketch the reads' k_max-mers with */
+/* the table of the largest k as a plain mg_db (owned by db): for mg_containment_dev and the table-wide helpers */
+const mg_db* mg_refdb_kmax_table(const mg_refdb* db);
+void mg_refdb_free(mg_refdb* db);
+/* Stage B of the reference pipeline.  q: the read sketch of the table's LARGEST k (complete: s = 0; a pending sketch is
+ * consumed on the device like mg_containment_dev does).  d_hits[i] / d_sizes[i]: the column of ks[i], ngenomes u32 each.
+ * Three launches for the largest k (bucket index, pairs — a matched pair also sets the bits of its prefixes —, reduction)
+ * and three for all smaller k together (the count lists streamed against the prefix bitmaps). */
+int mg_refpipe_containment_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uint32_t* const* d_hits,
+                               uint32_t* const* d_sizes);
+/* The two halves, for a multi-GPU job whose ranks hold hash-range slices of the pairs and prefix-range slices of the count
+ * lists: mark = the largest k's column of this rank's pairs + this rank's prefix bitmaps (zeroed, then set; mg_refdb_marks
+ * gives bitmap ki's device words for the exchange — the bitwise OR over the ranks is what count needs); count = the smaller
+ * k's columns (nk - 1 of them) from bitmaps d_marks[ki] (NULL: the handle's own). */
+int mg_refpipe_mark_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax);
+int mg_refpipe_count_dev(const mg_refdb* db, const uint32_t* const* d_marks, uint32_t* const* d_hits,
+                         uint32_t* const* d_sizes);
+int mg_refdb_marks(const mg_refdb* db, int ki, uint32_t** d_marks, uint64_t* nwords);
+
+/* ------------------------------------------------------------------------ *
  * Stage C — per-read taxon assignment + abundance histogram.
  * Replaces the loop of map_and_process (scripts/map_and_profile.py:193-264)
  * with parse_flag :104-111, filter_line :86-100, clean_read_hits :130-147,

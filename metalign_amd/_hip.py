@@ -38,6 +38,9 @@ EXPORTS = [
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
+    "mg_sketch_genomes_kmers", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
+    "mg_refdb_ngenomes", "mg_refdb_max_hash", "mg_refdb_kmax_table", "mg_refdb_free", "mg_refpipe_containment_dev", "mg_refpipe_mark_dev",
+    "mg_refpipe_count_dev", "mg_refdb_marks",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
     "mg_profile_multimapped_size", "mg_profile_multimapped", "mg_profile_resolve_multimapped_dev", "mg_multimapped_shares", "mg_profile_free", "mg_profile_assign",
 ]
@@ -90,6 +93,10 @@ def load_library(path=LIB_PATH):
     lib.mg_filter_resident_bytes.restype = ctypes.c_uint64
     lib.mg_count_saturation.restype = ctypes.c_uint32
     lib.mg_db_free.restype = None
+    lib.mg_refdb_free.restype = None
+    lib.mg_refdb_kmax_table.restype = ctypes.c_void_p
+    lib.mg_refdb_ngenomes.restype = ctypes.c_uint64
+    lib.mg_refdb_max_hash.restype = ctypes.c_uint64
     lib.mg_profile_free.restype = None
     lib.mg_shutdown.restype = None
     return lib
@@ -482,6 +489,76 @@ class SketchTable:
     def free(self):
         if self.handle:
             self.hip.lib.mg_db_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class RefTable:
+    """Device-resident table of the REFERENCE PIPELINE (opaque mg_refdb handle; include/metalign_hip.h): the hash-major table
+    of the largest k plus, per smaller k, the prefix numbers of every pair and the count list."""
+
+    def __init__(self, hip, handle, ks):
+        self.hip, self.handle, self.ks = hip, handle, [int(k) for k in ks]
+
+    @property
+    def ngenomes(self):
+        return int(self.hip.lib.mg_refdb_ngenomes(self.handle))
+
+    @property
+    def max_hash(self):
+        return int(self.hip.lib.mg_refdb_max_hash(self.handle))
+
+    def kmax_table(self):
+        """The table of the largest k as a SketchTable view (owned by this handle: do not free it)."""
+        t = SketchTable(self.hip, _vp(self.hip.lib.mg_refdb_kmax_table(self.handle)))
+        t.free = lambda: None
+        t._owner = self
+        return t
+
+    def sizes(self):
+        """-> (npairs, nprefix[nk-1], ncount[nk-1])"""
+        m = max(len(self.ks) - 1, 1)
+        npairs, npre, nc = ctypes.c_uint64(0), (ctypes.c_uint64 * m)(), (ctypes.c_uint64 * m)()
+        self.hip._chk(self.hip.lib.mg_refdb_sizes(self.handle, ctypes.byref(npairs), npre, nc))
+        return int(npairs.value), [int(x) for x in npre][: len(self.ks) - 1], [int(x) for x in nc][: len(self.ks) - 1]
+
+    def download(self, kmers=True):
+        """Everything the table builder stores: dict(pair_hash, pair_gen, gsize, [kmer_hi, kmer_lo,] small={k: dict(pa, pb, cid,
+        cgen, gsize, nprefix)})."""
+        npairs, npre, nc = self.sizes()
+        g = self.ngenomes
+        ph, pg, gs = np.zeros(max(npairs, 1), np.uint64), np.zeros(max(npairs, 1), np.uint32), np.zeros(max(g, 1), np.uint32)
+        khi = np.zeros(max(npairs, 1), np.uint64) if kmers else None
+        klo = np.zeros(max(npairs, 1), np.uint64) if kmers else None
+        self.hip._chk(self.hip.lib.mg_refdb_download_kmax(self.handle, _np(ph, ctypes.c_uint64), _np(pg, ctypes.c_uint32),
+                                                          _np(gs, ctypes.c_uint32), _np(khi, ctypes.c_uint64) if kmers else None,
+                                                          _np(klo, ctypes.c_uint64) if kmers else None))
+        out = dict(ks=list(self.ks), ngenomes=g, pair_hash=ph[:npairs], pair_gen=pg[:npairs], gsize=gs[:g], small={})
+        if kmers:
+            out.update(kmer_hi=khi[:npairs], kmer_lo=klo[:npairs])
+        for ki, k in enumerate(self.ks[:-1]):
+            pa, pb = np.zeros(max(npairs, 1), np.uint32), np.zeros(max(npairs, 1), np.uint32)
+            cid, cgen = np.zeros(max(nc[ki], 1), np.uint32), np.zeros(max(nc[ki], 1), np.uint32)
+            gk = np.zeros(max(g, 1), np.uint32)
+            self.hip._chk(self.hip.lib.mg_refdb_download_k(self.handle, ctypes.c_int(ki), _np(pa, ctypes.c_uint32), _np(pb, ctypes.c_uint32),
+                                                       _np(cid, ctypes.c_uint32), _np(cgen, ctypes.c_uint32), _np(gk, ctypes.c_uint32)))
+            out["small"][k] = dict(pa=pa[:npairs], pb=pb[:npairs], cid=cid[:nc[ki]], cgen=cgen[:nc[ki]], gsize=gk[:g], nprefix=npre[ki])
+        return out
+
+    def marks(self, ki):
+        """(device pointer, words) of the prefix bitmap of k number ki (after a mark call)."""
+        p, n = _vp(), ctypes.c_uint64(0)
+        self.hip._chk(self.hip.lib.mg_refdb_marks(self.handle, ctypes.c_int(ki), ctypes.byref(p), ctypes.byref(n)))
+        return int(p.value or 0), int(n.value)
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_refdb_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -1008,6 +1085,94 @@ class Hip:
                                                     ctypes.c_int(kmax), ctypes.c_int(k), ctypes.c_uint64(n),
                                                     _np(out_h, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
         return out_h[: int(out_o[-1])].copy(), out_o
+
+    def sketch_genomes_kmers(self, bases, offsets, k, n):
+        """mg_sketch_genomes plus every sketch entry's k-mer as the table keeps it, 2-bit packed (the reference pipeline's
+        table is built from these: refdb_build).  -> (hashes, kmer_hi, kmer_lo, offsets[G+1])"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        g = len(offsets) - 1
+        out_h, out_hi, out_lo = (np.zeros(max(g * n, 1), dtype=np.uint64) for _ in range(3))
+        out_o = np.zeros(g + 1, dtype=np.uint64)
+        self._chk(self.lib.mg_sketch_genomes_kmers(_np(bases, ctypes.c_uint8), _np(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
+                                                   ctypes.c_int(k), ctypes.c_uint64(n), _np(out_h, ctypes.c_uint64),
+                                                   _np(out_hi, ctypes.c_uint64), _np(out_lo, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
+        e = int(out_o[-1])
+        return out_h[:e].copy(), out_hi[:e].copy(), out_lo[:e].copy(), out_o
+
+    def refdb_build(self, hashes, kmer_hi, kmer_lo, offsets, ks):
+        """The reference pipeline's table from the genome-major entries of the largest k (sketch_genomes_kmers), on the device."""
+        hashes, kmer_hi, kmer_lo = (np.ascontiguousarray(a, dtype=np.uint64) for a in (hashes, kmer_hi, kmer_lo))
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        one = np.zeros(1, np.uint64)
+        c_ks = (ctypes.c_int * len(ks))(*[int(k) for k in ks])
+        h = _vp()
+        self._chk(self.lib.mg_refdb_build(_np(hashes if hashes.size else one, ctypes.c_uint64), _np(kmer_hi if kmer_hi.size else one, ctypes.c_uint64),
+                                          _np(kmer_lo if kmer_lo.size else one, ctypes.c_uint64), _np(offsets, ctypes.c_uint64),
+                                          ctypes.c_uint64(len(offsets) - 1), ctypes.c_int(len(ks)), c_ks, ctypes.byref(h)))
+        return RefTable(self, h, ks)
+
+    def refdb_upload(self, ks, ngenomes, pair_hash, pair_gen, gsize, max_hash, small):
+        """The same handle from stored arrays (formats.SketchTable.refpipe_arrays), or a rank's share of them.
+        small: per k below the largest, in order: dict(pa, pb, cid, cgen, gsize, nprefix)."""
+        ks = [int(k) for k in ks]
+        pair_hash = np.ascontiguousarray(pair_hash, dtype=np.uint64)
+        pair_gen = np.ascontiguousarray(pair_gen, dtype=np.uint32)
+        gsize = np.ascontiguousarray(gsize, dtype=np.uint32)
+        n, m = pair_hash.size, len(ks) - 1
+        assert len(small) == m
+        keep = []
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data_as(ctypes.c_void_p)
+        mm = max(m, 1)
+        c_pa, c_pb, c_cid, c_cgen, c_gs = ((_vp * mm)() for _ in range(5))
+        c_np, c_nc = (ctypes.c_uint64 * mm)(), (ctypes.c_uint64 * mm)()
+        for i, t in enumerate(small):
+            c_pa[i], c_pb[i] = arr(t["pa"], np.uint32), arr(t["pb"], np.uint32)
+            c_cid[i], c_cgen[i], c_gs[i] = arr(t["cid"], np.uint32), arr(t["cgen"], np.uint32), arr(t["gsize"], np.uint32)
+            c_np[i], c_nc[i] = int(t["nprefix"]), len(t["cid"])
+        c_ks = (ctypes.c_int * len(ks))(*ks)
+        h = _vp()
+        self._chk(self.lib.mg_refdb_upload(ctypes.c_uint64(int(ngenomes)), ctypes.c_int(len(ks)), c_ks, ctypes.c_uint64(n),
+                                           arr(pair_hash, np.uint64), arr(pair_gen, np.uint32), arr(gsize, np.uint32),
+                                           ctypes.c_uint64(int(max_hash)), c_pa, c_pb, c_np, c_cid, c_cgen, c_nc, c_gs, ctypes.byref(h)))
+        return RefTable(self, h, ks)
+
+    def refpipe_containment_dev(self, sketch, reftable, ci, d_hits, d_sizes):
+        """Stage B of the reference pipeline: sketch = the read sketch of the table's largest k; d_hits / d_sizes: one device
+        pointer per k of the table."""
+        nk = len(reftable.ks)
+        c_h = (_vp * nk)(*[_vp(p) for p in d_hits])
+        c_s = (_vp * nk)(*[_vp(p) for p in d_sizes])
+        self._chk(self.lib.mg_refpipe_containment_dev(sketch.handle, reftable.handle, ctypes.c_uint32(ci), c_h, c_s))
+
+    def refpipe_mark_dev(self, sketch, reftable, ci, d_hits_kmax, d_sizes_kmax):
+        self._chk(self.lib.mg_refpipe_mark_dev(sketch.handle, reftable.handle, ctypes.c_uint32(ci), _vp(d_hits_kmax), _vp(d_sizes_kmax)))
+
+    def refpipe_count_dev(self, reftable, d_marks, d_hits, d_sizes):
+        """d_marks: one device pointer per smaller k (None: the handle's own bitmaps); d_hits / d_sizes: nk - 1 pointers."""
+        m = max(len(reftable.ks) - 1, 1)
+        c_m = (_vp * m)(*[_vp(p) for p in d_marks]) if d_marks is not None else None
+        c_h = (_vp * m)(*[_vp(p) for p in d_hits])
+        c_s = (_vp * m)(*[_vp(p) for p in d_sizes])
+        self._chk(self.lib.mg_refpipe_count_dev(reftable.handle, c_m, c_h, c_s))
+
+    def refpipe_containment(self, sketch, reftable, ci=2):
+        """-> (hits u32[K][G], sizes u32[K][G]), k ascending."""
+        g, nk = reftable.ngenomes, len(reftable.ks)
+        d = self.empty(max(2 * g * nk, 1), np.uint32)
+        try:
+            self.refpipe_containment_dev(sketch, reftable, ci, [d.ptr + 4 * (2 * ki * g) for ki in range(nk)],
+                                         [d.ptr + 4 * ((2 * ki + 1) * g) for ki in range(nk)])
+            a = d.download()[: 2 * g * nk].reshape(nk, 2, g)
+            return a[:, 0, :].copy(), a[:, 1, :].copy()
+        finally:
+            d.free()
 
     def upload_table(self, hashes, offsets):
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)

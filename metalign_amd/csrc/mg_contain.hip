@@ -22,6 +22,7 @@ namespace mg {
 
 // One k of a stage-B call (every k of a pass goes through ONE launch of each kernel: at 10k genomes a launch is 5-50 us
 // of mostly latency, and a pass had nine of them).
+constexpr int kMaxSmallK = 3;  // k below the largest in a reference-pipeline table (mg_refdb)
 struct ContainK {
   // the read sketch and its bucket index
   const uint64_t* q;
@@ -43,6 +44,12 @@ struct ContainK {
   uint32_t* sizes_part;   // null unless the sketch is truncated
   uint32_t* hits;
   uint32_t* sizes;
+  // the reference pipeline (k_contain_pairs<true>, mg_refpipe_*): per k below the largest, the prefix numbers of every pair
+  // (kept strand / other strand, 0xffffffff = none) and the bitmap over D_k that a matched pair marks
+  int nsmall;
+  const uint32_t* pa[kMaxSmallK];
+  const uint32_t* pb[kMaxSmallK];
+  uint32_t* marks[kMaxSmallK];
 };
 constexpr int kMaxContainK = 4;
 struct ContainArgs {
@@ -52,6 +59,8 @@ struct ContainArgs {
   uint64_t ntiles;        // of all k together
   uint32_t* zero;         // the hit-counter copies of the call, zeroed by the index kernel (one launch less)
   uint64_t nzero;
+  uint32_t* zero2;        // (reference pipeline: the prefix bitmaps, zeroed in the same launch)
+  uint64_t nzero2;
 };
 
 // idx[b] = first position whose hash >= b << shift; idx[nbuckets] = n.  One thread per sketch entry i (and one
@@ -61,6 +70,7 @@ __global__ void k_build_index(const ContainArgs a) {
   const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t z = i0; z < a.nzero; z += stride) a.zero[z] = 0;
+  for (uint64_t z = i0; z < a.nzero2; z += stride) a.zero2[z] = 0;
   for (int ki = 0; ki < a.nk; ++ki) {
     const ContainK& K = a.k[ki];
     if (!K.build_index) continue;
@@ -83,6 +93,17 @@ constexpr uint32_t kCCap = 2048;        // read-sketch entries staged in LDS per
 
 // hits[g] += 1 for every pair (h, g) with h in the read sketch at count >= ci; sizes (optional, truncated
 // sketches only) counts every pair.  npairs = pairs with hash <= the sketch's completeness bound.
+// A matched pair of a reference-pipeline table marks, for every k below the largest, the k-prefix of its k-mer and of the reverse
+// complement (the streaming query tries both strands, scripts/select_db.py:73-76).
+__device__ __forceinline__ void mark_pair(const ContainK& K, uint64_t i) {
+  for (int s = 0; s < K.nsmall; ++s) {
+    const uint32_t x = K.pa[s][i], y = K.pb[s][i];
+    atomicOr(&K.marks[s][x >> 5], 1u << (x & 31u));
+    if (y != 0xffffffffu) atomicOr(&K.marks[s][y >> 5], 1u << (y & 31u));
+  }
+}
+
+template <bool MARK>
 __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
   __shared__ uint64_t s_q[kCCap];
   __shared__ uint32_t s_c[kCCap];
@@ -185,7 +206,10 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {  // p <= len; s_q[len] is padding, and an inactive slot (h = +inf) stops there
-        if (s_q[p[j]] == h[j] && h[j] != ~0ull && s_c[p[j]] >= ci) atomicAdd(&hits[g[j]], 1u);
+        if (s_q[p[j]] == h[j] && h[j] != ~0ull && s_c[p[j]] >= ci) {
+          atomicAdd(&hits[g[j]], 1u);
+          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT);
+        }
       }
     } else if (len) {
       // A run longer than the LDS stage: either the read sketch is locally much denser than the table (the top of
@@ -204,7 +228,10 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
           const uint32_t mid = (x + y) >> 1;
           if (q[mid] < h[j]) x = mid + 1; else y = mid;
         }
-        if (x < b[j] && q[x] == h[j] && qc[x] >= ci) atomicAdd(&hits[g[j]], 1u);
+        if (x < b[j] && q[x] == h[j] && qc[x] >= ci) {
+          atomicAdd(&hits[g[j]], 1u);
+          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT);
+        }
       }
     }
     __syncthreads();
@@ -241,6 +268,69 @@ __global__ void k_contain_reduce(const ContainArgs a) {
       }
       K.hits[g] = h;
       K.sizes[g] = sizes_part ? z : K.gsize[g];
+    }
+  }
+}
+
+// ---- the reference pipeline's smaller-k columns: count list x prefix bitmap ----
+struct CountK {
+  const uint32_t* cid;    // the distinct (prefix number, genome) combinations of this k, ascending by prefix number
+  const uint32_t* cgen;
+  uint64_t n, tile0, ngenomes;
+  const uint32_t* marks;  // bit p: prefix p of D_k was marked by a matched pair (this rank's, or the OR over the ranks)
+  const uint32_t* gsize;  // distinct prefixes per genome (within this list)
+  uint32_t* hits_part;
+  uint32_t* hits;
+  uint32_t* sizes;
+};
+struct CountArgs {
+  CountK k[kMaxSmallK];
+  int nk;
+  uint32_t copies;
+  uint64_t ntiles;
+};
+
+// hits[g] += 1 for every (p, g) of the list whose prefix is marked.  The list is sorted by prefix number, so a tile reads a short
+// run of the bitmap (coalesced, cached) and atomics go only to the marked entries; counters replicated as in k_contain_pairs.
+__global__ __launch_bounds__(kCT) void k_refpipe_count(const CountArgs a) {
+  constexpr int kPer = kCTile / kCT;
+  const int tid = threadIdx.x;
+  for (uint64_t gtile = blockIdx.x; gtile < a.ntiles; gtile += gridDim.x) {
+    int ki = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxSmallK; ++j) ki += (j < a.nk && gtile >= a.k[j].tile0) ? 1 : 0;
+    const CountK& K = a.k[ki];
+    const uint32_t* __restrict__ cid = K.cid;
+    const uint32_t* __restrict__ cgen = K.cgen;
+    const uint32_t* __restrict__ marks = K.marks;
+    uint32_t* const hits = K.hits_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes;
+    const uint64_t t0 = (gtile - K.tile0) * kCTile;
+    uint32_t p[kPer], g[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const uint64_t i = t0 + tid + (uint64_t)j * kCT;
+      p[j] = 0xffffffffu; g[j] = 0;
+      if (i < K.n) { p[j] = cid[i]; g[j] = cgen[i]; }
+    }
+    uint32_t w[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) w[j] = p[j] != 0xffffffffu ? marks[p[j] >> 5] : 0u;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+      if ((w[j] >> (p[j] & 31u)) & 1u) atomicAdd(&hits[g[j]], 1u);
+  }
+}
+
+__global__ void k_refpipe_reduce(const CountArgs a) {
+  const uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (int ki = 0; ki < a.nk; ++ki) {
+    const CountK& K = a.k[ki];
+    for (uint64_t g = g0; g < K.ngenomes; g += stride) {
+      uint32_t h = 0;
+      for (uint32_t c = 0; c < a.copies; ++c) h += K.hits_part[(uint64_t)c * K.ngenomes + g];
+      K.hits[g] = h;
+      K.sizes[g] = K.gsize[g];
     }
   }
 }
@@ -423,9 +513,13 @@ uint64_t mg_db_ngenomes(const mg_db* db) { return db ? db->ngenomes : 0; }
 uint64_t mg_db_max_hash(const mg_db* db) { return db ? db->max_hash : 0; }
 void mg_db_free(mg_db* db) { delete db; }
 
+}  // extern "C"
+
 // Stage B for every k of a pass: ONE index launch, ONE pairs launch over the tiles of all tables, ONE reduction.
-int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* const* dbs, uint32_t ci, uint32_t* const* d_hits,
-                             uint32_t* const* d_sizes) {
+// rp (the reference pipeline): nk == 1, qs[0] = the read sketch of the table's largest k against rp->kmax; a matched pair also
+// marks its prefixes in rp's bitmaps.
+static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* const* dbs, uint32_t ci, uint32_t* const* d_hits,
+                              uint32_t* const* d_sizes, const mg_refdb* rp) {
   MG_REQUIRE_READY();
   if (nk < 1 || nk > kMaxContainK) return fail(MG_ERR_ARG, "between 1 and %d k per stage-B call", kMaxContainK);
   if (!qs || !dbs || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
@@ -451,6 +545,9 @@ int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* co
     MG_TRY(sketch_wait(sk));  // built on another stream: this one waits for it on the device
     uint64_t bound = (sk->truncated && sk->n > 0) ? sk->last_hash : ~0ull;
     if (sk->has_bound) bound = sk->truncated ? sk->bound : ~0ull;
+    if (rp && bound != ~0ull)
+      return fail(MG_ERR_ARG, "the reference pipeline counts every k_max-mer of the reads (kmc, scripts/select_db.py:50-52): a bottom-s "
+                              "sketch cannot be its query");
     pend[m] = Pend{sk, dbs[i], bound != ~0ull, bound};  // truncated sketch: only table hashes <= bound take part, in the sizes too
     ContainK& K = a.k[m];
     K.hits = d_hits[i];
@@ -508,8 +605,18 @@ int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* co
     K.tile0 = tiles;
     tiles += (K.npairs + kCTile - 1) / kCTile;
     if (db->ngenomes > reduce_work) reduce_work = db->ngenomes;
+    K.nsmall = 0;
+    if (rp) {
+      K.nsmall = rp->nk - 1;
+      for (int s = 0; s < K.nsmall; ++s) {
+        K.pa[s] = rp->small[s].pa.as<uint32_t>();
+        K.pb[s] = rp->small[s].pb.as<uint32_t>();
+        K.marks[s] = rp->marks.as<uint32_t>() + rp->small[s].marks_at;
+      }
+    }
   }
   a.ntiles = tiles;
+  if (rp) { a.zero2 = rp->marks.as<uint32_t>(); a.nzero2 = rp->marks_words; }
   {
     ProfScope ps("contain_index");
     const uint64_t work = index_work > part_total ? index_work : part_total;
@@ -517,11 +624,81 @@ int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* co
     MG_HIP(hipGetLastError());
   }
   ProfScope ps("containment");
-  if (tiles)
-    hipLaunchKernelGGL(k_contain_pairs, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st, a);
+  if (tiles) {
+    if (rp)
+      hipLaunchKernelGGL(k_contain_pairs<true>, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st, a);
+    else
+      hipLaunchKernelGGL(k_contain_pairs<false>, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st, a);
+  }
   hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(reduce_work, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, a);
   MG_HIP(hipGetLastError());
   return MG_OK;
+}
+
+// The smaller-k columns of the reference pipeline from the prefix bitmaps (rp's own after a mark, or d_marks: the OR over the ranks
+// of a multi-GPU job): ONE launch over the count lists of all k, one reduction.  d_hits / d_sizes: nk - 1 of them.
+static int refpipe_count_launch(const mg_refdb* rp, const uint32_t* const* d_marks, uint32_t* const* d_hits, uint32_t* const* d_sizes) {
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  const int m = rp->nk - 1;
+  if (m == 0 || rp->kmax.ngenomes == 0) return MG_OK;
+  CountArgs a{};
+  a.nk = m;
+  const uint64_t G = rp->kmax.ngenomes;
+  uint32_t copies = 1;
+  while (copies < 64 && (uint64_t)copies * 2 * G <= 65536) copies *= 2;
+  a.copies = copies;
+  uint32_t* d_part = (uint32_t*)scratch("refpipe_part", (uint64_t)m * copies * G * sizeof(uint32_t));
+  if (!d_part) return MG_ERR_NOMEM;
+  uint64_t tiles = 0;
+  for (int s = 0; s < m; ++s) {
+    CountK& K = a.k[s];
+    K.cid = rp->small[s].cid.as<uint32_t>();
+    K.cgen = rp->small[s].cgen.as<uint32_t>();
+    K.n = rp->small[s].ncount;
+    K.tile0 = tiles;
+    tiles += (K.n + kCTile - 1) / kCTile;
+    K.ngenomes = G;
+    K.marks = d_marks ? d_marks[s] : rp->marks.as<uint32_t>() + rp->small[s].marks_at;
+    K.gsize = rp->small[s].gsize.as<uint32_t>();
+    K.hits_part = d_part + (uint64_t)s * copies * G;
+    K.hits = d_hits[s];
+    K.sizes = d_sizes[s];
+  }
+  a.ntiles = tiles;
+  ProfScope ps("refpipe_count");
+  hipLaunchKernelGGL(k_zero_u32, dim3(grid_for((uint64_t)m * copies * G, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_part,
+                     (uint64_t)m * copies * G);
+  if (tiles) hipLaunchKernelGGL(k_refpipe_count, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 8)), dim3(kCT), 0, st, a);
+  hipLaunchKernelGGL(k_refpipe_reduce, dim3(grid_for(G, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, a);
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
+extern "C" {
+
+int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* const* dbs, uint32_t ci, uint32_t* const* d_hits,
+                             uint32_t* const* d_sizes) {
+  return containment_launch(nk, qs, dbs, ci, d_hits, d_sizes, nullptr);
+}
+
+int mg_refpipe_mark_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax) {
+  if (!q || !db) return fail(MG_ERR_ARG, "null argument");
+  const mg_db* kdb = &db->kmax;
+  return containment_launch(1, &q, &kdb, ci, &d_hits_kmax, &d_sizes_kmax, db);
+}
+
+int mg_refpipe_count_dev(const mg_refdb* db, const uint32_t* const* d_marks, uint32_t* const* d_hits, uint32_t* const* d_sizes) {
+  MG_REQUIRE_READY();
+  if (!db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
+  return refpipe_count_launch(db, d_marks, d_hits, d_sizes);
+}
+
+int mg_refpipe_containment_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uint32_t* const* d_hits, uint32_t* const* d_sizes) {
+  if (!q || !db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
+  const int last = db->nk - 1;
+  MG_TRY(mg_refpipe_mark_dev(q, db, ci, d_hits[last], d_sizes[last]));
+  return refpipe_count_launch(db, nullptr, d_hits, d_sizes);
 }
 
 int mg_containment_dev(const mg_sketch* q, const mg_db* db, uint32_t ci, uint32_t* d_hits, uint32_t* d_sizes) {

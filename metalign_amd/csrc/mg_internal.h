@@ -323,3 +323,20 @@ struct mg_db {
   uint64_t max_hash = 0;
 };
 
+struct mg_refdb {
+  // The table of the REFERENCE PIPELINE (mg_refpipe.hip; oracle/mg_oracle.c, "THE REFERENCE'S OWN WIRING"): the hash-major
+  // table of the largest k, and for every k below it what derives that k's column from WHICH pairs matched.
+  mg_db kmax;
+  int nk = 0;
+  int ks[4] = {0, 0, 0, 0};
+  mg::DevBuf kmer_hi, kmer_lo;  // u64[npairs]: the kept k_max-mers in pair order (a table built here; empty after an upload)
+  struct Small {
+    mg::DevBuf pa, pb;      // u32[npairs]: number of the k-prefix of the pair's k-mer / of its reverse complement (0xffffffff: none)
+    mg::DevBuf cid, cgen;   // u32[ncount]: the distinct (prefix number, genome) combinations, ascending
+    mg::DevBuf gsize;       // u32[ngenomes]: distinct prefixes per genome
+    uint64_t nprefix = 0, ncount = 0;
+    uint64_t marks_at = 0, marks_n = 0;  // this k's bitmap inside `marks`: first word, words
+  } small[3];
+  mg::DevBuf marks;         // the prefix bitmaps of all smaller k, back to back (zeroed and written by a mark call)
+  uint64_t marks_words = 0;
+};

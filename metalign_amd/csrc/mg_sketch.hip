@@ -1708,6 +1708,64 @@ __global__ __launch_bounds__(256) void k_prefix_keys(const uint64_t* __restrict_
   }
 }
 
+// ---- stage A' with the k-mers kept (mg_sketch_genomes_kmers; oracle: mgo_sketch_genomes_kmers) ----
+// first[g * n + slot] = the smallest position p at which a k-mer with the slot's hash ENDS (CountEstimator.add keeps the first
+// k-mer of a hash).  pos[p]: the position hashes (mode 1: tagged with the kept strand in bit 63).
+__global__ __launch_bounds__(256) void k_first_positions(const uint64_t* __restrict__ pos, int tagged, const uint64_t* __restrict__ offsets,
+                                                         uint64_t nseq, uint64_t nbases, const uint64_t* __restrict__ sketch,
+                                                         const uint32_t* __restrict__ cnt, uint64_t n, unsigned long long* __restrict__ first) {
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; p < nbases; p += stride) {
+    const uint64_t t = pos[p];
+    if (t == kReservedHash) continue;
+    const uint64_t h = tagged ? (t & ~kTagBit) : t;
+    uint64_t lo = 0, hi = nseq;  // genome of p: offsets[lo] <= p < offsets[hi]
+    while (hi - lo > 1) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint64_t g = lo;
+    const uint64_t* sk = sketch + g * n;
+    uint32_t a = 0, b = cnt[g];
+    while (a < b) {
+      const uint32_t mid = (a + b) >> 1;
+      if (sk[mid] < h) a = mid + 1; else b = mid;
+    }
+    if (a >= cnt[g] || sk[a] != h) continue;
+    atomicMin(&first[g * n + a], (unsigned long long)p);
+  }
+}
+
+// The kept k-mer of every sketch entry, 2-bit packed (first base most significant) into (khi, klo): the window that ends at
+// first[entry], as the table keeps it — mode 0: the lexicographically smaller strand (KMC's canonical k-mer); mode 1 (tagged
+// position hashes): the strand CountEstimator.add keeps, bit 63 of the position's hash = the reverse complement.
+__global__ __launch_bounds__(256) void k_entry_kmers(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ pos, int tagged,
+                                                     const unsigned long long* __restrict__ first, const uint32_t* __restrict__ cnt,
+                                                     uint64_t nseq, uint64_t n, int k, uint64_t* __restrict__ khi, uint64_t* __restrict__ klo) {
+  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; e < nseq * n; e += stride) {
+    const uint64_t g = e / n, slot = e - g * n;
+    if (slot >= cnt[g]) continue;
+    const uint64_t p = first[e];
+    uint64_t f_hi = 0, f_lo = 0, r_hi = 0, r_lo = 0;
+    for (int i = 0; i < k; ++i) {
+      uint32_t c;
+      decode_base(bases[p + 1 - (uint64_t)k + (uint64_t)i], c);
+      f_hi = (f_hi << 2) | (f_lo >> 62);
+      f_lo = (f_lo << 2) | c;
+      const uint64_t cc = 3u - c;
+      if (2 * i < 64) r_lo |= cc << (2 * i); else r_hi |= cc << (2 * i - 64);
+    }
+    bool use_rc;
+    if (tagged) use_rc = (pos[p] & kTagBit) != 0;
+    else use_rc = r_hi < f_hi || (r_hi == f_hi && r_lo < f_lo);
+    khi[e] = use_rc ? r_hi : f_hi;
+    klo[e] = use_rc ? r_lo : f_lo;
+  }
+}
+
 }  // namespace mg
 
 extern "C" {
@@ -1790,8 +1848,11 @@ int mg_sketch_genomes_prefix(const uint8_t* bases, const uint64_t* offsets, uint
   return MG_OK;
 }
 
-int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
-                      uint64_t* out_hashes, uint64_t* out_offsets) {
+}  // extern "C"
+
+// mg_sketch_genomes, and (out_khi / out_klo given) mg_sketch_genomes_kmers
+static int sketch_genomes_impl(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                               uint64_t* out_hashes, uint64_t* out_khi, uint64_t* out_klo, uint64_t* out_offsets) {
   MG_REQUIRE_READY();
   if (!offsets || !out_offsets) return fail(MG_ERR_ARG, "null argument");
   if (k < 1 || k > MG_MAX_K) return fail(MG_ERR_ARG, "k=%d outside [1,%d]", k, MG_MAX_K);
@@ -1801,7 +1862,7 @@ int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ng
   out_offsets[0] = 0;
   const uint64_t kBatchBases = 1ull << 28;  // 2 GiB of position hashes per batch
   uint64_t g0 = 0, written = 0;
-  std::vector<uint64_t> h_slots;
+  std::vector<uint64_t> h_slots, h_hi, h_lo;
   std::vector<uint32_t> h_cnt;
   std::vector<uint64_t> rel;
   while (g0 < ngenomes) {
@@ -1818,23 +1879,40 @@ int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ng
     uint64_t* d_out = (uint64_t*)scratch("g_out", ng * n * sizeof(uint64_t));
     uint32_t* d_cnt = (uint32_t*)scratch("g_cnt", ng * sizeof(uint32_t));
     if (!d_bases || !d_off || !d_pos || !d_sorted || !d_out || !d_cnt) return MG_ERR_NOMEM;
+    const bool kmers = out_khi != nullptr;
+    const bool tagged = kmers && ctx().hash_mode == kHashCmash;  // the kept strand rides in bit 63 of the position hashes
+    uint64_t* d_key = d_pos;  // what is sorted (the untagged hashes)
+    unsigned long long* d_first = nullptr;
+    uint64_t *d_khi = nullptr, *d_klo = nullptr;
+    if (tagged) {
+      d_key = (uint64_t*)scratch("gk_key", (nb + 1) * sizeof(uint64_t));
+      if (!d_key) return MG_ERR_NOMEM;
+    }
+    if (kmers) {
+      d_first = (unsigned long long*)scratch("gk_first", ng * n * sizeof(uint64_t));
+      d_khi = (uint64_t*)scratch("gk_hi", ng * n * sizeof(uint64_t));
+      d_klo = (uint64_t*)scratch("gk_lo", ng * n * sizeof(uint64_t));
+      if (!d_first || !d_khi || !d_klo) return MG_ERR_NOMEM;
+    }
     if (nb) MG_HIP(hipMemcpyAsync(d_bases, bases + offsets[g0], nb, hipMemcpyHostToDevice, st));
     MG_HIP(hipMemcpyAsync(d_off, rel.data(), (ng + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const unsigned g256 = grid_for(nb ? nb : 1, 256, (unsigned)c.num_cus * 8);
     if (nb) {
       ProfScope ps("hash_positions");
       const uint64_t nchunks = (nb + kChunk - 1) / kChunk;
       unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
       bool ok = dispatch_k(k, [&]<int K>() {
         if (ctx().hash_mode == kHashCmash)  // (instantiated in mg_sketch_cmash.hip)
-          (void)launch_hash_positions_cmash(K, grid, st, d_bases, d_off, ng, nb, d_pos);
+          (void)launch_hash_positions_cmash(K, grid, st, d_bases, d_off, ng, nb, d_pos, tagged);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCanonical>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
                            d_pos);
       });
       if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
+      if (tagged) hipLaunchKernelGGL(k_clear_tags, dim3(g256), dim3(256), 0, st, d_pos, nb, d_key);
       MG_HIP(hipGetLastError());
     }
-    MG_TRY(segmented_sort_keys(d_pos, d_sorted, nb, d_off, ng));
+    MG_TRY(segmented_sort_keys(d_key, d_sorted, nb, d_off, ng));
     {
       ProfScope ps("take_bottom_n");
       hipLaunchKernelGGL(k_take_bottom_n, dim3(grid_for(ng, 1, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_sorted,
@@ -1843,17 +1921,48 @@ int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ng
     }
     h_slots.resize(ng * n);
     h_cnt.resize(ng);
+    if (kmers) {
+      // per sketch entry the first window of the genome that has its hash, then that window as the table keeps it
+      hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(ng * n, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st,
+                         reinterpret_cast<uint64_t*>(d_first), ng * n, kReservedHash);
+      if (nb) {
+        hipLaunchKernelGGL(k_first_positions, dim3(g256), dim3(256), 0, st, d_pos, tagged ? 1 : 0, d_off, ng, nb, d_out, d_cnt, n, d_first);
+        hipLaunchKernelGGL(k_entry_kmers, dim3(grid_for(ng * n, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_bases, d_pos,
+                           tagged ? 1 : 0, d_first, d_cnt, ng, n, k, d_khi, d_klo);
+      }
+      MG_HIP(hipGetLastError());
+      h_hi.resize(ng * n);
+      h_lo.resize(ng * n);
+      MG_HIP(hipMemcpyAsync(h_hi.data(), d_khi, ng * n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipMemcpyAsync(h_lo.data(), d_klo, ng * n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
     MG_HIP(hipMemcpyAsync(h_slots.data(), d_out, ng * n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     MG_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt, ng * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
     for (uint64_t i = 0; i < ng; ++i) {
-      for (uint32_t j = 0; j < h_cnt[i]; ++j) out_hashes[written + j] = h_slots[i * n + j];
+      for (uint32_t j = 0; j < h_cnt[i]; ++j) {
+        out_hashes[written + j] = h_slots[i * n + j];
+        if (kmers) { out_khi[written + j] = h_hi[i * n + j]; out_klo[written + j] = h_lo[i * n + j]; }
+      }
       written += h_cnt[i];
       out_offsets[g0 + i + 1] = written;
     }
     g0 = g1;
   }
   return MG_OK;
+}
+
+extern "C" {
+
+int mg_sketch_genomes(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                      uint64_t* out_hashes, uint64_t* out_offsets) {
+  return sketch_genomes_impl(bases, offsets, ngenomes, k, n, out_hashes, nullptr, nullptr, out_offsets);
+}
+
+int mg_sketch_genomes_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                            uint64_t* out_hashes, uint64_t* out_kmer_hi, uint64_t* out_kmer_lo, uint64_t* out_offsets) {
+  if (!out_kmer_hi || !out_kmer_lo) return fail(MG_ERR_ARG, "null argument");
+  return sketch_genomes_impl(bases, offsets, ngenomes, k, n, out_hashes, out_kmer_hi, out_kmer_lo, out_offsets);
 }
 
 }  // extern "C"
