@@ -30,6 +30,51 @@ def genome_bases(path):
     return np.concatenate(parts)
 
 
+def build_reference_pipeline(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0):
+    """The table of the REFERENCE PIPELINE (formats.py, version 3): the genomes are sketched at the LARGEST k only, with their
+    k-mers kept (CMash: MakeStreamingDNADatabase.py -n 1000 -k 60, /root/reference/local_tests/retrain_and_test_metalign.sh:49),
+    and what derives the smaller k's columns from the matched k_max-mers is prepared on the device (mg_refdb_build) — the role
+    of the prefix tree inside CMash's database and of the KMC dump of the sketches' k-mers (:59-66)."""
+    hip = _hip.Hip.get()
+    previous = hip.hash_mode
+    hip.set_hash_mode(hash_mode)
+    try:
+        ks = sorted(int(k) for k in ks)
+        names = [os.path.basename(p) for p in paths]
+        hs, his, los, offs = [], [], [], [0]
+        i = 0
+        while i < len(paths):
+            seqs, total = [], 0
+            while i < len(paths) and (not seqs or total < batch_bases):
+                g = genome_bases(paths[i])
+                seqs.append(g)
+                total += len(g)
+                i += 1
+            o = np.zeros(len(seqs) + 1, dtype=np.uint64)
+            o[1:] = np.cumsum([len(s) for s in seqs])
+            bases = np.concatenate(seqs) if total else np.zeros(1, np.uint8)
+            h, hi, lo, go = hip.sketch_genomes_kmers(bases, o, ks[-1], n)
+            hs.append(h)
+            his.append(hi)
+            los.append(lo)
+            offs.extend(int(v) + offs[-1] for v in go[1:])
+
+        def cat(parts):
+            return np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+        table = hip.refdb_build(cat(hs), cat(his), cat(los), np.asarray(offs, dtype=np.uint64), ks)
+        try:
+            arrays = table.download()
+        finally:
+            table.free()
+        f = hip.filter_build(arrays["pair_hash"])
+        bits = f.download()
+        f.free()
+        formats.write_refpipe_table(out_dir, names, n, arrays, bits, hash_mode=hash_mode)
+        return arrays
+    finally:
+        hip.set_hash_mode(previous)
+
+
 def build(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0, prefix_tables=False):
     """hash_mode: 0 = MurmurHash3 of the canonical k-mer (default); 1 = min(hash(kmer), hash(revcomp)) % 9999999999971,
     CMash's CountEstimator as SURVEY.md §8(c) recollects it (unverified; include/metalign_hip.h: mg_set_hash_mode).  The
@@ -93,16 +138,28 @@ def main(argv=None):
     p.add_argument('--prefix_tables', action='store_true',
                    help="with --hash_mode cmash: the k < k_max tables hold the k-prefixes of the sketched k_max-mers (CMash's "
                         "smaller-k columns as recollected) instead of a sketch per k.")
+    p.add_argument('--reference_pipeline', action='store_true',
+                   help="Build the table for stage A/B wired as the reference wires KMC and CMash (select_db.py:50-59,73-76): reads are "
+                        "sketched at the largest k only, every smaller k's column comes from the k-prefixes of the matched k_max-mers. "
+                        "Works with either --hash_mode.")
     a = p.parse_args(argv)
     if a.prefix_tables and a.hash_mode != 'cmash':
         p.error('--prefix_tables needs --hash_mode cmash')
+    if a.prefix_tables and a.reference_pipeline:
+        p.error('--prefix_tables and --reference_pipeline are two different definitions of the smaller-k columns')
     if os.path.isdir(a.genomes):
         paths = sorted(os.path.join(a.genomes, f) for f in os.listdir(a.genomes)
                        if '.fna' in f or f.endswith(('.fa', '.fa.gz', '.fasta', '.fasta.gz')))
     else:
         with open(a.genomes) as fh:
             paths = [ln.strip() for ln in fh if ln.strip()]
-    build(paths, a.out_dir, [int(x) for x in a.ks.split(',')], a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0, prefix_tables=a.prefix_tables)
+    ks = [int(x) for x in a.ks.split(',')]
+    if a.reference_pipeline:
+        if len(ks) > 4:
+            p.error('--reference_pipeline takes at most four k')
+        build_reference_pipeline(paths, a.out_dir, ks, a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0)
+        return
+    build(paths, a.out_dir, ks, a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0, prefix_tables=a.prefix_tables)
 
 
 if __name__ == '__main__':

@@ -103,10 +103,13 @@ class HipEngine:
         self.filters = []  # one membership pre-filter per k (set_filter), None = unfiltered
 
     # ---- inputs ----
-    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables):
+    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables, reftable=None):
         """tables: one (hashes, offsets[G+1]) per k — this rank's hash-range slice of each sketch table — or, for a
-        table already laid out hash-major on disk (formats.SketchTable.pairs), a dict(pair_hash=, pair_gen=, gsize=)."""
+        table already laid out hash-major on disk (formats.SketchTable.pairs), a dict(pair_hash=, pair_gen=, gsize=).
+        reftable (the reference pipeline: `tables` is then empty): this rank's share of the table as a _hip.RefTable —
+        stage A sketches the largest k only, stage B gives a column per k of the table."""
         hip = self.hip
+        self.reftable = reftable
         self.nreads = len(roffsets) - 1
         self.d_rb = hip.array(rbases if len(rbases) else np.zeros(1, np.uint8))
         self.d_ro = hip.array(roffsets)
@@ -115,8 +118,13 @@ class HipEngine:
         self.d_recs = hip.array(recs if len(recs) else np.zeros(1, _hip.REC_DTYPE))
         self.d_r2t = hip.array(ref2tax)
         self.nref, self.ntax = len(ref2tax), ntax
-        self.tables = [hip.upload_table_sorted(**t) if isinstance(t, dict) else hip.upload_table(t[0], t[1]) for t in tables]
-        self.nk = len(tables)
+        if reftable is not None:
+            self.tables = [reftable.kmax_table()]
+            self.nk = len(reftable.ks)  # columns of the result
+        else:
+            self.tables = [hip.upload_table_sorted(**t) if isinstance(t, dict) else hip.upload_table(t[0], t[1]) for t in tables]
+            self.nk = len(tables)
+        self.nsk = len(self.tables)  # k the reads are sketched at (the reference pipeline: the largest only)
         self.ngen_local = self.tables[0].ngenomes
         g = self.gpad = max(self.ngen_local, 1)
         # per k: [hits g | sizes g], all k in one buffer: one read-back
@@ -126,7 +134,7 @@ class HipEngine:
         # page-locked landing buffers: a step queues both read-backs behind its kernels and syncs once
         self.h_hs = hip.pinned(2 * g * self.nk, np.uint32)
         self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
-        self.filters += [None] * (self.nk - len(self.filters))
+        self.filters += [None] * (self.nsk - len(self.filters))
 
     # ---- stage A ----
     def set_filter(self, ki, table_hashes):
@@ -149,7 +157,7 @@ class HipEngine:
         if e in ("0", "1", "2", "3"):
             return int(e)
         free, _, pooled = self.hip.mem_info()
-        return 1 if 2 * 2 * 48 * nhashes * max(getattr(self, "nk", 1), 1) <= (free + pooled) // 2 else 0
+        return 1 if 2 * 2 * 48 * nhashes * max(getattr(self, "nsk_hint", getattr(self, "nk", 1)), 1) <= (free + pooled) // 2 else 0
 
     def wants_resident_index(self, hmax, nhashes):
         """MG_RESIDENT_INDEX=1 / 0 forces it on / off; otherwise: when at least 5 % of all k-mers pass the table's threshold
@@ -165,7 +173,7 @@ class HipEngine:
         if (hmax + 1) / hash_range < 0.05:
             return False
         free, _, pooled = self.hip.mem_info()
-        return 2 * 48 * nhashes * max(getattr(self, "nk", 1), 1) <= (free + pooled) // 2
+        return 2 * 48 * nhashes * max(getattr(self, "nsk_hint", getattr(self, "nk", 1)), 1) <= (free + pooled) // 2
 
     def set_filter_bits(self, ki, bits):
         """The same from the bit array the table builder stored (formats.SketchTable.filter_bits)."""
@@ -249,9 +257,42 @@ class HipEngine:
         return base_ptr + 4 * (2 * g * ki), base_ptr + 4 * (2 * g * ki + g)
 
     def _stage_b(self, sks, ci, base_ptr):
-        """Stage B of every k: one launch of each kernel for all of them (mg_containment_multi_dev)."""
+        """Stage B of every k: one launch of each kernel for all of them (mg_containment_multi_dev; at most four k per call).
+        The reference pipeline: the one sketch of the largest k against the table's pairs and count lists
+        (mg_refpipe_containment_dev), a column per k."""
+        if getattr(self, "reftable", None) is not None:
+            ptrs = [self._hs_ptrs(base_ptr, ki) for ki in range(self.nk)]
+            hook = getattr(self, "mark_exchange", None)
+            if hook is None:
+                self.hip.refpipe_containment_dev(sks[0], self.reftable, ci, [p[0] for p in ptrs], [p[1] for p in ptrs])
+                return
+            # a rank of a multi-GPU job: the matched pairs of ITS hash range mark prefixes anywhere in the table; the ranks'
+            # bitmaps are OR-ed (the job's exchange: every rank receives its own prefix share of every other rank's bitmap)
+            # before the rank's runs of the count lists are streamed against them
+            t, last = self.torch, self.nk - 1
+            self.hip.refpipe_mark_dev(sks[0], self.reftable, ci, ptrs[last][0], ptrs[last][1])
+            mine = []
+            for ki in range(last):
+                ptr, nw = self.reftable.marks(ki)
+                mine.append(t.as_tensor(_CudaView(ptr, nw, "<i4"), device="cuda") if nw else t.zeros(0, dtype=t.int32, device="cuda"))
+            ored = hook(mine)
+            self.hip.refpipe_count_dev(self.reftable, [o.data_ptr() if o.numel() else self.reftable.marks(ki)[0] for ki, o in enumerate(ored)],
+                                       [p[0] for p in ptrs[:last]], [p[1] for p in ptrs[:last]])
+            self._marks_keep = (mine, ored)  # (until the next call; the count is queued on the stream torch allocates for)
+            return
         ptrs = [self._hs_ptrs(base_ptr, ki) for ki in range(len(sks))]
-        self.hip.containment_multi_dev(sks, self.tables[:len(sks)], ci, [p[0] for p in ptrs], [p[1] for p in ptrs])
+        for a in range(0, len(sks), 4):  # (kMaxContainK of mg_contain.hip)
+            self.hip.containment_multi_dev(sks[a:a + 4], self.tables[a:a + 4], ci, [p[0] for p in ptrs[a:a + 4]],
+                                           [p[1] for p in ptrs[a:a + 4]])
+
+    def _stage_b_again(self, sks, ki, ci, base_ptr):
+        """Stage B of sketch number ki once more (its counting table overflowed and it was rebuilt at resolution)."""
+        self.hip.sync()
+        if getattr(self, "reftable", None) is not None:
+            self._stage_b(sks, ci, base_ptr)
+        else:
+            self.hip.containment_dev(sks[ki], self.tables[ki], ci, *self._hs_ptrs(base_ptr, ki))
+        self.hip.sync()
 
     def _hs_split(self, hs):
         g, G = self.gpad, self.ngen_local
@@ -274,8 +315,7 @@ class HipEngine:
         self.hip.sync()
         for ki, sk in enumerate(sks):
             if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
-                self.hip.containment_dev(sk, self.tables[ki], ci, *self._hs_ptrs(self.h_hs.ptr, ki))
-                self.hip.sync()
+                self._stage_b_again(sks, ki, ci, self.h_hs.ptr)
         hs, acc = self._hs_split(self.h_hs.array), self.h_acc.array.copy()
         mm = self.shard.multimapped() if want_multimapped else None
         self.shard.free()
@@ -343,9 +383,7 @@ class HipEngine:
         sks, shard = q["sks"], q["shard"]
         for ki, sk in enumerate(sks):
             if sk.resolve():  # stage A's counting table overflowed and the sketch was rebuilt: stage B again
-                self.hip.sync()
-                self.hip.containment_dev(sk, self.tables[ki], q["ci"], *self._hs_ptrs(rs["h_hs"].ptr, ki))
-                self.hip.sync()
+                self._stage_b_again(sks, ki, q["ci"], rs["h_hs"].ptr)
         hs, acc = self._hs_split(rs["h_hs"].array), rs["h_acc"].array.copy()
         mm = shard.multimapped() if want_multimapped else None
         shard.free()
@@ -374,7 +412,8 @@ class HipEngine:
     def x_setup(self, W, G, T, bounds, nslot):
         """bounds: per k, the W+1 hash-range bounds."""
         hip, g, K = self.hip, self.gpad, self.nk
-        self._xW, self._xNW, self._xnred = W, K * (W + 4) + 3, 2 * K * G + 2 * T + W * T + K + 2
+        # (words: per SKETCHED k; the reduce buffer: per column)
+        self._xW, self._xNW, self._xnred = W, self.nsk * (W + 4) + 3, 2 * K * G + 2 * T + W * T + K + 2
         if not hasattr(self, "_xs"):
             self._xs = [dict(d_acc=hip.empty(3 * T + 2, np.uint64), h_acc=hip.pinned(3 * T + 2, np.uint64),
                              h_hs=hip.pinned(2 * g * K, np.uint32), h_words=hip.pinned(W * self._xNW, np.int64),
@@ -410,7 +449,7 @@ class HipEngine:
         word_t = t.empty(self._xNW, dtype=t.int64, device="cuda")
         for ki, sk in enumerate(P["sks"]):
             sk.slice_words_dev(self._xbounds[ki].ptr, W - 1, word_t.data_ptr() + 8 * ki * (W + 4))
-        P["shard"].map_words_dev(word_t.data_ptr() + 8 * self.nk * (W + 4))
+        P["shard"].map_words_dev(word_t.data_ptr() + 8 * self.nsk * (W + 4))
         return word_t
 
     def x_redo_words(self, P, bounds, tail):
@@ -444,6 +483,10 @@ class HipEngine:
 
     def x_merge(self, P, rh, rc, k, lo, hi, any_trunc, bound):
         P.setdefault("keep", []).append((rh, rc))  # a deferred merge reads its inputs again if it has to be redone
+        if getattr(self, "reftable", None) is not None:
+            # the reference pipeline's stage B contains a collective (the prefix bitmaps): a merge that had to be redone a
+            # phase later could not repeat it on one rank alone — settled here instead (one sketch per pass, not one per k)
+            return self.hip.sketch_merge_dev(rh.data_ptr(), rc.data_ptr(), int(rh.numel()), k, lo, hi, 0, any_trunc, bound)
         return self.hip.sketch_merge_dev_async(rh.data_ptr(), rc.data_ptr(), int(rh.numel()), k, lo, hi, 0, any_trunc, bound)
 
     def x_stage_b(self, P, merged, ci):
@@ -598,14 +641,26 @@ def selfcheck_collectives(dist, torch, rank, world, device):
 class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 
-    def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None, always_exchange=False):
-        """k: one k-mer size or a sequence of them (ascending; the reference's cutoff reads the largest)."""
+    def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None, always_exchange=False,
+                 definition="sketch_per_k"):
+        """k: one k-mer size or a sequence of them (ascending; the reference's cutoff reads the largest).
+        definition: "sketch_per_k" — every k has a genome table of its own and the reads are sketched at every k; or
+        "reference_pipeline" — stage A/B wired as scripts/select_db.py:50-59,73-76 wires KMC and CMash: the reads are sketched
+        at the LARGEST k only and every smaller k's column comes from the k-prefixes of the matched k_max-mers (load() then
+        takes the reference pipeline's table: include/metalign_hip.h, mg_refdb)."""
         self.dist, self.rank, self.world = dist, rank, world
         # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
         self.exchange = dist is not None and (world > 1 or always_exchange)
         self.single_k = np.isscalar(k)
         self.ks = [int(k)] if self.single_k else [int(x) for x in k]
         self.k = self.ks[-1]
+        self.definition = definition
+        self.refpipe = definition == "reference_pipeline"
+        if definition not in ("sketch_per_k", "reference_pipeline"):
+            raise ValueError("unknown stage A/B definition %r" % (definition,))
+        if self.refpipe and s:
+            raise ValueError("the reference pipeline counts every k_max-mer of the reads: no bottom-s sketch (s = %d)" % s)
+        self.sks_k = [self.ks[-1]] if self.refpipe else self.ks  # the k the READS are sketched at
         self.ci, self.pct_id, self.s = ci, pct_id, s
         if engine is not None:
             self.engine = engine
@@ -629,19 +684,24 @@ class ShardJob:
         if dist is not None and self.device != "cpu" and dist.get_backend() == "gloo":
             self.dist = _HostStagedGloo(dist, self.torch)  # (tests: several ranks on one GPU)
 
-    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo=None, ntax=None):
+    def load(self, rbases, roffsets, recs, ref2tax, dbh, dbo=None, ntax=None, reftable=None):
         """recs: this rank's shard (starts on a read boundary).
+        The reference pipeline (definition="reference_pipeline"): dbh = the table's host arrays — a formats.SketchTable of
+        version 3, or the dict _hip.RefTable.download() returns — of which this rank uploads its share (pairs by hash range,
+        count lists by prefix range); reftable = the whole table already on the device (world size 1: nothing is uploaded).
         Tables, one per k (a single k takes them bare): either dbh / dbo = the FULL genome-major table (hashes,
         offsets[G+1]), sliced here by hash range; or dbh = a formats.SketchTable whose files are hash-major — then only
         this rank's hash range [bounds[r], bounds[r+1]) of every k is read from disk (dbo stays None).
         ntax: number of dense taxon ids (default: max(ref2tax) + 1)."""
-        K = len(self.ks)
+        K = len(self.sks_k)
         if hasattr(self.engine, "wants_resident_index"):
-            self.engine.nk = K  # (its memory estimate covers every k's index)
+            self.engine.nsk_hint = K  # (its memory estimate covers every sketched k's index)
             self.engine.bottom_s = self.s  # (a bottom-s sketch keeps the bit filter's definition: no index then)
         self.T = int(ntax) if ntax is not None else (int(np.max(ref2tax)) + 1 if len(ref2tax) else 0)
         tables, self.hmaxs, self.bounds = [], [], []
-        if hasattr(dbh, "pairs"):  # an on-disk hash-major table (formats.SketchTable, version 2)
+        if self.refpipe:
+            reftable = self._load_refpipe(dbh, reftable)
+        elif hasattr(dbh, "pairs"):  # an on-disk hash-major table (formats.SketchTable, version 2)
             disk = dbh
             self.G = disk.ngenomes
             for ki, k in enumerate(self.ks):
@@ -694,9 +754,13 @@ class ShardJob:
                 has_look = True
         else:
             self.nonempty = [len(recs) > 0]
-        self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
+        if self.refpipe:
+            self.engine.mark_exchange = self._or_marks if self.exchange else None
+            self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, [], reftable=reftable)
+        else:
+            self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
         if hasattr(self.engine, "prime") and (len(roffsets) > 1 or self.exchange):
-            choice = self.engine.prime(self.ks, self.hmaxs, self.s) if len(roffsets) > 1 else None
+            choice = self.engine.prime(self.sks_k, self.hmaxs, self.s) if len(roffsets) > 1 else None
             resident = any(f is not None and f.resident_bytes for f in getattr(self.engine, "filters", []))
             drop = resident and choice is not None and choice[1] < choice[0]
             if self.exchange and self.world > 1:
@@ -722,6 +786,87 @@ class ShardJob:
             # and (with the exchange) the collectives  (MG_SINGLE_STREAM=1: everything on one stream, for profiles in
             # which no two kernels overlap)
             self.engine.hip.stage_c_side_stream(os.environ.get("MG_SINGLE_STREAM", "0") != "1")
+
+    def _load_refpipe(self, src, reftable):
+        """The reference pipeline's table for this rank: hash-range bounds and the pre-filter from ALL pairs of the largest k;
+        the pairs of this rank's hash range with their prefix numbers, and of every smaller k's count list the run whose prefix
+        numbers fall in this rank's share of [0, nprefix) (cut on multiples of 32: a rank's share of a prefix bitmap is whole
+        words).  -> the engine's table handle."""
+        eng, W = self.engine, self.world
+        disk = hasattr(src, "refpipe_arrays")
+        full = src.refpipe_arrays() if disk else src
+        if [int(k) for k in full["ks"]] != self.ks:
+            raise ValueError("the table holds k = %r, the job was made for %r" % (list(full["ks"]), self.ks))
+        self.G = int(full["ngenomes"])
+        ph = full["pair_hash"]
+        hmax = int(full["max_hash"]) if "max_hash" in full else (int(ph[-1]) if len(ph) else 0)
+        b = table_bounds(ph, W, hmax, presorted=True)
+        self.hmaxs, self.bounds = [hmax], [b]
+        small_all = full["small"] if isinstance(full["small"], list) else [full["small"][k] for k in self.ks[:-1]]
+        self.nprefix = [int(t["nprefix"]) for t in small_all]
+        # word-aligned prefix cuts per smaller k: rank r counts prefixes [32 * cut[r], 32 * cut[r + 1])
+        self.mark_cuts = [[((npre + 31) // 32) * r // W for r in range(W)] + [(npre + 31) // 32] for npre in self.nprefix]
+        if hasattr(eng, "set_filter"):
+            bits = src.filter_bits(self.ks[-1]) if disk else None
+            if hasattr(eng, "wants_resident_index") and eng.wants_resident_index(hmax, len(ph)):
+                bits = None
+            if bits is not None and hasattr(eng, "set_filter_bits"):
+                eng.set_filter_bits(0, bits)
+            else:
+                eng.set_filter(0, ph)
+        if reftable is not None and W == 1:
+            return reftable
+        if W == 1:
+            share = dict(pair_hash=ph, pair_gen=full["pair_gen"], gsize=full["gsize"], small=small_all)
+        else:
+            r = self.rank
+            a = int(np.searchsorted(ph, np.uint64(b[r]), side="left"))
+            z = len(ph) if b[r + 1] > U64_MAX else int(np.searchsorted(ph, np.uint64(b[r + 1]), side="left"))
+            pg = np.asarray(full["pair_gen"][a:z])
+            small = []
+            for ki, t in enumerate(small_all):
+                lo, hi = 32 * self.mark_cuts[ki][r], 32 * self.mark_cuts[ki][r + 1]
+                ca, cb = int(np.searchsorted(t["cid"], lo, side="left")), int(np.searchsorted(t["cid"], hi, side="left"))
+                cg = np.asarray(t["cgen"][ca:cb])
+                small.append(dict(pa=t["pa"][a:z], pb=t["pb"][a:z], cid=t["cid"][ca:cb], cgen=cg,
+                                  gsize=np.bincount(cg, minlength=self.G).astype(np.uint32), nprefix=t["nprefix"]))
+            share = dict(pair_hash=ph[a:z], pair_gen=pg, gsize=np.bincount(pg, minlength=self.G).astype(np.uint32), small=small)
+        if hasattr(eng, "hip"):
+            return eng.hip.refdb_upload(self.ks, self.G, share["pair_hash"], share["pair_gen"], share["gsize"], hmax, share["small"])
+        share.update(ks=self.ks, ngenomes=self.G)
+        return share  # (a host engine of the tests takes the arrays themselves)
+
+    def _or_marks(self, marks):
+        """The reference pipeline's one extra exchange.  marks: per k below the largest, this rank's bitmap over ALL prefixes of
+        the table (int32 words; the prefixes of the k_max-mers that matched in this rank's hash range).  -> per k a bitmap of the
+        same size in which the words of THIS rank's prefix share hold the OR over the ranks (what its runs of the count lists
+        read): an all-to-all of word ranges — bytes per rank do not grow with the world size — and W - 1 ORs."""
+        t, dist, W, r = self.torch, self.dist, self.world, self.rank
+        out = []
+        for ki, m in enumerate(marks):
+            cuts = self.mark_cuts[ki]
+            if W == 1 or m.numel() == 0:
+                out.append(m)
+                continue
+            sizes = [cuts[q + 1] - cuts[q] for q in range(W)]
+            my = sizes[r]
+            if dist.get_backend() == "nccl":
+                recv = t.empty(W * my, dtype=m.dtype, device=m.device)
+                dist.all_to_all_single(recv, m, [my] * W, sizes)
+                red = recv[:my].clone()
+                for q in range(1, W):
+                    red |= recv[q * my:(q + 1) * my]
+            else:  # gloo (tests): no all-to-all — the whole bitmaps gathered
+                parts = [t.empty_like(m) for _ in range(W)]
+                dist.all_gather(parts, m.contiguous())
+                full = parts[0].clone()
+                for q in range(1, W):
+                    full |= parts[q]
+                red = full[cuts[r]:cuts[r + 1]]
+            mine = t.zeros_like(m)
+            mine[cuts[r]:cuts[r + 1]] = red
+            out.append(mine)
+        return out
 
     # ------------------------------------------------------------------
     def _all_to_all(self, send_h, send_c, send_counts, recv_counts):
@@ -767,17 +912,17 @@ class ShardJob:
         completeness of every k, carried-state map) and ONE all-to-all round of sketch slices, during which stage C's
         commit runs (it only needs the gathered state maps).
         -> (this rank's slice of the sample sketch for every k, commit results)."""
-        eng, t, dist, W, K = self.engine, self.torch, self.dist, self.world, len(self.ks)
+        eng, t, dist, W, K = self.engine, self.torch, self.dist, self.world, len(self.sks_k)
         if hasattr(eng, "profile_begin_async"):
             # stage C's map-only pass is queued first: stage A's one synchronisation covers it too
             if self._given is not None:
                 sks, eng.shard = self._given  # queued a pass ahead by run()
             else:
                 eng.profile_begin_async(self.pct_id)
-                sks = eng.sketch_local(self.ks, self.hmaxs, self.s)
+                sks = eng.sketch_local(self.sks_k, self.hmaxs, self.s)
             (m0, m1), ngroups = eng.profile_map()
         else:
-            sks = eng.sketch_local(self.ks, self.hmaxs, self.s)
+            sks = eng.sketch_local(self.sks_k, self.hmaxs, self.s)
             (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
         word, send_counts = [], []
         for ki, sk in enumerate(sks):
@@ -815,9 +960,9 @@ class ShardJob:
         merged = []
         for ki, (rh, rc) in enumerate(received):
             any_trunc, complete_to, lo, hi = self._merge_args(words, ki)
-            m = eng.merge_sketches(rh, rc, self.ks[ki], 0, any_trunc, complete_to, (lo, hi))
+            m = eng.merge_sketches(rh, rc, self.sks_k[ki], 0, any_trunc, complete_to, (lo, hi))
             if self.s or any_trunc:
-                m = self._bottom_s(m, any_trunc, self.ks[ki])
+                m = self._bottom_s(m, any_trunc, self.sks_k[ki])
             merged.append(m)
         # the sketches' buffers were the all-to-all's send buffers: they go back to the pool only now that the merges
         # (which read what the all-to-all delivered, and synchronised) are done
@@ -879,10 +1024,10 @@ class ShardJob:
             gc_was_on = gc.isenabled()
             gc.disable()  # (a cyclic collection in the loop is a hole of milliseconds in the GPU's queue)
             try:
-                q = eng.queue_pass(0, self.ks, self.hmaxs, self.s, self.ci, self.pct_id, side)
+                q = eng.queue_pass(0, self.sks_k, self.hmaxs, self.s, self.ci, self.pct_id, side)
                 out = None
                 for i in range(nsteps):
-                    nxt = (eng.queue_pass((i + 1) & 1, self.ks, self.hmaxs, self.s, self.ci, self.pct_id, side)
+                    nxt = (eng.queue_pass((i + 1) & 1, self.sks_k, self.hmaxs, self.s, self.ci, self.pct_id, side)
                            if i + 1 < nsteps else None)
                     sks, (hits, sizes), committed = eng.finish_pass(q, want_multimapped)
                     out = self._results(sks, hits, sizes, committed)
@@ -898,7 +1043,7 @@ class ShardJob:
         eng.hip.stage_a_side_stream(True)
         try:
             def front():  # what does not depend on the other ranks: stage A and stage C's map-only pass
-                return eng.sketch_local_async(self.ks, self.hmaxs, self.s), eng.new_shard_async(self.pct_id)
+                return eng.sketch_local_async(self.sks_k, self.hmaxs, self.s), eng.new_shard_async(self.pct_id)
             nxt = front()
             out = None
             for i in range(nsteps):
@@ -934,7 +1079,7 @@ class ShardJob:
         buf[o_bases:o_bases + T] = bases.view(np.int64)
         o = o_first + self.rank * T
         buf[o:o + T] = first.view(np.int64)
-        buf[o_qn:o_qn + K] = qn  # sample sketch size = sum of slice sizes
+        buf[o_qn:o_qn + len(qn)] = qn  # sample sketch size = sum of slice sizes (one per SKETCHED k)
         buf[o_scal:o_scal + 2] = scalars.view(np.int64)
 
     def _read_reduce(self, buf, mm):
@@ -945,12 +1090,12 @@ class ShardJob:
         count, bases = buf[o_count:o_count + T].view(np.uint64), buf[o_bases:o_bases + T].view(np.uint64)
         first = buf[o_first:o_first + W * T].view(np.uint64).reshape(W, T).min(axis=0)  # shards hold disjoint, increasing read-index ranges
         scalars = buf[o_scal:o_scal + 2].view(np.uint64)
-        return self._pack_out(hits, sizes, count, bases, first, scalars, [int(x) for x in buf[o_qn:o_qn + K]], mm)
+        return self._pack_out(hits, sizes, count, bases, first, scalars, [int(x) for x in buf[o_qn:o_qn + len(self.sks_k)]], mm)
 
     def _pack_out(self, hits, sizes, count, bases, first, scalars, qn, mm):
         out = dict(hits_k=hits, sizes_k=sizes, hits=hits[-1], sizes=sizes[-1], count=count, bases=bases, first_seen=first,
                    tot_rds=int(scalars[0]), n_ambig=int(scalars[1]), sketch_sizes=qn, sketch_size=qn[-1], multimapped=mm,
-                   ks=list(self.ks))
+                   ks=list(self.ks), sketched_ks=list(self.sks_k), definition=self.definition)
         ci_vals = hits / np.maximum(sizes, 1)
         out["containment_k"] = ci_vals
         out["containment"] = ci_vals[-1]  # the largest k: the column the cutoff reads (select_db.py:85-86)
@@ -958,7 +1103,7 @@ class ShardJob:
         return out
 
     def _run_exchange_pipelined(self, nsteps, want_multimapped):
-        eng, t, dist, W, K = self.engine, self.torch, self.dist, self.world, len(self.ks)
+        eng, t, dist, W, K = self.engine, self.torch, self.dist, self.world, len(self.sks_k)
         G, T = self.G, self.T
         NSLOT, NW = 4, K * (W + 4) + 3  # per rank, per k: W slice sizes | truncated | last hash | n | overflows; then m0 | m1 | reads
         eng.x_setup(W, G, T, self.bounds, NSLOT)
@@ -1000,9 +1145,9 @@ class ShardJob:
             for ki, (rh, rc) in enumerate(received):
                 any_trunc, complete_to, lo, hi = self._merge_args(words, ki)
                 # queued, not waited for: the merged slice is consumed on the device by stage B; phase C settles it
-                m = eng.x_merge(P, rh, rc, self.ks[ki], lo, hi, any_trunc, complete_to)
+                m = eng.x_merge(P, rh, rc, self.sks_k[ki], lo, hi, any_trunc, complete_to)
                 if self.s or any_trunc:
-                    m = self._bottom_s(m, any_trunc, self.ks[ki])
+                    m = self._bottom_s(m, any_trunc, self.sks_k[ki])
                 merged.append(m)
             eng.x_stage_b(P, merged, self.ci)
 
@@ -1025,7 +1170,7 @@ class ShardJob:
             AHEAD = 3  # stage A queued this many passes ahead: the GPU keeps hashing through a host stall of a millisecond or two
 
             def front():
-                return eng.x_front(self.ks, self.hmaxs, self.s, self.pct_id)
+                return eng.x_front(self.sks_k, self.hmaxs, self.s, self.pct_id)
             fronts = [front() for _ in range(min(AHEAD, nsteps))]
             passes, out = {}, None
             for tick in range(nsteps + 3):
@@ -1069,8 +1214,8 @@ class ShardJob:
                 sks, ahead = _sketch
                 ahead.free()  # (a single shard needs no map-only pass; its handle is created below)
             else:
-                sks = (eng.sketch_local_async(self.ks, self.hmaxs, self.s) if split
-                       else eng.sketch_local(self.ks, self.hmaxs, self.s))
+                sks = (eng.sketch_local_async(self.sks_k, self.hmaxs, self.s) if split
+                       else eng.sketch_local(self.sks_k, self.hmaxs, self.s))
             eng.profile_begin(self.pct_id, False)
             if split:
                 eng.profile_commit_launch(1, True, 0)

@@ -17,6 +17,17 @@ Sketch table directory (replaces data/cmash_db_n1000_k60.h5, ..._dump.kmc_{pre,s
                                  the size, include/metalign_hip.h: mg_filter) — the reference's ..._30-60-10.bf
 Version 1 (genome-major k<K>.hashes.u64 + k<K>.offsets.u64: every genome's ascending sketch back to back) is still
 read; it is inverted on the host when it is opened.
+Version 3 — the REFERENCE PIPELINE's table (meta "stage_a_definition": "reference_pipeline"; include/metalign_hip.h, mg_refdb):
+the reads are sketched at the LARGEST k only, as the reference's kmc call does (select_db.py:50-52), and every smaller k's column
+comes from the k-prefixes of the matched k_max-mers (the streaming query, :73-76).  The largest k has the version-2 files plus
+    <dir>/k<KMAX>.kmer_hi.u64 / .kmer_lo.u64   the sketched k_max-mer of every pair as the table keeps it, 2-bit packed, first base
+                                 most significant (CMash's database holds the sketches' k-mers too: local_tests/dump_kmers.py:7-14)
+and every k below it has, instead of a table of its own,
+    <dir>/k<K>.rp_pa.u32 / .rp_pb.u32          per pair of the k_max table: the number of the k-prefix of its k-mer / of the reverse
+                                 complement's (0xffffffff: not a prefix of the table), numbered in ascending order of the prefixes
+    <dir>/k<K>.rp_cid.u32 / .rp_cgen.u32       the distinct (prefix number, genome) combinations, ascending
+    <dir>/k<K>.gsize.u32                       distinct k-prefixes per genome (the column's denominators)
+    meta "nprefix": {K: number of distinct k-prefixes in the table}.
 Flat files so that a RefSeq-scale table (2.4 GB per k) is np.memmap'ed and uploaded slice by slice.
 """
 import gzip
@@ -91,6 +102,9 @@ class SketchTable:
         # tables written before the field existed are mode 0
         self.hash_mode = int(self.meta.get("hash_mode", 0))
         self.prefix_tables = bool(self.meta.get("prefix_tables", False))  # mode 1: k < k_max tables of k-prefixes (build_db)
+        # "reference_pipeline": only the largest k is sketched on the read side; "sketch_per_k": every k has a table of its own
+        self.definition = self.meta.get("stage_a_definition", "sketch_per_k")
+        self.refpipe = self.definition == "reference_pipeline"
         with open(os.path.join(path, "names.txt")) as fh:
             self.names = [ln.rstrip("\n") for ln in fh]
         self.ngenomes = len(self.names)
@@ -132,6 +146,43 @@ class SketchTable:
         if len(sl) != self.ngenomes:  # (a genome id >= ngenomes in the slice: bincount grew)
             raise ValueError("sketch table %s, k = %d: genome id %d in a table of %d genomes" % (self.path, k, len(sl) - 1, self.ngenomes))
         return dict(pair_hash=ph[a:b], pair_gen=pg[a:b], gsize=sl, max_hash=mx)
+
+    def refpipe_arrays(self, rank=0, world=1, bounds=None):
+        """The reference pipeline's table (version 3) as Hip.refdb_upload takes it — dict(ks, ngenomes, pair_hash, pair_gen, gsize,
+        max_hash, small=[dict(pa, pb, cid, cgen, gsize, nprefix) per k below the largest]) — or rank `rank`'s share of it: the
+        pairs whose hash lies in [bounds[rank], bounds[rank + 1]) with their pa / pb, and of every count list the run whose
+        prefix numbers lie in [nprefix * rank / world, nprefix * (rank + 1) / world); gsize counted within the share.  Memory
+        maps: only the share is read."""
+        if not self.refpipe:
+            raise ValueError("%s is not a reference-pipeline table" % self.path)
+        kmax = self.ks[-1]
+        ph, pg, gs = self._pair_maps(kmax)
+        a, b = 0, len(ph)
+        if world > 1:
+            a = int(np.searchsorted(ph, np.uint64(bounds[rank]), side="left"))
+            b = len(ph) if bounds[rank + 1] > 0xFFFFFFFFFFFFFFFF else int(np.searchsorted(ph, np.uint64(bounds[rank + 1]), side="left"))
+            gs = np.bincount(np.asarray(pg[a:b]), minlength=self.ngenomes).astype(np.uint32)
+        small = []
+        for k in self.ks[:-1]:
+            npre = int(self.meta["nprefix"][str(k)])
+            pa = np.memmap(self._f(k, "rp_pa.u32"), dtype="<u4", mode="r") if len(ph) else np.zeros(0, np.uint32)
+            pb = np.memmap(self._f(k, "rp_pb.u32"), dtype="<u4", mode="r") if len(ph) else np.zeros(0, np.uint32)
+            if os.path.getsize(self._f(k, "rp_cid.u32")):
+                cid = np.memmap(self._f(k, "rp_cid.u32"), dtype="<u4", mode="r")
+                cgen = np.memmap(self._f(k, "rp_cgen.u32"), dtype="<u4", mode="r")
+            else:
+                cid = cgen = np.zeros(0, np.uint32)
+            gk = np.fromfile(self._f(k, "gsize.u32"), dtype="<u4")
+            if len(pa) != len(ph) or len(pb) != len(ph) or len(cid) != len(cgen) or len(gk) != self.ngenomes:
+                raise ValueError("sketch table %s, k = %d: the reference-pipeline files do not belong together" % (self.path, k))
+            ca, cb = 0, len(cid)
+            if world > 1:
+                ca = int(np.searchsorted(cid, npre * rank // world, side="left"))
+                cb = int(np.searchsorted(cid, npre * (rank + 1) // world, side="left"))
+                gk = np.bincount(np.asarray(cgen[ca:cb]), minlength=self.ngenomes).astype(np.uint32)
+            small.append(dict(pa=pa[a:b], pb=pb[a:b], cid=cid[ca:cb], cgen=cgen[ca:cb], gsize=gk, nprefix=npre))
+        return dict(ks=list(self.ks), ngenomes=self.ngenomes, pair_hash=ph[a:b], pair_gen=pg[a:b], gsize=gs,
+                    max_hash=self.max_hash(kmax), small=small)
 
     def filter_bits(self, k):
         """The stored membership pre-filter of k (None for a table without one)."""
@@ -184,6 +235,40 @@ def write_sketch_table(path, names, ks, n, per_k, filters=None, hash_mode=0, pre
             np.ascontiguousarray(filters[k], dtype="<u4").tofile(os.path.join(path, "k%d.filter.u32" % k))
     meta = {"format": TABLE_FORMAT, "version": 2, "n": int(n), "ks": [int(k) for k in ks], "ngenomes": len(names), "hash_mode": int(hash_mode), "prefix_tables": bool(prefix_tables),
             "layout": "hash-major pairs", "hash": "murmur3_x64_128.h1(canonical ASCII k-mer), seed 0"}
+    with open(os.path.join(path, "meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
+def write_refpipe_table(path, names, n, table, filter_bits=None, hash_mode=0):
+    """Version 3: the reference pipeline's table.  table: what _hip.RefTable.download() returns (dict(ks, pair_hash, pair_gen,
+    gsize, kmer_hi, kmer_lo, small={k: dict(pa, pb, cid, cgen, gsize, nprefix)})); filter_bits: the membership pre-filter
+    over the largest k's hashes (Filter.download)."""
+    _write_common(path, names)
+    ks = [int(k) for k in table["ks"]]
+    kmax = ks[-1]
+
+    def put(arr, dt, name):
+        np.ascontiguousarray(arr, dtype=dt).tofile(os.path.join(path, name))
+    put(table["pair_hash"], "<u8", "k%d.pair_hash.u64" % kmax)
+    put(table["pair_gen"], "<u4", "k%d.pair_gen.u32" % kmax)
+    put(table["gsize"], "<u4", "k%d.gsize.u32" % kmax)
+    if table.get("kmer_hi") is not None:
+        put(table["kmer_hi"], "<u8", "k%d.kmer_hi.u64" % kmax)
+        put(table["kmer_lo"], "<u8", "k%d.kmer_lo.u64" % kmax)
+    if filter_bits is not None:
+        put(filter_bits, "<u4", "k%d.filter.u32" % kmax)
+    for k in ks[:-1]:
+        t = table["small"][k]
+        put(t["pa"], "<u4", "k%d.rp_pa.u32" % k)
+        put(t["pb"], "<u4", "k%d.rp_pb.u32" % k)
+        put(t["cid"], "<u4", "k%d.rp_cid.u32" % k)
+        put(t["cgen"], "<u4", "k%d.rp_cgen.u32" % k)
+        put(t["gsize"], "<u4", "k%d.gsize.u32" % k)
+    meta = {"format": TABLE_FORMAT, "version": 3, "n": int(n), "ks": ks, "ngenomes": len(names), "hash_mode": int(hash_mode),
+            "stage_a_definition": "reference_pipeline", "nprefix": {str(k): int(table["small"][k]["nprefix"]) for k in ks[:-1]},
+            "layout": "hash-major pairs of the largest k + prefix numbers and count lists of the smaller k",
+            "hash": "murmur3_x64_128.h1(canonical ASCII k-mer), seed 0" if not hash_mode else
+                    "min(murmur3_x64_128.h1(k-mer), murmur3_x64_128.h1(reverse complement)) % 9999999999971"}
     with open(os.path.join(path, "meta.json"), "w") as fh:
         json.dump(meta, fh, indent=1)
 

@@ -263,8 +263,10 @@ def run_sketch_steps_dist(args, ctx):
     reads = hip.parse_reads(text, 'fastq' if args.input_type == 'fastq' else 'fasta_ml')
     rb, ro = reads.download()
     reads.free()
+    # (a reference-pipeline table, formats.py version 3: the job sketches the largest k only and shares the table out by hash
+    # range for the pairs and by prefix range for the smaller k's count lists)
     job = ShardJob(hip, dist, rank, world, k=list(table.ks), ci=int(getattr(args, 'min_count', 2)),
-                   s=int(getattr(args, 'sketch_size', 0)), always_exchange=True)
+                   s=int(getattr(args, 'sketch_size', 0)), always_exchange=True, definition=table.definition)
     # (a format-2 table is hash-major on disk: the rank maps only its hash range; a format-1 table is inverted on the host
     # first, by every rank)
     job.load(rb, ro, np.zeros(0, dtype=_hip.REC_DTYPE), np.zeros(1, dtype=np.uint32), table, ntax=1)
@@ -401,13 +403,39 @@ def run_sketch_steps(args):
     table = formats.SketchTable(table_dir)
     previous_mode = hip.hash_mode
     hip.set_hash_mode(table.hash_mode)  # the reads are hashed by the definition the table was sketched with
+    try:
+        return _run_sketch_steps(args, hip, table, t_start)
+    finally:
+        hip.set_hash_mode(previous_mode)
+
+
+def stream_ok(ks):
+    """Whether mg_sketch_stream_begin takes this k set (1..4 of them, ascending); any other set goes through the piece-wise
+    path, whose per-k launches take any number of k in any order."""
+    return 1 <= len(ks) <= 4 and all(a < b for a, b in zip(ks, ks[1:]))
+
+
+def _run_sketch_steps(args, hip, table, t_start):
+    import time
     min_count = int(getattr(args, 'min_count', 2))
     s = int(getattr(args, 'sketch_size', 0))
-    # every k of the table: the hash-major pairs go up as they lie on disk (no sort), the stored pre-filter with them
-    # (the role of the reference's bloom pre-filter, -f ...bf, :70,75) ...
-    dev_tables, filts = [], []
-    for k in table.ks:
-        dev_tables.append(hip.upload_table_sorted(**table.pairs(k)))
+    # A reference-pipeline table (formats.py, version 3): the reads are sketched at the LARGEST k only — what the reference's
+    # kmc call counts (:50-52) — and stage B derives the smaller k's columns from the matched k_max-mers (:54-59, :73-76).
+    # Any other table: every k of the table has its own hash-major pairs, which go up as they lie on disk (no sort) ...
+    reftable = None
+    if table.refpipe:
+        if s:
+            sys.exit('Error: a reference-pipeline sketch table counts every k_max-mer of the reads; --sketch_size does not apply.')
+        arrays = table.refpipe_arrays()
+        reftable = hip.refdb_upload(arrays['ks'], arrays['ngenomes'], arrays['pair_hash'], arrays['pair_gen'], arrays['gsize'],
+                                    arrays['max_hash'], arrays['small'])
+        sketch_ks, dev_tables = [table.ks[-1]], [reftable.kmax_table()]
+    else:
+        sketch_ks = list(table.ks)
+        dev_tables = [hip.upload_table_sorted(**table.pairs(k)) for k in sketch_ks]
+    # ... the stored pre-filter with them (the role of the reference's bloom pre-filter, -f ...bf, :70,75) ...
+    filts = []
+    for k in sketch_ks:
         bits = table.filter_bits(k)
         filts.append(hip.filter_from_bits(bits) if bits is not None
                      else hip.filter_build(np.asarray(table.pairs(k)['pair_hash'])))
@@ -417,7 +445,9 @@ def run_sketch_steps(args):
     hmaxs = [t.max_hash for t in dev_tables]
     run_timings['table_load_s'] = time.perf_counter() - t_start
     t_start = time.perf_counter()
-    sks = None if os.environ.get('MG_NO_STREAM') == '1' else stream_reads_file(hip, args.reads, args.input_type, table.ks, hmaxs, s, filts)
+    sks = None
+    if os.environ.get('MG_NO_STREAM') != '1' and stream_ok(sketch_ks):
+        sks = stream_reads_file(hip, args.reads, args.input_type, sketch_ks, hmaxs, s, filts)
     free, _, pooled = hip.mem_info()
     batch_bytes = int(os.environ.get('MG_READ_BATCH_BYTES', 0)) or max((free + pooled) // 4, 1 << 26)
     for reads in (iter_read_batches(hip, args.reads, args.input_type, batch_bytes) if sks is None else ()):
@@ -425,35 +455,38 @@ def run_sketch_steps(args):
         if sks is None and reads.count > int(os.environ.get('MG_PRIME_READS', 4_000_000)):
             # the library sizes a k's counting table from the distinct-to-candidate ratio of its previous call and has
             # none yet (worst case: tens of GB to clear and sort against a dense table): the first million reads tell it
-            for sk in hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, min(1_000_000, max(reads.count // 4, 1)), table.ks,
+            for sk in hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, min(1_000_000, max(reads.count // 4, 1)), sketch_ks,
                                                        hmaxs, s, filts):
                 sk.resolve()
                 sk.free()
-        part = hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, reads.count, table.ks, hmaxs, s, filts)
+        part = hip.sketch_reads_multi_dev_async(d_b_ptr, d_o_ptr, reads.count, sketch_ks, hmaxs, s, filts)
         for sk in part:
             sk.resolve()  # (a sketch whose counting table overflowed is redone from the reads: before they go)
         reads.free()
-        sks = part if sks is None else [_merge_two(hip, a, b, k, hm, s) for a, b, k, hm in zip(sks, part, table.ks, hmaxs)]
+        sks = part if sks is None else [_merge_two(hip, a, b, k, hm, s) for a, b, k, hm in zip(sks, part, sketch_ks, hmaxs)]
     if sks is None:  # an empty reads file (on the piece-wise path)
         empty = _HostParsedReads(hip, np.zeros(0, np.uint8), np.zeros(1, np.uint64))
-        sks = hip.sketch_reads_multi_dev_async(*empty.device_ptrs(), 0, table.ks, hmaxs, s, filts)
+        sks = hip.sketch_reads_multi_dev_async(*empty.device_ptrs(), 0, sketch_ks, hmaxs, s, filts)
         for sk in sks:
             sk.resolve()
         empty.free()
     run_timings['stream_s'] = time.perf_counter() - t_start
     t_start = time.perf_counter()
     per_k = []
-    for sk, dev_table in zip(sks, dev_tables):
-        hits, sizes = hip.containment(sk, dev_table, min_count)
-        with np.errstate(divide='ignore', invalid='ignore'):
-            ci = np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0)
-        per_k.append(ci)
-    for h in sks + filts + dev_tables:
+    with np.errstate(divide='ignore', invalid='ignore'):
+        if reftable is not None:
+            hits_k, sizes_k = hip.refpipe_containment(sks[0], reftable, min_count)
+            for hits, sizes in zip(hits_k, sizes_k):
+                per_k.append(np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0))
+        else:
+            for sk, dev_table in zip(sks, dev_tables):
+                hits, sizes = hip.containment(sk, dev_table, min_count)
+                per_k.append(np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0))
+    for h in sks + filts + dev_tables + ([reftable] if reftable is not None else []):
         h.free()
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
     run_timings['containment_s'] = time.perf_counter() - t_start
-    hip.set_hash_mode(previous_mode)
     return out
 
 

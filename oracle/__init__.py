@@ -247,6 +247,41 @@ def refpipe_containment(q_hashes, q_counts, ci, table):
     return np.asarray(hits, dtype=np.uint32).reshape(len(table["ks"]), g), np.asarray(sizes, dtype=np.uint32).reshape(len(table["ks"]), g)
 
 
+def refpipe_matched(q_hashes, q_counts, ci, pair_hash):
+    """uint8[npairs]: the pair's hash is in the read sketch with count >= ci (mgo_refpipe_matched)."""
+    q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)
+    q_counts = np.ascontiguousarray(q_counts, dtype=np.uint32)
+    ph = np.ascontiguousarray(pair_hash, dtype=np.uint64)
+    matched = np.zeros(max(len(ph), 1), dtype=np.uint8)
+    lib().mgo_refpipe_matched(_p(q_hashes if len(q_hashes) else np.zeros(1, np.uint64), ctypes.c_uint64),
+                              _p(q_counts if len(q_counts) else np.zeros(1, np.uint32), ctypes.c_uint32),
+                              ctypes.c_uint64(len(q_hashes)), ctypes.c_uint32(ci),
+                              _p(ph if len(ph) else np.zeros(1, np.uint64), ctypes.c_uint64), ctypes.c_uint64(len(ph)),
+                              _p(matched, ctypes.c_uint8))
+    return matched[: len(ph)]
+
+
+def refpipe_mark_words(matched, t):
+    """The prefix bitmap a set of matched pairs marks (numpy; bit p of word p >> 5 = prefix p): t = dict(pa, pb, nprefix) of one
+    k below the largest, for the pairs `matched` is about.  -> uint32[(nprefix + 31) // 32]"""
+    nw = (int(t["nprefix"]) + 31) // 32
+    bits = np.zeros(nw * 32, dtype=np.uint8)
+    m = np.asarray(matched, dtype=bool)
+    bits[np.asarray(t["pa"])[m].astype(np.int64)] = 1
+    pb = np.asarray(t["pb"])[m]
+    bits[pb[pb != 0xFFFFFFFF].astype(np.int64)] = 1
+    return np.packbits(bits, bitorder="little").view("<u4").copy() if nw else np.zeros(0, np.uint32)
+
+
+def refpipe_count_words(words, t, ngenomes):
+    """hits u32[G] of one k below the largest from a prefix bitmap and (a run of) the k's count list t = dict(cid, cgen)."""
+    words = np.ascontiguousarray(words, dtype="<u4")
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little") if len(words) else np.zeros(0, np.uint8)
+    cid, cgen = np.asarray(t["cid"]).astype(np.int64), np.asarray(t["cgen"]).astype(np.int64)
+    on = bits[cid] == 1 if len(cid) else np.zeros(0, bool)
+    return np.bincount(cgen[on], minlength=ngenomes).astype(np.uint32)[:ngenomes]
+
+
 def containment(q_hashes, q_counts, q_truncated, ci, db_hashes, db_offsets):
     """-> (hits u32[G], sizes u32[G])."""
     q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)

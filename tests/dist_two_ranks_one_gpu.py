@@ -80,6 +80,28 @@ for kspec, s_cut in ((21, 0), ([21, 31, 51], 0), (21, 500), ([21, 31, 51], 700))
         assert np.array_equal(rd, want["mm_read"]) and np.array_equal(off, want["mm_offsets"]), (rank, idx)
     if os.environ.get("MG_DEBUG_DISTINCT_HINT"):
         assert getattr(job, "words_redone", 0) >= 1, getattr(job, "words_redone", 0)
+# ---- the reference pipeline (reads sketched at the largest k only; prefix bitmaps OR-ed across the ranks), both hash modes ----
+for ks, mode in (([21, 31, 51], 0), ([30, 40, 50, 60], 1), ([31], 0)):
+    hip.set_hash_mode(mode)
+    oracle.set_hash_mode(mode)
+    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200)
+    table = hip.refdb_build(h, khi, klo, o, ks)
+    full = table.download(kmers=False)
+    table.free()
+    wtab = oracle.refpipe_build(*oracle.sketch_genomes_kmers(gb, go, ks[-1], 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200), ks)
+    qh, qc, _, _ = oracle.sketch_reads(rb, ro, ks[-1], hmax=int(h.max()))
+    whits, wsizes = oracle.refpipe_containment(qh, qc, 2, wtab)
+    job = ShardJob(hip, dist, rank, world, k=ks, definition="reference_pipeline")
+    job.load(my_rb, my_ro, my_recs, ref2tax, full)
+    for idx, got in enumerate([job.step(), job.run(4), job.step()]):
+        assert np.array_equal(got["hits_k"], whits) and np.array_equal(got["sizes_k"], wsizes), (rank, idx, ks, mode)
+        for key in ("count", "bases", "first_seen"):
+            assert np.array_equal(got[key], want[key]), (rank, idx, key)
+        assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
+        assert got["definition"] == "reference_pipeline" and got["sketched_ks"] == [ks[-1]]
+    assert whits[-1].max() > 100
+    hip.set_hash_mode(0)
+    oracle.set_hash_mode(0)
 dist.barrier()
 dist.destroy_process_group()
 print("two-ranks-one-gpu ok (rank %d)" % rank, flush=True)

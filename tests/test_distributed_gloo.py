@@ -21,11 +21,13 @@ class OracleEngine:
         self.o = oracle
         self.torch = torch_mod
 
-    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables):
+    def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables, reftable=None):
         self.rb, self.ro = rbases, roffsets
         self.recs, self.has_look = recs, has_lookahead
         self.ref2tax, self.ntax = ref2tax, ntax
         self.tables = tables  # one (hashes, offsets) per k: this rank's hash-range slice
+        self.reftable = reftable  # the reference pipeline: this rank's share of the table (host arrays)
+        self.ncols = len(reftable["ks"]) if reftable is not None else len(tables)
 
     class _Sk:
         def __init__(self, h, c, trunc):
@@ -73,6 +75,18 @@ class OracleEngine:
         return self._Sk(uh, uc, trunc)
 
     def containment(self, sks, ci):
+        if self.reftable is not None:
+            # the reference pipeline: mark from this rank's pairs, the job's OR exchange, count over this rank's count-list runs
+            share, sk = self.reftable, sks[0]
+            G = share["ngenomes"]
+            matched = self.o.refpipe_matched(sk.h, sk.c, ci, share["pair_hash"])
+            marks = [self.torch.from_numpy(self.o.refpipe_mark_words(matched, t).view(np.int32)) for t in share["small"]]
+            hook = getattr(self, "mark_exchange", None)
+            ored = hook(marks) if hook is not None else marks
+            hits = [self.o.refpipe_count_words(ored[ki].numpy().view(np.uint32), t, G) for ki, t in enumerate(share["small"])]
+            hits.append(np.bincount(np.asarray(share["pair_gen"])[matched != 0], minlength=G).astype(np.uint32)[:G])
+            sizes = [np.asarray(t["gsize"], dtype=np.uint32) for t in share["small"]] + [np.asarray(share["gsize"], dtype=np.uint32)]
+            return np.stack(hits), np.stack(sizes)
         res = [self._containment_one(sk, ci, *self.tables[ki]) for ki, sk in enumerate(sks)]
         return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
 
@@ -112,8 +126,8 @@ class PipelinedOracleEngine(OracleEngine):
     force_stale_words = False  # publish an overflow count once: every rank must then repeat the all-gather
 
     def x_setup(self, W, G, T, bounds, nslot):
-        K = len(bounds)
-        self._xW, self._xNW, self._xnred, self._xbounds_list = W, K * (W + 4) + 3, 2 * K * G + 2 * T + W * T + K + 2, [list(b) for b in bounds]
+        K, C = len(bounds), self.ncols  # sketched k (words), columns (reduce buffer)
+        self._xW, self._xNW, self._xnred, self._xbounds_list = W, K * (W + 4) + 3, 2 * C * G + 2 * T + W * T + C + 2, [list(b) for b in bounds]
 
     def x_begin(self):
         pass
@@ -252,6 +266,29 @@ def _worker(rank, world, port, tmpdir):
         if not ok:
             print("rank", rank, "case", case, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
         res[case] = bool(ok)
+    # ---- the reference pipeline (reads sketched at the largest k only; the prefix bitmaps OR-ed across the ranks) ----
+    for case, (ks, mode) in enumerate([([15, 21, 31], 0), ([21], 0), ([9, 12, 15, 21], 1)], start=100):
+        oracle.set_hash_mode(mode)
+        h, khi, klo, o = oracle.sketch_genomes_kmers(gb, go, ks[-1], n)
+        full = oracle.refpipe_build(h, khi, klo, o, ks)
+        qh, qc, _, _ = oracle.sketch_reads(rb, ro, ks[-1], hmax=int(h.max()))
+        whits, wsizes = oracle.refpipe_containment(qh, qc, 2, full)
+        job = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=OracleEngine(torch), definition="reference_pipeline")
+        job.load(my_reads[0], my_reads[1], my_recs, ref2tax, full, ntax=ntax)
+        out = job.step()
+        checks = dict(hits=np.array_equal(out["hits_k"], whits), sizes=np.array_equal(out["sizes_k"], wsizes),
+                      qn=out["sketch_sizes"] == [len(qh)], count=np.array_equal(out["count"], want["count"]),
+                      first=np.array_equal(out["first_seen"], want["first_seen"]), some=bool(whits.any()))
+        pjob = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=PipelinedOracleEngine(torch), definition="reference_pipeline")
+        pjob.load(my_reads[0], my_reads[1], my_recs, ref2tax, full, ntax=ntax)
+        pout = pjob.run(4)
+        for key in ("hits_k", "sizes_k", "count", "bases", "first_seen"):
+            checks["run_" + key] = np.array_equal(pout[key], out[key])
+        ok = all(checks.values())
+        if not ok:
+            print("rank", rank, "refpipe case", case, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
+        res[case] = bool(ok)
+        oracle.set_hash_mode(0)
     with open(os.path.join(tmpdir, "rank%d.txt" % rank), "w") as fh:
         fh.write(repr(res))
     dist.barrier()
@@ -268,7 +305,7 @@ def test_sharding_matches_single_process(tmp_path, world):
     s.close()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 1: True, 2: True, 3: True})
+        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 1: True, 2: True, 3: True, 100: True, 101: True, 102: True})
 
 
 def _sam_worker(rank, world, port, tmpdir):

@@ -314,3 +314,141 @@ def test_select_main_on_a_cmash_mode_table_with_prefix_columns(hip, oracle_lib, 
         else:
             assert nm not in got
     assert csv[1].split(",")[0] in (names[3], names[8])
+
+
+
+def _joined(gb, go, n):
+    """The contigs of _make_data_dir's genomes as build_db sketches them: joined by 'N'."""
+    joined, offs = [], [0]
+    for g in range(n):
+        s = gb[int(go[g]):int(go[g + 1])]
+        half = len(s) // 2
+        j = np.concatenate([s[:half], np.frombuffer(b"N", np.uint8), s[half:]])
+        joined.append(j)
+        offs.append(offs[-1] + len(j))
+    return np.concatenate(joined), np.asarray(offs, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["canonical_kmer_hash", "cmash_recollection"])
+def test_select_main_on_a_reference_pipeline_table(hip, oracle_lib, tmp_path, mode):
+    """build_db --reference_pipeline, then select_main on it, as one process and as 1 / 2 / 3 ranks of a torch.distributed.run
+    launch: the reads are sketched at the largest k only (what the reference's kmc call counts, scripts/select_db.py:50-52) and
+    the CSV — same layout, one column per k — equals the oracle's reference pipeline; the selection and the subset database
+    come out of the reference's own cutoff code unchanged."""
+    import subprocess
+    import sys
+    from metalign_amd import build_db, formats, select_db
+    rng = np.random.default_rng(5150 + mode)
+    data, gb, go, names, accs = _make_data_dir(tmp_path, rng)
+    ks, n = [21, 31, 41, 51], 150
+    tdir = str(data / "sketch_table")
+    build_db.main([str(data / "organism_files"), tdir, "-n", str(n), "-k", "21,31,41,51", "--reference_pipeline"] +
+                  (["--hash_mode", "cmash"] if mode else []))
+    assert hip.hash_mode == 0
+    table = formats.SketchTable(tdir)
+    assert table.refpipe and table.hash_mode == mode and table.ks == ks and table.names == sorted(names)
+    order = [names.index(nm) for nm in table.names]  # (build_db lists the directory sorted)
+    jb, jo = _joined(gb, go, len(names))
+    oracle_lib.set_hash_mode(mode)
+    try:
+        h, khi, klo, o = oracle_lib.sketch_genomes_kmers(jb, jo, ks[-1], n)
+        # genomes in the table's order
+        parts = [(h[int(o[g]):int(o[g + 1])], khi[int(o[g]):int(o[g + 1])], klo[int(o[g]):int(o[g + 1])]) for g in order]
+        oo = np.zeros(len(order) + 1, np.uint64)
+        oo[1:] = np.cumsum([len(p[0]) for p in parts])
+        want = oracle_lib.refpipe_build(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+                                        np.concatenate([p[2] for p in parts]), oo, ks)
+        got = table.refpipe_arrays()
+        assert np.array_equal(got["pair_hash"], want["pair_hash"]) and np.array_equal(got["pair_gen"], want["pair_gen"])
+        for t, k in zip(got["small"], ks[:-1]):
+            for key in ("pa", "pb", "cid", "cgen", "gsize"):
+                assert np.array_equal(np.asarray(t[key]), want["small"][k][key]), (k, key)
+            assert t["nprefix"] == want["small"][k]["nprefix"]
+        rb, ro, src = util.sample_reads(rng, gb, go, 4000, 150, err=0.005, present=[3, 8, 9])
+        fq = tmp_path / "sample.fq"
+        with open(fq, "w") as fh:
+            for i in range(len(ro) - 1):
+                s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
+                fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+        qh, qc, _, _ = oracle_lib.sketch_reads(rb, ro, ks[-1], hmax=int(want["pair_hash"][-1]))
+        hits, sizes = oracle_lib.refpipe_containment(qh, qc, 2, want)
+    finally:
+        oracle_lib.set_hash_mode(0)
+    per_k = [hits[ki] / np.maximum(sizes[ki], 1) for ki in range(len(ks))]
+    tmpd = tmp_path / "tmp"
+    args = select_db.select_parseargs([str(fq), str(data), "--temp_dir", str(tmpd), "--keep_temp_files", "--sketch_table", tdir])
+    select_db.select_main(args)
+    assert hip.hash_mode == 0
+    csv = (tmpd / "cmash_query_results.csv").read_text().splitlines()
+    assert csv[0] == ",k=21,k=31,k=41,k=51"
+    got = {ln.split(",")[0]: [float(x) for x in ln.split(",")[1:]] for ln in csv[1:]}
+    for g, nm in enumerate(table.names):
+        if per_k[0][g] > 0:
+            assert got[nm] == [float(c[g]) for c in per_k], nm
+        else:
+            assert nm not in got
+    top = {csv[i].split(",")[0] for i in (1, 2, 3)}
+    assert top == {names[3], names[8], names[9]}
+    sub = (tmpd / "subset_db_info.txt").read_text().splitlines()
+    assert sub[0].startswith("Accesion") and len(sub) > 2
+    # the same command as ranks of a torch.distributed.run launch: world 1 under RCCL (every collective in the path), 2 and 3
+    # ranks sharing this GPU over gloo — the pairs by hash range, the count lists by prefix range, the bitmaps OR-ed
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for world in (1, 2, 3):
+        tmpw = tmp_path / ("tmp_world%d" % world)
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        if world == 1:
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29620 + mode), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MG_FORCE_DIST="1")
+            cmd = [sys.executable]
+        else:
+            env.update(MG_DIST_BACKEND="gloo")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                   "127.0.0.1", "--master-port", str(29622 + 2 * world + mode)]
+        r = subprocess.run(cmd + ["-m", "metalign_amd.select_db", str(fq), str(data), "--temp_dir", str(tmpw), "--keep_temp_files",
+                                  "--sketch_table", tdir], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert (tmpw / "cmash_query_results.csv").read_text().splitlines() == csv, world
+        assert (tmpw / "subset_db_info.txt").read_text().splitlines() == sub
+
+
+def test_select_main_takes_tables_of_five_k_and_of_descending_k(hip, oracle_lib, tmp_path):
+    """A table of more than four k, and one whose k are not ascending (build_db neither sorts nor limits -k): the streamed
+    sketch session takes 1..4 ascending k, so these go through the per-k launches — as one process and as a ShardJob (whose
+    stage B takes its k four at a time)."""
+    from metalign_amd import build_db, select_db
+    from metalign_amd.distributed import ShardJob
+    rng = np.random.default_rng(77)
+    data, gb, go, names, accs = _make_data_dir(tmp_path, rng)
+    jb, jo = _joined(gb, go, len(names))
+    rb, ro, src = util.sample_reads(rng, gb, go, 3000, 150, err=0.005, present=[2, 7])
+    fq = tmp_path / "sample.fq"
+    with open(fq, "w") as fh:
+        for i in range(len(ro) - 1):
+            s = bytes(rb[int(ro[i]):int(ro[i + 1])]).decode()
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    paths = [str(data / "organism_files" / nm) for nm in names]
+    for ks in ([21, 31, 41, 51, 61], [60, 50, 40, 30]):
+        tdir = str(tmp_path / ("table_%d" % len(ks)))
+        build_db.build(paths, tdir, ks, 120)
+        tmpd = tmp_path / ("tmp_%d" % len(ks))
+        args = select_db.select_parseargs([str(fq), str(data), "--temp_dir", str(tmpd), "--keep_temp_files", "--sketch_table", tdir])
+        select_db.select_main(args)
+        csv = (tmpd / "cmash_query_results.csv").read_text().splitlines()
+        assert csv[0] == "," + ",".join("k=%d" % k for k in ks)
+        per_k, tabs = [], []
+        for k in ks:
+            oh, oo = oracle_lib.sketch_genomes(jb, jo, k, 120)
+            tabs.append((oh, oo))
+            qh, qc, tr, _ = oracle_lib.sketch_reads_filtered(rb, ro, k, oh, hmax=int(oh.max()))
+            hits, sizes = oracle_lib.containment(qh, qc, tr, 2, oh, oo)
+            per_k.append((hits, sizes))
+        got = {ln.split(",")[0]: [float(x) for x in ln.split(",")[1:]] for ln in csv[1:]}
+        for g, nm in enumerate(names):
+            if per_k[0][0][g] > 0:
+                assert got[nm] == [float(h[g] / max(z[g], 1)) for h, z in per_k], nm
+        if ks == sorted(ks):  # (a job wants its k ascending)
+            job = ShardJob(hip, None, 0, 1, k=ks)
+            job.load(rb, ro, np.zeros(0, dtype=oracle_lib.REC_DTYPE), np.zeros(1, np.uint32), [t[0] for t in tabs], [t[1] for t in tabs], ntax=1)
+            for out in (job.step(), job.run(3)):
+                for ki in range(len(ks)):
+                    assert np.array_equal(out["hits_k"][ki], per_k[ki][0]) and np.array_equal(out["sizes_k"][ki], per_k[ki][1]), ks[ki]
