@@ -57,7 +57,8 @@ def build_reference_pipeline(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mo
             hs.append(h)
             his.append(hi)
             los.append(lo)
-            offs.extend(int(v) + offs[-1] for v in go[1:])
+            base = offs[-1]
+            offs.extend(int(v) + base for v in go[1:])
 
         def cat(parts):
             return np.concatenate(parts) if parts else np.zeros(0, np.uint64)
