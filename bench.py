@@ -2,9 +2,17 @@
 """bench.py — 150 bp reads/s through the hot path (CMash-style filter + profile) on N MI355X, inputs resident in HBM.
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-    stage A  read sketch, every k of the config (k_sketch_reads* + bucket sort / pack)   scripts/select_db.py:50-52,73-76
-    stage B  containment per k (k_contain_pairs vs the genome sketch table of that k)     scripts/select_db.py:54-56,73-76
+    stage A  read sketch (k_sketch_reads* + bucket sort / pack)                            scripts/select_db.py:50-52
+    stage B  containment, one column per k of the config                                  scripts/select_db.py:54-59,73-76
     stage C  assign + histogram (k_profile_pass), once                                    scripts/map_and_profile.py:193-264
+Stage A/B definition (--definition):
+    reference_pipeline (DEFAULT)  wired as the reference wires KMC and CMash: the reads are sketched at the LARGEST k only
+                  (`kmc -k<kmax> -ci2 -cs3`, :50-52), stage B finds the matched sketched k_max-mers (:54-59) and derives every
+                  smaller k's column from their k-prefixes (the streaming query, :73-76)
+    sketch_per_k  rounds 1-3: every k has a genome sketch table of its own and the reads are hashed at every k (one fused launch)
+--hash_mode 0 (default): MurmurHash3 of the lexicographically smaller strand, 64 bits; 1: min over the strands mod 9999999999971
+(CMash as recollected).  The definitions NOT selected are measured in the same process over the same passes and reported beside
+the headline (`definitions`).
 File I/O, PCIe, on-device ingest and the host CAMI tail are NOT in the timed region; `with_ingest` reports the kept
 command line end to end (files on disk -> subset DB / CAMI profile) on the SAME workload as a secondary figure.
 
@@ -30,6 +38,7 @@ count and every per-taxon accumulator came out identical.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -66,6 +75,10 @@ def parse():
     p.add_argument("--genome_len", type=int, default=0)
     p.add_argument("--ks", type=str, default="", help="comma-separated k-mer sizes (overrides the preset)")
     p.add_argument("--sketch_n", type=int, default=1000)
+    p.add_argument("--definition", choices=["reference_pipeline", "sketch_per_k"], default="reference_pipeline",
+                   help="stage A/B as the reference wires it (reads sketched at the largest k only; default) or a sketch per k")
+    p.add_argument("--hash_mode", type=int, choices=[0, 1], default=0, help="0: hash(min(kmer, revcomp)); 1: min(hash(kmer), hash(revcomp)) %% p")
+    p.add_argument("--no_definitions", action="store_true", help="skip the passes of the definitions that were not selected")
     p.add_argument("--no_cpu_baseline", action="store_true", help="also skips the oracle check (it shares the sample)")
     p.add_argument("--cpu_seconds", type=float, default=15.0, help="target CPU-baseline duration")
     p.add_argument("--no_kernel_table", action="store_true", help="skip the extra instrumented steps (clean traces)")
@@ -91,10 +104,32 @@ def resolve_config(args, world):
         pre["ks"] = [int(x) for x in args.ks.split(",")]
     pre["custom"] = bool(args.reads or args.genomes or args.genome_len or args.ks)
     pre["config"] = cfg
+    pre["definition"], pre["hash_mode"] = args.definition, args.hash_mode
     return pre
 
 
-def build_workload(cfg, sketch_n, rank, hip):
+def build_tables(cfg, sketch_n, hip, gb, go, definition, hash_mode, world=1):
+    """Stage A' on the GPU (not timed), under `hash_mode`: the genome sketch tables of `definition`."""
+    prev = hip.hash_mode
+    hip.set_hash_mode(hash_mode)
+    try:
+        if definition == "reference_pipeline":
+            h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, cfg["ks"][-1], sketch_n)
+            table = hip.refdb_build(h, khi, klo, o, cfg["ks"])
+            arrays = table.download(kmers=False)
+            arrays["max_hash"] = table.max_hash
+            if world > 1:  # (a rank uploads its share from the arrays)
+                table.free()
+                table = None
+            return dict(definition=definition, hash_mode=hash_mode, ref_arrays=arrays, reftable=table, table_hashes=len(h))
+        tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in cfg["ks"]]
+        return dict(definition=definition, hash_mode=hash_mode, dbh=[t[0] for t in tables], dbo=[t[1] for t in tables],
+                    table_hashes=sum(len(t[0]) for t in tables))
+    finally:
+        hip.set_hash_mode(prev)
+
+
+def build_workload(cfg, sketch_n, rank, hip, definition="reference_pipeline", hash_mode=0, world=1):
     """Synthetic inputs, generated on the host once and left resident in HBM."""
     from metalign_amd import synth
     G = cfg["genomes"]
@@ -110,16 +145,22 @@ def build_workload(cfg, sketch_n, rank, hip):
     else:
         # the aligner runs against the SUBSET db that the pre-filter selected (10^2..10^4 taxa): dense ids
         ref2tax = (np.arange(G + 1, dtype=np.uint64) % np.uint64(cfg["ntax"])).astype(np.uint32)
-    tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in cfg["ks"]]  # stage A' on the GPU (not timed)
-    return dict(rb=rb, ro=ro, src=src, recs=recs, ref2tax=ref2tax, ntax=int(ref2tax.max()) + 1,
-                dbh=[t[0] for t in tables], dbo=[t[1] for t in tables], gb=gb, go=go)
+    w = dict(rb=rb, ro=ro, src=src, recs=recs, ref2tax=ref2tax, ntax=int(ref2tax.max()) + 1, gb=gb, go=go)
+    w.update(build_tables(cfg, sketch_n, hip, gb, go, definition, hash_mode, world))
+    return w
 
 
 def make_job(hip, dist, rank, world, cfg, w, force_dist=False, sub=None):
+    """A job over workload `w` under w's definition and hash mode (the library's mode is set here and stays: a job's passes
+    hash the reads by the definition its tables were sketched with)."""
     from metalign_amd import distributed as mgd
-    job = mgd.ShardJob(hip, dist, rank, world, k=cfg["ks"], ci=2, pct_id=0.5, always_exchange=force_dist)
+    hip.set_hash_mode(w["hash_mode"])
+    job = mgd.ShardJob(hip, dist, rank, world, k=cfg["ks"], ci=2, pct_id=0.5, always_exchange=force_dist, definition=w["definition"])
     rb, ro, recs = (w["rb"], w["ro"], w["recs"]) if sub is None else sub
-    job.load(rb, ro, recs, w["ref2tax"], w["dbh"], w["dbo"], ntax=w["ntax"])
+    if w["definition"] == "reference_pipeline":
+        job.load(rb, ro, recs, w["ref2tax"], w["ref_arrays"], ntax=w["ntax"], reftable=w["reftable"])
+    else:
+        job.load(rb, ro, recs, w["ref2tax"], w["dbh"], w["dbo"], ntax=w["ntax"])
     return job
 
 
@@ -134,8 +175,12 @@ def cpu_baseline_and_check(args, cfg, w, hip):
     import oracle
     from concurrent.futures import ThreadPoolExecutor
     oracle.build()
+    oracle.set_hash_mode(w["hash_mode"])
     ks = cfg["ks"]
-    hmaxs = [int(h.max()) for h in w["dbh"]]
+    refpipe = w["definition"] == "reference_pipeline"
+    # the k the READS are sketched at: the reference pipeline counts only k_max-mers (kmc -k<kmax>, scripts/select_db.py:50-52)
+    sk_ks = [ks[-1]] if refpipe else ks
+    hmaxs = [int(w["ref_arrays"]["max_hash"])] if refpipe else [int(h.max()) for h in w["dbh"]]
     leaders = np.cumsum(w["recs"]["ref_new"] >> 31)
     nreads_all = len(w["ro"]) - 1
 
@@ -143,7 +188,7 @@ def cpu_baseline_and_check(args, cfg, w, hip):
         b0, b1 = int(w["ro"][lo]), int(w["ro"][hi])
         r0 = int(np.searchsorted(leaders, lo, side="right"))
         r1 = int(np.searchsorted(leaders, hi, side="right"))
-        sk = [oracle.sketch_reads(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo], k, hmax=hm)[:2] for k, hm in zip(ks, hmaxs)]
+        sk = [oracle.sketch_reads(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo], k, hmax=hm)[:2] for k, hm in zip(sk_ks, hmaxs)]
         prof = oracle.profile_assign(w["recs"][r0:r1], w["ref2tax"], w["ntax"], 0.5) if r1 > r0 else None
         return sk, prof
 
@@ -155,13 +200,20 @@ def cpu_baseline_and_check(args, cfg, w, hip):
         else:
             with ThreadPoolExecutor(cores) as ex:
                 parts = list(ex.map(lambda i: share(cuts[i], cuts[i + 1]), range(cores)))
-        res = []
-        for ki in range(len(ks)):
+        merged = []
+        for ki in range(len(sk_ks)):
             allh = np.concatenate([p[0][ki][0] for p in parts])
             allc = np.concatenate([p[0][ki][1] for p in parts]).astype(np.uint64)
             uh, inv = np.unique(allh, return_inverse=True)
             uc = np.minimum(np.bincount(inv, weights=allc, minlength=len(uh)), oracle.DEFAULT_CS).astype(np.uint32)
-            res.append(oracle.containment(uh, uc, False, 2, w["dbh"][ki], w["dbo"][ki]))
+            merged.append((uh, uc))
+        if refpipe:
+            # the oracle's query against the table the GPU builder laid out (the builder itself is held to the oracle's by
+            # tests/test_gpu_refpipe.py and, at this size, tests/test_gpu_fullsize.py: 54 s of qsort are not for a benchmark)
+            hits, sizes = oracle.refpipe_containment(merged[0][0], merged[0][1], 2, w["ref_arrays"])
+            res = [(hits[ki], sizes[ki]) for ki in range(len(ks))]
+        else:
+            res = [oracle.containment(uh, uc, False, 2, w["dbh"][ki], w["dbo"][ki]) for ki, (uh, uc) in enumerate(merged)]
         return time.perf_counter() - t0, res
 
     cores = max(1, min(os.cpu_count() or 1, 64))
@@ -172,8 +224,8 @@ def cpu_baseline_and_check(args, cfg, w, hip):
     t, want_hs = run(n, cores)
     base = {"value": n / t, "unit": "reads/s", "cores": cores, "kind": "port", "single_core_value": single,
             "sample": "the first %d of the %d reads (%.1f %%) + their alignment records in %d contiguous shares, one thread "
-                      "each: read sketches for k in %s, merged, containment against the full %d-genome tables, stage C; "
-                      "C oracle, %.1f s" % (n, nreads_all, 100.0 * n / nreads_all, cores, ks, cfg["genomes"], t)}
+                      "each: read sketches for k in %s, merged, containment (%s) against the full %d-genome tables for k in %s, stage C; "
+                      "C oracle, %.1f s" % (n, nreads_all, 100.0 * n / nreads_all, cores, sk_ks, w["definition"], cfg["genomes"], ks, t)}
     # ---- the same sample through the GPU path (one job, one step), against the oracle ----
     b1 = int(w["ro"][n])
     r1 = int(np.searchsorted(leaders, n, side="right"))
@@ -192,7 +244,8 @@ def cpu_baseline_and_check(args, cfg, w, hip):
             bad.append(key)
     if (got["tot_rds"], got["n_ambig"]) != (want_c["tot_rds"], want_c["n_ambig"]):
         bad.append("tot_rds/n_ambig")
-    check = {"oracle_equal": not bad, "mismatch": bad,
+    oracle.set_hash_mode(0)
+    check = {"oracle_equal": not bad, "mismatch": bad, "definition": w["definition"], "hash_mode": w["hash_mode"],
              "compared": "hits and sizes of all %d genomes for k in %s; count / bases / first_seen of all %d taxa; tot_rds; "
                          "n_ambig — GPU path vs C oracle on the cpu_baseline sample (%d reads, %d records)"
                          % (cfg["genomes"], ks, w["ntax"], n, r1)}
@@ -211,7 +264,9 @@ def committed_profile(name, cfg):
             with open(os.path.join(pdir, rnd, fn)) as fh:
                 d = json.load(fh)
             wl = d.get("workload", {})
-            if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")])) == (cfg["reads"], cfg["genomes"], cfg["ks"]):
+            # (profiles of rounds 1-3 carry no definition: a sketch per k, hash mode 0)
+            if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")]), wl.get("definition", "sketch_per_k"), wl.get("hash_mode", 0)) == \
+                    (cfg["reads"], cfg["genomes"], cfg["ks"], cfg.get("definition", "sketch_per_k"), cfg.get("hash_mode", 0)):
                 best = d
     return best
 
@@ -226,14 +281,18 @@ def valu_roofline(sq, ms_alone_live):
     gui = sum(sq["kernels"][k].get("GRBM_GUI_ACTIVE", 0.0) for k in names)
     model = None
     pdir = os.path.join(ROOT, "profiles")
-    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        fn = os.path.join(pdir, rnd, "k1_valu_roofline.json")
+    # the per-opcode table of the kernel the passes run: the fused {21,31,51} launch (k1_valu_roofline.json) or the one-k kernel
+    # of the reference pipeline's largest k (k1_single_k<K>_valu_roofline.json)
+    fused = len(names) == 1 and "multi" in names[0]
+    m = re.match(r"k_sketch_reads<(\d+)", names[0]) if len(names) == 1 else None
+    model_name = "k1_valu_roofline.json" if fused else ("k1_single_k%s_valu_roofline.json" % m.group(1) if m else None)
+    for rnd in sorted(os.listdir(pdir)) if (os.path.isdir(pdir) and model_name) else []:
+        fn = os.path.join(pdir, rnd, model_name)
         if os.path.isfile(fn):
             with open(fn) as fh:
-                model = dict(json.load(fh), source="profiles/%s/k1_valu_roofline.json" % rnd)
-    fused = len(names) == 1 and "multi" in names[0]
-    if not (insts and gui and model and fused):
-        return out  # (the per-opcode table is the fused {21,31,51} kernel's)
+                model = dict(json.load(fh), source="profiles/%s/%s" % (rnd, model_name))
+    if not (insts and gui and model):
+        return out
     simd_cycles = gui / XCDS * SIMDS
     cpi = model["cycles_per_valu_instruction"]
     out["valu_frac"] = insts * cpi / simd_cycles
@@ -269,7 +328,7 @@ def committed_run(name, cfg):
 def secondary_config1(hip, args):
     """configs[1] (1M reads, 1k genomes, k = 21) in the same process: reads/s of the pipelined passes."""
     cfg = dict(PRESETS[1], config=1)
-    w = build_workload(cfg, args.sketch_n, 0, hip)
+    w = build_workload(cfg, args.sketch_n, 0, hip, args.definition, args.hash_mode)
     job = make_job(hip, None, 0, 1, cfg, w)
     job.run(60)
     hip.sync()
@@ -278,8 +337,49 @@ def secondary_config1(hip, args):
     job.run(steps)
     hip.sync()
     dt = time.perf_counter() - t0
+    if w.get("reftable") is not None:
+        del job
+        w["reftable"].free()
+    hip.set_hash_mode(0)
     return {"workload": cfg["name"], "value": cfg["reads"] / (dt / steps), "unit": "reads/s", "ms_per_step": 1e3 * dt / steps,
             "steps": steps}
+
+
+def other_definitions(hip, args, cfg, w):
+    """The stage A/B definitions that were NOT selected, on the same reads / records / genomes, over the same number of
+    pipelined passes (untimed by the driver; the same loop as the headline's): ms per pass and reads/s each."""
+    out = {}
+    for definition, mode in (("reference_pipeline", 0), ("reference_pipeline", 1), ("sketch_per_k", 0)):
+        if (definition, mode) == (args.definition, args.hash_mode):
+            continue
+        t0 = time.perf_counter()
+        w2 = dict(w)
+        for key in ("ref_arrays", "reftable", "dbh", "dbo"):
+            w2.pop(key, None)
+        w2.update(build_tables(cfg, args.sketch_n, hip, w["gb"], w["go"], definition, mode))
+        job = make_job(hip, None, 0, 1, cfg, w2)
+        job.run(max(args.warmup, 2))
+        hip.sync()
+        hip.prof_reset()
+        hip.prof_enable(True)
+        hip.prof_only("sketch_reads")
+        t1 = time.perf_counter()
+        res = job.run(args.steps)
+        hip.sync()
+        dt = (time.perf_counter() - t1) / args.steps
+        nk1, k1_ms = hip.prof_get("sketch_reads")
+        hip.prof_enable(False)
+        out["%s_mode%d" % (definition, mode)] = {
+            "definition": definition, "hash_mode": mode, "ms_per_pass": 1e3 * dt, "value": cfg["reads"] / dt, "unit": "reads/s",
+            "steps": args.steps, "stage_a_avg_launch_ms": k1_ms / max(nk1, 1), "stage_a_launches_per_pass": nk1 / max(args.steps, 1),
+            "sketched_ks": res.get("sketched_ks"), "sketch_sizes": res.get("sketch_sizes"), "top_genomes_recovered": res.get("top_ok"),
+            "setup_s": t1 - t0}
+        del job
+        if w2.get("reftable") is not None:
+            w2["reftable"].free()
+        hip.mem_trim()
+    hip.set_hash_mode(w["hash_mode"])
+    return out
 
 
 _LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
@@ -422,7 +522,7 @@ def main():
         hip = Hip.get(0)
 
     cfg = resolve_config(args, world)
-    w = build_workload(cfg, args.sketch_n, rank, hip)
+    w = build_workload(cfg, args.sketch_n, rank, hip, args.definition, args.hash_mode, world)
     job = make_job(hip, dist, rank, world, cfg, w, force_dist)
     nreads, nrecs, K = cfg["reads"], len(w["recs"]), len(cfg["ks"])
 
@@ -461,7 +561,7 @@ def main():
         sync()
         hip.stage_c_side_stream(True)
         for name in ("table_clear", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort",
-                     "sketch_rle", "contain_index", "containment", "profile_map", "profile_pass"):
+                     "sketch_rle", "contain_index", "containment", "refpipe_count", "profile_map", "profile_pass"):
             n, t = hip.prof_get(name)
             if n:
                 kernels_ms[name] = {"ms_per_pass": round(t / nt, 4), "launches_per_pass": n / nt}
@@ -503,8 +603,12 @@ def main():
         kern = []
         if "containment" in kernels_ms:
             t_b = kernels_ms["containment"]["ms_per_pass"] + kernels_ms.get("contain_index", {}).get("ms_per_pass", 0.0)
-            algo = sum(int(len(h)) for h in w["dbh"]) * 8 // max(world, 1)
-            kern.append({"kernel": "k_contain_pairs (+ index, reduce), all k", "algorithmic_bytes_per_pass": algo, "ms_per_pass": t_b,
+            t_b += kernels_ms.get("refpipe_count", {}).get("ms_per_pass", 0.0)
+            # 8 B per table hash and k; the reference pipeline: the largest k's hashes, and per smaller k one
+            # 8-byte (prefix number, genome) entry per table hash
+            algo = (w["table_hashes"] * (len(cfg["ks"]) if w["definition"] == "reference_pipeline" else 1)) * 8 // max(world, 1)
+            kern.append({"kernel": "k_contain_pairs (+ index, reduce%s), all k" % (", k_refpipe_count" if w["definition"] == "reference_pipeline" else ""),
+                         "algorithmic_bytes_per_pass": algo, "ms_per_pass": t_b,
                          "achieved_GBs": algo / (t_b * 1e-3) / 1e9, "frac": algo / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm"})
         if "profile_pass" in kernels_ms:
             t_c = kernels_ms["profile_pass"]["ms_per_pass"]
@@ -529,6 +633,8 @@ def main():
                                    % (cfg["name"], " [custom sizes]" if cfg["custom"] else "", nreads, cfg["genomes"],
                                       cfg["genome_len"], args.sketch_n, cfg["ks"], nrecs, w["ntax"]),
                        "baseline_config": cfg["config"],
+                       "stage_a_definition": w["definition"], "hash_mode": w["hash_mode"],
+                       "stage_a_sketched_ks": out.get("sketched_ks"),
                        "parallelism": "reads + alignment records sharded x%d, read sketches and sketch tables sharded by hash range" % world},
             "roofline": roof,
             "kernels": kern,
@@ -554,8 +660,22 @@ def main():
             res["collective_selfcheck"] = "ok"
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
             res["cpu_baseline"], res["check"] = cpu_baseline_and_check(args, cfg, w, hip)
-        if not args.no_secondary and world == 1 and cfg["config"] != 1:
+        if world == 1 and not args.no_definitions and not args.no_secondary:
+            # the other definitions of stage A/B on the same reads, genomes and records, the same pipelined loop
             del job
+            job = None
+            try:
+                res["definitions"] = other_definitions(hip, args, cfg, w)
+                res["definitions"]["%s_mode%d" % (w["definition"], w["hash_mode"])] = {
+                    "definition": w["definition"], "hash_mode": w["hash_mode"], "ms_per_pass": ms, "value": res["value"], "unit": "reads/s",
+                    "steps": args.steps, "note": "the headline of this line"}
+                # (as VERDICT r03 asked: the reference pipeline under both hash definitions by name)
+                res["reference_pipeline"] = {"mode%d" % m: {k: res["definitions"]["reference_pipeline_mode%d" % m][k]
+                                                             for k in ("ms_per_pass", "value", "unit")} for m in (0, 1)}
+            except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline down)
+                res["definitions"] = {"error": repr(e)}
+        if not args.no_secondary and world == 1 and cfg["config"] != 1:
+            job = None
             res["secondary"] = secondary_config1(hip, args)
             try:
                 # the kept command line on THIS workload from files on disk (page cache): the same reads as a FASTQ file,
