@@ -164,7 +164,7 @@ def make_job(hip, dist, rank, world, cfg, w, force_dist=False, sub=None):
     return job
 
 
-def cpu_baseline_and_check(args, cfg, w, hip):
+def cpu_baseline_and_check(args, cfg, w, hip, dist=None, force_dist=False):
     """The CPU oracle on a bounded sample of the same workload (the first n reads and their alignment records) on every
     host core: the sample is cut into one contiguous share per thread (ctypes releases the GIL inside the C oracle;
     threads, not processes: this process has initialised the GPU); per share the read sketch of every k and stage C
@@ -231,7 +231,9 @@ def cpu_baseline_and_check(args, cfg, w, hip):
     r1 = int(np.searchsorted(leaders, n, side="right"))
     sub = (w["rb"][:b1], w["ro"][: n + 1], w["recs"][:r1])
     want_c = oracle.profile_assign(sub[2], w["ref2tax"], w["ntax"], 0.5)  # exact (sequential) stage C of the sample
-    job = make_job(hip, None, 0, 1, cfg, w, sub=sub)
+    # (dist / force_dist: the same job with every collective of the multi-GPU pass in its path, at world size 1 —
+    # tests/dist_config3_full.py)
+    job = make_job(hip, dist, 0, 1, cfg, w, force_dist=force_dist, sub=sub)
     got = job.step()
     bad = []
     for ki, k in enumerate(ks):

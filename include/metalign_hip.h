@@ -255,6 +255,10 @@ unsigned mg_filter_log2_bits(const mg_filter* f);
  * MG_ERR_CAPACITY: the hashes crowd some range (a bucket without a free slot) — the filter stays a bit filter. */
 int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, uint64_t hmax, unsigned spread);
 int mg_filter_drop_resident(mg_filter* f);   /* back to a bit filter (sketches made with it must have been resolved) */
+/* on = 0: sketch calls given this filter take its bit array although it has a resident index (which stays seeded); on != 0:
+ * back to the index.  What a job uses to MEASURE both forms on its own sample before it keeps one (the index pays when most
+ * candidates are hashes of the table, the bit filter when most are not). */
+int mg_filter_use_resident(mg_filter* f, int on);
 uint64_t mg_filter_resident_bytes(const mg_filter* f);
 void mg_filter_free(mg_filter* f);
 int mg_sketch_reads_filtered_dev(const uint8_t* d_bases, const uint64_t* d_offsets,

@@ -26,10 +26,18 @@ constexpr int kBytesPerThread = 16;
 // ---------------------------------------------------------------------------------------------
 // line index
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, uint64_t nbytes, uint64_t base) {
-  // bit j set <=> text[base + j] == '\n'
+// Thread g of the line-index kernels looks at the 16-byte ALIGNED window of memory number g counted from the aligned address
+// at or below `text`: text offsets [16 g - mis, 16 g - mis + 16), mis = address of text modulo 16.  A piece of a streamed file
+// begins wherever the carried record put it (mg_stream.hip), so `text` is rarely aligned itself; with windows fixed to the
+// text's own start every thread of such a piece took the byte-by-byte path below.
+__device__ __forceinline__ int64_t nl_window(const uint8_t* text, uint64_t g) {
+  return (int64_t)(g * kBytesPerThread) - (int64_t)(reinterpret_cast<uintptr_t>(text) & 15);
+}
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, uint64_t nbytes, int64_t base) {
+  // bit j set <=> text[base + j] == '\n' (offsets outside [0, nbytes) never)
   uint32_t m = 0;
-  if (base + kBytesPerThread <= nbytes && ((reinterpret_cast<uintptr_t>(text) + base) & 15) == 0) {
+  if (base >= 0 && (uint64_t)base + kBytesPerThread <= nbytes) {
     const uint4 v = *reinterpret_cast<const uint4*>(text + base);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -37,8 +45,10 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, 
 #pragma unroll
       for (int b = 0; b < 4; ++b) m |= (((w[q] >> (8 * b)) & 0xffu) == 0x0au ? 1u : 0u) << (4 * q + b);
   } else {
-    for (int j = 0; j < kBytesPerThread; ++j)
-      if (base + j < nbytes && text[base + j] == '\n') m |= 1u << j;
+    for (int j = 0; j < kBytesPerThread; ++j) {
+      const int64_t o = base + j;
+      if (o >= 0 && (uint64_t)o < nbytes && text[o] == '\n') m |= 1u << j;
+    }
   }
   return m;
 }
@@ -46,8 +56,8 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, 
 __global__ __launch_bounds__(kIB) void k_count_newlines(const uint8_t* __restrict__ text, uint64_t nbytes,
                                                         uint32_t* __restrict__ blk_count) {
   __shared__ uint32_t wsum[kIB / 64];
-  const uint64_t base = ((uint64_t)blockIdx.x * kIB + threadIdx.x) * kBytesPerThread;
-  uint32_t c = base < nbytes ? __popc(nl_mask16(text, nbytes, base)) : 0;
+  const int64_t base = nl_window(text, (uint64_t)blockIdx.x * kIB + threadIdx.x);
+  uint32_t c = base < (int64_t)nbytes ? __popc(nl_mask16(text, nbytes, base)) : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -61,8 +71,8 @@ __global__ __launch_bounds__(kIB) void k_mark_newlines(const uint8_t* __restrict
                                                        uint64_t* __restrict__ line_end) {
   __shared__ uint32_t wsum[kIB / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t base = ((uint64_t)blockIdx.x * kIB + threadIdx.x) * kBytesPerThread;
-  const uint32_t m = base < nbytes ? nl_mask16(text, nbytes, base) : 0;
+  const int64_t base = nl_window(text, (uint64_t)blockIdx.x * kIB + threadIdx.x);
+  const uint32_t m = base < (int64_t)nbytes ? nl_mask16(text, nbytes, base) : 0;
   const uint32_t c = __popc(m);
   uint32_t inc = c;
 #pragma unroll
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(kIB) void k_mark_newlines(const uint8_t* __restrict
   uint32_t mm = m;
   while (mm) {
     const int j = __ffs(mm) - 1;
-    line_end[at++] = base + j;
+    line_end[at++] = (uint64_t)(base + j);
     mm &= mm - 1;
   }
 }
@@ -526,7 +536,8 @@ static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d
   *virtual_last = false;
   if (nbytes == 0) { *d_line_end = (uint64_t*)scratch("ing_lines", 16); return *d_line_end ? MG_OK : MG_ERR_NOMEM; }
   const uint64_t per_block = (uint64_t)kIB * kBytesPerThread;
-  const uint64_t nblocks = (nbytes + per_block - 1) / per_block;
+  // (the threads' windows are aligned in MEMORY: up to 15 bytes of slack in front of the text)
+  const uint64_t nblocks = (nbytes + (kBytesPerThread - 1) + per_block - 1) / per_block;
   if (nblocks > 0x7fffffffull) return fail(MG_ERR_ARG, "text too large for one ingest call");
   uint32_t* d_cnt = (uint32_t*)scratch("ing_blk_cnt", nblocks * sizeof(uint32_t));
   uint64_t* d_base = (uint64_t*)scratch("ing_blk_base", (nblocks + 1) * sizeof(uint64_t));

@@ -309,6 +309,7 @@ struct mg_filter {
     ~Resident();
   };
   mutable std::unique_ptr<Resident> resident;
+  bool resident_off = false;  // mg_filter_use_resident(f, 0): sketch calls take the bit filter although an index exists
 };
 
 struct mg_db {

@@ -772,7 +772,7 @@ int sketch_resolve(mg_sketch* sk, int* rebuilt) {
   sk->index.release();
   sk->hashes.release();
   sk->counts.release();
-  if (sk->redo.s == 0 && sk->redo.filter && sk->redo.filter->resident && !getenv("MG_DEBUG_NO_RESIDENT")) {
+  if (sk->redo.s == 0 && sk->redo.filter && sk->redo.filter->resident && !sk->redo.filter->resident_off) {
     // made against a resident index, whose sketch is the exact intersection (the list path's filter lets ~6 % of the
     // other hashes through): the list of touched hashes, or the sketch's buffers, were too small — again, with room for
     // every hash of the index (the hint has just been reset)
@@ -902,6 +902,10 @@ static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t
     cp.stream = st;
     R.copies.push_back(cp);
     MG_HIP(hipMemcpyAsync(cp.slots, R.copies[0].slots, R.slots * sizeof(Slot), hipMemcpyDeviceToDevice, st));
+    // The SOURCE belongs to another stream, whose next pass — queued by the caller right after this call returns, with a
+    // LARGER epoch — must not write slots the copy has not read yet: a slot copied with that later epoch in it would read
+    // as "count 0" to this call's smaller one (atomicMax of an epoch below the stored one is a no-op).  Once per stream.
+    MG_HIP(hipStreamSynchronize(st));
     slots = cp.slots;
   }
   if (hmax > R.hmax) hmax = R.hmax;
@@ -940,7 +944,7 @@ static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t
 }
 // (a bottom-s sketch keeps the bit filter's definition — the s smallest of what passes the FILTER — so that the cut does
 // not depend on whether the table has an index)
-static bool use_resident(const mg_filter* f, uint64_t s) { return s == 0 && f && f->resident && !getenv("MG_DEBUG_NO_RESIDENT"); }
+static bool use_resident(const mg_filter* f, uint64_t s) { return s == 0 && f && f->resident && !f->resident_off; }
 
 // sketch_resolve's way out when the list of touched hashes (or the sketch's buffers) of a resident sketch was too small:
 // the one-k kernel again, synchronously, sized for every hash of the index.
@@ -1357,6 +1361,12 @@ int mg_filter_make_resident(mg_filter* f, const uint64_t* hashes, uint64_t n, ui
 }
 
 // The filter back to a bit filter: its resident index (every copy) is freed.
+int mg_filter_use_resident(mg_filter* f, int on) {
+  if (!f) return fail(MG_ERR_ARG, "null filter");
+  f->resident_off = !on;
+  return MG_OK;
+}
+
 int mg_filter_drop_resident(mg_filter* f) {
   MG_REQUIRE_READY();
   if (!f) return fail(MG_ERR_ARG, "null argument");

@@ -69,7 +69,7 @@ struct PlainSource : Source {
 struct GzipSource : Source {
   int fd = -1;
   z_stream zs;
-  bool zs_live = false, ended = false, in_member = false;
+  bool zs_live = false, ended = false, in_member = false, at_boundary = false;
   std::vector<uint8_t> in;
   uint64_t in_off = 0;  // file offset of the next compressed byte to read
   GzipSource() { memset(&zs, 0, sizeof(zs)); in.resize(4u << 20); }
@@ -97,6 +97,13 @@ struct GzipSource : Source {
         zs.next_in = in.data();
         zs.avail_in = (uInt)n;
       }
+      if (at_boundary) {
+        // between members only another gzip member may follow; anything else — zero padding, a tape block's fill — is
+        // trailing garbage, which gzip / zcat ignore with a warning (the reference feeds `.gz` files to kmc and zcat,
+        // scripts/select_db.py:105,146-148)
+        if (zs.next_in[0] != 0x1f || (zs.avail_in > 1 && zs.next_in[1] != 0x8b)) { ended = true; break; }
+        at_boundary = false;
+      }
       zs.avail_out = (uInt)(room > 0x40000000ull ? 0x40000000ull : room);
       const uInt before = zs.avail_out;
       in_member = true;
@@ -104,6 +111,7 @@ struct GzipSource : Source {
       room -= before - zs.avail_out;
       if (rc == Z_STREAM_END) {
         in_member = false;  // a member ended: another may follow (bgzip, cat a.gz b.gz, pigz -i)
+        at_boundary = true;
         if (inflateReset(&zs) != Z_OK) { error = "inflateReset failed"; return -1; }
       } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
         error = std::string("inflate failed: ") + (zs.msg ? zs.msg : "corrupt gzip data");

@@ -211,12 +211,15 @@ class HipEngine:
                 # candidate and 2 % of a present genome's are members — the bit filter's one cached word rejects them for
                 # less.  Which it is depends on the sample: measured, stage A once more each way (the caller drops the loser).
                 with_index = one_pass()
-                os.environ["MG_DEBUG_NO_RESIDENT"] = "1"  # (read by the library at every call)
+                have = [f for f in self.filters[: len(ks)] if f is not None and f.resident_bytes]
+                for f in have:
+                    f.use_resident(False)
                 try:
                     one_pass()  # (the first pass of this form sizes its tables for the worst case)
                     with_filter = one_pass()
                 finally:
-                    del os.environ["MG_DEBUG_NO_RESIDENT"]
+                    for f in have:
+                        f.use_resident(True)
                 return with_index, with_filter
         finally:
             self.hip.stage_a_side_stream(False)
@@ -761,8 +764,12 @@ class ShardJob:
             self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
         if hasattr(self.engine, "prime") and (len(roffsets) > 1 or self.exchange):
             choice = self.engine.prime(self.sks_k, self.hmaxs, self.s) if len(roffsets) > 1 else None
-            resident = any(f is not None and f.resident_bytes for f in getattr(self.engine, "filters", []))
-            drop = resident and choice is not None and choice[1] < choice[0]
+            # (all(): a rank on which only SOME k got an index — no room, crowded buckets — does not count as having one:
+            # every rank, and every k of a rank, ends up on the same side)
+            fl = [f for f in getattr(self.engine, "filters", [])[: len(self.sks_k)]]
+            resident = bool(fl) and all(f is not None and f.resident_bytes for f in fl)
+            some = any(f is not None and f.resident_bytes for f in fl)
+            drop = (some and not resident) or (resident and choice is not None and choice[1] < choice[0])
             if self.exchange and self.world > 1:
                 # every rank takes the same side (the ranks' sketches are slices of ONE sketch): an index everywhere or
                 # nowhere (a rank may have had no room for it), and the SUM of the ranks' timings decides
@@ -775,7 +782,7 @@ class ShardJob:
                 choice = (with_index, with_filter) if have else None
             if choice is not None:
                 self.resident_choice = dict(with_index_s=choice[0], with_filter_s=choice[1])
-            if drop and resident:
+            if drop and some:
                 self.engine.drop_resident_indexes()
             # the priming pass was sized for the worst case (no distinct-count ratio yet: tens of GB against a dense
             # table); its blocks would stay cached for the life of the process

@@ -311,6 +311,8 @@ def inflate_file(path, block=16 << 20):
                 out.append(d.decompress(buf))
                 if d.eof:  # a member ended: another may follow
                     buf, d, fed = d.unused_data, zlib.decompressobj(47), False
+                    if buf and not buf.startswith(b'\x1f\x8b'[:len(buf)]):
+                        return b''.join(out)  # trailing garbage (zero padding, a tape block's fill): ignored, as gzip / zcat do
                 else:
                     buf = b''
         if fed:

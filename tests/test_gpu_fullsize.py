@@ -168,10 +168,12 @@ def test_config2_full_size_properties(hip):
         assert np.array_equal(np.asarray(sharded[key]), np.asarray(res[key])), key
 
 
-def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib):
+@pytest.mark.parametrize("definition,mode", [("reference_pipeline", 0), ("reference_pipeline", 1), ("sketch_per_k", 0)])
+def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib, definition, mode):
     """BASELINE.json configs[2] EXACTLY as bench.py runs it at N = 1 (bench.build_workload: 10M reads of 500 present 50 kb
-    genomes among 10 000, K = {21,31,51}, 12.5M alignment records, 10 001 taxa): ShardJob.step() — the fused stage-A
-    launch, stage B per k, stage C — on a >= 2M-read sample against the C oracle on every host core: hits and sizes of
+    genomes among 10 000, K = {21,31,51}, 12.5M alignment records, 10 001 taxa), under the headline's definition of stage
+    A/B (the reference pipeline, hash mode 0) and the two bench.py reports beside it: ShardJob.step() — stage A, stage B
+    with one column per k, stage C — on a >= 2M-read sample against the C oracle on every host core: hits and sizes of
     all 10 000 genomes for every k, count / bases / first_seen of every taxon, tot_rds, n_ambig.  (bench.py prints the
     same comparison as `check.oracle_equal`; here it is the driver's GPU test tier that holds it.)"""
     import argparse
@@ -181,15 +183,50 @@ def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib):
     sys.path.insert(0, root)
     import bench
     cfg = dict(bench.PRESETS[2], config=2, custom=False)
-    w = bench.build_workload(cfg, 1000, 0, hip)
-    assert len(w["ro"]) - 1 == 10_000_000 and len(w["dbh"]) == 3 and w["ntax"] == 10_001
-    args = argparse.Namespace(cpu_seconds=20.0)
-    base, check = bench.cpu_baseline_and_check(args, cfg, w, hip)
-    nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
-    assert nsample >= 2_000_000 or nsample == 10_000_000, check["compared"]
-    assert check["oracle_equal"], check["mismatch"]
-    # and the pipelined passes the benchmark times give the same sketches as single steps
-    job = bench.make_job(hip, None, 0, 1, cfg, w)
-    one = job.step()
-    out = job.run(3)
-    assert out["sketch_sizes"] == one["sketch_sizes"] and out["tot_rds"] == one["tot_rds"]
+    try:
+        w = bench.build_workload(cfg, 1000, 0, hip, definition, mode)
+        assert len(w["ro"]) - 1 == 10_000_000 and w["ntax"] == 10_001 and w["table_hashes"] == (1 if definition == "reference_pipeline" else 3) * 10_000_000
+        args = argparse.Namespace(cpu_seconds=20.0)
+        base, check = bench.cpu_baseline_and_check(args, cfg, w, hip)
+        nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
+        assert nsample >= 2_000_000 or nsample == 10_000_000, check["compared"]
+        assert check["oracle_equal"], check["mismatch"]
+        assert (check["definition"], check["hash_mode"]) == (definition, mode)
+        # and the pipelined passes the benchmark times give the same sketches as single steps
+        job = bench.make_job(hip, None, 0, 1, cfg, w)
+        one = job.step()
+        out = job.run(3)
+        assert out["sketch_sizes"] == one["sketch_sizes"] and out["tot_rds"] == one["tot_rds"]
+        assert np.array_equal(out["hits_k"], one["hits_k"]) and out["hits_k"].shape == (3, 10_000)
+        assert out["sketched_ks"] == ([51] if definition == "reference_pipeline" else [21, 31, 51])
+        del job
+    finally:
+        hip.set_hash_mode(0)
+        oracle_lib.set_hash_mode(0)
+
+
+def test_reference_pipeline_table_at_the_benchmarked_size(hip, oracle_lib):
+    """The table bench.py's headline runs against — 10 000 genomes x 1000 sketched 51-mers, prefix columns for k = 21 and 31 —
+    as the device builder lays it out (mg_sketch_genomes_kmers + mg_refdb_build) against the oracle's, entry for entry: the
+    sketches and their kept k-mers on a subset of the genomes (the oracle hashes every position on one core), the derived
+    structures on all 10M pairs."""
+    ks = [21, 31, 51]
+    gb, go = synth.make_genomes(10_000, 50_000)
+    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, 51, 1000)
+    assert len(h) == 10_000_000 and np.all(np.diff(o.astype(np.int64)) == 1000)
+    sub = [0, 1, 4999, 9999]
+    for g in sub:
+        a, b = int(go[g]), int(go[g + 1])
+        oh, ohi, olo, oo = oracle_lib.sketch_genomes_kmers(gb[a:b], np.asarray([0, b - a], dtype=np.uint64), 51, 1000)
+        sl = slice(int(o[g]), int(o[g + 1]))
+        assert np.array_equal(h[sl], oh) and np.array_equal(khi[sl], ohi) and np.array_equal(klo[sl], olo), g
+    table = hip.refdb_build(h, khi, klo, o, ks)
+    got = table.download()
+    table.free()
+    want = oracle_lib.refpipe_build(h, khi, klo, o, ks)
+    assert np.array_equal(got["pair_hash"], want["pair_hash"]) and np.array_equal(got["pair_gen"], want["pair_gen"])
+    assert np.array_equal(got["kmer_hi"], want["kmer_hi"]) and np.array_equal(got["kmer_lo"], want["kmer_lo"])
+    for k in ks[:-1]:
+        assert got["small"][k]["nprefix"] == want["small"][k]["nprefix"]
+        for key in ("pa", "pb", "cid", "cgen", "gsize"):
+            assert np.array_equal(got["small"][k][key], want["small"][k][key]), (k, key)

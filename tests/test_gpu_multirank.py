@@ -243,3 +243,25 @@ def test_hash_major_table_on_disk_sliced_loads(hip, oracle_lib, tmp_path):
             hits += hr
             sizes += sr
         assert touched == len(dbh) and np.array_equal(hits, oh) and np.array_equal(sizes, osz)
+
+
+@pytest.mark.parametrize("definition,mode", [("reference_pipeline", 0), ("sketch_per_k", 0)])
+def test_config3_default_path_at_full_size_with_every_collective(definition, mode):
+    """bench.py --config 3 (the N > 1 driver workload) AS THE JOB RUNS IT on a rank, at full size: 12.5M reads, 15.6M
+    records, the 200k-genome table with the resident index the job chooses for itself, RCCL at world size 1 with every
+    collective of the pass in the path — a >= 2M-read sample against the threaded C oracle (hits and sizes of all 200 000
+    genomes for every k, every stage-C accumulator), the same with every list / table undersized (overflow -> redo at this
+    size), then step() == run(3) on the whole workload.  tests/dist_config3_full.py, a child process (torch.distributed
+    stays out of this one)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29640 + mode + (2 if definition == "sketch_per_k" else 0)))
+    r = subprocess.run([sys.executable, os.path.join(here, "dist_config3_full.py"), definition, str(mode)], capture_output=True,
+                       text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and "config3-full ok" in r.stdout, (r.stdout[-3000:], r.stderr[-6000:])
+    rep = json.loads(r.stdout.split("config3-full ok ", 1)[1].splitlines()[0])
+    assert rep["check_hint_None"]["sample_reads"] >= 2_000_000 and rep["check_hint_0.002"]["sample_reads"] >= 2_000_000
+    print(json.dumps(rep))

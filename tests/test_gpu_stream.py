@@ -156,6 +156,9 @@ def test_files_through_the_pipeline(hip, tmp_path, chunk):
         "wrapped.fa": ("fasta_ml", _fasta_ml(rb, ro)),
         "one.fq.gz": ("fastq", gzip.compress(fq, 4)),
         "members.fq.gz": ("fastq", b"".join(gzip.compress(fq[a: a + 700001], 1) for a in range(0, len(fq), 700001))),
+        # trailing padding after the last member (tar / tape blocks): gzip and zcat warn and go on, so does the reader
+        "padded.fq.gz": ("fastq", gzip.compress(fq, 4) + b"\0" * 1000),
+        "members_padded.fq.gz": ("fastq", b"".join(gzip.compress(fq[a: a + 900001], 1) for a in range(0, len(fq), 900001)) + b"\0\0\0garbage"),
         "bgzf.fq.gz": ("fastq", _bgzf(fq)),
         "bgzf.fa.gz": ("fasta_ml", _bgzf(_fasta_ml(rb, ro))),
     }

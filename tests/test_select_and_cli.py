@@ -467,3 +467,21 @@ def test_when_a_job_builds_the_resident_index(monkeypatch):
     assert eng.wants_resident_index(sparse, 1000)
     eng.bottom_s = 500                                             # a bottom-s job: the library would not use the index
     assert not eng.wants_resident_index(dense, 1000)
+
+
+
+def test_inflate_file_ignores_trailing_padding_and_refuses_truncation(tmp_path):
+    """formats.inflate_file (the subset database's zcat, the multi-GPU launch's reads): every member of a file, trailing
+    garbage after the last member ignored as gzip / zcat do, a stream that ends inside a member refused."""
+    import gzip
+    from metalign_amd import formats
+    text = b"@r0\nACGT\n+\nIIII\n" * 5000
+    a, b = gzip.compress(text[:30000], 1), gzip.compress(text[30000:], 6)
+    for name, blob in (("one.gz", gzip.compress(text)), ("two.gz", a + b), ("padded.gz", a + b + b"\0" * 777), ("junk.gz", a + b + b"garbage")):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        assert formats.inflate_file(str(p), block=4096) == text, name
+    p = tmp_path / "cut.gz"
+    p.write_bytes((a + b)[:-9])
+    with pytest.raises(OSError):
+        formats.inflate_file(str(p))

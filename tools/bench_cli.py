@@ -117,32 +117,53 @@ def write_data_dir(data, gb, go, G, glen, threads=16):
     return names, accs, "".join(rows)
 
 
-def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, glen=50_000, sketch_n=1000):
-    """workload: dict(gb, go, rb, src, dbh, dbo) — genomes, reads, source genome of every read, the per-k genome-major
-    sketch table — as bench.py builds them; None: generated here."""
+def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, glen=50_000, sketch_n=1000,
+            definition="reference_pipeline", hash_mode=0):
+    """workload: dict(gb, go, rb, src, + dbh, dbo | ref_arrays) — genomes, reads, source genome of every read, and the sketch
+    table (per-k genome-major arrays, or the reference pipeline's arrays) — as bench.py builds them; None: generated here.
+    definition / hash_mode: of the table written to disk (formats.py version 2 or 3); select_main follows the table."""
     from metalign_amd import formats, map_and_profile, select_db, synth
     from metalign_amd._hip import Hip
     hip = Hip.get()
     td = tempfile.mkdtemp(prefix="mg_cli_")
     try:
         t_gen = time.perf_counter()
+        ref_arrays = dbh = dbo = None
         if workload is None:
             gb, go = synth.make_genomes(G, glen)
             rb, ro, src = synth.make_reads(gb, go, n, npresent=max(40, G // 20))
-            tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in ks]
-            dbh, dbo = [t[0] for t in tables], [t[1] for t in tables]
         else:
-            gb, go, rb, src, dbh, dbo = (workload[x] for x in ("gb", "go", "rb", "src", "dbh", "dbo"))
+            gb, go, rb, src = (workload[x] for x in ("gb", "go", "rb", "src"))
+            definition, hash_mode = workload.get("definition", definition), workload.get("hash_mode", hash_mode)
+            ref_arrays, dbh, dbo = workload.get("ref_arrays"), workload.get("dbh"), workload.get("dbo")
+        prev_mode = hip.hash_mode
+        hip.set_hash_mode(hash_mode)
+        try:
+            if definition == "reference_pipeline" and ref_arrays is None:
+                h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], sketch_n)
+                t = hip.refdb_build(h, khi, klo, o, list(ks))
+                ref_arrays = t.download(kmers=False)
+                t.free()
+            elif definition != "reference_pipeline" and dbh is None:
+                tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in ks]
+                dbh, dbo = [t[0] for t in tables], [t[1] for t in tables]
+        finally:
+            hip.set_hash_mode(prev_mode)
         n -= n % 4
         data = os.path.join(td, "data")
         names, accs, sub_text = write_data_dir(data, gb, go, G, glen)
-        filters = {}
-        for k, h in zip(ks, dbh):
-            f = hip.filter_build(h)
-            filters[k] = f.download()
+        if definition == "reference_pipeline":
+            f = hip.filter_build(ref_arrays["pair_hash"])
+            formats.write_refpipe_table(os.path.join(data, "sketch_table"), names, sketch_n, ref_arrays, f.download(), hash_mode=hash_mode)
             f.free()
-        formats.write_sketch_table(os.path.join(data, "sketch_table"), names, list(ks), sketch_n,
-                                   {k: (h, o) for k, h, o in zip(ks, dbh, dbo)}, filters)
+        else:
+            filters = {}
+            for k, h in zip(ks, dbh):
+                f = hip.filter_build(h)
+                filters[k] = f.download()
+                f.free()
+            formats.write_sketch_table(os.path.join(data, "sketch_table"), names, list(ks), sketch_n,
+                                       {k: (h, o) for k, h, o in zip(ks, dbh, dbo)}, filters, hash_mode=hash_mode)
         sub = os.path.join(td, "subset_db_info.txt")
         with open(sub, "w") as fh:
             fh.write(sub_text)
@@ -188,7 +209,7 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, 
             del sk_t0
         sel, mp, tm = best
         nsel = sum(1 for _ in open(os.path.join(td, "tmp0", "subset_db_info.txt"))) - 2
-        res = {"reads": n, "genomes": G, "ks": list(ks), "fastq_mb": fq_bytes >> 20, "sam_mb": sam_bytes >> 20, "sam_lines": sam_lines,
+        res = {"reads": n, "genomes": G, "ks": list(ks), "stage_a_definition": definition, "hash_mode": hash_mode, "fastq_mb": fq_bytes >> 20, "sam_mb": sam_bytes >> 20, "sam_lines": sam_lines,
                "select_main_s": sel, "map_main_s": mp, "generate_s": t_gen, "selected_genomes": nsel,
                "select_main_reads_per_s": n / sel, "map_main_reads_per_s": n / mp,
                "value": n / (sel + mp), "unit": "reads/s",
@@ -214,4 +235,5 @@ if __name__ == "__main__":
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     ks = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (21,)
     import json
-    print(json.dumps(measure(n, G=G, ks=ks, verbose=True), indent=1))
+    print(json.dumps(measure(n, G=G, ks=ks, verbose=True, definition=os.environ.get("MG_DEFINITION", "reference_pipeline"),
+                             hash_mode=int(os.environ.get("MG_HASH_MODE", "0"))), indent=1))

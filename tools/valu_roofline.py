@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--read_len", type=int, default=150)
     ap.add_argument("--ks", default="21,31,51")
     ap.add_argument("--out", default="")
+    ap.add_argument("--positions_per_iteration", type=int, default=1,
+                    help="read positions one iteration of the walk loop covers (the one-k kernels, mg_sketch_kernel.h walk_reads: 2)")
     a = ap.parse_args()
     ks = [int(x) for x in a.ks.split(",")]
     cyc = cycles_table(a.classes, a.waves)
@@ -174,6 +176,8 @@ def main():
             for (op, how), (n, c) in per_block[b].items():
                 n_i += n
                 c_i += n * c
+        n_i /= a.positions_per_iteration
+        c_i /= a.positions_per_iteration
         kinds.append({"complete_k": ks[: i + 1], "positions_per_read": npos[i], "valu_instructions": n_i, "valu_cycles": c_i})
         tot_instr += npos[i] * n_i
         tot_cyc += npos[i] * c_i
@@ -190,6 +194,7 @@ def main():
     for k, (n, c) in sorted(full.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         table.append({"instruction": k, "count": n, "cycles_each": round(c, 2), "cycles": round(n * c, 1)})
     res = {"kernel": a.kernel, "loop": {"head": head, "hash_blocks": hot}, "ks": ks, "read_len": L,
+           "positions_per_loop_iteration": a.positions_per_iteration,
            "ubench_column": "%d waves per SIMD" % a.waves,
            "all_k_complete_position": table, "position_kinds": kinds, "warm_up_positions_per_read": warm,
            "valu_instructions_per_wave_step": tot_instr / L, "valu_cycles_per_wave_step": tot_cyc / L,
