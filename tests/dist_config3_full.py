@@ -9,7 +9,7 @@ the reference pipeline's all-to-all of prefix-bitmap words, THE all-reduce), fou
   * the same with every list / counting table undersized (MG_DEBUG_DISTINCT_HINT): overflow -> redo at this size;
   * the full workload: run(3) == step(), sketch sizes and stage-C totals as they must be.
 
-    python tests/dist_config3_full.py [reference_pipeline|sketch_per_k] [hash mode]
+    python tests/dist_config3_full.py [reference_pipeline|sketch_per_k] [hash mode] [sample reads] [overflow|plain]
 """
 import argparse
 import json
@@ -47,8 +47,9 @@ G, nreads = cfg["genomes"], len(w["ro"]) - 1
 assert G == 200_000 and nreads == 12_500_000 and w["ntax"] == 10_001
 report = {"definition": definition, "hash_mode": mode, "build_s": time.perf_counter() - t0}
 # ---- a sample against the oracle, every collective in the path; then once more with everything undersized ----
-args = argparse.Namespace(cpu_seconds=float(os.environ.get("MG_TEST_CPU_SECONDS", "6")))
-for hint in (None, "0.002"):
+min_sample = int(sys.argv[3]) if len(sys.argv) > 3 else 2_000_000
+args = argparse.Namespace(cpu_seconds=float(os.environ.get("MG_TEST_CPU_SECONDS", "6")), min_sample=min_sample)
+for hint in ((None, "0.002") if (len(sys.argv) <= 4 or sys.argv[4] == "overflow") else (None,)):
     if hint is None:
         os.environ.pop("MG_DEBUG_DISTINCT_HINT", None)
     else:
@@ -57,7 +58,7 @@ for hint in (None, "0.002"):
     base, check = bench.cpu_baseline_and_check(args, cfg, w, hip, dist=dist, force_dist=True)
     nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
     assert check["oracle_equal"], (hint, check["mismatch"])
-    assert nsample >= 2_000_000, check["compared"]
+    assert nsample >= min_sample, check["compared"]
     report["check_hint_%s" % hint] = {"sample_reads": nsample, "seconds": time.perf_counter() - t1, "cpu_reads_per_s": base["value"]}
 os.environ.pop("MG_DEBUG_DISTINCT_HINT", None)
 # ---- the whole workload: the job the driver's N > 1 bench runs on a rank ----
