@@ -341,6 +341,22 @@ int mg_reads_download(const mg_reads* r, uint8_t* bases, uint64_t* offsets);
 void mg_reads_free(mg_reads* r);
 
 /* ------------------------------------------------------------------------ *
+ * A gzip file's text through the library's PARALLEL inflater (mg_pgzip.hip) — the reference takes `.gz` reads as ordinary
+ * input (scripts/select_db.py:146-148; zcat of the selected genomes :103-105).  One gzip stream is entered in the middle by
+ * many host threads (deflate block starts found speculatively, back-references into the unknown 32 KB window kept symbolic
+ * and resolved in order — the pugz / rapidgzip scheme), every member's CRC-32 and length are checked, trailing garbage
+ * after the last member is ignored as gzip does.  mg_sketch_stream_add_file / mg_sam_stream_file use the same decoder for
+ * `.gz` input that is not BGZF.  Plain host code: needs no device and no mg_init.
+ *   open:  nthreads <= 0 = every core (at most 64).
+ *   read:  the next bytes of the inflated stream, up to cap; *n < cap only at the end of the stream (0: nothing left).
+ *          MG_ERR_ARG with the text in mg_last_error for a corrupt or truncated stream.
+ * ------------------------------------------------------------------------ */
+typedef struct mg_gunzip mg_gunzip;
+int mg_gunzip_open(const char* path, int nthreads, mg_gunzip** out);
+int mg_gunzip_read(mg_gunzip* h, uint8_t* dst, uint64_t cap, uint64_t* n);
+void mg_gunzip_close(mg_gunzip* h);
+
+/* ------------------------------------------------------------------------ *
  * Stage A' — genome sketch table (the pre-built DB the hot path consumes).
  * Replaces: CMash MakeStreamingDNADatabase.py -n 1000 -k 60
  * (local_tests/retrain_and_test_metalign.sh:49) and the .h5 / KMC-dump / bloom

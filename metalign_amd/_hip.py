@@ -36,6 +36,7 @@ EXPORTS = [
     "mg_reads_download", "mg_reads_free",
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
+    "mg_gunzip_open", "mg_gunzip_read", "mg_gunzip_close",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_sketch_genomes_kmers", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
@@ -94,6 +95,7 @@ def load_library(path=LIB_PATH):
     lib.mg_count_saturation.restype = ctypes.c_uint32
     lib.mg_db_free.restype = None
     lib.mg_refdb_free.restype = None
+    lib.mg_gunzip_close.restype = None
     lib.mg_refdb_kmax_table.restype = ctypes.c_void_p
     lib.mg_refdb_ngenomes.restype = ctypes.c_uint64
     lib.mg_refdb_max_hash.restype = ctypes.c_uint64
@@ -129,6 +131,34 @@ def multimapped_shares(mm_offsets, mm_tax, mm_hitlen, weight, genome_len=None):
     if rc != 0:
         raise HipError("libmetalign_hip rc=%d: %s" % (rc, _host_lib.mg_last_error().decode("utf-8", "replace")), rc)
     return extra, touched.astype(bool)
+
+
+def gunzip_file(path, nthreads=0, piece=256 << 20):
+    """A gzip file's text (every member; trailing garbage ignored) through the library's parallel inflater (mg_gunzip_*: one
+    stream entered in the middle by many host threads).  Host code of the library: no device involved.  OSError for a corrupt
+    or truncated stream."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    h = _vp()
+    rc = _host_lib.mg_gunzip_open(path.encode(), ctypes.c_int(nthreads), ctypes.byref(h))
+    if rc != 0:
+        raise OSError("%s: %s" % (path, _host_lib.mg_last_error().decode("utf-8", "replace")))
+    out = []
+    try:
+        while True:
+            buf = np.empty(piece, dtype=np.uint8)
+            n = ctypes.c_uint64(0)
+            rc = _host_lib.mg_gunzip_read(h, _np(buf, ctypes.c_uint8), ctypes.c_uint64(piece), ctypes.byref(n))
+            if rc != 0:
+                raise OSError("%s: %s" % (path, _host_lib.mg_last_error().decode("utf-8", "replace")))
+            if n.value:
+                out.append(buf[: n.value])
+            if n.value < piece:
+                break
+    finally:
+        _host_lib.mg_gunzip_close(h)
+    return out[0].tobytes() if len(out) == 1 else b"".join(x.tobytes() for x in out)
 
 
 class DeviceArray:

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "mg_internal.h"
+#include "mg_pgzip.h"
 
 namespace mg {
 
@@ -120,6 +121,22 @@ struct GzipSource : Source {
     }
     if (ended) *last = true;
     return (int64_t)(cap - room);
+  }
+};
+
+// The same stream inflated by MANY host threads (mg_pgzip.hip: deflate entered in the middle, the pugz / rapidgzip scheme):
+// the decoder runs ahead in the background, one reader thread copies its output into the slots in order.
+struct ParallelGzipSource : Source {
+  std::unique_ptr<PGzip> g;
+  bool ended = false;
+  bool parallel() const override { return false; }
+  int64_t fill(uint64_t, uint8_t* dst, uint64_t cap, bool* last) override {
+    *last = false;
+    if (ended) { *last = true; return 0; }
+    const int64_t n = g->read(dst, cap);
+    if (n < 0) { error = g->error(); return -1; }
+    if ((uint64_t)n < cap) { ended = true; *last = true; }
+    return n;
   }
 };
 
@@ -408,8 +425,23 @@ static int open_source(const char* path, uint64_t offset, uint64_t length, uint6
     uint64_t bc = *chunk_bytes ? *chunk_bytes : (16ull << 20);
     if (bc < (1u << 16)) bc = 1u << 16;
     if (bz->index(fsize, bc)) { *chunk_bytes = bc; *out = std::move(bz); return MG_OK; }
-    bz->fd = -1;  // not BGZF: one inflate stream
+    bz->fd = -1;  // not BGZF: one deflate stream
     if (!*chunk_bytes) *chunk_bytes = 32ull << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    int threads = (int)(hw == 0 ? 4 : (hw > 64 ? 64 : hw));
+    if (const char* e = getenv("MG_GZIP_THREADS")) { const int v = atoi(e); if (v > 0) threads = v; }
+    if (threads > 1) {
+      // ... entered in the middle by every core the box has (MG_GZIP_THREADS=1: zlib, one thread, as rounds 2-3)
+      std::string err;
+      uint64_t pc = 1ull << 20;
+      if (threads > 32) threads = 32;  // (two chunks per thread in flight, ~15 MB each inflated: a gigabyte of host memory at 32)
+      if (const char* e = getenv("MG_PGZIP_CHUNK")) { const long long v = atoll(e); if (v > 0) pc = (uint64_t)v; }
+      std::unique_ptr<ParallelGzipSource> pg(new ParallelGzipSource());
+      pg->g = PGzip::open(fd, true, fsize, threads, pc, &err);
+      if (!pg->g) { close(fd); return fail(MG_ERR_ARG, "%s: %s", path, err.c_str()); }
+      *out = std::move(pg);
+      return MG_OK;
+    }
     std::unique_ptr<GzipSource> g(new GzipSource());
     g->fd = fd;
     *out = std::move(g);
