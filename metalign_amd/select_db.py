@@ -206,6 +206,75 @@ def read_range_of_rank(path, kind, rank, world, all_gather_ints):
             fastq_record_start(path, raw[rank + 1], before[rank + 1], size))
 
 
+def text_record_cuts(text, kind, world):
+    """world + 1 offsets into `text` (bytes): share r = [cut[r], cut[r + 1]) holds whole records only — FASTQ records are four
+    lines (a quality line may begin with '@': the line NUMBER decides), FASTA records begin at a '>' that follows a newline."""
+    arr = np.frombuffer(text, dtype=np.uint8)
+    size = len(arr)
+    raw = [size * r // world for r in range(world + 1)]
+    cuts = [0]
+    lines_before = 0
+    for r in range(1, world):
+        lines_before += int(np.count_nonzero(arr[raw[r - 1]:raw[r]] == 10))
+        pos = raw[r]
+        if pos >= size:
+            cuts.append(size)
+            continue
+        if kind != 'fastq':
+            at = text.find(b'\n>', pos - 1 if pos else 0)
+            cuts.append(at + 1 if at >= 0 else size)
+            continue
+        # the first line that STARTS at or after pos, and its number
+        if pos == 0 or arr[pos - 1] == 10:
+            line_start, idx = pos, lines_before
+        else:
+            nl = text.find(b'\n', pos)
+            if nl < 0:
+                cuts.append(size)
+                continue
+            line_start, idx = nl + 1, lines_before + 1
+        for _ in range((-idx) % 4):  # on to the next record's '@' line
+            nl = text.find(b'\n', line_start)
+            if nl < 0:
+                line_start = size
+                break
+            line_start = nl + 1
+        cuts.append(min(line_start, size))
+    cuts.append(size)
+    for i in range(1, len(cuts)):  # (monotone whatever the text looks like)
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
+
+
+def scatter_text(dist, rank, world, dev, text, kind):
+    """Rank 0 holds `text` (bytes); -> this rank's record-aligned share of it.  Sizes by broadcast, the shares by point-to-point
+    sends (device tensors under RCCL: the share lands in HBM over xGMI)."""
+    import torch
+    if world == 1:
+        return text
+    sizes = [None]
+    if rank == 0:
+        cuts = text_record_cuts(text, kind, world)
+        sizes = [[cuts[r + 1] - cuts[r] for r in range(world)]]
+    dist.broadcast_object_list(sizes, src=0)
+    sizes = sizes[0]
+    if rank == 0:
+        arr = np.frombuffer(text, dtype=np.uint8)
+        reqs = []
+        for q in range(1, world):
+            if sizes[q]:
+                t = torch.from_numpy(arr[cuts[q]:cuts[q + 1]].copy()).to(dev)
+                reqs.append((dist.isend(t, dst=q), t))
+        for r, _ in reqs:
+            r.wait()
+        return text[cuts[0]:cuts[1]]
+    if not sizes[rank]:
+        return b''
+    t = torch.empty(sizes[rank], dtype=torch.uint8, device=dev)
+    dist.recv(t, src=0)
+    return t.cpu().numpy().tobytes()
+
+
 _dist_keep = []  # (the torch stream the library launches on must outlive the job)
 
 
@@ -251,10 +320,11 @@ def run_sketch_steps_dist(args, ctx):
         return [int(o.item()) for o in out]
 
     if formats.is_gzip(args.reads):
-        # a gzip stream cannot be entered in the middle: rank 0 inflates it (zlib, members one after the other) and
-        # sketches all of it; the other ranks bring empty shards to the exchange and their table slices to stage B.
-        # Inflating — ~0.3 GB/s of text per core — is what such a run waits for, not the hashing (one GPU takes 200 GB/s).
-        text = formats.inflate_file(args.reads) if rank == 0 else b''
+        # rank 0 inflates the file with every core of the host (the library's parallel inflater, mg_pgzip.hip: one gzip
+        # stream entered in the middle by many threads) and SCATTERS record-aligned shares of the text: every rank parses
+        # and sketches its own (rounds 2-3: rank 0 inflated on one core and sketched everything, the others brought
+        # empty shards)
+        text = scatter_text(dist, rank, world, dev, _hip.gunzip_file(args.reads) if rank == 0 else None, args.input_type)
     else:
         start, end = read_range_of_rank(args.reads, args.input_type, rank, world, gather)
         with open(args.reads, 'rb') as fh:
@@ -263,6 +333,9 @@ def run_sketch_steps_dist(args, ctx):
     reads = hip.parse_reads(text, 'fastq' if args.input_type == 'fastq' else 'fasta_ml')
     rb, ro = reads.download()
     reads.free()
+    if os.environ.get('MG_DIST_REPORT') == '1':  # (tests: what every rank's shard held)
+        with open(os.path.join(args.temp_dir, 'shard_rank%d.txt' % rank), 'w') as fh:
+            fh.write('%d reads, %d bases\n' % (len(ro) - 1, len(rb)))
     # (a reference-pipeline table, formats.py version 3: the job sketches the largest k only and shares the table out by hash
     # range for the pairs and by prefix range for the smaller k's count lists)
     job = ShardJob(hip, dist, rank, world, k=list(table.ks), ci=int(getattr(args, 'min_count', 2)),

@@ -178,18 +178,21 @@ def test_build_db_select_and_profile(hip, oracle_lib, tmp_path, monkeypatch):
     # ... and both command lines with two, three and eight ranks sharing this GPU (torch.distributed.run; gloo staged through
     # the host, since RCCL refuses several ranks on one device): the same CSV, subset db_info and CAMI file
     for world in (2, 3, 8):
-        env = dict(os.environ, MG_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env = dict(os.environ, MG_DIST_BACKEND="gloo", MG_DIST_REPORT="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
         launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                   "--master-addr", "127.0.0.1", "--master-port", str(29560 + world)]
         tmpw = tmp_path / ("tmp_world%d" % world)
-        # (world 2 is handed the GZIPPED reads — rank 0 inflates and sketches them, the other rank brings an empty shard and
-        # its table slices; round 2 exited with an error there — world 3 the FASTA file, world 8 the FASTQ file)
+        # (world 2 is handed the GZIPPED reads — rank 0 inflates them with the library's parallel inflater and scatters
+        # record-aligned shares of the text, so EVERY rank sketches; rounds 2-3 had rank 0 sketch everything — world 3 the
+        # FASTA file, world 8 the FASTQ file)
         r = subprocess.run(launch + ["-m", "metalign_amd.select_db", str({2: gzq, 3: fa}.get(world, fq)), str(data), "--temp_dir", str(tmpw), "--keep_temp_files",
                                      "--sketch_table", str(data / "sketch_table")],
                            capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert (tmpw / "cmash_query_results.csv").read_text().splitlines() == csv, world
         assert (tmpw / "subset_db_info.txt").read_text().splitlines() == sub
+        shards = [int((tmpw / ("shard_rank%d.txt" % r)).read_text().split()[0]) for r in range(world)]
+        assert sum(shards) == len(ro) - 1 and min(shards) > 0, (world, shards)  # every rank had reads of its own, .gz included
         outw = tmp_path / ("abundances_world%d.tsv" % world)
         r = subprocess.run(launch + ["-m", "metalign_amd.map_and_profile", str(sam), str(data), "--dbinfo",
                                      str(tmpd / "subset_db_info.txt"), "--output", str(outw), "--sampleID", "s1"],

@@ -485,3 +485,29 @@ def test_inflate_file_ignores_trailing_padding_and_refuses_truncation(tmp_path):
     p.write_bytes((a + b)[:-9])
     with pytest.raises(OSError):
         formats.inflate_file(str(p))
+
+
+
+def test_text_record_cuts_for_the_scattered_gz_reads():
+    """select_db.text_record_cuts: the record-aligned shares rank 0 scatters after inflating a `.gz` reads file — FASTQ by line
+    number (quality lines that begin with '@' or '+'), FASTA by '>' after a newline (a '>' inside a sequence line is not one)."""
+    import numpy as np
+    from metalign_amd import select_db
+    rng = np.random.default_rng(0)
+    recs = []
+    for i in range(1000):
+        ln = int(rng.integers(1, 200))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=ln))
+        qual = bytes(rng.choice(np.frombuffer(b"@IJ+>", dtype=np.uint8), size=ln))
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + qual + b"\n")
+    text = b"".join(recs)
+    starts = set(np.cumsum([0] + [len(r) for r in recs]).tolist())
+    for world in (1, 2, 3, 7, 8, 64, 2000):
+        cuts = select_db.text_record_cuts(text, "fastq", world)
+        assert cuts[0] == 0 and cuts[-1] == len(text) and len(cuts) == world + 1 and cuts == sorted(cuts)
+        assert all(c in starts for c in cuts), world
+    fa = b"junk\n" + b"".join(b">s%d desc\nACGT\nAC>GT\n" % i for i in range(500))
+    for world in (2, 5, 9):
+        cuts = select_db.text_record_cuts(fa, "fasta", world)
+        assert all(c == 0 or c == len(fa) or (fa[c:c + 1] == b">" and fa[c - 1:c] == b"\n") for c in cuts), (world, cuts)
+    assert select_db.text_record_cuts(b"", "fastq", 4) == [0, 0, 0, 0, 0]
