@@ -39,6 +39,9 @@
 
 namespace mg {
 
+#ifndef MG_K3_LOAD_BATCH
+#define MG_K3_LOAD_BATCH 3
+#endif
 constexpr int kPB = 256;                 // threads per workgroup
 constexpr int kItems = 8;                // consecutive records per thread
 constexpr int kTile = kPB * kItems;      // records per tile
@@ -547,60 +550,63 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
     const uint64_t t0 = tile * kTile;
     const uint32_t nst = (uint32_t)(A.ntotal - t0 < (uint64_t)kStaged ? A.ntotal - t0 : (uint64_t)kStaged);  // staged
     const uint32_t nown = (uint32_t)(A.nrecs - t0 < (uint64_t)kTile ? A.nrecs - t0 : (uint64_t)kTile);      // owned
-    // 1. records -> descriptors in LDS (coalesced 16-byte loads, one division per record)
-    for (uint32_t i = tid; i < nst; i += kPB) {
-      const mg_aln_rec r = A.recs[t0 + i];
-      s_desc[slot(i)] = make_desc(r, A.ref2tax[r.ref_new & MG_REC_REF_MASK], A.pct_id);
+    // 1. records -> descriptors in LDS (coalesced 16-byte loads, one division per record).  All of a thread's record
+    //    loads are issued before the first is used, then all of its taxon gathers: as a plain loop this was nine times
+    //    two DEPENDENT round trips (record, then ref2tax[record]) — 14.5 k of a tile's 87 k clocks, all of it latency.
+    {
+      constexpr int kRounds = (kStaged + kPB - 1) / kPB;
+      constexpr int kBatch = MG_K3_LOAD_BATCH;  // rounds in flight together (registers: 5 per round)
+#pragma unroll
+      for (int j0 = 0; j0 < kRounds; j0 += kBatch) {
+        mg_aln_rec r[kBatch];
+        uint32_t tx[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const uint32_t i = (uint32_t)tid + (uint32_t)(j0 + j) * kPB;
+          if (j0 + j < kRounds && i < nst) r[j] = A.recs[t0 + i];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const uint32_t i = (uint32_t)tid + (uint32_t)(j0 + j) * kPB;
+          if (j0 + j < kRounds && i < nst) tx[j] = A.ref2tax[r[j].ref_new & MG_REC_REF_MASK];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const uint32_t i = (uint32_t)tid + (uint32_t)(j0 + j) * kPB;
+          if (j0 + j < kRounds && i < nst) s_desc[slot(i)] = make_desc(r[j], tx[j], A.pct_id);
+        }
+      }
     }
     __syncthreads();
     PH(1);
     const DescView at{(LdsDescPtr)s_desc, t0, nst, A.recs, A.ref2tax, A.pct_id};
 
-    // 2. leaders classify their read under both hypotheses; the thread's 8 records fold into one RunFn
+    // 2. every read is classified under BOTH hypotheses by the thread that owns its first line; the thread's reads fold
+    //    into one RunFn.  ONE linear walk: the thread's own eight descriptors come out of LDS in one round trip (registers,
+    //    static indices), a read's counters run along under both hypotheses ("dropped" is the same read without its
+    //    first line), and the line that opens the next read closes the current one (its pair flags are what
+    //    process_read is told, :225-226).  Only a read that runs past the thread's own records goes on reading LDS.
+    //    (Rounds 1-3 looked for the closing line first and walked the read a second time: two dependent LDS chains per
+    //    read and a wavefront as slow as its longest read.)
     const uint32_t l0 = (uint32_t)tid * kItems;
     RunFn mine{kIdentity, {0, 0}};
     {
-      uint32_t st0 = 0, st1 = 1;  // state after the records seen so far, for the thread entered kept / dropped
-      for (int j = 0; j < kItems; ++j) {
-        const uint32_t li = l0 + j;
-        if (li >= nown) break;
-        const uint2 d = s_desc[slot(li)];
-        if (!(d.y & D_NEW)) continue;
-        mine.pk[0] += kPkOneRead;
-        mine.pk[1] += kPkOneRead;
-        uint32_t e = li + 1;
-        while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
-        uint32_t k0, k1;  // kind | nmm << 2 under "kept" / "dropped"
-        uint64_t ge = t0 + e;
-        bool npx;  // what the general evaluator is told about the next read
-        if (e < nst) {
-          const bool np = s_desc[slot(e)].y & (D_P1 | D_P2);
-          Walk w{0, 0, 0, 0, 0}, w1{0, 0, 0, 0, 0};
-          walk_add(w, d);
-          for (uint32_t q = li + 1; q < e; ++q) {  // "dropped" is the same read without its first line
-            const uint2 dq = s_desc[slot(q)];
-            walk_add(w, dq);
-            walk_add(w1, dq);
-          }
-          k0 = classify(w, np);
-          k1 = classify(w1, np);
-          npx = true;
-        } else {  // the read runs past the staged window (or to the end of the shard)
-          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
-          if (ge >= A.ntotal) continue;  // no closing line: the read is never processed (:259-264)
-          npx = at(ge).y & (D_P1 | D_P2);
-          k0 = k1 = 3u;
-        }
-        // the general evaluator for what the straight-line walk does not cover — ONE inlined copy for both hypotheses
+      uint32_t st0 = 0, st1 = 1;  // state after the reads closed so far, for the thread entered kept / dropped
+      bool open = false;
+      uint32_t lead = 0;
+      Walk w{0, 0, 0, 0, 0}, w1{0, 0, 0, 0, 0};
+      // the read [lead, e) is closed by a line with pair flags np (staged), or runs to global record ge (staged == false)
+      auto close = [&](bool staged, bool np, uint64_t ge) {
+        uint32_t k0 = staged ? classify(w, np) : 3u, k1 = staged ? classify(w1, np) : 3u;
+        // the general evaluator for what the counters do not decide — ONE inlined copy for both hypotheses
         // (every copy is ~3 KB of code in the tile loop; the kernel was 42 KB with six of them)
 #pragma unroll 1
         for (uint32_t hyp = 0; hyp < 2; ++hyp) {
           if ((hyp ? k1 : k0) != 3u) continue;
-          const Verdict v = eval_group(at, t0 + li + hyp, ge, npx, nullptr);
+          const Verdict v = eval_group(at, t0 + lead + hyp, ge, np, nullptr);
           const uint32_t kk = v.kind | (v.nmm << 2);
           if (hyp) k1 = kk; else k0 = kk;
         }
-        // advance both paths through this read
         const uint32_t ka = st0 ? k1 : k0, kb = st1 ? k1 : k0;
         if (COMMIT) {
           if ((ka & 3u) == 2u) mine.pk[0] += kPkOneMm + (ka >> 2);
@@ -608,6 +614,39 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         }
         st0 = (ka & 3u) == 0u;
         st1 = (kb & 3u) == 0u;
+      };
+      // (a rolled loop, the next line requested from LDS before this one is used: one copy of the code above — unrolled
+      // over the thread's eight records it was nine, 222 VGPRs and two workgroups per CU)
+      const uint32_t own_end = l0 + kItems < nown ? l0 + kItems : nown;
+      uint32_t e = l0;
+      uint2 d = e < nst ? s_desc[slot(e)] : make_uint2(0u, 0u);
+#pragma unroll 1
+      while (e < nst) {
+        const uint2 dn = e + 1 < nst ? s_desc[slot(e + 1)] : make_uint2(0u, 0u);
+        const bool own = e < own_end;
+        if (d.y & D_NEW) {
+          if (open) { close(true, d.y & (D_P1 | D_P2), t0 + e); open = false; }
+          if (!own) break;
+          open = true;
+          lead = e;
+          w = Walk{0, 0, 0, 0, 0};
+          w1 = w;
+          walk_add(w, d);
+          mine.pk[0] += kPkOneRead;
+          mine.pk[1] += kPkOneRead;
+        } else if (open) {
+          walk_add(w, d);
+          walk_add(w1, d);
+        } else if (!own) {
+          break;
+        }
+        ++e;
+        d = dn;
+      }
+      if (open) {  // ... past the staged window (or to the end of the shard)
+        uint64_t ge = t0 + e;
+        while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
+        if (ge < A.ntotal) close(false, at(ge).y & (D_P1 | D_P2), ge);  // (no closing line: the read is never processed, :259-264)
       }
       mine.out = st0 | (st1 << 1);
     }
@@ -675,35 +714,27 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       uint64_t gidx = A.group_base + s_bcast[1] + pk_reads(ex);
       uint32_t ambig = (tid == 0 && tile == 0 && A.first_shard) ? 1u : 0u;  // the phantom first boundary (:155-156)
       bool used_priv = false;
-      for (int j = 0; j < kItems; ++j) {
-        const uint32_t li = l0 + j;
-        if (li >= nown) break;
-        const uint2 d = s_desc[slot(li)];
-        if (!(d.y & D_NEW)) continue;
-        const uint64_t my_gidx = gidx++;
-        uint32_t e = li + 1;
-        while (e < nst && !(s_desc[slot(e)].y & D_NEW)) ++e;
+      // the same linear walk with the TRUE state: a read's counters run along from the line that opens it (without that
+      // line when the state says "dropped") and the read is committed by the line that closes it
+      bool open = false;
+      uint32_t lead = 0;
+      uint64_t my_gidx = 0;
+      Walk w{0, 0, 0, 0, 0};
+      // commits the read whose lines are [lead + st, e): e staged (e_loc) or global (ge, staged == false)
+      auto commit_read = [&](bool staged, uint32_t e_loc, bool np, uint64_t ge) {
         uint32_t kind, tax, nmm = 0;
-        uint64_t hitlen, ge = t0 + e;
-        bool np, slow = false;
-        if (e < nst) {
-          np = s_desc[slot(e)].y & (D_P1 | D_P2);
-          Walk w{0, 0, 0, 0, 0};
-          for (uint32_t q = li + st; q < e; ++q) walk_add(w, s_desc[slot(q)]);
+        uint64_t hitlen;
+        bool slow = !staged;
+        if (staged) {
           const uint32_t k = classify(w, np);
           kind = k & 3u; nmm = k >> 2; tax = w.tax; hitlen = w.hsum;
           slow = kind == 3u;
-        } else {
-          while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
-          if (ge >= A.ntotal) continue;  // never processed
-          np = at(ge).y & (D_P1 | D_P2);
-          slow = true;
         }
         if (slow) {  // verdict first; a multimapped read's taxon list (SAM order) in a second round of the same code
           uint32_t* out = nullptr;
 #pragma unroll 1
           for (int round = 0; round < 2; ++round) {
-            const Verdict v = eval_group(at, t0 + li + st, ge, np, out);
+            const Verdict v = eval_group(at, t0 + lead + st, ge, np, out);
             kind = v.kind; tax = v.tax; nmm = v.nmm; hitlen = v.hitlen;
             if (kind != 2u) break;
             out = A.mm_tax + eo;
@@ -724,9 +755,9 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
             for (uint32_t step = 0; step < kHashProbe / 4 && !in_lds; ++step) {
               const uint4 kq = *reinterpret_cast<const uint4*>(&h_key[b * 4]);
               // the usual case without a branch: the key is one of the four
-              const uint32_t at = kq.x == tax ? 0u : kq.y == tax ? 1u : kq.z == tax ? 2u : kq.w == tax ? 3u : 4u;
-              if (at < 4u) {
-                bin = b * 4 + at; in_lds = true;
+              const uint32_t at4 = kq.x == tax ? 0u : kq.y == tax ? 1u : kq.z == tax ? 2u : kq.w == tax ? 3u : 4u;
+              if (at4 < 4u) {
+                bin = b * 4 + at4; in_lds = true;
               } else if (kq.w == 0xffffffffu) {  // room in this bucket (slots fill in order): claim the first free one
                 const uint32_t kv[4] = {kq.x, kq.y, kq.z, kq.w};
 #pragma unroll
@@ -765,7 +796,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         } else {
           if (!slow) {
             uint64_t wpos = eo;
-            for (uint32_t q = li + st; q < e; ++q) {  // every kept line (:172-173)
+            for (uint32_t q = lead + st; q < e_loc; ++q) {  // every kept line (:172-173)
               const uint2 dq = s_desc[slot(q)];
               if (!(dq.y & D_REJ)) A.mm_tax[wpos++] = dq.x;
             }
@@ -777,6 +808,34 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           ++so;
         }
         st = kind == 0;
+      };
+      const uint32_t own_end = l0 + kItems < nown ? l0 + kItems : nown;
+      uint32_t e = l0;
+      uint2 d = e < nst ? s_desc[slot(e)] : make_uint2(0u, 0u);
+#pragma unroll 1
+      while (e < nst) {
+        const uint2 dn = e + 1 < nst ? s_desc[slot(e + 1)] : make_uint2(0u, 0u);
+        const bool own = e < own_end;
+        if (d.y & D_NEW) {
+          if (open) { commit_read(true, e, d.y & (D_P1 | D_P2), t0 + e); open = false; }
+          if (!own) break;
+          open = true;
+          lead = e;
+          my_gidx = gidx++;
+          w = Walk{0, 0, 0, 0, 0};
+          if (!st) walk_add(w, d);
+        } else if (open) {
+          walk_add(w, d);
+        } else if (!own) {
+          break;
+        }
+        ++e;
+        d = dn;
+      }
+      if (open) {
+        uint64_t ge = t0 + e;
+        while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
+        if (ge < A.ntotal) commit_read(false, e, at(ge).y & (D_P1 | D_P2), ge);  // (else: never processed)
       }
       if (ambig) atomicAdd(&s_ambig, (unsigned long long)ambig);
       if (used_priv && __hip_atomic_load(A.priv_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicExch(A.priv_used, 1u);
@@ -809,8 +868,11 @@ template <>
 __global__ __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(4))) void k_profile_pass<false>(const PassArgs A) {
   profile_pass_body<false>(A);
 }
+#ifndef MG_K3_COMMIT_WAVES
+#define MG_K3_COMMIT_WAVES 3
+#endif
 template <>
-__global__ __launch_bounds__(kPB) void k_profile_pass<true>(const PassArgs A) {
+__global__ __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(MG_K3_COMMIT_WAVES))) void k_profile_pass<true>(const PassArgs A) {
   profile_pass_body<true>(A);
 }
 
