@@ -24,10 +24,14 @@ done
 timeout -s KILL 900 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
   --kernel-trace -d "$OUT/pmc_SQ" -o run -- python3 bench.py $ARGS > "$OUT/pmc_SQ.log" 2>&1
 python3 tools/summarize_profiles.py "$OUT" > "$OUT/summary.log" 2>&1
-# the per-opcode pricing of the fused kernel's hot loop, from the assembly of the library as built here
+# the per-opcode pricing of the fused kernel's hot loop, from the assembly of the library as built here (MG_PROFILE_ASM=1: a
+# minute of compiling on the GPU box; the one-k kernel of the reference pipeline — mg_sketch.hip, three minutes — is priced in
+# the build container instead: tools/valu_roofline.py --kernel 14k_sketch_readsILi51ELi0E --ks 51 --positions_per_iteration 2)
+if [ "${MG_PROFILE_ASM:-0}" = "1" ]; then
 /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 --cuda-device-only -S -o "$OUT/mg_sketch_multi.s" metalign_amd/csrc/mg_sketch_multi.hip 2>/dev/null
 CLASSES=$(ls profiles/*/valu_classes.json | tail -1)
 python3 tools/valu_roofline.py "$OUT/mg_sketch_multi.s" "$CLASSES" --out "$OUT/k1_valu_roofline.json" > "$OUT/k1_valu_roofline.txt" 2>&1
 rm -f "$OUT/mg_sketch_multi.s"
+fi
 for d in stats stats_pipelined pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do rm -rf "$OUT/$d"; done
 tail -n 30 "$OUT/summary.log"
