@@ -449,13 +449,15 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 // something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
 // had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
 // pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
-// kHashProbe slots = kHashProbe / 4 buckets of four keys (one 16-byte LDS read each) are looked at before the private
-// bins take a record.  Per 125M records over 10 001 uniform taxa (keys probed one by one): 32 probes 7.9 ms, 8: 5.6,
-// 2: 5.1, but below 16 a sample of 500 hot taxa starts to overflow and pays the reduction (0.52 -> 0.56 ms per
-// 12.5M); with the buckets of four: 4.73 ms and 0.49 ms.  (Measured, and not understood: on the SAME records the
-// hashed bins cost 0.15 ms more than direct ones — 0.55 against 0.40 ms at 500 taxa, MG_DEBUG_K3_HASHED — although a
-// record takes 1.09 bucket reads on average and 0.6 % overflow; tools/experiments/README.md has the counters.)
-constexpr uint32_t kHashSlots = 1024, kHashProbe = 16, kFlushTiles = 256;
+// kHashProbe slots (double hashing, one 4-byte key per probe) are looked at before the private bins take a record.  Measured
+// in round 4 on bench.py's configs[2] records (12.5M, 10 001 taxa): 0.47 ms with the bins hashed against 0.30 ms with direct bins
+// on the same records folded onto 2001 taxa — and 0.32 ms with the look-up ablated (slot = taxon mod 1024, wrong results), whatever
+// the look-up's form (buckets of four keys in rounds 2-3, single keys now: the same 0.47).  The table is simply FULL: the sample's 500
+// genomes are hit uniquely, and so are their ~500 sibling accessions (a read whose first line was dropped is left with its
+// secondary alignment alone: unique, to the sibling) — ~1000 taxa for 1024 slots, long probe walks and overflows into the private
+// bins.  2048 slots would cost the third workgroup per CU (LDS); key + count + bases in ONE 64-bit word (12-byte slots, flushed
+// every 16 tiles) would fit 2048 at three — not built.
+constexpr uint32_t kHashSlots = 1024, kHashProbe = 8, kFlushTiles = 256;
 constexpr uint32_t kBinLenLimit = 1u << 20;
 constexpr int kBinCountShift = 40;
 
@@ -746,33 +748,21 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           uint32_t bin = tax;
           bool in_lds = A.use_lds_hist == 1;
           if (A.use_lds_hist == 2) {
-            // kHashSlots / 4 buckets of four keys, one 16-byte LDS read each: with the keys probed one at a time the
-            // slowest lane of the wavefront set the pace (~10 dependent LDS reads per record at half load; 28 k of
-            // the commit's 63 k clocks per tile at 10 001 taxa).  A key never changes once set and every lane scans
-            // the slots in the same order, so a taxon cannot end up in two of them.
-            uint32_t b = (tax * 2654435761u) >> 24;  // 8 bits
-            static_assert(kHashSlots == 1024, "bucket index width");
-            for (uint32_t step = 0; step < kHashProbe / 4 && !in_lds; ++step) {
-              const uint4 kq = *reinterpret_cast<const uint4*>(&h_key[b * 4]);
-              // the usual case without a branch: the key is one of the four
-              const uint32_t at4 = kq.x == tax ? 0u : kq.y == tax ? 1u : kq.z == tax ? 2u : kq.w == tax ? 3u : 4u;
-              if (at4 < 4u) {
-                bin = b * 4 + at4; in_lds = true;
-              } else if (kq.w == 0xffffffffu) {  // room in this bucket (slots fill in order): claim the first free one
-                const uint32_t kv[4] = {kq.x, kq.y, kq.z, kq.w};
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
-                  if (in_lds || kv[q] != 0xffffffffu) continue;
-                  const uint32_t old = atomicCAS(&h_key[b * 4 + q], 0xffffffffu, tax);
-                  if (old == 0xffffffffu || old == tax) { bin = b * 4 + q; in_lds = true; }
-                }
-                if (!in_lds) {  // lost every free slot of the snapshot to other taxa: look again (rare)
-                  const uint4 k2 = *reinterpret_cast<const uint4*>(&h_key[b * 4]);
-                  const uint32_t a2 = k2.x == tax ? 0u : k2.y == tax ? 1u : k2.z == tax ? 2u : k2.w == tax ? 3u : 4u;
-                  if (a2 < 4u) { bin = b * 4 + a2; in_lds = true; }
-                }
-              }
-              b = (b + 1) & (kHashSlots / 4 - 1);
+            // Open addressing with double hashing, one 4-byte key per probe, at most kHashProbe probes: the usual case is ONE
+            // LDS read and a compare.  A key never changes once set and a taxon always walks the same slots in the same order,
+            // so it cannot end up in two of them; two lanes that race for an empty slot are settled by the compare-and-swap
+            // (the loser of another taxon goes on to its next slot).  Rounds 2-3 read a bucket of four keys (16 bytes) per
+            // step and claimed inside a four-way loop: 0.15 ms of a 0.47 ms pass on configs[2]'s records went into that look-up
+            // (ablated: 0.32 ms) — a workgroup lives for eight tiles, so the claiming first tile is an eighth of its work.
+            static_assert(kHashSlots == 1024, "slot index width");
+            const uint32_t hh = tax * 2654435761u;
+            uint32_t sl = hh >> 22;                              // 10 bits
+            const uint32_t stride = ((hh >> 11) & 1022u) | 1u;   // odd: every slot is reached
+            for (uint32_t step = 0; step < kHashProbe && !in_lds; ++step) {
+              uint32_t k = h_key[sl];
+              if (k == 0xffffffffu) k = atomicCAS(&h_key[sl], 0xffffffffu, tax) == 0xffffffffu ? tax : h_key[sl];
+              if (k == tax) { bin = sl; in_lds = true; }
+              sl = (sl + stride) & (kHashSlots - 1);
             }
           }
           if (in_lds && hitlen < kBinLenLimit) {

@@ -234,9 +234,19 @@ __device__ __forceinline__ void walk_reads(const uint8_t* src, uint32_t start, u
   kmers += nk;
 }
 
+// (A/B builds: -DMG_K1_WAVES_BIG=5 holds the kernels of k > 32 — two 64-bit words per packed strand, 112 VGPRs at k = 51, four
+// wavefronts per SIMD — to the register budget of five)
+#ifndef MG_K1_WAVES_BIG
+#define MG_K1_WAVES_BIG 0
+#endif
+#if MG_K1_WAVES_BIG
+#define MG_K1_ATTR(K) __attribute__((amdgpu_waves_per_eu((K) > 32 ? MG_K1_WAVES_BIG : 4)))
+#else
+#define MG_K1_ATTR(K)
+#endif
 // counters[0] = candidates produced (may exceed cap: overflow => caller retries), counters[1] = k-mers hashed
 template <int K, int HM>
-__global__ __launch_bounds__(kBlock) void k_sketch_reads(const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock) MG_K1_ATTR(K) void k_sketch_reads(const uint8_t* __restrict__ bases,
                                                          const uint64_t* __restrict__ offsets, uint64_t nreads,
                                                          uint64_t hmax, uint64_t* __restrict__ cand, uint64_t cand_cap,
                                                          unsigned long long* __restrict__ counters,
