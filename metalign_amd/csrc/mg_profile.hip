@@ -434,30 +434,34 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 
 // Per-workgroup privatised histogram in LDS, flushed with global atomics every kFlushTiles tiles and at the end:
 //   use_lds_hist == 1  direct:  ntax <= 4096 bins (dynamic LDS: 12 B per bin; above 2048 taxa two workgroups per CU, like the hashed form)
-//   use_lds_hist == 2  hashed:  any ntax; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
-//                      fewer taxa than the table lists).  A taxon that finds no bin within kHashProbe steps goes to
+//   use_lds_hist == 2  hashed:  ntax < 2^18; kHashSlots open-addressed bins keyed by taxon id (a sample hits far
+//                      fewer taxa than the table lists).  A taxon that finds no bin within kHashProbe probes goes to
 //                      the WORKGROUP'S PRIVATE BINS IN GLOBAL MEMORY (priv_pack / priv_first: [workgroup][ntax]),
 //                      updated with WORKGROUP-scope atomics — executed in the L2 of the XCD the workgroup runs on,
-//                      not at the memory side like device-scope ones (~14 G/s on this multi-XCD part: with 10 001
-//                      taxa hit uniformly the 2048 LDS bins overflow by design, and the commit phase was 108 k
-//                      cycles per tile of memory-side atomics).  Nothing else touches a workgroup's copy while the
-//                      kernel runs; k_bins_reduce sums the copies afterwards (and leaves them zeroed), and returns
-//                      at once when no workgroup overflowed.
+//                      not at the memory side like device-scope ones (~14 G/s on this multi-XCD part).  Nothing else
+//                      touches a workgroup's copy while the kernel runs; k_bins_reduce sums the copies afterwards (and
+//                      leaves them zeroed), and returns at once when no workgroup overflowed.
 //   use_lds_hist == 0  global atomics only (shards of 2^32 reads or more: the bins hold 32-bit read indices).
 // A bin is ONE packed 64-bit word (count << 40 | bases) plus the 32-bit shard-relative index of the first read
 // seen: one LDS atomic per unique read (the minimum is only attempted when a plain read says it would change
 // something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
 // had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
 // pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
-// kHashProbe slots (double hashing, one 4-byte key per probe) are looked at before the private bins take a record.  Measured
-// in round 4 on bench.py's configs[2] records (12.5M, 10 001 taxa): 0.47 ms with the bins hashed against 0.30 ms with direct bins
-// on the same records folded onto 2001 taxa — and 0.32 ms with the look-up ablated (slot = taxon mod 1024, wrong results), whatever
-// the look-up's form (buckets of four keys in rounds 2-3, single keys now: the same 0.47).  The table is simply FULL: the sample's 500
-// genomes are hit uniquely, and so are their ~500 sibling accessions (a read whose first line was dropped is left with its
-// secondary alignment alone: unique, to the sibling) — ~1000 taxa for 1024 slots, long probe walks and overflows into the private
-// bins.  2048 slots would cost the third workgroup per CU (LDS); key + count + bases in ONE 64-bit word (12-byte slots, flushed
-// every 16 tiles) would fit 2048 at three — not built.
-constexpr uint32_t kHashSlots = 1024, kHashProbe = 8, kFlushTiles = 256;
+// kHashProbe slots (double hashing over the packed words) are looked at before the private bins take a record.  Measured in round 4
+// on bench.py's configs[2] records (12.5M, 10 001 taxa, ~1000 of them hit uniquely: the sample's 500 genomes and — through reads
+// whose first line was dropped — their sibling accessions): 0.46 ms with the bins hashed against 0.30 ms with direct bins on the
+// same records folded onto 2001 taxa, and 0.32 ms with the look-up ablated (slot = taxon mod 1024: wrong results).  Neither the
+// look-up's form nor the table's load explains the 0.14 ms: buckets of four keys read 16 bytes at a time (rounds 2-3, 1024
+// slots), single 4-byte keys with double hashing, and this round's packed words in 2048 slots all take 0.46-0.47 ms; four times
+// the records (a workgroup then lives for 32 tiles instead of 8, so claiming the keys is amortised) still pay 0.09 ms per 12.5M
+// records over direct bins.  What the look-up adds is ONE dependent LDS read in front of the atomic and a loop over probes that
+// ends when the slowest lane of the wavefront has found its slot; open.
+constexpr uint32_t kHashSlots = 2048, kHashProbe = 8, kFlushTiles = 256;
+// The hashed form's bin (round 4): taxon + 1 (18 bits) | count (15) | bases (31) in ONE 64-bit word, so that a slot is 12 bytes
+// (word + first read seen) and 2048 of them fit beside three workgroups per CU; 0 = empty.  The fields hold kHashFlushTiles tiles
+// (8 x 2048 reads of < 2^17 bases each; longer reads bypass the bins), then the bins are flushed — and their keys with them.
+constexpr int kHKeyShift = 46, kHCountShift = 31;
+constexpr uint32_t kHashFlushTiles = 8, kHashMaxTax = (1u << 18) - 2, kHashLenLimit = 1u << 17;
 constexpr uint32_t kBinLenLimit = 1u << 20;
 constexpr int kBinCountShift = 40;
 
@@ -513,17 +517,21 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   __shared__ unsigned long long s_ambig, s_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nbins = A.use_lds_hist == 2 ? kHashSlots : A.ntax;
-  unsigned long long* h_pack = hist;                                     // count << 40 | bases
+  unsigned long long* h_pack = hist;                                     // direct: count << 40 | bases; hashed: taxon + 1 | count | bases
   uint32_t* h_first = reinterpret_cast<uint32_t*>(hist + nbins);         // first read seen, relative to the shard
-  uint32_t* h_key = h_first + nbins;                                     // hashed mode only
   auto flush_bins = [&](bool reset) {
     for (uint32_t t = tid; t < nbins; t += kPB) {
       const unsigned long long pk = h_pack[t];
       if (pk) {
-        const uint32_t tax = A.use_lds_hist == 2 ? h_key[t] : t;
-        atomicAdd(&A.g_count[tax], pk >> kBinCountShift);
-        atomicAdd(&A.g_bases[tax], pk & ((1ull << kBinCountShift) - 1));
-        atomicMin(&A.g_first[tax], (unsigned long long)(A.group_base + h_first[t]));
+        const bool hashed = A.use_lds_hist == 2;
+        const uint32_t tax = hashed ? (uint32_t)(pk >> kHKeyShift) - 1u : t;
+        const unsigned long long cnt = hashed ? (pk >> kHCountShift) & 0x7fffull : pk >> kBinCountShift;
+        const unsigned long long bas = hashed ? pk & ((1ull << kHCountShift) - 1) : pk & ((1ull << kBinCountShift) - 1);
+        if (cnt) {  // (a hashed slot may be claimed and not yet counted in)
+          atomicAdd(&A.g_count[tax], cnt);
+          atomicAdd(&A.g_bases[tax], bas);
+          atomicMin(&A.g_first[tax], (unsigned long long)(A.group_base + h_first[t]));
+        }
         if (reset) { h_pack[t] = 0; h_first[t] = 0xffffffffu; }
       }
     }
@@ -532,7 +540,6 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   if (COMMIT && A.use_lds_hist) {
     for (uint32_t t = tid; t < nbins; t += kPB) {
       h_pack[t] = 0; h_first[t] = 0xffffffffu;
-      if (A.use_lds_hist == 2) h_key[t] = 0xffffffffu;
     }
   }
   if (tid == 0) { s_ambig = 0; s_groups = 0; }
@@ -748,28 +755,31 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
           uint32_t bin = tax;
           bool in_lds = A.use_lds_hist == 1;
           if (A.use_lds_hist == 2) {
-            // Open addressing with double hashing, one 4-byte key per probe, at most kHashProbe probes: the usual case is ONE
-            // LDS read and a compare.  A key never changes once set and a taxon always walks the same slots in the same order,
-            // so it cannot end up in two of them; two lanes that race for an empty slot are settled by the compare-and-swap
-            // (the loser of another taxon goes on to its next slot).  Rounds 2-3 read a bucket of four keys (16 bytes) per
-            // step and claimed inside a four-way loop: 0.15 ms of a 0.47 ms pass on configs[2]'s records went into that look-up
-            // (ablated: 0.32 ms) — a workgroup lives for eight tiles, so the claiming first tile is an eighth of its work.
-            static_assert(kHashSlots == 1024, "slot index width");
+            // Open addressing with double hashing over the packed words, at most kHashProbe probes: the usual case is ONE 8-byte
+            // LDS read and a compare of its key field.  Between two flushes a key never changes once set and a taxon always
+            // walks the same slots in the same order, so it cannot sit in two of them; two lanes that race for an empty slot are
+            // settled by the compare-and-swap (the loser of another taxon goes on to its next slot).
+            static_assert(kHashSlots == 2048, "slot index width");
             const uint32_t hh = tax * 2654435761u;
-            uint32_t sl = hh >> 22;                              // 10 bits
-            const uint32_t stride = ((hh >> 11) & 1022u) | 1u;   // odd: every slot is reached
+            uint32_t sl = hh >> 21;                              // 11 bits
+            const uint32_t stride = ((hh >> 10) & 2046u) | 1u;   // odd: every slot is reached
+            const unsigned long long mine = (unsigned long long)(tax + 1u) << kHKeyShift;
             for (uint32_t step = 0; step < kHashProbe && !in_lds; ++step) {
-              uint32_t k = h_key[sl];
-              if (k == 0xffffffffu) k = atomicCAS(&h_key[sl], 0xffffffffu, tax) == 0xffffffffu ? tax : h_key[sl];
-              if (k == tax) { bin = sl; in_lds = true; }
+              unsigned long long w = h_pack[sl];
+              if (w == 0ull) {
+                const unsigned long long old = atomicCAS(&h_pack[sl], 0ull, mine);
+                w = old == 0ull ? mine : old;
+              }
+              if ((w >> kHKeyShift) == (unsigned long long)(tax + 1u)) { bin = sl; in_lds = true; }
               sl = (sl + stride) & (kHashSlots - 1);
             }
           }
-          if (in_lds && hitlen < kBinLenLimit) {
+          const uint32_t len_limit = A.use_lds_hist == 2 ? kHashLenLimit : kBinLenLimit;
+          if (in_lds && hitlen < len_limit) {
             const uint32_t rel = (uint32_t)(my_gidx - A.group_base);
-            atomicAdd(&h_pack[bin], (1ull << kBinCountShift) + hitlen);
+            atomicAdd(&h_pack[bin], (1ull << (A.use_lds_hist == 2 ? kHCountShift : kBinCountShift)) + hitlen);
             if (h_first[bin] > rel) atomicMin(&h_first[bin], rel);
-          } else if (A.use_lds_hist == 2 && hitlen < kBinLenLimit) {  // the hashed bins are full: this workgroup's private copy
+          } else if (A.use_lds_hist == 2 && hitlen < kBinLenLimit) {  // no slot within kHashProbe probes (or a very long read): this workgroup's private copy
             const uint32_t rel = (uint32_t)(my_gidx - A.group_base);
             unsigned long long* pp = A.priv_pack + (size_t)blockIdx.x * A.ntax + tax;
             uint32_t* pf = A.priv_first + (size_t)blockIdx.x * A.ntax + tax;
@@ -830,7 +840,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       if (ambig) atomicAdd(&s_ambig, (unsigned long long)ambig);
       if (used_priv && __hip_atomic_load(A.priv_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicExch(A.priv_used, 1u);
       if (tid == 0) s_groups += tile_g;
-      if (A.use_lds_hist && ++tiles_binned == kFlushTiles) {  // before a packed field can overflow
+      if (A.use_lds_hist && ++tiles_binned == (A.use_lds_hist == 2 ? kHashFlushTiles : kFlushTiles)) {  // before a packed field can overflow
         __syncthreads();
         flush_bins(true);
         tiles_binned = 0;
@@ -1046,11 +1056,11 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
-  a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 4096 ? 1u : 2u;
+  a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 4096 ? 1u : p->ntax <= kHashMaxTax ? 2u : 0u;
   if (a.use_lds_hist == 1 && getenv("MG_DEBUG_K3_HASHED")) a.use_lds_hist = 2;  // tests: the hashed bins on a small taxonomy
   const size_t lds = a.use_lds_hist == 0 ? 0
                    : a.use_lds_hist == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t))
-                                         : kHashSlots * (sizeof(unsigned long long) + 2 * sizeof(uint32_t));
+                                         : kHashSlots * (sizeof(unsigned long long) + sizeof(uint32_t));
   a.g_count = (unsigned long long*)d_count; a.g_bases = (unsigned long long*)d_bases;
   a.g_first = (unsigned long long*)d_first_seen; a.g_scalars = (unsigned long long*)d_scalars;
   a.mm_offsets = p->mm_offsets.as<uint64_t>(); a.mm_tax = p->mm_tax.as<uint32_t>();
