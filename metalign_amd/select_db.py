@@ -588,7 +588,7 @@ def run_cmash_and_cutoff(args, taxid2info):
     return chosen
 
 
-def _zcat_into(out, paths, threads=8, batch=64):
+def _zcat_into(out, paths, threads=None, batch=256):
     import zlib
     from concurrent.futures import ThreadPoolExecutor
 
@@ -598,6 +598,8 @@ def _zcat_into(out, paths, threads=8, batch=64):
         except (OSError, zlib.error) as e:
             sys.stderr.write('zcat: %s: %s\n' % (path, e))
             return b''
+    if threads is None:  # (500 genomes of 50 kb took 0.04-0.06 s of a 0.17 s select_main on eight threads)
+        threads = max(1, min(32, os.cpu_count() or 4))
     with ThreadPoolExecutor(threads) as ex:  # (zlib releases the GIL; a batch bounds what is held in memory)
         for i in range(0, len(paths), batch):
             for blob in ex.map(one, paths[i:i + batch]):
