@@ -22,26 +22,6 @@ namespace mg {
 
 // One k of a stage-B call (every k of a pass goes through ONE launch of each kernel: at 10k genomes a launch is 5-50 us
 // of mostly latency, and a pass had nine of them).
-// The XCD this wavefront runs on (0..7).  Stage B's counters and prefix bitmaps are replicated PER XCD and updated with atomics
-// that are resolved in that XCD's L2 (workgroup-scope encoding: no sc1) instead of device-scope ones, which this multi-XCD part
-// resolves at the memory side at ~14 G/s for the whole chip: a matched pair costs one counter add and, in the reference pipeline,
-// up to four bit sets, and at 200k genomes 5 x 10^7 such atomics were 3.6 of a pass's 17 ms.  Every access to a copy comes from
-// the XCD whose id indexes it — read from the hardware register, not inferred from blockIdx — so the L2 is the one place the
-// copy lives while the kernel runs; the kernel's end writes it back and a later kernel combines the copies.
-__device__ __forceinline__ uint32_t xcc_id() {
-  uint32_t v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 7u;
-}
-constexpr uint32_t kXcds = 8;
-__device__ __forceinline__ void l2_add(uint32_t* p) { (void)__hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void l2_or(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// the counter copy of this workgroup: its XCD's group of `copies / 8` copies, spread over them by workgroup
-__device__ __forceinline__ uint32_t my_copy(uint32_t copies) {
-  const uint32_t sub = copies / kXcds;
-  return xcc_id() * sub + ((blockIdx.x / kXcds) & (sub - 1));
-}
-
 constexpr int kMaxSmallK = 3;  // k below the largest in a reference-pipeline table (mg_refdb)
 struct ContainK {
   // the read sketch and its bucket index
@@ -69,8 +49,7 @@ struct ContainK {
   int nsmall;
   const uint32_t* pa[kMaxSmallK];
   const uint32_t* pb[kMaxSmallK];
-  uint32_t* marks[kMaxSmallK];  // this k's bitmap inside copy 0; the XCDs' copies lie marks_stride words apart
-  uint64_t marks_stride;
+  uint32_t* marks[kMaxSmallK];
 };
 constexpr int kMaxContainK = 4;
 struct ContainArgs {
@@ -116,12 +95,11 @@ constexpr uint32_t kCCap = 2048;        // read-sketch entries staged in LDS per
 // sketches only) counts every pair.  npairs = pairs with hash <= the sketch's completeness bound.
 // A matched pair of a reference-pipeline table marks, for every k below the largest, the k-prefix of its k-mer and of the reverse
 // complement (the streaming query tries both strands, scripts/select_db.py:73-76).
-__device__ __forceinline__ void mark_pair(const ContainK& K, uint64_t i, uint64_t xcd_off) {
+__device__ __forceinline__ void mark_pair(const ContainK& K, uint64_t i) {
   for (int s = 0; s < K.nsmall; ++s) {
     const uint32_t x = K.pa[s][i], y = K.pb[s][i];
-    uint32_t* const m = K.marks[s] + xcd_off;
-    l2_or(&m[x >> 5], 1u << (x & 31u));
-    if (y != 0xffffffffu) l2_or(&m[y >> 5], 1u << (y & 31u));
+    atomicOr(&K.marks[s][x >> 5], 1u << (x & 31u));
+    if (y != 0xffffffffu) atomicOr(&K.marks[s][y >> 5], 1u << (y & 31u));
   }
 }
 
@@ -150,10 +128,8 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
     const uint64_t q_last = K.meta ? K.meta[2] : K.q_last;
     // counters are replicated (copy = workgroup id modulo the number of copies, see mg_containment_dev): a few
     // abundant genomes collect most hits, and atomics on one address retire one at a time
-    const uint32_t cp = my_copy(a.copies);
-    uint32_t* const hits = K.hits_part + (uint64_t)cp * K.ngenomes;
-    uint32_t* const sizes = K.sizes_part ? K.sizes_part + (uint64_t)cp * K.ngenomes : nullptr;
-    const uint64_t xcd_off = MARK ? (uint64_t)xcc_id() * K.marks_stride : 0;
+    uint32_t* const hits = K.hits_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes;
+    uint32_t* const sizes = K.sizes_part ? K.sizes_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes : nullptr;
     const uint64_t tile = gtile - K.tile0;
     const uint64_t t0 = tile * kCTile;
     const uint64_t t1 = t0 + kCTile < npairs ? t0 + kCTile : npairs;
@@ -213,7 +189,7 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
     if (sizes) {
 #pragma unroll
       for (int j = 0; j < kPer; ++j)
-        if (h[j] != ~0ull) l2_add(&sizes[g[j]]);
+        if (h[j] != ~0ull) atomicAdd(&sizes[g[j]], 1u);
     }
     if (len && staged) {
       // Eight lower bounds in lock step over the LDS run, padded with +inf up to a power of two so that a probe
@@ -231,8 +207,8 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {  // p <= len; s_q[len] is padding, and an inactive slot (h = +inf) stops there
         if (s_q[p[j]] == h[j] && h[j] != ~0ull && s_c[p[j]] >= ci) {
-          l2_add(&hits[g[j]]);
-          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT, xcd_off);
+          atomicAdd(&hits[g[j]], 1u);
+          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT);
         }
       }
     } else if (len) {
@@ -253,8 +229,8 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
           if (q[mid] < h[j]) x = mid + 1; else y = mid;
         }
         if (x < b[j] && q[x] == h[j] && qc[x] >= ci) {
-          l2_add(&hits[g[j]]);
-          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT, xcd_off);
+          atomicAdd(&hits[g[j]], 1u);
+          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT);
         }
       }
     }
@@ -327,7 +303,7 @@ __global__ __launch_bounds__(kCT) void k_refpipe_count(const CountArgs a) {
     const uint32_t* __restrict__ cid = K.cid;
     const uint32_t* __restrict__ cgen = K.cgen;
     const uint32_t* __restrict__ marks = K.marks;
-    uint32_t* const hits = K.hits_part + (uint64_t)my_copy(a.copies) * K.ngenomes;
+    uint32_t* const hits = K.hits_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes;
     const uint64_t t0 = (gtile - K.tile0) * kCTile;
     uint32_t p[kPer], g[kPer];
 #pragma unroll
@@ -341,20 +317,7 @@ __global__ __launch_bounds__(kCT) void k_refpipe_count(const CountArgs a) {
     for (int j = 0; j < kPer; ++j) w[j] = p[j] != 0xffffffffu ? marks[p[j] >> 5] : 0u;
 #pragma unroll
     for (int j = 0; j < kPer; ++j)
-      if ((w[j] >> (p[j] & 31u)) & 1u) l2_add(&hits[g[j]]);
-  }
-}
-
-// marks[0 .. words) |= the other XCDs' copies (each `words` words further on): what the count lists — or a multi-GPU job's
-// exchange — read.
-__global__ void k_marks_or(uint32_t* __restrict__ marks, uint64_t words) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < words; i += stride) {
-    uint32_t v = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < kXcds; ++c) v |= marks[(uint64_t)c * words + i];
-    marks[i] = v;
+      if ((w[j] >> (p[j] & 31u)) & 1u) atomicAdd(&hits[g[j]], 1u);
   }
 }
 
@@ -595,8 +558,7 @@ static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* c
   if (m == 0) return MG_OK;
   a.nk = m;
   // counter copies: enough to spread a skewed sample's hits, few enough to zero and sum in microseconds
-  // (one group per XCD, my_copy: at least eight)
-  uint32_t copies = kXcds;
+  uint32_t copies = 1;
   while (copies < 64 && (uint64_t)copies * 2 * gmax <= 65536) copies *= 2;
   a.copies = copies;
   for (int i = 0; i < m; ++i) part_total += (pend[i].count_sizes ? 2 : 1) * (uint64_t)copies * pend[i].db->ngenomes;
@@ -651,11 +613,10 @@ static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* c
         K.pb[s] = rp->small[s].pb.as<uint32_t>();
         K.marks[s] = rp->marks.as<uint32_t>() + rp->small[s].marks_at;
       }
-      K.marks_stride = rp->marks_words;
     }
   }
   a.ntiles = tiles;
-  if (rp) { a.zero2 = rp->marks.as<uint32_t>(); a.nzero2 = rp->marks_words * kXcds; }
+  if (rp) { a.zero2 = rp->marks.as<uint32_t>(); a.nzero2 = rp->marks_words; }
   {
     ProfScope ps("contain_index");
     const uint64_t work = index_work > part_total ? index_work : part_total;
@@ -670,9 +631,6 @@ static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* c
       hipLaunchKernelGGL(k_contain_pairs<false>, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 6)), dim3(kCT), 0, st, a);
   }
   hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(reduce_work, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, a);
-  if (rp && rp->marks_words)  // the XCDs' bitmap copies into the first one
-    hipLaunchKernelGGL(k_marks_or, dim3(grid_for(rp->marks_words, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, rp->marks.as<uint32_t>(),
-                       rp->marks_words);
   MG_HIP(hipGetLastError());
   return MG_OK;
 }
@@ -687,7 +645,7 @@ static int refpipe_count_launch(const mg_refdb* rp, const uint32_t* const* d_mar
   CountArgs a{};
   a.nk = m;
   const uint64_t G = rp->kmax.ngenomes;
-  uint32_t copies = kXcds;
+  uint32_t copies = 1;
   while (copies < 64 && (uint64_t)copies * 2 * G <= 65536) copies *= 2;
   a.copies = copies;
   uint32_t* d_part = (uint32_t*)scratch("refpipe_part", (uint64_t)m * copies * G * sizeof(uint32_t));

@@ -173,9 +173,8 @@ int alloc_marks(mg_refdb* db) {
     words += db->small[s].marks_n;
   }
   db->marks_words = words;
-  // (eight copies, one per XCD: a mark call sets bits in the copy of the XCD it runs on and ORs them into the first, mg_contain.hip)
-  MG_TRY(db->marks.alloc((8 * words + 1) * sizeof(uint32_t)));
-  MG_HIP(hipMemsetAsync(db->marks.p, 0, (8 * words + 1) * sizeof(uint32_t), ctx().stream));
+  MG_TRY(db->marks.alloc((words + 1) * sizeof(uint32_t)));
+  MG_HIP(hipMemsetAsync(db->marks.p, 0, (words + 1) * sizeof(uint32_t), ctx().stream));
   return MG_OK;
 }
 
