@@ -95,11 +95,27 @@ constexpr uint32_t kCCap = 2048;        // read-sketch entries staged in LDS per
 // sketches only) counts every pair.  npairs = pairs with hash <= the sketch's completeness bound.
 // A matched pair of a reference-pipeline table marks, for every k below the largest, the k-prefix of its k-mer and of the reverse
 // complement (the streaming query tries both strands, scripts/select_db.py:73-76).
-__device__ __forceinline__ void mark_pair(const ContainK& K, uint64_t i) {
+// (all of a thread's matched pairs at once, per k: their prefix numbers are requested together, then the bits are set — pair
+// by pair inside the search's branches it was a chain of load -> wait -> atomic per pair and k, and the tile waited for the
+// thread with the most matches: 131 us per 10M pairs against 41 for the same kernel without the marks)
+template <int N>
+__device__ __forceinline__ void mark_pairs(const ContainK& K, uint64_t i0, uint32_t stride, uint32_t matched) {
+  if (!matched) return;
   for (int s = 0; s < K.nsmall; ++s) {
-    const uint32_t x = K.pa[s][i], y = K.pb[s][i];
-    atomicOr(&K.marks[s][x >> 5], 1u << (x & 31u));
-    if (y != 0xffffffffu) atomicOr(&K.marks[s][y >> 5], 1u << (y & 31u));
+    const uint32_t* __restrict__ pa = K.pa[s];
+    const uint32_t* __restrict__ pb = K.pb[s];
+    uint32_t* __restrict__ marks = K.marks[s];
+    uint32_t x[N], y[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      x[j] = y[j] = 0xffffffffu;
+      if ((matched >> j) & 1u) { const uint64_t i = i0 + (uint64_t)j * stride; x[j] = pa[i]; y[j] = pb[i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (x[j] != 0xffffffffu) atomicOr(&marks[x[j] >> 5], 1u << (x[j] & 31u));
+      if (y[j] != 0xffffffffu) atomicOr(&marks[y[j] >> 5], 1u << (y[j] & 31u));
+    }
   }
 }
 
@@ -204,13 +220,15 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
           p[j] = s_q[t - 1] < h[j] ? t : p[j];
         }
       }
+      uint32_t matched = 0;
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {  // p <= len; s_q[len] is padding, and an inactive slot (h = +inf) stops there
         if (s_q[p[j]] == h[j] && h[j] != ~0ull && s_c[p[j]] >= ci) {
           atomicAdd(&hits[g[j]], 1u);
-          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT);
+          matched |= 1u << j;
         }
       }
+      if constexpr (MARK) mark_pairs<kPer>(K, t0 + tid, kCT, matched);
     } else if (len) {
       // A run longer than the LDS stage: either the read sketch is locally much denser than the table (the top of
       // the hash range, where few genome sketches reach) or simply huge.  Every pair goes through the bucket index
@@ -221,6 +239,7 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
         a[j] = b[j] = 0;
         if (h[j] <= q_last) { const uint64_t bk = h[j] >> shift; a[j] = idx[bk]; b[j] = idx[bk + 1]; }
       }
+      uint32_t matched = 0;
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
         uint32_t x = a[j], y = b[j];
@@ -230,9 +249,10 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
         }
         if (x < b[j] && q[x] == h[j] && qc[x] >= ci) {
           atomicAdd(&hits[g[j]], 1u);
-          if constexpr (MARK) mark_pair(K, t0 + tid + (uint64_t)j * kCT);
+          matched |= 1u << j;
         }
       }
+      if constexpr (MARK) mark_pairs<kPer>(K, t0 + tid, kCT, matched);
     }
     __syncthreads();
   }
@@ -374,7 +394,10 @@ __global__ void k_upper_bound_one(const uint64_t* __restrict__ uniq, uint64_t n,
   *out = lo;
 }
 
-// zero / nzero: a buffer to clear in the same launch; *zeroed tells whether that happened.
+// Counts the containment calls: the counter copies one of them zeroed for the count step that follows it are good only
+// until the next call takes the same scratch buffer.
+static uint64_t g_contain_gen = 0;
+
 // Sizes and allocates the sketch's bucket index if it has none; *build = the index kernel of this call must fill it.
 static int plan_index(mg_sketch* sk, bool* build) {
   *build = false;
@@ -562,10 +585,14 @@ static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* c
   while (copies < 64 && (uint64_t)copies * 2 * gmax <= 65536) copies *= 2;
   a.copies = copies;
   for (int i = 0; i < m; ++i) part_total += (pend[i].count_sizes ? 2 : 1) * (uint64_t)copies * pend[i].db->ngenomes;
-  uint32_t* d_part = (uint32_t*)scratch("contain_part", part_total * sizeof(uint32_t));
+  // (the reference pipeline: the count step's counter copies ride in the same buffer and are zeroed by the same launch)
+  const uint64_t count_total = rp ? (uint64_t)(rp->nk - 1) * copies * rp->kmax.ngenomes : 0;
+  uint32_t* d_part = (uint32_t*)scratch("contain_part", (part_total + count_total) * sizeof(uint32_t));
   if (!d_part) return MG_ERR_NOMEM;
   a.zero = d_part;
-  a.nzero = part_total;
+  a.nzero = part_total + count_total;
+  ++g_contain_gen;
+  if (rp) { rp->count_part = d_part + part_total; rp->count_copies = copies; rp->count_gen = g_contain_gen; }
   uint64_t at = 0, tiles = 0;
   for (int i = 0; i < m; ++i) {
     mg_sketch* sk = pend[i].sk;
@@ -619,7 +646,7 @@ static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* c
   if (rp) { a.zero2 = rp->marks.as<uint32_t>(); a.nzero2 = rp->marks_words; }
   {
     ProfScope ps("contain_index");
-    const uint64_t work = index_work > part_total ? index_work : part_total;
+    const uint64_t work = index_work > a.nzero ? index_work : a.nzero;
     hipLaunchKernelGGL(k_build_index, dim3(grid_for(work ? work : 1, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, a);
     MG_HIP(hipGetLastError());
   }
@@ -648,8 +675,11 @@ static int refpipe_count_launch(const mg_refdb* rp, const uint32_t* const* d_mar
   uint32_t copies = 1;
   while (copies < 64 && (uint64_t)copies * 2 * G <= 65536) copies *= 2;
   a.copies = copies;
-  uint32_t* d_part = (uint32_t*)scratch("refpipe_part", (uint64_t)m * copies * G * sizeof(uint32_t));
+  // zeroed by the mark call that came before (same copies: same G), else here
+  const bool prezeroed = rp->count_part != nullptr && rp->count_copies == copies && rp->count_gen == g_contain_gen;
+  uint32_t* d_part = prezeroed ? rp->count_part : (uint32_t*)scratch("refpipe_part", (uint64_t)m * copies * G * sizeof(uint32_t));
   if (!d_part) return MG_ERR_NOMEM;
+  rp->count_part = nullptr;  // (used up: a second count without a mark in between zeroes for itself)
   uint64_t tiles = 0;
   for (int s = 0; s < m; ++s) {
     CountK& K = a.k[s];
@@ -667,8 +697,9 @@ static int refpipe_count_launch(const mg_refdb* rp, const uint32_t* const* d_mar
   }
   a.ntiles = tiles;
   ProfScope ps("refpipe_count");
-  hipLaunchKernelGGL(k_zero_u32, dim3(grid_for((uint64_t)m * copies * G, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_part,
-                     (uint64_t)m * copies * G);
+  if (!prezeroed)
+    hipLaunchKernelGGL(k_zero_u32, dim3(grid_for((uint64_t)m * copies * G, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_part,
+                       (uint64_t)m * copies * G);
   if (tiles) hipLaunchKernelGGL(k_refpipe_count, dim3(grid_for(tiles, 1, (unsigned)c.num_cus * 8)), dim3(kCT), 0, st, a);
   hipLaunchKernelGGL(k_refpipe_reduce, dim3(grid_for(G, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, a);
   MG_HIP(hipGetLastError());

@@ -340,4 +340,8 @@ struct mg_refdb {
   } small[3];
   mg::DevBuf marks;         // the prefix bitmaps of all smaller k, back to back (zeroed and written by a mark call)
   uint64_t marks_words = 0;
+  // the count step's counter copies, zeroed by the mark call that precedes it (one launch less per pass)
+  mutable uint32_t* count_part = nullptr;
+  mutable uint32_t count_copies = 0;
+  mutable uint64_t count_gen = 0;  // the containment call that zeroed them (any later one reuses the buffer)
 };
