@@ -446,7 +446,7 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 // seen: one LDS atomic per unique read (the minimum is only attempted when a plain read says it would change
 // something — after a workgroup's first tile it almost never does).  Three atomics per read on a few dozen hot bins
 // had been 2/3 of the commit pass: LDS atomics to one address serialise, and every workgroup of the CU shares the
-// pipeline.  Reads of 2^20 bases or more bypass the bins, so that kFlushTiles tiles cannot overflow a field.
+// pipeline.  Reads of 2^14 bases or more bypass the bins (kQueueLenLimit), so that kFlushTiles tiles cannot overflow a field.
 // kHashProbe slots (double hashing over the packed words) are looked at before the private bins take a record.  Measured in round 4
 // on bench.py's configs[2] records (12.5M, 10 001 taxa, ~1000 of them hit uniquely: the sample's 500 genomes and — through reads
 // whose first line was dropped — their sibling accessions): 0.46 ms with the bins hashed against 0.30 ms with direct bins on the
@@ -456,14 +456,40 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 // the records (a workgroup then lives for 32 tiles instead of 8, so claiming the keys is amortised) still pay 0.09 ms per 12.5M
 // records over direct bins.  What the look-up adds is ONE dependent LDS read in front of the atomic and a loop over probes that
 // ends when the slowest lane of the wavefront has found its slot; open.
+// The commit walk queues a uniquely mapped read as ONE 32-bit word (taxon << 14 | bases) in the LDS the look-back used, kItems
+// words per thread; reads of 2^14 bases or more go to the global bins at once.
+constexpr int kQueueLenBits = 14;
+constexpr uint32_t kQueueLenLimit = 1u << kQueueLenBits;
+static_assert(kItems <= 32 && kPB * kItems * sizeof(uint32_t) <= sizeof(u32x4) * kWinTiles * 2, "the queue lives in one look-back window");
 constexpr uint32_t kHashSlots = 2048, kHashProbe = 8, kFlushTiles = 256;
+// ... 8 probes once the table is crowded (more than kHashCrowded keys claimed since the last flush: a sample with more taxa than
+// slots must not walk 64 of them per read), 64 while it is not: at configs[2]'s ~1000 taxa in 2048 slots 8 probes failed for a
+// handful of taxa per workgroup, every workgroup then had used its private copy, and the reduction over ~90 MB of copies that
+// followed was 0.05 of the pass's 0.46 ms.
+constexpr uint32_t kHashProbeFree = 64, kHashCrowded = kHashSlots * 3 / 4;
 // The hashed form's bin (round 4): taxon + 1 (18 bits) | count (15) | bases (31) in ONE 64-bit word, so that a slot is 12 bytes
 // (word + first read seen) and 2048 of them fit beside three workgroups per CU; 0 = empty.  The fields hold kHashFlushTiles tiles
-// (8 x 2048 reads of < 2^17 bases each; longer reads bypass the bins), then the bins are flushed — and their keys with them.
+// (15 x 2048 reads of < 2^14 bases each; longer reads bypass the bins), then the bins are flushed — and their keys with them.
 constexpr int kHKeyShift = 46, kHCountShift = 31;
-constexpr uint32_t kHashFlushTiles = 8, kHashMaxTax = (1u << 18) - 2, kHashLenLimit = 1u << 17;
-constexpr uint32_t kBinLenLimit = 1u << 20;
+constexpr uint32_t kHashFlushTiles = 15, kHashMaxTax = (1u << 18) - 2;
+static_assert((uint64_t)kHashFlushTiles * kTile < (1u << 15) && (uint64_t)kHashFlushTiles * kTile * kQueueLenLimit < (1ull << 31), "hashed bin fields");
+static_assert(kHashMaxTax < (1u << (32 - kQueueLenBits)), "taxon field of a queue word");
 constexpr int kBinCountShift = 40;
+
+// The XCD this wavefront runs on (0..7), from the hardware register.  Atomics without device scope are resolved in that XCD's L2;
+// every access to an XCD's copy comes from workgroups of that XCD, the kernel's end writes it back, a later kernel sums the copies.
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7u;
+}
+constexpr uint32_t kXcds = 8;
+__device__ __forceinline__ void l2_add64(unsigned long long* p, unsigned long long v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void l2_min64(unsigned long long* p, unsigned long long v) {
+  (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 struct PassArgs {
   const mg_aln_rec* recs;
@@ -480,7 +506,10 @@ struct PassArgs {
   unsigned long long *g_count, *g_bases, *g_first, *g_scalars;
   unsigned long long* priv_pack;  // hashed mode: [gridDim.x][ntax] packed bins (count << 40 | bases), all zero between passes ...
   uint32_t* priv_first;           // ... first-seen words (0xffffffff between passes) ...
-  uint32_t* priv_used;            // ... and one flag: some workgroup used its private bins in this pass
+  unsigned long long* xcd_bins;   // hashed mode: [8 XCDs][count | bases | first seen][ntax], (0, 0, all-ones) between passes
+  unsigned long long* dump_pack;  // hashed mode: [gridDim.x][kHashSlots] every workgroup's LDS bins as they are at its end ...
+  uint32_t* dump_first;           // ... summed slot by slot by k_bins_reduce
+  uint32_t* priv_used;            // ... and the flags: [0] some workgroup used its private bins in this pass, [1 + w] workgroup w did
   uint64_t* mm_offsets; uint32_t* mm_tax; uint64_t* mm_hitlen; uint64_t* mm_read;
   uint64_t* out_tot;              // [0] composed map, [1] reads, [2] multimapped entries, [3] multimapped reads
 };
@@ -488,16 +517,16 @@ struct PassArgs {
 // Phase timing (make K3_PHASES=1; tools/k3_phases.py): thread 0's shader-clock time between the phase boundaries
 // of every tile, summed per kernel variant.  Compiled out of the normal build.
 #ifdef MG_K3_PHASES
-__device__ unsigned long long g_ph[16];
+__device__ unsigned long long g_ph[24];
 extern "C" int mg_debug_k3_phases(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ph), sizeof(g_ph)) != hipSuccess) return MG_ERR_HIP;
-  unsigned long long z[16] = {0};
+  unsigned long long z[24] = {0};
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ph), z, sizeof(z)) != hipSuccess) return MG_ERR_HIP;
   return MG_OK;
 }
-#define PH_DECL __shared__ unsigned long long s_ph[8]; unsigned long long tprev = clock64(); if (threadIdx.x < 8) s_ph[threadIdx.x] = 0
+#define PH_DECL __shared__ unsigned long long s_ph[12]; unsigned long long tprev = clock64(); if (threadIdx.x < 12) s_ph[threadIdx.x] = 0
 #define PH(i) do { if (tid == 0) { const unsigned long long now_ = clock64(); s_ph[i] += now_ - tprev; tprev = now_; } } while (0)
-#define PH_FLUSH(c) do { if (tid == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ph[i_ + ((c) ? 8 : 0)], s_ph[i_]); } while (0)
+#define PH_FLUSH(c) do { if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_ph[i_ + ((c) ? 12 : 0)], s_ph[i_]); } while (0)
 #else
 #define PH_DECL
 #define PH(i)
@@ -515,6 +544,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
   __shared__ uint32_t s_lbf[kLbWaves + 1];
   __shared__ unsigned long long s_ticket;
   __shared__ unsigned long long s_ambig, s_groups;
+  __shared__ uint32_t s_nkeys;  // hashed bins: slots claimed since the last flush
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nbins = A.use_lds_hist == 2 ? kHashSlots : A.ntax;
   unsigned long long* h_pack = hist;                                     // direct: count << 40 | bases; hashed: taxon + 1 | count | bases
@@ -527,7 +557,15 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         const uint32_t tax = hashed ? (uint32_t)(pk >> kHKeyShift) - 1u : t;
         const unsigned long long cnt = hashed ? (pk >> kHCountShift) & 0x7fffull : pk >> kBinCountShift;
         const unsigned long long bas = hashed ? pk & ((1ull << kHCountShift) - 1) : pk & ((1ull << kBinCountShift) - 1);
-        if (cnt) {  // (a hashed slot may be claimed and not yet counted in)
+        if (cnt && hashed) {  // (a hashed slot may be claimed and not yet counted in)
+          // Slots hold taxa in hash order: a wavefront's flush touches 64 different cache lines per instruction where the direct
+          // bins' touches four, and ~3000 device-scope atomics from each of 768 workgroups, all at the end of the pass, were
+          // 0.08 of its 0.43 ms (phase clocks, profiles/r04).  They go to THIS XCD's copy of the accumulators, resolved in its L2.
+          unsigned long long* x = A.xcd_bins + (size_t)xcc_id() * 3 * A.ntax;
+          l2_add64(x + tax, cnt);
+          l2_add64(x + A.ntax + tax, bas);
+          l2_min64(x + 2 * (size_t)A.ntax + tax, (unsigned long long)(A.group_base + h_first[t]));
+        } else if (cnt) {
           atomicAdd(&A.g_count[tax], cnt);
           atomicAdd(&A.g_bases[tax], bas);
           atomicMin(&A.g_first[tax], (unsigned long long)(A.group_base + h_first[t]));
@@ -535,6 +573,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         if (reset) { h_pack[t] = 0; h_first[t] = 0xffffffffu; }
       }
     }
+    if (reset && tid == 0) s_nkeys = 0;
   };
   uint32_t tiles_binned = 0;
   if (COMMIT && A.use_lds_hist) {
@@ -542,8 +581,9 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       h_pack[t] = 0; h_first[t] = 0xffffffffu;
     }
   }
-  if (tid == 0) { s_ambig = 0; s_groups = 0; }
+  if (tid == 0) { s_ambig = 0; s_groups = 0; s_nkeys = 0; }
   __syncthreads();
+  PH(10);
 
   for (;;) {
     // Tiles are handed out in order, by kTicketLanes interleaved counters (tile = ticket * lanes + lane, a workgroup
@@ -721,6 +761,9 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
       uint64_t eo = s_bcast[3] + pk_ent(ex);
       uint64_t so = s_bcast[2] + pk_mm(ex);
       uint64_t gidx = A.group_base + s_bcast[1] + pk_reads(ex);
+      const uint64_t gidx0 = gidx;      // the thread opens at most kItems reads: gidx0 .. gidx0 + 7
+      uint32_t qn = 0, qmask = 0;       // its queue of uniquely mapped reads (s_queue[tid + kPB * i]) and which reads those are
+      uint32_t* const s_queue = reinterpret_cast<uint32_t*>(&s_lbuf[0][0]);  // (the look-back of this tile is over)
       uint32_t ambig = (tid == 0 && tile == 0 && A.first_shard) ? 1u : 0u;  // the phantom first boundary (:155-156)
       bool used_priv = false;
       // the same linear walk with the TRUE state: a read's counters run along from the line that opens it (without that
@@ -752,40 +795,11 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         if (kind == 0) {
           ++ambig;
         } else if (kind == 1) {
-          uint32_t bin = tax;
-          bool in_lds = A.use_lds_hist == 1;
-          if (A.use_lds_hist == 2) {
-            // Open addressing with double hashing over the packed words, at most kHashProbe probes: the usual case is ONE 8-byte
-            // LDS read and a compare of its key field.  Between two flushes a key never changes once set and a taxon always
-            // walks the same slots in the same order, so it cannot sit in two of them; two lanes that race for an empty slot are
-            // settled by the compare-and-swap (the loser of another taxon goes on to its next slot).
-            static_assert(kHashSlots == 2048, "slot index width");
-            const uint32_t hh = tax * 2654435761u;
-            uint32_t sl = hh >> 21;                              // 11 bits
-            const uint32_t stride = ((hh >> 10) & 2046u) | 1u;   // odd: every slot is reached
-            const unsigned long long mine = (unsigned long long)(tax + 1u) << kHKeyShift;
-            for (uint32_t step = 0; step < kHashProbe && !in_lds; ++step) {
-              unsigned long long w = h_pack[sl];
-              if (w == 0ull) {
-                const unsigned long long old = atomicCAS(&h_pack[sl], 0ull, mine);
-                w = old == 0ull ? mine : old;
-              }
-              if ((w >> kHKeyShift) == (unsigned long long)(tax + 1u)) { bin = sl; in_lds = true; }
-              sl = (sl + stride) & (kHashSlots - 1);
-            }
-          }
-          const uint32_t len_limit = A.use_lds_hist == 2 ? kHashLenLimit : kBinLenLimit;
-          if (in_lds && hitlen < len_limit) {
-            const uint32_t rel = (uint32_t)(my_gidx - A.group_base);
-            atomicAdd(&h_pack[bin], (1ull << (A.use_lds_hist == 2 ? kHCountShift : kBinCountShift)) + hitlen);
-            if (h_first[bin] > rel) atomicMin(&h_first[bin], rel);
-          } else if (A.use_lds_hist == 2 && hitlen < kBinLenLimit) {  // no slot within kHashProbe probes (or a very long read): this workgroup's private copy
-            const uint32_t rel = (uint32_t)(my_gidx - A.group_base);
-            unsigned long long* pp = A.priv_pack + (size_t)blockIdx.x * A.ntax + tax;
-            uint32_t* pf = A.priv_first + (size_t)blockIdx.x * A.ntax + tax;
-            __hip_atomic_fetch_add(pp, (1ull << kBinCountShift) + hitlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (*pf > rel) __hip_atomic_fetch_min(pf, rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            used_priv = true;
+          if (A.use_lds_hist && hitlen < kQueueLenLimit) {
+            // binned after the walk, every lane of the wavefront together (below): here only the lanes whose read closes on
+            // THIS line are active, and the bin look-up + atomics were paid once per line of the walk
+            s_queue[tid + kPB * qn++] = (tax << kQueueLenBits) | (uint32_t)hitlen;
+            qmask |= 1u << (uint32_t)(my_gidx - gidx0);
           } else {
             atomicAdd(&A.g_count[tax], 1ull);
             atomicAdd(&A.g_bases[tax], (unsigned long long)hitlen);
@@ -837,8 +851,55 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         while (ge < A.ntotal && !(A.recs[ge].ref_new & MG_REC_NEW_BIT)) ++ge;
         if (ge < A.ntotal) commit_read(false, e, at(ge).y & (D_P1 | D_P2), ge);  // (else: never processed)
       }
+      PH(8);
+      // the thread's uniquely mapped reads into the bins: entry i belongs to the read of the i-th set bit of qmask
+      const uint32_t max_probe = A.use_lds_hist == 2 && s_nkeys <= kHashCrowded ? kHashProbeFree : kHashProbe;
+      for (uint32_t qi = 0; qmask; ++qi) {
+        const uint32_t ord = (uint32_t)__builtin_ctz(qmask);
+        qmask &= qmask - 1u;
+        const uint32_t ent = s_queue[tid + kPB * qi];
+        const uint32_t tax = ent >> kQueueLenBits, hitlen = ent & (kQueueLenLimit - 1u);
+        const uint32_t rel = (uint32_t)(gidx0 + ord - A.group_base);
+        uint32_t bin = tax;
+        bool in_lds = A.use_lds_hist == 1;
+        if (A.use_lds_hist == 2) {
+          // Open addressing with double hashing over the packed words, at most kHashProbe probes: the usual case is ONE 8-byte
+          // LDS read and a compare of its key field.  Between two flushes a key never changes once set and a taxon always
+          // walks the same slots in the same order, so it cannot sit in two of them; two lanes that race for an empty slot are
+          // settled by the compare-and-swap (the loser of another taxon goes on to its next slot).
+          static_assert(kHashSlots == 2048, "slot index width");
+          const uint32_t hh = tax * 2654435761u;
+          uint32_t sl = hh >> 21;                              // 11 bits
+          const uint32_t stride = ((hh >> 10) & 2046u) | 1u;   // odd: every slot is reached
+          const unsigned long long mine = (unsigned long long)(tax + 1u) << kHKeyShift;
+          for (uint32_t step = 0; step < max_probe && !in_lds; ++step) {
+            unsigned long long w = h_pack[sl];
+            if (w == 0ull) {
+              const unsigned long long old = atomicCAS(&h_pack[sl], 0ull, mine);
+              w = old == 0ull ? mine : old;
+              if (old == 0ull) atomicAdd(&s_nkeys, 1u);
+            }
+            if ((w >> kHKeyShift) == (unsigned long long)(tax + 1u)) { bin = sl; in_lds = true; }
+            sl = (sl + stride) & (kHashSlots - 1);
+          }
+        }
+        if (in_lds) {
+          atomicAdd(&h_pack[bin], (1ull << (A.use_lds_hist == 2 ? kHCountShift : kBinCountShift)) + hitlen);
+          if (h_first[bin] > rel) atomicMin(&h_first[bin], rel);
+        } else {  // no slot within kHashProbe probes: this workgroup's private copy
+          unsigned long long* pp = A.priv_pack + (size_t)blockIdx.x * A.ntax + tax;
+          uint32_t* pf = A.priv_first + (size_t)blockIdx.x * A.ntax + tax;
+          __hip_atomic_fetch_add(pp, (1ull << kBinCountShift) + hitlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (*pf > rel) __hip_atomic_fetch_min(pf, rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          used_priv = true;
+        }
+      }
+      PH(9);
       if (ambig) atomicAdd(&s_ambig, (unsigned long long)ambig);
-      if (used_priv && __hip_atomic_load(A.priv_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicExch(A.priv_used, 1u);
+      if (used_priv) {
+        A.priv_used[1 + blockIdx.x] = 1u;
+        if (__hip_atomic_load(A.priv_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicExch(A.priv_used, 1u);
+      }
       if (tid == 0) s_groups += tile_g;
       if (A.use_lds_hist && ++tiles_binned == (A.use_lds_hist == 2 ? kHashFlushTiles : kFlushTiles)) {  // before a packed field can overflow
         __syncthreads();
@@ -849,15 +910,24 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
     __syncthreads();  // s_desc / s_bcast / s_ticket are reused by the next tile
     PH(6);
   }
-  PH_FLUSH(COMMIT);
   if (COMMIT) {
     __syncthreads();
-    if (A.use_lds_hist) flush_bins(false);
+    if (A.use_lds_hist == 2) {
+      // The last flush is a plain copy of the table: every workgroup hashes alike, so slot s holds the SAME taxon in nearly
+      // all of them and k_bins_reduce adds a slot's 768 words up in registers — three atomics per run of equal keys instead of
+      // three per workgroup and taxon (2.3 M of them, all at the end of the pass: 0.06-0.08 of 0.43 ms by the phase clocks).
+      for (uint32_t t = tid; t < kHashSlots; t += kPB) {
+        A.dump_pack[(size_t)blockIdx.x * kHashSlots + t] = h_pack[t];
+        A.dump_first[(size_t)blockIdx.x * kHashSlots + t] = h_first[t];
+      }
+    } else if (A.use_lds_hist) flush_bins(false);
     if (tid == 0) {
       if (s_groups) atomicAdd(&A.g_scalars[0], s_groups);
       if (s_ambig) atomicAdd(&A.g_scalars[1], s_ambig);
     }
   }
+  PH(11);
+  PH_FLUSH(COMMIT);
 }
 
 // The two instantiations as kernels.  The map-only pass fits 128 VGPRs (4 wavefronts per SIMD: four workgroups
@@ -880,15 +950,68 @@ __global__ __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(MG_K3_COMMI
 // the copies (consecutive threads read consecutive words of a copy) and leaves them zeroed for the next pass.  Nothing
 // to do (and nothing read) when no workgroup overflowed its LDS bins.
 __global__ __launch_bounds__(256) void k_bins_reduce(unsigned long long* __restrict__ priv_pack, uint32_t* __restrict__ priv_first,
-                                                     uint32_t* __restrict__ priv_used, uint32_t ncopies, uint32_t ntax,
+                                                     uint32_t* __restrict__ priv_used, unsigned long long* __restrict__ xcd_bins,
+                                                     const unsigned long long* __restrict__ dump_pack, const uint32_t* __restrict__ dump_first,
+                                                     uint32_t ncopies, uint32_t ntax,
                                                      uint64_t group_base, unsigned long long* __restrict__ g_count,
                                                      unsigned long long* __restrict__ g_bases,
                                                      unsigned long long* __restrict__ g_first) {
-  if (*priv_used == 0u) return;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  // blockIdx.y: a slice of the copies (enough blocks to fill the GPU: the copies are ~100 MB at 10 001 taxa)
+  // blockIdx.y: a slice of the workgroups' copies (enough blocks to fill the GPU: the private copies are ~100 MB at 10 001 taxa)
   const uint32_t per = (ncopies + gridDim.y - 1) / gridDim.y;
   const uint32_t cbeg = blockIdx.y * per, cend = cbeg + per < ncopies ? cbeg + per : ncopies;
+  if (t < kHashSlots) {  // slot t of the workgroups' last tables: runs of equal keys are summed before they are added
+    unsigned long long cur = 0, cnt = 0, bas = 0;
+    uint32_t first = 0xffffffffu;
+    auto emit = [&]() {
+      if (cnt) {
+        const uint32_t tax = (uint32_t)cur - 1u;
+        atomicAdd(&g_count[tax], cnt);
+        atomicAdd(&g_bases[tax], bas);
+        atomicMin(&g_first[tax], (unsigned long long)(group_base + first));
+      }
+    };
+    for (uint32_t c0 = cbeg; c0 < cend; c0 += 8) {
+      unsigned long long v[8];
+      uint32_t f[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t c = c0 + u;
+        v[u] = c < cend ? dump_pack[(size_t)c * kHashSlots + t] : 0ull;
+        f[u] = c < cend ? dump_first[(size_t)c * kHashSlots + t] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long key = v[u] >> kHKeyShift, n1 = (v[u] >> kHCountShift) & 0x7fffull;
+        if (n1 == 0) continue;  // empty, or claimed and never counted in
+        if (key != cur) { emit(); cur = key; cnt = 0; bas = 0; first = 0xffffffffu; }
+        cnt += n1;
+        bas += v[u] & ((1ull << kHCountShift) - 1);
+        first = f[u] < first ? f[u] : first;
+      }
+    }
+    emit();
+  }
+  if (blockIdx.y == 0 && t < ntax) {  // the XCDs' copies of the accumulators (always: the LDS bins are flushed into them)
+    unsigned long long cnt = 0, bas = 0, first = ~0ull;
+#pragma unroll
+    for (uint32_t x = 0; x < kXcds; ++x) {
+      unsigned long long* b = xcd_bins + (size_t)x * 3 * ntax;
+      const unsigned long long c1 = b[t];
+      if (c1) {
+        cnt += c1; bas += b[ntax + t];
+        const unsigned long long f1 = b[2 * (size_t)ntax + t];
+        first = f1 < first ? f1 : first;
+        b[t] = 0; b[ntax + t] = 0; b[2 * (size_t)ntax + t] = ~0ull;
+      }
+    }
+    if (cnt) {
+      atomicAdd(&g_count[t], cnt);
+      atomicAdd(&g_bases[t], bas);
+      atomicMin(&g_first[t], first);
+    }
+  }
+  if (*priv_used == 0u) return;
   if (t < ntax) {
     unsigned long long cnt = 0, bas = 0;
     uint32_t first = 0xffffffffu;
@@ -898,8 +1021,9 @@ __global__ __launch_bounds__(256) void k_bins_reduce(unsigned long long* __restr
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const uint32_t c = c0 + u;
-        v[u] = c < cend ? priv_pack[(size_t)c * ntax + t] : 0ull;
-        f[u] = c < cend ? priv_first[(size_t)c * ntax + t] : 0xffffffffu;
+        const bool used = c < cend && priv_used[1 + c] != 0u;  // (uniform: most workgroups never leave their LDS bins)
+        v[u] = used ? priv_pack[(size_t)c * ntax + t] : 0ull;
+        f[u] = used ? priv_first[(size_t)c * ntax + t] : 0xffffffffu;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -921,7 +1045,10 @@ __global__ __launch_bounds__(256) void k_bins_reduce(unsigned long long* __restr
   }
 }
 // (its own launch, behind the reduction: every block of k_bins_reduce reads the flag first)
-__global__ void k_bins_done(uint32_t* priv_used) { *priv_used = 0u; }
+__global__ void k_bins_done(uint32_t* priv_used, uint32_t ncopies) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= ncopies) priv_used[i] = 0u;
+}
 
 // Before a pass: tile descriptors + ticket = 0 and, when asked, the accumulators of a fresh batch (one launch).
 __global__ void k_pass_prepare(uint64_t* __restrict__ desc, uint64_t ndesc, uint64_t* __restrict__ count,
@@ -1074,18 +1201,27 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     // the private overflow bins: a grow-only buffer of the library, all-zero (first-seen words all-ones) between passes —
     // zeroed when it is (re)allocated, re-zeroed by k_bins_reduce wherever a pass wrote
     const uint64_t nb = (uint64_t)c.num_cus * 3 * p->ntax;
-    const uint64_t bytes = nb * (sizeof(unsigned long long) + sizeof(uint32_t)) + 64;
+    const uint64_t nflags = (uint64_t)c.num_cus * 3 + 1;
+    const uint64_t nx = (uint64_t)kXcds * 3 * p->ntax;  // the XCDs' accumulator copies
+    const uint64_t nd = (uint64_t)c.num_cus * 3 * kHashSlots;  // the workgroups' last tables (written whole by every pass)
+    const uint64_t bytes = (nb + nx + nd) * sizeof(unsigned long long) + (nb + nd) * sizeof(uint32_t) + nflags * sizeof(uint32_t) + 64;
     void*& priv_ptr = c.k3_priv_ptr;
     uint64_t& priv_nb = c.k3_priv_nb;
     uint8_t* buf = (uint8_t*)scratch("k3_priv_bins", bytes);
     if (!buf) return MG_ERR_NOMEM;
     a.priv_pack = reinterpret_cast<unsigned long long*>(buf);
-    a.priv_first = reinterpret_cast<uint32_t*>(a.priv_pack + nb);
-    a.priv_used = a.priv_first + nb;
+    a.xcd_bins = a.priv_pack + nb;
+    a.dump_pack = a.xcd_bins + nx;
+    a.priv_first = reinterpret_cast<uint32_t*>(a.dump_pack + nd);
+    a.dump_first = a.priv_first + nb;
+    a.priv_used = a.dump_first + nd;
     if (buf != priv_ptr || nb != priv_nb) {  // new block, or a different partition of it: establish the invariant
       MG_HIP(hipMemsetAsync(a.priv_pack, 0, nb * sizeof(unsigned long long), st));
       MG_HIP(hipMemsetAsync(a.priv_first, 0xff, nb * sizeof(uint32_t), st));
-      MG_HIP(hipMemsetAsync(a.priv_used, 0, sizeof(uint32_t), st));
+      MG_HIP(hipMemsetAsync(a.xcd_bins, 0, nx * sizeof(unsigned long long), st));
+      for (uint32_t x = 0; x < kXcds; ++x)
+        MG_HIP(hipMemsetAsync(a.xcd_bins + ((size_t)x * 3 + 2) * p->ntax, 0xff, p->ntax * sizeof(unsigned long long), st));
+      MG_HIP(hipMemsetAsync(a.priv_used, 0, nflags * sizeof(uint32_t), st));
       priv_ptr = buf;
       priv_nb = nb;
     }
@@ -1093,9 +1229,9 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   hipLaunchKernelGGL(k_profile_pass<true>, dim3(grid), dim3(kPB), lds, st, a);
   MG_HIP(hipGetLastError());
   if (a.use_lds_hist == 2) {
-    hipLaunchKernelGGL(k_bins_reduce, dim3((p->ntax + 255) / 256, 32), dim3(256), 0, st, a.priv_pack, a.priv_first, a.priv_used, grid,
+    hipLaunchKernelGGL(k_bins_reduce, dim3(((p->ntax > kHashSlots ? p->ntax : kHashSlots) + 255) / 256, 32), dim3(256), 0, st, a.priv_pack, a.priv_first, a.priv_used, a.xcd_bins, a.dump_pack, a.dump_first, grid,
                        p->ntax, group_base, a.g_count, a.g_bases, a.g_first);
-    hipLaunchKernelGGL(k_bins_done, dim3(1), dim3(1), 0, st, a.priv_used);
+    hipLaunchKernelGGL(k_bins_done, dim3((grid + 256) / 256), dim3(256), 0, st, a.priv_used, grid);
     MG_HIP(hipGetLastError());
   }
   return MG_OK;

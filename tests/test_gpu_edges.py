@@ -42,6 +42,31 @@ def test_one_giant_read_group(hip, oracle_lib):
             assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
 
 
+@pytest.mark.parametrize("hashed", [False, True])
+def test_stage_c_reads_around_the_bin_length_limit(hip, oracle_lib, monkeypatch, hashed):
+    """Uniquely mapped reads of 2^14 bases or more bypass the workgroup's bins (one queue word holds 14 bits of length):
+    lengths either side of the limit and up to the record field's 2^20 - 1, through the direct and the hashed bins."""
+    if hashed:
+        monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
+    rng = np.random.default_rng(7)
+    n = 60000
+    ntax = 37
+    r2t = rng.integers(0, ntax, size=200).astype(np.uint32)
+    recs = np.zeros(n, dtype=oracle_lib.REC_DTYPE)
+    new = rng.random(n) < 0.8
+    new[0] = True
+    recs["ref_new"] = rng.integers(0, 200, size=n).astype(np.uint32) | (new.astype(np.uint32) << 31)
+    lens = rng.choice([150, 16383, 16384, 16385, 500000, (1 << 20) - 1], size=n, p=[0.5, 0.1, 0.1, 0.1, 0.1, 0.1]).astype(np.uint32)
+    recs["total"] = lens
+    recs["matched"] = lens - rng.integers(0, 20, size=n).astype(np.uint32)
+    recs["flag_len"] = rng.choice([0, 16, 256], size=n, p=[0.5, 0.4, 0.1]).astype(np.uint32) | (lens << 12)
+    got = hip.profile_assign(recs, r2t, ntax, 0.5)
+    want = oracle_lib.profile_assign(recs, r2t, ntax, 0.5)
+    assert int(np.asarray(want["count"]).sum()) > n // 3
+    for key in want:
+        assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
+
+
 def test_sketch_degenerate_inputs(hip, oracle_lib):
     cases = {
         "all N": ([b"N" * 200] * 70, 21),

@@ -332,9 +332,9 @@ def test_stage_c_bulk_hip(hip, name, monkeypatch, tmp_path):
 @pytest.mark.parametrize("force_hashed", [False, True])
 def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib, force_hashed, monkeypatch):
     """Random record streams straight into the C ABI: direct LDS bins at three, then two workgroups per CU (37 / 3500
-    taxa) and, beyond 4096 taxa, hashed bins (buckets of four keys) that overflow into the workgroups' private bins;
-    and the hashed bins on the small taxonomies too (MG_DEBUG_K3_HASHED, a test hook): few taxa — every bucket probe
-    hits at once — and 3500 — most of them overflow."""
+    taxa) and, beyond 4096 taxa, hashed bins (open addressing, 2048 slots) that overflow into the workgroups' private bins;
+    and the hashed bins on the small taxonomies too (MG_DEBUG_K3_HASHED, a test hook): few taxa — every probe hits at
+    once — and 3500 — the table is crowded, the probe limit drops and many taxa overflow."""
     if force_hashed:
         monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
     rng = np.random.default_rng(9)

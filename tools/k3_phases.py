@@ -12,7 +12,7 @@ hip = Hip.get(0)
 lib = hip.lib
 if not hasattr(lib, "mg_debug_k3_phases"):
     sys.exit("build with K3_PHASES=1 first (see the docstring)")
-names = ["ticket", "load+desc", "walk", "blockscan", "lookback", "publish", "commit", "looptop/exit"]
+names = ["ticket", "load+desc", "walk", "blockscan", "lookback", "publish", "flush+sync", "looptop/exit", "commit walk", "binning", "start", "last flush"]
 for R, G, present in [(12500000, 2000, 2000), (10000000, 10000, 500)]:
     rng = np.random.default_rng(1)
     pres = rng.choice(np.arange(1, G + 1), size=present, replace=False)
@@ -31,7 +31,7 @@ for R, G, present in [(12500000, 2000, 2000), (10000000, 10000, 500)]:
         sh.free()
     for commit in (True, False):
         run(commit); hip.sync()
-        out = (ctypes.c_ulonglong * 16)()
+        out = (ctypes.c_ulonglong * 24)()
         lib.mg_debug_k3_phases(out, 1)
         hip.prof_reset(); hip.prof_enable(True)
         for _ in range(5): run(commit)
@@ -41,7 +41,7 @@ for R, G, present in [(12500000, 2000, 2000), (10000000, 10000, 500)]:
         for nm in ("profile_pass", "profile_map"):
             n, t = hip.prof_get(nm)
             if n: print("R=%d T=%d %s: %.4f ms (%.0f GB/s) tiles=%d" % (R, T, nm, t / n, len(recs) * 16 / (t / n) / 1e6, ntiles))
-        off = 8 if commit else 0
-        tot = sum(out[off:off + 8])
-        print("   cycles/tile: " + ", ".join("%s %.0f" % (names[i], out[off + i] / 5 / ntiles) for i in range(8)), " total %.0f" % (tot / 5 / ntiles))
+        off = 12 if commit else 0
+        tot = sum(out[off:off + 12])
+        print("   cycles/tile: " + ", ".join("%s %.0f" % (names[i], out[off + i] / 5 / ntiles) for i in range(12)), " total %.0f" % (tot / 5 / ntiles))
     d_recs.free(); d_r2t.free(); d_acc.free()
