@@ -449,13 +449,13 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 // pipeline.  Reads of 2^14 bases or more bypass the bins (kQueueLenLimit), so that kFlushTiles tiles cannot overflow a field.
 // kHashProbe slots (double hashing over the packed words) are looked at before the private bins take a record.  Measured in round 4
 // on bench.py's configs[2] records (12.5M, 10 001 taxa, ~1000 of them hit uniquely: the sample's 500 genomes and — through reads
-// whose first line was dropped — their sibling accessions): 0.46 ms with the bins hashed against 0.30 ms with direct bins on the
-// same records folded onto 2001 taxa, and 0.32 ms with the look-up ablated (slot = taxon mod 1024: wrong results).  Neither the
-// look-up's form nor the table's load explains the 0.14 ms: buckets of four keys read 16 bytes at a time (rounds 2-3, 1024
-// slots), single 4-byte keys with double hashing, and this round's packed words in 2048 slots all take 0.46-0.47 ms; four times
-// the records (a workgroup then lives for 32 tiles instead of 8, so claiming the keys is amortised) still pay 0.09 ms per 12.5M
-// records over direct bins.  What the look-up adds is ONE dependent LDS read in front of the atomic and a loop over probes that
-// ends when the slowest lane of the wavefront has found its slot; open.
+// whose first line was dropped — their sibling accessions): 0.46-0.47 ms with the bins hashed against 0.30 ms with direct bins on
+// the same records folded onto 2001 taxa, whatever the look-up's form (buckets of four keys, single keys, packed words).  The
+// phase clocks (profiles/r04/k3_phases_queue_dump.txt) found the 0.16 ms elsewhere: (1) 8 probes failed for a handful of taxa per
+// workgroup, so every pass ended with the reduction over ~90 MB of private copies; (2) the flush every 8 tiles fell in the middle
+// of a workgroup's life and stalled the look-back chain behind it; (3) the last flush — hash-ordered slots touch 64 cache lines
+// per instruction, 2.3 M atomics from 768 workgroups at the same moment.  Now: 0.36 ms; what is left over direct bins is the
+// look-up (one dependent LDS read per read and the wavefront's slowest probe sequence).
 // The commit walk queues a uniquely mapped read as ONE 32-bit word (taxon << 14 | bases) in the LDS the look-back used, kItems
 // words per thread; reads of 2^14 bases or more go to the global bins at once.
 constexpr int kQueueLenBits = 14;
