@@ -356,6 +356,13 @@ int mg_gunzip_open(const char* path, int nthreads, mg_gunzip** out);
 int mg_gunzip_read(mg_gunzip* h, uint8_t* dst, uint64_t cap, uint64_t* n);
 void mg_gunzip_close(mg_gunzip* h);
 
+/* zcat of many files into one: `zcat <genome>.gz >> cmashed_db.fna` per selected genome (scripts/select_db.py:103-105, exit codes
+ * ignored there).  out_path is created / truncated and receives every file's text — all members of it — in the order of paths;
+ * files are inflated by nthreads host threads (<= 0: every core, at most 32) and written at their offsets.  A file that cannot be
+ * read, is not gzip, is corrupt or ends inside a member contributes NOTHING, gets a `zcat: <path>: <reason>` line on stderr and
+ * failed[i] = 1 (failed may be null); the call still succeeds.  Plain host code: needs no device and no mg_init. */
+int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_path, int nthreads, uint64_t* bytes_out, uint8_t* failed);
+
 /* ------------------------------------------------------------------------ *
  * Stage A' — genome sketch table (the pre-built DB the hot path consumes).
  * Replaces: CMash MakeStreamingDNADatabase.py -n 1000 -k 60

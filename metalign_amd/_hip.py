@@ -36,7 +36,7 @@ EXPORTS = [
     "mg_reads_download", "mg_reads_free",
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
-    "mg_gunzip_open", "mg_gunzip_read", "mg_gunzip_close",
+    "mg_gunzip_open", "mg_gunzip_read", "mg_gunzip_close", "mg_zcat_files",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_sketch_genomes_kmers", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
@@ -159,6 +159,24 @@ def gunzip_file(path, nthreads=0, piece=256 << 20):
     finally:
         _host_lib.mg_gunzip_close(h)
     return out[0].tobytes() if len(out) == 1 else b"".join(x.tobytes() for x in out)
+
+
+def zcat_files(paths, out_path, nthreads=0):
+    """mg_zcat_files: every file's inflated text (all members), in order, into out_path (created / truncated); a file that is not
+    gzip, corrupt or truncated contributes nothing and a `zcat:` line on stderr.  Host code of the library: no device involved.
+    -> (bytes written, bool[len(paths)] failed)."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    n = len(paths)
+    arr = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(p) for p in paths])
+    failed = np.zeros(max(n, 1), dtype=np.uint8)
+    nbytes = ctypes.c_uint64(0)
+    rc = _host_lib.mg_zcat_files(arr, ctypes.c_uint64(n), os.fsencode(out_path), ctypes.c_int(nthreads), ctypes.byref(nbytes),
+                                 _np(failed, ctypes.c_uint8))
+    if rc != 0:
+        raise OSError(_host_lib.mg_last_error().decode("utf-8", "replace"))
+    return nbytes.value, failed[:n].astype(bool)
 
 
 class DeviceArray:

@@ -278,6 +278,7 @@ __device__ __forceinline__ int64_t acc_lookup(const AccTable& t, const uint8_t* 
   }
 }
 
+constexpr uint32_t kQnameInline = 256;  // (SAM: QNAME is at most 254 characters)
 struct LineOut {
   mg_aln_rec rec;      // ref_new without the new-read bit
   uint64_t qbeg;       // QNAME span in the text
@@ -528,8 +529,10 @@ __global__ void k_sam_emit(const uint8_t* __restrict__ text, const LineOut* __re
 
 // Shared: build the line index of a text buffer.  If the text does not end in '\n' the last partial
 // line is terminated virtually.  -> d_line_end (scratch "ing_lines"), *nlines.
+// last_end (optional): the end of the last line, brought back in the same round trip as the marks' completion (a piece of a
+// stream is consumed up to there).  Two host synchronisations per call: the count, then the marks.
 static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d_line_end, uint64_t* nlines,
-                            bool* virtual_last, bool allow_virtual = true) {
+                            bool* virtual_last, bool allow_virtual = true, uint64_t* last_end = nullptr) {
   Context& c = ctx();
   hipStream_t st = c.stream;
   *nlines = 0;
@@ -548,16 +551,20 @@ static int build_line_index(const uint8_t* d_text, uint64_t nbytes, uint64_t** d
     ProfScope ps("ingest_lines");
     hipLaunchKernelGGL(k_count_newlines, dim3((unsigned)nblocks), dim3(kIB), 0, st, d_text, nbytes, d_cnt);
     MG_HIP(hipGetLastError());
+    uint64_t* pin = host_words();
+    MG_HIP(hipMemcpyAsync(pin + 13, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, st));  // (rides on the scan's synchronisation)
     MG_TRY(exclusive_sum_u32_to_u64(d_cnt, d_base, nblocks, &total));
-    MG_HIP(hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
+    last = *reinterpret_cast<const volatile uint8_t*>(pin + 13);
     *virtual_last = allow_virtual && last != '\n';  // (a piece of a stream: what follows the last newline is not a line yet)
     uint64_t* d_le = (uint64_t*)scratch("ing_lines", (total + 2) * sizeof(uint64_t));
     if (!d_le) return MG_ERR_NOMEM;
     hipLaunchKernelGGL(k_mark_newlines, dim3((unsigned)nblocks), dim3(kIB), 0, st, d_text, nbytes, d_base, d_le);
     MG_HIP(hipGetLastError());
     if (*virtual_last) MG_HIP(hipMemcpyAsync(d_le + total, &nbytes, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const uint64_t nl = total + (*virtual_last ? 1 : 0);
+    if (last_end && nl) MG_HIP(hipMemcpyAsync(pin + 12, d_le + (nl - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
+    if (last_end) *last_end = nl ? pin[12] : 0;
     *d_line_end = d_le;
   }
   *nlines = total + (*virtual_last ? 1 : 0);
@@ -802,6 +809,19 @@ static int aln_tokenize_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc
 
 }  // extern "C"
 
+namespace mg {
+// out: [0..8) QNAME offset, [8..12) length, [16..) its first kQnameInline bytes — of the last retained line.
+__global__ void k_sam_last_qname(const uint8_t* __restrict__ text, const LineOut* __restrict__ lines, const uint64_t* __restrict__ list,
+                                 uint64_t nret, uint8_t* __restrict__ out) {
+  const LineOut& lo = lines[list[nret - 1]];
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<uint64_t*>(out) = lo.qbeg;
+    *reinterpret_cast<uint32_t*>(out + 8) = lo.qlen;
+  }
+  for (uint32_t i = threadIdx.x; i < lo.qlen && i < kQnameInline; i += blockDim.x) out[16 + i] = text[lo.qbeg + i];
+}
+}  // namespace mg
+
 // final = false: a PIECE of the text that begins at a line start; the complete lines in it are tokenised and *consumed =
 // the byte after the last newline (what follows is carried to the next piece by the caller, mg_stream.hip).
 int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
@@ -818,19 +838,15 @@ int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg
   uint64_t* d_le = nullptr;
   uint64_t nlines = 0;
   bool vlast = false;
-  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast, final));
+  uint64_t last_end = 0;
+  MG_TRY(build_line_index(d_text, nbytes, &d_le, &nlines, &vlast, final, (!final && consumed) ? &last_end : nullptr));
   if (consumed) *consumed = final ? nbytes : 0;
   if (nlines == 0) {
     MG_TRY(sb->recs.alloc(16));
     *out = sb.release();
     return MG_OK;
   }
-  if (!final && consumed) {
-    uint64_t* pin = host_words();
-    MG_HIP(hipMemcpyAsync(pin + 12, d_le + (nlines - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
-    *consumed = pin[12] + 1;
-  }
+  if (!final && consumed) *consumed = last_end + 1;
   LineOut* d_lines = (LineOut*)scratch("sam_lines", nlines * sizeof(LineOut));
   uint32_t* d_ret = (uint32_t*)scratch("sam_ret", nlines * sizeof(uint32_t));
   uint64_t* d_rank = (uint64_t*)scratch("sam_rank", (nlines + 1) * sizeof(uint64_t));
@@ -853,10 +869,10 @@ int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg
       hipLaunchKernelGGL(k_sam_parse, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
                          nlines, at, d_lines, d_ret, d_err, d_kind);
     MG_HIP(hipGetLastError());
+    uint64_t* pin = host_words();
+    MG_HIP(hipMemcpyAsync(pin + 14, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));  // (rides on the scan's synchronisation)
     MG_TRY(exclusive_sum_u32_to_u64(d_ret, d_rank, nlines, &nret));
-    unsigned long long h_err = 0;
-    MG_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
+    const unsigned long long h_err = *reinterpret_cast<const volatile unsigned long long*>(pin + 14);
     if (h_err != ~0ull) {
       uint32_t kind = 0;
       MG_HIP(hipMemcpyAsync(&kind, d_kind + h_err, sizeof(kind), hipMemcpyDeviceToHost, st));
@@ -874,16 +890,25 @@ int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg
       hipLaunchKernelGGL(k_sam_emit, dim3(grid_for(nret, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_lines,
                          d_list, nret, d_prev, (uint32_t)plen, sb->recs.as<mg_aln_rec>());
       MG_HIP(hipGetLastError());
-      // QNAME of the last retained line, for the next chunk
-      uint64_t last_line = 0;
-      MG_HIP(hipMemcpyAsync(&last_line, d_list + (nret - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      // QNAME of the last retained line, for the next chunk: its span and its first kQnameInline bytes in ONE round trip
+      // (three dependent ones — line number, span, bytes — were a quarter of a streamed piece's host time)
+      uint8_t* d_q = (uint8_t*)scratch("sam_lastq", 16 + kQnameInline);
+      if (!d_q) return MG_ERR_NOMEM;
+      hipLaunchKernelGGL(k_sam_last_qname, dim3(1), dim3(64), 0, st, d_text, d_lines, d_list, nret, d_q);
+      MG_HIP(hipGetLastError());
+      std::vector<uint8_t> hq(16 + kQnameInline);
+      MG_HIP(hipMemcpyAsync(hq.data(), d_q, hq.size(), hipMemcpyDeviceToHost, st));
       MG_HIP(hipStreamSynchronize(st));
-      LineOut lo;
-      MG_HIP(hipMemcpyAsync(&lo, d_lines + last_line, sizeof(LineOut), hipMemcpyDeviceToHost, st));
-      MG_HIP(hipStreamSynchronize(st));
-      sb->last_qname.resize(lo.qlen);
-      if (lo.qlen) MG_HIP(hipMemcpyAsync(&sb->last_qname[0], d_text + lo.qbeg, lo.qlen, hipMemcpyDeviceToHost, st));
-      MG_HIP(hipStreamSynchronize(st));
+      uint64_t qbeg;
+      uint32_t qlen;
+      memcpy(&qbeg, hq.data(), 8);
+      memcpy(&qlen, hq.data() + 8, 4);
+      sb->last_qname.assign(reinterpret_cast<const char*>(hq.data() + 16), qlen < kQnameInline ? qlen : kQnameInline);
+      if (qlen > kQnameInline) {  // (a QNAME longer than the SAM format allows: the rest in a second trip)
+        sb->last_qname.resize(qlen);
+        MG_HIP(hipMemcpyAsync(&sb->last_qname[0], d_text + qbeg, qlen, hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+      }
     }
   }
   sb->nrecs = nret;

@@ -28,6 +28,8 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <cerrno>
+#include <cstdio>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -809,5 +811,131 @@ int mg_gunzip_read(mg_gunzip* h, uint8_t* dst, uint64_t cap, uint64_t* n) {
 }
 
 void mg_gunzip_close(mg_gunzip* h) { delete h; }
+
+// ---- zcat of many small files (the selected genomes, scripts/select_db.py:103-105) ----
+// One file: every member inflated by zlib (gzip or zlib header, as `zlib.decompressobj(47)`); bytes after the last member that
+// do not begin another member are ignored, as gzip / zcat do.  false + *why for a stream that is not gzip, corrupt, or ends
+// inside a member: such a file contributes NOTHING (zcat's partial output is not reproduced; the caller reports the file).
+static bool zcat_one(const char* path, std::string* text, std::string* why) {
+  text->clear();
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { *why = strerror(errno); return false; }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { *why = strerror(errno); close(fd); return false; }
+  std::vector<uint8_t> in((size_t)sb.st_size);
+  size_t got = 0;
+  while (got < in.size()) {
+    const ssize_t r = pread(fd, in.data() + got, in.size() - got, (off_t)got);
+    if (r < 0 && errno == EINTR) continue;
+    if (r <= 0) break;
+    got += (size_t)r;
+  }
+  close(fd);
+  if (got != in.size()) { *why = "short read"; return false; }
+  if (in.empty()) return true;
+  z_stream z;
+  memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, 47) != Z_OK) { *why = "zlib initialisation failed"; return false; }
+  z.next_in = in.data();
+  z.avail_in = (uInt)(in.size() > 0x7fffffffu ? 0x7fffffffu : in.size());
+  size_t fed_to = z.avail_in;  // bytes of `in` handed to zlib so far
+  text->resize(in.size() * 4 + (1u << 16));
+  size_t at = 0;
+  bool ok = true, in_member = false;
+  for (;;) {
+    if (at == text->size()) text->resize(text->size() * 2);
+    const size_t room = text->size() - at;
+    z.next_out = reinterpret_cast<Bytef*>(&(*text)[at]);
+    z.avail_out = (uInt)(room > 0x7fffffffu ? 0x7fffffffu : room);
+    const uInt out0 = z.avail_out;
+    if (z.avail_in == 0 && fed_to < in.size()) {
+      const size_t more = in.size() - fed_to;
+      z.avail_in = (uInt)(more > 0x7fffffffu ? 0x7fffffffu : more);
+      fed_to += z.avail_in;
+    }
+    if (z.avail_in) in_member = true;
+    const int rc = inflate(&z, Z_NO_FLUSH);
+    at += out0 - z.avail_out;
+    if (rc == Z_STREAM_END) {
+      in_member = false;
+      const size_t left = (size_t)z.avail_in + (in.size() - fed_to);
+      if (left == 0) break;
+      const uint8_t* nx = z.avail_in ? z.next_in : in.data() + fed_to;
+      const bool again = nx[0] == 0x1f && (left < 2 || nx[1] == 0x8b);
+      if (!again) break;  // trailing garbage
+      if (inflateReset(&z) != Z_OK) { ok = false; *why = "zlib reset failed"; break; }
+      continue;
+    }
+    if (rc == Z_OK) continue;
+    if (rc == Z_BUF_ERROR && z.avail_in == 0 && fed_to == in.size()) {
+      ok = false; *why = "the gzip stream ends in the middle of a member"; break;
+    }
+    if (rc == Z_BUF_ERROR) continue;  // (no room: the buffer grows at the top of the loop)
+    ok = false; *why = z.msg ? z.msg : "not a gzip stream"; break;
+  }
+  (void)in_member;
+  inflateEnd(&z);
+  if (!ok) { text->clear(); return false; }
+  text->resize(at);
+  return true;
+}
+
+int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_path, int nthreads, uint64_t* bytes_out, uint8_t* failed) {
+  if (!out_path || (nfiles && !paths)) return mg::fail(MG_ERR_ARG, "null argument");
+  if (nthreads <= 0) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    nthreads = (int)(hw == 0 ? 4 : (hw > 32 ? 32 : hw));
+  }
+  if ((uint64_t)nthreads > nfiles) nthreads = nfiles ? (int)nfiles : 1;
+  const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) return mg::fail(MG_ERR_ARG, "cannot open %s: %s", out_path, strerror(errno));
+  std::vector<std::string> text(nfiles), why(nfiles);
+  std::vector<uint8_t> bad(nfiles, 0);
+  std::atomic<uint64_t> next{0};
+  auto inflate_some = [&]() {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= nfiles) return;
+      bad[i] = zcat_one(paths[i], &text[i], &why[i]) ? 0 : 1;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(inflate_some);
+    inflate_some();
+    for (auto& t : th) t.join();
+  }
+  std::vector<uint64_t> at(nfiles + 1, 0);
+  for (uint64_t i = 0; i < nfiles; ++i) at[i + 1] = at[i] + text[i].size();
+  for (uint64_t i = 0; i < nfiles; ++i)
+    if (bad[i]) fprintf(stderr, "zcat: %s: %s\n", paths[i], why[i].c_str());  // (as zcat: a line on stderr, and on with the rest)
+  std::atomic<bool> werr{false};
+  next.store(0);
+  auto write_some = [&]() {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= nfiles) return;
+      size_t done = 0;
+      while (done < text[i].size()) {
+        const ssize_t w = pwrite(fd, text[i].data() + done, text[i].size() - done, (off_t)(at[i] + done));
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { werr.store(true); return; }
+        done += (size_t)w;
+      }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    const int wt = nthreads > 8 ? 8 : nthreads;
+    for (int t = 1; t < wt; ++t) th.emplace_back(write_some);
+    write_some();
+    for (auto& t : th) t.join();
+  }
+  const int cerr = close(fd);
+  if (werr.load() || cerr != 0) return mg::fail(MG_ERR_ARG, "writing %s failed: %s", out_path, strerror(errno));
+  if (bytes_out) *bytes_out = at[nfiles];
+  if (failed) for (uint64_t i = 0; i < nfiles; ++i) failed[i] = bad[i];
+  return MG_OK;
+}
 
 }  // extern "C"

@@ -588,33 +588,20 @@ def run_cmash_and_cutoff(args, taxid2info):
     return chosen
 
 
-def _zcat_into(out, paths, threads=None, batch=256):
-    import zlib
-    from concurrent.futures import ThreadPoolExecutor
-
-    def one(path):
-        try:
-            return formats.inflate_file(path)
-        except (OSError, zlib.error) as e:
-            sys.stderr.write('zcat: %s: %s\n' % (path, e))
-            return b''
-    if threads is None:  # (500 genomes of 50 kb took 0.04-0.06 s of a 0.17 s select_main on eight threads)
-        threads = max(1, min(32, os.cpu_count() or 4))
-    with ThreadPoolExecutor(threads) as ex:  # (zlib releases the GIL; a batch bounds what is held in memory)
-        for i in range(0, len(paths), batch):
-            for blob in ex.map(one, paths[i:i + batch]):
-                out.write(blob)
+def _zcat_into(out_path, paths, threads=0):
+    """`zcat` of every path into out_path (created / truncated), in order: the library's host threads inflate the files and
+    write them at their offsets (mg_zcat_files).  The per-file work in Python threads — open, read, zlib, write — held the
+    interpreter lock for most of its 0.05 s on 500 genomes, a quarter of select_main at 10M reads."""
+    from . import _hip
+    _hip.zcat_files(list(paths), out_path, threads)
 
 
 def make_db_and_dbinfo(args, organisms_to_include, taxid2info):
     """Concatenate the selected genomes and write the subset db_info (reference :99-117)."""
-    open(args.db, 'w').close()
-    with open(args.db, 'ab') as out:
-        # The reference starts one `zcat` per genome and appends its output (:103-105; exit codes ignored).  The bytes
-        # appended here are the same — every selected file inflated (all members of it) in the reference's order — by
-        # zlib in a few threads of this process: 500 genomes took 0.12 s of a 0.23 s select_main as three `zcat`
-        # subprocesses, and a file zcat would refuse (not gzip) contributes nothing and a line on stderr, as there.
-        _zcat_into(out, [args.db_dir + o for o in organisms_to_include])
+    # The reference truncates args.db and starts one `zcat` per genome that appends its output (:101-105; exit codes ignored).
+    # The bytes written here are the same — every selected file inflated (all members of it) in the reference's order — by
+    # zlib in host threads of the library: a file zcat would refuse (not gzip) contributes nothing and a line on stderr.
+    _zcat_into(args.db, [args.db_dir + o for o in organisms_to_include])
     with open(args.dbinfo_out, 'w') as out:
         out.write('Accesion\tLength\tTaxID\tLineage\tTaxID_Lineage\n')  # sic: the reference's header
         out.write('Unmapped\t0\tUnmapped\t|||||||Unmapped\t|||||||Unmapped\n')
@@ -646,7 +633,14 @@ def select_main(args=None):
     if args.input_type == 'AUTO':
         args.input_type = cli.sniff_reads_type(args.reads)
 
-    taxid2info = read_dbinfo(args)
+    # db_info is parsed by a second thread while the reads stream through the device (the library calls release the
+    # interpreter lock): 0.011 s of a 0.16 s select_main at 10M reads.  The file is opened here, so that a missing one still
+    # fails before anything is sketched, as in the reference (:143).
+    open(args.dbinfo_in, 'r').close()
+    from concurrent.futures import ThreadPoolExecutor
+    dbinfo_pool = ThreadPoolExecutor(1)
+    dbinfo_job = dbinfo_pool.submit(read_dbinfo, args)
+    dbinfo_pool.shutdown(wait=False)
     ctx = dist_context() if args.cmash_results == 'NONE' else None
     if ctx is not None:  # one process per GPU: all ranks sketch, rank 0 goes on alone
         run_sketch_steps_dist(args, ctx)
@@ -660,6 +654,7 @@ def select_main(args=None):
         run_sketch_steps(args)
     import time
     t_tail = time.perf_counter()
+    taxid2info = dbinfo_job.result()
     organisms = run_cmash_and_cutoff(args, taxid2info)
     make_db_and_dbinfo(args, organisms, taxid2info)
     run_timings['host_tail_s'] = time.perf_counter() - t_tail

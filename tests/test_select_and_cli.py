@@ -349,22 +349,45 @@ def test_inflate_file_takes_every_member_and_refuses_a_truncated_stream(tmp_path
         formats.inflate_file(str(cut))
 
 
-def test_subset_database_is_what_zcat_would_write(tmp_path, capsys):
-    """make_db_and_dbinfo appends `zcat <organism file>` per selected genome (reference scripts/select_db.py:103-105, exit
-    codes ignored): gzip files — every member — inflated in order; a file zcat refuses contributes nothing but a message."""
+def test_subset_database_is_what_zcat_would_write(tmp_path, capfd):
+    """make_db_and_dbinfo writes `zcat <organism file>` per selected genome (reference scripts/select_db.py:103-105, exit
+    codes ignored): gzip files — every member, padding after the last ignored — inflated in order by the library's host
+    threads (mg_zcat_files); a file zcat refuses (not gzip, cut short, missing) contributes nothing but a message."""
     import gzip
+
+    import numpy as np
+    from metalign_amd import formats
 
     org = tmp_path / "org"
     org.mkdir()
     (org / "a.fna.gz").write_bytes(gzip.compress(b">a\nACGT\n"))
-    (org / "b.fna.gz").write_bytes(gzip.compress(b">b1\nAA\n") + gzip.compress(b">b2\nCC\n"))
+    (org / "b.fna.gz").write_bytes(gzip.compress(b">b1\nAA\n") + gzip.compress(b">b2\nCC\n") + b"\0" * 512)
     (org / "c.fna.gz").write_bytes(b">not gzip\nGG\n")
     (org / "d.fna.gz").write_bytes(gzip.compress(b">d\nTT\n"))
+    (org / "e.fna.gz").write_bytes(gzip.compress(b">e\n" + b"ACGT" * 5000 + b"\n")[:-9])
+    (org / "f.fna.gz").write_bytes(b"")
+    big = b">g\n" + bytes(np.random.default_rng(3).choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300000)) + b"\n"
+    (org / "g.fna.gz").write_bytes(gzip.compress(big))
     out = tmp_path / "db.fna"
-    with open(out, "wb") as fh:
-        select_db._zcat_into(fh, [str(org / n) for n in ("a.fna.gz", "b.fna.gz", "c.fna.gz", "d.fna.gz")], threads=3, batch=2)
-    assert out.read_bytes() == b">a\nACGT\n>b1\nAA\n>b2\nCC\n>d\nTT\n"
-    assert "c.fna.gz" in capsys.readouterr().err
+    out.write_bytes(b"left over from an earlier run")
+    names = ("a.fna.gz", "b.fna.gz", "c.fna.gz", "d.fna.gz", "e.fna.gz", "f.fna.gz", "missing.fna.gz", "g.fna.gz")
+    select_db._zcat_into(str(out), [str(org / n) for n in names], threads=3)
+    assert out.read_bytes() == b">a\nACGT\n>b1\nAA\n>b2\nCC\n>d\nTT\n" + big
+    err = capfd.readouterr().err
+    for bad in ("c.fna.gz", "e.fna.gz", "missing.fna.gz"):
+        assert "zcat: " in err and "/" + bad in err
+    for good in ("a.fna.gz", "b.fna.gz", "f.fna.gz", "g.fna.gz"):
+        assert "/" + good not in err
+    # the same bytes as the Python inflater gives (formats.inflate_file: what the multi-GPU launch reads `.gz` input with)
+    want = b""
+    for n in names:
+        try:
+            want += formats.inflate_file(str(org / n))
+        except Exception:
+            pass
+    assert out.read_bytes() == want
+    select_db._zcat_into(str(out), [], threads=2)
+    assert out.read_bytes() == b""
 
 
 class _FakeSketch:

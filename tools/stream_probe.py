@@ -16,7 +16,7 @@ from metalign_amd._hip import Hip  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
-ks = [21, 31, 51]
+ks = [int(x) for x in os.environ.get("MG_PROBE_KS", "21,31,51").split(",")]  # (the reference pipeline sketches the largest k only)
 hip = Hip.get(0)
 gb, go = synth.make_genomes(G, 50_000)
 rb, ro, src = synth.make_reads(gb, go, n, npresent=max(40, G // 20))
@@ -47,7 +47,7 @@ def once(chunk, threads):
 
 once(64 << 20, 8)  # distinct-count hint, clocks
 for chunk_mb in (8, 16, 32, 64, 128):
-    for threads in (4, 8, 16):
+    for threads in (4, 8, 16, 32):
         cold, s1 = once(chunk_mb << 20, threads)
         warm = min(once(chunk_mb << 20, threads)[0] for _ in range(3))
         print("chunk %3d MB, %2d readers: cold %.3f s, warm %.3f s = %.1f GB/s = %.2e reads/s   %s"
