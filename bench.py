@@ -653,6 +653,13 @@ def main():
         resident = sum(f.resident_bytes for f in getattr(job.engine, "filters", []) if f is not None)
         res["config"]["stage_a_tables"] = ("resident index of the genome table, %.1f GB in HBM" % (resident / 1e9)) if resident \
             else "counting tables per pass + the table's membership filter"
+        tr = job.traffic_per_pass() if hasattr(job, "traffic_per_pass") else None
+        if tr:
+            # what rank 0 hands to the other ranks per pass, by collective (nothing at world size 1: `sketch_entries` x 12 B is
+            # the all-to-all volume that W ranks split), and what it holds for stage A besides the batch
+            res["exchange_bytes"] = dict(tr, note="bytes per pass rank 0 sends to other ranks; sketch entries are (hash u64, count "
+                                                  "u32) = 12 B, the slice a rank keeps is not counted")
+            res["resident_bytes"] = resident
         if world > 1:
             # the default workload differs between N = 1 (configs[2]) and N > 1 (configs[3] shapes): the figure this
             # line's per-GPU workload gives on ONE GPU (world 1, same collectives in the path), as committed

@@ -843,6 +843,26 @@ class ShardJob:
         share.update(ks=self.ks, ngenomes=self.G)
         return share  # (a host engine of the tests takes the arrays themselves)
 
+    def _sent(self, kind, nbytes, entries=0):
+        """Bytes this rank hands to OTHER ranks, by collective, summed over the passes so far (traffic["passes"]); what stays
+        on the rank — its own slice of an all-to-all — is not counted.  `sketch_entries` counts every entry it routes, its
+        own slice included: at world size 1 that is the volume that would be split W ways."""
+        tr = self.__dict__.setdefault("traffic", {"passes": 0, "words_all_gather": 0, "sketch_all_to_all": 0, "sketch_entries": 0,
+                                                  "prefix_marks_all_to_all": 0, "results_all_reduce": 0})
+        tr[kind] += int(nbytes)
+        tr["sketch_entries"] += int(entries)
+
+    def traffic_per_pass(self):
+        """-> bytes per pass this rank sent, by collective (all_reduce: the payload; a ring moves 2 (W - 1) / W of it per rank)."""
+        tr = getattr(self, "traffic", None)
+        if not tr or not tr["passes"]:
+            return None
+        n = tr["passes"]
+        out = {k: v / n for k, v in tr.items() if k != "passes"}
+        out["total_bytes"] = sum(v for k, v in out.items() if k != "sketch_entries")
+        out["passes"] = n
+        return out
+
     def _or_marks(self, marks):
         """The reference pipeline's one extra exchange.  marks: per k below the largest, this rank's bitmap over ALL prefixes of
         the table (int32 words; the prefixes of the k_max-mers that matched in this rank's hash range).  -> per k a bitmap of the
@@ -857,6 +877,7 @@ class ShardJob:
                 continue
             sizes = [cuts[q + 1] - cuts[q] for q in range(W)]
             my = sizes[r]
+            self._sent("prefix_marks_all_to_all", (int(m.numel()) - my) * m.element_size())
             if dist.get_backend() == "nccl":
                 recv = t.empty(W * my, dtype=m.dtype, device=m.device)
                 dist.all_to_all_single(recv, m, [my] * W, sizes)
@@ -882,6 +903,7 @@ class ShardJob:
         t, dist, W = self.torch, self.dist, self.world
         rh = t.zeros(sum(recv_counts), dtype=t.int64, device=self.device)
         rc = t.zeros(sum(recv_counts), dtype=t.int32, device=self.device)
+        self._sent("sketch_all_to_all", 12 * (sum(send_counts) - send_counts[self.rank]), entries=sum(send_counts))
         if dist.get_backend() == "nccl":
             w1 = dist.all_to_all_single(rh, send_h, list(recv_counts), list(send_counts), async_op=True)
             w2 = dist.all_to_all_single(rc, send_c, list(recv_counts), list(send_counts), async_op=True)
@@ -943,6 +965,7 @@ class ShardJob:
         NW = K * (W + 4) + 3
         words = [t.zeros(NW, dtype=t.int64, device=self.device) for _ in range(W)]
         dist.all_gather(words, t.as_tensor(np.asarray(word, dtype=np.int64), device=self.device))
+        self._sent("words_all_gather", 8 * len(word) * (W - 1))
         words = t.stack(words).cpu().numpy().tolist()
         received, inflight = [], []
         for ki, sk in enumerate(sks):
@@ -1118,6 +1141,7 @@ class ShardJob:
         def gather_words(P, word_t):
             words = t.empty((W, NW), dtype=t.int64, device=word_t.device)
             dist.all_gather(list(words.unbind(0)), word_t)
+            self._sent("words_all_gather", 8 * NW * (W - 1))
             eng.x_fetch_words(P, words, word_t)
 
         def phase_a(P, slot):  # this rank's words into the all-gather: no host wait at all
@@ -1164,6 +1188,8 @@ class ShardJob:
             self._fill_reduce(buf, hits, sizes, count, bases, first, scalars, qn)
             tb = eng.x_reduce_tensor(P)
             dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+            self._sent("results_all_reduce", int(tb.numel()) * tb.element_size() if W > 1 else 0)
+            self.traffic["passes"] += 1
             eng.x_fetch_reduced(P, tb)
 
         def phase_d(P):
@@ -1246,5 +1272,7 @@ class ShardJob:
             self._fill_reduce(buf, hits, sizes, count, bases, first, scalars, qn)
             tb = t.as_tensor(buf, device=self.device)
             dist.all_reduce(tb, op=dist.ReduceOp.SUM)  # THE all-reduce
+            self._sent("results_all_reduce", int(tb.numel()) * tb.element_size() if self.world > 1 else 0)
+            self.traffic["passes"] += 1
             return self._read_reduce(tb.cpu().numpy(), mm)
         return self._pack_out(hits.astype(np.uint32), sizes.astype(np.uint32), count, bases, first, scalars, qn, mm)

@@ -284,6 +284,16 @@ def _worker(rank, world, port, tmpdir):
         pout = pjob.run(4)
         for key in ("hits_k", "sizes_k", "count", "bases", "first_seen"):
             checks["run_" + key] = np.array_equal(pout[key], out[key])
+        # the bytes a rank reports having sent per pass: every sketch entry routed once (12 B for those that leave the rank),
+        # one all-reduce of the results, the words of the all-gather
+        tr, ptr = job.traffic_per_pass(), pjob.traffic_per_pass()
+        mine = int(oracle.sketch_reads(my_reads[0], my_reads[1], ks[-1], hmax=int(h.max()))[0].size)
+        checks["traffic_passes"] = tr["passes"] == 1 and ptr["passes"] == 4
+        checks["traffic_entries"] = tr["sketch_entries"] == mine and ptr["sketch_entries"] == mine
+        checks["traffic_all_to_all"] = 0 < tr["sketch_all_to_all"] <= 12 * mine and tr["sketch_all_to_all"] % 12 == 0
+        checks["traffic_all_reduce"] = tr["results_all_reduce"] > 0 and tr["words_all_gather"] > 0
+        checks["traffic_marks"] = (tr["prefix_marks_all_to_all"] == 0) == (len(ks) == 1)
+        checks["traffic_total"] = tr["total_bytes"] == sum(tr[k] for k in ("words_all_gather", "sketch_all_to_all", "prefix_marks_all_to_all", "results_all_reduce"))
         ok = all(checks.values())
         if not ok:
             print("rank", rank, "refpipe case", case, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
