@@ -302,6 +302,8 @@ int mg_mem_trim(void) {
   mg::scratch_release_all();
   mg::ctx().k3_priv_ptr = nullptr;  // (stage C's private bins are scratch: their all-zero invariant goes with them)
   mg::ctx().k3_priv_nb = 0;
+  mg::ctx().k3_flags = nullptr;
+  mg::ctx().k3_nflags = 0;
   mg::pool_release_all();
   return MG_OK;
 }

@@ -52,6 +52,8 @@ struct Context {
   // stage C's private overflow bins (mg_profile.hip): which block / partition is known to be all-zero
   void* k3_priv_ptr = nullptr;
   uint64_t k3_priv_nb = 0;
+  uint32_t* k3_flags = nullptr;  // ... its overflow flags (zeroed by every k_pass_prepare)
+  uint32_t k3_nflags = 0;
   // occurrence counters of read sketches saturate here (kmc -cs3, scripts/select_db.py:50); 0 = exact counts
   uint32_t count_sat = 3;
   // which definition of a k-mer's hash the stage-A / A' kernels compute (mg_set_hash_mode; mg_kmer.h)

@@ -440,7 +440,7 @@ __device__ __forceinline__ TileFn look_window(const uint64_t* __restrict__ desc,
 //                      updated with WORKGROUP-scope atomics — executed in the L2 of the XCD the workgroup runs on,
 //                      not at the memory side like device-scope ones (~14 G/s on this multi-XCD part).  Nothing else
 //                      touches a workgroup's copy while the kernel runs; k_bins_reduce sums the copies afterwards (and
-//                      leaves them zeroed), and returns at once when no workgroup overflowed.
+//                      leaves them zeroed), and reads none of them when no workgroup overflowed.
 //   use_lds_hist == 0  global atomics only (shards of 2^32 reads or more: the bins hold 32-bit read indices).
 // A bin is ONE packed 64-bit word (count << 40 | bases) plus the 32-bit shard-relative index of the first read
 // seen: one LDS atomic per unique read (the minimum is only attempted when a plain read says it would change
@@ -946,6 +946,12 @@ __global__ __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(MG_K3_COMMI
   profile_pass_body<true>(A);
 }
 
+// k_bins_reduce's view of the dumped tables: a block takes kRedSlots consecutive slots x kRedSlices shares of a quarter of the tables
+constexpr uint32_t kRedSlots = 32, kRedSlices = 8, kRedCache = 4, kRedY = 4;
+constexpr int kRedBatch = 24;
+static_assert(kRedSlots * kRedSlices == 256 && kHashSlots % kRedSlots == 0, "one thread per (slot, share)");
+struct RedEnt { uint32_t key, first; unsigned long long cnt, bas; };  // key = taxon + 1, 0 = free
+
 // Hashed mode, after the pass: the workgroups' private bins summed into the accumulators — one thread per taxon walks
 // the copies (consecutive threads read consecutive words of a copy) and leaves them zeroed for the next pass.  Nothing
 // to do (and nothing read) when no workgroup overflowed its LDS bins.
@@ -960,37 +966,71 @@ __global__ __launch_bounds__(256) void k_bins_reduce(unsigned long long* __restr
   // blockIdx.y: a slice of the workgroups' copies (enough blocks to fill the GPU: the private copies are ~100 MB at 10 001 taxa)
   const uint32_t per = (ncopies + gridDim.y - 1) / gridDim.y;
   const uint32_t cbeg = blockIdx.y * per, cend = cbeg + per < ncopies ? cbeg + per : ncopies;
-  if (t < kHashSlots) {  // slot t of the workgroups' last tables: runs of equal keys are summed before they are added
-    unsigned long long cur = 0, cnt = 0, bas = 0;
-    uint32_t first = 0xffffffffu;
-    auto emit = [&]() {
-      if (cnt) {
-        const uint32_t tax = (uint32_t)cur - 1u;
-        atomicAdd(&g_count[tax], cnt);
-        atomicAdd(&g_bases[tax], bas);
-        atomicMin(&g_first[tax], (unsigned long long)(group_base + first));
+  // The workgroups' last tables.  Every workgroup hashes alike, but which of two colliding taxa took a slot first differs from
+  // workgroup to workgroup: a slot holds two or three different keys across them.  A thread reads slot s of 1/32 of the tables into a
+  // four-key cache in registers, the eight threads of a slot leave their caches in LDS and one of them merges the 32 entries: three
+  // atomics per slot, key and quarter of the workgroups (summing only RUNS of equal keys left 0.7 M atomics — 43 us at the ~16 G/s
+  // the part retires them — where this leaves tens of thousands).
+  if (blockIdx.x < kHashSlots / kRedSlots && blockIdx.y < kRedY) {
+    __shared__ RedEnt s_ent[kRedSlots][kRedSlices][kRedCache];
+    const uint32_t sl = threadIdx.x / kRedSlots, sloc = threadIdx.x % kRedSlots;  // (consecutive lanes: consecutive slots, 256 B of a table)
+    const uint32_t slot = blockIdx.x * kRedSlots + sloc;
+    const uint32_t nsl = kRedY * kRedSlices, dper = (ncopies + nsl - 1) / nsl;
+    const uint32_t dbeg = (blockIdx.y * kRedSlices + sl) * dper, dend = dbeg + dper < ncopies ? dbeg + dper : ncopies;
+    auto emit = [&](const RedEnt& e) {
+      if (e.cnt) {
+        const uint32_t tax = e.key - 1u;
+        atomicAdd(&g_count[tax], e.cnt);
+        atomicAdd(&g_bases[tax], e.bas);
+        atomicMin(&g_first[tax], (unsigned long long)(group_base + e.first));
       }
     };
-    for (uint32_t c0 = cbeg; c0 < cend; c0 += 8) {
-      unsigned long long v[8];
-      uint32_t f[8];
+    RedEnt cache[kRedCache];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+    for (int j = 0; j < kRedCache; ++j) cache[j] = RedEnt{0u, 0xffffffffu, 0ull, 0ull};
+    auto add = [&](uint32_t key, unsigned long long n1, unsigned long long b1, uint32_t f1) {
+      bool placed = false;
+#pragma unroll
+      for (int j = 0; j < kRedCache; ++j) {  // (static indices: the cache stays in registers)
+        const bool here = !placed && (cache[j].key == key || cache[j].key == 0u);
+        if (here) {
+          cache[j].key = key; cache[j].cnt += n1; cache[j].bas += b1;
+          cache[j].first = f1 < cache[j].first ? f1 : cache[j].first;
+        }
+        placed = placed || here;
+      }
+      if (!placed) emit(RedEnt{key, f1, n1, b1});  // a fifth key in one slot: straight to the accumulators
+    };
+    for (uint32_t c0 = dbeg; c0 < dend; c0 += kRedBatch) {  // (a thread's whole share in ONE round trip at 768 workgroups)
+      unsigned long long v[kRedBatch];
+      uint32_t f[kRedBatch];
+#pragma unroll
+      for (int u = 0; u < kRedBatch; ++u) {
         const uint32_t c = c0 + u;
-        v[u] = c < cend ? dump_pack[(size_t)c * kHashSlots + t] : 0ull;
-        f[u] = c < cend ? dump_first[(size_t)c * kHashSlots + t] : 0xffffffffu;
+        v[u] = c < dend ? dump_pack[(size_t)c * kHashSlots + slot] : 0ull;
+        f[u] = c < dend ? dump_first[(size_t)c * kHashSlots + slot] : 0xffffffffu;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned long long key = v[u] >> kHKeyShift, n1 = (v[u] >> kHCountShift) & 0x7fffull;
-        if (n1 == 0) continue;  // empty, or claimed and never counted in
-        if (key != cur) { emit(); cur = key; cnt = 0; bas = 0; first = 0xffffffffu; }
-        cnt += n1;
-        bas += v[u] & ((1ull << kHCountShift) - 1);
-        first = f[u] < first ? f[u] : first;
+      for (int u = 0; u < kRedBatch; ++u) {
+        const unsigned long long n1 = (v[u] >> kHCountShift) & 0x7fffull;
+        if (n1) add((uint32_t)(v[u] >> kHKeyShift), n1, v[u] & ((1ull << kHCountShift) - 1), f[u]);  // (0: empty, or claimed and never counted in)
       }
     }
-    emit();
+#pragma unroll
+    for (int j = 0; j < kRedCache; ++j) s_ent[sloc][sl][j] = cache[j];
+    __syncthreads();
+    if (sl == 0) {
+#pragma unroll
+      for (int j = 0; j < kRedCache; ++j) cache[j] = RedEnt{0u, 0xffffffffu, 0ull, 0ull};
+      for (uint32_t q = 0; q < kRedSlices; ++q)
+#pragma unroll
+        for (int j = 0; j < kRedCache; ++j) {
+          const RedEnt e = s_ent[sloc][q][j];
+          if (e.cnt) add(e.key, e.cnt, e.bas, e.first);
+        }
+#pragma unroll
+      for (int j = 0; j < kRedCache; ++j) emit(cache[j]);
+    }
   }
   if (blockIdx.y == 0 && t < ntax) {  // the XCDs' copies of the accumulators (always: the LDS bins are flushed into them)
     unsigned long long cnt = 0, bas = 0, first = ~0ull;
@@ -1011,8 +1051,7 @@ __global__ __launch_bounds__(256) void k_bins_reduce(unsigned long long* __restr
       atomicMin(&g_first[t], first);
     }
   }
-  if (*priv_used == 0u) return;
-  if (t < ntax) {
+  if (*priv_used != 0u && t < ntax) {  // (no workgroup overflowed its LDS bins: nothing read)
     unsigned long long cnt = 0, bas = 0;
     uint32_t first = 0xffffffffu;
     for (uint32_t c0 = cbeg; c0 < cend; c0 += 8) {
@@ -1043,20 +1082,19 @@ __global__ __launch_bounds__(256) void k_bins_reduce(unsigned long long* __restr
       atomicMin(&g_first[t], (unsigned long long)(group_base + first));
     }
   }
-}
-// (its own launch, behind the reduction: every block of k_bins_reduce reads the flag first)
-__global__ void k_bins_done(uint32_t* priv_used, uint32_t ncopies) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= ncopies) priv_used[i] = 0u;
+  // (the flags are zeroed by the NEXT pass's k_pass_prepare.  Counting the blocks that are through and letting the last one do it
+  // cost 46 us: 2048 returning atomics on one address)
 }
 
 // Before a pass: tile descriptors + ticket = 0 and, when asked, the accumulators of a fresh batch (one launch).
+// flags: the hashed bins' overflow flags of the pass before (read by its k_bins_reduce, which ran ahead of this on the stream).
 __global__ void k_pass_prepare(uint64_t* __restrict__ desc, uint64_t ndesc, uint64_t* __restrict__ count,
                                uint64_t* __restrict__ bases, uint64_t* __restrict__ first, uint64_t* __restrict__ scalars,
-                               uint32_t ntax) {
+                               uint32_t ntax, uint32_t* __restrict__ flags, uint32_t nflags) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (uint64_t i = i0; i < ndesc; i += stride) desc[i] = 0;
+  for (uint64_t i = i0; i < nflags; i += stride) flags[i] = 0;
   if (count) {
     for (uint64_t t = i0; t < ntax; t += stride) { count[t] = 0; bases[t] = 0; first[t] = ~0ull; }
     if (i0 < 2) scalars[i0] = 0;
@@ -1162,7 +1200,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     const uint64_t work = ndesc > p->ntax ? ndesc : p->ntax;
     hipLaunchKernelGGL(k_pass_prepare, dim3(grid_for(work, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st,
                        p->desc.as<uint64_t>(), ndesc, reset_acc ? d_count : (uint64_t*)nullptr, d_bases, d_first_seen, d_scalars,
-                       p->ntax);
+                       p->ntax, c.k3_flags, c.k3_flags ? c.k3_nflags : 0u);
     MG_HIP(hipGetLastError());
   }
   PassArgs a{};
@@ -1201,7 +1239,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     // the private overflow bins: a grow-only buffer of the library, all-zero (first-seen words all-ones) between passes —
     // zeroed when it is (re)allocated, re-zeroed by k_bins_reduce wherever a pass wrote
     const uint64_t nb = (uint64_t)c.num_cus * 3 * p->ntax;
-    const uint64_t nflags = (uint64_t)c.num_cus * 3 + 1;
+    const uint64_t nflags = (uint64_t)c.num_cus * 3 + 1;  // [0] any, [1 + w] workgroup w
     const uint64_t nx = (uint64_t)kXcds * 3 * p->ntax;  // the XCDs' accumulator copies
     const uint64_t nd = (uint64_t)c.num_cus * 3 * kHashSlots;  // the workgroups' last tables (written whole by every pass)
     const uint64_t bytes = (nb + nx + nd) * sizeof(unsigned long long) + (nb + nd) * sizeof(uint32_t) + nflags * sizeof(uint32_t) + 64;
@@ -1224,14 +1262,16 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
       MG_HIP(hipMemsetAsync(a.priv_used, 0, nflags * sizeof(uint32_t), st));
       priv_ptr = buf;
       priv_nb = nb;
+      c.k3_flags = a.priv_used;  // (zeroed again by every k_pass_prepare from now on)
+      c.k3_nflags = (uint32_t)nflags;
     }
   }
   hipLaunchKernelGGL(k_profile_pass<true>, dim3(grid), dim3(kPB), lds, st, a);
   MG_HIP(hipGetLastError());
   if (a.use_lds_hist == 2) {
-    hipLaunchKernelGGL(k_bins_reduce, dim3(((p->ntax > kHashSlots ? p->ntax : kHashSlots) + 255) / 256, 32), dim3(256), 0, st, a.priv_pack, a.priv_first, a.priv_used, a.xcd_bins, a.dump_pack, a.dump_first, grid,
+    const unsigned rx = (p->ntax + 255) / 256 > kHashSlots / kRedSlots ? (p->ntax + 255) / 256 : kHashSlots / kRedSlots;
+    hipLaunchKernelGGL(k_bins_reduce, dim3(rx, 32), dim3(256), 0, st, a.priv_pack, a.priv_first, a.priv_used, a.xcd_bins, a.dump_pack, a.dump_first, grid,
                        p->ntax, group_base, a.g_count, a.g_bases, a.g_first);
-    hipLaunchKernelGGL(k_bins_done, dim3((grid + 256) / 256), dim3(256), 0, st, a.priv_used, grid);
     MG_HIP(hipGetLastError());
   }
   return MG_OK;
