@@ -65,7 +65,7 @@ struct ContainArgs {
 
 // idx[b] = first position whose hash >= b << shift; idx[nbuckets] = n.  One thread per sketch entry i (and one
 // past the end) writes i into every bucket in (bucket(q[i-1]), bucket(q[i])]: hashes are uniform and there is
-// about one bucket per entry, so that is ~1 store per thread, against a 20-step binary search per bucket.
+// about one bucket per eight entries, so that is a store for one thread in eight, against a 20-step binary search per bucket.
 __global__ void k_build_index(const ContainArgs a) {
   const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
     } else if (len) {
       // A run longer than the LDS stage: either the read sketch is locally much denser than the table (the top of
       // the hash range, where few genome sketches reach) or simply huge.  Every pair goes through the bucket index
-      // on its own (about one sketch entry per bucket): three dependent loads, the eight pairs' chains independent.
+      // on its own (about eight sketch entries per bucket): three dependent loads, the eight pairs' chains independent.
       uint32_t a[kPer], b[kPer];
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
@@ -409,8 +409,11 @@ static int plan_index(mg_sketch* sk, bool* build) {
   unsigned bits = 0;
   for (uint64_t v = pending ? sk->hmax : sk->last_hash; v; v >>= 1) ++bits;
   if (bits == 0) bits = 1;
-  unsigned lb = 0;  // log2(buckets): about one sketch entry per bucket, at most 2^27 buckets
-  while ((1ull << lb) < n && lb < 27) ++lb;
+  // log2(buckets): about eight sketch entries per bucket.  A tile reads two words of the index (its run has up to eight entries of
+  // slack at either end), the rare unstaged pair does three more search steps — and the build is a pass over the sketch in which
+  // one thread in eight stores (one bucket per entry was 0.66 ms for the 9.7M-entry sketch at configs[3]: 67 MB of scattered stores)
+  unsigned lb = 0;
+  while ((1ull << lb) < (n + 7) / 8 && lb < 27) ++lb;
   if (lb < 1) lb = 1;  // keeps the shift below 64
   if (lb > bits) lb = bits;
   sk->index_shift = bits - lb;
