@@ -503,6 +503,7 @@ struct PassArgs {
   uint32_t incoming, first_shard;
   uint64_t group_base;
   uint32_t ntax, use_lds_hist;
+  uint32_t flush_tiles;           // the LDS bins go to the accumulators every so many tiles (kFlushTiles / kHashFlushTiles)
   unsigned long long *g_count, *g_bases, *g_first, *g_scalars;
   unsigned long long* priv_pack;  // hashed mode: [gridDim.x][ntax] packed bins (count << 40 | bases), all zero between passes ...
   uint32_t* priv_first;           // ... first-seen words (0xffffffff between passes) ...
@@ -901,7 +902,7 @@ __device__ __forceinline__ void profile_pass_body(const PassArgs& A) {
         if (__hip_atomic_load(A.priv_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicExch(A.priv_used, 1u);
       }
       if (tid == 0) s_groups += tile_g;
-      if (A.use_lds_hist && ++tiles_binned == (A.use_lds_hist == 2 ? kHashFlushTiles : kFlushTiles)) {  // before a packed field can overflow
+      if (A.use_lds_hist && ++tiles_binned == A.flush_tiles) {  // before a packed field can overflow
         __syncthreads();
         flush_bins(true);
         tiles_binned = 0;
@@ -1233,7 +1234,11 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   ProfScope ps("profile_pass", st);
   // every workgroup flushes its private histogram once: few, long-lived workgroups
   const unsigned per_cu = lds > 40 * 1024 ? 2u : 3u;
-  const unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
+  unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
+  a.flush_tiles = a.use_lds_hist == 2 ? kHashFlushTiles : kFlushTiles;
+  // test hooks: a workgroup at this size lives for ~8 tiles and never reaches a mid-life flush — fewer workgroups, shorter intervals
+  if (const char* e = getenv("MG_DEBUG_K3_FLUSH_TILES")) { const int v = atoi(e); if (v > 0 && (uint32_t)v < a.flush_tiles) a.flush_tiles = (uint32_t)v; }
+  if (const char* e = getenv("MG_DEBUG_K3_GRID")) { const int v = atoi(e); if (v > 0 && (unsigned)v < grid) grid = (unsigned)v; }
   if (grid < a.ticket_lanes) a.ticket_lanes = grid;
   if (a.use_lds_hist == 2) {
     // the private overflow bins: a grow-only buffer of the library, all-zero (first-seen words all-ones) between passes —

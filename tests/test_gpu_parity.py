@@ -360,6 +360,40 @@ def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib, force_hashed, mon
             assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
 
 
+@pytest.mark.parametrize("force_hashed", [False, True])
+@pytest.mark.parametrize("flush_tiles,grid", [(1, 0), (2, 3), (3, 7), (0, 2)])
+def test_stage_c_bins_flushed_in_the_middle_of_a_workgroups_life(hip, oracle_lib, force_hashed, flush_tiles, grid, monkeypatch):
+    """A workgroup's LDS bins are flushed every 256 (direct) / 15 (hashed) tiles — which no input of a test's size reaches, a
+    workgroup living for a tile or two.  With the test hooks (fewer workgroups, shorter intervals) the same records go through
+    mid-life flushes (hashed: into the per-XCD copies, keys released and claimed again), bins that persist over many tiles,
+    and the last dump of a table that was just flushed; small, crowded (3500 taxa in 2048 slots) and large taxonomies."""
+    if force_hashed:
+        monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
+    if flush_tiles:
+        monkeypatch.setenv("MG_DEBUG_K3_FLUSH_TILES", str(flush_tiles))
+    if grid:
+        monkeypatch.setenv("MG_DEBUG_K3_GRID", str(grid))
+    rng = np.random.default_rng(21)
+    for ntax, nref in ((37, 90), (3500, 7000), (5000, 9000)):
+        n = 60000  # 30 tiles
+        ref2tax = rng.integers(0, ntax, size=nref).astype(np.uint32)
+        recs = np.zeros(n, dtype=oracle_lib.REC_DTYPE)
+        new = rng.random(n) < 0.75
+        new[0] = True
+        hot = rng.integers(0, nref, size=12)
+        ref = np.where(rng.random(n) < 0.5, hot[rng.integers(0, 12, size=n)], rng.integers(0, nref, size=n))
+        recs["ref_new"] = ref.astype(np.uint32) | (new.astype(np.uint32) << 31)
+        total = rng.integers(30, 151, size=n).astype(np.uint32)
+        recs["total"] = total
+        recs["matched"] = (total * np.clip(rng.normal(0.8, 0.25, size=n), 0, 1)).astype(np.uint32)
+        recs["flag_len"] = rng.choice([0, 16, 256, 272, 99, 147], size=n, p=[.35, .35, .1, .1, .05, .05]).astype(np.uint32) | (total << 12)
+        want = oracle_lib.profile_assign(recs, ref2tax, ntax, 0.5)
+        for rep in range(2):  # (twice: the copies a pass leaves behind must be as it found them)
+            got = hip.profile_assign(recs, ref2tax, ntax, 0.5)
+            for key in want:
+                assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), (ntax, rep, key)
+
+
 def test_sketch_two_million_distinct(hip, oracle_lib):
     """~2.4M distinct hashes at hmax = max (bucket path, thousands of buckets) against the oracle's full sort."""
     rng = np.random.default_rng(99)
