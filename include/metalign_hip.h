@@ -363,6 +363,16 @@ void mg_gunzip_close(mg_gunzip* h);
  * failed[i] = 1 (failed may be null); the call still succeeds.  Plain host code: needs no device and no mg_init. */
 int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_path, int nthreads, uint64_t* bytes_out, uint8_t* failed);
 
+/* Diagnostic, host code only.  With MG_STREAM_THIN=1 in the environment mg_sketch_stream_add_file / mg_sam_stream_file THIN a
+ * plain FASTQ / SAM file in their reader threads to what the device parsers read (a FASTQ record -> ">", its sequence line; a SAM
+ * line with its SEQ field replaced by a mark + len(SEQ) and its QUAL by '*': from the page cache both files go up at the PCIe
+ * link's rate, and half / two thirds of their bytes are never looked at on the device).  Off by default: as built the readers'
+ * per-byte work costs more than the link saves (mg_stream.hip, ThinSource).  This writes the thinned
+ * text to out_path — kind 0 FASTQ, 1 SAM; piece_bytes = the streaming slot size (0: the default); the same checks and errors
+ * as the stream (malformed FASTQ record, lines that are not a whole number of records, a record that does not fit a piece:
+ * MG_ERR_CAPACITY). */
+int mg_stream_thin_file(const char* path, int kind, uint64_t piece_bytes, int nthreads, const char* out_path);
+
 /* ------------------------------------------------------------------------ *
  * Stage A' — genome sketch table (the pre-built DB the hot path consumes).
  * Replaces: CMash MakeStreamingDNADatabase.py -n 1000 -k 60

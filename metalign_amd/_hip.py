@@ -36,7 +36,7 @@ EXPORTS = [
     "mg_reads_download", "mg_reads_free",
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
-    "mg_gunzip_open", "mg_gunzip_read", "mg_gunzip_close", "mg_zcat_files",
+    "mg_gunzip_open", "mg_gunzip_read", "mg_gunzip_close", "mg_zcat_files", "mg_stream_thin_file",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_sketch_genomes_kmers", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
@@ -177,6 +177,18 @@ def zcat_files(paths, out_path, nthreads=0):
     if rc != 0:
         raise OSError(_host_lib.mg_last_error().decode("utf-8", "replace"))
     return nbytes.value, failed[:n].astype(bool)
+
+
+def thin_file(path, kind, out_path, piece_bytes=0, nthreads=4):
+    """mg_stream_thin_file (diagnostic, host only): what the streaming readers hand to the device for a plain "fastq" / "sam" file,
+    written to out_path.  HipError with the stream's own codes (ERR_ARG: malformed; ERR_CAPACITY: a record does not fit a piece)."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    rc = _host_lib.mg_stream_thin_file(os.fsencode(path), ctypes.c_int({"fastq": 0, "sam": 1}[kind]), ctypes.c_uint64(int(piece_bytes)),
+                                       ctypes.c_int(int(nthreads)), os.fsencode(out_path))
+    if rc != 0:
+        raise HipError("libmetalign_hip rc=%d: %s" % (rc, _host_lib.mg_last_error().decode("utf-8", "replace")), rc)
 
 
 class DeviceArray:

@@ -290,7 +290,7 @@ struct LineOut {
 // kinds[line] holds the failure kind for the host to look up.
 __global__ void k_sam_parse(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_end, uint64_t nlines,
                             AccTable acc, LineOut* __restrict__ out, uint32_t* __restrict__ retained,
-                            unsigned long long* __restrict__ err, uint32_t* __restrict__ err_kind) {
+                            unsigned long long* __restrict__ err, uint32_t* __restrict__ err_kind, uint32_t thin) {
   uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; l < nlines; l += stride) {
@@ -357,7 +357,11 @@ __global__ void k_sam_parse(const uint8_t* __restrict__ text, const uint64_t* __
               if (!tok) kind = kErrValue;
             }
             if (kind == kErrNone && total == 0) kind = kErrZeroDiv;
-            const uint64_t slen = (fe[9] - fb[9] == 1 && text[fb[9]] == '*') ? 0 : fe[9] - fb[9];
+            uint64_t slen = (fe[9] - fb[9] == 1 && text[fb[9]] == '*') ? 0 : fe[9] - fb[9];
+            if (thin && text[fb[9]] == MG_THIN_MARK) {  // a line thinned by the file reader (mg_stream.hip): SEQ = mark + its length in decimal
+              slen = 0;
+              for (uint64_t c = fb[9] + 1; c < fe[9]; ++c) slen = slen * 10 + (uint64_t)(text[c] - '0');
+            }
             if (kind == kErrNone && (slen > MG_REC_MAX_SEQLEN || matched > 0xffffffffull || total > 0xffffffffull))
               kind = kErrOverflow;
             if (kind == kErrNone) {
@@ -825,7 +829,8 @@ __global__ void k_sam_last_qname(const uint8_t* __restrict__ text, const LineOut
 // final = false: a PIECE of the text that begins at a line start; the complete lines in it are tokenised and *consumed =
 // the byte after the last newline (what follows is carried to the next piece by the caller, mg_stream.hip).
 int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname,
-                                bool paf, bool final, uint64_t* consumed, mg_sam_batch** out, int* err_kind, uint64_t* err_line) {
+                                bool paf, bool final, uint64_t* consumed, mg_sam_batch** out, int* err_kind, uint64_t* err_line,
+                                bool thin) {
   MG_REQUIRE_READY();
   if (!out || !ix) return fail(MG_ERR_ARG, "null argument");
   *out = nullptr;
@@ -867,7 +872,7 @@ int mg::aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg
                          nlines, at, d_lines, d_ret, d_err, d_kind);
     else
       hipLaunchKernelGGL(k_sam_parse, dim3(grid_for(nlines, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, d_text, d_le,
-                         nlines, at, d_lines, d_ret, d_err, d_kind);
+                         nlines, at, d_lines, d_ret, d_err, d_kind, thin ? 1u : 0u);
     MG_HIP(hipGetLastError());
     uint64_t* pin = host_words();
     MG_HIP(hipMemcpyAsync(pin + 14, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));  // (rides on the scan's synchronisation)

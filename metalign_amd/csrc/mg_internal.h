@@ -281,6 +281,8 @@ struct mg_acc_index {
   uint32_t nacc = 0;
 };
 
+#define MG_THIN_MARK 0x01  // first byte of a SEQ field the file reader replaced by its length (never whitespace, never a base)
+
 struct mg_sam_batch {
   mg::DevBuf recs;
   uint64_t nrecs = 0;
@@ -288,8 +290,9 @@ struct mg_sam_batch {
 };
 
 namespace mg {
+// thin: the piece comes from the file reader's thinning (mg_stream.hip: a SEQ field is MG_THIN_MARK + its length in decimal).
 int aln_tokenize_prefix_dev(const uint8_t* d_text, uint64_t nbytes, const mg_acc_index* ix, const char* prev_qname, bool paf,
-                            bool final, uint64_t* consumed, mg_sam_batch** out, int* err_kind, uint64_t* err_line);
+                            bool final, uint64_t* consumed, mg_sam_batch** out, int* err_kind, uint64_t* err_line, bool thin = false);
 }
 
 struct mg_filter {

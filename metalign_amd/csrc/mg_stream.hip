@@ -38,6 +38,7 @@ namespace mg {
 // ---------------------------------------------------------------------------------------------------------------------
 struct Source {
   std::string error;  // set by fill() on failure (a reader thread must not touch the library's error text)
+  int error_code = MG_ERR_ARG;
   virtual ~Source() {}
   // Piece i of the byte stream into dst (at most cap bytes).  *last = this is the stream's final piece (possibly empty).
   // Returns the bytes written, -1 on error.  Called for i = 0, 1, 2, ... — by ANY thread in any order when parallel(),
@@ -212,6 +213,255 @@ struct BgzfSource : Source {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// A plain FASTQ or SAM file THINNED by the reader threads to what the device parsers read.  From the page cache both
+// files go up at the PCIe link's rate (3.0 + 3.5 GB per 10M reads: 0.14 s of a 0.28 s pair of command lines), and half
+// of a FASTQ record (the quality line, the '+', most of the header) and two thirds of a SAM line (SEQ and QUAL, of which
+// only len(SEQ) is used, scripts/map_and_profile.py:213) are never looked at on the device.
+//   FASTQ  a record -> ">\n<sequence line>\n": the device parses single-line FASTA.  The reader that owns a record's
+//          header line checks what k_read_lengths checks (header '@...', separator '+...') and what the parser checks
+//          at the end of the file (only blank lines after the last whole record).  Which line of its record a line is
+//          follows from the number of newlines in front of it: every reader counts its raw piece first and waits for
+//          the counts of the pieces before it.
+//   SAM    a line with at least 11 fields of str.split(): SEQ -> MG_THIN_MARK + len(SEQ) in decimal (a '*' stays),
+//          QUAL -> '*'; every other byte, white space included, is kept, so the tokeniser sees the same fields, the
+//          same errors and the same line numbers.  k_sam_parse takes the length from the mark (its `thin` flag).
+// A raw piece is read into the slot it will leave from, behind a little room, and thinned in place (the output never
+// overtakes the input: a FASTQ record shrinks, a SAM line grows by one byte only when SEQ and QUAL are one character
+// each); a reader owns the lines / records that START in its piece and reads on past its end to finish the last one.
+// OPT-IN (MG_STREAM_THIN=1).  Measured on the pool's 256-core hosts at 10M reads with 16 readers: the FASTQ stream 0.103 s thinned
+// against 0.079 s plain, the SAM command line 0.145 against 0.129 s — a reader thins ~1.8 GB/s (one memchr per line, twice: the
+// count and the walk) where it reads 12 GB/s, so the host side, not the link, becomes the bound.  It would pay with a line scanner
+// that takes 32 bytes per step (newline and white-space positions from one compare + movemask) or with 48+ readers.
+// ---------------------------------------------------------------------------------------------------------------------
+static inline bool h_is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+
+// first whitespace byte in [p, end), or end (the device's scan_to_ws: eight bytes per step)
+static inline const uint8_t* h_scan_to_ws(const uint8_t* p, const uint8_t* end) {
+  while (p + 8 <= end) {
+    uint64_t x;
+    memcpy(&x, p, 8);
+    uint64_t m = (x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull;
+    while (m) {
+      const unsigned b = (unsigned)__builtin_ctzll(m) >> 3;
+      if (h_is_ws((uint8_t)(x >> (8 * b)))) return p + b;
+      m &= m - 1;
+    }
+    p += 8;
+  }
+  while (p < end && !h_is_ws(*p)) ++p;
+  return p;
+}
+
+static inline uint64_t h_count_nl(const uint8_t* p, uint64_t n) {
+  uint64_t c = 0;
+  const uint8_t* e = p + n;
+  while (p < e) {
+    const uint8_t* q = static_cast<const uint8_t*>(memchr(p, '\n', (size_t)(e - p)));
+    if (!q) break;
+    ++c;
+    p = q + 1;
+  }
+  return c;
+}
+
+struct ThinSource : Source {
+  enum Kind { kFastq = 0, kSam = 1 };
+  int fd = -1;
+  Kind kind = kFastq;
+  uint64_t len = 0, raw = 0, npieces = 1;
+  static constexpr uint64_t kRoom = 4096;  // in front of the raw bytes: what a piece of absurd SAM lines may grow by
+  // FASTQ: newlines per raw piece, as the readers come to know them
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<int64_t> nl;
+  bool dead = false;  // a reader failed: nobody waits for its count
+  ~ThinSource() override { if (fd >= 0) close(fd); }
+  bool parallel() const override { return true; }
+
+  // the raw piece size for slots of `cap` bytes
+  static uint64_t raw_for(uint64_t cap) {
+    const uint64_t tail = cap / 4 > (4u << 20) ? (4u << 20) : cap / 4;
+    return cap > kRoom + tail + 1 ? cap - kRoom - tail : 1;
+  }
+  void setup(uint64_t file_len, uint64_t cap) {
+    len = file_len;
+    raw = raw_for(cap);
+    npieces = len ? (len + raw - 1) / raw : 1;
+    if (kind == kFastq) nl.assign(npieces, -1);
+  }
+  bool read_at(uint8_t* dst, uint64_t n, uint64_t at) {
+    uint64_t got = 0;
+    while (got < n) {
+      const ssize_t r = pread(fd, dst + got, n - got, (off_t)(at + got));
+      if (r < 0 && errno == EINTR) continue;
+      if (r < 0) { error = std::string("read failed: ") + strerror(errno); return false; }
+      if (r == 0) { error = "file is shorter than its size said"; return false; }
+      got += (uint64_t)r;
+    }
+    return true;
+  }
+  int64_t give_up(const std::string& why, int code = MG_ERR_ARG) {
+    error = why;
+    error_code = code;
+    { std::lock_guard<std::mutex> lk(m); dead = true; }
+    cv.notify_all();
+    return -1;
+  }
+
+  int64_t fill(uint64_t i, uint8_t* dst, uint64_t cap, bool* last) override {
+    *last = i + 1 >= npieces;
+    if (i >= npieces || len == 0) return 0;
+    const uint64_t a = i * raw, b = a + raw < len ? a + raw : len;
+    uint8_t* const in0 = dst + kRoom;          // raw byte a lands here; byte a - 1 right in front of it
+    uint64_t have = b - a;                     // raw bytes in the slot so far: [a, a + have)
+    if (a > 0) { if (!read_at(in0 - 1, have + 1, a - 1)) return give_up(error); }
+    else if (!read_at(in0, have, 0)) return give_up(error);
+    if (kind == kFastq) {
+      const int64_t c = (int64_t)h_count_nl(in0, have);
+      { std::lock_guard<std::mutex> lk(m); nl[i] = c; }
+      cv.notify_all();
+    }
+    // more of the file behind the piece, for the line / record that starts in it and ends after it
+    auto more = [&]() -> int {  // 1: got some, 0: end of the file, -1: no room / error
+      if (a + have >= len) return 0;
+      const uint64_t room = cap - kRoom - have;
+      if (room == 0) return -1;
+      uint64_t n = len - (a + have);
+      if (n > room) n = room;
+      if (n > (256u << 10)) n = 256u << 10;
+      if (!read_at(in0 + have, n, a + have)) return -1;
+      have += n;
+      return 1;
+    };
+    // end of the line that starts at in0 + s: offset of its '\n', or of the end of the file (*eof); -1: no room / error
+    auto line_end = [&](uint64_t s, bool* eof) -> int64_t {
+      *eof = false;
+      uint64_t from = s;
+      for (;;) {
+        const uint8_t* q = from < have ? static_cast<const uint8_t*>(memchr(in0 + from, '\n', (size_t)(have - from))) : nullptr;
+        if (q) return (int64_t)(q - in0);
+        from = have;
+        const int r = more();
+        if (r < 0) return -1;
+        if (r == 0) { *eof = true; return (int64_t)have; }
+      }
+    };
+    const auto too_long = [&]() {
+      return give_up(error.empty() ? "a record of more than " + std::to_string((unsigned long long)(cap - kRoom - raw)) +
+                                         " bytes past its piece does not fit the streaming pieces"
+                                   : error,
+                     error.empty() ? MG_ERR_CAPACITY : MG_ERR_ARG);
+    };
+    // the first line that starts in [a, b)
+    uint64_t s = 0;
+    bool fresh = a == 0 || in0[-1] == '\n';
+    if (!fresh) {
+      const uint8_t* q = static_cast<const uint8_t*>(memchr(in0, '\n', (size_t)(b - a)));
+      if (!q) return 0;  // one line runs through the whole piece: its owner is an earlier piece
+      s = (uint64_t)(q - in0) + 1;
+    }
+    uint8_t* out = dst;
+    if (kind == kSam) {
+      while (s < b - a) {
+        bool eof;
+        const int64_t e = line_end(s, &eof);
+        if (e < 0) return too_long();
+        const uint8_t *lb = in0 + s, *le = in0 + e;
+        const uint8_t *f9b = nullptr, *f9e = nullptr, *f10b = nullptr, *f10e = nullptr;
+        if (le > lb && *lb != '@') {
+          const uint8_t* p = lb;
+          int nf = 0;
+          while (nf < 11) {
+            while (p < le && h_is_ws(*p)) ++p;
+            if (p >= le) break;
+            const uint8_t* fb = p;
+            p = h_scan_to_ws(p, le);
+            if (nf == 9) { f9b = fb; f9e = p; }
+            if (nf == 10) { f10b = fb; f10e = p; }
+            ++nf;
+          }
+          if (nf < 11) f9b = nullptr;
+        }
+        if (f9b) {
+          const bool star = f9e - f9b == 1 && *f9b == '*';
+          char num[24];
+          const int nd = star ? 0 : snprintf(num, sizeof(num), "%llu", (unsigned long long)(f9e - f9b));
+          // every part is written at or below where it came from as long as the rewritten SEQ ends no later than the original did
+          // (it is longer only for a one-character SEQ: kRoom such lines per piece before this gives up)
+          if (out + (f9b - lb) + (star ? 1 : 1 + nd) > f9e) return give_up("a piece of SAM text grew while it was thinned");
+          memmove(out, lb, (size_t)(f9b - lb)); out += f9b - lb;
+          if (star) *out++ = '*';
+          else { *out++ = (uint8_t)MG_THIN_MARK; memcpy(out, num, (size_t)nd); out += nd; }
+          memmove(out, f9e, (size_t)(f10b - f9e)); out += f10b - f9e;
+          *out++ = '*';
+          memmove(out, f10e, (size_t)(le - f10e)); out += le - f10e;
+        } else {
+          memmove(out, lb, (size_t)(le - lb)); out += le - lb;
+        }
+        if (!eof) *out++ = '\n';
+        s = (uint64_t)e + 1;
+        if (eof) break;
+      }
+      return (int64_t)(out - dst);
+    }
+    // FASTQ: the index of the line at s = the newlines in front of it
+    uint64_t before = 0;
+    {
+      std::unique_lock<std::mutex> lk(m);
+      for (uint64_t j = 0; j < i; ++j) {
+        cv.wait(lk, [&] { return dead || nl[j] >= 0; });
+        if (dead) return -1;
+        before += (uint64_t)nl[j];
+      }
+    }
+    uint64_t L = before + (fresh ? 0 : 1);
+    while (s < b - a) {
+      bool eof = false;
+      if (L % 4 != 0) {  // a line of a record that an earlier piece owns
+        const int64_t e = line_end(s, &eof);
+        if (e < 0) return too_long();
+        if (eof) break;
+        s = (uint64_t)e + 1;
+        ++L;
+        continue;
+      }
+      uint64_t lb[4], le[4];
+      int k = 0;
+      uint64_t at = s;
+      for (; k < 4; ++k) {
+        if (k > 0 && at >= have) { const int r = more(); if (r < 0) return too_long(); if (r == 0) break; }
+        if (at >= have && a + have >= len) break;  // the file ended behind the last newline
+        const int64_t e = line_end(at, &eof);
+        if (e < 0) return too_long();
+        lb[k] = at; le[k] = (uint64_t)e;
+        at = (uint64_t)e + 1;
+        if (eof) { if (le[k] > lb[k]) ++k; break; }  // (nothing behind the last newline is not a line)
+      }
+      if (k < 4) {  // the end of the file inside a record: only blank lines may be left (the parser's rule)
+        for (int j = 0; j < k; ++j) {
+          const uint64_t n = le[j] - lb[j];
+          if (!(n == 0 || (n == 1 && in0[lb[j]] == '\r')))
+            return give_up("reads text: " + std::to_string((unsigned long long)(L + (uint64_t)k)) + " lines is not a whole number of 4-line records");
+        }
+        break;
+      }
+      auto stripped = [&](int j) { return le[j] > lb[j] && in0[le[j] - 1] == '\r' ? le[j] - 1 : le[j]; };
+      if (stripped(0) == lb[0] || in0[lb[0]] != '@' || stripped(2) == lb[2] || in0[lb[2]] != '+')
+        return give_up("reads file: malformed record " + std::to_string((unsigned long long)(L / 4)) + " (header / separator line)");
+      *out++ = '>';
+      *out++ = '\n';
+      memmove(out, in0 + lb[1], (size_t)(le[1] - lb[1]));
+      out += le[1] - lb[1];
+      *out++ = '\n';
+      s = at;
+      L += 4;
+      if (eof) break;
+    }
+    return (int64_t)(out - dst);
+  }
+};
+
 static bool looks_gzip(int fd) {
   uint8_t h[2];
   return pread(fd, h, 2, 0) == 2 && h[0] == 0x1f && h[1] == 0x8b;
@@ -353,7 +603,7 @@ static int run_pipeline(Source& src, uint64_t chunk_bytes, int nthreads, const C
       *bytes = ss.bytes;
       *last = ss.last;
     }
-    if (failed.load()) return fail(MG_ERR_ARG, "%s", src.error.empty() ? "reading the input failed" : src.error.c_str());
+    if (failed.load()) return fail(src.error_code, "%s", src.error.empty() ? "reading the input failed" : src.error.c_str());
     if (j >= 3) MG_HIP(hipStreamWaitEvent(r.copy, r.ev_parsed[b], 0));  // the buffer's previous piece has been parsed
     if (*bytes > 0)
       MG_HIP(hipMemcpyAsync(dtext[b].as<uint8_t>() + headroom, r.slots[s], (size_t)*bytes, hipMemcpyHostToDevice, r.copy));
@@ -411,7 +661,10 @@ static int run_pipeline(Source& src, uint64_t chunk_bytes, int nthreads, const C
 // *chunk_bytes: 0 = the default of the source's kind (32 MB: tools/stream_probe.py — 3.2 GB of FASTQ, 8 readers: 16 MB pieces
 // 0.089 s, 32 MB 0.071 s, 64 MB 0.067 s warm, but 0.105 against 0.122 s with the page-locked slots still to be allocated, which is
 // what a one-shot command line pays; BGZF 16 MB: many inflating threads, each with a slot).
-static int open_source(const char* path, uint64_t offset, uint64_t length, uint64_t* chunk_bytes, std::unique_ptr<Source>* out, bool* gz) {
+// thin_kind: -1, or what a plain file read from its first to its last byte may be thinned as (ThinSource::Kind); *thinned tells.
+static int open_source(const char* path, uint64_t offset, uint64_t length, uint64_t* chunk_bytes, std::unique_ptr<Source>* out, bool* gz,
+                       int thin_kind = -1, bool* thinned = nullptr) {
+  if (thinned) *thinned = false;
   const int fd = open(path, O_RDONLY);
   if (fd < 0) return fail(MG_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
   struct stat sb;
@@ -449,12 +702,35 @@ static int open_source(const char* path, uint64_t offset, uint64_t length, uint6
   }
   if (offset > fsize) { close(fd); return fail(MG_ERR_ARG, "offset beyond the end of %s", path); }
   if (!*chunk_bytes) *chunk_bytes = 32ull << 20;
+  if (thin_kind >= 0 && thinned && offset == 0 && length == 0) {
+    const char* e = getenv("MG_STREAM_THIN");
+    if (e && e[0] == '1') {  // opt-in: see the note at ThinSource
+      uint64_t cb = *chunk_bytes < (1u << 16) ? (1u << 16) : *chunk_bytes;  // (the pipeline's own rounding of the slot size)
+      cb = (cb + 4095) & ~4095ull;
+      std::unique_ptr<ThinSource> t(new ThinSource());
+      t->fd = fd;
+      t->kind = thin_kind == 0 ? ThinSource::kFastq : ThinSource::kSam;
+      t->setup(fsize, cb);
+      *thinned = true;
+      *out = std::move(t);
+      return MG_OK;
+    }
+  }
   std::unique_ptr<PlainSource> p(new PlainSource());
   p->fd = fd;
   p->off = offset;
   p->len = length ? (offset + length > fsize ? fsize - offset : length) : fsize - offset;
   *out = std::move(p);
   return MG_OK;
+}
+
+// Thinning is host work per byte (a reader does ~4 GB/s of it against ~12 GB/s of plain reads): twice the readers, when the
+// box has them and nobody fixed the number.
+static int thin_threads(int n) {
+  if (getenv("MG_STREAM_THREADS")) return n;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int want = n * 2;
+  return hw >= (unsigned)want * 2 ? want : n;
 }
 
 static int default_threads() {
@@ -477,15 +753,19 @@ int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format
   if (format < 0 || format > 2) return fail(MG_ERR_ARG, "format must be 0 (fastq), 1 (single-line fasta) or 2 (fasta)");
   std::unique_ptr<Source> src;
   bool gz = false;
-  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz));
+  bool thinned = false;
+  const bool auto_threads = nthreads <= 0;
+  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz, format == 0 ? (int)ThinSource::kFastq : -1, &thinned));
   if (nthreads <= 0) nthreads = default_threads();
   if (gz && src->parallel()) {  // BGZF: inflating is the work — every core the box has
     unsigned hw = std::thread::hardware_concurrency();
     if (!getenv("MG_STREAM_THREADS") && hw > (unsigned)nthreads) nthreads = (int)(hw > 32 ? 32 : hw);
   }
+  if (thinned && auto_threads) nthreads = thin_threads(nthreads);
+  const int dev_format = thinned ? 1 : format;  // (a thinned FASTQ piece is single-line FASTA: ">", the sequence line)
   Consumer consume = [&](const uint8_t* d_text, uint64_t nbytes, bool final, uint64_t* consumed) -> int {
     mg_reads* rd = nullptr;
-    MG_TRY(mg_reads_parse_prefix_dev(d_text, nbytes, format, final ? 1 : 0, consumed, &rd));
+    MG_TRY(mg_reads_parse_prefix_dev(d_text, nbytes, dev_format, final ? 1 : 0, consumed, &rd));
     const uint8_t* d_b = nullptr;
     const uint64_t* d_o = nullptr;
     int rc = mg_reads_device_ptrs(rd, &d_b, &d_o);
@@ -510,14 +790,17 @@ int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64
   if (err_line) *err_line = 0;
   std::unique_ptr<Source> src;
   bool gz = false;
-  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz));
+  bool thinned = false;
+  const bool auto_threads = nthreads <= 0;
+  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz, paf ? -1 : (int)ThinSource::kSam, &thinned));
   if (nthreads <= 0) nthreads = default_threads();
+  if (thinned && auto_threads) nthreads = thin_threads(nthreads);
   std::vector<std::unique_ptr<mg_sam_batch>> parts;
   std::string prev;
   uint64_t total = 0;
   Consumer consume = [&](const uint8_t* d_text, uint64_t nbytes, bool final, uint64_t* consumed) -> int {
     mg_sam_batch* b = nullptr;
-    MG_TRY(aln_tokenize_prefix_dev(d_text, nbytes, ix, prev.c_str(), paf != 0, final, consumed, &b, err_kind, err_line));
+    MG_TRY(aln_tokenize_prefix_dev(d_text, nbytes, ix, prev.c_str(), paf != 0, final, consumed, &b, err_kind, err_line, thinned));
     prev = b->last_qname;
     total += b->nrecs;
     parts.emplace_back(b);
@@ -542,6 +825,53 @@ int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64
   }
   *out = all.release();
   return MG_OK;
+}
+
+// What the file readers hand to the device for a plain FASTQ (kind 0) or SAM (kind 1) file, written to out_path instead: the
+// pieces of `piece_bytes` slots thinned by nthreads readers, in order.  Host code only (no device, no mg_init): the thinning can be
+// checked where there is no GPU.
+int mg_stream_thin_file(const char* path, int kind, uint64_t piece_bytes, int nthreads, const char* out_path) {
+  if (!path || !out_path) return fail(MG_ERR_ARG, "null argument");
+  if (kind != 0 && kind != 1) return fail(MG_ERR_ARG, "kind must be 0 (fastq) or 1 (sam)");
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(MG_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return fail(MG_ERR_ARG, "cannot stat %s", path); }
+  uint64_t cb = piece_bytes ? piece_bytes : (32ull << 20);
+  if (cb < (1u << 16)) cb = 1u << 16;
+  cb = (cb + 4095) & ~4095ull;
+  ThinSource t;
+  t.fd = fd;
+  t.kind = kind == 0 ? ThinSource::kFastq : ThinSource::kSam;
+  t.setup((uint64_t)sb.st_size, cb);
+  std::vector<std::vector<uint8_t>> outs(t.npieces);
+  std::atomic<uint64_t> next{0};
+  std::atomic<bool> failed{false};
+  auto work = [&]() {
+    std::vector<uint8_t> buf(cb);
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= t.npieces) return;
+      bool last = false;
+      const int64_t n = t.fill(i, buf.data(), cb, &last);
+      if (n < 0) { failed.store(true); return; }
+      outs[i].assign(buf.begin(), buf.begin() + n);
+    }
+  };
+  {
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::thread> th;
+    for (int k = 1; k < nthreads; ++k) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  }
+  if (failed.load()) return fail(t.error_code, "%s", t.error.empty() ? "thinning failed" : t.error.c_str());
+  FILE* fo = fopen(out_path, "wb");
+  if (!fo) return fail(MG_ERR_ARG, "cannot open %s: %s", out_path, strerror(errno));
+  bool ok = true;
+  for (auto& o : outs) ok = ok && (o.empty() || fwrite(o.data(), 1, o.size(), fo) == o.size());
+  ok = (fclose(fo) == 0) && ok;
+  return ok ? MG_OK : fail(MG_ERR_ARG, "writing %s failed", out_path);
 }
 
 }  // extern "C"

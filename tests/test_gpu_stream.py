@@ -139,10 +139,14 @@ def test_pieces_into_one_table_equal_the_whole(hip, oracle_lib, ks):
     assert np.array_equal(got[0][0], oh) and np.array_equal(got[0][1], oc)
 
 
+@pytest.mark.parametrize("thin", [False, True])
 @pytest.mark.parametrize("chunk", [1 << 16, 3 << 16, 64 << 20])
-def test_files_through_the_pipeline(hip, tmp_path, chunk):
+def test_files_through_the_pipeline(hip, tmp_path, chunk, thin, monkeypatch):
     """FASTQ (LF, CRLF, no final newline), wrapped FASTA, gzip (one member, several members), BGZF: every form of the same
-    reads through mg_sketch_stream_add_file in pieces of `chunk` bytes == the whole reads in one launch."""
+    reads through mg_sketch_stream_add_file in pieces of `chunk` bytes == the whole reads in one launch.  thin: the plain
+    FASTQ files thinned by the reader threads (MG_STREAM_THIN=1: a record goes up as ">" + its sequence line)."""
+    if thin:
+        monkeypatch.setenv("MG_STREAM_THIN", "1")
     ks = [21, 31, 51]
     gb, go, rb, ro = _sample(2, nreads=20000)
     tabs, hmaxs, filts = _tables(hip, gb, go, ks)
@@ -163,6 +167,8 @@ def test_files_through_the_pipeline(hip, tmp_path, chunk):
         "bgzf.fa.gz": ("fasta_ml", _bgzf(_fasta_ml(rb, ro))),
     }
     for name, (fmt, data) in forms.items():
+        if thin and not name.endswith(".fq"):
+            continue  # (only plain FASTQ is thinned)
         p = tmp_path / name
         p.write_bytes(data)
         for threads in (1, 5):
@@ -200,7 +206,10 @@ def test_byte_range_of_a_plain_file_and_empty_files(hip, tmp_path):
         stream.free()
 
 
-def test_what_the_pipeline_refuses(hip, tmp_path):
+@pytest.mark.parametrize("thin", [False, True])
+def test_what_the_pipeline_refuses(hip, tmp_path, thin, monkeypatch):
+    if thin:
+        monkeypatch.setenv("MG_STREAM_THIN", "1")  # (the readers' own checks then: same codes)
     ks = [21]
     gb, go, rb, ro = _sample(4, nreads=2000)
     tabs, hmaxs, filts = _tables(hip, gb, go, ks)
@@ -230,6 +239,14 @@ def test_what_the_pipeline_refuses(hip, tmp_path):
         stream.add_file(str(fa), "fasta_ml", chunk_bytes=1 << 16)
     assert e.value.code == _hip.ERR_CAPACITY
     stream.free()
+    # ... and a FASTQ record like that
+    lq = tmp_path / "long.fq"
+    lq.write_bytes(b"@a\n" + b"ACGT" * 40000 + b"\n+\n" + b"I" * 160000 + b"\n@b\nACGT\n+\nIIII\n")
+    stream = hip.sketch_stream(ks, hmaxs, 0, filts, expect_bases=200000)
+    with pytest.raises(_hip.HipError) as e:
+        stream.add_file(str(lq), "fastq", chunk_bytes=1 << 16)
+    assert e.value.code == _hip.ERR_CAPACITY
+    stream.free()
     # an undersized table (the estimate was far too small): reported at resolution, the hint reset
     os.environ["MG_DEBUG_DISTINCT_HINT"] = "0.00002"
     try:
@@ -248,10 +265,12 @@ def test_what_the_pipeline_refuses(hip, tmp_path):
     d_o.free()
 
 
-def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch):
+@pytest.mark.parametrize("thin", [False, True])
+def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch, thin):
     """select_main and map_main on files: the streamed pipelines (small chunks, so that every file is many pieces with
     carried records / lines) against round 2's whole-file path (MG_NO_STREAM=1) — CSV, subset db_info and CAMI file byte
-    for byte; the reads as plain FASTQ, gzip and BGZF."""
+    for byte; the reads as plain FASTQ, gzip and BGZF.  thin: the plain FASTQ and the SAM file thinned by the reader threads
+    (MG_STREAM_THIN=1; the tokeniser takes len(SEQ) from the mark the readers leave)."""
     import argparse
 
     import test_pipeline_gpu as tp
@@ -294,6 +313,8 @@ def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch):
     want_cami = profile(sam, sub_path, "whole")
     assert want_csv.count("\n") >= 3 and want_cami.count("\n") > 10
     monkeypatch.delenv("MG_NO_STREAM")
+    if thin:
+        monkeypatch.setenv("MG_STREAM_THIN", "1")
     for chunk in ("65536", "0"):
         monkeypatch.setenv("MG_STREAM_CHUNK_BYTES", chunk)
         for name, blob in files.items():
