@@ -17,6 +17,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 #include <atomic>
 #include <condition_variable>
@@ -229,10 +232,10 @@ struct BgzfSource : Source {
 // A raw piece is read into the slot it will leave from, behind a little room, and thinned in place (the output never
 // overtakes the input: a FASTQ record shrinks, a SAM line grows by one byte only when SEQ and QUAL are one character
 // each); a reader owns the lines / records that START in its piece and reads on past its end to finish the last one.
-// OPT-IN (MG_STREAM_THIN=1).  Measured on the pool's 256-core hosts at 10M reads with 16 readers: the FASTQ stream 0.103 s thinned
-// against 0.079 s plain, the SAM command line 0.145 against 0.129 s — a reader thins ~1.8 GB/s (one memchr per line, twice: the
-// count and the walk) where it reads 12 GB/s, so the host side, not the link, becomes the bound.  It would pay with a line scanner
-// that takes 32 bytes per step (newline and white-space positions from one compare + movemask) or with 48+ readers.
+// OPT-IN (MG_STREAM_THIN=1).  First form, measured on the pool's 256-core hosts at 10M reads with 16 readers: the FASTQ stream
+// 0.103 s thinned against 0.079 s plain, the SAM command line 0.145 against 0.129 s — a reader thinned ~1.8 GB/s (one memchr per
+// line, twice: the count and the walk; eight bytes per step through SEQ and QUAL) where it reads 12 GB/s, so the host side, not
+// the link, became the bound.  Hence CandIter: newline / white-space positions 32 bytes per step (one compare + movemask).
 // ---------------------------------------------------------------------------------------------------------------------
 static inline bool h_is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
@@ -253,17 +256,76 @@ static inline const uint8_t* h_scan_to_ws(const uint8_t* p, const uint8_t* end) 
   return p;
 }
 
+// ---- candidate positions, 32 bytes per step where the host has AVX2 ----
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define MG_HOST_AVX2 1
+__attribute__((target("avx2"))) static inline uint32_t mask32_eq(const uint8_t* p, uint8_t v) {
+  const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+  return (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, _mm256_set1_epi8((char)v)));
+}
+__attribute__((target("avx2"))) static inline uint32_t mask32_le(const uint8_t* p, uint8_t v) {
+  const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+  return (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_min_epu8(x, _mm256_set1_epi8((char)v)), x));
+}
+static bool host_has_avx2() {  // (MG_DEBUG_NO_AVX2=1: the byte-by-byte scanner, for the tests)
+  static const bool yes = __builtin_cpu_supports("avx2") && !(getenv("MG_DEBUG_NO_AVX2") && getenv("MG_DEBUG_NO_AVX2")[0] == '1');
+  return yes;
+}
+#endif
+
 static inline uint64_t h_count_nl(const uint8_t* p, uint64_t n) {
-  uint64_t c = 0;
-  const uint8_t* e = p + n;
-  while (p < e) {
-    const uint8_t* q = static_cast<const uint8_t*>(memchr(p, '\n', (size_t)(e - p)));
-    if (!q) break;
-    ++c;
-    p = q + 1;
-  }
+  uint64_t c = 0, i = 0;
+#ifdef MG_HOST_AVX2
+  if (host_has_avx2())
+    for (; i + 32 <= n; i += 32) c += (uint64_t)__builtin_popcount(mask32_eq(p + i, '\n'));
+#endif
+  for (; i < n; ++i) c += p[i] == '\n';
   return c;
 }
+
+// The positions in [*, *n) of the bytes that are '\n' (LE = false) or <= 0x20 (LE = true: every white-space byte of str.split()
+// is one, and a few control characters that are not), in ascending order.  *n may grow between calls (the reader reads on).
+template <bool LE>
+struct CandIter {
+  const uint8_t* base;
+  const uint64_t* n;
+  uint64_t pos;    // everything below pos has been looked at
+  uint64_t wbase = 0;
+  uint32_t mask = 0;
+  CandIter(const uint8_t* b, const uint64_t* nn, uint64_t from) : base(b), n(nn), pos(from) {}
+  // the next candidate at or after the last one returned + 1; *n when there is none (so far)
+  uint64_t next() {
+    for (;;) {
+      if (mask) {
+        const unsigned bit = (unsigned)__builtin_ctz(mask);
+        mask &= mask - 1;
+        return wbase + bit;
+      }
+#ifdef MG_HOST_AVX2
+      if (pos + 32 <= *n && host_has_avx2()) {
+        mask = LE ? mask32_le(base + pos, 0x20) : mask32_eq(base + pos, '\n');
+        wbase = pos;
+        pos += 32;
+        continue;
+      }
+#endif
+      while (pos < *n) {
+        const uint8_t c = base[pos++];
+        if (LE ? c <= 0x20 : c == '\n') return pos - 1;
+      }
+      return *n;
+    }
+  }
+  // forget what lies below `from` (the caller jumped ahead, e.g. past a record it has taken)
+  void skip_to(uint64_t from) {
+    if (from <= pos) {
+      if (mask && from > wbase) mask &= from - wbase >= 32 ? 0u : ~((1u << (from - wbase)) - 1u);
+    } else {
+      mask = 0;
+      pos = from;
+    }
+  }
+};
 
 struct ThinSource : Source {
   enum Kind { kFastq = 0, kSam = 1 };
@@ -290,21 +352,23 @@ struct ThinSource : Source {
     npieces = len ? (len + raw - 1) / raw : 1;
     if (kind == kFastq) nl.assign(npieces, -1);
   }
-  bool read_at(uint8_t* dst, uint64_t n, uint64_t at) {
+  bool read_at(uint8_t* dst, uint64_t n, uint64_t at, std::string* why) {
     uint64_t got = 0;
     while (got < n) {
       const ssize_t r = pread(fd, dst + got, n - got, (off_t)(at + got));
       if (r < 0 && errno == EINTR) continue;
-      if (r < 0) { error = std::string("read failed: ") + strerror(errno); return false; }
-      if (r == 0) { error = "file is shorter than its size said"; return false; }
+      if (r < 0) { *why = std::string("read failed: ") + strerror(errno); return false; }
+      if (r == 0) { *why = "file is shorter than its size said"; return false; }
       got += (uint64_t)r;
     }
     return true;
   }
   int64_t give_up(const std::string& why, int code = MG_ERR_ARG) {
-    error = why;
-    error_code = code;
-    { std::lock_guard<std::mutex> lk(m); dead = true; }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (!dead) { error = why; error_code = code; }  // (the first failure is the one reported)
+      dead = true;
+    }
     cv.notify_all();
     return -1;
   }
@@ -315,8 +379,9 @@ struct ThinSource : Source {
     const uint64_t a = i * raw, b = a + raw < len ? a + raw : len;
     uint8_t* const in0 = dst + kRoom;          // raw byte a lands here; byte a - 1 right in front of it
     uint64_t have = b - a;                     // raw bytes in the slot so far: [a, a + have)
-    if (a > 0) { if (!read_at(in0 - 1, have + 1, a - 1)) return give_up(error); }
-    else if (!read_at(in0, have, 0)) return give_up(error);
+    std::string io_error;  // (this call's own: `error` belongs to whichever reader failed first)
+    if (a > 0) { if (!read_at(in0 - 1, have + 1, a - 1, &io_error)) return give_up(io_error); }
+    else if (!read_at(in0, have, 0, &io_error)) return give_up(io_error);
     if (kind == kFastq) {
       const int64_t c = (int64_t)h_count_nl(in0, have);
       { std::lock_guard<std::mutex> lk(m); nl[i] = c; }
@@ -330,32 +395,18 @@ struct ThinSource : Source {
       uint64_t n = len - (a + have);
       if (n > room) n = room;
       if (n > (256u << 10)) n = 256u << 10;
-      if (!read_at(in0 + have, n, a + have)) return -1;
+      if (!read_at(in0 + have, n, a + have, &io_error)) return -1;
       have += n;
       return 1;
     };
-    // end of the line that starts at in0 + s: offset of its '\n', or of the end of the file (*eof); -1: no room / error
-    auto line_end = [&](uint64_t s, bool* eof) -> int64_t {
-      *eof = false;
-      uint64_t from = s;
-      for (;;) {
-        const uint8_t* q = from < have ? static_cast<const uint8_t*>(memchr(in0 + from, '\n', (size_t)(have - from))) : nullptr;
-        if (q) return (int64_t)(q - in0);
-        from = have;
-        const int r = more();
-        if (r < 0) return -1;
-        if (r == 0) { *eof = true; return (int64_t)have; }
-      }
-    };
     const auto too_long = [&]() {
-      return give_up(error.empty() ? "a record of more than " + std::to_string((unsigned long long)(cap - kRoom - raw)) +
-                                         " bytes past its piece does not fit the streaming pieces"
-                                   : error,
-                     error.empty() ? MG_ERR_CAPACITY : MG_ERR_ARG);
+      if (!io_error.empty()) return give_up(io_error);
+      return give_up("a record of more than " + std::to_string((unsigned long long)(cap - kRoom - raw)) +
+                         " bytes past its piece does not fit the streaming pieces", MG_ERR_CAPACITY);
     };
     // the first line that starts in [a, b)
     uint64_t s = 0;
-    bool fresh = a == 0 || in0[-1] == '\n';
+    const bool fresh = a == 0 || in0[-1] == '\n';
     if (!fresh) {
       const uint8_t* q = static_cast<const uint8_t*>(memchr(in0, '\n', (size_t)(b - a)));
       if (!q) return 0;  // one line runs through the whole piece: its owner is an earlier piece
@@ -363,44 +414,52 @@ struct ThinSource : Source {
     }
     uint8_t* out = dst;
     if (kind == kSam) {
+      CandIter<true> it(in0, &have, s);
       while (s < b - a) {
-        bool eof;
-        const int64_t e = line_end(s, &eof);
-        if (e < 0) return too_long();
-        const uint8_t *lb = in0 + s, *le = in0 + e;
-        const uint8_t *f9b = nullptr, *f9e = nullptr, *f10b = nullptr, *f10e = nullptr;
-        if (le > lb && *lb != '@') {
-          const uint8_t* p = lb;
-          int nf = 0;
-          while (nf < 11) {
-            while (p < le && h_is_ws(*p)) ++p;
-            if (p >= le) break;
-            const uint8_t* fb = p;
-            p = h_scan_to_ws(p, le);
-            if (nf == 9) { f9b = fb; f9e = p; }
-            if (nf == 10) { f10b = fb; f10e = p; }
+        // the line's fields = the gaps between its white-space bytes (str.split()); the line ends at its '\n' or with the file
+        const uint8_t* lb = in0 + s;
+        uint64_t prev = s;  // one past the last white-space byte seen (s: none yet)
+        int nf = 0;
+        uint64_t f9b = 0, f9e = 0, f10b = 0, f10e = 0, e = 0;
+        bool eof = false;
+        for (;;) {
+          uint64_t c = it.next();
+          if (c >= have) {
+            const int r = more();
+            if (r < 0) return too_long();
+            if (r > 0) continue;
+            eof = true;
+            c = have;
+          }
+          if (!eof && !h_is_ws(in0[c])) continue;  // (a control character inside a field)
+          if (c > prev) {
+            if (nf == 9) { f9b = prev; f9e = c; }
+            if (nf == 10) { f10b = prev; f10e = c; }
             ++nf;
           }
-          if (nf < 11) f9b = nullptr;
+          prev = c + 1;
+          if (eof || in0[c] == '\n') { e = c; break; }
         }
-        if (f9b) {
-          const bool star = f9e - f9b == 1 && *f9b == '*';
+        const uint8_t* le = in0 + e;
+        if (le > lb && *lb != '@' && nf >= 11) {
+          const uint8_t *p9b = in0 + f9b, *p9e = in0 + f9e, *p10b = in0 + f10b, *p10e = in0 + f10e;
+          const bool star = f9e - f9b == 1 && *p9b == '*';
           char num[24];
           const int nd = star ? 0 : snprintf(num, sizeof(num), "%llu", (unsigned long long)(f9e - f9b));
           // every part is written at or below where it came from as long as the rewritten SEQ ends no later than the original did
           // (it is longer only for a one-character SEQ: kRoom such lines per piece before this gives up)
-          if (out + (f9b - lb) + (star ? 1 : 1 + nd) > f9e) return give_up("a piece of SAM text grew while it was thinned");
-          memmove(out, lb, (size_t)(f9b - lb)); out += f9b - lb;
+          if (out + (p9b - lb) + (star ? 1 : 1 + nd) > p9e) return give_up("a piece of SAM text grew while it was thinned");
+          memmove(out, lb, (size_t)(p9b - lb)); out += p9b - lb;
           if (star) *out++ = '*';
           else { *out++ = (uint8_t)MG_THIN_MARK; memcpy(out, num, (size_t)nd); out += nd; }
-          memmove(out, f9e, (size_t)(f10b - f9e)); out += f10b - f9e;
+          memmove(out, p9e, (size_t)(p10b - p9e)); out += p10b - p9e;
           *out++ = '*';
-          memmove(out, f10e, (size_t)(le - f10e)); out += le - f10e;
+          memmove(out, p10e, (size_t)(le - p10e)); out += le - p10e;
         } else {
           memmove(out, lb, (size_t)(le - lb)); out += le - lb;
         }
         if (!eof) *out++ = '\n';
-        s = (uint64_t)e + 1;
+        s = e + 1;
         if (eof) break;
       }
       return (int64_t)(out - dst);
@@ -415,11 +474,23 @@ struct ThinSource : Source {
         before += (uint64_t)nl[j];
       }
     }
+    CandIter<false> it(in0, &have, s);
+    // end of the line the scanner stands in: offset of its '\n', or of the end of the file (*eof); -1: no room / error
+    auto line_end = [&](bool* eof) -> int64_t {
+      *eof = false;
+      for (;;) {
+        const uint64_t c = it.next();
+        if (c < have) return (int64_t)c;
+        const int r = more();
+        if (r < 0) return -1;
+        if (r == 0) { *eof = true; return (int64_t)have; }
+      }
+    };
     uint64_t L = before + (fresh ? 0 : 1);
     while (s < b - a) {
       bool eof = false;
       if (L % 4 != 0) {  // a line of a record that an earlier piece owns
-        const int64_t e = line_end(s, &eof);
+        const int64_t e = line_end(&eof);
         if (e < 0) return too_long();
         if (eof) break;
         s = (uint64_t)e + 1;
@@ -430,9 +501,7 @@ struct ThinSource : Source {
       int k = 0;
       uint64_t at = s;
       for (; k < 4; ++k) {
-        if (k > 0 && at >= have) { const int r = more(); if (r < 0) return too_long(); if (r == 0) break; }
-        if (at >= have && a + have >= len) break;  // the file ended behind the last newline
-        const int64_t e = line_end(at, &eof);
+        const int64_t e = line_end(&eof);
         if (e < 0) return too_long();
         lb[k] = at; le[k] = (uint64_t)e;
         at = (uint64_t)e + 1;

@@ -160,3 +160,17 @@ def test_sam_lines_that_grow_and_lines_longer_than_a_piece(tmp_path):
     assert run(tmp_path, "sam", text, 1 << 20) == thin_sam(text)
     # a line that runs through whole pieces: the pieces in between own no line start
     assert run(tmp_path, "sam", b"@CO\t" + b"x" * 400000 + b"\n" + one, 1 << 20) == b"@CO\t" + b"x" * 400000 + b"\n" + thin_sam(one)
+
+
+def test_the_byte_by_byte_scanner_gives_the_same(tmp_path):
+    """The scanners take 32 bytes per step where the host has AVX2; MG_DEBUG_NO_AVX2=1 (read once per process) selects the plain
+    loop: this module again in a process of its own."""
+    import subprocess
+    import sys
+    if os.environ.get("MG_DEBUG_NO_AVX2") == "1":
+        pytest.skip("already the plain loop")
+    env = dict(os.environ, MG_DEBUG_NO_AVX2="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-p", "no:cacheprovider",
+                        "-k", "not byte_by_byte"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
