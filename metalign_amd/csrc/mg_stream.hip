@@ -232,10 +232,12 @@ struct BgzfSource : Source {
 // A raw piece is read into the slot it will leave from, behind a little room, and thinned in place (the output never
 // overtakes the input: a FASTQ record shrinks, a SAM line grows by one byte only when SEQ and QUAL are one character
 // each); a reader owns the lines / records that START in its piece and reads on past its end to finish the last one.
-// OPT-IN (MG_STREAM_THIN=1).  First form, measured on the pool's 256-core hosts at 10M reads with 16 readers: the FASTQ stream
-// 0.103 s thinned against 0.079 s plain, the SAM command line 0.145 against 0.129 s — a reader thinned ~1.8 GB/s (one memchr per
-// line, twice: the count and the walk; eight bytes per step through SEQ and QUAL) where it reads 12 GB/s, so the host side, not
-// the link, became the bound.  Hence CandIter: newline / white-space positions 32 bytes per step (one compare + movemask).
+// OPT-IN (MG_STREAM_THIN=1), because it does not pay on the hosts it was measured on (profiles/r04/stream_ceilings.txt): the plain
+// streams run at ~50 GB/s of text, which is the PCIe link's rate AND about what these hosts read out of the page cache at all
+// (tools/pread_probe.py: 60 GB/s at four threads, less with more).  Thinning takes bytes off the link, not out of the page cache,
+// and adds work per byte: with the scanner below (newline / white-space positions 32 bytes per step; the first form, one memchr per
+// line, thinned 1.8 GB/s per reader) 16 readers draw level with 4 plain ones on FASTQ (0.066 s for 3.2 GB) and stay behind on SAM
+// (0.097 against 0.078 s for 3.7 GB).  On a host whose memory outruns its link it is one environment variable away.
 // ---------------------------------------------------------------------------------------------------------------------
 static inline bool h_is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
