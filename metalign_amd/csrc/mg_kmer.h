@@ -49,13 +49,45 @@ __device__ __forceinline__ uint64_t mul64c(uint64_t x) {
   const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
   constexpr uint32_t cl = (uint32_t)C, ch = (uint32_t)(C >> 32);
   uint64_t p, t, u, c0, c1, c2;  // (c*: the carry-outs nobody reads; any SGPR pair)
+#ifdef MG_MUL64_SPLIT
+  // Round 4, measured and NOT shipped (A/B build: -DMG_MUL64_SPLIT -DMG_MUL5_LSHL): the cross terms chained on their own (lo x hi,
+  // + hi x lo: the sum's low dword is what counts) and ONE 32-bit add onto the full product's high dword, in place — three
+  // v_mad_u64_u32 + v_add_u32 and no register moves, where the chained form below moves the full product's high dword into a
+  // register pair for the second multiply and the last result's low dword up (two v_mov_b32 per multiply).  With mul5_add's
+  // v_lshl_add_u64 form the one-k kernel's hot loop went from 432 to 400 VALU instructions per pair of positions (53 v_mov_b32 -> 1,
+  // 94 v_mad_u64_u32 -> 70, 15 v_lshl_add_u64 -> 39) and took exactly as long: 6.18 ms per 10M reads alone, 5.67 per pipelined pass
+  // (mode 1: 10.8 / 9.8).  The moves are not what the SIMDs wait for; the count of 64-bit operations (109 per pair either way) is.
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(c0) : "v"(xl), "s"(cl));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(t), "=s"(c1) : "v"(xl), "s"(ch));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(u), "=s"(c2) : "v"(xh), "s"(cl), "v"(t));
+  uint32_t hi;  // (opaque on purpose: as C the compiler makes it a 64-bit sum again — a move into a register pair + v_lshl_add_u64)
+  asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"((uint32_t)(p >> 32)), "v"((uint32_t)u));
+  return (uint64_t)(uint32_t)p | ((uint64_t)hi << 32);
+#else
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(c0) : "v"(xl), "s"(cl));
   const uint64_t hi0 = p >> 32;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(c1) : "v"(xl), "s"(ch), "v"(hi0));
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(u), "=s"(c2) : "v"(xh), "s"(cl), "v"(t));
   return (uint64_t)(uint32_t)p | (u << 32);
+#endif
 #else
   return x * C;
+#endif
+}
+
+// h * 5 + C (the end of a body block's h1 / h2 step).  The compiler's form: two v_mad_u64_u32 (low dword x 5 + C, high dword x 5
+// + the carry) and two register moves between their pairs; six per hash of a 51-mer.  MG_MUL5_LSHL (A/B builds): two
+// v_lshl_add_u64 — (h << 2) + h, then + C out of an SGPR pair — measured with MG_MUL64_SPLIT (see mul64c): no gain, not shipped.
+template <uint64_t C>
+__device__ __forceinline__ uint64_t mul5_add(uint64_t h) {
+#if defined(MG_MUL5_LSHL) && !defined(MG_HOST_CHECK)
+  uint64_t a, r;
+  constexpr uint64_t c = C;
+  asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(a) : "v"(h));
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(c));
+  return r;
+#else
+  return h * 5 + C;
 #endif
 }
 
@@ -179,9 +211,9 @@ __device__ __forceinline__ uint64_t murmur3_h1_packed(const Packed& p, const uin
     uint64_t k1 = key_word_times_c<K, 2 * B, 0>(p, tab);
     uint64_t k2 = key_word_times_c<K, 2 * B + 1, 1>(p, tab);
     k1 = rotl64(k1, 31); k1 = mul64c<C2>(k1); h1 ^= k1;
-    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = mul5_add<0x52dce729ULL>(h1);
     k2 = rotl64(k2, 33); k2 = mul64c<C1>(k2); h2 ^= k2;
-    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = mul5_add<0x38495ab5ULL>(h2);
   };
   [&]<int... B>(std::integer_sequence<int, B...>) { (body.template operator()<B>(), ...); }(std::make_integer_sequence<int, NBLK>{});
   if constexpr (TAIL > 8) {
