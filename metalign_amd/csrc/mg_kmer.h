@@ -35,7 +35,22 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 
 namespace mg {
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// rotl of a 64-bit value by a constant as two funnel shifts over its dwords (v_alignbit_b32: 2 x 4.2 issue cycles).  Written as
+// (x << r) | (x >> (64 - r)) the compiler made some of the hash's rotates a v_lshlrev_b64 + v_lshrrev_b64 + two v_or_b32 (12.9).
+// MG_ROTL_PLAIN (A/B builds) keeps the shifts.
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) {
+#ifndef MG_ROTL_PLAIN
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  r &= 63;
+  if (r >= 32) { const uint32_t t = lo; lo = hi; hi = t; r -= 32; }
+  if (r == 0) return (uint64_t)lo | ((uint64_t)hi << 32);
+  const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32u - (uint32_t)r);
+  const uint32_t nl = __builtin_amdgcn_alignbit(lo, hi, 32u - (uint32_t)r);
+  return (uint64_t)nl | ((uint64_t)nh << 32);
+#else
+  return (x << r) | (x >> (64 - r));
+#endif
+}
 
 // x * C mod 2^64 for a 64-bit constant as three chained v_mad_u64_u32 (lo x lo in full; + lo x hi; + hi x lo): 13.7 issue
 // cycles + two register moves (the chain's 64-bit addends want register pairs) against 17.3 for the compiler's form — v_mad_u64_u32 + 2 x v_mul_lo_u32 (the cross terms) + v_add3_u32
