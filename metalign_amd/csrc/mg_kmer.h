@@ -92,7 +92,10 @@ __device__ __forceinline__ uint64_t mul64c(uint64_t x) {
 
 // h * 5 + C (the end of a body block's h1 / h2 step).  The compiler's form: two v_mad_u64_u32 (low dword x 5 + C, high dword x 5
 // + the carry) and two register moves between their pairs; six per hash of a 51-mer.  MG_MUL5_LSHL (A/B builds): two
-// v_lshl_add_u64 — (h << 2) + h, then + C out of an SGPR pair — measured with MG_MUL64_SPLIT (see mul64c): no gain, not shipped.
+// v_lshl_add_u64 — (h << 2) + h, then + C out of an SGPR pair.  Measured on the kernel with the alignbit rotates, each change alone,
+// same run, pipelined pass per 10M reads: shipped 5.22 ms; this 5.32-5.36; MG_MUL64_SPLIT 5.44-5.52; low dword x 5 + C as one
+// v_mad_u64_u32 and the high dword's x 5 in 32-bit operations 5.39-5.45; the hash's 64-bit additions as v_add_co_u32 +
+// v_addc_co_u32 instead of v_lshl_add_u64 5.32-5.33.  The compiler's forms stay.
 template <uint64_t C>
 __device__ __forceinline__ uint64_t mul5_add(uint64_t h) {
 #if defined(MG_MUL5_LSHL) && !defined(MG_HOST_CHECK)
