@@ -363,6 +363,35 @@ void mg_gunzip_close(mg_gunzip* h);
  * failed[i] = 1 (failed may be null); the call still succeeds.  Plain host code: needs no device and no mg_init. */
 int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_path, int nthreads, uint64_t* bytes_out, uint8_t* failed);
 
+/* ------------------------------------------------------------------------ *
+ * gzip / BGZF inflated ON THE DEVICE (mg_inflate.hip): the compressed bytes cross the link, the text is born in HBM — the
+ * reference's `.fq.gz` reads (scripts/select_db.py:50-52,146-148 hands them to kmc) and `zcat` of genomes (:101-105).  One
+ * wavefront per job: a BGZF block, or a chunk of a gzip stream entered at a deflate block start found on the device, decoded
+ * to 16-bit symbols against the unknown 32 KB window, the windows chained and the symbols resolved by further kernels; every
+ * member's CRC-32 and ISIZE are checked (CRC computed on the device); trailing garbage after the last member is ignored as
+ * gzip does.  mg_sketch_stream_add_file / mg_sam_stream_file take this path for `.gz` input unless mg_inflate_config turns it
+ * off (then: the host inflater above).
+ *   mg_inflate_dev:   comp[ncomp] = a whole gzip file in host memory -> its text on the device (stream-ordered on the library
+ *                     stream; synchronised on return).  MG_ERR_ARG with zlib's wording in mg_last_error for a corrupt or
+ *                     truncated stream.
+ *   mg_inflate_config: chunk_bytes = compressed bytes per job of a gzip stream (default 32 KB), stage_bytes = compressed bytes
+ *                     decoded together (default 128 MB), ratio = symbols reserved per compressed byte (default 10; a job that
+ *                     needs more is decoded again), on = whether the streaming entry points use the device inflater; values
+ *                     <= 0 (on: < 0) leave a setting as it is.
+ *   mg_inflate_stats: counters since the last reset (host seconds of the stages' phases, jobs, jobs decoded again).
+ * ------------------------------------------------------------------------ */
+typedef struct mg_inflated mg_inflated;
+typedef struct mg_inflate_counters {
+  uint64_t stages, jobs, redone, find_candidates, find_steps;
+  double find_s, decode_s, resolve_s, stage_s;
+} mg_inflate_counters;
+int mg_inflate_dev(const uint8_t* comp, uint64_t ncomp, mg_inflated** out);
+uint64_t mg_inflated_bytes(const mg_inflated* t);
+int mg_inflated_download(const mg_inflated* t, uint8_t* dst);
+void mg_inflated_free(mg_inflated* t);
+int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on);
+int mg_inflate_stats(mg_inflate_counters* out, int reset);
+
 /* Diagnostic, host code only.  With MG_STREAM_THIN=1 in the environment mg_sketch_stream_add_file / mg_sam_stream_file THIN a
  * plain FASTQ / SAM file in their reader threads to what the device parsers read (a FASTQ record -> ">", its sequence line; a SAM
  * line with its SEQ field replaced by a mark + len(SEQ) and its QUAL by '*': from the page cache both files go up at the PCIe

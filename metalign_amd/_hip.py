@@ -37,6 +37,7 @@ EXPORTS = [
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
     "mg_sam_batch_last_qname", "mg_sam_batch_device_ptr", "mg_sam_batch_download", "mg_sam_batch_free",
     "mg_gunzip_open", "mg_gunzip_read", "mg_gunzip_close", "mg_zcat_files", "mg_stream_thin_file",
+    "mg_inflate_dev", "mg_inflated_bytes", "mg_inflated_download", "mg_inflated_free", "mg_inflate_config", "mg_inflate_stats",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
     "mg_sketch_genomes_kmers", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
@@ -96,6 +97,8 @@ def load_library(path=LIB_PATH):
     lib.mg_db_free.restype = None
     lib.mg_refdb_free.restype = None
     lib.mg_gunzip_close.restype = None
+    lib.mg_inflated_bytes.restype = ctypes.c_uint64
+    lib.mg_inflated_free.restype = None
     lib.mg_refdb_kmax_table.restype = ctypes.c_void_p
     lib.mg_refdb_ngenomes.restype = ctypes.c_uint64
     lib.mg_refdb_max_hash.restype = ctypes.c_uint64
@@ -907,6 +910,41 @@ class Hip:
         n, ms = ctypes.c_uint64(0), ctypes.c_double(0.0)
         self._chk(self.lib.mg_prof_get(kernel.encode(), ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
+
+    # ---- gzip / BGZF inflated on the device (mg_inflate.hip) ----
+    def inflate(self, blob):
+        """mg_inflate_dev + download: a whole gzip / BGZF file's bytes -> its text (every member; trailing garbage ignored), inflated
+        by the device.  OSError (zlib's wording) for a corrupt or truncated stream."""
+        src = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else np.ascontiguousarray(blob, dtype=np.uint8)
+        h = _vp()
+        rc = self.lib.mg_inflate_dev(_np(src if src.size else np.zeros(1, np.uint8), ctypes.c_uint8), ctypes.c_uint64(src.size), ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.mg_last_error().decode("utf-8", "replace")
+            if rc == ERR_ARG:
+                raise OSError(msg)
+            raise HipError("libmetalign_hip rc=%d: %s" % (rc, msg), rc)
+        try:
+            n = self.lib.mg_inflated_bytes(h)
+            out = np.empty(max(n, 1), dtype=np.uint8)
+            self._chk(self.lib.mg_inflated_download(h, _np(out, ctypes.c_uint8)))
+        finally:
+            self.lib.mg_inflated_free(h)
+        return out[:n].tobytes()
+
+    def inflate_config(self, chunk_bytes=0, stage_bytes=0, ratio=0, on=-1):
+        """mg_inflate_config: compressed bytes per job / per stage, symbols reserved per compressed byte, and whether `.gz` inputs of
+        the streaming entry points are inflated on the device (on = 1 / 0; -1 and 0 leave a setting as it is)."""
+        self._chk(self.lib.mg_inflate_config(ctypes.c_int64(int(chunk_bytes)), ctypes.c_int64(int(stage_bytes)), ctypes.c_int(int(ratio)), ctypes.c_int(int(on))))
+
+    def inflate_stats(self, reset=False):
+        """-> dict of the device inflater's counters since the last reset."""
+        class _C(ctypes.Structure):
+            _fields_ = [("stages", ctypes.c_uint64), ("jobs", ctypes.c_uint64), ("redone", ctypes.c_uint64), ("find_candidates", ctypes.c_uint64),
+                        ("find_steps", ctypes.c_uint64), ("find_s", ctypes.c_double),
+                        ("decode_s", ctypes.c_double), ("resolve_s", ctypes.c_double), ("stage_s", ctypes.c_double)]
+        c = _C()
+        self._chk(self.lib.mg_inflate_stats(ctypes.byref(c), ctypes.c_int(1 if reset else 0)))
+        return {k: getattr(c, k) for k, _ in _C._fields_}
 
     # ---- stage A ----
     def count_saturation(self, cs=None):

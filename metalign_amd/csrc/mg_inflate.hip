@@ -1,0 +1,970 @@
+// mg_inflate.hip — gzip / BGZF inflated ON THE DEVICE: compressed bytes cross PCIe, the text is born in HBM.
+//
+// The reference hands `.fq.gz` straight to kmc (scripts/select_db.py:50-52,146-148) and `zcat`s the selected genomes
+// (:101-105).  Round 4 inflated on host threads (mg_pgzip.hip: 2.5e7 reads/s, 3.16 GB of text over the link for 0.52 GB of
+// file).  Here the decoder of mg_inflate_core.h runs as one WAVEFRONT per job:
+//
+//   BGZF      every block says how long it is and how long its text is (the host walks the 18-byte headers): one job per block,
+//             bytes written straight to their place, CRC-32 per block on the device.
+//   gzip      the stream is cut into chunks of compressed bytes; k_find_block_starts finds in every chunk the first bit at which
+//             a dynamic-Huffman block plausibly starts (64 bit positions per step and wavefront: header fields + the code-length
+//             code's Kraft sum per lane, then the whole header by the wavefront); k_inflate<uint16_t> decodes from there to the
+//             next chunk's start with an UNKNOWN window (16-bit symbols: a byte, or "byte i of the 32 KB in front of me"); the
+//             host checks that every job ended exactly where the next one started (a job that started at a false positive is
+//             dropped and the hole decoded again); k_window_chain hands the 32 KB window from job to job (one workgroup, the
+//             window in LDS); k_resolve_text turns symbols into bytes at their final place; k_crc_segments + the host check
+//             every member's CRC-32 and ISIZE.
+//
+// A file goes through in STAGES of compressed bytes (default 128 MB: ~4000 jobs in flight), the next stage starting at the
+// bit where the previous one ended, with its window.  The compressed bytes go up through page-locked slots filled by reader
+// threads while earlier stages decode.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+
+#include "mg_inflate.h"
+#include "mg_inflate_core.h"
+
+namespace mg {
+using namespace mgi;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------------
+// chunk c (blockIdx.x + 1) of the stage: absolute bits [grid0 + c * chunk_bits, + chunk_bits) below limit_bit.  grid0 and
+// chunk_bits are multiples of 64.  starts[blockIdx.x] = first plausible block start in it behind min_bit, or ~0.
+__global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __restrict__ in, uint64_t nbytes, uint64_t grid0, uint64_t chunk_bits,
+                                                          uint64_t min_bit, uint64_t limit_bit, uint64_t* __restrict__ starts, uint32_t* __restrict__ info) {
+  __shared__ Shared sh;
+  const int lane = (int)threadIdx.x;
+  DevExec ex{&sh, lane};
+  const uint64_t nwords = (nbytes + 3) / 4, nbits = nbytes * 8;
+  const uint64_t lo = grid0 + (uint64_t)(blockIdx.x + 1) * chunk_bits;
+  uint64_t hi = lo + chunk_bits;
+  if (hi > limit_bit) hi = limit_bit;
+  uint64_t found = ~0ull;
+  uint32_t ncand = 0, nsteps = 0;
+  for (uint64_t p0 = lo; p0 < hi && found == ~0ull; p0 += 64) {
+    ++nsteps;
+    const uint64_t w = p0 >> 5;
+    uint32_t a[5];
+    for (uint32_t i = 0; i < 5; ++i) a[i] = w + i < nwords ? MGI_UNI(in[w + i]) : 0u;
+    const bool up = lane >= 32;
+    const uint32_t t = (uint32_t)lane & 31u;
+    const uint64_t x0 = (uint64_t)(up ? a[1] : a[0]) | (uint64_t)(up ? a[2] : a[1]) << 32;
+    const uint64_t x1 = (uint64_t)(up ? a[3] : a[2]) | (uint64_t)(up ? a[4] : a[3]) << 32;
+    const uint64_t blo = t ? (x0 >> t) | (x1 << (64 - t)) : x0, bhi = x1 >> t;
+    const uint64_t p = p0 + (uint64_t)lane;
+    const bool ok = p < hi && p > min_bit && p + 80 <= nbits && probe_bits(blo, bhi);
+    uint64_t m = __ballot(ok);
+    while (m) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1;
+      ++ncand;
+      if (validate_block_start(ex, sh, in, nbytes, p0 + l)) { found = p0 + l; break; }
+    }
+  }
+  if (lane == 0) {
+    starts[blockIdx.x] = found;
+    info[2 * blockIdx.x] = ncand;
+    info[2 * blockIdx.x + 1] = nsteps;
+  }
+}
+
+template <class OutT>
+__global__ __launch_bounds__(64) void k_inflate(const uint32_t* __restrict__ in, uint64_t nbytes, int input_final, const Job* __restrict__ jobs,
+                                                OutT* out, Result* __restrict__ results, Event* events, uint32_t* nevents, uint32_t max_events,
+                                                uint16_t* tails) {
+  __shared__ Shared sh;
+  DevExec ex{&sh, (int)threadIdx.x};
+  const uint32_t j = blockIdx.x;
+  Job job;
+  job.start_bit = jobs[j].start_bit;
+  job.stop_bit = jobs[j].stop_bit;
+  job.out_off = jobs[j].out_off;
+  job.out_cap = jobs[j].out_cap;
+  job.flags = jobs[j].flags;
+  job.pad = 0;
+  run_job<DevExec, OutT>(ex, sh, in, nbytes, input_final != 0, job, j, out + job.out_off, &results[j], events, nevents, max_events,
+                         tails ? tails + (uint64_t)j * kWindow : nullptr);
+}
+
+// The window from job to job.  Every job has left the window behind it AS FAR AS IT KNOWS IT (tail: 32768 symbols, window
+// symbols where it depends on what was in front of the job).  Resolving that is a chain through all jobs; it is cut into
+// groups of K jobs: k_chain_groups (a workgroup per group, the previous row in LDS) composes the rows of a group relative to the
+// window in front of the GROUP; k_chain_tops (one workgroup) resolves the last row of every group from group to group;
+// k_chain_rows resolves every row against its group's incoming window, all at once.  wins: (njobs + 1) rows of 32 KB bytes, row j =
+// the window in front of job j (row 0 given).
+struct ChainJob { const uint16_t* sym; const uint16_t* tail; uint64_t n; uint64_t t_off; uint64_t tile0; };
+struct alignas(16) U16x8 { uint16_t v[8]; };
+struct alignas(16) U8x16 { uint8_t v[16]; };
+
+__global__ __launch_bounds__(1024) void k_chain_groups(const ChainJob* __restrict__ jobs, uint32_t njobs, uint32_t K, uint16_t* __restrict__ comp) {
+  extern __shared__ uint16_t L16[];  // 2 x 32768 symbols
+  const uint32_t t = threadIdx.x;
+  const uint32_t j0 = blockIdx.x * K;
+  uint32_t j1 = j0 + K;
+  if (j1 > njobs) j1 = njobs;
+  uint16_t* prev = L16;
+  uint16_t* now = L16 + kWindow;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    U16x8 x;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) x.v[k] = (uint16_t)(0x8000u | (32u * t + 8u * i + k));
+    *reinterpret_cast<U16x8*>(prev + 32u * t + 8u * i) = x;
+  }
+  U16x8 cur[4], nxt[4];
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) cur[i] = *reinterpret_cast<const U16x8*>(jobs[j0].tail + 32u * t + 8u * i);
+  __syncthreads();
+  for (uint32_t j = j0; j < j1; ++j) {
+    if (j + 1 < j1) {
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const U16x8*>(jobs[j + 1].tail + 32u * t + 8u * i);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t v = cur[i].v[k];
+        if (v & 0x8000u) cur[i].v[k] = prev[v & 0x7fffu];
+      }
+      *reinterpret_cast<U16x8*>(now + 32u * t + 8u * i) = cur[i];
+      *reinterpret_cast<U16x8*>(comp + (uint64_t)j * kWindow + 32u * t + 8u * i) = cur[i];
+    }
+    __syncthreads();
+    uint16_t* sw = prev; prev = now; now = sw;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) cur[i] = nxt[i];
+  }
+}
+
+// tops: (G + 1) rows of bytes; row 0 = the window in front of the stage (given), row g + 1 = behind group g
+__global__ __launch_bounds__(1024) void k_chain_tops(const uint16_t* __restrict__ comp, uint32_t njobs, uint32_t K, uint32_t G, uint8_t* tops) {
+  extern __shared__ uint8_t L8[];  // 2 x 32 KB
+  const uint32_t t = threadIdx.x;
+  *reinterpret_cast<U8x16*>(L8 + 32u * t) = *reinterpret_cast<const U8x16*>(tops + 32u * t);
+  *reinterpret_cast<U8x16*>(L8 + 32u * t + 16u) = *reinterpret_cast<const U8x16*>(tops + 32u * t + 16u);
+  auto last = [&](uint32_t g) { const uint32_t e = (g + 1) * K; return (e < njobs ? e : njobs) - 1u; };
+  U16x8 cur[4], nxt[4];
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) cur[i] = *reinterpret_cast<const U16x8*>(comp + (uint64_t)last(0) * kWindow + 32u * t + 8u * i);
+  __syncthreads();
+  for (uint32_t g = 0; g < G; ++g) {
+    if (g + 1 < G) {
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const U16x8*>(comp + (uint64_t)last(g + 1) * kWindow + 32u * t + 8u * i);
+    }
+    const uint8_t* prev = L8 + (g & 1u) * kWindow;
+    uint8_t* now = L8 + ((g + 1) & 1u) * kWindow;
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+      U8x16 r;
+#pragma unroll
+      for (uint32_t k = 0; k < 16; ++k) {
+        const uint32_t v = cur[2 * h + (k >> 3)].v[k & 7u];
+        r.v[k] = v & 0x8000u ? prev[v & 0x7fffu] : (uint8_t)v;
+      }
+      *reinterpret_cast<U8x16*>(now + 32u * t + 16u * h) = r;
+      *reinterpret_cast<U8x16*>(tops + (uint64_t)(g + 1) * kWindow + 32u * t + 16u * h) = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) cur[i] = nxt[i];
+  }
+}
+
+// wins row j + 1 = comp row j resolved against the window in front of j's group; one thread makes 16 bytes
+__global__ __launch_bounds__(256) void k_chain_rows(const uint16_t* __restrict__ comp, uint32_t njobs, uint32_t K, const uint8_t* __restrict__ tops,
+                                                    uint8_t* __restrict__ wins) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // 16-byte piece
+  const uint64_t j = i / (kWindow / 16);
+  if (j >= njobs) return;
+  const uint32_t w0 = (uint32_t)(i % (kWindow / 16)) * 16u;
+  const uint8_t* top = tops + (uint64_t)(j / K) * kWindow;
+  const U16x8 a = *reinterpret_cast<const U16x8*>(comp + j * kWindow + w0), b = *reinterpret_cast<const U16x8*>(comp + j * kWindow + w0 + 8);
+  U8x16 r;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; ++k) {
+    const uint32_t v = k < 8 ? a.v[k] : b.v[k - 8];
+    r.v[k] = v & 0x8000u ? top[v & 0x7fffu] : (uint8_t)v;
+  }
+  *reinterpret_cast<U8x16*>(wins + (j + 1) * kWindow + w0) = r;
+}
+
+// symbols -> bytes at their final place.  A block makes one tile of 4096 text bytes of one job (tiles on a 16-byte grid of the
+// text, so that full tiles leave as 16-byte stores); jobs[j].tile0 = the first tile of job j.
+__global__ __launch_bounds__(256) void k_resolve_text(const ChainJob* __restrict__ jobs, uint32_t njobs, const uint8_t* __restrict__ wins,
+                                                      uint8_t* __restrict__ text) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[4096];
+  const uint32_t t = threadIdx.x;
+  const uint64_t b = blockIdx.x;
+  uint32_t lo = 0, hi = njobs;  // last job with tile0 <= b
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (jobs[mid].tile0 <= b) lo = mid; else hi = mid;
+  }
+  const uint32_t j = lo;
+  const uint64_t t_off = jobs[j].t_off, n = jobs[j].n;
+  const uint16_t* sym = jobs[j].sym;
+  const uint8_t* win = wins + (uint64_t)j * kWindow;
+  const uint64_t T0 = (t_off & ~15ull) + (b - jobs[j].tile0) * 4096ull;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; ++k) {
+    const uint64_t e = T0 + k * 256u + t;
+    uint8_t r = 0;
+    if (e >= t_off && e < t_off + n) {
+      const uint32_t v = sym[e - t_off];
+      r = v < 256u ? (uint8_t)v : win[v & 0x7fffu];
+    }
+    tile[k * 256u + t] = r;
+  }
+  __syncthreads();
+  const uint64_t e0 = T0 + 16ull * t;
+  if (e0 >= t_off && e0 + 16 <= t_off + n) {
+    *reinterpret_cast<uint4*>(text + e0) = *reinterpret_cast<const uint4*>(tile + 16u * t);
+  } else {
+    for (uint32_t i = 0; i < 16; ++i)
+      if (e0 + i >= t_off && e0 + i < t_off + n) text[e0 + i] = tile[16u * t + i];
+  }
+}
+
+// CRC-32 of segments of the text, one wavefront per segment: the segment is laid out right-aligned over 64 equal slices (a CRC
+// register that starts at 0 does not see leading zeros), a slice per lane with four table look-ups per word, the lanes combined
+// by multiplying with x^(8 * slice) mod p; the initial and final inversions are put in at the end.
+struct CrcSeg { uint64_t start, len; };
+struct X2N { uint32_t v[32]; };
+__global__ __launch_bounds__(256) void k_crc_segments(const uint8_t* __restrict__ text, const CrcSeg* __restrict__ segs, uint32_t nsegs,
+                                                      uint32_t* __restrict__ crcs, X2N x2n) {
+  __shared__ uint32_t T[4][256];
+  const uint32_t t = threadIdx.x;
+  {
+    uint32_t c = t;
+    for (int k = 0; k < 8; ++k) c = c & 1u ? (c >> 1) ^ kCrcPoly : c >> 1;
+    T[0][t] = c;
+    __syncthreads();
+    for (int s = 1; s < 4; ++s) {
+      T[s][t] = (T[s - 1][t] >> 8) ^ T[0][T[s - 1][t] & 0xffu];
+      __syncthreads();
+    }
+  }
+  const uint32_t seg = blockIdx.x * 4u + (t >> 6), lane = t & 63u;
+  if (seg >= nsegs) return;
+  const uint64_t start = segs[seg].start, len = segs[seg].len;
+  const uint64_t L = (((len + 63) / 64) + 3) & ~3ull;
+  const int64_t V = (int64_t)(start + len) - (int64_t)(64 * L);
+  int64_t a = V + (int64_t)(lane * L), b = a + (int64_t)L;
+  if (a < (int64_t)start) a = (int64_t)start;
+  uint32_t c = 0;
+  if (a < b) {
+    const uint8_t* p = text + a;
+    const uint8_t* e = text + b;
+    while (p < e && ((uintptr_t)p & 3u)) c = T[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+    for (; p + 4 <= e; p += 4) {
+      c ^= *reinterpret_cast<const uint32_t*>(p);
+      c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
+    }
+    while (p < e) c = T[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+  }
+  uint32_t X = crc_x8n(L, x2n.v);
+  for (uint32_t s = 0; s < 6; ++s) {
+    const uint32_t other = (uint32_t)__shfl_down((int)c, 1u << s, 64);
+    c = crc_multmodp(X, c) ^ other;
+    X = crc_multmodp(X, X);
+  }
+  if (lane == 0) crcs[seg] = c ^ crc_multmodp(crc_x8n(len, x2n.v), 0xffffffffu) ^ 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// configuration (mg_inflate_config) and counters (mg_inflate_stats)
+// ---------------------------------------------------------------------------------------------------------------------
+struct InflateConfig {
+  uint64_t chunk_bytes = 32u << 10;   // compressed bytes per job of a gzip stream
+  uint64_t stage_bytes = 128u << 20;  // compressed bytes per stage
+  uint32_t ratio = 10;                // symbols reserved per compressed byte of a job (a job that needs more is decoded again)
+  int on = 1;                         // .gz files of the streaming entry points take the device inflater
+};
+static InflateConfig g_cfg;
+static mg_inflate_counters g_cnt;
+InflateConfig& inflate_cfg() { return g_cfg; }
+bool inflate_dev_enabled() { return g_cfg.on != 0; }
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the compressed bytes: file -> page-locked slots (reader threads) -> device, in order, while the stages run
+// ---------------------------------------------------------------------------------------------------------------------
+struct CompUploader {
+  static constexpr uint64_t kPiece = 16ull << 20;
+  static constexpr size_t kSlots = 6;
+  const uint8_t* src = nullptr;   // host bytes (a mapped file, or the caller's buffer)
+  uint64_t n = 0;
+  uint8_t* d_comp = nullptr;
+  uint64_t npieces = 0;
+  hipStream_t copy = nullptr;
+  std::vector<uint8_t*> slots;
+  std::vector<hipEvent_t> ev_piece;  // piece i is on the device
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<int> filled;           // piece i is in its slot
+  uint64_t queued = 0;               // pieces whose DMA has been queued
+  std::atomic<uint64_t> next{0};
+  bool stop = false, failed = false;
+  std::vector<std::thread> readers;
+  std::thread dma;
+  int device = 0;
+
+  ~CompUploader() { finish(); }
+  void finish() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : readers) if (t.joinable()) t.join();
+    if (dma.joinable()) dma.join();
+    readers.clear();
+    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); copy = nullptr; }
+    for (uint8_t* p : slots) (void)hipHostFree(p);
+    slots.clear();
+    for (hipEvent_t e : ev_piece) (void)hipEventDestroy(e);
+    ev_piece.clear();
+  }
+  int start(const uint8_t* s, uint64_t nbytes, uint8_t* d, int nthreads) {
+    src = s; n = nbytes; d_comp = d;
+    device = ctx().device;
+    npieces = (n + kPiece - 1) / kPiece;
+    if (npieces == 0) return MG_OK;
+    MG_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    const size_t ns = npieces < kSlots ? (size_t)npieces : kSlots;
+    for (size_t i = 0; i < ns; ++i) {
+      uint8_t* p = nullptr;
+      MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), kPiece, hipHostMallocDefault));
+      slots.push_back(p);
+    }
+    for (uint64_t i = 0; i < npieces; ++i) {
+      hipEvent_t e = nullptr;
+      MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev_piece.push_back(e);
+    }
+    filled.assign(npieces, 0);
+    if (nthreads < 1) nthreads = 1;
+    if ((uint64_t)nthreads > ns) nthreads = (int)ns;
+    for (int t = 0; t < nthreads; ++t) readers.emplace_back([this] { read_loop(); });
+    dma = std::thread([this] { dma_loop(); });
+    return MG_OK;
+  }
+  void read_loop() {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= npieces) return;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || i < queued + slots.size(); });  // the slot's previous piece has been queued ...
+        if (stop) return;
+      }
+      if (i >= slots.size()) (void)hipEventSynchronize(ev_piece[i - slots.size()]);  // ... and has left it
+      const uint64_t at = i * kPiece, len = std::min(kPiece, n - at);
+      memcpy(slots[i % slots.size()], src + at, len);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        filled[i] = 1;
+      }
+      cv.notify_all();
+    }
+  }
+  void dma_loop() {
+    (void)hipSetDevice(device);
+    for (uint64_t i = 0; i < npieces; ++i) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || filled[i]; });
+        if (stop) return;
+      }
+      const uint64_t at = i * kPiece, len = std::min(kPiece, n - at);
+      bool ok = hipMemcpyAsync(d_comp + at, slots[i % slots.size()], len, hipMemcpyHostToDevice, copy) == hipSuccess;
+      ok = ok && hipEventRecord(ev_piece[i], copy) == hipSuccess;
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (!ok) failed = true;
+        queued = i + 1;
+      }
+      cv.notify_all();
+      if (!ok) return;
+    }
+  }
+  // makes `st` wait until the first `bytes` compressed bytes are on the device
+  int need(uint64_t bytes, hipStream_t st) {
+    if (bytes == 0 || npieces == 0) return MG_OK;
+    if (bytes > n) bytes = n;
+    const uint64_t last = (bytes - 1) / kPiece;
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return failed || queued > last; });
+      if (failed) return fail(MG_ERR_HIP, "uploading the compressed bytes failed");
+    }
+    MG_HIP(hipStreamWaitEvent(st, ev_piece[last], 0));
+    return MG_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the inflater
+// ---------------------------------------------------------------------------------------------------------------------
+struct BgzfBlock { uint64_t coff; uint32_t csize, isize, hdr; };
+
+static bool bgzf_index(const uint8_t* h, uint64_t n, std::vector<BgzfBlock>* blocks) {
+  uint64_t at = 0;
+  while (at < n) {
+    if (n - at < 28) return false;
+    const uint8_t* p = h + at;
+    if (!(p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && (p[3] & 4) && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0)) return false;
+    if (p[3] != 4) return false;  // (only the extra field: what bgzip / htslib write)
+    const uint32_t xlen = (uint32_t)(p[10] | (p[11] << 8));
+    if (xlen != 6) return false;
+    const uint32_t csize = (uint32_t)(p[16] | (p[17] << 8)) + 1u;
+    if (csize < 26 || at + csize > n) return false;
+    const uint8_t* tl = h + at + csize - 4;
+    const uint32_t isize = (uint32_t)tl[0] | ((uint32_t)tl[1] << 8) | ((uint32_t)tl[2] << 16) | ((uint32_t)tl[3] << 24);
+    if (isize > 65536u) return false;
+    blocks->push_back(BgzfBlock{at, csize, isize, 12u + xlen});
+    at += csize;
+  }
+  return true;
+}
+
+static const char* status_text(uint32_t st) {
+  switch (st) {
+    case ST_TRUNC: return "the gzip stream ends inside a member (truncated file)";
+    case ST_BAD_BLOCK: return "corrupt deflate data: invalid block type";
+    case ST_BAD_STORED: return "corrupt deflate data: invalid stored block lengths";
+    case ST_BAD_CODES: return "corrupt deflate data: invalid code lengths set";
+    case ST_BAD_SYMBOL: return "corrupt deflate data: invalid literal/length or distance code";
+    case ST_BAD_DIST: return "corrupt deflate data: invalid distance too far back";
+    case ST_BAD_HEADER: return "not in gzip format";
+    case ST_EVENTS_FULL: return "more gzip members in one stage than the inflater keeps track of";
+    default: return "unexpected decoder state";
+  }
+}
+
+struct DevInflater {
+  const uint8_t* h = nullptr;  // the compressed bytes on the host
+  uint64_t n = 0;
+  DevBuf comp;                 // ... and on the device (whole file)
+  CompUploader up;
+  hipStream_t st = nullptr;
+  bool bgzf = false;
+  std::vector<BgzfBlock> blocks;
+  uint64_t next_block = 0;
+  // gzip: where the next stage starts
+  uint64_t next_bit = 0;
+  bool first = true, done = false;
+  DevBuf win;                  // the 32 KB in front of next_bit
+  uint32_t mcrc = 0;           // the open member: CRC and length of what has been produced of it
+  uint64_t mlen = 0;
+  uint32_t x2n[32];
+  std::vector<std::pair<uint64_t, uint32_t>> x8n_cache;  // (length, x^(8 length) mod p)
+
+  int open(const uint8_t* host, uint64_t nbytes, int upload_threads) {
+    h = host;
+    n = nbytes;
+    st = ctx().stream;
+    crc_make_x2n(x2n);
+    if (n < 2 || !(h[0] == 0x1f && h[1] == 0x8b)) return fail(MG_ERR_ARG, "%s", status_text(ST_BAD_HEADER));
+    if (n < 18) return fail(MG_ERR_ARG, "%s", status_text(ST_TRUNC));
+    bgzf = bgzf_index(h, n, &blocks);
+    if (!bgzf) blocks.clear();
+    MG_TRY(comp.alloc(((n + 3) & ~3ull) + 64));
+    // (the bytes behind the file's end inside its last word are read by nobody: BitReader::load is bounded by words, the decoder by bits)
+    MG_HIP(hipMemsetAsync(comp.as<uint8_t>() + (n & ~3ull), 0, 64, st));
+    MG_HIP(hipStreamSynchronize(st));
+    MG_TRY(up.start(h, n, comp.as<uint8_t>(), upload_threads));
+    MG_TRY(win.alloc(kWindow));
+    MG_HIP(hipMemsetAsync(win.p, 0, kWindow, st));
+    return MG_OK;
+  }
+
+  uint32_t x8n(uint64_t len) {
+    for (auto& e : x8n_cache) if (e.first == len) return e.second;
+    const uint32_t v = crc_x8n(len, x2n);
+    if (x8n_cache.size() < 8) x8n_cache.emplace_back(len, v);
+    return v;
+  }
+
+  // CRC-32 of text[seg] for every segment -> host
+  int crc_of(const uint8_t* d_text, const std::vector<CrcSeg>& segs, std::vector<uint32_t>* out) {
+    out->assign(segs.size(), 0);
+    if (segs.empty()) return MG_OK;
+    DevBuf dsegs, dcrc;
+    MG_TRY(dsegs.alloc(segs.size() * sizeof(CrcSeg)));
+    MG_TRY(dcrc.alloc(segs.size() * 4));
+    MG_HIP(hipMemcpyAsync(dsegs.p, segs.data(), segs.size() * sizeof(CrcSeg), hipMemcpyHostToDevice, st));
+    X2N x;
+    memcpy(x.v, x2n, sizeof(x2n));
+    {
+      ProfScope ps("k_crc_segments", st);
+      k_crc_segments<<<(unsigned)((segs.size() + 3) / 4), 256, 0, st>>>(d_text, dsegs.as<CrcSeg>(), (uint32_t)segs.size(), dcrc.as<uint32_t>(), x);
+    }
+    MG_HIP(hipMemcpyAsync(out->data(), dcrc.p, segs.size() * 4, hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    return MG_OK;
+  }
+
+  // ---- BGZF: a stage = consecutive blocks of at most text_cap bytes of text ----
+  int stage_bgzf(uint64_t headroom, uint64_t text_cap, DevBuf* text, uint64_t* ntext, bool* finished) {
+    const uint64_t b0 = next_block;
+    uint64_t b1 = b0, bytes = 0;
+    while (b1 < blocks.size() && (b1 == b0 || bytes + blocks[b1].isize <= text_cap) && b1 - b0 < (1u << 20)) bytes += blocks[b1++].isize;
+    const uint64_t nj = b1 - b0;
+    MG_TRY(text->alloc(headroom + bytes + 64));
+    *ntext = bytes;
+    next_block = b1;
+    *finished = b1 >= blocks.size();
+    if (nj == 0) return MG_OK;
+    std::vector<Job> jobs(nj);
+    std::vector<CrcSeg> segs(nj);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < nj; ++i) {
+      const BgzfBlock& b = blocks[b0 + i];
+      jobs[i] = Job{(b.coff + b.hdr) * 8, ~0ull, at, b.isize, F_ONE_MEMBER | F_MEMBER_START, 0};
+      segs[i] = CrcSeg{headroom + at, b.isize};
+      at += b.isize;
+    }
+    MG_TRY(up.need(blocks[b1 - 1].coff + blocks[b1 - 1].csize, st));
+    DevBuf djobs, dres, dev;
+    MG_TRY(djobs.alloc(nj * sizeof(Job)));
+    MG_TRY(dres.alloc(nj * sizeof(Result)));
+    MG_TRY(dev.alloc(64));
+    MG_HIP(hipMemcpyAsync(djobs.p, jobs.data(), nj * sizeof(Job), hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemsetAsync(dev.p, 0, 64, st));
+    {
+      ProfScope ps("k_inflate_bgzf", st);
+      k_inflate<uint8_t><<<(unsigned)nj, 64, 0, st>>>(comp.as<uint32_t>(), n, 1, djobs.as<Job>(), text->as<uint8_t>() + headroom, dres.as<Result>(),
+                                                      nullptr, dev.as<uint32_t>(), 0, nullptr);
+    }
+    std::vector<Result> res(nj);
+    MG_HIP(hipMemcpyAsync(res.data(), dres.p, nj * sizeof(Result), hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> crcs;
+    MG_TRY(crc_of(text->as<uint8_t>(), segs, &crcs));  // (synchronises: res is there as well)
+    for (uint64_t i = 0; i < nj; ++i) {
+      const BgzfBlock& b = blocks[b0 + i];
+      const Result& r = res[i];
+      if (r.status != ST_MEMBER) return fail(MG_ERR_ARG, "BGZF block at byte %llu: %s", (unsigned long long)b.coff, status_text(r.status));
+      if (r.overflow || r.out_count != b.isize || r.isize != b.isize || r.end_bit != (b.coff + b.csize) * 8)
+        return fail(MG_ERR_ARG, "BGZF block at byte %llu: corrupt (size mismatch)", (unsigned long long)b.coff);
+      if (r.crc != crcs[i]) return fail(MG_ERR_ARG, "BGZF block at byte %llu: corrupt (CRC mismatch)", (unsigned long long)b.coff);
+    }
+    g_cnt.jobs += nj;
+    g_cnt.stages += 1;
+    return MG_OK;
+  }
+
+  // ---- gzip ----
+  struct Launch {  // jobs decoded together into one symbol buffer
+    std::vector<Job> jobs;
+    std::vector<Result> res;
+    DevBuf sym, tails;  // tails: 32768 symbols per job, the window behind it as far as it knows it
+  };
+  // decode `jobs` (out_off / out_cap filled in here from `caps`) -> results and member ends
+  int run_launch(Launch* L, const std::vector<uint64_t>& caps, bool input_final, uint64_t avail, std::vector<Event>* events, uint32_t launch_id) {
+    const size_t nj = L->jobs.size();
+    uint64_t total = 0;
+    for (size_t i = 0; i < nj; ++i) {
+      L->jobs[i].out_off = total;
+      L->jobs[i].out_cap = caps[i];
+      total += (caps[i] + 7) & ~7ull;
+    }
+    MG_TRY(L->sym.alloc(total * 2 + 64));
+    MG_TRY(L->tails.alloc((uint64_t)nj * kWindow * 2));
+    DevBuf djobs, dres, dev, dcnt;
+    const uint32_t max_events = 1u << 16;
+    MG_TRY(djobs.alloc(nj * sizeof(Job)));
+    MG_TRY(dres.alloc(nj * sizeof(Result)));
+    MG_TRY(dev.alloc(max_events * sizeof(Event)));
+    MG_TRY(dcnt.alloc(64));
+    MG_HIP(hipMemcpyAsync(djobs.p, L->jobs.data(), nj * sizeof(Job), hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemsetAsync(dcnt.p, 0, 64, st));
+    {
+      ProfScope ps("k_inflate", st);
+      k_inflate<uint16_t><<<(unsigned)nj, 64, 0, st>>>(comp.as<uint32_t>(), avail, input_final ? 1 : 0, djobs.as<Job>(), L->sym.as<uint16_t>(),
+                                                       dres.as<Result>(), dev.as<Event>(), dcnt.as<uint32_t>(), max_events, L->tails.as<uint16_t>());
+    }
+    L->res.resize(nj);
+    uint32_t nev = 0;
+    MG_HIP(hipMemcpyAsync(L->res.data(), dres.p, nj * sizeof(Result), hipMemcpyDeviceToHost, st));
+    MG_HIP(hipMemcpyAsync(&nev, dcnt.p, 4, hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    if (nev > max_events) return fail(MG_ERR_CAPACITY, "%s", status_text(ST_EVENTS_FULL));
+    if (nev) {
+      const size_t at = events->size();
+      events->resize(at + nev);
+      MG_HIP(hipMemcpyAsync(events->data() + at, dev.p, nev * sizeof(Event), hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      for (size_t i = at; i < events->size(); ++i) (*events)[i].pad = launch_id;
+    }
+    g_cnt.jobs += nj;
+    return MG_OK;
+  }
+
+  // The text of the next stage: compressed bytes [next_bit / 8, ...) of which `avail` are on their way to the device (`final`:
+  // that is the whole file).  *ntext = 0 with *finished = false: nothing could be finished with the bytes there are.
+  int stage_gzip(uint64_t avail, bool final, uint64_t headroom, DevBuf* text, uint64_t* ntext, bool* finished) {
+    const double t_begin = now_s();
+    *ntext = 0;
+    *finished = false;
+    const uint64_t margin = 4ull << 20;
+    const uint64_t chunk_bits = ((g_cfg.chunk_bytes + 7) & ~7ull) * 8;
+    uint64_t limit_bit = ~0ull;  // the last job stops at the first block boundary at or behind it
+    {
+      const uint64_t stage_end = (next_bit / 8 + g_cfg.stage_bytes) * 8;
+      const uint64_t safe_end = final ? avail * 8 : (avail > margin ? (avail - margin) * 8 : 0);
+      if (!final || stage_end < safe_end) limit_bit = std::min(stage_end, safe_end);
+      if (limit_bit != ~0ull && limit_bit <= next_bit + 64) {
+        if (!final) return MG_OK;  // more bytes first
+        limit_bit = ~0ull;
+      }
+    }
+    MG_TRY(up.need(avail, st));
+    // 1. block starts
+    const uint64_t grid0 = (next_bit / 64) * 64;
+    const uint64_t scan_end = limit_bit == ~0ull ? avail * 8 : limit_bit;
+    const uint64_t nchunks = scan_end > grid0 ? (scan_end - grid0 + chunk_bits - 1) / chunk_bits : 1;
+    std::vector<uint64_t> starts;
+    const double t_find0 = now_s();
+    if (nchunks > 1) {
+      DevBuf dstarts, dinfo;
+      MG_TRY(dstarts.alloc((nchunks - 1) * 8));
+      MG_TRY(dinfo.alloc((nchunks - 1) * 8));
+      {
+        ProfScope ps("k_find_block_starts", st);
+        k_find_block_starts<<<(unsigned)(nchunks - 1), 64, 0, st>>>(comp.as<uint32_t>(), avail, grid0, chunk_bits, next_bit, scan_end, dstarts.as<uint64_t>(), dinfo.as<uint32_t>());
+      }
+      starts.resize(nchunks - 1);
+      std::vector<uint32_t> info(2 * (nchunks - 1));
+      MG_HIP(hipMemcpyAsync(starts.data(), dstarts.p, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
+      MG_HIP(hipMemcpyAsync(info.data(), dinfo.p, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
+      MG_HIP(hipStreamSynchronize(st));
+      for (uint64_t c = 0; c + 1 < nchunks; ++c) { g_cnt.find_candidates += info[2 * c]; g_cnt.find_steps += info[2 * c + 1]; }
+    }
+    g_cnt.find_s += now_s() - t_find0;
+    // 2. jobs: from every start to the next one
+    const double t_dec0 = now_s();
+    std::deque<Launch> launches(1);
+    {
+      Launch& L = launches[0];
+      L.jobs.push_back(Job{next_bit, 0, 0, 0, first ? (uint32_t)(F_HEADER | F_MEMBER_START) : 0u, 0});
+      for (uint64_t s : starts)
+        if (s != ~0ull) L.jobs.push_back(Job{s, 0, 0, 0, 0, 0});
+      std::vector<uint64_t> caps(L.jobs.size());
+      for (size_t i = 0; i < L.jobs.size(); ++i) {
+        L.jobs[i].stop_bit = i + 1 < L.jobs.size() ? L.jobs[i + 1].start_bit : limit_bit;
+        const uint64_t span_end = i + 1 < L.jobs.size() ? L.jobs[i + 1].start_bit : scan_end;
+        caps[i] = ((span_end - L.jobs[i].start_bit) / 8 + 1) * g_cfg.ratio + 4096;
+      }
+      events_.clear();
+      MG_TRY(run_launch(&L, caps, final, avail, &events_, 0));
+    }
+    // 3. the chain: every job must have ended where the next one started
+    struct Link { uint32_t launch, job; };
+    std::vector<Link> chain;
+    bool stream_end = false;
+    {
+      uint32_t li = 0, ji = 0;  // the job the chain stands at
+      size_t main_next = 1;     // the first job of launch 0 that has not been passed
+      for (;;) {
+        Launch& L = launches[li];
+        Result& r = L.res[ji];
+        if (r.overflow) {  // more symbols than were reserved: again, with room for what it counted
+          launches.emplace_back();
+          Launch& R = launches.back();
+          R.jobs.push_back(launches[li].jobs[ji]);
+          MG_TRY(run_launch(&R, {launches[li].res[ji].out_count + 64}, final, avail, &events_, (uint32_t)launches.size() - 1));
+          g_cnt.redone += 1;
+          li = (uint32_t)launches.size() - 1;
+          ji = 0;
+          continue;
+        }
+        if (r.status >= ST_ERR) return fail(MG_ERR_ARG, "%s (near compressed byte %llu)", status_text(r.status), (unsigned long long)(r.end_bit / 8));
+        if (r.status == ST_NEED_MORE) {
+          if (final) return fail(MG_ERR_ARG, "%s", status_text(ST_TRUNC));
+          break;  // the stage ends in front of this job
+        }
+        chain.push_back(Link{li, ji});
+        if (r.status == ST_END) { stream_end = true; break; }
+        if (r.status != ST_STOP) return fail(MG_ERR_STATE, "inflate: job ended in state %u", r.status);
+        const uint64_t end = r.end_bit;
+        if (limit_bit != ~0ull && end >= limit_bit) break;  // the stage's last boundary
+        while (main_next < launches[0].jobs.size() && launches[0].jobs[main_next].start_bit < end) ++main_next;  // (run over: false starts)
+        if (main_next < launches[0].jobs.size() && launches[0].jobs[main_next].start_bit == end) {
+          li = 0;
+          ji = (uint32_t)main_next++;
+          continue;
+        }
+        // a hole: nobody started where this job ended
+        launches.emplace_back();
+        Launch& R = launches.back();
+        const uint64_t stop = main_next < launches[0].jobs.size() ? launches[0].jobs[main_next].start_bit : limit_bit;
+        const uint64_t span_end = stop == ~0ull ? avail * 8 : stop;
+        R.jobs.push_back(Job{end, stop, 0, 0, 0, 0});
+        MG_TRY(run_launch(&R, {((span_end > end ? span_end - end : 0) / 8 + 1) * g_cfg.ratio + 4096}, final, avail, &events_, (uint32_t)launches.size() - 1));
+        g_cnt.redone += 1;
+        li = (uint32_t)launches.size() - 1;
+        ji = 0;
+      }
+    }
+    g_cnt.decode_s += now_s() - t_dec0;
+    if (chain.empty()) return MG_OK;  // (not final, and the first job already ran out of bytes)
+    // 4. where every job's text goes
+    const double t_res0 = now_s();
+    const size_t nc = chain.size();
+    std::vector<ChainJob> cj(nc);
+    uint64_t total = 0, tiles = 0;
+    for (size_t i = 0; i < nc; ++i) {
+      Launch& L = launches[chain[i].launch];
+      const Result& r = L.res[chain[i].job];
+      cj[i].sym = L.sym.as<uint16_t>() + L.jobs[chain[i].job].out_off;
+      cj[i].tail = L.tails.as<uint16_t>() + (uint64_t)chain[i].job * kWindow;
+      cj[i].n = r.out_count;
+      cj[i].t_off = headroom + total;
+      cj[i].tile0 = tiles;
+      total += r.out_count;
+      tiles += r.out_count ? ((cj[i].t_off + r.out_count - (cj[i].t_off & ~15ull)) + 4095) / 4096 : 0;
+    }
+    MG_TRY(text->alloc(headroom + total + 64));
+    DevBuf dcj, wins;
+    MG_TRY(dcj.alloc(nc * sizeof(ChainJob)));
+    MG_TRY(wins.alloc((uint64_t)(nc + 1) * kWindow));
+    MG_HIP(hipMemcpyAsync(dcj.p, cj.data(), nc * sizeof(ChainJob), hipMemcpyHostToDevice, st));
+    MG_HIP(hipMemcpyAsync(wins.p, win.p, kWindow, hipMemcpyDeviceToDevice, st));
+    {
+      // groups of K jobs: K steps in every group at once, then one step per group
+      uint32_t K = 1;
+      while ((uint64_t)K * K < nc) ++K;
+      const uint32_t G = (uint32_t)((nc + K - 1) / K);
+      DevBuf comp, tops;
+      MG_TRY(comp.alloc((uint64_t)nc * kWindow * 2));
+      MG_TRY(tops.alloc((uint64_t)(G + 1) * kWindow));
+      MG_HIP(hipMemcpyAsync(tops.p, win.p, kWindow, hipMemcpyDeviceToDevice, st));
+      static bool attr = false;
+      if (!attr) {
+        MG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_groups), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kWindow));
+        attr = true;
+      }
+      ProfScope ps("k_window_chain", st);
+      k_chain_groups<<<G, 1024, 4 * kWindow, st>>>(dcj.as<ChainJob>(), (uint32_t)nc, K, comp.as<uint16_t>());
+      k_chain_tops<<<1, 1024, 2 * kWindow, st>>>(comp.as<uint16_t>(), (uint32_t)nc, K, G, tops.as<uint8_t>());
+      k_chain_rows<<<(unsigned)(((uint64_t)nc * (kWindow / 16) + 255) / 256), 256, 0, st>>>(comp.as<uint16_t>(), (uint32_t)nc, K, tops.as<uint8_t>(), wins.as<uint8_t>());
+    }
+    if (tiles) {
+      ProfScope ps("k_resolve_text", st);
+      k_resolve_text<<<(unsigned)tiles, 256, 0, st>>>(dcj.as<ChainJob>(), (uint32_t)nc, wins.as<uint8_t>(), text->as<uint8_t>());
+    }
+    MG_HIP(hipMemcpyAsync(win.p, wins.as<uint8_t>() + (uint64_t)nc * kWindow, kWindow, hipMemcpyDeviceToDevice, st));
+    // 5. the members' CRC-32 and ISIZE: the text between member ends, in segments of 256 KB
+    std::vector<std::pair<uint64_t, Event>> ends;  // (position in the stage's text, trailer)
+    {
+      std::map<uint64_t, size_t> where;
+      for (size_t i = 0; i < nc; ++i) where[(uint64_t)chain[i].launch << 32 | chain[i].job] = i;
+      for (const Event& e : events_) {  // (member ends seen by jobs that are not on the chain are nobody's)
+        const auto it = where.find((uint64_t)e.pad << 32 | e.job);
+        if (it != where.end()) ends.emplace_back(cj[it->second].t_off - headroom + e.out_pos, e);
+      }
+    }
+    std::stable_sort(ends.begin(), ends.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    const uint64_t kSeg = 256u << 10;
+    std::vector<CrcSeg> segs;
+    std::vector<size_t> seg_end_of;  // for every member end: segments before it
+    {
+      uint64_t at = 0;
+      size_t ei = 0;
+      while (at < total || ei < ends.size()) {
+        const uint64_t until = ei < ends.size() ? ends[ei].first : total;
+        while (at < until) {
+          const uint64_t len = std::min(kSeg, until - at);
+          segs.push_back(CrcSeg{headroom + at, len});
+          at += len;
+        }
+        if (ei < ends.size()) { seg_end_of.push_back(segs.size()); ++ei; }
+        else break;
+      }
+    }
+    std::vector<uint32_t> crcs;
+    MG_TRY(crc_of(text->as<uint8_t>(), segs, &crcs));
+    {
+      size_t si = 0;
+      for (size_t ei = 0; ei <= ends.size(); ++ei) {
+        const size_t upto = ei < ends.size() ? seg_end_of[ei] : segs.size();
+        for (; si < upto; ++si) {
+          mcrc = mlen ? crc_multmodp(x8n(segs[si].len), mcrc) ^ crcs[si] : crcs[si];
+          mlen += segs[si].len;
+        }
+        if (ei < ends.size()) {
+          const Event& e = ends[ei].second;
+          if ((mlen ? mcrc : 0u) != e.crc) return fail(MG_ERR_ARG, "corrupt gzip data: CRC mismatch in the member that ends at byte %llu of the text", (unsigned long long)(text_base_ + ends[ei].first));
+          if ((uint32_t)mlen != e.isize) return fail(MG_ERR_ARG, "corrupt gzip data: length mismatch in the member that ends at byte %llu of the text", (unsigned long long)(text_base_ + ends[ei].first));
+          mcrc = 0;
+          mlen = 0;
+        }
+      }
+    }
+    g_cnt.resolve_s += now_s() - t_res0;
+    const Launch& LL = launches[chain.back().launch];
+    next_bit = LL.res[chain.back().job].end_bit;
+    first = false;
+    text_base_ += total;
+    *ntext = total;
+    if (stream_end) {
+      if (mlen) return fail(MG_ERR_ARG, "%s", status_text(ST_TRUNC));
+      *finished = true;
+    }
+    g_cnt.stages += 1;
+    g_cnt.stage_s += now_s() - t_begin;
+    return MG_OK;
+  }
+
+  // the next piece of text; *finished: nothing follows
+  int next(uint64_t headroom, DevBuf* text, uint64_t* ntext, bool* finished) {
+    if (done) { *ntext = 0; *finished = true; return MG_OK; }
+    int rc;
+    if (bgzf) {
+      rc = stage_bgzf(headroom, 768ull << 20, text, ntext, finished);
+    } else {
+      // a stage needs its own compressed bytes and a little more (its last job reads on to the end of its block)
+      const uint64_t avail = std::min<uint64_t>(n, next_bit / 8 + g_cfg.stage_bytes + (8ull << 20));
+      rc = stage_gzip(avail, avail == n, headroom, text, ntext, finished);
+      if (rc == MG_OK && *ntext == 0 && !*finished && avail < n) rc = stage_gzip(n, true, headroom, text, ntext, finished);
+    }
+    if (rc == MG_OK && *finished) done = true;
+    return rc;
+  }
+
+  std::vector<Event> events_;
+  uint64_t text_base_ = 0;
+};
+
+// the pipeline of mg_stream.hip's entry points for a .gz file: every stage's text, the unfinished last record carried in front of
+// the next stage's
+int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const uint8_t*, uint64_t, bool, uint64_t*)>& consume) {
+  if (fsize == 0) return fail(MG_ERR_ARG, "empty file: not in gzip format");
+  void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (map == MAP_FAILED) return fail(MG_ERR_ARG, "cannot map the file: %s", strerror(errno));
+  (void)madvise(map, fsize, MADV_SEQUENTIAL);
+  int rc = MG_OK;
+  {
+    DevInflater inf;
+    rc = inf.open(static_cast<const uint8_t*>(map), fsize, 4);
+    const uint64_t headroom = 4ull << 20;
+    DevBuf prev;
+    const uint8_t* carry_src = nullptr;
+    uint64_t carry = 0;
+    hipStream_t st = ctx().stream;
+    while (rc == MG_OK) {
+      DevBuf text;
+      uint64_t nt = 0;
+      bool fin = false;
+      rc = inf.next(headroom, &text, &nt, &fin);
+      if (rc != MG_OK) break;
+      if (carry) {
+        if (hipMemcpyAsync(text.as<uint8_t>() + headroom - carry, carry_src, carry, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = fail(MG_ERR_HIP, "carry copy failed"); break; }
+      }
+      const uint8_t* d = text.as<uint8_t>() + headroom - carry;
+      const uint64_t nbytes = carry + nt;
+      uint64_t consumed = 0;
+      rc = consume(d, nbytes, fin, &consumed);
+      if (rc != MG_OK || fin) break;
+      if (consumed > nbytes) consumed = nbytes;
+      carry = nbytes - consumed;
+      if (carry > headroom) { rc = fail(MG_ERR_CAPACITY, "a record of more than %llu bytes does not fit the streaming pieces", (unsigned long long)headroom); break; }
+      carry_src = d + consumed;
+      prev = std::move(text);  // (kept until the carry has been copied out of it)
+    }
+    if (rc != MG_OK) (void)hipStreamSynchronize(st);
+    inf.up.finish();
+  }
+  munmap(map, fsize);
+  return rc;
+}
+
+}  // namespace mg
+
+using namespace mg;
+
+struct mg_inflated {
+  std::vector<mg::DevBuf> parts;
+  std::vector<uint64_t> sizes;
+  uint64_t headroom = 0, total = 0;
+};
+
+extern "C" {
+
+int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on) {
+  if (chunk_bytes > 0) {
+    if (chunk_bytes < 1024) return fail(MG_ERR_ARG, "inflate chunks of at least 1024 bytes");
+    g_cfg.chunk_bytes = (uint64_t)chunk_bytes;
+  }
+  if (stage_bytes > 0) {
+    if (stage_bytes < 4096) return fail(MG_ERR_ARG, "inflate stages of at least 4096 bytes");
+    g_cfg.stage_bytes = (uint64_t)stage_bytes;
+  }
+  if (ratio > 0) g_cfg.ratio = (uint32_t)ratio;
+  if (on >= 0) g_cfg.on = on;
+  return MG_OK;
+}
+
+int mg_inflate_stats(mg_inflate_counters* out, int reset) {
+  if (out) *out = g_cnt;
+  if (reset) g_cnt = mg_inflate_counters();
+  return MG_OK;
+}
+
+int mg_inflate_dev(const uint8_t* comp, uint64_t ncomp, mg_inflated** out) {
+  MG_REQUIRE_READY();
+  if (!comp || !out) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  std::unique_ptr<mg_inflated> res(new mg_inflated());
+  DevInflater inf;
+  MG_TRY(inf.open(comp, ncomp, 4));
+  for (;;) {
+    mg::DevBuf text;
+    uint64_t nt = 0;
+    bool fin = false;
+    MG_TRY(inf.next(0, &text, &nt, &fin));
+    res->total += nt;
+    res->sizes.push_back(nt);
+    res->parts.push_back(std::move(text));
+    if (fin) break;
+  }
+  MG_HIP(hipStreamSynchronize(ctx().stream));
+  *out = res.release();
+  return MG_OK;
+}
+
+uint64_t mg_inflated_bytes(const mg_inflated* t) { return t ? t->total : 0; }
+
+int mg_inflated_download(const mg_inflated* t, uint8_t* dst) {
+  MG_REQUIRE_READY();
+  if (!t || (!dst && t->total)) return fail(MG_ERR_ARG, "null argument");
+  uint64_t at = 0;
+  for (size_t i = 0; i < t->parts.size(); ++i) {
+    if (t->sizes[i]) MG_HIP(hipMemcpyAsync(dst + at, t->parts[i].as<uint8_t>(), t->sizes[i], hipMemcpyDeviceToHost, ctx().stream));
+    at += t->sizes[i];
+  }
+  MG_HIP(hipStreamSynchronize(ctx().stream));
+  return MG_OK;
+}
+
+void mg_inflated_free(mg_inflated* t) { delete t; }
+
+}  // extern "C"

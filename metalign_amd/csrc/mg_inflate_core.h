@@ -1,0 +1,869 @@
+// mg_inflate_core.h — DEFLATE (RFC 1951) inside gzip (RFC 1952), decoded by ONE 64-lane wavefront per job.
+//
+// The reference takes `.fq.gz` reads as ordinary input (scripts/select_db.py:146-148; kmc inflates them itself, :50-52) and
+// `zcat`s the selected genomes (:101-105).  mg_inflate.hip moves that to the device: compressed bytes cross PCIe, the text is
+// born in HBM.  This header is the decoder itself, written so that the SAME code compiles for the host (tests/host_inflate_check.cpp
+// runs it lane by lane against zlib where there is no GPU) and for gfx950:
+//
+//   * everything a Huffman decoder does serially is WAVE-UNIFORM code: every lane executes it, the values that come back from LDS
+//     or memory go through readfirstlane (MGI_UNI), so the bit buffer, the table look-ups' results, lengths and distances live
+//     in SGPRs and the loop runs on the scalar unit; LDS writes of such code are made by one lane (Exec::leader());
+//   * what is parallel is written per LANE (Exec::lanes): counting code lengths, ranking the symbols of a length (canonical
+//     codes), filling the look-up tables, and EMITTING: the uniform loop only queues up to 64 symbols (literal | length,
+//     distance) of at most 4096 output bytes; then lane l produces output bytes l, l + 64, ... of the batch — the owner of a
+//     byte is a popcount over a bitmap of the symbols' first bytes, a back-reference is followed (through other symbols of
+//     the same batch if need be) to a literal of the batch or to a byte that was in memory before the batch — so no byte of
+//     a batch depends on a store of the same batch and every load is independent of every other;
+//   * a job that starts in the middle of a deflate stream (mg_inflate.hip finds block starts speculatively) does not know the
+//     32 KB in front of it: its output is 16-bit symbols, a byte or 0x8000 + i = "byte i of that window" (the pugz scheme).
+//
+// Phases are separated by Exec::sync() (a workgroup barrier of the single wavefront); the host runs a phase for lane 0..63
+// in turn, which is the same thing as long as the lanes of a phase do not depend on each other — they are written not to.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MGI_HD __host__ __device__ inline
+#else
+#define MGI_HD inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGI_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define MGI_UNI(x) ((uint32_t)(x))
+#endif
+
+namespace mgi {
+
+constexpr int LB = 10;                   // primary bits of the literal/length table
+constexpr int DB = 8;                    // ... of the distance table
+constexpr uint32_t kBatchSyms = 256;     // symbols queued per batch
+constexpr uint32_t kBatchBytes = 4096;   // output bytes per batch (bitmap of 64 x 64 bits)
+constexpr uint32_t kWindow = 32768;
+
+enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_LONG = 3, K_BAD = 4, K_DIST = 5 };
+
+// how a job ended (Result::status)
+enum : uint32_t {
+  ST_STOP = 1,        // at a block boundary at or behind Job::stop_bit
+  ST_END = 2,         // the gzip stream ended: input exhausted at a member boundary, or something that is no member follows
+  ST_MEMBER = 3,      // F_ONE_MEMBER: the member's final block and trailer were read
+  ST_NEED_MORE = 4,   // ran behind the bytes that are there so far (Job input not final)
+  ST_ERR = 16,        // everything from here on is an error
+  ST_TRUNC = 16,      // the stream ends inside a member
+  ST_BAD_BLOCK = 17,  // block type 3
+  ST_BAD_STORED = 18, // LEN / NLEN of a stored block
+  ST_BAD_CODES = 19,  // code lengths: over-subscribed, incomplete, no end-of-block, a repeat with nothing to repeat
+  ST_BAD_SYMBOL = 20, // an unassigned code, a length / distance symbol that does not exist
+  ST_BAD_DIST = 21,   // a distance behind the start of the member (or of the known window)
+  ST_BAD_HEADER = 22, // gzip header
+  ST_EVENTS_FULL = 23,
+};
+enum : uint32_t {
+  F_HEADER = 1,        // a gzip member header stands at start_bit (a byte position)
+  F_ONE_MEMBER = 2,    // stop behind the trailer of the member (BGZF); crc / isize go to the Result
+  F_MEMBER_START = 4,  // nothing of the member lies in front of start_bit: a distance behind it is an error
+  F_COUNT_ONLY = 8,    // decode and count, write nothing
+};
+
+struct Job {
+  uint64_t start_bit, stop_bit;  // ST_STOP at the first block boundary >= stop_bit
+  uint64_t out_off, out_cap;     // elements (bytes, or 16-bit symbols) in the output buffer; beyond out_cap: counted, not written
+  uint32_t flags, pad;
+};
+struct Result {
+  uint64_t end_bit, out_count;
+  uint32_t status, overflow;
+  uint32_t crc, isize;           // F_ONE_MEMBER: the trailer
+  uint32_t nblocks, nevents;
+};
+struct Event {                   // a member ended inside a job (not F_ONE_MEMBER)
+  uint64_t out_pos;              // elements the job had produced when it ended
+  uint32_t job, crc, isize, pad;
+};
+
+struct Shared {
+  uint32_t lit[1 << LB];
+  uint32_t dist[1 << DB];
+  uint32_t cnt[2][16], first[2][16], offs[2][16];
+  uint32_t blkcnt[5][16];        // code lengths per block of 64 symbols
+  uint32_t nshort, err;
+  uint16_t shortsym[32], shortrc[32];
+  uint16_t sorted[320];          // symbols by (length, symbol): [0, 288) literal/length, [288, 320) distance
+  uint8_t cl[320];
+  uint8_t pre[128];
+  uint32_t rec_lo[kBatchSyms], rec_hi[kBatchSyms];  // first byte in the batch | len << 16 ; dist | literal << 16
+  uint64_t headbits[kBatchBytes / 64];
+  uint16_t headbase[kBatchBytes / 64];
+  uint32_t scan[64];             // what Exec::scan sums up
+  uint32_t cut;
+};
+
+MGI_HD uint32_t bitrev(uint32_t v, uint32_t nbits) {
+#if defined(__has_builtin)
+#if __has_builtin(__builtin_bitreverse32)
+  return __builtin_bitreverse32(v) >> (32 - nbits);
+#define MGI_HAVE_BREV 1
+#endif
+#endif
+#ifndef MGI_HAVE_BREV
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < nbits; ++i) { r = (r << 1) | (v & 1u); v >>= 1; }
+  return r;
+#endif
+}
+MGI_HD uint32_t popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+
+// length symbol 257 + i -> base | extra bits << 16 (RFC 1951 3.2.5)
+MGI_HD uint32_t len_sym(uint32_t i) {
+  if (i < 8) return 3 + i;
+  if (i == 28) return 258;
+  const uint32_t x = (i - 4) >> 2;
+  return (3 + ((4 + (i & 3)) << x)) | (x << 16);
+}
+MGI_HD uint32_t dist_sym(uint32_t d) {
+  if (d < 4) return 1 + d;
+  const uint32_t x = (d - 2) >> 1;
+  return (1 + ((2 + (d & 1)) << x)) | (x << 16);
+}
+// table entry of a symbol whose code has l bits: l | extra << 4 | kind << 8 | value << 16
+MGI_HD uint32_t lit_entry(uint32_t s, uint32_t l) {
+  if (s < 256) return l | (K_LIT << 8) | (s << 16);
+  if (s == 256) return l | (K_EOB << 8);
+  if (s > 285) return l | (K_BAD << 8);
+  const uint32_t b = len_sym(s - 257);
+  return l | ((b >> 16) << 4) | (K_LEN << 8) | ((b & 0xffff) << 16);
+}
+MGI_HD uint32_t dist_entry(uint32_t s, uint32_t l) {
+  if (s > 29) return l | (K_BAD << 8);
+  const uint32_t b = dist_sym(s);
+  return l | ((b >> 16) << 4) | (K_DIST << 8) | ((b & 0xffff) << 16);
+}
+
+// ---- the bit reader: wave-uniform; deflate packs bits LSB first; the input is read as aligned 32-bit words ----
+struct BitReader {
+  const uint32_t* in;
+  uint64_t nwords;  // words that may be read (zero behind them)
+  uint64_t bb;      // the next bc bits
+  uint32_t bc;
+  uint64_t wi;      // index of the word in nxt
+  uint32_t nxt;
+  MGI_HD uint32_t load(uint64_t w) const { return w < nwords ? MGI_UNI(in[w]) : 0u; }
+  MGI_HD void init(const uint32_t* p, uint64_t nw, uint64_t bitpos) {
+    in = p;
+    nwords = nw;
+    const uint32_t sh = (uint32_t)bitpos & 31u;
+    wi = bitpos >> 5;
+    bb = (uint64_t)(load(wi) >> sh);
+    bc = 32 - sh;
+    ++wi;
+    nxt = load(wi);
+  }
+  MGI_HD void refill() {  // afterwards bc > 32
+    if (bc <= 32) {
+      bb |= (uint64_t)nxt << bc;
+      bc += 32;
+      ++wi;
+      nxt = load(wi);
+    }
+  }
+  MGI_HD uint64_t pos() const { return wi * 32 - bc; }
+  MGI_HD void drop(uint32_t n) { bb >>= n; bc -= n; }
+  MGI_HD uint32_t bits(uint32_t n) {  // n <= 32 <= bc
+    const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1ull));
+    drop(n);
+    return v;
+  }
+};
+
+// ---- execution policies: how a phase meets the lanes ----
+// Per-lane values that live from one phase to the next (the speculative decode of a window: bits, length, distance | literal of
+// the symbol that would start at the lane's bit) are registers on the device and arrays on the host; tot_at / len_at read
+// another lane's (v_readlane with a uniform index).  scan: exclusive prefix sums of sh.scan[0..64) in place -> the total.
+struct HostExec {
+  Shared* sh = nullptr;
+  uint32_t r_tot[64], r_len[64], r_hi[64];
+  bool leader() const { return true; }
+  void sync() const {}
+  void set_sym(int lane, uint32_t tot, uint32_t len, uint32_t hi) { r_tot[lane] = tot; r_len[lane] = len; r_hi[lane] = hi; }
+  uint32_t tot_at(uint32_t l) const { return r_tot[l]; }
+  uint32_t len_at(uint32_t l) const { return r_len[l]; }
+  uint32_t my_len(int lane) const { return r_len[lane]; }
+  uint32_t my_hi(int lane) const { return r_hi[lane]; }
+  uint32_t scan() const {
+    uint32_t run = 0;
+    for (int l = 0; l < 64; ++l) { const uint32_t v = sh->scan[l]; sh->scan[l] = run; run += v; }
+    return run;
+  }
+  template <class F> void lanes(F&& f) const { for (int l = 0; l < 64; ++l) f(l); }
+  static void atomic_inc(uint32_t* p) { ++*p; }
+  static uint32_t atomic_fetch_inc(uint32_t* p) { return (*p)++; }
+  static void atomic_or64(uint64_t* p, uint64_t v) { *p |= v; }
+  static void atomic_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+};
+#if defined(__HIPCC__)
+struct DevExec {
+  Shared* sh;
+  int lane;
+  uint32_t v_tot = 0, v_len = 0, v_hi = 0;
+  __device__ bool leader() const { return lane == 0; }
+  __device__ void sync() const { __syncthreads(); }
+  __device__ void set_sym(int, uint32_t tot, uint32_t len, uint32_t hi) { v_tot = tot; v_len = len; v_hi = hi; }
+  __device__ uint32_t tot_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_tot, (int)l); }
+  __device__ uint32_t len_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_len, (int)l); }
+  __device__ uint32_t my_len(int) const { return v_len; }
+  __device__ uint32_t my_hi(int) const { return v_hi; }
+  __device__ uint32_t scan() const {
+    const uint32_t v = sh->scan[lane];
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
+      if (lane >= d) x += y;
+    }
+    sh->scan[lane] = x - v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  }
+  template <class F> __device__ void lanes(F&& f) const { f(lane); }
+  __device__ static void atomic_inc(uint32_t* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ static uint32_t atomic_fetch_inc(uint32_t* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ static void atomic_or64(uint64_t* p, uint64_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ static void atomic_min(uint32_t* p, uint32_t v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
+#endif
+
+// ---- canonical Huffman codes -> look-up table + what the slow path (codes longer than the table's bits) needs ----
+// which = 0: literal/length code, cl[base, base + n), table sh.lit of LB bits; 1: distance code, table sh.dist of DB bits.
+// strict: what the block-start finder asks of a candidate (a complete code, or at most one distance code).
+// Returns 0, or ST_BAD_CODES.
+template <class Exec>
+MGI_HD uint32_t build_table(Exec& ex, Shared& sh, int which, uint32_t base, uint32_t n, bool table, bool strict = false) {
+  const uint32_t TB = which ? DB : LB;
+  uint32_t* tab = which ? sh.dist : sh.lit;
+  ex.lanes([&](int lane) {
+    if (lane < 16) sh.cnt[which][lane] = 0;
+    for (uint32_t i = (uint32_t)lane; i < 80; i += 64) (&sh.blkcnt[0][0])[i] = 0;
+    if (lane == 0) sh.nshort = 0;
+    if (table)
+      for (uint32_t i = (uint32_t)lane; i < (1u << TB); i += 64) tab[i] = 0;
+  });
+  ex.sync();
+  ex.lanes([&](int lane) {
+    for (uint32_t s = (uint32_t)lane; s < n; s += 64) Exec::atomic_inc(&sh.blkcnt[s >> 6][sh.cl[base + s]]);
+  });
+  ex.sync();
+  // uniform: counts, Kraft, first code and first rank of every length
+  uint32_t used = 0, code = 0, rank = 0, c1 = 0;
+  int32_t left = 1;
+  bool over = false;
+  for (uint32_t l = 1; l <= 15; ++l) {
+    uint32_t c = 0;
+    for (uint32_t b = 0; b * 64 < n; ++b) c += MGI_UNI(sh.blkcnt[b][l]);
+    if (l == 1) c1 = c;
+    left = (left << 1) - (int32_t)c;
+    if (left < 0) over = true;
+    if (ex.leader()) { sh.cnt[which][l] = c; sh.first[which][l] = code; sh.offs[which][l] = rank; }
+    code = (code + c) << 1;
+    rank += c;
+    used += c;
+  }
+  if (over) return ST_BAD_CODES;
+  if (left > 0) {
+    // zlib (inflate_table): an incomplete code is accepted only when every code has one bit — and never for the literal/length
+    // code of a block the finder is to trust
+    if (used != 0 && !(c1 == used)) return ST_BAD_CODES;
+    if (strict && (which == 0 || used > 1)) return ST_BAD_CODES;
+  }
+  ex.sync();
+  if (!table) return 0;
+  ex.lanes([&](int lane) {
+    for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+      const uint32_t s = s0 + (uint32_t)lane;
+      if (s >= n) break;
+      const uint32_t l = sh.cl[base + s];
+      if (!l) continue;
+      uint32_t r = 0;
+      for (uint32_t b = 0; b < (s0 >> 6); ++b) r += sh.blkcnt[b][l];
+      for (uint32_t j = 0; j < (uint32_t)lane; ++j) r += sh.cl[base + s0 + j] == l;
+      sh.sorted[(which ? 288 : 0) + sh.offs[which][l] + r] = (uint16_t)s;
+      const uint32_t rc = bitrev(sh.first[which][l] + r, l);  // the code as its bits arrive
+      const uint32_t e = which ? dist_entry(s, l) : lit_entry(s, l);
+      if (l > TB) {
+        tab[rc & ((1u << TB) - 1u)] = K_LONG << 8 | 15u;  // (the slow path finds the length)
+      } else if ((1u << (TB - l)) >= 64u) {
+        const uint32_t i = Exec::atomic_fetch_inc(&sh.nshort);
+        sh.shortsym[i] = (uint16_t)s;
+        sh.shortrc[i] = (uint16_t)rc;
+      } else {
+        for (uint32_t j = rc; j < (1u << TB); j += 1u << l) tab[j] = e;
+      }
+    }
+  });
+  ex.sync();
+  const uint32_t ns = MGI_UNI(sh.nshort);
+  if (ns) {
+    ex.lanes([&](int lane) {
+      for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t s = sh.shortsym[i], rc = sh.shortrc[i], l = sh.cl[base + s];
+        const uint32_t e = which ? dist_entry(s, l) : lit_entry(s, l);
+        for (uint32_t j = (uint32_t)lane; j < (1u << (TB - l)); j += 64) tab[rc + (j << l)] = e;
+      }
+    });
+    ex.sync();
+  }
+  return 0;
+}
+
+// a code longer than the table's bits: canonical search over the lengths (uniform)
+MGI_HD uint32_t slow_entry(const Shared& sh, int which, uint64_t bb) {
+  const uint32_t TB = which ? DB : LB;
+  const uint32_t c15 = bitrev((uint32_t)bb & 0x7fffu, 15);
+  for (uint32_t l = TB + 1; l <= 15; ++l) {
+    const uint32_t c = c15 >> (15 - l);
+    const uint32_t i = c - MGI_UNI(sh.first[which][l]);
+    if (i < MGI_UNI(sh.cnt[which][l])) {
+      const uint32_t s = MGI_UNI(sh.sorted[(which ? 288 : 0) + MGI_UNI(sh.offs[which][l]) + i]);
+      return which ? dist_entry(s, l) : lit_entry(s, l);
+    }
+  }
+  return 0;  // no such code
+}
+
+// ---- the header of a dynamic block: code lengths into sh.cl[0, nlit + ndist) ----
+template <class Exec>
+MGI_HD uint32_t read_dynamic_lengths(Exec& ex, Shared& sh, BitReader& br, uint32_t* nlit_out, uint32_t* ndist_out) {
+  br.refill();
+  const uint32_t nlit = br.bits(5) + 257, ndist = br.bits(5) + 1, ncl = br.bits(4) + 4;
+  if (nlit > 286 || ndist > 30) return ST_BAD_CODES;
+  // the code-length code: 3-bit lengths in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+  const uint64_t order_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                            5ull << 45 | 11ull << 50 | 4ull << 55;
+  const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+  uint64_t plen = 0;  // 3 bits per symbol
+  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = 0; i < ncl; ++i) {
+    br.refill();
+    const uint32_t l = br.bits(3);
+    const uint32_t sym = (uint32_t)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31u);
+    plen |= (uint64_t)l << (3 * sym);
+    // (a fixed-trip unrolled update keeps cnt[] in registers)
+    for (uint32_t k = 1; k < 8; ++k) cnt[k] += l == k;
+  }
+  int32_t left = 1;
+  uint32_t next[8];
+  {
+    uint32_t code = 0;
+    for (uint32_t l = 1; l < 8; ++l) {
+      left = (left << 1) - (int32_t)cnt[l];
+      if (left < 0) return ST_BAD_CODES;
+      next[l] = code;
+      code = (code + cnt[l]) << 1;
+    }
+  }
+  if (left != 0) return ST_BAD_CODES;  // (zlib: an incomplete code-length code is an error)
+  ex.sync();                           // (whoever read sh.pre before is done)
+  for (uint32_t s = 0; s < 19; ++s) {
+    const uint32_t l = (uint32_t)(plen >> (3 * s)) & 7u;
+    if (!l) continue;
+    uint32_t c = 0;
+    for (uint32_t k = 1; k < 8; ++k) if (k == l) { c = next[k]; next[k] = c + 1; }
+    const uint32_t rc = bitrev(c, l);
+    if (ex.leader())
+      for (uint32_t j = rc; j < 128; j += 1u << l) sh.pre[j] = (uint8_t)(l | (s << 3));
+  }
+  ex.sync();
+  const uint32_t total = nlit + ndist;
+  uint32_t i = 0, prev = 0;
+  while (i < total) {
+    br.refill();
+    const uint32_t e = MGI_UNI(sh.pre[(uint32_t)br.bb & 127u]);
+    br.drop(e & 7u);
+    const uint32_t s = e >> 3;
+    if (s < 16) {
+      if (ex.leader()) sh.cl[i] = (uint8_t)s;
+      prev = s;
+      ++i;
+      continue;
+    }
+    uint32_t rep, val = 0;
+    if (s == 16) {
+      if (i == 0) return ST_BAD_CODES;
+      rep = 3 + br.bits(2);
+      val = prev;
+    } else if (s == 17) {
+      rep = 3 + br.bits(3);
+    } else {
+      rep = 11 + br.bits(7);
+    }
+    if (i + rep > total) return ST_BAD_CODES;
+    if (ex.leader())
+      for (uint32_t j = 0; j < rep; ++j) sh.cl[i + j] = (uint8_t)val;
+    if (s != 16) prev = 0;
+    i += rep;
+  }
+  ex.sync();
+  if (MGI_UNI(sh.cl[256]) == 0) return ST_BAD_CODES;  // no end-of-block code
+  *nlit_out = nlit;
+  *ndist_out = ndist;
+  return 0;
+}
+
+template <class Exec>
+MGI_HD void fixed_lengths(Exec& ex, Shared& sh) {
+  ex.sync();
+  ex.lanes([&](int lane) {
+    for (uint32_t s = (uint32_t)lane; s < 320; s += 64) sh.cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+  });
+  ex.sync();
+}
+
+// ---- one batch of symbols ----
+// One symbol by the scalar path (uniform): what the window decode leaves over — the end of a block, codes longer than the tables'
+// bits.  -> K_LIT / K_LEN with *len, *hi (distance | literal << 16), K_EOB, or K_BAD.
+MGI_HD uint32_t decode_one(const Shared& sh, BitReader& br, uint32_t* len, uint32_t* hi) {
+  br.refill();
+  uint32_t e = MGI_UNI(sh.lit[(uint32_t)br.bb & ((1u << LB) - 1u)]);
+  if (((e >> 8) & 7u) == K_LONG) e = slow_entry(sh, 0, br.bb);
+  if ((e & 15u) == 0) return K_BAD;
+  br.drop(e & 15u);
+  const uint32_t kind = (e >> 8) & 7u;
+  if (kind == K_LIT) { *len = 1; *hi = (e >> 16) << 16; return K_LIT; }
+  if (kind != K_LEN) return kind == K_EOB ? K_EOB : K_BAD;
+  *len = (e >> 16) + br.bits((e >> 4) & 15u);
+  br.refill();
+  uint32_t d = MGI_UNI(sh.dist[(uint32_t)br.bb & ((1u << DB) - 1u)]);
+  if (((d >> 8) & 7u) == K_LONG) d = slow_entry(sh, 1, br.bb);
+  if ((d & 15u) == 0 || ((d >> 8) & 7u) != K_DIST) return K_BAD;
+  br.drop(d & 15u);
+  *hi = (d >> 16) + br.bits((d >> 4) & 15u);
+  return K_LEN;
+}
+
+MGI_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u)); }
+
+// The symbol that WOULD start o bits into the words W (o < 96), decoded by one lane: both table look-ups, extra bits included.
+// -> *tot = its bits (at most 48) with *len / *hi, or *tot = 0: the scalar path's business (*len = why: K_EOB, K_LONG, K_BAD).
+MGI_HD void decode_at(const Shared& sh, const uint32_t (&W)[5], uint32_t o, uint32_t* tot, uint32_t* len, uint32_t* hi) {
+  const uint32_t i = o >> 5, sft = o & 31u;
+  const uint32_t a0 = i == 0 ? W[0] : i == 1 ? W[1] : W[2], a1 = i == 0 ? W[1] : i == 1 ? W[2] : W[3], a2 = i == 0 ? W[2] : i == 1 ? W[3] : W[4];
+  const uint32_t b0 = funnel32(a1, a0, sft), b1 = funnel32(a2, a1, sft);  // the 64 bits at o
+  const uint32_t e = sh.lit[b0 & ((1u << LB) - 1u)];
+  const uint32_t nb = e & 15u, kind = (e >> 8) & 7u;
+  *hi = 0;
+  if (kind == K_LIT && nb) {
+    *tot = nb;
+    *len = 1;
+    *hi = (e >> 16) << 16;
+    return;
+  }
+  *tot = 0;
+  *len = nb == 0 ? (uint32_t)K_BAD : kind;
+  if (kind != K_LEN || nb == 0) return;
+  const uint32_t xb = (e >> 4) & 15u;
+  const uint32_t length = (e >> 16) + ((b0 >> nb) & ((1u << xb) - 1u));
+  const uint32_t c1 = nb + xb;  // 1..20
+  const uint32_t y = (b0 >> c1) | (b1 << (32u - c1));
+  const uint32_t d = sh.dist[y & ((1u << DB) - 1u)];
+  const uint32_t dn = d & 15u, dk = (d >> 8) & 7u;
+  if (dk != K_DIST || dn == 0) { *len = dk == K_LONG ? (uint32_t)K_LONG : (uint32_t)K_BAD; return; }
+  const uint32_t dxb = (d >> 4) & 15u;
+  *hi = (d >> 16) + ((y >> dn) & ((1u << dxb) - 1u));
+  *len = length;
+  *tot = c1 + dn + dxb;
+}
+
+// Symbols until the batch is full (-> 0), the block ends (-> 1), or an ST_ error.  Every step looks at a window of 64 bit
+// positions: lane l decodes the symbol that would start at bit l (decode_at), a uniform walk from bit 0 — one v_readlane per
+// symbol — picks the lanes that really start one, and those lanes queue their symbols: place in the batch from a popcount, first
+// output byte from a prefix sum of the lengths, a bit in the bitmap of first bytes.  queue = false: count only.
+template <class Exec>
+MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, uint32_t* nsym_out, uint32_t* T_out) {
+  uint32_t nsym = 0, T = 0, rc = 0;
+  uint64_t pos = br.pos();
+  const uint32_t* in = br.in;
+  const uint64_t nwords = br.nwords;
+  if (queue) {
+    ex.sync();
+    ex.lanes([&](int lane) { sh.headbits[lane] = 0; });
+    ex.sync();
+  }
+  for (;;) {
+    if (nsym + 64 > kBatchSyms || T + 258 > kBatchBytes) break;
+    const uint64_t wi = pos >> 5;
+    const uint32_t so = (uint32_t)pos & 31u;
+    uint32_t W[5];
+    if (wi + 5 <= nwords) {
+      for (uint32_t i = 0; i < 5; ++i) W[i] = MGI_UNI(in[wi + i]);
+    } else {
+      for (uint32_t i = 0; i < 5; ++i) W[i] = wi + i < nwords ? MGI_UNI(in[wi + i]) : 0u;
+    }
+    ex.lanes([&](int lane) {
+      uint32_t tot, len, hi;
+      decode_at(sh, W, so + (uint32_t)lane, &tot, &len, &hi);
+      ex.set_sym(lane, tot, len, hi);
+    });
+    // which lanes start a symbol: from bit 0, every symbol says where the next one starts
+    uint32_t off = 0, cnt = 0;
+    uint64_t S = 0;
+    bool special = false;
+    while (off < 64) {
+      const uint32_t t = ex.tot_at(off);
+      if (t == 0) { special = true; break; }
+      S |= 1ull << off;
+      ++cnt;
+      off += t;
+    }
+    if (cnt) {
+      ex.sync();
+      ex.lanes([&](int lane) { sh.scan[lane] = (S >> lane) & 1u ? ex.my_len(lane) : 0u; if (lane == 0) sh.cut = 64; });
+      ex.sync();
+      uint32_t total = ex.scan();
+      ex.sync();
+      if (T + total > kBatchBytes) {  // the batch's bytes run out inside this window: up to the first symbol that does not fit
+        ex.lanes([&](int lane) {
+          if (((S >> lane) & 1u) && T + sh.scan[lane] + ex.my_len(lane) > kBatchBytes) Exec::atomic_min(&sh.cut, (uint32_t)lane);
+        });
+        ex.sync();
+        const uint32_t c = MGI_UNI(sh.cut);
+        total = MGI_UNI(sh.scan[c]);
+        S &= (1ull << c) - 1ull;
+        cnt = popc64(S);
+        off = c;
+        special = false;
+      }
+      if (queue) {
+        ex.lanes([&](int lane) {
+          if (!((S >> lane) & 1u)) return;
+          const uint32_t i = nsym + popc64(S & ((1ull << lane) - 1ull));
+          const uint32_t dst = T + sh.scan[lane];
+          sh.rec_lo[i] = dst | ex.my_len(lane) << 16;
+          sh.rec_hi[i] = ex.my_hi(lane);
+          Exec::atomic_or64(&sh.headbits[dst >> 6], 1ull << (dst & 63u));
+        });
+      }
+      nsym += cnt;
+      T += total;
+    }
+    pos += off;
+    if (!special) {
+      if (cnt == 0) break;  // (the first symbol of the window did not fit the batch any more)
+      continue;
+    }
+    const uint32_t why = ex.len_at(off);
+    if (why == K_BAD) { rc = ST_BAD_SYMBOL; break; }
+    BitReader one;
+    one.init(in, nwords, pos);
+    uint32_t len = 0, hi = 0;
+    const uint32_t kind = decode_one(sh, one, &len, &hi);
+    if (kind == K_BAD) { rc = ST_BAD_SYMBOL; break; }
+    if (kind == K_EOB) { pos = one.pos(); rc = 1; break; }
+    if (nsym + 1 > kBatchSyms || T + len > kBatchBytes) break;  // (not taken: the next batch starts with it)
+    if (queue) {
+      ex.sync();
+      if (ex.leader()) {
+        sh.rec_lo[nsym] = T | len << 16;
+        sh.rec_hi[nsym] = hi;
+        sh.headbits[T >> 6] |= 1ull << (T & 63u);
+      }
+      ex.sync();
+    }
+    ++nsym;
+    T += len;
+    pos = one.pos();
+  }
+  if (queue && T) {  // how many symbols start before every 64 bytes of the batch
+    ex.sync();
+    ex.lanes([&](int lane) { sh.scan[lane] = popc64(sh.headbits[lane]); });
+    ex.sync();
+    ex.scan();
+    ex.sync();
+    ex.lanes([&](int lane) { sh.headbase[lane] = (uint16_t)sh.scan[lane]; });
+  }
+  br.init(in, nwords, pos);
+  *nsym_out = nsym;
+  *T_out = T;
+  return rc;
+}
+
+// ---- emission: lane l makes bytes l, l + 64, ... of the batch ----
+// out: the job's output (element 0 = the first the job produces); pos0: elements before the batch; floor: the position
+// below which nothing may be referenced — the member's start inside the job, 0 when the job starts a member, and
+// -32768 for a job that starts inside a member (16-bit output only: positions below 0 become window symbols).
+template <class OutT>
+MGI_HD void emit_lane(Shared& sh, int lane, uint32_t T, OutT* out, uint64_t pos0, int64_t floor) {
+  for (uint32_t f = (uint32_t)lane; f < T; f += 64) {
+    uint32_t p = f;
+    uint32_t val;
+    for (;;) {
+      const uint32_t w = p >> 6;
+      const uint32_t own = sh.headbase[w] + popc64(sh.headbits[w] & ((2ull << (p & 63u)) - 1ull)) - 1u;
+      const uint32_t lo = sh.rec_lo[own], hi = sh.rec_hi[own];
+      const uint32_t dist = hi & 0xffffu;
+      if (dist == 0) { val = hi >> 16; break; }
+      const uint32_t dst = lo & 0xffffu, len = lo >> 16;
+      uint32_t off = p - dst;
+      if (dist < len) off %= dist;  // a match that overlaps itself repeats its first dist bytes
+      const int64_t q = (int64_t)pos0 + (int64_t)dst + (int64_t)off - (int64_t)dist;
+      if (q >= (int64_t)pos0) { p = (uint32_t)(q - (int64_t)pos0); continue; }  // made by this batch: follow it
+      if (q < floor) { sh.err = ST_BAD_DIST; val = 0; break; }
+      if (q >= 0) { val = out[q]; break; }
+      val = sizeof(OutT) == 2 ? (0x8000u | (uint32_t)(q + (int64_t)kWindow)) : 0u;  // (q < 0 <= floor is excluded for bytes by the caller's floor)
+      break;
+    }
+    out[pos0 + f] = (OutT)val;
+  }
+}
+
+// ---- gzip member header at byte P (RFC 1952) -> first byte of the deflate data.  0 ok, 1 not a member, 2 ends inside ----
+MGI_HD uint32_t in_byte(const uint32_t* in, uint64_t i) { return (MGI_UNI(in[i >> 2]) >> (8u * ((uint32_t)i & 3u))) & 0xffu; }
+MGI_HD uint32_t gzip_header(const uint32_t* in, uint64_t nbytes, uint64_t P, uint64_t* data) {
+  // what is there of the first three bytes decides between "not a member" (trailing garbage, ignored as gzip does) and "cut"
+  const uint32_t magic[3] = {0x1f, 0x8b, 8};
+  for (uint32_t i = 0; i < 3; ++i) {
+    if (P + i >= nbytes) return i == 0 ? 1u : 2u;
+    if (in_byte(in, P + i) != magic[i]) return 1u;
+  }
+  if (P + 10 > nbytes) return 2u;
+  const uint32_t flg = in_byte(in, P + 3);
+  uint64_t at = P + 10;
+  if (flg & 4u) {  // FEXTRA
+    if (at + 2 > nbytes) return 2u;
+    at += 2 + (in_byte(in, at) | in_byte(in, at + 1) << 8);
+  }
+  for (uint32_t f = 8u; f <= 16u; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
+    if (!(flg & f)) continue;
+    for (;;) {
+      if (at >= nbytes) return 2u;
+      if (in_byte(in, at++) == 0) break;
+    }
+  }
+  if (flg & 2u) at += 2;  // FHCRC
+  if (at > nbytes) return 2u;
+  *data = at;
+  return 0u;
+}
+
+// ---- a job: blocks from start_bit until a boundary at or behind stop_bit / the end of the member / of the stream ----
+// in: the compressed bytes as words, nbytes of them there so far, input_final: that is the whole file.
+// out: the job's own output (already offset).  events / nevents / max_events: member ends inside jobs (global, atomic).
+struct alignas(16) Sym8 { uint16_t v[8]; };
+// tail (16-bit output only; may be null): 32768 symbols, 16-byte aligned — the window BEHIND the job as far as the job knows it:
+// its last 32 KB of symbols, or, for a shorter job, the end of the window in front of it (as window symbols) and then its own.
+template <class Exec, class OutT>
+MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, bool input_final, const Job& job, uint32_t jobidx,
+                    OutT* out, Result* res, Event* events, uint32_t* nevents, uint32_t max_events, uint16_t* tail = nullptr) {
+  const uint64_t nbits = nbytes * 8, nwords = (nbytes + 3) / 4;
+  const uint32_t cut = input_final ? ST_TRUNC : ST_NEED_MORE;
+  uint64_t outn = 0;
+  int64_t floor = (job.flags & F_MEMBER_START) ? 0 : (sizeof(OutT) == 2 ? -(int64_t)kWindow : 0);
+  uint32_t status = 0, overflow = 0, nblocks = 0, nev = 0, crc = 0, isize = 0;
+  bool count_only = (job.flags & F_COUNT_ONLY) != 0;
+  uint64_t pos = job.start_bit;
+  if (ex.leader()) sh.err = 0;
+  if (job.flags & F_HEADER) {
+    uint64_t data = 0;
+    const uint32_t h = gzip_header(in, nbytes, pos >> 3, &data);
+    if (h) status = h == 1 ? ST_BAD_HEADER : cut;
+    pos = data * 8;
+  }
+  BitReader br;
+  br.init(in, nwords, pos);
+  while (!status) {
+    if (br.pos() >= job.stop_bit) { status = ST_STOP; break; }
+    br.refill();
+    if (br.pos() + 3 > nbits) { status = cut; break; }
+    const uint32_t bfinal = br.bits(1), btype = br.bits(2);
+    ++nblocks;
+    if (btype == 3) { status = ST_BAD_BLOCK; break; }
+    if (btype == 0) {
+      br.drop(br.bc & 7u);  // to the byte boundary (pos() is a multiple of 8 exactly when bc is)
+      br.refill();
+      if (br.pos() + 32 > nbits) { status = cut; break; }
+      const uint32_t len = br.bits(16);
+      br.refill();
+      const uint32_t nlen = br.bits(16);
+      if ((len ^ nlen) != 0xffffu) { status = ST_BAD_STORED; break; }
+      const uint64_t P = br.pos() >> 3;
+      if (P + len > nbytes) { status = cut; break; }
+      if (!count_only && outn + len > job.out_cap) { overflow = 1; count_only = true; }
+      if (!count_only) {
+        const uint8_t* bytes = reinterpret_cast<const uint8_t*>(in);
+        ex.lanes([&](int lane) {
+          for (uint32_t i = (uint32_t)lane; i < len; i += 64) out[outn + i] = (OutT)bytes[P + i];
+        });
+      }
+      outn += len;
+      br.init(in, nwords, (P + len) * 8);
+    } else {
+      uint32_t nlit = 288, ndist = 32, rc;
+      if (btype == 1) {
+        fixed_lengths(ex, sh);
+      } else {
+        rc = read_dynamic_lengths(ex, sh, br, &nlit, &ndist);
+        if (rc) { status = rc; break; }
+        if (br.pos() > nbits) { status = cut; break; }
+      }
+      rc = build_table(ex, sh, 0, 0, nlit, true);
+      if (!rc) rc = build_table(ex, sh, 1, nlit, ndist, true);
+      if (rc) { status = rc; break; }
+      for (;;) {
+        uint32_t nsym = 0, T = 0;
+        rc = decode_batch(ex, sh, br, !count_only, &nsym, &T);
+        if (rc >= ST_ERR) { status = rc; break; }
+        if (br.pos() > nbits) { status = cut; break; }
+        if (!count_only && outn + T > job.out_cap) { overflow = 1; count_only = true; }
+        if (!count_only && T) {
+          ex.sync();
+          ex.lanes([&](int lane) { emit_lane<OutT>(sh, lane, T, out, outn, floor); });
+          ex.sync();
+          const uint32_t er = MGI_UNI(sh.err);
+          if (er) { status = er; break; }
+        }
+        outn += T;
+        if (rc == 1) break;
+      }
+      if (status) break;
+    }
+    if (bfinal) {  // the member's trailer: CRC-32 and ISIZE at the next byte boundary
+      br.drop(br.bc & 7u);
+      br.refill();
+      if (br.pos() + 64 > nbits) { status = cut; break; }
+      crc = br.bits(32);
+      br.refill();
+      isize = br.bits(32);
+      if (job.flags & F_ONE_MEMBER) { status = ST_MEMBER; break; }
+      ++nev;
+      if (ex.leader()) {
+        uint32_t at;
+#if defined(__HIP_DEVICE_COMPILE__)
+        at = __hip_atomic_fetch_add(nevents, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        at = (*nevents)++;
+#endif
+        if (at < max_events) {
+          events[at].out_pos = outn;
+          events[at].job = jobidx;
+          events[at].crc = crc;
+          events[at].isize = isize;
+          events[at].pad = 0;
+        } else {
+          sh.err = ST_EVENTS_FULL;
+        }
+      }
+      ex.sync();
+      if (MGI_UNI(sh.err)) { status = ST_EVENTS_FULL; break; }
+      uint64_t data = 0;
+      const uint32_t h = gzip_header(in, nbytes, br.pos() >> 3, &data);
+      if (h == 1) {  // nothing follows, or something that is no member (padding, garbage: ignored as gzip does): the stream is over
+        status = (br.pos() >> 3) >= nbytes && !input_final ? ST_NEED_MORE : ST_END;
+        break;
+      }
+      if (h == 2) { status = cut; break; }
+      floor = (int64_t)outn;
+      br.init(in, nwords, data * 8);
+    }
+  }
+  if (sizeof(OutT) == 2 && tail && !count_only && status < ST_ERR) {
+    ex.sync();
+    ex.lanes([&](int lane) {
+      for (uint32_t w0 = (uint32_t)lane * 8u; w0 < kWindow; w0 += 512u) {
+        Sym8 x;
+        for (uint32_t k = 0; k < 8; ++k) {
+          const uint32_t w = w0 + k;
+          x.v[k] = outn >= kWindow ? (uint16_t)out[outn - kWindow + w]
+                                   : (w < kWindow - outn ? (uint16_t)(0x8000u | (w + (uint32_t)outn)) : (uint16_t)out[w - (kWindow - (uint32_t)outn)]);
+        }
+        *reinterpret_cast<Sym8*>(tail + w0) = x;
+      }
+    });
+  }
+  // garbage decoded from behind the end of the input is the input's end, not a damaged stream
+  if (status >= ST_ERR && status != ST_BAD_HEADER && br.pos() > nbits) status = cut;
+  if (ex.leader()) {
+    res->end_bit = br.pos();
+    res->out_count = outn;
+    res->status = status;
+    res->overflow = overflow;
+    res->crc = crc;
+    res->isize = isize;
+    res->nblocks = nblocks;
+    res->nevents = nev;
+  }
+}
+
+// ---- block-start finder ----
+// Could a dynamic-Huffman block with BFINAL = 0 begin at bit p?  The cheap part, per lane: header fields in range and the
+// code-length code a complete prefix code (what zlib, pigz, libdeflate write; a false negative only costs parallelism).
+// lo / hi: the 128 bits that start at the candidate position
+MGI_HD bool probe_bits(uint64_t lo, uint64_t hi) {
+  if ((lo & 7u) != 4u) return false;  // BFINAL = 0, BTYPE = 2 (bits 1-2, LSB first)
+  if (((lo >> 3) & 31u) > 29u || ((lo >> 8) & 31u) > 29u) return false;
+  const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
+  const uint64_t v = lo >> 17;                             // lengths 0..14
+  const uint32_t v2 = (uint32_t)((lo >> 62) | (hi << 2));  // lengths 15..18
+  uint32_t kraft = 0;
+  for (uint32_t i = 0; i < 19; ++i) {
+    const uint32_t l = i < 15 ? (uint32_t)(v >> (3 * i)) & 7u : (v2 >> (3 * (i - 15))) & 7u;
+    kraft += (i < ncl && l) ? 128u >> l : 0u;
+  }
+  return kraft == 128u;
+}
+MGI_HD bool probe_block_start(const uint32_t* in, uint64_t nwords, uint64_t p) {
+  const uint64_t w = p >> 5;
+  const uint32_t s = (uint32_t)p & 31u;
+  uint32_t a[4];
+  for (uint32_t i = 0; i < 4; ++i) a[i] = w + i < nwords ? in[w + i] : 0u;
+  const uint64_t x0 = a[0] | (uint64_t)a[1] << 32, x1 = a[2] | (uint64_t)a[3] << 32;
+  return probe_bits(s ? (x0 >> s) | (x1 << (64 - s)) : x0, x1 >> s);
+}
+// ... and the whole header (uniform): the code lengths decode, both codes are complete (or there is at most one distance code)
+template <class Exec>
+MGI_HD bool validate_block_start(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, uint64_t p) {
+  BitReader br;
+  br.init(in, (nbytes + 3) / 4, p);
+  br.refill();
+  br.drop(3);
+  uint32_t nlit = 0, ndist = 0;
+  if (read_dynamic_lengths(ex, sh, br, &nlit, &ndist)) return false;
+  if (br.pos() > nbytes * 8) return false;
+  if (build_table(ex, sh, 0, 0, nlit, false, true)) return false;
+  if (build_table(ex, sh, 1, nlit, ndist, false, true)) return false;
+  return true;
+}
+
+// ---- CRC-32 (gzip): combination of the CRCs of adjacent pieces, as zlib's crc32_combine does it since 1.2.12 ----
+constexpr uint32_t kCrcPoly = 0xedb88320u;
+MGI_HD uint32_t crc_multmodp(uint32_t a, uint32_t b) {  // a(x) * b(x) mod p(x), reflected
+  uint32_t m = 1u << 31, p = 0;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1)) == 0) break;
+    }
+    m >>= 1;
+    b = b & 1 ? (b >> 1) ^ kCrcPoly : b >> 1;
+  }
+  return p;
+}
+// x^(8 n) mod p(x): x2n[k] = x^(2^k) mod p
+MGI_HD uint32_t crc_x8n(uint64_t nbytes, const uint32_t* x2n) {
+  uint32_t p = 1u << 31;
+  uint32_t k = 3;
+  while (nbytes) {
+    if (nbytes & 1) p = crc_multmodp(x2n[k & 31u], p);
+    nbytes >>= 1;
+    ++k;
+  }
+  return p;
+}
+MGI_HD void crc_make_x2n(uint32_t* x2n) {
+  uint32_t p = 1u << 30;  // x^1
+  x2n[0] = p;
+  for (uint32_t n = 1; n < 32; ++n) x2n[n] = p = crc_multmodp(p, p);
+}
+// crc of A || B from crc(A), crc(B), len(B)
+MGI_HD uint32_t crc_combine(uint32_t crc1, uint32_t crc2, uint64_t len2, const uint32_t* x2n) {
+  return crc_multmodp(crc_x8n(len2, x2n), crc1) ^ crc2;
+}
+
+}  // namespace mgi

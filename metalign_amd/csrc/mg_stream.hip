@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "mg_inflate.h"
 #include "mg_internal.h"
 #include "mg_pgzip.h"
 
@@ -811,6 +812,18 @@ static int default_threads() {
   return (int)(hw > 8 ? 8 : hw);
 }
 
+// A `.gz` file (gzip or BGZF) whose compressed bytes go to the device and are inflated there (mg_inflate.hip), unless
+// mg_inflate_config turned that off: -> fd >= 0 and its size; -1: not such a file (the host readers take it)
+static int open_for_device_inflate(const char* path, uint64_t offset, uint64_t length, uint64_t* fsize) {
+  if (!inflate_dev_enabled() || offset || length) return -1;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return -1;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || !looks_gzip(fd)) { close(fd); return -1; }
+  *fsize = (uint64_t)sb.st_size;
+  return fd;
+}
+
 }  // namespace mg
 
 using namespace mg;
@@ -822,6 +835,25 @@ int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format
   MG_REQUIRE_READY();
   if (!ss || !path) return fail(MG_ERR_ARG, "null argument");
   if (format < 0 || format > 2) return fail(MG_ERR_ARG, "format must be 0 (fastq), 1 (single-line fasta) or 2 (fasta)");
+  {
+    uint64_t fsize = 0;
+    const int gfd = open_for_device_inflate(path, offset, length, &fsize);
+    if (gfd >= 0) {
+      Consumer consume_gz = [&](const uint8_t* d_text, uint64_t nbytes, bool final, uint64_t* consumed) -> int {
+        mg_reads* rd = nullptr;
+        MG_TRY(mg_reads_parse_prefix_dev(d_text, nbytes, format, final ? 1 : 0, consumed, &rd));
+        const uint8_t* d_b = nullptr;
+        const uint64_t* d_o = nullptr;
+        int rc = mg_reads_device_ptrs(rd, &d_b, &d_o);
+        if (rc == MG_OK) rc = mg_sketch_stream_add_dev(ss, d_b, d_o, mg_reads_count(rd), mg_reads_nbases(rd));
+        mg_reads_free(rd);
+        return rc;
+      };
+      const int rc = inflate_file_pipeline(gfd, fsize, consume_gz);
+      close(gfd);
+      return rc;
+    }
+  }
   std::unique_ptr<Source> src;
   bool gz = false;
   bool thinned = false;
@@ -863,7 +895,9 @@ int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64
   bool gz = false;
   bool thinned = false;
   const bool auto_threads = nthreads <= 0;
-  MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz, paf ? -1 : (int)ThinSource::kSam, &thinned));
+  uint64_t gsize = 0;
+  const int gfd = open_for_device_inflate(path, offset, length, &gsize);
+  if (gfd < 0) MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz, paf ? -1 : (int)ThinSource::kSam, &thinned));
   if (nthreads <= 0) nthreads = default_threads();
   if (thinned && auto_threads) nthreads = thin_threads(nthreads);
   std::vector<std::unique_ptr<mg_sam_batch>> parts;
@@ -877,7 +911,13 @@ int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64
     parts.emplace_back(b);
     return MG_OK;
   };
-  MG_TRY(run_pipeline(*src, chunk_bytes, nthreads, consume, nullptr));
+  if (gfd >= 0) {
+    const int rc = inflate_file_pipeline(gfd, gsize, consume);
+    close(gfd);
+    MG_TRY(rc);
+  } else {
+    MG_TRY(run_pipeline(*src, chunk_bytes, nthreads, consume, nullptr));
+  }
   std::unique_ptr<mg_sam_batch> all(new mg_sam_batch());
   all->last_qname = prev;
   all->nrecs = total;
