@@ -62,6 +62,10 @@ PRESETS = {
     4: dict(reads=12_500_000, genomes=200_000, genome_len=5_000, ks=[21, 31, 51], ntax=10_001,
             name="configs[4]: configs[3] + alignment replay -> full CAMI profile"),
 }
+# the reference's OWN parameters (scripts/select_db.py:44,50,69-70,75: kmc -k60, StreamingQueryDNADatabase 30-60-10, n = 1000) on
+# configs[2]'s sizes: --preset stock makes it the headline; the default line carries it in `definitions`
+STOCK_KS = [30, 40, 50, 60]
+STOCK_NAME = "stock Metalign parameters (k_max = 60, k range 30-60-10, n = 1000) on configs[2]'s sizes"
 
 
 def parse():
@@ -74,6 +78,7 @@ def parse():
     p.add_argument("--genomes", type=int, default=0)
     p.add_argument("--genome_len", type=int, default=0)
     p.add_argument("--ks", type=str, default="", help="comma-separated k-mer sizes (overrides the preset)")
+    p.add_argument("--preset", choices=["", "stock"], default="", help="stock: the reference's own k_max = 60, range 30-60-10 on configs[2]'s sizes")
     p.add_argument("--sketch_n", type=int, default=1000)
     p.add_argument("--definition", choices=["reference_pipeline", "sketch_per_k"], default="reference_pipeline",
                    help="stage A/B as the reference wires it (reads sketched at the largest k only; default) or a sketch per k")
@@ -102,6 +107,9 @@ def resolve_config(args, world):
         pre["genome_len"] = args.genome_len
     if args.ks:
         pre["ks"] = [int(x) for x in args.ks.split(",")]
+    if args.preset == "stock":
+        pre["ks"] = list(STOCK_KS)
+        pre["name"] = STOCK_NAME
     pre["custom"] = bool(args.reads or args.genomes or args.genome_len or args.ks)
     pre["config"] = cfg
     pre["definition"], pre["hash_mode"] = args.definition, args.hash_mode
@@ -275,6 +283,28 @@ def committed_profile(name, cfg):
     return best
 
 
+def committed_kernel_stats(cfg):
+    """The dominant kernel's average duration in the committed `rocprofv3 --kernel-trace --stats` summary of this workload
+    (profiles/<round>/config<N>_kernel_stats.csv, newest round): the cross-check of roofline.kernel_ms_alone."""
+    import csv
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    kmax = cfg["ks"][-1] if cfg.get("definition") == "reference_pipeline" else None
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        fn = os.path.join(pdir, rnd, "config%d_kernel_stats.csv" % cfg["config"])
+        if not os.path.isfile(fn):
+            continue
+        with open(fn) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("kernel", row.get("Name", ""))
+                if "k_sketch_reads" in name and (kmax is None or ("<%d," % kmax) in name):
+                    best = {"kernel": name, "avg_ms": float(row.get("avg_ns", row.get("AverageNs", 0))) / 1e6,
+                            "calls": int(row.get("calls", row.get("Calls", 0))),
+                            "source": "profiles/%s/config%d_kernel_stats.csv" % (rnd, cfg["config"])}
+                    break
+    return best
+
+
 def valu_roofline(sq, ms_alone_live):
     """valu_frac and what it was computed from; {} of Nones when a piece is missing."""
     out = {"valu_frac": None, "valu_model": None}
@@ -353,15 +383,19 @@ def other_definitions(hip, args, cfg, w):
     """The stage A/B definitions that were NOT selected, on the same reads / records / genomes, over the same number of
     pipelined passes (untimed by the driver; the same loop as the headline's): ms per pass and reads/s each."""
     out = {}
-    for definition, mode in (("reference_pipeline", 0), ("reference_pipeline", 1), ("sketch_per_k", 0)):
-        if (definition, mode) == (args.definition, args.hash_mode):
+    todo = [("reference_pipeline", 0, None), ("reference_pipeline", 1, None), ("sketch_per_k", 0, None)]
+    if cfg["ks"] != STOCK_KS:  # the reference's own k set, both hash definitions (the only configuration a Metalign user runs)
+        todo += [("reference_pipeline", 0, STOCK_KS), ("reference_pipeline", 1, STOCK_KS)]
+    for definition, mode, ks in todo:
+        if (definition, mode) == (args.definition, args.hash_mode) and ks is None:
             continue
         t0 = time.perf_counter()
         w2 = dict(w)
         for key in ("ref_arrays", "reftable", "dbh", "dbo"):
             w2.pop(key, None)
-        w2.update(build_tables(cfg, args.sketch_n, hip, w["gb"], w["go"], definition, mode))
-        job = make_job(hip, None, 0, 1, cfg, w2)
+        cfg_run = cfg if ks is None else dict(cfg, ks=list(ks), name=STOCK_NAME)
+        w2.update(build_tables(cfg_run, args.sketch_n, hip, w["gb"], w["go"], definition, mode))
+        job = make_job(hip, None, 0, 1, cfg_run, w2)
         job.run(max(args.warmup, 2))
         hip.sync()
         hip.prof_reset()
@@ -373,12 +407,21 @@ def other_definitions(hip, args, cfg, w):
         dt = (time.perf_counter() - t1) / args.steps
         nk1, k1_ms = hip.prof_get("sketch_reads")
         hip.prof_enable(False)
-        out["%s_mode%d" % (definition, mode)] = {
-            "definition": definition, "hash_mode": mode, "ms_per_pass": 1e3 * dt, "value": cfg["reads"] / dt, "unit": "reads/s",
+        key = ("stock_" if ks is not None else "") + "%s_mode%d" % (definition, mode)
+        out[key] = {
+            "definition": definition, "hash_mode": mode, "ks": cfg_run["ks"], "ms_per_pass": 1e3 * dt, "value": cfg["reads"] / dt, "unit": "reads/s",
             "steps": args.steps, "stage_a_avg_launch_ms": k1_ms / max(nk1, 1), "stage_a_launches_per_pass": nk1 / max(args.steps, 1),
             "sketched_ks": res.get("sketched_ks"), "sketch_sizes": res.get("sketch_sizes"), "top_genomes_recovered": res.get("top_ok"),
             "setup_s": t1 - t0}
         del job
+        if ks is not None and mode == 0 and not args.no_cpu_baseline:
+            # the stock preset against the oracle on a sample of its own (all 10 000 genomes x {30,40,50,60}, every stage-C accumulator)
+            import copy
+            a2 = copy.copy(args)
+            a2.cpu_seconds = min(args.cpu_seconds, 6.0)
+            base2, chk2 = cpu_baseline_and_check(a2, cfg_run, w2, hip)
+            out[key]["check"] = chk2
+            out[key]["cpu_baseline"] = {k2: base2[k2] for k2 in ("value", "unit", "cores", "kind")}
         if w2.get("reftable") is not None:
             w2["reftable"].free()
         hip.mem_trim()
@@ -581,7 +624,12 @@ def main():
         k1_per_pass_ms = k1_ms / max(args.steps, 1)  # all k of one pass (one fused launch, or one launch per k)
         launches_per_pass = nk1 / max(args.steps, 1)
         algo_k1 = ALGO_BYTES_PER_READ_K1 * nreads
-        achieved = algo_k1 / (k1_per_pass_ms * 1e-3) / 1e9 if nk1 else 0.0
+        # the kernel's OWN duration: HIP events around it with nothing else on the device (the extra one-stream steps below the
+        # timed region; rocprofv3's average of the same kernel is in profiles/<round>/config2_kernel_stats.csv).  In the timed
+        # region two launches overlap (stage A of pass i + 1 starts while pass i finishes), so a launch there is STRETCHED
+        # (avg_launch_ms_pipelined) although one starts every period_ms: that is why ms_per_step can be below the kernel alone.
+        k1_alone_ms = kernels_ms.get("sketch_reads", {}).get("ms_per_pass") or k1_per_pass_ms
+        achieved = algo_k1 / (k1_alone_ms * 1e-3) / 1e9 if k1_alone_ms else 0.0
         traffic = committed_profile("pmc_traffic.json", cfg)
         sq = committed_profile("pmc_sq_summary.json", cfg)
         valu_insts = sq["k_sketch_reads"].get("SQ_INSTS_VALU_per_pass") if sq else None
@@ -589,8 +637,12 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (traffic["k_sketch_reads"].get("hbm_bytes_per_pass", traffic["k_sketch_reads"].get("hbm_bytes_per_launch"))
                             if traffic else None),
-                "avg_launch_ms": k1_ms / max(nk1, 1), "ms_per_pass": k1_per_pass_ms,
+                "kernel_ms_alone": k1_alone_ms, "period_ms": ms,
+                "avg_launch_ms_pipelined": k1_ms / max(nk1, 1), "overlap_ms": max(0.0, k1_per_pass_ms - ms),
+                "ms_per_pass_pipelined": k1_per_pass_ms,
+                "rocprofv3": committed_kernel_stats(cfg),
                 "algorithmic_bytes_per_pass": algo_k1,
+                "traffic_correction": (traffic or {}).get("correction"),
                 # VALU roofline (the kernel is integer-VALU bound), calibrated: every opcode of the hot loop priced with its
                 # measured issue cost (tools/ubench_valu.hip -> profiles/<round>/valu_classes.json; tools/valu_roofline.py
                 # -> k1_valu_roofline.json: cycles per VALU instruction of this kernel's mix), times the VALU instructions the
@@ -602,8 +654,9 @@ def main():
                 "note": "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
                         "cycles per VALU instruction of this kernel's opcode mix / the SIMD cycles of the launch (GRBM_GUI_ACTIVE "
                         "/ 8 x 1024), all from the committed PMC pass of this workload, is the figure that describes it; achieved "
-                        "/ frac price 158 B/read, one pass for all k, with the average launch duration of the (pipelined) timed "
-                        "region against 8 TB/s"}
+                        "/ frac = 158 B/read x reads / kernel_ms_alone (the kernel's own duration, HIP events, nothing else on the "
+                        "device) against 8 TB/s; in the timed region a launch starts every period_ms and overlaps its predecessor "
+                        "by overlap_ms (avg_launch_ms_pipelined is the stretched duration there)"}
         kern = []
         if "containment" in kernels_ms:
             t_b = kernels_ms["containment"]["ms_per_pass"] + kernels_ms.get("contain_index", {}).get("ms_per_pass", 0.0)

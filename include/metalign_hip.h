@@ -375,7 +375,7 @@ int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_pat
  *                     stream; synchronised on return).  MG_ERR_ARG with zlib's wording in mg_last_error for a corrupt or
  *                     truncated stream.
  *   mg_inflate_config: chunk_bytes = compressed bytes per job of a gzip stream (default 32 KB), stage_bytes = compressed bytes
- *                     decoded together (default 128 MB), ratio = symbols reserved per compressed byte (default 10; a job that
+ *                     decoded together (default 176 MB), ratio = symbols reserved per compressed byte (default 10; a job that
  *                     needs more is decoded again), on = whether the streaming entry points use the device inflater; values
  *                     <= 0 (on: < 0) leave a setting as it is.
  *   mg_inflate_stats: counters since the last reset (host seconds of the stages' phases, jobs, jobs decoded again).
@@ -383,6 +383,9 @@ int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_pat
 typedef struct mg_inflated mg_inflated;
 typedef struct mg_inflate_counters {
   uint64_t stages, jobs, redone, find_candidates, find_steps;
+  uint64_t blocks, batches, windows, symbols_out;               /* deflate blocks, symbol batches, 64-bit windows, bytes produced */
+  uint64_t clk_tables, clk_decode, clk_emit, clk_tail;          /* shader clocks summed over the jobs: where a job's time goes */
+  uint64_t clk_sub[6];                                          /* (a -DMGI_SUBCLOCKS build only) inside clk_decode: stage refill, lanes' decode, walk, prefix sums, queueing, rest */
   double find_s, decode_s, resolve_s, stage_s;
 } mg_inflate_counters;
 int mg_inflate_dev(const uint8_t* comp, uint64_t ncomp, mg_inflated** out);

@@ -940,11 +940,13 @@ class Hip:
         """-> dict of the device inflater's counters since the last reset."""
         class _C(ctypes.Structure):
             _fields_ = [("stages", ctypes.c_uint64), ("jobs", ctypes.c_uint64), ("redone", ctypes.c_uint64), ("find_candidates", ctypes.c_uint64),
-                        ("find_steps", ctypes.c_uint64), ("find_s", ctypes.c_double),
+                        ("find_steps", ctypes.c_uint64), ("blocks", ctypes.c_uint64), ("batches", ctypes.c_uint64), ("windows", ctypes.c_uint64),
+                        ("symbols_out", ctypes.c_uint64), ("clk_tables", ctypes.c_uint64), ("clk_decode", ctypes.c_uint64), ("clk_emit", ctypes.c_uint64),
+                        ("clk_tail", ctypes.c_uint64), ("clk_sub", ctypes.c_uint64 * 6), ("find_s", ctypes.c_double),
                         ("decode_s", ctypes.c_double), ("resolve_s", ctypes.c_double), ("stage_s", ctypes.c_double)]
         c = _C()
         self._chk(self.lib.mg_inflate_stats(ctypes.byref(c), ctypes.c_int(1 if reset else 0)))
-        return {k: getattr(c, k) for k, _ in _C._fields_}
+        return {k: (list(getattr(c, k)) if k == "clk_sub" else getattr(c, k)) for k, _ in _C._fields_}
 
     # ---- stage A ----
     def count_saturation(self, cs=None):

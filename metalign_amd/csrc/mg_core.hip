@@ -260,6 +260,7 @@ void mg_shutdown(void) {
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
   mg::stream_release_all();
+  mg::inflate_release_all();
   mg::scratch_release_all();
   mg::pool_release_all();
   if (c.pinned) (void)hipHostFree(c.pinned);

@@ -47,6 +47,7 @@ using namespace mgi;
 __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __restrict__ in, uint64_t nbytes, uint64_t grid0, uint64_t chunk_bits,
                                                           uint64_t min_bit, uint64_t limit_bit, uint64_t* __restrict__ starts, uint32_t* __restrict__ info) {
   __shared__ Shared sh;
+  __shared__ uint32_t cand[128];  // candidate positions (bits behind lo), ascending
   const int lane = (int)threadIdx.x;
   DevExec ex{&sh, lane};
   const uint64_t nwords = (nbytes + 3) / 4, nbits = nbytes * 8;
@@ -54,30 +55,52 @@ __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __rest
   uint64_t hi = lo + chunk_bits;
   if (hi > limit_bit) hi = limit_bit;
   uint64_t found = ~0ull;
-  uint32_t ncand = 0, nsteps = 0;
-  for (uint64_t p0 = lo; p0 < hi && found == ~0ull; p0 += 64) {
-    ++nsteps;
-    const uint64_t w = p0 >> 5;
-    uint32_t a[5];
-    for (uint32_t i = 0; i < 5; ++i) a[i] = w + i < nwords ? MGI_UNI(in[w + i]) : 0u;
-    const bool up = lane >= 32;
-    const uint32_t t = (uint32_t)lane & 31u;
-    const uint64_t x0 = (uint64_t)(up ? a[1] : a[0]) | (uint64_t)(up ? a[2] : a[1]) << 32;
-    const uint64_t x1 = (uint64_t)(up ? a[3] : a[2]) | (uint64_t)(up ? a[4] : a[3]) << 32;
-    const uint64_t blo = t ? (x0 >> t) | (x1 << (64 - t)) : x0, bhi = x1 >> t;
-    const uint64_t p = p0 + (uint64_t)lane;
-    const bool ok = p < hi && p > min_bit && p + 80 <= nbits && probe_bits(blo, bhi);
-    uint64_t m = __ballot(ok);
-    while (m) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(m);
-      m &= m - 1;
-      ++ncand;
-      if (validate_block_start(ex, sh, in, nbytes, p0 + l)) { found = p0 + l; break; }
+  uint32_t ncand = 0, tried = 0, nsteps = 0;
+  __shared__ uint32_t words[72];  // 2048 bit positions and what the last of them look at
+  for (uint64_t q0 = lo; q0 < hi && found == ~0ull; q0 += 2048) {
+    // one coalesced load per 32 steps (a step by itself waited for its own five words: the scan was bound by that latency)
+    const uint64_t w0 = q0 >> 5;
+    __syncthreads();
+    words[lane] = w0 + (uint64_t)lane < nwords ? in[w0 + lane] : 0u;
+    if (lane < 8) words[64 + lane] = w0 + 64 + (uint64_t)lane < nwords ? in[w0 + 64 + lane] : 0u;
+    __syncthreads();
+    for (uint32_t t2 = 0; t2 < 32 && q0 + 64ull * t2 < hi && found == ~0ull; ++t2) {
+      ++nsteps;
+      const uint64_t p0 = q0 + 64ull * t2;
+      const uint32_t i = 2u * t2 + ((uint32_t)lane >> 5), sft = (uint32_t)lane & 31u;
+      const uint64_t x0 = (uint64_t)words[i] | (uint64_t)words[i + 1] << 32, x1 = (uint64_t)words[i + 2] | (uint64_t)words[i + 3] << 32;
+      const uint64_t blo = sft ? (x0 >> sft) | (x1 << (64 - sft)) : x0, bhi = x1 >> sft;
+      const uint64_t p = p0 + (uint64_t)lane;
+      const bool ok = p < hi && p > min_bit && p + 80 <= nbits && probe_bits(blo, bhi);
+      const uint64_t m = __ballot(ok);
+      if (m) {
+        if (ok) cand[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)(p - lo);
+        ncand += (uint32_t)__builtin_popcountll(m);
+      }
+      // the candidates' whole headers, up to 64 at once, a lane each (light_validate); the first that passes is looked at once more
+      // by the wavefront as the decoder will read it
+      if (ncand >= 64 || (ncand && p0 + 64 >= hi)) {
+        __syncthreads();
+        for (uint32_t base = 0; base < ncand && found == ~0ull; base += 64) {
+          const uint32_t ci = base + (uint32_t)lane;
+          const bool good = ci < ncand && light_validate(in, nbytes, lo + cand[ci < ncand ? ci : 0]);
+          uint64_t g = __ballot(good);
+          tried += ncand - base < 64 ? ncand - base : 64;
+          while (g) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(g);
+            g &= g - 1;
+            const uint64_t q = lo + cand[base + l];
+            if (validate_block_start(ex, sh, in, nbytes, q)) { found = q; break; }
+          }
+        }
+        __syncthreads();
+        ncand = 0;
+      }
     }
   }
   if (lane == 0) {
     starts[blockIdx.x] = found;
-    info[2 * blockIdx.x] = ncand;
+    info[2 * blockIdx.x] = tried;
     info[2 * blockIdx.x + 1] = nsteps;
   }
 }
@@ -292,7 +315,7 @@ __global__ __launch_bounds__(256) void k_crc_segments(const uint8_t* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 struct InflateConfig {
   uint64_t chunk_bytes = 32u << 10;   // compressed bytes per job of a gzip stream
-  uint64_t stage_bytes = 128u << 20;  // compressed bytes per stage
+  uint64_t stage_bytes = 176u << 20;  // compressed bytes per stage (~5600 jobs: what 256 CUs hold at once)
   uint32_t ratio = 10;                // symbols reserved per compressed byte of a job (a job that needs more is decoded again)
   int on = 1;                         // .gz files of the streaming entry points take the device inflater
 };
@@ -301,6 +324,7 @@ static mg_inflate_counters g_cnt;
 InflateConfig& inflate_cfg() { return g_cfg; }
 bool inflate_dev_enabled() { return g_cfg.on != 0; }
 
+void inflate_release_all();
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -327,6 +351,9 @@ struct CompUploader {
   int device = 0;
 
   ~CompUploader() { finish(); }
+  // page-locking a slot costs milliseconds: the slots and the copy stream stay with the library (inflate_release_all)
+  struct Kept { std::vector<uint8_t*> slots; hipStream_t copy = nullptr; };
+  static Kept& kept() { static Kept k; return k; }
   void finish() {
     {
       std::lock_guard<std::mutex> lk(m);
@@ -336,8 +363,8 @@ struct CompUploader {
     for (auto& t : readers) if (t.joinable()) t.join();
     if (dma.joinable()) dma.join();
     readers.clear();
-    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); copy = nullptr; }
-    for (uint8_t* p : slots) (void)hipHostFree(p);
+    if (copy) (void)hipStreamSynchronize(copy);
+    copy = nullptr;
     slots.clear();
     for (hipEvent_t e : ev_piece) (void)hipEventDestroy(e);
     ev_piece.clear();
@@ -347,13 +374,16 @@ struct CompUploader {
     device = ctx().device;
     npieces = (n + kPiece - 1) / kPiece;
     if (npieces == 0) return MG_OK;
-    MG_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    Kept& k = kept();
+    if (!k.copy) MG_HIP(hipStreamCreateWithFlags(&k.copy, hipStreamNonBlocking));
+    copy = k.copy;
     const size_t ns = npieces < kSlots ? (size_t)npieces : kSlots;
-    for (size_t i = 0; i < ns; ++i) {
+    while (k.slots.size() < ns) {
       uint8_t* p = nullptr;
       MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), kPiece, hipHostMallocDefault));
-      slots.push_back(p);
+      k.slots.push_back(p);
     }
+    slots.assign(k.slots.begin(), k.slots.begin() + (long)ns);
     for (uint64_t i = 0; i < npieces; ++i) {
       hipEvent_t e = nullptr;
       MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -419,6 +449,13 @@ struct CompUploader {
     return MG_OK;
   }
 };
+
+void inflate_release_all() {
+  CompUploader::Kept& k = CompUploader::kept();
+  if (k.copy) { (void)hipStreamSynchronize(k.copy); (void)hipStreamDestroy(k.copy); }
+  for (uint8_t* p : k.slots) (void)hipHostFree(p);
+  k = CompUploader::Kept();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the inflater
@@ -568,6 +605,10 @@ struct DevInflater {
     }
     g_cnt.jobs += nj;
     g_cnt.stages += 1;
+    for (const Result& r : res) {
+      g_cnt.clk_tables += r.t_tab; g_cnt.clk_decode += r.t_dec; g_cnt.clk_emit += r.t_emit; g_cnt.clk_tail += r.t_tail;
+      g_cnt.batches += r.nbatch; g_cnt.windows += r.nstep; g_cnt.blocks += r.nblocks; g_cnt.symbols_out += r.out_count;
+    }
     return MG_OK;
   }
 
@@ -615,6 +656,11 @@ struct DevInflater {
       for (size_t i = at; i < events->size(); ++i) (*events)[i].pad = launch_id;
     }
     g_cnt.jobs += nj;
+    for (const Result& r : L->res) {
+      g_cnt.clk_tables += r.t_tab; g_cnt.clk_decode += r.t_dec; g_cnt.clk_emit += r.t_emit; g_cnt.clk_tail += r.t_tail;
+      g_cnt.batches += r.nbatch; g_cnt.windows += r.nstep; g_cnt.blocks += r.nblocks; g_cnt.symbols_out += r.out_count;
+      for (int i = 0; i < 6; ++i) g_cnt.clk_sub[i] += r.t_sub[i];
+    }
     return MG_OK;
   }
 

@@ -27,10 +27,18 @@
 #else
 #define MGI_HD inline
 #endif
+#define MGI_HDI MGI_HD __attribute__((always_inline))
+#if defined(__clang__)
+#define MGI_UNROLL _Pragma("unroll")
+#else
+#define MGI_UNROLL
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MGI_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define MGI_CLOCK() ((uint64_t)__builtin_readcyclecounter())
 #else
 #define MGI_UNI(x) ((uint32_t)(x))
+#define MGI_CLOCK() ((uint64_t)0)
 #endif
 
 namespace mgi {
@@ -40,6 +48,9 @@ constexpr int DB = 8;                    // ... of the distance table
 constexpr uint32_t kBatchSyms = 256;     // symbols queued per batch
 constexpr uint32_t kBatchBytes = 4096;   // output bytes per batch (bitmap of 64 x 64 bits)
 constexpr uint32_t kWindow = 32768;
+constexpr uint32_t kInWords = 128;       // compressed words staged in LDS for the window decode
+constexpr uint32_t kStepBits = 256;      // bit positions one window step looks at (four per lane)
+constexpr uint32_t kStepSyms = 64;       // ... and the symbols it takes at most
 
 enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_LONG = 3, K_BAD = 4, K_DIST = 5 };
 
@@ -76,27 +87,40 @@ struct Result {
   uint32_t status, overflow;
   uint32_t crc, isize;           // F_ONE_MEMBER: the trailer
   uint32_t nblocks, nevents;
+  // where the job's time went (shader clocks): block headers + tables, symbol decoding, emission, the tail row; batches, windows
+  uint64_t t_tab, t_dec, t_emit, t_tail;
+  uint32_t nbatch, nstep;
+  uint64_t t_sub[6];  // (MGI_SUBCLOCKS builds only) inside the symbol decoding: stage refill, lanes' decode, walk, prefix sums, queueing, the rest
 };
 struct Event {                   // a member ended inside a job (not F_ONE_MEMBER)
   uint64_t out_pos;              // elements the job had produced when it ended
   uint32_t job, crc, isize, pad;
 };
 
+// (16-bit table entries — code length | symbol << 4, base and extra bits recomputed per look-up — were measured: 7 KB of LDS and 23
+// wavefronts per CU instead of 10.5 KB and 15, and 20 % SLOWER: the kernel is bound by instructions issued, not by latency hidden)
 struct Shared {
   uint32_t lit[1 << LB];
   uint32_t dist[1 << DB];
   uint32_t cnt[2][16], first[2][16], offs[2][16];
-  uint32_t blkcnt[5][16];        // code lengths per block of 64 symbols
-  uint32_t nshort, err;
-  uint16_t shortsym[32], shortrc[32];
   uint16_t sorted[320];          // symbols by (length, symbol): [0, 288) literal/length, [288, 320) distance
-  uint8_t cl[320];
-  uint8_t pre[128];
-  uint32_t rec_lo[kBatchSyms], rec_hi[kBatchSyms];  // first byte in the batch | len << 16 ; dist | literal << 16
+  uint32_t nshort, err;
+  union {
+    struct {                     // while a block's header is read and its tables are made
+      uint32_t blkcnt[5][16];    // code lengths per block of 64 symbols
+      uint16_t shortsym[32], shortrc[32];
+      uint8_t cl[320];
+      uint8_t pre[128];
+    };
+    struct {                     // while its symbols are decoded
+      uint32_t rec_lo[kBatchSyms], rec_hi[kBatchSyms];  // first byte in the batch | len << 16 ; dist | literal << 16
+    };
+  };
   uint64_t headbits[kBatchBytes / 64];
   uint16_t headbase[kBatchBytes / 64];
   uint32_t scan[64];             // what Exec::scan sums up
-  uint32_t cut;
+  uint32_t cut, cut_total;
+  uint32_t inbuf[kInWords];      // the compressed words the window decode stands in
 };
 
 MGI_HD uint32_t bitrev(uint32_t v, uint32_t nbits) {
@@ -140,15 +164,26 @@ MGI_HD uint32_t dist_entry(uint32_t s, uint32_t l) {
   return l | ((b >> 16) << 4) | (K_DIST << 8) | ((b & 0xffff) << 16);
 }
 
-// ---- the bit reader: wave-uniform; deflate packs bits LSB first; the input is read as aligned 32-bit words ----
-struct BitReader {
+MGI_HDI uint32_t expand_lit(uint32_t c) {
+  if (c & 0x8000u) return K_LONG << 8 | 15u;
+  return (c & 15u) ? lit_entry((c >> 4) & 511u, c & 15u) : 0u;
+}
+MGI_HDI uint32_t expand_dist(uint32_t c) {
+  if (c & 0x8000u) return K_LONG << 8 | 15u;
+  return (c & 15u) ? dist_entry((c >> 4) & 511u, c & 15u) : 0u;
+}
+
+// ---- the bit reader; deflate packs bits LSB first; the input is read as aligned 32-bit words.  U: the reader is wave-uniform
+// (what it loads goes through readfirstlane and it lives in SGPRs); a lane's own reader otherwise ----
+template <bool U>
+struct BitReaderT {
   const uint32_t* in;
   uint64_t nwords;  // words that may be read (zero behind them)
   uint64_t bb;      // the next bc bits
   uint32_t bc;
   uint64_t wi;      // index of the word in nxt
   uint32_t nxt;
-  MGI_HD uint32_t load(uint64_t w) const { return w < nwords ? MGI_UNI(in[w]) : 0u; }
+  MGI_HD uint32_t load(uint64_t w) const { return w < nwords ? (U ? MGI_UNI(in[w]) : in[w]) : 0u; }
   MGI_HD void init(const uint32_t* p, uint64_t nw, uint64_t bitpos) {
     in = p;
     nwords = nw;
@@ -175,6 +210,7 @@ struct BitReader {
     return v;
   }
 };
+using BitReader = BitReaderT<true>;
 
 // ---- execution policies: how a phase meets the lanes ----
 // Per-lane values that live from one phase to the next (the speculative decode of a window: bits, length, distance | literal of
@@ -182,14 +218,18 @@ struct BitReader {
 // another lane's (v_readlane with a uniform index).  scan: exclusive prefix sums of sh.scan[0..64) in place -> the total.
 struct HostExec {
   Shared* sh = nullptr;
-  uint32_t r_tot[64], r_len[64], r_hi[64];
+  uint32_t r_totp[64], r_whyp[64], r_len[64][4], r_hi[64][4];
   bool leader() const { return true; }
   void sync() const {}
-  void set_sym(int lane, uint32_t tot, uint32_t len, uint32_t hi) { r_tot[lane] = tot; r_len[lane] = len; r_hi[lane] = hi; }
-  uint32_t tot_at(uint32_t l) const { return r_tot[l]; }
-  uint32_t len_at(uint32_t l) const { return r_len[l]; }
-  uint32_t my_len(int lane) const { return r_len[lane]; }
-  uint32_t my_hi(int lane) const { return r_hi[lane]; }
+  void set_syms(int lane, uint32_t totp, uint32_t whyp, const uint32_t (&len)[4], const uint32_t (&hi)[4]) {
+    r_totp[lane] = totp;
+    r_whyp[lane] = whyp;
+    for (int j = 0; j < 4; ++j) { r_len[lane][j] = len[j]; r_hi[lane][j] = hi[j]; }
+  }
+  uint32_t totp_at(uint32_t l) const { return r_totp[l]; }
+  uint32_t whyp_at(uint32_t l) const { return r_whyp[l]; }
+  uint32_t my_len(int lane, int j) const { return r_len[lane][j]; }
+  uint32_t my_hi(int lane, int j) const { return r_hi[lane][j]; }
   uint32_t scan() const {
     uint32_t run = 0;
     for (int l = 0; l < 64; ++l) { const uint32_t v = sh->scan[l]; sh->scan[l] = run; run += v; }
@@ -205,14 +245,19 @@ struct HostExec {
 struct DevExec {
   Shared* sh;
   int lane;
-  uint32_t v_tot = 0, v_len = 0, v_hi = 0;
+  uint32_t v_totp = 0, v_whyp = 0, v_len[4] = {0, 0, 0, 0}, v_hi[4] = {0, 0, 0, 0};
   __device__ bool leader() const { return lane == 0; }
   __device__ void sync() const { __syncthreads(); }
-  __device__ void set_sym(int, uint32_t tot, uint32_t len, uint32_t hi) { v_tot = tot; v_len = len; v_hi = hi; }
-  __device__ uint32_t tot_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_tot, (int)l); }
-  __device__ uint32_t len_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_len, (int)l); }
-  __device__ uint32_t my_len(int) const { return v_len; }
-  __device__ uint32_t my_hi(int) const { return v_hi; }
+  __device__ void set_syms(int, uint32_t totp, uint32_t whyp, const uint32_t (&len)[4], const uint32_t (&hi)[4]) {
+    v_totp = totp;
+    v_whyp = whyp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v_len[j] = len[j]; v_hi[j] = hi[j]; }
+  }
+  __device__ uint32_t totp_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_totp, (int)l); }
+  __device__ uint32_t whyp_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_whyp, (int)l); }
+  __device__ uint32_t my_len(int, int j) const { return v_len[j]; }
+  __device__ uint32_t my_hi(int, int j) const { return v_hi[j]; }
   __device__ uint32_t scan() const {
     const uint32_t v = sh->scan[lane];
     uint32_t x = v;
@@ -439,14 +484,10 @@ MGI_HD uint32_t decode_one(const Shared& sh, BitReader& br, uint32_t* len, uint3
   return K_LEN;
 }
 
-MGI_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u)); }
-
-// The symbol that WOULD start o bits into the words W (o < 96), decoded by one lane: both table look-ups, extra bits included.
-// -> *tot = its bits (at most 48) with *len / *hi, or *tot = 0: the scalar path's business (*len = why: K_EOB, K_LONG, K_BAD).
-MGI_HD void decode_at(const Shared& sh, const uint32_t (&W)[5], uint32_t o, uint32_t* tot, uint32_t* len, uint32_t* hi) {
-  const uint32_t i = o >> 5, sft = o & 31u;
-  const uint32_t a0 = i == 0 ? W[0] : i == 1 ? W[1] : W[2], a1 = i == 0 ? W[1] : i == 1 ? W[2] : W[3], a2 = i == 0 ? W[2] : i == 1 ? W[3] : W[4];
-  const uint32_t b0 = funnel32(a1, a0, sft), b1 = funnel32(a2, a1, sft);  // the 64 bits at o
+// The symbol that WOULD start at a bit, decoded by one lane from the 48 bits there (b0: the first 32, b1: the rest): both table
+// look-ups, extra bits included.  -> *tot = its bits (at most 48) with *len / *hi, or *tot = 0: the scalar path's business
+// (*len = why: K_EOB, K_LONG, K_BAD).
+MGI_HDI void decode_at(const Shared& sh, uint32_t b0, uint32_t b1, uint32_t* tot, uint32_t* len, uint32_t* hi) {
   const uint32_t e = sh.lit[b0 & ((1u << LB) - 1u)];
   const uint32_t nb = e & 15u, kind = (e >> 8) & 7u;
   *hi = 0;
@@ -472,84 +513,181 @@ MGI_HD void decode_at(const Shared& sh, const uint32_t (&W)[5], uint32_t o, uint
   *tot = c1 + dn + dxb;
 }
 
-// Symbols until the batch is full (-> 0), the block ends (-> 1), or an ST_ error.  Every step looks at a window of 64 bit
-// positions: lane l decodes the symbol that would start at bit l (decode_at), a uniform walk from bit 0 — one v_readlane per
-// symbol — picks the lanes that really start one, and those lanes queue their symbols: place in the batch from a popcount, first
-// output byte from a prefix sum of the lengths, a bit in the bitmap of first bytes.  queue = false: count only.
+// the word of a window's 256-bit membership set that holds lane's four positions; those four bits
+MGI_HDI uint64_t lane_word(int lane, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3) {
+  const uint32_t r = (uint32_t)lane >> 4;
+  return r == 0 ? s0 : r == 1 ? s1 : r == 2 ? s2 : s3;
+}
+MGI_HDI uint32_t lane_members(int lane, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3) {
+  return (uint32_t)(lane_word(lane, s0, s1, s2, s3) >> (4u * ((uint32_t)lane & 15u))) & 15u;
+}
+
+// Symbols until the batch is full (-> 0), the block ends (-> 1), or an ST_ error.  Every step looks at a window of 256 bit
+// positions: lane l decodes the four symbols that would start at bits 4l .. 4l + 3 (decode_at; the compressed words come from a
+// small stage in LDS), a uniform walk from bit 0 — one v_readlane per symbol — picks the positions that really start one, and their
+// lanes queue the symbols: place in the batch from a popcount, first output byte from a prefix sum of the lengths, a bit in the
+// bitmap of first bytes.  queue = false: count only.
 template <class Exec>
-MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, uint32_t* nsym_out, uint32_t* T_out) {
-  uint32_t nsym = 0, T = 0, rc = 0;
+#if defined(MGI_SUBCLOCKS)
+#define MGI_SUB(i) do { const uint64_t now_ = MGI_CLOCK(); if (sub) sub[i] += now_ - tick_; tick_ = now_; } while (0)
+#else
+#define MGI_SUB(i) do { } while (0)
+#endif
+MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, uint32_t* nsym_out, uint32_t* T_out, uint32_t* nstep = nullptr,
+                             uint64_t* sub = nullptr) {
+  uint32_t nsym = 0, T = 0, rc = 0, steps = 0;
+#if defined(MGI_SUBCLOCKS)
+  uint64_t tick_ = MGI_CLOCK();
+#endif
+  (void)sub;
   uint64_t pos = br.pos();
   const uint32_t* in = br.in;
   const uint64_t nwords = br.nwords;
+  uint64_t base_w = ~0ull;  // sh.inbuf = words [base_w, base_w + kInWords)
   if (queue) {
     ex.sync();
     ex.lanes([&](int lane) { sh.headbits[lane] = 0; });
-    ex.sync();
   }
   for (;;) {
-    if (nsym + 64 > kBatchSyms || T + 258 > kBatchBytes) break;
+    if (nsym + kStepSyms + 64 > kBatchSyms || T + 258 > kBatchBytes) break;
+    ++steps;
     const uint64_t wi = pos >> 5;
     const uint32_t so = (uint32_t)pos & 31u;
-    uint32_t W[5];
-    if (wi + 5 <= nwords) {
-      for (uint32_t i = 0; i < 5; ++i) W[i] = MGI_UNI(in[wi + i]);
-    } else {
-      for (uint32_t i = 0; i < 5; ++i) W[i] = wi + i < nwords ? MGI_UNI(in[wi + i]) : 0u;
-    }
-    ex.lanes([&](int lane) {
-      uint32_t tot, len, hi;
-      decode_at(sh, W, so + (uint32_t)lane, &tot, &len, &hi);
-      ex.set_sym(lane, tot, len, hi);
-    });
-    // which lanes start a symbol: from bit 0, every symbol says where the next one starts
-    uint32_t off = 0, cnt = 0;
-    uint64_t S = 0;
-    bool special = false;
-    while (off < 64) {
-      const uint32_t t = ex.tot_at(off);
-      if (t == 0) { special = true; break; }
-      S |= 1ull << off;
-      ++cnt;
-      off += t;
-    }
-    if (cnt) {
+    if (base_w == ~0ull || wi < base_w || wi + 11 > base_w + kInWords) {  // (31 + 255 + 51 bits: eleven words)
       ex.sync();
-      ex.lanes([&](int lane) { sh.scan[lane] = (S >> lane) & 1u ? ex.my_len(lane) : 0u; if (lane == 0) sh.cut = 64; });
+      base_w = wi;
+      ex.lanes([&](int lane) {
+        for (uint32_t i = (uint32_t)lane; i < kInWords; i += 64) sh.inbuf[i] = base_w + i < nwords ? in[base_w + i] : 0u;
+      });
+    }
+    ex.sync();
+    MGI_SUB(0);
+    const uint32_t rel = (uint32_t)(wi - base_w);
+    ex.lanes([&](int lane) {
+      const uint32_t o0 = so + 4u * (uint32_t)lane;
+      const uint32_t i = rel + (o0 >> 5), sft = o0 & 31u;
+      const uint64_t lo = sh.inbuf[i] | (uint64_t)sh.inbuf[i + 1] << 32;
+      const uint64_t x = sft ? (lo >> sft) | ((uint64_t)sh.inbuf[i + 2] << (64u - sft)) : lo;  // the 64 bits at o0
+      uint32_t totp = 0, whyp = 0, len[4], hi[4];
+      MGI_UNROLL
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t y = x >> j;
+        uint32_t tot;
+        decode_at(sh, (uint32_t)y, (uint32_t)(y >> 32), &tot, &len[j], &hi[j]);
+        totp |= tot << (8u * j);
+        if (!tot) whyp |= len[j] << (8u * j);
+      }
+      ex.set_syms(lane, totp, whyp, len, hi);
+    });
+    MGI_SUB(1);
+    // which positions start a symbol: from bit 0, every symbol says where the next one starts
+    uint32_t off = 0, cnt = 0;
+    uint64_t S0 = 0, S1 = 0, S2 = 0, S3 = 0;  // (four words, not an array: they stay in SGPRs)
+    bool special = false;
+    // (one loop per 64 positions, so that its word of the set stays in one register pair and the loop is a dozen scalar
+    // instructions per symbol; the step's symbol limit is looked at between the loops: at most kStepSyms - 1 + 64 symbols)
+#define MGI_WALK(Sr, END)                                                              \
+    if (!special && cnt < kStepSyms) {                                                   \
+      const uint32_t before_ = off;                                                      \
+      uint32_t n_ = 0;                                                                   \
+      while (off < (END)) {                                                              \
+        const uint32_t t = (ex.totp_at(off >> 2) >> (8u * (off & 3u))) & 0xffu;          \
+        if (t == 0) { special = true; break; }                                           \
+        Sr |= 1ull << (off & 63u);                                                       \
+        ++n_;                                                                            \
+        off += t;                                                                        \
+      }                                                                                  \
+      (void)before_;                                                                     \
+      cnt += n_;                                                                         \
+    }
+    MGI_WALK(S0, 64u)
+    MGI_WALK(S1, 128u)
+    MGI_WALK(S2, 192u)
+    MGI_WALK(S3, 256u)
+#undef MGI_WALK
+    MGI_SUB(2);
+    if (cnt) {
+      const uint64_t a0 = S0, a1 = S1, a2 = S2, a3 = S3;  // (as found; the cut below may drop the last ones)
+      ex.sync();
+      ex.lanes([&](int lane) {
+        const uint32_t m = lane_members(lane, a0, a1, a2, a3);
+        uint32_t sum = 0;
+        MGI_UNROLL
+        for (int j = 0; j < 4; ++j) sum += (m >> j) & 1u ? ex.my_len(lane, j) : 0u;
+        sh.scan[lane] = sum;
+        if (lane == 0) sh.cut = kStepBits;
+      });
       ex.sync();
       uint32_t total = ex.scan();
       ex.sync();
       if (T + total > kBatchBytes) {  // the batch's bytes run out inside this window: up to the first symbol that does not fit
         ex.lanes([&](int lane) {
-          if (((S >> lane) & 1u) && T + sh.scan[lane] + ex.my_len(lane) > kBatchBytes) Exec::atomic_min(&sh.cut, (uint32_t)lane);
+          const uint32_t m = lane_members(lane, a0, a1, a2, a3);
+          uint32_t run = T + sh.scan[lane];
+          bool done = false;
+          MGI_UNROLL
+          for (int j = 0; j < 4; ++j) {
+            if (done || !((m >> j) & 1u)) continue;
+            if (run + ex.my_len(lane, j) > kBatchBytes) { Exec::atomic_min(&sh.cut, 4u * (uint32_t)lane + (uint32_t)j); done = true; continue; }
+            run += ex.my_len(lane, j);
+          }
         });
         ex.sync();
         const uint32_t c = MGI_UNI(sh.cut);
-        total = MGI_UNI(sh.scan[c]);
-        S &= (1ull << c) - 1ull;
-        cnt = popc64(S);
+        ex.lanes([&](int lane) {
+          if ((uint32_t)lane != c >> 2) return;
+          const uint32_t m = lane_members(lane, a0, a1, a2, a3);
+          uint32_t run = sh.scan[lane];
+          MGI_UNROLL
+          for (uint32_t j = 0; j < 3; ++j) run += j < (c & 3u) && ((m >> j) & 1u) ? ex.my_len(lane, (int)j) : 0u;
+          sh.cut_total = run;
+        });
+        ex.sync();
+        total = MGI_UNI(sh.cut_total);
+        auto trim = [&](uint64_t Sr, uint32_t first) -> uint64_t {
+          return c < first ? 0ull : c < first + 64u ? Sr & ((1ull << (c & 63u)) - 1ull) : Sr;
+        };
+        S0 = trim(S0, 0);
+        S1 = trim(S1, 64);
+        S2 = trim(S2, 128);
+        S3 = trim(S3, 192);
+        cnt = popc64(S0) + popc64(S1) + popc64(S2) + popc64(S3);
         off = c;
         special = false;
       }
+      MGI_SUB(3);
       if (queue) {
+        const uint64_t b0 = S0, b1 = S1, b2 = S2, b3 = S3;
+        const uint32_t d0 = popc64(b0), d1 = popc64(b1), d2 = popc64(b2);
         ex.lanes([&](int lane) {
-          if (!((S >> lane) & 1u)) return;
-          const uint32_t i = nsym + popc64(S & ((1ull << lane) - 1ull));
-          const uint32_t dst = T + sh.scan[lane];
-          sh.rec_lo[i] = dst | ex.my_len(lane) << 16;
-          sh.rec_hi[i] = ex.my_hi(lane);
-          Exec::atomic_or64(&sh.headbits[dst >> 6], 1ull << (dst & 63u));
+          const uint32_t m = lane_members(lane, b0, b1, b2, b3);
+          if (!m) return;
+          const uint32_t r = (uint32_t)lane >> 4;
+          uint32_t i = nsym + (r >= 1 ? d0 : 0u) + (r >= 2 ? d1 : 0u) + (r >= 3 ? d2 : 0u) +  // (sums, not a chain of ==: that became a table in scratch)
+                       popc64(lane_word(lane, b0, b1, b2, b3) & ((1ull << (4u * ((uint32_t)lane & 15u))) - 1ull));
+          uint32_t dst = T + sh.scan[lane];
+          MGI_UNROLL
+          for (int j = 0; j < 4; ++j) {
+            if (!((m >> j) & 1u)) continue;
+            const uint32_t len = ex.my_len(lane, j);
+            sh.rec_lo[i] = dst | len << 16;
+            sh.rec_hi[i] = ex.my_hi(lane, j);
+            Exec::atomic_or64(&sh.headbits[dst >> 6], 1ull << (dst & 63u));
+            ++i;
+            dst += len;
+          }
         });
       }
       nsym += cnt;
       T += total;
+      MGI_SUB(4);
     }
     pos += off;
     if (!special) {
       if (cnt == 0) break;  // (the first symbol of the window did not fit the batch any more)
       continue;
     }
-    const uint32_t why = ex.len_at(off);
+    const uint32_t why = (ex.whyp_at(off >> 2) >> (8u * (off & 3u))) & 0xffu;
     if (why == K_BAD) { rc = ST_BAD_SYMBOL; break; }
     BitReader one;
     one.init(in, nwords, pos);
@@ -565,7 +703,6 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
         sh.rec_hi[nsym] = hi;
         sh.headbits[T >> 6] |= 1ull << (T & 63u);
       }
-      ex.sync();
     }
     ++nsym;
     T += len;
@@ -582,6 +719,8 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
   br.init(in, nwords, pos);
   *nsym_out = nsym;
   *T_out = T;
+  if (nstep) *nstep += steps;
+  MGI_SUB(5);
   return rc;
 }
 
@@ -589,28 +728,51 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
 // out: the job's output (element 0 = the first the job produces); pos0: elements before the batch; floor: the position
 // below which nothing may be referenced — the member's start inside the job, 0 when the job starts a member, and
 // -32768 for a job that starts inside a member (16-bit output only: positions below 0 become window symbols).
+struct Chase {  // one output byte on its way through the batch's records
+  uint32_t p, val;
+  int64_t q;
+  bool act, ld;
+};
 template <class OutT>
-MGI_HD void emit_lane(Shared& sh, int lane, uint32_t T, OutT* out, uint64_t pos0, int64_t floor) {
-  for (uint32_t f = (uint32_t)lane; f < T; f += 64) {
-    uint32_t p = f;
-    uint32_t val;
-    for (;;) {
-      const uint32_t w = p >> 6;
-      const uint32_t own = sh.headbase[w] + popc64(sh.headbits[w] & ((2ull << (p & 63u)) - 1ull)) - 1u;
-      const uint32_t lo = sh.rec_lo[own], hi = sh.rec_hi[own];
-      const uint32_t dist = hi & 0xffffu;
-      if (dist == 0) { val = hi >> 16; break; }
-      const uint32_t dst = lo & 0xffffu, len = lo >> 16;
-      uint32_t off = p - dst;
-      if (dist < len) off %= dist;  // a match that overlaps itself repeats its first dist bytes
-      const int64_t q = (int64_t)pos0 + (int64_t)dst + (int64_t)off - (int64_t)dist;
-      if (q >= (int64_t)pos0) { p = (uint32_t)(q - (int64_t)pos0); continue; }  // made by this batch: follow it
-      if (q < floor) { sh.err = ST_BAD_DIST; val = 0; break; }
-      if (q >= 0) { val = out[q]; break; }
-      val = sizeof(OutT) == 2 ? (0x8000u | (uint32_t)(q + (int64_t)kWindow)) : 0u;  // (q < 0 <= floor is excluded for bytes by the caller's floor)
-      break;
+MGI_HDI bool chase_step(Shared& sh, Chase& c, uint64_t pos0, int64_t floor) {  // -> still inside the batch
+  const uint32_t w = c.p >> 6;
+  const uint32_t own = sh.headbase[w] + popc64(sh.headbits[w] & ((2ull << (c.p & 63u)) - 1ull)) - 1u;
+  const uint32_t lo = sh.rec_lo[own], hi = sh.rec_hi[own];
+  const uint32_t dist = hi & 0xffffu;
+  if (dist == 0) { c.val = hi >> 16; c.act = false; return false; }
+  const uint32_t dst = lo & 0xffffu, len = lo >> 16;
+  uint32_t off = c.p - dst;
+  if (dist < len) off %= dist;  // a match that overlaps itself repeats its first dist bytes
+  const int64_t src = (int64_t)pos0 + (int64_t)dst + (int64_t)off - (int64_t)dist;
+  if (src >= (int64_t)pos0) { c.p = (uint32_t)(src - (int64_t)pos0); return true; }  // made by this batch: follow it
+  c.act = false;
+  if (src < floor) { sh.err = ST_BAD_DIST; return false; }
+  if (src >= 0) { c.ld = true; c.q = src; return false; }
+  c.val = sizeof(OutT) == 2 ? (0x8000u | (uint32_t)(src + (int64_t)kWindow)) : 0u;
+  return false;
+}
+template <class OutT>
+MGI_HDI void emit_lane(Shared& sh, int lane, uint32_t T, OutT* out, uint64_t pos0, int64_t floor) {
+  // four bytes per lane at a time (f, f + 64, f + 128, f + 192): their chains through the batch's records are independent, so
+  // their LDS reads are in flight together; then the loads from memory, then the stores
+  for (uint32_t f0 = (uint32_t)lane; f0 < T; f0 += 256) {
+    Chase c0{f0, 0, 0, f0 < T, false}, c1{f0 + 64, 0, 0, f0 + 64 < T, false}, c2{f0 + 128, 0, 0, f0 + 128 < T, false},
+        c3{f0 + 192, 0, 0, f0 + 192 < T, false};
+    for (bool any = true; any;) {
+      any = false;
+      if (c0.act) any |= chase_step<OutT>(sh, c0, pos0, floor);
+      if (c1.act) any |= chase_step<OutT>(sh, c1, pos0, floor);
+      if (c2.act) any |= chase_step<OutT>(sh, c2, pos0, floor);
+      if (c3.act) any |= chase_step<OutT>(sh, c3, pos0, floor);
     }
-    out[pos0 + f] = (OutT)val;
+    if (c0.ld) c0.val = out[c0.q];
+    if (c1.ld) c1.val = out[c1.q];
+    if (c2.ld) c2.val = out[c2.q];
+    if (c3.ld) c3.val = out[c3.q];
+    if (f0 < T) out[pos0 + f0] = (OutT)c0.val;
+    if (f0 + 64 < T) out[pos0 + f0 + 64] = (OutT)c1.val;
+    if (f0 + 128 < T) out[pos0 + f0 + 128] = (OutT)c2.val;
+    if (f0 + 192 < T) out[pos0 + f0 + 192] = (OutT)c3.val;
   }
 }
 
@@ -656,7 +818,8 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
   const uint32_t cut = input_final ? ST_TRUNC : ST_NEED_MORE;
   uint64_t outn = 0;
   int64_t floor = (job.flags & F_MEMBER_START) ? 0 : (sizeof(OutT) == 2 ? -(int64_t)kWindow : 0);
-  uint32_t status = 0, overflow = 0, nblocks = 0, nev = 0, crc = 0, isize = 0;
+  uint32_t status = 0, overflow = 0, nblocks = 0, nev = 0, crc = 0, isize = 0, nbatch = 0, nstep = 0;
+  uint64_t t_tab = 0, t_dec = 0, t_emit = 0, t_tail = 0, t_sub[6] = {0, 0, 0, 0, 0, 0};
   bool count_only = (job.flags & F_COUNT_ONLY) != 0;
   uint64_t pos = job.start_bit;
   if (ex.leader()) sh.err = 0;
@@ -696,6 +859,7 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
       br.init(in, nwords, (P + len) * 8);
     } else {
       uint32_t nlit = 288, ndist = 32, rc;
+      const uint64_t c0 = MGI_CLOCK();
       if (btype == 1) {
         fixed_lengths(ex, sh);
       } else {
@@ -706,9 +870,14 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
       rc = build_table(ex, sh, 0, 0, nlit, true);
       if (!rc) rc = build_table(ex, sh, 1, nlit, ndist, true);
       if (rc) { status = rc; break; }
+      t_tab += MGI_CLOCK() - c0;
       for (;;) {
         uint32_t nsym = 0, T = 0;
-        rc = decode_batch(ex, sh, br, !count_only, &nsym, &T);
+        const uint64_t c1 = MGI_CLOCK();
+        rc = decode_batch(ex, sh, br, !count_only, &nsym, &T, &nstep, t_sub);
+        ++nbatch;
+        const uint64_t c2 = MGI_CLOCK();
+        t_dec += c2 - c1;
         if (rc >= ST_ERR) { status = rc; break; }
         if (br.pos() > nbits) { status = cut; break; }
         if (!count_only && outn + T > job.out_cap) { overflow = 1; count_only = true; }
@@ -717,6 +886,7 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
           ex.lanes([&](int lane) { emit_lane<OutT>(sh, lane, T, out, outn, floor); });
           ex.sync();
           const uint32_t er = MGI_UNI(sh.err);
+          t_emit += MGI_CLOCK() - c2;
           if (er) { status = er; break; }
         }
         outn += T;
@@ -763,6 +933,7 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
       br.init(in, nwords, data * 8);
     }
   }
+  const uint64_t c3 = MGI_CLOCK();
   if (sizeof(OutT) == 2 && tail && !count_only && status < ST_ERR) {
     ex.sync();
     ex.lanes([&](int lane) {
@@ -777,6 +948,7 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
       }
     });
   }
+  t_tail = MGI_CLOCK() - c3;
   // garbage decoded from behind the end of the input is the input's end, not a damaged stream
   if (status >= ST_ERR && status != ST_BAD_HEADER && br.pos() > nbits) status = cut;
   if (ex.leader()) {
@@ -788,6 +960,13 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
     res->isize = isize;
     res->nblocks = nblocks;
     res->nevents = nev;
+    res->t_tab = t_tab;
+    res->t_dec = t_dec;
+    res->t_emit = t_emit;
+    res->t_tail = t_tail;
+    res->nbatch = nbatch;
+    res->nstep = nstep;
+    for (int i = 0; i < 6; ++i) res->t_sub[i] = t_sub[i];
   }
 }
 
@@ -799,13 +978,13 @@ MGI_HD bool probe_bits(uint64_t lo, uint64_t hi) {
   if ((lo & 7u) != 4u) return false;  // BFINAL = 0, BTYPE = 2 (bits 1-2, LSB first)
   if (((lo >> 3) & 31u) > 29u || ((lo >> 8) & 31u) > 29u) return false;
   const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
-  const uint64_t v = lo >> 17;                             // lengths 0..14
-  const uint32_t v2 = (uint32_t)((lo >> 62) | (hi << 2));  // lengths 15..18
+  // the 3-bit lengths as three words of up to eight (24 bits each), those behind the ncl-th zeroed; a length l weighs
+  // 64 >> (l - 1), and l = 0 shifts everything out (the shift count wraps to 31)
+  const uint64_t all = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * ncl)) - 1ull);
+  const uint32_t f[3] = {(uint32_t)all & 0xffffffu, (uint32_t)(all >> 24) & 0xffffffu, (uint32_t)(all >> 48)};
   uint32_t kraft = 0;
-  for (uint32_t i = 0; i < 19; ++i) {
-    const uint32_t l = i < 15 ? (uint32_t)(v >> (3 * i)) & 7u : (v2 >> (3 * (i - 15))) & 7u;
-    kraft += (i < ncl && l) ? 128u >> l : 0u;
-  }
+  for (uint32_t w = 0; w < 3; ++w)
+    for (uint32_t i = 0; i < (w < 2 ? 8u : 3u); ++i) kraft += 64u >> ((((f[w] >> (3u * i)) & 7u) - 1u) & 31u);
   return kraft == 128u;
 }
 MGI_HD bool probe_block_start(const uint32_t* in, uint64_t nwords, uint64_t p) {
@@ -828,6 +1007,97 @@ MGI_HD bool validate_block_start(Exec& ex, Shared& sh, const uint32_t* in, uint6
   if (br.pos() > nbytes * 8) return false;
   if (build_table(ex, sh, 0, 0, nlit, false, true)) return false;
   if (build_table(ex, sh, 1, nlit, ndist, false, true)) return false;
+  return true;
+}
+
+// The same decision as validate_block_start by ONE lane, in registers only (the finder validates up to 64 candidates at once): the
+// code-length code decoded canonically (at most seven compares per symbol), the Kraft sums of both codes kept as the lengths arrive —
+// an over-subscribed code is refused at once.
+MGI_HD bool light_validate(const uint32_t* in, uint64_t nbytes, uint64_t p) {
+  BitReaderT<false> br;
+  br.init(in, (nbytes + 3) / 4, p);
+  br.refill();
+  br.drop(3);
+  const uint32_t nlit = br.bits(5) + 257, ndist = br.bits(5) + 1, ncl = br.bits(4) + 4;
+  if (nlit > 286 || ndist > 30) return false;
+  const uint64_t order_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                            5ull << 45 | 11ull << 50 | 4ull << 55;
+  const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+  uint64_t plen = 0, cnts = 0;  // 3 bits per symbol; 8 bits per length
+  for (uint32_t i = 0; i < ncl; ++i) {
+    br.refill();
+    const uint32_t l = br.bits(3);
+    const uint32_t sym = (uint32_t)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31u);
+    plen |= (uint64_t)l << (3 * sym);
+    cnts += 1ull << (8 * l);
+  }
+  // canonical code of the code-length code: first code and first rank per length, the symbols in (length, symbol) order
+  uint64_t firsts = 0, offs = 0, sorted_lo = 0, sorted_hi = 0;  // 8 bits per length; 5 bits per rank
+  {
+    int32_t left = 1;
+    uint32_t code = 0, rank = 0;
+    for (uint32_t l = 1; l < 8; ++l) {
+      const uint32_t c = (uint32_t)(cnts >> (8 * l)) & 0xffu;
+      left = (left << 1) - (int32_t)c;
+      if (left < 0) return false;
+      firsts |= (uint64_t)code << (8 * l);
+      offs |= (uint64_t)rank << (8 * l);
+      for (uint32_t s = 0; s < 19; ++s) {
+        if (((uint32_t)(plen >> (3 * s)) & 7u) != l) continue;
+        if (rank < 12) sorted_lo |= (uint64_t)s << (5 * rank); else sorted_hi |= (uint64_t)s << (5 * (rank - 12));
+        ++rank;
+      }
+      code = (code + c) << 1;
+    }
+    if (left != 0) return false;
+  }
+  const uint32_t total = nlit + ndist;
+  uint32_t i = 0, prev = 0, eob = 0;
+  uint32_t kl = 0, kd = 0, nd = 0, d1 = 0;  // Kraft sums in units of 2^-15; distance codes used, of one bit
+  while (i < total) {
+    br.refill();
+    uint32_t code = 0, sym = 32;
+    for (uint32_t l = 1; l < 8; ++l) {
+      code = (code << 1) | ((uint32_t)(br.bb >> (l - 1)) & 1u);
+      const uint32_t k = code - ((uint32_t)(firsts >> (8 * l)) & 0xffu);
+      if (k < ((uint32_t)(cnts >> (8 * l)) & 0xffu)) {
+        const uint32_t r = ((uint32_t)(offs >> (8 * l)) & 0xffu) + k;
+        sym = (uint32_t)((r < 12 ? sorted_lo >> (5 * r) : sorted_hi >> (5 * (r - 12))) & 31u);
+        br.drop(l);
+        break;
+      }
+    }
+    if (sym == 32) return false;
+    uint32_t rep = 1, val = sym;
+    if (sym == 16) {
+      if (i == 0) return false;
+      rep = 3 + br.bits(2);
+      val = prev;
+    } else if (sym == 17) {
+      rep = 3 + br.bits(3);
+      val = 0;
+    } else if (sym == 18) {
+      rep = 11 + br.bits(7);
+      val = 0;
+    }
+    if (i + rep > total) return false;
+    if (sym != 16) prev = val;
+    if (val) {
+      // (a run may cross from the literal/length lengths into the distance lengths)
+      const uint32_t a = i < nlit ? (i + rep < nlit ? rep : nlit - i) : 0u;
+      kl += a * (32768u >> val);
+      kd += (rep - a) * (32768u >> val);
+      nd += rep - a;
+      if (val == 1) d1 += rep - a;
+      if (i <= 256 && 256 < i + rep) eob = 1;
+      if (kl > 32768u || kd > 32768u) return false;
+    }
+    i += rep;
+  }
+  if (br.pos() > nbytes * 8 || !eob) return false;
+  if (kl != 32768u) return false;                // the literal/length code must be complete
+  if (kd != 32768u && nd > 1) return false;      // the distance code complete, or a single code (of one bit: zlib's rule)
+  if (kd != 32768u && nd == 1 && d1 != 1) return false;
   return true;
 }
 

@@ -155,6 +155,8 @@ void* scratch(const char* name, uint64_t bytes);
 void scratch_release_all();
 // mg_stream.hip: the page-locked slots, DMA stream and events of the file pipelines (kept between calls).
 void stream_release_all();
+// mg_inflate.hip: the page-locked slots and copy stream of the compressed-byte uploads.
+void inflate_release_all();
 
 // Times one kernel family with HIP events on the library stream when profiling is on.
 struct ProfScope {

@@ -142,7 +142,9 @@ static int check_entered(const char* what, const std::string& text, const std::s
     uint64_t found = ~0ull;
     for (uint64_t p = from; p < from + step_bytes * 8 && p + 64 < gz.size() * 8; ++p) {
       if (!probe_block_start(in.w.data(), in.w.size(), p)) continue;
-      if (!validate_block_start(ex, g_sh, in.w.data(), in.nbytes, p)) continue;
+      const bool heavy = validate_block_start(ex, g_sh, in.w.data(), in.nbytes, p);
+      CHECK(light_validate(in.w.data(), in.nbytes, p) == heavy, "%s: the two validators disagree at bit %llu (%d)", what, (unsigned long long)p, (int)heavy);
+      if (!heavy) continue;
       found = p;
       break;
     }

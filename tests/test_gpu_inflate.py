@@ -38,7 +38,7 @@ def text():
 @pytest.fixture()
 def cfg(hip):
     yield hip
-    hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=128 << 20, ratio=10, on=1)
+    hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=176 << 20, ratio=10, on=1)
 
 
 def _same(hip, blob, want, what):
@@ -137,27 +137,26 @@ def test_corrupt_and_truncated_streams_are_errors(cfg, text):
     _same(cfg, blob, text[:6_000_000], "the library is in order after the errors")
 
 
-def test_streamed_gz_files_give_what_the_plain_files_give(cfg, tmp_path, text, oracle_lib):
-    """mg_sketch_stream_add_file / mg_sam_stream_file on .gz (gzip and BGZF) = on the plain file; device inflater on and off."""
-    from metalign_amd._hip import SketchStream
+def test_streamed_gz_files_give_what_the_plain_files_give(cfg, tmp_path):
+    """mg_sketch_stream_add_file on .gz (gzip, many members, BGZF) = the reads in one launch; many small stages (the unfinished record of
+    a stage is carried in front of the next stage's text on the device) and one; the device inflater on and off."""
+    import test_gpu_stream as tgs
     hip = cfg
-    plain = tmp_path / "reads.fq"
-    plain.write_bytes(text)
-    (tmp_path / "reads.fq.gz").write_bytes(gzip.compress(text, 6))
-    (tmp_path / "reads.bgzf.gz").write_bytes(bgzf(text))
-    k = 21
-
-    def sketch(path, on):
-        hip.inflate_config(chunk_bytes=16 << 10, stage_bytes=1 << 20, on=on)
-        ss = SketchStream(hip, [k], [1 << 60])
-        ss.add_file(str(path), "fastq")
-        n = ss.nreads
-        (sk,) = ss.finish()
-        h, c = sk.download()
-        return n, h, c
-    want = sketch(plain, 1)
-    assert want[0] == 60000
-    for name in ("reads.fq.gz", "reads.bgzf.gz"):
-        for on in (1, 0):
-            got = sketch(tmp_path / name, on)
-            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (name, on)
+    ks = [21, 51]
+    gb, go, rb, ro = tgs._sample(2, nreads=20000)
+    tabs, hmaxs, filts = tgs._tables(hip, gb, go, ks)
+    want = tgs._whole(hip, rb, ro, ks, hmaxs, filts)
+    fq = tgs._fastq(rb, ro)
+    forms = {"one.fq.gz": gzip.compress(fq, 6), "bgzf.fq.gz": bgzf(fq), "padded.fq.gz": gzip.compress(fq, 1) + b"\0" * 1000,
+             "members.fq.gz": b"".join(gzip.compress(fq[a: a + 700001], 1) for a in range(0, len(fq), 700001))}
+    for name, data in forms.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        for stage, on in ((100_000, 1), (128 << 20, 1), (0, 0)):
+            hip.inflate_config(chunk_bytes=16 << 10, stage_bytes=stage, on=on)
+            hip.inflate_stats(reset=True)
+            got, counts = tgs._streamed(hip, ks, hmaxs, filts, rb.size, lambda st: st.add_file(str(p), "fastq"))
+            assert counts == (len(ro) - 1, rb.size), (name, stage, on)
+            tgs._same(got, want)
+            st = hip.inflate_stats()
+            assert (st["jobs"] > 0) == (on == 1) and (stage != 100_000 or name.startswith("bgzf") or st["stages"] > 5), (name, stage, on, st)
