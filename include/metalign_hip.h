@@ -376,8 +376,9 @@ int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_pat
  *                     truncated stream.
  *   mg_inflate_config: chunk_bytes = compressed bytes per job of a gzip stream (default 32 KB), stage_bytes = compressed bytes
  *                     decoded together (default 176 MB), ratio = symbols reserved per compressed byte (default 10; a job that
- *                     needs more is decoded again), on = whether the streaming entry points use the device inflater; values
- *                     <= 0 (on: < 0) leave a setting as it is.
+ *                     needs more is decoded again), on = whether the streaming entry points use the device inflater, lane_jobs =
+ *                     launches of at least this many jobs decode ONE JOB PER LANE (64 serial decoders per wavefront; off by
+ *                     default: it pays from ~25 000 jobs in a launch), smaller ones one job per wavefront; values <= 0 (on, lane_jobs: < 0) leave a setting as it is.
  *   mg_inflate_stats: counters since the last reset (host seconds of the stages' phases, jobs, jobs decoded again).
  * ------------------------------------------------------------------------ */
 typedef struct mg_inflated mg_inflated;
@@ -392,7 +393,7 @@ int mg_inflate_dev(const uint8_t* comp, uint64_t ncomp, mg_inflated** out);
 uint64_t mg_inflated_bytes(const mg_inflated* t);
 int mg_inflated_download(const mg_inflated* t, uint8_t* dst);
 void mg_inflated_free(mg_inflated* t);
-int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on);
+int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on, int64_t lane_jobs);
 int mg_inflate_stats(mg_inflate_counters* out, int reset);
 
 /* Diagnostic, host code only.  With MG_STREAM_THIN=1 in the environment mg_sketch_stream_add_file / mg_sam_stream_file THIN a

@@ -82,7 +82,7 @@ static void seal_open_batch() {
   if (c.fence_open.empty()) return;
   Context::FenceBatch b;
   b.blocks.swap(c.fence_open);
-  hipStream_t streams[4] = {c.stream, c.stream_a, c.stream_a2, c.stream_c};
+  hipStream_t streams[5] = {c.stream, c.stream_a, c.stream_a2, c.stream_c, c.stream_inf};
   for (hipStream_t st : streams) {
     if (!st) continue;
     hipEvent_t e = fence_event();
@@ -113,7 +113,7 @@ static void release_completed_batches() {
 void pool_free(void* p, uint64_t bytes) {
   Context& c = ctx();
   if (!c.ready) { (void)hipFree(p); return; }
-  if (c.a_side || c.c_side) {  // side streams in use: reusable once they have passed
+  if (c.a_side || c.c_side || c.inf_side) {  // side streams in use: reusable once they have passed
     c.fence_open.emplace_back(p, bytes);
     // Sealed promptly, not only when an allocation finds its free list empty: otherwise the open batch collects the
     // frees of as many passes as the free lists last, every drained list then costs fresh hipMallocs until the batch
@@ -149,7 +149,7 @@ void* scratch(const char* name, uint64_t bytes) {
   if (b->bytes < bytes || !b->p) {
     // growing frees the old block to the pool: with more than one stream in use, whatever still runs on it has to
     // finish first (rare: sizes settle after the first batch)
-    if (b->p && (c.a_side || c.c_side)) (void)hipDeviceSynchronize();
+    if (b->p && (c.a_side || c.c_side || c.inf_side)) (void)hipDeviceSynchronize();
     uint64_t want = bytes + bytes / 4 + 256;
     if (b->alloc(want) != MG_OK) return nullptr;
   }
@@ -266,6 +266,7 @@ void mg_shutdown(void) {
   if (c.pinned) (void)hipHostFree(c.pinned);
   if (c.pend_pinned) (void)hipHostFree(c.pend_pinned);
   if (c.stream_c) { (void)hipStreamSynchronize(c.stream_c); (void)hipStreamDestroy(c.stream_c); }
+  if (c.stream_inf) { (void)hipStreamSynchronize(c.stream_inf); (void)hipStreamDestroy(c.stream_inf); }
   if (c.stream_a) { (void)hipStreamSynchronize(c.stream_a); (void)hipStreamDestroy(c.stream_a); }
   if (c.stream_a2) { (void)hipStreamSynchronize(c.stream_a2); (void)hipStreamDestroy(c.stream_a2); }
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);

@@ -123,6 +123,46 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t* __restrict__ in,
                          tails ? tails + (uint64_t)j * kWindow : nullptr);
 }
 
+// One job per LANE (mg_inflate_core.h, LaneDec): 64 serial decoders side by side, their tables in LDS (80 KB per wavefront), rounds
+// until every lane is done.  What a file offers in deflate blocks is all in flight at once.
+template <class OutT>
+__global__ __launch_bounds__(64) void k_inflate_lanes(const uint32_t* __restrict__ in, uint64_t nbytes, int input_final, const Job* __restrict__ jobs,
+                                                      uint32_t njobs, OutT* out, Result* __restrict__ results, Event* events, uint32_t* nevents,
+                                                      uint32_t max_events, LaneScratch* scratch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  LaneMem* mem = reinterpret_cast<LaneMem*>(lds_raw) + threadIdx.x;
+  const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+  LaneDec<OutT> d;
+  d.state = LS_DONE;
+  if (j < njobs) {
+    Job job;
+    job.start_bit = jobs[j].start_bit;
+    job.stop_bit = jobs[j].stop_bit;
+    job.out_off = jobs[j].out_off;
+    job.out_cap = jobs[j].out_cap;
+    job.flags = jobs[j].flags;
+    job.pad = 0;
+    d.init(in, nbytes, input_final != 0, job, j, out + job.out_off, mem, scratch + j, events, nevents, max_events);
+  }
+  while (__any(d.state != LS_DONE)) {
+    if (d.state != LS_DONE) d.round();
+  }
+  if (j < njobs) d.result(&results[j]);
+}
+
+// the tail rows of jobs decoded by k_inflate_lanes (the wavefront-per-job kernel writes its own): the window behind a job as far as the
+// job knows it, one workgroup per job
+__global__ __launch_bounds__(256) void k_make_tails(const Job* __restrict__ jobs, const Result* __restrict__ results, const uint16_t* __restrict__ sym,
+                                                    uint16_t* __restrict__ tails) {
+  const uint32_t j = blockIdx.x;
+  if (results[j].overflow || results[j].status >= ST_ERR) return;
+  const uint64_t n = results[j].out_count;
+  const uint16_t* s = sym + jobs[j].out_off;
+  uint16_t* row = tails + (uint64_t)j * kWindow;
+  for (uint32_t w = threadIdx.x; w < kWindow; w += 256)
+    row[w] = n >= kWindow ? s[n - kWindow + w] : (w < kWindow - n ? (uint16_t)(0x8000u | (w + (uint32_t)n)) : s[w - (kWindow - (uint32_t)n)]);
+}
+
 // The window from job to job.  Every job has left the window behind it AS FAR AS IT KNOWS IT (tail: 32768 symbols, window
 // symbols where it depends on what was in front of the job).  Resolving that is a chain through all jobs; it is cut into
 // groups of K jobs: k_chain_groups (a workgroup per group, the previous row in LDS) composes the rows of a group relative to the
@@ -264,50 +304,56 @@ __global__ __launch_bounds__(256) void k_resolve_text(const ChainJob* __restrict
   }
 }
 
-// CRC-32 of segments of the text, one wavefront per segment: the segment is laid out right-aligned over 64 equal slices (a CRC
-// register that starts at 0 does not see leading zeros), a slice per lane with four table look-ups per word, the lanes combined
-// by multiplying with x^(8 * slice) mod p; the initial and final inversions are put in at the end.
+// CRC-32 of segments of the text, one wavefront per segment, COALESCED: a CRC register that starts at 0 is linear in the message, so
+// lane l takes every 64th word (the words 4 l bytes into every 256-byte row) — per row one 256-byte load of the wavefront and, per
+// lane, b = shift256(b) ^ word, the shift by 256 zero bytes being four table look-ups (tables made by the block) — and at the end
+// a lane's register is shifted by what lies behind its last word and the 64 are XORed.  Rows are aligned to the END of the segment's
+// whole words (leading zeros do not change a register that starts at 0); the at most three bytes in front of the first aligned word
+// and behind the last one are lane 0's.  The initial and final inversions are put in at the end.
+// (Rounds 1-2 of this kernel gave a lane a contiguous 4 KB: 64 cache lines per load instruction, 216 GB/s.)
 struct CrcSeg { uint64_t start, len; };
 struct X2N { uint32_t v[32]; };
 __global__ __launch_bounds__(256) void k_crc_segments(const uint8_t* __restrict__ text, const CrcSeg* __restrict__ segs, uint32_t nsegs,
                                                       uint32_t* __restrict__ crcs, X2N x2n) {
-  __shared__ uint32_t T[4][256];
+  __shared__ uint32_t T0[256];
+  __shared__ uint32_t TX[4][256];
   const uint32_t t = threadIdx.x;
   {
     uint32_t c = t;
     for (int k = 0; k < 8; ++k) c = c & 1u ? (c >> 1) ^ kCrcPoly : c >> 1;
-    T[0][t] = c;
+    T0[t] = c;
+    const uint32_t x256 = crc_x8n(256, x2n.v);
+    for (int k = 0; k < 4; ++k) TX[k][t] = crc_multmodp(x256, t << (8 * k));
     __syncthreads();
-    for (int s = 1; s < 4; ++s) {
-      T[s][t] = (T[s - 1][t] >> 8) ^ T[0][T[s - 1][t] & 0xffu];
-      __syncthreads();
-    }
   }
   const uint32_t seg = blockIdx.x * 4u + (t >> 6), lane = t & 63u;
   if (seg >= nsegs) return;
-  const uint64_t start = segs[seg].start, len = segs[seg].len;
-  const uint64_t L = (((len + 63) / 64) + 3) & ~3ull;
-  const int64_t V = (int64_t)(start + len) - (int64_t)(64 * L);
-  int64_t a = V + (int64_t)(lane * L), b = a + (int64_t)L;
-  if (a < (int64_t)start) a = (int64_t)start;
-  uint32_t c = 0;
-  if (a < b) {
-    const uint8_t* p = text + a;
-    const uint8_t* e = text + b;
-    while (p < e && ((uintptr_t)p & 3u)) c = T[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
-    for (; p + 4 <= e; p += 4) {
-      c ^= *reinterpret_cast<const uint32_t*>(p);
-      c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
-    }
-    while (p < e) c = T[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+  const uint64_t start = segs[seg].start, len = segs[seg].len, end = start + len;
+  const uint64_t base = reinterpret_cast<uintptr_t>(text);
+  uint64_t A = start + ((4 - ((base + start) & 3u)) & 3u);  // the first aligned word
+  if (A > end) A = end;
+  const uint64_t M4 = (end - A) & ~3ull, K = (M4 + 255) / 256;
+  const uint64_t mid_end = A + M4;
+  uint32_t b = 0;
+  for (uint64_t k = 0; k < K; ++k) {
+    const int64_t at = (int64_t)mid_end - (int64_t)(256 * (K - k)) + 4 * (int64_t)lane;
+    const uint32_t w = at >= (int64_t)A ? *reinterpret_cast<const uint32_t*>(text + at) : 0u;
+    b = TX[3][b >> 24] ^ TX[2][(b >> 16) & 0xffu] ^ TX[1][(b >> 8) & 0xffu] ^ TX[0][b & 0xffu] ^ w;
   }
-  uint32_t X = crc_x8n(L, x2n.v);
-  for (uint32_t s = 0; s < 6; ++s) {
-    const uint32_t other = (uint32_t)__shfl_down((int)c, 1u << s, 64);
-    c = crc_multmodp(X, c) ^ other;
-    X = crc_multmodp(X, X);
+  // the register behind a lane's last word: four more bytes through the register, then what lies behind that word
+  uint32_t c = b;
+  for (int k = 0; k < 4; ++k) c = T0[c & 0xffu] ^ (c >> 8);
+  const uint64_t tail = end - mid_end;
+  c = K ? crc_multmodp(crc_x8n(4 * (63 - lane) + tail, x2n.v), c) : 0u;
+  for (uint32_t s2 = 1; s2 < 64; s2 <<= 1) c ^= (uint32_t)__shfl_xor((int)c, (int)s2, 64);
+  if (lane == 0) {
+    uint32_t h = 0;  // the bytes in front of the first aligned word ...
+    for (uint64_t i = start; i < A; ++i) h = T0[(h ^ text[i]) & 0xffu] ^ (h >> 8);
+    uint32_t tl = 0;  // ... and behind the last one
+    for (uint64_t i = mid_end; i < end; ++i) tl = T0[(tl ^ text[i]) & 0xffu] ^ (tl >> 8);
+    const uint32_t raw = crc_multmodp(crc_x8n(end - A, x2n.v), h) ^ c ^ tl;
+    crcs[seg] = raw ^ crc_multmodp(crc_x8n(len, x2n.v), 0xffffffffu) ^ 0xffffffffu;
   }
-  if (lane == 0) crcs[seg] = c ^ crc_multmodp(crc_x8n(len, x2n.v), 0xffffffffu) ^ 0xffffffffu;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -317,6 +363,11 @@ struct InflateConfig {
   uint64_t chunk_bytes = 32u << 10;   // compressed bytes per job of a gzip stream
   uint64_t stage_bytes = 176u << 20;  // compressed bytes per stage (~5600 jobs: what 256 CUs hold at once)
   uint32_t ratio = 10;                // symbols reserved per compressed byte of a job (a job that needs more is decoded again)
+  // launches of at least this many jobs decode a job per LANE (k_inflate_lanes) instead of a job per wavefront.  OFF by default: measured
+  // (profiles/r05/inflate_lanes.txt) a round of the 64 side-by-side decoders takes ~3.5 us whatever the number of jobs — every lane's
+  // loads and stores are its own cache lines — so 16 000 jobs (a 10M-read FASTQ) take 89 ms against 67 ms a job per wavefront;
+  // it wins only from ~25 000 jobs in one launch
+  uint32_t lane_jobs = 0xffffffffu;
   int on = 1;                         // .gz files of the streaming entry points take the device inflater
 };
 static InflateConfig g_cfg;
@@ -514,10 +565,16 @@ struct DevInflater {
   uint32_t x2n[32];
   std::vector<std::pair<uint64_t, uint32_t>> x8n_cache;  // (length, x^(8 length) mod p)
 
-  int open(const uint8_t* host, uint64_t nbytes, int upload_threads) {
+  uint64_t headroom = 0;  // bytes left free in front of every stage's text (the caller's carried record)
+  int open(const uint8_t* host, uint64_t nbytes, int upload_threads, uint64_t headroom_) {
     h = host;
     n = nbytes;
-    st = ctx().stream;
+    headroom = headroom_;
+    // a stream of its own: a stage decodes while the caller parses and hashes the previous stage's text on the library's main stream
+    Context& c = ctx();
+    if (!c.stream_inf) MG_HIP(hipStreamCreateWithFlags(&c.stream_inf, hipStreamNonBlocking));
+    st = c.stream_inf;
+    c.inf_side = true;  // (blocks freed from now on are fenced across the streams: mg_core.hip, pool_free)
     crc_make_x2n(x2n);
     if (n < 2 || !(h[0] == 0x1f && h[1] == 0x8b)) return fail(MG_ERR_ARG, "%s", status_text(ST_BAD_HEADER));
     if (n < 18) return fail(MG_ERR_ARG, "%s", status_text(ST_TRUNC));
@@ -540,6 +597,16 @@ struct DevInflater {
     return v;
   }
 
+  static int lanes_attr() {  // (80 KB of dynamic LDS per wavefront: above the default limit)
+    static bool done = false;
+    if (!done) {
+      MG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * sizeof(LaneMem)));
+      MG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * sizeof(LaneMem)));
+      done = true;
+    }
+    return MG_OK;
+  }
+
   // CRC-32 of text[seg] for every segment -> host
   int crc_of(const uint8_t* d_text, const std::vector<CrcSeg>& segs, std::vector<uint32_t>* out) {
     out->assign(segs.size(), 0);
@@ -560,55 +627,81 @@ struct DevInflater {
   }
 
   // ---- BGZF: a stage = consecutive blocks of at most text_cap bytes of text ----
-  int stage_bgzf(uint64_t headroom, uint64_t text_cap, DevBuf* text, uint64_t* ntext, bool* finished) {
+  struct PendingBz {
+    uint64_t b0 = 0, b1 = 0, bytes = 0;
+    DevBuf text, djobs, dres, dev, scr;
+    std::vector<CrcSeg> segs;
+  } pb;
+  int bz_begin(uint64_t text_cap) {
     const uint64_t b0 = next_block;
     uint64_t b1 = b0, bytes = 0;
     while (b1 < blocks.size() && (b1 == b0 || bytes + blocks[b1].isize <= text_cap) && b1 - b0 < (1u << 20)) bytes += blocks[b1++].isize;
     const uint64_t nj = b1 - b0;
-    MG_TRY(text->alloc(headroom + bytes + 64));
-    *ntext = bytes;
+    pb.b0 = b0; pb.b1 = b1; pb.bytes = bytes;
+    MG_TRY(pb.text.alloc(headroom + bytes + 64));
     next_block = b1;
-    *finished = b1 >= blocks.size();
     if (nj == 0) return MG_OK;
     std::vector<Job> jobs(nj);
-    std::vector<CrcSeg> segs(nj);
+    pb.segs.resize(nj);
     uint64_t at = 0;
     for (uint64_t i = 0; i < nj; ++i) {
       const BgzfBlock& b = blocks[b0 + i];
       jobs[i] = Job{(b.coff + b.hdr) * 8, ~0ull, at, b.isize, F_ONE_MEMBER | F_MEMBER_START, 0};
-      segs[i] = CrcSeg{headroom + at, b.isize};
+      pb.segs[i] = CrcSeg{headroom + at, b.isize};
       at += b.isize;
     }
     MG_TRY(up.need(blocks[b1 - 1].coff + blocks[b1 - 1].csize, st));
-    DevBuf djobs, dres, dev;
+    DevBuf &djobs = pb.djobs, &dres = pb.dres, &dev = pb.dev;
+    DevBuf* text = &pb.text;
     MG_TRY(djobs.alloc(nj * sizeof(Job)));
     MG_TRY(dres.alloc(nj * sizeof(Result)));
     MG_TRY(dev.alloc(64));
     MG_HIP(hipMemcpyAsync(djobs.p, jobs.data(), nj * sizeof(Job), hipMemcpyHostToDevice, st));
+    MG_HIP(hipStreamSynchronize(st));  // (jobs is a local: the copy has to have read it)
     MG_HIP(hipMemsetAsync(dev.p, 0, 64, st));
-    {
+    if (nj >= g_cfg.lane_jobs) {
+      DevBuf& scr = pb.scr;
+      MG_TRY(scr.alloc(nj * sizeof(LaneScratch)));
+      MG_TRY(lanes_attr());
+      ProfScope ps("k_inflate_bgzf", st);
+      k_inflate_lanes<uint8_t><<<(unsigned)((nj + 63) / 64), 64, 64 * sizeof(LaneMem), st>>>(
+          comp.as<uint32_t>(), n, 1, djobs.as<Job>(), (uint32_t)nj, text->as<uint8_t>() + headroom, dres.as<Result>(), nullptr, dev.as<uint32_t>(), 0,
+          scr.as<LaneScratch>());
+    } else {
       ProfScope ps("k_inflate_bgzf", st);
       k_inflate<uint8_t><<<(unsigned)nj, 64, 0, st>>>(comp.as<uint32_t>(), n, 1, djobs.as<Job>(), text->as<uint8_t>() + headroom, dres.as<Result>(),
                                                       nullptr, dev.as<uint32_t>(), 0, nullptr);
     }
-    std::vector<Result> res(nj);
-    MG_HIP(hipMemcpyAsync(res.data(), dres.p, nj * sizeof(Result), hipMemcpyDeviceToHost, st));
-    std::vector<uint32_t> crcs;
-    MG_TRY(crc_of(text->as<uint8_t>(), segs, &crcs));  // (synchronises: res is there as well)
-    for (uint64_t i = 0; i < nj; ++i) {
-      const BgzfBlock& b = blocks[b0 + i];
-      const Result& r = res[i];
-      if (r.status != ST_MEMBER) return fail(MG_ERR_ARG, "BGZF block at byte %llu: %s", (unsigned long long)b.coff, status_text(r.status));
-      if (r.overflow || r.out_count != b.isize || r.isize != b.isize || r.end_bit != (b.coff + b.csize) * 8)
-        return fail(MG_ERR_ARG, "BGZF block at byte %llu: corrupt (size mismatch)", (unsigned long long)b.coff);
-      if (r.crc != crcs[i]) return fail(MG_ERR_ARG, "BGZF block at byte %llu: corrupt (CRC mismatch)", (unsigned long long)b.coff);
+    return MG_OK;
+  }
+  int bz_finish(DevBuf* text_out, uint64_t* ntext, bool* finished) {
+    const uint64_t b0 = pb.b0, b1 = pb.b1, nj = b1 - b0;
+    *ntext = pb.bytes;
+    *finished = b1 >= blocks.size();
+    if (nj) {
+      std::vector<Result> res(nj);
+      MG_HIP(hipMemcpyAsync(res.data(), pb.dres.p, nj * sizeof(Result), hipMemcpyDeviceToHost, st));
+      std::vector<uint32_t> crcs;
+      MG_TRY(crc_of(pb.text.as<uint8_t>(), pb.segs, &crcs));  // (synchronises: res is there as well)
+      for (uint64_t i = 0; i < nj; ++i) {
+        const BgzfBlock& b = blocks[b0 + i];
+        const Result& r = res[i];
+        if (r.status != ST_MEMBER) return fail(MG_ERR_ARG, "BGZF block at byte %llu: %s", (unsigned long long)b.coff, status_text(r.status));
+        if (r.overflow || r.out_count != b.isize || r.isize != b.isize || r.end_bit != (b.coff + b.csize) * 8)
+          return fail(MG_ERR_ARG, "BGZF block at byte %llu: corrupt (size mismatch)", (unsigned long long)b.coff);
+        if (r.crc != crcs[i]) return fail(MG_ERR_ARG, "BGZF block at byte %llu: corrupt (CRC mismatch)", (unsigned long long)b.coff);
+      }
+      g_cnt.jobs += nj;
+      for (const Result& r : res) {
+        g_cnt.clk_tables += r.t_tab; g_cnt.clk_decode += r.t_dec; g_cnt.clk_emit += r.t_emit; g_cnt.clk_tail += r.t_tail;
+        g_cnt.batches += r.nbatch; g_cnt.windows += r.nstep; g_cnt.blocks += r.nblocks; g_cnt.symbols_out += r.out_count;
+      }
+    } else {
+      MG_HIP(hipStreamSynchronize(st));
     }
-    g_cnt.jobs += nj;
     g_cnt.stages += 1;
-    for (const Result& r : res) {
-      g_cnt.clk_tables += r.t_tab; g_cnt.clk_decode += r.t_dec; g_cnt.clk_emit += r.t_emit; g_cnt.clk_tail += r.t_tail;
-      g_cnt.batches += r.nbatch; g_cnt.windows += r.nstep; g_cnt.blocks += r.nblocks; g_cnt.symbols_out += r.out_count;
-    }
+    *text_out = std::move(pb.text);
+    pb = PendingBz();
     return MG_OK;
   }
 
@@ -617,9 +710,16 @@ struct DevInflater {
     std::vector<Job> jobs;
     std::vector<Result> res;
     DevBuf sym, tails;  // tails: 32768 symbols per job, the window behind it as far as it knows it
+    DevBuf djobs, dres, dev, dcnt, scr;
   };
+  static constexpr uint32_t kMaxEvents = 1u << 16;
   // decode `jobs` (out_off / out_cap filled in here from `caps`) -> results and member ends
   int run_launch(Launch* L, const std::vector<uint64_t>& caps, bool input_final, uint64_t avail, std::vector<Event>* events, uint32_t launch_id) {
+    MG_TRY(launch_jobs(L, caps, input_final, avail));
+    return collect_jobs(L, events, launch_id);
+  }
+  // ... in two halves: everything up to the kernel (nothing waits) | the results
+  int launch_jobs(Launch* L, const std::vector<uint64_t>& caps, bool input_final, uint64_t avail) {
     const size_t nj = L->jobs.size();
     uint64_t total = 0;
     for (size_t i = 0; i < nj; ++i) {
@@ -629,19 +729,37 @@ struct DevInflater {
     }
     MG_TRY(L->sym.alloc(total * 2 + 64));
     MG_TRY(L->tails.alloc((uint64_t)nj * kWindow * 2));
-    DevBuf djobs, dres, dev, dcnt;
-    const uint32_t max_events = 1u << 16;
+    DevBuf &djobs = L->djobs, &dres = L->dres, &dev = L->dev, &dcnt = L->dcnt;
+    const uint32_t max_events = kMaxEvents;
     MG_TRY(djobs.alloc(nj * sizeof(Job)));
     MG_TRY(dres.alloc(nj * sizeof(Result)));
     MG_TRY(dev.alloc(max_events * sizeof(Event)));
     MG_TRY(dcnt.alloc(64));
     MG_HIP(hipMemcpyAsync(djobs.p, L->jobs.data(), nj * sizeof(Job), hipMemcpyHostToDevice, st));
     MG_HIP(hipMemsetAsync(dcnt.p, 0, 64, st));
-    {
+    if (nj >= g_cfg.lane_jobs) {
+      DevBuf& scr = L->scr;
+      MG_TRY(scr.alloc(nj * sizeof(LaneScratch)));
+      MG_TRY(lanes_attr());
+      {
+        ProfScope ps("k_inflate", st);
+        k_inflate_lanes<uint16_t><<<(unsigned)((nj + 63) / 64), 64, 64 * sizeof(LaneMem), st>>>(
+            comp.as<uint32_t>(), avail, input_final ? 1 : 0, djobs.as<Job>(), (uint32_t)nj, L->sym.as<uint16_t>(), dres.as<Result>(), dev.as<Event>(),
+            dcnt.as<uint32_t>(), max_events, scr.as<LaneScratch>());
+      }
+      ProfScope ps("k_make_tails", st);
+      k_make_tails<<<(unsigned)nj, 256, 0, st>>>(djobs.as<Job>(), dres.as<Result>(), L->sym.as<uint16_t>(), L->tails.as<uint16_t>());
+    } else {
       ProfScope ps("k_inflate", st);
       k_inflate<uint16_t><<<(unsigned)nj, 64, 0, st>>>(comp.as<uint32_t>(), avail, input_final ? 1 : 0, djobs.as<Job>(), L->sym.as<uint16_t>(),
                                                        dres.as<Result>(), dev.as<Event>(), dcnt.as<uint32_t>(), max_events, L->tails.as<uint16_t>());
     }
+    return MG_OK;
+  }
+  int collect_jobs(Launch* L, std::vector<Event>* events, uint32_t launch_id) {
+    const size_t nj = L->jobs.size();
+    DevBuf &dres = L->dres, &dev = L->dev, &dcnt = L->dcnt;
+    const uint32_t max_events = kMaxEvents;
     L->res.resize(nj);
     uint32_t nev = 0;
     MG_HIP(hipMemcpyAsync(L->res.data(), dres.p, nj * sizeof(Result), hipMemcpyDeviceToHost, st));
@@ -666,10 +784,22 @@ struct DevInflater {
 
   // The text of the next stage: compressed bytes [next_bit / 8, ...) of which `avail` are on their way to the device (`final`:
   // that is the whole file).  *ntext = 0 with *finished = false: nothing could be finished with the bytes there are.
-  int stage_gzip(uint64_t avail, bool final, uint64_t headroom, DevBuf* text, uint64_t* ntext, bool* finished) {
-    const double t_begin = now_s();
-    *ntext = 0;
-    *finished = false;
+  // A stage in two halves.  gz_begin: compressed bytes [next_bit / 8, ...) of which `avail` are on their way to the device (`final`:
+  // that is the whole file) -> block starts found (one wait), the jobs launched; returns with the decoder RUNNING on the inflater's
+  // stream.  gz_finish: its results -> the stage's text; *ntext = 0 with *finished = false: nothing could be finished with the bytes
+  // there were.
+  struct PendingGz {
+    bool active = false, nothing = false, final = false;
+    uint64_t avail = 0, limit_bit = 0, scan_end = 0;
+    double t_begin = 0, t_dec0 = 0;
+    std::deque<Launch> launches;
+  } pg;
+  int gz_begin(uint64_t avail, bool final) {
+    pg = PendingGz();
+    pg.active = true;
+    pg.avail = avail;
+    pg.final = final;
+    pg.t_begin = now_s();
     const uint64_t margin = 4ull << 20;
     const uint64_t chunk_bits = ((g_cfg.chunk_bytes + 7) & ~7ull) * 8;
     uint64_t limit_bit = ~0ull;  // the last job stops at the first block boundary at or behind it
@@ -678,7 +808,7 @@ struct DevInflater {
       const uint64_t safe_end = final ? avail * 8 : (avail > margin ? (avail - margin) * 8 : 0);
       if (!final || stage_end < safe_end) limit_bit = std::min(stage_end, safe_end);
       if (limit_bit != ~0ull && limit_bit <= next_bit + 64) {
-        if (!final) return MG_OK;  // more bytes first
+        if (!final) { pg.nothing = true; return MG_OK; }  // more bytes first
         limit_bit = ~0ull;
       }
     }
@@ -686,6 +816,8 @@ struct DevInflater {
     // 1. block starts
     const uint64_t grid0 = (next_bit / 64) * 64;
     const uint64_t scan_end = limit_bit == ~0ull ? avail * 8 : limit_bit;
+    pg.limit_bit = limit_bit;
+    pg.scan_end = scan_end;
     const uint64_t nchunks = scan_end > grid0 ? (scan_end - grid0 + chunk_bits - 1) / chunk_bits : 1;
     std::vector<uint64_t> starts;
     const double t_find0 = now_s();
@@ -706,10 +838,10 @@ struct DevInflater {
     }
     g_cnt.find_s += now_s() - t_find0;
     // 2. jobs: from every start to the next one
-    const double t_dec0 = now_s();
-    std::deque<Launch> launches(1);
+    pg.t_dec0 = now_s();
+    pg.launches.emplace_back();
     {
-      Launch& L = launches[0];
+      Launch& L = pg.launches[0];
       L.jobs.push_back(Job{next_bit, 0, 0, 0, first ? (uint32_t)(F_HEADER | F_MEMBER_START) : 0u, 0});
       for (uint64_t s : starts)
         if (s != ~0ull) L.jobs.push_back(Job{s, 0, 0, 0, 0, 0});
@@ -720,8 +852,20 @@ struct DevInflater {
         caps[i] = ((span_end - L.jobs[i].start_bit) / 8 + 1) * g_cfg.ratio + 4096;
       }
       events_.clear();
-      MG_TRY(run_launch(&L, caps, final, avail, &events_, 0));
+      MG_TRY(launch_jobs(&L, caps, final, avail));
     }
+    return MG_OK;
+  }
+  int gz_finish(uint64_t headroom, DevBuf* text, uint64_t* ntext, bool* finished) {
+    *ntext = 0;
+    *finished = false;
+    pg.active = false;
+    if (pg.nothing) return MG_OK;
+    const bool final = pg.final;
+    const uint64_t avail = pg.avail, limit_bit = pg.limit_bit;
+    const double t_begin = pg.t_begin, t_dec0 = pg.t_dec0;
+    std::deque<Launch>& launches = pg.launches;
+    MG_TRY(collect_jobs(&launches[0], &events_, 0));
     // 3. the chain: every job must have ended where the next one started
     struct Link { uint32_t launch, job; };
     std::vector<Link> chain;
@@ -877,23 +1021,44 @@ struct DevInflater {
     }
     g_cnt.stages += 1;
     g_cnt.stage_s += now_s() - t_begin;
+    launches.clear();
     return MG_OK;
   }
 
   // the next piece of text; *finished: nothing follows
-  int next(uint64_t headroom, DevBuf* text, uint64_t* ntext, bool* finished) {
+  // The next piece of text in two halves: begin() returns with the stage's decoder running on the inflater's stream (the caller's
+  // work on the library's main stream — parsing and hashing the previous stage's text — runs beside it); finish() -> the text.
+  // *finished: nothing follows.
+  bool pending = false;
+  int begin() {
+    if (done || pending) return MG_OK;
+    pending = true;
+    if (bgzf) return bz_begin(768ull << 20);
+    // a stage needs its own compressed bytes and a little more (its last job reads on to the end of its block)
+    const uint64_t avail = std::min<uint64_t>(n, next_bit / 8 + g_cfg.stage_bytes + (8ull << 20));
+    return gz_begin(avail, avail == n);
+  }
+  int finish(DevBuf* text, uint64_t* ntext, bool* finished) {
     if (done) { *ntext = 0; *finished = true; return MG_OK; }
+    if (!pending) MG_TRY(begin());
+    pending = false;
     int rc;
     if (bgzf) {
-      rc = stage_bgzf(headroom, 768ull << 20, text, ntext, finished);
+      rc = bz_finish(text, ntext, finished);
     } else {
-      // a stage needs its own compressed bytes and a little more (its last job reads on to the end of its block)
-      const uint64_t avail = std::min<uint64_t>(n, next_bit / 8 + g_cfg.stage_bytes + (8ull << 20));
-      rc = stage_gzip(avail, avail == n, headroom, text, ntext, finished);
-      if (rc == MG_OK && *ntext == 0 && !*finished && avail < n) rc = stage_gzip(n, true, headroom, text, ntext, finished);
+      const bool was_final = pg.final;
+      rc = gz_finish(headroom, text, ntext, finished);
+      if (rc == MG_OK && *ntext == 0 && !*finished && !was_final) {  // (a block longer than the margin: with every byte there is)
+        rc = gz_begin(n, true);
+        if (rc == MG_OK) rc = gz_finish(headroom, text, ntext, finished);
+      }
     }
     if (rc == MG_OK && *finished) done = true;
     return rc;
+  }
+  ~DevInflater() {
+    if (st) (void)hipStreamSynchronize(st);  // (a stage may still be running when an error ends the pipeline: before its buffers go)
+    ctx().inf_side = false;
   }
 
   std::vector<Event> events_;
@@ -910,18 +1075,23 @@ int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const 
   int rc = MG_OK;
   {
     DevInflater inf;
-    rc = inf.open(static_cast<const uint8_t*>(map), fsize, 4);
     const uint64_t headroom = 4ull << 20;
+    rc = inf.open(static_cast<const uint8_t*>(map), fsize, 4, headroom);
     DevBuf prev;
     const uint8_t* carry_src = nullptr;
     uint64_t carry = 0;
     hipStream_t st = ctx().stream;
+    if (rc == MG_OK) rc = inf.begin();
     while (rc == MG_OK) {
       DevBuf text;
       uint64_t nt = 0;
       bool fin = false;
-      rc = inf.next(headroom, &text, &nt, &fin);
+      rc = inf.finish(&text, &nt, &fin);
       if (rc != MG_OK) break;
+      if (!fin) {  // the next stage's decoder starts now and runs beside the consumer of this stage's text
+        rc = inf.begin();
+        if (rc != MG_OK) break;
+      }
       if (carry) {
         if (hipMemcpyAsync(text.as<uint8_t>() + headroom - carry, carry_src, carry, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = fail(MG_ERR_HIP, "carry copy failed"); break; }
       }
@@ -936,7 +1106,7 @@ int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const 
       carry_src = d + consumed;
       prev = std::move(text);  // (kept until the carry has been copied out of it)
     }
-    if (rc != MG_OK) (void)hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(st);
     inf.up.finish();
   }
   munmap(map, fsize);
@@ -955,7 +1125,8 @@ struct mg_inflated {
 
 extern "C" {
 
-int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on) {
+int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on, int64_t lane_jobs) {
+  if (lane_jobs >= 0) g_cfg.lane_jobs = lane_jobs > 0xffffffffll ? 0xffffffffu : (uint32_t)lane_jobs;
   if (chunk_bytes > 0) {
     if (chunk_bytes < 1024) return fail(MG_ERR_ARG, "inflate chunks of at least 1024 bytes");
     g_cfg.chunk_bytes = (uint64_t)chunk_bytes;
@@ -981,12 +1152,12 @@ int mg_inflate_dev(const uint8_t* comp, uint64_t ncomp, mg_inflated** out) {
   *out = nullptr;
   std::unique_ptr<mg_inflated> res(new mg_inflated());
   DevInflater inf;
-  MG_TRY(inf.open(comp, ncomp, 4));
+  MG_TRY(inf.open(comp, ncomp, 4, 0));
   for (;;) {
     mg::DevBuf text;
     uint64_t nt = 0;
     bool fin = false;
-    MG_TRY(inf.next(0, &text, &nt, &fin));
+    MG_TRY(inf.finish(&text, &nt, &fin));
     res->total += nt;
     res->sizes.push_back(nt);
     res->parts.push_back(std::move(text));

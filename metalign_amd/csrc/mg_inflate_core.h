@@ -236,6 +236,14 @@ struct HostExec {
     return run;
   }
   template <class F> void lanes(F&& f) const { for (int l = 0; l < 64; ++l) f(l); }
+  // every lane produces a value, gets the sum of the lanes below it and the sum of all; -> that sum
+  template <class P, class C> uint32_t lanes_scan(P&& produce, C&& consume) const {
+    uint32_t v[64], run = 0;
+    for (int l = 0; l < 64; ++l) v[l] = produce(l);
+    for (int l = 0; l < 64; ++l) { const uint32_t x = v[l]; v[l] = run; run += x; }
+    for (int l = 0; l < 64; ++l) consume(l, v[l], run);
+    return run;
+  }
   static void atomic_inc(uint32_t* p) { ++*p; }
   static uint32_t atomic_fetch_inc(uint32_t* p) { return (*p)++; }
   static void atomic_or64(uint64_t* p, uint64_t v) { *p |= v; }
@@ -270,6 +278,27 @@ struct DevExec {
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
   }
   template <class F> __device__ void lanes(F&& f) const { f(lane); }
+  // (prefix sums over the wavefront in registers: four row_shr steps inside the rows of 16 lanes, row_bcast:15 into rows 1 and 3,
+  // row_bcast:31 into rows 2 and 3 — no LDS, no barrier)
+  __device__ static uint32_t dpp_inclusive(uint32_t v) {
+    uint32_t x = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+#endif
+    return x;
+  }
+  template <class P, class C> __device__ uint32_t lanes_scan(P&& produce, C&& consume) const {
+    const uint32_t v = produce(lane);
+    const uint32_t x = dpp_inclusive(v);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    consume(lane, x - v, total);
+    return total;
+  }
   __device__ static void atomic_inc(uint32_t* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ static uint32_t atomic_fetch_inc(uint32_t* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ static void atomic_or64(uint64_t* p, uint64_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -488,29 +517,22 @@ MGI_HD uint32_t decode_one(const Shared& sh, BitReader& br, uint32_t* len, uint3
 // look-ups, extra bits included.  -> *tot = its bits (at most 48) with *len / *hi, or *tot = 0: the scalar path's business
 // (*len = why: K_EOB, K_LONG, K_BAD).
 MGI_HDI void decode_at(const Shared& sh, uint32_t b0, uint32_t b1, uint32_t* tot, uint32_t* len, uint32_t* hi) {
+  // (no branches: the lanes of a wavefront hold literals and matches side by side, both ways would be walked anyway; a literal's
+  // distance look-up reads some entry and is thrown away)
   const uint32_t e = sh.lit[b0 & ((1u << LB) - 1u)];
-  const uint32_t nb = e & 15u, kind = (e >> 8) & 7u;
-  *hi = 0;
-  if (kind == K_LIT && nb) {
-    *tot = nb;
-    *len = 1;
-    *hi = (e >> 16) << 16;
-    return;
-  }
-  *tot = 0;
-  *len = nb == 0 ? (uint32_t)K_BAD : kind;
-  if (kind != K_LEN || nb == 0) return;
-  const uint32_t xb = (e >> 4) & 15u;
+  const uint32_t nb = e & 15u, xb = (e >> 4) & 15u, kind = (e >> 8) & 7u;
   const uint32_t length = (e >> 16) + ((b0 >> nb) & ((1u << xb) - 1u));
-  const uint32_t c1 = nb + xb;  // 1..20
-  const uint32_t y = (b0 >> c1) | (b1 << (32u - c1));
+  const uint32_t c1 = (nb + xb) & 31u;  // 1..20 for a length symbol
+  const uint32_t y = (uint32_t)((((uint64_t)b1 << 32) | b0) >> c1);
   const uint32_t d = sh.dist[y & ((1u << DB) - 1u)];
-  const uint32_t dn = d & 15u, dk = (d >> 8) & 7u;
-  if (dk != K_DIST || dn == 0) { *len = dk == K_LONG ? (uint32_t)K_LONG : (uint32_t)K_BAD; return; }
-  const uint32_t dxb = (d >> 4) & 15u;
-  *hi = (d >> 16) + ((y >> dn) & ((1u << dxb) - 1u));
-  *len = length;
-  *tot = c1 + dn + dxb;
+  const uint32_t dn = d & 15u, dxb = (d >> 4) & 15u, dk = (d >> 8) & 7u;
+  const uint32_t distance = (d >> 16) + ((y >> dn) & ((1u << dxb) - 1u));
+  const bool is_lit = kind == K_LIT && nb != 0, is_len = kind == K_LEN && nb != 0;
+  const bool is_match = is_len && dk == K_DIST && dn != 0;
+  const uint32_t why = nb == 0 ? (uint32_t)K_BAD : is_len ? (dk == K_LONG ? (uint32_t)K_LONG : (uint32_t)K_BAD) : kind;
+  *tot = is_lit ? nb : is_match ? c1 + dn + dxb : 0u;
+  *len = is_lit ? 1u : is_match ? length : why;
+  *hi = is_lit ? (e >> 16) << 16 : is_match ? distance : 0u;
 }
 
 // the word of a window's 256-bit membership set that holds lane's four positions; those four bits
@@ -574,7 +596,7 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
         const uint64_t y = x >> j;
         uint32_t tot;
         decode_at(sh, (uint32_t)y, (uint32_t)(y >> 32), &tot, &len[j], &hi[j]);
-        totp |= tot << (8u * j);
+        totp |= (tot ? tot : 255u) << (8u * j);  // (255 "bits": the walk leaves the window at a position the scalar path has to look at)
         if (!tot) whyp |= len[j] << (8u * j);
       }
       ex.set_syms(lane, totp, whyp, len, hi);
@@ -584,43 +606,81 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
     uint32_t off = 0, cnt = 0;
     uint64_t S0 = 0, S1 = 0, S2 = 0, S3 = 0;  // (four words, not an array: they stay in SGPRs)
     bool special = false;
-    // (one loop per 64 positions, so that its word of the set stays in one register pair and the loop is a dozen scalar
-    // instructions per symbol; the step's symbol limit is looked at between the loops: at most kStepSyms - 1 + 64 symbols)
-#define MGI_WALK(Sr, END)                                                              \
-    if (!special && cnt < kStepSyms) {                                                   \
-      const uint32_t before_ = off;                                                      \
-      uint32_t n_ = 0;                                                                   \
-      while (off < (END)) {                                                              \
-        const uint32_t t = (ex.totp_at(off >> 2) >> (8u * (off & 3u))) & 0xffu;          \
-        if (t == 0) { special = true; break; }                                           \
-        Sr |= 1ull << (off & 63u);                                                       \
-        ++n_;                                                                            \
-        off += t;                                                                        \
-      }                                                                                  \
-      (void)before_;                                                                     \
-      cnt += n_;                                                                         \
+    // (one loop per 64 positions, so that its word of the set stays in one register pair; a position the scalar path has to look at
+    // says "255 bits", which ends the walk by itself — the loop is: read the lane, extract, set the bit, add, compare; the step's
+    // symbol limit is looked at between the loops: at most kStepSyms - 1 + 64 symbols)
+    uint32_t last = 0;
+#define MGI_TOT(p) ((ex.totp_at((p) >> 2) >> (8u * ((p) & 3u))) & 0xffu)
+#define MGI_WALK(Sr, END)                                                                                    \
+    if (off < (END) && cnt < kStepSyms) {                                                                      \
+      do {                                                                                                     \
+        last = off;                                                                                            \
+        Sr |= 1ull << (off & 63u);                                                                             \
+        off += MGI_TOT(off);                                                                                   \
+      } while (off < (END));                                                                                   \
+      cnt += popc64(Sr);                                                                                       \
     }
-    MGI_WALK(S0, 64u)
-    MGI_WALK(S1, 128u)
-    MGI_WALK(S2, 192u)
-    MGI_WALK(S3, 256u)
+    if (MGI_TOT(0u) == 255u) {  // (from any other position 255 more bits are behind the window)
+      special = true;
+    } else {
+      MGI_WALK(S0, 64u)
+      MGI_WALK(S1, 128u)
+      MGI_WALK(S2, 192u)
+      MGI_WALK(S3, 256u)
+      if (MGI_TOT(last) == 255u) {  // the last position looked at was the scalar path's: it is no member, the walk stands there
+        special = true;
+        off = last;
+        const uint64_t bit = 1ull << (last & 63u);
+        const uint32_t r = last >> 6;
+        if (r == 0) S0 &= ~bit; else if (r == 1) S1 &= ~bit; else if (r == 2) S2 &= ~bit; else S3 &= ~bit;
+        --cnt;
+      }
+    }
 #undef MGI_WALK
+#undef MGI_TOT
     MGI_SUB(2);
     if (cnt) {
       const uint64_t a0 = S0, a1 = S1, a2 = S2, a3 = S3;  // (as found; the cut below may drop the last ones)
-      ex.sync();
-      ex.lanes([&](int lane) {
-        const uint32_t m = lane_members(lane, a0, a1, a2, a3);
-        uint32_t sum = 0;
+      const uint32_t d0 = popc64(a0), d1 = popc64(a1), d2 = popc64(a2);
+      // a lane's symbols: place in the batch from the popcounts, first output byte from the prefix sum of the lengths — in one phase
+      // (the sums in registers); only a window in which the batch's bytes run out takes the slow way below
+      auto queue_lane = [&](int lane, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t excl) {
+        const uint32_t m = lane_members(lane, s0, s1, s2, s3);
+        if (!m) return;
+        const uint32_t r = (uint32_t)lane >> 4;
+        uint32_t i = nsym + (r >= 1 ? e0 : 0u) + (r >= 2 ? e1 : 0u) + (r >= 3 ? e2 : 0u) +  // (sums, not a chain of ==: that became a table in scratch)
+                     popc64(lane_word(lane, s0, s1, s2, s3) & ((1ull << (4u * ((uint32_t)lane & 15u))) - 1ull));
+        uint32_t dst = T + excl;
         MGI_UNROLL
-        for (int j = 0; j < 4; ++j) sum += (m >> j) & 1u ? ex.my_len(lane, j) : 0u;
-        sh.scan[lane] = sum;
-        if (lane == 0) sh.cut = kStepBits;
-      });
-      ex.sync();
-      uint32_t total = ex.scan();
-      ex.sync();
+        for (int j = 0; j < 4; ++j) {
+          if (!((m >> j) & 1u)) continue;
+          const uint32_t len = ex.my_len(lane, j);
+          sh.rec_lo[i] = dst | len << 16;
+          sh.rec_hi[i] = ex.my_hi(lane, j);
+          Exec::atomic_or64(&sh.headbits[dst >> 6], 1ull << (dst & 63u));
+          ++i;
+          dst += len;
+        }
+      };
+      uint32_t total = ex.lanes_scan(
+          [&](int lane) -> uint32_t {
+            const uint32_t m = lane_members(lane, a0, a1, a2, a3);
+            uint32_t sum = 0;
+            MGI_UNROLL
+            for (int j = 0; j < 4; ++j) sum += (m >> j) & 1u ? ex.my_len(lane, j) : 0u;
+            return sum;
+          },
+          [&](int lane, uint32_t excl, uint32_t tot) {
+            if (T + tot > kBatchBytes) {
+              sh.scan[lane] = excl;
+              if (lane == 0) sh.cut = kStepBits;
+            } else if (queue) {
+              queue_lane(lane, a0, a1, a2, a3, d0, d1, d2, excl);
+            }
+          });
+      MGI_SUB(3);
       if (T + total > kBatchBytes) {  // the batch's bytes run out inside this window: up to the first symbol that does not fit
+        ex.sync();
         ex.lanes([&](int lane) {
           const uint32_t m = lane_members(lane, a0, a1, a2, a3);
           uint32_t run = T + sh.scan[lane];
@@ -654,29 +714,11 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
         cnt = popc64(S0) + popc64(S1) + popc64(S2) + popc64(S3);
         off = c;
         special = false;
-      }
-      MGI_SUB(3);
-      if (queue) {
-        const uint64_t b0 = S0, b1 = S1, b2 = S2, b3 = S3;
-        const uint32_t d0 = popc64(b0), d1 = popc64(b1), d2 = popc64(b2);
-        ex.lanes([&](int lane) {
-          const uint32_t m = lane_members(lane, b0, b1, b2, b3);
-          if (!m) return;
-          const uint32_t r = (uint32_t)lane >> 4;
-          uint32_t i = nsym + (r >= 1 ? d0 : 0u) + (r >= 2 ? d1 : 0u) + (r >= 3 ? d2 : 0u) +  // (sums, not a chain of ==: that became a table in scratch)
-                       popc64(lane_word(lane, b0, b1, b2, b3) & ((1ull << (4u * ((uint32_t)lane & 15u))) - 1ull));
-          uint32_t dst = T + sh.scan[lane];
-          MGI_UNROLL
-          for (int j = 0; j < 4; ++j) {
-            if (!((m >> j) & 1u)) continue;
-            const uint32_t len = ex.my_len(lane, j);
-            sh.rec_lo[i] = dst | len << 16;
-            sh.rec_hi[i] = ex.my_hi(lane, j);
-            Exec::atomic_or64(&sh.headbits[dst >> 6], 1ull << (dst & 63u));
-            ++i;
-            dst += len;
-          }
-        });
+        if (queue) {
+          const uint64_t b0 = S0, b1 = S1, b2 = S2, b3 = S3;
+          const uint32_t f0 = popc64(b0), f1 = popc64(b1), f2 = popc64(b2);
+          ex.lanes([&](int lane) { queue_lane(lane, b0, b1, b2, b3, f0, f1, f2, sh.scan[lane]); });
+        }
       }
       nsym += cnt;
       T += total;
@@ -715,6 +757,27 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
     ex.scan();
     ex.sync();
     ex.lanes([&](int lane) { sh.headbase[lane] = (uint16_t)sh.scan[lane]; });
+    // Matches that copy a match of this batch that copies a match ... (the quality line of one FASTQ record after another): every
+    // byte of the last one would walk the whole chain.  A match whose source lies inside ONE earlier match of the batch (one that does
+    // not overlap itself) may as well copy from where that one copies: twice over all symbols, distances added (pointer jumping).
+    for (int it = 0; it < 2; ++it) {
+      ex.sync();
+      ex.lanes([&](int lane) {
+        for (uint32_t k = (uint32_t)lane; k < nsym; k += 64) {
+          const uint32_t lo = sh.rec_lo[k], hi = sh.rec_hi[k];
+          const uint32_t dist = hi & 0xffffu, dst = lo & 0xffffu, len = lo >> 16;
+          if (dist == 0 || dist > dst || dist < len) continue;  // a literal; a source in front of the batch; a run
+          const uint32_t a = dst - dist, b = a + len - 1;
+          const uint32_t wa = a >> 6, wb = b >> 6;
+          const uint32_t j = sh.headbase[wa] + popc64(sh.headbits[wa] & ((2ull << (a & 63u)) - 1ull)) - 1u;
+          const uint32_t je = sh.headbase[wb] + popc64(sh.headbits[wb] & ((2ull << (b & 63u)) - 1ull)) - 1u;
+          if (j != je) continue;
+          const uint32_t hj = sh.rec_hi[j], dj = hj & 0xffffu;
+          if (dj == 0 || dj < (sh.rec_lo[j] >> 16) || dist + dj > 0xffffu) continue;
+          sh.rec_hi[k] = dist + dj;
+        }
+      });
+    }
   }
   br.init(in, nwords, pos);
   *nsym_out = nsym;
@@ -777,26 +840,31 @@ MGI_HDI void emit_lane(Shared& sh, int lane, uint32_t T, OutT* out, uint64_t pos
 }
 
 // ---- gzip member header at byte P (RFC 1952) -> first byte of the deflate data.  0 ok, 1 not a member, 2 ends inside ----
-MGI_HD uint32_t in_byte(const uint32_t* in, uint64_t i) { return (MGI_UNI(in[i >> 2]) >> (8u * ((uint32_t)i & 3u))) & 0xffu; }
+template <bool U = true>
+MGI_HD uint32_t in_byte(const uint32_t* in, uint64_t i) {
+  const uint32_t w = in[i >> 2];
+  return ((U ? MGI_UNI(w) : w) >> (8u * ((uint32_t)i & 3u))) & 0xffu;
+}
+template <bool U = true>
 MGI_HD uint32_t gzip_header(const uint32_t* in, uint64_t nbytes, uint64_t P, uint64_t* data) {
   // what is there of the first three bytes decides between "not a member" (trailing garbage, ignored as gzip does) and "cut"
   const uint32_t magic[3] = {0x1f, 0x8b, 8};
   for (uint32_t i = 0; i < 3; ++i) {
     if (P + i >= nbytes) return i == 0 ? 1u : 2u;
-    if (in_byte(in, P + i) != magic[i]) return 1u;
+    if (in_byte<U>(in, P + i) != magic[i]) return 1u;
   }
   if (P + 10 > nbytes) return 2u;
-  const uint32_t flg = in_byte(in, P + 3);
+  const uint32_t flg = in_byte<U>(in, P + 3);
   uint64_t at = P + 10;
   if (flg & 4u) {  // FEXTRA
     if (at + 2 > nbytes) return 2u;
-    at += 2 + (in_byte(in, at) | in_byte(in, at + 1) << 8);
+    at += 2 + (in_byte<U>(in, at) | in_byte<U>(in, at + 1) << 8);
   }
   for (uint32_t f = 8u; f <= 16u; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
     if (!(flg & f)) continue;
     for (;;) {
       if (at >= nbytes) return 2u;
-      if (in_byte(in, at++) == 0) break;
+      if (in_byte<U>(in, at++) == 0) break;
     }
   }
   if (flg & 2u) at += 2;  // FHCRC
@@ -969,6 +1037,408 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
     for (int i = 0; i < 6; ++i) res->t_sub[i] = t_sub[i];
   }
 }
+
+
+// =====================================================================================================================
+// One job per LANE (k_inflate_lanes): the serial decoder as every inflate is written, 64 of them side by side in a wavefront.
+//
+// The wavefront-per-job decoder above spends ~50 vector instructions per symbol whichever way it is arranged (a scalar loop on
+// the CU's one scalar unit, or 256 speculative decodes of which 16 are symbols); a file of F deflate blocks offers F-fold
+// parallelism, and a 10M-read FASTQ has 17 000 of them.  Here a lane is a whole decoder: its bit buffer and counters in registers,
+// its look-up tables in LDS (1280 bytes a lane: 9 bits of literal/length code, 6 of distance code, 16-bit entries = code length
+// | symbol << 4; longer codes are searched canonically from the per-length counts), what is touched rarely (code lengths, the
+// symbols in code order) in a scratch block of memory per job.  A lane is a small state machine and the wavefront runs ROUNDS: in a
+// round a lane reads a block header and builds its tables, or decodes one symbol, or copies up to 16 elements of a match (a long
+// match takes several rounds, so one lane's 258-byte match does not hold up 63 literals).  The sources of a match are final
+// before the match starts (an overlapping match re-reads its first `dist` elements), so a round's loads never wait for its stores.
+// =====================================================================================================================
+constexpr int LLB = 9, LDB = 6;
+struct LaneMem {            // a lane's LDS: 319 words, an odd number, so that equal indices of different lanes fall into different banks
+  uint16_t lit[1 << LLB];
+  uint16_t dist[1 << LDB];
+  uint16_t cnt_[30];        // codes per length 1..15 of either code (the search for long codes derives first codes and ranks from them)
+  uint16_t next[16];        // table build: the next code of every length ...
+  uint16_t offs[16];        // ... and the rank of its first symbol
+  MGI_HD uint16_t& cnt(int which, uint32_t l) { return cnt_[which * 15 + (int)l - 1]; }
+};
+static_assert(sizeof(LaneMem) == 1276, "a lane's tables");
+struct LaneScratch {        // a job's block of memory
+  uint16_t sorted[320];     // symbols by (length, symbol): [0, 288) literal/length, [288, 320) distance
+  uint8_t cl[320];
+};
+enum : uint32_t { LS_BLOCK = 0, LS_SYM = 1, LS_COPY = 2, LS_STORED = 3, LS_MEMBER = 4, LS_DONE = 5 };
+
+template <class OutT>
+struct LaneDec {
+  const uint32_t* in;
+  uint64_t nbytes, nbits;
+  bool input_final;
+  Job job;
+  uint32_t jobidx;
+  OutT* out;
+  LaneMem* mem;
+  LaneScratch* scr;
+  Event* events;
+  uint32_t* nevents;
+  uint32_t max_events;
+  BitReaderT<false> br;
+  uint64_t outn;
+  int64_t floor;
+  uint32_t state, status, overflow, nblocks, nev, crc, isize, bfinal;
+  bool count_only;
+  uint64_t cp_base;         // a match: where it starts, its distance and length, elements done, the source offset of the next one
+  uint32_t cp_dist, cp_len, cp_i, cp_o;
+  uint64_t st_pos;          // a stored block: the next input byte, bytes left
+  uint32_t st_left;
+  uint32_t rounds;
+
+  MGI_HD uint32_t cut() const { return input_final ? ST_TRUNC : ST_NEED_MORE; }
+  MGI_HD void finish(uint32_t st) {
+    // garbage decoded from behind the end of the input is the input's end, not a damaged stream
+    if (st >= ST_ERR && st != ST_BAD_HEADER && br.pos() > nbits) st = cut();
+    status = st;
+    state = LS_DONE;
+  }
+  MGI_HD void init(const uint32_t* in_, uint64_t nbytes_, bool final_, const Job& job_, uint32_t jobidx_, OutT* out_, LaneMem* mem_, LaneScratch* scr_,
+                   Event* events_, uint32_t* nevents_, uint32_t max_events_) {
+    in = in_; nbytes = nbytes_; nbits = nbytes_ * 8; input_final = final_; job = job_; jobidx = jobidx_; out = out_; mem = mem_; scr = scr_;
+    events = events_; nevents = nevents_; max_events = max_events_;
+    outn = 0;
+    floor = (job.flags & F_MEMBER_START) ? 0 : (sizeof(OutT) == 2 ? -(int64_t)kWindow : 0);
+    state = LS_BLOCK; status = 0; overflow = 0; nblocks = 0; nev = 0; crc = 0; isize = 0; bfinal = 0; rounds = 0;
+    count_only = (job.flags & F_COUNT_ONLY) != 0;
+    cp_base = 0; cp_dist = cp_len = cp_i = cp_o = 0; st_pos = 0; st_left = 0;
+    uint64_t pos = job.start_bit;
+    br.init(in, (nbytes + 3) / 4, pos);
+    if (job.flags & F_HEADER) {
+      uint64_t data = 0;
+      const uint32_t h = gzip_header<false>(in, nbytes, pos >> 3, &data);
+      if (h) { finish(h == 1 ? (uint32_t)ST_BAD_HEADER : cut()); return; }
+      br.init(in, (nbytes + 3) / 4, data * 8);
+    }
+  }
+
+  // a code longer than the table's bits: canonical search from the counts
+  MGI_HD uint32_t slow(int which) {
+    const uint32_t TB = which ? LDB : LLB;
+    const uint32_t c15 = bitrev((uint32_t)br.bb & 0x7fffu, 15);
+    uint32_t first = 0, rank = 0;
+    for (uint32_t l = 1; l <= 15; ++l) {
+      const uint32_t c = mem->cnt(which, l);
+      if (l > TB) {
+        const uint32_t k = (c15 >> (15 - l)) - first;
+        if (k < c) return l | (uint32_t)scr->sorted[(which ? 288 : 0) + rank + k] << 4;
+      }
+      rank += c;
+      first = (first + c) << 1;
+    }
+    return 0;
+  }
+
+  // code lengths cl[base, base + n) -> the lane's table; 0 or ST_BAD_CODES
+  MGI_HD uint32_t build(int which, uint32_t base, uint32_t n) {
+    const uint32_t TB = which ? LDB : LLB;
+    uint16_t* tab = which ? mem->dist : mem->lit;
+    for (uint32_t l = 1; l < 16; ++l) mem->cnt(which, l) = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+      const uint32_t l = scr->cl[base + s];
+      if (l) ++mem->cnt(which, l);
+    }
+    int32_t left = 1;
+    uint32_t code = 0, rank = 0, used = 0;
+    for (uint32_t l = 1; l <= 15; ++l) {
+      const uint32_t c = mem->cnt(which, l);
+      left = (left << 1) - (int32_t)c;
+      if (left < 0) return ST_BAD_CODES;
+      mem->next[l] = (uint16_t)code;
+      mem->offs[l] = (uint16_t)rank;
+      code = (code + c) << 1;
+      rank += c;
+      used += c;
+    }
+    if (left > 0 && used != 0 && mem->cnt(which, 1) != used) return ST_BAD_CODES;  // (zlib: incomplete only when every code has one bit)
+    for (uint32_t i = 0; i < (1u << TB); ++i) tab[i] = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+      const uint32_t l = scr->cl[base + s];
+      if (!l) continue;
+      const uint32_t c = mem->next[l];
+      mem->next[l] = (uint16_t)(c + 1);
+      const uint32_t r = mem->offs[l];
+      mem->offs[l] = (uint16_t)(r + 1);
+      scr->sorted[(which ? 288 : 0) + r] = (uint16_t)s;
+      const uint32_t rc = bitrev(c, l);
+      if (l > TB) tab[rc & ((1u << TB) - 1u)] = 0x800fu;
+      else
+        for (uint32_t j = rc; j < (1u << TB); j += 1u << l) tab[j] = (uint16_t)(l | s << 4);
+    }
+    return 0;
+  }
+
+  // the header of a block, its tables
+  MGI_HD void block() {
+    if (br.pos() >= job.stop_bit) { finish(ST_STOP); return; }
+    br.refill();
+    if (br.pos() + 3 > nbits) { finish(cut()); return; }
+    bfinal = br.bits(1);
+    const uint32_t btype = br.bits(2);
+    ++nblocks;
+    if (btype == 3) { finish(ST_BAD_BLOCK); return; }
+    if (btype == 0) {
+      br.drop(br.bc & 7u);
+      br.refill();
+      if (br.pos() + 32 > nbits) { finish(cut()); return; }
+      const uint32_t len = br.bits(16);
+      br.refill();
+      const uint32_t nlen = br.bits(16);
+      if ((len ^ nlen) != 0xffffu) { finish(ST_BAD_STORED); return; }
+      st_pos = br.pos() >> 3;
+      st_left = len;
+      if (st_pos + len > nbytes) { finish(cut()); return; }
+      state = LS_STORED;
+      return;
+    }
+    uint32_t nlit = 288, ndist = 32;
+    if (btype == 1) {
+      for (uint32_t s = 0; s < 320; ++s) scr->cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+    } else {
+      br.refill();
+      nlit = br.bits(5) + 257;
+      ndist = br.bits(5) + 1;
+      const uint32_t ncl = br.bits(4) + 4;
+      if (nlit > 286 || ndist > 30) { finish(ST_BAD_CODES); return; }
+      const uint64_t order_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                                5ull << 45 | 11ull << 50 | 4ull << 55;
+      const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+      uint64_t plen = 0, cnts = 0;  // 3 bits per symbol; 8 bits per length
+      for (uint32_t i = 0; i < ncl; ++i) {
+        br.refill();
+        const uint32_t l = br.bits(3);
+        const uint32_t sym = (uint32_t)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31u);
+        plen |= (uint64_t)l << (3 * sym);
+        cnts += 1ull << (8 * l);
+      }
+      uint64_t firsts = 0, offs = 0, sorted_lo = 0, sorted_hi = 0;
+      {
+        int32_t left = 1;
+        uint32_t code = 0, rank = 0;
+        for (uint32_t l = 1; l < 8; ++l) {
+          const uint32_t c = (uint32_t)(cnts >> (8 * l)) & 0xffu;
+          left = (left << 1) - (int32_t)c;
+          if (left < 0) { finish(ST_BAD_CODES); return; }
+          firsts |= (uint64_t)code << (8 * l);
+          offs |= (uint64_t)rank << (8 * l);
+          for (uint32_t s = 0; s < 19; ++s) {
+            if (((uint32_t)(plen >> (3 * s)) & 7u) != l) continue;
+            if (rank < 12) sorted_lo |= (uint64_t)s << (5 * rank); else sorted_hi |= (uint64_t)s << (5 * (rank - 12));
+            ++rank;
+          }
+          code = (code + c) << 1;
+        }
+        if (left != 0) { finish(ST_BAD_CODES); return; }
+      }
+      const uint32_t total = nlit + ndist;
+      uint32_t i = 0, prev = 0;
+      while (i < total) {
+        br.refill();
+        uint32_t code = 0, sym = 32;
+        for (uint32_t l = 1; l < 8; ++l) {
+          code = (code << 1) | ((uint32_t)(br.bb >> (l - 1)) & 1u);
+          const uint32_t k = code - ((uint32_t)(firsts >> (8 * l)) & 0xffu);
+          if (k < ((uint32_t)(cnts >> (8 * l)) & 0xffu)) {
+            const uint32_t r = ((uint32_t)(offs >> (8 * l)) & 0xffu) + k;
+            sym = (uint32_t)((r < 12 ? sorted_lo >> (5 * r) : sorted_hi >> (5 * (r - 12))) & 31u);
+            br.drop(l);
+            break;
+          }
+        }
+        if (sym == 32) { finish(ST_BAD_CODES); return; }
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+          if (i == 0) { finish(ST_BAD_CODES); return; }
+          rep = 3 + br.bits(2);
+          val = prev;
+        } else if (sym == 17) {
+          rep = 3 + br.bits(3);
+          val = 0;
+        } else if (sym == 18) {
+          rep = 11 + br.bits(7);
+          val = 0;
+        }
+        if (i + rep > total) { finish(ST_BAD_CODES); return; }
+        if (sym != 16) prev = val;
+        for (uint32_t j = 0; j < rep; ++j) scr->cl[i + j] = (uint8_t)val;
+        i += rep;
+      }
+      if (br.pos() > nbits) { finish(cut()); return; }
+      if (scr->cl[256] == 0) { finish(ST_BAD_CODES); return; }
+    }
+    uint32_t rc = build(0, 0, nlit);
+    if (!rc) rc = build(1, nlit, ndist);
+    if (rc) { finish(rc); return; }
+    state = LS_SYM;
+  }
+
+  MGI_HD void end_of_block() {
+    if (bfinal) { state = LS_MEMBER; return; }
+    state = LS_BLOCK;
+  }
+
+  // behind a member's last block: the trailer, what follows
+  MGI_HD void member() {
+    br.drop(br.bc & 7u);
+    br.refill();
+    if (br.pos() + 64 > nbits) { finish(cut()); return; }
+    crc = br.bits(32);
+    br.refill();
+    isize = br.bits(32);
+    if (job.flags & F_ONE_MEMBER) { finish(ST_MEMBER); return; }
+    ++nev;
+    uint32_t at;
+#if defined(__HIP_DEVICE_COMPILE__)
+    at = __hip_atomic_fetch_add(nevents, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    at = (*nevents)++;
+#endif
+    if (at >= max_events) { finish(ST_EVENTS_FULL); return; }
+    events[at].out_pos = outn;
+    events[at].job = jobidx;
+    events[at].crc = crc;
+    events[at].isize = isize;
+    events[at].pad = 0;
+    uint64_t data = 0;
+    const uint32_t h = gzip_header<false>(in, nbytes, br.pos() >> 3, &data);
+    if (h == 1) { finish((br.pos() >> 3) >= nbytes && !input_final ? (uint32_t)ST_NEED_MORE : (uint32_t)ST_END); return; }
+    if (h == 2) { finish(cut()); return; }
+    floor = (int64_t)outn;
+    br.init(in, (nbytes + 3) / 4, data * 8);
+    state = LS_BLOCK;
+  }
+
+  MGI_HD void room(uint32_t n) {
+    if (!count_only && outn + n > job.out_cap) { overflow = 1; count_only = true; }
+  }
+
+  // one symbol
+  MGI_HD void symbol() {
+    br.refill();
+    if (br.pos() > nbits) { finish(cut()); return; }
+    uint32_t c = mem->lit[(uint32_t)br.bb & ((1u << LLB) - 1u)];
+    if (c & 0x8000u) c = slow(0);
+    const uint32_t l = c & 15u;
+    if (!l) { finish(ST_BAD_SYMBOL); return; }
+    br.drop(l);
+    const uint32_t sym = (c >> 4) & 511u;
+    if (sym < 256) {
+      room(1);
+      if (!count_only) out[outn] = (OutT)sym;
+      ++outn;
+      return;
+    }
+    if (sym == 256) { end_of_block(); return; }
+    if (sym > 285) { finish(ST_BAD_SYMBOL); return; }
+    const uint32_t b = len_sym(sym - 257);
+    const uint32_t len = (b & 0xffffu) + br.bits(b >> 16);
+    br.refill();
+    uint32_t d = mem->dist[(uint32_t)br.bb & ((1u << LDB) - 1u)];
+    if (d & 0x8000u) d = slow(1);
+    const uint32_t dl = d & 15u, ds = (d >> 4) & 511u;
+    if (!dl || ds > 29) { finish(ST_BAD_SYMBOL); return; }
+    br.drop(dl);
+    const uint32_t db = dist_sym(ds);
+    const uint32_t dist = (db & 0xffffu) + br.bits(db >> 16);
+    if ((int64_t)outn - (int64_t)dist < floor) { finish(ST_BAD_DIST); return; }
+    cp_base = outn;
+    cp_dist = dist;
+    cp_len = len;
+    cp_i = 0;
+    cp_o = 0;
+    state = LS_COPY;
+  }
+
+  // up to 16 elements of the match
+  MGI_HD void copy() {
+    const uint32_t left = cp_len - cp_i, n = left < 16u ? left : 16u;
+    room(n);
+    if (!count_only) {
+      const int64_t q0 = (int64_t)cp_base - (int64_t)cp_dist + (int64_t)cp_i;
+      OutT* dst = out + cp_base + cp_i;
+      if (cp_dist >= 16 && q0 >= 0 && outn + 16 <= job.out_cap) {
+        // sixteen elements as ONE wide access each way (a lane's accesses are its own cache lines: sixteen narrow ones per lane were a
+        // thousand requests per round and wavefront, and the round waited for them).  The source lies at least 16 elements back, so it
+        // is complete — written by earlier rounds where the match overlaps itself; what is stored beyond the n elements is overwritten
+        // by what the job produces next (or lies behind its end, inside its own reservation).
+        OutT t[16];
+        __builtin_memcpy(t, out + q0, sizeof(t));
+        __builtin_memcpy(dst, t, sizeof(t));
+        cp_o += n;
+        if (cp_o >= cp_dist) cp_o -= cp_dist;
+      } else if (cp_dist == 1 && cp_base >= 1 && outn + 16 <= job.out_cap) {  // a run of one element
+        const OutT x = out[cp_base - 1];
+        OutT t[16];
+        MGI_UNROLL
+        for (uint32_t i = 0; i < 16; ++i) t[i] = x;
+        __builtin_memcpy(dst, t, sizeof(t));
+      } else {
+        uint32_t v[16];
+        uint32_t o = cp_o;
+        MGI_UNROLL
+        for (uint32_t i = 0; i < 16; ++i) {
+          if (i < n) {
+            const int64_t q = (int64_t)cp_base - (int64_t)cp_dist + (int64_t)o;
+            v[i] = q >= 0 ? (uint32_t)out[q] : (0x8000u | (uint32_t)(q + (int64_t)kWindow));
+            ++o;
+            if (o == cp_dist) o = 0;  // (an overlapping match repeats its first dist elements: they were there before it began)
+          }
+        }
+        MGI_UNROLL
+        for (uint32_t i = 0; i < 16; ++i)
+          if (i < n) dst[i] = (OutT)v[i];
+        cp_o = o;
+      }
+    }
+    cp_i += n;
+    outn = cp_base + cp_i;
+    if (cp_i == cp_len) state = LS_SYM;
+  }
+
+  MGI_HD void stored() {
+    const uint32_t n = st_left < 16u ? st_left : 16u;
+    room(n);
+    if (!count_only)
+      for (uint32_t i = 0; i < n; ++i) out[outn + i] = (OutT)in_byte<false>(in, st_pos + i);
+    outn += n;
+    st_pos += n;
+    st_left -= n;
+    if (st_left == 0) {
+      br.init(in, (nbytes + 3) / 4, st_pos * 8);
+      end_of_block();
+    }
+  }
+
+  MGI_HD void round() {
+    ++rounds;
+    if (state == LS_BLOCK) block();
+    if (state == LS_MEMBER) member();
+    if (state == LS_STORED) stored();
+    if (state == LS_SYM) symbol();
+    if (state == LS_COPY) copy();
+  }
+
+  MGI_HD void result(Result* res) const {
+    res->end_bit = br.pos();
+    res->out_count = outn;
+    res->status = status;
+    res->overflow = overflow;
+    res->crc = crc;
+    res->isize = isize;
+    res->nblocks = nblocks;
+    res->nevents = nev;
+    res->t_tab = res->t_dec = res->t_emit = res->t_tail = 0;
+    res->nbatch = 0;
+    res->nstep = rounds;
+    for (int i = 0; i < 6; ++i) res->t_sub[i] = 0;
+  }
+};
 
 // ---- block-start finder ----
 // Could a dynamic-Huffman block with BFINAL = 0 begin at bit p?  The cheap part, per lane: header fields in range and the

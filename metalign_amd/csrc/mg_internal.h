@@ -42,6 +42,9 @@ struct Context {
   // optional stream for stage A (mg_stage_a_side_stream): the heavy sketch pipeline of the NEXT batch then runs
   // while the current batch's stage B / exchange / read-backs proceed on the main stream
   hipStream_t stream_a = nullptr, stream_a2 = nullptr;  // two, so that consecutive batches' stage A can overlap
+  // the device inflater's stream (mg_inflate.hip): a stage of a .gz file decodes while the previous stage's text is parsed and hashed
+  hipStream_t stream_inf = nullptr;
+  bool inf_side = false;
   int a_side = 0;                                        // 0 off, 1 / 2 = which of them the next sketch goes to
   unsigned a_side_wg_per_cu = 2;                         // k_sketch_reads workgroups per CU on those streams (0 = LDS limit)
   bool is_stage_a(hipStream_t st) const { return st && (st == stream_a || st == stream_a2); }

@@ -85,6 +85,25 @@ static Result whole(const std::string& gz, std::string* out, std::vector<Event>*
   std::vector<Event> events(64);
   uint32_t nev = 0;
   run_job<HostExec, uint8_t>(ex, g_sh, in.w.data(), in.nbytes, final_input, job, 0, buf.data(), &res, events.data(), &nev, (uint32_t)events.size());
+  {  // the same job by the one-job-per-lane decoder: the same result, the same bytes, the same member ends
+    static LaneMem lmem;
+    static LaneScratch lscr;
+    std::vector<uint8_t> buf2(buf.size());
+    std::vector<Event> ev2(64);
+    uint32_t nev2 = 0;
+    LaneDec<uint8_t> d;
+    d.init(in.w.data(), in.nbytes, final_input, job, 0, buf2.data(), &lmem, &lscr, ev2.data(), &nev2, (uint32_t)ev2.size());
+    while (d.state != LS_DONE) d.round();
+    Result r2;
+    d.result(&r2);
+    CHECK(r2.status == res.status && (res.status >= ST_ERR || (r2.out_count == res.out_count && r2.overflow == res.overflow && r2.end_bit == res.end_bit &&
+                                                                   r2.crc == res.crc && r2.isize == res.isize && nev2 == nev)),
+          "the lane decoder: status %u/%u count %llu/%llu overflow %u/%u end %llu/%llu events %u/%u", r2.status, res.status, (unsigned long long)r2.out_count,
+          (unsigned long long)res.out_count, r2.overflow, res.overflow, (unsigned long long)r2.end_bit, (unsigned long long)res.end_bit, nev2, nev);
+    if (!res.overflow && !(flags & F_COUNT_ONLY) && res.status < ST_ERR) CHECK(memcmp(buf.data(), buf2.data(), (size_t)res.out_count) == 0, "the lane decoder: bytes");
+    for (uint32_t i = 0; res.status < ST_ERR && i < nev && i < 64; ++i)
+      CHECK(ev2[i].out_pos == events[i].out_pos && ev2[i].crc == events[i].crc && ev2[i].isize == events[i].isize, "the lane decoder: member end %u", i);
+  }
   if (out) out->assign((const char*)buf.data(), (size_t)(res.overflow ? 0 : res.out_count));
   if (evs) evs->assign(events.begin(), events.begin() + (nev < events.size() ? nev : events.size()));
   return res;
@@ -163,6 +182,16 @@ static int check_entered(const char* what, const std::string& text, const std::s
     alignas(16) static uint16_t tail[32768];
     run_job<HostExec, uint16_t>(ex, g_sh, in.w.data(), in.nbytes, true, job, 0, sym.data(), &res, events.data(), &nev, 8, tail);
     CHECK(res.status == ST_END, "%s: entered job status %u", what, res.status);
+    {  // ... and by the lane decoder
+      static LaneMem lmem;
+      static LaneScratch lscr;
+      std::vector<uint16_t> sym2(sym.size());
+      LaneDec<uint16_t> d;
+      uint32_t nev2 = 0;
+      d.init(in.w.data(), in.nbytes, true, job, 0, sym2.data(), &lmem, &lscr, events.data(), &nev2, 8);
+      while (d.state != LS_DONE) d.round();
+      CHECK(d.status == res.status && d.outn == res.out_count && memcmp(sym.data(), sym2.data(), (size_t)res.out_count * 2) == 0, "%s: the lane decoder's symbols", what);
+    }
     for (uint32_t w = 0; w < 32768; ++w) {  // the window behind the job, as the job knows it
       const uint64_t n = res.out_count;
       const uint16_t want = n >= 32768 ? sym[n - 32768 + w] : (w < 32768 - n ? (uint16_t)(0x8000 | (w + n)) : sym[w - (32768 - n)]);
