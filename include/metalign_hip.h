@@ -68,6 +68,16 @@ typedef struct mg_aln_rec {
  * ------------------------------------------------------------------------ */
 int mg_abi_version(void);
 int mg_device_count(void);
+/* Test and diagnostic knobs.  The library reads NO environment variable: what rounds 1-4 steered through MG_DEBUG_* / MG_STREAM_* /
+ * MG_PGZIP_* variables is set here (key = the variable's name without its prefix, lower case; value 0 = off / the default).
+ * key = NULL: every knob back to its default.  Keys: k3_hashed, k3_flush_tiles, k3_grid (stage C: hashed bins on a small taxonomy,
+ * flush interval, grid size), lds_pad, force_list, distinct_hint_ppm (stage A's distinct-count estimate as parts per million of the
+ * expected candidates: forces table overflows), resident_scan, no_fused, resident_ablate, flush_order (1: filter words first, 2: slots
+ * first), no_avx2, gzip_threads, pgzip_chunk, pgzip_thp, pgzip_timing (the host inflater), stream_thin, stream_threads (the file
+ * readers).  Needs no device and no mg_init.  MG_ERR_ARG for a key that does not exist. */
+int mg_debug_set(const char* key, int64_t value);
+int64_t mg_debug_get(const char* key);
+
 /* Binds the calling process to `device` and creates the library stream. */
 int mg_init(int device);
 /* As mg_init, but launches on a caller-owned hipStream_t, so that the library's kernels are ordered with the
@@ -396,7 +406,7 @@ void mg_inflated_free(mg_inflated* t);
 int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int on, int64_t lane_jobs);
 int mg_inflate_stats(mg_inflate_counters* out, int reset);
 
-/* Diagnostic, host code only.  With MG_STREAM_THIN=1 in the environment mg_sketch_stream_add_file / mg_sam_stream_file THIN a
+/* Diagnostic, host code only.  With the knob stream_thin set (mg_debug_set) mg_sketch_stream_add_file / mg_sam_stream_file THIN a
  * plain FASTQ / SAM file in their reader threads to what the device parsers read (a FASTQ record -> ">", its sequence line; a SAM
  * line with its SEQ field replaced by a mark + len(SEQ) and its QUAL by '*': from the page cache both files go up at the PCIe
  * link's rate, and half / two thirds of their bytes are never looked at on the device).  Off by default: as built the readers'

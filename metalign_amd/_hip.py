@@ -23,7 +23,7 @@ MAX_K = 64
 
 # every symbol include/metalign_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mg_abi_version", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
+    "mg_abi_version", "mg_debug_set", "mg_debug_get", "mg_device_count", "mg_init", "mg_init_on_stream", "mg_shutdown", "mg_last_error",
     "mg_device_name", "mg_mem_info", "mg_mem_trim", "mg_dev_malloc", "mg_dev_free", "mg_memcpy_h2d", "mg_memcpy_d2h", "mg_dev_memset", "mg_sync",
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
@@ -97,6 +97,7 @@ def load_library(path=LIB_PATH):
     lib.mg_db_free.restype = None
     lib.mg_refdb_free.restype = None
     lib.mg_gunzip_close.restype = None
+    lib.mg_debug_get.restype = ctypes.c_int64
     lib.mg_inflated_bytes.restype = ctypes.c_uint64
     lib.mg_inflated_free.restype = None
     lib.mg_refdb_kmax_table.restype = ctypes.c_void_p
@@ -110,6 +111,24 @@ def load_library(path=LIB_PATH):
 _READS_FORMAT = {"fastq": 0, "fasta": 1, "fasta_ml": 2}
 
 _host_lib = None
+
+
+def debug_set(key=None, value=0):
+    """mg_debug_set: a test / diagnostic knob of the library (include/metalign_hip.h lists them); key = None: all back to their
+    defaults.  The library reads no environment variable.  Needs no device."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    rc = _host_lib.mg_debug_set(key.encode() if key is not None else None, ctypes.c_int64(int(value)))
+    if rc != 0:
+        raise HipError("libmetalign_hip rc=%d: %s" % (rc, _host_lib.mg_last_error().decode("utf-8", "replace")), rc)
+
+
+def debug_get(key):
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    return int(_host_lib.mg_debug_get(key.encode()))
 
 
 def multimapped_shares(mm_offsets, mm_tax, mm_hitlen, weight, genome_len=None):

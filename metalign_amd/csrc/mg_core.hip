@@ -20,6 +20,21 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- test / diagnostic knobs ----
+static const char* const kDebugKeys[] = {
+    "k3_hashed", "k3_flush_tiles", "k3_grid", "lds_pad", "force_list", "distinct_hint_ppm", "resident_scan", "no_fused", "resident_ablate",
+    "flush_order", "no_avx2", "gzip_threads", "pgzip_chunk", "pgzip_thp", "pgzip_timing", "stream_thin", "stream_threads"};
+static int64_t g_debug[sizeof(kDebugKeys) / sizeof(kDebugKeys[0])] = {};
+static int debug_index(const char* key) {
+  for (size_t i = 0; i < sizeof(kDebugKeys) / sizeof(kDebugKeys[0]); ++i)
+    if (strcmp(kDebugKeys[i], key) == 0) return (int)i;
+  return -1;
+}
+int64_t dbg(const char* key) {
+  const int i = debug_index(key);
+  return i < 0 ? 0 : g_debug[i];
+}
+
 static uint64_t size_class(uint64_t n) {
   if (n < 256) return 256;
   // classes: powers of two and the midpoints between them (<= 33 % slack)
@@ -214,6 +229,19 @@ using mg::fail;
 extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+int mg_debug_set(const char* key, int64_t value) {
+  if (!key) {  // every knob back to "never set"
+    memset(mg::g_debug, 0, sizeof(mg::g_debug));
+    return MG_OK;
+  }
+  const int i = mg::debug_index(key);
+  if (i < 0) return fail(MG_ERR_ARG, "mg_debug_set: no knob named %s", key);
+  mg::g_debug[i] = value;
+  return MG_OK;
+}
+
+int64_t mg_debug_get(const char* key) { return key ? mg::dbg(key) : 0; }
 
 int mg_device_count(void) {
   int n = 0;

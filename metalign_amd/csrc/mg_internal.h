@@ -89,11 +89,13 @@ struct Context {
 
 Context& ctx();
 int fail(int code, const char* fmt, ...);
+// A test / diagnostic knob (mg_debug_set; include/metalign_hip.h lists them): 0 when it was never set.  The library reads no
+// environment variable.
+int64_t dbg(const char* key);
 
 // The stage-A kernels' cs word (mg_sketch_dev.h: kCsMask): count saturation + the tests' flush-order pin.
 inline uint32_t stage_a_cs_word() {
-  uint32_t order = 0;
-  if (const char* e = getenv("MG_DEBUG_FLUSH_ORDER")) order = e[0] == 'f' ? 1u : (e[0] == 's' ? 2u : 0u);
+  const uint32_t order = (uint32_t)dbg("flush_order") & 3u;  // 1: filter words first, 2: slots first (the tests pin either)
   return ctx().count_sat | (order << 30);
 }
 

@@ -231,7 +231,7 @@ struct PGzip::Chunk {
       if (!q) return false;
       // (MADV_HUGEPAGE was tried: where huge pages are not to be had — this container — every fault pays a failed compaction,
       // 0.9 s instead of 0.28 s for 130 MB on first use; opt-in)
-      static const bool thp = getenv("MG_PGZIP_THP") != nullptr;
+      const bool thp = mg::dbg("pgzip_thp") != 0;
       if (thp) (void)madvise(q, bytes, MADV_HUGEPAGE);
       if (n) memcpy(q, p, n * sizeof(T));
       free(p);
@@ -263,9 +263,13 @@ namespace {
 bool skip_gzip_header(Bits& b, bool* trunc) {
   *trunc = false;
   const uint64_t byte = b.pos >> 3, nbytes = b.nbits >> 3;
-  if (byte + 10 > nbytes) { *trunc = byte < nbytes; return false; }
   const uint8_t* h = b.p + byte;
-  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8) return false;
+  // what there is of the first three bytes decides: anything that is not the start of a member is trailing garbage (1 to 9 bytes of
+  // padding after the last member are as good as 4000: gzip / zcat ignore them); a member's start that is cut short is a truncated file
+  static const uint8_t magic[3] = {0x1f, 0x8b, 8};
+  for (uint64_t i = 0; i < 3 && byte + i < nbytes; ++i)
+    if (h[i] != magic[i]) return false;
+  if (byte + 10 > nbytes) { *trunc = byte < nbytes; return false; }
   const uint8_t flg = h[3];
   uint64_t at = byte + 10;
   if (flg & 4) { if (at + 2 > nbytes) { *trunc = true; return false; } at += 2 + (uint64_t)(b.p[at] | (b.p[at + 1] << 8)); }
@@ -609,7 +613,7 @@ void PGzip::run() {
   const uint64_t nbytes = size_;
   if (nbytes == 0) { std::lock_guard<std::mutex> lk(m_); done_ = true; cv_data_.notify_all(); return; }
   const uint64_t per_batch = (uint64_t)nthreads_ * 2;
-  const bool timing = getenv("MG_PGZIP_TIMING") != nullptr;
+  const bool timing = mg::dbg("pgzip_timing") != 0;
   double t_find = 0, t_dec = 0, t_chain = 0, t_res = 0, t_wait = 0;
   uint64_t n_used = 0, n_all = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -795,7 +799,7 @@ int mg_gunzip_open(const char* path, int nthreads, mg_gunzip** out) {
   if (nthreads <= 0) { unsigned hw = std::thread::hardware_concurrency(); nthreads = (int)(hw == 0 ? 4 : (hw > 64 ? 64 : hw)); }
   std::string err;
   uint64_t chunk = 1ull << 20;
-  if (const char* e = getenv("MG_PGZIP_CHUNK")) { const long long v = atoll(e); if (v > 0) chunk = (uint64_t)v; }
+  if (mg::dbg("pgzip_chunk") > 0) chunk = (uint64_t)mg::dbg("pgzip_chunk");
   std::unique_ptr<mg::PGzip> g = mg::PGzip::open(fd, true, (uint64_t)sb.st_size, nthreads, chunk, &err);
   if (!g) { close(fd); return mg::fail(MG_ERR_ARG, "%s: %s", path, err.c_str()); }
   *out = new mg_gunzip{std::move(g)};
@@ -889,48 +893,68 @@ int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_pat
   if ((uint64_t)nthreads > nfiles) nthreads = nfiles ? (int)nfiles : 1;
   const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
   if (fd < 0) return mg::fail(MG_ERR_ARG, "cannot open %s: %s", out_path, strerror(errno));
-  std::vector<std::string> text(nfiles), why(nfiles);
+  // In WINDOWS of files whose text is about a gigabyte (estimated from their sizes): inflated by all threads, written at their
+  // offsets, released — a selection of thousands of genomes does not sit in host memory whole (the reference streams one zcat per
+  // genome into the append handle, scripts/select_db.py:99-105).  Order and bytes are those of one pass.
+  std::vector<std::string> why(nfiles);
   std::vector<uint8_t> bad(nfiles, 0);
-  std::atomic<uint64_t> next{0};
-  auto inflate_some = [&]() {
-    for (;;) {
-      const uint64_t i = next.fetch_add(1);
-      if (i >= nfiles) return;
-      bad[i] = zcat_one(paths[i], &text[i], &why[i]) ? 0 : 1;
-    }
-  };
-  {
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(inflate_some);
-    inflate_some();
-    for (auto& t : th) t.join();
-  }
-  std::vector<uint64_t> at(nfiles + 1, 0);
-  for (uint64_t i = 0; i < nfiles; ++i) at[i + 1] = at[i] + text[i].size();
-  for (uint64_t i = 0; i < nfiles; ++i)
-    if (bad[i]) fprintf(stderr, "zcat: %s: %s\n", paths[i], why[i].c_str());  // (as zcat: a line on stderr, and on with the rest)
   std::atomic<bool> werr{false};
-  next.store(0);
-  auto write_some = [&]() {
-    for (;;) {
-      const uint64_t i = next.fetch_add(1);
-      if (i >= nfiles) return;
-      size_t done = 0;
-      while (done < text[i].size()) {
-        const ssize_t w = pwrite(fd, text[i].data() + done, text[i].size() - done, (off_t)(at[i] + done));
-        if (w < 0 && errno == EINTR) continue;
-        if (w <= 0) { werr.store(true); return; }
-        done += (size_t)w;
-      }
+  uint64_t base = 0;
+  const uint64_t budget = 1ull << 30;
+  for (uint64_t w0 = 0; w0 < nfiles && !werr.load();) {
+    uint64_t w1 = w0, est = 0;
+    while (w1 < nfiles) {
+      struct stat sb;
+      const uint64_t sz = stat(paths[w1], &sb) == 0 ? (uint64_t)sb.st_size : 0;
+      if (w1 > w0 && est + 5 * sz > budget) break;
+      est += 5 * sz;
+      ++w1;
     }
-  };
-  {
-    std::vector<std::thread> th;
-    const int wt = nthreads > 8 ? 8 : nthreads;
-    for (int t = 1; t < wt; ++t) th.emplace_back(write_some);
-    write_some();
-    for (auto& t : th) t.join();
+    const uint64_t nw = w1 - w0;
+    std::vector<std::string> text(nw);
+    std::atomic<uint64_t> next{0};
+    auto inflate_some = [&]() {
+      for (;;) {
+        const uint64_t i = next.fetch_add(1);
+        if (i >= nw) return;
+        bad[w0 + i] = zcat_one(paths[w0 + i], &text[i], &why[w0 + i]) ? 0 : 1;
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthreads && (uint64_t)t < nw; ++t) th.emplace_back(inflate_some);
+      inflate_some();
+      for (auto& t : th) t.join();
+    }
+    std::vector<uint64_t> at(nw + 1, base);
+    for (uint64_t i = 0; i < nw; ++i) at[i + 1] = at[i] + text[i].size();
+    for (uint64_t i = 0; i < nw; ++i)
+      if (bad[w0 + i]) fprintf(stderr, "zcat: %s: %s\n", paths[w0 + i], why[w0 + i].c_str());  // (as zcat: a line on stderr, and on with the rest)
+    next.store(0);
+    auto write_some = [&]() {
+      for (;;) {
+        const uint64_t i = next.fetch_add(1);
+        if (i >= nw) return;
+        size_t done = 0;
+        while (done < text[i].size()) {
+          const ssize_t w = pwrite(fd, text[i].data() + done, text[i].size() - done, (off_t)(at[i] + done));
+          if (w < 0 && errno == EINTR) continue;
+          if (w <= 0) { werr.store(true); return; }
+          done += (size_t)w;
+        }
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      const int wt = nthreads > 8 ? 8 : nthreads;
+      for (int t = 1; t < wt && (uint64_t)t < nw; ++t) th.emplace_back(write_some);
+      write_some();
+      for (auto& t : th) t.join();
+    }
+    base = at[nw];
+    w0 = w1;
   }
+  std::vector<uint64_t> at(nfiles + 1, base);
   const int cerr = close(fd);
   if (werr.load() || cerr != 0) return mg::fail(MG_ERR_ARG, "writing %s failed: %s", out_path, strerror(errno));
   if (bytes_out) *bytes_out = at[nfiles];

@@ -484,11 +484,20 @@ __device__ __forceinline__ uint32_t xcc_id() {
   return v & 7u;
 }
 constexpr uint32_t kXcds = 8;
+// ASSUMPTION, by architecture: on gfx942 / gfx950 a global atomic below device scope is executed in the L2 of the XCD the wavefront
+// runs on, so workgroups of ONE XCD that update the same word of that XCD's copy see each other's updates although the scope says
+// "workgroup" (under the HIP memory model alone that sharing would be a race); the kernel's end writes the L2 back and the next kernel
+// sums the eight copies.  Any other part gets the agent-scope atomic (correct anywhere, resolved at the memory side).
+#if defined(__gfx942__) || defined(__gfx950__)
+#define MG_L2_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#else
+#define MG_L2_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 __device__ __forceinline__ void l2_add64(unsigned long long* p, unsigned long long v) {
-  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, MG_L2_SCOPE);
 }
 __device__ __forceinline__ void l2_min64(unsigned long long* p, unsigned long long v) {
-  (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, MG_L2_SCOPE);
 }
 
 struct PassArgs {
@@ -1223,7 +1232,7 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
     return MG_OK;
   }
   a.use_lds_hist = p->nrecs >= 0xffffffffull ? 0u : p->ntax <= 4096 ? 1u : p->ntax <= kHashMaxTax ? 2u : 0u;
-  if (a.use_lds_hist == 1 && getenv("MG_DEBUG_K3_HASHED")) a.use_lds_hist = 2;  // tests: the hashed bins on a small taxonomy
+  if (a.use_lds_hist == 1 && dbg("k3_hashed")) a.use_lds_hist = 2;  // tests: the hashed bins on a small taxonomy
   const size_t lds = a.use_lds_hist == 0 ? 0
                    : a.use_lds_hist == 1 ? (size_t)p->ntax * (sizeof(unsigned long long) + sizeof(uint32_t))
                                          : kHashSlots * (sizeof(unsigned long long) + sizeof(uint32_t));
@@ -1237,8 +1246,8 @@ int launch_pass(mg_profile* p, bool commit, uint32_t incoming, uint32_t first_sh
   unsigned grid = grid_for(p->ntiles, 1, (unsigned)c.num_cus * per_cu);
   a.flush_tiles = a.use_lds_hist == 2 ? kHashFlushTiles : kFlushTiles;
   // test hooks: a workgroup at this size lives for ~8 tiles and never reaches a mid-life flush — fewer workgroups, shorter intervals
-  if (const char* e = getenv("MG_DEBUG_K3_FLUSH_TILES")) { const int v = atoi(e); if (v > 0 && (uint32_t)v < a.flush_tiles) a.flush_tiles = (uint32_t)v; }
-  if (const char* e = getenv("MG_DEBUG_K3_GRID")) { const int v = atoi(e); if (v > 0 && (unsigned)v < grid) grid = (unsigned)v; }
+  { const int64_t v = dbg("k3_flush_tiles"); if (v > 0 && (uint64_t)v < a.flush_tiles) a.flush_tiles = (uint32_t)v; }
+  { const int64_t v = dbg("k3_grid"); if (v > 0 && (uint64_t)v < grid) grid = (unsigned)v; }
   if (grid < a.ticket_lanes) a.ticket_lanes = grid;
   if (a.use_lds_hist == 2) {
     // the private overflow bins: a grow-only buffer of the library, all-zero (first-seen words all-ones) between passes —

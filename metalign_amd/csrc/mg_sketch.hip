@@ -490,7 +490,7 @@ static int launch_sketch_reads(const uint8_t* d_bases, const uint64_t* d_offsets
                                uint32_t epoch = 0) {
   Context& c = ctx();
   size_t lds = (size_t)kWavesPerBlock * (stage_bytes + kCandBuf * sizeof(uint64_t));
-  if (const char* pad = getenv("MG_DEBUG_LDS_PAD")) lds += (size_t)atol(pad);  // occupancy experiments only
+  if (dbg("lds_pad") > 0) lds += (size_t)dbg("lds_pad");  // occupancy experiments only
   const uint64_t ntiles = (nreads + 63) / 64;
   // enough resident blocks to fill every CU at the LDS-limited occupancy, grid-stride over the rest
   unsigned per_cu = (unsigned)(160 * 1024 / (lds + kHashTabEntries * sizeof(uint64_t)));  // (+ the static hash tables)
@@ -607,7 +607,7 @@ static int table_pack(const TablePlan& tp, mg_sketch* sk, uint64_t* d_meta, uint
     MG_HIP(hipGetLastError());
     return MG_OK;
   }
-  if (tp.epoch) {  // (MG_DEBUG_RESIDENT_SCAN: the same sketch from a walk over every slot of the index)
+  if (tp.epoch) {  // (knob resident_scan: the same sketch from a walk over every slot of the index)
     const unsigned grid = grid_for(tp.nbuckets, 4, (unsigned)c.num_cus * 8);
     MG_TRY(sk->hashes.alloc((cap + 1) * sizeof(uint64_t)));
     MG_TRY(sk->counts.alloc((cap + 1) * sizeof(uint32_t)));
@@ -868,9 +868,9 @@ static void plan_k(const ReadPlan& rp, int k, uint64_t hmax, KPlan& kp) {
   // Sized from the expected number of DISTINCT candidates: `expect` bounds it; the ratio observed on the
   // previous call of the same k (x kHintSafety) tightens it for steady-state batches.  Under-sizing is detected (a
   // bucket with no free slot) and handled by the list path.
-  const bool force_list = getenv("MG_DEBUG_FORCE_LIST") != nullptr;
+  const bool force_list = dbg("force_list") != 0;
   kp.distinct_est = (double)kp.expect * mg::distinct_hint_for(k);
-  if (const char* e = getenv("MG_DEBUG_DISTINCT_HINT")) kp.distinct_est = (double)kp.expect * atof(e);  // tests: force overflow
+  if (dbg("distinct_hint_ppm") > 0) kp.distinct_est = (double)kp.expect * (double)dbg("distinct_hint_ppm") * 1e-6;  // tests: force overflow
   kp.table = !force_list && kp.expect >= 32768 && plan_table(0, hmax, kp.distinct_est, kp.tp);
 }
 
@@ -916,9 +916,9 @@ static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t
   // the sketch cannot hold a hash the index does not; fewer when the previous sketch of this k held fewer (an estimate: a
   // list or a sketch too small is reported like a table overflow, and the sketch made again with room for every hash)
   kp.distinct_est = (double)kp.expect * mg::distinct_hint_for(k);
-  if (full || kp.distinct_est > (double)R.distinct || getenv("MG_DEBUG_RESIDENT_SCAN")) kp.distinct_est = (double)R.distinct;
-  const char* tight = full ? nullptr : getenv("MG_DEBUG_DISTINCT_HINT");  // tests: force the overflow
-  if (tight) kp.distinct_est = (double)kp.expect * atof(tight);
+  if (full || kp.distinct_est > (double)R.distinct || dbg("resident_scan")) kp.distinct_est = (double)R.distinct;
+  const double tight = full ? 0.0 : (double)dbg("distinct_hint_ppm") * 1e-6;  // tests: force the overflow
+  if (tight > 0.0) kp.distinct_est = (double)kp.expect * tight;
   kp.table = true;
   kp.tp.lo = 0;
   kp.tp.shift = R.shift;
@@ -931,10 +931,10 @@ static int plan_resident(const mg_filter* f, const ReadPlan& rp, int k, uint64_t
   *t_counters = (unsigned long long*)scratch(name, 4 * sizeof(unsigned long long));
   if (!*t_counters) return MG_ERR_NOMEM;
   MG_HIP(hipMemsetAsync(*t_counters, 0, 4 * sizeof(unsigned long long), st));
-  if (!getenv("MG_DEBUG_RESIDENT_SCAN")) {
+  if (!dbg("resident_scan")) {
     // room for the estimate, the few hashes two lanes list, and a last chunk per wavefront of the largest grid
     kp.tp.listcap = (uint64_t)kp.distinct_est + (uint64_t)kp.distinct_est / 16 + (uint64_t)c.num_cus * 8 * kWavesPerBlock * kListChunk + 4096;
-    if (tight) kp.tp.listcap = (uint64_t)kp.distinct_est + 16 * kListChunk;  // (tests: ... of the list too)
+    if (tight > 0.0) kp.tp.listcap = (uint64_t)kp.distinct_est + 16 * kListChunk;  // (tests: ... of the list too)
     snprintf(name, sizeof(name), "sk_rlist#%d", ki);
     kp.tp.list = (uint32_t*)scratch(name, kp.tp.listcap * sizeof(uint32_t));
     if (!kp.tp.list) return MG_ERR_NOMEM;
@@ -1073,7 +1073,7 @@ static int sketch_reads_multi_async(const uint8_t* d_bases, const uint64_t* d_of
     }
     return MG_OK;
   };
-  if (nreads == 0 || nk == 1 || nk > 4 || !sketch_reads_multi_supported(ks, nk) || getenv("MG_DEBUG_NO_FUSED")) return per_k();
+  if (nreads == 0 || nk == 1 || nk > 4 || !sketch_reads_multi_supported(ks, nk) || dbg("no_fused")) return per_k();
   if (!d_bases || !d_offsets) return fail(MG_ERR_ARG, "null device input");
   Context& c = ctx();
   hipStream_t side = c.a_side == 2 ? c.stream_a2 : c.stream_a;
@@ -1182,7 +1182,7 @@ static int stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s
     ProfScope ps("table_clear");
     MG_HIP(hipMemsetAsync(ss->tab[i].p, 0, tab_bytes + 4 * sizeof(unsigned long long), st));
   }
-  ss->fused = nk > 1 && sketch_reads_multi_supported(ss->ks, nk) && !getenv("MG_DEBUG_NO_FUSED");
+  ss->fused = nk > 1 && sketch_reads_multi_supported(ss->ks, nk) && !dbg("no_fused");
   *out = ss.release();
   return MG_OK;
 }
@@ -1455,7 +1455,7 @@ int mg_sketch_merge_dev(const uint64_t* d_hashes, const uint32_t* d_counts, uint
   std::unique_ptr<mg_sketch> sk(new mg_sketch());
   hipStream_t st = ctx().stream;
   TablePlan tp;
-  if (n >= 32768 && range_hi >= range_lo && !getenv("MG_DEBUG_FORCE_LIST") && plan_table(range_lo, range_hi, (double)n, tp)) {
+  if (n >= 32768 && range_hi >= range_lo && !dbg("force_list") && plan_table(range_lo, range_hi, (double)n, tp)) {
     unsigned long long* d_counters = (unsigned long long*)scratch("mp_meta", 8 * sizeof(uint64_t));
     if (!d_counters) return MG_ERR_NOMEM;
     uint64_t* d_meta = reinterpret_cast<uint64_t*>(d_counters) + 4;
@@ -1491,7 +1491,7 @@ int mg_sketch_merge_dev_async(const uint64_t* d_hashes, const uint32_t* d_counts
   *out = nullptr;
   if (n > 0 && (!d_hashes || !d_counts)) return fail(MG_ERR_ARG, "null device input");
   TablePlan tp;
-  if (!(n >= 32768 && range_hi >= range_lo && !getenv("MG_DEBUG_FORCE_LIST") && plan_table(range_lo, range_hi, (double)n, tp)))
+  if (!(n >= 32768 && range_hi >= range_lo && !dbg("force_list") && plan_table(range_lo, range_hi, (double)n, tp)))
     return mg_sketch_merge_dev(d_hashes, d_counts, n, range_lo, range_hi, s, any_truncated, bound, out);
   std::unique_ptr<mg_sketch> sk(new mg_sketch());
   Context& cc = ctx();

@@ -32,7 +32,7 @@ struct MultiArgs {
   uint32_t* list[kMaxMultiK];            // resident indexes: the list of slots the pass has touched in index i (or null)
   uint64_t listcap[kMaxMultiK];
   uint32_t epoch;  // != 0: the tables are resident indexes (mg_sketch_dev.h: resident_count) and this the pass's epoch
-  uint32_t ablate; // resident kernel only, MG_DEBUG_RESIDENT_ABLATE (tools/k1_probe.py): 1 = a flush drops its candidates (what the kernel costs without any look-up)
+  uint32_t ablate; // resident kernel only, knob resident_ablate (tools/k1_probe.py): 1 = a flush drops its candidates (what the kernel costs without any look-up)
 };
 
 // Wave-level candidate sink shared by all k: (hash, k index) pairs staged in LDS, flushed into the per-k tables.
@@ -461,7 +461,7 @@ int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, con
       a.list[i] = tabs[i].list; a.listcap[i] = tabs[i].listcap;
     }
   }
-  if (const char* e = getenv("MG_DEBUG_RESIDENT_ABLATE")) a.ablate = (uint32_t)atoi(e);
+  a.ablate = (uint32_t)dbg("resident_ablate");
   a.cs = stage_a_cs_word() & kCsMask;
   a.order = stage_a_cs_word() >> 30;
   if (nk == 3 && ks[0] == 21 && ks[1] == 31 && ks[2] == 51)

@@ -233,7 +233,7 @@ struct BgzfSource : Source {
 // A raw piece is read into the slot it will leave from, behind a little room, and thinned in place (the output never
 // overtakes the input: a FASTQ record shrinks, a SAM line grows by one byte only when SEQ and QUAL are one character
 // each); a reader owns the lines / records that START in its piece and reads on past its end to finish the last one.
-// OPT-IN (MG_STREAM_THIN=1), because it does not pay on the hosts it was measured on (profiles/r04/stream_ceilings.txt): the plain
+// OPT-IN (mg_debug_set("stream_thin", 1)), because it does not pay on the hosts it was measured on (profiles/r04/stream_ceilings.txt): the plain
 // streams run at ~50 GB/s of text, which is the PCIe link's rate AND about what these hosts read out of the page cache at all
 // (tools/pread_probe.py: 60 GB/s at four threads, less with more).  Thinning takes bytes off the link, not out of the page cache,
 // and adds work per byte: with the scanner below (newline / white-space positions 32 bytes per step; the first form, one memchr per
@@ -270,8 +270,8 @@ __attribute__((target("avx2"))) static inline uint32_t mask32_le(const uint8_t* 
   const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
   return (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_min_epu8(x, _mm256_set1_epi8((char)v)), x));
 }
-static bool host_has_avx2() {  // (MG_DEBUG_NO_AVX2=1: the byte-by-byte scanner, for the tests)
-  static const bool yes = __builtin_cpu_supports("avx2") && !(getenv("MG_DEBUG_NO_AVX2") && getenv("MG_DEBUG_NO_AVX2")[0] == '1');
+static bool host_has_avx2() {  // (knob no_avx2: the byte-by-byte scanner, for the tests)
+  static const bool yes = __builtin_cpu_supports("avx2") && !dbg("no_avx2");  // (read once per process)
   return yes;
 }
 #endif
@@ -754,13 +754,13 @@ static int open_source(const char* path, uint64_t offset, uint64_t length, uint6
     if (!*chunk_bytes) *chunk_bytes = 32ull << 20;
     unsigned hw = std::thread::hardware_concurrency();
     int threads = (int)(hw == 0 ? 4 : (hw > 64 ? 64 : hw));
-    if (const char* e = getenv("MG_GZIP_THREADS")) { const int v = atoi(e); if (v > 0) threads = v; }
+    if (dbg("gzip_threads") > 0) threads = (int)dbg("gzip_threads");
     if (threads > 1) {
-      // ... entered in the middle by every core the box has (MG_GZIP_THREADS=1: zlib, one thread, as rounds 2-3)
+      // ... entered in the middle by every core the box has (knob gzip_threads = 1: zlib, one thread, as rounds 2-3)
       std::string err;
       uint64_t pc = 1ull << 20;
       if (threads > 32) threads = 32;  // (two chunks per thread in flight, ~15 MB each inflated: a gigabyte of host memory at 32)
-      if (const char* e = getenv("MG_PGZIP_CHUNK")) { const long long v = atoll(e); if (v > 0) pc = (uint64_t)v; }
+      if (dbg("pgzip_chunk") > 0) pc = (uint64_t)dbg("pgzip_chunk");
       std::unique_ptr<ParallelGzipSource> pg(new ParallelGzipSource());
       pg->g = PGzip::open(fd, true, fsize, threads, pc, &err);
       if (!pg->g) { close(fd); return fail(MG_ERR_ARG, "%s: %s", path, err.c_str()); }
@@ -775,8 +775,7 @@ static int open_source(const char* path, uint64_t offset, uint64_t length, uint6
   if (offset > fsize) { close(fd); return fail(MG_ERR_ARG, "offset beyond the end of %s", path); }
   if (!*chunk_bytes) *chunk_bytes = 32ull << 20;
   if (thin_kind >= 0 && thinned && offset == 0 && length == 0) {
-    const char* e = getenv("MG_STREAM_THIN");
-    if (e && e[0] == '1') {  // opt-in: see the note at ThinSource
+    if (dbg("stream_thin")) {  // opt-in: see the note at ThinSource
       uint64_t cb = *chunk_bytes < (1u << 16) ? (1u << 16) : *chunk_bytes;  // (the pipeline's own rounding of the slot size)
       cb = (cb + 4095) & ~4095ull;
       std::unique_ptr<ThinSource> t(new ThinSource());
@@ -799,7 +798,7 @@ static int open_source(const char* path, uint64_t offset, uint64_t length, uint6
 // Thinning is host work per byte (a reader does ~4 GB/s of it against ~12 GB/s of plain reads): twice the readers, when the
 // box has them and nobody fixed the number.
 static int thin_threads(int n) {
-  if (getenv("MG_STREAM_THREADS")) return n;
+  if (dbg("stream_threads") > 0) return n;
   const unsigned hw = std::thread::hardware_concurrency();
   const int want = n * 2;
   return hw >= (unsigned)want * 2 ? want : n;
@@ -808,7 +807,7 @@ static int thin_threads(int n) {
 static int default_threads() {
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 4;
-  if (const char* e = getenv("MG_STREAM_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+  if (dbg("stream_threads") > 0) return (int)dbg("stream_threads");
   return (int)(hw > 8 ? 8 : hw);
 }
 
@@ -862,7 +861,7 @@ int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format
   if (nthreads <= 0) nthreads = default_threads();
   if (gz && src->parallel()) {  // BGZF: inflating is the work — every core the box has
     unsigned hw = std::thread::hardware_concurrency();
-    if (!getenv("MG_STREAM_THREADS") && hw > (unsigned)nthreads) nthreads = (int)(hw > 32 ? 32 : hw);
+    if (dbg("stream_threads") <= 0 && hw > (unsigned)nthreads) nthreads = (int)(hw > 32 ? 32 : hw);
   }
   if (thinned && auto_threads) nthreads = thin_threads(nthreads);
   const int dev_format = thinned ? 1 : format;  // (a thinned FASTQ piece is single-line FASTA: ">", the sequence line)

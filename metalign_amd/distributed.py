@@ -508,6 +508,10 @@ class HipEngine:
             sk.free()  # their buffers were the all-to-all's send buffers: back to the pool only now
         for ki, m in enumerate(merged):
             if m.resolve():
+                # (a reference-pipeline merge is settled in the phase that queues it — x_merge: its redo needs the prefix-bitmap collective on
+                # every rank — so a rebuilt sketch cannot turn up here; if it ever does, the columns below would be stale)
+                if self.reftable is not None:
+                    raise RuntimeError("a reference-pipeline sketch was rebuilt after its stage B had run: x_merge must settle it")
                 self.hip.sync()
                 self.hip.containment_dev(m, self.tables[ki], ci, *self._hs_ptrs(rs["h_hs"].ptr, ki))
                 self.hip.sync()

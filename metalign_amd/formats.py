@@ -147,21 +147,14 @@ class SketchTable:
             raise ValueError("sketch table %s, k = %d: genome id %d in a table of %d genomes" % (self.path, k, len(sl) - 1, self.ngenomes))
         return dict(pair_hash=ph[a:b], pair_gen=pg[a:b], gsize=sl, max_hash=mx)
 
-    def refpipe_arrays(self, rank=0, world=1, bounds=None):
+    def refpipe_arrays(self):
         """The reference pipeline's table (version 3) as Hip.refdb_upload takes it — dict(ks, ngenomes, pair_hash, pair_gen, gsize,
-        max_hash, small=[dict(pa, pb, cid, cgen, gsize, nprefix) per k below the largest]) — or rank `rank`'s share of it: the
-        pairs whose hash lies in [bounds[rank], bounds[rank + 1]) with their pa / pb, and of every count list the run whose
-        prefix numbers lie in [nprefix * rank / world, nprefix * (rank + 1) / world); gsize counted within the share.  Memory
-        maps: only the share is read."""
+        max_hash, small=[dict(pa, pb, cid, cgen, gsize, nprefix) per k below the largest]) — as memory maps.  A rank's share of it is
+        cut by distributed.ShardJob (pairs by hash range, count lists by prefix range on multiples of 32: mark_cuts)."""
         if not self.refpipe:
             raise ValueError("%s is not a reference-pipeline table" % self.path)
         kmax = self.ks[-1]
         ph, pg, gs = self._pair_maps(kmax)
-        a, b = 0, len(ph)
-        if world > 1:
-            a = int(np.searchsorted(ph, np.uint64(bounds[rank]), side="left"))
-            b = len(ph) if bounds[rank + 1] > 0xFFFFFFFFFFFFFFFF else int(np.searchsorted(ph, np.uint64(bounds[rank + 1]), side="left"))
-            gs = np.bincount(np.asarray(pg[a:b]), minlength=self.ngenomes).astype(np.uint32)
         small = []
         for k in self.ks[:-1]:
             npre = int(self.meta["nprefix"][str(k)])
@@ -175,13 +168,8 @@ class SketchTable:
             gk = np.fromfile(self._f(k, "gsize.u32"), dtype="<u4")
             if len(pa) != len(ph) or len(pb) != len(ph) or len(cid) != len(cgen) or len(gk) != self.ngenomes:
                 raise ValueError("sketch table %s, k = %d: the reference-pipeline files do not belong together" % (self.path, k))
-            ca, cb = 0, len(cid)
-            if world > 1:
-                ca = int(np.searchsorted(cid, npre * rank // world, side="left"))
-                cb = int(np.searchsorted(cid, npre * (rank + 1) // world, side="left"))
-                gk = np.bincount(np.asarray(cgen[ca:cb]), minlength=self.ngenomes).astype(np.uint32)
-            small.append(dict(pa=pa[a:b], pb=pb[a:b], cid=cid[ca:cb], cgen=cgen[ca:cb], gsize=gk, nprefix=npre))
-        return dict(ks=list(self.ks), ngenomes=self.ngenomes, pair_hash=ph[a:b], pair_gen=pg[a:b], gsize=gs,
+            small.append(dict(pa=pa, pb=pb, cid=cid, cgen=cgen, gsize=gk, nprefix=npre))
+        return dict(ks=list(self.ks), ngenomes=self.ngenomes, pair_hash=ph, pair_gen=pg, gsize=gs,
                     max_hash=self.max_hash(kmax), small=small)
 
     def filter_bits(self, k):

@@ -399,7 +399,16 @@ def expected_bases(path, kind):
     gzip: DNA text deflates about 4 x."""
     size = os.path.getsize(path)
     if path.endswith('.gz'):
-        size *= 4
+        guess = size * 4
+        try:  # a gzip member ends with the length of its text (mod 2^32): the whole text for a file of one member below 4 GB
+            with open(path, 'rb') as fh:
+                fh.seek(-4, os.SEEK_END)
+                isize = int.from_bytes(fh.read(4), 'little')
+            if size < isize < 64 * size:
+                guess = max(guess if isize < size * 2 else 0, isize)
+        except OSError:
+            pass
+        size = guess
     return int(size * (0.5 if kind == 'fastq' else 1.0)) + 1
 
 

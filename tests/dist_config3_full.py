@@ -6,7 +6,7 @@ the reference pipeline's all-to-all of prefix-bitmap words, THE all-reduce), fou
 
   * a >= 2M-read sample through ShardJob.step() against the C oracle on every host core: hits and sizes of ALL 200 000
     genomes for every k, every stage-C accumulator (bench.cpu_baseline_and_check with the job's collectives in the path);
-  * the same with every list / counting table undersized (MG_DEBUG_DISTINCT_HINT): overflow -> redo at this size;
+  * the same with every list / counting table undersized (the knob distinct_hint_ppm): overflow -> redo at this size;
   * the full workload: run(3) == step(), sketch sizes and stage-C totals as they must be.
 
     python tests/dist_config3_full.py [reference_pipeline|sketch_per_k] [hash mode] [sample reads] [overflow|plain]
@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 import bench  # noqa: E402
 import oracle  # noqa: E402
+from metalign_amd import _hip  # noqa: E402
 from metalign_amd._hip import Hip  # noqa: E402
 
 definition = sys.argv[1] if len(sys.argv) > 1 else "reference_pipeline"
@@ -50,17 +51,14 @@ report = {"definition": definition, "hash_mode": mode, "build_s": time.perf_coun
 min_sample = int(sys.argv[3]) if len(sys.argv) > 3 else 2_000_000
 args = argparse.Namespace(cpu_seconds=float(os.environ.get("MG_TEST_CPU_SECONDS", "6")), min_sample=min_sample)
 for hint in ((None, "0.002") if (len(sys.argv) <= 4 or sys.argv[4] == "overflow") else (None,)):
-    if hint is None:
-        os.environ.pop("MG_DEBUG_DISTINCT_HINT", None)
-    else:
-        os.environ["MG_DEBUG_DISTINCT_HINT"] = hint  # (lists, sketch buffers and counting tables too small: redo)
+    _hip.debug_set("distinct_hint_ppm", 0 if hint is None else int(float(hint) * 1e6))  # (lists, sketch buffers and counting tables too small: redo)
     t1 = time.perf_counter()
     base, check = bench.cpu_baseline_and_check(args, cfg, w, hip, dist=dist, force_dist=True)
     nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
     assert check["oracle_equal"], (hint, check["mismatch"])
     assert nsample >= min_sample, check["compared"]
     report["check_hint_%s" % hint] = {"sample_reads": nsample, "seconds": time.perf_counter() - t1, "cpu_reads_per_s": base["value"]}
-os.environ.pop("MG_DEBUG_DISTINCT_HINT", None)
+_hip.debug_set("distinct_hint_ppm", 0)
 # ---- the whole workload: the job the driver's N > 1 bench runs on a rank ----
 job = bench.make_job(hip, dist, 0, 1, cfg, w, force_dist=True)
 resident = sum(f.resident_bytes for f in job.engine.filters if f is not None)

@@ -17,8 +17,11 @@ import torch.distributed as dist  # noqa: E402
 import oracle  # noqa: E402
 import util  # noqa: E402
 from metalign_amd import synth  # noqa: E402
-from metalign_amd._hip import Hip  # noqa: E402
+from metalign_amd._hip import Hip, debug_set  # noqa: E402
 from metalign_amd.distributed import ShardJob  # noqa: E402
+
+for _kv in filter(None, os.environ.get("MG_TEST_KNOBS", "").split(",")):  # (the parent test's knobs: the library reads no environment)
+    debug_set(_kv.split("=")[0], int(_kv.split("=")[1]))
 
 torch.cuda.set_device(0)
 stream = torch.cuda.Stream()  # explicit: the default stream's handle is 0 and is refused by mg_init_on_stream
@@ -30,7 +33,7 @@ gb, go = synth.make_genomes(60, 20000)
 rb, ro, src = synth.make_reads(gb, go, 80000, npresent=9)
 recs = synth.make_alignment_records(src + 1, 61)
 ref2tax = np.arange(61, dtype=np.uint32)
-n = 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200  # forced-overflow run: enough distinct hashes to fill a minimum-size table
+n = 1000 if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")) else 200  # forced-overflow run: enough distinct hashes to fill a minimum-size table
 want = oracle.profile_assign(recs, ref2tax, 61, 0.5)
 # one k given bare (the single-k surface), then the k set of BASELINE configs[2] (the fused stage-A launch): every k's
 # words in the one all-gather, its slices in the all-to-all round, its hits / sizes in the one all-reduce
@@ -64,7 +67,7 @@ for kspec in (21, [21, 31, 51]):
         off, tax, hl, rd = got["multimapped"]
         assert np.array_equal(off, want["mm_offsets"]) and np.array_equal(tax, want["mm_tax"])
         assert np.array_equal(hl, want["mm_hitlen"]) and np.array_equal(rd, want["mm_read"])
-    if os.environ.get("MG_DEBUG_DISTINCT_HINT"):  # the forced-overflow run must have taken the repeat-the-all-gather path
+    if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")):  # the forced-overflow run must have taken the repeat-the-all-gather path
         assert getattr(job, "words_redone", 0) >= 4, getattr(job, "words_redone", 0)
 dist.barrier()
 dist.destroy_process_group()

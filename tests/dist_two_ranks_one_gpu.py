@@ -18,8 +18,11 @@ import torch.distributed as dist  # noqa: E402
 import oracle  # noqa: E402
 import util  # noqa: E402
 from metalign_amd import synth  # noqa: E402
-from metalign_amd._hip import Hip  # noqa: E402
+from metalign_amd._hip import Hip, debug_set  # noqa: E402
 from metalign_amd.distributed import ShardJob  # noqa: E402
+
+for _kv in filter(None, os.environ.get("MG_TEST_KNOBS", "").split(",")):  # (the parent test's knobs: the library reads no environment)
+    debug_set(_kv.split("=")[0], int(_kv.split("=")[1]))
 
 torch.cuda.set_device(0)
 stream = torch.cuda.Stream()
@@ -45,8 +48,8 @@ my_recs = recs[rcuts[rank]: rcuts[rank + 1]]
 # (k set, s): one k given bare, the fused multi-k launch, and bottom-s sketches (the sample-wide cut over the ranks' slices)
 for kspec, s_cut in ((21, 0), ([21, 31, 51], 0), (21, 500), ([21, 31, 51], 700)):
     ks = [kspec] if np.isscalar(kspec) else kspec
-    # (MG_DEBUG_DISTINCT_HINT: every counting table undersized -> sketches redone, words stale, the all-gather repeated)
-    tabs = [hip.sketch_genomes(gb, go, k, 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200) for k in ks]
+    # (MG_TEST_KNOBS distinct_hint_ppm: every counting table undersized -> sketches redone, words stale, the all-gather repeated)
+    tabs = [hip.sketch_genomes(gb, go, k, 1000 if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")) else 200) for k in ks]
     job = ShardJob(hip, dist, rank, world, k=kspec, s=s_cut)
     if np.isscalar(kspec):
         job.load(my_rb, my_ro, my_recs, ref2tax, tabs[0][0], tabs[0][1])
@@ -78,17 +81,17 @@ for kspec, s_cut in ((21, 0), ([21, 31, 51], 0), (21, 500), ([21, 31, 51], 700))
         off = np.concatenate(off)
         assert np.array_equal(tax, want["mm_tax"]) and np.array_equal(hl, want["mm_hitlen"]), (rank, idx)
         assert np.array_equal(rd, want["mm_read"]) and np.array_equal(off, want["mm_offsets"]), (rank, idx)
-    if os.environ.get("MG_DEBUG_DISTINCT_HINT"):
+    if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")):
         assert getattr(job, "words_redone", 0) >= 1, getattr(job, "words_redone", 0)
 # ---- the reference pipeline (reads sketched at the largest k only; prefix bitmaps OR-ed across the ranks), both hash modes ----
 for ks, mode in (([21, 31, 51], 0), ([30, 40, 50, 60], 1), ([31], 0)):
     hip.set_hash_mode(mode)
     oracle.set_hash_mode(mode)
-    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200)
+    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], 1000 if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")) else 200)
     table = hip.refdb_build(h, khi, klo, o, ks)
     full = table.download(kmers=False)
     table.free()
-    wtab = oracle.refpipe_build(*oracle.sketch_genomes_kmers(gb, go, ks[-1], 1000 if os.environ.get("MG_DEBUG_DISTINCT_HINT") else 200), ks)
+    wtab = oracle.refpipe_build(*oracle.sketch_genomes_kmers(gb, go, ks[-1], 1000 if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")) else 200), ks)
     qh, qc, _, _ = oracle.sketch_reads(rb, ro, ks[-1], hmax=int(h.max()))
     whits, wsizes = oracle.refpipe_containment(qh, qc, 2, wtab)
     job = ShardJob(hip, dist, rank, world, k=ks, definition="reference_pipeline")

@@ -43,11 +43,11 @@ def test_one_giant_read_group(hip, oracle_lib):
 
 
 @pytest.mark.parametrize("hashed", [False, True])
-def test_stage_c_reads_around_the_bin_length_limit(hip, oracle_lib, monkeypatch, hashed):
+def test_stage_c_reads_around_the_bin_length_limit(hip, oracle_lib, monkeypatch, knobs, hashed):
     """Uniquely mapped reads of 2^14 bases or more bypass the workgroup's bins (one queue word holds 14 bits of length):
     lengths either side of the limit and up to the record field's 2^20 - 1, through the direct and the hashed bins."""
     if hashed:
-        monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
+        knobs("k3_hashed", 1)
     rng = np.random.default_rng(7)
     n = 60000
     ntax = 37

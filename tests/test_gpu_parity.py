@@ -143,7 +143,7 @@ def test_count_saturation_matches_oracle(hip, oracle_lib, cs):
 
 @pytest.mark.parametrize("ks", [(21, 31, 51), (30, 40, 50, 60), (21, 31), (15, 21, 31, 51)])
 @pytest.mark.parametrize("kind", ["clean", "ragged", "dirty"])
-def test_multi_k_sketch_matches_oracle_per_k(hip, oracle_lib, ks, kind, monkeypatch):
+def test_multi_k_sketch_matches_oracle_per_k(hip, oracle_lib, ks, kind, monkeypatch, knobs):
     """mg_sketch_reads_multi_dev_async: every k of the query from one pass (select_db.py:73-76 is a multi-k query).
     {21,31,51} and {30,40,50,60} run the fused kernel (one roller at the largest k, every smaller k's k-mer derived
     from it), other sets one launch per k; either way each sketch equals the oracle's for that k bit for bit — hashes,
@@ -181,10 +181,10 @@ def test_multi_k_sketch_matches_oracle_per_k(hip, oracle_lib, ks, kind, monkeypa
             h1, c1 = one.download()
             assert np.array_equal(h, h1) and np.array_equal(c, c1)
     # an undersized counting table of the fused launch is detected per k and that sketch is redone (list path)
-    monkeypatch.setenv("MG_DEBUG_DISTINCT_HINT", "0.0005")
+    knobs("distinct_hint_ppm", 500)
     sks = hip.sketch_reads_multi_dev_async(d_b.ptr, d_o.ptr, nreads, list(ks), [int(0.2 * 2 ** 64)] * len(ks), 0, None)
     rebuilt = [sk.resolve() for sk in sks]
-    monkeypatch.delenv("MG_DEBUG_DISTINCT_HINT")
+    knobs("distinct_hint_ppm", 0)
     assert any(rebuilt)
     for i, k in enumerate(ks):
         h, c = sks[i].download()
@@ -194,13 +194,13 @@ def test_multi_k_sketch_matches_oracle_per_k(hip, oracle_lib, ks, kind, monkeypa
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("order", ["filter", "slot"])
-def test_flush_order_does_not_change_the_sketch(hip, oracle_lib, order, monkeypatch):
+def test_flush_order_does_not_change_the_sketch(hip, oracle_lib, order, monkeypatch, knobs):
     """A flush of stage A's candidate buffer looks at the membership filter and at the candidate's home slot in the
     counting table; each wavefront takes whichever order was cheaper for its previous flush (mg_sketch_multi.hip:
-    MultiSink::flush).  Pinned to either order (MG_DEBUG_FLUSH_ORDER, a test hook) the sketches are the oracle's, bit for
+    MultiSink::flush).  Pinned to either order (knob flush_order, a test hook) the sketches are the oracle's, bit for
     bit, at high coverage (nearly every candidate is a repeat) and at none (every candidate is new), with error k-mers
     the filter rejects, for the single-k kernel and the fused one."""
-    monkeypatch.setenv("MG_DEBUG_FLUSH_ORDER", order)
+    knobs("flush_order", {"f": 1, "s": 2}.get(order[:1], 0))
     rng = np.random.default_rng(5 + len(order))
     gb, go = util.random_genomes(rng, 10, 8000)
     ks = (21, 31, 51)
@@ -317,12 +317,12 @@ def test_deferred_merge_equals_merge(hip):
 
 
 @pytest.mark.parametrize("name,idx,run", sc.hand_cases(), ids=lambda v: str(v) if not isinstance(v, dict) else "")
-def test_stage_c_hand_cases_hip(hip, name, idx, run, monkeypatch, tmp_path):
+def test_stage_c_hand_cases_hip(hip, name, idx, run, monkeypatch, knobs, tmp_path):
     sc.check_hand_case(name, run, None, monkeypatch, tmp_path)
 
 
 @pytest.mark.parametrize("name", ["single_3k", "paired_2k", "single_100k", "paired_40k"])
-def test_stage_c_bulk_hip(hip, name, monkeypatch, tmp_path):
+def test_stage_c_bulk_hip(hip, name, monkeypatch, knobs, tmp_path):
     spec = sc.load_bulk()[name]
     sam, dbp = sc.materialise_bulk(name, spec, tmp_path)
     for run in spec["runs"]:
@@ -330,13 +330,13 @@ def test_stage_c_bulk_hip(hip, name, monkeypatch, tmp_path):
 
 
 @pytest.mark.parametrize("force_hashed", [False, True])
-def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib, force_hashed, monkeypatch):
+def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib, force_hashed, monkeypatch, knobs):
     """Random record streams straight into the C ABI: direct LDS bins at three, then two workgroups per CU (37 / 3500
     taxa) and, beyond 4096 taxa, hashed bins (open addressing, 2048 slots) that overflow into the workgroups' private bins;
-    and the hashed bins on the small taxonomies too (MG_DEBUG_K3_HASHED, a test hook): few taxa — every probe hits at
+    and the hashed bins on the small taxonomies too (knob k3_hashed, a test hook): few taxa — every probe hits at
     once — and 3500 — the table is crowded, the probe limit drops and many taxa overflow."""
     if force_hashed:
-        monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
+        knobs("k3_hashed", 1)
     rng = np.random.default_rng(9)
     for ntax, nref in ((37, 90), (3500, 7000), (5000, 9000)):
         n = 300000
@@ -362,17 +362,17 @@ def test_stage_c_records_vs_oracle_large_taxa(hip, oracle_lib, force_hashed, mon
 
 @pytest.mark.parametrize("force_hashed", [False, True])
 @pytest.mark.parametrize("flush_tiles,grid", [(1, 0), (2, 3), (3, 7), (0, 2)])
-def test_stage_c_bins_flushed_in_the_middle_of_a_workgroups_life(hip, oracle_lib, force_hashed, flush_tiles, grid, monkeypatch):
+def test_stage_c_bins_flushed_in_the_middle_of_a_workgroups_life(hip, oracle_lib, force_hashed, flush_tiles, grid, monkeypatch, knobs):
     """A workgroup's LDS bins are flushed every 256 (direct) / 15 (hashed) tiles — which no input of a test's size reaches, a
     workgroup living for a tile or two.  With the test hooks (fewer workgroups, shorter intervals) the same records go through
     mid-life flushes (hashed: into the per-XCD copies, keys released and claimed again), bins that persist over many tiles,
     and the last dump of a table that was just flushed; small, crowded (3500 taxa in 2048 slots) and large taxonomies."""
     if force_hashed:
-        monkeypatch.setenv("MG_DEBUG_K3_HASHED", "1")
+        knobs("k3_hashed", 1)
     if flush_tiles:
-        monkeypatch.setenv("MG_DEBUG_K3_FLUSH_TILES", str(flush_tiles))
+        knobs("k3_flush_tiles", flush_tiles)
     if grid:
-        monkeypatch.setenv("MG_DEBUG_K3_GRID", str(grid))
+        knobs("k3_grid", grid)
     rng = np.random.default_rng(21)
     for ntax, nref in ((37, 90), (3500, 7000), (5000, 9000)):
         n = 60000  # 30 tiles
@@ -404,9 +404,9 @@ def test_sketch_two_million_distinct(hip, oracle_lib):
     assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
 
 
-def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch):
+def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch, knobs):
     """A k-mer repeated far more often than a bucket slab holds (adapter-like reads) forces the list path;
-    MG_DEBUG_FORCE_LIST exercises the list path on ordinary input.  Same sketch either way."""
+    the knob force_list exercises the list path on ordinary input.  Same sketch either way."""
     rng = np.random.default_rng(123)
     gb, go = util.random_genomes(rng, 8, 30000)
     bases, offsets, _ = util.sample_reads(rng, gb, go, 30000, 150, err=0.005)
@@ -414,15 +414,15 @@ def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch):
     oh, oc, _, oseen = oracle_lib.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
     for force in (False, True):
         if force:
-            monkeypatch.setenv("MG_DEBUG_FORCE_LIST", "1")
+            knobs("force_list", 1)
         h, c, _, seen = hip.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
         assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
-    monkeypatch.delenv("MG_DEBUG_FORCE_LIST", raising=False)
+    knobs("force_list", 0)
     # an undersized table (distinct-count hint far too low) must be detected and redone on the list path
-    monkeypatch.setenv("MG_DEBUG_DISTINCT_HINT", "0.0005")
+    knobs("distinct_hint_ppm", 500)
     h, c, _, seen = hip.sketch_reads(bases, offsets, k, hmax=int(0.3 * 2**64))
     assert seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
-    monkeypatch.delenv("MG_DEBUG_DISTINCT_HINT", raising=False)
+    knobs("distinct_hint_ppm", 0)
     # 6000 copies of one read: each of its k-mers occurs 6000x (one table slot, count 6000+)
     rep = np.tile(bases[: 150], 6000)
     b2 = np.concatenate([bases, rep])
@@ -440,7 +440,7 @@ def test_sketch_bucket_path_overflow_falls_back(hip, oracle_lib, monkeypatch):
         hip.count_saturation(3)
 
 
-def test_deferred_sketch_feeds_containment_without_a_sync(hip, oracle_lib, monkeypatch):
+def test_deferred_sketch_feeds_containment_without_a_sync(hip, oracle_lib, monkeypatch, knobs):
     """mg_sketch_reads_dev_async: stage B consumes the sketch while its size is still on the device; the results
     equal the oracle's, and a counting-table overflow discovered at resolve() is reported so that stage B is redone."""
     rng = np.random.default_rng(77)
@@ -456,7 +456,7 @@ def test_deferred_sketch_feeds_containment_without_a_sync(hip, oracle_lib, monke
     d_h, d_s = hip.empty(12, np.uint32), hip.empty(12, np.uint32)
     for hint, want_rebuilt in ((None, False), ("0.0005", True)):
         if hint:
-            monkeypatch.setenv("MG_DEBUG_DISTINCT_HINT", hint)
+            knobs("distinct_hint_ppm", int(float(hint) * 1e6))
         sk = hip.sketch_reads_dev_async(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, 0)
         hip.containment_dev(sk, table, 2, d_h.ptr, d_s.ptr)  # queued behind stage A, nothing synchronised yet
         hip.sync()
@@ -469,7 +469,7 @@ def test_deferred_sketch_feeds_containment_without_a_sync(hip, oracle_lib, monke
         assert sk.kmers_seen == oseen and np.array_equal(h, oh) and np.array_equal(c, oc)
         assert not sk.resolve()  # idempotent
         sk.free()
-        monkeypatch.delenv("MG_DEBUG_DISTINCT_HINT", raising=False)
+        knobs("distinct_hint_ppm", 0)
 
 
 @pytest.mark.parametrize("name", ["single_3k", "paired_2k", "single_100k", "paired_40k"])
@@ -564,15 +564,15 @@ def test_filtered_sketch_matches_oracle_and_keeps_containment(hip, oracle_lib, k
             assert np.array_equal(hits, ohits) and np.array_equal(sizes, osizes)
         sk.free()
     # the list path (small / forced) applies the same filter
-    import os
-    os.environ["MG_DEBUG_FORCE_LIST"] = "1"
+    from metalign_amd import _hip
+    _hip.debug_set("force_list", 1)
     try:
         sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, s, filt=filt)
         h, c = sk.download()
         assert np.array_equal(h, oh) and np.array_equal(c, oc)
         sk.free()
     finally:
-        del os.environ["MG_DEBUG_FORCE_LIST"]
+        _hip.debug_set("force_list", 0)
     # an empty table: nothing passes
     empty = hip.filter_build(np.zeros(0, dtype=np.uint64))
     sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(offsets) - 1, k, hmax, 0, filt=empty)
@@ -750,13 +750,13 @@ def test_resident_index_sketches_are_the_exact_intersection(hip, oracle_lib, ks)
         f.free()
 
 
-@pytest.mark.parametrize("hook", ["MG_DEBUG_DISTINCT_HINT", "MG_DEBUG_RESIDENT_SCAN"])
-def test_resident_index_list_overflow_and_slot_walk(hip, oracle_lib, hook, monkeypatch):
+@pytest.mark.parametrize("hook", ["distinct_HINT", "resident_scan"])
+def test_resident_index_list_overflow_and_slot_walk(hip, oracle_lib, hook, monkeypatch, knobs):
     """The sketch of a resident index is made from the LIST of hashes the kernel touched.  A list (or sketch buffer) sized for
-    far fewer hashes than the sample has (MG_DEBUG_DISTINCT_HINT, a test hook) is reported like a table overflow and the
+    far fewer hashes than the sample has (knob distinct_hint_ppm, a test hook) is reported like a table overflow and the
     sketch made again at full size when it is resolved — exact either way; and a walk over every slot of the index
-    (MG_DEBUG_RESIDENT_SCAN) gives the same sketch as the list."""
-    monkeypatch.setenv(hook, "0.0001" if hook.endswith("HINT") else "1")
+    (knob resident_scan) gives the same sketch as the list."""
+    knobs("distinct_hint_ppm" if hook.endswith("HINT") else hook, 100 if hook.endswith("HINT") else 1)
     rng = np.random.default_rng(77)
     ks = (21, 31, 51)
     gb, go = util.random_genomes(rng, 40, 6000)

@@ -141,12 +141,12 @@ def test_pieces_into_one_table_equal_the_whole(hip, oracle_lib, ks):
 
 @pytest.mark.parametrize("thin", [False, True])
 @pytest.mark.parametrize("chunk", [1 << 16, 3 << 16, 64 << 20])
-def test_files_through_the_pipeline(hip, tmp_path, chunk, thin, monkeypatch):
+def test_files_through_the_pipeline(hip, tmp_path, chunk, thin, monkeypatch, knobs):
     """FASTQ (LF, CRLF, no final newline), wrapped FASTA, gzip (one member, several members), BGZF: every form of the same
     reads through mg_sketch_stream_add_file in pieces of `chunk` bytes == the whole reads in one launch.  thin: the plain
-    FASTQ files thinned by the reader threads (MG_STREAM_THIN=1: a record goes up as ">" + its sequence line)."""
+    FASTQ files thinned by the reader threads (knob stream_thin: a record goes up as ">" + its sequence line)."""
     if thin:
-        monkeypatch.setenv("MG_STREAM_THIN", "1")
+        knobs("stream_thin", 1)
     ks = [21, 31, 51]
     gb, go, rb, ro = _sample(2, nreads=20000)
     tabs, hmaxs, filts = _tables(hip, gb, go, ks)
@@ -207,9 +207,9 @@ def test_byte_range_of_a_plain_file_and_empty_files(hip, tmp_path):
 
 
 @pytest.mark.parametrize("thin", [False, True])
-def test_what_the_pipeline_refuses(hip, tmp_path, thin, monkeypatch):
+def test_what_the_pipeline_refuses(hip, tmp_path, thin, monkeypatch, knobs):
     if thin:
-        monkeypatch.setenv("MG_STREAM_THIN", "1")  # (the readers' own checks then: same codes)
+        knobs("stream_thin", 1)  # (the readers' own checks then: same codes)
     ks = [21]
     gb, go, rb, ro = _sample(4, nreads=2000)
     tabs, hmaxs, filts = _tables(hip, gb, go, ks)
@@ -248,11 +248,11 @@ def test_what_the_pipeline_refuses(hip, tmp_path, thin, monkeypatch):
     assert e.value.code == _hip.ERR_CAPACITY
     stream.free()
     # an undersized table (the estimate was far too small): reported at resolution, the hint reset
-    os.environ["MG_DEBUG_DISTINCT_HINT"] = "0.00002"
+    _hip.debug_set("distinct_hint_ppm", 20)
     try:
         stream = hip.sketch_stream(ks, hmaxs, 0, None, expect_bases=rb.size)
     finally:
-        del os.environ["MG_DEBUG_DISTINCT_HINT"]
+        _hip.debug_set("distinct_hint_ppm", 0)
     d_b, d_o = hip.array(rb), hip.array(ro)
     stream.add_dev(d_b.ptr, d_o.ptr, len(ro) - 1, rb.size)
     sks = stream.finish()
@@ -266,11 +266,11 @@ def test_what_the_pipeline_refuses(hip, tmp_path, thin, monkeypatch):
 
 
 @pytest.mark.parametrize("thin", [False, True])
-def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch, thin):
+def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch, knobs, thin):
     """select_main and map_main on files: the streamed pipelines (small chunks, so that every file is many pieces with
     carried records / lines) against round 2's whole-file path (MG_NO_STREAM=1) — CSV, subset db_info and CAMI file byte
     for byte; the reads as plain FASTQ, gzip and BGZF.  thin: the plain FASTQ and the SAM file thinned by the reader threads
-    (MG_STREAM_THIN=1; the tokeniser takes len(SEQ) from the mark the readers leave)."""
+    (knob stream_thin; the tokeniser takes len(SEQ) from the mark the readers leave)."""
     import argparse
 
     import test_pipeline_gpu as tp
@@ -314,7 +314,7 @@ def test_command_lines_streamed_equal_unstreamed(hip, tmp_path, monkeypatch, thi
     assert want_csv.count("\n") >= 3 and want_cami.count("\n") > 10
     monkeypatch.delenv("MG_NO_STREAM")
     if thin:
-        monkeypatch.setenv("MG_STREAM_THIN", "1")
+        knobs("stream_thin", 1)
     for chunk in ("65536", "0"):
         monkeypatch.setenv("MG_STREAM_CHUNK_BYTES", chunk)
         for name, blob in files.items():

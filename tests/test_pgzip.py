@@ -19,6 +19,12 @@ def _fastq(rng, nreads, readlen=150):
     return b"".join(out)
 
 
+@pytest.fixture(autouse=True)
+def _knobs_back():
+    yield
+    _hip.debug_set(None)
+
+
 @pytest.fixture(scope="module")
 def text():
     return _fastq(np.random.default_rng(1), 60000)  # ~19 MB of FASTQ
@@ -28,7 +34,7 @@ def _roundtrip(tmp_path, name, blob, want, monkeypatch, chunk=None, threads=0):
     p = tmp_path / name
     p.write_bytes(blob)
     if chunk:
-        monkeypatch.setenv("MG_PGZIP_CHUNK", str(chunk))
+        _hip.debug_set("pgzip_chunk", chunk)
     got = _hip.gunzip_file(str(p), nthreads=threads)
     assert len(got) == len(want) and got == want, name
 
@@ -43,6 +49,8 @@ def test_members_padding_and_odd_shapes(tmp_path, text, monkeypatch):
     a, b, c = gzip.compress(text[:5_000_000], 6), gzip.compress(text[5_000_000:5_000_100], 1), gzip.compress(text[5_000_100:], 4)
     _roundtrip(tmp_path, "members.gz", a + b + c, text, monkeypatch, chunk=100_000, threads=5)
     _roundtrip(tmp_path, "padded.gz", a + b + c + b"\0" * 4000, text, monkeypatch, chunk=100_000, threads=5)
+    for pad in (b"\n", b"\0" * 3, b"\0" * 9, b"x" * 9):  # (fewer bytes than a member header has: still garbage, not a truncated member)
+        _roundtrip(tmp_path, "padded%d.gz" % len(pad), a + b + c + pad, text, monkeypatch, chunk=100_000, threads=5)
     _roundtrip(tmp_path, "garbage.gz", a + b"trailing garbage", text[:5_000_000], monkeypatch, chunk=100_000, threads=3)
     _roundtrip(tmp_path, "empty_member.gz", gzip.compress(b"") + a + gzip.compress(b""), text[:5_000_000], monkeypatch, chunk=64 << 10)
     _roundtrip(tmp_path, "tiny.gz", gzip.compress(b"@r\nACGT\n+\nIIII\n"), b"@r\nACGT\n+\nIIII\n", monkeypatch)
@@ -71,7 +79,7 @@ def test_binary_data_is_still_inflated_correctly(tmp_path, monkeypatch):
 
 
 def test_corrupt_and_truncated_streams_are_errors(tmp_path, text, monkeypatch):
-    monkeypatch.setenv("MG_PGZIP_CHUNK", str(100_000))
+    _hip.debug_set("pgzip_chunk", 100_000)
     blob = gzip.compress(text[:6_000_000], 6)
     for name, bad in (("cut.gz", blob[:-9]), ("cut_mid.gz", blob[: len(blob) // 2]), ("cut_header.gz", blob[:6]),
                       ("crc.gz", blob[:-8] + b"\0\0\0\0" + blob[-4:]), ("isize.gz", blob[:-4] + b"\1\0\0\0")):

@@ -213,7 +213,7 @@ def test_exchange_path_on_one_gpu_under_rccl():
     assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     # the same with stage A's counting table forced to overflow on every pass: the words a rank publishes from its
     # pending sketch are then stale, every rank sees the flag and the all-gather is repeated after the rebuild
-    env["MG_DEBUG_DISTINCT_HINT"] = "0.0005"
+    env["MG_TEST_KNOBS"] = "distinct_hint_ppm=500"
     r = subprocess.run([sys.executable, os.path.join(here, "dist_single_rank.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "dist-single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
@@ -232,7 +232,7 @@ def test_several_ranks_on_one_gpu_with_the_real_kernels(world, overflow):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
     if overflow:  # every counting table undersized: sketches redone on the list path, the words all-gather repeated
-        env["MG_DEBUG_DISTINCT_HINT"] = "0.0005"
+        env["MG_TEST_KNOBS"] = "distinct_hint_ppm=500"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(29590 + world + (5 if overflow else 0)),
                         os.path.join(here, "dist_two_ranks_one_gpu.py")], capture_output=True, text=True, timeout=900, env=env)

@@ -163,13 +163,13 @@ def test_sam_lines_that_grow_and_lines_longer_than_a_piece(tmp_path):
 
 
 def test_the_byte_by_byte_scanner_gives_the_same(tmp_path):
-    """The scanners take 32 bytes per step where the host has AVX2; MG_DEBUG_NO_AVX2=1 (read once per process) selects the plain
+    """The scanners take 32 bytes per step where the host has AVX2; the knob no_avx2 (read once per process) selects the plain
     loop: this module again in a process of its own."""
     import subprocess
     import sys
-    if os.environ.get("MG_DEBUG_NO_AVX2") == "1":
+    if "no_avx2=1" in os.environ.get("MG_TEST_KNOBS", ""):
         pytest.skip("already the plain loop")
-    env = dict(os.environ, MG_DEBUG_NO_AVX2="1")
+    env = dict(os.environ, MG_TEST_KNOBS="no_avx2=1")  # (tests/conftest.py hands it to mg_debug_set when the child's session starts)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-p", "no:cacheprovider",
                         "-k", "not byte_by_byte"], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

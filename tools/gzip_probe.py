@@ -64,9 +64,10 @@ def main():
     hmax = int(dbh.max())
     filt = hip.filter_build(dbh)
     out["pipeline"] = {}
-    for name, path, env in (("plain", fq, {}), ("gzip_parallel", fq + ".gz", {}), ("gzip_zlib_one_thread", fq + ".gz", {"MG_GZIP_THREADS": "1"})):
+    for name, path, env in (("plain", fq, {}), ("gzip_parallel", fq + ".gz", {}), ("gzip_zlib_one_thread", fq + ".gz", {"gzip_threads": 1})):
+        hip.inflate_config(on=0)  # (this probe is about the HOST inflaters; tools/inflate_probe.py has the device one beside them)
         for kk, v in env.items():
-            os.environ[kk] = v
+            _hip.debug_set(kk, v)
         best, sizes = None, None
         for rep in range(2):
             st = hip.sketch_stream([k], [hmax], 0, [filt], nbytes // 2)
@@ -82,7 +83,7 @@ def main():
             st.free()
             best = dt if best is None else min(best, dt)
         for kk in env:
-            del os.environ[kk]
+            _hip.debug_set(kk, 0)
         out["pipeline"][name] = {"seconds": best, "reads_per_s": n / best, "text_GBs": nbytes / best / 1e9, "sketch_sizes": sizes}
     print(json.dumps(out, indent=1))
 

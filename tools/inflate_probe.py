@@ -24,70 +24,7 @@ from metalign_amd import _hip, synth  # noqa: E402
 import bench_cli  # noqa: E402
 
 
-def parallel_gzip(text, level=6, piece=16 << 20, threads=32):
-    """ONE gzip member, compressed in pieces by many threads the way pigz does it: every piece is raw deflate primed with the 32 KB in
-    front of it and ends on a sync flush (the last one finishes the stream), so the concatenation is one deflate stream."""
-    mv = memoryview(text)
-    cuts = list(range(0, len(mv), piece)) or [0]
-
-    def one(i):
-        a = cuts[i]
-        b = min(a + piece, len(mv))
-        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY, bytes(mv[max(a - 32768, 0):a])) if a else zlib.compressobj(level, zlib.DEFLATED, -15)
-        out = co.compress(mv[a:b])
-        out += co.flush(zlib.Z_FINISH if i == len(cuts) - 1 else zlib.Z_SYNC_FLUSH)
-        return out, zlib.crc32(mv[a:b]), b - a
-    with ThreadPoolExecutor(threads) as ex:
-        parts = list(ex.map(one, range(len(cuts))))
-    crc = 0
-    for _, c, n in parts:
-        crc = _crc_combine(crc, c, n)
-    return b"\x1f\x8b\x08\0\0\0\0\0\0\x03" + b"".join(p[0] for p in parts) + struct.pack("<II", crc, len(mv) & 0xFFFFFFFF)
-
-
-def _gf2_times(mat, vec):
-    s, i = 0, 0
-    while vec:
-        if vec & 1:
-            s ^= mat[i]
-        vec >>= 1
-        i += 1
-    return s
-
-
-def _crc_combine(crc1, crc2, len2):
-    if len2 == 0:
-        return crc1
-    odd = [0xEDB88320] + [1 << i for i in range(31)]
-    even = [_gf2_times(odd, odd[i]) for i in range(32)]
-    odd = [_gf2_times(even, even[i]) for i in range(32)]
-    while True:
-        even = [_gf2_times(odd, odd[i]) for i in range(32)]
-        if len2 & 1:
-            crc1 = _gf2_times(even, crc1)
-        len2 >>= 1
-        if not len2:
-            break
-        odd = [_gf2_times(even, even[i]) for i in range(32)]
-        if len2 & 1:
-            crc1 = _gf2_times(odd, crc1)
-        len2 >>= 1
-        if not len2:
-            break
-    return crc1 ^ crc2
-
-
-def parallel_bgzf(text, level=6, threads=32, block=65280):
-    mv = memoryview(text)
-
-    def one(a):
-        c = mv[a:a + block]
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
-        raw = co.compress(c) + co.flush()
-        return b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(raw) + 8 - 1) + raw + struct.pack("<II", zlib.crc32(c), len(c))
-    with ThreadPoolExecutor(threads) as ex:
-        parts = list(ex.map(one, range(0, len(mv), block)))
-    return b"".join(parts) + b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0"
+from bench_cli import parallel_gzip, parallel_bgzf  # noqa: E402,F401
 
 
 _WARM = {}

@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from metalign_amd import synth
+from metalign_amd import _hip
 from metalign_amd._hip import Hip
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
@@ -42,9 +43,9 @@ if os.environ.get("MG_PROBE_RESIDENT", "1") != "0":
     run(hmaxs, res, "thresholds + resident indexes of the table:")
     for ab, what in ((1, "a flush drops its candidates"), (2, "looks them up, counts nothing, none goes round again"),
                      (3, "looks them up, counts nothing")):
-        os.environ["MG_DEBUG_RESIDENT_ABLATE"] = str(ab)
+        _hip.debug_set("resident_ablate", ab)
         run(hmaxs, res, "resident, %s:" % what)
-    del os.environ["MG_DEBUG_RESIDENT_ABLATE"]
+    _hip.debug_set("resident_ablate", 0)
     for f in res: f.free()
 run(hmaxs, None, "thresholds, no filter:")
 span = 9999999999971 if os.environ.get("MG_PROBE_HASH_MODE") == "1" else 2 ** 64
