@@ -748,7 +748,7 @@ def main():
                 import bench_cli
                 res["with_ingest"] = bench_cli.measure(nreads, G=cfg["genomes"], ks=tuple(cfg["ks"]), glen=cfg["genome_len"],
                                                        sketch_n=args.sketch_n, workload=w)
-            except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline down)
+            except BaseException as e:  # noqa: BLE001  (a secondary figure must not take the headline down — a sys.exit of the command line neither)
                 res["with_ingest"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -205,6 +205,38 @@ def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib, definition
         oracle_lib.set_hash_mode(0)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_the_reference_s_own_parameters_at_the_benchmarked_size(hip, oracle_lib, mode):
+    """`bench.py --preset stock`: the parameters the reference itself runs (scripts/select_db.py:44,50,69-70,75 — kmc -k60, the streaming
+    query's range 30-60-10, n = 1000) on configs[2]'s sizes, both hash definitions: a 12-byte tail in MurmurHash3 and four prefix columns,
+    which the headline's {21,31,51} does not exercise.  A >= 2M-read sample against the C oracle: hits and sizes of all 10 000 genomes for
+    k = 30, 40, 50, 60, every per-taxon accumulator."""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cfg = dict(bench.PRESETS[2], config=2, custom=False, ks=list(bench.STOCK_KS), name=bench.STOCK_NAME)
+    try:
+        w = bench.build_workload(cfg, 1000, 0, hip, "reference_pipeline", mode)
+        assert len(w["ro"]) - 1 == 10_000_000 and w["table_hashes"] == 10_000_000
+        args = argparse.Namespace(cpu_seconds=20.0)
+        base, check = bench.cpu_baseline_and_check(args, cfg, w, hip)
+        nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
+        assert nsample >= 2_000_000 or nsample == 10_000_000, check["compared"]
+        assert check["oracle_equal"], check["mismatch"]
+        job = bench.make_job(hip, None, 0, 1, cfg, w)
+        one = job.step()
+        out = job.run(3)
+        assert out["sketch_sizes"] == one["sketch_sizes"] and np.array_equal(out["hits_k"], one["hits_k"]) and out["hits_k"].shape == (4, 10_000)
+        assert out["sketched_ks"] == [60]
+        del job
+    finally:
+        hip.set_hash_mode(0)
+        oracle_lib.set_hash_mode(0)
+
+
 def test_reference_pipeline_table_at_the_benchmarked_size(hip, oracle_lib):
     """The table bench.py's headline runs against — 10 000 genomes x 1000 sketched 51-mers, prefix columns for k = 21 and 31 —
     as the device builder lays it out (mg_sketch_genomes_kmers + mg_refdb_build) against the oracle's, entry for entry: the

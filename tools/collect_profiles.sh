@@ -17,7 +17,8 @@ MG_SINGLE_STREAM=1 timeout -s KILL 600 python3 bench.py --no_cpu_baseline --no_s
 timeout -s KILL 900 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_pipelined" -o run -- python3 bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_secondary --no_kernel_table "$@" > "$OUT/bench_pipelined_under_rocprof.json" 2> "$OUT/stats_pipelined.log"
 python3 tools/trace_timeline.py "$OUT/stats_pipelined" "$OUT/pipelined_timeline.json" > "$OUT/pipelined_timeline.txt" 2>&1
 export MG_SINGLE_STREAM=1
-timeout -s KILL 900 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o run -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+# (30 passes: the first launches of a process run at low clocks — with 5 passes they were a third of the average)
+timeout -s KILL 900 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o run -- python3 bench.py --steps 30 --warmup 5 --no_cpu_baseline --no_secondary --no_kernel_table "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 900 rocprofv3 --output-format csv --pmc $c --kernel-trace -d "$OUT/pmc_$c" -o run -- python3 bench.py $ARGS > "$OUT/pmc_$c.log" 2>&1
 done
