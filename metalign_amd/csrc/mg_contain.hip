@@ -512,8 +512,7 @@ int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uin
   MG_TRY(db->pair_gen.alloc((npairs + 1) * sizeof(uint32_t)));
   MG_TRY(db->gsize.alloc((ngenomes + 1) * sizeof(uint32_t)));
   if (npairs) {
-    MG_HIP(hipMemcpyAsync(db->pair_hash.p, pair_hash, npairs * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    MG_HIP(hipMemcpyAsync(db->pair_gen.p, pair_gen, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MG_TRY(upload_ranges({{pair_hash, {db->pair_hash.p, npairs * sizeof(uint64_t)}}, {pair_gen, {db->pair_gen.p, npairs * sizeof(uint32_t)}}}, st));
   }
   if (ngenomes) MG_HIP(hipMemcpyAsync(db->gsize.p, gsize, ngenomes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (npairs) {

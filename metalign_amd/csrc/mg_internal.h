@@ -162,6 +162,8 @@ void scratch_release_all();
 void stream_release_all();
 // mg_inflate.hip: the page-locked slots and copy stream of the compressed-byte uploads.
 void inflate_release_all();
+// ... host arrays in pageable memory -> the device through those slots (reader threads + one DMA stream); st waits for the last piece.
+int upload_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, hipStream_t st);
 
 // Times one kernel family with HIP events on the library stream when profiling is on.
 struct ProfScope {

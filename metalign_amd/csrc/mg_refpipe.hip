@@ -325,15 +325,13 @@ int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, c
     MG_TRY(S.pa.alloc((npairs + 1) * 4)); MG_TRY(S.pb.alloc((npairs + 1) * 4));
     MG_TRY(S.cid.alloc((ncount[s] + 1) * 4)); MG_TRY(S.cgen.alloc((ncount[s] + 1) * 4));
     MG_TRY(S.gsize.alloc((ngenomes + 1) * 4));
-    if (npairs) {
-      MG_HIP(hipMemcpyAsync(S.pa.p, pa[s], npairs * 4, hipMemcpyHostToDevice, st));
-      MG_HIP(hipMemcpyAsync(S.pb.p, pb[s], npairs * 4, hipMemcpyHostToDevice, st));
+    {
+      std::vector<std::pair<const void*, std::pair<void*, uint64_t>>> up;
+      if (npairs) { up.push_back({pa[s], {S.pa.p, npairs * 4}}); up.push_back({pb[s], {S.pb.p, npairs * 4}}); }
+      if (ncount[s]) { up.push_back({cid[s], {S.cid.p, ncount[s] * 4}}); up.push_back({cgen[s], {S.cgen.p, ncount[s] * 4}}); }
+      if (ngenomes) up.push_back({gsize[s], {S.gsize.p, ngenomes * 4}});
+      MG_TRY(upload_ranges(up, st));
     }
-    if (ncount[s]) {
-      MG_HIP(hipMemcpyAsync(S.cid.p, cid[s], ncount[s] * 4, hipMemcpyHostToDevice, st));
-      MG_HIP(hipMemcpyAsync(S.cgen.p, cgen[s], ncount[s] * 4, hipMemcpyHostToDevice, st));
-    }
-    if (ngenomes) MG_HIP(hipMemcpyAsync(S.gsize.p, gsize[s], ngenomes * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_rp_check, dim3(g256(npairs > ncount[s] ? npairs : ncount[s])), dim3(256), 0, st, S.pa.as<uint32_t>(), S.pb.as<uint32_t>(),
                        npairs, S.cid.as<uint32_t>(), S.cgen.as<uint32_t>(), ncount[s], nprefix[s], ngenomes, d_bad);
     MG_HIP(hipGetLastError());
