@@ -1911,14 +1911,16 @@ static int sketch_genomes_impl(const uint8_t* bases, const uint64_t* offsets, ui
       ProfScope ps("hash_positions");
       const uint64_t nchunks = (nb + kChunk - 1) / kChunk;
       unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
+      int crc = MG_OK;
       bool ok = dispatch_k(k, [&]<int K>() {
-        if (ctx().hash_mode == kHashCmash)  // (instantiated in mg_sketch_cmash.hip)
-          (void)launch_hash_positions_cmash(K, grid, st, d_bases, d_off, ng, nb, d_pos, tagged);
+        if (ctx().hash_mode == kHashCmash)  // (instantiated in mg_sketch_cmash.hip, for the k of its list)
+          crc = launch_hash_positions_cmash(K, grid, st, d_bases, d_off, ng, nb, d_pos, tagged);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCanonical>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
                            d_pos);
       });
       if (!ok) return fail(MG_ERR_ARG, "unsupported k=%d", k);
+      MG_TRY(crc);
       if (tagged) hipLaunchKernelGGL(k_clear_tags, dim3(g256), dim3(256), 0, st, d_pos, nb, d_key);
       MG_HIP(hipGetLastError());
     }
