@@ -385,10 +385,10 @@ int mg_zcat_files(const char* const* paths, uint64_t nfiles, const char* out_pat
  *                     stream; synchronised on return).  MG_ERR_ARG with zlib's wording in mg_last_error for a corrupt or
  *                     truncated stream.
  *   mg_inflate_config: chunk_bytes = compressed bytes per job of a gzip stream (default 32 KB), stage_bytes = compressed bytes
- *                     decoded together (default 176 MB), ratio = symbols reserved per compressed byte (default 10; a job that
+ *                     decoded together (default, and stage_bytes < 0: sized by the device — as many jobs as it holds at once), ratio = symbols reserved per compressed byte (default 10; a job that
  *                     needs more is decoded again), on = whether the streaming entry points use the device inflater, lane_jobs =
  *                     launches of at least this many jobs decode ONE JOB PER LANE (64 serial decoders per wavefront; off by
- *                     default: it pays from ~25 000 jobs in a launch), smaller ones one job per wavefront; values <= 0 (on, lane_jobs: < 0) leave a setting as it is.
+ *                     default: it pays from ~25 000 jobs in a launch), smaller ones one job per wavefront; 0 (on, lane_jobs: < 0) leaves a setting as it is.
  *   mg_inflate_stats: counters since the last reset (host seconds of the stages' phases, jobs, jobs decoded again).
  * ------------------------------------------------------------------------ */
 typedef struct mg_inflated mg_inflated;

@@ -953,7 +953,8 @@ class Hip:
     def inflate_config(self, chunk_bytes=0, stage_bytes=0, ratio=0, on=-1, lane_jobs=-1):
         """mg_inflate_config: compressed bytes per job / per stage, symbols reserved per compressed byte, and whether `.gz` inputs of
         the streaming entry points are inflated on the device (on = 1 / 0), and from how many jobs a launch decodes a job per lane instead
-        of a job per wavefront (lane_jobs; 0 = always per lane); -1 (chunk_bytes, stage_bytes, ratio: 0) leave a setting as it is."""
+        of a job per wavefront (lane_jobs; 0 = always per lane); -1 (chunk_bytes, stage_bytes, ratio: 0) leave a setting as it is;
+        stage_bytes = -1: stages sized by the device (a round of jobs each, the default)."""
         self._chk(self.lib.mg_inflate_config(ctypes.c_int64(int(chunk_bytes)), ctypes.c_int64(int(stage_bytes)), ctypes.c_int(int(ratio)), ctypes.c_int(int(on)),
                                              ctypes.c_int64(int(lane_jobs))))
 

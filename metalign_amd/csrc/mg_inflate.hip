@@ -42,21 +42,59 @@ using namespace mgi;
 // ---------------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
-// chunk c (blockIdx.x + 1) of the stage: absolute bits [grid0 + c * chunk_bits, + chunk_bits) below limit_bit.  grid0 and
-// chunk_bits are multiples of 64.  starts[blockIdx.x] = first plausible block start in it behind min_bit, or ~0.
+// chunk c (blockIdx.x / parts + 1) of the stage: absolute bits [grid0 + c * chunk_bits, + chunk_bits) below limit_bit, part
+// blockIdx.x % parts of it.  grid0 and chunk_bits / parts are multiples of 64.  starts[blockIdx.x] = first plausible block start in
+// the part behind min_bit, or ~0.
 __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __restrict__ in, uint64_t nbytes, uint64_t grid0, uint64_t chunk_bits,
-                                                          uint64_t min_bit, uint64_t limit_bit, uint64_t* __restrict__ starts, uint32_t* __restrict__ info) {
-  __shared__ Shared sh;
+                                                          uint64_t min_bit, uint64_t limit_bit, uint64_t* __restrict__ starts, uint32_t* __restrict__ info,
+                                                          int strict_, int parts) {
+  const bool strict = strict_ != 0;
   __shared__ uint32_t cand[128];  // candidate positions (bits behind lo), ascending
   const int lane = (int)threadIdx.x;
-  DevExec ex{&sh, lane};
   const uint64_t nwords = (nbytes + 3) / 4, nbits = nbytes * 8;
-  const uint64_t lo = grid0 + (uint64_t)(blockIdx.x + 1) * chunk_bits;
-  uint64_t hi = lo + chunk_bits;
+  // `parts` workgroups per chunk, a part of it each (the host takes the first part that found something)
+  const uint64_t part_bits = chunk_bits / (uint64_t)parts;
+  const uint64_t lo = grid0 + (uint64_t)(blockIdx.x / (uint32_t)parts + 1) * chunk_bits + (uint64_t)(blockIdx.x % (uint32_t)parts) * part_bits;
+  uint64_t hi = lo + part_bits;
   if (hi > limit_bit) hi = limit_bit;
   uint64_t found = ~0ull;
-  uint32_t ncand = 0, tried = 0, nsteps = 0;
+  uint32_t ncand = 0, npre = 0, tried = 0, nsteps = 0;
   __shared__ uint32_t words[72];  // 2048 bit positions and what the last of them look at
+  __shared__ uint16_t pre[128];   // positions (behind q0) whose header FIELDS are possible, ascending: their code lengths 64 at a time
+  // the candidates' whole headers, up to 64 at once, a lane each (light_validate: the decision of validate_block_start — the host
+  // check holds the two against each other at every position — in registers, so that this kernel needs none of the decoder's LDS
+  // and a stage's chunks are all resident at once)
+  auto validate_queued = [&]() {
+    __syncthreads();
+    for (uint32_t base = 0; base < ncand && found == ~0ull; base += 64) {
+      const uint32_t ci = base + (uint32_t)lane;
+      const bool good = ci < ncand && light_validate(in, nbytes, lo + cand[ci < ncand ? ci : 0], strict);
+      const uint64_t g = __ballot(good);
+      tried += ncand - base < 64 ? ncand - base : 64;
+      if (g) found = lo + cand[base + (uint32_t)__builtin_ctzll(g)];
+    }
+    __syncthreads();
+    ncand = 0;
+  };
+  // the first `take` queued positions: the code-length code of each (a lane each) -> the candidates
+  auto code_lengths_of_queued = [&](uint64_t q0, uint32_t take) {
+    __syncthreads();
+    const uint32_t off = pre[(uint32_t)lane < take ? lane : 0];
+    const uint32_t i = off >> 5, sft = off & 31u;
+    const uint64_t x0 = (uint64_t)words[i] | (uint64_t)words[i + 1] << 32, x1 = (uint64_t)words[i + 2] | (uint64_t)words[i + 3] << 32;
+    const uint64_t blo = sft ? (x0 >> sft) | (x1 << (64 - sft)) : x0, bhi = x1 >> sft;
+    const bool ok = (uint32_t)lane < take && probe_code_lengths(blo, bhi, strict);
+    const uint64_t m = __ballot(ok);
+    if (ok) cand[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)(q0 + off - lo);
+    ncand += (uint32_t)__builtin_popcountll(m);
+    // (the rest of the queue moves to its front)
+    const uint32_t rest = npre - take;
+    const uint32_t mv = (uint32_t)lane < rest ? pre[take + lane] : 0u;
+    __syncthreads();
+    if ((uint32_t)lane < rest) pre[lane] = (uint16_t)mv;
+    npre = rest;
+    if (ncand >= 64) validate_queued();
+  };
   for (uint64_t q0 = lo; q0 < hi && found == ~0ull; q0 += 2048) {
     // one coalesced load per 32 steps (a step by itself waited for its own five words: the scan was bound by that latency)
     const uint64_t w0 = q0 >> 5;
@@ -68,36 +106,20 @@ __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __rest
       ++nsteps;
       const uint64_t p0 = q0 + 64ull * t2;
       const uint32_t i = 2u * t2 + ((uint32_t)lane >> 5), sft = (uint32_t)lane & 31u;
-      const uint64_t x0 = (uint64_t)words[i] | (uint64_t)words[i + 1] << 32, x1 = (uint64_t)words[i + 2] | (uint64_t)words[i + 3] << 32;
-      const uint64_t blo = sft ? (x0 >> sft) | (x1 << (64 - sft)) : x0, bhi = x1 >> sft;
+      const uint64_t x0 = (uint64_t)words[i] | (uint64_t)words[i + 1] << 32;
       const uint64_t p = p0 + (uint64_t)lane;
-      const bool ok = p < hi && p > min_bit && p + 80 <= nbits && probe_bits(blo, bhi);
+      const bool ok = p < hi && p > min_bit && p + 80 <= nbits && probe_fields(x0 >> sft);
       const uint64_t m = __ballot(ok);
       if (m) {
-        if (ok) cand[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)(p - lo);
-        ncand += (uint32_t)__builtin_popcountll(m);
-      }
-      // the candidates' whole headers, up to 64 at once, a lane each (light_validate); the first that passes is looked at once more
-      // by the wavefront as the decoder will read it
-      if (ncand >= 64 || (ncand && p0 + 64 >= hi)) {
-        __syncthreads();
-        for (uint32_t base = 0; base < ncand && found == ~0ull; base += 64) {
-          const uint32_t ci = base + (uint32_t)lane;
-          const bool good = ci < ncand && light_validate(in, nbytes, lo + cand[ci < ncand ? ci : 0]);
-          uint64_t g = __ballot(good);
-          tried += ncand - base < 64 ? ncand - base : 64;
-          while (g) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(g);
-            g &= g - 1;
-            const uint64_t q = lo + cand[base + l];
-            if (validate_block_start(ex, sh, in, nbytes, q)) { found = q; break; }
-          }
-        }
-        __syncthreads();
-        ncand = 0;
+        if (ok) pre[npre + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)(p - q0);
+        npre += (uint32_t)__builtin_popcountll(m);
+        if (npre >= 64) code_lengths_of_queued(q0, 64);
       }
     }
+    if (npre && found == ~0ull) code_lengths_of_queued(q0, npre);  // (the words go: what is queued is looked at now)
+    npre = 0;
   }
+  if (ncand && found == ~0ull) validate_queued();
   if (lane == 0) {
     starts[blockIdx.x] = found;
     info[2 * blockIdx.x] = tried;
@@ -361,7 +383,10 @@ __global__ __launch_bounds__(256) void k_crc_segments(const uint8_t* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 struct InflateConfig {
   uint64_t chunk_bytes = 32u << 10;   // compressed bytes per job of a gzip stream
-  uint64_t stage_bytes = 176u << 20;  // compressed bytes per stage (~5600 jobs: what 256 CUs hold at once)
+  // compressed bytes per stage.  0 = sized by the device: jobs take about the same time each, so a launch runs in ROUNDS of as many
+  // jobs as the chip holds at once (16 per CU, bounded by LDS: 4096 on 256 CUs) and a stage of 1.4 rounds costs two — a stage is
+  // what is left of the file cut into equal parts of at most one round of jobs, at the jobs per byte the stages before it had
+  uint64_t stage_bytes = 0;
   uint32_t ratio = 10;                // symbols reserved per compressed byte of a job (a job that needs more is decoded again)
   // launches of at least this many jobs decode a job per LANE (k_inflate_lanes) instead of a job per wavefront.  OFF by default: measured
   // (profiles/r05/inflate_lanes.txt) a round of the 64 side-by-side decoders takes ~3.5 us whatever the number of jobs — every lane's
@@ -371,7 +396,19 @@ struct InflateConfig {
   int on = 1;                         // .gz files of the streaming entry points take the device inflater
 };
 static InflateConfig g_cfg;
+constexpr uint64_t kFindParts = 2;  // workgroups of k_find_block_starts per chunk
 static mg_inflate_counters g_cnt;
+static uint64_t round_of_jobs() {  // jobs the device decodes at once (a job per wavefront)
+  static uint64_t v = 0;
+  if (!v) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_inflate<uint16_t>), 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    v = (uint64_t)per_cu * (uint64_t)prop.multiProcessorCount;
+  }
+  return v;
+}
 InflateConfig& inflate_cfg() { return g_cfg; }
 bool inflate_dev_enabled() { return g_cfg.on != 0; }
 
@@ -587,6 +624,15 @@ struct DevInflater {
   uint32_t x2n[32];
   std::vector<std::pair<uint64_t, uint32_t>> x8n_cache;  // (length, x^(8 length) mod p)
 
+  uint64_t seen_jobs = 0, seen_bytes = 0;  // of the stages so far: the jobs a compressed byte makes
+  uint64_t stage_size() const {
+    if (g_cfg.stage_bytes) return g_cfg.stage_bytes;
+    const uint64_t left = n - std::min<uint64_t>(n, next_bit / 8);
+    const double per_byte = seen_bytes ? (double)seen_jobs / (double)seen_bytes : 1.0 / (double)g_cfg.chunk_bytes;
+    const double room = 0.98 * (double)round_of_jobs();
+    const uint64_t parts = std::max<uint64_t>(1, (uint64_t)std::ceil((double)left * per_byte / room));
+    return std::max<uint64_t>((left + parts - 1) / parts, 1ull << 20);
+  }
   uint64_t headroom = 0;  // bytes left free in front of every stage's text (the caller's carried record)
   int open(const uint8_t* host, uint64_t nbytes, int upload_threads, uint64_t headroom_) {
     h = host;
@@ -823,10 +869,10 @@ struct DevInflater {
     pg.final = final;
     pg.t_begin = now_s();
     const uint64_t margin = 4ull << 20;
-    const uint64_t chunk_bits = ((g_cfg.chunk_bytes + 7) & ~7ull) * 8;
+    const uint64_t chunk_bits = ((g_cfg.chunk_bytes + 8 * kFindParts - 1) / (8 * kFindParts)) * (64 * kFindParts);  // (every part on the 64-bit grid)
     uint64_t limit_bit = ~0ull;  // the last job stops at the first block boundary at or behind it
     {
-      const uint64_t stage_end = (next_bit / 8 + g_cfg.stage_bytes) * 8;
+      const uint64_t stage_end = (next_bit / 8 + stage_size()) * 8;
       const uint64_t safe_end = final ? avail * 8 : (avail > margin ? (avail - margin) * 8 : 0);
       if (!final || stage_end < safe_end) limit_bit = std::min(stage_end, safe_end);
       if (limit_bit != ~0ull && limit_bit <= next_bit + 64) {
@@ -845,18 +891,31 @@ struct DevInflater {
     const double t_find0 = now_s();
     if (nchunks > 1) {
       DevBuf dstarts, dinfo;
-      MG_TRY(dstarts.alloc((nchunks - 1) * 8));
-      MG_TRY(dinfo.alloc((nchunks - 1) * 8));
-      {
-        ProfScope ps("k_find_block_starts", st);
-        k_find_block_starts<<<(unsigned)(nchunks - 1), 64, 0, st>>>(comp.as<uint32_t>(), avail, grid0, chunk_bits, next_bit, scan_end, dstarts.as<uint64_t>(), dinfo.as<uint32_t>());
+      const uint64_t nparts = (nchunks - 1) * kFindParts;
+      MG_TRY(dstarts.alloc(nparts * 8));
+      MG_TRY(dinfo.alloc(nparts * 8));
+      std::vector<uint64_t> found_at(nparts);
+      std::vector<uint32_t> info(2 * nparts);
+      starts.assign(nchunks - 1, ~0ull);
+      // strict first (mg_inflate_core.h, probe_bits: only headers as encoders write them); a stage that finds next to nothing that
+      // way — a writer that pads its length lists — is searched again by the format's rules alone
+      for (int strict = dbg("inflate_loose_find") ? 0 : 1; strict >= 0; --strict) {
+        {
+          ProfScope ps("k_find_block_starts", st);
+          k_find_block_starts<<<(unsigned)nparts, 64, 0, st>>>(comp.as<uint32_t>(), avail, grid0, chunk_bits, next_bit, scan_end, dstarts.as<uint64_t>(), dinfo.as<uint32_t>(), strict, (int)kFindParts);
+        }
+        MG_HIP(hipMemcpyAsync(found_at.data(), dstarts.p, nparts * 8, hipMemcpyDeviceToHost, st));
+        MG_HIP(hipMemcpyAsync(info.data(), dinfo.p, nparts * 8, hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+        uint64_t found = 0;
+        for (uint64_t c = 0; c + 1 < nchunks; ++c) {  // a chunk's first start: of its first part that has one
+          starts[c] = ~0ull;
+          for (uint64_t q = 0; q < kFindParts && starts[c] == ~0ull; ++q) starts[c] = found_at[c * kFindParts + q];
+          found += starts[c] != ~0ull;
+        }
+        if (!strict || nchunks - 1 < 8 || found * 4 >= nchunks - 1) break;
       }
-      starts.resize(nchunks - 1);
-      std::vector<uint32_t> info(2 * (nchunks - 1));
-      MG_HIP(hipMemcpyAsync(starts.data(), dstarts.p, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
-      MG_HIP(hipMemcpyAsync(info.data(), dinfo.p, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
-      MG_HIP(hipStreamSynchronize(st));
-      for (uint64_t c = 0; c + 1 < nchunks; ++c) { g_cnt.find_candidates += info[2 * c]; g_cnt.find_steps += info[2 * c + 1]; }
+      for (uint64_t c = 0; c < nparts; ++c) { g_cnt.find_candidates += info[2 * c]; g_cnt.find_steps += info[2 * c + 1]; }
     }
     g_cnt.find_s += now_s() - t_find0;
     // 2. jobs: from every start to the next one
@@ -872,6 +931,9 @@ struct DevInflater {
         L.jobs[i].stop_bit = i + 1 < L.jobs.size() ? L.jobs[i + 1].start_bit : limit_bit;
         const uint64_t span_end = i + 1 < L.jobs.size() ? L.jobs[i + 1].start_bit : scan_end;
         caps[i] = ((span_end - L.jobs[i].start_bit) / 8 + 1) * g_cfg.ratio + 4096;
+        // (the stage's last job runs on to the first block boundary BEHIND the limit: room for a block more, or every stage has a
+        // job that counts on and is decoded a second time, alone on the device)
+        if (i + 1 == L.jobs.size() && limit_bit != ~0ull) caps[i] += 2 * g_cfg.chunk_bytes * g_cfg.ratio;
       }
       events_.clear();
       MG_TRY(launch_jobs(&L, caps, final, avail));
@@ -888,6 +950,26 @@ struct DevInflater {
     const double t_begin = pg.t_begin, t_dec0 = pg.t_dec0;
     std::deque<Launch>& launches = pg.launches;
     MG_TRY(collect_jobs(&launches[0], &events_, 0));
+    // jobs that needed more room than was reserved: all of them again in ONE launch (they counted what they need)
+    std::vector<uint32_t> again_of(launches[0].jobs.size(), ~0u);
+    {
+      std::vector<uint64_t> caps;
+      std::vector<Job> again;
+      for (size_t j = 0; j < launches[0].jobs.size(); ++j)
+        if (launches[0].res[j].overflow) {
+          again_of[j] = (uint32_t)again.size();
+          again.push_back(launches[0].jobs[j]);
+          caps.push_back(launches[0].res[j].out_count + 64);
+        }
+      if (!again.empty()) {
+        g_cnt.redone += again.size();
+        launches.emplace_back();
+        launches.back().jobs = again;
+        MG_TRY(run_launch(&launches.back(), caps, final, avail, &events_, (uint32_t)launches.size() - 1));
+      }
+    }
+    const bool trace = dbg("inflate_trace") != 0;
+    if (trace) std::fprintf(stderr, "[inflate] stage at bit %llu: %zu jobs, %zu decoded again for room\n", (unsigned long long)next_bit, launches[0].jobs.size(), launches.size() > 1 ? launches[1].jobs.size() : (size_t)0);
     // 3. the chain: every job must have ended where the next one started
     struct Link { uint32_t launch, job; };
     std::vector<Link> chain;
@@ -898,7 +980,12 @@ struct DevInflater {
       for (;;) {
         Launch& L = launches[li];
         Result& r = L.res[ji];
-        if (r.overflow) {  // more symbols than were reserved: again, with room for what it counted
+        if (r.overflow && li == 0 && again_of[ji] != ~0u) {  // more symbols than were reserved: decoded again above
+          li = 1;
+          ji = again_of[ji];
+          continue;
+        }
+        if (r.overflow) {
           launches.emplace_back();
           Launch& R = launches.back();
           R.jobs.push_back(launches[li].jobs[ji]);
@@ -925,6 +1012,7 @@ struct DevInflater {
           continue;
         }
         // a hole: nobody started where this job ended
+        if (trace) std::fprintf(stderr, "[inflate] hole at bit %llu (the next start: %lld bits on)\n", (unsigned long long)end, main_next < launches[0].jobs.size() ? (long long)(launches[0].jobs[main_next].start_bit - end) : -1ll);
         launches.emplace_back();
         Launch& R = launches.back();
         const uint64_t stop = main_next < launches[0].jobs.size() ? launches[0].jobs[main_next].start_bit : limit_bit;
@@ -1033,6 +1121,8 @@ struct DevInflater {
     }
     g_cnt.resolve_s += now_s() - t_res0;
     const Launch& LL = launches[chain.back().launch];
+    seen_jobs += chain.size();
+    seen_bytes += (LL.res[chain.back().job].end_bit - next_bit) / 8;
     next_bit = LL.res[chain.back().job].end_bit;
     first = false;
     text_base_ += total;
@@ -1057,7 +1147,7 @@ struct DevInflater {
     pending = true;
     if (bgzf) return bz_begin(768ull << 20);
     // a stage needs its own compressed bytes and a little more (its last job reads on to the end of its block)
-    const uint64_t avail = std::min<uint64_t>(n, next_bit / 8 + g_cfg.stage_bytes + (8ull << 20));
+    const uint64_t avail = std::min<uint64_t>(n, next_bit / 8 + stage_size() + (8ull << 20));
     return gz_begin(avail, avail == n);
   }
   int finish(DevBuf* text, uint64_t* ntext, bool* finished) {
@@ -1156,6 +1246,8 @@ int mg_inflate_config(int64_t chunk_bytes, int64_t stage_bytes, int ratio, int o
   if (stage_bytes > 0) {
     if (stage_bytes < 4096) return fail(MG_ERR_ARG, "inflate stages of at least 4096 bytes");
     g_cfg.stage_bytes = (uint64_t)stage_bytes;
+  } else if (stage_bytes < 0) {
+    g_cfg.stage_bytes = 0;  // sized by the device
   }
   if (ratio > 0) g_cfg.ratio = (uint32_t)ratio;
   if (on >= 0) g_cfg.on = on;

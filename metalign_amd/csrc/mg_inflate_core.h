@@ -48,7 +48,7 @@ constexpr int DB = 8;                    // ... of the distance table
 constexpr uint32_t kBatchSyms = 256;     // symbols queued per batch
 constexpr uint32_t kBatchBytes = 4096;   // output bytes per batch (bitmap of 64 x 64 bits)
 constexpr uint32_t kWindow = 32768;
-constexpr uint32_t kInWords = 128;       // compressed words staged in LDS for the window decode
+constexpr uint32_t kInWords = 64;        // compressed words staged in LDS for the window decode
 constexpr uint32_t kStepBits = 256;      // bit positions one window step looks at (four per lane)
 constexpr uint32_t kStepSyms = 64;       // ... and the symbols it takes at most
 
@@ -102,7 +102,7 @@ struct Event {                   // a member ended inside a job (not F_ONE_MEMBE
 struct Shared {
   uint32_t lit[1 << LB];
   uint32_t dist[1 << DB];
-  uint32_t cnt[2][16], first[2][16], offs[2][16];
+  uint16_t cnt[2][16], first[2][16], offs[2][16];  // (16 bits each: with the 64-word stage a job takes 10 064 bytes of LDS — SIXTEEN per CU)
   uint16_t sorted[320];          // symbols by (length, symbol): [0, 288) literal/length, [288, 320) distance
   uint32_t nshort, err;
   union {
@@ -1444,10 +1444,20 @@ struct LaneDec {
 // Could a dynamic-Huffman block with BFINAL = 0 begin at bit p?  The cheap part, per lane: header fields in range and the
 // code-length code a complete prefix code (what zlib, pigz, libdeflate write; a false negative only costs parallelism).
 // lo / hi: the 128 bits that start at the candidate position
-MGI_HD bool probe_bits(uint64_t lo, uint64_t hi) {
-  if ((lo & 7u) != 4u) return false;  // BFINAL = 0, BTYPE = 2 (bits 1-2, LSB first)
-  if (((lo >> 3) & 31u) > 29u || ((lo >> 8) & 31u) > 29u) return false;
+// strict: the header must also be one an ENCODER writes — zlib, pigz, libdeflate, bgzip and igzip all send as few lengths as they
+// can, so the last length of each of the three lists is not zero (unless the list has its minimum size).  The format does not ask
+// for it: a true start written otherwise is only found with strict = false (the host falls back to that when a stage finds next to
+// nothing).  It is what keeps FALSE starts rare — a false start in front of the true one of its chunk hides it, and the text between
+// the two jobs around it then takes a launch of its own (measured: 3 in 16 000 chunks without this rule, ~4 ms each).
+// (in two parts: one position in nine passes the first, and the finder runs the second — fifty times the instructions — only on
+// those, sixty-four of them at a time)
+MGI_HD bool probe_fields(uint64_t lo) {
+  // BFINAL = 0, BTYPE = 2 (bits 1-2, LSB first); at most 286 literal/length and 30 distance codes
+  return (lo & 7u) == 4u && ((lo >> 3) & 31u) <= 29u && ((lo >> 8) & 31u) <= 29u;
+}
+MGI_HD bool probe_code_lengths(uint64_t lo, uint64_t hi, bool strict = true) {
   const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
+  if (strict && ncl > 4u && ((((lo >> 17) | (hi << 47)) >> (3u * (ncl - 1u))) & 7u) == 0u) return false;
   // the 3-bit lengths as three words of up to eight (24 bits each), those behind the ncl-th zeroed; a length l weighs
   // 64 >> (l - 1), and l = 0 shifts everything out (the shift count wraps to 31)
   const uint64_t all = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * ncl)) - 1ull);
@@ -1457,17 +1467,18 @@ MGI_HD bool probe_bits(uint64_t lo, uint64_t hi) {
     for (uint32_t i = 0; i < (w < 2 ? 8u : 3u); ++i) kraft += 64u >> ((((f[w] >> (3u * i)) & 7u) - 1u) & 31u);
   return kraft == 128u;
 }
-MGI_HD bool probe_block_start(const uint32_t* in, uint64_t nwords, uint64_t p) {
+MGI_HD bool probe_bits(uint64_t lo, uint64_t hi, bool strict = true) { return probe_fields(lo) && probe_code_lengths(lo, hi, strict); }
+MGI_HD bool probe_block_start(const uint32_t* in, uint64_t nwords, uint64_t p, bool strict = true) {
   const uint64_t w = p >> 5;
   const uint32_t s = (uint32_t)p & 31u;
   uint32_t a[4];
   for (uint32_t i = 0; i < 4; ++i) a[i] = w + i < nwords ? in[w + i] : 0u;
   const uint64_t x0 = a[0] | (uint64_t)a[1] << 32, x1 = a[2] | (uint64_t)a[3] << 32;
-  return probe_bits(s ? (x0 >> s) | (x1 << (64 - s)) : x0, x1 >> s);
+  return probe_bits(s ? (x0 >> s) | (x1 << (64 - s)) : x0, x1 >> s, strict);
 }
 // ... and the whole header (uniform): the code lengths decode, both codes are complete (or there is at most one distance code)
 template <class Exec>
-MGI_HD bool validate_block_start(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, uint64_t p) {
+MGI_HD bool validate_block_start(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, uint64_t p, bool strict = true) {
   BitReader br;
   br.init(in, (nbytes + 3) / 4, p);
   br.refill();
@@ -1475,6 +1486,10 @@ MGI_HD bool validate_block_start(Exec& ex, Shared& sh, const uint32_t* in, uint6
   uint32_t nlit = 0, ndist = 0;
   if (read_dynamic_lengths(ex, sh, br, &nlit, &ndist)) return false;
   if (br.pos() > nbytes * 8) return false;
+  if (strict) {
+    const uint32_t last_lit = MGI_UNI(sh.cl[nlit - 1]), last_dist = MGI_UNI(sh.cl[nlit + ndist - 1]);
+    if ((nlit > 257 && !last_lit) || (ndist > 1 && !last_dist)) return false;
+  }
   if (build_table(ex, sh, 0, 0, nlit, false, true)) return false;
   if (build_table(ex, sh, 1, nlit, ndist, false, true)) return false;
   return true;
@@ -1483,7 +1498,7 @@ MGI_HD bool validate_block_start(Exec& ex, Shared& sh, const uint32_t* in, uint6
 // The same decision as validate_block_start by ONE lane, in registers only (the finder validates up to 64 candidates at once): the
 // code-length code decoded canonically (at most seven compares per symbol), the Kraft sums of both codes kept as the lengths arrive —
 // an over-subscribed code is refused at once.
-MGI_HD bool light_validate(const uint32_t* in, uint64_t nbytes, uint64_t p) {
+MGI_HD bool light_validate(const uint32_t* in, uint64_t nbytes, uint64_t p, bool strict = true) {
   BitReaderT<false> br;
   br.init(in, (nbytes + 3) / 4, p);
   br.refill();
@@ -1552,6 +1567,7 @@ MGI_HD bool light_validate(const uint32_t* in, uint64_t nbytes, uint64_t p) {
     }
     if (i + rep > total) return false;
     if (sym != 16) prev = val;
+    if (strict && !val && ((i < nlit && nlit <= i + rep && nlit > 257) || (i + rep == total && ndist > 1))) return false;  // (a last length of zero)
     if (val) {
       // (a run may cross from the literal/length lengths into the distance lengths)
       const uint32_t a = i < nlit ? (i + rep < nlit ? rep : nlit - i) : 0u;

@@ -160,6 +160,13 @@ static int check_entered(const char* what, const std::string& text, const std::s
     // first plausible block start at or behind `from`, inside the next step_bytes
     uint64_t found = ~0ull;
     for (uint64_t p = from; p < from + step_bytes * 8 && p + 64 < gz.size() * 8; ++p) {
+      if (probe_block_start(in.w.data(), in.w.size(), p, false)) {  // by the format's rules alone (the finder's second try)
+        const bool loose = validate_block_start(ex, g_sh, in.w.data(), in.nbytes, p, false);
+        CHECK(light_validate(in.w.data(), in.nbytes, p, false) == loose, "%s: the two validators disagree (loose) at bit %llu (%d)", what, (unsigned long long)p, (int)loose);
+        CHECK(loose || !validate_block_start(ex, g_sh, in.w.data(), in.nbytes, p), "%s: strict accepts what loose refuses at bit %llu", what, (unsigned long long)p);
+      } else {
+        CHECK(!probe_block_start(in.w.data(), in.w.size(), p), "%s: the strict probe accepts what the loose one refuses at bit %llu", what, (unsigned long long)p);
+      }
       if (!probe_block_start(in.w.data(), in.w.size(), p)) continue;
       const bool heavy = validate_block_start(ex, g_sh, in.w.data(), in.nbytes, p);
       CHECK(light_validate(in.w.data(), in.nbytes, p) == heavy, "%s: the two validators disagree at bit %llu (%d)", what, (unsigned long long)p, (int)heavy);

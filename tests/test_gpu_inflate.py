@@ -40,7 +40,7 @@ def cfg(hip, request):
     """Both decoders on every case: launches of any size decode a job per lane (lane_jobs = 0) or a job per wavefront (never per lane)."""
     hip.inflate_config(lane_jobs=0 if request.param == "job per lane" else 1 << 40)
     yield hip
-    hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=176 << 20, ratio=10, on=1, lane_jobs=1 << 40)
+    hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=-1, ratio=10, on=1, lane_jobs=1 << 40)
 
 
 def _same(hip, blob, want, what):

@@ -69,6 +69,8 @@ def main():
            "qualities": "binned, random" if realistic else "constant"}
     assert zlib.decompress(gz[: 50 << 20] if False else gz, 47)[:1000] == text[:1000].tobytes()
     hip = _hip.Hip.get(0)
+    if os.environ.get("MG_INFLATE_TRACE"):  # every stage's jobs, the jobs decoded twice and the holes of the chain on stderr
+        _hip.debug_set("inflate_trace", 1)
     k = 51
     dbh, dbo = hip.sketch_genomes(gb, go, k, 1000)
     hmax = int(dbh.max())
