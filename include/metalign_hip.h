@@ -497,6 +497,12 @@ int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts,
  *   holds the sketches' k-mers beside their hashes: local_tests/dump_kmers.py:7-14), 2-bit packed, first base most
  *   significant, right-aligned in (hi, lo): mode 0 the lexicographically smaller strand, mode 1 the strand with the smaller
  *   MurmurHash3 (the reverse complement on a tie); of the FIRST window of the genome that has the hash.
+ * mg_sketch_genomes_kmers_forward (`build_db --sketch_hash forward`): CMash's TRAINING without reverse complements, as
+ *   recollected and unverifiable here: a genome's entries are its k-mers with the n smallest distinct
+ *   MurmurHash3(k-mer as it stands in the genome) mod 9999999999971, kept as they stand (first window of a value);
+ *   out_hashes = what each entry MATCHES by — its hash under the mode in force (canonical k-mer / min of the two strands) —
+ *   in the order of the selecting hashes: not ascending, and a genome that holds a k-mer and its reverse complement carries
+ *   the same value twice (two k-mers of the sketch, both counted).  For the k of hash mode 1's list.
  * mg_refdb_build: from those genome-major entries of the LARGEST k (ks[nk-1]; ks ascending, nk <= 4), on the device: the
  *   hash-major pairs of k_max and, per k below it, pa / pb per pair (the number — rank among the table's distinct
  *   k-prefixes — of the kept k-mer's k-prefix / of its reverse complement's, 0xffffffff when that is no prefix of the
@@ -508,6 +514,8 @@ int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts,
 typedef struct mg_refdb mg_refdb;
 int mg_sketch_genomes_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
                             uint64_t* out_hashes, uint64_t* out_kmer_hi, uint64_t* out_kmer_lo, uint64_t* out_offsets);
+int mg_sketch_genomes_kmers_forward(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                                    uint64_t* out_hashes, uint64_t* out_kmer_hi, uint64_t* out_kmer_lo, uint64_t* out_offsets);
 int mg_refdb_build(const uint64_t* hashes, const uint64_t* kmer_hi, const uint64_t* kmer_lo, const uint64_t* offsets,
                    uint64_t ngenomes, int nk, const int* ks, mg_refdb** out);
 int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash,

@@ -40,7 +40,7 @@ EXPORTS = [
     "mg_inflate_dev", "mg_inflated_bytes", "mg_inflated_download", "mg_inflated_free", "mg_inflate_config", "mg_inflate_stats",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
-    "mg_sketch_genomes_kmers", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
+    "mg_sketch_genomes_kmers", "mg_sketch_genomes_kmers_forward", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
     "mg_refdb_ngenomes", "mg_refdb_max_hash", "mg_refdb_kmax_table", "mg_refdb_free", "mg_refpipe_containment_dev", "mg_refpipe_mark_dev",
     "mg_refpipe_count_dev", "mg_refdb_marks",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
@@ -1212,17 +1212,21 @@ class Hip:
                                                     _np(out_h, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
         return out_h[: int(out_o[-1])].copy(), out_o
 
-    def sketch_genomes_kmers(self, bases, offsets, k, n):
+    def sketch_genomes_kmers(self, bases, offsets, k, n, sketch_hash="canonical"):
         """mg_sketch_genomes plus every sketch entry's k-mer as the table keeps it, 2-bit packed (the reference pipeline's
-        table is built from these: refdb_build).  -> (hashes, kmer_hi, kmer_lo, offsets[G+1])"""
+        table is built from these: refdb_build).  -> (hashes, kmer_hi, kmer_lo, offsets[G+1]).  sketch_hash = "forward"
+        (mg_sketch_genomes_kmers_forward): the entries are SELECTED by MurmurHash3(k-mer as it stands) mod 9999999999971 and kept as
+        they stand; `hashes` is still what they match by (not ascending within a genome then, and not necessarily distinct)."""
+        if sketch_hash not in ("canonical", "forward"):
+            raise ValueError("sketch_hash: 'canonical' or 'forward'")
+        fn = self.lib.mg_sketch_genomes_kmers_forward if sketch_hash == "forward" else self.lib.mg_sketch_genomes_kmers
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         g = len(offsets) - 1
         out_h, out_hi, out_lo = (np.zeros(max(g * n, 1), dtype=np.uint64) for _ in range(3))
         out_o = np.zeros(g + 1, dtype=np.uint64)
-        self._chk(self.lib.mg_sketch_genomes_kmers(_np(bases, ctypes.c_uint8), _np(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
-                                                   ctypes.c_int(k), ctypes.c_uint64(n), _np(out_h, ctypes.c_uint64),
-                                                   _np(out_hi, ctypes.c_uint64), _np(out_lo, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
+        self._chk(fn(_np(bases, ctypes.c_uint8), _np(offsets, ctypes.c_uint64), ctypes.c_uint64(g), ctypes.c_int(k), ctypes.c_uint64(n),
+                     _np(out_h, ctypes.c_uint64), _np(out_hi, ctypes.c_uint64), _np(out_lo, ctypes.c_uint64), _np(out_o, ctypes.c_uint64)))
         e = int(out_o[-1])
         return out_h[:e].copy(), out_hi[:e].copy(), out_lo[:e].copy(), out_o
 

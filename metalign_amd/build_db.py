@@ -30,11 +30,14 @@ def genome_bases(path):
     return np.concatenate(parts)
 
 
-def build_reference_pipeline(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0):
+def build_reference_pipeline(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mode=0, sketch_hash='canonical'):
     """The table of the REFERENCE PIPELINE (formats.py, version 3): the genomes are sketched at the LARGEST k only, with their
     k-mers kept (CMash: MakeStreamingDNADatabase.py -n 1000 -k 60, /root/reference/local_tests/retrain_and_test_metalign.sh:49),
     and what derives the smaller k's columns from the matched k_max-mers is prepared on the device (mg_refdb_build) — the role
-    of the prefix tree inside CMash's database and of the KMC dump of the sketches' k-mers (:59-66)."""
+    of the prefix tree inside CMash's database and of the KMC dump of the sketches' k-mers (:59-66).
+    sketch_hash = 'forward': a genome's entries are SELECTED by MurmurHash3(k-mer as it stands) % 9999999999971 and kept as they
+    stand — CMash's training without reverse complements, as recollected (unverified: DESIGN.md §2); what an entry matches by is
+    unchanged (hash_mode), so the query side is the same."""
     hip = _hip.Hip.get()
     previous = hip.hash_mode
     hip.set_hash_mode(hash_mode)
@@ -53,7 +56,7 @@ def build_reference_pipeline(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mo
             o = np.zeros(len(seqs) + 1, dtype=np.uint64)
             o[1:] = np.cumsum([len(s) for s in seqs])
             bases = np.concatenate(seqs) if total else np.zeros(1, np.uint8)
-            h, hi, lo, go = hip.sketch_genomes_kmers(bases, o, ks[-1], n)
+            h, hi, lo, go = hip.sketch_genomes_kmers(bases, o, ks[-1], n, sketch_hash=sketch_hash)
             hs.append(h)
             his.append(hi)
             los.append(lo)
@@ -70,7 +73,7 @@ def build_reference_pipeline(paths, out_dir, ks, n, batch_bases=1 << 27, hash_mo
         f = hip.filter_build(arrays["pair_hash"])
         bits = f.download()
         f.free()
-        formats.write_refpipe_table(out_dir, names, n, arrays, bits, hash_mode=hash_mode)
+        formats.write_refpipe_table(out_dir, names, n, arrays, bits, hash_mode=hash_mode, sketch_hash=sketch_hash)
         return arrays
     finally:
         hip.set_hash_mode(previous)
@@ -143,7 +146,13 @@ def main(argv=None):
                    help="Build the table for stage A/B wired as the reference wires KMC and CMash (select_db.py:50-59,73-76): reads are "
                         "sketched at the largest k only, every smaller k's column comes from the k-prefixes of the matched k_max-mers. "
                         "Works with either --hash_mode.")
+    p.add_argument('--sketch_hash', choices=['canonical', 'forward'], default='canonical',
+                   help="with --reference_pipeline: what SELECTS a genome's n k-mers. canonical (default): the hash they match by "
+                        "(--hash_mode). forward: MurmurHash3(k-mer as it stands in the genome) %% 9999999999971, the k-mer kept as it "
+                        "stands - CMash's training without reverse complements as recollected (unverified).")
     a = p.parse_args(argv)
+    if a.sketch_hash != 'canonical' and not a.reference_pipeline:
+        p.error('--sketch_hash forward needs --reference_pipeline')
     if a.prefix_tables and a.hash_mode != 'cmash':
         p.error('--prefix_tables needs --hash_mode cmash')
     if a.prefix_tables and a.reference_pipeline:
@@ -158,7 +167,7 @@ def main(argv=None):
     if a.reference_pipeline:
         if len(ks) > 4:
             p.error('--reference_pipeline takes at most four k')
-        build_reference_pipeline(paths, a.out_dir, ks, a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0)
+        build_reference_pipeline(paths, a.out_dir, ks, a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0, sketch_hash=a.sketch_hash)
         return
     build(paths, a.out_dir, ks, a.num_hashes, hash_mode=1 if a.hash_mode == 'cmash' else 0, prefix_tables=a.prefix_tables)
 

@@ -58,9 +58,9 @@ __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __rest
   uint64_t hi = lo + part_bits;
   if (hi > limit_bit) hi = limit_bit;
   uint64_t found = ~0ull;
-  uint32_t ncand = 0, npre = 0, tried = 0, nsteps = 0;
+  uint32_t ncand = 0, tried = 0, nsteps = 0;
   __shared__ uint32_t words[72];  // 2048 bit positions and what the last of them look at
-  __shared__ uint16_t pre[128];   // positions (behind q0) whose header FIELDS are possible, ascending: their code lengths 64 at a time
+  __shared__ uint16_t pre[2048];  // positions (behind q0) whose header FIELDS are possible, ascending: their code lengths 64 at a time
   // the candidates' whole headers, up to 64 at once, a lane each (light_validate: the decision of validate_block_start — the host
   // check holds the two against each other at every position — in registers, so that this kernel needs none of the decoder's LDS
   // and a stage's chunks are all resident at once)
@@ -76,10 +76,9 @@ __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __rest
     __syncthreads();
     ncand = 0;
   };
-  // the first `take` queued positions: the code-length code of each (a lane each) -> the candidates
-  auto code_lengths_of_queued = [&](uint64_t q0, uint32_t take) {
-    __syncthreads();
-    const uint32_t off = pre[(uint32_t)lane < take ? lane : 0];
+  // `take` queued positions from pre[base]: the code-length code of each (a lane each) -> the candidates
+  auto code_lengths_of_queued = [&](uint64_t q0, uint32_t base, uint32_t take) {
+    const uint32_t off = pre[base + ((uint32_t)lane < take ? (uint32_t)lane : 0u)];
     const uint32_t i = off >> 5, sft = off & 31u;
     const uint64_t x0 = (uint64_t)words[i] | (uint64_t)words[i + 1] << 32, x1 = (uint64_t)words[i + 2] | (uint64_t)words[i + 3] << 32;
     const uint64_t blo = sft ? (x0 >> sft) | (x1 << (64 - sft)) : x0, bhi = x1 >> sft;
@@ -87,37 +86,33 @@ __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __rest
     const uint64_t m = __ballot(ok);
     if (ok) cand[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)(q0 + off - lo);
     ncand += (uint32_t)__builtin_popcountll(m);
-    // (the rest of the queue moves to its front)
-    const uint32_t rest = npre - take;
-    const uint32_t mv = (uint32_t)lane < rest ? pre[take + lane] : 0u;
-    __syncthreads();
-    if ((uint32_t)lane < rest) pre[lane] = (uint16_t)mv;
-    npre = rest;
     if (ncand >= 64) validate_queued();
   };
+  // positions a candidate may stand at: behind min_bit, below hi, its 80 bits of header inside the input
+  const uint64_t p_lower = min_bit + 1, p_upper = nbits >= 80 ? (hi < nbits - 79 ? hi : nbits - 79) : 0;
   for (uint64_t q0 = lo; q0 < hi && found == ~0ull; q0 += 2048) {
-    // one coalesced load per 32 steps (a step by itself waited for its own five words: the scan was bound by that latency)
     const uint64_t w0 = q0 >> 5;
     __syncthreads();
     words[lane] = w0 + (uint64_t)lane < nwords ? in[w0 + lane] : 0u;
     if (lane < 8) words[64 + lane] = w0 + 64 + (uint64_t)lane < nwords ? in[w0 + 64 + lane] : 0u;
     __syncthreads();
-    for (uint32_t t2 = 0; t2 < 32 && q0 + 64ull * t2 < hi && found == ~0ull; ++t2) {
-      ++nsteps;
-      const uint64_t p0 = q0 + 64ull * t2;
-      const uint32_t i = 2u * t2 + ((uint32_t)lane >> 5), sft = (uint32_t)lane & 31u;
-      const uint64_t x0 = (uint64_t)words[i] | (uint64_t)words[i + 1] << 32;
-      const uint64_t p = p0 + (uint64_t)lane;
-      const bool ok = p < hi && p > min_bit && p + 80 <= nbits && probe_fields(x0 >> sft);
-      const uint64_t m = __ballot(ok);
-      if (m) {
-        if (ok) pre[npre + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)(p - q0);
-        npre += (uint32_t)__builtin_popcountll(m);
-        if (npre >= 64) code_lengths_of_queued(q0, 64);
-      }
+    nsteps += (uint32_t)(((hi - q0 < 2048 ? hi - q0 : 2048) + 63) / 64);
+    // the header's fields at the lane's 32 positions, all at once (probe_fields_mask) -> the queue, in ascending order
+    const uint64_t pb = q0 + 32ull * (uint64_t)lane;
+    const uint32_t from = p_lower > pb ? (p_lower - pb < 32 ? (uint32_t)(p_lower - pb) : 32u) : 0u;
+    const uint32_t to = p_upper > pb ? (p_upper - pb < 32 ? (uint32_t)(p_upper - pb) : 32u) : 0u;
+    const uint32_t in_range = (to >= 32u ? ~0u : (1u << to) - 1u) & ~(from >= 32u ? ~0u : (1u << from) - 1u);
+    uint32_t mask = probe_fields_mask((uint64_t)words[lane] | (uint64_t)words[lane + 1] << 32) & in_range;
+    const uint32_t mine = (uint32_t)__builtin_popcount(mask);
+    const uint32_t incl = DevExec::dpp_inclusive(mine);
+    const uint32_t npre = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t w = incl - mine;
+    while (mask) {
+      pre[w++] = (uint16_t)(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mask));
+      mask &= mask - 1u;
     }
-    if (npre && found == ~0ull) code_lengths_of_queued(q0, npre);  // (the words go: what is queued is looked at now)
-    npre = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < npre && found == ~0ull; base += 64) code_lengths_of_queued(q0, base, npre - base < 64 ? npre - base : 64u);
   }
   if (ncand && found == ~0ull) validate_queued();
   if (lane == 0) {
@@ -396,7 +391,7 @@ struct InflateConfig {
   int on = 1;                         // .gz files of the streaming entry points take the device inflater
 };
 static InflateConfig g_cfg;
-constexpr uint64_t kFindParts = 2;  // workgroups of k_find_block_starts per chunk
+constexpr uint64_t kFindParts = 4;  // workgroups of k_find_block_starts per chunk
 static mg_inflate_counters g_cnt;
 static uint64_t round_of_jobs() {  // jobs the device decodes at once (a job per wavefront)
   static uint64_t v = 0;

@@ -267,6 +267,8 @@ int launch_sketch_reads_cmash(int k, unsigned grid, size_t lds, hipStream_t st, 
                               uint32_t cs_word);
 int launch_hash_positions_cmash(int k, unsigned grid, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nseq,
                                 uint64_t nbases, uint64_t* d_out, bool tagged = false);
+int launch_hash_positions_forward(int k, unsigned grid, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nseq,
+                                  uint64_t nbases, uint64_t* d_out);
 bool sketch_reads_multi_supported(const int* ks, int nk);
 int launch_sketch_reads_multi(const int* ks, int nk, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
                               const MultiKTable* tabs, unsigned stage_bytes);

@@ -128,6 +128,10 @@ constexpr int kHashCanonical = 0, kHashCmash = 1;
 // (table builder only: kHashCmash with the kept strand in bit 63 — set when the reverse complement's hash is the smaller or
 // equal one, the strand CMash's CountEstimator.add keeps; mode-1 hashes are below 2^44)
 constexpr int kHashCmashTagged = 2;
+// (table builder only, `build_db --sketch_hash forward`: MurmurHash3 of the k-mer AS IT STANDS in the genome mod the prime — what
+// selects a genome's sketch when CMash trains without reverse complements, as recollected; what a k-mer MATCHES by stays
+// kHashCanonical / kHashCmash)
+constexpr int kHashForward = 3;
 constexpr uint64_t kCmashPrime = 9999999999971ULL;
 
 // Base decode: A,C,G,T (either case) -> 0..3 (lexicographic order), anything else -> invalid.
@@ -299,6 +303,7 @@ struct Roller {
   // The k-mer's hash under definition HM.  tab: fill_hash_tables().
   template <int HM = kHashCanonical>
   __device__ __forceinline__ uint64_t hash(const uint64_t* tab) const {
+    if constexpr (HM == kHashForward) return murmur3_h1_packed<K>(make_packed(pf_lo, NW == 1 ? 0ull : pf_hi), tab) % kCmashPrime;
     if constexpr (HM == kHashCmash || HM == kHashCmashTagged) {
       const uint64_t a = murmur3_h1_packed<K>(make_packed(pf_lo, NW == 1 ? 0ull : pf_hi), tab);
       const uint64_t b = murmur3_h1_packed<K>(make_packed(pr_lo, NW == 1 ? 0ull : pr_hi), tab);

@@ -210,8 +210,10 @@ int mg_refdb_build(const uint64_t* hashes, const uint64_t* kmer_hi, const uint64
   uint64_t mx = 0;
   for (uint64_t g = 0; g < ngenomes; ++g) {
     if (offsets[g + 1] < offsets[g]) return fail(MG_ERR_ARG, "offsets must be non-decreasing");
-    if (offsets[g + 1] > offsets[g] && hashes[offsets[g + 1] - 1] > mx) mx = hashes[offsets[g + 1] - 1];
   }
+  // (every entry: the entries of a genome selected by the forward hash, mg_sketch_genomes_kmers_forward, do not ascend)
+  for (uint64_t e = 0; e < E; ++e)
+    if (hashes[e] > mx) mx = hashes[e];
   T.max_hash = mx;
   MG_TRY(T.offsets.alloc((ngenomes + 1) * sizeof(uint64_t)));
   MG_TRY(T.pair_hash.alloc((E + 1) * sizeof(uint64_t)));

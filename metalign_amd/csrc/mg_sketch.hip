@@ -1769,10 +1769,23 @@ __global__ __launch_bounds__(256) void k_entry_kmers(const uint8_t* __restrict__
       if (2 * i < 64) r_lo |= cc << (2 * i); else r_hi |= cc << (2 * i - 64);
     }
     bool use_rc;
-    if (tagged) use_rc = (pos[p] & kTagBit) != 0;
+    if (tagged == 2) use_rc = false;  // (a sketch selected by the forward hash keeps the k-mer as it stands in the genome)
+    else if (tagged) use_rc = (pos[p] & kTagBit) != 0;
     else use_rc = r_hi < f_hi || (r_hi == f_hi && r_lo < f_lo);
     khi[e] = use_rc ? r_hi : f_hi;
     klo[e] = use_rc ? r_lo : f_lo;
+  }
+}
+
+// A sketch selected by the forward hash: what its entries MATCH by — the hash of the window that ends at first[entry] under the
+// mode in force (ident[p], untagged) — in the place of the hash that selected them.
+__global__ __launch_bounds__(256) void k_entry_identity(const uint64_t* __restrict__ ident, const unsigned long long* __restrict__ first,
+                                                        const uint32_t* __restrict__ cnt, uint64_t nseq, uint64_t n, uint64_t* __restrict__ out) {
+  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; e < nseq * n; e += stride) {
+    const uint64_t g = e / n, slot = e - g * n;
+    if (slot < cnt[g]) out[e] = ident[first[e]];
   }
 }
 
@@ -1861,8 +1874,11 @@ int mg_sketch_genomes_prefix(const uint8_t* bases, const uint64_t* offsets, uint
 }  // extern "C"
 
 // mg_sketch_genomes, and (out_khi / out_klo given) mg_sketch_genomes_kmers
+// forward_select (with the k-mers only): the n smallest MurmurHash3(k-mer as it stands) mod the prime select a genome's entries, the
+// k-mer is kept as it stands, and out_hashes = what it matches by (the mode in force) — neither ascending nor necessarily distinct
+// within a genome (a genome may hold a k-mer and its reverse complement).  oracle: mgo_sketch_genomes_kmers_forward
 static int sketch_genomes_impl(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
-                               uint64_t* out_hashes, uint64_t* out_khi, uint64_t* out_klo, uint64_t* out_offsets) {
+                               uint64_t* out_hashes, uint64_t* out_khi, uint64_t* out_klo, uint64_t* out_offsets, bool forward_select = false) {
   MG_REQUIRE_READY();
   if (!offsets || !out_offsets) return fail(MG_ERR_ARG, "null argument");
   if (k < 1 || k > MG_MAX_K) return fail(MG_ERR_ARG, "k=%d outside [1,%d]", k, MG_MAX_K);
@@ -1890,7 +1906,7 @@ static int sketch_genomes_impl(const uint8_t* bases, const uint64_t* offsets, ui
     uint32_t* d_cnt = (uint32_t*)scratch("g_cnt", ng * sizeof(uint32_t));
     if (!d_bases || !d_off || !d_pos || !d_sorted || !d_out || !d_cnt) return MG_ERR_NOMEM;
     const bool kmers = out_khi != nullptr;
-    const bool tagged = kmers && ctx().hash_mode == kHashCmash;  // the kept strand rides in bit 63 of the position hashes
+    const bool tagged = kmers && !forward_select && ctx().hash_mode == kHashCmash;  // the kept strand rides in bit 63 of the position hashes
     uint64_t* d_key = d_pos;  // what is sorted (the untagged hashes)
     unsigned long long* d_first = nullptr;
     uint64_t *d_khi = nullptr, *d_klo = nullptr;
@@ -1913,7 +1929,9 @@ static int sketch_genomes_impl(const uint8_t* bases, const uint64_t* offsets, ui
       unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
       int crc = MG_OK;
       bool ok = dispatch_k(k, [&]<int K>() {
-        if (ctx().hash_mode == kHashCmash)  // (instantiated in mg_sketch_cmash.hip, for the k of its list)
+        if (forward_select)
+          crc = launch_hash_positions_forward(K, grid, st, d_bases, d_off, ng, nb, d_pos);
+        else if (ctx().hash_mode == kHashCmash)  // (instantiated in mg_sketch_cmash.hip, for the k of its list)
           crc = launch_hash_positions_cmash(K, grid, st, d_bases, d_off, ng, nb, d_pos, tagged);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCanonical>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb,
@@ -1940,7 +1958,20 @@ static int sketch_genomes_impl(const uint8_t* bases, const uint64_t* offsets, ui
       if (nb) {
         hipLaunchKernelGGL(k_first_positions, dim3(g256), dim3(256), 0, st, d_pos, tagged ? 1 : 0, d_off, ng, nb, d_out, d_cnt, n, d_first);
         hipLaunchKernelGGL(k_entry_kmers, dim3(grid_for(ng * n, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_bases, d_pos,
-                           tagged ? 1 : 0, d_first, d_cnt, ng, n, k, d_khi, d_klo);
+                           forward_select ? 2 : tagged ? 1 : 0, d_first, d_cnt, ng, n, k, d_khi, d_klo);
+        if (forward_select) {  // the entries' matching identity: the position hashes of the mode in force (d_sorted is free again)
+          const uint64_t nchunks = (nb + kChunk - 1) / kChunk;
+          unsigned grid = grid_for(nchunks, 256, (unsigned)c.num_cus * 8);
+          int crc = MG_OK;
+          dispatch_k(k, [&]<int K>() {
+            if (ctx().hash_mode == kHashCmash)
+              crc = launch_hash_positions_cmash(K, grid, st, d_bases, d_off, ng, nb, d_sorted, false);
+            else
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashCanonical>), dim3(grid), dim3(256), 0, st, d_bases, d_off, ng, nb, d_sorted);
+          });
+          MG_TRY(crc);
+          hipLaunchKernelGGL(k_entry_identity, dim3(grid_for(ng * n, 256, (unsigned)c.num_cus * 8)), dim3(256), 0, st, d_sorted, d_first, d_cnt, ng, n, d_out);
+        }
       }
       MG_HIP(hipGetLastError());
       h_hi.resize(ng * n);
@@ -1975,6 +2006,12 @@ int mg_sketch_genomes_kmers(const uint8_t* bases, const uint64_t* offsets, uint6
                             uint64_t* out_hashes, uint64_t* out_kmer_hi, uint64_t* out_kmer_lo, uint64_t* out_offsets) {
   if (!out_kmer_hi || !out_kmer_lo) return fail(MG_ERR_ARG, "null argument");
   return sketch_genomes_impl(bases, offsets, ngenomes, k, n, out_hashes, out_kmer_hi, out_kmer_lo, out_offsets);
+}
+
+int mg_sketch_genomes_kmers_forward(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                                    uint64_t* out_hashes, uint64_t* out_kmer_hi, uint64_t* out_kmer_lo, uint64_t* out_offsets) {
+  if (!out_kmer_hi || !out_kmer_lo) return fail(MG_ERR_ARG, "null argument");
+  return sketch_genomes_impl(bases, offsets, ngenomes, k, n, out_hashes, out_kmer_hi, out_kmer_lo, out_offsets, true);
 }
 
 }  // extern "C"

@@ -43,4 +43,13 @@ int launch_hash_positions_cmash(int k, unsigned grid, hipStream_t st, const uint
   return ok ? MG_OK : refuse(k);
 }
 
+// `build_db --sketch_hash forward`: the position hashes that SELECT a genome's sketch (mg_kmer.h, kHashForward), for the same list of k
+int launch_hash_positions_forward(int k, unsigned grid, hipStream_t st, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nseq,
+                                  uint64_t nbases, uint64_t* d_out) {
+  const bool ok = dispatch_listed(k, [&]<int K>() {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hash_positions<K, kHashForward>), dim3(grid), dim3(256), 0, st, d_bases, d_offsets, nseq, nbases, d_out);
+  }, CmashKs());
+  return ok ? MG_OK : fail(MG_ERR_ARG, "sketches selected by the forward hash are built for k in {%s}, not k = %d", kCmashKsText, k);
+}
+
 }  // namespace mg

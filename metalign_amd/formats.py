@@ -101,6 +101,8 @@ class SketchTable:
         # which definition of a k-mer's hash the table was sketched with (include/metalign_hip.h: mg_set_hash_mode);
         # tables written before the field existed are mode 0
         self.hash_mode = int(self.meta.get("hash_mode", 0))
+        # (version 3) what selected a genome's k-mers: "canonical" = the hash they match by; "forward" = build_db --sketch_hash forward
+        self.sketch_hash = str(self.meta.get("sketch_hash", "canonical"))
         self.prefix_tables = bool(self.meta.get("prefix_tables", False))  # mode 1: k < k_max tables of k-prefixes (build_db)
         # "reference_pipeline": only the largest k is sketched on the read side; "sketch_per_k": every k has a table of its own
         self.definition = self.meta.get("stage_a_definition", "sketch_per_k")
@@ -227,7 +229,7 @@ def write_sketch_table(path, names, ks, n, per_k, filters=None, hash_mode=0, pre
         json.dump(meta, fh, indent=1)
 
 
-def write_refpipe_table(path, names, n, table, filter_bits=None, hash_mode=0):
+def write_refpipe_table(path, names, n, table, filter_bits=None, hash_mode=0, sketch_hash="canonical"):
     """Version 3: the reference pipeline's table.  table: what _hip.RefTable.download() returns (dict(ks, pair_hash, pair_gen,
     gsize, kmer_hi, kmer_lo, small={k: dict(pa, pb, cid, cgen, gsize, nprefix)})); filter_bits: the membership pre-filter
     over the largest k's hashes (Filter.download)."""
@@ -253,7 +255,7 @@ def write_refpipe_table(path, names, n, table, filter_bits=None, hash_mode=0):
         put(t["cgen"], "<u4", "k%d.rp_cgen.u32" % k)
         put(t["gsize"], "<u4", "k%d.gsize.u32" % k)
     meta = {"format": TABLE_FORMAT, "version": 3, "n": int(n), "ks": ks, "ngenomes": len(names), "hash_mode": int(hash_mode),
-            "stage_a_definition": "reference_pipeline", "nprefix": {str(k): int(table["small"][k]["nprefix"]) for k in ks[:-1]},
+            "stage_a_definition": "reference_pipeline", "sketch_hash": str(sketch_hash), "nprefix": {str(k): int(table["small"][k]["nprefix"]) for k in ks[:-1]},
             "layout": "hash-major pairs of the largest k + prefix numbers and count lists of the smaller k",
             "hash": "murmur3_x64_128.h1(canonical ASCII k-mer), seed 0" if not hash_mode else
                     "min(murmur3_x64_128.h1(k-mer), murmur3_x64_128.h1(reverse complement)) % 9999999999971"}

@@ -157,9 +157,11 @@ def sketch_genomes_prefix(bases, offsets, kmax, k, n):
     return h[: int(o[-1])].copy(), o
 
 
-def sketch_genomes_kmers(bases, offsets, k, n):
+def sketch_genomes_kmers(bases, offsets, k, n, sketch_hash="canonical"):
     """Stage A' with the k-mers kept (oracle/mg_oracle.c: mgo_sketch_genomes_kmers), under the mode in force.
-    -> (hashes u64[*], kmer_hi u64[*], kmer_lo u64[*], offsets u64[G+1]); the k-mer 2-bit packed, first base most significant."""
+    -> (hashes u64[*], kmer_hi u64[*], kmer_lo u64[*], offsets u64[G+1]); the k-mer 2-bit packed, first base most significant.
+    sketch_hash = "forward": mgo_sketch_genomes_kmers_forward (entries selected by the forward k-mer's hash, kept as they stand)."""
+    fn = lib().mgo_sketch_genomes_kmers_forward if sketch_hash == "forward" else lib().mgo_sketch_genomes_kmers
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     g = len(offsets) - 1
@@ -167,9 +169,8 @@ def sketch_genomes_kmers(bases, offsets, k, n):
     hi = np.zeros(max(g * n, 1), dtype=np.uint64)
     lo = np.zeros(max(g * n, 1), dtype=np.uint64)
     o = np.zeros(g + 1, dtype=np.uint64)
-    rc = lib().mgo_sketch_genomes_kmers(_p(bases, ctypes.c_uint8), _p(offsets, ctypes.c_uint64), ctypes.c_uint64(g),
-                                        ctypes.c_int(k), ctypes.c_uint64(n), _p(h, ctypes.c_uint64), _p(hi, ctypes.c_uint64),
-                                        _p(lo, ctypes.c_uint64), _p(o, ctypes.c_uint64))
+    rc = fn(_p(bases, ctypes.c_uint8), _p(offsets, ctypes.c_uint64), ctypes.c_uint64(g), ctypes.c_int(k), ctypes.c_uint64(n),
+            _p(h, ctypes.c_uint64), _p(hi, ctypes.c_uint64), _p(lo, ctypes.c_uint64), _p(o, ctypes.c_uint64))
     if rc != 0:
         raise RuntimeError("mgo_sketch_genomes_kmers rc=%d" % rc)
     e = int(o[-1])

@@ -429,6 +429,68 @@ int mgo_sketch_genomes_kmers(const uint8_t* bases, const uint64_t* offsets, uint
   return MG_OK;
 }
 
+/* `build_db --sketch_hash forward`: CMash's TRAINING without reverse complements, as recollected (nothing under /root/reference
+ * shows it: parity unpinned like the rest of stage A/B).  A genome's entries: its k-mers with the n smallest distinct values of
+ * MurmurHash3(k-mer as it stands, seed 0).h1 % 9999999999971, the first window of a value, kept as they stand.  out_hashes[i] =
+ * what entry i MATCHES by: the hash of its k-mer under the mode in force (as mgo_sketch_genomes_kmers computes it) — in the order of the
+ * selecting values, so neither ascending nor necessarily distinct within a genome. */
+int mgo_sketch_genomes_kmers_forward(const uint8_t* bases, const uint64_t* offsets, uint64_t ngenomes, int k, uint64_t n,
+                                     uint64_t* out_hashes, uint64_t* out_khi, uint64_t* out_klo, uint64_t* out_offsets) {
+  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
+  uint64_t w = 0;
+  out_offsets[0] = 0;
+  for (uint64_t g = 0; g < ngenomes; ++g) {
+    const uint8_t* seq = bases + offsets[g];
+    const uint64_t len = offsets[g + 1] - offsets[g];
+    hp_entry* v = (hp_entry*)malloc((len + 1) * sizeof(hp_entry));
+    if (!v) return MG_ERR_NOMEM;
+    uint64_t nv = 0, run = 0;
+    for (uint64_t j = 0; j < len; ++j) {
+      run = base_code(seq[j]) >= 0 ? run + 1 : 0;
+      if (run < (uint64_t)k) continue;
+      const uint8_t* win = seq + (j + 1 - (uint64_t)k);
+      char fwd[MG_MAX_K];
+      for (int i = 0; i < k; ++i) fwd[i] = kUpper[base_code(win[i])];
+      uint64_t o[2];
+      mgo_murmur3_x64_128(fwd, k, 0, o);
+      v[nv].h = o[0] % MGO_CMASH_PRIME;
+      v[nv].use_rc = 0;
+      v[nv].pos = j + 1 - (uint64_t)k;
+      ++nv;
+    }
+    if (nv) qsort(v, nv, sizeof(hp_entry), cmp_hp);
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < nv && kept < n; ++i) {
+      if (i > 0 && v[i].h == v[i - 1].h) continue;
+      const uint8_t* win = seq + v[i].pos;
+      uint8_t codes[MG_MAX_K];
+      char fwd[MG_MAX_K], rc[MG_MAX_K];
+      for (int t = 0; t < k; ++t) {
+        int c = base_code(win[t]);
+        codes[t] = (uint8_t)c;
+        fwd[t] = kUpper[c];
+        rc[k - 1 - t] = kUpper[3 - c];
+      }
+      uint64_t o[2], id;
+      if (g_hash_mode == 1) {
+        uint64_t hf, hr;
+        mgo_murmur3_x64_128(fwd, k, 0, o); hf = o[0];
+        mgo_murmur3_x64_128(rc, k, 0, o); hr = o[0];
+        id = (hf < hr ? hf : hr) % MGO_CMASH_PRIME;
+      } else {
+        mgo_murmur3_x64_128(memcmp(fwd, rc, (size_t)k) > 0 ? rc : fwd, k, 0, o);
+        id = o[0];
+      }
+      out_hashes[w] = id;
+      pack_codes(codes, k, &out_khi[w], &out_klo[w]);
+      ++w; ++kept;
+    }
+    free(v);
+    out_offsets[g + 1] = w;
+  }
+  return MG_OK;
+}
+
 typedef struct { uint64_t h; uint32_t g; uint64_t e; } pair_ent;   /* e: index of the entry in the genome-major arrays */
 static int cmp_pair_ent(const void* a, const void* b) {
   const pair_ent* x = (const pair_ent*)a; const pair_ent* y = (const pair_ent*)b;

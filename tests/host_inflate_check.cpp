@@ -160,6 +160,12 @@ static int check_entered(const char* what, const std::string& text, const std::s
     // first plausible block start at or behind `from`, inside the next step_bytes
     uint64_t found = ~0ull;
     for (uint64_t p = from; p < from + step_bytes * 8 && p + 64 < gz.size() * 8; ++p) {
+      if ((p & 31u) == 0) {  // the finder's first test, 32 positions per word operation, against the same test position by position
+        const uint64_t w = p >> 5;
+        const uint64_t x = (uint64_t)in.w[w] | (w + 1 < in.w.size() ? (uint64_t)in.w[w + 1] << 32 : 0ull);
+        const uint32_t mask = probe_fields_mask(x);
+        for (uint32_t i = 0; i < 32; ++i) CHECK(((mask >> i) & 1u) == (probe_fields(x >> i) ? 1u : 0u), "%s: probe_fields_mask differs at bit %llu", what, (unsigned long long)(p + i));
+      }
       if (probe_block_start(in.w.data(), in.w.size(), p, false)) {  // by the format's rules alone (the finder's second try)
         const bool loose = validate_block_start(ex, g_sh, in.w.data(), in.nbytes, p, false);
         CHECK(light_validate(in.w.data(), in.nbytes, p, false) == loose, "%s: the two validators disagree (loose) at bit %llu (%d)", what, (unsigned long long)p, (int)loose);

@@ -170,6 +170,21 @@ def _revcomp(s: bytes) -> bytes:
     return s.translate(_COMP)[::-1]
 
 
+def refpipe_genome_kmers_forward(seq: bytes, kmax: int, n: int):
+    """`build_db --sketch_hash forward`: the kmax-mers of one genome with the n smallest distinct MurmurHash3(k-mer as it stands) %
+    9999999999971, per value the first window, kept AS THEY STAND (CMash's training without reverse complements, as recollected).
+    A genome that holds a k-mer and its reverse complement may list both: two strings of the sketch."""
+    first = {}
+    for m in _RUNS.finditer(seq):
+        run = m.group().upper()
+        for i in range(len(run) - kmax + 1):
+            kmer = run[i:i + kmax]
+            h = murmur3_x64_128(kmer, 0)[0] % CMASH_PRIME
+            if h not in first:
+                first[h] = kmer
+    return [first[h] for h in sorted(first)[:n]]
+
+
 def refpipe_genome_kmers(seq: bytes, kmax: int, n: int):
     """The sketched kmax-mers of one genome as the table keeps them: bottom-n by hash (the definition HASH_MODE selects), per hash
     the first window that has it, oriented as the sketch stores it — mode 0: the lexicographically smaller strand; mode 1: the

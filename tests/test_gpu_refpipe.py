@@ -8,7 +8,7 @@ from util import flat, refpipe_case
 
 pytestmark = pytest.mark.gpu
 
-K_SETS = [[21, 31, 51], [30, 40, 50, 60], [4, 6, 9], [5, 33, 64], [32], [8, 16, 32], [31, 32, 33, 64]]
+K_SETS = [[21, 31, 51], [30, 40, 50, 60], [4, 6, 10], [5, 33, 64], [32], [8, 16, 32], [31, 32, 33, 64]]
 
 
 @pytest.fixture(params=[0, 1], ids=["canonical_kmer_hash", "cmash_recollection"])
@@ -37,11 +37,31 @@ def _same_table(got, want, ks, kmers=True):
 def test_table_and_query_match_the_oracle(hip, oracle_lib, mode, ks):
     rng = np.random.default_rng(9000 + 13 * sum(ks) + mode)
     genomes, reads = refpipe_case(rng)
+    _table_and_query(hip, oracle_lib, ks, genomes, reads, "canonical")
+
+
+@pytest.mark.parametrize("ks", [[21, 31, 51], [30, 40, 50, 60], [4, 6, 10], [32]], ids=str)
+def test_forward_selected_table_and_query_match_the_oracle(hip, oracle_lib, mode, ks):
+    """`build_db --sketch_hash forward` (mg_sketch_genomes_kmers_forward): entries chosen by the hash of the k-mer as it stands and kept
+    as they stand; one genome holds a stretch and its reverse complement — the same matching identity twice in its sketch."""
+    rng = np.random.default_rng(9400 + 13 * sum(ks) + mode)
+    genomes, reads = refpipe_case(rng)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    genomes[3] = genomes[3].upper()[:500] + genomes[3].upper()[100:400].translate(comp)[::-1]
+    for a in range(0, len(genomes[3]) - 150, 40):
+        reads += [genomes[3][a:a + 150]] * 2
+    h, o = _table_and_query(hip, oracle_lib, ks, genomes, reads, "forward")
+    if ks[-1] >= 21:
+        ids = [int(x) for x in h[int(o[3]):int(o[4])]]
+        assert len(ids) > len(set(ids))
+
+
+def _table_and_query(hip, oracle_lib, ks, genomes, reads, sketch_hash):
     kmax, n = ks[-1], 150
     gb, go = flat(genomes)
     # stage A' with the k-mers kept
-    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, kmax, n)
-    oh, ohi, olo, oo = oracle_lib.sketch_genomes_kmers(gb, go, kmax, n)
+    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, kmax, n, sketch_hash=sketch_hash)
+    oh, ohi, olo, oo = oracle_lib.sketch_genomes_kmers(gb, go, kmax, n, sketch_hash=sketch_hash)
     assert np.array_equal(o, oo) and np.array_equal(h, oh)
     assert np.array_equal(khi, ohi) and np.array_equal(klo, olo)
     # the table, built on the device
@@ -80,6 +100,7 @@ def test_table_and_query_match_the_oracle(hip, oracle_lib, mode, ks):
     _same_table(up.download(kmers=False), want, ks, kmers=False)
     for x in (sk, up, table, filt, d_b, d_o):
         x.free()
+    return h, o
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

@@ -242,6 +242,49 @@ def test_reference_pipeline_c_oracle_equals_the_string_restatement(oracle_lib, h
         assert np.all(hits[ki] <= sizes[ki])
 
 
+@pytest.mark.parametrize("ks", [[21, 31, 51], [30, 40, 50, 60], [4, 6, 10], [32]], ids=str)
+def test_forward_selected_sketches_c_oracle_equals_the_string_restatement(oracle_lib, hash_mode, ks):
+    """`build_db --sketch_hash forward`: the entries are chosen by the hash of the k-mer AS IT STANDS and kept as they stand; the query
+    side is unchanged.  One genome holds a stretch and its reverse complement, so a k-mer and its reverse complement are both in its
+    sketch: two strings, one matching identity, both counted."""
+    rng = np.random.default_rng(4400 + 7 * sum(ks) + hash_mode)
+    genomes, reads = _refpipe_case(rng)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    genomes[3] = genomes[3].upper()[:500] + genomes[3].upper()[100:400].translate(comp)[::-1]
+    src = genomes[3]
+    for a in range(0, len(src) - 150, 40):
+        reads += [src[a:a + 150]] * 2
+    kmax, n = ks[-1], 150
+    gb, go = _flat(genomes)
+    h, khi, klo, o = oracle_lib.sketch_genomes_kmers(gb, go, kmax, n, sketch_hash="forward")
+    want_kmers = [ind.refpipe_genome_kmers_forward(g, kmax, n) for g in genomes]
+    twice = 0
+    for g, w in enumerate(want_kmers):
+        got = [_unpack(khi[e], klo[e], kmax) for e in range(int(o[g]), int(o[g + 1]))]
+        assert got == w, g
+        ids = [int(x) for x in h[int(o[g]):int(o[g + 1])]]
+        twice += len(ids) - len(set(ids))
+        # what an entry matches by: the hash of its k-mer under the mode in force, as the canonical sketch computes it
+        for y, v in list(zip(w, ids))[:40]:
+            hf, hr = ind.murmur3_x64_128(y, 0)[0], ind.murmur3_x64_128(ind._revcomp(y), 0)[0]
+            assert v == (min(hf, hr) % ind.CMASH_PRIME if hash_mode == 1 else ind.murmur3_x64_128(min(y, ind._revcomp(y)), 0)[0])
+    if kmax >= 21:
+        assert twice > 0  # (genome 3 lists a k-mer and its reverse complement)
+    table = oracle_lib.refpipe_build(h, khi, klo, o, ks)
+    for k in ks[:-1]:
+        t = table["small"][k]
+        assert t["nprefix"] == len({y[:k] for g in want_kmers for y in g})
+        assert [int(x) for x in t["gsize"]] == [len({y[:k] for y in g}) for g in want_kmers]
+    rb, ro = _flat(reads)
+    for ci in (1, 2):
+        qh, qc, _, _ = oracle_lib.sketch_reads(rb, ro, kmax, hmax=int(h.max()) if len(h) else 0)
+        hits, sizes = oracle_lib.refpipe_containment(qh, qc, ci, table)
+        want = ind.refpipe_query(reads, want_kmers, ks, ci)
+        for ki in range(len(ks)):
+            assert [(int(a), int(b)) for a, b in zip(hits[ki], sizes[ki])] == want[ki], (ks[ki], ci)
+    assert hits[-1][3] > 0
+
+
 def test_reference_pipeline_smaller_k_columns_are_not_independent_sketches(oracle_lib):
     """What separates the reference's wiring from a sketch per k: a read that holds a genome's 21-mers but none of its 51-mers
     (every 51-mer is broken by an error) contributes NOTHING to the k = 21 column."""

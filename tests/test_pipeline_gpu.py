@@ -269,7 +269,7 @@ def test_select_main_on_a_cmash_mode_table_with_prefix_columns(hip, oracle_lib, 
     from metalign_amd import build_db, formats, select_db
     rng = np.random.default_rng(99)
     data, gb, go, names, accs = _make_data_dir(tmp_path, rng)
-    ks, n = [21, 31, 41], 120
+    ks, n = [21, 31, 40], 120  # (hash mode 1 is built for a list of k: mg_sketch_cmash.hip)
     paths = [str(data / "organism_files" / nm) for nm in names]
     build_db.build(paths, str(data / "sketch_table"), ks, n, hash_mode=1, prefix_tables=True)
     assert hip.hash_mode == 0  # (the builder puts the library's mode back)
@@ -301,7 +301,7 @@ def test_select_main_on_a_cmash_mode_table_with_prefix_columns(hip, oracle_lib, 
                                            str(data / "sketch_table")])
         select_db.select_main(args)
         csv = (tmpd / "cmash_query_results.csv").read_text().splitlines()
-        assert csv[0] == ",k=21,k=31,k=41"
+        assert csv[0] == ",k=21,k=31,k=40"
         per_k = []
         for k, (oh, oo) in zip(ks, want_tabs):
             qh, qc, tr, _ = oracle_lib.sketch_reads_filtered(rb, ro, k, oh, hmax=int(oh.max()))
@@ -332,8 +332,9 @@ def _joined(gb, go, n):
     return np.concatenate(joined), np.asarray(offs, dtype=np.uint64)
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["canonical_kmer_hash", "cmash_recollection"])
-def test_select_main_on_a_reference_pipeline_table(hip, oracle_lib, tmp_path, mode):
+@pytest.mark.parametrize("mode,sketch_hash", [(0, "canonical"), (1, "canonical"), (0, "forward")],
+                         ids=["canonical_kmer_hash", "cmash_recollection", "entries_selected_by_the_forward_hash"])
+def test_select_main_on_a_reference_pipeline_table(hip, oracle_lib, tmp_path, mode, sketch_hash):
     """build_db --reference_pipeline, then select_main on it, as one process and as 1 / 2 / 3 ranks of a torch.distributed.run
     launch: the reads are sketched at the largest k only (what the reference's kmc call counts, scripts/select_db.py:50-52) and
     the CSV — same layout, one column per k — equals the oracle's reference pipeline; the selection and the subset database
@@ -346,15 +347,15 @@ def test_select_main_on_a_reference_pipeline_table(hip, oracle_lib, tmp_path, mo
     ks, n = [21, 31, 41, 51], 150
     tdir = str(data / "sketch_table")
     build_db.main([str(data / "organism_files"), tdir, "-n", str(n), "-k", "21,31,41,51", "--reference_pipeline"] +
-                  (["--hash_mode", "cmash"] if mode else []))
+                  (["--hash_mode", "cmash"] if mode else []) + (["--sketch_hash", "forward"] if sketch_hash == "forward" else []))
     assert hip.hash_mode == 0
     table = formats.SketchTable(tdir)
-    assert table.refpipe and table.hash_mode == mode and table.ks == ks and table.names == sorted(names)
+    assert table.refpipe and table.hash_mode == mode and table.ks == ks and table.names == sorted(names) and table.sketch_hash == sketch_hash
     order = [names.index(nm) for nm in table.names]  # (build_db lists the directory sorted)
     jb, jo = _joined(gb, go, len(names))
     oracle_lib.set_hash_mode(mode)
     try:
-        h, khi, klo, o = oracle_lib.sketch_genomes_kmers(jb, jo, ks[-1], n)
+        h, khi, klo, o = oracle_lib.sketch_genomes_kmers(jb, jo, ks[-1], n, sketch_hash=sketch_hash)
         # genomes in the table's order
         parts = [(h[int(o[g]):int(o[g + 1])], khi[int(o[g]):int(o[g + 1])], klo[int(o[g]):int(o[g + 1])]) for g in order]
         oo = np.zeros(len(order) + 1, np.uint64)
