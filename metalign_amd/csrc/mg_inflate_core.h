@@ -228,6 +228,9 @@ struct HostExec {
   }
   uint32_t totp_at(uint32_t l) const { return r_totp[l]; }
   uint32_t whyp_at(uint32_t l) const { return r_whyp[l]; }
+  // the bit counts of all 256 positions laid out for the walk: word r of 64 positions in one register, a lane per position
+  void spread_tots() {}
+  uint32_t tot_in_word(uint32_t r, uint32_t off) const { const uint32_t p = 64u * r + (off & 63u); return (r_totp[p >> 2] >> (8u * (p & 3u))) & 0xffu; }
   uint32_t my_len(int lane, int j) const { return r_len[lane][j]; }
   uint32_t my_hi(int lane, int j) const { return r_hi[lane][j]; }
   uint32_t scan() const {
@@ -254,6 +257,7 @@ struct DevExec {
   Shared* sh;
   int lane;
   uint32_t v_totp = 0, v_whyp = 0, v_len[4] = {0, 0, 0, 0}, v_hi[4] = {0, 0, 0, 0};
+  uint32_t v_t0 = 0, v_t1 = 0, v_t2 = 0, v_t3 = 0;  // (four names, not an array: indexed by the walk's word it went to scratch)
   __device__ bool leader() const { return lane == 0; }
   __device__ void sync() const { __syncthreads(); }
   __device__ void set_syms(int, uint32_t totp, uint32_t whyp, const uint32_t (&len)[4], const uint32_t (&hi)[4]) {
@@ -264,6 +268,24 @@ struct DevExec {
   }
   __device__ uint32_t totp_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_totp, (int)l); }
   __device__ uint32_t whyp_at(uint32_t l) const { return (uint32_t)__builtin_amdgcn_readlane((int)v_whyp, (int)l); }
+  // The walk reads one position's bit count per symbol: with four positions packed per lane that was shift, readlane, shift, mask,
+  // add in a chain.  Transposed through 256 bytes of LDS (sh.scan is free during a step's first half) position 64 r + i is lane i of
+  // register r, and v_readlane takes the walk's offset as it is (the lane select is its low six bits): readlane, add.
+  __device__ void spread_tots() {
+    sh->scan[lane] = v_totp;
+    __syncthreads();
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(sh->scan);
+    v_t0 = b[lane];
+    v_t1 = b[64 + lane];
+    v_t2 = b[128 + lane];
+    v_t3 = b[192 + lane];
+    __syncthreads();
+  }
+  __device__ uint32_t tot_in_word(uint32_t r, uint32_t off) const {
+    const int o = (int)(off & 63u);
+    return (uint32_t)(r == 0 ? __builtin_amdgcn_readlane((int)v_t0, o) : r == 1 ? __builtin_amdgcn_readlane((int)v_t1, o)
+                      : r == 2 ? __builtin_amdgcn_readlane((int)v_t2, o) : __builtin_amdgcn_readlane((int)v_t3, o));
+  }
   __device__ uint32_t my_len(int, int j) const { return v_len[j]; }
   __device__ uint32_t my_hi(int, int j) const { return v_hi[j]; }
   __device__ uint32_t scan() const {
@@ -601,6 +623,7 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
       }
       ex.set_syms(lane, totp, whyp, len, hi);
     });
+    ex.spread_tots();
     MGI_SUB(1);
     // which positions start a symbol: from bit 0, every symbol says where the next one starts
     uint32_t off = 0, cnt = 0;
@@ -610,23 +633,23 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
     // says "255 bits", which ends the walk by itself — the loop is: read the lane, extract, set the bit, add, compare; the step's
     // symbol limit is looked at between the loops: at most kStepSyms - 1 + 64 symbols)
     uint32_t last = 0;
-#define MGI_TOT(p) ((ex.totp_at((p) >> 2) >> (8u * ((p) & 3u))) & 0xffu)
-#define MGI_WALK(Sr, END)                                                                                    \
+#define MGI_TOT(p) (ex.tot_in_word((p) >> 6, (p)))
+#define MGI_WALK(Sr, R, END)                                                                                 \
     if (off < (END) && cnt < kStepSyms) {                                                                      \
       do {                                                                                                     \
         last = off;                                                                                            \
         Sr |= 1ull << (off & 63u);                                                                             \
-        off += MGI_TOT(off);                                                                                   \
+        off += ex.tot_in_word(R, off);                                                                         \
       } while (off < (END));                                                                                   \
       cnt += popc64(Sr);                                                                                       \
     }
     if (MGI_TOT(0u) == 255u) {  // (from any other position 255 more bits are behind the window)
       special = true;
     } else {
-      MGI_WALK(S0, 64u)
-      MGI_WALK(S1, 128u)
-      MGI_WALK(S2, 192u)
-      MGI_WALK(S3, 256u)
+      MGI_WALK(S0, 0u, 64u)
+      MGI_WALK(S1, 1u, 128u)
+      MGI_WALK(S2, 2u, 192u)
+      MGI_WALK(S3, 3u, 256u)
       if (MGI_TOT(last) == 255u) {  // the last position looked at was the scalar path's: it is no member, the walk stands there
         special = true;
         off = last;
