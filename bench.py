@@ -90,6 +90,8 @@ def parse():
     p.add_argument("--no_secondary", action="store_true", help="skip the configs[1] secondary line and the with-ingest figure")
     p.add_argument("--no_same_workload_n1", action="store_true",
                    help="N > 1: do not measure this workload on one GPU first (rank 0 alone, same collectives in the path)")
+    p.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
+                   help="A/B runs: a diagnostic knob of the library (mg_debug_set; include/metalign_hip.h), recorded in config.knobs")
     p.add_argument("--dry_run", action="store_true",
                    help="plumbing check only: rendezvous + the known-answer collectives, one JSON line, no GPU work")
     a = p.parse_args()
@@ -568,6 +570,12 @@ def main():
         from metalign_amd._hip import Hip
         hip = Hip.get(0)
 
+    knobs = {}
+    for kv in args.knob:
+        key, _, val = kv.partition("=")
+        from metalign_amd import _hip as _hipmod
+        _hipmod.debug_set(key, int(val or 1))
+        knobs[key] = int(val or 1)
     cfg = resolve_config(args, world)
     w = build_workload(cfg, args.sketch_n, rank, hip, args.definition, args.hash_mode, world)
     job = make_job(hip, dist, rank, world, cfg, w, force_dist)
@@ -704,6 +712,8 @@ def main():
         # a dense table (>= 5 % of all k-mers pass its threshold: configs[3]'s 5 kb genomes) gets a resident index at load
         # (DESIGN.md §4): stage A then counts in it, and the sketch is the exact intersection with the table
         resident = sum(f.resident_bytes for f in getattr(job.engine, "filters", []) if f is not None)
+        if knobs:
+            res["config"]["knobs"] = knobs
         res["config"]["stage_a_tables"] = ("resident index of the genome table, %.1f GB in HBM" % (resident / 1e9)) if resident \
             else "counting tables per pass + the table's membership filter"
         tr = job.traffic_per_pass() if hasattr(job, "traffic_per_pass") else None
