@@ -54,6 +54,9 @@ struct CandSink {
       // is made again: its flush takes the buffer 64 candidates at a time, each lane's candidate round after round until it is
       // found or known absent — four to a lane in one round trip, as the fused kernel does it, costs every one-k kernel 35
       // registers (100 -> 135: three wavefronts per SIMD instead of four) whether it ever sees an index or not.
+      // (diagnostics, tools/k1_dense_ablation.sh: the flush_order knob — meaningless against an index — ablates this branch: 1 = the
+      // candidates are dropped, 2 = looked up but not counted and not listed, 3 = counted but not listed)
+      if (order == 1u) { wave_lds_sync(); n = 0; return; }
 #pragma unroll 1
       for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -62,9 +65,9 @@ struct CandSink {
         Slot* bucket[1] = {tab + (hh[0] != kReservedHash ? hh[0] >> shift : 0ull) * kBucketSlots};
         bool hit[1], fresh[1], on[1];
         for (;;) {
-          resident_lookup<1>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos);
+          resident_lookup<1>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos, order != 2u);
           produced += hit[0];
-          if (out)
+          if (out && order < 2u)
             resident_list_append(fresh[0], (uint32_t)(hh[0] >> shift) * kBucketSlots + pos[0], reinterpret_cast<uint32_t*>(out), cap,
                                  counters, lbase, lfill, lane);
           bool more = false;
