@@ -288,7 +288,6 @@ __global__ __launch_bounds__(256) void k_chain_rows(const uint16_t* __restrict__
 // text, so that full tiles leave as 16-byte stores); jobs[j].tile0 = the first tile of job j.
 __global__ __launch_bounds__(256) void k_resolve_text(const ChainJob* __restrict__ jobs, uint32_t njobs, const uint8_t* __restrict__ wins,
                                                       uint8_t* __restrict__ text) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[4096];
   const uint32_t t = threadIdx.x;
   const uint64_t b = blockIdx.x;
   uint32_t lo = 0, hi = njobs;  // last job with tile0 <= b
@@ -301,23 +300,28 @@ __global__ __launch_bounds__(256) void k_resolve_text(const ChainJob* __restrict
   const uint16_t* sym = jobs[j].sym;
   const uint8_t* win = wins + (uint64_t)j * kWindow;
   const uint64_t T0 = (t_off & ~15ull) + (b - jobs[j].tile0) * 4096ull;
-#pragma unroll
-  for (uint32_t k = 0; k < 16; ++k) {
-    const uint64_t e = T0 + k * 256u + t;
-    uint8_t r = 0;
-    if (e >= t_off && e < t_off + n) {
-      const uint32_t v = sym[e - t_off];
-      r = v < 256u ? (uint8_t)v : win[v & 0x7fffu];
-    }
-    tile[k * 256u + t] = r;
-  }
-  __syncthreads();
+  // a thread makes 16 consecutive bytes of the text (one aligned 16-byte store) from 16 consecutive symbols (two 16-byte loads,
+  // wherever the job's symbols happen to start), window symbols looked up in the job's row of windows
   const uint64_t e0 = T0 + 16ull * t;
   if (e0 >= t_off && e0 + 16 <= t_off + n) {
-    *reinterpret_cast<uint4*>(text + e0) = *reinterpret_cast<const uint4*>(tile + 16u * t);
+    U16x8 a, c;
+    __builtin_memcpy(&a, sym + (e0 - t_off), 16);
+    __builtin_memcpy(&c, sym + (e0 - t_off) + 8, 16);
+    U8x16 r;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint32_t v = a.v[i], w = c.v[i];
+      r.v[i] = v < 256u ? (uint8_t)v : win[v & 0x7fffu];
+      r.v[8 + i] = w < 256u ? (uint8_t)w : win[w & 0x7fffu];
+    }
+    *reinterpret_cast<U8x16*>(text + e0) = r;
   } else {
-    for (uint32_t i = 0; i < 16; ++i)
-      if (e0 + i >= t_off && e0 + i < t_off + n) text[e0 + i] = tile[16u * t + i];
+    for (uint32_t i = 0; i < 16; ++i) {
+      const uint64_t e = e0 + i;
+      if (e < t_off || e >= t_off + n) continue;
+      const uint32_t v = sym[e - t_off];
+      text[e] = v < 256u ? (uint8_t)v : win[v & 0x7fffu];
+    }
   }
 }
 
