@@ -51,6 +51,7 @@ constexpr uint32_t kWindow = 32768;
 constexpr uint32_t kInWords = 64;        // compressed words staged in LDS for the window decode
 constexpr uint32_t kStepBits = 256;      // bit positions one window step looks at (four per lane)
 constexpr uint32_t kStepSyms = 64;       // ... and the symbols it takes at most
+constexpr uint32_t kEmitWays = 4;        // output bytes a lane makes side by side in the emission (8: the same time — it is instructions, not waiting)
 
 enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_LONG = 3, K_BAD = 4, K_DIST = 5 };
 
@@ -839,26 +840,25 @@ MGI_HDI bool chase_step(Shared& sh, Chase& c, uint64_t pos0, int64_t floor) {  /
 }
 template <class OutT>
 MGI_HDI void emit_lane(Shared& sh, int lane, uint32_t T, OutT* out, uint64_t pos0, int64_t floor) {
-  // four bytes per lane at a time (f, f + 64, f + 128, f + 192): their chains through the batch's records are independent, so
+  // kEmitWays bytes per lane at a time (f, f + 64, f + 128, ...): their chains through the batch's records are independent, so
   // their LDS reads are in flight together; then the loads from memory, then the stores
-  for (uint32_t f0 = (uint32_t)lane; f0 < T; f0 += 256) {
-    Chase c0{f0, 0, 0, f0 < T, false}, c1{f0 + 64, 0, 0, f0 + 64 < T, false}, c2{f0 + 128, 0, 0, f0 + 128 < T, false},
-        c3{f0 + 192, 0, 0, f0 + 192 < T, false};
+  constexpr uint32_t W = kEmitWays;
+  for (uint32_t f0 = (uint32_t)lane; f0 < T; f0 += 64u * W) {
+    Chase c[W];
+    MGI_UNROLL
+    for (uint32_t i = 0; i < W; ++i) c[i] = Chase{f0 + 64u * i, 0, 0, f0 + 64u * i < T, false};
     for (bool any = true; any;) {
       any = false;
-      if (c0.act) any |= chase_step<OutT>(sh, c0, pos0, floor);
-      if (c1.act) any |= chase_step<OutT>(sh, c1, pos0, floor);
-      if (c2.act) any |= chase_step<OutT>(sh, c2, pos0, floor);
-      if (c3.act) any |= chase_step<OutT>(sh, c3, pos0, floor);
+      MGI_UNROLL
+      for (uint32_t i = 0; i < W; ++i)
+        if (c[i].act) any |= chase_step<OutT>(sh, c[i], pos0, floor);
     }
-    if (c0.ld) c0.val = out[c0.q];
-    if (c1.ld) c1.val = out[c1.q];
-    if (c2.ld) c2.val = out[c2.q];
-    if (c3.ld) c3.val = out[c3.q];
-    if (f0 < T) out[pos0 + f0] = (OutT)c0.val;
-    if (f0 + 64 < T) out[pos0 + f0 + 64] = (OutT)c1.val;
-    if (f0 + 128 < T) out[pos0 + f0 + 128] = (OutT)c2.val;
-    if (f0 + 192 < T) out[pos0 + f0 + 192] = (OutT)c3.val;
+    MGI_UNROLL
+    for (uint32_t i = 0; i < W; ++i)
+      if (c[i].ld) c[i].val = out[c[i].q];
+    MGI_UNROLL
+    for (uint32_t i = 0; i < W; ++i)
+      if (f0 + 64u * i < T) out[pos0 + f0 + 64u * i] = (OutT)c[i].val;
   }
 }
 
