@@ -96,7 +96,8 @@ int64_t dbg(const char* key);
 // The stage-A kernels' cs word (mg_sketch_dev.h: kCsMask): count saturation + the tests' flush-order pin.
 inline uint32_t stage_a_cs_word() {
   const uint32_t order = (uint32_t)dbg("flush_order") & 3u;  // 1: filter words first, 2: slots first (the tests pin either)
-  return ctx().count_sat | (order << 30);
+  const uint32_t ablate = (uint32_t)dbg("resident_ablate") & 3u;  // (diagnostics: the one-k kernel's look-ups in a resident index)
+  return ctx().count_sat | (order << 30) | (ablate << 28);
 }
 
 #define MG_HIP(call)                                                                          \

@@ -33,9 +33,10 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
-// The kernels' `cs` word: the saturation value in the low 30 bits; the top two pin the order of a flush's two look-ups
-// for the tests (0: each wavefront adapts, 1: filter first, 2: home slot first) — MG_DEBUG_FLUSH_ORDER=filter|slot.
-constexpr uint32_t kCsMask = 0x3fffffffu;
+// The kernels' `cs` word: the saturation value in the low 28 bits; the top two pin the order of a flush's two look-ups
+// for the tests (0: each wavefront adapts, 1: filter first, 2: home slot first: knob flush_order); bits 28-29 ablate the look-ups in a
+// resident index for diagnostics (knob resident_ablate; tools/k1_dense_ablation.sh).
+constexpr uint32_t kCsMask = 0x0fffffffu;
 constexpr uint32_t kBucketSlots = 256;  // open-addressed slots per hash-range bucket (power of two)
 constexpr uint32_t kBucketTarget = 128;  // expected distinct hashes per bucket at most (load factor <= 1/2; the shift rounds it down by up to 2x)
 

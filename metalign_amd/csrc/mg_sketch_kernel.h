@@ -25,6 +25,7 @@ struct CandSink {
   unsigned long long produced = 0;  // table mode: this lane's candidates inserted so far
   bool slot_first = false;          // table mode: the order of the two look-ups of a flush (wave-uniform)
   uint32_t order = 0;               // 0: adapt; 1 / 2: pinned (tests)
+  uint32_t ablate = 0;              // resident index: diagnostics (see flush)
   uint32_t epoch = 0;               // table mode, != 0: `tab` is a resident index (mg_sketch_dev.h) and out / cap the list of hashes touched
   uint32_t* lbase = nullptr;        // ... this wavefront's chunk of that list (slot numbers: `out`, there, is a uint32_t array)
   uint32_t lfill = 0;
@@ -54,9 +55,9 @@ struct CandSink {
       // is made again: its flush takes the buffer 64 candidates at a time, each lane's candidate round after round until it is
       // found or known absent — four to a lane in one round trip, as the fused kernel does it, costs every one-k kernel 35
       // registers (100 -> 135: three wavefronts per SIMD instead of four) whether it ever sees an index or not.
-      // (diagnostics, tools/k1_dense_ablation.sh: the flush_order knob — meaningless against an index — ablates this branch: 1 = the
-      // candidates are dropped, 2 = looked up but not counted and not listed, 3 = counted but not listed)
-      if (order == 1u) { wave_lds_sync(); n = 0; return; }
+      // (diagnostics, tools/k1_dense_ablation.sh, knob resident_ablate: 1 = the candidates are dropped, 2 = looked up but not counted
+      // and not listed, 3 = counted but not listed)
+      if (ablate == 1u) { wave_lds_sync(); n = 0; return; }
 #pragma unroll 1
       for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -65,9 +66,9 @@ struct CandSink {
         Slot* bucket[1] = {tab + (hh[0] != kReservedHash ? hh[0] >> shift : 0ull) * kBucketSlots};
         bool hit[1], fresh[1], on[1];
         for (;;) {
-          resident_lookup<1>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos, order != 2u);
+          resident_lookup<1>(bucket, hh, hop, epoch, cs, hit, fresh, on, pos, ablate != 2u);
           produced += hit[0];
-          if (out && order < 2u)
+          if (out && ablate < 2u)
             resident_list_append(fresh[0], (uint32_t)(hh[0] >> shift) * kBucketSlots + pos[0], reinterpret_cast<uint32_t*>(out), cap,
                                  counters, lbase, lfill, lane);
           bool more = false;
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(kBlock) MG_K1_ATTR(K) void k_sketch_reads(const uin
   uint64_t* cbuf = reinterpret_cast<uint64_t*>(smem + (size_t)kWavesPerBlock * stage_bytes) + wave * kCandBuf;
   CandSink sink{cbuf, cand, cand_cap, counters, tab, bucket_shift, fbits, fmask, cs & kCsMask, 0};
   sink.order = cs >> 30;
+  sink.ablate = (cs >> 28) & 3u;
   sink.slot_first = sink.order == 2u;
   if (!fbits) sink.epoch = (uint32_t)fmask;  // no filter words and a "mask": the table is a resident index, this its epoch
   uint64_t kmers = 0;
