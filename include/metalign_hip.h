@@ -507,6 +507,11 @@ int mg_containment(const uint64_t* q_hashes, const uint32_t* q_counts,
  *   hash-major pairs of k_max and, per k below it, pa / pb per pair (the number — rank among the table's distinct
  *   k-prefixes — of the kept k-mer's k-prefix / of its reverse complement's, 0xffffffff when that is no prefix of the
  *   table) and the count list (distinct (prefix number, genome), ascending) with gsize_k[g] = entries of genome g.
+ * mg_refdb_upload_begin: mg_refdb_upload that RETURNS WHILE THE ARRAYS GO UP (reader threads + a DMA thread of the library fill
+ *   page-locked slots of their own): the caller's arrays must stay where they are until the first call that reads the table —
+ *   any stage-B call, a download, mg_refdb_kmax_table — which waits for them and checks them as mg_refdb_upload does at once
+ *   (a corrupt table is reported THERE).  What select_main does while the reads stream (mg_refdb_max_hash, _ngenomes, _nk
+ *   answer at once).
  * mg_refdb_upload: the same handle from stored arrays (metalign_amd/formats.py, table version 3) — or from a rank's share:
  *   any contiguous run of the pairs with its pa / pb, any contiguous run of a count list with gsize counted within it;
  *   nprefix is always the whole table's.  mg_refdb_download_*: what the builder stores.
@@ -519,6 +524,10 @@ int mg_sketch_genomes_kmers_forward(const uint8_t* bases, const uint64_t* offset
 int mg_refdb_build(const uint64_t* hashes, const uint64_t* kmer_hi, const uint64_t* kmer_lo, const uint64_t* offsets,
                    uint64_t ngenomes, int nk, const int* ks, mg_refdb** out);
 int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash,
+                    const uint32_t* pair_gen, const uint32_t* gsize_kmax, uint64_t max_hash, const uint32_t* const* pa,
+                    const uint32_t* const* pb, const uint64_t* nprefix, const uint32_t* const* cid,
+                    const uint32_t* const* cgen, const uint64_t* ncount, const uint32_t* const* gsize, mg_refdb** out);
+int mg_refdb_upload_begin(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash,
                     const uint32_t* pair_gen, const uint32_t* gsize_kmax, uint64_t max_hash, const uint32_t* const* pa,
                     const uint32_t* const* pb, const uint64_t* nprefix, const uint32_t* const* cid,
                     const uint32_t* const* cgen, const uint64_t* ncount, const uint32_t* const* gsize, mg_refdb** out);

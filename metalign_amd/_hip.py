@@ -40,7 +40,7 @@ EXPORTS = [
     "mg_inflate_dev", "mg_inflated_bytes", "mg_inflated_download", "mg_inflated_free", "mg_inflate_config", "mg_inflate_stats",
     "mg_sketch_genomes", "mg_sketch_genomes_prefix", "mg_db_upload", "mg_db_upload_sorted", "mg_db_ngenomes", "mg_db_max_hash", "mg_db_free",
     "mg_containment_dev", "mg_containment_multi_dev", "mg_containment",
-    "mg_sketch_genomes_kmers", "mg_sketch_genomes_kmers_forward", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
+    "mg_sketch_genomes_kmers", "mg_sketch_genomes_kmers_forward", "mg_refdb_build", "mg_refdb_upload", "mg_refdb_upload_begin", "mg_refdb_sizes", "mg_refdb_download_kmax", "mg_refdb_download_k", "mg_refdb_nk",
     "mg_refdb_ngenomes", "mg_refdb_max_hash", "mg_refdb_kmax_table", "mg_refdb_free", "mg_refpipe_containment_dev", "mg_refpipe_mark_dev",
     "mg_refpipe_count_dev", "mg_refdb_marks",
     "mg_profile_begin_dev", "mg_profile_acc_reset", "mg_profile_map_launch", "mg_profile_state_map", "mg_profile_map_words_dev", "mg_profile_ngroups", "mg_profile_commit_dev", "mg_profile_commit_reset_dev",
@@ -601,7 +601,10 @@ class RefTable:
 
     def kmax_table(self):
         """The table of the largest k as a SketchTable view (owned by this handle: do not free it)."""
-        t = SketchTable(self.hip, _vp(self.hip.lib.mg_refdb_kmax_table(self.handle)))
+        ptr = self.hip.lib.mg_refdb_kmax_table(self.handle)  # (waits for a table that is still on its way up, and checks it)
+        if not ptr:
+            raise HipError("libmetalign_hip: %s" % self.hip.lib.mg_last_error().decode("utf-8", "replace"), ERR_ARG)
+        t = SketchTable(self.hip, _vp(ptr))
         t.free = lambda: None
         t._owner = self
         return t
@@ -644,8 +647,9 @@ class RefTable:
 
     def free(self):
         if self.handle:
-            self.hip.lib.mg_refdb_free(self.handle)
+            self.hip.lib.mg_refdb_free(self.handle)  # (joins the uploader's threads of a table still on its way)
             self.handle = None
+        self._arrays_on_their_way = None
 
     def __del__(self):
         try:
@@ -1242,9 +1246,11 @@ class Hip:
                                           ctypes.c_uint64(len(offsets) - 1), ctypes.c_int(len(ks)), c_ks, ctypes.byref(h)))
         return RefTable(self, h, ks)
 
-    def refdb_upload(self, ks, ngenomes, pair_hash, pair_gen, gsize, max_hash, small):
+    def refdb_upload(self, ks, ngenomes, pair_hash, pair_gen, gsize, max_hash, small, wait=True):
         """The same handle from stored arrays (formats.SketchTable.refpipe_arrays), or a rank's share of them.
-        small: per k below the largest, in order: dict(pa, pb, cid, cgen, gsize, nprefix)."""
+        small: per k below the largest, in order: dict(pa, pb, cid, cgen, gsize, nprefix).
+        wait = False (mg_refdb_upload_begin): returns while the library's threads still copy the arrays up — the handle keeps the
+        arrays alive; the first call that reads the table waits for them and checks them (a corrupt table is reported there)."""
         ks = [int(k) for k in ks]
         pair_hash = np.ascontiguousarray(pair_hash, dtype=np.uint64)
         pair_gen = np.ascontiguousarray(pair_gen, dtype=np.uint32)
@@ -1268,10 +1274,14 @@ class Hip:
             c_np[i], c_nc[i] = int(t["nprefix"]), len(t["cid"])
         c_ks = (ctypes.c_int * len(ks))(*ks)
         h = _vp()
-        self._chk(self.lib.mg_refdb_upload(ctypes.c_uint64(int(ngenomes)), ctypes.c_int(len(ks)), c_ks, ctypes.c_uint64(n),
-                                           arr(pair_hash, np.uint64), arr(pair_gen, np.uint32), arr(gsize, np.uint32),
-                                           ctypes.c_uint64(int(max_hash)), c_pa, c_pb, c_np, c_cid, c_cgen, c_nc, c_gs, ctypes.byref(h)))
-        return RefTable(self, h, ks)
+        fn = self.lib.mg_refdb_upload if wait else self.lib.mg_refdb_upload_begin
+        self._chk(fn(ctypes.c_uint64(int(ngenomes)), ctypes.c_int(len(ks)), c_ks, ctypes.c_uint64(n),
+                     arr(pair_hash, np.uint64), arr(pair_gen, np.uint32), arr(gsize, np.uint32),
+                     ctypes.c_uint64(int(max_hash)), c_pa, c_pb, c_np, c_cid, c_cgen, c_nc, c_gs, ctypes.byref(h)))
+        t = RefTable(self, h, ks)
+        if not wait:
+            t._arrays_on_their_way = keep  # (memory maps of the stored table: the uploader's threads read them until the first use)
+        return t
 
     def refpipe_containment_dev(self, sketch, reftable, ci, d_hits, d_sizes):
         """Stage B of the reference pipeline: sketch = the read sketch of the table's largest k; d_hits / d_sizes: one device

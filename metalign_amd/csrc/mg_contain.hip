@@ -493,6 +493,29 @@ __global__ void k_check_pairs(const uint64_t* __restrict__ pair_hash, const uint
   if (g) atomicAdd(bad + 2, (unsigned long long)g);
 }
 
+}  // extern "C"
+namespace mg {
+// k_check_pairs over an uploaded table (stream-ordered on the library stream; waits for the answer)
+int check_pairs_dev(const mg_db& db) {
+  if (!db.total) return MG_OK;
+  hipStream_t st = ctx().stream;
+  unsigned long long* d_bad = (unsigned long long*)scratch("db_check", 4 * sizeof(unsigned long long));
+  if (!d_bad) return MG_ERR_NOMEM;
+  MG_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_check_pairs, dim3(grid_for(db.total, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st,
+                     db.pair_hash.as<uint64_t>(), db.pair_gen.as<uint32_t>(), db.total, db.ngenomes, db.max_hash, d_bad);
+  MG_HIP(hipGetLastError());
+  uint64_t* pin = host_words();
+  MG_HIP(hipMemcpyAsync(pin, d_bad, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  if (pin[0] || pin[1] || pin[2])
+    return fail(MG_ERR_ARG, "hash-major sketch table is corrupt: %llu pairs out of order, %llu above max_hash, %llu with a genome id >= %llu",
+                (unsigned long long)pin[0], (unsigned long long)pin[1], (unsigned long long)pin[2], (unsigned long long)db.ngenomes);
+  return MG_OK;
+}
+}  // namespace mg
+extern "C" {
+
 int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uint64_t npairs, const uint32_t* gsize,
                         uint64_t ngenomes, uint64_t max_hash, mg_db** out) {
   MG_REQUIRE_READY();
@@ -515,20 +538,7 @@ int mg_db_upload_sorted(const uint64_t* pair_hash, const uint32_t* pair_gen, uin
     MG_TRY(upload_ranges({{pair_hash, {db->pair_hash.p, npairs * sizeof(uint64_t)}}, {pair_gen, {db->pair_gen.p, npairs * sizeof(uint32_t)}}}, st));
   }
   if (ngenomes) MG_HIP(hipMemcpyAsync(db->gsize.p, gsize, ngenomes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  if (npairs) {
-    unsigned long long* d_bad = (unsigned long long*)scratch("db_check", 4 * sizeof(unsigned long long));
-    if (!d_bad) return MG_ERR_NOMEM;
-    MG_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_check_pairs, dim3(grid_for(npairs, 256, (unsigned)ctx().num_cus * 8)), dim3(256), 0, st,
-                       db->pair_hash.as<uint64_t>(), db->pair_gen.as<uint32_t>(), npairs, ngenomes, max_hash, d_bad);
-    MG_HIP(hipGetLastError());
-    uint64_t* pin = host_words();
-    MG_HIP(hipMemcpyAsync(pin, d_bad, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
-    if (pin[0] || pin[1] || pin[2])
-      return fail(MG_ERR_ARG, "hash-major sketch table is corrupt: %llu pairs out of order, %llu above max_hash, %llu with a genome id >= %llu",
-                  (unsigned long long)pin[0], (unsigned long long)pin[1], (unsigned long long)pin[2], (unsigned long long)ngenomes);
-  }
+  MG_TRY(check_pairs_dev(*db));
   MG_HIP(hipStreamSynchronize(st));
   *out = db.release();
   return MG_OK;
@@ -717,6 +727,7 @@ int mg_containment_multi_dev(int nk, const mg_sketch* const* qs, const mg_db* co
 
 int mg_refpipe_mark_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax) {
   if (!q || !db) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(refdb_ready(db));
   const mg_db* kdb = &db->kmax;
   return containment_launch(1, &q, &kdb, ci, &d_hits_kmax, &d_sizes_kmax, db);
 }
@@ -724,6 +735,7 @@ int mg_refpipe_mark_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uin
 int mg_refpipe_count_dev(const mg_refdb* db, const uint32_t* const* d_marks, uint32_t* const* d_hits, uint32_t* const* d_sizes) {
   MG_REQUIRE_READY();
   if (!db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(refdb_ready(db));
   return refpipe_count_launch(db, d_marks, d_hits, d_sizes);
 }
 

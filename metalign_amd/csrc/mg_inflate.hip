@@ -439,8 +439,9 @@ struct CompUploader {
 
   ~CompUploader() { finish(); }
   // page-locking a slot costs milliseconds: the slots and the copy stream stay with the library (inflate_release_all)
+  // (two sets: 0 = the inflater's compressed bytes, 1 = table uploads that run BESIDE a stream — mg_refdb_upload_begin)
   struct Kept { std::vector<uint8_t*> slots; hipStream_t copy = nullptr; };
-  static Kept& kept() { static Kept k; return k; }
+  static Kept& kept(int set = 0) { static Kept k[2]; return k[set & 1]; }
   void finish() {
     {
       std::lock_guard<std::mutex> lk(m);
@@ -461,7 +462,7 @@ struct CompUploader {
     return start_ranges(one, nthreads);
   }
   // several host arrays, each to its own place on the device, as one job
-  int start_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, int nthreads) {
+  int start_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, int nthreads, int set = 0) {
     device = ctx().device;
     pieces.clear();
     n = 0;
@@ -473,7 +474,7 @@ struct CompUploader {
       }
     npieces = pieces.size();
     if (npieces == 0) return MG_OK;
-    Kept& k = kept();
+    Kept& k = kept(set);
     if (!k.copy) MG_HIP(hipStreamCreateWithFlags(&k.copy, hipStreamNonBlocking));
     copy = k.copy;
     const size_t ns = npieces < kSlots ? (size_t)npieces : kSlots;
@@ -559,11 +560,32 @@ int upload_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint
   return MG_OK;
 }
 
+// ... in two halves: begin returns with the reader threads and the DMA thread at work (the caller's arrays must stay where they are
+// until end), end makes `st` wait for the last piece and joins them.  A set of slots of its own: a `.gz` reads file may be going up
+// through the inflater's at the same time.
+struct UploadJob { CompUploader up; };
+int upload_ranges_begin(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, UploadJob** out) {
+  std::unique_ptr<UploadJob> job(new UploadJob());
+  MG_TRY(job->up.start_ranges(ranges, 4, 1));
+  *out = job.release();
+  return MG_OK;
+}
+int upload_ranges_end(UploadJob* job, hipStream_t st) {
+  if (!job) return MG_OK;
+  std::unique_ptr<UploadJob> hold(job);
+  MG_TRY(job->up.need(job->up.n, st));
+  job->up.finish();
+  return MG_OK;
+}
+void upload_ranges_abort(UploadJob* job) { delete job; }  // (~CompUploader joins the threads and waits for what is on the wire)
+
 void inflate_release_all() {
-  CompUploader::Kept& k = CompUploader::kept();
-  if (k.copy) { (void)hipStreamSynchronize(k.copy); (void)hipStreamDestroy(k.copy); }
-  for (uint8_t* p : k.slots) (void)hipHostFree(p);
-  k = CompUploader::Kept();
+  for (int set = 0; set < 2; ++set) {
+    CompUploader::Kept& k = CompUploader::kept(set);
+    if (k.copy) { (void)hipStreamSynchronize(k.copy); (void)hipStreamDestroy(k.copy); }
+    for (uint8_t* p : k.slots) (void)hipHostFree(p);
+    k = CompUploader::Kept();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -165,6 +165,10 @@ void stream_release_all();
 void inflate_release_all();
 // ... host arrays in pageable memory -> the device through those slots (reader threads + one DMA stream); st waits for the last piece.
 int upload_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, hipStream_t st);
+struct UploadJob;
+int upload_ranges_begin(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, UploadJob** out);
+int upload_ranges_end(UploadJob* job, hipStream_t st);
+void upload_ranges_abort(UploadJob* job);
 
 // Times one kernel family with HIP events on the library stream when profiling is on.
 struct ProfScope {
@@ -361,4 +365,9 @@ struct mg_refdb {
   mutable uint32_t* count_part = nullptr;
   mutable uint32_t count_copies = 0;
   mutable uint64_t count_gen = 0;  // the containment call that zeroed them (any later one reuses the buffer)
+  // mg_refdb_upload_begin: the arrays still on their way up (settled, and the table checked, by the first call that reads it)
+  mutable mg::UploadJob* pending = nullptr;
+  mutable bool unchecked = false;
+  ~mg_refdb();
 };
+namespace mg { int refdb_ready(const mg_refdb* db); int check_pairs_dev(const mg_db& db); }

@@ -180,7 +180,43 @@ int alloc_marks(mg_refdb* db) {
 
 }  // namespace
 
+// A table whose arrays are still on their way up (mg_refdb_upload_begin): wait for them, then trust them for nothing — the pairs
+// (k_check_pairs) and the prefix structures (k_rp_check) are checked before anything reads them.  An error stays with the handle.
+int refdb_ready(const mg_refdb* db) {
+  if (!db) return fail(MG_ERR_ARG, "null argument");
+  hipStream_t st = ctx().stream;
+  if (db->pending) {
+    UploadJob* job = db->pending;
+    db->pending = nullptr;
+    MG_TRY(upload_ranges_end(job, st));
+  }
+  if (!db->unchecked) return MG_OK;
+  MG_TRY(check_pairs_dev(db->kmax));
+  unsigned long long* d_bad = (unsigned long long*)scratch("db_check", 4 * sizeof(unsigned long long));
+  if (!d_bad) return MG_ERR_NOMEM;
+  MG_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), st));
+  const uint64_t npairs = db->kmax.total;
+  for (int s = 0; s < db->nk - 1; ++s) {
+    const mg_refdb::Small& S = db->small[s];
+    hipLaunchKernelGGL(k_rp_check, dim3(g256(npairs > S.ncount ? npairs : S.ncount)), dim3(256), 0, st, S.pa.as<uint32_t>(), S.pb.as<uint32_t>(),
+                       npairs, S.cid.as<uint32_t>(), S.cgen.as<uint32_t>(), S.ncount, S.nprefix, db->kmax.ngenomes, d_bad);
+    MG_HIP(hipGetLastError());
+  }
+  uint64_t* pin = host_words();
+  MG_HIP(hipMemcpyAsync(pin, d_bad, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MG_HIP(hipStreamSynchronize(st));
+  if (pin[0]) return fail(MG_ERR_ARG, "reference-pipeline table is corrupt: %llu prefix numbers / genome ids out of range or out of order",
+                          (unsigned long long)pin[0]);
+  db->unchecked = false;
+  return MG_OK;
+}
+
 }  // namespace mg
+
+mg_refdb::~mg_refdb() {
+  if (pending) mg::upload_ranges_abort(pending);  // (joins the uploader's threads before the buffers go)
+  pending = nullptr;
+}
 
 using namespace mg;
 
@@ -293,31 +329,31 @@ int mg_refdb_build(const uint64_t* hashes, const uint64_t* kmer_hi, const uint64
   return MG_OK;
 }
 
-int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash, const uint32_t* pair_gen,
-                    const uint32_t* gsize_kmax, uint64_t max_hash, const uint32_t* const* pa, const uint32_t* const* pb,
-                    const uint64_t* nprefix, const uint32_t* const* cid, const uint32_t* const* cgen, const uint64_t* ncount,
-                    const uint32_t* const* gsize, mg_refdb** out) {
+int mg_refdb_upload_begin(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash, const uint32_t* pair_gen,
+                          const uint32_t* gsize_kmax, uint64_t max_hash, const uint32_t* const* pa, const uint32_t* const* pb,
+                          const uint64_t* nprefix, const uint32_t* const* cid, const uint32_t* const* cgen, const uint64_t* ncount,
+                          const uint32_t* const* gsize, mg_refdb** out) {
   MG_REQUIRE_READY();
-  if (!out || !ks || !gsize_kmax) return fail(MG_ERR_ARG, "null argument");
+  if (!out || !ks || !gsize_kmax || (npairs && (!pair_hash || !pair_gen))) return fail(MG_ERR_ARG, "null argument");
   *out = nullptr;
   if (nk < 1 || nk > 4) return fail(MG_ERR_ARG, "between 1 and 4 k per table");
   if (nk > 1 && (!pa || !pb || !nprefix || !cid || !cgen || !ncount || !gsize)) return fail(MG_ERR_ARG, "null argument");
-  mg_db* kdb = nullptr;
-  MG_TRY(mg_db_upload_sorted(pair_hash, pair_gen, npairs, gsize_kmax, ngenomes, max_hash, &kdb));  // (validates the pairs)
-  std::unique_ptr<mg_db> hold(kdb);
+  if (npairs > 0xfffffff0ull) return fail(MG_ERR_ARG, "sketch table of %llu hashes exceeds the 32-bit position range", (unsigned long long)npairs);
+  if (ngenomes > 0xfffffff0ull) return fail(MG_ERR_ARG, "too many genomes");
+  if (npairs && (pair_hash[0] > pair_hash[npairs - 1] || pair_hash[npairs - 1] > max_hash))
+    return fail(MG_ERR_ARG, "pair list is not ascending within [0, max_hash]");
   std::unique_ptr<mg_refdb> db(new mg_refdb());
   db->nk = nk;
   for (int i = 0; i < nk; ++i) db->ks[i] = ks[i];
-  db->kmax.pair_hash = std::move(kdb->pair_hash);
-  db->kmax.pair_gen = std::move(kdb->pair_gen);
-  db->kmax.gsize = std::move(kdb->gsize);
   db->kmax.ngenomes = ngenomes;
   db->kmax.total = npairs;
   db->kmax.max_hash = max_hash;
-  hipStream_t st = ctx().stream;
-  unsigned long long* d_bad = (unsigned long long*)scratch("db_check", 4 * sizeof(unsigned long long));
-  if (!d_bad) return MG_ERR_NOMEM;
-  MG_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), st));
+  MG_TRY(db->kmax.pair_hash.alloc((npairs + 1) * sizeof(uint64_t)));
+  MG_TRY(db->kmax.pair_gen.alloc((npairs + 1) * sizeof(uint32_t)));
+  MG_TRY(db->kmax.gsize.alloc((ngenomes + 1) * sizeof(uint32_t)));
+  std::vector<std::pair<const void*, std::pair<void*, uint64_t>>> up;
+  if (npairs) { up.push_back({pair_hash, {db->kmax.pair_hash.p, npairs * 8}}); up.push_back({pair_gen, {db->kmax.pair_gen.p, npairs * 4}}); }
+  if (ngenomes) up.push_back({gsize_kmax, {db->kmax.gsize.p, ngenomes * 4}});
   for (int s = 0; s < nk - 1; ++s) {
     mg_refdb::Small& S = db->small[s];
     if (nprefix[s] > 0xfffffff0ull || ncount[s] > 0xfffffff0ull) return fail(MG_ERR_ARG, "table too large for 32-bit positions");
@@ -327,25 +363,28 @@ int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, c
     MG_TRY(S.pa.alloc((npairs + 1) * 4)); MG_TRY(S.pb.alloc((npairs + 1) * 4));
     MG_TRY(S.cid.alloc((ncount[s] + 1) * 4)); MG_TRY(S.cgen.alloc((ncount[s] + 1) * 4));
     MG_TRY(S.gsize.alloc((ngenomes + 1) * 4));
-    {
-      std::vector<std::pair<const void*, std::pair<void*, uint64_t>>> up;
-      if (npairs) { up.push_back({pa[s], {S.pa.p, npairs * 4}}); up.push_back({pb[s], {S.pb.p, npairs * 4}}); }
-      if (ncount[s]) { up.push_back({cid[s], {S.cid.p, ncount[s] * 4}}); up.push_back({cgen[s], {S.cgen.p, ncount[s] * 4}}); }
-      if (ngenomes) up.push_back({gsize[s], {S.gsize.p, ngenomes * 4}});
-      MG_TRY(upload_ranges(up, st));
-    }
-    hipLaunchKernelGGL(k_rp_check, dim3(g256(npairs > ncount[s] ? npairs : ncount[s])), dim3(256), 0, st, S.pa.as<uint32_t>(), S.pb.as<uint32_t>(),
-                       npairs, S.cid.as<uint32_t>(), S.cgen.as<uint32_t>(), ncount[s], nprefix[s], ngenomes, d_bad);
-    MG_HIP(hipGetLastError());
+    if (npairs) { up.push_back({pa[s], {S.pa.p, npairs * 4}}); up.push_back({pb[s], {S.pb.p, npairs * 4}}); }
+    if (ncount[s]) { up.push_back({cid[s], {S.cid.p, ncount[s] * 4}}); up.push_back({cgen[s], {S.cgen.p, ncount[s] * 4}}); }
+    if (ngenomes) up.push_back({gsize[s], {S.gsize.p, ngenomes * 4}});
   }
-  uint64_t* pin = host_words();
-  MG_HIP(hipMemcpyAsync(pin, d_bad, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MG_HIP(hipStreamSynchronize(st));
-  if (pin[0]) return fail(MG_ERR_ARG, "reference-pipeline table is corrupt: %llu prefix numbers / genome ids out of range or out of order",
-                          (unsigned long long)pin[0]);
   MG_TRY(alloc_marks(db.get()));
-  MG_HIP(hipStreamSynchronize(st));
+  // (the buffers may have been other kernels' a moment ago: nothing of the copy stream may land before the library stream got here)
+  MG_HIP(hipStreamSynchronize(ctx().stream));
+  db->unchecked = true;
+  MG_TRY(upload_ranges_begin(up, &db->pending));
   *out = db.release();
+  return MG_OK;
+}
+
+int mg_refdb_upload(uint64_t ngenomes, int nk, const int* ks, uint64_t npairs, const uint64_t* pair_hash, const uint32_t* pair_gen,
+                    const uint32_t* gsize_kmax, uint64_t max_hash, const uint32_t* const* pa, const uint32_t* const* pb,
+                    const uint64_t* nprefix, const uint32_t* const* cid, const uint32_t* const* cgen, const uint64_t* ncount,
+                    const uint32_t* const* gsize, mg_refdb** out) {
+  mg_refdb* db = nullptr;
+  MG_TRY(mg_refdb_upload_begin(ngenomes, nk, ks, npairs, pair_hash, pair_gen, gsize_kmax, max_hash, pa, pb, nprefix, cid, cgen, ncount, gsize, &db));
+  const int rc = refdb_ready(db);
+  if (rc != MG_OK) { delete db; return rc; }
+  *out = db;
   return MG_OK;
 }
 
@@ -362,6 +401,7 @@ int mg_refdb_sizes(const mg_refdb* db, uint64_t* npairs, uint64_t* nprefix, uint
 int mg_refdb_download_kmax(const mg_refdb* db, uint64_t* pair_hash, uint32_t* pair_gen, uint32_t* gsize, uint64_t* kmer_hi, uint64_t* kmer_lo) {
   MG_REQUIRE_READY();
   if (!db) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(refdb_ready(db));
   const uint64_t n = db->kmax.total, G = db->kmax.ngenomes;
   if (pair_hash && n) MG_TRY(mg_memcpy_d2h(pair_hash, db->kmax.pair_hash.p, n * 8));
   if (pair_gen && n) MG_TRY(mg_memcpy_d2h(pair_gen, db->kmax.pair_gen.p, n * 4));
@@ -375,6 +415,7 @@ int mg_refdb_download_kmax(const mg_refdb* db, uint64_t* pair_hash, uint32_t* pa
 int mg_refdb_download_k(const mg_refdb* db, int ki, uint32_t* pa, uint32_t* pb, uint32_t* cid, uint32_t* cgen, uint32_t* gsize) {
   MG_REQUIRE_READY();
   if (!db || ki < 0 || ki >= db->nk - 1) return fail(MG_ERR_ARG, "no such k below the largest");
+  MG_TRY(refdb_ready(db));
   const mg_refdb::Small& S = db->small[ki];
   const uint64_t n = db->kmax.total, G = db->kmax.ngenomes;
   if (pa && n) MG_TRY(mg_memcpy_d2h(pa, S.pa.p, n * 4));
@@ -395,7 +436,10 @@ int mg_refdb_marks(const mg_refdb* db, int ki, uint32_t** d_marks, uint64_t* nwo
 int mg_refdb_nk(const mg_refdb* db) { return db ? db->nk : 0; }
 uint64_t mg_refdb_ngenomes(const mg_refdb* db) { return db ? db->kmax.ngenomes : 0; }
 uint64_t mg_refdb_max_hash(const mg_refdb* db) { return db ? db->kmax.max_hash : 0; }
-const mg_db* mg_refdb_kmax_table(const mg_refdb* db) { return db ? &db->kmax : nullptr; }
+const mg_db* mg_refdb_kmax_table(const mg_refdb* db) {  // (what the caller does with it reads the pairs: they have to be there, and checked)
+  if (!db || refdb_ready(db) != MG_OK) return nullptr;
+  return &db->kmax;
+}
 void mg_refdb_free(mg_refdb* db) { delete db; }
 
 }  // extern "C"

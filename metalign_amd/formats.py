@@ -108,7 +108,9 @@ class SketchTable:
         self.definition = self.meta.get("stage_a_definition", "sketch_per_k")
         self.refpipe = self.definition == "reference_pipeline"
         with open(os.path.join(path, "names.txt")) as fh:
-            self.names = [ln.rstrip("\n") for ln in fh]
+            self.names = fh.read().split("\n")
+        if self.names and self.names[-1] == "":
+            self.names.pop()
         self.ngenomes = len(self.names)
         self._maps = {}
 

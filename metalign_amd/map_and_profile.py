@@ -61,11 +61,14 @@ def get_acc2info(args):
     """db_info -> (acc2info, taxid2info) exactly as the reference builds them (:64-81)."""
     echo('Reading dbinfo file...', args.verbose)
     acc2info, taxid2info = {}, {}
+    rank_of = {}  # (a genome's accessions share their lineage: the rank of a lineage string is worked out once)
     with open(args.dbinfo, 'r') as fh:
         fh.readline()
         for row in fh:
             acc, acclen, taxid, namelin, taxlin = row.strip().split('\t')
-            rank = get_taxid_rank(taxlin)
+            rank = rank_of.get(taxlin)
+            if rank is None:
+                rank = rank_of[taxlin] = get_taxid_rank(taxlin)
             if rank == 'strain' and acc != 'Unmapped':
                 taxid, taxlin = taxid + '.1', taxlin + '.1'
             acclen = int(acclen)

@@ -195,3 +195,51 @@ def test_edges(hip, oracle_lib, mode):
         hip.refpipe_containment(sk, table, 2)
     for x in (sk, d_b, d_o, table, t0, empty):
         x.free()
+
+
+def test_a_table_that_goes_up_beside_the_reads(hip, oracle_lib):
+    """mg_refdb_upload_begin (refdb_upload(..., wait=False): what select_main does): the handle comes back while the library's
+    threads still copy the arrays up; max_hash / ngenomes answer at once; the first call that reads the table waits for it and
+    checks it — the same columns as the table uploaded at once, and a corrupt table is refused THERE."""
+    rng = np.random.default_rng(4242)
+    genomes, reads = refpipe_case(rng, ngenomes=40, glen=(20_000, 30_000))
+    ks, n = [21, 31, 51], 2000
+    gb, go = flat(genomes)
+    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], n)
+    built = hip.refdb_build(h, khi, klo, o, ks)
+    got = built.download(kmers=False)
+    rb, ro = flat(reads)
+    d_b, d_o = hip.array(rb), hip.array(ro)
+    small = [got["small"][k] for k in ks[:-1]]
+    for rep in range(3):  # (several: the uploader's slots and threads are made and joined every time)
+        up = hip.refdb_upload(ks, len(genomes), got["pair_hash"], got["pair_gen"], got["gsize"], built.max_hash, small, wait=False)
+        assert up.max_hash == built.max_hash and up.ngenomes == len(genomes)
+        sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(reads), ks[-1], up.max_hash, 0, None)  # (the stream's place: work beside the upload)
+        hits, sizes = hip.refpipe_containment(sk, up, 2)
+        whits, wsizes = hip.refpipe_containment(sk, built, 2)
+        assert np.array_equal(hits, whits) and np.array_equal(sizes, wsizes)
+        same = up.download(kmers=False)
+        assert np.array_equal(same["pair_hash"], got["pair_hash"]) and np.array_equal(same["small"][ks[0]]["cid"], got["small"][ks[0]]["cid"])
+        sk.free()
+        up.free()
+    # freed before anything read it: the uploader is joined, nothing is left behind
+    hip.refdb_upload(ks, len(genomes), got["pair_hash"], got["pair_gen"], got["gsize"], built.max_hash, small, wait=False).free()
+    # a corrupt table: accepted by begin, refused by the first reader (and by mg_refdb_upload at once)
+    bad_gen = got["pair_gen"].copy()
+    bad_gen[len(bad_gen) // 2] = len(genomes) + 7
+    bad = hip.refdb_upload(ks, len(genomes), got["pair_hash"], bad_gen, got["gsize"], built.max_hash, small, wait=False)
+    sk = hip.sketch_reads_dev(d_b.ptr, d_o.ptr, len(reads), ks[-1], built.max_hash, 0, None)
+    with pytest.raises(Exception, match="corrupt"):
+        hip.refpipe_containment(sk, bad, 2)
+    bad.free()
+    with pytest.raises(Exception, match="corrupt"):
+        hip.refdb_upload(ks, len(genomes), got["pair_hash"], bad_gen, got["gsize"], built.max_hash, small)
+    bad_pa = dict(small[0])
+    bad_pa["pa"] = small[0]["pa"].copy()
+    bad_pa["pa"][3] = 0xFFFFFFF0
+    bad = hip.refdb_upload(ks, len(genomes), got["pair_hash"], got["pair_gen"], got["gsize"], built.max_hash, [bad_pa] + small[1:], wait=False)
+    with pytest.raises(Exception, match="corrupt"):
+        bad.kmax_table()
+    bad.free()
+    for x in (sk, built, d_b, d_o):
+        x.free()
