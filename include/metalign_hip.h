@@ -74,7 +74,9 @@ int mg_device_count(void);
  * flush interval, grid size), lds_pad, force_list, distinct_hint_ppm (stage A's distinct-count estimate as parts per million of the
  * expected candidates: forces table overflows), resident_scan, no_fused, resident_ablate, flush_order (1: filter words first, 2: slots
  * first), no_avx2, gzip_threads, pgzip_chunk, pgzip_thp, pgzip_timing (the host inflater), stream_thin, stream_threads (the file
- * readers).  Needs no device and no mg_init.  MG_ERR_ARG for a key that does not exist. */
+ * readers), inflate_trace, inflate_loose_find (the device inflater: a line per stage and hole on stderr; block starts by the format's
+ * rules alone), shares_threads (mg_multimapped_shares: 1 = the serial loop, 2 / 4 / 8 host threads; 0 = by the list's length).
+ * Needs no device and no mg_init.  MG_ERR_ARG for a key that does not exist. */
 int mg_debug_set(const char* key, int64_t value);
 int64_t mg_debug_get(const char* key);
 

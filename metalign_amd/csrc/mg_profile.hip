@@ -1437,9 +1437,9 @@ int mg_profile_commit_reset_dev(mg_profile* p, int incoming_dropped, int first_s
 #pragma clang fp contract(off)
 // resolve_multi_prop's per-read split (scripts/map_and_profile.py:269-312) in the reference's ORDER OF ADDITIONS per taxon.  One read's
 // shares — its distinct taxa that still have an entry, weight / sum of weights x hitlen [/ genome length] — depend on nothing but the
-// read; what must keep its order is every taxon's running sum.  So, for a long list: host threads work the reads' shares out into a
-// list (read order kept: a thread takes a contiguous run of reads), then every thread adds up the taxa it owns (t mod threads) over the
-// whole list, in read order — bit for bit the serial loop (14 -> 5 ms for the 2.5M multimapped reads of bench.py's records).
+// read; what must keep its order is every taxon's running sum.  So, for a long list: host threads take contiguous runs of reads and
+// sort their shares into one list per OWNER of the taxon (eight neighbouring taxa — a cache line of sums — have one owner); then every
+// owner adds its lists up, run after run: each taxon's additions in read order, bit for bit the serial loop.
 int mg_multimapped_shares(const uint64_t* mm_offsets, uint64_t nreads, const uint32_t* mm_tax, const uint64_t* mm_hitlen,
                           const double* weight, uint32_t ntax, const double* genome_len, double* extra, uint8_t* touched) {
   if (!extra || !touched || !weight || (nreads && (!mm_offsets || !mm_tax || !mm_hitlen)))
@@ -1447,18 +1447,18 @@ int mg_multimapped_shares(const uint64_t* mm_offsets, uint64_t nreads, const uin
   for (uint32_t t = 0; t < ntax; ++t) { extra[t] = 0.0; touched[t] = 0; }
   if (nreads == 0) return MG_OK;
   const uint64_t nent = mm_offsets[nreads] - mm_offsets[0];
-  unsigned nth = std::thread::hardware_concurrency();
-  if (nth > 8) nth = 8;
-  if (nth < 1 || nent < (1u << 16)) nth = 1;
-  // phase 1: per read, its shares at the read's own place in the entry arrays (at most as many as it has entries)
-  std::vector<uint32_t> s_tax(nent);
-  std::vector<double> s_part(nent);
-  std::vector<uint32_t> s_n(nreads);
+  const unsigned hw = std::thread::hardware_concurrency();
+  unsigned nth = nent >= (1u << 16) && hw >= 8 ? 8u : 1u;  // (a power of two; two or four threads lose to the serial loop: the lists cost more than they save)
+  if (const int64_t forced = dbg("shares_threads")) nth = forced >= 8 ? 8u : forced >= 4 ? 4u : forced >= 2 ? 2u : 1u;  // (tests, probes)
+  struct Share { uint32_t t; double part; };
+  std::vector<std::vector<Share>> lists((size_t)nth * nth);  // [run of reads][owner]
   std::atomic<uint32_t> bad_taxon{0xffffffffu};
-  auto shares_of = [&](uint64_t r0, uint64_t r1) {
+  auto shares_of = [&](unsigned run, uint64_t r0, uint64_t r1) {
     std::vector<uint32_t> taxa;
+    std::vector<Share>* mine = &lists[(size_t)run * nth];
+    if (nth > 1)
+      for (unsigned o = 0; o < nth; ++o) mine[o].reserve((size_t)((mm_offsets[r1] - mm_offsets[r0]) / nth + 1024));
     for (uint64_t i = r0; i < r1; ++i) {
-      s_n[i] = 0;
       taxa.clear();
       for (uint64_t e = mm_offsets[i]; e < mm_offsets[i + 1]; ++e) {
         const uint32_t t = mm_tax[e];
@@ -1472,44 +1472,42 @@ int mg_multimapped_shares(const uint64_t* mm_offsets, uint64_t nreads, const uin
       for (uint32_t t : taxa) denom += weight[t];
       if (denom == 0.0) continue;
       const double hitlen = (double)mm_hitlen[i];
-      uint64_t at = mm_offsets[i] - mm_offsets[0];
       for (uint32_t t : taxa) {
         double part = (weight[t] / denom) * hitlen;
         if (genome_len) part = part / genome_len[t];
-        s_tax[at] = t;
-        s_part[at] = part;
-        ++at;
-      }
-      s_n[i] = (uint32_t)taxa.size();
-    }
-  };
-  // phase 2: the taxa of one owner, over all reads in order
-  auto add_up = [&](uint32_t owner, uint32_t owners) {
-    for (uint64_t i = 0; i < nreads; ++i) {
-      const uint64_t at = mm_offsets[i] - mm_offsets[0];
-      for (uint32_t j = 0; j < s_n[i]; ++j) {
-        const uint32_t t = s_tax[at + j];
-        if (owners > 1 && t % owners != owner) continue;
-        extra[t] += s_part[at + j];
-        touched[t] = 1;
+        if (nth == 1) {
+          extra[t] += part;
+          touched[t] = 1;
+        } else {
+          mine[(t >> 3) & (nth - 1)].push_back(Share{t, part});
+        }
       }
     }
   };
   if (nth == 1) {
-    shares_of(0, nreads);
+    shares_of(0, 0, nreads);
     if (bad_taxon.load() != 0xffffffffu) return fail(MG_ERR_ARG, "multimapped taxon %u outside [0,%u)", bad_taxon.load(), ntax);
-    add_up(0, 1);
     return MG_OK;
   }
   {
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < nth; ++k) th.emplace_back(shares_of, nreads * k / nth, nreads * (k + 1) / nth);
+    for (unsigned k = 0; k < nth; ++k) th.emplace_back(shares_of, k, nreads * k / nth, nreads * (k + 1) / nth);
     for (auto& t : th) t.join();
   }
   if (bad_taxon.load() != 0xffffffffu) return fail(MG_ERR_ARG, "multimapped taxon %u outside [0,%u)", bad_taxon.load(), ntax);
   {
+    auto add_up = [&](unsigned owner) {
+      std::vector<uint8_t> seen(ntax, 0);  // (64 taxa to a cache line of marks: every owner its own, merged below)
+      for (unsigned run = 0; run < nth; ++run)
+        for (const Share& s : lists[(size_t)run * nth + owner]) {
+          extra[s.t] += s.part;
+          seen[s.t] = 1;
+        }
+      for (uint32_t t0 = owner * 8u; t0 < ntax; t0 += 8u * nth)
+        for (uint32_t t = t0; t < t0 + 8u && t < ntax; ++t) touched[t] = seen[t];
+    };
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < nth; ++k) th.emplace_back(add_up, k, nth);
+    for (unsigned k = 0; k < nth; ++k) th.emplace_back(add_up, k);
     for (auto& t : th) t.join();
   }
   return MG_OK;

@@ -92,6 +92,7 @@ def test_library_multimap_resolution_equals_numpy_bit_for_bit():
     import argparse
     import copy
     from metalign_amd import map_and_profile as mp
+    from metalign_amd import _hip as _hip_mod
     rng = np.random.default_rng(9)
     for trial in range(8):
         big = trial >= 6  # (a list long enough for the library's host THREADS: the same sums, every taxon in read order)
@@ -115,3 +116,9 @@ def test_library_multimap_resolution_equals_numpy_bit_for_bit():
             got = mp.resolve_multi_prop_csr(args, copy.deepcopy(t2a), mm, t2i)
             want = mp.resolve_multi_prop_csr_numpy(args, copy.deepcopy(t2a), mm, t2i)
             assert got == want, (trial, ln)
+            for threads in (1, 2, 8):  # (forced: the short lists too, and the serial loop on the long ones)
+                _hip_mod.debug_set("shares_threads", threads)
+                try:
+                    assert mp.resolve_multi_prop_csr(args, copy.deepcopy(t2a), mm, t2i) == want, (trial, ln, threads)
+                finally:
+                    _hip_mod.debug_set("shares_threads", 0)
