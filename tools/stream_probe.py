@@ -46,6 +46,15 @@ def once(chunk, threads):
 
 
 once(64 << 20, 8)  # distinct-count hint, clocks
+if os.environ.get("MG_PROBE_AB"):  # a knob of the library off / on, alternating, at the pipeline's default chunk size and readers
+    from metalign_amd import _hip as _hipmod
+    for rep in range(4):
+        for v in (0, 1):
+            _hipmod.debug_set(os.environ["MG_PROBE_AB"], v)
+            warm = min(once(0, 0)[0] for _ in range(3))
+            print("%s = %d: warm %.4f s = %.1f GB/s" % (os.environ["MG_PROBE_AB"], v, warm, nbytes / warm / 1e9), flush=True)
+    _hipmod.debug_set(os.environ["MG_PROBE_AB"], 0)
+    sys.exit(0)
 for chunk_mb in (8, 16, 32, 64, 128):
     for threads in (4, 8, 16, 32):
         cold, s1 = once(chunk_mb << 20, threads)
