@@ -71,6 +71,10 @@ def main():
     hip = _hip.Hip.get(0)
     if os.environ.get("MG_INFLATE_TRACE"):  # every stage's jobs, the jobs decoded twice and the holes of the chain on stderr
         _hip.debug_set("inflate_trace", 1)
+    if os.environ.get("MG_PROBE_STAGE_MB"):  # compressed bytes per stage instead of the device's round of jobs
+        hip.inflate_config(stage_bytes=int(os.environ["MG_PROBE_STAGE_MB"]) << 20)
+    if os.environ.get("MG_PROBE_CHUNK_KB"):
+        hip.inflate_config(chunk_bytes=int(os.environ["MG_PROBE_CHUNK_KB"]) << 10)
     k = 51
     dbh, dbo = hip.sketch_genomes(gb, go, k, 1000)
     hmax = int(dbh.max())
