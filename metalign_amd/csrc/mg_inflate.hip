@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void k_find_block_starts(const uint32_t* __rest
 }
 
 template <class OutT>
-__global__ __launch_bounds__(64) void k_inflate(const uint32_t* __restrict__ in, uint64_t nbytes, int input_final, const Job* __restrict__ jobs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_inflate(const uint32_t* __restrict__ in, uint64_t nbytes, int input_final, const Job* __restrict__ jobs,
                                                 OutT* out, Result* __restrict__ results, Event* events, uint32_t* nevents, uint32_t max_events,
                                                 uint16_t* tails) {
   __shared__ Shared sh;

@@ -101,8 +101,8 @@ struct Event {                   // a member ended inside a job (not F_ONE_MEMBE
 // (16-bit table entries — code length | symbol << 4, base and extra bits recomputed per look-up — were measured: 7 KB of LDS and 23
 // wavefronts per CU instead of 10.5 KB and 15, and 20 % SLOWER: the kernel is bound by instructions issued, not by latency hidden)
 struct Shared {
-  uint32_t lit[1 << LB];
-  uint32_t dist[1 << DB];
+  uint16_t lit[1 << LB];         // 16-bit entries (lit16 / dist16 below): 2.5 KB of tables instead of 5 — twenty-four jobs per CU
+  uint16_t dist[1 << DB];
   uint16_t cnt[2][16], first[2][16], offs[2][16];  // (16 bits each: with the 64-word stage a job takes 10 064 bytes of LDS — SIXTEEN per CU)
   uint16_t sorted[320];          // symbols by (length, symbol): [0, 288) literal/length, [288, 320) distance
   uint32_t nshort, err;
@@ -163,6 +163,38 @@ MGI_HD uint32_t dist_entry(uint32_t s, uint32_t l) {
   if (s > 29) return l | (K_BAD << 8);
   const uint32_t b = dist_sym(s);
   return l | ((b >> 16) << 4) | (K_DIST << 8) | ((b & 0xffff) << 16);
+}
+
+// The window decode's tables hold 16-bit entries:
+//   literal/length  bits 0-3 the code's length (1 .. LB), bit 4 = a length symbol, bits 5-7 its extra bits, bits 8-15 the literal | the
+//                   length's base - 3;  length 0 = not for the window decode: bits 4-7 say why (K_EOB with the code's length in bits
+//                   8-11, K_LONG, K_BAD; an empty slot reads as K_BAD)
+//   distance        bits 0-3 the code's length (1 .. DB), bits 4-8 the distance symbol (base and extra bits are arithmetic: dist_sym);
+//                   length 0: bits 4-7 why (K_LONG, K_BAD)
+MGI_HD uint32_t lit16(uint32_t s, uint32_t l) {
+  if (s < 256) return l | (s << 8);
+  if (s == 256) return (K_EOB << 4) | (l << 8);
+  if (s > 285) return K_BAD << 4;
+  const uint32_t b = len_sym(s - 257);
+  return l | (1u << 4) | ((b >> 16) << 5) | (((b & 0xffffu) - 3u) << 8);
+}
+MGI_HD uint32_t dist16(uint32_t s, uint32_t l) { return s > 29 ? (uint32_t)(K_BAD << 4) : l | (s << 4); }
+// ... as the 32-bit entries the scalar path works with (lit_entry / dist_entry)
+MGI_HD uint32_t wide_lit(uint32_t c) {
+  const uint32_t nb = c & 15u;
+  if (nb) {
+    const uint32_t is_len = (c >> 4) & 1u;
+    return nb | (((c >> 5) & 7u) << 4) | ((is_len ? K_LEN : K_LIT) << 8) | (((c >> 8) + (is_len ? 3u : 0u)) << 16);
+  }
+  const uint32_t why = (c >> 4) & 15u;
+  if (why == K_EOB) return ((c >> 8) & 15u) | (K_EOB << 8);
+  if (why == K_LONG) return K_LONG << 8 | 15u;
+  return 0u;
+}
+MGI_HD uint32_t wide_dist(uint32_t c) {
+  const uint32_t dn = c & 15u;
+  if (dn) return dist_entry((c >> 4) & 31u, dn);
+  return ((c >> 4) & 15u) == K_LONG ? (K_LONG << 8 | 15u) : 0u;
 }
 
 MGI_HDI uint32_t expand_lit(uint32_t c) {
@@ -336,7 +368,7 @@ struct DevExec {
 template <class Exec>
 MGI_HD uint32_t build_table(Exec& ex, Shared& sh, int which, uint32_t base, uint32_t n, bool table, bool strict = false) {
   const uint32_t TB = which ? DB : LB;
-  uint32_t* tab = which ? sh.dist : sh.lit;
+  uint16_t* tab = which ? sh.dist : sh.lit;
   ex.lanes([&](int lane) {
     if (lane < 16) sh.cnt[which][lane] = 0;
     for (uint32_t i = (uint32_t)lane; i < 80; i += 64) (&sh.blkcnt[0][0])[i] = 0;
@@ -384,9 +416,9 @@ MGI_HD uint32_t build_table(Exec& ex, Shared& sh, int which, uint32_t base, uint
       for (uint32_t j = 0; j < (uint32_t)lane; ++j) r += sh.cl[base + s0 + j] == l;
       sh.sorted[(which ? 288 : 0) + sh.offs[which][l] + r] = (uint16_t)s;
       const uint32_t rc = bitrev(sh.first[which][l] + r, l);  // the code as its bits arrive
-      const uint32_t e = which ? dist_entry(s, l) : lit_entry(s, l);
+      const uint16_t e = (uint16_t)(which ? dist16(s, l) : lit16(s, l));
       if (l > TB) {
-        tab[rc & ((1u << TB) - 1u)] = K_LONG << 8 | 15u;  // (the slow path finds the length)
+        tab[rc & ((1u << TB) - 1u)] = (uint16_t)(K_LONG << 4);  // (the slow path finds the length)
       } else if ((1u << (TB - l)) >= 64u) {
         const uint32_t i = Exec::atomic_fetch_inc(&sh.nshort);
         sh.shortsym[i] = (uint16_t)s;
@@ -402,7 +434,7 @@ MGI_HD uint32_t build_table(Exec& ex, Shared& sh, int which, uint32_t base, uint
     ex.lanes([&](int lane) {
       for (uint32_t i = 0; i < ns; ++i) {
         const uint32_t s = sh.shortsym[i], rc = sh.shortrc[i], l = sh.cl[base + s];
-        const uint32_t e = which ? dist_entry(s, l) : lit_entry(s, l);
+        const uint16_t e = (uint16_t)(which ? dist16(s, l) : lit16(s, l));
         for (uint32_t j = (uint32_t)lane; j < (1u << (TB - l)); j += 64) tab[rc + (j << l)] = e;
       }
     });
@@ -519,7 +551,7 @@ MGI_HD void fixed_lengths(Exec& ex, Shared& sh) {
 // bits.  -> K_LIT / K_LEN with *len, *hi (distance | literal << 16), K_EOB, or K_BAD.
 MGI_HD uint32_t decode_one(const Shared& sh, BitReader& br, uint32_t* len, uint32_t* hi) {
   br.refill();
-  uint32_t e = MGI_UNI(sh.lit[(uint32_t)br.bb & ((1u << LB) - 1u)]);
+  uint32_t e = wide_lit(MGI_UNI(sh.lit[(uint32_t)br.bb & ((1u << LB) - 1u)]));
   if (((e >> 8) & 7u) == K_LONG) e = slow_entry(sh, 0, br.bb);
   if ((e & 15u) == 0) return K_BAD;
   br.drop(e & 15u);
@@ -528,7 +560,7 @@ MGI_HD uint32_t decode_one(const Shared& sh, BitReader& br, uint32_t* len, uint3
   if (kind != K_LEN) return kind == K_EOB ? K_EOB : K_BAD;
   *len = (e >> 16) + br.bits((e >> 4) & 15u);
   br.refill();
-  uint32_t d = MGI_UNI(sh.dist[(uint32_t)br.bb & ((1u << DB) - 1u)]);
+  uint32_t d = wide_dist(MGI_UNI(sh.dist[(uint32_t)br.bb & ((1u << DB) - 1u)]));
   if (((d >> 8) & 7u) == K_LONG) d = slow_entry(sh, 1, br.bb);
   if ((d & 15u) == 0 || ((d >> 8) & 7u) != K_DIST) return K_BAD;
   br.drop(d & 15u);
@@ -543,19 +575,22 @@ MGI_HDI void decode_at(const Shared& sh, uint32_t b0, uint32_t b1, uint32_t* tot
   // (no branches: the lanes of a wavefront hold literals and matches side by side, both ways would be walked anyway; a literal's
   // distance look-up reads some entry and is thrown away)
   const uint32_t e = sh.lit[b0 & ((1u << LB) - 1u)];
-  const uint32_t nb = e & 15u, xb = (e >> 4) & 15u, kind = (e >> 8) & 7u;
-  const uint32_t length = (e >> 16) + ((b0 >> nb) & ((1u << xb) - 1u));
-  const uint32_t c1 = (nb + xb) & 31u;  // 1..20 for a length symbol
+  const uint32_t nb = e & 15u, is_len = (e >> 4) & 1u, xb = (e >> 5) & 7u, v = e >> 8;  // (a literal's extra bits are 0: c1 = nb)
+  const uint32_t length = v + 3u + ((b0 >> nb) & ((1u << xb) - 1u));
+  const uint32_t c1 = nb + xb;  // at most 15
   const uint32_t y = (uint32_t)((((uint64_t)b1 << 32) | b0) >> c1);
   const uint32_t d = sh.dist[y & ((1u << DB) - 1u)];
-  const uint32_t dn = d & 15u, dxb = (d >> 4) & 15u, dk = (d >> 8) & 7u;
-  const uint32_t distance = (d >> 16) + ((y >> dn) & ((1u << dxb) - 1u));
-  const bool is_lit = kind == K_LIT && nb != 0, is_len = kind == K_LEN && nb != 0;
-  const bool is_match = is_len && dk == K_DIST && dn != 0;
-  const uint32_t why = nb == 0 ? (uint32_t)K_BAD : is_len ? (dk == K_LONG ? (uint32_t)K_LONG : (uint32_t)K_BAD) : kind;
-  *tot = is_lit ? nb : is_match ? c1 + dn + dxb : 0u;
+  const uint32_t dn = d & 15u, ds = (d >> 4) & 31u;
+  const uint32_t dx = ds < 2u ? 0u : (ds - 2u) >> 1;                              // dist_sym, branch-free
+  const uint32_t dbase = ds < 2u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
+  const uint32_t distance = dbase + ((y >> dn) & ((1u << dx) - 1u));
+  const bool ok = nb != 0u;
+  const bool is_lit = ok && !is_len, is_match = ok && is_len && dn != 0u;
+  const uint32_t wl = (e >> 4) & 15u, wd = (d >> 4) & 15u;                        // why, of an entry without a length
+  const uint32_t why = !ok ? (wl ? wl : (uint32_t)K_BAD) : (wd == K_LONG ? (uint32_t)K_LONG : (uint32_t)K_BAD);
+  *tot = is_lit ? nb : is_match ? c1 + dn + dx : 0u;
   *len = is_lit ? 1u : is_match ? length : why;
-  *hi = is_lit ? (e >> 16) << 16 : is_match ? distance : 0u;
+  *hi = is_lit ? v << 16 : is_match ? distance : 0u;
 }
 
 // the word of a window's 256-bit membership set that holds lane's four positions; those four bits
