@@ -15,8 +15,9 @@
 //             window in LDS); k_resolve_text turns symbols into bytes at their final place; k_crc_segments + the host check
 //             every member's CRC-32 and ISIZE.
 //
-// A file goes through in STAGES of compressed bytes (default 128 MB: ~4000 jobs in flight), the next stage starting at the
-// bit where the previous one ended, with its window.  The compressed bytes go up through page-locked slots filled by reader
+// A file goes through in STAGES of compressed bytes (as many as make one ROUND of jobs: 24 per CU — the decoder is bound by its own
+// latency, so the jobs in flight are what counts; 6144 jobs = ~197 MB on 256 CUs), the next stage starting at the bit where the
+// previous one ended, with its window.  The compressed bytes go up through page-locked slots filled by reader
 // threads while earlier stages decode.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void k_crc_segments(const uint8_t* __restrict_
 struct InflateConfig {
   uint64_t chunk_bytes = 32u << 10;   // compressed bytes per job of a gzip stream
   // compressed bytes per stage.  0 = sized by the device: jobs take about the same time each, so a launch runs in ROUNDS of as many
-  // jobs as the chip holds at once (16 per CU, bounded by LDS: 4096 on 256 CUs) and a stage of 1.4 rounds costs two — a stage is
+  // jobs as the chip holds at once (24 per CU, bounded by LDS and registers: 6144 on 256 CUs) and a stage of 1.4 rounds costs two — a stage is
   // what is left of the file cut into equal parts of at most one round of jobs, at the jobs per byte the stages before it had
   uint64_t stage_bytes = 0;
   uint32_t ratio = 10;                // symbols reserved per compressed byte of a job (a job that needs more is decoded again)

@@ -103,7 +103,7 @@ struct Event {                   // a member ended inside a job (not F_ONE_MEMBE
 struct Shared {
   uint16_t lit[1 << LB];         // 16-bit entries (lit16 / dist16 below): 2.5 KB of tables instead of 5 — twenty-four jobs per CU
   uint16_t dist[1 << DB];
-  uint16_t cnt[2][16], first[2][16], offs[2][16];  // (16 bits each: with the 64-word stage a job takes 10 064 bytes of LDS — SIXTEEN per CU)
+  uint16_t cnt[2][16], first[2][16], offs[2][16];  // (16 bits each; the whole struct is 6 608 bytes: twenty-four jobs per CU)
   uint16_t sorted[320];          // symbols by (length, symbol): [0, 288) literal/length, [288, 320) distance
   uint32_t nshort, err;
   union {
