@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random gzip streams through the device inflater (mg_inflate_dev) against zlib: texts, FASTQ-like records, binary noise, long runs,
 mixtures; levels 1-9, several members, Z_SYNC / Z_FULL flushes, Z_FIXED / Z_HUFFMAN_ONLY / Z_RLE strategies, small and large chunk / stage
-settings, both decoders.  python tools/inflate_soak.py [streams] [seed]"""
+settings, both decoders.  python tools/inflate_soak.py [streams] [seed] [corrupt]
+(corrupt: every stream damaged — bits flipped, cut — and zlib's verdict expected: an error, or the same text)."""
 import os
 import sys
 import zlib
@@ -58,18 +59,54 @@ def main():
     nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     hip = _hip.Hip.get(0)
-    total = 0
+    corrupt = len(sys.argv) > 3 and sys.argv[3] == "corrupt"
+    total = refused = 0
     for i in range(nstreams):
         n = int(rng.choice([0, 1, 100, 5000, 70_000, 400_000, 3_000_000, 12_000_000], p=[.02, .03, .1, .15, .2, .25, .2, .05]))
         data = payload(rng, n) if n else b""
         gz = compress(rng, data)
         hip.inflate_config(chunk_bytes=int(rng.choice([4 << 10, 16 << 10, 32 << 10, 100_000])), stage_bytes=int(rng.choice([-1, -1, 300_000, 2 << 20])),
                            ratio=int(rng.choice([10, 10, 2, 40])), lane_jobs=0 if rng.random() < 0.2 else 1 << 40)
+        if corrupt and len(gz) > 30:  # a damaged stream: zlib's verdict is the expected one (an error, or — a flipped header byte — the same text)
+            b = bytearray(gz)
+            for _ in range(int(rng.integers(1, 4))):
+                if rng.random() < 0.3:
+                    del b[int(rng.integers(len(b) // 2, len(b))):]  # cut
+                else:
+                    b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            gz = bytes(b)
+            try:
+                d = zlib.decompressobj(47)
+                want, rest = d.decompress(gz), d.unused_data
+                while rest and b"\x1f\x8b\x08".startswith(rest[:3]) or rest[:3] == b"\x1f\x8b\x08":  # further members, as gzip reads them:
+                    # what follows a member is one if it starts like one — also when the file ends inside the three bytes that say so
+                    if len(rest) < 3:
+                        raise zlib.error("ends inside a member header")
+                    d = zlib.decompressobj(31)
+                    want += d.decompress(rest)
+                    if not d.eof:
+                        raise zlib.error("truncated member")
+                    rest = d.unused_data
+                if not d.eof:
+                    raise zlib.error("truncated")
+            except zlib.error:
+                want = None
+            try:
+                got = hip.inflate(gz)
+            except OSError:
+                got = None
+            assert got == want, "damaged stream %d: zlib %s, device %s" % (i, "refuses" if want is None else "%d bytes" % len(want),
+                                                                         "refuses" if got is None else "%d bytes" % len(got))
+            refused += want is None
+            continue
         got = hip.inflate(gz)
         assert got == data, "stream %d: %d bytes in, %d out, %d expected" % (i, len(gz), len(got), len(data))
         total += len(data)
     hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=-1, ratio=10, lane_jobs=1 << 40)
-    print("ok: %d streams, %.1f MB of text, all equal to what zlib compressed" % (nstreams, total / 1e6))
+    if corrupt:
+        print("ok: %d damaged streams, %d refused by both, the rest read alike" % (nstreams, refused))
+    else:
+        print("ok: %d streams, %.1f MB of text, all equal to what zlib compressed" % (nstreams, total / 1e6))
 
 
 if __name__ == "__main__":
