@@ -2,6 +2,7 @@
 tests/test_pgzip.py (levels, members, padding, header fields, stored blocks, binary data, truncated / corrupt streams refused),
 BGZF, many stages, jobs that overflow their reservation, and the streaming entry points on `.gz` files."""
 import gzip
+import os
 import struct
 import zlib
 
@@ -162,3 +163,21 @@ def test_streamed_gz_files_give_what_the_plain_files_give(cfg, tmp_path):
             tgs._same(got, want)
             st = hip.inflate_stats()
             assert (st["jobs"] > 0) == (on == 1) and (stage != 100_000 or name.startswith("bgzf") or st["stages"] > 5), (name, stage, on, st)
+
+
+def test_random_streams_and_damaged_ones_against_zlib(hip):
+    """tools/inflate_soak.py in small: random payloads (text, FASTQ-like, noise, runs), levels, members, flushes, Z_FIXED / Z_HUFFMAN_ONLY /
+    Z_RLE, random chunk / stage / ratio settings and both decoders — equal to what zlib compressed; and the same damaged (bits flipped,
+    cut): refused where zlib refuses, read alike where it does not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("inflate_soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "inflate_soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    sizes = ([0, 1, 100, 5000, 70_000, 400_000], [.05, .05, .2, .3, .25, .15])
+    try:
+        total, _ = soak.soak(hip, 60, 314, False, sizes)
+        assert total > 1_000_000
+        _, refused = soak.soak(hip, 60, 315, True, sizes)
+        assert refused > 30
+    finally:
+        hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=-1, ratio=10, on=1, lane_jobs=1 << 40)

@@ -55,14 +55,14 @@ def compress(rng, data):
     return out
 
 
-def main():
-    nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    hip = _hip.Hip.get(0)
-    corrupt = len(sys.argv) > 3 and sys.argv[3] == "corrupt"
+SIZES = ([0, 1, 100, 5000, 70_000, 400_000, 3_000_000, 12_000_000], [.02, .03, .1, .15, .2, .25, .2, .05])
+
+
+def soak(hip, nstreams, seed, corrupt, sizes=SIZES):
+    rng = np.random.default_rng(seed)
     total = refused = 0
     for i in range(nstreams):
-        n = int(rng.choice([0, 1, 100, 5000, 70_000, 400_000, 3_000_000, 12_000_000], p=[.02, .03, .1, .15, .2, .25, .2, .05]))
+        n = int(rng.choice(sizes[0], p=sizes[1]))
         data = payload(rng, n) if n else b""
         gz = compress(rng, data)
         hip.inflate_config(chunk_bytes=int(rng.choice([4 << 10, 16 << 10, 32 << 10, 100_000])), stage_bytes=int(rng.choice([-1, -1, 300_000, 2 << 20])),
@@ -103,6 +103,14 @@ def main():
         assert got == data, "stream %d: %d bytes in, %d out, %d expected" % (i, len(gz), len(got), len(data))
         total += len(data)
     hip.inflate_config(chunk_bytes=32 << 10, stage_bytes=-1, ratio=10, lane_jobs=1 << 40)
+    return total, refused
+
+
+def main():
+    nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    corrupt = len(sys.argv) > 3 and sys.argv[3] == "corrupt"
+    total, refused = soak(_hip.Hip.get(0), nstreams, seed, corrupt)
     if corrupt:
         print("ok: %d damaged streams, %d refused by both, the rest read alike" % (nstreams, refused))
     else:
