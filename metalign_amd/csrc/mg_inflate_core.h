@@ -613,8 +613,10 @@ template <class Exec>
 #else
 #define MGI_SUB(i) do { } while (0)
 #endif
-MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, uint32_t* nsym_out, uint32_t* T_out, uint32_t* nstep = nullptr,
-                             uint64_t* sub = nullptr) {
+// *inbuf_base: which compressed words sh.inbuf holds (~0: none) — it lives from batch to batch of a job: a batch starts where the one
+// before ended, in words the stage mostly still holds (every batch used to begin with a trip to memory).
+MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, uint32_t* nsym_out, uint32_t* T_out, uint64_t* inbuf_base,
+                             uint32_t* nstep = nullptr, uint64_t* sub = nullptr) {
   uint32_t nsym = 0, T = 0, rc = 0, steps = 0;
 #if defined(MGI_SUBCLOCKS)
   uint64_t tick_ = MGI_CLOCK();
@@ -623,7 +625,7 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
   uint64_t pos = br.pos();
   const uint32_t* in = br.in;
   const uint64_t nwords = br.nwords;
-  uint64_t base_w = ~0ull;  // sh.inbuf = words [base_w, base_w + kInWords)
+  uint64_t base_w = *inbuf_base;  // sh.inbuf = words [base_w, base_w + kInWords)
   if (queue) {
     ex.sync();
     ex.lanes([&](int lane) { sh.headbits[lane] = 0; });
@@ -839,6 +841,7 @@ MGI_HD uint32_t decode_batch(Exec& ex, Shared& sh, BitReader& br, bool queue, ui
     }
   }
   br.init(in, nwords, pos);
+  *inbuf_base = base_w;
   *nsym_out = nsym;
   *T_out = T;
   if (nstep) *nstep += steps;
@@ -947,7 +950,7 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
   uint32_t status = 0, overflow = 0, nblocks = 0, nev = 0, crc = 0, isize = 0, nbatch = 0, nstep = 0;
   uint64_t t_tab = 0, t_dec = 0, t_emit = 0, t_tail = 0, t_sub[6] = {0, 0, 0, 0, 0, 0};
   bool count_only = (job.flags & F_COUNT_ONLY) != 0;
-  uint64_t pos = job.start_bit;
+  uint64_t pos = job.start_bit, inbuf_base = ~0ull;
   if (ex.leader()) sh.err = 0;
   if (job.flags & F_HEADER) {
     uint64_t data = 0;
@@ -1000,7 +1003,7 @@ MGI_HD void run_job(Exec& ex, Shared& sh, const uint32_t* in, uint64_t nbytes, b
       for (;;) {
         uint32_t nsym = 0, T = 0;
         const uint64_t c1 = MGI_CLOCK();
-        rc = decode_batch(ex, sh, br, !count_only, &nsym, &T, &nstep, t_sub);
+        rc = decode_batch(ex, sh, br, !count_only, &nsym, &T, &inbuf_base, &nstep, t_sub);
         ++nbatch;
         const uint64_t c2 = MGI_CLOCK();
         t_dec += c2 - c1;
