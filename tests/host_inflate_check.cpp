@@ -230,7 +230,29 @@ static int check_entered(const char* what, const std::string& text, const std::s
   return entered;
 }
 
+// the 16-bit table entries of the window decode (lit16 / dist16) say what the 32-bit entries of the scalar path say, for every symbol and
+// every code length a table slot can hold; what is not for the window decode (end of block, a symbol that does not exist) says so
+static void check_entries() {
+  for (uint32_t l = 1; l <= (uint32_t)LB; ++l)
+    for (uint32_t s = 0; s < 288; ++s) {
+      const uint32_t w = wide_lit(lit16(s, l)), e = lit_entry(s, l);
+      if (s == 256) { CHECK(w == (l | (K_EOB << 8)), "entries: end of block, length %u: %x", l, w); continue; }
+      if (s > 285) { CHECK(w == 0u, "entries: literal/length symbol %u: %x", s, w); continue; }
+      CHECK(w == e, "entries: literal/length symbol %u, length %u: %x vs %x", s, l, w, e);
+      CHECK(lit16(s, l) <= 0xffffu && (lit16(s, l) & 15u) == l, "entries: literal/length symbol %u does not fit", s);
+    }
+  for (uint32_t l = 1; l <= (uint32_t)DB; ++l)
+    for (uint32_t s = 0; s < 32; ++s) {
+      const uint32_t w = wide_dist(dist16(s, l)), e = dist_entry(s, l);
+      if (s > 29) { CHECK(w == 0u, "entries: distance symbol %u: %x", s, w); continue; }
+      CHECK(w == e && dist16(s, l) <= 0xffffu, "entries: distance symbol %u, length %u: %x vs %x", s, l, w, e);
+    }
+  CHECK(wide_lit(K_LONG << 4) == (K_LONG << 8 | 15u) && wide_dist(K_LONG << 4) == (K_LONG << 8 | 15u) && wide_lit(0) == 0u && wide_dist(0) == 0u,
+        "entries: %s", "long / empty");
+}
+
 int main() {
+  check_entries();
   const std::string fq = fastq(6000);  // ~1.9 MB
   std::string bin(300000, '\0');
   for (auto& c : bin) c = (char)rnd();
