@@ -562,6 +562,46 @@ int mg_refpipe_count_dev(const mg_refdb* db, const uint32_t* const* d_marks, uin
 int mg_refdb_marks(const mg_refdb* db, int ki, uint32_t** d_marks, uint64_t* nwords);
 
 /* ------------------------------------------------------------------------ *
+ * Stage A of the reference pipeline BY K-MER IDENTITY (round 6; the default of the reference-pipeline path).
+ * Replaces `kmc -k<kmax> -ci2 -cs3` over the reads + `kmc_tools simple ... intersect` with the sketches' k-mers
+ * (scripts/select_db.py:50-59) as those tools compute it: canonical k-mers compared as k-mers — the read side hashes
+ * nothing (MurmurHash3 only SELECTS a genome's sketch, when the table is built).  Normative: oracle/mg_oracle.c,
+ * mgo_refpipe_count_kmers.  Differs from the hash path (mg_sketch_* + mg_refpipe_mark_dev) only where two k-mers share a
+ * hash value.  k_max in [15, 64]; other k stay with the hash path.
+ *
+ * mg_refdb_index_kmers: builds, on the device, the index the read side needs over the table's distinct canonical k_max-mers
+ *   (grouped by minimizer: metalign_amd/csrc/mg_kcount_core.h).  kmer_hi / kmer_lo: the kept k_max-mer of every pair in pair
+ *   order, 2-bit packed, first base most significant (table format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64) — or NULL for a table
+ *   built here by mg_refdb_build, which holds them.  A rank of a multi-GPU job indexes the WHOLE table's pairs it was given.
+ * mg_kcounts: one sample's occurrence counters for one table (zeroed when made; mg_kcounts_reset zeroes again, stream-ordered).
+ * mg_count_kmers_dev: adds the k_max-mers of a batch of reads resident in device memory (bases as ASCII, offsets[nreads + 1];
+ *   nbases = offsets[nreads] - offsets[0], for sizing only) — one launch on the library's current stream, no host sync; a
+ *   sample streamed in pieces is a sequence of these calls.  Windows over non-ACGT symbols are skipped, either case counts.
+ * mg_kcounts_stats: [0] k-mers of the reads (KMC's total), [1] minimizer runs, [2] runs past the gate, [3] matched windows.
+ * mg_kcounts_download: per PAIR of the table min(occurrences of its k-mer, cs) (cs: mg_set_count_saturation, 0 = exact).
+ * mg_kcounts_device: the raw counters (u32[npairs], meaningful at the pairs mg_refdb_kmer_heads names) for a multi-GPU sum.
+ * mg_refpipe_mark_counts_dev / _containment_counts_dev: mg_refpipe_mark_dev / _containment_dev with "the pair's k-mer occurred
+ *   >= ci times" read from the counters instead of a read sketch (_ptr_: from counters the caller summed over the ranks). */
+typedef struct mg_kcounts mg_kcounts;
+int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* kmer_lo);
+int mg_refdb_has_kmer_index(const mg_refdb* db);
+uint64_t mg_refdb_distinct_kmers(const mg_refdb* db);
+int mg_refdb_kmer_heads(const mg_refdb* db, uint32_t* head); /* u32[npairs]: the pair that counts for each pair's k-mer */
+int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out);
+int mg_kcounts_reset(mg_kcounts* kc);
+int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t nbases, const mg_refdb* db,
+                       mg_kcounts* kc);
+int mg_kcounts_stats(const mg_kcounts* kc, uint64_t* out4);
+int mg_kcounts_download(const mg_kcounts* kc, const mg_refdb* db, uint32_t* per_pair);
+int mg_kcounts_device(const mg_kcounts* kc, uint32_t** d_counts, uint64_t* n);
+void mg_kcounts_free(mg_kcounts* kc);
+int mg_refpipe_mark_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax);
+int mg_refpipe_mark_counts_ptr_dev(const uint32_t* d_counts, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax,
+                                   uint32_t* d_sizes_kmax);
+int mg_refpipe_containment_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_t ci, uint32_t* const* d_hits,
+                                      uint32_t* const* d_sizes);
+
+/* ------------------------------------------------------------------------ *
  * Stage C — per-read taxon assignment + abundance histogram.
  * Replaces the loop of map_and_process (scripts/map_and_profile.py:193-264)
  * with parse_flag :104-111, filter_line :86-100, clean_read_hits :130-147,

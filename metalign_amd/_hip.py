@@ -28,6 +28,9 @@ EXPORTS = [
     "mg_host_alloc", "mg_host_free", "mg_memcpy_d2h_async", "mg_memcpy_h2d_async",
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
+    "mg_refdb_index_kmers", "mg_refdb_has_kmer_index", "mg_refdb_distinct_kmers", "mg_refdb_kmer_heads", "mg_kcounts_new", "mg_kcounts_reset", "mg_count_kmers_dev",
+    "mg_kcounts_stats", "mg_kcounts_download", "mg_kcounts_device", "mg_kcounts_free", "mg_refpipe_mark_counts_dev", "mg_refpipe_mark_counts_ptr_dev",
+    "mg_refpipe_containment_counts_dev",
     "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_drop_resident", "mg_filter_use_resident", "mg_filter_resident_bytes", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
@@ -103,6 +106,8 @@ def load_library(path=LIB_PATH):
     lib.mg_refdb_kmax_table.restype = ctypes.c_void_p
     lib.mg_refdb_ngenomes.restype = ctypes.c_uint64
     lib.mg_refdb_max_hash.restype = ctypes.c_uint64
+    lib.mg_refdb_distinct_kmers.restype = ctypes.c_uint64
+    lib.mg_kcounts_free.restype = None
     lib.mg_profile_free.restype = None
     lib.mg_shutdown.restype = None
     return lib
@@ -639,6 +644,41 @@ class RefTable:
             out["small"][k] = dict(pa=pa[:npairs], pb=pb[:npairs], cid=cid[:nc[ki]], cgen=cgen[:nc[ki]], gsize=gk[:g], nprefix=npre[ki])
         return out
 
+    def index_kmers(self, kmer_hi=None, kmer_lo=None):
+        """The index stage A BY K-MER IDENTITY reads (mg_refdb_index_kmers): over the table's distinct canonical k_max-mers,
+        built on the device.  kmer_hi / kmer_lo: the pairs' k-mers (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64) — None for a table
+        built here (refdb_build), which holds them."""
+        if kmer_hi is None:
+            self.hip._chk(self.hip.lib.mg_refdb_index_kmers(self.handle, None, None))
+        else:
+            hi = np.ascontiguousarray(kmer_hi, dtype=np.uint64)
+            lo = np.ascontiguousarray(kmer_lo, dtype=np.uint64)
+            one = np.zeros(1, np.uint64)
+            self.hip._chk(self.hip.lib.mg_refdb_index_kmers(self.handle, _np(hi if hi.size else one, ctypes.c_uint64),
+                                                            _np(lo if lo.size else one, ctypes.c_uint64)))
+        return self
+
+    @property
+    def has_kmer_index(self):
+        return bool(self.hip.lib.mg_refdb_has_kmer_index(self.handle))
+
+    @property
+    def distinct_kmers(self):
+        return int(self.hip.lib.mg_refdb_distinct_kmers(self.handle))
+
+    def kmer_heads(self):
+        """u32[npairs]: for every pair the pair whose counter holds the occurrences of its k-mer (KmerCounts.device())."""
+        npairs = self.sizes()[0]
+        out = np.zeros(max(npairs, 1), np.uint32)
+        self.hip._chk(self.hip.lib.mg_refdb_kmer_heads(self.handle, _np(out, ctypes.c_uint32)))
+        return out[:npairs]
+
+    def kmer_counts(self):
+        """A sample's occurrence counters for this table (zeroed)."""
+        h = _vp()
+        self.hip._chk(self.hip.lib.mg_kcounts_new(self.handle, ctypes.byref(h)))
+        return KmerCounts(self.hip, h, self)
+
     def marks(self, ki):
         """(device pointer, words) of the prefix bitmap of k number ki (after a mark call)."""
         p, n = _vp(), ctypes.c_uint64(0)
@@ -650,6 +690,56 @@ class RefTable:
             self.hip.lib.mg_refdb_free(self.handle)  # (joins the uploader's threads of a table still on its way)
             self.handle = None
         self._arrays_on_their_way = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class KmerCounts:
+    """One sample's occurrence counters of a reference-pipeline table's k_max-mers, counted BY K-MER IDENTITY (opaque mg_kcounts
+    handle; include/metalign_hip.h): what `kmc -ci2 -cs3` + `kmc_tools intersect` leave (scripts/select_db.py:50-59)."""
+
+    def __init__(self, hip, handle, table):
+        self.hip, self.handle, self.table = hip, handle, table
+
+    def reset(self):
+        self.hip._chk(self.hip.lib.mg_kcounts_reset(self.handle))
+
+    def add_dev(self, d_bases, d_offsets, nreads, nbases=0):
+        """The k_max-mers of a batch of reads resident on the device (one launch, no sync)."""
+        self.hip._chk(self.hip.lib.mg_count_kmers_dev(_vp(d_bases), _vp(d_offsets), ctypes.c_uint64(nreads), ctypes.c_uint64(nbases),
+                                                      self.table.handle, self.handle))
+
+    def add_reads(self, reads):
+        p_b, p_o = reads.device_ptrs()
+        self.add_dev(p_b, p_o, reads.count, reads.nbases)
+
+    def stats(self):
+        """-> dict(kmers, runs, passed, matches) of everything added since the last reset (synchronises)."""
+        out = np.zeros(4, np.uint64)
+        self.hip._chk(self.hip.lib.mg_kcounts_stats(self.handle, _np(out, ctypes.c_uint64)))
+        return dict(kmers=int(out[0]), runs=int(out[1]), passed=int(out[2]), matches=int(out[3]))
+
+    def download(self):
+        """u32[npairs]: min(occurrences of the pair's k-mer, cs)."""
+        npairs = self.table.sizes()[0]
+        out = np.zeros(max(npairs, 1), np.uint32)
+        self.hip._chk(self.hip.lib.mg_kcounts_download(self.handle, self.table.handle, _np(out, ctypes.c_uint32)))
+        return out[:npairs]
+
+    def device(self):
+        """(device pointer of the raw u32 counters, their number)"""
+        p, n = _vp(), ctypes.c_uint64(0)
+        self.hip._chk(self.hip.lib.mg_kcounts_device(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return int(p.value or 0), int(n.value)
+
+    def free(self):
+        if self.handle:
+            self.hip.lib.mg_kcounts_free(self.handle)
+            self.handle = None
 
     def __del__(self):
         try:
@@ -1290,6 +1380,32 @@ class Hip:
         c_h = (_vp * nk)(*[_vp(p) for p in d_hits])
         c_s = (_vp * nk)(*[_vp(p) for p in d_sizes])
         self._chk(self.lib.mg_refpipe_containment_dev(sketch.handle, reftable.handle, ctypes.c_uint32(ci), c_h, c_s))
+
+    def refpipe_containment_counts_dev(self, counts, reftable, ci, d_hits, d_sizes):
+        """Stage B of the reference pipeline from the k-mer counters of stage A by identity (KmerCounts)."""
+        nk = len(reftable.ks)
+        c_h = (_vp * nk)(*[_vp(p) for p in d_hits])
+        c_s = (_vp * nk)(*[_vp(p) for p in d_sizes])
+        self._chk(self.lib.mg_refpipe_containment_counts_dev(counts.handle, reftable.handle, ctypes.c_uint32(ci), c_h, c_s))
+
+    def refpipe_mark_counts_dev(self, counts, reftable, ci, d_hits_kmax, d_sizes_kmax):
+        """counts: a KmerCounts, or the device pointer of counters summed over the ranks (u32[npairs])."""
+        if isinstance(counts, KmerCounts):
+            self._chk(self.lib.mg_refpipe_mark_counts_dev(counts.handle, reftable.handle, ctypes.c_uint32(ci), _vp(d_hits_kmax), _vp(d_sizes_kmax)))
+        else:
+            self._chk(self.lib.mg_refpipe_mark_counts_ptr_dev(_vp(counts), reftable.handle, ctypes.c_uint32(ci), _vp(d_hits_kmax), _vp(d_sizes_kmax)))
+
+    def refpipe_containment_counts(self, counts, reftable, ci=2):
+        """-> (hits u32[K][G], sizes u32[K][G]), k ascending."""
+        g, nk = reftable.ngenomes, len(reftable.ks)
+        d = self.empty(max(2 * g * nk, 1), np.uint32)
+        try:
+            self.refpipe_containment_counts_dev(counts, reftable, ci, [d.ptr + 4 * (2 * ki * g) for ki in range(nk)],
+                                                [d.ptr + 4 * ((2 * ki + 1) * g) for ki in range(nk)])
+            a = d.download()[: 2 * g * nk].reshape(nk, 2, g)
+            return a[:, 0, :].copy(), a[:, 1, :].copy()
+        finally:
+            d.free()
 
     def refpipe_mark_dev(self, sketch, reftable, ci, d_hits_kmax, d_sizes_kmax):
         self._chk(self.lib.mg_refpipe_mark_dev(sketch.handle, reftable.handle, ctypes.c_uint32(ci), _vp(d_hits_kmax), _vp(d_sizes_kmax)))

@@ -46,6 +46,9 @@ struct ContainK {
   uint32_t* sizes;
   // the reference pipeline (k_contain_pairs<true>, mg_refpipe_*): per k below the largest, the prefix numbers of every pair
   // (kept strand / other strand, 0xffffffff = none) and the bitmap over D_k that a matched pair marks
+  // stage A by k-mer identity (mg_kcount.hip; k_match_pairs): where a pair's k-mer is counted, and the counters
+  const uint32_t* head;
+  const uint32_t* counts;
   int nsmall;
   const uint32_t* pa[kMaxSmallK];
   const uint32_t* pb[kMaxSmallK];
@@ -56,6 +59,7 @@ struct ContainArgs {
   ContainK k[kMaxContainK];
   int nk;
   uint32_t ci, copies;
+  uint32_t cs;            // (k_match_pairs) counters saturate here, 0 = never
   uint64_t ntiles;        // of all k together
   uint32_t* zero;         // the hit-counter copies of the call, zeroed by the index kernel (one launch less)
   uint64_t nzero;
@@ -255,6 +259,43 @@ __global__ __launch_bounds__(kCT) void k_contain_pairs(const ContainArgs a) {
       if constexpr (MARK) mark_pairs<kPer>(K, t0 + tid, kCT, matched);
     }
     __syncthreads();
+  }
+}
+
+// Stage B after stage A BY K-MER IDENTITY (mg_kcount.hip): a pair is matched when its k-mer — counted at the first pair of the
+// hash-major table that holds it, so the gather runs nearly in step with the stream — occurred >= ci times in the reads
+// (saturating at cs, as `kmc -cs<cs>` does; scripts/select_db.py:50-56).  No search: 4 B of genome id, 4 B of head and one
+// counter per pair; the marks of the smaller k as in k_contain_pairs.
+template <bool MARK>
+__global__ __launch_bounds__(kCT) void k_match_pairs(const ContainArgs a) {
+  constexpr int kPer = kCTile / kCT;
+  const int tid = threadIdx.x;
+  const ContainK& K = a.k[0];
+  const uint32_t* __restrict__ pg = K.pg;
+  const uint32_t* __restrict__ head = K.head;
+  const uint32_t* __restrict__ counts = K.counts;
+  uint32_t* const hits = K.hits_part + (uint64_t)(blockIdx.x & (a.copies - 1)) * K.ngenomes;
+  for (uint64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const uint64_t t0 = tile * kCTile;
+    uint32_t g[kPer], hd[kPer], c[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const uint64_t i = t0 + tid + (uint64_t)j * kCT;
+      g[j] = 0; hd[j] = 0xffffffffu;
+      if (i < K.npairs) { g[j] = pg[i]; hd[j] = head[i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) c[j] = hd[j] != 0xffffffffu ? counts[hd[j]] : 0u;
+    uint32_t matched = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const uint32_t v = (a.cs && c[j] > a.cs) ? a.cs : c[j];
+      if (hd[j] != 0xffffffffu && v >= a.ci) {
+        atomicAdd(&hits[g[j]], 1u);
+        matched |= 1u << j;
+      }
+    }
+    if constexpr (MARK) mark_pairs<kPer>(K, t0 + tid, kCT, matched);
   }
 }
 
@@ -674,6 +715,59 @@ static int containment_launch(int nk, const mg_sketch* const* qs, const mg_db* c
   return MG_OK;
 }
 
+// Stage B of the reference pipeline from the k-mer counters of stage A by identity: the largest k's column + the prefix marks.
+static int match_launch(const uint32_t* d_counts, const mg_refdb* rp, uint32_t ci, uint32_t* d_hits, uint32_t* d_sizes) {
+  Context& c = ctx();
+  hipStream_t st = c.stream;
+  if (c.count_sat && ci > c.count_sat)
+    return fail(MG_ERR_ARG, "count threshold ci=%u above the counters' saturation cs=%u: nothing could ever match", ci, c.count_sat);
+  const mg_db* db = &rp->kmax;
+  if (db->ngenomes == 0) return MG_OK;
+  if (ci == 0) return fail(MG_ERR_ARG, "ci = 0 would match every pair");
+  ContainArgs a{};
+  a.ci = ci;
+  a.cs = c.count_sat;
+  a.nk = 1;
+  uint32_t copies = 1;
+  while (copies < 64 && (uint64_t)copies * 2 * db->ngenomes <= 65536) copies *= 2;
+  a.copies = copies;
+  const uint64_t part_total = (uint64_t)copies * db->ngenomes;
+  const uint64_t count_total = (uint64_t)(rp->nk - 1) * copies * db->ngenomes;
+  uint32_t* d_part = (uint32_t*)scratch("contain_part", (part_total + count_total) * sizeof(uint32_t));
+  if (!d_part) return MG_ERR_NOMEM;
+  a.zero = d_part;
+  a.nzero = part_total + count_total;
+  ++g_contain_gen;
+  rp->count_part = d_part + part_total; rp->count_copies = copies; rp->count_gen = g_contain_gen;
+  ContainK& K = a.k[0];
+  K.hits = d_hits;
+  K.sizes = d_sizes;
+  K.pg = db->pair_gen.as<uint32_t>();
+  K.gsize = db->gsize.as<uint32_t>();
+  K.ngenomes = db->ngenomes;
+  K.npairs = db->total;
+  K.hits_part = d_part;
+  K.sizes_part = nullptr;
+  K.head = rp->kidx->head.as<uint32_t>();
+  K.counts = d_counts;
+  K.nsmall = rp->nk - 1;
+  for (int s = 0; s < K.nsmall; ++s) {
+    K.pa[s] = rp->small[s].pa.as<uint32_t>();
+    K.pb[s] = rp->small[s].pb.as<uint32_t>();
+    K.marks[s] = rp->marks.as<uint32_t>() + rp->small[s].marks_at;
+  }
+  a.ntiles = (K.npairs + kCTile - 1) / kCTile;
+  a.zero2 = rp->marks.as<uint32_t>();
+  a.nzero2 = rp->marks_words;
+  ProfScope ps("containment");
+  const uint64_t work = a.nzero > a.nzero2 ? a.nzero : a.nzero2;
+  hipLaunchKernelGGL(k_build_index, dim3(grid_for(work ? work : 1, 256, (unsigned)c.num_cus * 16)), dim3(256), 0, st, a);  // (zeroes; no index here)
+  if (a.ntiles) hipLaunchKernelGGL(k_match_pairs<true>, dim3(grid_for(a.ntiles, 1, (unsigned)c.num_cus * 8)), dim3(kCT), 0, st, a);
+  hipLaunchKernelGGL(k_contain_reduce, dim3(grid_for(db->ngenomes, 256, (unsigned)c.num_cus * 4)), dim3(256), 0, st, a);
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
 // The smaller-k columns of the reference pipeline from the prefix bitmaps (rp's own after a mark, or d_marks: the OR over the ranks
 // of a multi-GPU job): ONE launch over the count lists of all k, one reduction.  d_hits / d_sizes: nk - 1 of them.
 static int refpipe_count_launch(const mg_refdb* rp, const uint32_t* const* d_marks, uint32_t* const* d_hits, uint32_t* const* d_sizes) {
@@ -743,6 +837,33 @@ int mg_refpipe_containment_dev(const mg_sketch* q, const mg_refdb* db, uint32_t 
   if (!q || !db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
   const int last = db->nk - 1;
   MG_TRY(mg_refpipe_mark_dev(q, db, ci, d_hits[last], d_sizes[last]));
+  return refpipe_count_launch(db, nullptr, d_hits, d_sizes);
+}
+
+int mg_refpipe_mark_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax) {
+  MG_REQUIRE_READY();
+  if (!kc || !db || !d_hits_kmax || !d_sizes_kmax) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(refdb_ready(db));
+  if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
+  uint32_t* d_counts = nullptr;
+  uint64_t n = 0;
+  MG_TRY(mg_kcounts_device(kc, &d_counts, &n));
+  if (n != db->kmax.total) return fail(MG_ERR_ARG, "these counters belong to another table");
+  return match_launch(d_counts, db, ci, d_hits_kmax, d_sizes_kmax);
+}
+
+int mg_refpipe_mark_counts_ptr_dev(const uint32_t* d_counts, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax) {
+  MG_REQUIRE_READY();
+  if (!d_counts || !db || !d_hits_kmax || !d_sizes_kmax) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(refdb_ready(db));
+  if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
+  return match_launch(d_counts, db, ci, d_hits_kmax, d_sizes_kmax);
+}
+
+int mg_refpipe_containment_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_t ci, uint32_t* const* d_hits, uint32_t* const* d_sizes) {
+  if (!kc || !db || !d_hits || !d_sizes) return fail(MG_ERR_ARG, "null argument");
+  const int last = db->nk - 1;
+  MG_TRY(mg_refpipe_mark_counts_dev(kc, db, ci, d_hits[last], d_sizes[last]));
   return refpipe_count_launch(db, nullptr, d_hits, d_sizes);
 }
 

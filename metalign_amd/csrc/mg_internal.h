@@ -345,6 +345,20 @@ struct mg_db {
   uint64_t max_hash = 0;
 };
 
+namespace mg {
+// The index over a reference-pipeline table's distinct canonical k_max-mers that stage A BY K-MER IDENTITY reads (mg_kcount.hip,
+// mg_kcount_core.h): built once per table on the device from the pairs' k-mers.
+struct KmerIndex {
+  int k = 0;
+  uint64_t ndistinct = 0, nbuckets = 0;
+  unsigned bshift = 0;   // bucket of a minimizer = key >> bshift
+  DevBuf gate;           // 2^30 bits over the minimizer values
+  DevBuf offs;           // u32[nbuckets + 1]
+  DevBuf ent;            // KcEntry[ndistinct], ascending by minimizer
+  DevBuf head;           // u32[npairs]: the pair whose counter holds the occurrences of this pair's k-mer
+};
+}  // namespace mg
+
 struct mg_refdb {
   // The table of the REFERENCE PIPELINE (mg_refpipe.hip; oracle/mg_oracle.c, "THE REFERENCE'S OWN WIRING"): the hash-major
   // table of the largest k, and for every k below it what derives that k's column from WHICH pairs matched.
@@ -368,6 +382,7 @@ struct mg_refdb {
   // mg_refdb_upload_begin: the arrays still on their way up (settled, and the table checked, by the first call that reads it)
   mutable mg::UploadJob* pending = nullptr;
   mutable bool unchecked = false;
+  std::unique_ptr<mg::KmerIndex> kidx;  // mg_refdb_index_kmers
   ~mg_refdb();
 };
 namespace mg { int refdb_ready(const mg_refdb* db); int check_pairs_dev(const mg_db& db); }

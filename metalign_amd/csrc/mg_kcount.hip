@@ -1,0 +1,568 @@
+// mg_kcount.hip — stage A of the reference pipeline by K-MER IDENTITY: k_count_kmers<K> and the table-side index it reads.
+//
+// Replaces `kmc -k<kmax> -ci2 -cs3` + `kmc_tools simple ... intersect` (scripts/select_db.py:50-59) without hashing a single read
+// position: the design, the definitions and every per-lane piece are in mg_kcount_core.h; here are
+//   * the index over the table's distinct canonical k_max-mers (mg_refdb_index_kmers): entries ascending by minimizer, a bucket
+//     directory over the leading bits of the minimizer, a gate bitmap over all 2^30 minimizer values, and per pair of the
+//     hash-major table the pair that counts for its k-mer (`head`: equal k-mers are adjacent in hash order, so stage B reads
+//     counts[head[i]] nearly sequentially);
+//   * the kernel: one wavefront per tile of 64 reads, one lane per read.  The tile's bases go HBM -> LDS with 16-byte coalesced
+//     loads, packed to 2 bits per base on the way (a big-endian stream: 32 bits at any base offset are sixteen bases as k-mers
+//     compare); every lane slides the minimizer over its read (kc_walk) and leaves the runs it closes in a list of its own in
+//     LDS; kc_drain — ONE copy of the cold code, called — takes the lists through the gate, compacts the runs that pass
+//     (ballot + popcount) and matches them 64 at a time against their buckets;
+//   * the handle that holds a sample's counters (mg_kcounts) and its way into stage B (mg_contain.hip: k_match_pairs).
+// Normative statement: oracle/mg_oracle.c, mgo_refpipe_count_kmers.
+#include <memory>
+
+#include "mg_internal.h"
+#include "mg_kcount_core.h"
+#include "mg_sketch_dev.h"
+
+namespace mg {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the index
+// ---------------------------------------------------------------------------------------------------------------------
+inline unsigned g256(uint64_t n) { return grid_for(n ? n : 1, 256, (unsigned)ctx().num_cus * 8); }
+#define KC_FOR(i, n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (uint64_t)gridDim.x * blockDim.x)
+
+// pair i: its kept k-mer (right-aligned) -> the canonical strand, left-aligned, as two words that compare like the k-mer
+__global__ void k_kc_canon(const uint64_t* __restrict__ khi, const uint64_t* __restrict__ klo, uint64_t n, int k,
+                           uint64_t* __restrict__ chi, uint64_t* __restrict__ clo, uint32_t* __restrict__ iota) {
+  KC_FOR(i, n) {
+    const KcWin c = kc_canonical(kc_from_right(khi[i], klo[i], k), k);
+    chi[i] = ((uint64_t)c.w[0] << 32) | c.w[1];
+    clo[i] = ((uint64_t)c.w[2] << 32) | c.w[3];
+    iota[i] = (uint32_t)i;
+  }
+}
+__global__ void k_kc_gather(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint64_t* __restrict__ dst) {
+  KC_FOR(i, n) dst[i] = src[idx[i]];
+}
+__global__ void k_kc_heads(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n, uint32_t* __restrict__ flag) {
+  KC_FOR(j, n) flag[j] = (j == 0 || hi[j] != hi[j - 1] || lo[j] != lo[j - 1]) ? 1u : 0u;
+}
+// sorted position j opens distinct k-mer number before[j]: its words, the pair that counts for it (the sort is stable and
+// started from pair order: the first of a group is its lowest pair), its minimizer
+__global__ void k_kc_distinct(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, const uint32_t* __restrict__ order,
+                              const uint32_t* __restrict__ flag, const uint64_t* __restrict__ before, uint64_t n, int k,
+                              uint64_t* __restrict__ dhi, uint64_t* __restrict__ dlo, uint32_t* __restrict__ dhead,
+                              uint64_t* __restrict__ dkey, uint32_t* __restrict__ iota) {
+  KC_FOR(j, n) {
+    if (!flag[j]) continue;
+    const uint64_t id = before[j];
+    const KcWin x{{(uint32_t)(hi[j] >> 32), (uint32_t)hi[j], (uint32_t)(lo[j] >> 32), (uint32_t)lo[j]}};
+    dhi[id] = hi[j];
+    dlo[id] = lo[j];
+    dhead[id] = order[j];
+    dkey[id] = kc_minimizer(x, k);
+    iota[id] = (uint32_t)id;
+  }
+}
+__global__ void k_kc_pair_heads(const uint32_t* __restrict__ order, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ before,
+                                const uint32_t* __restrict__ dhead, uint64_t n, uint32_t* __restrict__ head) {
+  KC_FOR(j, n) head[order[j]] = dhead[before[j] + flag[j] - 1];
+}
+// entry j = distinct k-mer perm[j] (ascending by minimizer); its gate bit
+__global__ void k_kc_entries(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ dhi,
+                             const uint64_t* __restrict__ dlo, const uint32_t* __restrict__ dhead, uint64_t nd, int k,
+                             KcEntry* __restrict__ ent, uint32_t* __restrict__ gate) {
+  KC_FOR(j, nd) {
+    const uint32_t id = perm[j];
+    const uint64_t h = dhi[id], l = dlo[id];
+    KcEntry e;
+    e.w[0] = (uint32_t)(h >> 32); e.w[1] = (uint32_t)h; e.w[2] = (uint32_t)(l >> 32); e.w[3] = (uint32_t)l;
+    e.head = dhead[id];
+    e.key = (uint32_t)skey[j];
+    e.sig_rc = kc_revcomp(KcWin{{e.w[0], e.w[1], e.w[2], e.w[3]}}, k).w[0];
+    e.pad = 0;
+    ent[j] = e;
+    atomicOr(&gate[e.key >> 5], 1u << (e.key & 31u));
+  }
+}
+// offs[b] = first entry whose key >> shift is >= b; offs[nb] = nd
+__global__ void k_kc_offsets(const uint64_t* __restrict__ skey, uint64_t nd, unsigned shift, uint64_t nb, uint32_t* __restrict__ offs) {
+  KC_FOR(j, nd + 1) {
+    const uint64_t first = j == 0 ? 0 : (skey[j - 1] >> shift) + 1;
+    const uint64_t last = j == nd ? nb : (skey[j] >> shift);
+    for (uint64_t b = first; b <= last; ++b) offs[b] = (uint32_t)j;
+  }
+}
+__global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ head, uint64_t n, uint32_t cs,
+                              uint32_t* __restrict__ out) {
+  KC_FOR(i, n) {
+    const uint32_t c = counts[head[i]];
+    out[i] = (cs && c > cs) ? cs : c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kKcWaves = 4;              // wavefronts per workgroup (each works alone)
+constexpr uint32_t kKcListCap = 12;      // closed runs a lane can hold before the lists are emptied (150 bp, k = 51: six per read)
+constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for a full batch
+constexpr uint32_t kKcSlack = 8;         // dwords a k-mer taken at the end of the stream may read past it
+
+// LDS of one wavefront (bytes), for a stage of sd dwords (sd a multiple of 64)
+struct KcLds {
+  uint32_t fwd, inv, p0s, lists, hitq, total;
+  __host__ __device__ explicit KcLds(uint32_t sd) {
+    fwd = 0;
+    inv = fwd + 4u * (sd + kKcSlack);
+    p0s = inv + 4u * (sd / 2 + kKcSlack);
+    lists = p0s + 4u * 64u;
+    hitq = lists + 8u * 64u * (kKcListCap + 1u);
+    total = hitq + 8u * kKcHitCap;
+  }
+};
+
+struct KcArgs {
+  const uint8_t* bases;
+  const uint64_t* offsets;
+  uint64_t nreads;
+  const uint32_t* gate;
+  const uint32_t* offs;
+  const KcEntry* ent;
+  uint32_t* counts;
+  unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the gate, [3] matches
+  uint32_t bshift, sd;
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+#ifndef MG_KC_WAVES_PER_EU
+#define MG_KC_WAVES_PER_EU 3
+#endif
+// A batch of runs that passed the gate, one per lane, against their buckets.
+__device__ __forceinline__ uint32_t kc_hits(const KcIndexView& ix, const MG_LDS unsigned long long* q, uint32_t n, const MG_LDS uint32_t* fwd,
+                                            const MG_LDS uint32_t* inv, const MG_LDS uint32_t* p0s, int k, bool bad, int lane) {
+  uint32_t found = 0;
+  if ((uint32_t)lane < n) {
+    const unsigned long long ev = q[lane];
+    const uint32_t key = (uint32_t)ev, info = (uint32_t)(ev >> 32);
+    const uint32_t p0 = p0s[info >> 20], i1 = info & 1023u, i2 = (info >> 10) & 1023u;
+    found = bad ? kc_match_run<true>(ix, fwd, inv, k, key, p0, i1, i2) : kc_match_run<false>(ix, fwd, inv, k, key, p0, i1, i2);
+  }
+  return found;
+}
+
+// The lists of a wavefront: every closed run through the gate; the ones that pass are compacted and matched 64 at a time.
+// One copy of this code per kernel, CALLED from the walk's unrolled steps (cfg: bshift | k << 8 | bad << 16).
+__device__ __attribute__((noinline)) void kc_drain(const uint32_t* gate, const uint32_t* offs, const KcEntry* ent, uint32_t* counts,
+                                                   unsigned long long* stats, uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt,
+                                                   uint32_t limit) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const KcLds L(sd);
+  const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
+  const MG_LDS uint32_t* inv = (const MG_LDS uint32_t*)(size_t)(lds + L.inv);
+  const MG_LDS uint32_t* p0s = (const MG_LDS uint32_t*)(size_t)(lds + L.p0s);
+  const MG_LDS unsigned long long* lists = (const MG_LDS unsigned long long*)(size_t)(lds + L.lists);
+  MG_LDS unsigned long long* hitq = (MG_LDS unsigned long long*)(size_t)(lds + L.hitq);
+  const KcIndexView ix{gate, offs, ent, counts, cfg & 0xffu};
+  const int k = (int)((cfg >> 8) & 0xffu);
+  const bool bad = (cfg >> 16) & 1u;
+  const uint32_t maxc = wave_max_u32(cnt);
+  uint32_t hn = 0, nev = 0, npass = 0, found = 0;
+  for (uint32_t s0 = 0; s0 < maxc; s0 += 4) {
+    unsigned long long ev[4];
+    uint32_t gw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ev[j] = (unsigned long long)kKcNone;
+      if (s0 + j < cnt) ev[j] = lists[(s0 + j) * 64u + (uint32_t)lane];
+      // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
+      const uint32_t info = (uint32_t)(ev[j] >> 32), i1 = info & 1023u, i2 = (info >> 10) & 1023u;
+      if (i1 >= limit) ev[j] = (unsigned long long)kKcNone;
+      else if (i2 >= limit) ev[j] = (ev[j] & ~(1023ull << 42)) | ((unsigned long long)(limit - 1u) << 42);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gw[j] = (uint32_t)ev[j] != kKcNone ? gate[(uint32_t)ev[j] >> 5] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      nev += (uint32_t)ev[j] != kKcNone ? 1u : 0u;
+      const bool pass = (gw[j] >> ((uint32_t)ev[j] & 31u)) & 1u;  // (gw = 0 for no event)
+      const unsigned long long m = __ballot(pass);
+      if (m == 0ull) continue;
+      if (pass) hitq[hn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ev[j] | ((unsigned long long)lane << 52);
+      hn += (uint32_t)__popcll(m);
+      npass += pass ? 1u : 0u;
+      if (hn >= 64u) {
+        wave_lds_sync();
+        hn -= 64u;
+        found += kc_hits(ix, hitq + hn, 64u, fwd, inv, p0s, k, bad, lane);
+        wave_lds_sync();
+      }
+    }
+  }
+  if (hn) {
+    wave_lds_sync();
+    found += kc_hits(ix, hitq, hn, fwd, inv, p0s, k, bad, lane);
+    wave_lds_sync();
+  }
+  nev = wave_sum_u32(nev); npass = wave_sum_u32(npass); found = wave_sum_u32(found);
+  if (lane == 0) {
+    if (nev) atomicAdd(stats + 1, (unsigned long long)nev);
+    if (npass) atomicAdd(stats + 2, (unsigned long long)npass);
+    if (found) atomicAdd(stats + 3, (unsigned long long)found);
+  }
+}
+
+// what kc_walk writes through
+struct KcDevOut {
+  MG_LDS unsigned long long* mine;  // this lane's column of the lists (slot s at mine[s * 64]): key | info << 32
+  const uint32_t* gate;
+  const uint32_t* offs;
+  const KcEntry* ent;
+  uint32_t* counts;
+  unsigned long long* stats;
+  uint32_t cfg, lds, sd;
+  __device__ __forceinline__ void put(uint32_t slot, uint32_t key, uint32_t info) { mine[slot * 64u] = (unsigned long long)key | ((unsigned long long)info << 32); }
+  __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
+#ifdef MG_KC_NO_DRAIN  // (ISA inspection: what the walks need by themselves)
+    return;
+#endif
+    wave_lds_sync();
+    kc_drain(gate, offs, ent, counts, stats, cfg, lds, sd, cnt, limit);
+    wave_lds_sync();
+  }
+  static constexpr uint32_t kCap = kKcListCap;
+  __device__ __forceinline__ bool any_full(uint32_t cnt) const { return __builtin_amdgcn_ballot_w64(cnt >= kKcListCap) != 0ull; }
+  __device__ __forceinline__ uint32_t last_window(uint32_t slot) const { return ((uint32_t)(mine[slot * 64u] >> 32) >> 10) & 1023u; }
+  __device__ __forceinline__ uint32_t wave_min(uint32_t v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(v, o, 64);
+      v = t < v ? t : v;
+    }
+    return v;
+  }
+};
+
+// a staged tile through the walk, as often as the lists fill up
+template <int K>
+__device__ __forceinline__ void kc_tile(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, uint32_t p0, uint32_t len, uint32_t maxlen,
+                                        int mode, KcDevOut& out) {
+  if (maxlen < (uint32_t)K) return;
+  const uint32_t nwmax = maxlen - (uint32_t)K + 1u;
+  uint32_t w0 = 0;
+  do {
+    uint32_t cnt = 0;
+    if (mode == 0) w0 = kc_walk<K, 0>(fwd, inv, p0, len, maxlen, w0, out, cnt);
+    else if (mode == 1) w0 = kc_walk<K, 1>(fwd, inv, p0, len, maxlen, w0, out, cnt);
+    else w0 = kc_walk<K, 2>(fwd, inv, p0, len, maxlen, w0, out, cnt);
+    out.drain(cnt, w0);
+  } while (w0 < nwmax);
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(MG_KC_WAVES_PER_EU))) void k_count_kmers(const KcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const KcLds L(a.sd);
+  MG_LDS uint8_t* base = (MG_LDS uint8_t*)smem + (size_t)wave * L.total;
+  const uint32_t lds = (uint32_t)(size_t)base;
+  MG_LDS uint32_t* fwd = (MG_LDS uint32_t*)(base + L.fwd);
+  MG_LDS uint32_t* inv = (MG_LDS uint32_t*)(base + L.inv);
+  MG_LDS uint16_t* inv16 = (MG_LDS uint16_t*)(base + L.inv);
+  MG_LDS uint32_t* p0s = (MG_LDS uint32_t*)(base + L.p0s);
+  MG_LDS unsigned long long* lists = (MG_LDS unsigned long long*)(base + L.lists);
+  const uint32_t cfg0 = (a.bshift & 0xffu) | ((uint32_t)K << 8);
+  uint32_t kmers = 0;
+  const uint64_t ntiles = (a.nreads + 63) / 64;
+  for (uint64_t tile = (uint64_t)blockIdx.x * kKcWaves + wave; tile < ntiles; tile += (uint64_t)gridDim.x * kKcWaves) {
+    const uint64_t rd = tile * 64 + lane;
+    uint64_t beg = 0, end = 0;
+    if (rd < a.nreads) { beg = a.offsets[rd]; end = a.offsets[rd + 1]; }
+    const uint64_t len64 = end - beg;
+    const uint64_t maxlen64 = wave_max_u64(len64);
+    const uint64_t t_beg = __shfl(beg, 0, 64);
+    const uint64_t t_end = wave_max_u64(end);
+    const uintptr_t a_first = reinterpret_cast<uintptr_t>(a.bases) + t_beg;
+    const uintptr_t a0 = a_first & ~(uintptr_t)15;
+    const uint64_t shift = a_first - a0;
+    const uint64_t nbytes = shift + (t_end - t_beg);
+    if (maxlen64 < (uint64_t)K) continue;  // no k-mer in the tile
+    if (nbytes <= 16ull * a.sd && maxlen64 <= kKcMaxRead) {
+      // ---- the usual tile: coalesced HBM -> LDS copy of its whole span, 16 bases per lane and step -> one dword of the stream
+      const uint32_t nd = (uint32_t)((nbytes + 15) / 16);
+      const uint4* g = reinterpret_cast<const uint4*>(a0);
+      uint32_t notbase = 0;
+      for (uint32_t i = lane; i < nd; i += 64) {
+        const uint4 v = g[i];
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        uint32_t nb;
+        fwd[i] = kc_pack16(vv, nb);
+        notbase |= nb;
+      }
+      const bool bad = __ballot(notbase != 0) != 0ull;
+      if (bad) {  // (rare: N runs, the slop of the neighbouring tiles at a buffer's edge) the same bytes again, for the bit per base
+        for (uint32_t i = lane; i < nd + 4; i += 64) {
+          uint32_t bits = 0;
+          if (i < nd) {
+            const uint4 v = g[i];
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            bits = kc_notbase16(vv);
+          }
+          inv16[i ^ 1u] = (uint16_t)bits;  // (dword i >> 1 holds group i in its HIGH half when i is even)
+        }
+      }
+      const uint32_t p0 = rd < a.nreads ? (uint32_t)(shift + (beg - t_beg)) : 0u;  // (a lane without a read walks the tile's first bases, masked)
+      p0s[lane] = p0;
+      wave_lds_sync();
+      KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.stats, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
+      const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
+      kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
+      kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
+    } else {
+      // ---- a tile that does not fit (a long read, or a span above the stage): every lane takes its read through in chunks of
+      // ch bases that overlap by K - 1, in a slot of its own — byte loads, the general walk; no window is seen twice
+      const uint32_t per = (a.sd * 16u / 64u) & ~15u;
+      const uint32_t ch = per < 1008u ? per : 1008u;  // (>= K + 15: the launcher sizes the stage so)
+      const uint32_t stride = ch - (uint32_t)K + 1u;
+      const uint32_t p0 = (uint32_t)lane * ch;
+      p0s[lane] = p0;
+      const uint64_t nwin = len64 >= (uint64_t)K ? len64 - (uint64_t)K + 1 : 0;
+      const uint64_t nchunks = (wave_max_u64(nwin) + stride - 1) / stride;
+      for (uint64_t c = 0; c < nchunks; ++c) {
+        const uint64_t cs = c * stride;
+        const uint32_t clen = cs < nwin ? (uint32_t)(len64 - cs < ch ? len64 - cs : ch) : 0u;
+        const uint8_t* src = a.bases + beg + cs;
+        for (uint32_t gi = 0; gi < ch / 16u; ++gi) {
+          uint32_t vv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const uint32_t at = gi * 16u + (uint32_t)(q * 4 + bb);
+              v |= (at < clen ? (uint32_t)src[at] : (uint32_t)'A') << (8 * bb);
+            }
+            vv[q] = v;
+          }
+          uint32_t nb;
+          const uint32_t gidx = p0 / 16u + gi;
+          fwd[gidx] = kc_pack16(vv, nb);
+          inv16[gidx ^ 1u] = (uint16_t)kc_notbase16(vv);
+        }
+        wave_lds_sync();
+        KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.stats, cfg0 | (1u << 16), lds, a.sd};
+        const uint32_t cmax = wave_max_u32(clen);
+        kmers += kc_clean_windows(inv, p0, clen, cmax, K);
+        kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
+      }
+    }
+  }
+  const uint64_t total = wave_sum_u64((uint64_t)kmers);
+  if (lane == 0 && total) atomicAdd(a.stats, (unsigned long long)total);
+}
+
+template <int K>
+int launch_k(const KcArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_kmers<K>), dim3(grid), dim3(64 * kKcWaves), lds, st, a);
+  return MG_OK;
+}
+#ifndef MG_KC_ONLY_K  // (A/B builds and ISA inspection: one k instead of fifty)
+#define MG_KC_ONLY_K 0
+#endif
+template <int K = (MG_KC_ONLY_K ? MG_KC_ONLY_K : kKcMinK)>
+int dispatch_kc(int k, const KcArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  if constexpr (K > (MG_KC_ONLY_K ? MG_KC_ONLY_K : kKcMaxK)) {
+    return fail(MG_ERR_ARG, "k = %d is outside [%d, %d]: no k-mer index for it", k, kKcMinK, kKcMaxK);
+  } else {
+    if (k == K) return launch_k<K>(a, grid, lds, st);
+    return dispatch_kc<K + 1>(k, a, grid, lds, st);
+  }
+}
+
+}  // namespace
+
+}  // namespace mg
+
+struct mg_kcounts {
+  mg::DevBuf counts;  // u32[npairs + 1]
+  mg::DevBuf stats;   // u64[4]
+  uint64_t n = 0;
+};
+
+using namespace mg;
+
+extern "C" {
+
+int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* kmer_lo) {
+  MG_REQUIRE_READY();
+  if (!db) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(refdb_ready(db));
+  const int k = db->ks[db->nk - 1];
+  if (k < kKcMinK || k > kKcMaxK)
+    return fail(MG_ERR_ARG, "k = %d is outside [%d, %d]: no k-mer index for it (the hash path serves it)", k, kKcMinK, kKcMaxK);
+  const uint64_t n = db->kmax.total;
+  hipStream_t st = ctx().stream;
+  if (n && (kmer_hi || kmer_lo)) {
+    if (!kmer_hi || !kmer_lo) return fail(MG_ERR_ARG, "both words of the k-mers, or neither");
+    MG_TRY(db->kmer_hi.alloc((n + 1) * 8));
+    MG_TRY(db->kmer_lo.alloc((n + 1) * 8));
+    MG_HIP(hipStreamSynchronize(st));
+    MG_TRY(upload_ranges({{kmer_hi, {db->kmer_hi.p, n * 8}}, {kmer_lo, {db->kmer_lo.p, n * 8}}}, st));
+  }
+  if (n && !db->kmer_hi.p) return fail(MG_ERR_STATE, "the table does not hold its k-mers: pass them (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64)");
+  std::unique_ptr<KmerIndex> ix(new KmerIndex());
+  ix->k = k;
+  MG_TRY(ix->gate.alloc((1ull << 30) / 8));
+  MG_HIP(hipMemsetAsync(ix->gate.p, 0, (1ull << 30) / 8, st));
+  MG_TRY(ix->head.alloc((n + 1) * 4));
+  DevBuf chi, clo, iota, ord1, ord2, s_lo, s_hi, g_hi, flag, before, dhi, dlo, dhead, dkey, skey, perm;
+  uint64_t nd = 0;
+  if (n) {
+    MG_TRY(chi.alloc(n * 8)); MG_TRY(clo.alloc(n * 8)); MG_TRY(iota.alloc(n * 4)); MG_TRY(ord1.alloc(n * 4)); MG_TRY(ord2.alloc(n * 4));
+    MG_TRY(s_lo.alloc(n * 8)); MG_TRY(s_hi.alloc(n * 8)); MG_TRY(g_hi.alloc(n * 8)); MG_TRY(flag.alloc(n * 4)); MG_TRY(before.alloc((n + 2) * 8));
+    hipLaunchKernelGGL(k_kc_canon, dim3(g256(n)), dim3(256), 0, st, db->kmer_hi.as<uint64_t>(), db->kmer_lo.as<uint64_t>(), n, k,
+                       chi.as<uint64_t>(), clo.as<uint64_t>(), iota.as<uint32_t>());
+    // ascending by (chi, clo): low word first, then a stable pass over the high word
+    MG_TRY(sort_pairs(clo.as<uint64_t>(), s_lo.as<uint64_t>(), iota.as<uint32_t>(), ord1.as<uint32_t>(), n));
+    hipLaunchKernelGGL(k_kc_gather, dim3(g256(n)), dim3(256), 0, st, chi.as<uint64_t>(), ord1.as<uint32_t>(), n, g_hi.as<uint64_t>());
+    MG_TRY(sort_pairs(g_hi.as<uint64_t>(), s_hi.as<uint64_t>(), ord1.as<uint32_t>(), ord2.as<uint32_t>(), n));
+    hipLaunchKernelGGL(k_kc_gather, dim3(g256(n)), dim3(256), 0, st, clo.as<uint64_t>(), ord2.as<uint32_t>(), n, s_lo.as<uint64_t>());
+    hipLaunchKernelGGL(k_kc_heads, dim3(g256(n)), dim3(256), 0, st, s_hi.as<uint64_t>(), s_lo.as<uint64_t>(), n, flag.as<uint32_t>());
+    MG_HIP(hipGetLastError());
+    MG_TRY(exclusive_sum_u32_to_u64(flag.as<uint32_t>(), before.as<uint64_t>(), n, &nd));
+    MG_TRY(dhi.alloc(nd * 8)); MG_TRY(dlo.alloc(nd * 8)); MG_TRY(dhead.alloc(nd * 4)); MG_TRY(dkey.alloc(nd * 8)); MG_TRY(skey.alloc(nd * 8));
+    MG_TRY(perm.alloc(nd * 4));
+    hipLaunchKernelGGL(k_kc_distinct, dim3(g256(n)), dim3(256), 0, st, s_hi.as<uint64_t>(), s_lo.as<uint64_t>(), ord2.as<uint32_t>(),
+                       flag.as<uint32_t>(), before.as<uint64_t>(), n, k, dhi.as<uint64_t>(), dlo.as<uint64_t>(), dhead.as<uint32_t>(),
+                       dkey.as<uint64_t>(), iota.as<uint32_t>());
+    hipLaunchKernelGGL(k_kc_pair_heads, dim3(g256(n)), dim3(256), 0, st, ord2.as<uint32_t>(), flag.as<uint32_t>(), before.as<uint64_t>(),
+                       dhead.as<uint32_t>(), n, ix->head.as<uint32_t>());
+    MG_HIP(hipGetLastError());
+    MG_TRY(sort_pairs(dkey.as<uint64_t>(), skey.as<uint64_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), nd));
+  }
+  ix->ndistinct = nd;
+  unsigned bb = 8;  // log2(buckets): about one k-mer per bucket
+  while (bb < 28 && (1ull << bb) < nd) ++bb;
+  ix->bshift = 30 - bb;
+  ix->nbuckets = 1ull << bb;
+  MG_TRY(ix->offs.alloc((ix->nbuckets + 2) * 4));
+  MG_TRY(ix->ent.alloc((nd + 1) * sizeof(KcEntry)));
+  if (nd) {
+    hipLaunchKernelGGL(k_kc_entries, dim3(g256(nd)), dim3(256), 0, st, skey.as<uint64_t>(), perm.as<uint32_t>(), dhi.as<uint64_t>(),
+                       dlo.as<uint64_t>(), dhead.as<uint32_t>(), nd, k, ix->ent.as<KcEntry>(), ix->gate.as<uint32_t>());
+    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(nd + 1)), dim3(256), 0, st, skey.as<uint64_t>(), nd, ix->bshift, ix->nbuckets,
+                       ix->offs.as<uint32_t>());
+  } else {
+    MG_HIP(hipMemsetAsync(ix->offs.p, 0, (ix->nbuckets + 2) * 4, st));
+  }
+  MG_HIP(hipGetLastError());
+  MG_HIP(hipStreamSynchronize(st));
+  db->kidx = std::move(ix);
+  return MG_OK;
+}
+
+int mg_refdb_has_kmer_index(const mg_refdb* db) { return db && db->kidx ? 1 : 0; }
+uint64_t mg_refdb_distinct_kmers(const mg_refdb* db) { return db && db->kidx ? db->kidx->ndistinct : 0; }
+
+int mg_refdb_kmer_heads(const mg_refdb* db, uint32_t* head) {
+  MG_REQUIRE_READY();
+  if (!db || !db->kidx || !head) return fail(MG_ERR_ARG, "null argument, or a table without a k-mer index");
+  return db->kmax.total ? mg_memcpy_d2h(head, db->kidx->head.p, db->kmax.total * 4) : MG_OK;
+}
+
+int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
+  MG_REQUIRE_READY();
+  if (!db || !out) return fail(MG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
+  std::unique_ptr<mg_kcounts> kc(new mg_kcounts());
+  kc->n = db->kmax.total;
+  MG_TRY(kc->counts.alloc((kc->n + 1) * 4));
+  MG_TRY(kc->stats.alloc(4 * 8));
+  MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
+  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 4 * 8, ctx().stream));
+  *out = kc.release();
+  return MG_OK;
+}
+
+int mg_kcounts_reset(mg_kcounts* kc) {
+  MG_REQUIRE_READY();
+  if (!kc) return fail(MG_ERR_ARG, "null argument");
+  MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
+  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 4 * 8, ctx().stream));
+  return MG_OK;
+}
+
+int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t nbases, const mg_refdb* db,
+                       mg_kcounts* kc) {
+  MG_REQUIRE_READY();
+  if (!db || !kc || (nreads && (!d_bases || !d_offsets))) return fail(MG_ERR_ARG, "null argument");
+  if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
+  if (kc->n != db->kmax.total) return fail(MG_ERR_ARG, "these counters belong to another table");
+  if (nreads == 0) return MG_OK;
+  Context& c = ctx();
+  const KmerIndex& ix = *db->kidx;
+  // the stage of a wavefront: 64 reads of average length + 12.5 %, in dwords of sixteen bases, a multiple of 64; never below what
+  // a chunk of a long read needs (k + 15 bases per lane)
+  const uint64_t avg = nbases ? (nbases + nreads - 1) / nreads : 150;
+  uint64_t sd = ((64 * avg * 9 / 8 + 64 + 15) / 16 + 63) / 64 * 64;
+  const uint64_t floor_sd = 64ull * (((uint64_t)ix.k + 15 + 15) / 16 + 1);
+  if (sd < floor_sd) sd = floor_sd;
+  if (sd > 2048) sd = 2048;  // 32 k bases
+  const KcLds L((uint32_t)sd);
+  const size_t lds = (size_t)kKcWaves * L.total;
+  unsigned per_cu = (unsigned)(160 * 1024 / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  if (dbg("kc_wg_per_cu") > 0) per_cu = (unsigned)dbg("kc_wg_per_cu");
+  if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
+  const uint64_t ntiles = (nreads + 63) / 64;
+  const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
+  KcArgs a{d_bases, d_offsets, nreads, ix.gate.as<uint32_t>(), ix.offs.as<uint32_t>(), ix.ent.as<KcEntry>(), kc->counts.as<uint32_t>(),
+           kc->stats.as<unsigned long long>(), ix.bshift, (uint32_t)sd};
+  ProfScope ps("count_kmers");
+  MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
+  MG_HIP(hipGetLastError());
+  return MG_OK;
+}
+
+int mg_kcounts_stats(const mg_kcounts* kc, uint64_t* out4) {
+  MG_REQUIRE_READY();
+  if (!kc || !out4) return fail(MG_ERR_ARG, "null argument");
+  return mg_memcpy_d2h(out4, kc->stats.p, 4 * 8);
+}
+
+int mg_kcounts_download(const mg_kcounts* kc, const mg_refdb* db, uint32_t* per_pair) {
+  MG_REQUIRE_READY();
+  if (!kc || !db || !db->kidx || !per_pair) return fail(MG_ERR_ARG, "null argument");
+  if (kc->n != db->kmax.total) return fail(MG_ERR_ARG, "these counters belong to another table");
+  if (!kc->n) return MG_OK;
+  DevBuf out;
+  MG_TRY(out.alloc(kc->n * 4));
+  hipLaunchKernelGGL(k_kc_per_pair, dim3(g256(kc->n)), dim3(256), 0, ctx().stream, kc->counts.as<uint32_t>(), db->kidx->head.as<uint32_t>(),
+                     kc->n, ctx().count_sat, out.as<uint32_t>());
+  MG_HIP(hipGetLastError());
+  return mg_memcpy_d2h(per_pair, out.p, kc->n * 4);
+}
+
+int mg_kcounts_device(const mg_kcounts* kc, uint32_t** d_counts, uint64_t* n) {
+  if (!kc || !d_counts || !n) return fail(MG_ERR_ARG, "null argument");
+  *d_counts = kc->counts.as<uint32_t>();
+  *n = kc->n;
+  return MG_OK;
+}
+
+void mg_kcounts_free(mg_kcounts* kc) { delete kc; }
+
+}  // extern "C"

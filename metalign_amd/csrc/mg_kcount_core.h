@@ -1,0 +1,383 @@
+// mg_kcount_core.h — stage A of the reference pipeline BY K-MER IDENTITY: the per-lane pieces of k_count_kmers (mg_kcount.hip).
+//
+// What it replaces: `kmc -k<kmax> -ci2 -cs3` over the reads + `kmc_tools simple ... intersect` with the k_max-mers of the genome
+// sketches (scripts/select_db.py:50-59).  KMC counts canonical k-mers and intersects k-mer SETS: nothing on the read side is
+// hashed.  So the read side here hashes nothing either: a read k-mer is looked up among the table's sketched k-mers by what it IS.
+//
+// How: minimizer partitioning (KMC's own signatures are the same idea).  The minimizer of a k-mer is the smallest KEY among its
+// w = k - m + 1 m-mers (m = 15; key = an odd multiplier over the lexicographically smaller strand of the m-mer, 30 bits, a
+// bijection — so equal keys are equal m-mers and the value is the same on either strand).  Equal k-mers have equal minimizers:
+// the table's distinct canonical k-mers are grouped by minimizer once (mg_refdb_index_kmers), and a read's windows are cut into
+// RUNS of consecutive windows that share their minimizer (about w / 2 windows each).  Per run: one bit of a gate bitmap over the
+// 2^30 keys; for the few runs that pass, the bucket of table k-mers with that minimizer, each compared against the run's
+// windows (a 16-base signature first, the whole canonical k-mer on a signature hit); a match adds one to the k-mer's counter.
+//
+// The sliding minimum is van Herk / Gil-Werman in registers: m-mers in blocks of w; a window that starts in block b and ends
+// in block b + 1 has min(suffix minimum of block b from its first m-mer on, prefix minimum of block b + 1 up to its last):
+// one v_min for the prefix, one for the combination, one per m-mer for the suffix minima after the block — no deque, no
+// branch, every index a compile-time constant (the block loop is unrolled, the block's keys live in w registers).
+//
+// Host / device, one source: everything here is per-lane code without cross-lane operations; tests/host_kcount_check.cpp
+// compiles it with g++ (MG_HOST_CHECK) and holds it to the oracle where there is no GPU (tests/test_kcount_core_host.py).
+#pragma once
+#include <cstdint>
+#include <utility>
+
+#ifdef MG_HOST_CHECK
+#define MG_LDS
+#define MG_HD static inline
+#define MG_UNIFORM(x) (x)
+#else
+#include <hip/hip_runtime.h>
+#define MG_LDS __attribute__((address_space(3)))
+#define MG_HD __device__ __forceinline__
+#define MG_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  // the same in every lane: say so (an SGPR, scalar branches)
+#endif
+
+namespace mg {
+
+constexpr int kKcM = 15;                     // minimizer length: odd (no m-mer is its own reverse complement), 30 bits
+constexpr uint32_t kKcMask = 0x3fffffffu;
+constexpr uint32_t kKcNone = 0xffffffffu;    // "no key": above every key, so it is also +infinity of the minima
+constexpr uint32_t kKcXor = 0x1b873593u & kKcMask;  // (poly-A is m-mer 0: without this its key would be the smallest of all)
+constexpr uint32_t kKcMul = 0x2545f491u;     // odd: x -> x * kKcMul mod 2^30 is a bijection
+constexpr int kKcMinK = kKcM, kKcMaxK = 64;
+constexpr uint32_t kKcMaxRead = 1023;        // window numbers of an event take ten bits: longer reads go through in chunks
+
+// key of an m-mer given both strands 2-bit packed (first base most significant, right-aligned in 30 bits)
+MG_HD uint32_t kc_key(uint32_t f, uint32_t r) {
+  const uint32_t c = f < r ? f : r;
+  return ((c ^ kKcXor) * kKcMul) & kKcMask;
+}
+
+// ---- the staged tile: a big-endian 2-bit base stream -----------------------------------------------------------------
+// Base p of the stream sits in dword p >> 4 at bits [30 - 2 (p & 15), +2): the first base of a dword is its most significant
+// pair, so 32 bits taken at any base offset ARE sixteen bases packed first-base-most-significant — what k-mers compare by.
+// (The reverse strand of a window is computed from the window itself, kc_revcomp, and only where a signature has matched.)
+// `inv` is one bit per base (bit 31 - (p & 31) of dword p >> 5): set = not one of ACGTacgt.
+
+// 32 bits of a 2-bit stream from base p on (sixteen bases)
+MG_HD uint32_t kc_ext32(const MG_LDS uint32_t* s, uint32_t p) {
+  const uint32_t d = p >> 4, sh = (p & 15u) << 1;
+  const uint64_t v = ((uint64_t)s[d] << 32) | s[d + 1];
+  return (uint32_t)((v << sh) >> 32);
+}
+// 32 bits of a 1-bit stream from position p on
+MG_HD uint32_t kc_bits32(const MG_LDS uint32_t* s, uint32_t p) {
+  const uint32_t d = p >> 5, sh = p & 31u;
+  const uint64_t v = ((uint64_t)s[d] << 32) | s[d + 1];
+  return (uint32_t)((v << sh) >> 32);
+}
+
+struct KcWin { uint32_t w[4]; };  // a k-mer, LEFT-aligned: base 0 in the top pair of w[0]; bits below 2k are zero
+
+MG_HD uint32_t kc_keep_mask(int k, int word) {  // the bits of dword `word` that belong to a left-aligned k-mer
+  const int nb = 2 * k - 32 * word;
+  return nb <= 0 ? 0u : (nb >= 32 ? 0xffffffffu : 0xffffffffu << (32 - nb));
+}
+
+MG_HD KcWin kc_ext128(const MG_LDS uint32_t* s, uint32_t p, int k) {
+  const uint32_t d = p >> 4, sh = (p & 15u) << 1;
+  uint32_t a[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) a[i] = s[d + i];
+  KcWin x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x.w[i] = (uint32_t)(((((uint64_t)a[i]) << 32 | a[i + 1]) << sh) >> 32) & kc_keep_mask(k, i);
+  return x;
+}
+
+MG_HD bool kc_less(const KcWin& a, const KcWin& b) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+  return a.w[3] < b.w[3];
+}
+MG_HD bool kc_equal(const KcWin& a, const KcWin& b) {
+  return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2] && a.w[3] == b.w[3];
+}
+
+// the order of the sixteen 2-bit groups of a dword reversed
+MG_HD uint32_t kc_rev2(uint32_t x) {
+#ifdef MG_HOST_CHECK
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+  x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+  x = (x >> 16) | (x << 16);
+#else
+  x = __builtin_bitreverse32(x);  // v_bfrev_b32: every bit reversed ...
+#endif
+  return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);  // ... and the two bits of a group put back in order
+}
+// reverse complement of sixteen packed bases
+MG_HD uint32_t kc_rc32(uint32_t x) { return kc_rev2(~x); }
+
+// reverse complement of a left-aligned k-mer
+MG_HD KcWin kc_revcomp(const KcWin& x, int k) {
+  // all 64 groups reversed and complemented: the k-mer's groups end up at the BOTTOM of the 128 bits; shift them to the top
+  const uint32_t r[4] = {kc_rc32(x.w[3]), kc_rc32(x.w[2]), kc_rc32(x.w[1]), kc_rc32(x.w[0])};
+  const int s = 2 * (64 - k);  // left shift, 0 .. 98
+  KcWin o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i + (s >> 5), sh = s & 31;
+    const uint32_t hi = q < 4 ? r[q < 4 ? q : 3] : 0u, lo = q + 1 < 4 ? r[q + 1 < 4 ? q + 1 : 3] : 0u;
+    o.w[i] = (sh ? (hi << sh) | (lo >> (32 - sh)) : hi) & kc_keep_mask(k, i);
+  }
+  return o;
+}
+
+// (hi, lo): a k-mer right-aligned in 128 bits, first base most significant (the table's kmer_hi / kmer_lo) -> left-aligned
+MG_HD KcWin kc_from_right(uint64_t hi, uint64_t lo, int k) {
+  const int s = 128 - 2 * k;  // 0 .. 98
+  uint64_t h, l;
+  if (s == 0) { h = hi; l = lo; }
+  else if (s < 64) { h = (hi << s) | (lo >> (64 - s)); l = lo << s; }
+  else { h = s == 64 ? lo : lo << (s - 64); l = 0; }
+  return KcWin{{(uint32_t)(h >> 32), (uint32_t)h, (uint32_t)(l >> 32), (uint32_t)l}};
+}
+
+// the lexicographically smaller strand (KMC's canonical k-mer)
+MG_HD KcWin kc_canonical(const KcWin& x, int k) {
+  const KcWin r = kc_revcomp(x, k);
+  return kc_less(r, x) ? r : x;
+}
+
+// m-mer number j (bases j .. j + 14) of a left-aligned k-mer, right-aligned in 30 bits
+MG_HD uint32_t kc_mmer_at(const KcWin& x, int j) {
+  const int d = j >> 4, sh = (j & 15) << 1;
+  const uint64_t v = ((uint64_t)x.w[d] << 32) | (d + 1 < 4 ? x.w[d + 1 < 4 ? d + 1 : 3] : 0u);
+  return (uint32_t)((v << sh) >> 34);
+}
+// reverse complement of a 15-mer (30 bits, right-aligned)
+MG_HD uint32_t kc_mmer_rc(uint32_t f) { return kc_rc32(f << 2) & kKcMask; }
+
+// the minimizer of a k-mer: the smallest key among its m-mers (table side; the read side slides: kc_walk)
+MG_HD uint32_t kc_minimizer(const KcWin& x, int k) {
+  uint32_t best = kKcNone;
+  for (int j = 0; j + kKcM <= k; ++j) {
+    const uint32_t f = kc_mmer_at(x, j);
+    const uint32_t key = kc_key(f, kc_mmer_rc(f));
+    best = key < best ? key : best;
+  }
+  return best;
+}
+
+// One distinct canonical k-mer of the table, as the read side meets it (32 bytes, two 16-byte loads).
+struct __attribute__((aligned(16))) KcEntry {
+  uint32_t w[4];   // the canonical k-mer, left-aligned
+  uint32_t head;   // where it is counted: the first pair of the hash-major table that holds it
+  uint32_t key;    // its minimizer
+  uint32_t sig_rc; // the first sixteen bases of its reverse complement (w[0] is the signature of the k-mer itself)
+  uint32_t pad;
+};
+
+// ---- staging: sixteen ASCII bases -> one dword of the stream ----------------------------------------------------------
+// v: the sixteen bytes as four little-endian dwords (byte 0 = the first base).  Returns the packed dword; *notbase gets a
+// non-zero value when any byte is not one of ACGTacgt (per byte: bit 7 of the byte's lane in nz[i]).
+MG_HD uint32_t kc_pack4(uint32_t x, uint32_t& nz) {
+  const uint32_t u = x & 0xDFDFDFDFu;                       // upper case
+  const uint32_t t = (x >> 1) & 0x03030303u;                // A:0 C:1 T:2 G:3
+  const uint32_t c = t ^ ((t >> 1) & 0x01010101u);          // A:0 C:1 G:2 T:3
+#ifdef MG_HOST_CHECK
+  uint32_t letters = 0;
+  for (int b = 0; b < 4; ++b) letters |= ((0x54474341u >> (8 * ((c >> (8 * b)) & 3u))) & 0xffu) << (8 * b);
+#else
+  const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, c);  // "ACGT"[code] per byte
+#endif
+  nz = letters ^ u;                                          // a byte that is not its own code's letter is no base
+  // the four codes (byte b holds base b) -> eight bits, base 0 most significant: one multiply gathers them (the partial
+  // products land in disjoint bit pairs, nothing carries)
+  return (c * 0x40100401u) >> 24;
+}
+MG_HD uint32_t kc_pack16(const uint32_t v[4], uint32_t& notbase) {
+  uint32_t n0, n1, n2, n3;
+  const uint32_t p = (kc_pack4(v[0], n0) << 24) | (kc_pack4(v[1], n1) << 16) | (kc_pack4(v[2], n2) << 8) | kc_pack4(v[3], n3);
+  notbase = n0 | n1 | n2 | n3;
+  return p;
+}
+// the same sixteen bytes -> sixteen "not a base" bits, the first base most significant
+MG_HD uint32_t kc_notbase16(const uint32_t v[4]) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t nz;
+    (void)kc_pack4(v[i], nz);
+    const uint32_t b = ((((nz & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nz) >> 7) & 0x01010101u;  // 1 per non-zero byte
+    out = (out << 4) | (((b * 0x08040201u) >> 24) & 0xFu);
+  }
+  return out;
+}
+
+// ---- the read side: runs of windows that share their minimizer -------------------------------------------------------
+// An event = a closed run: (key, first window | last window << 10); key == kKcNone: nothing (skipped by whoever reads the list).
+// Out: put(slot, key, info) stores the run a lane is ABOUT to close in its list (every step, at the slot after its closed
+// ones: whether the run closes is known one compare later — an unconditional store and an add-with-carry instead of a branch);
+// a list has kCap slots and one more that takes the stores of a lane whose list is full; any_full(cnt), wave_min(x): the two
+// things the walk asks of the whole wavefront, once per block and once per call.
+//
+// The walk starts at window w0 (wave-uniform) and goes on to the end of the tile's longest read — or to the end of the block in
+// which some lane's list filled up.  It returns the window to go on from: the first it has not walked, or the first that a full
+// lane has not RECORDED (the window after its last event); whoever empties the lists drops what lies at or beyond that window
+// (other lanes may have recorded further: they record it again).  Nothing else is carried from one call to the next: the
+// sliding minimum is primed anew (k - 1 bases: what a restart costs) and a run that straddles the restart is two events with
+// one key — every window is still in exactly one event.  So whatever empties the lists runs where nothing of the walk is live.
+//
+// MODE 0: any tile (bases that are no bases: an m-mer over one has no key, a run of such windows is no event; windows over
+//         one are sorted out when a run is matched).  1: no such base in the tile, every read as long as the longest.
+//         2: no such base, ragged lengths.
+// fwd / inv: the staged tile; p0: stream position of this lane's first base; len: its read's length; maxlen: the longest of
+// the tile (wave-uniform: so are the loop bounds and the stream's refill points).
+template <int K, int MODE, class Out>
+MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, uint32_t p0, uint32_t len, uint32_t maxlen, uint32_t w0,
+                       Out& out, uint32_t& cnt) {
+  constexpr int M = kKcM, W = K - M + 1;
+  constexpr uint32_t kCap = Out::kCap;
+  static_assert(K >= kKcMinK && K <= kKcMaxK, "k out of range for the minimizer path");
+  maxlen = MG_UNIFORM(maxlen);
+  w0 = MG_UNIFORM(w0);
+  if (maxlen < (uint32_t)K) return 0u;  // (uniform) no window in the whole tile
+  const uint32_t nw = len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u;
+  const uint32_t nwmax = maxlen - (uint32_t)K + 1u;  // windows of the longest read
+  if (w0 >= nwmax) return nwmax;
+  const uint32_t nmers = nwmax + (uint32_t)(W - 1);  // ... and its m-mers
+  uint32_t f = 0, r = 0, vrun = 0;
+  uint32_t word = kc_ext32(fwd, p0 + (w0 & ~15u)), iw = 0;
+  if constexpr (MODE == 0) iw = kc_bits32(inv, p0 + (w0 & ~31u));
+  uint32_t A[W];  // this block's keys; from the end of the block on, the block's suffix minima
+  uint32_t P = kKcNone, Mprev = kKcNone, rstart = w0;
+  auto take = [&](uint32_t u) -> uint32_t {  // base u of the read comes in; the key of the m-mer that ends there
+    if ((u & 15u) == 0) word = kc_ext32(fwd, p0 + u);
+    const uint32_t c = (word >> (30u - 2u * (u & 15u))) & 3u;
+    f = ((f << 2) | c) & kKcMask;
+    r = (r >> 2) | ((c ^ 3u) << 28);
+    uint32_t key = kc_key(f, r);
+    if constexpr (MODE == 0) {
+      if ((u & 31u) == 0) iw = kc_bits32(inv, p0 + u);
+      const uint32_t bad = (iw >> (31u - (u & 31u))) & 1u;
+      vrun = bad ? 0u : vrun + 1u;
+      key = vrun >= (uint32_t)M ? key : kKcNone;
+    }
+    return key;
+  };
+  for (uint32_t u = w0; u + 1 < w0 + (uint32_t)M; ++u) (void)take(u);
+  // The W steps of a block and the W - 2 of its suffix minima are EXPANDED, not looped (fold expressions over the step number):
+  // every A[...] is a register, and a block is straight-line code — only the block in which the longest read ends looks, every
+  // eighth step, whether it has (what it walks beyond that end is masked like a ragged read's tail).
+  // block 0: the first window (m-mers w0 .. w0 + W - 1, all there: w0 < nwmax) opens the first run
+  [&]<int... T>(std::integer_sequence<int, T...>) {
+    ((A[T] = take(w0 + (uint32_t)(T + M - 1)), P = T == 0 ? A[T] : (A[T] < P ? A[T] : P)), ...);
+  }(std::make_integer_sequence<int, W>{});
+  Mprev = P;
+  if constexpr (MODE != 1) Mprev = w0 < nw ? Mprev : kKcNone;
+  uint32_t walked = w0 + 1u;  // the first window not walked
+  for (uint32_t b = 1;; ++b) {
+    if constexpr (W > 2) {
+      [&]<int... T>(std::integer_sequence<int, T...>) {
+        ((A[W - 2 - T] = A[W - 2 - T] < A[W - 1 - T] ? A[W - 2 - T] : A[W - 1 - T]), ...);  // A[W-2] .. A[1]
+      }(std::make_integer_sequence<int, W - 2>{});
+    }
+    const uint32_t j0 = w0 + b * (uint32_t)W;  // the block's first m-mer (m-mer j ends at base j + M - 1 and closes window j - (W - 1))
+    if (j0 >= nmers || out.any_full(cnt)) break;
+    const bool tail = j0 + (uint32_t)W > nmers;
+    auto step = [&]<int T>() -> bool {
+      const uint32_t j = j0 + (uint32_t)T;
+      if constexpr (T % 8 == 0 && T > 0) { if (tail && j >= nmers) return false; }
+      const uint32_t key = take(j + (uint32_t)M - 1u);
+      P = T == 0 ? key : (key < P ? key : P);
+      uint32_t Mc = P;
+      if constexpr (T != W - 1) { const uint32_t s = A[T + 1 < W ? T + 1 : 0]; Mc = s < P ? s : P; }
+      const uint32_t i = j - (uint32_t)(W - 1);
+      if (MODE != 1 || tail) Mc = i < nw ? Mc : kKcNone;
+      out.put(cnt, Mprev, rstart | (((i - 1u) & 1023u) << 10));
+      const bool ch = Mc != Mprev;
+      cnt += (ch && cnt < kCap) ? 1u : 0u;
+      rstart = ch ? i : rstart;
+      Mprev = Mc;
+      A[T] = key;
+      walked = i + 1u;
+      return true;
+    };
+    const bool whole = [&]<int... T>(std::integer_sequence<int, T...>) { return (step.template operator()<T>() && ...); }(
+        std::make_integer_sequence<int, W>{});
+    if (!whole) break;
+  }
+  walked = walked < nwmax ? walked : nwmax;  // (the tail block may have walked past the end)
+  // the run still open (nothing, if its key is kKcNone: a lane whose read has ended closed its last run where it ended)
+  out.put(cnt, Mprev, rstart | (((walked - 1u) & 1023u) << 10));
+  cnt += cnt < kCap ? 1u : 0u;
+  // a full list: everything up to its last event is recorded, what follows may not be
+  const uint32_t safe = cnt >= kCap ? out.last_window(kCap - 1u) + 1u : walked;
+  return out.wave_min(safe < walked ? safe : walked);
+}
+
+// the windows of a read that hold no "not a base" bit (KMC's total of k-mers, for the tiles that have such bases)
+MG_HD uint32_t kc_clean_windows(const MG_LDS uint32_t* inv, uint32_t p0, uint32_t len, uint32_t maxlen, int k) {
+  uint32_t vrun = 0, n = 0, iw = 0;
+  for (uint32_t u = 0; u < maxlen; ++u) {
+    if ((u & 31u) == 0) iw = kc_bits32(inv, p0 + u);
+    const uint32_t bad = (iw >> (31u - (u & 31u))) & 1u;
+    vrun = bad ? 0u : vrun + 1u;
+    n += (vrun >= (uint32_t)k && u < len) ? 1u : 0u;
+  }
+  return n;
+}
+
+// ---- a run against the table -------------------------------------------------------------------------------------------
+struct KcIndexView {
+  const uint32_t* gate;   // 2^30 bits: bit `key` set <=> some table k-mer has this minimizer
+  const uint32_t* offs;   // [buckets + 1]: entries of bucket b = key >> bshift are ent[offs[b] .. offs[b + 1])
+  const KcEntry* ent;     // ascending by key
+  uint32_t* counts;       // [npairs]: occurrences, at the entry's `head`
+  uint32_t bshift;
+};
+
+MG_HD bool kc_gate(const uint32_t* gate, uint32_t key) { return (gate[key >> 5] >> (key & 31u)) & 1u; }
+
+// no "not a base" bit in [p, p + k)
+MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
+  const uint32_t d = p >> 5, sh = p & 31u;
+  const uint32_t a = inv[d], b = inv[d + 1], c = inv[d + 2];
+  const uint32_t v0 = (uint32_t)(((((uint64_t)a) << 32 | b) << sh) >> 32), v1 = (uint32_t)(((((uint64_t)b) << 32 | c) << sh) >> 32);
+  const uint32_t m0 = k >= 32 ? 0xffffffffu : 0xffffffffu << (32 - k);
+  const uint32_t m1 = k <= 32 ? 0u : (k >= 64 ? 0xffffffffu : 0xffffffffu << (64 - k));
+  return ((v0 & m0) | (v1 & m1)) == 0u;
+}
+
+#ifdef MG_HOST_CHECK
+#define MG_KC_COUNT(ptr) (++*(ptr))
+#else
+#define MG_KC_COUNT(ptr) atomicAdd((ptr), 1u)
+#endif
+
+// The windows [i1, i2] of the read that starts at stream position p0 share the minimizer `key`, and the gate has it: every
+// table k-mer with that minimizer against every window.  Returns the matches.
+template <bool BAD>
+MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, uint32_t key,
+                            uint32_t p0, uint32_t i1, uint32_t i2) {
+  const uint32_t b = key >> ix.bshift;
+  const uint32_t lo = ix.offs[b], hi = ix.offs[b + 1];
+  const uint32_t sigmask = kc_keep_mask(k, 0);
+  uint32_t found = 0;
+  for (uint32_t e = lo; e < hi; ++e) {
+    const KcEntry E = ix.ent[e];
+    if (E.key != key) continue;
+    for (uint32_t i = i1; i <= i2; ++i) {
+      const uint32_t p = p0 + i;
+      const uint32_t x0 = kc_ext32(fwd, p) & sigmask;
+      if (x0 != E.w[0] && x0 != E.sig_rc) continue;
+      if constexpr (BAD) { if (!kc_window_clean(inv, p, k)) continue; }
+      const KcWin x = kc_ext128(fwd, p, k), y = kc_revcomp(x, k);
+      const KcWin c = kc_less(y, x) ? y : x;
+      if (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) {
+        // (a k-mer that fills a sample could wrap a 32-bit counter: stop far above any saturation value)
+        if (ix.counts[E.head] < 0x7fffff00u) MG_KC_COUNT(&ix.counts[E.head]);
+        ++found;
+      }
+    }
+  }
+  return found;
+}
+
+}  // namespace mg

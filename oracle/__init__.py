@@ -248,6 +248,53 @@ def refpipe_containment(q_hashes, q_counts, ci, table):
     return np.asarray(hits, dtype=np.uint32).reshape(len(table["ks"]), g), np.asarray(sizes, dtype=np.uint32).reshape(len(table["ks"]), g)
 
 
+def refpipe_count_kmers(bases, offsets, k, kmer_hi, kmer_lo, cs=DEFAULT_CS):
+    """Stage A of the reference pipeline by k-mer IDENTITY (oracle/mg_oracle.c: mgo_refpipe_count_kmers): per pair of a table
+    (kmer_hi / kmer_lo in pair order) the occurrences of its canonical k-mer among the reads' canonical k-mers — what `kmc` +
+    `kmc_tools intersect` compute (scripts/select_db.py:50-59) — saturating at cs (0: exact).  -> (counts u32[npairs], kmers_seen)"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    khi = np.ascontiguousarray(kmer_hi, dtype=np.uint64)
+    klo = np.ascontiguousarray(kmer_lo, dtype=np.uint64)
+    e = len(khi)
+    out = np.zeros(max(e, 1), dtype=np.uint32)
+    seen = ctypes.c_uint64(0)
+    bptr = _p(bases, ctypes.c_uint8) if bases.size else ctypes.POINTER(ctypes.c_uint8)()
+    rc = lib().mgo_refpipe_count_kmers(bptr, _p(offsets, ctypes.c_uint64), ctypes.c_uint64(len(offsets) - 1), ctypes.c_int(int(k)),
+                                       ctypes.c_uint32(int(cs)), _p(khi if e else np.zeros(1, np.uint64), ctypes.c_uint64),
+                                       _p(klo if e else np.zeros(1, np.uint64), ctypes.c_uint64), ctypes.c_uint64(e),
+                                       _p(out, ctypes.c_uint32), ctypes.byref(seen))
+    if rc != 0:
+        raise RuntimeError("mgo_refpipe_count_kmers rc=%d" % rc)
+    return out[:e].copy(), int(seen.value)
+
+
+def refpipe_containment_counts(counts, ci, table):
+    """refpipe_containment with the matched pairs taken from per-pair occurrence counts (refpipe_count_kmers): counts >= ci."""
+    ph, pg, g = table["pair_hash"], table["pair_gen"], table["ngenomes"]
+    e = len(ph)
+    matched = np.zeros(max(e, 1), dtype=np.uint8)
+    matched[:e] = np.asarray(counts, dtype=np.uint32)[:e] >= ci
+    hits, sizes = [], []
+    for k in table["ks"][:-1]:
+        t = table["small"][k]
+        out = np.zeros(max(g, 1), dtype=np.uint32)
+        rc = lib().mgo_refpipe_hits_k(_p(matched, ctypes.c_uint8),
+                                      _p(t["pa"] if e else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                      _p(t["pb"] if e else np.zeros(1, np.uint32), ctypes.c_uint32), ctypes.c_uint64(e),
+                                      ctypes.c_uint64(t["nprefix"]),
+                                      _p(t["cid"] if len(t["cid"]) else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                      _p(t["cgen"] if len(t["cgen"]) else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                      ctypes.c_uint64(len(t["cid"])), ctypes.c_uint64(g), _p(out, ctypes.c_uint32))
+        if rc != 0:
+            raise RuntimeError("mgo_refpipe_hits_k rc=%d" % rc)
+        hits.append(out[:g].copy())
+        sizes.append(t["gsize"].copy())
+    hits.append(np.bincount(pg[matched[:e] != 0], minlength=g).astype(np.uint32)[:g] if e else np.zeros(g, np.uint32))
+    sizes.append(table["gsize"].copy())
+    return np.asarray(hits, dtype=np.uint32).reshape(len(table["ks"]), g), np.asarray(sizes, dtype=np.uint32).reshape(len(table["ks"]), g)
+
+
 def refpipe_matched(q_hashes, q_counts, ci, pair_hash):
     """uint8[npairs]: the pair's hash is in the read sketch with count >= ci (mgo_refpipe_matched)."""
     q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)

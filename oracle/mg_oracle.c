@@ -603,6 +603,82 @@ int mgo_refpipe_hits_k(const uint8_t* matched, const uint32_t* pa, const uint32_
   return MG_OK;
 }
 
+/* ---------------------------------------------------------------------- *
+ * Stage A of the reference pipeline BY K-MER IDENTITY (the build's default since round 6).
+ *
+ * `kmc -k<kmax> -ci<ci> -cs<cs>` counts the reads' CANONICAL k-mers — the lexicographically smaller strand — and `kmc_tools simple
+ * ... intersect` keeps those that are k-mers of the genome sketches (scripts/select_db.py:50-59): k-mers are compared as what they
+ * ARE, nothing on the read side is hashed (MurmurHash3 only SELECTS a genome's sketch, when the table is built).  So:
+ *   counts[i] = occurrences, over all reads, of windows (free of non-ACGT symbols) whose canonical k-mer equals the canonical
+ *               form of pair i's kept k-mer (khi / klo: 2-bit packed, first base most significant, as mgo_sketch_genomes_kmers
+ *               leaves them, in any orientation), saturating at cs when cs > 0;
+ *   a pair is MATCHED when counts[i] >= ci.
+ * mgo_refpipe_matched (by hash value) gives the same pairs unless two different k-mers share a hash.  tests/indep_sketch.py:
+ * refpipe_query states this on strings.  PARITY UNPINNED like the rest of stage A/B.
+ * ---------------------------------------------------------------------- */
+typedef struct { uint64_t hi, lo; uint64_t idx; } kc_ent;
+static int cmp_kc_ent(const void* a, const void* b) {
+  const kc_ent* x = (const kc_ent*)a; const kc_ent* y = (const kc_ent*)b;
+  if (x->hi != y->hi) return x->hi < y->hi ? -1 : 1;
+  if (x->lo != y->lo) return x->lo < y->lo ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+/* the smaller of codes c[0..k) and their reverse complement, packed */
+static void canonical_pack(const uint8_t* c, int k, uint64_t* hi, uint64_t* lo) {
+  uint8_t r[MG_MAX_K];
+  for (int t = 0; t < k; ++t) r[k - 1 - t] = (uint8_t)(3 - c[t]);
+  pack_codes(memcmp(c, r, (size_t)k) <= 0 ? c : r, k, hi, lo);
+}
+
+int mgo_refpipe_count_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t nreads, int k, uint32_t cs,
+                            const uint64_t* khi, const uint64_t* klo, uint64_t npairs, uint32_t* out_counts,
+                            uint64_t* out_kmers_seen) {
+  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
+  kc_ent* t = (kc_ent*)malloc((npairs + 1) * sizeof(kc_ent));
+  uint64_t* cnt = (uint64_t*)calloc(npairs + 1, sizeof(uint64_t));   /* per position of the sorted table: the first of a group counts */
+  if (!t || !cnt) { free(t); free(cnt); return MG_ERR_NOMEM; }
+  for (uint64_t i = 0; i < npairs; ++i) {
+    uint8_t c[MG_MAX_K];
+    unpack_codes(khi[i], klo[i], k, c);
+    canonical_pack(c, k, &t[i].hi, &t[i].lo);
+    t[i].idx = i;
+  }
+  if (npairs) qsort(t, npairs, sizeof(kc_ent), cmp_kc_ent);
+  uint64_t seen = 0;
+  for (uint64_t r = 0; r < nreads; ++r) {
+    const uint8_t* seq = bases + offsets[r];
+    const uint64_t len = offsets[r + 1] - offsets[r];
+    uint64_t run = 0;
+    for (uint64_t j = 0; j < len; ++j) {
+      run = base_code(seq[j]) >= 0 ? run + 1 : 0;
+      if (run < (uint64_t)k) continue;
+      ++seen;
+      uint8_t c[MG_MAX_K];
+      for (int u = 0; u < k; ++u) c[u] = (uint8_t)base_code(seq[j + 1 - (uint64_t)k + (uint64_t)u]);
+      kc_ent key;
+      canonical_pack(c, k, &key.hi, &key.lo);
+      uint64_t lo = 0, hi = npairs;   /* the first entry >= (key, idx 0) */
+      while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (t[mid].hi < key.hi || (t[mid].hi == key.hi && t[mid].lo < key.lo)) lo = mid + 1; else hi = mid;
+      }
+      if (lo < npairs && t[lo].hi == key.hi && t[lo].lo == key.lo) ++cnt[lo];
+    }
+  }
+  for (uint64_t i = 0; i < npairs;) {
+    uint64_t j = i;
+    while (j < npairs && t[j].hi == t[i].hi && t[j].lo == t[i].lo) ++j;
+    uint64_t c = cnt[i];
+    if (cs && c > cs) c = cs;
+    if (c > 0xffffffffULL) c = 0xffffffffULL;
+    for (uint64_t e = i; e < j; ++e) out_counts[t[e].idx] = (uint32_t)c;
+    i = j;
+  }
+  if (out_kmers_seen) *out_kmers_seen = seen;
+  free(t); free(cnt);
+  return MG_OK;
+}
+
 /* Stage B.  See include/metalign_hip.h (mg_containment). */
 int mgo_containment(const uint64_t* q_hashes, const uint32_t* q_counts, uint64_t qn,
                     int q_truncated, uint32_t ci, const uint64_t* db_hashes,
