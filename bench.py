@@ -2,7 +2,9 @@
 """bench.py — 150 bp reads/s through the hot path (CMash-style filter + profile) on N MI355X, inputs resident in HBM.
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-    stage A  read sketch (k_sketch_reads* + bucket sort / pack)                            scripts/select_db.py:50-52
+    stage A  the reads' k_max-mers counted against the table's BY K-MER IDENTITY (k_count_kmers: minimizer-partitioned, no hash
+             on the read side — what kmc + kmc_tools intersect compute; --match hash: the read sketch of rounds 1-5,
+             k_sketch_reads* + bucket sort / pack)                                         scripts/select_db.py:50-59
     stage B  containment, one column per k of the config                                  scripts/select_db.py:54-59,73-76
     stage C  assign + histogram (k_profile_pass), once                                    scripts/map_and_profile.py:193-264
 Stage A/B definition (--definition):
@@ -83,6 +85,9 @@ def parse():
     p.add_argument("--definition", choices=["reference_pipeline", "sketch_per_k"], default="reference_pipeline",
                    help="stage A/B as the reference wires it (reads sketched at the largest k only; default) or a sketch per k")
     p.add_argument("--hash_mode", type=int, choices=[0, 1], default=0, help="0: hash(min(kmer, revcomp)); 1: min(hash(kmer), hash(revcomp)) %% p")
+    p.add_argument("--match", choices=["kmer", "hash"], default="kmer",
+                   help="the reference pipeline on one GPU: a read k_max-mer meets a sketched one by what it IS (kmc's way, default) or by "
+                        "its MurmurHash3 value (rounds 4-5)")
     p.add_argument("--no_definitions", action="store_true", help="skip the passes of the definitions that were not selected")
     p.add_argument("--no_cpu_baseline", action="store_true", help="also skips the oracle check (it shares the sample)")
     p.add_argument("--cpu_seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -115,6 +120,7 @@ def resolve_config(args, world):
     pre["custom"] = bool(args.reads or args.genomes or args.genome_len or args.ks)
     pre["config"] = cfg
     pre["definition"], pre["hash_mode"] = args.definition, args.hash_mode
+    pre["match"] = args.match if args.definition == "reference_pipeline" else None
     return pre
 
 
@@ -126,7 +132,7 @@ def build_tables(cfg, sketch_n, hip, gb, go, definition, hash_mode, world=1):
         if definition == "reference_pipeline":
             h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, cfg["ks"][-1], sketch_n)
             table = hip.refdb_build(h, khi, klo, o, cfg["ks"])
-            arrays = table.download(kmers=False)
+            arrays = table.download(kmers=cfg.get("match") == "kmer")  # (the k-mers in pair order: what the identity oracle looks up)
             arrays["max_hash"] = table.max_hash
             if world > 1:  # (a rank uploads its share from the arrays)
                 table.free()
@@ -165,7 +171,12 @@ def make_job(hip, dist, rank, world, cfg, w, force_dist=False, sub=None):
     hash the reads by the definition its tables were sketched with)."""
     from metalign_amd import distributed as mgd
     hip.set_hash_mode(w["hash_mode"])
-    job = mgd.ShardJob(hip, dist, rank, world, k=cfg["ks"], ci=2, pct_id=0.5, always_exchange=force_dist, definition=w["definition"])
+    exchange = dist is not None and (world > 1 or force_dist)
+    match = None
+    if w["definition"] == "reference_pipeline":  # (the sharded path still meets k-mers by hash value: distributed.ShardJob)
+        match = "kmer" if (cfg.get("match") == "kmer" and not exchange and 15 <= cfg["ks"][-1] <= 64) else "hash"
+    job = mgd.ShardJob(hip, dist, rank, world, k=cfg["ks"], ci=2, pct_id=0.5, always_exchange=force_dist, definition=w["definition"],
+                       match=match)
     rb, ro, recs = (w["rb"], w["ro"], w["recs"]) if sub is None else sub
     if w["definition"] == "reference_pipeline":
         job.load(rb, ro, recs, w["ref2tax"], w["ref_arrays"], ntax=w["ntax"], reftable=w["reftable"])
@@ -193,12 +204,19 @@ def cpu_baseline_and_check(args, cfg, w, hip, dist=None, force_dist=False):
     hmaxs = [int(w["ref_arrays"]["max_hash"])] if refpipe else [int(h.max()) for h in w["dbh"]]
     leaders = np.cumsum(w["recs"]["ref_new"] >> 31)
     nreads_all = len(w["ro"]) - 1
+    # stage A by k-mer identity (the default): the oracle counts the reads' canonical k_max-mers among the table's k-mers as kmc +
+    # kmc_tools intersect do (mgo_kmer_table_*: a look-up per window, no hash of the k-mer's text)
+    by_kmer = refpipe and cfg.get("match") == "kmer" and dist is None and w["ref_arrays"].get("kmer_hi") is not None
+    ktab = oracle.KmerTable(w["ref_arrays"]["kmer_hi"], w["ref_arrays"]["kmer_lo"], ks[-1]) if by_kmer else None
 
     def share(lo, hi):  # reads [lo, hi) and their records
         b0, b1 = int(w["ro"][lo]), int(w["ro"][hi])
         r0 = int(np.searchsorted(leaders, lo, side="right"))
         r1 = int(np.searchsorted(leaders, hi, side="right"))
-        sk = [oracle.sketch_reads(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo], k, hmax=hm)[:2] for k, hm in zip(sk_ks, hmaxs)]
+        if by_kmer:
+            sk = ktab.count(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo])[0]
+        else:
+            sk = [oracle.sketch_reads(w["rb"][b0:b1], w["ro"][lo: hi + 1] - w["ro"][lo], k, hmax=hm)[:2] for k, hm in zip(sk_ks, hmaxs)]
         prof = oracle.profile_assign(w["recs"][r0:r1], w["ref2tax"], w["ntax"], 0.5) if r1 > r0 else None
         return sk, prof
 
@@ -211,6 +229,12 @@ def cpu_baseline_and_check(args, cfg, w, hip, dist=None, force_dist=False):
             with ThreadPoolExecutor(cores) as ex:
                 parts = list(ex.map(lambda i: share(cuts[i], cuts[i + 1]), range(cores)))
         merged = []
+        if by_kmer:
+            total = parts[0][0]
+            for p in parts[1:]:
+                total = total + p[0]
+            hits, sizes = oracle.refpipe_containment_counts(ktab.per_pair(total, oracle.DEFAULT_CS), 2, w["ref_arrays"])
+            return time.perf_counter() - t0, [(hits[ki], sizes[ki]) for ki in range(len(ks))]
         for ki in range(len(sk_ks)):
             allh = np.concatenate([p[0][ki][0] for p in parts])
             allc = np.concatenate([p[0][ki][1] for p in parts]).astype(np.uint64)
@@ -236,8 +260,10 @@ def cpu_baseline_and_check(args, cfg, w, hip, dist=None, force_dist=False):
     t, want_hs = run(n, cores)
     base = {"value": n / t, "unit": "reads/s", "cores": cores, "kind": "port", "single_core_value": single,
             "sample": "the first %d of the %d reads (%.1f %%) + their alignment records in %d contiguous shares, one thread "
-                      "each: read sketches for k in %s, merged, containment (%s) against the full %d-genome tables for k in %s, stage C; "
-                      "C oracle, %.1f s" % (n, nreads_all, 100.0 * n / nreads_all, cores, sk_ks, w["definition"], cfg["genomes"], ks, t)}
+                      "each: %s for k in %s, merged, containment (%s) against the full %d-genome tables for k in %s, stage C; "
+                      "C oracle, %.1f s" % (n, nreads_all, 100.0 * n / nreads_all, cores,
+                                            "the reads' canonical k-mers counted among the table's k-mers by identity" if by_kmer else "read sketches",
+                                            sk_ks, w["definition"], cfg["genomes"], ks, t)}
     # ---- the same sample through the GPU path (one job, one step), against the oracle ----
     b1 = int(w["ro"][n])
     r1 = int(np.searchsorted(leaders, n, side="right"))
@@ -259,7 +285,7 @@ def cpu_baseline_and_check(args, cfg, w, hip, dist=None, force_dist=False):
     if (got["tot_rds"], got["n_ambig"]) != (want_c["tot_rds"], want_c["n_ambig"]):
         bad.append("tot_rds/n_ambig")
     oracle.set_hash_mode(0)
-    check = {"oracle_equal": not bad, "mismatch": bad, "definition": w["definition"], "hash_mode": w["hash_mode"],
+    check = {"oracle_equal": not bad, "mismatch": bad, "definition": w["definition"], "hash_mode": w["hash_mode"], "match": got.get("match"),
              "compared": "hits and sizes of all %d genomes for k in %s; count / bases / first_seen of all %d taxa; tot_rds; "
                          "n_ambig — GPU path vs C oracle on the cpu_baseline sample (%d reads, %d records)"
                          % (cfg["genomes"], ks, w["ntax"], n, r1)}
@@ -279,8 +305,12 @@ def committed_profile(name, cfg):
                 d = json.load(fh)
             wl = d.get("workload", {})
             # (profiles of rounds 1-3 carry no definition: a sketch per k, hash mode 0)
-            if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")]), wl.get("definition", "sketch_per_k"), wl.get("hash_mode", 0)) == \
-                    (cfg["reads"], cfg["genomes"], cfg["ks"], cfg.get("definition", "sketch_per_k"), cfg.get("hash_mode", 0)):
+            # (... and those of rounds 4-5 no match: the reference pipeline met k-mers by hash value then)
+            refp = wl.get("definition", "sketch_per_k") == "reference_pipeline"
+            if (wl.get("reads"), wl.get("genomes"), wl.get("ks", [wl.get("k")]), wl.get("definition", "sketch_per_k"), wl.get("hash_mode", 0),
+                    (wl.get("match") or "hash") if refp else None) == \
+                    (cfg["reads"], cfg["genomes"], cfg["ks"], cfg.get("definition", "sketch_per_k"), cfg.get("hash_mode", 0),
+                     (cfg.get("match") or "hash") if cfg.get("definition") == "reference_pipeline" else None):
                 best = d
     return best
 
@@ -299,7 +329,8 @@ def committed_kernel_stats(cfg):
         with open(fn) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("kernel", row.get("Name", ""))
-                if "k_sketch_reads" in name and (kmax is None or ("<%d," % kmax) in name):
+                fam = "k_count_kmers" if cfg.get("match") == "kmer" and kmax is not None else "k_sketch_reads"
+                if fam in name and (kmax is None or ("<%d," % kmax) in name or ("<%d>" % kmax) in name):
                     best = {"kernel": name, "avg_ms": float(row.get("avg_ns", row.get("AverageNs", 0))) / 1e6,
                             "calls": int(row.get("calls", row.get("Calls", 0))),
                             "source": "profiles/%s/config%d_kernel_stats.csv" % (rnd, cfg["config"])}
@@ -312,8 +343,9 @@ def valu_roofline(sq, ms_alone_live):
     out = {"valu_frac": None, "valu_model": None}
     if not sq:
         return out
-    names = sq["k_sketch_reads"]["kernels"]
-    insts = sq["k_sketch_reads"].get("SQ_INSTS_VALU_per_pass")
+    sa = sq.get("stage_a", sq.get("k_sketch_reads"))
+    names = sa["kernels"]
+    insts = sa.get("SQ_INSTS_VALU_per_pass")
     gui = sum(sq["kernels"][k].get("GRBM_GUI_ACTIVE", 0.0) for k in names)
     model = None
     pdir = os.path.join(ROOT, "profiles")
@@ -322,6 +354,9 @@ def valu_roofline(sq, ms_alone_live):
     fused = len(names) == 1 and "multi" in names[0]
     m = re.match(r"k_sketch_reads<(\d+)", names[0]) if len(names) == 1 else None
     model_name = "k1_valu_roofline.json" if fused else ("k1_single_k%s_valu_roofline.json" % m.group(1) if m else None)
+    mk = re.match(r"k_count_kmers<(\d+)", names[0]) if len(names) == 1 else None
+    if mk:
+        model_name = "k1_count_kmers_k%s_valu_roofline.json" % mk.group(1)
     for rnd in sorted(os.listdir(pdir)) if (os.path.isdir(pdir) and model_name) else []:
         fn = os.path.join(pdir, rnd, model_name)
         if os.path.isfile(fn):
@@ -363,7 +398,7 @@ def committed_run(name, cfg):
 
 def secondary_config1(hip, args):
     """configs[1] (1M reads, 1k genomes, k = 21) in the same process: reads/s of the pipelined passes."""
-    cfg = dict(PRESETS[1], config=1)
+    cfg = dict(PRESETS[1], config=1, match=args.match if args.definition == "reference_pipeline" else None)
     w = build_workload(cfg, args.sketch_n, 0, hip, args.definition, args.hash_mode)
     job = make_job(hip, None, 0, 1, cfg, w)
     job.run(60)
@@ -385,38 +420,40 @@ def other_definitions(hip, args, cfg, w):
     """The stage A/B definitions that were NOT selected, on the same reads / records / genomes, over the same number of
     pipelined passes (untimed by the driver; the same loop as the headline's): ms per pass and reads/s each."""
     out = {}
-    todo = [("reference_pipeline", 0, None), ("reference_pipeline", 1, None), ("sketch_per_k", 0, None)]
+    todo = [("reference_pipeline", 0, None, "kmer"), ("reference_pipeline", 0, None, "hash"), ("reference_pipeline", 1, None, "kmer"),
+            ("reference_pipeline", 1, None, "hash"), ("sketch_per_k", 0, None, None)]
     if cfg["ks"] != STOCK_KS:  # the reference's own k set, both hash definitions (the only configuration a Metalign user runs)
-        todo += [("reference_pipeline", 0, STOCK_KS), ("reference_pipeline", 1, STOCK_KS)]
-    for definition, mode, ks in todo:
-        if (definition, mode) == (args.definition, args.hash_mode) and ks is None:
+        todo += [("reference_pipeline", 0, STOCK_KS, "kmer"), ("reference_pipeline", 0, STOCK_KS, "hash"), ("reference_pipeline", 1, STOCK_KS, "kmer")]
+    for definition, mode, ks, match in todo:
+        if (definition, mode, match) == (args.definition, args.hash_mode, cfg.get("match")) and ks is None:
             continue
         t0 = time.perf_counter()
         w2 = dict(w)
         for key in ("ref_arrays", "reftable", "dbh", "dbo"):
             w2.pop(key, None)
-        cfg_run = cfg if ks is None else dict(cfg, ks=list(ks), name=STOCK_NAME)
+        cfg_run = dict(cfg, match=match) if ks is None else dict(cfg, ks=list(ks), name=STOCK_NAME, match=match)
+        k1_name = "count_kmers" if match == "kmer" else "sketch_reads"
         w2.update(build_tables(cfg_run, args.sketch_n, hip, w["gb"], w["go"], definition, mode))
         job = make_job(hip, None, 0, 1, cfg_run, w2)
         job.run(max(args.warmup, 2))
         hip.sync()
         hip.prof_reset()
         hip.prof_enable(True)
-        hip.prof_only("sketch_reads")
+        hip.prof_only(k1_name)
         t1 = time.perf_counter()
         res = job.run(args.steps)
         hip.sync()
         dt = (time.perf_counter() - t1) / args.steps
-        nk1, k1_ms = hip.prof_get("sketch_reads")
+        nk1, k1_ms = hip.prof_get(k1_name)
         hip.prof_enable(False)
-        key = ("stock_" if ks is not None else "") + "%s_mode%d" % (definition, mode)
+        key = ("stock_" if ks is not None else "") + "%s_mode%d" % (definition, mode) + ("_hash_match" if match == "hash" else "")
         out[key] = {
-            "definition": definition, "hash_mode": mode, "ks": cfg_run["ks"], "ms_per_pass": 1e3 * dt, "value": cfg["reads"] / dt, "unit": "reads/s",
+            "definition": definition, "hash_mode": mode, "match": res.get("match"), "ks": cfg_run["ks"], "ms_per_pass": 1e3 * dt, "value": cfg["reads"] / dt, "unit": "reads/s",
             "steps": args.steps, "stage_a_avg_launch_ms": k1_ms / max(nk1, 1), "stage_a_launches_per_pass": nk1 / max(args.steps, 1),
             "sketched_ks": res.get("sketched_ks"), "sketch_sizes": res.get("sketch_sizes"), "top_genomes_recovered": res.get("top_ok"),
             "setup_s": t1 - t0}
         del job
-        if ks is not None and mode == 0 and not args.no_cpu_baseline:
+        if ks is not None and mode == 0 and match == "kmer" and not args.no_cpu_baseline:
             # the stock preset against the oracle on a sample of its own (all 10 000 genomes x {30,40,50,60}, every stage-C accumulator)
             import copy
             a2 = copy.copy(args)
@@ -598,12 +635,13 @@ def main():
     sync()
     hip.prof_reset()
     hip.prof_enable(True)
-    hip.prof_only("sketch_reads")  # the dominant kernel is timed with HIP events inside the timed region
+    k1_name = "count_kmers" if getattr(job, "match", None) == "kmer" else "sketch_reads"
+    hip.prof_only(k1_name)  # the dominant kernel is timed with HIP events inside the timed region
     t0 = time.perf_counter()
     out = job.run(args.steps)  # K passes, software-pipelined (stage A of pass i+1 is queued before pass i is finished)
     sync()
     dt = time.perf_counter() - t0
-    nk1, k1_ms = hip.prof_get("sketch_reads")
+    nk1, k1_ms = hip.prof_get(k1_name)
     # per-kernel table from a few extra, untimed steps on ONE stream (nothing overlaps: clean per-family times)
     kernels_ms = {}
     if not args.no_kernel_table:
@@ -615,7 +653,7 @@ def main():
             job.step()
         sync()
         hip.stage_c_side_stream(True)
-        for name in ("table_clear", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort",
+        for name in ("table_clear", "count_kmers", "sketch_reads", "merge_insert", "merge_sort", "bucket_sort", "bucket_pack", "sketch_sort",
                      "sketch_rle", "contain_index", "containment", "refpipe_count", "profile_map", "profile_pass"):
             n, t = hip.prof_get(name)
             if n:
@@ -636,15 +674,18 @@ def main():
         # timed region; rocprofv3's average of the same kernel is in profiles/<round>/config2_kernel_stats.csv).  In the timed
         # region two launches overlap (stage A of pass i + 1 starts while pass i finishes), so a launch there is STRETCHED
         # (avg_launch_ms_pipelined) although one starts every period_ms: that is why ms_per_step can be below the kernel alone.
-        k1_alone_ms = kernels_ms.get("sketch_reads", {}).get("ms_per_pass") or k1_per_pass_ms
+        k1_alone_ms = kernels_ms.get(k1_name, {}).get("ms_per_pass") or k1_per_pass_ms
         achieved = algo_k1 / (k1_alone_ms * 1e-3) / 1e9 if k1_alone_ms else 0.0
         traffic = committed_profile("pmc_traffic.json", cfg)
         sq = committed_profile("pmc_sq_summary.json", cfg)
-        valu_insts = sq["k_sketch_reads"].get("SQ_INSTS_VALU_per_pass") if sq else None
-        roof = {"kernel": "k_sketch_reads* (stage A, all k of the pass: %.0f launch(es) per pass)" % launches_per_pass,
+        by_kmer = k1_name == "count_kmers"
+        sq_a = (sq.get("stage_a", sq.get("k_sketch_reads")) if sq else None)
+        tr_a = (traffic.get("stage_a", traffic.get("k_sketch_reads")) if traffic else None)
+        valu_insts = sq_a.get("SQ_INSTS_VALU_per_pass") if sq_a else None
+        roof = {"kernel": ("k_count_kmers<%d> (stage A by k-mer identity: %.0f launch(es) per pass)" % (cfg["ks"][-1], launches_per_pass)) if by_kmer
+                else "k_sketch_reads* (stage A, all k of the pass: %.0f launch(es) per pass)" % launches_per_pass,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic["k_sketch_reads"].get("hbm_bytes_per_pass", traffic["k_sketch_reads"].get("hbm_bytes_per_launch"))
-                            if traffic else None),
+                "traffic": (tr_a.get("hbm_bytes_per_pass", tr_a.get("hbm_bytes_per_launch")) if tr_a else None),
                 "kernel_ms_alone": k1_alone_ms, "period_ms": ms,
                 "avg_launch_ms_pipelined": k1_ms / max(nk1, 1), "overlap_ms": max(0.0, k1_per_pass_ms - ms),
                 "ms_per_pass_pipelined": k1_per_pass_ms,
@@ -656,10 +697,13 @@ def main():
                 # -> k1_valu_roofline.json: cycles per VALU instruction of this kernel's mix), times the VALU instructions the
                 # launch executed, over the SIMD cycles the launch had — both from the SAME committed PMC pass
                 # (SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), the kernel running alone on one stream
-                **valu_roofline(sq, kernels_ms.get("sketch_reads", {}).get("ms_per_pass")),
-                "ms_per_pass_alone": kernels_ms.get("sketch_reads", {}).get("ms_per_pass"),
+                **valu_roofline(sq, kernels_ms.get(k1_name, {}).get("ms_per_pass")),
+                "ms_per_pass_alone": kernels_ms.get(k1_name, {}).get("ms_per_pass"),
                 "valu_insts_per_pass": valu_insts,
-                "note": "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
+                "note": ("stage A by k-mer identity: one lane per read slides a 15-mer minimizer over its windows (no hash of a k-mer), one "
+                         "gate bit per run of windows, the runs that pass matched against their buckets; bound by integer VALU work and by "
+                         "random bit / entry look-ups, not by streamed bytes; " if by_kmer else "") +
+                        "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
                         "cycles per VALU instruction of this kernel's opcode mix / the SIMD cycles of the launch (GRBM_GUI_ACTIVE "
                         "/ 8 x 1024), all from the committed PMC pass of this workload, is the figure that describes it; achieved "
                         "/ frac = 158 B/read x reads / kernel_ms_alone (the kernel's own duration, HIP events, nothing else on the "
@@ -698,7 +742,7 @@ def main():
                                    % (cfg["name"], " [custom sizes]" if cfg["custom"] else "", nreads, cfg["genomes"],
                                       cfg["genome_len"], args.sketch_n, cfg["ks"], nrecs, w["ntax"]),
                        "baseline_config": cfg["config"],
-                       "stage_a_definition": w["definition"], "hash_mode": w["hash_mode"],
+                       "stage_a_definition": w["definition"], "hash_mode": w["hash_mode"], "stage_a_match": getattr(job, "match", None),
                        "stage_a_sketched_ks": out.get("sketched_ks"),
                        "parallelism": "reads + alignment records sharded x%d, read sketches and sketch tables sharded by hash range" % world},
             "roofline": roof,
@@ -715,7 +759,8 @@ def main():
         if knobs:
             res["config"]["knobs"] = knobs
         res["config"]["stage_a_tables"] = ("resident index of the genome table, %.1f GB in HBM" % (resident / 1e9)) if resident \
-            else "counting tables per pass + the table's membership filter"
+            else ("the index over the table's k-mers (minimizer gate, buckets of 32-byte entries) + one 32-bit counter per pair and pass"
+                  if by_kmer else "counting tables per pass + the table's membership filter")
         tr = job.traffic_per_pass() if hasattr(job, "traffic_per_pass") else None
         if tr:
             # what rank 0 hands to the other ranks per pass, by collective (nothing at world size 1: `sketch_entries` x 12 B is

@@ -75,7 +75,8 @@ int mg_device_count(void);
  * expected candidates: forces table overflows), resident_scan, no_fused, resident_ablate, flush_order (1: filter words first, 2: slots
  * first), no_avx2, gzip_threads, pgzip_chunk, pgzip_thp, pgzip_timing (the host inflater), stream_thin, stream_threads (the file
  * readers), inflate_trace, inflate_loose_find (the device inflater: a line per stage and hole on stderr; block starts by the format's
- * rules alone), shares_threads (mg_multimapped_shares: 1 = the serial loop, 2 / 4 / 8 host threads; 0 = by the list's length).
+ * rules alone), shares_threads (mg_multimapped_shares: 1 = the serial loop, 2 / 4 / 8 host threads; 0 = by the list's length),
+ * kc_wg_per_cu, kc_ablate (k_count_kmers: workgroups per CU; measurements only — 1: the minimizer runs are dropped, 2: ... after the gate).
  * Needs no device and no mg_init.  MG_ERR_ARG for a key that does not exist. */
 int mg_debug_set(const char* key, int64_t value);
 int64_t mg_debug_get(const char* key);
@@ -231,6 +232,12 @@ int mg_sketch_reads_multi_dev_async(const uint8_t* d_bases, const uint64_t* d_of
 typedef struct mg_sketch_stream mg_sketch_stream;
 int mg_sketch_stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters,
                            uint64_t expect_bases, mg_sketch_stream** out);
+/* mg_sketch_stream_begin_counts: the same stream of pieces COUNTED by k-mer identity into `kc` against `db`'s k-mer index
+ * (mg_count_kmers_dev per piece; mg_sketch_stream_finish then has nothing to return: nk = 0) — what lets
+ * mg_sketch_stream_add_file feed stage A by k-mer identity from a reads file.  db and kc outlive the stream. */
+struct mg_refdb;
+struct mg_kcounts;
+int mg_sketch_stream_begin_counts(const struct mg_refdb* db, struct mg_kcounts* kc, mg_sketch_stream** out);
 int mg_sketch_stream_add_dev(mg_sketch_stream* ss, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
                              uint64_t nbases);
 int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format, uint64_t offset, uint64_t length,

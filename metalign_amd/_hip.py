@@ -34,7 +34,7 @@ EXPORTS = [
     "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_drop_resident", "mg_filter_use_resident", "mg_filter_resident_bytes", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
-    "mg_sketch_stream_begin", "mg_sketch_stream_add_dev", "mg_sketch_stream_add_file", "mg_sketch_stream_finish", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases", "mg_sketch_stream_free",
+    "mg_sketch_stream_begin", "mg_sketch_stream_begin_counts", "mg_sketch_stream_add_dev", "mg_sketch_stream_add_file", "mg_sketch_stream_finish", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases", "mg_sketch_stream_free",
     "mg_reads_parse_dev", "mg_reads_parse_prefix_dev", "mg_reads_parse", "mg_reads_count", "mg_reads_nbases", "mg_reads_device_ptrs",
     "mg_reads_download", "mg_reads_free",
     "mg_acc_index_build", "mg_acc_index_free", "mg_sam_tokenize_dev", "mg_sam_tokenize", "mg_paf_tokenize_dev", "mg_paf_tokenize", "mg_sam_stream_file", "mg_sam_batch_count",
@@ -404,8 +404,14 @@ class SketchStream:
     """mg_sketch_stream_*: every piece of a sample is hashed into the SAME per-k counting tables; finish() gives the
     sketches (pending, like sketch_reads_multi_dev_async's) of the concatenated pieces."""
 
-    def __init__(self, hip, ks, hmaxs, s=0, filters=None, expect_bases=0):
+    def __init__(self, hip, ks, hmaxs, s=0, filters=None, expect_bases=0, counts=None):
         self.hip, self.ks = hip, [int(k) for k in ks]
+        if counts is not None:  # the pieces are counted by k-mer identity into a KmerCounts (mg_sketch_stream_begin_counts)
+            self.ks, self.filts, self.counts = [], [], counts
+            h = _vp()
+            hip._chk(hip.lib.mg_sketch_stream_begin_counts(counts.table.handle, counts.handle, ctypes.byref(h)))
+            self.handle = h
+            return
         nk = len(self.ks)
         self.filts = list(filters) if filters is not None else [None] * nk
         c_ks = (ctypes.c_int * nk)(*self.ks)
@@ -441,6 +447,8 @@ class SketchStream:
 
     def finish(self):
         nk = len(self.ks)
+        if nk == 0:
+            return []
         c_out = (_vp * nk)()
         self.hip._chk(self.hip.lib.mg_sketch_stream_finish(self.handle, c_out))
         out = []
@@ -719,9 +727,13 @@ class KmerCounts:
 
     def stats(self):
         """-> dict(kmers, runs, passed, matches) of everything added since the last reset (synchronises)."""
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(12, np.uint64)  # (a clocks build of the library fills more words: wave-cycles / 64, tallies of the matching)
         self.hip._chk(self.hip.lib.mg_kcounts_stats(self.handle, _np(out, ctypes.c_uint64)))
-        return dict(kmers=int(out[0]), runs=int(out[1]), passed=int(out[2]), matches=int(out[3]))
+        st = dict(kmers=int(out[0]), runs=int(out[1]), passed=int(out[2]), matches=int(out[3]))
+        if out[6]:
+            st.update(clk_drain=int(out[4]) * 64, clk_hits=int(out[5]) * 64, clk_kernel=int(out[6]) * 64, entries_looked_at=int(out[7]),
+                      windows_scanned=int(out[8]), longest_lane_windows=int(out[9]), longest_lane_entries=int(out[10]), drains=int(out[11]))
+        return st
 
     def download(self):
         """u32[npairs]: min(occurrences of the pair's k-mer, cs)."""
@@ -1197,6 +1209,10 @@ class Hip:
     def sketch_stream(self, ks, hmaxs, s=0, filters=None, expect_bases=0):
         """A streamed read sketch: one set of counting tables for a sample that arrives in pieces (SketchStream)."""
         return SketchStream(self, ks, hmaxs, s, filters, expect_bases)
+
+    def count_stream(self, counts):
+        """The same stream of pieces (add_file / add_dev / add_reads) counted by k-mer identity into `counts` (a KmerCounts)."""
+        return SketchStream(self, [], [], counts=counts)
 
     def parse_reads_dev(self, d_text, nbytes, fmt):
         """As parse_reads, for text already resident in HBM."""

@@ -38,6 +38,10 @@ _OPTIONS = {
     'sketch_table': dict(default='AUTO', help='Genome sketch table directory (default: data/sketch_table).'),
     'min_count': dict(type=int, default=2, help='A read k-mer must occur this often to count (kmc -ci, default 2).'),
     'sketch_size': dict(type=int, default=0, help='Read sketch size per k; 0 keeps every hash up to the table maximum.'),
+    'kmer_match': dict(default='identity', choices=['identity', 'identity_only', 'hash'],
+                       help='A reference-pipeline sketch table: a read k-mer meets a sketched one by what it IS, as kmc and kmc_tools '
+                            'intersect compare k-mers (default; falls back to "hash" where it does not apply: a table without its '
+                            'k-mers, a largest k below 15, several ranks) or by its MurmurHash3 value.'),
     'device_multimap': dict(action='store_true', help='Resolve multimapped reads on the GPU (their lists never leave '
                             'the device; abundances equal the default path to ~1e-15 relative, not byte for byte).'),
 }
@@ -52,14 +56,14 @@ _TOOLS = {
         options=['cutoff', 'db_dir', 'dbinfo_in', 'keep_temp_files', ('input_type', _READ_TYPES), 'length_normalize',
                  'low_mem', 'min_abundance', 'no_quantify_unmapped', 'output', 'pct_id', 'precise', 'rank_renormalize',
                  'read_cutoff', 'sampleID', 'sensitive', 'strain_level', 'temp_dir', 'threads', 'verbose',
-                 'sketch_table', 'min_count', 'sketch_size', 'device_multimap']),
+                 'sketch_table', 'min_count', 'sketch_size', 'kmer_match', 'device_multimap']),
     'select_db': dict(
         description='Run CMash and select a subset of the whole database to align to.',
         positionals=[('reads', dict(help='Reads file (FASTA / FASTQ, optionally .gz).')),
                      ('data', dict(help='data/ directory (db_info.txt, organism_files/, sketch_table/).'))],
         options=['cmash_results', 'cutoff', ('db', 'AUTO', 'Subset database FASTA to write (default: temp_dir/cmashed_db.fna).'),
                  'db_dir', 'dbinfo_in', 'dbinfo_out', ('input_type', _READ_TYPES), 'keep_temp_files', 'strain_level',
-                 'temp_dir', 'threads', 'sketch_table', 'min_count', 'sketch_size']),
+                 'temp_dir', 'threads', 'sketch_table', 'min_count', 'sketch_size', 'kmer_match']),
     'map_and_profile': dict(
         description='Compute abundance estimations for species in a sample.',
         positionals=[('infiles', dict(nargs='+', help='SAM file(s), or reads file(s) to align with minimap2.')),

@@ -351,7 +351,8 @@ namespace mg {
 struct KmerIndex {
   int k = 0;
   uint64_t ndistinct = 0, nbuckets = 0;
-  unsigned bshift = 0;   // bucket of a minimizer = key >> bshift
+  uint32_t maxkey = 0;   // the largest minimizer of the table (the gate and a sample's "done" bits are read up to it)
+  uint32_t bmask = 0;    // bucket of a minimizer = key & bmask (its LOW bits: a minimum's high bits are nearly all zero)
   DevBuf gate;           // 2^30 bits over the minimizer values
   DevBuf offs;           // u32[nbuckets + 1]
   DevBuf ent;            // KcEntry[ndistinct], ascending by minimizer

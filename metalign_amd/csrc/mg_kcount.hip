@@ -58,7 +58,7 @@ __global__ void k_kc_distinct(const uint64_t* __restrict__ hi, const uint64_t* _
     dhi[id] = hi[j];
     dlo[id] = lo[j];
     dhead[id] = order[j];
-    dkey[id] = kc_minimizer(x, k);
+    dkey[id] = kc_minimizer(x, k);  // (the caller turns it into the sort key: bucket above the minimizer)
     iota[id] = (uint32_t)id;
   }
 }
@@ -66,7 +66,11 @@ __global__ void k_kc_pair_heads(const uint32_t* __restrict__ order, const uint32
                                 const uint32_t* __restrict__ dhead, uint64_t n, uint32_t* __restrict__ head) {
   KC_FOR(j, n) head[order[j]] = dhead[before[j] + flag[j] - 1];
 }
-// entry j = distinct k-mer perm[j] (ascending by minimizer); its gate bit
+// the sort key of a distinct k-mer: its bucket (the minimizer's low bits) above the minimizer itself
+__global__ void k_kc_bucket_keys(uint64_t* __restrict__ dkey, uint64_t nd, uint32_t bmask) {
+  KC_FOR(i, nd) dkey[i] = ((dkey[i] & bmask) << 32) | dkey[i];
+}
+// entry j = distinct k-mer perm[j] (ascending by bucket, then minimizer); its gate bit
 __global__ void k_kc_entries(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ dhi,
                              const uint64_t* __restrict__ dlo, const uint32_t* __restrict__ dhead, uint64_t nd, int k,
                              KcEntry* __restrict__ ent, uint32_t* __restrict__ gate) {
@@ -76,20 +80,25 @@ __global__ void k_kc_entries(const uint64_t* __restrict__ skey, const uint32_t* 
     KcEntry e;
     e.w[0] = (uint32_t)(h >> 32); e.w[1] = (uint32_t)h; e.w[2] = (uint32_t)(l >> 32); e.w[3] = (uint32_t)l;
     e.head = dhead[id];
-    e.key = (uint32_t)skey[j];
+    e.key = (uint32_t)skey[j];  // (the low word of the sort key: the minimizer)
     e.sig_rc = kc_revcomp(KcWin{{e.w[0], e.w[1], e.w[2], e.w[3]}}, k).w[0];
     e.pad = 0;
     ent[j] = e;
     atomicOr(&gate[e.key >> 5], 1u << (e.key & 31u));
   }
 }
-// offs[b] = first entry whose key >> shift is >= b; offs[nb] = nd
-__global__ void k_kc_offsets(const uint64_t* __restrict__ skey, uint64_t nd, unsigned shift, uint64_t nb, uint32_t* __restrict__ offs) {
+// offs[b] = first entry whose bucket (the high word of its sort key) is >= b; offs[nb] = nd
+__global__ void k_kc_offsets(const uint64_t* __restrict__ skey, uint64_t nd, uint64_t nb, uint32_t* __restrict__ offs) {
   KC_FOR(j, nd + 1) {
-    const uint64_t first = j == 0 ? 0 : (skey[j - 1] >> shift) + 1;
-    const uint64_t last = j == nd ? nb : (skey[j] >> shift);
+    const uint64_t first = j == 0 ? 0 : (skey[j - 1] >> 32) + 1;
+    const uint64_t last = j == nd ? nb : (skey[j] >> 32);
     for (uint64_t b = first; b <= last; ++b) offs[b] = (uint32_t)j;
   }
+}
+__global__ void k_kc_max_key(const uint64_t* __restrict__ dkey, uint64_t nd, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  KC_FOR(i, nd) m = (uint32_t)dkey[i] > m ? (uint32_t)dkey[i] : m;
+  if (m) atomicMax(out, m);
 }
 __global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ head, uint64_t n, uint32_t cs,
                               uint32_t* __restrict__ out) {
@@ -102,21 +111,29 @@ __global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_
 // ---------------------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kKcWaves = 4;              // wavefronts per workgroup (each works alone)
-constexpr uint32_t kKcListCap = 12;      // closed runs a lane can hold before the lists are emptied (150 bp, k = 51: six per read)
+#ifndef MG_KC_WAVES  // (A/B builds: tools/kcount_variants.sh)
+#define MG_KC_WAVES 4
+#endif
+#ifndef MG_KC_LIST_CAP
+#define MG_KC_LIST_CAP 12
+#endif
+constexpr int kKcWaves = MG_KC_WAVES;    // wavefronts per workgroup (each works alone)
+constexpr uint32_t kKcListCap = MG_KC_LIST_CAP;  // closed runs a lane can hold before the lists are emptied (150 bp, k = 51: six per read)
 constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for a full batch
 constexpr uint32_t kKcSlack = 8;         // dwords a k-mer taken at the end of the stream may read past it
 
 // LDS of one wavefront (bytes), for a stage of sd dwords (sd a multiple of 64)
 struct KcLds {
-  uint32_t fwd, inv, p0s, lists, hitq, total;
+  uint32_t fwd, inv, p0s, stat, lists, hitq, scanq, total;
   __host__ __device__ explicit KcLds(uint32_t sd) {
     fwd = 0;
     inv = fwd + 4u * (sd + kKcSlack);
     p0s = inv + 4u * (sd / 2 + kKcSlack);
-    lists = p0s + 4u * 64u;
+    stat = p0s + 4u * 64u;  // [0] runs, [1] runs past the gate, [2] matches of this wavefront so far; MG_KC_CLOCKS: [4..7] cycles / 64
+    lists = stat + 4u * 12u;
     hitq = lists + 8u * 64u * (kKcListCap + 1u);
-    total = hitq + 8u * kKcHitCap;
+    scanq = hitq + 8u * kKcHitCap;
+    total = scanq + 8u * kKcHitCap;
   }
 };
 
@@ -128,8 +145,9 @@ struct KcArgs {
   const uint32_t* offs;
   const KcEntry* ent;
   uint32_t* counts;
-  unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the gate, [3] matches
-  uint32_t bshift, sd;
+  uint32_t* done;
+  unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the gate (and not done), [3] matches counted
+  uint32_t maxkey, bmask, sd, cs, ablate, stagger;  // ablate (knob kc_ablate, measurements only): 1 = the lists are dropped, 2 = ... after the gate
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -149,24 +167,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef MG_KC_WAVES_PER_EU
 #define MG_KC_WAVES_PER_EU 3
 #endif
-// A batch of runs that passed the gate, one per lane, against their buckets.
-__device__ __forceinline__ uint32_t kc_hits(const KcIndexView& ix, const MG_LDS unsigned long long* q, uint32_t n, const MG_LDS uint32_t* fwd,
-                                            const MG_LDS uint32_t* inv, const MG_LDS uint32_t* p0s, int k, bool bad, int lane) {
-  uint32_t found = 0;
-  if ((uint32_t)lane < n) {
-    const unsigned long long ev = q[lane];
-    const uint32_t key = (uint32_t)ev, info = (uint32_t)(ev >> 32);
-    const uint32_t p0 = p0s[info >> 20], i1 = info & 1023u, i2 = (info >> 10) & 1023u;
-    found = bad ? kc_match_run<true>(ix, fwd, inv, k, key, p0, i1, i2) : kc_match_run<false>(ix, fwd, inv, k, key, p0, i1, i2);
-  }
-  return found;
-}
 
-// The lists of a wavefront: every closed run through the gate; the ones that pass are compacted and matched 64 at a time.
-// One copy of this code per kernel, CALLED from the walk's unrolled steps (cfg: bshift | k << 8 | bad << 16).
-__device__ __attribute__((noinline)) void kc_drain(const uint32_t* gate, const uint32_t* offs, const KcEntry* ent, uint32_t* counts,
-                                                   unsigned long long* stats, uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt,
-                                                   uint32_t limit) {
+// The lists of a wavefront, in three phases that each keep all 64 lanes on one kind of work and wait for memory ONCE per batch:
+//   gate    every closed run's minimizer against the table's gate bit and the sample's "done" bit (both bitmaps are hot in a
+//           few MB: minimizers are minima, the keys that occur sit in the lowest few per cent of the key space); the runs that
+//           pass are compacted (ballot + popcount) into `hitq`;
+//   lookup  64 runs at a time: the bucket's bounds, then (minimizer, head) of up to four entries per lane and round trip, then
+//           the counters of those with the run's minimizer — an entry whose counter is below the saturation value becomes an
+//           ITEM (run, entry) in `scanq`; a run all of whose entries are saturated marks its minimizer done: at a metagenome's
+//           coverage nine runs in ten of an abundant genome stop at the gate from then on;
+//   scan    64 items at a time: kc_scan_run (registers only).
+// One copy of this code per translation unit, CALLED where nothing of the walk is live
+// (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
+__device__ __attribute__((noinline)) void kc_drain(const MG_GLB uint32_t* gate, const MG_GLB uint32_t* offs, const MG_GLB KcEntry* ent,
+                                                   MG_GLB uint32_t* counts, MG_GLB uint32_t* done, uint32_t maxkey, uint32_t cfg, uint32_t lds,
+                                                   uint32_t sd, uint32_t cnt, uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
   const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
@@ -174,53 +189,143 @@ __device__ __attribute__((noinline)) void kc_drain(const uint32_t* gate, const u
   const MG_LDS uint32_t* p0s = (const MG_LDS uint32_t*)(size_t)(lds + L.p0s);
   const MG_LDS unsigned long long* lists = (const MG_LDS unsigned long long*)(size_t)(lds + L.lists);
   MG_LDS unsigned long long* hitq = (MG_LDS unsigned long long*)(size_t)(lds + L.hitq);
-  const KcIndexView ix{gate, offs, ent, counts, cfg & 0xffu};
+  MG_LDS unsigned long long* scanq = (MG_LDS unsigned long long*)(size_t)(lds + L.scanq);
+  MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
+  const uint32_t ablate = (cfg >> 17) & 7u;
+  const KcIndexView ix{gate, offs, ent, counts, done, (1u << (cfg & 0xffu)) - 1u, maxkey, cfg >> 20, ablate};
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
+  if (ablate == 1u) return;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t hn = 0, sn = 0, nev = 0, npass = 0, found = 0;
+#ifdef MG_KC_CLOCKS
+  const uint64_t clk0 = __builtin_readcyclecounter();
+  uint64_t clk_hits = 0;
+#endif
+
+  auto scan_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
+    if ((uint32_t)lane < n) {
+      const unsigned long long it = q[lane];
+      const uint32_t info = (uint32_t)it;
+      const KcEntry E = kc_load_entry(ix.ent, (uint32_t)(it >> 32));
+      const uint32_t p0 = p0s[(info >> 20) & 63u], i1 = info & 1023u, i2 = (info >> 10) & 1023u;
+      found += bad ? kc_scan_run<true>(ix, fwd, inv, k, E, p0, i1, i2) : kc_scan_run<false>(ix, fwd, inv, k, E, p0, i1, i2);
+    }
+  };
+
+  auto lookup_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
+    const bool active = (uint32_t)lane < n;
+    uint32_t key = kKcNone, info = 0, lo = 0, hi = 0;
+    if (active) {
+      const unsigned long long ev = q[lane];
+      key = (uint32_t)ev;
+      info = (uint32_t)(ev >> 32);
+      const uint32_t b = key & ix.bmask;
+      lo = ix.offs[b];
+      hi = ix.offs[b + 1];
+    }
+    bool allsat = ix.cs != 0u;
+    for (uint32_t base = 0; __ballot(lo + base < hi) != 0ull; base += 4) {
+      uint32_t eh[4], ek[4], c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t idx = lo + base + (uint32_t)j;
+        eh[j] = 0; ek[j] = ~key;
+        if (idx < hi) kc_load_head_key(ix.ent, idx, eh[j], ek[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = (ek[j] == key && ix.cs) ? ix.counts[eh[j]] : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool unsat = ek[j] == key && !(ix.cs && c[j] >= ix.cs);
+        allsat = allsat && !unsat;
+        const unsigned long long m = __ballot(unsat && ablate != 3u);
+        if (m == 0ull) continue;
+        if (unsat) scanq[sn + (uint32_t)__popcll(m & below)] = (unsigned long long)info | ((unsigned long long)(lo + base + (uint32_t)j) << 32);
+        sn += (uint32_t)__popcll(m);
+        if (sn >= 64u) {
+          wave_lds_sync();
+          sn -= 64u;
+          scan_batch(scanq + sn, 64u);
+          wave_lds_sync();
+        }
+      }
+    }
+    if (active && allsat) MG_KC_OR(&ix.done[key >> 5], 1u << (key & 31u));
+  };
+
   const uint32_t maxc = wave_max_u32(cnt);
-  uint32_t hn = 0, nev = 0, npass = 0, found = 0;
+  const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
   for (uint32_t s0 = 0; s0 < maxc; s0 += 4) {
     unsigned long long ev[4];
-    uint32_t gw[4];
+    uint32_t gw[4], dw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ev[j] = (unsigned long long)kKcNone;
       if (s0 + j < cnt) ev[j] = lists[(s0 + j) * 64u + (uint32_t)lane];
-      // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
-      const uint32_t info = (uint32_t)(ev[j] >> 32), i1 = info & 1023u, i2 = (info >> 10) & 1023u;
-      if (i1 >= limit) ev[j] = (unsigned long long)kKcNone;
-      else if (i2 >= limit) ev[j] = (ev[j] & ~(1023ull << 42)) | ((unsigned long long)(limit - 1u) << 42);
+      if (clip) {  // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
+        const uint32_t info = (uint32_t)(ev[j] >> 32), i1 = info & 1023u, i2 = (info >> 10) & 1023u;
+        if (i1 >= limit) ev[j] = (unsigned long long)kKcNone;
+        else if (i2 >= limit) ev[j] = (ev[j] & ~(1023ull << 42)) | ((unsigned long long)(limit - 1u) << 42);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gw[j] = (uint32_t)ev[j] != kKcNone ? gate[(uint32_t)ev[j] >> 5] : 0u;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t key = (uint32_t)ev[j];
+      const bool on = key <= maxkey;  // (kKcNone is above every key)
+      gw[j] = on ? gate[key >> 5] : 0u;
+      dw[j] = on ? done[key >> 5] : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      nev += (uint32_t)ev[j] != kKcNone ? 1u : 0u;
-      const bool pass = (gw[j] >> ((uint32_t)ev[j] & 31u)) & 1u;  // (gw = 0 for no event)
+      const uint32_t key = (uint32_t)ev[j];
+      nev += key != kKcNone ? 1u : 0u;
+      const bool pass = ((gw[j] & ~dw[j]) >> (key & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
       if (m == 0ull) continue;
-      if (pass) hitq[hn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ev[j] | ((unsigned long long)lane << 52);
+      if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = ev[j] | ((unsigned long long)lane << 52);
       hn += (uint32_t)__popcll(m);
       npass += pass ? 1u : 0u;
-      if (hn >= 64u) {
+      if (hn >= 64u && ablate != 2u) {
         wave_lds_sync();
         hn -= 64u;
-        found += kc_hits(ix, hitq + hn, 64u, fwd, inv, p0s, k, bad, lane);
+#ifdef MG_KC_CLOCKS
+        const uint64_t h0 = __builtin_readcyclecounter();
+#endif
+        lookup_batch(hitq + hn, 64u);
+#ifdef MG_KC_CLOCKS
+        clk_hits += __builtin_readcyclecounter() - h0;
+#endif
         wave_lds_sync();
+      } else if (hn >= 64u) {
+        hn -= 64u;
       }
     }
   }
-  if (hn) {
+  if (ablate != 2u) {
+#ifdef MG_KC_CLOCKS
+    const uint64_t h0 = __builtin_readcyclecounter();
+#endif
+    if (hn) {
+      wave_lds_sync();
+      lookup_batch(hitq, hn);
+    }
+    if (sn) {
+      wave_lds_sync();
+      scan_batch(scanq, sn);
+    }
     wave_lds_sync();
-    found += kc_hits(ix, hitq, hn, fwd, inv, p0s, k, bad, lane);
-    wave_lds_sync();
+#ifdef MG_KC_CLOCKS
+    clk_hits += __builtin_readcyclecounter() - h0;
+#endif
   }
+  // (the wavefront's totals stay in LDS until the kernel ends: an atomic per call on three global words that every wavefront
+  // shares was most of the kernel's time — 31 k calls per 2M reads, each queueing behind the others at the memory side)
   nev = wave_sum_u32(nev); npass = wave_sum_u32(npass); found = wave_sum_u32(found);
-  if (lane == 0) {
-    if (nev) atomicAdd(stats + 1, (unsigned long long)nev);
-    if (npass) atomicAdd(stats + 2, (unsigned long long)npass);
-    if (found) atomicAdd(stats + 3, (unsigned long long)found);
-  }
+  if (lane == 0) { stat[0] += nev; stat[1] += npass; stat[2] += found; }
+#ifdef MG_KC_CLOCKS
+  if (lane == 0) { stat[4] += (uint32_t)((__builtin_readcyclecounter() - clk0) >> 6); stat[5] += (uint32_t)(clk_hits >> 6); stat[11] += 1; }
+#endif
 }
 
 // what kc_walk writes through
@@ -230,15 +335,16 @@ struct KcDevOut {
   const uint32_t* offs;
   const KcEntry* ent;
   uint32_t* counts;
-  unsigned long long* stats;
-  uint32_t cfg, lds, sd;
+  uint32_t* done;
+  uint32_t maxkey, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t key, uint32_t info) { mine[slot * 64u] = (unsigned long long)key | ((unsigned long long)info << 32); }
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
 #ifdef MG_KC_NO_DRAIN  // (ISA inspection: what the walks need by themselves)
     return;
 #endif
     wave_lds_sync();
-    kc_drain(gate, offs, ent, counts, stats, cfg, lds, sd, cnt, limit);
+    kc_drain((const MG_GLB uint32_t*)gate, (const MG_GLB uint32_t*)offs, (const MG_GLB KcEntry*)ent, (MG_GLB uint32_t*)counts,
+             (MG_GLB uint32_t*)done, maxkey, cfg, lds, sd, cnt, limit);
     wave_lds_sync();
   }
   static constexpr uint32_t kCap = kKcListCap;
@@ -266,7 +372,7 @@ __device__ __forceinline__ void kc_tile(const MG_LDS uint32_t* fwd, const MG_LDS
     if (mode == 0) w0 = kc_walk<K, 0>(fwd, inv, p0, len, maxlen, w0, out, cnt);
     else if (mode == 1) w0 = kc_walk<K, 1>(fwd, inv, p0, len, maxlen, w0, out, cnt);
     else w0 = kc_walk<K, 2>(fwd, inv, p0, len, maxlen, w0, out, cnt);
-    out.drain(cnt, w0);
+    out.drain(cnt, w0 < nwmax ? w0 : 1024u);
   } while (w0 < nwmax);
 }
 
@@ -282,13 +388,37 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
   MG_LDS uint16_t* inv16 = (MG_LDS uint16_t*)(base + L.inv);
   MG_LDS uint32_t* p0s = (MG_LDS uint32_t*)(base + L.p0s);
   MG_LDS unsigned long long* lists = (MG_LDS unsigned long long*)(base + L.lists);
-  const uint32_t cfg0 = (a.bshift & 0xffu) | ((uint32_t)K << 8);
+  MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(base + L.stat);
+  const uint32_t cfg0 = (uint32_t)__builtin_popcount(a.bmask) | ((uint32_t)K << 8) | ((a.ablate & 7u) << 17) | ((a.cs > 4095u ? 0u : a.cs) << 20);
   uint32_t kmers = 0;
+  if (lane < 12) stat[lane] = 0;
+  wave_lds_sync();
+  // The wavefronts of a SIMD start together and every tile costs them the same: left alone they walk at the same time (the
+  // vector units busy, memory idle) and empty their lists at the same time (the reverse).  Each waits, once, for its slot's share
+  // of a tile's duration: from then on one of them probes while the others walk.
+  if (a.stagger) {
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4) % 3u;  // HW_ID.WAVE_ID: the wavefront's slot on its SIMD
+    for (uint32_t i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#ifdef MG_KC_CLOCKS
+  const uint64_t kclk0 = __builtin_readcyclecounter();
+#endif
   const uint64_t ntiles = (a.nreads + 63) / 64;
-  for (uint64_t tile = (uint64_t)blockIdx.x * kKcWaves + wave; tile < ntiles; tile += (uint64_t)gridDim.x * kKcWaves) {
+  // (a tile's offsets are requested while the tile before it is walked: two round trips to memory less at the head of every tile)
+  const uint64_t tstep = (uint64_t)gridDim.x * kKcWaves;
+  uint64_t nbeg = 0, nend = 0;
+  {
+    const uint64_t rd0 = ((uint64_t)blockIdx.x * kKcWaves + wave) * 64 + lane;
+    if (rd0 < a.nreads) { nbeg = a.offsets[rd0]; nend = a.offsets[rd0 + 1]; }
+  }
+  for (uint64_t tile = (uint64_t)blockIdx.x * kKcWaves + wave; tile < ntiles; tile += tstep) {
     const uint64_t rd = tile * 64 + lane;
-    uint64_t beg = 0, end = 0;
-    if (rd < a.nreads) { beg = a.offsets[rd]; end = a.offsets[rd + 1]; }
+    const uint64_t beg = nbeg, end = nend;
+    {
+      const uint64_t rdn = (tile + tstep) * 64 + lane;
+      nbeg = nend = 0;
+      if (rdn < a.nreads) { nbeg = a.offsets[rdn]; nend = a.offsets[rdn + 1]; }
+    }
     const uint64_t len64 = end - beg;
     const uint64_t maxlen64 = wave_max_u64(len64);
     const uint64_t t_beg = __shfl(beg, 0, 64);
@@ -303,12 +433,25 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t nd = (uint32_t)((nbytes + 15) / 16);
       const uint4* g = reinterpret_cast<const uint4*>(a0);
       uint32_t notbase = 0;
-      for (uint32_t i = lane; i < nd; i += 64) {
-        const uint4 v = g[i];
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-        uint32_t nb;
-        fwd[i] = kc_pack16(vv, nb);
-        notbase |= nb;
+      // (six loads in flight per lane, then their packing: as a plain loop every 16 bytes were a round trip of their own, eleven per
+      // tile of 150 bp reads — most of what a wavefront waited for)
+      for (uint32_t i0 = lane; i0 < nd; i0 += 64 * 6) {
+        uint4 v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const uint32_t i = i0 + 64u * (uint32_t)j;
+          v[j] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+          if (i < nd) v[j] = g[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const uint32_t i = i0 + 64u * (uint32_t)j;
+          const uint32_t vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+          uint32_t nb;
+          const uint32_t packed = kc_pack16(vv, nb);
+          if (i < nd) fwd[i] = packed;
+          notbase |= nb;
+        }
       }
       const bool bad = __ballot(notbase != 0) != 0ull;
       if (bad) {  // (rare: N runs, the slop of the neighbouring tiles at a buffer's edge) the same bytes again, for the bit per base
@@ -325,7 +468,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t p0 = rd < a.nreads ? (uint32_t)(shift + (beg - t_beg)) : 0u;  // (a lane without a read walks the tile's first bases, masked)
       p0s[lane] = p0;
       wave_lds_sync();
-      KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.stats, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
+      KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.done, a.maxkey, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
       kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
@@ -361,7 +504,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
           inv16[gidx ^ 1u] = (uint16_t)kc_notbase16(vv);
         }
         wave_lds_sync();
-        KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.stats, cfg0 | (1u << 16), lds, a.sd};
+        KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.done, a.maxkey, cfg0 | (1u << 16), lds, a.sd};
         const uint32_t cmax = wave_max_u32(clen);
         kmers += kc_clean_windows(inv, p0, clen, cmax, K);
         kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
@@ -369,7 +512,14 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
     }
   }
   const uint64_t total = wave_sum_u64((uint64_t)kmers);
+  wave_lds_sync();
   if (lane == 0 && total) atomicAdd(a.stats, (unsigned long long)total);
+  if (lane >= 1 && lane < 4 && stat[lane - 1]) atomicAdd(a.stats + lane, (unsigned long long)stat[lane - 1]);
+#ifdef MG_KC_CLOCKS
+  if (lane == 0) stat[6] = (uint32_t)((__builtin_readcyclecounter() - kclk0) >> 6);
+  wave_lds_sync();
+  if (lane >= 4 && lane < 12) atomicAdd(a.stats + lane, (unsigned long long)stat[lane]);
+#endif
 }
 
 template <int K>
@@ -396,8 +546,9 @@ int dispatch_kc(int k, const KcArgs& a, unsigned grid, size_t lds, hipStream_t s
 
 struct mg_kcounts {
   mg::DevBuf counts;  // u32[npairs + 1]
+  mg::DevBuf done;    // bits over the minimizer values up to the table's largest: every k-mer of this minimizer is saturated
   mg::DevBuf stats;   // u64[4]
-  uint64_t n = 0;
+  uint64_t n = 0, done_words = 0;
 };
 
 using namespace mg;
@@ -423,8 +574,8 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
   if (n && !db->kmer_hi.p) return fail(MG_ERR_STATE, "the table does not hold its k-mers: pass them (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64)");
   std::unique_ptr<KmerIndex> ix(new KmerIndex());
   ix->k = k;
-  MG_TRY(ix->gate.alloc((1ull << 30) / 8));
-  MG_HIP(hipMemsetAsync(ix->gate.p, 0, (1ull << 30) / 8, st));
+  MG_TRY(ix->gate.alloc((1ull << 30) / 8));  // (only the words up to the largest minimizer are ever read: they are what is zeroed)
+
   MG_TRY(ix->head.alloc((n + 1) * 4));
   DevBuf chi, clo, iota, ord1, ord2, s_lo, s_hi, g_hi, flag, before, dhi, dlo, dhead, dkey, skey, perm;
   uint64_t nd = 0;
@@ -449,20 +600,31 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
     hipLaunchKernelGGL(k_kc_pair_heads, dim3(g256(n)), dim3(256), 0, st, ord2.as<uint32_t>(), flag.as<uint32_t>(), before.as<uint64_t>(),
                        dhead.as<uint32_t>(), n, ix->head.as<uint32_t>());
     MG_HIP(hipGetLastError());
-    MG_TRY(sort_pairs(dkey.as<uint64_t>(), skey.as<uint64_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), nd));
   }
   ix->ndistinct = nd;
   unsigned bb = 8;  // log2(buckets): about one k-mer per bucket
   while (bb < 28 && (1ull << bb) < nd) ++bb;
-  ix->bshift = 30 - bb;
+  ix->bmask = (1u << bb) - 1u;
   ix->nbuckets = 1ull << bb;
+  if (nd) {
+    uint32_t* d_max = (uint32_t*)scratch("kc_maxkey", 64);
+    if (!d_max) return MG_ERR_NOMEM;
+    MG_HIP(hipMemsetAsync(d_max, 0, 4, st));
+    hipLaunchKernelGGL(k_kc_max_key, dim3(g256(nd)), dim3(256), 0, st, dkey.as<uint64_t>(), nd, d_max);
+    uint64_t* pin = host_words();
+    MG_HIP(hipMemcpyAsync(pin + 12, d_max, 4, hipMemcpyDeviceToHost, st));
+    MG_HIP(hipStreamSynchronize(st));
+    ix->maxkey = (uint32_t)pin[12];
+    MG_HIP(hipMemsetAsync(ix->gate.p, 0, (((uint64_t)ix->maxkey >> 5) + 1) * 4, st));
+    hipLaunchKernelGGL(k_kc_bucket_keys, dim3(g256(nd)), dim3(256), 0, st, dkey.as<uint64_t>(), nd, ix->bmask);
+    MG_TRY(sort_pairs(dkey.as<uint64_t>(), skey.as<uint64_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), nd));
+  }
   MG_TRY(ix->offs.alloc((ix->nbuckets + 2) * 4));
   MG_TRY(ix->ent.alloc((nd + 1) * sizeof(KcEntry)));
   if (nd) {
     hipLaunchKernelGGL(k_kc_entries, dim3(g256(nd)), dim3(256), 0, st, skey.as<uint64_t>(), perm.as<uint32_t>(), dhi.as<uint64_t>(),
                        dlo.as<uint64_t>(), dhead.as<uint32_t>(), nd, k, ix->ent.as<KcEntry>(), ix->gate.as<uint32_t>());
-    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(nd + 1)), dim3(256), 0, st, skey.as<uint64_t>(), nd, ix->bshift, ix->nbuckets,
-                       ix->offs.as<uint32_t>());
+    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(nd + 1)), dim3(256), 0, st, skey.as<uint64_t>(), nd, ix->nbuckets, ix->offs.as<uint32_t>());
   } else {
     MG_HIP(hipMemsetAsync(ix->offs.p, 0, (ix->nbuckets + 2) * 4, st));
   }
@@ -488,10 +650,13 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
   if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
   std::unique_ptr<mg_kcounts> kc(new mg_kcounts());
   kc->n = db->kmax.total;
+  kc->done_words = ((uint64_t)db->kidx->maxkey >> 5) + 1;
   MG_TRY(kc->counts.alloc((kc->n + 1) * 4));
-  MG_TRY(kc->stats.alloc(4 * 8));
+  MG_TRY(kc->done.alloc(kc->done_words * 4));
+  MG_TRY(kc->stats.alloc(12 * 8));
+  MG_HIP(hipMemsetAsync(kc->done.p, 0, kc->done_words * 4, ctx().stream));
   MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 4 * 8, ctx().stream));
+  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, ctx().stream));
   *out = kc.release();
   return MG_OK;
 }
@@ -499,8 +664,9 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
 int mg_kcounts_reset(mg_kcounts* kc) {
   MG_REQUIRE_READY();
   if (!kc) return fail(MG_ERR_ARG, "null argument");
+  MG_HIP(hipMemsetAsync(kc->done.p, 0, kc->done_words * 4, ctx().stream));
   MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 4 * 8, ctx().stream));
+  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, ctx().stream));
   return MG_OK;
 }
 
@@ -509,7 +675,8 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   MG_REQUIRE_READY();
   if (!db || !kc || (nreads && (!d_bases || !d_offsets))) return fail(MG_ERR_ARG, "null argument");
   if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
-  if (kc->n != db->kmax.total) return fail(MG_ERR_ARG, "these counters belong to another table");
+  if (kc->n != db->kmax.total || kc->done_words != ((uint64_t)db->kidx->maxkey >> 5) + 1)
+    return fail(MG_ERR_ARG, "these counters belong to another table");
   if (nreads == 0) return MG_OK;
   Context& c = ctx();
   const KmerIndex& ix = *db->kidx;
@@ -530,7 +697,7 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   const uint64_t ntiles = (nreads + 63) / 64;
   const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
   KcArgs a{d_bases, d_offsets, nreads, ix.gate.as<uint32_t>(), ix.offs.as<uint32_t>(), ix.ent.as<KcEntry>(), kc->counts.as<uint32_t>(),
-           kc->stats.as<unsigned long long>(), ix.bshift, (uint32_t)sd};
+           kc->done.as<uint32_t>(), kc->stats.as<unsigned long long>(), ix.maxkey, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
   ProfScope ps("count_kmers");
   MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
   MG_HIP(hipGetLastError());
@@ -540,7 +707,11 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
 int mg_kcounts_stats(const mg_kcounts* kc, uint64_t* out4) {
   MG_REQUIRE_READY();
   if (!kc || !out4) return fail(MG_ERR_ARG, "null argument");
+#ifdef MG_KC_CLOCKS  // (a build for tools/kcount_clocks.sh: four more words — wave-cycles / 64 in the drain, its matching part, the kernel)
+  return mg_memcpy_d2h(out4, kc->stats.p, 12 * 8);
+#else
   return mg_memcpy_d2h(out4, kc->stats.p, 4 * 8);
+#endif
 }
 
 int mg_kcounts_download(const mg_kcounts* kc, const mg_refdb* db, uint32_t* per_pair) {

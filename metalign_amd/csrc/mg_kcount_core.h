@@ -25,11 +25,13 @@
 
 #ifdef MG_HOST_CHECK
 #define MG_LDS
+#define MG_GLB
 #define MG_HD static inline
 #define MG_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define MG_LDS __attribute__((address_space(3)))
+#define MG_GLB __attribute__((address_space(1)))  // device memory, said in the type: a generic pointer into a CALLED function is a FLAT access
 #define MG_HD __device__ __forceinline__
 #define MG_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  // the same in every lane: say so (an SGPR, scalar branches)
 #endif
@@ -326,14 +328,38 @@ MG_HD uint32_t kc_clean_windows(const MG_LDS uint32_t* inv, uint32_t p0, uint32_
 
 // ---- a run against the table -------------------------------------------------------------------------------------------
 struct KcIndexView {
-  const uint32_t* gate;   // 2^30 bits: bit `key` set <=> some table k-mer has this minimizer
-  const uint32_t* offs;   // [buckets + 1]: entries of bucket b = key >> bshift are ent[offs[b] .. offs[b + 1])
-  const KcEntry* ent;     // ascending by key
-  uint32_t* counts;       // [npairs]: occurrences, at the entry's `head`
-  uint32_t bshift;
+  const MG_GLB uint32_t* gate;   // bit `key` set <=> some table k-mer has this minimizer (keys above maxkey: no bit)
+  const MG_GLB uint32_t* offs;   // [buckets + 1]: entries of bucket b = key & bmask are ent[offs[b] .. offs[b + 1])
+  const MG_GLB KcEntry* ent;     // ascending by (bucket, key)
+  MG_GLB uint32_t* counts;       // [npairs]: occurrences, at the entry's `head`
+  MG_GLB uint32_t* done;         // per sample: bit `key` set <=> every table k-mer with this minimizer has been seen at its saturation value
+  uint32_t bmask;         // buckets - 1: the LOW bits of a minimizer (minimizers are minima: their high bits are nearly all zero)
+  uint32_t maxkey;        // the largest minimizer of the table
+  uint32_t cs;            // counters are read as min(counter, cs) (kmc -cs<cs>; 0: exact): one seen at cs is left alone
+  uint32_t ablate;        // measurements only (knob kc_ablate): 3 = no run is scanned; 4 = signatures only; 5 = no count
 };
 
-MG_HD bool kc_gate(const uint32_t* gate, uint32_t key) { return (gate[key >> 5] >> (key & 31u)) & 1u; }
+// an entry / its (head, minimizer) pair out of device memory (class types do not copy out of a qualified address space: as vectors)
+#ifdef MG_HOST_CHECK
+MG_HD KcEntry kc_load_entry(const KcEntry* ent, uint32_t e) { return ent[e]; }
+MG_HD void kc_load_head_key(const KcEntry* ent, uint32_t e, uint32_t& head, uint32_t& key) { head = ent[e].head; key = ent[e].key; }
+#else
+typedef uint32_t kc_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t kc_u32x2 __attribute__((ext_vector_type(2)));
+MG_HD KcEntry kc_load_entry(const MG_GLB KcEntry* ent, uint32_t e) {
+  const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ent + e);
+  const kc_u32x4 a = p[0], b = p[1];
+  return KcEntry{{a.x, a.y, a.z, a.w}, b.x, b.y, b.z, b.w};
+}
+MG_HD void kc_load_head_key(const MG_GLB KcEntry* ent, uint32_t e, uint32_t& head, uint32_t& key) {
+  const kc_u32x2 v = *reinterpret_cast<const MG_GLB kc_u32x2*>(&ent[e].head);  // (side by side: one 8-byte load)
+  head = v.x; key = v.y;
+}
+#endif
+
+MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) {
+  return key <= ix.maxkey && ((ix.gate[key >> 5] >> (key & 31u)) & 1u) && !((ix.done[key >> 5] >> (key & 31u)) & 1u);
+}
 
 // no "not a base" bit in [p, p + k)
 MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
@@ -347,36 +373,83 @@ MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
 
 #ifdef MG_HOST_CHECK
 #define MG_KC_COUNT(ptr) (++*(ptr))
+#define MG_KC_OR(ptr, v) (*(ptr) |= (v))
 #else
-#define MG_KC_COUNT(ptr) atomicAdd((ptr), 1u)
+#define MG_KC_COUNT(ptr) __hip_atomic_fetch_add((ptr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MG_KC_OR(ptr, v) __hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
-// The windows [i1, i2] of the read that starts at stream position p0 share the minimizer `key`, and the gate has it: every
-// table k-mer with that minimizer against every window.  Returns the matches.
+// One table k-mer E against the windows [i1, i2] of the read that starts at stream position p0 (a run that shares E's
+// minimizer).  What every window is tested by is its first sixteen bases against E's two signatures: the bases those tests need
+// — the run's windows begin within w <= 50 bases: 2 (k - 15) + 32 bits, NS dwords — are taken into registers ONCE and shifted
+// along two bits per window; the loop touches neither LDS nor memory (re-reading the stream per window was a dependent LDS
+// round trip each, and the lanes of a batch wait for the longest run).  Only a signature hit — a match, or one window in
+// 2^31 — reads the window's k-mer from the stream and settles it (the reverse strand computed, not read).  Returns the matches.
+template <bool BAD, int NS>
+MG_HD uint32_t kc_scan_run_n(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, const KcEntry& E,
+                             uint32_t p0, uint32_t i1, uint32_t i2) {
+  static_assert(NS >= 2 && NS <= 5, "2 (k - 15) + 32 bits for k <= 64");
+  const uint32_t p = p0 + i1, d = p >> 4, sh = (p & 15u) << 1;
+  uint32_t w[NS];
+  {
+    uint32_t a[NS + 1];
+#pragma unroll
+    for (int j = 0; j < NS + 1; ++j) a[j] = fwd[d + j];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) w[j] = (uint32_t)(((((uint64_t)a[j]) << 32 | a[j + 1]) << sh) >> 32);
+  }
+  const uint32_t sigmask = kc_keep_mask(k, 0);
+  uint32_t found = 0;
+  for (uint32_t i = i1; i <= i2; ++i) {
+    const uint32_t x0 = w[0] & sigmask;
+    if ((x0 == E.w[0] || x0 == E.sig_rc) && ix.ablate != 4u) {
+      bool ok = true;
+      if constexpr (BAD) ok = kc_window_clean(inv, p0 + i, k);
+      if (ok) {
+        const KcWin x = kc_ext128(fwd, p0 + i, k), y = kc_revcomp(x, k);
+        const KcWin c = kc_less(y, x) ? y : x;
+        if (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) {
+          // A counter seen at its saturation value is left alone (counters only grow: a stale look can only cost an add that
+          // changes nothing); exact counters stop far below a 32-bit wrap.
+          if (ix.ablate != 5u && ix.counts[E.head] < (ix.cs ? ix.cs : 0x7fffff00u)) MG_KC_COUNT(&ix.counts[E.head]);
+          ++found;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j) w[j] = (w[j] << 2) | (w[j + 1] >> 30);
+    w[NS - 1] <<= 2;
+  }
+  return found;
+}
+template <bool BAD>
+MG_HD uint32_t kc_scan_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, const KcEntry& E,
+                           uint32_t p0, uint32_t i1, uint32_t i2) {
+  const int bits = 2 * (k - kKcM) + 32;  // the signatures of a run's windows: from the first base of the first to the sixteenth of the last
+  if (bits <= 64) return kc_scan_run_n<BAD, 2>(ix, fwd, inv, k, E, p0, i1, i2);
+  if (bits <= 96) return kc_scan_run_n<BAD, 3>(ix, fwd, inv, k, E, p0, i1, i2);
+  if (bits <= 128) return kc_scan_run_n<BAD, 4>(ix, fwd, inv, k, E, p0, i1, i2);
+  return kc_scan_run_n<BAD, 5>(ix, fwd, inv, k, E, p0, i1, i2);
+}
+
+// A run past the gate against its bucket, one lane on its own (the host check, and the statement of what the kernel's batched
+// phases — mg_kcount.hip: kc_drain — compute): every entry with the run's minimizer whose counter is not saturated is scanned;
+// when all of them are saturated the minimizer is marked done for the rest of the sample.
 template <bool BAD>
 MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, uint32_t key,
                             uint32_t p0, uint32_t i1, uint32_t i2) {
-  const uint32_t b = key >> ix.bshift;
+  const uint32_t b = key & ix.bmask;
   const uint32_t lo = ix.offs[b], hi = ix.offs[b + 1];
-  const uint32_t sigmask = kc_keep_mask(k, 0);
   uint32_t found = 0;
+  bool allsat = ix.cs != 0u;
   for (uint32_t e = lo; e < hi; ++e) {
-    const KcEntry E = ix.ent[e];
+    const KcEntry E = kc_load_entry(ix.ent, e);
     if (E.key != key) continue;
-    for (uint32_t i = i1; i <= i2; ++i) {
-      const uint32_t p = p0 + i;
-      const uint32_t x0 = kc_ext32(fwd, p) & sigmask;
-      if (x0 != E.w[0] && x0 != E.sig_rc) continue;
-      if constexpr (BAD) { if (!kc_window_clean(inv, p, k)) continue; }
-      const KcWin x = kc_ext128(fwd, p, k), y = kc_revcomp(x, k);
-      const KcWin c = kc_less(y, x) ? y : x;
-      if (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) {
-        // (a k-mer that fills a sample could wrap a 32-bit counter: stop far above any saturation value)
-        if (ix.counts[E.head] < 0x7fffff00u) MG_KC_COUNT(&ix.counts[E.head]);
-        ++found;
-      }
-    }
+    if (ix.cs && ix.counts[E.head] >= ix.cs) continue;
+    allsat = false;
+    found += kc_scan_run<BAD>(ix, fwd, inv, k, E, p0, i1, i2);
   }
+  if (allsat) MG_KC_OR(&ix.done[key >> 5], 1u << (key & 31u));
   return found;
 }
 

@@ -1134,6 +1134,9 @@ struct mg_sketch_stream {
   unsigned long long* t_counters[4] = {nullptr, nullptr, nullptr, nullptr};
   bool fused = false;
   uint64_t nreads = 0, nbases = 0, expect_bases = 0;
+  // mg_sketch_stream_begin_counts: the pieces are not sketched but COUNTED, by k-mer identity, into these (mg_kcount.hip)
+  const mg_refdb* count_db = nullptr;
+  mg_kcounts* count_kc = nullptr;
 };
 
 static unsigned stage_bytes_for(uint64_t nbases, uint64_t nreads) {
@@ -1197,6 +1200,12 @@ static int stream_add(mg_sketch_stream* ss, const uint8_t* d_bases, const uint64
     MG_TRY(plan_reads(d_offsets, nreads, ctx().stream, rp));
     nbases = rp.nbases;
   }
+  if (ss->count_kc) {
+    MG_TRY(mg_count_kmers_dev(d_bases, d_offsets, nreads, nbases, ss->count_db, ss->count_kc));
+    ss->nreads += nreads;
+    ss->nbases += nbases;
+    return MG_OK;
+  }
   const unsigned stage = stage_bytes_for(nbases, nreads);
   if (ss->fused) {
     MultiKTable tabs[4];
@@ -1247,6 +1256,15 @@ extern "C" {
 int mg_sketch_stream_begin(int nk, const int* ks, const uint64_t* hmaxs, uint64_t s, const mg_filter* const* filters,
                            uint64_t expect_bases, mg_sketch_stream** out) {
   return stream_begin(nk, ks, hmaxs, s, filters, expect_bases, out);
+}
+int mg_sketch_stream_begin_counts(const mg_refdb* db, mg_kcounts* kc, mg_sketch_stream** out) {
+  MG_REQUIRE_READY();
+  if (!db || !kc || !out) return fail(MG_ERR_ARG, "null argument");
+  std::unique_ptr<mg_sketch_stream> ss(new mg_sketch_stream());
+  ss->count_db = db;
+  ss->count_kc = kc;
+  *out = ss.release();
+  return MG_OK;
 }
 int mg_sketch_stream_add_dev(mg_sketch_stream* ss, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads,
                              uint64_t nbases) {

@@ -91,6 +91,24 @@ class _CudaView:
                                          "version": 2, "strides": None}
 
 
+class _KmerSketch:
+    """What stage A BY K-MER IDENTITY leaves for stage B (the reference pipeline's default since round 6): one sample's
+    occurrence counters of the table's k_max-mers (_hip.KmerCounts) instead of a sketch of hashes.  Quacks like a _hip.Sketch
+    where a pass touches it: nothing to settle, nothing that can overflow; freeing it hands the counters back to the engine."""
+
+    def __init__(self, engine, counts):
+        self.engine, self.counts = engine, counts
+        self.size = None  # (no sketch: ShardJob._results reports the matched pairs of the largest k in its place)
+
+    def resolve(self):
+        return False
+
+    def free(self):
+        if self.counts is not None:
+            self.engine._kc_free.append(self.counts)
+            self.counts = None
+
+
 class HipEngine:
     wg_per_cu_exchange = 3  # the hashing kernel's workgroups per CU beside the exchange chain (x_begin)
 
@@ -135,6 +153,11 @@ class HipEngine:
         self.h_hs = hip.pinned(2 * g * self.nk, np.uint32)
         self.h_acc = hip.pinned(3 * ntax + 2, np.uint64)
         self.filters += [None] * (self.nsk - len(self.filters))
+        # stage A by k-mer identity (ShardJob(match="kmer")): the counters of the passes in flight, handed out and taken back
+        self.kmer = reftable is not None and bool(getattr(self, "match_kmer", False))
+        self._kc_free = []
+        if self.kmer and not reftable.has_kmer_index:
+            raise _hip.HipError("the reference-pipeline table has no k-mer index (RefTable.index_kmers)")
 
     # ---- stage A ----
     def set_filter(self, ki, table_hashes):
@@ -231,7 +254,13 @@ class HipEngine:
                 f.drop_resident()
 
     def sketch_local_async(self, ks, hmaxs, s):
-        """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set)."""
+        """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set).
+        match = "kmer": the reads' k_max-mers counted against the table's by identity instead (one launch, no sync)."""
+        if getattr(self, "kmer", False):
+            kc = self._kc_free.pop() if self._kc_free else self.reftable.kmer_counts()
+            kc.reset()
+            kc.add_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, int(self.d_rb.count))
+            return [_KmerSketch(self, kc)]
         return self.hip.sketch_reads_multi_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, ks, hmaxs, s,
                                                      self.filters[: len(ks)])
 
@@ -266,6 +295,11 @@ class HipEngine:
         if getattr(self, "reftable", None) is not None:
             ptrs = [self._hs_ptrs(base_ptr, ki) for ki in range(self.nk)]
             hook = getattr(self, "mark_exchange", None)
+            if isinstance(sks[0], _KmerSketch):
+                if hook is not None:
+                    raise _hip.HipError("stage A by k-mer identity has no multi-rank exchange yet: ShardJob(match='hash') for a sharded table")
+                self.hip.refpipe_containment_counts_dev(sks[0].counts, self.reftable, ci, [p[0] for p in ptrs], [p[1] for p in ptrs])
+                return
             if hook is None:
                 self.hip.refpipe_containment_dev(sks[0], self.reftable, ci, [p[0] for p in ptrs], [p[1] for p in ptrs])
                 return
@@ -649,12 +683,15 @@ class ShardJob:
     """One rank's share of a sample and the collective choreography around it."""
 
     def __init__(self, hip, dist, rank, world, k, ci=2, pct_id=0.5, s=0, engine=None, always_exchange=False,
-                 definition="sketch_per_k"):
+                 definition="sketch_per_k", match=None):
         """k: one k-mer size or a sequence of them (ascending; the reference's cutoff reads the largest).
         definition: "sketch_per_k" — every k has a genome table of its own and the reads are sketched at every k; or
         "reference_pipeline" — stage A/B wired as scripts/select_db.py:50-59,73-76 wires KMC and CMash: the reads are sketched
         at the LARGEST k only and every smaller k's column comes from the k-prefixes of the matched k_max-mers (load() then
-        takes the reference pipeline's table: include/metalign_hip.h, mg_refdb)."""
+        takes the reference pipeline's table: include/metalign_hip.h, mg_refdb).
+        match (the reference pipeline): how a read k_max-mer meets a sketched one — "kmer": by what it IS, as `kmc` +
+        `kmc_tools intersect` do (scripts/select_db.py:50-59; mg_kcount.hip: no hash on the read side; k_max >= 15, one shard);
+        "hash": by its MurmurHash3 value (rounds 4-5; any k, any world size); None: "kmer" where it applies."""
         self.dist, self.rank, self.world = dist, rank, world
         # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
         self.exchange = dist is not None and (world > 1 or always_exchange)
@@ -668,6 +705,12 @@ class ShardJob:
         if self.refpipe and s:
             raise ValueError("the reference pipeline counts every k_max-mer of the reads: no bottom-s sketch (s = %d)" % s)
         self.sks_k = [self.ks[-1]] if self.refpipe else self.ks  # the k the READS are sketched at
+        if match not in (None, "kmer", "hash"):
+            raise ValueError("match is 'kmer' or 'hash', not %r" % (match,))
+        can_kmer = self.refpipe and not self.exchange and 15 <= self.ks[-1] <= 64 and engine is None
+        if match == "kmer" and not can_kmer:
+            raise ValueError("match='kmer' needs the reference pipeline, one shard and 15 <= k_max <= 64")
+        self.match = "kmer" if (match in (None, "kmer") and can_kmer) else ("hash" if self.refpipe else None)
         self.ci, self.pct_id, self.s = ci, pct_id, s
         if engine is not None:
             self.engine = engine
@@ -763,6 +806,7 @@ class ShardJob:
             self.nonempty = [len(recs) > 0]
         if self.refpipe:
             self.engine.mark_exchange = self._or_marks if self.exchange else None
+            self.engine.match_kmer = self.match == "kmer"
             self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, [], reftable=reftable)
         else:
             self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
@@ -817,6 +861,18 @@ class ShardJob:
         self.nprefix = [int(t["nprefix"]) for t in small_all]
         # word-aligned prefix cuts per smaller k: rank r counts prefixes [32 * cut[r], 32 * cut[r + 1])
         self.mark_cuts = [[((npre + 31) // 32) * r // W for r in range(W)] + [(npre + 31) // 32] for npre in self.nprefix]
+        if self.match == "kmer":
+            # no filter, no resident index: the read side hashes nothing.  The index over the table's k-mers (built once, on the
+            # device) from the k-mers a table built here holds, or from the stored ones
+            if reftable is None:
+                if full.get("kmer_hi") is None:
+                    raise ValueError("match='kmer' needs the table's k-mers (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64); "
+                                     "this table has none: ShardJob(match='hash')")
+                reftable = eng.hip.refdb_upload(self.ks, self.G, ph, full["pair_gen"], full["gsize"], hmax, small_all)
+                reftable.index_kmers(full["kmer_hi"], full["kmer_lo"])
+            elif not reftable.has_kmer_index:
+                reftable.index_kmers()
+            return reftable
         if hasattr(eng, "set_filter"):
             bits = src.filter_bits(self.ks[-1]) if disk else None
             if hasattr(eng, "wants_resident_index") and eng.wants_resident_index(hmax, len(ph)):
@@ -1129,7 +1185,7 @@ class ShardJob:
     def _pack_out(self, hits, sizes, count, bases, first, scalars, qn, mm):
         out = dict(hits_k=hits, sizes_k=sizes, hits=hits[-1], sizes=sizes[-1], count=count, bases=bases, first_seen=first,
                    tot_rds=int(scalars[0]), n_ambig=int(scalars[1]), sketch_sizes=qn, sketch_size=qn[-1], multimapped=mm,
-                   ks=list(self.ks), sketched_ks=list(self.sks_k), definition=self.definition)
+                   ks=list(self.ks), sketched_ks=list(self.sks_k), definition=self.definition, match=getattr(self, "match", None))
         ci_vals = hits / np.maximum(sizes, 1)
         out["containment_k"] = ci_vals
         out["containment"] = ci_vals[-1]  # the largest k: the column the cutoff reads (select_db.py:85-86)
@@ -1265,11 +1321,12 @@ class ShardJob:
 
     def _results(self, sks, hits, sizes, committed):
         """Sample-wide results from this rank's stage B counts and stage C accumulators (the all-reduce when sharded)."""
-        qn = [sk.size for sk in sks]
-        for sk in sks:
-            sk.free()
         count, bases, first, scalars, mm = committed
         hits, sizes = np.asarray(hits), np.asarray(sizes)
+        # (stage A by k-mer identity leaves no sketch: the matched pairs of the largest k stand in its place)
+        qn = [sk.size if sk.size is not None else int(hits[-1].sum()) for sk in sks]
+        for sk in sks:
+            sk.free()
         if self.exchange:
             t, dist = self.torch, self.dist
             buf = np.zeros(self._red_layout()[-1], dtype=np.int64)

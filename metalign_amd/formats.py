@@ -173,8 +173,17 @@ class SketchTable:
             if len(pa) != len(ph) or len(pb) != len(ph) or len(cid) != len(cgen) or len(gk) != self.ngenomes:
                 raise ValueError("sketch table %s, k = %d: the reference-pipeline files do not belong together" % (self.path, k))
             small.append(dict(pa=pa, pb=pb, cid=cid, cgen=cgen, gsize=gk, nprefix=npre))
-        return dict(ks=list(self.ks), ngenomes=self.ngenomes, pair_hash=ph, pair_gen=pg, gsize=gs,
-                    max_hash=self.max_hash(kmax), small=small)
+        out = dict(ks=list(self.ks), ngenomes=self.ngenomes, pair_hash=ph, pair_gen=pg, gsize=gs,
+                   max_hash=self.max_hash(kmax), small=small)
+        # the sketched k_max-mers themselves, in pair order (what stage A by k-mer identity indexes; absent from tables written
+        # without them)
+        if os.path.exists(self._f(kmax, "kmer_hi.u64")) and os.path.exists(self._f(kmax, "kmer_lo.u64")):
+            khi = np.memmap(self._f(kmax, "kmer_hi.u64"), dtype="<u8", mode="r") if len(ph) else np.zeros(0, np.uint64)
+            klo = np.memmap(self._f(kmax, "kmer_lo.u64"), dtype="<u8", mode="r") if len(ph) else np.zeros(0, np.uint64)
+            if len(khi) != len(ph) or len(klo) != len(ph):
+                raise ValueError("sketch table %s, k = %d: the k-mer files do not belong to the pair list" % (self.path, kmax))
+            out.update(kmer_hi=khi, kmer_lo=klo)
+        return out
 
     def filter_bits(self, k):
         """The stored membership pre-filter of k (None for a table without one)."""

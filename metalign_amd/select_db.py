@@ -514,6 +514,8 @@ def _run_sketch_steps(args, hip, table, t_start):
         if s:
             sys.exit('Error: a reference-pipeline sketch table counts every k_max-mer of the reads; --sketch_size does not apply.')
         arrays = table.refpipe_arrays()
+        if kmer_match_applies(args, table, arrays):
+            return _run_count_steps(args, hip, table, arrays, t_start)
         # (the table goes up BESIDE the reads: the library's uploader threads copy the memory maps through page-locked slots of their
         # own while the stream below runs — 450 MB at 10k genomes, 20 ms of select_main that used to come first; stage B waits for it)
         reftable = hip.refdb_upload(arrays['ks'], arrays['ngenomes'], arrays['pair_hash'], arrays['pair_gen'], arrays['gsize'],
@@ -573,6 +575,67 @@ def _run_sketch_steps(args, hip, table, t_start):
                 per_k.append(np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0))
     for h in sks + filts + dev_tables + ([reftable] if reftable is not None else []):
         h.free()
+    out = args.temp_dir + 'cmash_query_results.csv'
+    write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
+    run_timings['containment_s'] = time.perf_counter() - t_start
+    return out
+
+
+def kmer_match_applies(args, table, arrays):
+    """Stage A BY K-MER IDENTITY (mg_kcount.hip; the default): the reads' k_max-mers are counted among the table's as `kmc` +
+    `kmc_tools intersect` do it (:50-59) — as k-mers, nothing on the read side hashed.  Needs the table's k-mers (format 3 stores
+    them) and 15 <= k_max <= 64; `--kmer_match hash` keeps the read sketch of rounds 4-5."""
+    want = str(getattr(args, 'kmer_match', 'identity'))
+    if want == 'hash':
+        return False
+    ok = arrays.get('kmer_hi') is not None and 15 <= table.ks[-1] <= 64
+    if not ok and want == 'identity_only':
+        sys.exit('Error: --kmer_match identity_only needs a reference-pipeline table that stores its k-mers, with the largest k in [15, 64].')
+    return ok
+
+
+def _run_count_steps(args, hip, table, arrays, t_start):
+    """run_sketch_steps for a reference-pipeline table, k-mers met by identity: table + its k-mer index up, the reads file
+    streamed through the device parser into ONE set of counters (no sketch, no merge of pieces), stage B from the counters."""
+    import time
+    min_count = int(getattr(args, 'min_count', 2))
+    reftable = hip.refdb_upload(arrays['ks'], arrays['ngenomes'], arrays['pair_hash'], arrays['pair_gen'], arrays['gsize'],
+                                arrays['max_hash'], arrays['small'], wait=False)
+    reftable.index_kmers(arrays['kmer_hi'], arrays['kmer_lo'])
+    counts = reftable.kmer_counts()
+    run_timings['table_load_s'] = time.perf_counter() - t_start
+    t_start = time.perf_counter()
+    kind = args.input_type
+    done = False
+    if os.environ.get('MG_NO_STREAM') != '1':
+        stream = hip.count_stream(counts)
+        try:
+            stream.add_file(args.reads, 'fastq' if kind == 'fastq' else 'fasta_ml', chunk_bytes=int(os.environ.get('MG_STREAM_CHUNK_BYTES', 0)))
+            done = True
+        except _hip.HipError as e:
+            # a record longer than a piece's headroom (capacity), or FASTA text the device parser refuses: the piece-wise path's
+            # host parser decides; a malformed FASTQ record is the caller's error, as on the whole-file path
+            if not (e.code == _hip.ERR_CAPACITY or (e.code == _hip.ERR_ARG and kind != 'fastq')):
+                raise
+            counts.reset()
+        finally:
+            stream.free()
+    if not done:
+        free, _, pooled = hip.mem_info()
+        batch_bytes = int(os.environ.get('MG_READ_BATCH_BYTES', 0)) or max((free + pooled) // 4, 1 << 26)
+        for reads in iter_read_batches(hip, args.reads, kind, batch_bytes):
+            counts.add_reads(reads)
+            hip.sync()  # (the batch's buffers go back to the pool below)
+            reads.free()
+    run_timings['stream_s'] = time.perf_counter() - t_start
+    t_start = time.perf_counter()
+    per_k = []
+    with np.errstate(divide='ignore', invalid='ignore'):
+        hits_k, sizes_k = hip.refpipe_containment_counts(counts, reftable, min_count)
+        for hits, sizes in zip(hits_k, sizes_k):
+            per_k.append(np.where(sizes > 0, hits.astype(np.float64) / sizes.astype(np.float64), 0.0))
+    counts.free()
+    reftable.free()
     out = args.temp_dir + 'cmash_query_results.csv'
     write_containment_csv(out, table.ks, containment_rows(table.names, per_k))
     run_timings['containment_s'] = time.perf_counter() - t_start

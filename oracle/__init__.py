@@ -269,6 +269,56 @@ def refpipe_count_kmers(bases, offsets, k, kmer_hi, kmer_lo, cs=DEFAULT_CS):
     return out[:e].copy(), int(seen.value)
 
 
+class KmerTable:
+    """The table's canonical k-mers as a look-up set, built once (mgo_kmer_table_new); count() may run on several threads at once
+    (ctypes releases the GIL), each call with counters of its own — bench.py's cpu_baseline."""
+
+    def __init__(self, kmer_hi, kmer_lo, k):
+        khi = np.ascontiguousarray(kmer_hi, dtype=np.uint64)
+        klo = np.ascontiguousarray(kmer_lo, dtype=np.uint64)
+        self.npairs, self.k = len(khi), int(k)
+        one = np.zeros(1, np.uint64)
+        lib().mgo_kmer_table_new.restype = ctypes.c_void_p
+        self.handle = ctypes.c_void_p(lib().mgo_kmer_table_new(_p(khi if self.npairs else one, ctypes.c_uint64),
+                                                               _p(klo if self.npairs else one, ctypes.c_uint64),
+                                                               ctypes.c_uint64(self.npairs), ctypes.c_int(self.k)))
+        if not self.handle:
+            raise MemoryError("mgo_kmer_table_new")
+
+    def count(self, bases, offsets):
+        """-> (uint64[npairs] exact occurrences, at the first pair of every k-mer; kmers_seen)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        cnt = np.zeros(max(self.npairs, 1), dtype=np.uint64)
+        seen = ctypes.c_uint64(0)
+        bptr = _p(bases, ctypes.c_uint8) if bases.size else ctypes.POINTER(ctypes.c_uint8)()
+        rc = lib().mgo_kmer_table_count(self.handle, bptr, _p(offsets, ctypes.c_uint64), ctypes.c_uint64(len(offsets) - 1),
+                                        _p(cnt, ctypes.c_uint64), ctypes.byref(seen))
+        if rc != 0:
+            raise RuntimeError("mgo_kmer_table_count rc=%d" % rc)
+        return cnt, int(seen.value)
+
+    def per_pair(self, counts, cs=DEFAULT_CS):
+        """counts: the sum of count()'s arrays over the sample's shares -> uint32[npairs]: min(occurrences of the pair's k-mer, cs)"""
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        out = np.zeros(max(self.npairs, 1), dtype=np.uint32)
+        rc = lib().mgo_kmer_table_per_pair(self.handle, _p(counts, ctypes.c_uint64), ctypes.c_uint32(int(cs)), _p(out, ctypes.c_uint32))
+        if rc != 0:
+            raise RuntimeError("mgo_kmer_table_per_pair rc=%d" % rc)
+        return out[: self.npairs].copy()
+
+    def free(self):
+        if self.handle:
+            lib().mgo_kmer_table_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def refpipe_containment_counts(counts, ci, table):
     """refpipe_containment with the matched pairs taken from per-pair occurrence counts (refpipe_count_kmers): counts >= ci."""
     ph, pg, g = table["pair_hash"], table["pair_gen"], table["ngenomes"]

@@ -616,13 +616,6 @@ int mgo_refpipe_hits_k(const uint8_t* matched, const uint32_t* pa, const uint32_
  * mgo_refpipe_matched (by hash value) gives the same pairs unless two different k-mers share a hash.  tests/indep_sketch.py:
  * refpipe_query states this on strings.  PARITY UNPINNED like the rest of stage A/B.
  * ---------------------------------------------------------------------- */
-typedef struct { uint64_t hi, lo; uint64_t idx; } kc_ent;
-static int cmp_kc_ent(const void* a, const void* b) {
-  const kc_ent* x = (const kc_ent*)a; const kc_ent* y = (const kc_ent*)b;
-  if (x->hi != y->hi) return x->hi < y->hi ? -1 : 1;
-  if (x->lo != y->lo) return x->lo < y->lo ? -1 : 1;
-  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
-}
 /* the smaller of codes c[0..k) and their reverse complement, packed */
 static void canonical_pack(const uint8_t* c, int k, uint64_t* hi, uint64_t* lo) {
   uint8_t r[MG_MAX_K];
@@ -630,20 +623,63 @@ static void canonical_pack(const uint8_t* c, int k, uint64_t* hi, uint64_t* lo) 
   pack_codes(memcmp(c, r, (size_t)k) <= 0 ? c : r, k, hi, lo);
 }
 
-int mgo_refpipe_count_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t nreads, int k, uint32_t cs,
-                            const uint64_t* khi, const uint64_t* klo, uint64_t npairs, uint32_t* out_counts,
-                            uint64_t* out_kmers_seen) {
-  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
-  kc_ent* t = (kc_ent*)malloc((npairs + 1) * sizeof(kc_ent));
-  uint64_t* cnt = (uint64_t*)calloc(npairs + 1, sizeof(uint64_t));   /* per position of the sorted table: the first of a group counts */
-  if (!t || !cnt) { free(t); free(cnt); return MG_ERR_NOMEM; }
-  for (uint64_t i = 0; i < npairs; ++i) {
+/* The table's canonical k-mers as a set one can look a k-mer up in — KMC's database of the sketches' k-mers
+ * (local_tests/retrain_and_test_metalign.sh:59-66).  An open-addressed table keyed by the packed canonical k-mer (the slot a
+ * key starts from is a function of the oracle's own choosing: it decides nothing but where to look); head[i] = the first pair
+ * that holds pair i's canonical k-mer — where that k-mer is counted.  Read-only once built: mgo_kmer_table_count may run on
+ * several threads at once, each with counters of its own (bench.py's cpu_baseline). */
+typedef struct mgo_kmer_table {
+  int k;
+  uint64_t npairs, nslots;
+  uint64_t* hi; uint64_t* lo;
+  uint32_t* slot_head;   /* 0xffffffff = empty */
+  uint32_t* head;        /* [npairs] */
+} mgo_kmer_table;
+
+static inline uint64_t kt_start(uint64_t hi, uint64_t lo, uint64_t mask) {
+  uint64_t x = lo * 0x9e3779b97f4a7c15ULL ^ (hi + 0x632be59bd9b4e019ULL) * 0xff51afd7ed558ccdULL;
+  x ^= x >> 29;
+  return x & mask;
+}
+
+void mgo_kmer_table_free(mgo_kmer_table* t) {
+  if (!t) return;
+  free(t->hi); free(t->lo); free(t->slot_head); free(t->head); free(t);
+}
+
+mgo_kmer_table* mgo_kmer_table_new(const uint64_t* khi, const uint64_t* klo, uint64_t npairs, int k) {
+  if (k < 1 || k > MG_MAX_K || npairs > 0xfffffff0ULL) return NULL;
+  mgo_kmer_table* t = (mgo_kmer_table*)calloc(1, sizeof(mgo_kmer_table));
+  if (!t) return NULL;
+  t->k = k; t->npairs = npairs;
+  t->nslots = 16;
+  while (t->nslots < 2 * npairs + 2) t->nslots <<= 1;
+  t->hi = (uint64_t*)malloc(t->nslots * sizeof(uint64_t));
+  t->lo = (uint64_t*)malloc(t->nslots * sizeof(uint64_t));
+  t->slot_head = (uint32_t*)malloc(t->nslots * sizeof(uint32_t));
+  t->head = (uint32_t*)malloc((npairs + 1) * sizeof(uint32_t));
+  if (!t->hi || !t->lo || !t->slot_head || !t->head) { mgo_kmer_table_free(t); return NULL; }
+  memset(t->slot_head, 0xff, t->nslots * sizeof(uint32_t));
+  const uint64_t mask = t->nslots - 1;
+  for (uint64_t i = 0; i < npairs; ++i) {   /* ascending i: the first pair of a k-mer claims its slot */
     uint8_t c[MG_MAX_K];
+    uint64_t hi, lo;
     unpack_codes(khi[i], klo[i], k, c);
-    canonical_pack(c, k, &t[i].hi, &t[i].lo);
-    t[i].idx = i;
+    canonical_pack(c, k, &hi, &lo);
+    uint64_t s = kt_start(hi, lo, mask);
+    while (t->slot_head[s] != 0xffffffffu && !(t->hi[s] == hi && t->lo[s] == lo)) s = (s + 1) & mask;
+    if (t->slot_head[s] == 0xffffffffu) { t->hi[s] = hi; t->lo[s] = lo; t->slot_head[s] = (uint32_t)i; }
+    t->head[i] = t->slot_head[s];
   }
-  if (npairs) qsort(t, npairs, sizeof(kc_ent), cmp_kc_ent);
+  return t;
+}
+
+/* counts[head] += occurrences among the reads' canonical k-mers (counts: uint64[npairs], the caller's, zeroed by it) */
+int mgo_kmer_table_count(const mgo_kmer_table* t, const uint8_t* bases, const uint64_t* offsets, uint64_t nreads, uint64_t* counts,
+                         uint64_t* out_kmers_seen) {
+  if (!t || !counts) return MG_ERR_ARG;
+  const int k = t->k;
+  const uint64_t mask = t->nslots - 1;
   uint64_t seen = 0;
   for (uint64_t r = 0; r < nreads; ++r) {
     const uint8_t* seq = bases + offsets[r];
@@ -655,28 +691,40 @@ int mgo_refpipe_count_kmers(const uint8_t* bases, const uint64_t* offsets, uint6
       ++seen;
       uint8_t c[MG_MAX_K];
       for (int u = 0; u < k; ++u) c[u] = (uint8_t)base_code(seq[j + 1 - (uint64_t)k + (uint64_t)u]);
-      kc_ent key;
-      canonical_pack(c, k, &key.hi, &key.lo);
-      uint64_t lo = 0, hi = npairs;   /* the first entry >= (key, idx 0) */
-      while (lo < hi) {
-        const uint64_t mid = lo + (hi - lo) / 2;
-        if (t[mid].hi < key.hi || (t[mid].hi == key.hi && t[mid].lo < key.lo)) lo = mid + 1; else hi = mid;
-      }
-      if (lo < npairs && t[lo].hi == key.hi && t[lo].lo == key.lo) ++cnt[lo];
+      uint64_t hi, lo;
+      canonical_pack(c, k, &hi, &lo);
+      uint64_t s = kt_start(hi, lo, mask);
+      while (t->slot_head[s] != 0xffffffffu && !(t->hi[s] == hi && t->lo[s] == lo)) s = (s + 1) & mask;
+      if (t->slot_head[s] != 0xffffffffu) ++counts[t->slot_head[s]];
     }
   }
-  for (uint64_t i = 0; i < npairs;) {
-    uint64_t j = i;
-    while (j < npairs && t[j].hi == t[i].hi && t[j].lo == t[i].lo) ++j;
-    uint64_t c = cnt[i];
-    if (cs && c > cs) c = cs;
-    if (c > 0xffffffffULL) c = 0xffffffffULL;
-    for (uint64_t e = i; e < j; ++e) out_counts[t[e].idx] = (uint32_t)c;
-    i = j;
-  }
   if (out_kmers_seen) *out_kmers_seen = seen;
-  free(t); free(cnt);
   return MG_OK;
+}
+
+/* per pair: min(occurrences of its k-mer, cs) (cs = 0: exact, clamped to 32 bits) */
+int mgo_kmer_table_per_pair(const mgo_kmer_table* t, const uint64_t* counts, uint32_t cs, uint32_t* out_counts) {
+  if (!t || !counts || !out_counts) return MG_ERR_ARG;
+  for (uint64_t i = 0; i < t->npairs; ++i) {
+    uint64_t c = counts[t->head[i]];
+    if (cs && c > cs) c = cs;
+    out_counts[i] = c > 0xffffffffULL ? 0xffffffffu : (uint32_t)c;
+  }
+  return MG_OK;
+}
+
+int mgo_refpipe_count_kmers(const uint8_t* bases, const uint64_t* offsets, uint64_t nreads, int k, uint32_t cs,
+                            const uint64_t* khi, const uint64_t* klo, uint64_t npairs, uint32_t* out_counts,
+                            uint64_t* out_kmers_seen) {
+  if (k < 1 || k > MG_MAX_K) return MG_ERR_ARG;
+  mgo_kmer_table* t = mgo_kmer_table_new(khi, klo, npairs, k);
+  uint64_t* cnt = (uint64_t*)calloc(npairs + 1, sizeof(uint64_t));
+  if (!t || !cnt) { mgo_kmer_table_free(t); free(cnt); return MG_ERR_NOMEM; }
+  int rc = mgo_kmer_table_count(t, bases, offsets, nreads, cnt, out_kmers_seen);
+  if (rc == MG_OK) rc = mgo_kmer_table_per_pair(t, cnt, cs, out_counts);
+  mgo_kmer_table_free(t);
+  free(cnt);
+  return rc;
 }
 
 /* Stage B.  See include/metalign_hip.h (mg_containment). */

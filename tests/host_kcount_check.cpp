@@ -5,9 +5,10 @@
 // the oracle (tests/test_kcount_core_host.py).  What is NOT covered here is the wavefront glue of mg_kcount.hip (LDS addresses,
 // ballots, the drain's batches, atomics): the GPU tests hold that to the same oracle.
 //
-// stdin:  "k cap ntable nreads lead\n", then ntable lines with a table k-mer each (ACGT, any strand), then nreads lines with a
+// stdin:  "k cap ntable nreads lead cs\n", then ntable lines with a table k-mer each (ACGT, any strand), then nreads lines with a
 //         read each (anything; may be empty).  cap = slots of a lane's event list (small values force restarts); lead = bytes
-//         in front of the first read in the buffer (the tile then starts off a 16-byte boundary).
+//         in front of the first read in the buffer (the tile then starts off a 16-byte boundary); cs = the counters' saturation
+//         value (0: exact counts; else a k-mer seen cs times is skipped from then on and its minimizer marked done).
 // stdout: one line per table k-mer: the number of windows of the reads whose canonical k-mer equals its canonical form;
 //         then "kmers N runs R passed P restarts S".
 #define MG_HOST_CHECK 1
@@ -25,6 +26,7 @@
 using namespace mg;
 
 static int g_cap = 12;
+static uint32_t g_cs = 0;  // counters saturate here (0: exact); > 0 exercises the "done" marks
 
 struct HostOut {
   static constexpr uint32_t kCap = 0;  // (not used: the capacity is a run-time value here, see below)
@@ -51,10 +53,10 @@ static KcWin win_from_string(const std::string& s) {
 }
 
 struct Index {
-  std::vector<uint32_t> gate, offs, counts;
+  std::vector<uint32_t> gate, offs, counts, done;
   std::vector<KcEntry> ent;
-  uint32_t bshift = 0;
-  KcIndexView view() { return KcIndexView{gate.data(), offs.data(), ent.data(), counts.data(), bshift}; }
+  uint32_t bmask = 0, maxkey = 0, cs = 0;
+  KcIndexView view() { return KcIndexView{gate.data(), offs.data(), ent.data(), counts.data(), done.data(), bmask, maxkey, cs, 0u}; }
 };
 
 template <int K, uint32_t CAP>
@@ -92,19 +94,24 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
     e.pad = 0;
     ix.ent.push_back(e);
   }
-  std::stable_sort(ix.ent.begin(), ix.ent.end(), [](const KcEntry& a, const KcEntry& b) { return a.key < b.key; });
   unsigned bb = 8;
   while (bb < 28 && (1ull << bb) < ix.ent.size()) ++bb;
-  ix.bshift = 30 - bb;
+  ix.bmask = (1u << bb) - 1u;
+  const uint32_t bm = ix.bmask;
+  std::stable_sort(ix.ent.begin(), ix.ent.end(), [bm](const KcEntry& a, const KcEntry& b) {
+    return (a.key & bm) != (b.key & bm) ? (a.key & bm) < (b.key & bm) : a.key < b.key;
+  });
   ix.offs.assign((1u << bb) + 2, 0u);
   {
     size_t j = 0;
     for (uint32_t b = 0; b <= (1u << bb); ++b) {
-      while (j < ix.ent.size() && (ix.ent[j].key >> ix.bshift) < b) ++j;
+      while (j < ix.ent.size() && (ix.ent[j].key & bm) < b) ++j;
       ix.offs[b] = (uint32_t)j;
     }
   }
-  for (auto& e : ix.ent) ix.gate[e.key >> 5] |= 1u << (e.key & 31u);
+  for (auto& e : ix.ent) { ix.gate[e.key >> 5] |= 1u << (e.key & 31u); ix.maxkey = std::max(ix.maxkey, e.key); }
+  ix.done.assign((ix.maxkey >> 5) + 1, 0u);
+  ix.cs = g_cs;
   const KcIndexView view = ix.view();
 
   // ---- the reads, one buffer, tiles of 64 ----
@@ -153,7 +160,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
             if (key == kKcNone || i1 >= next) continue;
             if (i2 >= next) i2 = next - 1;
             ++runs;
-            if (!kc_gate(view.gate, key)) continue;
+            if (!kc_gate(view, key)) continue;
             ++passed;
             if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
             else kc_match_run<false>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
@@ -227,7 +234,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
       }
     }
   }
-  for (size_t i = 0; i < table.size(); ++i) std::printf("%u\n", ix.counts[head[i]]);
+  for (size_t i = 0; i < table.size(); ++i) std::printf("%u\n", g_cs && ix.counts[head[i]] > g_cs ? g_cs : ix.counts[head[i]]);
   std::printf("kmers %llu runs %llu passed %llu restarts %llu\n", (unsigned long long)kmers, (unsigned long long)runs,
               (unsigned long long)passed, (unsigned long long)restarts);
 }
@@ -249,7 +256,9 @@ int main() {
   int k = 0, ntable = 0, nreads = 0, lead = 0;
   std::string line;
   std::getline(std::cin, line);
-  if (std::sscanf(line.c_str(), "%d %d %d %d %d", &k, &g_cap, &ntable, &nreads, &lead) != 5) return 2;
+  int cs = 0;
+  if (std::sscanf(line.c_str(), "%d %d %d %d %d %d", &k, &g_cap, &ntable, &nreads, &lead, &cs) != 6) return 2;
+  g_cs = (uint32_t)cs;
   std::vector<std::string> table(ntable), reads(nreads);
   for (auto& t : table) std::getline(std::cin, t);
   for (auto& r : reads) std::getline(std::cin, r);

@@ -168,11 +168,13 @@ def test_config2_full_size_properties(hip):
         assert np.array_equal(np.asarray(sharded[key]), np.asarray(res[key])), key
 
 
-@pytest.mark.parametrize("definition,mode", [("reference_pipeline", 0), ("reference_pipeline", 1), ("sketch_per_k", 0)])
-def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib, definition, mode):
+@pytest.mark.parametrize("definition,mode,match", [("reference_pipeline", 0, "kmer"), ("reference_pipeline", 0, "hash"),
+                                                   ("reference_pipeline", 1, "kmer"), ("sketch_per_k", 0, None)])
+def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib, definition, mode, match):
     """BASELINE.json configs[2] EXACTLY as bench.py runs it at N = 1 (bench.build_workload: 10M reads of 500 present 50 kb
     genomes among 10 000, K = {21,31,51}, 12.5M alignment records, 10 001 taxa), under the headline's definition of stage
-    A/B (the reference pipeline, hash mode 0) and the two bench.py reports beside it: ShardJob.step() — stage A, stage B
+    A/B (the reference pipeline, k-mers met by identity — match "kmer", against the oracle's mgo_kmer_table_* — or by hash value)
+    and the others bench.py reports beside it: ShardJob.step() — stage A, stage B
     with one column per k, stage C — on a >= 2M-read sample against the C oracle on every host core: hits and sizes of
     all 10 000 genomes for every k, count / bases / first_seen of every taxon, tot_rds, n_ambig.  (bench.py prints the
     same comparison as `check.oracle_equal`; here it is the driver's GPU test tier that holds it.)"""
@@ -182,7 +184,7 @@ def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib, definition
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    cfg = dict(bench.PRESETS[2], config=2, custom=False)
+    cfg = dict(bench.PRESETS[2], config=2, custom=False, match=match, definition=definition, hash_mode=mode)
     try:
         w = bench.build_workload(cfg, 1000, 0, hip, definition, mode)
         assert len(w["ro"]) - 1 == 10_000_000 and w["ntax"] == 10_001 and w["table_hashes"] == (1 if definition == "reference_pipeline" else 3) * 10_000_000
@@ -191,9 +193,10 @@ def test_the_benchmarked_workload_against_the_oracle(hip, oracle_lib, definition
         nsample = int(check["compared"].split("sample (")[1].split(" reads")[0])
         assert nsample >= 2_000_000 or nsample == 10_000_000, check["compared"]
         assert check["oracle_equal"], check["mismatch"]
-        assert (check["definition"], check["hash_mode"]) == (definition, mode)
+        assert (check["definition"], check["hash_mode"], check["match"]) == (definition, mode, match)
         # and the pipelined passes the benchmark times give the same sketches as single steps
         job = bench.make_job(hip, None, 0, 1, cfg, w)
+        assert job.match == match
         one = job.step()
         out = job.run(3)
         assert out["sketch_sizes"] == one["sketch_sizes"] and out["tot_rds"] == one["tot_rds"]
@@ -217,7 +220,8 @@ def test_the_reference_s_own_parameters_at_the_benchmarked_size(hip, oracle_lib,
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    cfg = dict(bench.PRESETS[2], config=2, custom=False, ks=list(bench.STOCK_KS), name=bench.STOCK_NAME)
+    cfg = dict(bench.PRESETS[2], config=2, custom=False, ks=list(bench.STOCK_KS), name=bench.STOCK_NAME, match="kmer" if mode == 0 else "hash",
+               definition="reference_pipeline", hash_mode=mode)
     try:
         w = bench.build_workload(cfg, 1000, 0, hip, "reference_pipeline", mode)
         assert len(w["ro"]) - 1 == 10_000_000 and w["table_hashes"] == 10_000_000
@@ -227,6 +231,7 @@ def test_the_reference_s_own_parameters_at_the_benchmarked_size(hip, oracle_lib,
         assert nsample >= 2_000_000 or nsample == 10_000_000, check["compared"]
         assert check["oracle_equal"], check["mismatch"]
         job = bench.make_job(hip, None, 0, 1, cfg, w)
+        assert job.match == cfg["match"] == check["match"]
         one = job.step()
         out = job.run(3)
         assert out["sketch_sizes"] == one["sketch_sizes"] and np.array_equal(out["hits_k"], one["hits_k"]) and out["hits_k"].shape == (4, 10_000)

@@ -90,12 +90,12 @@ def pack_table(table, k):
 
 
 @pytest.mark.parametrize("k", [15, 16, 17, 21, 31, 32, 33, 47, 51, 60, 63, 64])
-@pytest.mark.parametrize("kind,cap,lead", [("equal", 12, 0), ("ragged", 12, 5), ("ragged", 3, 0), ("long", 12, 3), ("equal", 3, 9)])
-def test_counts_equal_the_oracle(checker, k, kind, cap, lead):
+@pytest.mark.parametrize("kind,cap,lead,cs", [("equal", 12, 0, 0), ("ragged", 12, 5, 2), ("ragged", 3, 0, 0), ("long", 12, 3, 3), ("equal", 3, 9, 1)])
+def test_counts_equal_the_oracle(checker, k, kind, cap, lead, cs):
     oracle.build()
     rng = np.random.default_rng(1000 * k + cap + lead)
     table, reads = workload(rng, k, kind)
-    text = ("%d %d %d %d %d\n" % (k, cap, len(table), len(reads), lead)).encode() + b"".join(t + b"\n" for t in table) + \
+    text = ("%d %d %d %d %d %d\n" % (k, cap, len(table), len(reads), lead, cs)).encode() + b"".join(t + b"\n" for t in table) + \
         b"".join(r + b"\n" for r in reads)
     out = subprocess.run([checker], input=text, capture_output=True, check=True).stdout.decode().split("\n")
     got = np.array([int(x) for x in out[:len(table)]], dtype=np.uint32)
@@ -104,7 +104,7 @@ def test_counts_equal_the_oracle(checker, k, kind, cap, lead):
     offs = np.zeros(len(reads) + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(r) for r in reads])
     khi, klo = pack_table(table, k)
-    want, seen = oracle.refpipe_count_kmers(bases, offs, k, khi, klo, cs=0)
+    want, seen = oracle.refpipe_count_kmers(bases, offs, k, khi, klo, cs=cs)
     assert int(tail[1]) == seen, "k-mers of the reads"
     assert np.array_equal(got, want), "counts differ at %s" % np.flatnonzero(got != want)[:10]
     assert want.sum() > 0

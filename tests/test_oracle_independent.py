@@ -236,6 +236,26 @@ def test_reference_pipeline_c_oracle_equals_the_string_restatement(oracle_lib, h
         # the largest k's column is the plain containment of the k_max table
         ph_hits, ph_sizes = oracle_lib.containment(qh, qc, False, ci, h, o)
         assert np.array_equal(hits[-1], ph_hits) and np.array_equal(sizes[-1], ph_sizes)
+        # stage A BY K-MER IDENTITY (mgo_refpipe_count_kmers: what kmc + kmc_tools intersect compute, no hash on the read side):
+        # the same columns — and, per sketched k-mer, the string restatement's own count of the reads' canonical k-mers
+        counts, seen = oracle_lib.refpipe_count_kmers(rb, ro, kmax, table["kmer_hi"], table["kmer_lo"], cs=0)
+        khits, ksizes = oracle_lib.refpipe_containment_counts(counts, ci, table)
+        assert np.array_equal(khits, hits) and np.array_equal(ksizes, sizes)
+        if ci == 1:
+            occ = {}
+            for r in reads:
+                for m in ind._RUNS.finditer(r):
+                    run = m.group().upper()
+                    for i in range(len(run) - kmax + 1):
+                        x = run[i:i + kmax]
+                        c = min(x, ind._revcomp(x))
+                        occ[c] = occ.get(c, 0) + 1
+            assert seen == sum(occ.values())
+            for i in rng.integers(0, len(counts), size=min(300, len(counts))):
+                y = _unpack(table["kmer_hi"][i], table["kmer_lo"][i], kmax)
+                assert int(counts[i]) == occ.get(min(y, ind._revcomp(y)), 0)
+            sat = oracle_lib.refpipe_count_kmers(rb, ro, kmax, table["kmer_hi"], table["kmer_lo"], cs=3)[0]
+            assert np.array_equal(sat, np.minimum(counts, 3))
     # genomes that were sampled stand out at every k; a k-prefix column is never below the k_max column's hits / never above its size
     for ki in range(len(ks)):
         assert hits[ki][0] > 0 and hits[ki][2] > 0 and hits[ki][4] > 0

@@ -210,7 +210,7 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, 
             if definition == "reference_pipeline" and ref_arrays is None:
                 h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], sketch_n)
                 t = hip.refdb_build(h, khi, klo, o, list(ks))
-                ref_arrays = t.download(kmers=False)
+                ref_arrays = t.download(kmers=True)
                 t.free()
             elif definition != "reference_pipeline" and dbh is None:
                 tables = [hip.sketch_genomes(gb, go, k, sketch_n) for k in ks]
