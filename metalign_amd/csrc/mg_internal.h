@@ -353,9 +353,10 @@ struct KmerIndex {
   uint64_t ndistinct = 0, nbuckets = 0;
   uint32_t maxkey = 0;   // the largest minimizer of the table (the gate and a sample's "done" bits are read up to it)
   uint32_t bmask = 0;    // bucket of a minimizer = key & bmask (its LOW bits: a minimum's high bits are nearly all zero)
-  DevBuf gate;           // 2^30 bits over the minimizer values
-  DevBuf offs;           // u32[nbuckets + 1]
-  DevBuf ent;            // KcEntry[ndistinct], ascending by minimizer
+  DevBuf gate;           // bits over the minimizer values up to maxkey: some k-mer of the table has this minimizer
+  DevBuf prim;           // KcEntry[2 x nbuckets]: a bucket's first two entries (mg_kcount_core.h: KcIndexView)
+  DevBuf ovf;            // KcEntry[novf + 1]: the later ones
+  uint64_t novf = 0;
   DevBuf head;           // u32[npairs]: the pair whose counter holds the occurrences of this pair's k-mer
 };
 }  // namespace mg

@@ -95,6 +95,33 @@ __global__ void k_kc_offsets(const uint64_t* __restrict__ skey, uint64_t nd, uin
     for (uint64_t b = first; b <= last; ++b) offs[b] = (uint32_t)j;
   }
 }
+// bucket b (entries offs[b] .. offs[b + 1]) has this many entries beyond its two slots in prim
+__global__ void k_kc_extra(const uint32_t* __restrict__ offs, uint64_t nb, uint32_t* __restrict__ extra) {
+  KC_FOR(b, nb) {
+    const uint32_t n = offs[b + 1] - offs[b];
+    extra[b] = n > 2u ? n - 2u : 0u;
+  }
+}
+// ... its first two go to prim (an unused slot: key kKcNone), the rest to ovf from before[b] on; the bucket's first slot says
+// how many there are, its second where
+__global__ void k_kc_place(const KcEntry* __restrict__ ent, const uint32_t* __restrict__ offs, const uint64_t* __restrict__ before,
+                           uint64_t nb, KcEntry* __restrict__ prim, KcEntry* __restrict__ ovf) {
+  KC_FOR(b, nb) {
+    const uint32_t lo = offs[b], n = offs[b + 1] - lo;
+    KcEntry none;
+    none.w[0] = none.w[1] = none.w[2] = none.w[3] = 0; none.head = 0; none.key = kKcNone; none.sig_rc = 0; none.pad = 0;
+    KcEntry e0 = n > 0 ? ent[lo] : none, e1 = n > 1 ? ent[lo + 1] : none;
+    e0.pad = n > 2u ? n - 2u : 0u;
+    e1.pad = (uint32_t)before[b];
+    prim[2 * b] = e0;
+    prim[2 * b + 1] = e1;
+    for (uint32_t t = 2; t < n; ++t) {
+      KcEntry e = ent[lo + t];
+      e.pad = 0;
+      ovf[before[b] + (t - 2u)] = e;
+    }
+  }
+}
 __global__ void k_kc_max_key(const uint64_t* __restrict__ dkey, uint64_t nd, uint32_t* __restrict__ out) {
   uint32_t m = 0;
   KC_FOR(i, nd) m = (uint32_t)dkey[i] > m ? (uint32_t)dkey[i] : m;
@@ -141,12 +168,12 @@ struct KcArgs {
   const uint8_t* bases;
   const uint64_t* offsets;
   uint64_t nreads;
-  const uint32_t* gate;
-  const uint32_t* offs;
-  const KcEntry* ent;
+  uint32_t* live;
+  const KcEntry* prim;
+  const KcEntry* ovf;
   uint32_t* counts;
-  uint32_t* done;
-  unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the gate (and not done), [3] matches counted
+  uint32_t* sat;
+  unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the sample's gate, [3] matches counted
   uint32_t maxkey, bmask, sd, cs, ablate, stagger;  // ablate (knob kc_ablate, measurements only): 1 = the lists are dropped, 2 = ... after the gate
 };
 
@@ -169,18 +196,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #endif
 
 // The lists of a wavefront, in three phases that each keep all 64 lanes on one kind of work and wait for memory ONCE per batch:
-//   gate    every closed run's minimizer against the table's gate bit and the sample's "done" bit (both bitmaps are hot in a
-//           few MB: minimizers are minima, the keys that occur sit in the lowest few per cent of the key space); the runs that
-//           pass are compacted (ballot + popcount) into `hitq`;
-//   lookup  64 runs at a time: the bucket's bounds, then (minimizer, head) of up to four entries per lane and round trip, then
-//           the counters of those with the run's minimizer — an entry whose counter is below the saturation value becomes an
-//           ITEM (run, entry) in `scanq`; a run all of whose entries are saturated marks its minimizer done: at a metagenome's
-//           coverage nine runs in ten of an abundant genome stop at the gate from then on;
-//   scan    64 items at a time: kc_scan_run (registers only).
+//   gate    every closed run's minimizer against ONE bit of the sample's gate (the table's gate minus the minimizers whose k-mers
+//           are all saturated); the runs that pass are compacted (ballot + popcount) into `hitq`;
+//   lookup  64 runs at a time: the run's bucket — one 64-byte line, two entries — and the saturation bits of its two entry
+//           numbers, requested together; an entry with the run's minimizer whose bit is clear becomes an ITEM (run, entry
+//           number) in `scanq`; a bucket's later entries (one bucket in a dozen has any) are walked by the lanes that have
+//           them; a run all of whose entries are saturated clears its minimizer's bit in the sample's gate: at a metagenome's
+//           coverage most runs of an abundant genome stop at the gate from then on;
+//   scan    64 items at a time: kc_scan_run (registers only), ONE add per item that matched.
 // One copy of this code per translation unit, CALLED where nothing of the walk is live
 // (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
-__device__ __attribute__((noinline)) void kc_drain(const MG_GLB uint32_t* gate, const MG_GLB uint32_t* offs, const MG_GLB KcEntry* ent,
-                                                   MG_GLB uint32_t* counts, MG_GLB uint32_t* done, uint32_t maxkey, uint32_t cfg, uint32_t lds,
+__device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB KcEntry* prim, const MG_GLB KcEntry* ovf,
+                                                   MG_GLB uint32_t* counts, MG_GLB uint32_t* sat, uint32_t maxkey, uint32_t cfg, uint32_t lds,
                                                    uint32_t sd, uint32_t cnt, uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
@@ -192,7 +219,8 @@ __device__ __attribute__((noinline)) void kc_drain(const MG_GLB uint32_t* gate, 
   MG_LDS unsigned long long* scanq = (MG_LDS unsigned long long*)(size_t)(lds + L.scanq);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
   const uint32_t ablate = (cfg >> 17) & 7u;
-  const KcIndexView ix{gate, offs, ent, counts, done, (1u << (cfg & 0xffu)) - 1u, maxkey, cfg >> 20, ablate};
+  const KcIndexView ix{live, prim, ovf, counts, sat, (1u << (cfg & 0xffu)) - 1u, maxkey, cfg >> 20, ablate};
+  const uint32_t nprim = 2u * (ix.bmask + 1u);
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
   if (ablate == 1u) return;
@@ -206,59 +234,70 @@ __device__ __attribute__((noinline)) void kc_drain(const MG_GLB uint32_t* gate, 
   auto scan_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
     if ((uint32_t)lane < n) {
       const unsigned long long it = q[lane];
-      const uint32_t info = (uint32_t)it;
-      const KcEntry E = kc_load_entry(ix.ent, (uint32_t)(it >> 32));
+      const uint32_t info = (uint32_t)it, num = (uint32_t)(it >> 32);
+      const KcEntry E = kc_entry(ix, num);
       const uint32_t p0 = p0s[(info >> 20) & 63u], i1 = info & 1023u, i2 = (info >> 10) & 1023u;
-      found += bad ? kc_scan_run<true>(ix, fwd, inv, k, E, p0, i1, i2) : kc_scan_run<false>(ix, fwd, inv, k, E, p0, i1, i2);
+      const uint32_t f = bad ? kc_scan_run<true>(ix, fwd, inv, k, E, p0, i1, i2) : kc_scan_run<false>(ix, fwd, inv, k, E, p0, i1, i2);
+      kc_count_entry(ix, num, E.head, f);
+      found += f;
+    }
+  };
+  // an entry number that has the run's minimizer and no saturation bit -> scanq (every lane takes part: ballots)
+  auto push_item = [&](bool want, uint32_t info, uint32_t num) {
+    const unsigned long long m = __ballot(want && ablate != 3u);
+    if (m == 0ull) return;
+    if (want) scanq[sn + (uint32_t)__popcll(m & below)] = (unsigned long long)info | ((unsigned long long)num << 32);
+    sn += (uint32_t)__popcll(m);
+    if (sn >= 64u) {
+      wave_lds_sync();
+      sn -= 64u;
+      scan_batch(scanq + sn, 64u);
+      wave_lds_sync();
     }
   };
 
   auto lookup_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
     const bool active = (uint32_t)lane < n;
-    uint32_t key = kKcNone, info = 0, lo = 0, hi = 0;
+    uint32_t key = kKcNone, info = 0, num0 = 0, k0 = ~0u, k1 = ~0u, satw = 0, novf = 0, ovf_at = 0;
     if (active) {
       const unsigned long long ev = q[lane];
       key = (uint32_t)ev;
       info = (uint32_t)(ev >> 32);
-      const uint32_t b = key & ix.bmask;
-      lo = ix.offs[b];
-      hi = ix.offs[b + 1];
+      num0 = 2u * (key & ix.bmask);
+      // (key and pad of the bucket's two entries: one 16-byte load each out of the same 64-byte line; the words of an entry
+      // are read again, by the scan, only for the few that are scanned)
+      const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0);
+      const kc_u32x4 e0 = p[1], e1 = p[3];
+      satw = ix.sat[num0 >> 5];
+      k0 = e0.y; novf = e0.w;
+      k1 = e1.y; ovf_at = e1.w;
     }
-    bool allsat = ix.cs != 0u;
-    for (uint32_t base = 0; __ballot(lo + base < hi) != 0ull; base += 4) {
-      uint32_t eh[4], ek[4], c[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t idx = lo + base + (uint32_t)j;
-        eh[j] = 0; ek[j] = ~key;
-        if (idx < hi) kc_load_head_key(ix.ent, idx, eh[j], ek[j]);
+    const uint32_t sbit = num0 & 31u;  // (num0 is even: both bits are in the same word)
+    const bool m0 = active && k0 == key, m1 = active && k1 == key;
+    const bool u0 = m0 && !((satw >> sbit) & 1u), u1 = m1 && !((satw >> (sbit + 1u)) & 1u);
+    bool allsat = ix.cs != 0u && !u0 && !u1;
+    push_item(u0, info, num0);
+    push_item(u1, info, num0 + 1u);
+    // the bucket's later entries: minimizer, then the bit, then the next one (a lane in a dozen has any; two are rare)
+    if (!active) novf = 0;
+    for (uint32_t t = 0; __ballot(t < novf) != 0ull; ++t) {
+      const uint32_t num = nprim + ovf_at + t;
+      bool want = false;
+      if (t < novf) {
+        const kc_u32x4 e = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (ovf_at + t))[1];
+        if (e.y == key) want = !((ix.sat[num >> 5] >> (num & 31u)) & 1u);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = (ek[j] == key && ix.cs) ? ix.counts[eh[j]] : 0u;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool unsat = ek[j] == key && !(ix.cs && c[j] >= ix.cs);
-        allsat = allsat && !unsat;
-        const unsigned long long m = __ballot(unsat && ablate != 3u);
-        if (m == 0ull) continue;
-        if (unsat) scanq[sn + (uint32_t)__popcll(m & below)] = (unsigned long long)info | ((unsigned long long)(lo + base + (uint32_t)j) << 32);
-        sn += (uint32_t)__popcll(m);
-        if (sn >= 64u) {
-          wave_lds_sync();
-          sn -= 64u;
-          scan_batch(scanq + sn, 64u);
-          wave_lds_sync();
-        }
-      }
+      allsat = allsat && !want;
+      push_item(want, info, num);
     }
-    if (active && allsat) MG_KC_OR(&ix.done[key >> 5], 1u << (key & 31u));
+    if (active && allsat) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
   };
 
   const uint32_t maxc = wave_max_u32(cnt);
   const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
   for (uint32_t s0 = 0; s0 < maxc; s0 += 4) {
     unsigned long long ev[4];
-    uint32_t gw[4], dw[4];
+    uint32_t gw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ev[j] = (unsigned long long)kKcNone;
@@ -272,15 +311,13 @@ __device__ __attribute__((noinline)) void kc_drain(const MG_GLB uint32_t* gate, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t key = (uint32_t)ev[j];
-      const bool on = key <= maxkey;  // (kKcNone is above every key)
-      gw[j] = on ? gate[key >> 5] : 0u;
-      dw[j] = on ? done[key >> 5] : 0u;
+      gw[j] = key <= maxkey ? live[key >> 5] : 0u;  // (kKcNone is above every key)
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t key = (uint32_t)ev[j];
       nev += key != kKcNone ? 1u : 0u;
-      const bool pass = ((gw[j] & ~dw[j]) >> (key & 31u)) & 1u;
+      const bool pass = (gw[j] >> (key & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
       if (m == 0ull) continue;
       if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = ev[j] | ((unsigned long long)lane << 52);
@@ -331,11 +368,11 @@ __device__ __attribute__((noinline)) void kc_drain(const MG_GLB uint32_t* gate, 
 // what kc_walk writes through
 struct KcDevOut {
   MG_LDS unsigned long long* mine;  // this lane's column of the lists (slot s at mine[s * 64]): key | info << 32
-  const uint32_t* gate;
-  const uint32_t* offs;
-  const KcEntry* ent;
+  uint32_t* live;
+  const KcEntry* prim;
+  const KcEntry* ovf;
   uint32_t* counts;
-  uint32_t* done;
+  uint32_t* sat;
   uint32_t maxkey, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t key, uint32_t info) { mine[slot * 64u] = (unsigned long long)key | ((unsigned long long)info << 32); }
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
@@ -343,8 +380,8 @@ struct KcDevOut {
     return;
 #endif
     wave_lds_sync();
-    kc_drain((const MG_GLB uint32_t*)gate, (const MG_GLB uint32_t*)offs, (const MG_GLB KcEntry*)ent, (MG_GLB uint32_t*)counts,
-             (MG_GLB uint32_t*)done, maxkey, cfg, lds, sd, cnt, limit);
+    kc_drain((MG_GLB uint32_t*)live, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf, (MG_GLB uint32_t*)counts,
+             (MG_GLB uint32_t*)sat, maxkey, cfg, lds, sd, cnt, limit);
     wave_lds_sync();
   }
   static constexpr uint32_t kCap = kKcListCap;
@@ -468,7 +505,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t p0 = rd < a.nreads ? (uint32_t)(shift + (beg - t_beg)) : 0u;  // (a lane without a read walks the tile's first bases, masked)
       p0s[lane] = p0;
       wave_lds_sync();
-      KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.done, a.maxkey, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
+      KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, a.maxkey, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
       kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
@@ -504,7 +541,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
           inv16[gidx ^ 1u] = (uint16_t)kc_notbase16(vv);
         }
         wave_lds_sync();
-        KcDevOut out{lists + lane, a.gate, a.offs, a.ent, a.counts, a.done, a.maxkey, cfg0 | (1u << 16), lds, a.sd};
+        KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, a.maxkey, cfg0 | (1u << 16), lds, a.sd};
         const uint32_t cmax = wave_max_u32(clen);
         kmers += kc_clean_windows(inv, p0, clen, cmax, K);
         kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
@@ -546,9 +583,11 @@ int dispatch_kc(int k, const KcArgs& a, unsigned grid, size_t lds, hipStream_t s
 
 struct mg_kcounts {
   mg::DevBuf counts;  // u32[npairs + 1]
-  mg::DevBuf done;    // bits over the minimizer values up to the table's largest: every k-mer of this minimizer is saturated
+  mg::DevBuf live;    // the sample's gate: the table's, minus the minimizers all of whose k-mers are saturated (mg_kcount_core.h)
+  mg::DevBuf sat;     // a bit per entry number: its counter has reached the saturation value
   mg::DevBuf stats;   // u64[4]
-  uint64_t n = 0, done_words = 0;
+  uint64_t n = 0, live_words = 0, sat_words = 0;
+  const void* gate = nullptr;  // the table's gate bitmap the live one is reset from (owned by the table: it outlives the counters)
 };
 
 using namespace mg;
@@ -574,7 +613,7 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
   if (n && !db->kmer_hi.p) return fail(MG_ERR_STATE, "the table does not hold its k-mers: pass them (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64)");
   std::unique_ptr<KmerIndex> ix(new KmerIndex());
   ix->k = k;
-  MG_TRY(ix->gate.alloc((1ull << 30) / 8));  // (only the words up to the largest minimizer are ever read: they are what is zeroed)
+  MG_TRY(ix->gate.alloc(4));  // (sized below, once the largest minimizer is known)
 
   MG_TRY(ix->head.alloc((n + 1) * 4));
   DevBuf chi, clo, iota, ord1, ord2, s_lo, s_hi, g_hi, flag, before, dhi, dlo, dhead, dkey, skey, perm;
@@ -615,19 +654,33 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
     MG_HIP(hipMemcpyAsync(pin + 12, d_max, 4, hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st));
     ix->maxkey = (uint32_t)pin[12];
-    MG_HIP(hipMemsetAsync(ix->gate.p, 0, (((uint64_t)ix->maxkey >> 5) + 1) * 4, st));
+    MG_TRY(ix->gate.alloc((((uint64_t)ix->maxkey >> 5) + 2) * 4));
+    MG_HIP(hipMemsetAsync(ix->gate.p, 0, (((uint64_t)ix->maxkey >> 5) + 2) * 4, st));
     hipLaunchKernelGGL(k_kc_bucket_keys, dim3(g256(nd)), dim3(256), 0, st, dkey.as<uint64_t>(), nd, ix->bmask);
     MG_TRY(sort_pairs(dkey.as<uint64_t>(), skey.as<uint64_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), nd));
   }
-  MG_TRY(ix->offs.alloc((ix->nbuckets + 2) * 4));
-  MG_TRY(ix->ent.alloc((nd + 1) * sizeof(KcEntry)));
+  // the entries in (bucket, minimizer) order, the buckets' bounds, then their places: two per bucket in prim, the rest in ovf
+  DevBuf offs, ent, extra, obefore;
+  MG_TRY(offs.alloc((ix->nbuckets + 2) * 4));
+  MG_TRY(ent.alloc((nd + 1) * sizeof(KcEntry)));
+  MG_TRY(extra.alloc((ix->nbuckets + 1) * 4));
+  MG_TRY(obefore.alloc((ix->nbuckets + 2) * 8));
+  MG_TRY(ix->prim.alloc(2 * ix->nbuckets * sizeof(KcEntry)));
   if (nd) {
     hipLaunchKernelGGL(k_kc_entries, dim3(g256(nd)), dim3(256), 0, st, skey.as<uint64_t>(), perm.as<uint32_t>(), dhi.as<uint64_t>(),
-                       dlo.as<uint64_t>(), dhead.as<uint32_t>(), nd, k, ix->ent.as<KcEntry>(), ix->gate.as<uint32_t>());
-    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(nd + 1)), dim3(256), 0, st, skey.as<uint64_t>(), nd, ix->nbuckets, ix->offs.as<uint32_t>());
+                       dlo.as<uint64_t>(), dhead.as<uint32_t>(), nd, k, ent.as<KcEntry>(), ix->gate.as<uint32_t>());
+    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(nd + 1)), dim3(256), 0, st, skey.as<uint64_t>(), nd, ix->nbuckets, offs.as<uint32_t>());
   } else {
-    MG_HIP(hipMemsetAsync(ix->offs.p, 0, (ix->nbuckets + 2) * 4, st));
+    MG_HIP(hipMemsetAsync(offs.p, 0, (ix->nbuckets + 2) * 4, st));
   }
+  hipLaunchKernelGGL(k_kc_extra, dim3(g256(ix->nbuckets)), dim3(256), 0, st, offs.as<uint32_t>(), ix->nbuckets, extra.as<uint32_t>());
+  MG_HIP(hipGetLastError());
+  uint64_t novf = 0;
+  MG_TRY(exclusive_sum_u32_to_u64(extra.as<uint32_t>(), obefore.as<uint64_t>(), ix->nbuckets, &novf));
+  ix->novf = novf;
+  MG_TRY(ix->ovf.alloc((novf + 1) * sizeof(KcEntry)));
+  hipLaunchKernelGGL(k_kc_place, dim3(g256(ix->nbuckets)), dim3(256), 0, st, ent.as<KcEntry>(), offs.as<uint32_t>(), obefore.as<uint64_t>(),
+                     ix->nbuckets, ix->prim.as<KcEntry>(), ix->ovf.as<KcEntry>());
   MG_HIP(hipGetLastError());
   MG_HIP(hipStreamSynchronize(st));
   db->kidx = std::move(ix);
@@ -650,11 +703,15 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
   if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
   std::unique_ptr<mg_kcounts> kc(new mg_kcounts());
   kc->n = db->kmax.total;
-  kc->done_words = ((uint64_t)db->kidx->maxkey >> 5) + 1;
+  kc->live_words = ((uint64_t)db->kidx->maxkey >> 5) + 2;
+  kc->sat_words = (2 * db->kidx->nbuckets + db->kidx->novf) / 32 + 2;
+  kc->gate = db->kidx->gate.p;
   MG_TRY(kc->counts.alloc((kc->n + 1) * 4));
-  MG_TRY(kc->done.alloc(kc->done_words * 4));
+  MG_TRY(kc->live.alloc(kc->live_words * 4));
+  MG_TRY(kc->sat.alloc(kc->sat_words * 4));
   MG_TRY(kc->stats.alloc(12 * 8));
-  MG_HIP(hipMemsetAsync(kc->done.p, 0, kc->done_words * 4, ctx().stream));
+  MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, ctx().stream));
+  MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, ctx().stream));
   MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
   MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, ctx().stream));
   *out = kc.release();
@@ -664,7 +721,8 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
 int mg_kcounts_reset(mg_kcounts* kc) {
   MG_REQUIRE_READY();
   if (!kc) return fail(MG_ERR_ARG, "null argument");
-  MG_HIP(hipMemsetAsync(kc->done.p, 0, kc->done_words * 4, ctx().stream));
+  MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, ctx().stream));
+  MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, ctx().stream));
   MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
   MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, ctx().stream));
   return MG_OK;
@@ -675,7 +733,7 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   MG_REQUIRE_READY();
   if (!db || !kc || (nreads && (!d_bases || !d_offsets))) return fail(MG_ERR_ARG, "null argument");
   if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
-  if (kc->n != db->kmax.total || kc->done_words != ((uint64_t)db->kidx->maxkey >> 5) + 1)
+  if (kc->n != db->kmax.total || kc->gate != db->kidx->gate.p)
     return fail(MG_ERR_ARG, "these counters belong to another table");
   if (nreads == 0) return MG_OK;
   Context& c = ctx();
@@ -696,8 +754,8 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const uint64_t ntiles = (nreads + 63) / 64;
   const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
-  KcArgs a{d_bases, d_offsets, nreads, ix.gate.as<uint32_t>(), ix.offs.as<uint32_t>(), ix.ent.as<KcEntry>(), kc->counts.as<uint32_t>(),
-           kc->done.as<uint32_t>(), kc->stats.as<unsigned long long>(), ix.maxkey, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
+  KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
+           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), ix.maxkey, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
   ProfScope ps("count_kmers");
   MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
   MG_HIP(hipGetLastError());

@@ -327,39 +327,44 @@ MG_HD uint32_t kc_clean_windows(const MG_LDS uint32_t* inv, uint32_t p0, uint32_
 }
 
 // ---- a run against the table -------------------------------------------------------------------------------------------
+// The table's distinct canonical k-mers, laid out so that a run's look-up is ONE access to memory in the usual case:
+//   prim   two 32-byte entries per bucket (bucket of a minimizer = its LOW bits; as many buckets as a power of two >= the k-mers):
+//          the bucket's first two entries in (minimizer) order, an unused slot has key kKcNone — one 64-byte line;
+//   ovf    the third and later entries of the (few) buckets that hold more: prim[2 b].pad = how many, prim[2 b + 1].pad = where;
+//   an entry's NUMBER: 2 b + s in prim, 2 * buckets + j in ovf — what a sample's saturation bits go by.
+// Per sample (mg_kcounts): `live` = a copy of the table's gate bitmap (bit `key` set <=> some table k-mer has this minimizer)
+// in which the bit of a minimizer is CLEARED once every k-mer of it has been seen at the saturation value: ONE bit probe per
+// run decides both; `sat` = a bit per entry number: its counter has reached the saturation value; `counts` at the entry's head.
 struct KcIndexView {
-  const MG_GLB uint32_t* gate;   // bit `key` set <=> some table k-mer has this minimizer (keys above maxkey: no bit)
-  const MG_GLB uint32_t* offs;   // [buckets + 1]: entries of bucket b = key & bmask are ent[offs[b] .. offs[b + 1])
-  const MG_GLB KcEntry* ent;     // ascending by (bucket, key)
-  MG_GLB uint32_t* counts;       // [npairs]: occurrences, at the entry's `head`
-  MG_GLB uint32_t* done;         // per sample: bit `key` set <=> every table k-mer with this minimizer has been seen at its saturation value
-  uint32_t bmask;         // buckets - 1: the LOW bits of a minimizer (minimizers are minima: their high bits are nearly all zero)
-  uint32_t maxkey;        // the largest minimizer of the table
-  uint32_t cs;            // counters are read as min(counter, cs) (kmc -cs<cs>; 0: exact): one seen at cs is left alone
+  MG_GLB uint32_t* live;
+  const MG_GLB KcEntry* prim;
+  const MG_GLB KcEntry* ovf;
+  MG_GLB uint32_t* counts;
+  MG_GLB uint32_t* sat;
+  uint32_t bmask;         // buckets - 1 (minimizers are minima: their HIGH bits are nearly all zero, the low ones spread)
+  uint32_t maxkey;        // the largest minimizer of the table: `live` ends there
+  uint32_t cs;            // counters are read as min(counter, cs) (kmc -cs<cs>; 0: exact, nothing ever saturates)
   uint32_t ablate;        // measurements only (knob kc_ablate): 3 = no run is scanned; 4 = signatures only; 5 = no count
 };
 
-// an entry / its (head, minimizer) pair out of device memory (class types do not copy out of a qualified address space: as vectors)
+// an entry out of device memory (class types do not copy out of a qualified address space: as vectors)
 #ifdef MG_HOST_CHECK
 MG_HD KcEntry kc_load_entry(const KcEntry* ent, uint32_t e) { return ent[e]; }
-MG_HD void kc_load_head_key(const KcEntry* ent, uint32_t e, uint32_t& head, uint32_t& key) { head = ent[e].head; key = ent[e].key; }
 #else
 typedef uint32_t kc_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t kc_u32x2 __attribute__((ext_vector_type(2)));
 MG_HD KcEntry kc_load_entry(const MG_GLB KcEntry* ent, uint32_t e) {
   const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ent + e);
   const kc_u32x4 a = p[0], b = p[1];
   return KcEntry{{a.x, a.y, a.z, a.w}, b.x, b.y, b.z, b.w};
 }
-MG_HD void kc_load_head_key(const MG_GLB KcEntry* ent, uint32_t e, uint32_t& head, uint32_t& key) {
-  const kc_u32x2 v = *reinterpret_cast<const MG_GLB kc_u32x2*>(&ent[e].head);  // (side by side: one 8-byte load)
-  head = v.x; key = v.y;
-}
 #endif
-
-MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) {
-  return key <= ix.maxkey && ((ix.gate[key >> 5] >> (key & 31u)) & 1u) && !((ix.done[key >> 5] >> (key & 31u)) & 1u);
+// entry number n
+MG_HD KcEntry kc_entry(const KcIndexView& ix, uint32_t n) {
+  const uint32_t nprim = 2u * (ix.bmask + 1u);
+  return n < nprim ? kc_load_entry(ix.prim, n) : kc_load_entry(ix.ovf, n - nprim);
 }
+
+MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) { return key <= ix.maxkey && ((ix.live[key >> 5] >> (key & 31u)) & 1u); }
 
 // no "not a base" bit in [p, p + k)
 MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
@@ -372,11 +377,13 @@ MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
 }
 
 #ifdef MG_HOST_CHECK
-#define MG_KC_COUNT(ptr) (++*(ptr))
+#define MG_KC_ADD(ptr, v) ((*(ptr) += (v)) - (v))
 #define MG_KC_OR(ptr, v) (*(ptr) |= (v))
+#define MG_KC_AND(ptr, v) (*(ptr) &= (v))
 #else
-#define MG_KC_COUNT(ptr) __hip_atomic_fetch_add((ptr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MG_KC_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MG_KC_OR(ptr, v) __hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MG_KC_AND(ptr, v) __hip_atomic_fetch_and((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 // One table k-mer E against the windows [i1, i2] of the read that starts at stream position p0 (a run that shares E's
@@ -408,12 +415,7 @@ MG_HD uint32_t kc_scan_run_n(const KcIndexView& ix, const MG_LDS uint32_t* fwd, 
       if (ok) {
         const KcWin x = kc_ext128(fwd, p0 + i, k), y = kc_revcomp(x, k);
         const KcWin c = kc_less(y, x) ? y : x;
-        if (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) {
-          // A counter seen at its saturation value is left alone (counters only grow: a stale look can only cost an add that
-          // changes nothing); exact counters stop far below a 32-bit wrap.
-          if (ix.ablate != 5u && ix.counts[E.head] < (ix.cs ? ix.cs : 0x7fffff00u)) MG_KC_COUNT(&ix.counts[E.head]);
-          ++found;
-        }
+        found += (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) ? 1u : 0u;
       }
     }
 #pragma unroll
@@ -432,24 +434,36 @@ MG_HD uint32_t kc_scan_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, co
   return kc_scan_run_n<BAD, 5>(ix, fwd, inv, k, E, p0, i1, i2);
 }
 
+// `found` windows of a run were entry number n (counted at `head`): ONE add for the run, and — counters that saturate — the
+// entry's bit once the add has taken the counter to the saturation value (the add's old value decides: whoever crosses sets it).
+MG_HD void kc_count_entry(const KcIndexView& ix, uint32_t n, uint32_t head, uint32_t found) {
+  if (!found || ix.ablate == 5u) return;
+  const uint32_t old = MG_KC_ADD(&ix.counts[head], found);
+  if (ix.cs && old + found >= ix.cs) MG_KC_OR(&ix.sat[n >> 5], 1u << (n & 31u));
+}
+
 // A run past the gate against its bucket, one lane on its own (the host check, and the statement of what the kernel's batched
 // phases — mg_kcount.hip: kc_drain — compute): every entry with the run's minimizer whose counter is not saturated is scanned;
-// when all of them are saturated the minimizer is marked done for the rest of the sample.
+// when all of them are saturated the minimizer's bit is cleared in the sample's gate.
 template <bool BAD>
 MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, uint32_t key,
                             uint32_t p0, uint32_t i1, uint32_t i2) {
-  const uint32_t b = key & ix.bmask;
-  const uint32_t lo = ix.offs[b], hi = ix.offs[b + 1];
-  uint32_t found = 0;
+  const uint32_t b = key & ix.bmask, nprim = 2u * (ix.bmask + 1u);
+  uint32_t found = 0, novf = 0, ovf_at = 0;
   bool allsat = ix.cs != 0u;
-  for (uint32_t e = lo; e < hi; ++e) {
-    const KcEntry E = kc_load_entry(ix.ent, e);
+  for (uint32_t t = 0; t < 2u + novf; ++t) {
+    const uint32_t n = t < 2u ? 2u * b + t : nprim + ovf_at + (t - 2u);
+    const KcEntry E = kc_entry(ix, n);
+    if (t == 0) novf = E.pad;
+    if (t == 1) ovf_at = E.pad;
     if (E.key != key) continue;
-    if (ix.cs && ix.counts[E.head] >= ix.cs) continue;
+    if ((ix.sat[n >> 5] >> (n & 31u)) & 1u) continue;
     allsat = false;
-    found += kc_scan_run<BAD>(ix, fwd, inv, k, E, p0, i1, i2);
+    const uint32_t f = kc_scan_run<BAD>(ix, fwd, inv, k, E, p0, i1, i2);
+    kc_count_entry(ix, n, E.head, f);
+    found += f;
   }
-  if (allsat) MG_KC_OR(&ix.done[key >> 5], 1u << (key & 31u));
+  if (allsat) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
   return found;
 }
 

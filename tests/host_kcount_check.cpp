@@ -53,17 +53,17 @@ static KcWin win_from_string(const std::string& s) {
 }
 
 struct Index {
-  std::vector<uint32_t> gate, offs, counts, done;
-  std::vector<KcEntry> ent;
+  std::vector<uint32_t> live, counts, sat;
+  std::vector<KcEntry> ent, prim, ovf;
   uint32_t bmask = 0, maxkey = 0, cs = 0;
-  KcIndexView view() { return KcIndexView{gate.data(), offs.data(), ent.data(), counts.data(), done.data(), bmask, maxkey, cs, 0u}; }
+  KcIndexView view() { return KcIndexView{live.data(), prim.data(), ovf.data(), counts.data(), sat.data(), bmask, maxkey, cs, 0u}; }
 };
 
 template <int K, uint32_t CAP>
 static void run(const std::vector<std::string>& table, const std::vector<std::string>& reads, size_t lead) {
   // ---- the index, as mg_refdb_index_kmers builds it (here with a map) ----
   Index ix;
-  ix.gate.assign(1u << 25, 0u);
+  ix.live.assign(1u << 25, 0u);
   ix.counts.assign(table.size() + 1, 0u);
   std::map<std::array<uint32_t, 4>, uint32_t> first;  // canonical k-mer -> the first pair that holds it
   std::vector<uint32_t> head(table.size());
@@ -101,16 +101,24 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
   std::stable_sort(ix.ent.begin(), ix.ent.end(), [bm](const KcEntry& a, const KcEntry& b) {
     return (a.key & bm) != (b.key & bm) ? (a.key & bm) < (b.key & bm) : a.key < b.key;
   });
-  ix.offs.assign((1u << bb) + 2, 0u);
-  {
+  {  // the first two entries of a bucket in prim, the rest in ovf (mg_kcount.hip: k_kc_place)
+    KcEntry none{};
+    none.key = kKcNone;
+    ix.prim.assign(2u << bb, none);
     size_t j = 0;
-    for (uint32_t b = 0; b <= (1u << bb); ++b) {
-      while (j < ix.ent.size() && (ix.ent[j].key & bm) < b) ++j;
-      ix.offs[b] = (uint32_t)j;
+    for (uint32_t b = 0; b < (1u << bb); ++b) {
+      size_t j0 = j;
+      while (j < ix.ent.size() && (ix.ent[j].key & bm) == b) ++j;
+      const size_t n = j - j0;
+      for (size_t t = 0; t < n && t < 2; ++t) { ix.prim[2 * b + t] = ix.ent[j0 + t]; ix.prim[2 * b + t].pad = 0; }
+      ix.prim[2 * b].pad = n > 2 ? (uint32_t)(n - 2) : 0u;
+      ix.prim[2 * b + 1].pad = (uint32_t)ix.ovf.size();
+      for (size_t t = 2; t < n; ++t) ix.ovf.push_back(ix.ent[j0 + t]);
     }
+    ix.ovf.push_back(none);
   }
-  for (auto& e : ix.ent) { ix.gate[e.key >> 5] |= 1u << (e.key & 31u); ix.maxkey = std::max(ix.maxkey, e.key); }
-  ix.done.assign((ix.maxkey >> 5) + 1, 0u);
+  for (auto& e : ix.ent) { ix.live[e.key >> 5] |= 1u << (e.key & 31u); ix.maxkey = std::max(ix.maxkey, e.key); }
+  ix.sat.assign(((2u << bb) + ix.ovf.size()) / 32 + 2, 0u);
   ix.cs = g_cs;
   const KcIndexView view = ix.view();
 
