@@ -13,6 +13,7 @@
 //     (ballot + popcount) and matches them 64 at a time against their buckets;
 //   * the handle that holds a sample's counters (mg_kcounts) and its way into stage B (mg_contain.hip: k_match_pairs).
 // Normative statement: oracle/mg_oracle.c, mgo_refpipe_count_kmers.
+#include <algorithm>
 #include <memory>
 
 #include "mg_internal.h"
@@ -174,6 +175,11 @@ struct KcArgs {
   uint32_t* counts;
   uint32_t* sat;
   unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the sample's gate, [3] matches counted
+  // the runs past the gate are handed on to k_match_items: a region of `qcap` 16-byte items per wavefront of this launch
+  // (minimizer, windows, read, -), how many it wrote in qcount[wavefront]; a wavefront whose region is full matches in place
+  kc_u32x4* queue;
+  uint32_t* qcount;
+  uint32_t qcap;
   uint32_t maxkey, bmask, sd, cs, ablate, stagger;  // ablate (knob kc_ablate, measurements only): 1 = the lists are dropped, 2 = ... after the gate
 };
 
@@ -204,11 +210,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 //           them; a run all of whose entries are saturated clears its minimizer's bit in the sample's gate: at a metagenome's
 //           coverage most runs of an abundant genome stop at the gate from then on;
 //   scan    64 items at a time: kc_scan_run (registers only), ONE add per item that matched.
+// The usual kernel stops after the gate: the runs that pass are HANDED ON — (minimizer, windows, read) into this wavefront's
+// region of a queue in device memory — and a second kernel (k_match_items), whose lanes need neither this kernel's registers
+// nor its LDS and so run sixteen wavefronts to a SIMD where this one runs three, does lookup and scan from the reads' text:
+// those phases wait for memory, this kernel's walk keeps the vector units busy, and side by side neither waits for the other.
+// Lookup and scan stay here for what cannot be handed on (a full region; the chunks of a long read, whose windows are numbered
+// within the chunk).
 // One copy of this code per translation unit, CALLED where nothing of the walk is live
-// (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
+// (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20 (eleven bits) | match here << 31).
 __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB KcEntry* prim, const MG_GLB KcEntry* ovf,
-                                                   MG_GLB uint32_t* counts, MG_GLB uint32_t* sat, uint32_t maxkey, uint32_t cfg, uint32_t lds,
-                                                   uint32_t sd, uint32_t cnt, uint32_t limit) {
+                                                   MG_GLB uint32_t* counts, MG_GLB uint32_t* sat, MG_GLB kc_u32x4* region, uint32_t qcap,
+                                                   uint32_t read0, uint32_t maxkey, uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt,
+                                                   uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
   const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
@@ -219,7 +232,9 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   MG_LDS unsigned long long* scanq = (MG_LDS unsigned long long*)(size_t)(lds + L.scanq);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
   const uint32_t ablate = (cfg >> 17) & 7u;
-  const KcIndexView ix{live, prim, ovf, counts, sat, (1u << (cfg & 0xffu)) - 1u, maxkey, cfg >> 20, ablate};
+  const KcIndexView ix{live, prim, ovf, counts, sat, (1u << (cfg & 0xffu)) - 1u, maxkey, (cfg >> 20) & 0x7ffu, ablate};
+  const bool hand_on = region != nullptr && !(cfg >> 31);
+  uint32_t cursor = stat[3];  // items this wavefront has handed on so far
   const uint32_t nprim = 2u * (ix.bmask + 1u);
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
@@ -268,7 +283,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
       // are read again, by the scan, only for the few that are scanned)
       const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0);
       const kc_u32x4 e0 = p[1], e1 = p[3];
-      satw = ix.sat[num0 >> 5];
+      satw = MG_KC_LOAD(&ix.sat[num0 >> 5]);
       k0 = e0.y; novf = e0.w;
       k1 = e1.y; ovf_at = e1.w;
     }
@@ -285,12 +300,28 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
       bool want = false;
       if (t < novf) {
         const kc_u32x4 e = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (ovf_at + t))[1];
-        if (e.y == key) want = !((ix.sat[num >> 5] >> (num & 31u)) & 1u);
+        if (e.y == key) want = !((MG_KC_LOAD(&ix.sat[num >> 5]) >> (num & 31u)) & 1u);
       }
       allsat = allsat && !want;
       push_item(want, info, num);
     }
-    if (active && allsat) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
+    if (active && allsat) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));  // (it was set a moment ago: this run passed the gate)
+  };
+
+  // 64 (or the last few) runs past the gate: handed on, or — no room, or not that kind of tile — matched here
+  auto settle = [&](const MG_LDS unsigned long long* q, uint32_t n) {
+    if (hand_on && cursor + n <= qcap) {
+      if ((uint32_t)lane < n) {
+        const unsigned long long ev = q[lane];
+        const uint32_t info = (uint32_t)(ev >> 32);
+        kc_u32x4 it;
+        it.x = (uint32_t)ev; it.y = info & 0xfffffu; it.z = read0 + ((info >> 20) & 63u); it.w = 0u;
+        region[cursor + (uint32_t)lane] = it;
+      }
+      cursor += n;
+    } else {
+      lookup_batch(q, n);
+    }
   };
 
   const uint32_t maxc = wave_max_u32(cnt);
@@ -311,7 +342,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t key = (uint32_t)ev[j];
-      gw[j] = key <= maxkey ? live[key >> 5] : 0u;  // (kKcNone is above every key)
+      gw[j] = key <= maxkey ? MG_KC_LOAD(&live[key >> 5]) : 0u;  // (kKcNone is above every key)
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -329,7 +360,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 #ifdef MG_KC_CLOCKS
         const uint64_t h0 = __builtin_readcyclecounter();
 #endif
-        lookup_batch(hitq + hn, 64u);
+        settle(hitq + hn, 64u);
 #ifdef MG_KC_CLOCKS
         clk_hits += __builtin_readcyclecounter() - h0;
 #endif
@@ -345,7 +376,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 #endif
     if (hn) {
       wave_lds_sync();
-      lookup_batch(hitq, hn);
+      settle(hitq, hn);
     }
     if (sn) {
       wave_lds_sync();
@@ -359,7 +390,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   // (the wavefront's totals stay in LDS until the kernel ends: an atomic per call on three global words that every wavefront
   // shares was most of the kernel's time — 31 k calls per 2M reads, each queueing behind the others at the memory side)
   nev = wave_sum_u32(nev); npass = wave_sum_u32(npass); found = wave_sum_u32(found);
-  if (lane == 0) { stat[0] += nev; stat[1] += npass; stat[2] += found; }
+  if (lane == 0) { stat[0] += nev; stat[1] += npass; stat[2] += found; stat[3] = cursor; }
 #ifdef MG_KC_CLOCKS
   if (lane == 0) { stat[4] += (uint32_t)((__builtin_readcyclecounter() - clk0) >> 6); stat[5] += (uint32_t)(clk_hits >> 6); stat[11] += 1; }
 #endif
@@ -373,6 +404,8 @@ struct KcDevOut {
   const KcEntry* ovf;
   uint32_t* counts;
   uint32_t* sat;
+  kc_u32x4* region;
+  uint32_t qcap, read0;
   uint32_t maxkey, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t key, uint32_t info) { mine[slot * 64u] = (unsigned long long)key | ((unsigned long long)info << 32); }
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
@@ -381,7 +414,7 @@ struct KcDevOut {
 #endif
     wave_lds_sync();
     kc_drain((MG_GLB uint32_t*)live, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf, (MG_GLB uint32_t*)counts,
-             (MG_GLB uint32_t*)sat, maxkey, cfg, lds, sd, cnt, limit);
+             (MG_GLB uint32_t*)sat, (MG_GLB kc_u32x4*)region, qcap, read0, maxkey, cfg, lds, sd, cnt, limit);
     wave_lds_sync();
   }
   static constexpr uint32_t kCap = kKcListCap;
@@ -426,7 +459,8 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
   MG_LDS uint32_t* p0s = (MG_LDS uint32_t*)(base + L.p0s);
   MG_LDS unsigned long long* lists = (MG_LDS unsigned long long*)(base + L.lists);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(base + L.stat);
-  const uint32_t cfg0 = (uint32_t)__builtin_popcount(a.bmask) | ((uint32_t)K << 8) | ((a.ablate & 7u) << 17) | ((a.cs > 4095u ? 0u : a.cs) << 20);
+  const uint32_t cfg0 = (uint32_t)__builtin_popcount(a.bmask) | ((uint32_t)K << 8) | ((a.ablate & 7u) << 17) | ((a.cs > 2047u ? 0u : a.cs) << 20);
+  kc_u32x4* region = a.queue ? a.queue + (size_t)((uint64_t)blockIdx.x * kKcWaves + wave) * a.qcap : nullptr;
   uint32_t kmers = 0;
   if (lane < 12) stat[lane] = 0;
   wave_lds_sync();
@@ -505,7 +539,8 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t p0 = rd < a.nreads ? (uint32_t)(shift + (beg - t_beg)) : 0u;  // (a lane without a read walks the tile's first bases, masked)
       p0s[lane] = p0;
       wave_lds_sync();
-      KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, a.maxkey, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
+      KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, region, a.qcap, (uint32_t)(tile * 64), a.maxkey,
+                   cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
       kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
@@ -541,7 +576,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
           inv16[gidx ^ 1u] = (uint16_t)kc_notbase16(vv);
         }
         wave_lds_sync();
-        KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, a.maxkey, cfg0 | (1u << 16), lds, a.sd};
+        KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, nullptr, 0u, 0u, a.maxkey, cfg0 | (1u << 16) | (1u << 31), lds, a.sd};
         const uint32_t cmax = wave_max_u32(clen);
         kmers += kc_clean_windows(inv, p0, clen, cmax, K);
         kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
@@ -552,11 +587,112 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
   wave_lds_sync();
   if (lane == 0 && total) atomicAdd(a.stats, (unsigned long long)total);
   if (lane >= 1 && lane < 4 && stat[lane - 1]) atomicAdd(a.stats + lane, (unsigned long long)stat[lane - 1]);
+  if (lane == 0 && a.qcount) a.qcount[(uint64_t)blockIdx.x * kKcWaves + wave] = stat[3];
 #ifdef MG_KC_CLOCKS
   if (lane == 0) stat[6] = (uint32_t)((__builtin_readcyclecounter() - kclk0) >> 6);
   wave_lds_sync();
   if (lane >= 4 && lane < 12) atomicAdd(a.stats + lane, (unsigned long long)stat[lane]);
 #endif
+}
+
+// The second half: the runs the first kernel handed on against their buckets, from the reads' text (what a lane computes for its
+// run is stated in mg_kcount_core.h: kc_match_item_ascii).  A workgroup takes the regions of the queue in turn.
+struct KbArgs {
+  const uint8_t* bases;
+  const uint64_t* offsets;
+  const kc_u32x4* queue;
+  const uint32_t* qcount;
+  uint32_t qcap, nregions;
+  uint32_t* live;
+  const KcEntry* prim;
+  const KcEntry* ovf;
+  uint32_t* counts;
+  uint32_t* sat;
+  unsigned long long* stats;
+  uint32_t maxkey, bmask, cs, ablate;
+  int k;
+};
+// A wavefront takes 64 items at a time through the lookup (the bucket's line and the saturation word, one round trip for all
+// 64) and compacts the (item, entry number) combinations that have to be SCANNED — an entry with the run's minimizer that is not
+// saturated: one item in ten at a metagenome's coverage — into a queue of its own in LDS; scans run 64 to a batch.  (Lane per
+// item all the way — lookup and scan in one loop — cost 5700 vector instructions per 64 items: one or two lanes of every
+// wavefront scanning, the others waiting.)
+__global__ __launch_bounds__(256) void k_match_items(const KbArgs a) {
+  __shared__ unsigned long long s_q[4][192];
+  const KcIndexView ix{(MG_GLB uint32_t*)a.live, (const MG_GLB KcEntry*)a.prim, (const MG_GLB KcEntry*)a.ovf, (MG_GLB uint32_t*)a.counts,
+                       (MG_GLB uint32_t*)a.sat, a.bmask, a.maxkey, a.cs > 2047u ? 0u : a.cs, a.ablate};
+  const MG_GLB uint8_t* bases = (const MG_GLB uint8_t*)a.bases;
+  const uint32_t nprim = 2u * (ix.bmask + 1u);
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  unsigned long long* q = s_q[wave];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t sn = 0, found = 0;
+  auto scan_batch = [&](uint32_t at, uint32_t n) {
+    if ((uint32_t)lane < n) {
+      const unsigned long long e = q[at + (uint32_t)lane];
+      const uint32_t num = (uint32_t)(e >> 32);
+      const kc_u32x4 it = a.queue[(uint32_t)e];
+      const KcEntry E = kc_entry(ix, num);
+      const uint64_t beg = a.offsets[it.z], end = a.offsets[it.z + 1];
+      const uint32_t f = kc_scan_ascii(ix, bases + beg, (uint32_t)(end - beg), a.k, E, it.y & 1023u, (it.y >> 10) & 1023u);
+      kc_count_entry(ix, num, E.head, f);
+      found += f;
+    }
+  };
+  auto push_item = [&](bool want, uint32_t idx, uint32_t num) {
+    const unsigned long long m = __ballot(want && a.ablate != 3u);
+    if (m == 0ull) return;
+    if (want) q[sn + (uint32_t)__popcll(m & below)] = (unsigned long long)idx | ((unsigned long long)num << 32);
+    sn += (uint32_t)__popcll(m);
+    if (sn >= 64u) {
+      wave_lds_sync();
+      sn -= 64u;
+      scan_batch(sn, 64u);
+      wave_lds_sync();
+    }
+  };
+  for (uint32_t r = blockIdx.x; r < a.nregions; r += gridDim.x) {
+    const uint32_t n = a.qcount[r];
+    for (uint32_t i0 = (uint32_t)wave * 64u; i0 < n; i0 += 256u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool active = i < n;
+      const uint32_t idx = r * a.qcap + i;
+      uint32_t key = kKcNone, num0 = 0, k0 = ~0u, k1 = ~0u, satw = 0, novf = 0, ovf_at = 0;
+      if (active) {
+        key = a.queue[idx].x;
+        num0 = 2u * (key & ix.bmask);
+        const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0);
+        const kc_u32x4 e0 = p[1], e1 = p[3];
+        satw = MG_KC_LOAD(&ix.sat[num0 >> 5]);
+        k0 = e0.y; novf = e0.w;
+        k1 = e1.y; ovf_at = e1.w;
+      }
+      const uint32_t sbit = num0 & 31u;
+      const bool u0 = active && k0 == key && !((satw >> sbit) & 1u), u1 = active && k1 == key && !((satw >> (sbit + 1u)) & 1u);
+      bool allsat = ix.cs != 0u && !u0 && !u1;
+      push_item(u0, idx, num0);
+      push_item(u1, idx, num0 + 1u);
+      if (!active) novf = 0;
+      for (uint32_t t = 0; __ballot(t < novf) != 0ull; ++t) {
+        const uint32_t num = nprim + ovf_at + t;
+        bool want = false;
+        if (t < novf) {
+          const kc_u32x4 e = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (ovf_at + t))[1];
+          if (e.y == key) want = !((MG_KC_LOAD(&ix.sat[num >> 5]) >> (num & 31u)) & 1u);
+        }
+        allsat = allsat && !want;
+        push_item(want, idx, num);
+      }
+      // (a look first: most runs of an abundant genome find the bit cleared already)
+      if (active && allsat && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u)) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
+    }
+  }
+  if (sn) {
+    wave_lds_sync();
+    scan_batch(0u, sn);
+  }
+  found = wave_sum_u32(found);
+  if (lane == 0 && found) atomicAdd(a.stats + 3, (unsigned long long)found);
 }
 
 template <int K>
@@ -586,6 +722,7 @@ struct mg_kcounts {
   mg::DevBuf live;    // the sample's gate: the table's, minus the minimizers all of whose k-mers are saturated (mg_kcount_core.h)
   mg::DevBuf sat;     // a bit per entry number: its counter has reached the saturation value
   mg::DevBuf stats;   // u64[4]
+  mg::DevBuf queue, qcount;  // the runs handed from k_count_kmers to k_match_items (grown to the launch that needs most)
   uint64_t n = 0, live_words = 0, sat_words = 0;
   const void* gate = nullptr;  // the table's gate bitmap the live one is reset from (owned by the table: it outlives the counters)
 };
@@ -754,11 +891,32 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const uint64_t ntiles = (nreads + 63) / 64;
   const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
+  // the queue between the two kernels: a region per wavefront of this launch, six runs past the gate per read of its share (a
+  // sample of a table's own genomes, 2 % of whose k-mers are sketched, passes 2.5; a wavefront that fills its region goes on
+  // matching in place)
+  const uint32_t nwaves = grid * kKcWaves;
+  const uint64_t reads_per_wave = ((ntiles + nwaves - 1) / nwaves) * 64;
+  uint32_t qcap = (uint32_t)std::min<uint64_t>(reads_per_wave * 6 + 64, 1u << 24);
+  const bool two = nreads < 0xffffff00ull && dbg("kc_one_kernel") == 0;
+  if (two) {
+    if (kc->queue.bytes < (uint64_t)nwaves * qcap * 16) MG_TRY(kc->queue.alloc((uint64_t)nwaves * qcap * 16));
+    if (kc->qcount.bytes < (uint64_t)nwaves * 4) MG_TRY(kc->qcount.alloc((uint64_t)nwaves * 4));
+  }
   KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
-           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), ix.maxkey, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
-  ProfScope ps("count_kmers");
-  MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
-  MG_HIP(hipGetLastError());
+           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), two ? kc->queue.as<kc_u32x4>() : nullptr,
+           two ? kc->qcount.as<uint32_t>() : nullptr, qcap, ix.maxkey, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
+  {
+    ProfScope ps("count_kmers");
+    MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
+    MG_HIP(hipGetLastError());
+  }
+  if (two && a.ablate != 6u) {
+    ProfScope ps("match_items");
+    KbArgs b{d_bases, d_offsets, kc->queue.as<kc_u32x4>(), kc->qcount.as<uint32_t>(), qcap, nwaves, a.live, a.prim, a.ovf, a.counts, a.sat,
+             a.stats, a.maxkey, a.bmask, a.cs, a.ablate, ix.k};
+    hipLaunchKernelGGL(k_match_items, dim3(std::min<unsigned>(nwaves, (unsigned)c.num_cus * 8)), dim3(256), 0, c.stream, b);
+    MG_HIP(hipGetLastError());
+  }
   return MG_OK;
 }
 

@@ -36,6 +36,21 @@
 #define MG_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  // the same in every lane: say so (an SGPR, scalar branches)
 #endif
 
+// the sample's words that many lanes update (counters, saturation bits, the live gate)
+#ifdef MG_HOST_CHECK
+#define MG_KC_ADD(ptr, v) ((*(ptr) += (v)) - (v))
+#define MG_KC_OR(ptr, v) (*(ptr) |= (v))
+#define MG_KC_AND(ptr, v) (*(ptr) &= (v))
+#define MG_KC_LOAD(ptr) (*(ptr))
+#else
+// (a sample's bits are set by lanes all over the device; each XCD's L2 keeps what it has read: a plain load may see a word as it
+// was long ago — and a k-mer that is saturated be scanned for again and again.  Device-scope loads for those words.)
+#define MG_KC_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MG_KC_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MG_KC_OR(ptr, v) __hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MG_KC_AND(ptr, v) __hip_atomic_fetch_and((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
 namespace mg {
 
 constexpr int kKcM = 15;                     // minimizer length: odd (no m-mer is its own reverse complement), 30 bits
@@ -364,7 +379,7 @@ MG_HD KcEntry kc_entry(const KcIndexView& ix, uint32_t n) {
   return n < nprim ? kc_load_entry(ix.prim, n) : kc_load_entry(ix.ovf, n - nprim);
 }
 
-MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) { return key <= ix.maxkey && ((ix.live[key >> 5] >> (key & 31u)) & 1u); }
+MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) { return key <= ix.maxkey && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u); }
 
 // no "not a base" bit in [p, p + k)
 MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
@@ -376,15 +391,6 @@ MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
   return ((v0 & m0) | (v1 & m1)) == 0u;
 }
 
-#ifdef MG_HOST_CHECK
-#define MG_KC_ADD(ptr, v) ((*(ptr) += (v)) - (v))
-#define MG_KC_OR(ptr, v) (*(ptr) |= (v))
-#define MG_KC_AND(ptr, v) (*(ptr) &= (v))
-#else
-#define MG_KC_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define MG_KC_OR(ptr, v) __hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define MG_KC_AND(ptr, v) __hip_atomic_fetch_and((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#endif
 
 // One table k-mer E against the windows [i1, i2] of the read that starts at stream position p0 (a run that shares E's
 // minimizer).  What every window is tested by is its first sixteen bases against E's two signatures: the bases those tests need
@@ -406,21 +412,29 @@ MG_HD uint32_t kc_scan_run_n(const KcIndexView& ix, const MG_LDS uint32_t* fwd, 
     for (int j = 0; j < NS; ++j) w[j] = (uint32_t)(((((uint64_t)a[j]) << 32 | a[j + 1]) << sh) >> 32);
   }
   const uint32_t sigmask = kc_keep_mask(k, 0);
-  uint32_t found = 0;
+  // the windows whose signature hits are only NOTED in the loop (a run has at most 50) and settled after it, every lane its next
+  // one together: settled where they hit, the lanes of a batch hit at different windows and the wavefront went through the
+  // settling code once per window instead of once or twice
+  uint64_t hits = 0;
   for (uint32_t i = i1; i <= i2; ++i) {
     const uint32_t x0 = w[0] & sigmask;
-    if ((x0 == E.w[0] || x0 == E.sig_rc) && ix.ablate != 4u) {
-      bool ok = true;
-      if constexpr (BAD) ok = kc_window_clean(inv, p0 + i, k);
-      if (ok) {
-        const KcWin x = kc_ext128(fwd, p0 + i, k), y = kc_revcomp(x, k);
-        const KcWin c = kc_less(y, x) ? y : x;
-        found += (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) ? 1u : 0u;
-      }
-    }
+    hits |= (x0 == E.w[0] || x0 == E.sig_rc) ? 1ull << (i - i1) : 0ull;
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j) w[j] = (w[j] << 2) | (w[j + 1] >> 30);
     w[NS - 1] <<= 2;
+  }
+  uint32_t found = 0;
+  if (ix.ablate == 4u) hits = 0;
+  while (hits) {
+    const uint32_t i = i1 + (uint32_t)__builtin_ctzll(hits);
+    hits &= hits - 1;
+    bool ok = true;
+    if constexpr (BAD) ok = kc_window_clean(inv, p0 + i, k);
+    if (ok) {
+      const KcWin x = kc_ext128(fwd, p0 + i, k), y = kc_revcomp(x, k);
+      const KcWin c = kc_less(y, x) ? y : x;
+      found += (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) ? 1u : 0u;
+    }
   }
   return found;
 }
@@ -457,13 +471,119 @@ MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, c
     if (t == 0) novf = E.pad;
     if (t == 1) ovf_at = E.pad;
     if (E.key != key) continue;
-    if ((ix.sat[n >> 5] >> (n & 31u)) & 1u) continue;
+    if ((MG_KC_LOAD(&ix.sat[n >> 5]) >> (n & 31u)) & 1u) continue;
     allsat = false;
     const uint32_t f = kc_scan_run<BAD>(ix, fwd, inv, k, E, p0, i1, i2);
     kc_count_entry(ix, n, E.head, f);
     found += f;
   }
-  if (allsat) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
+  // (a look first: in the second kernel most runs of an abundant genome find the bit cleared already, and an atomic on a word that
+  // a million other lanes are clearing too is the one thing here that queues)
+  if (allsat && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u)) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
+  return found;
+}
+
+
+// ---- the same against the read as it lies in memory (ASCII): the second kernel, k_match_items --------------------------------
+// sixteen ASCII bases at p -> one dword of the stream's packing.  avail: the bytes of the read from p on (past them: 'A').
+MG_HD uint32_t kc_pack16_ascii(const MG_GLB uint8_t* p, int64_t avail, uint32_t& notbase) {
+  uint32_t v[4];
+  if (avail >= 20) {  // aligned dwords around p, funnel-shifted by p's misalignment (at most three bytes past the sixteen are read)
+    const uintptr_t a = (uintptr_t)p;
+    const MG_GLB uint32_t* q = (const MG_GLB uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3u) * 8u;
+    uint32_t d[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) d[j] = q[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sh ? (d[j] >> sh) | (d[j + 1] << (32u - sh)) : d[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x |= ((int64_t)(4 * j + t) < avail ? (uint32_t)p[4 * j + t] : (uint32_t)'A') << (8 * t);
+      v[j] = x;
+    }
+  }
+  return kc_pack16(v, notbase);
+}
+
+// E against the windows [i1, i2] of the read rd[0 .. len): kc_scan_run with the signature registers filled from the read's text;
+// a signature hit reads the window's k bases from the text, every one of which has to be a base.
+template <int NS>
+MG_HD uint32_t kc_scan_ascii_n(const KcIndexView& ix, const MG_GLB uint8_t* rd, uint32_t len, int k, const KcEntry& E, uint32_t i1,
+                               uint32_t i2) {
+  uint32_t w[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    uint32_t nb;
+    w[j] = kc_pack16_ascii(rd + i1 + 16u * (uint32_t)j, (int64_t)len - (int64_t)(i1 + 16u * (uint32_t)j), nb);
+  }
+  const uint32_t sigmask = kc_keep_mask(k, 0);
+  uint64_t hits = 0;  // (noted in the loop, settled after it: kc_scan_run_n)
+  for (uint32_t i = i1; i <= i2; ++i) {
+    const uint32_t x0 = w[0] & sigmask;
+    hits |= (x0 == E.w[0] || x0 == E.sig_rc) ? 1ull << (i - i1) : 0ull;
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j) w[j] = (w[j] << 2) | (w[j + 1] >> 30);
+    w[NS - 1] <<= 2;
+  }
+  uint32_t found = 0;
+  if (ix.ablate == 4u) hits = 0;
+  while (hits) {
+    const uint32_t i = i1 + (uint32_t)__builtin_ctzll(hits);
+    hits &= hits - 1;
+    {
+      KcWin x;
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t nb = 0;
+        x.w[j] = 16 * j < k ? kc_pack16_ascii(rd + i + 16u * (uint32_t)j, (int64_t)len - (int64_t)(i + 16u * (uint32_t)j), nb) & kc_keep_mask(k, j) : 0u;
+      }
+      for (int t = 0; t < k; ++t) {  // (rare: a match, or one window in 2^31)
+        const uint32_t c = (uint32_t)rd[i + (uint32_t)t] & 0xDFu;
+        ok = ok && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+      }
+      if (ok) {
+        const KcWin y = kc_revcomp(x, k);
+        const KcWin c = kc_less(y, x) ? y : x;
+        found += (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) ? 1u : 0u;
+      }
+    }
+  }
+  return found;
+}
+MG_HD uint32_t kc_scan_ascii(const KcIndexView& ix, const MG_GLB uint8_t* rd, uint32_t len, int k, const KcEntry& E, uint32_t i1, uint32_t i2) {
+  const int bits = 2 * (k - kKcM) + 32;
+  if (bits <= 64) return kc_scan_ascii_n<2>(ix, rd, len, k, E, i1, i2);
+  if (bits <= 96) return kc_scan_ascii_n<3>(ix, rd, len, k, E, i1, i2);
+  if (bits <= 128) return kc_scan_ascii_n<4>(ix, rd, len, k, E, i1, i2);
+  return kc_scan_ascii_n<5>(ix, rd, len, k, E, i1, i2);
+}
+
+// kc_match_run for a run that was handed on as (minimizer, read, windows): what a lane of k_match_items does
+MG_HD uint32_t kc_match_item_ascii(const KcIndexView& ix, const MG_GLB uint8_t* rd, uint32_t len, int k, uint32_t key, uint32_t i1,
+                                   uint32_t i2) {
+  const uint32_t b = key & ix.bmask, nprim = 2u * (ix.bmask + 1u);
+  uint32_t found = 0, novf = 0, ovf_at = 0;
+  bool allsat = ix.cs != 0u;
+  for (uint32_t t = 0; t < 2u + novf; ++t) {
+    const uint32_t n = t < 2u ? 2u * b + t : nprim + ovf_at + (t - 2u);
+    const KcEntry E = kc_entry(ix, n);
+    if (t == 0) novf = E.pad;
+    if (t == 1) ovf_at = E.pad;
+    if (E.key != key) continue;
+    if ((MG_KC_LOAD(&ix.sat[n >> 5]) >> (n & 31u)) & 1u) continue;
+    allsat = false;
+    const uint32_t f = kc_scan_ascii(ix, rd, len, k, E, i1, i2);
+    kc_count_entry(ix, n, E.head, f);
+    found += f;
+  }
+  // (a look first: in the second kernel most runs of an abundant genome find the bit cleared already, and an atomic on a word that
+  // a million other lanes are clearing too is the one thing here that queues)
+  if (allsat && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u)) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
   return found;
 }
 

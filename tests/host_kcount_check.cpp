@@ -5,10 +5,11 @@
 // the oracle (tests/test_kcount_core_host.py).  What is NOT covered here is the wavefront glue of mg_kcount.hip (LDS addresses,
 // ballots, the drain's batches, atomics): the GPU tests hold that to the same oracle.
 //
-// stdin:  "k cap ntable nreads lead cs\n", then ntable lines with a table k-mer each (ACGT, any strand), then nreads lines with a
+// stdin:  "k cap ntable nreads lead cs ascii\n", then ntable lines with a table k-mer each (ACGT, any strand), then nreads lines with a
 //         read each (anything; may be empty).  cap = slots of a lane's event list (small values force restarts); lead = bytes
 //         in front of the first read in the buffer (the tile then starts off a 16-byte boundary); cs = the counters' saturation
-//         value (0: exact counts; else a k-mer seen cs times is skipped from then on and its minimizer marked done).
+//         value (0: exact counts; else a k-mer seen cs times is skipped from then on and its minimizer marked done); ascii = 1:
+//         runs past the gate are matched from the reads' text (kc_match_item_ascii), as the kernel's second half does.
 // stdout: one line per table k-mer: the number of windows of the reads whose canonical k-mer equals its canonical form;
 //         then "kmers N runs R passed P restarts S".
 #define MG_HOST_CHECK 1
@@ -27,6 +28,7 @@ using namespace mg;
 
 static int g_cap = 12;
 static uint32_t g_cs = 0;  // counters saturate here (0: exact); > 0 exercises the "done" marks
+static int g_ascii = 0;    // 1: a run past the gate is matched from the read's TEXT (kc_match_item_ascii: the second kernel's way)
 
 struct HostOut {
   static constexpr uint32_t kCap = 0;  // (not used: the capacity is a run-time value here, see below)
@@ -143,7 +145,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
     }
     const uint64_t t_beg = beg[0];
     if (maxlen < (uint64_t)K) continue;
-    auto drain_and_walk = [&](const uint32_t* p0, const uint32_t* len, uint32_t mlen, int mode) {
+    auto drain_and_walk = [&](const uint32_t* p0, const uint32_t* len, uint32_t mlen, int mode, bool regular = false) {
       const uint32_t nwmax = mlen - K + 1;
       uint32_t w0 = 0;
       bool first_call = true;
@@ -170,7 +172,8 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
             ++runs;
             if (!kc_gate(view, key)) continue;
             ++passed;
-            if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
+            if (g_ascii && regular) kc_match_item_ascii(view, bases.data() + beg[l], (uint32_t)(end[l] - beg[l]), K, key, i1, i2);
+            else if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
             else kc_match_run<false>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
           }
         w0 = next;
@@ -205,7 +208,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
         ragged = ragged || len[l] != maxlen;
         kmers += bad ? kc_clean_windows(inv.data(), p0[l], len[l], (uint32_t)maxlen, K) : (len[l] >= (uint32_t)K ? len[l] - K + 1 : 0);
       }
-      drain_and_walk(p0, len, (uint32_t)maxlen, bad ? 0 : (ragged ? 2 : 1));
+      drain_and_walk(p0, len, (uint32_t)maxlen, bad ? 0 : (ragged ? 2 : 1), true);
     } else {
       const uint32_t per = (sd * 16u / 64u) & ~15u;
       const uint32_t ch = per < 1008u ? per : 1008u, stride = ch - K + 1;
@@ -265,7 +268,7 @@ int main() {
   std::string line;
   std::getline(std::cin, line);
   int cs = 0;
-  if (std::sscanf(line.c_str(), "%d %d %d %d %d %d", &k, &g_cap, &ntable, &nreads, &lead, &cs) != 6) return 2;
+  if (std::sscanf(line.c_str(), "%d %d %d %d %d %d %d", &k, &g_cap, &ntable, &nreads, &lead, &cs, &g_ascii) != 7) return 2;
   g_cs = (uint32_t)cs;
   std::vector<std::string> table(ntable), reads(nreads);
   for (auto& t : table) std::getline(std::cin, t);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of k_count_kmers on the probe's workload (own rocprofv3 passes: --pmc with --kernel-trace only).
-# Usage: bash tools/kcount_pmc.sh <tag> [probe args]   -> gpurun_out/r06/kcount_pmc_<tag>.txt
+# Usage: [KERNEL=k_match_items] bash tools/kcount_pmc.sh <tag> [probe args]   -> gpurun_out/r06/kcount_pmc_<tag>.txt
 set -u
 TAG=${1:-x}; shift
 OUT=gpurun_out/r06/kcount_pmc_$TAG
@@ -12,13 +12,13 @@ for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_S
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INSTS_FLAT SQ_ACTIVE_INST_FLAT"; do
   rm -rf "$OUT/raw"
   rocprofv3 --output-format csv --pmc $SET --kernel-trace -d "$OUT/raw" -o run -- python3 tools/kcount_probe.py --no_hash_path --reps 2 "$@" > "$OUT/log.txt" 2>&1
-  python3 - "$OUT" >> "$OUT.txt" <<'PY'
+  python3 - "$OUT" "${KERNEL:-k_count_kmers}" >> "$OUT.txt" <<'PY'
 import csv, glob, sys
-out = sys.argv[1]
+out, kern = sys.argv[1], sys.argv[2]
 f = glob.glob(out + "/raw/**/*counter_collection.csv", recursive=True)
 acc = {}
 for r in csv.DictReader(open(f[0])):
-    if "k_count_kmers" not in r["Kernel_Name"]:
+    if kern not in r["Kernel_Name"]:
         continue
     a = acc.setdefault(r["Counter_Name"], [0, 0.0])
     a[0] += 1; a[1] += float(r["Counter_Value"])
