@@ -350,11 +350,13 @@ namespace mg {
 // mg_kcount_core.h): built once per table on the device from the pairs' k-mers.
 struct KmerIndex {
   int k = 0;
-  uint64_t ndistinct = 0, nbuckets = 0;
-  uint32_t maxkey = 0;   // the largest minimizer of the table (the gate and a sample's "done" bits are read up to it)
-  uint32_t bmask = 0;    // bucket of a minimizer = key & bmask (its LOW bits: a minimum's high bits are nearly all zero)
-  DevBuf gate;           // bits over the minimizer values up to maxkey: some k-mer of the table has this minimizer
-  DevBuf prim;           // KcEntry[2 x nbuckets]: a bucket's first two entries (mg_kcount_core.h: KcIndexView)
+  uint64_t ndistinct = 0, nentries = 0, nbuckets = 0;  // (entries: a k-mer filed under several hashes has one for each)
+  uint32_t gbits = 0;    // the gate has 2^gbits bits: a hash's bit is number hash >> (32 - gbits)
+  uint64_t gate_words = 0;
+  uint32_t bmask = 0;    // bucket of a hash = hash & bmask
+  DevBuf gate;           // some k-mer of the table is filed under a hash with these leading bits
+  DevBuf shared;         // ... and two different such hashes have them (a sample never clears that bit of its copy of the gate)
+  DevBuf prim;           // KcEntry[4 x nbuckets]: a bucket's first four entries (mg_kcount_core.h: KcIndexView)
   DevBuf ovf;            // KcEntry[novf + 1]: the later ones
   uint64_t novf = 0;
   DevBuf head;           // u32[npairs]: the pair whose counter holds the occurrences of this pair's k-mer

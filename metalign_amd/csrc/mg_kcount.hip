@@ -51,7 +51,7 @@ __global__ void k_kc_heads(const uint64_t* __restrict__ hi, const uint64_t* __re
 __global__ void k_kc_distinct(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, const uint32_t* __restrict__ order,
                               const uint32_t* __restrict__ flag, const uint64_t* __restrict__ before, uint64_t n, int k,
                               uint64_t* __restrict__ dhi, uint64_t* __restrict__ dlo, uint32_t* __restrict__ dhead,
-                              uint64_t* __restrict__ dkey, uint32_t* __restrict__ iota) {
+                              uint32_t* __restrict__ nkeys) {
   KC_FOR(j, n) {
     if (!flag[j]) continue;
     const uint64_t id = before[j];
@@ -59,33 +59,46 @@ __global__ void k_kc_distinct(const uint64_t* __restrict__ hi, const uint64_t* _
     dhi[id] = hi[j];
     dlo[id] = lo[j];
     dhead[id] = order[j];
-    dkey[id] = kc_minimizer(x, k);  // (the caller turns it into the sort key: bucket above the minimizer)
-    iota[id] = (uint32_t)id;
+    uint32_t keys[kKcMaxCands];
+    nkeys[id] = (uint32_t)kc_table_keys(x, k, keys);  // (entries it will have: one per hash it is filed under)
+  }
+}
+// distinct k-mer id -> its entries' sort keys (bucket = the hash's low bits, above the hash) and itself, from kbefore[id] on
+__global__ void k_kc_emit_keys(const uint64_t* __restrict__ dhi, const uint64_t* __restrict__ dlo, const uint64_t* __restrict__ kbefore,
+                               uint64_t nd, int k, uint32_t bmask, uint64_t* __restrict__ ekey, uint32_t* __restrict__ eid) {
+  KC_FOR(id, nd) {
+    const KcWin x{{(uint32_t)(dhi[id] >> 32), (uint32_t)dhi[id], (uint32_t)(dlo[id] >> 32), (uint32_t)dlo[id]}};
+    uint32_t keys[kKcMaxCands];
+    const int n = kc_table_keys(x, k, keys);
+    for (int t = 0; t < n; ++t) {
+      ekey[kbefore[id] + (uint64_t)t] = ((uint64_t)(keys[t] & bmask) << 32) | keys[t];
+      eid[kbefore[id] + (uint64_t)t] = (uint32_t)id;
+    }
   }
 }
 __global__ void k_kc_pair_heads(const uint32_t* __restrict__ order, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ before,
                                 const uint32_t* __restrict__ dhead, uint64_t n, uint32_t* __restrict__ head) {
   KC_FOR(j, n) head[order[j]] = dhead[before[j] + flag[j] - 1];
 }
-// the sort key of a distinct k-mer: its bucket (the minimizer's low bits) above the minimizer itself
-__global__ void k_kc_bucket_keys(uint64_t* __restrict__ dkey, uint64_t nd, uint32_t bmask) {
-  KC_FOR(i, nd) dkey[i] = ((dkey[i] & bmask) << 32) | dkey[i];
-}
-// entry j = distinct k-mer perm[j] (ascending by bucket, then minimizer); its gate bit
+// entry j = distinct k-mer perm[j] under the hash in skey[j] (ascending by bucket, then hash); the hash's gate bit — and, when a
+// DIFFERENT hash has set it before, its `shared` bit (equal hashes are adjacent: the first of them speaks for all)
 __global__ void k_kc_entries(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ dhi,
-                             const uint64_t* __restrict__ dlo, const uint32_t* __restrict__ dhead, uint64_t nd, int k,
-                             KcEntry* __restrict__ ent, uint32_t* __restrict__ gate) {
+                             const uint64_t* __restrict__ dlo, const uint32_t* __restrict__ dhead, uint64_t nd, int k, uint32_t gshift,
+                             KcEntry* __restrict__ ent, uint32_t* __restrict__ gate, uint32_t* __restrict__ shared) {
   KC_FOR(j, nd) {
     const uint32_t id = perm[j];
     const uint64_t h = dhi[id], l = dlo[id];
     KcEntry e;
     e.w[0] = (uint32_t)(h >> 32); e.w[1] = (uint32_t)h; e.w[2] = (uint32_t)(l >> 32); e.w[3] = (uint32_t)l;
     e.head = dhead[id];
-    e.key = (uint32_t)skey[j];  // (the low word of the sort key: the minimizer)
+    e.key = (uint32_t)skey[j];  // (the low word of the sort key: the hash)
     e.sig_rc = kc_revcomp(KcWin{{e.w[0], e.w[1], e.w[2], e.w[3]}}, k).w[0];
     e.pad = 0;
     ent[j] = e;
-    atomicOr(&gate[e.key >> 5], 1u << (e.key & 31u));
+    if (j == 0 || skey[j - 1] != skey[j]) {
+      const uint32_t g = e.key >> gshift, bit = 1u << (g & 31u);
+      if (atomicOr(&gate[g >> 5], bit) & bit) atomicOr(&shared[g >> 5], bit);
+    }
   }
 }
 // offs[b] = first entry whose bucket (the high word of its sort key) is >= b; offs[nb] = nd
@@ -96,37 +109,32 @@ __global__ void k_kc_offsets(const uint64_t* __restrict__ skey, uint64_t nd, uin
     for (uint64_t b = first; b <= last; ++b) offs[b] = (uint32_t)j;
   }
 }
-// bucket b (entries offs[b] .. offs[b + 1]) has this many entries beyond its two slots in prim
+// bucket b (entries offs[b] .. offs[b + 1]) has this many entries beyond its kKcSlots slots in prim
 __global__ void k_kc_extra(const uint32_t* __restrict__ offs, uint64_t nb, uint32_t* __restrict__ extra) {
   KC_FOR(b, nb) {
     const uint32_t n = offs[b + 1] - offs[b];
-    extra[b] = n > 2u ? n - 2u : 0u;
+    extra[b] = n > kKcSlots ? n - kKcSlots : 0u;
   }
 }
-// ... its first two go to prim (an unused slot: key kKcNone), the rest to ovf from before[b] on; the bucket's first slot says
-// how many there are, its second where
+// ... its first kKcSlots go to prim (an unused slot: key kKcNone), the rest to ovf from before[b] on; the bucket's first slot
+// says how many there are, its second where
 __global__ void k_kc_place(const KcEntry* __restrict__ ent, const uint32_t* __restrict__ offs, const uint64_t* __restrict__ before,
                            uint64_t nb, KcEntry* __restrict__ prim, KcEntry* __restrict__ ovf) {
   KC_FOR(b, nb) {
     const uint32_t lo = offs[b], n = offs[b + 1] - lo;
     KcEntry none;
     none.w[0] = none.w[1] = none.w[2] = none.w[3] = 0; none.head = 0; none.key = kKcNone; none.sig_rc = 0; none.pad = 0;
-    KcEntry e0 = n > 0 ? ent[lo] : none, e1 = n > 1 ? ent[lo + 1] : none;
-    e0.pad = n > 2u ? n - 2u : 0u;
-    e1.pad = (uint32_t)before[b];
-    prim[2 * b] = e0;
-    prim[2 * b + 1] = e1;
-    for (uint32_t t = 2; t < n; ++t) {
+    for (uint32_t t = 0; t < kKcSlots; ++t) {
+      KcEntry e = t < n ? ent[lo + t] : none;
+      e.pad = t == 0 ? (n > kKcSlots ? n - kKcSlots : 0u) : (t == 1 ? (uint32_t)before[b] : 0u);
+      prim[kKcSlots * b + t] = e;
+    }
+    for (uint32_t t = kKcSlots; t < n; ++t) {
       KcEntry e = ent[lo + t];
       e.pad = 0;
-      ovf[before[b] + (t - 2u)] = e;
+      ovf[before[b] + (t - kKcSlots)] = e;
     }
   }
-}
-__global__ void k_kc_max_key(const uint64_t* __restrict__ dkey, uint64_t nd, uint32_t* __restrict__ out) {
-  uint32_t m = 0;
-  KC_FOR(i, nd) m = (uint32_t)dkey[i] > m ? (uint32_t)dkey[i] : m;
-  if (m) atomicMax(out, m);
 }
 __global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ head, uint64_t n, uint32_t cs,
                               uint32_t* __restrict__ out) {
@@ -147,7 +155,7 @@ __global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_
 #endif
 constexpr int kKcWaves = MG_KC_WAVES;    // wavefronts per workgroup (each works alone)
 constexpr uint32_t kKcListCap = MG_KC_LIST_CAP;  // closed runs a lane can hold before the lists are emptied (150 bp, k = 51: six per read)
-constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for a full batch
+constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for a look-up of up to 127 (hitq), items waiting for a scan of 64 (scanq)
 constexpr uint32_t kKcSlack = 8;         // dwords a k-mer taken at the end of the stream may read past it
 
 // LDS of one wavefront (bytes), for a stage of sd dwords (sd a multiple of 64)
@@ -170,17 +178,13 @@ struct KcArgs {
   const uint64_t* offsets;
   uint64_t nreads;
   uint32_t* live;
+  const uint32_t* shared;
   const KcEntry* prim;
   const KcEntry* ovf;
   uint32_t* counts;
   uint32_t* sat;
   unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the sample's gate, [3] matches counted
-  // the runs past the gate are handed on to k_match_items: a region of `qcap` 16-byte items per wavefront of this launch
-  // (minimizer, windows, read, -), how many it wrote in qcount[wavefront]; a wavefront whose region is full matches in place
-  kc_u32x4* queue;
-  uint32_t* qcount;
-  uint32_t qcap;
-  uint32_t maxkey, bmask, sd, cs, ablate, stagger;  // ablate (knob kc_ablate, measurements only): 1 = the lists are dropped, 2 = ... after the gate
+  uint32_t gshift, bmask, sd, cs, ablate, stagger;  // ablate (knob kc_ablate, measurements only): 1 = the lists are dropped, 2 = ... after the gate
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -204,24 +208,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // The lists of a wavefront, in three phases that each keep all 64 lanes on one kind of work and wait for memory ONCE per batch:
 //   gate    every closed run's minimizer against ONE bit of the sample's gate (the table's gate minus the minimizers whose k-mers
 //           are all saturated); the runs that pass are compacted (ballot + popcount) into `hitq`;
-//   lookup  64 runs at a time: the run's bucket — one 64-byte line, two entries — and the saturation bits of its two entry
-//           numbers, requested together; an entry with the run's minimizer whose bit is clear becomes an ITEM (run, entry
-//           number) in `scanq`; a bucket's later entries (one bucket in a dozen has any) are walked by the lanes that have
-//           them; a run all of whose entries are saturated clears its minimizer's bit in the sample's gate: at a metagenome's
-//           coverage most runs of an abundant genome stop at the gate from then on;
+//   lookup  up to 128 runs at a time, two to a lane: the run's bucket — one 128-byte line, four entries — and the saturation
+//           bits of its four entry numbers, all requested together; an entry with the run's minimizer whose bit is clear becomes
+//           an ITEM (run, entry number) in `scanq`; a bucket's later entries (one bucket in a thousand has any) are walked by
+//           the lanes that have them; a run all of whose entries are saturated clears its minimizer's bit in the sample's gate:
+//           at a metagenome's coverage most runs of an abundant genome stop at the gate from then on;
 //   scan    64 items at a time: kc_scan_run (registers only), ONE add per item that matched.
-// The usual kernel stops after the gate: the runs that pass are HANDED ON — (minimizer, windows, read) into this wavefront's
-// region of a queue in device memory — and a second kernel (k_match_items), whose lanes need neither this kernel's registers
-// nor its LDS and so run sixteen wavefronts to a SIMD where this one runs three, does lookup and scan from the reads' text:
-// those phases wait for memory, this kernel's walk keeps the vector units busy, and side by side neither waits for the other.
-// Lookup and scan stay here for what cannot be handed on (a full region; the chunks of a long read, whose windows are numbered
-// within the chunk).
 // One copy of this code per translation unit, CALLED where nothing of the walk is live
-// (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20 (eleven bits) | match here << 31).
-__device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB KcEntry* prim, const MG_GLB KcEntry* ovf,
-                                                   MG_GLB uint32_t* counts, MG_GLB uint32_t* sat, MG_GLB kc_u32x4* region, uint32_t qcap,
-                                                   uint32_t read0, uint32_t maxkey, uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt,
-                                                   uint32_t limit) {
+// (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
+__device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB uint32_t* shared, const MG_GLB KcEntry* prim,
+                                                   const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* sat, uint32_t gshift,
+                                                   uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
   const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
@@ -232,10 +229,8 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   MG_LDS unsigned long long* scanq = (MG_LDS unsigned long long*)(size_t)(lds + L.scanq);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
   const uint32_t ablate = (cfg >> 17) & 7u;
-  const KcIndexView ix{live, prim, ovf, counts, sat, (1u << (cfg & 0xffu)) - 1u, maxkey, (cfg >> 20) & 0x7ffu, ablate};
-  const bool hand_on = region != nullptr && !(cfg >> 31);
-  uint32_t cursor = stat[3];  // items this wavefront has handed on so far
-  const uint32_t nprim = 2u * (ix.bmask + 1u);
+  const KcIndexView ix{live, shared, prim, ovf, counts, sat, (1u << (cfg & 0xffu)) - 1u, gshift, cfg >> 20, ablate};
+  const uint32_t nprim = kKcSlots * (ix.bmask + 1u);
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
   if (ablate == 1u) return;
@@ -271,66 +266,81 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
     }
   };
 
+  // up to 128 runs past the gate, two to a lane: their buckets' lines and saturation words are all requested before any is
+  // looked at — one round trip to memory for the lot (a tile of 150 bp reads leaves 80 to 110 such runs: one call).  What is
+  // kept of a bucket is its four minimizers and the two words about its overflow; the loops below are ROLLED (one copy of the
+  // compaction and of the scan they may trigger: the drain's code is fetched once per tile, it must stay small).
   auto lookup_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
-    const bool active = (uint32_t)lane < n;
-    uint32_t key = kKcNone, info = 0, num0 = 0, k0 = ~0u, k1 = ~0u, satw = 0, novf = 0, ovf_at = 0;
-    if (active) {
-      const unsigned long long ev = q[lane];
-      key = (uint32_t)ev;
-      info = (uint32_t)(ev >> 32);
-      num0 = 2u * (key & ix.bmask);
-      // (key and pad of the bucket's two entries: one 16-byte load each out of the same 64-byte line; the words of an entry
-      // are read again, by the scan, only for the few that are scanned)
-      const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0);
-      const kc_u32x4 e0 = p[1], e1 = p[3];
-      satw = MG_KC_LOAD(&ix.sat[num0 >> 5]);
-      k0 = e0.y; novf = e0.w;
-      k1 = e1.y; ovf_at = e1.w;
-    }
-    const uint32_t sbit = num0 & 31u;  // (num0 is even: both bits are in the same word)
-    const bool m0 = active && k0 == key, m1 = active && k1 == key;
-    const bool u0 = m0 && !((satw >> sbit) & 1u), u1 = m1 && !((satw >> (sbit + 1u)) & 1u);
-    bool allsat = ix.cs != 0u && !u0 && !u1;
-    push_item(u0, info, num0);
-    push_item(u1, info, num0 + 1u);
-    // the bucket's later entries: minimizer, then the bit, then the next one (a lane in a dozen has any; two are rare)
-    if (!active) novf = 0;
-    for (uint32_t t = 0; __ballot(t < novf) != 0ull; ++t) {
-      const uint32_t num = nprim + ovf_at + t;
-      bool want = false;
-      if (t < novf) {
-        const kc_u32x4 e = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (ovf_at + t))[1];
-        if (e.y == key) want = !((MG_KC_LOAD(&ix.sat[num >> 5]) >> (num & 31u)) & 1u);
+    constexpr int J = 2;
+    uint32_t key[J], info[J], num0[J], satw[J], ek[J][kKcSlots], novf[J], ovf_at[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const uint32_t at = (uint32_t)lane + 64u * (uint32_t)j;
+      key[j] = kKcNone; info[j] = 0; num0[j] = 0; satw[j] = 0; novf[j] = 0; ovf_at[j] = 0;
+#pragma unroll
+      for (uint32_t t = 0; t < kKcSlots; ++t) ek[j][t] = ~0u;
+      if (at < n) {
+        const unsigned long long ev = q[at];
+        key[j] = (uint32_t)ev;
+        info[j] = (uint32_t)(ev >> 32);
+        num0[j] = kKcSlots * (key[j] & ix.bmask);
+        // (head | minimizer | signature | pad of the bucket's entries: the second 16 bytes of each, out of one 128-byte line; an
+        // entry's words are read again, by the scan, only for the few that are scanned)
+        const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0[j]);
+        kc_u32x4 e[kKcSlots];
+#pragma unroll
+        for (uint32_t t = 0; t < kKcSlots; ++t) e[t] = p[2u * t + 1u];
+        satw[j] = MG_KC_LOAD(&ix.sat[num0[j] >> 5]);
+#pragma unroll
+        for (uint32_t t = 0; t < kKcSlots; ++t) ek[j][t] = e[t].y;
+        novf[j] = e[0].w;
+        ovf_at[j] = e[1].w;
       }
-      allsat = allsat && !want;
-      push_item(want, info, num);
     }
-    if (active && allsat) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));  // (it was set a moment ago: this run passed the gate)
-  };
-
-  // 64 (or the last few) runs past the gate: handed on, or — no room, or not that kind of tile — matched here
-  auto settle = [&](const MG_LDS unsigned long long* q, uint32_t n) {
-    if (hand_on && cursor + n <= qcap) {
-      if ((uint32_t)lane < n) {
-        const unsigned long long ev = q[lane];
-        const uint32_t info = (uint32_t)(ev >> 32);
-        kc_u32x4 it;
-        it.x = (uint32_t)ev; it.y = info & 0xfffffu; it.z = read0 + ((info >> 20) & 63u); it.w = 0u;
-        region[cursor + (uint32_t)lane] = it;
+#pragma unroll 1
+    for (int j = 0; j < J; ++j) {
+      const uint32_t kj = j ? key[1] : key[0], ij = j ? info[1] : info[0], nj = j ? num0[1] : num0[0], sj = j ? satw[1] : satw[0];
+      const bool active = kj != kKcNone;
+      const uint32_t sbit = nj & 31u;  // (a multiple of four: the bucket's bits are in one word)
+      bool any = false, open = false;  // an entry filed under the run's hash; one of them not saturated
+#pragma unroll 1
+      for (uint32_t t = 0; t < kKcSlots; ++t) {
+        const uint32_t e0 = j ? ek[1][0] : ek[0][0], e1 = j ? ek[1][1] : ek[0][1], e2 = j ? ek[1][2] : ek[0][2], e3 = j ? ek[1][3] : ek[0][3];
+        const uint32_t et = t == 0 ? e0 : (t == 1 ? e1 : (t == 2 ? e2 : e3));
+        const bool mine = active && et == kj, want = mine && !((sj >> (sbit + t)) & 1u);
+        any = any || mine;
+        open = open || want;
+        push_item(want, ij, nj + t);
       }
-      cursor += n;
-    } else {
-      lookup_batch(q, n);
+      // the bucket's later entries (one bucket in a thousand has any): minimizer, then the bit, then the next one
+      const uint32_t nv = active ? (j ? novf[1] : novf[0]) : 0u, oa = j ? ovf_at[1] : ovf_at[0];
+      for (uint32_t t = 0; __ballot(t < nv) != 0ull; ++t) {
+        const uint32_t num = nprim + oa + t;
+        bool want = false;
+        if (t < nv) {
+          const kc_u32x4 x = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (oa + t))[1];
+          if (x.y == kj) { any = true; want = !((MG_KC_LOAD(&ix.sat[num >> 5]) >> (num & 31u)) & 1u); }
+        }
+        open = open || want;
+        push_item(want, ij, num);
+      }
+      // every k-mer filed under this hash is saturated: its runs stop at the gate from now on — unless another hash of the table
+      // has the same bit (a run that such a bit let through found no entry of its own: not its bit to clear)
+      if (ix.cs != 0u && any && !open) {
+        const uint32_t g = kj >> ix.gshift;
+        if (!((ix.shared[g >> 5] >> (g & 31u)) & 1u)) MG_KC_AND(&ix.live[g >> 5], ~(1u << (g & 31u)));
+      }
     }
   };
 
   const uint32_t maxc = wave_max_u32(cnt);
+  const uint32_t myp0 = p0s[lane];
   const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
-  for (uint32_t s0 = 0; s0 < maxc; s0 += 4) {
-    unsigned long long ev[4];
-    uint32_t gw[4];
+  for (uint32_t s0 = 0; s0 < maxc; s0 += 8) {  // (eight runs of a lane per round trip: a 150 bp read has six)
+    unsigned long long ev[8];
+    uint32_t gw[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       ev[j] = (unsigned long long)kKcNone;
       if (s0 + j < cnt) ev[j] = lists[(s0 + j) * 64u + (uint32_t)lane];
       if (clip) {  // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
@@ -339,34 +349,35 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
         else if (i2 >= limit) ev[j] = (ev[j] & ~(1023ull << 42)) | ((unsigned long long)(limit - 1u) << 42);
       }
     }
+    // a run's word says where its candidate starts: the bases around it, hashed, are what the table files k-mers under
+    uint32_t hk[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t key = (uint32_t)ev[j];
-      gw[j] = key <= maxkey ? MG_KC_LOAD(&live[key >> 5]) : 0u;  // (kKcNone is above every key)
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t word = (uint32_t)ev[j];
+      hk[j] = kc_run_hash(fwd, myp0, word, k);
+      gw[j] = word != kKcNone ? MG_KC_LOAD(&live[(hk[j] >> gshift) >> 5]) : 0u;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t key = (uint32_t)ev[j];
-      nev += key != kKcNone ? 1u : 0u;
-      const bool pass = (gw[j] >> (key & 31u)) & 1u;
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t word = (uint32_t)ev[j];
+      nev += word != kKcNone ? 1u : 0u;
+      const bool pass = (gw[j] >> ((hk[j] >> gshift) & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
       if (m == 0ull) continue;
-      if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = ev[j] | ((unsigned long long)lane << 52);
+      if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = (unsigned long long)hk[j] | (ev[j] & 0xffffffff00000000ull) | ((unsigned long long)lane << 52);
       hn += (uint32_t)__popcll(m);
       npass += pass ? 1u : 0u;
-      if (hn >= 64u && ablate != 2u) {
+      if (hn >= 64u) {  // (room for one more push of 64 must stay)
         wave_lds_sync();
-        hn -= 64u;
 #ifdef MG_KC_CLOCKS
         const uint64_t h0 = __builtin_readcyclecounter();
 #endif
-        settle(hitq + hn, 64u);
+        if (ablate != 2u) lookup_batch(hitq, hn);
 #ifdef MG_KC_CLOCKS
         clk_hits += __builtin_readcyclecounter() - h0;
 #endif
+        hn = 0;
         wave_lds_sync();
-      } else if (hn >= 64u) {
-        hn -= 64u;
       }
     }
   }
@@ -376,7 +387,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 #endif
     if (hn) {
       wave_lds_sync();
-      settle(hitq, hn);
+      lookup_batch(hitq, hn);
     }
     if (sn) {
       wave_lds_sync();
@@ -390,7 +401,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   // (the wavefront's totals stay in LDS until the kernel ends: an atomic per call on three global words that every wavefront
   // shares was most of the kernel's time — 31 k calls per 2M reads, each queueing behind the others at the memory side)
   nev = wave_sum_u32(nev); npass = wave_sum_u32(npass); found = wave_sum_u32(found);
-  if (lane == 0) { stat[0] += nev; stat[1] += npass; stat[2] += found; stat[3] = cursor; }
+  if (lane == 0) { stat[0] += nev; stat[1] += npass; stat[2] += found; }
 #ifdef MG_KC_CLOCKS
   if (lane == 0) { stat[4] += (uint32_t)((__builtin_readcyclecounter() - clk0) >> 6); stat[5] += (uint32_t)(clk_hits >> 6); stat[11] += 1; }
 #endif
@@ -400,21 +411,20 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 struct KcDevOut {
   MG_LDS unsigned long long* mine;  // this lane's column of the lists (slot s at mine[s * 64]): key | info << 32
   uint32_t* live;
+  const uint32_t* shared;
   const KcEntry* prim;
   const KcEntry* ovf;
   uint32_t* counts;
   uint32_t* sat;
-  kc_u32x4* region;
-  uint32_t qcap, read0;
-  uint32_t maxkey, cfg, lds, sd;
+  uint32_t gshift, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t key, uint32_t info) { mine[slot * 64u] = (unsigned long long)key | ((unsigned long long)info << 32); }
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
 #ifdef MG_KC_NO_DRAIN  // (ISA inspection: what the walks need by themselves)
     return;
 #endif
     wave_lds_sync();
-    kc_drain((MG_GLB uint32_t*)live, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf, (MG_GLB uint32_t*)counts,
-             (MG_GLB uint32_t*)sat, (MG_GLB kc_u32x4*)region, qcap, read0, maxkey, cfg, lds, sd, cnt, limit);
+    kc_drain((MG_GLB uint32_t*)live, (const MG_GLB uint32_t*)shared, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf,
+             (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)sat, gshift, cfg, lds, sd, cnt, limit);
     wave_lds_sync();
   }
   static constexpr uint32_t kCap = kKcListCap;
@@ -459,8 +469,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
   MG_LDS uint32_t* p0s = (MG_LDS uint32_t*)(base + L.p0s);
   MG_LDS unsigned long long* lists = (MG_LDS unsigned long long*)(base + L.lists);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(base + L.stat);
-  const uint32_t cfg0 = (uint32_t)__builtin_popcount(a.bmask) | ((uint32_t)K << 8) | ((a.ablate & 7u) << 17) | ((a.cs > 2047u ? 0u : a.cs) << 20);
-  kc_u32x4* region = a.queue ? a.queue + (size_t)((uint64_t)blockIdx.x * kKcWaves + wave) * a.qcap : nullptr;
+  const uint32_t cfg0 = (uint32_t)__builtin_popcount(a.bmask) | ((uint32_t)K << 8) | ((a.ablate & 7u) << 17) | ((a.cs > 4095u ? 0u : a.cs) << 20);
   uint32_t kmers = 0;
   if (lane < 12) stat[lane] = 0;
   wave_lds_sync();
@@ -539,8 +548,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t p0 = rd < a.nreads ? (uint32_t)(shift + (beg - t_beg)) : 0u;  // (a lane without a read walks the tile's first bases, masked)
       p0s[lane] = p0;
       wave_lds_sync();
-      KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, region, a.qcap, (uint32_t)(tile * 64), a.maxkey,
-                   cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
+      KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.sat, a.gshift, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
       kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
           inv16[gidx ^ 1u] = (uint16_t)kc_notbase16(vv);
         }
         wave_lds_sync();
-        KcDevOut out{lists + lane, a.live, a.prim, a.ovf, a.counts, a.sat, nullptr, 0u, 0u, a.maxkey, cfg0 | (1u << 16) | (1u << 31), lds, a.sd};
+        KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.sat, a.gshift, cfg0 | (1u << 16), lds, a.sd};
         const uint32_t cmax = wave_max_u32(clen);
         kmers += kc_clean_windows(inv, p0, clen, cmax, K);
         kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
@@ -587,112 +595,11 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
   wave_lds_sync();
   if (lane == 0 && total) atomicAdd(a.stats, (unsigned long long)total);
   if (lane >= 1 && lane < 4 && stat[lane - 1]) atomicAdd(a.stats + lane, (unsigned long long)stat[lane - 1]);
-  if (lane == 0 && a.qcount) a.qcount[(uint64_t)blockIdx.x * kKcWaves + wave] = stat[3];
 #ifdef MG_KC_CLOCKS
   if (lane == 0) stat[6] = (uint32_t)((__builtin_readcyclecounter() - kclk0) >> 6);
   wave_lds_sync();
   if (lane >= 4 && lane < 12) atomicAdd(a.stats + lane, (unsigned long long)stat[lane]);
 #endif
-}
-
-// The second half: the runs the first kernel handed on against their buckets, from the reads' text (what a lane computes for its
-// run is stated in mg_kcount_core.h: kc_match_item_ascii).  A workgroup takes the regions of the queue in turn.
-struct KbArgs {
-  const uint8_t* bases;
-  const uint64_t* offsets;
-  const kc_u32x4* queue;
-  const uint32_t* qcount;
-  uint32_t qcap, nregions;
-  uint32_t* live;
-  const KcEntry* prim;
-  const KcEntry* ovf;
-  uint32_t* counts;
-  uint32_t* sat;
-  unsigned long long* stats;
-  uint32_t maxkey, bmask, cs, ablate;
-  int k;
-};
-// A wavefront takes 64 items at a time through the lookup (the bucket's line and the saturation word, one round trip for all
-// 64) and compacts the (item, entry number) combinations that have to be SCANNED — an entry with the run's minimizer that is not
-// saturated: one item in ten at a metagenome's coverage — into a queue of its own in LDS; scans run 64 to a batch.  (Lane per
-// item all the way — lookup and scan in one loop — cost 5700 vector instructions per 64 items: one or two lanes of every
-// wavefront scanning, the others waiting.)
-__global__ __launch_bounds__(256) void k_match_items(const KbArgs a) {
-  __shared__ unsigned long long s_q[4][192];
-  const KcIndexView ix{(MG_GLB uint32_t*)a.live, (const MG_GLB KcEntry*)a.prim, (const MG_GLB KcEntry*)a.ovf, (MG_GLB uint32_t*)a.counts,
-                       (MG_GLB uint32_t*)a.sat, a.bmask, a.maxkey, a.cs > 2047u ? 0u : a.cs, a.ablate};
-  const MG_GLB uint8_t* bases = (const MG_GLB uint8_t*)a.bases;
-  const uint32_t nprim = 2u * (ix.bmask + 1u);
-  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-  unsigned long long* q = s_q[wave];
-  const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t sn = 0, found = 0;
-  auto scan_batch = [&](uint32_t at, uint32_t n) {
-    if ((uint32_t)lane < n) {
-      const unsigned long long e = q[at + (uint32_t)lane];
-      const uint32_t num = (uint32_t)(e >> 32);
-      const kc_u32x4 it = a.queue[(uint32_t)e];
-      const KcEntry E = kc_entry(ix, num);
-      const uint64_t beg = a.offsets[it.z], end = a.offsets[it.z + 1];
-      const uint32_t f = kc_scan_ascii(ix, bases + beg, (uint32_t)(end - beg), a.k, E, it.y & 1023u, (it.y >> 10) & 1023u);
-      kc_count_entry(ix, num, E.head, f);
-      found += f;
-    }
-  };
-  auto push_item = [&](bool want, uint32_t idx, uint32_t num) {
-    const unsigned long long m = __ballot(want && a.ablate != 3u);
-    if (m == 0ull) return;
-    if (want) q[sn + (uint32_t)__popcll(m & below)] = (unsigned long long)idx | ((unsigned long long)num << 32);
-    sn += (uint32_t)__popcll(m);
-    if (sn >= 64u) {
-      wave_lds_sync();
-      sn -= 64u;
-      scan_batch(sn, 64u);
-      wave_lds_sync();
-    }
-  };
-  for (uint32_t r = blockIdx.x; r < a.nregions; r += gridDim.x) {
-    const uint32_t n = a.qcount[r];
-    for (uint32_t i0 = (uint32_t)wave * 64u; i0 < n; i0 += 256u) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      const bool active = i < n;
-      const uint32_t idx = r * a.qcap + i;
-      uint32_t key = kKcNone, num0 = 0, k0 = ~0u, k1 = ~0u, satw = 0, novf = 0, ovf_at = 0;
-      if (active) {
-        key = a.queue[idx].x;
-        num0 = 2u * (key & ix.bmask);
-        const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0);
-        const kc_u32x4 e0 = p[1], e1 = p[3];
-        satw = MG_KC_LOAD(&ix.sat[num0 >> 5]);
-        k0 = e0.y; novf = e0.w;
-        k1 = e1.y; ovf_at = e1.w;
-      }
-      const uint32_t sbit = num0 & 31u;
-      const bool u0 = active && k0 == key && !((satw >> sbit) & 1u), u1 = active && k1 == key && !((satw >> (sbit + 1u)) & 1u);
-      bool allsat = ix.cs != 0u && !u0 && !u1;
-      push_item(u0, idx, num0);
-      push_item(u1, idx, num0 + 1u);
-      if (!active) novf = 0;
-      for (uint32_t t = 0; __ballot(t < novf) != 0ull; ++t) {
-        const uint32_t num = nprim + ovf_at + t;
-        bool want = false;
-        if (t < novf) {
-          const kc_u32x4 e = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (ovf_at + t))[1];
-          if (e.y == key) want = !((MG_KC_LOAD(&ix.sat[num >> 5]) >> (num & 31u)) & 1u);
-        }
-        allsat = allsat && !want;
-        push_item(want, idx, num);
-      }
-      // (a look first: most runs of an abundant genome find the bit cleared already)
-      if (active && allsat && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u)) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
-    }
-  }
-  if (sn) {
-    wave_lds_sync();
-    scan_batch(0u, sn);
-  }
-  found = wave_sum_u32(found);
-  if (lane == 0 && found) atomicAdd(a.stats + 3, (unsigned long long)found);
 }
 
 template <int K>
@@ -722,7 +629,6 @@ struct mg_kcounts {
   mg::DevBuf live;    // the sample's gate: the table's, minus the minimizers all of whose k-mers are saturated (mg_kcount_core.h)
   mg::DevBuf sat;     // a bit per entry number: its counter has reached the saturation value
   mg::DevBuf stats;   // u64[4]
-  mg::DevBuf queue, qcount;  // the runs handed from k_count_kmers to k_match_items (grown to the launch that needs most)
   uint64_t n = 0, live_words = 0, sat_words = 0;
   const void* gate = nullptr;  // the table's gate bitmap the live one is reset from (owned by the table: it outlives the counters)
 };
@@ -750,11 +656,10 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
   if (n && !db->kmer_hi.p) return fail(MG_ERR_STATE, "the table does not hold its k-mers: pass them (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64)");
   std::unique_ptr<KmerIndex> ix(new KmerIndex());
   ix->k = k;
-  MG_TRY(ix->gate.alloc(4));  // (sized below, once the largest minimizer is known)
 
   MG_TRY(ix->head.alloc((n + 1) * 4));
-  DevBuf chi, clo, iota, ord1, ord2, s_lo, s_hi, g_hi, flag, before, dhi, dlo, dhead, dkey, skey, perm;
-  uint64_t nd = 0;
+  DevBuf chi, clo, iota, ord1, ord2, s_lo, s_hi, g_hi, flag, before, dhi, dlo, dhead, nkeys, kbefore, ekey, eid, skey, perm;
+  uint64_t nd = 0, ne = 0;  // distinct k-mers; entries (a k-mer filed under several hashes has one for each)
   if (n) {
     MG_TRY(chi.alloc(n * 8)); MG_TRY(clo.alloc(n * 8)); MG_TRY(iota.alloc(n * 4)); MG_TRY(ord1.alloc(n * 4)); MG_TRY(ord2.alloc(n * 4));
     MG_TRY(s_lo.alloc(n * 8)); MG_TRY(s_hi.alloc(n * 8)); MG_TRY(g_hi.alloc(n * 8)); MG_TRY(flag.alloc(n * 4)); MG_TRY(before.alloc((n + 2) * 8));
@@ -768,11 +673,11 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
     hipLaunchKernelGGL(k_kc_heads, dim3(g256(n)), dim3(256), 0, st, s_hi.as<uint64_t>(), s_lo.as<uint64_t>(), n, flag.as<uint32_t>());
     MG_HIP(hipGetLastError());
     MG_TRY(exclusive_sum_u32_to_u64(flag.as<uint32_t>(), before.as<uint64_t>(), n, &nd));
-    MG_TRY(dhi.alloc(nd * 8)); MG_TRY(dlo.alloc(nd * 8)); MG_TRY(dhead.alloc(nd * 4)); MG_TRY(dkey.alloc(nd * 8)); MG_TRY(skey.alloc(nd * 8));
-    MG_TRY(perm.alloc(nd * 4));
+    MG_TRY(dhi.alloc(nd * 8)); MG_TRY(dlo.alloc(nd * 8)); MG_TRY(dhead.alloc(nd * 4)); MG_TRY(nkeys.alloc((nd + 1) * 4));
+    MG_TRY(kbefore.alloc((nd + 2) * 8));
     hipLaunchKernelGGL(k_kc_distinct, dim3(g256(n)), dim3(256), 0, st, s_hi.as<uint64_t>(), s_lo.as<uint64_t>(), ord2.as<uint32_t>(),
                        flag.as<uint32_t>(), before.as<uint64_t>(), n, k, dhi.as<uint64_t>(), dlo.as<uint64_t>(), dhead.as<uint32_t>(),
-                       dkey.as<uint64_t>(), iota.as<uint32_t>());
+                       nkeys.as<uint32_t>());
     hipLaunchKernelGGL(k_kc_pair_heads, dim3(g256(n)), dim3(256), 0, st, ord2.as<uint32_t>(), flag.as<uint32_t>(), before.as<uint64_t>(),
                        dhead.as<uint32_t>(), n, ix->head.as<uint32_t>());
     MG_HIP(hipGetLastError());
@@ -782,31 +687,34 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
   while (bb < 28 && (1ull << bb) < nd) ++bb;
   ix->bmask = (1u << bb) - 1u;
   ix->nbuckets = 1ull << bb;
+  const int64_t gx = dbg("kc_gate_extra");
+  ix->gbits = kc_gate_bits(nd, gx > 0 ? (uint32_t)gx : kKcGateExtra);
+  ix->gate_words = (1ull << ix->gbits) / 32 + 2;
+  MG_TRY(ix->gate.alloc(ix->gate_words * 4));
+  MG_TRY(ix->shared.alloc(ix->gate_words * 4));
+  MG_HIP(hipMemsetAsync(ix->gate.p, 0, ix->gate_words * 4, st));
+  MG_HIP(hipMemsetAsync(ix->shared.p, 0, ix->gate_words * 4, st));
   if (nd) {
-    uint32_t* d_max = (uint32_t*)scratch("kc_maxkey", 64);
-    if (!d_max) return MG_ERR_NOMEM;
-    MG_HIP(hipMemsetAsync(d_max, 0, 4, st));
-    hipLaunchKernelGGL(k_kc_max_key, dim3(g256(nd)), dim3(256), 0, st, dkey.as<uint64_t>(), nd, d_max);
-    uint64_t* pin = host_words();
-    MG_HIP(hipMemcpyAsync(pin + 12, d_max, 4, hipMemcpyDeviceToHost, st));
-    MG_HIP(hipStreamSynchronize(st));
-    ix->maxkey = (uint32_t)pin[12];
-    MG_TRY(ix->gate.alloc((((uint64_t)ix->maxkey >> 5) + 2) * 4));
-    MG_HIP(hipMemsetAsync(ix->gate.p, 0, (((uint64_t)ix->maxkey >> 5) + 2) * 4, st));
-    hipLaunchKernelGGL(k_kc_bucket_keys, dim3(g256(nd)), dim3(256), 0, st, dkey.as<uint64_t>(), nd, ix->bmask);
-    MG_TRY(sort_pairs(dkey.as<uint64_t>(), skey.as<uint64_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), nd));
+    MG_TRY(exclusive_sum_u32_to_u64(nkeys.as<uint32_t>(), kbefore.as<uint64_t>(), nd, &ne));
+    MG_TRY(ekey.alloc((ne + 1) * 8)); MG_TRY(eid.alloc((ne + 1) * 4)); MG_TRY(skey.alloc((ne + 1) * 8)); MG_TRY(perm.alloc((ne + 1) * 4));
+    hipLaunchKernelGGL(k_kc_emit_keys, dim3(g256(nd)), dim3(256), 0, st, dhi.as<uint64_t>(), dlo.as<uint64_t>(), kbefore.as<uint64_t>(), nd, k,
+                       ix->bmask, ekey.as<uint64_t>(), eid.as<uint32_t>());
+    MG_HIP(hipGetLastError());
+    MG_TRY(sort_pairs(ekey.as<uint64_t>(), skey.as<uint64_t>(), eid.as<uint32_t>(), perm.as<uint32_t>(), ne));
   }
+  ix->nentries = ne;
   // the entries in (bucket, minimizer) order, the buckets' bounds, then their places: two per bucket in prim, the rest in ovf
   DevBuf offs, ent, extra, obefore;
   MG_TRY(offs.alloc((ix->nbuckets + 2) * 4));
-  MG_TRY(ent.alloc((nd + 1) * sizeof(KcEntry)));
+  MG_TRY(ent.alloc((ne + 1) * sizeof(KcEntry)));
   MG_TRY(extra.alloc((ix->nbuckets + 1) * 4));
   MG_TRY(obefore.alloc((ix->nbuckets + 2) * 8));
-  MG_TRY(ix->prim.alloc(2 * ix->nbuckets * sizeof(KcEntry)));
-  if (nd) {
-    hipLaunchKernelGGL(k_kc_entries, dim3(g256(nd)), dim3(256), 0, st, skey.as<uint64_t>(), perm.as<uint32_t>(), dhi.as<uint64_t>(),
-                       dlo.as<uint64_t>(), dhead.as<uint32_t>(), nd, k, ent.as<KcEntry>(), ix->gate.as<uint32_t>());
-    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(nd + 1)), dim3(256), 0, st, skey.as<uint64_t>(), nd, ix->nbuckets, offs.as<uint32_t>());
+  MG_TRY(ix->prim.alloc(kKcSlots * ix->nbuckets * sizeof(KcEntry)));
+  if (ne) {
+    hipLaunchKernelGGL(k_kc_entries, dim3(g256(ne)), dim3(256), 0, st, skey.as<uint64_t>(), perm.as<uint32_t>(), dhi.as<uint64_t>(),
+                       dlo.as<uint64_t>(), dhead.as<uint32_t>(), ne, k, 32u - ix->gbits, ent.as<KcEntry>(), ix->gate.as<uint32_t>(),
+                       ix->shared.as<uint32_t>());
+    hipLaunchKernelGGL(k_kc_offsets, dim3(g256(ne + 1)), dim3(256), 0, st, skey.as<uint64_t>(), ne, ix->nbuckets, offs.as<uint32_t>());
   } else {
     MG_HIP(hipMemsetAsync(offs.p, 0, (ix->nbuckets + 2) * 4, st));
   }
@@ -840,8 +748,8 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
   if (!db->kidx) return fail(MG_ERR_STATE, "the table has no k-mer index (mg_refdb_index_kmers)");
   std::unique_ptr<mg_kcounts> kc(new mg_kcounts());
   kc->n = db->kmax.total;
-  kc->live_words = ((uint64_t)db->kidx->maxkey >> 5) + 2;
-  kc->sat_words = (2 * db->kidx->nbuckets + db->kidx->novf) / 32 + 2;
+  kc->live_words = db->kidx->gate_words;
+  kc->sat_words = (kKcSlots * db->kidx->nbuckets + db->kidx->novf) / 32 + 2;
   kc->gate = db->kidx->gate.p;
   MG_TRY(kc->counts.alloc((kc->n + 1) * 4));
   MG_TRY(kc->live.alloc(kc->live_words * 4));
@@ -891,30 +799,11 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const uint64_t ntiles = (nreads + 63) / 64;
   const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
-  // the queue between the two kernels: a region per wavefront of this launch, six runs past the gate per read of its share (a
-  // sample of a table's own genomes, 2 % of whose k-mers are sketched, passes 2.5; a wavefront that fills its region goes on
-  // matching in place)
-  const uint32_t nwaves = grid * kKcWaves;
-  const uint64_t reads_per_wave = ((ntiles + nwaves - 1) / nwaves) * 64;
-  uint32_t qcap = (uint32_t)std::min<uint64_t>(reads_per_wave * 6 + 64, 1u << 24);
-  const bool two = nreads < 0xffffff00ull && dbg("kc_one_kernel") == 0;
-  if (two) {
-    if (kc->queue.bytes < (uint64_t)nwaves * qcap * 16) MG_TRY(kc->queue.alloc((uint64_t)nwaves * qcap * 16));
-    if (kc->qcount.bytes < (uint64_t)nwaves * 4) MG_TRY(kc->qcount.alloc((uint64_t)nwaves * 4));
-  }
-  KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
-           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), two ? kc->queue.as<kc_u32x4>() : nullptr,
-           two ? kc->qcount.as<uint32_t>() : nullptr, qcap, ix.maxkey, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
+  KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.shared.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
+           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), 32u - ix.gbits, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
   {
     ProfScope ps("count_kmers");
     MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
-    MG_HIP(hipGetLastError());
-  }
-  if (two && a.ablate != 6u) {
-    ProfScope ps("match_items");
-    KbArgs b{d_bases, d_offsets, kc->queue.as<kc_u32x4>(), kc->qcount.as<uint32_t>(), qcap, nwaves, a.live, a.prim, a.ovf, a.counts, a.sat,
-             a.stats, a.maxkey, a.bmask, a.cs, a.ablate, ix.k};
-    hipLaunchKernelGGL(k_match_items, dim3(std::min<unsigned>(nwaves, (unsigned)c.num_cus * 8)), dim3(256), 0, c.stream, b);
     MG_HIP(hipGetLastError());
   }
   return MG_OK;

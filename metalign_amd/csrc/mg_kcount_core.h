@@ -4,13 +4,19 @@
 // sketches (scripts/select_db.py:50-59).  KMC counts canonical k-mers and intersects k-mer SETS: nothing on the read side is
 // hashed.  So the read side here hashes nothing either: a read k-mer is looked up among the table's sketched k-mers by what it IS.
 //
-// How: minimizer partitioning (KMC's own signatures are the same idea).  The minimizer of a k-mer is the smallest KEY among its
-// w = k - m + 1 m-mers (m = 15; key = an odd multiplier over the lexicographically smaller strand of the m-mer, 30 bits, a
-// bijection — so equal keys are equal m-mers and the value is the same on either strand).  Equal k-mers have equal minimizers:
-// the table's distinct canonical k-mers are grouped by minimizer once (mg_refdb_index_kmers), and a read's windows are cut into
-// RUNS of consecutive windows that share their minimizer (about w / 2 windows each).  Per run: one bit of a gate bitmap over the
-// 2^30 keys; for the few runs that pass, the bucket of table k-mers with that minimizer, each compared against the run's
-// windows (a 16-base signature first, the whole canonical k-mer on a signature hit); a match adds one to the k-mer's counter.
+// How: minimizer partitioning (KMC's own signatures are the same idea).  The CANDIDATES of a k-mer are its m-mers (m = 15) that
+// have e more bases of the k-mer on either side (e = kc_flank(k): 2 from k = 23 on) — w = k - 14 - 2 e of them; every one has a
+// RANK (22 bits of an odd multiplier over the lexicographically smaller strand of the m-mer: the same on either strand), and the
+// k-mer's minimizer is a candidate of the smallest rank.  What a k-mer is FILED under is not the 15-mer but the (15 + 2 e)-mer
+// around it — 19 bases — hashed to 32 bits (the smaller strand: kc_ext_hash): a table of ten million k-mers holds a sixth of
+// all the 15-mers that ever come out smallest of 37 (minima crowd at the bottom of their range), and one read run in six then
+// met some unrelated k-mer's 15-mer; with the flanks it is one in a hundred thousand.  Equal k-mers have equal sets of
+// smallest-rank candidates: the table's distinct canonical k-mers are filed once under each of theirs (nearly always one; a
+// tandem repeat has several — mg_refdb_index_kmers), a read's windows are cut into RUNS of consecutive windows that share
+// their minimizer (the leftmost smallest: about w / 2 windows each), and whichever candidate a window chose, the table k-mer
+// equal to it is filed there.  Per run: one bit of a gate bitmap over the leading bits of the hash; for the few runs that pass,
+// the bucket of table k-mers filed under that hash, each compared against the run's windows (a 16-base signature first, the
+// whole canonical k-mer on a signature hit); a match adds one to the k-mer's counter.
 //
 // The sliding minimum is van Herk / Gil-Werman in registers: m-mers in blocks of w; a window that starts in block b and ends
 // in block b + 1 has min(suffix minimum of block b from its first m-mer on, prefix minimum of block b + 1 up to its last):
@@ -45,7 +51,11 @@
 #else
 // (a sample's bits are set by lanes all over the device; each XCD's L2 keeps what it has read: a plain load may see a word as it
 // was long ago — and a k-mer that is saturated be scanned for again and again.  Device-scope loads for those words.)
+#ifdef MG_KC_PLAIN_LOADS  // (A/B builds)
+#define MG_KC_LOAD(ptr) (*(ptr))
+#else
 #define MG_KC_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 #define MG_KC_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MG_KC_OR(ptr, v) __hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MG_KC_AND(ptr, v) __hip_atomic_fetch_and((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -56,15 +66,46 @@ namespace mg {
 constexpr int kKcM = 15;                     // minimizer length: odd (no m-mer is its own reverse complement), 30 bits
 constexpr uint32_t kKcMask = 0x3fffffffu;
 constexpr uint32_t kKcNone = 0xffffffffu;    // "no key": above every key, so it is also +infinity of the minima
-constexpr uint32_t kKcXor = 0x1b873593u & kKcMask;  // (poly-A is m-mer 0: without this its key would be the smallest of all)
-constexpr uint32_t kKcMul = 0x2545f491u;     // odd: x -> x * kKcMul mod 2^30 is a bijection
+constexpr uint32_t kKcXor = 0x1b873593u & kKcMask;  // (poly-A is m-mer 0: without this its rank would be the smallest of all)
+constexpr uint32_t kKcMul = 0x2545f491u;     // odd
+constexpr uint32_t kKcPos = 1023u;           // the low ten bits of a candidate's word: where it starts
 constexpr int kKcMinK = kKcM, kKcMaxK = 64;
+constexpr int kKcMaxCands = 50;              // candidates of a k-mer: k - 14 at most
+constexpr uint32_t kKcSlots = 4;             // entries of a bucket that sit in its own line (KcIndexView)
 constexpr uint32_t kKcMaxRead = 1023;        // window numbers of an event take ten bits: longer reads go through in chunks
 
-// key of an m-mer given both strands 2-bit packed (first base most significant, right-aligned in 30 bits)
-MG_HD uint32_t kc_key(uint32_t f, uint32_t r) {
+// bases of the k-mer that a candidate has on either side, and how many candidates that leaves
+constexpr int kc_flank(int k) { return k >= 23 ? 2 : (k >= 19 ? 1 : 0); }
+constexpr int kc_cands(int k) { return k - kKcM + 1 - 2 * kc_flank(k); }
+
+// the WORD of a candidate given both strands of its m-mer 2-bit packed (first base most significant, right-aligned in 30 bits)
+// and its number `pos` (< 1023): its rank above its number — the smallest word of a window is its leftmost candidate of the
+// smallest rank, and says where it is.
+MG_HD uint32_t kc_word(uint32_t f, uint32_t r, uint32_t pos) {
   const uint32_t c = f < r ? f : r;
-  return ((c ^ kKcXor) * kKcMul) & kKcMask;
+  return (((c ^ kKcXor) * kKcMul) & ~kKcPos) | pos;
+}
+// what a k-mer is filed under: v = 64 bits of bases from the candidate's first flank base on (the 15 + 2 e bases at the top);
+// the smaller strand of those bases, mixed to 32 bits.  Never kKcNone (an unused slot of a bucket has that).
+MG_HD uint32_t kc_rc32(uint32_t x);
+MG_HD uint32_t kc_ext_hash(uint64_t v, int k) {
+  const int nb = 2 * (kKcM + 2 * kc_flank(k));
+  const uint64_t f = v >> (64 - nb);
+  const uint64_t r = ((((uint64_t)kc_rc32((uint32_t)v)) << 32) | kc_rc32((uint32_t)(v >> 32))) & ((1ull << nb) - 1ull);
+  uint64_t z = (f < r ? f : r) * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 32;
+  z *= 0xD6E8FEB86659FD93ull;
+  const uint32_t h = (uint32_t)(z >> 32);
+  return h == kKcNone ? 0x7fffffffu : h;
+}
+// bits of the gate bitmap for a table of nd distinct k-mers: 2^extra bits per k-mer (one run in 2^extra that has nothing to find
+// passes), between 2^16 and 2^32
+constexpr uint32_t kKcGateExtra = 6;
+constexpr uint32_t kc_gate_bits(uint64_t nd, uint32_t extra) {
+  uint32_t b = 0;
+  while (b < 32u && (1ull << b) < nd) ++b;
+  b += extra;
+  return b < 16u ? 16u : (b > 32u ? 32u : b);
 }
 
 // ---- the staged tile: a big-endian 2-bit base stream -----------------------------------------------------------------
@@ -84,6 +125,18 @@ MG_HD uint32_t kc_bits32(const MG_LDS uint32_t* s, uint32_t p) {
   const uint32_t d = p >> 5, sh = p & 31u;
   const uint64_t v = ((uint64_t)s[d] << 32) | s[d + 1];
   return (uint32_t)((v << sh) >> 32);
+}
+
+// 64 bits of a 2-bit stream from base p on (thirty-two bases)
+MG_HD uint64_t kc_ext64(const MG_LDS uint32_t* s, uint32_t p) {
+  const uint32_t d = p >> 4, sh = (p & 15u) << 1;
+  const uint32_t a = s[d], b = s[d + 1], c = s[d + 2];
+  const uint32_t hi = (uint32_t)(((((uint64_t)a) << 32 | b) << sh) >> 32), lo = (uint32_t)(((((uint64_t)b) << 32 | c) << sh) >> 32);
+  return ((uint64_t)hi << 32) | lo;
+}
+// the hash a closed run is looked up by: its word's low bits say where its candidate starts in the lane's read
+MG_HD uint32_t kc_run_hash(const MG_LDS uint32_t* fwd, uint32_t p0, uint32_t word, int k) {
+  return kc_ext_hash(kc_ext64(fwd, p0 + (word & kKcPos)), k);
 }
 
 struct KcWin { uint32_t w[4]; };  // a k-mer, LEFT-aligned: base 0 in the top pair of w[0]; bits below 2k are zero
@@ -170,22 +223,42 @@ MG_HD uint32_t kc_mmer_at(const KcWin& x, int j) {
 // reverse complement of a 15-mer (30 bits, right-aligned)
 MG_HD uint32_t kc_mmer_rc(uint32_t f) { return kc_rc32(f << 2) & kKcMask; }
 
-// the minimizer of a k-mer: the smallest key among its m-mers (table side; the read side slides: kc_walk)
-MG_HD uint32_t kc_minimizer(const KcWin& x, int k) {
+// 64 bits of a left-aligned k-mer from base j on (zeros beyond its 128 bits)
+MG_HD uint64_t kc_sub64(const KcWin& x, int j) {
+  const int d = j >> 4, sh = (j & 15) << 1;
+  const uint32_t a = x.w[d < 4 ? d : 3], b = d + 1 < 4 ? x.w[d + 1 < 4 ? d + 1 : 3] : 0u, c = d + 2 < 4 ? x.w[d + 2 < 4 ? d + 2 : 3] : 0u;
+  const uint32_t hi = (uint32_t)(((((uint64_t)a) << 32 | b) << sh) >> 32), lo = (uint32_t)(((((uint64_t)b) << 32 | c) << sh) >> 32);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// What a table k-mer is filed under (the read side slides: kc_walk): the hash of EVERY candidate of the smallest rank — a read
+// window equal to this k-mer chooses the leftmost of them as the window stands, the rightmost here if the read shows the other
+// strand.  out[0 .. return): the distinct hashes, at most kKcMaxCands (nearly always one).
+MG_HD int kc_table_keys(const KcWin& x, int k, uint32_t* out) {
+  const int e = kc_flank(k), w = kc_cands(k);
   uint32_t best = kKcNone;
-  for (int j = 0; j + kKcM <= k; ++j) {
-    const uint32_t f = kc_mmer_at(x, j);
-    const uint32_t key = kc_key(f, kc_mmer_rc(f));
-    best = key < best ? key : best;
+  for (int j = 0; j < w; ++j) {
+    const uint32_t f = kc_mmer_at(x, j + e);
+    const uint32_t rank = kc_word(f, kc_mmer_rc(f), 0u);
+    best = rank < best ? rank : best;
   }
-  return best;
+  int n = 0;
+  for (int j = 0; j < w; ++j) {
+    const uint32_t f = kc_mmer_at(x, j + e);
+    if (kc_word(f, kc_mmer_rc(f), 0u) != best) continue;
+    const uint32_t h = kc_ext_hash(kc_sub64(x, j), k);
+    bool seen = false;
+    for (int t = 0; t < n; ++t) seen = seen || out[t] == h;
+    if (!seen) out[n++] = h;
+  }
+  return n;
 }
 
 // One distinct canonical k-mer of the table, as the read side meets it (32 bytes, two 16-byte loads).
 struct __attribute__((aligned(16))) KcEntry {
   uint32_t w[4];   // the canonical k-mer, left-aligned
   uint32_t head;   // where it is counted: the first pair of the hash-major table that holds it
-  uint32_t key;    // its minimizer
+  uint32_t key;    // what it is filed under here (kc_table_keys: a k-mer with several has an entry for each)
   uint32_t sig_rc; // the first sixteen bases of its reverse complement (w[0] is the signature of the k-mer itself)
   uint32_t pad;
 };
@@ -249,7 +322,7 @@ MG_HD uint32_t kc_notbase16(const uint32_t v[4]) {
 template <int K, int MODE, class Out>
 MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, uint32_t p0, uint32_t len, uint32_t maxlen, uint32_t w0,
                        Out& out, uint32_t& cnt) {
-  constexpr int M = kKcM, W = K - M + 1;
+  constexpr int M = kKcM, E = kc_flank(K), W = kc_cands(K);  // (candidate j: bases j + E .. j + E + 14 of the read; window i has j = i .. i + W - 1)
   constexpr uint32_t kCap = Out::kCap;
   static_assert(K >= kKcMinK && K <= kKcMaxK, "k out of range for the minimizer path");
   maxlen = MG_UNIFORM(maxlen);
@@ -260,16 +333,17 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
   if (w0 >= nwmax) return nwmax;
   const uint32_t nmers = nwmax + (uint32_t)(W - 1);  // ... and its m-mers
   uint32_t f = 0, r = 0, vrun = 0;
+  p0 += (uint32_t)E;  // (base u of the walk is base u + E of the read)
   uint32_t word = kc_ext32(fwd, p0 + (w0 & ~15u)), iw = 0;
   if constexpr (MODE == 0) iw = kc_bits32(inv, p0 + (w0 & ~31u));
   uint32_t A[W];  // this block's keys; from the end of the block on, the block's suffix minima
   uint32_t P = kKcNone, Mprev = kKcNone, rstart = w0;
-  auto take = [&](uint32_t u) -> uint32_t {  // base u of the read comes in; the key of the m-mer that ends there
+  auto take = [&](uint32_t u) -> uint32_t {  // base u comes in; the word of the candidate that ends there (number u - 14)
     if ((u & 15u) == 0) word = kc_ext32(fwd, p0 + u);
     const uint32_t c = (word >> (30u - 2u * (u & 15u))) & 3u;
     f = ((f << 2) | c) & kKcMask;
     r = (r >> 2) | ((c ^ 3u) << 28);
-    uint32_t key = kc_key(f, r);
+    uint32_t key = kc_word(f, r, u - (uint32_t)(M - 1));
     if constexpr (MODE == 0) {
       if ((u & 31u) == 0) iw = kc_bits32(inv, p0 + u);
       const uint32_t bad = (iw >> (31u - (u & 31u))) & 1u;
@@ -343,21 +417,25 @@ MG_HD uint32_t kc_clean_windows(const MG_LDS uint32_t* inv, uint32_t p0, uint32_
 
 // ---- a run against the table -------------------------------------------------------------------------------------------
 // The table's distinct canonical k-mers, laid out so that a run's look-up is ONE access to memory in the usual case:
-//   prim   two 32-byte entries per bucket (bucket of a minimizer = its LOW bits; as many buckets as a power of two >= the k-mers):
-//          the bucket's first two entries in (minimizer) order, an unused slot has key kKcNone — one 64-byte line;
-//   ovf    the third and later entries of the (few) buckets that hold more: prim[2 b].pad = how many, prim[2 b + 1].pad = where;
-//   an entry's NUMBER: 2 b + s in prim, 2 * buckets + j in ovf — what a sample's saturation bits go by.
-// Per sample (mg_kcounts): `live` = a copy of the table's gate bitmap (bit `key` set <=> some table k-mer has this minimizer)
-// in which the bit of a minimizer is CLEARED once every k-mer of it has been seen at the saturation value: ONE bit probe per
-// run decides both; `sat` = a bit per entry number: its counter has reached the saturation value; `counts` at the entry's head.
+//   prim   kKcSlots = four 32-byte entries per bucket (bucket of a minimizer = its LOW bits; as many buckets as a power of two >=
+//          the k-mers): the bucket's first four entries in (minimizer) order, an unused slot has key kKcNone — one 128-byte line;
+//   ovf    the fifth and later entries of the (very few: one bucket in a thousand) buckets that hold more: prim[4 b].pad = how
+//          many, prim[4 b + 1].pad = where.  (Two slots per bucket — a 64-byte line — left one bucket in forty with more, and a
+//          batch of 64 look-ups then nearly always had a lane that needed a second and third round trip to memory.)
+//   an entry's NUMBER: 4 b + s in prim, 4 * buckets + j in ovf — what a sample's saturation bits go by.
+// Per sample (mg_kcounts): `live` = a copy of the table's gate bitmap (bit hash >> gshift set <=> some table k-mer is filed
+// under a hash with these leading bits) in which a bit is CLEARED once a run has found every k-mer filed under its hash at the
+// saturation value — unless the table's `shared` bitmap says that two different hashes of the table have this bit (one in
+// 2^kKcGateExtra: their runs keep passing the gate and stop at the saturation bits); ONE bit probe per run decides both; `sat` = a bit per entry number: its counter has reached the saturation value; `counts` at the entry's head.
 struct KcIndexView {
   MG_GLB uint32_t* live;
+  const MG_GLB uint32_t* shared;
   const MG_GLB KcEntry* prim;
   const MG_GLB KcEntry* ovf;
   MG_GLB uint32_t* counts;
   MG_GLB uint32_t* sat;
   uint32_t bmask;         // buckets - 1 (minimizers are minima: their HIGH bits are nearly all zero, the low ones spread)
-  uint32_t maxkey;        // the largest minimizer of the table: `live` ends there
+  uint32_t gshift;        // a hash's gate bit is number hash >> gshift (32 - kc_gate_bits)
   uint32_t cs;            // counters are read as min(counter, cs) (kmc -cs<cs>; 0: exact, nothing ever saturates)
   uint32_t ablate;        // measurements only (knob kc_ablate): 3 = no run is scanned; 4 = signatures only; 5 = no count
 };
@@ -375,11 +453,14 @@ MG_HD KcEntry kc_load_entry(const MG_GLB KcEntry* ent, uint32_t e) {
 #endif
 // entry number n
 MG_HD KcEntry kc_entry(const KcIndexView& ix, uint32_t n) {
-  const uint32_t nprim = 2u * (ix.bmask + 1u);
+  const uint32_t nprim = kKcSlots * (ix.bmask + 1u);
   return n < nprim ? kc_load_entry(ix.prim, n) : kc_load_entry(ix.ovf, n - nprim);
 }
 
-MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) { return key <= ix.maxkey && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u); }
+MG_HD bool kc_gate(const KcIndexView& ix, uint32_t key) {
+  const uint32_t g = key >> ix.gshift;
+  return (MG_KC_LOAD(&ix.live[g >> 5]) >> (g & 31u)) & 1u;
+}
 
 // no "not a base" bit in [p, p + k)
 MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
@@ -462,129 +543,30 @@ MG_HD void kc_count_entry(const KcIndexView& ix, uint32_t n, uint32_t head, uint
 template <bool BAD>
 MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, uint32_t key,
                             uint32_t p0, uint32_t i1, uint32_t i2) {
-  const uint32_t b = key & ix.bmask, nprim = 2u * (ix.bmask + 1u);
+  const uint32_t b = key & ix.bmask, nprim = kKcSlots * (ix.bmask + 1u);
   uint32_t found = 0, novf = 0, ovf_at = 0;
-  bool allsat = ix.cs != 0u;
-  for (uint32_t t = 0; t < 2u + novf; ++t) {
-    const uint32_t n = t < 2u ? 2u * b + t : nprim + ovf_at + (t - 2u);
+  bool any = false, open = false;  // an entry filed under this hash; one of them whose counter is not saturated
+  for (uint32_t t = 0; t < kKcSlots + novf; ++t) {
+    const uint32_t n = t < kKcSlots ? kKcSlots * b + t : nprim + ovf_at + (t - kKcSlots);
     const KcEntry E = kc_entry(ix, n);
     if (t == 0) novf = E.pad;
     if (t == 1) ovf_at = E.pad;
     if (E.key != key) continue;
+    any = true;
     if ((MG_KC_LOAD(&ix.sat[n >> 5]) >> (n & 31u)) & 1u) continue;
-    allsat = false;
+    open = true;
     const uint32_t f = kc_scan_run<BAD>(ix, fwd, inv, k, E, p0, i1, i2);
     kc_count_entry(ix, n, E.head, f);
     found += f;
   }
   // (a look first: in the second kernel most runs of an abundant genome find the bit cleared already, and an atomic on a word that
   // a million other lanes are clearing too is the one thing here that queues)
-  if (allsat && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u)) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
+  const uint32_t g = key >> ix.gshift;
+  // (a run that another hash's bit let through finds no entry of its own: that bit is not its to clear)
+  if (ix.cs && any && !open && !((ix.shared[g >> 5] >> (g & 31u)) & 1u) && ((MG_KC_LOAD(&ix.live[g >> 5]) >> (g & 31u)) & 1u))
+    MG_KC_AND(&ix.live[g >> 5], ~(1u << (g & 31u)));
   return found;
 }
 
-
-// ---- the same against the read as it lies in memory (ASCII): the second kernel, k_match_items --------------------------------
-// sixteen ASCII bases at p -> one dword of the stream's packing.  avail: the bytes of the read from p on (past them: 'A').
-MG_HD uint32_t kc_pack16_ascii(const MG_GLB uint8_t* p, int64_t avail, uint32_t& notbase) {
-  uint32_t v[4];
-  if (avail >= 20) {  // aligned dwords around p, funnel-shifted by p's misalignment (at most three bytes past the sixteen are read)
-    const uintptr_t a = (uintptr_t)p;
-    const MG_GLB uint32_t* q = (const MG_GLB uint32_t*)(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3u) * 8u;
-    uint32_t d[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) d[j] = q[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = sh ? (d[j] >> sh) | (d[j + 1] << (32u - sh)) : d[j];
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t x = 0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) x |= ((int64_t)(4 * j + t) < avail ? (uint32_t)p[4 * j + t] : (uint32_t)'A') << (8 * t);
-      v[j] = x;
-    }
-  }
-  return kc_pack16(v, notbase);
-}
-
-// E against the windows [i1, i2] of the read rd[0 .. len): kc_scan_run with the signature registers filled from the read's text;
-// a signature hit reads the window's k bases from the text, every one of which has to be a base.
-template <int NS>
-MG_HD uint32_t kc_scan_ascii_n(const KcIndexView& ix, const MG_GLB uint8_t* rd, uint32_t len, int k, const KcEntry& E, uint32_t i1,
-                               uint32_t i2) {
-  uint32_t w[NS];
-#pragma unroll
-  for (int j = 0; j < NS; ++j) {
-    uint32_t nb;
-    w[j] = kc_pack16_ascii(rd + i1 + 16u * (uint32_t)j, (int64_t)len - (int64_t)(i1 + 16u * (uint32_t)j), nb);
-  }
-  const uint32_t sigmask = kc_keep_mask(k, 0);
-  uint64_t hits = 0;  // (noted in the loop, settled after it: kc_scan_run_n)
-  for (uint32_t i = i1; i <= i2; ++i) {
-    const uint32_t x0 = w[0] & sigmask;
-    hits |= (x0 == E.w[0] || x0 == E.sig_rc) ? 1ull << (i - i1) : 0ull;
-#pragma unroll
-    for (int j = 0; j < NS - 1; ++j) w[j] = (w[j] << 2) | (w[j + 1] >> 30);
-    w[NS - 1] <<= 2;
-  }
-  uint32_t found = 0;
-  if (ix.ablate == 4u) hits = 0;
-  while (hits) {
-    const uint32_t i = i1 + (uint32_t)__builtin_ctzll(hits);
-    hits &= hits - 1;
-    {
-      KcWin x;
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t nb = 0;
-        x.w[j] = 16 * j < k ? kc_pack16_ascii(rd + i + 16u * (uint32_t)j, (int64_t)len - (int64_t)(i + 16u * (uint32_t)j), nb) & kc_keep_mask(k, j) : 0u;
-      }
-      for (int t = 0; t < k; ++t) {  // (rare: a match, or one window in 2^31)
-        const uint32_t c = (uint32_t)rd[i + (uint32_t)t] & 0xDFu;
-        ok = ok && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
-      }
-      if (ok) {
-        const KcWin y = kc_revcomp(x, k);
-        const KcWin c = kc_less(y, x) ? y : x;
-        found += (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) ? 1u : 0u;
-      }
-    }
-  }
-  return found;
-}
-MG_HD uint32_t kc_scan_ascii(const KcIndexView& ix, const MG_GLB uint8_t* rd, uint32_t len, int k, const KcEntry& E, uint32_t i1, uint32_t i2) {
-  const int bits = 2 * (k - kKcM) + 32;
-  if (bits <= 64) return kc_scan_ascii_n<2>(ix, rd, len, k, E, i1, i2);
-  if (bits <= 96) return kc_scan_ascii_n<3>(ix, rd, len, k, E, i1, i2);
-  if (bits <= 128) return kc_scan_ascii_n<4>(ix, rd, len, k, E, i1, i2);
-  return kc_scan_ascii_n<5>(ix, rd, len, k, E, i1, i2);
-}
-
-// kc_match_run for a run that was handed on as (minimizer, read, windows): what a lane of k_match_items does
-MG_HD uint32_t kc_match_item_ascii(const KcIndexView& ix, const MG_GLB uint8_t* rd, uint32_t len, int k, uint32_t key, uint32_t i1,
-                                   uint32_t i2) {
-  const uint32_t b = key & ix.bmask, nprim = 2u * (ix.bmask + 1u);
-  uint32_t found = 0, novf = 0, ovf_at = 0;
-  bool allsat = ix.cs != 0u;
-  for (uint32_t t = 0; t < 2u + novf; ++t) {
-    const uint32_t n = t < 2u ? 2u * b + t : nprim + ovf_at + (t - 2u);
-    const KcEntry E = kc_entry(ix, n);
-    if (t == 0) novf = E.pad;
-    if (t == 1) ovf_at = E.pad;
-    if (E.key != key) continue;
-    if ((MG_KC_LOAD(&ix.sat[n >> 5]) >> (n & 31u)) & 1u) continue;
-    allsat = false;
-    const uint32_t f = kc_scan_ascii(ix, rd, len, k, E, i1, i2);
-    kc_count_entry(ix, n, E.head, f);
-    found += f;
-  }
-  // (a look first: in the second kernel most runs of an abundant genome find the bit cleared already, and an atomic on a word that
-  // a million other lanes are clearing too is the one thing here that queues)
-  if (allsat && ((MG_KC_LOAD(&ix.live[key >> 5]) >> (key & 31u)) & 1u)) MG_KC_AND(&ix.live[key >> 5], ~(1u << (key & 31u)));
-  return found;
-}
 
 }  // namespace mg

@@ -5,11 +5,11 @@
 // the oracle (tests/test_kcount_core_host.py).  What is NOT covered here is the wavefront glue of mg_kcount.hip (LDS addresses,
 // ballots, the drain's batches, atomics): the GPU tests hold that to the same oracle.
 //
-// stdin:  "k cap ntable nreads lead cs ascii\n", then ntable lines with a table k-mer each (ACGT, any strand), then nreads lines with a
+// stdin:  "k cap ntable nreads lead cs bb\n", then ntable lines with a table k-mer each (ACGT, any strand), then nreads lines with a
 //         read each (anything; may be empty).  cap = slots of a lane's event list (small values force restarts); lead = bytes
 //         in front of the first read in the buffer (the tile then starts off a 16-byte boundary); cs = the counters' saturation
-//         value (0: exact counts; else a k-mer seen cs times is skipped from then on and its minimizer marked done); ascii = 1:
-//         runs past the gate are matched from the reads' text (kc_match_item_ascii), as the kernel's second half does.
+//         value (0: exact counts; else a k-mer seen cs times is skipped from then on and its minimizer marked done); bb > 0:
+//         2^bb buckets (a handful of buckets: nearly every k-mer lives in the overflow list).
 // stdout: one line per table k-mer: the number of windows of the reads whose canonical k-mer equals its canonical form;
 //         then "kmers N runs R passed P restarts S".
 #define MG_HOST_CHECK 1
@@ -28,7 +28,8 @@ using namespace mg;
 
 static int g_cap = 12;
 static uint32_t g_cs = 0;  // counters saturate here (0: exact); > 0 exercises the "done" marks
-static int g_ascii = 0;    // 1: a run past the gate is matched from the read's TEXT (kc_match_item_ascii: the second kernel's way)
+static uint32_t g_gate_extra = kKcGateExtra;  // (bb > 0 also takes this to 0)
+static int g_bb = 0;       // > 0: this many bucket bits instead of about one bucket per k-mer (few buckets: most overflow their four slots)
 
 struct HostOut {
   static constexpr uint32_t kCap = 0;  // (not used: the capacity is a run-time value here, see below)
@@ -55,17 +56,16 @@ static KcWin win_from_string(const std::string& s) {
 }
 
 struct Index {
-  std::vector<uint32_t> live, counts, sat;
+  std::vector<uint32_t> live, shared, counts, sat;
   std::vector<KcEntry> ent, prim, ovf;
-  uint32_t bmask = 0, maxkey = 0, cs = 0;
-  KcIndexView view() { return KcIndexView{live.data(), prim.data(), ovf.data(), counts.data(), sat.data(), bmask, maxkey, cs, 0u}; }
+  uint32_t bmask = 0, gshift = 0, cs = 0;
+  KcIndexView view() { return KcIndexView{live.data(), shared.data(), prim.data(), ovf.data(), counts.data(), sat.data(), bmask, gshift, cs, 0u}; }
 };
 
 template <int K, uint32_t CAP>
 static void run(const std::vector<std::string>& table, const std::vector<std::string>& reads, size_t lead) {
   // ---- the index, as mg_refdb_index_kmers builds it (here with a map) ----
   Index ix;
-  ix.live.assign(1u << 25, 0u);
   ix.counts.assign(table.size() + 1, 0u);
   std::map<std::array<uint32_t, 4>, uint32_t> first;  // canonical k-mer -> the first pair that holds it
   std::vector<uint32_t> head(table.size());
@@ -91,13 +91,16 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
     std::memcpy(e.w, kv.first.data(), 16);
     const KcWin x{{e.w[0], e.w[1], e.w[2], e.w[3]}};
     e.head = kv.second;
-    e.key = kc_minimizer(x, K);
     e.sig_rc = kc_revcomp(x, K).w[0];
     e.pad = 0;
-    ix.ent.push_back(e);
+    uint32_t keys[kKcMaxCands];
+    const int nk = kc_table_keys(x, K, keys);  // (one entry per hash the k-mer is filed under)
+    if (nk < 1) { std::fprintf(stderr, "a k-mer without a key\n"); std::exit(2); }
+    for (int t = 0; t < nk; ++t) { e.key = keys[t]; ix.ent.push_back(e); }
   }
   unsigned bb = 8;
   while (bb < 28 && (1ull << bb) < ix.ent.size()) ++bb;
+  if (g_bb > 0) bb = (unsigned)g_bb;
   ix.bmask = (1u << bb) - 1u;
   const uint32_t bm = ix.bmask;
   std::stable_sort(ix.ent.begin(), ix.ent.end(), [bm](const KcEntry& a, const KcEntry& b) {
@@ -106,21 +109,32 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
   {  // the first two entries of a bucket in prim, the rest in ovf (mg_kcount.hip: k_kc_place)
     KcEntry none{};
     none.key = kKcNone;
-    ix.prim.assign(2u << bb, none);
+    ix.prim.assign((size_t)kKcSlots << bb, none);
     size_t j = 0;
     for (uint32_t b = 0; b < (1u << bb); ++b) {
       size_t j0 = j;
       while (j < ix.ent.size() && (ix.ent[j].key & bm) == b) ++j;
       const size_t n = j - j0;
-      for (size_t t = 0; t < n && t < 2; ++t) { ix.prim[2 * b + t] = ix.ent[j0 + t]; ix.prim[2 * b + t].pad = 0; }
-      ix.prim[2 * b].pad = n > 2 ? (uint32_t)(n - 2) : 0u;
-      ix.prim[2 * b + 1].pad = (uint32_t)ix.ovf.size();
-      for (size_t t = 2; t < n; ++t) ix.ovf.push_back(ix.ent[j0 + t]);
+      for (size_t t = 0; t < n && t < kKcSlots; ++t) { ix.prim[kKcSlots * b + t] = ix.ent[j0 + t]; ix.prim[kKcSlots * b + t].pad = 0; }
+      ix.prim[kKcSlots * b].pad = n > kKcSlots ? (uint32_t)(n - kKcSlots) : 0u;
+      ix.prim[kKcSlots * b + 1].pad = (uint32_t)ix.ovf.size();
+      for (size_t t = kKcSlots; t < n; ++t) ix.ovf.push_back(ix.ent[j0 + t]);
     }
     ix.ovf.push_back(none);
   }
-  for (auto& e : ix.ent) { ix.live[e.key >> 5] |= 1u << (e.key & 31u); ix.maxkey = std::max(ix.maxkey, e.key); }
-  ix.sat.assign(((2u << bb) + ix.ovf.size()) / 32 + 2, 0u);
+  {  // the gate: few bits here (g_gate_extra = 0: about one per k-mer), so that hashes SHARE bits and the shared ones stay set
+    const uint32_t gbits = kc_gate_bits(first.size(), g_gate_extra);
+    ix.gshift = 32u - gbits;
+    ix.live.assign(((size_t)1 << gbits) / 32 + 1, 0u);
+    ix.shared.assign(ix.live.size(), 0u);
+    for (size_t j = 0; j < ix.ent.size(); ++j) {
+      if (j && ix.ent[j].key == ix.ent[j - 1].key) continue;  // (sorted by bucket, then hash: equal hashes are adjacent)
+      const uint32_t g = ix.ent[j].key >> ix.gshift;
+      if ((ix.live[g >> 5] >> (g & 31u)) & 1u) ix.shared[g >> 5] |= 1u << (g & 31u);
+      ix.live[g >> 5] |= 1u << (g & 31u);
+    }
+  }
+  ix.sat.assign((((size_t)kKcSlots << bb) + ix.ovf.size()) / 32 + 2, 0u);
   ix.cs = g_cs;
   const KcIndexView view = ix.view();
 
@@ -145,7 +159,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
     }
     const uint64_t t_beg = beg[0];
     if (maxlen < (uint64_t)K) continue;
-    auto drain_and_walk = [&](const uint32_t* p0, const uint32_t* len, uint32_t mlen, int mode, bool regular = false) {
+    auto drain_and_walk = [&](const uint32_t* p0, const uint32_t* len, uint32_t mlen, int mode) {
       const uint32_t nwmax = mlen - K + 1;
       uint32_t w0 = 0;
       bool first_call = true;
@@ -170,10 +184,10 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
             if (key == kKcNone || i1 >= next) continue;
             if (i2 >= next) i2 = next - 1;
             ++runs;
+            key = kc_run_hash(fwd.data(), p0[l], key, K);
             if (!kc_gate(view, key)) continue;
             ++passed;
-            if (g_ascii && regular) kc_match_item_ascii(view, bases.data() + beg[l], (uint32_t)(end[l] - beg[l]), K, key, i1, i2);
-            else if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
+            if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
             else kc_match_run<false>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
           }
         w0 = next;
@@ -208,7 +222,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
         ragged = ragged || len[l] != maxlen;
         kmers += bad ? kc_clean_windows(inv.data(), p0[l], len[l], (uint32_t)maxlen, K) : (len[l] >= (uint32_t)K ? len[l] - K + 1 : 0);
       }
-      drain_and_walk(p0, len, (uint32_t)maxlen, bad ? 0 : (ragged ? 2 : 1), true);
+      drain_and_walk(p0, len, (uint32_t)maxlen, bad ? 0 : (ragged ? 2 : 1));
     } else {
       const uint32_t per = (sd * 16u / 64u) & ~15u;
       const uint32_t ch = per < 1008u ? per : 1008u, stride = ch - K + 1;
@@ -268,8 +282,9 @@ int main() {
   std::string line;
   std::getline(std::cin, line);
   int cs = 0;
-  if (std::sscanf(line.c_str(), "%d %d %d %d %d %d %d", &k, &g_cap, &ntable, &nreads, &lead, &cs, &g_ascii) != 7) return 2;
+  if (std::sscanf(line.c_str(), "%d %d %d %d %d %d %d", &k, &g_cap, &ntable, &nreads, &lead, &cs, &g_bb) != 7) return 2;
   g_cs = (uint32_t)cs;
+  if (g_bb > 0) g_gate_extra = 0;
   std::vector<std::string> table(ntable), reads(nreads);
   for (auto& t : table) std::getline(std::cin, t);
   for (auto& r : reads) std::getline(std::cin, r);

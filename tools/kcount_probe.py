@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--knob", action="append", default=[])
     ap.add_argument("--no_hash_path", action="store_true")
+    ap.add_argument("--cs", type=int, default=3, help="the counters' saturation (kmc -cs); 0 = none")
     args = ap.parse_args()
     from metalign_amd import _hip, synth
     from metalign_amd._hip import Hip
@@ -33,6 +34,7 @@ def main():
         k, v = kv.split("=")
         _hip.debug_set(k, int(v))
     ks = [int(x) for x in args.ks.split(",")]
+    hip.count_saturation(args.cs)
     t0 = time.time()
     gb, go = synth.make_genomes(args.genomes, args.genome_len)
     rb, ro, _ = synth.make_reads(gb, go, args.reads, npresent=max(50, args.genomes // 20))
