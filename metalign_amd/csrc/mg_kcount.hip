@@ -167,7 +167,7 @@ struct KcLds {
     p0s = inv + 4u * (sd / 2 + kKcSlack);
     stat = p0s + 4u * 64u;  // [0] runs, [1] runs past the gate, [2] matches of this wavefront so far; MG_KC_CLOCKS: [4..7] cycles / 64
     lists = stat + 4u * 12u;
-    hitq = lists + 8u * 64u * (kKcListCap + 1u);
+    hitq = lists + 4u * 64u * (kKcListCap + 1u);
     scanq = hitq + 8u * kKcHitCap;
     total = scanq + 8u * kKcHitCap;
   }
@@ -224,7 +224,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
   const MG_LDS uint32_t* inv = (const MG_LDS uint32_t*)(size_t)(lds + L.inv);
   const MG_LDS uint32_t* p0s = (const MG_LDS uint32_t*)(size_t)(lds + L.p0s);
-  const MG_LDS unsigned long long* lists = (const MG_LDS unsigned long long*)(size_t)(lds + L.lists);
+  const MG_LDS uint32_t* lists = (const MG_LDS uint32_t*)(size_t)(lds + L.lists);
   MG_LDS unsigned long long* hitq = (MG_LDS unsigned long long*)(size_t)(lds + L.hitq);
   MG_LDS unsigned long long* scanq = (MG_LDS unsigned long long*)(size_t)(lds + L.scanq);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
@@ -336,35 +336,31 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   const uint32_t maxc = wave_max_u32(cnt);
   const uint32_t myp0 = p0s[lane];
   const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
-  for (uint32_t s0 = 0; s0 < maxc; s0 += 8) {  // (eight runs of a lane per round trip: a 150 bp read has six)
-    unsigned long long ev[8];
-    uint32_t gw[8];
+  constexpr int G = (int)kKcListCap;  // (all of a lane's runs in one round trip to memory: a 150 bp read has seven)
+  for (uint32_t s0 = 0; s0 < maxc; s0 += G) {
+    uint32_t ev[G], hk[G], gw[G];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ev[j] = (unsigned long long)kKcNone;
+    for (int j = 0; j < G; ++j) {
+      ev[j] = ~0u; hk[j] = 0; gw[j] = 0;
+      if (s0 + j >= maxc) continue;  // (uniform)
       if (s0 + j < cnt) ev[j] = lists[(s0 + j) * 64u + (uint32_t)lane];
       if (clip) {  // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
-        const uint32_t info = (uint32_t)(ev[j] >> 32), i1 = info & 1023u, i2 = (info >> 10) & 1023u;
-        if (i1 >= limit) ev[j] = (unsigned long long)kKcNone;
-        else if (i2 >= limit) ev[j] = (ev[j] & ~(1023ull << 42)) | ((unsigned long long)(limit - 1u) << 42);
+        const uint32_t i1 = ev[j] & 1023u, i2 = (ev[j] >> 10) & 1023u;
+        if (i1 >= limit) ev[j] = ~0u;
+        else if (i2 >= limit) ev[j] = (ev[j] & ~(1023u << 10)) | ((limit - 1u) << 10);
       }
-    }
-    // a run's word says where its candidate starts: the bases around it, hashed, are what the table files k-mers under
-    uint32_t hk[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t word = (uint32_t)ev[j];
-      hk[j] = kc_run_hash(fwd, myp0, word, k);
-      gw[j] = word != kKcNone ? MG_KC_LOAD(&live[(hk[j] >> gshift) >> 5]) : 0u;
+      // a run's event says where its candidate starts: the bases around it, hashed, are what the table files k-mers under
+      hk[j] = kc_run_hash(fwd, myp0, kc_event_pos(ev[j]), k);
+      if (!kc_event_none(ev[j])) gw[j] = MG_KC_LOAD(&live[(hk[j] >> gshift) >> 5]);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t word = (uint32_t)ev[j];
-      nev += word != kKcNone ? 1u : 0u;
+    for (int j = 0; j < G; ++j) {
+      if (s0 + j >= maxc) continue;  // (uniform)
+      nev += kc_event_none(ev[j]) ? 0u : 1u;
       const bool pass = (gw[j] >> ((hk[j] >> gshift) & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
       if (m == 0ull) continue;
-      if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = (unsigned long long)hk[j] | (ev[j] & 0xffffffff00000000ull) | ((unsigned long long)lane << 52);
+      if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = (unsigned long long)hk[j] | ((unsigned long long)(ev[j] & 0xfffffu) << 32) | ((unsigned long long)lane << 52);
       hn += (uint32_t)__popcll(m);
       npass += pass ? 1u : 0u;
       if (hn >= 64u) {  // (room for one more push of 64 must stay)
@@ -409,7 +405,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 
 // what kc_walk writes through
 struct KcDevOut {
-  MG_LDS unsigned long long* mine;  // this lane's column of the lists (slot s at mine[s * 64]): key | info << 32
+  MG_LDS uint32_t* mine;  // this lane's column of the lists (slot s at mine[s * 64]): kc_event
   uint32_t* live;
   const uint32_t* shared;
   const KcEntry* prim;
@@ -417,7 +413,7 @@ struct KcDevOut {
   uint32_t* counts;
   uint32_t* sat;
   uint32_t gshift, cfg, lds, sd;
-  __device__ __forceinline__ void put(uint32_t slot, uint32_t key, uint32_t info) { mine[slot * 64u] = (unsigned long long)key | ((unsigned long long)info << 32); }
+  __device__ __forceinline__ void put(uint32_t slot, uint32_t word, uint32_t info) { mine[slot * 64u] = kc_event(word, info); }
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
 #ifdef MG_KC_NO_DRAIN  // (ISA inspection: what the walks need by themselves)
     return;
@@ -429,7 +425,7 @@ struct KcDevOut {
   }
   static constexpr uint32_t kCap = kKcListCap;
   __device__ __forceinline__ bool any_full(uint32_t cnt) const { return __builtin_amdgcn_ballot_w64(cnt >= kKcListCap) != 0ull; }
-  __device__ __forceinline__ uint32_t last_window(uint32_t slot) const { return ((uint32_t)(mine[slot * 64u] >> 32) >> 10) & 1023u; }
+  __device__ __forceinline__ uint32_t last_window(uint32_t slot) const { return (mine[slot * 64u] >> 10) & 1023u; }
   __device__ __forceinline__ uint32_t wave_min(uint32_t v) const {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -467,7 +463,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
   MG_LDS uint32_t* inv = (MG_LDS uint32_t*)(base + L.inv);
   MG_LDS uint16_t* inv16 = (MG_LDS uint16_t*)(base + L.inv);
   MG_LDS uint32_t* p0s = (MG_LDS uint32_t*)(base + L.p0s);
-  MG_LDS unsigned long long* lists = (MG_LDS unsigned long long*)(base + L.lists);
+  MG_LDS uint32_t* lists = (MG_LDS uint32_t*)(base + L.lists);
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(base + L.stat);
   const uint32_t cfg0 = (uint32_t)__builtin_popcount(a.bmask) | ((uint32_t)K << 8) | ((a.ablate & 7u) << 17) | ((a.cs > 4095u ? 0u : a.cs) << 20);
   uint32_t kmers = 0;
@@ -795,6 +791,9 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   unsigned per_cu = (unsigned)(160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
+  // (what the registers allow: MG_KC_WAVES_PER_EU wavefronts on each of a CU's four SIMDs — a workgroup more than fit would start
+  // when the first has finished, and the persistent grid's share of the tiles is cut by the workgroups LAUNCHED)
+  if (per_cu > (unsigned)(MG_KC_WAVES_PER_EU * 4 / kKcWaves)) per_cu = (unsigned)(MG_KC_WAVES_PER_EU * 4 / kKcWaves);
   if (dbg("kc_wg_per_cu") > 0) per_cu = (unsigned)dbg("kc_wg_per_cu");
   if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const uint64_t ntiles = (nreads + 63) / 64;

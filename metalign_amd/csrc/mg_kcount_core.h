@@ -92,10 +92,11 @@ MG_HD uint32_t kc_ext_hash(uint64_t v, int k) {
   const int nb = 2 * (kKcM + 2 * kc_flank(k));
   const uint64_t f = v >> (64 - nb);
   const uint64_t r = ((((uint64_t)kc_rc32((uint32_t)v)) << 32) | kc_rc32((uint32_t)(v >> 32))) & ((1ull << nb) - 1ull);
-  uint64_t z = (f < r ? f : r) * 0x9E3779B97F4A7C15ull;
-  z ^= z >> 32;
-  z *= 0xD6E8FEB86659FD93ull;
-  const uint32_t h = (uint32_t)(z >> 32);
+  const uint64_t c = f < r ? f : r;  // (38 bits at most)
+  uint32_t h = (uint32_t)c * 0x9E3779B1u ^ ((uint32_t)(c >> 32) + 0x7F4A7C15u) * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0x2C1B3C6Du;
+  h ^= h >> 12; h *= 0x297A2D39u;
+  h ^= h >> 15;
   return h == kKcNone ? 0x7fffffffu : h;
 }
 // bits of the gate bitmap for a table of nd distinct k-mers: 2^extra bits per k-mer (one run in 2^extra that has nothing to find
@@ -134,10 +135,15 @@ MG_HD uint64_t kc_ext64(const MG_LDS uint32_t* s, uint32_t p) {
   const uint32_t hi = (uint32_t)(((((uint64_t)a) << 32 | b) << sh) >> 32), lo = (uint32_t)(((((uint64_t)b) << 32 | c) << sh) >> 32);
   return ((uint64_t)hi << 32) | lo;
 }
-// the hash a closed run is looked up by: its word's low bits say where its candidate starts in the lane's read
-MG_HD uint32_t kc_run_hash(const MG_LDS uint32_t* fwd, uint32_t p0, uint32_t word, int k) {
-  return kc_ext_hash(kc_ext64(fwd, p0 + (word & kKcPos)), k);
+// the hash a closed run is looked up by (pos: where its candidate starts in the read that starts at stream position p0)
+MG_HD uint32_t kc_run_hash(const MG_LDS uint32_t* fwd, uint32_t p0, uint32_t pos, int k) {
+  return kc_ext_hash(kc_ext64(fwd, p0 + pos), k);
 }
+// An EVENT = a closed run in 32 bits: first window | last window << 10 | its candidate's number << 20 (the two bits above: whatever
+// the word's rank left there).  A run of windows that have no minimizer (word kKcNone) says candidate 1023: no event.
+MG_HD uint32_t kc_event(uint32_t word, uint32_t info) { return (word << 20) | info; }
+MG_HD bool kc_event_none(uint32_t ev) { return ((ev >> 20) & kKcPos) == kKcPos; }
+MG_HD uint32_t kc_event_pos(uint32_t ev) { return (ev >> 20) & kKcPos; }
 
 struct KcWin { uint32_t w[4]; };  // a k-mer, LEFT-aligned: base 0 in the top pair of w[0]; bits below 2k are zero
 
@@ -301,8 +307,8 @@ MG_HD uint32_t kc_notbase16(const uint32_t v[4]) {
 }
 
 // ---- the read side: runs of windows that share their minimizer -------------------------------------------------------
-// An event = a closed run: (key, first window | last window << 10); key == kKcNone: nothing (skipped by whoever reads the list).
-// Out: put(slot, key, info) stores the run a lane is ABOUT to close in its list (every step, at the slot after its closed
+// An event = a closed run: (word, first window | last window << 10), kept as kc_event(word, info); word == kKcNone: nothing
+// (skipped by whoever reads the list).  Out: put(slot, word, info) stores the run a lane is ABOUT to close in its list (every step, at the slot after its closed
 // ones: whether the run closes is known one compare later — an unconditional store and an add-with-carry instead of a branch);
 // a list has kCap slots and one more that takes the stores of a lane whose list is full; any_full(cnt), wave_min(x): the two
 // things the walk asks of the whole wavefront, once per block and once per call.

@@ -38,11 +38,11 @@ struct HostOut {
 template <uint32_t CAP>
 struct HostOutN {
   static constexpr uint32_t kCap = CAP;
-  std::vector<std::pair<uint32_t, uint32_t>> ev;  // CAP + 1 slots
+  std::vector<uint32_t> ev;  // CAP + 1 slots
   HostOutN() : ev(CAP + 1) {}
-  void put(uint32_t slot, uint32_t key, uint32_t info) { ev.at(slot) = {key, info}; }
+  void put(uint32_t slot, uint32_t word, uint32_t info) { ev.at(slot) = kc_event(word, info); }
   bool any_full(uint32_t) const { return false; }  // (the device leaves a block early when some lane is full: fewer wasted steps, same events)
-  uint32_t last_window(uint32_t slot) const { return (ev.at(slot).second >> 10) & 1023u; }
+  uint32_t last_window(uint32_t slot) const { return (ev.at(slot) >> 10) & 1023u; }
   uint32_t wave_min(uint32_t v) const { return v; }  // (the caller takes the minimum over the lanes)
 };
 
@@ -179,12 +179,12 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
         if (next <= w0) { std::fprintf(stderr, "the walk made no progress\n"); std::exit(2); }
         for (int l = 0; l < 64; ++l)
           for (uint32_t s = 0; s < cnt[l]; ++s) {
-            uint32_t key = out[l].ev[s].first, info = out[l].ev[s].second;
-            uint32_t i1 = info & 1023u, i2 = (info >> 10) & 1023u;
-            if (key == kKcNone || i1 >= next) continue;
+            const uint32_t ev = out[l].ev[s];
+            uint32_t i1 = ev & 1023u, i2 = (ev >> 10) & 1023u;
+            if (kc_event_none(ev) || i1 >= next) continue;
             if (i2 >= next) i2 = next - 1;
             ++runs;
-            key = kc_run_hash(fwd.data(), p0[l], key, K);
+            const uint32_t key = kc_run_hash(fwd.data(), p0[l], kc_event_pos(ev), K);
             if (!kc_gate(view, key)) continue;
             ++passed;
             if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
