@@ -92,7 +92,7 @@ __global__ void k_kc_entries(const uint64_t* __restrict__ skey, const uint32_t* 
     e.w[0] = (uint32_t)(h >> 32); e.w[1] = (uint32_t)h; e.w[2] = (uint32_t)(l >> 32); e.w[3] = (uint32_t)l;
     e.head = dhead[id];
     e.key = (uint32_t)skey[j];  // (the low word of the sort key: the hash)
-    e.sig_rc = kc_revcomp(KcWin{{e.w[0], e.w[1], e.w[2], e.w[3]}}, k).w[0];
+    e.off = kc_table_key_offset(KcWin{{e.w[0], e.w[1], e.w[2], e.w[3]}}, k, e.key);
     e.pad = 0;
     ent[j] = e;
     if (j == 0 || skey[j - 1] != skey[j]) {
@@ -123,7 +123,7 @@ __global__ void k_kc_place(const KcEntry* __restrict__ ent, const uint32_t* __re
   KC_FOR(b, nb) {
     const uint32_t lo = offs[b], n = offs[b + 1] - lo;
     KcEntry none;
-    none.w[0] = none.w[1] = none.w[2] = none.w[3] = 0; none.head = 0; none.key = kKcNone; none.sig_rc = 0; none.pad = 0;
+    none.w[0] = none.w[1] = none.w[2] = none.w[3] = 0; none.head = 0; none.key = kKcNone; none.off = 0; none.pad = 0;
     for (uint32_t t = 0; t < kKcSlots; ++t) {
       KcEntry e = t < n ? ent[lo + t] : none;
       e.pad = t == 0 ? (n > kKcSlots ? n - kKcSlots : 0u) : (t == 1 ? (uint32_t)before[b] : 0u);
@@ -155,12 +155,12 @@ __global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_
 #endif
 constexpr int kKcWaves = MG_KC_WAVES;    // wavefronts per workgroup (each works alone)
 constexpr uint32_t kKcListCap = MG_KC_LIST_CAP;  // closed runs a lane can hold before the lists are emptied (150 bp, k = 51: six per read)
-constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for a look-up of up to 127 (hitq), items waiting for a scan of 64 (scanq)
+constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for their look-up (hitq, hitl): it comes when 64 or more wait
 constexpr uint32_t kKcSlack = 8;         // dwords a k-mer taken at the end of the stream may read past it
 
 // LDS of one wavefront (bytes), for a stage of sd dwords (sd a multiple of 64)
 struct KcLds {
-  uint32_t fwd, inv, p0s, stat, lists, hitq, scanq, total;
+  uint32_t fwd, inv, p0s, stat, lists, hitq, hitl, total;
   __host__ __device__ explicit KcLds(uint32_t sd) {
     fwd = 0;
     inv = fwd + 4u * (sd + kKcSlack);
@@ -168,8 +168,8 @@ struct KcLds {
     stat = p0s + 4u * 64u;  // [0] runs, [1] runs past the gate, [2] matches of this wavefront so far; MG_KC_CLOCKS: [4..7] cycles / 64
     lists = stat + 4u * 12u;
     hitq = lists + 4u * 64u * (kKcListCap + 1u);
-    scanq = hitq + 8u * kKcHitCap;
-    total = scanq + 8u * kKcHitCap;
+    hitl = hitq + 8u * kKcHitCap;
+    total = hitl + 4u * kKcHitCap;
   }
 };
 
@@ -182,7 +182,7 @@ struct KcArgs {
   const KcEntry* prim;
   const KcEntry* ovf;
   uint32_t* counts;
-  uint32_t* sat;
+  uint32_t* csat;
   unsigned long long* stats;  // [0] k-mers of the reads, [1] runs, [2] runs past the sample's gate, [3] matches counted
   uint32_t gshift, bmask, sd, cs, ablate, stagger;  // ablate (knob kc_ablate, measurements only): 1 = the lists are dropped, 2 = ... after the gate
 };
@@ -205,19 +205,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #define MG_KC_WAVES_PER_EU 3
 #endif
 
-// The lists of a wavefront, in three phases that each keep all 64 lanes on one kind of work and wait for memory ONCE per batch:
-//   gate    every closed run's minimizer against ONE bit of the sample's gate (the table's gate minus the minimizers whose k-mers
-//           are all saturated); the runs that pass are compacted (ballot + popcount) into `hitq`;
-//   lookup  up to 128 runs at a time, two to a lane: the run's bucket — one 128-byte line, four entries — and the saturation
-//           bits of its four entry numbers, all requested together; an entry with the run's minimizer whose bit is clear becomes
-//           an ITEM (run, entry number) in `scanq`; a bucket's later entries (one bucket in a thousand has any) are walked by
-//           the lanes that have them; a run all of whose entries are saturated clears its minimizer's bit in the sample's gate:
-//           at a metagenome's coverage most runs of an abundant genome stop at the gate from then on;
-//   scan    64 items at a time: kc_scan_run (registers only), ONE add per item that matched.
-// One copy of this code per translation unit, CALLED where nothing of the walk is live
-// (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
+// The lists of a wavefront, in two phases that each keep all 64 lanes on one kind of work and wait for memory ONCE:
+//   gate    every closed run: the 19 bases around its candidate hashed, ONE bit of the sample's gate (the table's gate minus the
+//           hashes whose k-mers are all saturated); the runs that pass are compacted (ballot + popcount) into `hitq`;
+//   lookup  64 runs at a time, one to a lane: the run's bucket — one 128-byte line, four entries, all of it — and the four
+//           entries' own counters, all requested together.  An entry filed under the run's hash whose counter is below the
+//           saturation value is matched where it stands (kc_match_windows: the entry says which candidate of its k-mer the hash
+//           is of, so the k-mer can only be at two windows of the run) and counted with two adds that nothing waits for.  The
+//           rare rest — a bucket's entries beyond its line (one bucket in a thousand has any), entries whose hash is of several
+//           candidates (repeats) — go through one rolled loop afterwards (an entry read per turn).  A run all of whose entries
+//           are saturated clears its hash's bit in the sample's gate: at a metagenome's coverage most runs of an abundant
+//           genome stop at the gate from then on.
+// So a tile costs two round trips to memory beyond its own bases.  One copy of this code per translation unit, CALLED where
+// nothing of the walk is live (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
 __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB uint32_t* shared, const MG_GLB KcEntry* prim,
-                                                   const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* sat, uint32_t gshift,
+                                                   const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* csat, uint32_t gshift,
                                                    uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
@@ -225,109 +227,96 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   const MG_LDS uint32_t* inv = (const MG_LDS uint32_t*)(size_t)(lds + L.inv);
   const MG_LDS uint32_t* p0s = (const MG_LDS uint32_t*)(size_t)(lds + L.p0s);
   const MG_LDS uint32_t* lists = (const MG_LDS uint32_t*)(size_t)(lds + L.lists);
-  MG_LDS unsigned long long* hitq = (MG_LDS unsigned long long*)(size_t)(lds + L.hitq);
-  MG_LDS unsigned long long* scanq = (MG_LDS unsigned long long*)(size_t)(lds + L.scanq);
+  MG_LDS unsigned long long* hitq = (MG_LDS unsigned long long*)(size_t)(lds + L.hitq);  // hash | event << 32
+  MG_LDS uint32_t* hitl = (MG_LDS uint32_t*)(size_t)(lds + L.hitl);                      // ... and whose it is
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
   const uint32_t ablate = (cfg >> 17) & 7u;
-  const KcIndexView ix{live, shared, prim, ovf, counts, sat, (1u << (cfg & 0xffu)) - 1u, gshift, cfg >> 20, ablate};
+  const KcIndexView ix{live, shared, prim, ovf, counts, csat, (1u << (cfg & 0xffu)) - 1u, gshift, cfg >> 20, ablate};
   const uint32_t nprim = kKcSlots * (ix.bmask + 1u);
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
   if (ablate == 1u) return;
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t hn = 0, sn = 0, nev = 0, npass = 0, found = 0;
+  uint32_t hn = 0, nev = 0, npass = 0, found = 0;
 #ifdef MG_KC_CLOCKS
   const uint64_t clk0 = __builtin_readcyclecounter();
   uint64_t clk_hits = 0;
 #endif
 
-  auto scan_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
-    if ((uint32_t)lane < n) {
-      const unsigned long long it = q[lane];
-      const uint32_t info = (uint32_t)it, num = (uint32_t)(it >> 32);
-      const KcEntry E = kc_entry(ix, num);
-      const uint32_t p0 = p0s[(info >> 20) & 63u], i1 = info & 1023u, i2 = (info >> 10) & 1023u;
-      const uint32_t f = bad ? kc_scan_run<true>(ix, fwd, inv, k, E, p0, i1, i2) : kc_scan_run<false>(ix, fwd, inv, k, E, p0, i1, i2);
-      kc_count_entry(ix, num, E.head, f);
-      found += f;
-    }
-  };
-  // an entry number that has the run's minimizer and no saturation bit -> scanq (every lane takes part: ballots)
-  auto push_item = [&](bool want, uint32_t info, uint32_t num) {
-    const unsigned long long m = __ballot(want && ablate != 3u);
-    if (m == 0ull) return;
-    if (want) scanq[sn + (uint32_t)__popcll(m & below)] = (unsigned long long)info | ((unsigned long long)num << 32);
-    sn += (uint32_t)__popcll(m);
-    if (sn >= 64u) {
-      wave_lds_sync();
-      sn -= 64u;
-      scan_batch(scanq + sn, 64u);
-      wave_lds_sync();
-    }
-  };
-
-  // up to 128 runs past the gate, two to a lane: their buckets' lines and saturation words are all requested before any is
-  // looked at — one round trip to memory for the lot (a tile of 150 bp reads leaves 80 to 110 such runs: one call).  What is
-  // kept of a bucket is its four minimizers and the two words about its overflow; the loops below are ROLLED (one copy of the
-  // compaction and of the scan they may trigger: the drain's code is fetched once per tile, it must stay small).
-  auto lookup_batch = [&](const MG_LDS unsigned long long* q, uint32_t n) {
-    constexpr int J = 2;
-    uint32_t key[J], info[J], num0[J], satw[J], ek[J][kKcSlots], novf[J], ovf_at[J];
+  auto lookup_batch = [&](uint32_t n) {
+#pragma unroll 1
+    for (uint32_t at0 = 0; at0 < n; at0 += 64u) {
+      const uint32_t at = at0 + (uint32_t)lane;
+      const bool active = at < n;
+      uint32_t key = kKcNone, ev = 0, p0 = 0, num0 = 0, cv[kKcSlots];
+      kc_u32x4 ea[kKcSlots], eb[kKcSlots];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const uint32_t at = (uint32_t)lane + 64u * (uint32_t)j;
-      key[j] = kKcNone; info[j] = 0; num0[j] = 0; satw[j] = 0; novf[j] = 0; ovf_at[j] = 0;
+      for (uint32_t t = 0; t < kKcSlots; ++t) { ea[t] = kc_u32x4{0u, 0u, 0u, 0u}; eb[t] = kc_u32x4{0u, kKcNone, 0u, 0u}; cv[t] = 0; }
+      if (active) {
+        const unsigned long long hq = hitq[at];
+        key = (uint32_t)hq;
+        ev = (uint32_t)(hq >> 32);
+        p0 = p0s[hitl[at]];
+        num0 = kKcSlots * (key & ix.bmask);
+        const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0);
 #pragma unroll
-      for (uint32_t t = 0; t < kKcSlots; ++t) ek[j][t] = ~0u;
-      if (at < n) {
-        const unsigned long long ev = q[at];
-        key[j] = (uint32_t)ev;
-        info[j] = (uint32_t)(ev >> 32);
-        num0[j] = kKcSlots * (key[j] & ix.bmask);
-        // (head | minimizer | signature | pad of the bucket's entries: the second 16 bytes of each, out of one 128-byte line; an
-        // entry's words are read again, by the scan, only for the few that are scanned)
-        const MG_GLB kc_u32x4* p = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.prim + num0[j]);
-        kc_u32x4 e[kKcSlots];
+        for (uint32_t t = 0; t < kKcSlots; ++t) { ea[t] = p[2u * t]; eb[t] = p[2u * t + 1u]; }  // (words | head, hash, off, pad)
+        if (ix.cs != 0u) {
 #pragma unroll
-        for (uint32_t t = 0; t < kKcSlots; ++t) e[t] = p[2u * t + 1u];
-        satw[j] = MG_KC_LOAD(&ix.sat[num0[j] >> 5]);
-#pragma unroll
-        for (uint32_t t = 0; t < kKcSlots; ++t) ek[j][t] = e[t].y;
-        novf[j] = e[0].w;
-        ovf_at[j] = e[1].w;
+          for (uint32_t t = 0; t < kKcSlots; ++t) cv[t] = MG_KC_LOAD(&ix.csat[num0 + t]);
+        }
       }
-    }
-#pragma unroll 1
-    for (int j = 0; j < J; ++j) {
-      const uint32_t kj = j ? key[1] : key[0], ij = j ? info[1] : info[0], nj = j ? num0[1] : num0[0], sj = j ? satw[1] : satw[0];
-      const bool active = kj != kKcNone;
-      const uint32_t sbit = nj & 31u;  // (a multiple of four: the bucket's bits are in one word)
+      const uint32_t i1 = ev & 1023u, i2 = (ev >> 10) & 1023u, pos = kc_event_pos(ev);
       bool any = false, open = false;  // an entry filed under the run's hash; one of them not saturated
-#pragma unroll 1
+      uint32_t slow = 0, fastm = 0;    // entries of the line to match: whose hash is of several candidates / of one: bit t
+#pragma unroll
       for (uint32_t t = 0; t < kKcSlots; ++t) {
-        const uint32_t e0 = j ? ek[1][0] : ek[0][0], e1 = j ? ek[1][1] : ek[0][1], e2 = j ? ek[1][2] : ek[0][2], e3 = j ? ek[1][3] : ek[0][3];
-        const uint32_t et = t == 0 ? e0 : (t == 1 ? e1 : (t == 2 ? e2 : e3));
-        const bool mine = active && et == kj, want = mine && !((sj >> (sbit + t)) & 1u);
+        const bool mine = active && eb[t].y == key, want = mine && !(ix.cs != 0u && cv[t] >= ix.cs);
         any = any || mine;
         open = open || want;
-        push_item(want, ij, nj + t);
+        fastm |= (want && eb[t].z != kKcSeveral && ablate != 3u) ? 1u << t : 0u;
+        slow |= (want && eb[t].z == kKcSeveral && ablate != 3u) ? 1u << t : 0u;
       }
-      // the bucket's later entries (one bucket in a thousand has any): minimizer, then the bit, then the next one
-      const uint32_t nv = active ? (j ? novf[1] : novf[0]) : 0u, oa = j ? ovf_at[1] : ovf_at[0];
-      for (uint32_t t = 0; __ballot(t < nv) != 0ull; ++t) {
-        const uint32_t num = nprim + oa + t;
-        bool want = false;
-        if (t < nv) {
-          const kc_u32x4 x = reinterpret_cast<const MG_GLB kc_u32x4*>(ix.ovf + (oa + t))[1];
-          if (x.y == kj) { any = true; want = !((MG_KC_LOAD(&ix.sat[num >> 5]) >> (num & 31u)) & 1u); }
+#pragma unroll 1
+      for (uint32_t t = 0; t < kKcSlots; ++t) {  // (rolled: one copy of the comparison; the entry's words are selected)
+        const bool fast = (fastm >> t) & 1u;
+        if (__ballot(fast) == 0ull) continue;
+        const kc_u32x4 a = t == 0 ? ea[0] : (t == 1 ? ea[1] : (t == 2 ? ea[2] : ea[3]));
+        const kc_u32x4 b = t == 0 ? eb[0] : (t == 1 ? eb[1] : (t == 2 ? eb[2] : eb[3]));
+        if (fast) {
+          const uint32_t f = kc_match_windows(fwd, inv, k, bad, a.x, a.y, a.z, a.w, b.z, p0, pos, i1, i2);
+          kc_count_entry(ix, num0 + t, b.x, f);
+          found += f;
         }
-        open = open || want;
-        push_item(want, ij, num);
+      }
+      // the rare rest, an entry read per turn: the line's entries of several candidates, then the bucket's entries beyond its line
+      uint32_t nv = active ? eb[0].w : 0u, tv = 0;
+      const uint32_t oa = eb[1].w;
+      while (__ballot(slow != 0u || tv < nv) != 0ull) {
+        if (slow != 0u || tv < nv) {
+          const bool line = slow != 0u;
+          uint32_t num;
+          if (line) { num = num0 + (uint32_t)__builtin_ctz(slow); slow &= slow - 1u; }
+          else { num = nprim + oa + tv; ++tv; }
+          const KcEntry E = kc_entry(ix, num);
+          bool want = line;
+          if (!line && E.key == key) {
+            any = true;
+            want = !(ix.cs != 0u && MG_KC_LOAD(&ix.csat[num]) >= ix.cs);
+            open = open || want;
+          }
+          if (want && ablate != 3u) {
+            const uint32_t f = E.off == kKcSeveral ? kc_scan_run(fwd, inv, k, bad, E.w, p0, i1, i2)
+                                                   : kc_match_windows(fwd, inv, k, bad, E.w[0], E.w[1], E.w[2], E.w[3], E.off, p0, pos, i1, i2);
+            kc_count_entry(ix, num, E.head, f);
+            found += f;
+          }
+        }
       }
       // every k-mer filed under this hash is saturated: its runs stop at the gate from now on — unless another hash of the table
       // has the same bit (a run that such a bit let through found no entry of its own: not its bit to clear)
       if (ix.cs != 0u && any && !open) {
-        const uint32_t g = kj >> ix.gshift;
+        const uint32_t g = key >> ix.gshift;
         if (!((ix.shared[g >> 5] >> (g & 31u)) & 1u)) MG_KC_AND(&ix.live[g >> 5], ~(1u << (g & 31u)));
       }
     }
@@ -336,8 +325,12 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   const uint32_t maxc = wave_max_u32(cnt);
   const uint32_t myp0 = p0s[lane];
   const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
-  constexpr int G = (int)kKcListCap;  // (all of a lane's runs in one round trip to memory: a 150 bp read has seven)
-  for (uint32_t s0 = 0; s0 < maxc; s0 += G) {
+  // All of a lane's runs in one round trip to memory (a 150 bp read has seven), then ONE look-up for the runs that passed — a
+  // single call: a copy of the look-up per slot of the unrolled loop was 80 KB of code.  hitq holds 128: when a round's runs past
+  // the gate do not fit (a tile of reads from unsaturated k-mers), the slots that did not get in are taken again next round.
+  constexpr int G = (int)kKcListCap;
+  uint32_t done = G;
+  for (uint32_t s0 = 0; s0 < maxc; s0 += done) {
     uint32_t ev[G], hk[G], gw[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -353,46 +346,35 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
       hk[j] = kc_run_hash(fwd, myp0, kc_event_pos(ev[j]), k);
       if (!kc_event_none(ev[j])) gw[j] = MG_KC_LOAD(&live[(hk[j] >> gshift) >> 5]);
     }
+    done = G;
+    hn = 0;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      if (s0 + j >= maxc) continue;  // (uniform)
-      nev += kc_event_none(ev[j]) ? 0u : 1u;
+      if (s0 + j >= maxc || (uint32_t)j >= done) continue;  // (uniform)
       const bool pass = (gw[j] >> ((hk[j] >> gshift) & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
+      if (hn + (uint32_t)__popcll(m) > kKcHitCap) { done = (uint32_t)j; continue; }
+      nev += kc_event_none(ev[j]) ? 0u : 1u;
       if (m == 0ull) continue;
-      if (pass) hitq[hn + (uint32_t)__popcll(m & below)] = (unsigned long long)hk[j] | ((unsigned long long)(ev[j] & 0xfffffu) << 32) | ((unsigned long long)lane << 52);
+      if (pass) {
+        const uint32_t at = hn + (uint32_t)__popcll(m & below);
+        hitq[at] = (unsigned long long)hk[j] | ((unsigned long long)ev[j] << 32);
+        hitl[at] = (uint32_t)lane;
+      }
       hn += (uint32_t)__popcll(m);
       npass += pass ? 1u : 0u;
-      if (hn >= 64u) {  // (room for one more push of 64 must stay)
-        wave_lds_sync();
-#ifdef MG_KC_CLOCKS
-        const uint64_t h0 = __builtin_readcyclecounter();
-#endif
-        if (ablate != 2u) lookup_batch(hitq, hn);
-#ifdef MG_KC_CLOCKS
-        clk_hits += __builtin_readcyclecounter() - h0;
-#endif
-        hn = 0;
-        wave_lds_sync();
-      }
     }
-  }
-  if (ablate != 2u) {
+    if (ablate != 2u && hn) {
 #ifdef MG_KC_CLOCKS
-    const uint64_t h0 = __builtin_readcyclecounter();
+      const uint64_t h0 = __builtin_readcyclecounter();
 #endif
-    if (hn) {
       wave_lds_sync();
-      lookup_batch(hitq, hn);
-    }
-    if (sn) {
+      lookup_batch(hn);
       wave_lds_sync();
-      scan_batch(scanq, sn);
-    }
-    wave_lds_sync();
 #ifdef MG_KC_CLOCKS
-    clk_hits += __builtin_readcyclecounter() - h0;
+      clk_hits += __builtin_readcyclecounter() - h0;
 #endif
+    }
   }
   // (the wavefront's totals stay in LDS until the kernel ends: an atomic per call on three global words that every wavefront
   // shares was most of the kernel's time — 31 k calls per 2M reads, each queueing behind the others at the memory side)
@@ -411,7 +393,7 @@ struct KcDevOut {
   const KcEntry* prim;
   const KcEntry* ovf;
   uint32_t* counts;
-  uint32_t* sat;
+  uint32_t* csat;
   uint32_t gshift, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t word, uint32_t info) { mine[slot * 64u] = kc_event(word, info); }
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
@@ -420,7 +402,7 @@ struct KcDevOut {
 #endif
     wave_lds_sync();
     kc_drain((MG_GLB uint32_t*)live, (const MG_GLB uint32_t*)shared, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf,
-             (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)sat, gshift, cfg, lds, sd, cnt, limit);
+             (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)csat, gshift, cfg, lds, sd, cnt, limit);
     wave_lds_sync();
   }
   static constexpr uint32_t kCap = kKcListCap;
@@ -544,7 +526,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t p0 = rd < a.nreads ? (uint32_t)(shift + (beg - t_beg)) : 0u;  // (a lane without a read walks the tile's first bases, masked)
       p0s[lane] = p0;
       wave_lds_sync();
-      KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.sat, a.gshift, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
+      KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.csat, a.gshift, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
       kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
@@ -580,7 +562,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
           inv16[gidx ^ 1u] = (uint16_t)kc_notbase16(vv);
         }
         wave_lds_sync();
-        KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.sat, a.gshift, cfg0 | (1u << 16), lds, a.sd};
+        KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.csat, a.gshift, cfg0 | (1u << 16), lds, a.sd};
         const uint32_t cmax = wave_max_u32(clen);
         kmers += kc_clean_windows(inv, p0, clen, cmax, K);
         kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
@@ -623,7 +605,7 @@ int dispatch_kc(int k, const KcArgs& a, unsigned grid, size_t lds, hipStream_t s
 struct mg_kcounts {
   mg::DevBuf counts;  // u32[npairs + 1]
   mg::DevBuf live;    // the sample's gate: the table's, minus the minimizers all of whose k-mers are saturated (mg_kcount_core.h)
-  mg::DevBuf sat;     // a bit per entry number: its counter has reached the saturation value
+  mg::DevBuf sat;     // a counter per entry number: what has been found under it (at the saturation value the entry is skipped)
   mg::DevBuf stats;   // u64[4]
   uint64_t n = 0, live_words = 0, sat_words = 0;
   const void* gate = nullptr;  // the table's gate bitmap the live one is reset from (owned by the table: it outlives the counters)
@@ -745,7 +727,7 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
   std::unique_ptr<mg_kcounts> kc(new mg_kcounts());
   kc->n = db->kmax.total;
   kc->live_words = db->kidx->gate_words;
-  kc->sat_words = (kKcSlots * db->kidx->nbuckets + db->kidx->novf) / 32 + 2;
+  kc->sat_words = kKcSlots * db->kidx->nbuckets + db->kidx->novf + 4;  // (a counter per entry number)
   kc->gate = db->kidx->gate.p;
   MG_TRY(kc->counts.alloc((kc->n + 1) * 4));
   MG_TRY(kc->live.alloc(kc->live_words * 4));

@@ -71,6 +71,7 @@ constexpr uint32_t kKcMul = 0x2545f491u;     // odd
 constexpr uint32_t kKcPos = 1023u;           // the low ten bits of a candidate's word: where it starts
 constexpr int kKcMinK = kKcM, kKcMaxK = 64;
 constexpr int kKcMaxCands = 50;              // candidates of a k-mer: k - 14 at most
+constexpr uint32_t kKcSeveral = 0xffu;       // KcEntry::off of an entry whose hash belongs to several candidates of its k-mer
 constexpr uint32_t kKcSlots = 4;             // entries of a bucket that sit in its own line (KcIndexView)
 constexpr uint32_t kKcMaxRead = 1023;        // window numbers of an event take ten bits: longer reads go through in chunks
 
@@ -259,14 +260,34 @@ MG_HD int kc_table_keys(const KcWin& x, int k, uint32_t* out) {
   }
   return n;
 }
+// ... and which candidate of x the hash h (one of kc_table_keys') is of: a read window equal to x that chose candidate number c
+// as ITS minimizer starts c windows before it (x's strand) or w - 1 - c (the other) — two windows to compare instead of a run.
+// kKcSeveral when more than one candidate has this hash (a homopolymer, a tandem repeat: those runs are scanned whole).
+MG_HD uint32_t kc_table_key_offset(const KcWin& x, int k, uint32_t h) {
+  const int e = kc_flank(k), w = kc_cands(k);
+  uint32_t best = kKcNone, off = kKcSeveral;
+  for (int j = 0; j < w; ++j) {
+    const uint32_t f = kc_mmer_at(x, j + e);
+    const uint32_t rank = kc_word(f, kc_mmer_rc(f), 0u);
+    best = rank < best ? rank : best;
+  }
+  int n = 0;
+  for (int j = 0; j < w; ++j) {
+    const uint32_t f = kc_mmer_at(x, j + e);
+    if (kc_word(f, kc_mmer_rc(f), 0u) != best || kc_ext_hash(kc_sub64(x, j), k) != h) continue;
+    off = (uint32_t)j;
+    ++n;
+  }
+  return n == 1 ? off : kKcSeveral;
+}
 
 // One distinct canonical k-mer of the table, as the read side meets it (32 bytes, two 16-byte loads).
 struct __attribute__((aligned(16))) KcEntry {
   uint32_t w[4];   // the canonical k-mer, left-aligned
   uint32_t head;   // where it is counted: the first pair of the hash-major table that holds it
   uint32_t key;    // what it is filed under here (kc_table_keys: a k-mer with several has an entry for each)
-  uint32_t sig_rc; // the first sixteen bases of its reverse complement (w[0] is the signature of the k-mer itself)
-  uint32_t pad;
+  uint32_t off;    // which of its candidates that hash is of (its number, 0 .. w - 1) — kKcSeveral: more than one of them
+  uint32_t pad;    // (the first two entries of a bucket: its entries beyond the four of its line — how many, and where)
 };
 
 // ---- staging: sixteen ASCII bases -> one dword of the stream ----------------------------------------------------------
@@ -432,14 +453,16 @@ MG_HD uint32_t kc_clean_windows(const MG_LDS uint32_t* inv, uint32_t p0, uint32_
 // Per sample (mg_kcounts): `live` = a copy of the table's gate bitmap (bit hash >> gshift set <=> some table k-mer is filed
 // under a hash with these leading bits) in which a bit is CLEARED once a run has found every k-mer filed under its hash at the
 // saturation value — unless the table's `shared` bitmap says that two different hashes of the table have this bit (one in
-// 2^kKcGateExtra: their runs keep passing the gate and stop at the saturation bits); ONE bit probe per run decides both; `sat` = a bit per entry number: its counter has reached the saturation value; `counts` at the entry's head.
+// 2^kKcGateExtra: their runs keep passing the gate and stop at the saturation bits); ONE bit probe per
+// run decides both; `csat` = a counter per entry number: what has been found under it (read with its bucket: at the saturation
+// value the entry is skipped); `counts` at the entry's head: the k-mer's occurrences, what stage B reads.
 struct KcIndexView {
   MG_GLB uint32_t* live;
   const MG_GLB uint32_t* shared;
   const MG_GLB KcEntry* prim;
   const MG_GLB KcEntry* ovf;
   MG_GLB uint32_t* counts;
-  MG_GLB uint32_t* sat;
+  MG_GLB uint32_t* csat;
   uint32_t bmask;         // buckets - 1 (minimizers are minima: their HIGH bits are nearly all zero, the low ones spread)
   uint32_t gshift;        // a hash's gate bit is number hash >> gshift (32 - kc_gate_bits)
   uint32_t cs;            // counters are read as min(counter, cs) (kmc -cs<cs>; 0: exact, nothing ever saturates)
@@ -479,16 +502,14 @@ MG_HD bool kc_window_clean(const MG_LDS uint32_t* inv, uint32_t p, int k) {
 }
 
 
-// One table k-mer E against the windows [i1, i2] of the read that starts at stream position p0 (a run that shares E's
-// minimizer).  What every window is tested by is its first sixteen bases against E's two signatures: the bases those tests need
-// — the run's windows begin within w <= 50 bases: 2 (k - 15) + 32 bits, NS dwords — are taken into registers ONCE and shifted
-// along two bits per window; the loop touches neither LDS nor memory (re-reading the stream per window was a dependent LDS
-// round trip each, and the lanes of a batch wait for the longest run).  Only a signature hit — a match, or one window in
-// 2^31 — reads the window's k-mer from the stream and settles it (the reverse strand computed, not read).  Returns the matches.
-template <bool BAD, int NS>
-MG_HD uint32_t kc_scan_run_n(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, const KcEntry& E,
-                             uint32_t p0, uint32_t i1, uint32_t i2) {
-  static_assert(NS >= 2 && NS <= 5, "2 (k - 15) + 32 bits for k <= 64");
+// One table k-mer (words w, left-aligned canonical) against the windows [i1, i2] of the read that starts at stream position p0:
+// EVERY window of the run (the entries whose hash is of several candidates; one copy of this code, for the rare).  What every
+// window is tested by is its first sixteen bases against the k-mer's two signatures: the bases those tests need — the run's
+// windows begin within 50 bases: five dwords — are taken into registers ONCE and shifted along two bits per window; only a
+// signature hit reads the window's k-mer from the stream and settles it.  Returns the matches.
+MG_HD uint32_t kc_scan_run(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, bool bad, const uint32_t* ew,
+                           uint32_t p0, uint32_t i1, uint32_t i2) {
+  constexpr int NS = 5;  // 2 (k - 15) + 32 bits for k <= 64
   const uint32_t p = p0 + i1, d = p >> 4, sh = (p & 15u) << 1;
   uint32_t w[NS];
   {
@@ -499,56 +520,68 @@ MG_HD uint32_t kc_scan_run_n(const KcIndexView& ix, const MG_LDS uint32_t* fwd, 
     for (int j = 0; j < NS; ++j) w[j] = (uint32_t)(((((uint64_t)a[j]) << 32 | a[j + 1]) << sh) >> 32);
   }
   const uint32_t sigmask = kc_keep_mask(k, 0);
-  // the windows whose signature hits are only NOTED in the loop (a run has at most 50) and settled after it, every lane its next
-  // one together: settled where they hit, the lanes of a batch hit at different windows and the wavefront went through the
-  // settling code once per window instead of once or twice
+  const uint32_t sig_rc = kc_revcomp(KcWin{{ew[0], ew[1], ew[2], ew[3]}}, k).w[0];
   uint64_t hits = 0;
   for (uint32_t i = i1; i <= i2; ++i) {
     const uint32_t x0 = w[0] & sigmask;
-    hits |= (x0 == E.w[0] || x0 == E.sig_rc) ? 1ull << (i - i1) : 0ull;
+    hits |= (x0 == ew[0] || x0 == sig_rc) ? 1ull << (i - i1) : 0ull;
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j) w[j] = (w[j] << 2) | (w[j + 1] >> 30);
     w[NS - 1] <<= 2;
   }
   uint32_t found = 0;
-  if (ix.ablate == 4u) hits = 0;
   while (hits) {
     const uint32_t i = i1 + (uint32_t)__builtin_ctzll(hits);
     hits &= hits - 1;
-    bool ok = true;
-    if constexpr (BAD) ok = kc_window_clean(inv, p0 + i, k);
-    if (ok) {
-      const KcWin x = kc_ext128(fwd, p0 + i, k), y = kc_revcomp(x, k);
-      const KcWin c = kc_less(y, x) ? y : x;
-      found += (c.w[0] == E.w[0] && c.w[1] == E.w[1] && c.w[2] == E.w[2] && c.w[3] == E.w[3]) ? 1u : 0u;
+    if (bad && !kc_window_clean(inv, p0 + i, k)) continue;
+    const KcWin x = kc_ext128(fwd, p0 + i, k), y = kc_revcomp(x, k);
+    const KcWin c = kc_less(y, x) ? y : x;
+    found += (c.w[0] == ew[0] && c.w[1] == ew[1] && c.w[2] == ew[2] && c.w[3] == ew[3]) ? 1u : 0u;
+  }
+  return found;
+}
+
+// ... and the usual entry, whose hash is of ONE candidate (number off) of its k-mer: the run's candidate starts at base `pos` of
+// the read's candidate numbering, so a window equal to the k-mer is window pos - off (as the k-mer stands) or pos - (w - 1 - off)
+// (its reverse complement) — if that window is one of the run's (a window that chose another candidate of the same rank is in
+// another run, and meets the k-mer's entry under that candidate's hash).  Two windows, each tested by sixteen bases before its
+// k-mer is taken from the stream.  Returns the matches: 0, 1, or 2.
+MG_HD uint32_t kc_match_windows(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, bool bad, uint32_t e0, uint32_t e1,
+                                uint32_t e2, uint32_t e3, uint32_t off, uint32_t p0, uint32_t pos, uint32_t i1, uint32_t i2) {
+  const uint32_t wc = (uint32_t)kc_cands(k);
+  const uint32_t ia = pos - off, ib = pos - (wc - 1u - off);  // (below zero: far above i2)
+  const uint32_t sigmask = kc_keep_mask(k, 0);
+  uint32_t found = 0;
+  if (ia >= i1 && ia <= i2 && (kc_ext32(fwd, p0 + ia) & sigmask) == e0 && !(bad && !kc_window_clean(inv, p0 + ia, k))) {
+    const KcWin x = kc_ext128(fwd, p0 + ia, k);
+    found += (x.w[0] == e0 && x.w[1] == e1 && x.w[2] == e2 && x.w[3] == e3) ? 1u : 0u;
+  }
+  // (a k-mer that is its own reverse complement, met at the one window both ways: one occurrence)
+  if (ib >= i1 && ib <= i2 && !(ib == ia && found) && !(bad && !kc_window_clean(inv, p0 + ib, k))) {
+    // the first sixteen bases of the reverse complement are the last sixteen of the window, reversed and complemented
+    const uint32_t tail = kc_rc32(kc_ext32(fwd, p0 + ib + (uint32_t)k - 16u));
+    if (k < 16 || (tail & sigmask) == e0) {
+      const KcWin y = kc_revcomp(kc_ext128(fwd, p0 + ib, k), k);
+      found += (y.w[0] == e0 && y.w[1] == e1 && y.w[2] == e2 && y.w[3] == e3) ? 1u : 0u;
     }
   }
   return found;
 }
-template <bool BAD>
-MG_HD uint32_t kc_scan_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, const KcEntry& E,
-                           uint32_t p0, uint32_t i1, uint32_t i2) {
-  const int bits = 2 * (k - kKcM) + 32;  // the signatures of a run's windows: from the first base of the first to the sixteenth of the last
-  if (bits <= 64) return kc_scan_run_n<BAD, 2>(ix, fwd, inv, k, E, p0, i1, i2);
-  if (bits <= 96) return kc_scan_run_n<BAD, 3>(ix, fwd, inv, k, E, p0, i1, i2);
-  if (bits <= 128) return kc_scan_run_n<BAD, 4>(ix, fwd, inv, k, E, p0, i1, i2);
-  return kc_scan_run_n<BAD, 5>(ix, fwd, inv, k, E, p0, i1, i2);
-}
 
-// `found` windows of a run were entry number n (counted at `head`): ONE add for the run, and — counters that saturate — the
-// entry's bit once the add has taken the counter to the saturation value (the add's old value decides: whoever crosses sets it).
+// `found` windows of a run were entry number n (counted at `head`): one add to the k-mer's counter and — counters that saturate —
+// one to the ENTRY's own (what the next run that comes to this entry reads with its bucket: at the saturation value it is
+// skipped).  Neither add's old value is asked for: nothing waits for them.  (The k-mer's counter is at least the entry's.)
 MG_HD void kc_count_entry(const KcIndexView& ix, uint32_t n, uint32_t head, uint32_t found) {
   if (!found || ix.ablate == 5u) return;
-  const uint32_t old = MG_KC_ADD(&ix.counts[head], found);
-  if (ix.cs && old + found >= ix.cs) MG_KC_OR(&ix.sat[n >> 5], 1u << (n & 31u));
+  (void)MG_KC_ADD(&ix.counts[head], found);
+  if (ix.cs) (void)MG_KC_ADD(&ix.csat[n], found);
 }
 
 // A run past the gate against its bucket, one lane on its own (the host check, and the statement of what the kernel's batched
-// phases — mg_kcount.hip: kc_drain — compute): every entry with the run's minimizer whose counter is not saturated is scanned;
-// when all of them are saturated the minimizer's bit is cleared in the sample's gate.
-template <bool BAD>
-MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, uint32_t key,
-                            uint32_t p0, uint32_t i1, uint32_t i2) {
+// phases — mg_kcount.hip: kc_drain — compute): every entry filed under the run's hash whose counter is not saturated is
+// matched; when all of them are saturated the hash's bit is cleared in the sample's gate.
+MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, int k, bool bad, uint32_t key,
+                            uint32_t p0, uint32_t pos, uint32_t i1, uint32_t i2) {
   const uint32_t b = key & ix.bmask, nprim = kKcSlots * (ix.bmask + 1u);
   uint32_t found = 0, novf = 0, ovf_at = 0;
   bool any = false, open = false;  // an entry filed under this hash; one of them whose counter is not saturated
@@ -559,20 +592,18 @@ MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, c
     if (t == 1) ovf_at = E.pad;
     if (E.key != key) continue;
     any = true;
-    if ((MG_KC_LOAD(&ix.sat[n >> 5]) >> (n & 31u)) & 1u) continue;
+    if (ix.cs && MG_KC_LOAD(&ix.csat[n]) >= ix.cs) continue;
     open = true;
-    const uint32_t f = kc_scan_run<BAD>(ix, fwd, inv, k, E, p0, i1, i2);
+    const uint32_t f = E.off == kKcSeveral ? kc_scan_run(fwd, inv, k, bad, E.w, p0, i1, i2)
+                                           : kc_match_windows(fwd, inv, k, bad, E.w[0], E.w[1], E.w[2], E.w[3], E.off, p0, pos, i1, i2);
     kc_count_entry(ix, n, E.head, f);
     found += f;
   }
-  // (a look first: in the second kernel most runs of an abundant genome find the bit cleared already, and an atomic on a word that
-  // a million other lanes are clearing too is the one thing here that queues)
   const uint32_t g = key >> ix.gshift;
   // (a run that another hash's bit let through finds no entry of its own: that bit is not its to clear)
   if (ix.cs && any && !open && !((ix.shared[g >> 5] >> (g & 31u)) & 1u) && ((MG_KC_LOAD(&ix.live[g >> 5]) >> (g & 31u)) & 1u))
     MG_KC_AND(&ix.live[g >> 5], ~(1u << (g & 31u)));
   return found;
 }
-
 
 }  // namespace mg

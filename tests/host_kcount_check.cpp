@@ -91,12 +91,11 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
     std::memcpy(e.w, kv.first.data(), 16);
     const KcWin x{{e.w[0], e.w[1], e.w[2], e.w[3]}};
     e.head = kv.second;
-    e.sig_rc = kc_revcomp(x, K).w[0];
     e.pad = 0;
     uint32_t keys[kKcMaxCands];
     const int nk = kc_table_keys(x, K, keys);  // (one entry per hash the k-mer is filed under)
     if (nk < 1) { std::fprintf(stderr, "a k-mer without a key\n"); std::exit(2); }
-    for (int t = 0; t < nk; ++t) { e.key = keys[t]; ix.ent.push_back(e); }
+    for (int t = 0; t < nk; ++t) { e.key = keys[t]; e.off = kc_table_key_offset(x, K, keys[t]); ix.ent.push_back(e); }
   }
   unsigned bb = 8;
   while (bb < 28 && (1ull << bb) < ix.ent.size()) ++bb;
@@ -134,7 +133,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
       ix.live[g >> 5] |= 1u << (g & 31u);
     }
   }
-  ix.sat.assign((((size_t)kKcSlots << bb) + ix.ovf.size()) / 32 + 2, 0u);
+  ix.sat.assign(((size_t)kKcSlots << bb) + ix.ovf.size() + 2, 0u);  // (a counter per entry number)
   ix.cs = g_cs;
   const KcIndexView view = ix.view();
 
@@ -187,8 +186,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
             const uint32_t key = kc_run_hash(fwd.data(), p0[l], kc_event_pos(ev), K);
             if (!kc_gate(view, key)) continue;
             ++passed;
-            if (mode == 0) kc_match_run<true>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
-            else kc_match_run<false>(view, fwd.data(), inv.data(), K, key, p0[l], i1, i2);
+            kc_match_run(view, fwd.data(), inv.data(), K, mode == 0, key, p0[l], kc_event_pos(ev), i1, i2);
           }
         w0 = next;
       } while (w0 < nwmax);
