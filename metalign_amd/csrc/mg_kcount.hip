@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // nothing of the walk is live (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
 __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB uint32_t* shared, const MG_GLB KcEntry* prim,
                                                    const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* csat, uint32_t gshift,
-                                                   uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t limit) {
+                                                   uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t from, uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
   const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
@@ -235,7 +235,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   const uint32_t nprim = kKcSlots * (ix.bmask + 1u);
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
-  if (ablate == 1u) return;
+  if (ablate == 1u || ablate == 7u) return;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t hn = 0, nev = 0, npass = 0, found = 0;
 #ifdef MG_KC_CLOCKS
@@ -329,14 +329,14 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
   // single call: a copy of the look-up per slot of the unrolled loop was 80 KB of code.  hitq holds 128: when a round's runs past
   // the gate do not fit (a tile of reads from unsaturated k-mers), the slots that did not get in are taken again next round.
   constexpr int G = (int)kKcListCap;
-  uint32_t done = G;
+  uint32_t done = G, first = from;  // (first: the first window of the lane's next run — the walk leaves it out of the events)
   for (uint32_t s0 = 0; s0 < maxc; s0 += done) {
     uint32_t ev[G], hk[G], gw[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       ev[j] = ~0u; hk[j] = 0; gw[j] = 0;
       if (s0 + j >= maxc) continue;  // (uniform)
-      if (s0 + j < cnt) ev[j] = lists[(s0 + j) * 64u + (uint32_t)lane];
+      if (s0 + j < cnt) ev[j] = kc_event_first(lists[(s0 + j) * 64u + (uint32_t)lane], first);
       if (clip) {  // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
         const uint32_t i1 = ev[j] & 1023u, i2 = (ev[j] >> 10) & 1023u;
         if (i1 >= limit) ev[j] = ~0u;
@@ -353,7 +353,7 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
       if (s0 + j >= maxc || (uint32_t)j >= done) continue;  // (uniform)
       const bool pass = (gw[j] >> ((hk[j] >> gshift) & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
-      if (hn + (uint32_t)__popcll(m) > kKcHitCap) { done = (uint32_t)j; continue; }
+      if (hn + (uint32_t)__popcll(m) > kKcHitCap) { done = (uint32_t)j; first = ev[j] & 1023u; continue; }
       nev += kc_event_none(ev[j]) ? 0u : 1u;
       if (m == 0ull) continue;
       if (pass) {
@@ -396,13 +396,13 @@ struct KcDevOut {
   uint32_t* csat;
   uint32_t gshift, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t word, uint32_t info) { mine[slot * 64u] = kc_event(word, info); }
-  __device__ __forceinline__ void drain(uint32_t cnt, uint32_t limit) {
+  __device__ __forceinline__ void drain(uint32_t cnt, uint32_t from, uint32_t limit) {
 #ifdef MG_KC_NO_DRAIN  // (ISA inspection: what the walks need by themselves)
     return;
 #endif
     wave_lds_sync();
     kc_drain((MG_GLB uint32_t*)live, (const MG_GLB uint32_t*)shared, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf,
-             (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)csat, gshift, cfg, lds, sd, cnt, limit);
+             (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)csat, gshift, cfg, lds, sd, cnt, from, limit);
     wave_lds_sync();
   }
   static constexpr uint32_t kCap = kKcListCap;
@@ -427,10 +427,11 @@ __device__ __forceinline__ void kc_tile(const MG_LDS uint32_t* fwd, const MG_LDS
   uint32_t w0 = 0;
   do {
     uint32_t cnt = 0;
+    const uint32_t from = w0;
     if (mode == 0) w0 = kc_walk<K, 0>(fwd, inv, p0, len, maxlen, w0, out, cnt);
     else if (mode == 1) w0 = kc_walk<K, 1>(fwd, inv, p0, len, maxlen, w0, out, cnt);
     else w0 = kc_walk<K, 2>(fwd, inv, p0, len, maxlen, w0, out, cnt);
-    out.drain(cnt, w0 < nwmax ? w0 : 1024u);
+    out.drain(cnt, from, w0 < nwmax ? w0 : 1024u);
   } while (w0 < nwmax);
 }
 
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
         for (int j = 0; j < 6; ++j) {
           const uint32_t i = i0 + 64u * (uint32_t)j;
           v[j] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
-          if (i < nd) v[j] = g[i];
+          if (i < nd) v[j] = a.ablate != 7u ? g[i] : reinterpret_cast<const uint4*>(a.bases)[i & 511u];  // (7, measurements only: the walk alone, over 8 KB of text that stay in the caches)
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -529,7 +530,8 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.csat, a.gshift, cfg0 | (bad ? 1u << 16 : 0u), lds, a.sd};
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
-      kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
+      if (a.ablate != 6u)  // (6, measurements only: the tiles staged and nothing else)
+        kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
     } else {
       // ---- a tile that does not fit (a long read, or a span above the stage): every lane takes its read through in chunks of
       // ch bases that overlap by K - 1, in a slot of its own — byte loads, the general walk; no window is seen twice

@@ -82,9 +82,13 @@ constexpr int kc_cands(int k) { return k - kKcM + 1 - 2 * kc_flank(k); }
 // the WORD of a candidate given both strands of its m-mer 2-bit packed (first base most significant, right-aligned in 30 bits)
 // and its number `pos` (< 1023): its rank above its number — the smallest word of a window is its leftmost candidate of the
 // smallest rank, and says where it is.
+// (The rank is the first eleven bases of the smaller strand under a fixed relabelling of the bases — xor with a constant: three
+// operations.  An odd multiplier over all fifteen spreads the ranks better, but v_mul_lo_u32 runs at a quarter of the rate and this
+// is computed once per base of every read; candidates that tie on eleven bases are told apart by their numbers, and the table
+// files a k-mer under every one of its smallest.)
 MG_HD uint32_t kc_word(uint32_t f, uint32_t r, uint32_t pos) {
   const uint32_t c = f < r ? f : r;
-  return (((c ^ kKcXor) * kKcMul) & ~kKcPos) | pos;
+  return (((c ^ kKcXor) >> 8) << 10) | pos;
 }
 // what a k-mer is filed under: v = 64 bits of bases from the candidate's first flank base on (the 15 + 2 e bases at the top);
 // the smaller strand of those bases, mixed to 32 bits.  Never kKcNone (an unused slot of a bucket has that).
@@ -141,8 +145,15 @@ MG_HD uint32_t kc_run_hash(const MG_LDS uint32_t* fwd, uint32_t p0, uint32_t pos
   return kc_ext_hash(kc_ext64(fwd, p0 + pos), k);
 }
 // An EVENT = a closed run in 32 bits: first window | last window << 10 | its candidate's number << 20 (the two bits above: whatever
-// the word's rank left there).  A run of windows that have no minimizer (word kKcNone) says candidate 1023: no event.
+// the word's rank left there).  A run of windows that have no minimizer (word kKcNone) says candidate 1023: no event.  The walk
+// leaves the first window out (info = last window << 10): a lane's runs follow one another, so whoever reads its list fills it
+// in — the window after the previous event's last, or the window the walk started at (kc_event_first).
 MG_HD uint32_t kc_event(uint32_t word, uint32_t info) { return (word << 20) | info; }
+MG_HD uint32_t kc_event_first(uint32_t ev, uint32_t& next) {  // next: in, this run's first window; out, the following run's
+  const uint32_t out = (ev & ~1023u) | next;
+  next = ((ev >> 10) & 1023u) + 1u;
+  return out;
+}
 MG_HD bool kc_event_none(uint32_t ev) { return ((ev >> 20) & kKcPos) == kKcPos; }
 MG_HD uint32_t kc_event_pos(uint32_t ev) { return (ev >> 20) & kKcPos; }
 
@@ -364,7 +375,7 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
   uint32_t word = kc_ext32(fwd, p0 + (w0 & ~15u)), iw = 0;
   if constexpr (MODE == 0) iw = kc_bits32(inv, p0 + (w0 & ~31u));
   uint32_t A[W];  // this block's keys; from the end of the block on, the block's suffix minima
-  uint32_t P = kKcNone, Mprev = kKcNone, rstart = w0;
+  uint32_t P = kKcNone, Mprev = kKcNone;
   auto take = [&](uint32_t u) -> uint32_t {  // base u comes in; the word of the candidate that ends there (number u - 14)
     if ((u & 15u) == 0) word = kc_ext32(fwd, p0 + u);
     const uint32_t c = (word >> (30u - 2u * (u & 15u))) & 3u;
@@ -399,6 +410,9 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
     const uint32_t j0 = w0 + b * (uint32_t)W;  // the block's first m-mer (m-mer j ends at base j + M - 1 and closes window j - (W - 1))
     if (j0 >= nmers || out.any_full(cnt)) break;
     const bool tail = j0 + (uint32_t)W > nmers;
+    // (the windows past a lane's own read have no minimizer: one compare against the lane's window count — which is "none" while
+    // every lane's read goes on, so that the compare's result goes straight into the select, not through a scalar OR with `tail`)
+    const uint32_t nwt = (MODE != 1 || tail) ? nw : kKcNone;
     auto step = [&]<int T>() -> bool {
       const uint32_t j = j0 + (uint32_t)T;
       if constexpr (T % 8 == 0 && T > 0) { if (tail && j >= nmers) return false; }
@@ -407,11 +421,11 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
       uint32_t Mc = P;
       if constexpr (T != W - 1) { const uint32_t s = A[T + 1 < W ? T + 1 : 0]; Mc = s < P ? s : P; }
       const uint32_t i = j - (uint32_t)(W - 1);
-      if (MODE != 1 || tail) Mc = i < nw ? Mc : kKcNone;
-      out.put(cnt, Mprev, rstart | (((i - 1u) & 1023u) << 10));
+      Mc = i < nwt ? Mc : kKcNone;
+      out.put(cnt, Mprev, ((i - 1u) & 1023u) << 10);
       const bool ch = Mc != Mprev;
-      cnt += (ch && cnt < kCap) ? 1u : 0u;
-      rstart = ch ? i : rstart;
+      cnt += ch ? 1u : 0u;  // (add with carry, then the cap: no scalar AND of two compares in between)
+      cnt = cnt < kCap ? cnt : kCap;
       Mprev = Mc;
       A[T] = key;
       walked = i + 1u;
@@ -423,7 +437,7 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
   }
   walked = walked < nwmax ? walked : nwmax;  // (the tail block may have walked past the end)
   // the run still open (nothing, if its key is kKcNone: a lane whose read has ended closed its last run where it ended)
-  out.put(cnt, Mprev, rstart | (((walked - 1u) & 1023u) << 10));
+  out.put(cnt, Mprev, ((walked - 1u) & 1023u) << 10);
   cnt += cnt < kCap ? 1u : 0u;
   // a full list: everything up to its last event is recorded, what follows may not be
   const uint32_t safe = cnt >= kCap ? out.last_window(kCap - 1u) + 1u : walked;

@@ -176,9 +176,10 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
         if (!first_call) ++restarts;
         first_call = false;
         if (next <= w0) { std::fprintf(stderr, "the walk made no progress\n"); std::exit(2); }
-        for (int l = 0; l < 64; ++l)
+        for (int l = 0; l < 64; ++l) {
+          uint32_t first = w0;  // (the walk leaves a run's first window out: the one after the run before it)
           for (uint32_t s = 0; s < cnt[l]; ++s) {
-            const uint32_t ev = out[l].ev[s];
+            const uint32_t ev = kc_event_first(out[l].ev[s], first);
             uint32_t i1 = ev & 1023u, i2 = (ev >> 10) & 1023u;
             if (kc_event_none(ev) || i1 >= next) continue;
             if (i2 >= next) i2 = next - 1;
@@ -188,6 +189,7 @@ static void run(const std::vector<std::string>& table, const std::vector<std::st
             ++passed;
             kc_match_run(view, fwd.data(), inv.data(), K, mode == 0, key, p0[l], kc_event_pos(ev), i1, i2);
           }
+        }
         w0 = next;
       } while (w0 < nwmax);
     };
