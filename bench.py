@@ -134,7 +134,7 @@ def build_tables(cfg, sketch_n, hip, gb, go, definition, hash_mode, world=1):
             table = hip.refdb_build(h, khi, klo, o, cfg["ks"])
             arrays = table.download(kmers=cfg.get("match") == "kmer")  # (the k-mers in pair order: what the identity oracle looks up)
             arrays["max_hash"] = table.max_hash
-            if world > 1:  # (a rank uploads its share from the arrays)
+            if world > 1 and cfg.get("match") != "kmer":  # (a rank uploads its share from the arrays; by k-mer identity every rank keeps the whole table)
                 table.free()
                 table = None
             return dict(definition=definition, hash_mode=hash_mode, ref_arrays=arrays, reftable=table, table_hashes=len(h))
@@ -173,8 +173,8 @@ def make_job(hip, dist, rank, world, cfg, w, force_dist=False, sub=None):
     hip.set_hash_mode(w["hash_mode"])
     exchange = dist is not None and (world > 1 or force_dist)
     match = None
-    if w["definition"] == "reference_pipeline":  # (the sharded path still meets k-mers by hash value: distributed.ShardJob)
-        match = "kmer" if (cfg.get("match") == "kmer" and not exchange and 15 <= cfg["ks"][-1] <= 64) else "hash"
+    if w["definition"] == "reference_pipeline":
+        match = "kmer" if (cfg.get("match") == "kmer" and 15 <= cfg["ks"][-1] <= 64) else "hash"
     job = mgd.ShardJob(hip, dist, rank, world, k=cfg["ks"], ci=2, pct_id=0.5, always_exchange=force_dist, definition=w["definition"],
                        match=match)
     rb, ro, recs = (w["rb"], w["ro"], w["recs"]) if sub is None else sub

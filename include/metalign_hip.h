@@ -76,7 +76,9 @@ int mg_device_count(void);
  * first), no_avx2, gzip_threads, pgzip_chunk, pgzip_thp, pgzip_timing (the host inflater), stream_thin, stream_threads (the file
  * readers), inflate_trace, inflate_loose_find (the device inflater: a line per stage and hole on stderr; block starts by the format's
  * rules alone), shares_threads (mg_multimapped_shares: 1 = the serial loop, 2 / 4 / 8 host threads; 0 = by the list's length),
- * kc_wg_per_cu, kc_ablate (k_count_kmers: workgroups per CU; measurements only — 1: the minimizer runs are dropped, 2: ... after the gate).
+ * kc_wg_per_cu, kc_ablate (k_count_kmers: workgroups per CU; measurements only — 1: the minimizer runs are dropped, 2: ... after the
+ *   gate, 3: no entry is matched, 5: nothing is counted, 6: the tiles are staged and nothing else, 7: ... staged from 8 KB that
+ *   stay in the caches, the runs dropped); kc_gate_extra (mg_refdb_index_kmers: the gate has 2^this bits per k-mer; default 6).
  * Needs no device and no mg_init.  MG_ERR_ARG for a key that does not exist. */
 int mg_debug_set(const char* key, int64_t value);
 int64_t mg_debug_get(const char* key);
@@ -587,6 +589,12 @@ int mg_refdb_marks(const mg_refdb* db, int ki, uint32_t** d_marks, uint64_t* nwo
  * mg_kcounts_stats: [0] k-mers of the reads (KMC's total), [1] minimizer runs, [2] runs past the gate, [3] matched windows.
  * mg_kcounts_download: per PAIR of the table min(occurrences of its k-mer, cs) (cs: mg_set_count_saturation, 0 = exact).
  * mg_kcounts_device: the raw counters (u32[npairs], meaningful at the pairs mg_refdb_kmer_heads names) for a multi-GPU sum.
+ * mg_kcounts_pack2_dev / _merge2_dev: that sum for counters that saturate at 3 or below (kmc -cs3, the reference's setting): a
+ *   rank packs min(counter, 3) of every pair into two bits (mg_kcounts_pack2_bytes bytes, a multiple of four), the ranks
+ *   all-gather the arrays (2.5 MB per ten million pairs and rank), and every rank sets its counters to the sum over the ranks'
+ *   arrays (d_all: nranks arrays, stride_dwords apart) — min(sum, cs) is what the sample's reads, counted together, would give.
+ *   With mg_stage_a_side_stream on, mg_kcounts_reset and mg_count_kmers_dev run on the stage-A stream; every other call here
+ *   runs on the main stream, after them (an event per set of counters).
  * mg_refpipe_mark_counts_dev / _containment_counts_dev: mg_refpipe_mark_dev / _containment_dev with "the pair's k-mer occurred
  *   >= ci times" read from the counters instead of a read sketch (_ptr_: from counters the caller summed over the ranks). */
 typedef struct mg_kcounts mg_kcounts;
@@ -601,6 +609,10 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
 int mg_kcounts_stats(const mg_kcounts* kc, uint64_t* out4);
 int mg_kcounts_download(const mg_kcounts* kc, const mg_refdb* db, uint32_t* per_pair);
 int mg_kcounts_device(const mg_kcounts* kc, uint32_t** d_counts, uint64_t* n);
+int mg_kcounts_wait(const mg_kcounts* kc); /* the main stream waits for whatever was queued on the counters last (mg_kcounts_device's users) */
+uint64_t mg_kcounts_pack2_bytes(const mg_kcounts* kc);
+int mg_kcounts_pack2_dev(const mg_kcounts* kc, uint32_t* d_out);
+int mg_kcounts_merge2_dev(mg_kcounts* kc, const uint32_t* d_all, uint32_t nranks, uint64_t stride_dwords);
 void mg_kcounts_free(mg_kcounts* kc);
 int mg_refpipe_mark_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax, uint32_t* d_sizes_kmax);
 int mg_refpipe_mark_counts_ptr_dev(const uint32_t* d_counts, const mg_refdb* db, uint32_t ci, uint32_t* d_hits_kmax,

@@ -29,7 +29,7 @@ EXPORTS = [
     "mg_event_create", "mg_event_record", "mg_event_synchronize", "mg_event_destroy", "mg_stage_c_side_stream", "mg_stage_a_side_stream", "mg_stage_a_workgroups_per_cu", "mg_stage_c_join",
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_refdb_index_kmers", "mg_refdb_has_kmer_index", "mg_refdb_distinct_kmers", "mg_refdb_kmer_heads", "mg_kcounts_new", "mg_kcounts_reset", "mg_count_kmers_dev",
-    "mg_kcounts_stats", "mg_kcounts_download", "mg_kcounts_device", "mg_kcounts_free", "mg_refpipe_mark_counts_dev", "mg_refpipe_mark_counts_ptr_dev",
+    "mg_kcounts_stats", "mg_kcounts_download", "mg_kcounts_device", "mg_kcounts_wait", "mg_kcounts_pack2_bytes", "mg_kcounts_pack2_dev", "mg_kcounts_merge2_dev", "mg_kcounts_free", "mg_refpipe_mark_counts_dev", "mg_refpipe_mark_counts_ptr_dev",
     "mg_refpipe_containment_counts_dev",
     "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_drop_resident", "mg_filter_use_resident", "mg_filter_resident_bytes", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
@@ -747,6 +747,25 @@ class KmerCounts:
         p, n = _vp(), ctypes.c_uint64(0)
         self.hip._chk(self.hip.lib.mg_kcounts_device(self.handle, ctypes.byref(p), ctypes.byref(n)))
         return int(p.value or 0), int(n.value)
+
+    def wait(self):
+        """The main stream waits for whatever was queued on the counters last (before device()'s pointer is read there)."""
+        self.hip._chk(self.hip.lib.mg_kcounts_wait(self.handle))
+
+    def pack2_bytes(self):
+        """Bytes of the two-bit array pack2_dev writes (a multiple of four)."""
+        self.hip.lib.mg_kcounts_pack2_bytes.restype = ctypes.c_uint64
+        return int(self.hip.lib.mg_kcounts_pack2_bytes(self.handle))
+
+    def pack2_dev(self, d_out):
+        """min(counter, 3) of every pair in two bits -> device memory at d_out (pack2_bytes() bytes): what a rank of a multi-GPU
+        job hands to the others (counters that saturate at 3 or below)."""
+        self.hip._chk(self.hip.lib.mg_kcounts_pack2_dev(self.handle, ctypes.c_void_p(int(d_out))))
+
+    def merge2_dev(self, d_all, nranks, stride_bytes):
+        """The counters := the sum over the nranks two-bit arrays at d_all (stride_bytes apart, a multiple of four)."""
+        self.hip._chk(self.hip.lib.mg_kcounts_merge2_dev(self.handle, ctypes.c_void_p(int(d_all)), ctypes.c_uint32(int(nranks)),
+                                                         ctypes.c_uint64(int(stride_bytes) // 4)))
 
     def free(self):
         if self.handle:

@@ -849,6 +849,7 @@ int mg_refpipe_mark_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_
   uint64_t n = 0;
   MG_TRY(mg_kcounts_device(kc, &d_counts, &n));
   if (n != db->kmax.total) return fail(MG_ERR_ARG, "these counters belong to another table");
+  MG_TRY(kcounts_wait(kc));
   return match_launch(d_counts, db, ci, d_hits_kmax, d_sizes_kmax);
 }
 

@@ -361,6 +361,8 @@ struct KmerIndex {
   uint64_t novf = 0;
   DevBuf head;           // u32[npairs]: the pair whose counter holds the occurrences of this pair's k-mer
 };
+// the main stream is about to read a sample's k-mer counters (mg_kcount.hip): after whoever wrote them last, on whichever stream
+int kcounts_wait(const mg_kcounts* kc);
 }  // namespace mg
 
 struct mg_refdb {

@@ -204,6 +204,11 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef MG_KC_WAVES_PER_EU
 #define MG_KC_WAVES_PER_EU 3
 #endif
+#ifdef MG_KC_INLINE_DRAIN  // (A/B builds)
+constexpr bool kKcInlineDrain = true;
+#else
+constexpr bool kKcInlineDrain = false;
+#endif
 
 // The lists of a wavefront, in two phases that each keep all 64 lanes on one kind of work and wait for memory ONCE:
 //   gate    every closed run: the 19 bases around its candidate hashed, ONE bit of the sample's gate (the table's gate minus the
@@ -218,9 +223,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 //           genome stop at the gate from then on.
 // So a tile costs two round trips to memory beyond its own bases.  One copy of this code per translation unit, CALLED where
 // nothing of the walk is live (cfg: log2(buckets) | k << 8 | bad << 16 | ablate << 17 (three bits) | cs << 20).
-__device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB uint32_t* shared, const MG_GLB KcEntry* prim,
-                                                   const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* csat, uint32_t gshift,
-                                                   uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t from, uint32_t limit) {
+__device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GLB uint32_t* shared, const MG_GLB KcEntry* prim,
+                                              const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* csat, uint32_t gshift,
+                                              uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t from, uint32_t limit) {
   const int lane = (int)(threadIdx.x & 63u);
   const KcLds L(sd);
   const MG_LDS uint32_t* fwd = (const MG_LDS uint32_t*)(size_t)(lds + L.fwd);
@@ -385,6 +390,12 @@ __device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const 
 #endif
 }
 
+__device__ __attribute__((noinline)) void kc_drain(MG_GLB uint32_t* live, const MG_GLB uint32_t* shared, const MG_GLB KcEntry* prim,
+                                                   const MG_GLB KcEntry* ovf, MG_GLB uint32_t* counts, MG_GLB uint32_t* csat, uint32_t gshift,
+                                                   uint32_t cfg, uint32_t lds, uint32_t sd, uint32_t cnt, uint32_t from, uint32_t limit) {
+  kc_drain_body(live, shared, prim, ovf, counts, csat, gshift, cfg, lds, sd, cnt, from, limit);
+}
+
 // what kc_walk writes through
 struct KcDevOut {
   MG_LDS uint32_t* mine;  // this lane's column of the lists (slot s at mine[s * 64]): kc_event
@@ -396,11 +407,16 @@ struct KcDevOut {
   uint32_t* csat;
   uint32_t gshift, cfg, lds, sd;
   __device__ __forceinline__ void put(uint32_t slot, uint32_t word, uint32_t info) { mine[slot * 64u] = kc_event(word, info); }
+  template <bool INL>
   __device__ __forceinline__ void drain(uint32_t cnt, uint32_t from, uint32_t limit) {
 #ifdef MG_KC_NO_DRAIN  // (ISA inspection: what the walks need by themselves)
     return;
 #endif
     wave_lds_sync();
+    if constexpr (INL)
+      kc_drain_body((MG_GLB uint32_t*)live, (const MG_GLB uint32_t*)shared, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf,
+                    (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)csat, gshift, cfg, lds, sd, cnt, from, limit);
+    else
     kc_drain((MG_GLB uint32_t*)live, (const MG_GLB uint32_t*)shared, (const MG_GLB KcEntry*)prim, (const MG_GLB KcEntry*)ovf,
              (MG_GLB uint32_t*)counts, (MG_GLB uint32_t*)csat, gshift, cfg, lds, sd, cnt, from, limit);
     wave_lds_sync();
@@ -419,7 +435,7 @@ struct KcDevOut {
 };
 
 // a staged tile through the walk, as often as the lists fill up
-template <int K>
+template <int K, bool INL>
 __device__ __forceinline__ void kc_tile(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, uint32_t p0, uint32_t len, uint32_t maxlen,
                                         int mode, KcDevOut& out) {
   if (maxlen < (uint32_t)K) return;
@@ -431,7 +447,7 @@ __device__ __forceinline__ void kc_tile(const MG_LDS uint32_t* fwd, const MG_LDS
     if (mode == 0) w0 = kc_walk<K, 0>(fwd, inv, p0, len, maxlen, w0, out, cnt);
     else if (mode == 1) w0 = kc_walk<K, 1>(fwd, inv, p0, len, maxlen, w0, out, cnt);
     else w0 = kc_walk<K, 2>(fwd, inv, p0, len, maxlen, w0, out, cnt);
-    out.drain(cnt, from, w0 < nwmax ? w0 : 1024u);
+    out.template drain<INL>(cnt, from, w0 < nwmax ? w0 : 1024u);
   } while (w0 < nwmax);
 }
 
@@ -531,7 +547,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
       const uint32_t len = (uint32_t)len64, maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)maxlen64);
       kmers += bad ? kc_clean_windows(inv, p0, len, maxlen, K) : (len >= (uint32_t)K ? len - (uint32_t)K + 1u : 0u);
       if (a.ablate != 6u)  // (6, measurements only: the tiles staged and nothing else)
-        kc_tile<K>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
+        kc_tile<K, kKcInlineDrain>(fwd, inv, p0, len, maxlen, bad ? 0 : (__ballot(len != maxlen) == 0ull ? 1 : 2), out);
     } else {
       // ---- a tile that does not fit (a long read, or a span above the stage): every lane takes its read through in chunks of
       // ch bases that overlap by K - 1, in a slot of its own — byte loads, the general walk; no window is seen twice
@@ -567,7 +583,7 @@ __global__ __launch_bounds__(64 * kKcWaves) __attribute__((amdgpu_waves_per_eu(M
         KcDevOut out{lists + lane, a.live, a.shared, a.prim, a.ovf, a.counts, a.csat, a.gshift, cfg0 | (1u << 16), lds, a.sd};
         const uint32_t cmax = wave_max_u32(clen);
         kmers += kc_clean_windows(inv, p0, clen, cmax, K);
-        kc_tile<K>(fwd, inv, p0, clen, cmax, 0, out);
+        kc_tile<K, false>(fwd, inv, p0, clen, cmax, 0, out);
       }
     }
   }
@@ -611,9 +627,65 @@ struct mg_kcounts {
   mg::DevBuf stats;   // u64[4]
   uint64_t n = 0, live_words = 0, sat_words = 0;
   const void* gate = nullptr;  // the table's gate bitmap the live one is reset from (owned by the table: it outlives the counters)
+  // Who wrote last, and when: with mg_stage_a_side_stream on, a reset and the counting go to the stage-A stream (so that a
+  // rank's collectives on the main stream do not hold the next pass's counting back); whoever touches the counters on another
+  // stream waits for this event first.
+  hipEvent_t ev = nullptr;
+  hipStream_t ev_stream = nullptr;
+  ~mg_kcounts() { if (ev) (void)hipEventDestroy(ev); }
 };
 
 using namespace mg;
+
+namespace mg {
+// `st` is about to read or write the counters: after whatever was queued on them last
+int kcounts_order(const mg_kcounts* kc, hipStream_t st) {
+  if (kc && kc->ev && kc->ev_stream && kc->ev_stream != st) MG_HIP(hipStreamWaitEvent(st, kc->ev, 0));
+  return MG_OK;
+}
+int kcounts_wait(const mg_kcounts* kc) { return kcounts_order(kc, ctx().stream); }
+static int kcounts_wrote(mg_kcounts* kc, hipStream_t st) {
+  MG_HIP(hipEventRecord(kc->ev, st));
+  kc->ev_stream = st;
+  return MG_OK;
+}
+static hipStream_t kcounts_stage_stream() {
+  Context& c = ctx();
+  return c.a_side ? (c.a_side == 2 ? c.stream_a2 : c.stream_a) : c.stream;
+}
+
+// a sample's counters for the other ranks: min(counter, 3) in two bits, pair i in bits 2 (i & 15) of dword i >> 4
+__global__ void k_kc_pack2(const uint32_t* __restrict__ counts, uint64_t n, uint32_t* __restrict__ out) {
+  KC_FOR(w, (n + 15) / 16) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t i = w * 16 + (uint64_t)j;
+      const uint32_t c = i < n ? counts[i] : 0u;
+      v |= (c > 3u ? 3u : c) << (2 * j);
+    }
+    out[w] = v;
+  }
+}
+// ... and the sum of nranks such arrays (rank r's at all + r * stride dwords) back into counters
+__global__ void k_kc_merge2(const uint32_t* __restrict__ all, uint32_t nranks, uint64_t stride, uint64_t n, uint32_t* __restrict__ counts) {
+  KC_FOR(w, (n + 15) / 16) {
+    uint32_t s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = 0;
+    for (uint32_t r = 0; r < nranks; ++r) {
+      const uint32_t v = all[(uint64_t)r * stride + w];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s[j] += (v >> (2 * j)) & 3u;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t i = w * 16 + (uint64_t)j;
+      if (i < n) counts[i] = s[j];
+    }
+  }
+}
+}  // namespace mg
 
 extern "C" {
 
@@ -735,10 +807,8 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
   MG_TRY(kc->live.alloc(kc->live_words * 4));
   MG_TRY(kc->sat.alloc(kc->sat_words * 4));
   MG_TRY(kc->stats.alloc(12 * 8));
-  MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, ctx().stream));
+  MG_HIP(hipEventCreateWithFlags(&kc->ev, hipEventDisableTiming));
+  MG_TRY(mg_kcounts_reset(kc.get()));
   *out = kc.release();
   return MG_OK;
 }
@@ -746,11 +816,43 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
 int mg_kcounts_reset(mg_kcounts* kc) {
   MG_REQUIRE_READY();
   if (!kc) return fail(MG_ERR_ARG, "null argument");
-  MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, ctx().stream));
-  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, ctx().stream));
+  hipStream_t st = kcounts_stage_stream();
+  MG_TRY(kcounts_order(kc, st));
+  MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, st));
+  MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, st));
+  MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, st));
+  MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, st));
+  return kcounts_wrote(kc, st);
+}
+
+int mg_kcounts_wait(const mg_kcounts* kc) {
+  MG_REQUIRE_READY();
+  if (!kc) return fail(MG_ERR_ARG, "null argument");
+  return kcounts_wait(kc);
+}
+
+uint64_t mg_kcounts_pack2_bytes(const mg_kcounts* kc) { return kc ? ((kc->n + 15) / 16) * 4 : 0; }
+
+int mg_kcounts_pack2_dev(const mg_kcounts* kc, uint32_t* d_out) {
+  MG_REQUIRE_READY();
+  if (!kc || !d_out) return fail(MG_ERR_ARG, "null argument");
+  if (ctx().count_sat == 0 || ctx().count_sat > 3)
+    return fail(MG_ERR_STATE, "two bits hold a counter that saturates at 3 or below (it saturates at %u): exchange the counters themselves", ctx().count_sat);
+  MG_TRY(kcounts_wait(kc));
+  if (kc->n) hipLaunchKernelGGL(k_kc_pack2, dim3(g256((kc->n + 15) / 16)), dim3(256), 0, ctx().stream, kc->counts.as<uint32_t>(), kc->n, d_out);
+  MG_HIP(hipGetLastError());
   return MG_OK;
+}
+
+int mg_kcounts_merge2_dev(mg_kcounts* kc, const uint32_t* d_all, uint32_t nranks, uint64_t stride_dwords) {
+  MG_REQUIRE_READY();
+  if (!kc || !d_all || !nranks) return fail(MG_ERR_ARG, "null argument");
+  if (stride_dwords < (kc->n + 15) / 16) return fail(MG_ERR_ARG, "a rank's array is shorter than the counters");
+  MG_TRY(kcounts_wait(kc));
+  if (kc->n) hipLaunchKernelGGL(k_kc_merge2, dim3(g256((kc->n + 15) / 16)), dim3(256), 0, ctx().stream, d_all, nranks, stride_dwords, kc->n,
+                                kc->counts.as<uint32_t>());
+  MG_HIP(hipGetLastError());
+  return kcounts_wrote(kc, ctx().stream);
 }
 
 int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t nreads, uint64_t nbases, const mg_refdb* db,
@@ -762,6 +864,8 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
     return fail(MG_ERR_ARG, "these counters belong to another table");
   if (nreads == 0) return MG_OK;
   Context& c = ctx();
+  hipStream_t st = kcounts_stage_stream();
+  MG_TRY(kcounts_order(kc, st));
   const KmerIndex& ix = *db->kidx;
   // the stage of a wavefront: 64 reads of average length + 12.5 %, in dwords of sixteen bases, a multiple of 64; never below what
   // a chunk of a long read needs (k + 15 bases per lane)
@@ -779,22 +883,23 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   // when the first has finished, and the persistent grid's share of the tiles is cut by the workgroups LAUNCHED)
   if (per_cu > (unsigned)(MG_KC_WAVES_PER_EU * 4 / kKcWaves)) per_cu = (unsigned)(MG_KC_WAVES_PER_EU * 4 / kKcWaves);
   if (dbg("kc_wg_per_cu") > 0) per_cu = (unsigned)dbg("kc_wg_per_cu");
-  if (c.a_side && c.is_stage_a(c.stream) && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
+  if (c.a_side && c.a_side_wg_per_cu && per_cu > c.a_side_wg_per_cu) per_cu = c.a_side_wg_per_cu;
   const uint64_t ntiles = (nreads + 63) / 64;
   const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
   KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.shared.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
            kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), 32u - ix.gbits, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
   {
     ProfScope ps("count_kmers");
-    MG_TRY(dispatch_kc(ix.k, a, grid, lds, c.stream));
+    MG_TRY(dispatch_kc(ix.k, a, grid, lds, st));
     MG_HIP(hipGetLastError());
   }
-  return MG_OK;
+  return kcounts_wrote(kc, st);
 }
 
 int mg_kcounts_stats(const mg_kcounts* kc, uint64_t* out4) {
   MG_REQUIRE_READY();
   if (!kc || !out4) return fail(MG_ERR_ARG, "null argument");
+  MG_TRY(kcounts_wait(kc));
 #ifdef MG_KC_CLOCKS  // (a build for tools/kcount_clocks.sh: four more words — wave-cycles / 64 in the drain, its matching part, the kernel)
   return mg_memcpy_d2h(out4, kc->stats.p, 12 * 8);
 #else
@@ -807,6 +912,7 @@ int mg_kcounts_download(const mg_kcounts* kc, const mg_refdb* db, uint32_t* per_
   if (!kc || !db || !db->kidx || !per_pair) return fail(MG_ERR_ARG, "null argument");
   if (kc->n != db->kmax.total) return fail(MG_ERR_ARG, "these counters belong to another table");
   if (!kc->n) return MG_OK;
+  MG_TRY(kcounts_wait(kc));
   DevBuf out;
   MG_TRY(out.alloc(kc->n * 4));
   hipLaunchKernelGGL(k_kc_per_pair, dim3(g256(kc->n)), dim3(256), 0, ctx().stream, kc->counts.as<uint32_t>(), db->kidx->head.as<uint32_t>(),

@@ -296,8 +296,8 @@ class HipEngine:
             ptrs = [self._hs_ptrs(base_ptr, ki) for ki in range(self.nk)]
             hook = getattr(self, "mark_exchange", None)
             if isinstance(sks[0], _KmerSketch):
-                if hook is not None:
-                    raise _hip.HipError("stage A by k-mer identity has no multi-rank exchange yet: ShardJob(match='hash') for a sharded table")
+                # (a rank of a multi-GPU job holds the whole table, and its counters the whole sample's sums by now: every rank
+                # computes every column, ShardJob._fill_reduce lets rank 0's through)
                 self.hip.refpipe_containment_counts_dev(sks[0].counts, self.reftable, ci, [p[0] for p in ptrs], [p[1] for p in ptrs])
                 return
             if hook is None:
@@ -483,9 +483,11 @@ class HipEngine:
         """This rank's words, assembled on the device from the still pending sketches and the map-only pass."""
         P["rs"] = self._xs[slot]
         W, t = self._xW, self.torch
-        word_t = t.empty(self._xNW, dtype=t.int64, device="cuda")
+        kmer = getattr(self, "kmer", False)  # (no sketch to cut into slices: those words stay zero)
+        word_t = (t.zeros if kmer else t.empty)(self._xNW, dtype=t.int64, device="cuda")
         for ki, sk in enumerate(P["sks"]):
-            sk.slice_words_dev(self._xbounds[ki].ptr, W - 1, word_t.data_ptr() + 8 * ki * (W + 4))
+            if not kmer:
+                sk.slice_words_dev(self._xbounds[ki].ptr, W - 1, word_t.data_ptr() + 8 * ki * (W + 4))
         P["shard"].map_words_dev(word_t.data_ptr() + 8 * self.nsk * (W + 4))
         return word_t
 
@@ -690,8 +692,10 @@ class ShardJob:
         at the LARGEST k only and every smaller k's column comes from the k-prefixes of the matched k_max-mers (load() then
         takes the reference pipeline's table: include/metalign_hip.h, mg_refdb).
         match (the reference pipeline): how a read k_max-mer meets a sketched one — "kmer": by what it IS, as `kmc` +
-        `kmc_tools intersect` do (scripts/select_db.py:50-59; mg_kcount.hip: no hash on the read side; k_max >= 15, one shard);
-        "hash": by its MurmurHash3 value (rounds 4-5; any k, any world size); None: "kmer" where it applies."""
+        `kmc_tools intersect` do (scripts/select_db.py:50-59; mg_kcount.hip: no hash on the read side; 15 <= k_max <= 64; every
+        rank of a multi-GPU job holds the whole table and counts ITS reads, the ranks' counters — two bits per pair at the
+        reference's -cs3 — are all-gathered and summed: _sum_kmer_counts); "hash": by its MurmurHash3 value (rounds 4-5; any k;
+        the table sharded by hash range); None: "kmer" where it applies."""
         self.dist, self.rank, self.world = dist, rank, world
         # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
         self.exchange = dist is not None and (world > 1 or always_exchange)
@@ -707,10 +711,11 @@ class ShardJob:
         self.sks_k = [self.ks[-1]] if self.refpipe else self.ks  # the k the READS are sketched at
         if match not in (None, "kmer", "hash"):
             raise ValueError("match is 'kmer' or 'hash', not %r" % (match,))
-        can_kmer = self.refpipe and not self.exchange and 15 <= self.ks[-1] <= 64 and engine is None
+        can_kmer = self.refpipe and 15 <= self.ks[-1] <= 64 and engine is None
         if match == "kmer" and not can_kmer:
-            raise ValueError("match='kmer' needs the reference pipeline, one shard and 15 <= k_max <= 64")
+            raise ValueError("match='kmer' needs the reference pipeline, the library's engine and 15 <= k_max <= 64")
         self.match = "kmer" if (match in (None, "kmer") and can_kmer) else ("hash" if self.refpipe else None)
+        self._match_asked = match  # (None: a table that does not hold its k-mers falls back to "hash" at load())
         self.ci, self.pct_id, self.s = ci, pct_id, s
         if engine is not None:
             self.engine = engine
@@ -805,7 +810,7 @@ class ShardJob:
         else:
             self.nonempty = [len(recs) > 0]
         if self.refpipe:
-            self.engine.mark_exchange = self._or_marks if self.exchange else None
+            self.engine.mark_exchange = self._or_marks if (self.exchange and self.match != "kmer") else None
             self.engine.match_kmer = self.match == "kmer"
             self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, [], reftable=reftable)
         else:
@@ -864,6 +869,9 @@ class ShardJob:
         if self.match == "kmer":
             # no filter, no resident index: the read side hashes nothing.  The index over the table's k-mers (built once, on the
             # device) from the k-mers a table built here holds, or from the stored ones
+            if reftable is None and full.get("kmer_hi") is None and self._match_asked is None:
+                self.match = "hash"  # (nobody asked for it, and this table cannot serve it)
+        if self.match == "kmer":
             if reftable is None:
                 if full.get("kmer_hi") is None:
                     raise ValueError("match='kmer' needs the table's k-mers (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64); "
@@ -908,7 +916,7 @@ class ShardJob:
         on the rank — its own slice of an all-to-all — is not counted.  `sketch_entries` counts every entry it routes, its
         own slice included: at world size 1 that is the volume that would be split W ways."""
         tr = self.__dict__.setdefault("traffic", {"passes": 0, "words_all_gather": 0, "sketch_all_to_all": 0, "sketch_entries": 0,
-                                                  "prefix_marks_all_to_all": 0, "results_all_reduce": 0})
+                                                  "prefix_marks_all_to_all": 0, "kmer_counts_all_gather": 0, "results_all_reduce": 0})
         tr[kind] += int(nbytes)
         tr["sketch_entries"] += int(entries)
 
@@ -955,6 +963,30 @@ class ShardJob:
             mine[cuts[r]:cuts[r + 1]] = red
             out.append(mine)
         return out
+
+    def _sum_kmer_counts(self, kc):
+        """Stage A by k-mer identity on several ranks: this rank's counters (of ITS reads against the whole table) become the
+        sample's.  Counters that saturate at 3 or below (kmc -cs3, the reference's setting): min(counter, 3) of every pair in
+        two bits, ONE all-gather of those arrays (2.5 MB per ten million pairs and rank) and their sum on every rank;
+        otherwise the 32-bit counters themselves through an all-reduce.  Everything is queued on the main stream (torch's
+        current one); -> the tensors that must outlive the queue."""
+        t, dist, W = self.torch, self.dist, self.world
+        cs = self.engine.hip.count_saturation()
+        if 1 <= cs <= 3:
+            n32 = kc.pack2_bytes() // 4
+            mine = t.empty(max(n32, 1), dtype=t.int32, device="cuda")
+            kc.pack2_dev(mine.data_ptr())
+            every = t.empty((W, max(n32, 1)), dtype=t.int32, device="cuda")
+            dist.all_gather(list(every.unbind(0)), mine)
+            self._sent("kmer_counts_all_gather", 4 * n32 * (W - 1))
+            kc.merge2_dev(every.data_ptr(), W, 4 * max(n32, 1))
+            return mine, every
+        ptr, n = kc.device()
+        kc.wait()
+        tv = t.as_tensor(_CudaView(ptr, max(n, 1), "<i4"), device="cuda")
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+        self._sent("kmer_counts_all_gather", 4 * n if W > 1 else 0)
+        return (tv,)
 
     # ------------------------------------------------------------------
     def _all_to_all(self, send_h, send_c, send_counts, recv_counts):
@@ -1013,8 +1045,11 @@ class ShardJob:
         else:
             sks = eng.sketch_local(self.sks_k, self.hmaxs, self.s)
             (m0, m1), ngroups = eng.profile_begin(self.pct_id, True)
+        kmer = self.match == "kmer"
         word, send_counts = [], []
-        for ki, sk in enumerate(sks):
+        if kmer:
+            word = [0] * (K * (W + 4))
+        for ki, sk in enumerate([] if kmer else sks):
             n = sk.size
             cuts = [0] + eng.split_sketch(sk, self.bounds[ki][1:W]) + [n]
             sc = [cuts[q + 1] - cuts[q] for q in range(W)]
@@ -1028,7 +1063,7 @@ class ShardJob:
         self._sent("words_all_gather", 8 * len(word) * (W - 1))
         words = t.stack(words).cpu().numpy().tolist()
         received, inflight = [], []
-        for ki, sk in enumerate(sks):
+        for ki, sk in enumerate([] if kmer else sks):
             recv_counts = [words[p][ki * (W + 4) + self.rank] for p in range(W)]
             h, c = eng.export_sketch(sk)
             rh, rc, fl = self._all_to_all(h, c, send_counts[ki], recv_counts)
@@ -1045,6 +1080,9 @@ class ShardJob:
             committed = None
         else:
             committed = eng.profile_commit(incoming, first_shard, group_base, self._want_mm)
+        if kmer:
+            self._kmer_keep = self._sum_kmer_counts(sks[0].counts)  # (until the next pass: stage B is queued behind it)
+            return sks, committed
         for wk in inflight:
             wk.wait()
         merged = []
@@ -1163,6 +1201,12 @@ class ShardJob:
     def _fill_reduce(self, buf, hits, sizes, count, bases, first, scalars, qn):
         G, T, K = self.G, self.T, len(self.ks)
         o_sizes, o_count, o_bases, o_first, o_qn, o_scal, _ = self._red_layout()
+        if getattr(self, "match", None) == "kmer":
+            # every rank holds the whole table and the sample's summed counters: every rank's columns ARE the sample's — rank 0's
+            # go into the sum (the matched pairs of the largest k stand in for a sketch size)
+            qn = [int(np.asarray(hits)[-1].sum()) if q is None else q for q in qn]
+            if self.rank != 0:
+                hits, sizes, qn = np.zeros_like(np.asarray(hits)), np.zeros_like(np.asarray(sizes)), [0] * len(qn)
         buf[:K * G] = np.asarray(hits).reshape(-1)  # per-slice partial sums: the all-reduce adds them up
         buf[o_sizes:o_sizes + K * G] = np.asarray(sizes).reshape(-1)
         buf[o_count:o_count + T] = count.view(np.int64)
@@ -1217,7 +1261,7 @@ class ShardJob:
                 gather_words(P, eng.x_redo_words(P, self.bounds, words[self.rank][tail:]))
                 words = eng.x_wait_words(P)
             received, inflight = [], []
-            for ki, sk in enumerate(P["sks"]):
+            for ki, sk in enumerate(P["sks"] if self.match != "kmer" else []):
                 o = ki * (W + 4)
                 sc = [int(x) for x in words[self.rank][o:o + W]]
                 recv_counts = [int(words[p][o + self.rank]) for p in range(W)]
@@ -1230,6 +1274,10 @@ class ShardJob:
             group_base = int(sum(w[tail + 2] for w in words[: self.rank]))
             first_shard = self.nonempty[self.rank] and not any(self.nonempty[: self.rank])
             eng.x_commit(P, incoming, first_shard, group_base)  # runs during the all-to-all: it needs the maps only
+            if self.match == "kmer":
+                P["keep"] = self._sum_kmer_counts(P["sks"][0].counts)
+                eng.x_stage_b(P, P["sks"], self.ci)
+                return
             for wk in inflight:
                 wk.wait()
             merged = []

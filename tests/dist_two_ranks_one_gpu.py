@@ -84,26 +84,34 @@ for kspec, s_cut in ((21, 0), ([21, 31, 51], 0), (21, 500), ([21, 31, 51], 700))
     if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")):
         assert getattr(job, "words_redone", 0) >= 1, getattr(job, "words_redone", 0)
 # ---- the reference pipeline (reads sketched at the largest k only; prefix bitmaps OR-ed across the ranks), both hash modes ----
-for ks, mode in (([21, 31, 51], 0), ([30, 40, 50, 60], 1), ([31], 0)):
+# ... and both ways a read k-mer meets a sketched one: by its hash (the table sharded by hash range), by what it is (every rank the
+# whole table and its own reads; the ranks' counters all-gathered two bits a pair, or — counters that do not saturate — all-reduced)
+for ks, mode, match, cs in (([21, 31, 51], 0, "hash", 3), ([30, 40, 50, 60], 1, "hash", 3), ([31], 0, None, 3), ([21, 31, 51], 0, "kmer", 3),
+                            ([30, 40, 50, 60], 1, "kmer", 0), ([31], 0, "kmer", 2)):
     hip.set_hash_mode(mode)
+    hip.count_saturation(cs)  # (the columns below hold for every saturation value at or above ci = 2)
     oracle.set_hash_mode(mode)
     h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], 1000 if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")) else 200)
     table = hip.refdb_build(h, khi, klo, o, ks)
-    full = table.download(kmers=False)
+    full = table.download(kmers=match == "kmer")
     table.free()
     wtab = oracle.refpipe_build(*oracle.sketch_genomes_kmers(gb, go, ks[-1], 1000 if ("distinct_hint_ppm" in os.environ.get("MG_TEST_KNOBS", "")) else 200), ks)
     qh, qc, _, _ = oracle.sketch_reads(rb, ro, ks[-1], hmax=int(h.max()))
     whits, wsizes = oracle.refpipe_containment(qh, qc, 2, wtab)
-    job = ShardJob(hip, dist, rank, world, k=ks, definition="reference_pipeline")
+    job = ShardJob(hip, dist, rank, world, k=ks, definition="reference_pipeline", match=match)
     job.load(my_rb, my_ro, my_recs, ref2tax, full)
+    assert job.match == (match or "hash"), job.match  # (None: this table holds no k-mers -> the hash path)
     for idx, got in enumerate([job.step(), job.run(4), job.step()]):
         assert np.array_equal(got["hits_k"], whits) and np.array_equal(got["sizes_k"], wsizes), (rank, idx, ks, mode)
         for key in ("count", "bases", "first_seen"):
             assert np.array_equal(got[key], want[key]), (rank, idx, key)
         assert got["tot_rds"] == want["tot_rds"] and got["n_ambig"] == want["n_ambig"]
-        assert got["definition"] == "reference_pipeline" and got["sketched_ks"] == [ks[-1]]
+        assert got["definition"] == "reference_pipeline" and got["sketched_ks"] == [ks[-1]] and got["match"] == job.match
     assert whits[-1].max() > 100
+    if match == "kmer":
+        assert job.traffic_per_pass()["kmer_counts_all_gather"] > 0
     hip.set_hash_mode(0)
+    hip.count_saturation(3)
     oracle.set_hash_mode(0)
 dist.barrier()
 dist.destroy_process_group()
