@@ -75,7 +75,8 @@ int mg_device_count(void);
  * expected candidates: forces table overflows), resident_scan, no_fused, resident_ablate, flush_order (1: filter words first, 2: slots
  * first), no_avx2, gzip_threads, pgzip_chunk, pgzip_thp, pgzip_timing (the host inflater), stream_thin, stream_threads (the file
  * readers), inflate_trace, inflate_loose_find (the device inflater: a line per stage and hole on stderr; block starts by the format's
- * rules alone), shares_threads (mg_multimapped_shares: 1 = the serial loop, 2 / 4 / 8 host threads; 0 = by the list's length),
+ * rules alone), inflate_dev_max_bytes (a `.gz` file above this many bytes — or above half of the free device memory — goes through
+ * the host inflater, whose memory is bounded by its pieces; the device inflater holds the whole compressed file), shares_threads (mg_multimapped_shares: 1 = the serial loop, 2 / 4 / 8 host threads; 0 = by the list's length),
  * kc_wg_per_cu, kc_ablate (k_count_kmers: workgroups per CU; measurements only — 1: the minimizer runs are dropped, 2: ... after the
  *   gate, 3: no entry is matched, 5: nothing is counted, 6: the tiles are staged and nothing else, 7: ... staged from 8 KB that
  *   stay in the caches, the runs dropped); kc_gate_extra (mg_refdb_index_kmers: the gate has 2^this bits per k-mer; default 6).
@@ -188,6 +189,7 @@ uint32_t mg_count_saturation(void);
  *      compared at all. */
 int mg_set_hash_mode(int mode);
 int mg_hash_mode(void);
+const char* mg_hash_mode1_ks(void); /* "1, 5, 10, ...": the k mode 1 is built for (any other k in that mode: MG_ERR_ARG at the launch) */
 
 int mg_sketch_reads_dev(const uint8_t* d_bases, const uint64_t* d_offsets,
                         uint64_t nreads, int k, uint64_t hmax, uint64_t s,

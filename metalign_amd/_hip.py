@@ -31,7 +31,7 @@ EXPORTS = [
     "mg_refdb_index_kmers", "mg_refdb_has_kmer_index", "mg_refdb_distinct_kmers", "mg_refdb_kmer_heads", "mg_kcounts_new", "mg_kcounts_reset", "mg_count_kmers_dev",
     "mg_kcounts_stats", "mg_kcounts_download", "mg_kcounts_device", "mg_kcounts_wait", "mg_kcounts_pack2_bytes", "mg_kcounts_pack2_dev", "mg_kcounts_merge2_dev", "mg_kcounts_free", "mg_refpipe_mark_counts_dev", "mg_refpipe_mark_counts_ptr_dev",
     "mg_refpipe_containment_counts_dev",
-    "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_drop_resident", "mg_filter_use_resident", "mg_filter_resident_bytes", "mg_filter_free",
+    "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_hash_mode1_ks", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_drop_resident", "mg_filter_use_resident", "mg_filter_resident_bytes", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
     "mg_sketch_stream_begin", "mg_sketch_stream_begin_counts", "mg_sketch_stream_add_dev", "mg_sketch_stream_add_file", "mg_sketch_stream_finish", "mg_sketch_stream_nreads", "mg_sketch_stream_nbases", "mg_sketch_stream_free",
@@ -158,6 +158,15 @@ def multimapped_shares(mm_offsets, mm_tax, mm_hitlen, weight, genome_len=None):
     if rc != 0:
         raise HipError("libmetalign_hip rc=%d: %s" % (rc, _host_lib.mg_last_error().decode("utf-8", "replace")), rc)
     return extra, touched.astype(bool)
+
+
+def hash_mode1_ks():
+    """The k hash mode 1 (the CMash recollection) is built for.  Host code of the library: no device involved."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load_library()
+    _host_lib.mg_hash_mode1_ks.restype = ctypes.c_char_p
+    return [int(x) for x in _host_lib.mg_hash_mode1_ks().decode().split(",")]
 
 
 def gunzip_file(path, nthreads=0, piece=256 << 20):

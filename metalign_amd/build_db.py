@@ -164,6 +164,15 @@ def main(argv=None):
         with open(a.genomes) as fh:
             paths = [ln.strip() for ln in fh if ln.strip()]
     ks = [int(x) for x in a.ks.split(',')]
+    if a.hash_mode == 'cmash' or a.sketch_hash == 'forward':
+        # (that mode's kernels exist for a list of k; found out here, not at the first launch after the genomes have been read.  The
+        # reference pipeline hashes at its largest k only — the smaller k are prefixes)
+        from . import _hip
+        hashed = [max(ks)] if (a.reference_pipeline or a.prefix_tables) else ks
+        missing = [k for k in hashed if k not in _hip.hash_mode1_ks()]
+        if missing:
+            p.error('--hash_mode cmash / --sketch_hash forward are built for k in {%s}; not for k = %s (--hash_mode canonical takes every k from 1 to 64)'
+                    % (', '.join(str(k) for k in _hip.hash_mode1_ks()), ', '.join(str(k) for k in missing)))
     if a.reference_pipeline:
         if len(ks) > 4:
             p.error('--reference_pipeline takes at most four k')

@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 // ---- test / diagnostic knobs ----
 static const char* const kDebugKeys[] = {
     "k3_hashed", "k3_flush_tiles", "k3_grid", "lds_pad", "force_list", "distinct_hint_ppm", "resident_scan", "no_fused", "resident_ablate",
-    "flush_order", "no_avx2", "gzip_threads", "pgzip_chunk", "pgzip_thp", "pgzip_timing", "stream_thin", "stream_threads", "inflate_trace", "inflate_loose_find", "shares_threads", "kc_wg_per_cu", "kc_ablate", "kc_stagger", "kc_gate_extra"};
+    "flush_order", "no_avx2", "gzip_threads", "pgzip_chunk", "pgzip_thp", "pgzip_timing", "stream_thin", "stream_threads", "inflate_trace", "inflate_loose_find", "shares_threads", "kc_wg_per_cu", "kc_ablate", "kc_stagger", "kc_gate_extra", "inflate_dev_max_bytes"};
 static int64_t g_debug[sizeof(kDebugKeys) / sizeof(kDebugKeys[0])] = {};
 static int debug_index(const char* key) {
   for (size_t i = 0; i < sizeof(kDebugKeys) / sizeof(kDebugKeys[0]); ++i)

@@ -9,5 +9,6 @@ namespace mg {
 bool inflate_dev_enabled();
 // The file's text, stage by stage: consume(d_text, nbytes, final, &consumed) as in mg_stream.hip's pipeline — [consumed, nbytes) is
 // carried in front of the next stage's text on the device.
-int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const uint8_t*, uint64_t, bool, uint64_t*)>& consume);
+int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const uint8_t*, uint64_t, bool, uint64_t*)>& consume,
+                          bool* started);  // *started: a piece of text has been handed to `consume` (an error before that: nothing was taken)
 }  // namespace mg

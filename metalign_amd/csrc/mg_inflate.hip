@@ -441,8 +441,14 @@ struct CompUploader {
   ~CompUploader() { finish(); }
   // page-locking a slot costs milliseconds: the slots and the copy stream stay with the library (inflate_release_all)
   // (two sets: 0 = the inflater's compressed bytes, 1 = table uploads that run BESIDE a stream — mg_refdb_upload_begin)
-  struct Kept { std::vector<uint8_t*> slots; hipStream_t copy = nullptr; };
+  // A set serves ONE job at a time (`busy`): a second job that starts while the first is still copying — two table uploads in
+  // flight, a table upload beside a `.gz` stream on the same set — takes slots and a copy stream of its own and gives them back
+  // when it ends (their reader threads would otherwise fill the same slots and mix the two uploads).
+  struct Kept { std::vector<uint8_t*> slots; hipStream_t copy = nullptr; std::atomic<bool> busy{false}; };
   static Kept& kept(int set = 0) { static Kept k[2]; return k[set & 1]; }
+  Kept* holds = nullptr;             // the set this job has taken
+  std::vector<uint8_t*> own_slots;   // ... or its own slots and stream
+  hipStream_t own_copy = nullptr;
   void finish() {
     {
       std::lock_guard<std::mutex> lk(m);
@@ -455,6 +461,10 @@ struct CompUploader {
     if (copy) (void)hipStreamSynchronize(copy);
     copy = nullptr;
     slots.clear();
+    if (holds) { holds->busy.store(false); holds = nullptr; }
+    for (uint8_t* p : own_slots) (void)hipHostFree(p);
+    own_slots.clear();
+    if (own_copy) { (void)hipStreamDestroy(own_copy); own_copy = nullptr; }
     for (hipEvent_t e : ev_piece) (void)hipEventDestroy(e);
     ev_piece.clear();
   }
@@ -476,15 +486,27 @@ struct CompUploader {
     npieces = pieces.size();
     if (npieces == 0) return MG_OK;
     Kept& k = kept(set);
-    if (!k.copy) MG_HIP(hipStreamCreateWithFlags(&k.copy, hipStreamNonBlocking));
-    copy = k.copy;
     const size_t ns = npieces < kSlots ? (size_t)npieces : kSlots;
-    while (k.slots.size() < ns) {
-      uint8_t* p = nullptr;
-      MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), kPiece, hipHostMallocDefault));
-      k.slots.push_back(p);
+    if (!k.busy.exchange(true)) {
+      holds = &k;
+      if (!k.copy) MG_HIP(hipStreamCreateWithFlags(&k.copy, hipStreamNonBlocking));
+      copy = k.copy;
+      while (k.slots.size() < ns) {
+        uint8_t* p = nullptr;
+        MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), kPiece, hipHostMallocDefault));
+        k.slots.push_back(p);
+      }
+      slots.assign(k.slots.begin(), k.slots.begin() + (long)ns);
+    } else {  // the set is another job's for now
+      MG_HIP(hipStreamCreateWithFlags(&own_copy, hipStreamNonBlocking));
+      copy = own_copy;
+      while (own_slots.size() < ns) {
+        uint8_t* p = nullptr;
+        MG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), kPiece, hipHostMallocDefault));
+        own_slots.push_back(p);
+      }
+      slots = own_slots;
     }
-    slots.assign(k.slots.begin(), k.slots.begin() + (long)ns);
     for (uint64_t i = 0; i < npieces; ++i) {
       hipEvent_t e = nullptr;
       MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -554,6 +576,9 @@ struct CompUploader {
 // copying into the slots while earlier pieces are on the wire; `st` waits for the last piece; returns when everything is there.
 // (hipMemcpyAsync from pageable memory stages through the runtime's own small buffers: the reference-pipeline table's 440 MB took 25 ms.)
 int upload_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, hipStream_t st) {
+  // the destinations are blocks the caller has just taken from the pool — where a kernel of the main stream may still be reading
+  // or writing them (a block freed there is handed out again at once): the copy stream writes only after the main stream's work
+  MG_HIP(hipStreamSynchronize(ctx().stream));
   CompUploader up;
   MG_TRY(up.start_ranges(ranges, 4));
   MG_TRY(up.need(up.n, st));
@@ -565,27 +590,50 @@ int upload_ranges(const std::vector<std::pair<const void*, std::pair<void*, uint
 // until end), end makes `st` wait for the last piece and joins them.  A set of slots of its own: a `.gz` reads file may be going up
 // through the inflater's at the same time.
 struct UploadJob { CompUploader up; };
+// the jobs begun and not ended: mg_shutdown ends them before the library's slots go (inflate_release_all)
+static std::mutex g_jobs_m;
+static std::vector<UploadJob*> g_jobs;
+static void job_forget(UploadJob* job) {
+  std::lock_guard<std::mutex> lk(g_jobs_m);
+  g_jobs.erase(std::remove(g_jobs.begin(), g_jobs.end(), job), g_jobs.end());
+}
 int upload_ranges_begin(const std::vector<std::pair<const void*, std::pair<void*, uint64_t>>>& ranges, UploadJob** out) {
+  MG_HIP(hipStreamSynchronize(ctx().stream));  // (as upload_ranges: the destinations may be blocks the main stream has not let go of)
   std::unique_ptr<UploadJob> job(new UploadJob());
   MG_TRY(job->up.start_ranges(ranges, 4, 1));
+  {
+    std::lock_guard<std::mutex> lk(g_jobs_m);
+    g_jobs.push_back(job.get());
+  }
   *out = job.release();
   return MG_OK;
 }
 int upload_ranges_end(UploadJob* job, hipStream_t st) {
   if (!job) return MG_OK;
   std::unique_ptr<UploadJob> hold(job);
+  job_forget(job);
   MG_TRY(job->up.need(job->up.n, st));
   job->up.finish();
   return MG_OK;
 }
-void upload_ranges_abort(UploadJob* job) { delete job; }  // (~CompUploader joins the threads and waits for what is on the wire)
+void upload_ranges_abort(UploadJob* job) {  // (~CompUploader joins the threads and waits for what is on the wire)
+  if (job) job_forget(job);
+  delete job;
+}
 
 void inflate_release_all() {
+  {  // uploads still pending (a table handle that was never waited for): their threads stop here, before their slots are freed
+    std::lock_guard<std::mutex> lk(g_jobs_m);
+    for (UploadJob* j : g_jobs) j->up.finish();
+    g_jobs.clear();
+  }
   for (int set = 0; set < 2; ++set) {
     CompUploader::Kept& k = CompUploader::kept(set);
     if (k.copy) { (void)hipStreamSynchronize(k.copy); (void)hipStreamDestroy(k.copy); }
     for (uint8_t* p : k.slots) (void)hipHostFree(p);
-    k = CompUploader::Kept();
+    k.slots.clear();
+    k.copy = nullptr;
+    k.busy.store(false);
   }
 }
 
@@ -671,12 +719,15 @@ struct DevInflater {
     bgzf = bgzf_index(h, n, &blocks);
     if (!bgzf) blocks.clear();
     MG_TRY(comp.alloc(((n + 3) & ~3ull) + 64));
+    MG_TRY(win.alloc(kWindow));
+    // Both blocks come out of the pool, where a block freed on the main stream is handed out again at once ("stream order is
+    // enough" — for the main stream): what writes into them next are the copy stream and this one.  The main stream's work first.
+    MG_HIP(hipStreamSynchronize(c.stream));
     // (the bytes behind the file's end inside its last word are read by nobody: BitReader::load is bounded by words, the decoder by bits)
     MG_HIP(hipMemsetAsync(comp.as<uint8_t>() + (n & ~3ull), 0, 64, st));
+    MG_HIP(hipMemsetAsync(win.p, 0, kWindow, st));
     MG_HIP(hipStreamSynchronize(st));
     MG_TRY(up.start(h, n, comp.as<uint8_t>(), upload_threads));
-    MG_TRY(win.alloc(kWindow));
-    MG_HIP(hipMemsetAsync(win.p, 0, kWindow, st));
     return MG_OK;
   }
 
@@ -1201,7 +1252,9 @@ struct DevInflater {
 
 // the pipeline of mg_stream.hip's entry points for a .gz file: every stage's text, the unfinished last record carried in front of
 // the next stage's
-int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const uint8_t*, uint64_t, bool, uint64_t*)>& consume) {
+int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const uint8_t*, uint64_t, bool, uint64_t*)>& consume,
+                          bool* started) {
+  if (started) *started = false;
   if (fsize == 0) return fail(MG_ERR_ARG, "empty file: not in gzip format");
   void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
   if (map == MAP_FAILED) return fail(MG_ERR_ARG, "cannot map the file: %s", strerror(errno));
@@ -1232,6 +1285,7 @@ int inflate_file_pipeline(int fd, uint64_t fsize, const std::function<int(const 
       const uint8_t* d = text.as<uint8_t>() + headroom - carry;
       const uint64_t nbytes = carry + nt;
       uint64_t consumed = 0;
+      if (started) *started = true;
       rc = consume(d, nbytes, fin, &consumed);
       if (rc != MG_OK || fin) break;
       if (consumed > nbytes) consumed = nbytes;

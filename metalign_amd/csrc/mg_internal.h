@@ -388,6 +388,7 @@ struct mg_refdb {
   // mg_refdb_upload_begin: the arrays still on their way up (settled, and the table checked, by the first call that reads it)
   mutable mg::UploadJob* pending = nullptr;
   mutable bool unchecked = false;
+  mutable int failed = 0;  // the upload or the check failed: every later call on the handle answers this (mg_refpipe.hip: refdb_ready)
   std::unique_ptr<mg::KmerIndex> kidx;  // mg_refdb_index_kmers
   ~mg_refdb();
 };

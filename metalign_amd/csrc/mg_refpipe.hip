@@ -184,14 +184,19 @@ int alloc_marks(mg_refdb* db) {
 // (k_check_pairs) and the prefix structures (k_rp_check) are checked before anything reads them.  An error stays with the handle.
 int refdb_ready(const mg_refdb* db) {
   if (!db) return fail(MG_ERR_ARG, "null argument");
+  if (db->failed) return fail(db->failed, "this table's upload failed earlier (the handle holds no table: free it)");
   hipStream_t st = ctx().stream;
   if (db->pending) {
     UploadJob* job = db->pending;
     db->pending = nullptr;
-    MG_TRY(upload_ranges_end(job, st));
+    const int rc = upload_ranges_end(job, st);
+    if (rc != MG_OK) { db->failed = rc; return rc; }  // (its buffers are partly filled: nothing may read them, ever)
   }
   if (!db->unchecked) return MG_OK;
-  MG_TRY(check_pairs_dev(db->kmax));
+  {
+    const int rc = check_pairs_dev(db->kmax);
+    if (rc != MG_OK) { db->failed = rc; return rc; }
+  }
   unsigned long long* d_bad = (unsigned long long*)scratch("db_check", 4 * sizeof(unsigned long long));
   if (!d_bad) return MG_ERR_NOMEM;
   MG_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), st));
@@ -205,8 +210,11 @@ int refdb_ready(const mg_refdb* db) {
   uint64_t* pin = host_words();
   MG_HIP(hipMemcpyAsync(pin, d_bad, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   MG_HIP(hipStreamSynchronize(st));
-  if (pin[0]) return fail(MG_ERR_ARG, "reference-pipeline table is corrupt: %llu prefix numbers / genome ids out of range or out of order",
-                          (unsigned long long)pin[0]);
+  if (pin[0]) {
+    db->failed = MG_ERR_ARG;
+    return fail(MG_ERR_ARG, "reference-pipeline table is corrupt: %llu prefix numbers / genome ids out of range or out of order",
+                (unsigned long long)pin[0]);
+  }
   db->unchecked = false;
   return MG_OK;
 }

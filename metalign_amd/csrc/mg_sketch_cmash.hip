@@ -53,3 +53,6 @@ int launch_hash_positions_forward(int k, unsigned grid, hipStream_t st, const ui
 }
 
 }  // namespace mg
+
+// the k hash mode 1 is built for, as text ("1, 5, 10, ..."): a command line checks its k list against it before any genome is read
+extern "C" const char* mg_hash_mode1_ks(void) { return mg::kCmashKsText; }

@@ -813,6 +813,9 @@ static int default_threads() {
 
 // A `.gz` file (gzip or BGZF) whose compressed bytes go to the device and are inflated there (mg_inflate.hip), unless
 // mg_inflate_config turned that off: -> fd >= 0 and its size; -1: not such a file (the host readers take it)
+// (... or too large a file: the device inflater holds the WHOLE compressed file in device memory beside the pieces of text in
+// flight; a file above half of what is free — or above the knob inflate_dev_max_bytes — goes through the host inflater, whose
+// memory is bounded by its pieces.)
 static int open_for_device_inflate(const char* path, uint64_t offset, uint64_t length, uint64_t* fsize) {
   if (!inflate_dev_enabled() || offset || length) return -1;
   const int fd = open(path, O_RDONLY);
@@ -820,6 +823,10 @@ static int open_for_device_inflate(const char* path, uint64_t offset, uint64_t l
   struct stat sb;
   if (fstat(fd, &sb) != 0 || !looks_gzip(fd)) { close(fd); return -1; }
   *fsize = (uint64_t)sb.st_size;
+  size_t free_b = 0, total_b = 0;
+  uint64_t cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? (uint64_t)free_b / 2 : 0;
+  if (dbg("inflate_dev_max_bytes") > 0 && (uint64_t)dbg("inflate_dev_max_bytes") < cap) cap = (uint64_t)dbg("inflate_dev_max_bytes");
+  if (*fsize > cap) { close(fd); return -1; }
   return fd;
 }
 
@@ -848,9 +855,11 @@ int mg_sketch_stream_add_file(mg_sketch_stream* ss, const char* path, int format
         mg_reads_free(rd);
         return rc;
       };
-      const int rc = inflate_file_pipeline(gfd, fsize, consume_gz);
+      bool started = false;
+      const int rc = inflate_file_pipeline(gfd, fsize, consume_gz, &started);
       close(gfd);
-      return rc;
+      if (!(rc == MG_ERR_NOMEM && !started)) return rc;
+      // (no room on the device for the compressed file after all, and nothing consumed yet: the host inflater takes it)
     }
   }
   std::unique_ptr<Source> src;
@@ -895,7 +904,11 @@ int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64
   bool thinned = false;
   const bool auto_threads = nthreads <= 0;
   uint64_t gsize = 0;
-  const int gfd = open_for_device_inflate(path, offset, length, &gsize);
+  int gfd = open_for_device_inflate(path, offset, length, &gsize);
+  if (gfd >= 0) {  // (room for the compressed file on the device? probed here, so that the host inflater can still take the file)
+    DevBuf probe;
+    if (probe.alloc(((gsize + 3) & ~3ull) + 64) != MG_OK) { close(gfd); gfd = -1; }
+  }
   if (gfd < 0) MG_TRY(open_source(path, offset, length, &chunk_bytes, &src, &gz, paf ? -1 : (int)ThinSource::kSam, &thinned));
   if (nthreads <= 0) nthreads = default_threads();
   if (thinned && auto_threads) nthreads = thin_threads(nthreads);
@@ -911,7 +924,7 @@ int mg_sam_stream_file(const char* path, int paf, const mg_acc_index* ix, uint64
     return MG_OK;
   };
   if (gfd >= 0) {
-    const int rc = inflate_file_pipeline(gfd, gsize, consume);
+    const int rc = inflate_file_pipeline(gfd, gsize, consume, nullptr);
     close(gfd);
     MG_TRY(rc);
   } else {

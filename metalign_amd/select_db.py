@@ -326,8 +326,14 @@ def run_sketch_steps_dist(args, ctx):
         # others brought empty shards)
         whole = None
         if rank == 0:
-            with open(args.reads, 'rb') as fh:
-                whole = hip.inflate(fh.read())
+            try:
+                with open(args.reads, 'rb') as fh:
+                    whole = hip.inflate(fh.read())
+            except _hip.HipError as e:
+                if e.code != _hip.ERR_NOMEM:
+                    raise
+                # (the device has no room for the compressed file and its text at once: the host inflater, one piece at a time)
+                whole = _hip.gunzip_file(args.reads)
         text = scatter_text(dist, rank, world, dev, whole, args.input_type)
         del whole
     else:

@@ -163,6 +163,18 @@ def test_streamed_gz_files_give_what_the_plain_files_give(cfg, tmp_path):
             tgs._same(got, want)
             st = hip.inflate_stats()
             assert (st["jobs"] > 0) == (on == 1) and (stage != 100_000 or name.startswith("bgzf") or st["stages"] > 5), (name, stage, on, st)
+        # a file larger than the device inflater may hold (the knob stands in for "half of the free device memory"): the host
+        # inflater takes it, same reads
+        from metalign_amd import _hip as _h
+        hip.inflate_config(chunk_bytes=16 << 10, stage_bytes=128 << 20, on=1)
+        _h.debug_set("inflate_dev_max_bytes", 1000)
+        try:
+            hip.inflate_stats(reset=True)
+            got, counts = tgs._streamed(hip, ks, hmaxs, filts, rb.size, lambda st: st.add_file(str(p), "fastq"))
+            assert counts == (len(ro) - 1, rb.size) and hip.inflate_stats()["jobs"] == 0, name
+            tgs._same(got, want)
+        finally:
+            _h.debug_set("inflate_dev_max_bytes", 0)
 
 
 def test_random_streams_and_damaged_ones_against_zlib(hip):

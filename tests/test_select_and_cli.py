@@ -534,3 +534,18 @@ def test_text_record_cuts_for_the_scattered_gz_reads():
         cuts = select_db.text_record_cuts(fa, "fasta", world)
         assert all(c == 0 or c == len(fa) or (fa[c:c + 1] == b">" and fa[c - 1:c] == b"\n") for c in cuts), (world, cuts)
     assert select_db.text_record_cuts(b"", "fastq", 4) == [0, 0, 0, 0, 0]
+
+
+def test_build_db_refuses_an_unsupported_k_of_the_cmash_mode_before_reading_a_genome(tmp_path, capsys):
+    """Hash mode 1 and the forward sketch hash are built for a list of k (mg_hash_mode1_ks): a k outside it is a command-line
+    error naming the list — not an MG_ERR_ARG at the first kernel launch, after the genomes have been read."""
+    from metalign_amd import _hip, build_db
+    ks = _hip.hash_mode1_ks()
+    assert {30, 40, 50, 60, 21, 31, 51} <= set(ks) and ks == sorted(ks)
+    listing = tmp_path / "genomes.txt"
+    listing.write_text("")
+    for argv in (["--hash_mode", "cmash", "-k", "20,28,36"], ["--reference_pipeline", "--sketch_hash", "forward", "-k", "21,31,52"]):
+        with pytest.raises(SystemExit):
+            build_db.main([str(listing), str(tmp_path / "out")] + argv)
+        err = capsys.readouterr().err
+        assert "built for k in {1, 5, 10" in err and ("28, 36" in err or "52" in err)
