@@ -700,15 +700,21 @@ def main():
                 **valu_roofline(sq, kernels_ms.get(k1_name, {}).get("ms_per_pass")),
                 "ms_per_pass_alone": kernels_ms.get(k1_name, {}).get("ms_per_pass"),
                 "valu_insts_per_pass": valu_insts,
-                "note": ("stage A by k-mer identity: one lane per read slides a 15-mer minimizer over its windows (no hash of a k-mer), one "
-                         "gate bit per run of windows, the runs that pass matched against their buckets; bound by integer VALU work and by "
-                         "random bit / entry look-ups, not by streamed bytes; " if by_kmer else "") +
-                        "integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
-                        "cycles per VALU instruction of this kernel's opcode mix / the SIMD cycles of the launch (GRBM_GUI_ACTIVE "
-                        "/ 8 x 1024), all from the committed PMC pass of this workload, is the figure that describes it; achieved "
-                        "/ frac = 158 B/read x reads / kernel_ms_alone (the kernel's own duration, HIP events, nothing else on the "
-                        "device) against 8 TB/s; in the timed region a launch starts every period_ms and overlaps its predecessor "
-                        "by overlap_ms (avg_launch_ms_pipelined is the stretched duration there)"}
+                "note": (("stage A by k-mer identity (k_count_kmers): one lane per read slides a 15-mer minimizer over its windows — no k-mer is "
+                          "hashed — and leaves one event per run of windows; per run the 19 bases around the minimizer are hashed and ONE bit "
+                          "of a 2^30-bit gate is probed (6.9 runs per 150 bp read: 6.9 x 10^7 random 64-byte sectors per 10M reads), the 4 % "
+                          "that pass read their bucket's 128-byte line. achieved / frac = 158 B/read x reads / kernel_ms_alone against 8 TB/s; "
+                          "traffic (FETCH_SIZE + WRITE_SIZE of the committed PMC passes) is 4.5 x that: the gate's sectors. The walk alone "
+                          "is 1.3 of the kernel's 2.1-2.2 ms (SQ_INSTS_VALU 33 per wave-step, three wavefronts per SIMD at 168 VGPRs); "
+                          "valu_frac / valu_model are null: no per-opcode pricing of this kernel was made (profiles/r06/kcount_*.txt hold "
+                          "its SQ counters and ablations). ") if by_kmer else
+                         ("integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
+                          "cycles per VALU instruction of this kernel's opcode mix / the SIMD cycles of the launch (GRBM_GUI_ACTIVE "
+                          "/ 8 x 1024), all from the committed PMC pass of this workload, is the figure that describes it; achieved "
+                          "/ frac = 158 B/read x reads / kernel_ms_alone (the kernel's own duration, HIP events, nothing else on the "
+                          "device) against 8 TB/s; ")) +
+                        "in the timed region a launch starts every period_ms and overlaps its predecessor by overlap_ms "
+                        "(avg_launch_ms_pipelined is the stretched duration there)"}
         kern = []
         if "containment" in kernels_ms:
             t_b = kernels_ms["containment"]["ms_per_pass"] + kernels_ms.get("contain_index", {}).get("ms_per_pass", 0.0)

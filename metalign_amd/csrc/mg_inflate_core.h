@@ -98,8 +98,10 @@ struct Event {                   // a member ended inside a job (not F_ONE_MEMBE
   uint32_t job, crc, isize, pad;
 };
 
-// (16-bit table entries — code length | symbol << 4, base and extra bits recomputed per look-up — were measured: 7 KB of LDS and 23
-// wavefronts per CU instead of 10.5 KB and 15, and 20 % SLOWER: the kernel is bound by instructions issued, not by latency hidden)
+// (The tables hold 16-bit entries — lit16 / dist16 below — since the end of round 5.  A first 16-bit layout, code length | symbol << 4 with
+// base and extra bits recomputed per look-up, was 20 % slower than 32-bit entries: the kernel is bound by instructions issued.  The
+// layout kept decodes an entry with the 32-bit layout's instruction count; tests/host_inflate_check.cpp holds every symbol and length
+// of the two layouts against each other.)
 struct Shared {
   uint16_t lit[1 << LB];         // 16-bit entries (lit16 / dist16 below): 2.5 KB of tables instead of 5 — twenty-four jobs per CU
   uint16_t dist[1 << DB];

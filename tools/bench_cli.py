@@ -33,9 +33,15 @@ def _digits(idx, width):
     return out
 
 
-def write_fastq(path, rb, n, L=150, block=1_000_000):
-    """@r<9 digits>\\n<seq>\\n+\\n<qual>\\n per read."""
+QUAL_BINS = np.frombuffer(b"F:,#", dtype=np.uint8)  # a binning sequencer's four quality values (Q37 / 25 / 11 / 2) ...
+QUAL_CUM = np.array([0.86, 0.94, 0.985, 1.0])        # ... and how often each turns up
+
+
+def write_fastq(path, rb, n, L=150, block=1_000_000, qualities="binned"):
+    """@r<9 digits>\\n<seq>\\n+\\n<qual>\\n per read.  qualities: "binned" — every base one of four values drawn at random (what a
+    `.fq.gz` of a binning sequencer compresses like: 1.75 x the size of the constant file's); "constant" — all 'I' (rounds 1-5)."""
     seqs = rb.reshape(n, L)
+    rng = np.random.default_rng(20260)
     w = 2 + 9 + 1 + L + 3 + L + 1
     with open(path, "wb") as fh:
         for a in range(0, n, block):
@@ -46,7 +52,10 @@ def write_fastq(path, rb, n, L=150, block=1_000_000):
             rec[:, 11] = 10
             rec[:, 12:12 + L] = seqs[a:b]
             rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-            rec[:, 15 + L:15 + 2 * L] = ord("I")
+            if qualities == "binned":
+                rec[:, 15 + L:15 + 2 * L] = QUAL_BINS[np.searchsorted(QUAL_CUM, rng.random((b - a, L), dtype=np.float32))]
+            else:
+                rec[:, 15 + L:15 + 2 * L] = ord("I")
             rec[:, 15 + 2 * L] = 10
             rec.tofile(fh)
     return n * w
@@ -186,7 +195,7 @@ def parallel_bgzf(text, level=6, threads=32, block=65280):
 
 
 def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, glen=50_000, sketch_n=1000,
-            definition="reference_pipeline", hash_mode=0):
+            definition="reference_pipeline", hash_mode=0, qualities="binned"):
     """workload: dict(gb, go, rb, src, + dbh, dbo | ref_arrays) — genomes, reads, source genome of every read, and the sketch
     table (per-k genome-major arrays, or the reference pipeline's arrays) — as bench.py builds them; None: generated here.
     definition / hash_mode: of the table written to disk (formats.py version 2 or 3); select_main follows the table."""
@@ -236,7 +245,7 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, 
         with open(sub, "w") as fh:
             fh.write(sub_text)
         fq = os.path.join(td, "reads.fq")
-        fq_bytes = write_fastq(fq, rb[: n * 150], n)
+        fq_bytes = write_fastq(fq, rb[: n * 150], n, qualities=qualities)
         sam = os.path.join(td, "aln.sam")
         sam_bytes, sam_lines = write_sam(sam, rb[: n * 150], np.asarray(src[:n], dtype=np.int64), n, G)
         t_gen = time.perf_counter() - t_gen
@@ -305,10 +314,30 @@ def measure(n=1_000_000, G=200, ks=(21,), reps=2, verbose=False, workload=None, 
                 if gbest is None or (t1 - t0) < gbest:
                     gbest = t1 - t0
             same = open(os.path.join(td, "tmpgz0", "subset_db_info.txt"), "rb").read() == open(os.path.join(td, "tmp0", "subset_db_info.txt"), "rb").read()
-            res["gz"] = {"fastq_gz_mb": os.path.getsize(fq + ".gz") >> 20, "select_main_s": gbest, "select_main_reads_per_s": n / gbest,
+            res["gz"] = {"fastq_gz_mb": os.path.getsize(fq + ".gz") >> 20, "qualities": qualities, "select_main_s": gbest, "select_main_reads_per_s": n / gbest,
                          "value": n / (gbest + mp), "unit": "reads/s", "selection_identical_to_plain_file": same, "compress_s": t_z,
                          "what": "select_main on reads.fq.gz (one gzip member, level 6: compressed bytes over PCIe, inflated on the device, "
                                  "mg_inflate.hip) + the plain run's map_main, files in the page cache, best of %d" % reps}
+            # ... and the alignments as samtools / bgzip leave them: BGZF (every 64 KB block its own deflate stream: no window to carry)
+            t_z = time.perf_counter()
+            sam_z = os.path.join(td, "aln_bgzf.sam")  # (the command line tells SAM input by the name's ending; the stream code by the content)
+            with open(sam_z, "wb") as fh:
+                fh.write(parallel_bgzf(np.fromfile(sam, dtype=np.uint8), threads=nthreads))
+            t_z = time.perf_counter() - t_z
+            mbest = None
+            for rep in range(reps):
+                a2 = argparse.Namespace(infiles=[sam_z], data=data, db="NONE", dbinfo=sub, input_type="AUTO", length_normalize=False, low_mem=False,
+                                        min_abundance=1e-4, rank_renormalize=False, output=os.path.join(td, "ab_gz.tsv"), pct_id=0.5,
+                                        no_quantify_unmapped=False, read_cutoff=1, sampleID="x", threads=4, verbose=False)
+                t0 = time.perf_counter()
+                map_and_profile.map_main(a2)
+                t1 = time.perf_counter()
+                mbest = t1 - t0 if mbest is None or t1 - t0 < mbest else mbest
+            same_profile = open(os.path.join(td, "ab_gz.tsv"), "rb").read() == open(os.path.join(td, "ab.tsv"), "rb").read()
+            res["gz"].update({"sam_bgzf_mb": os.path.getsize(sam_z) >> 20, "map_main_bgzf_s": mbest, "profile_identical_to_plain_file": same_profile,
+                              "sam_compress_s": t_z, "value_both_compressed": n / (gbest + mbest),
+                              "what_bgzf": "map_main on the BGZF-compressed SAM file (level 6, inflated on the device); value_both_compressed = reads / "
+                                           "(select_main on the .fq.gz + map_main on the .sam.gz)"})
         except BaseException as e:  # noqa: BLE001  (a secondary figure; sys.exit of the command line included)
             res["gz"] = {"error": repr(e)}
         if tm.get("stream_s"):

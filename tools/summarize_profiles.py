@@ -14,6 +14,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")  # (mg_kcount.hip keeps its kernels in one)
     m = re.search(r"mg::(k_\w+(?:<.*>)?)", name)
     if m:
         return m.group(1).replace("mg::", "").replace(" ", "")

@@ -15,11 +15,11 @@ d = sys.argv[1]
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
-    m = re.search(r"mg::(k_\w+)", r["Kernel_Name"])
+    m = re.search(r"mg::(k_\w+)", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
     name = m.group(1) if m else r["Kernel_Name"].split("(")[0][-40:]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
-a = [r for r in rows if r[2].startswith("k_sketch_reads")]
+a = [r for r in rows if r[2].startswith("k_count_kmers")] or [r for r in rows if r[2].startswith("k_sketch_reads")]  # (stage A: by k-mer identity, or the read sketch)
 tail = a[-20:]  # the timed region's launches (bench.py --steps 20)
 starts = [r[0] for r in tail]
 periods = [(y - x) / 1e6 for x, y in zip(starts, starts[1:])]
