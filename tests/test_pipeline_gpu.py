@@ -456,3 +456,41 @@ def test_select_main_takes_tables_of_five_k_and_of_descending_k(hip, oracle_lib,
             for out in (job.step(), job.run(3)):
                 for ki in range(len(ks)):
                     assert np.array_equal(out["hits_k"][ki], per_k[ki][0]) and np.array_equal(out["sizes_k"][ki], per_k[ki][1]), ks[ki]
+
+
+def test_this_package_s_side_of_the_verification_kit_gives_what_the_fixture_was_built_to_give(tmp_path):
+    """tools/verify_kit/make_fixture.py, then the two command lines tools/verify_against_cmash.sh runs for this package (build_db
+    --reference_pipeline --hash_mode cmash, select_db): the CSV's k = 60 column is high for the present genomes and the reverse-complemented
+    copy, low for the 97 % strain and the 0.5x genome, absent or zero for the rest; the k = 30 column sees the strain."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kit = tmp_path / "kit"
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "verify_kit", "make_fixture.py"), str(kit)], check=True, timeout=300)
+    r = subprocess.run([sys.executable, "-m", "metalign_amd.build_db", str(kit / "training_files.txt"), str(kit / "ours" / "sketch_table"), "-n", "1000",
+                        "-k", "30,40,50,60", "--reference_pipeline", "--hash_mode", "cmash"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "metalign_amd.select_db", str(kit / "reads.fq"), str(kit) + "/", "--sketch_table", str(kit / "ours" / "sketch_table"),
+                        "--temp_dir", str(kit / "ours" / "tmp"), "--keep_temp_files", "--dbinfo_out", str(kit / "ours" / "subset_db_info.txt"),
+                        "--db", str(kit / "ours" / "subset.fna")], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    expect = json.load(open(kit / "expected.json"))
+    rows = list(csv.reader(open(kit / "ours" / "tmp" / "cmash_query_results.csv")))
+    got = {int(os.path.basename(x[0]).split("_")[1]) - 100000: [float(v) for v in x[1:]] for x in rows[1:]}
+    assert len(rows[0]) == 5  # name + four k
+    for g in range(expect["genomes"]):
+        kind, row = expect["expected_k60"][str(g)], got.get(g)
+        if kind == "high":
+            assert row is not None and row[-1] > 0.5, (g, row)
+        elif kind == "zero":
+            assert row is None or row[-1] == 0.0, (g, row)
+        else:
+            assert row is None or row[-1] < 0.35, (g, row)
+    assert abs(got[2][-1] - got[3][-1]) < 0.05          # a genome and its reverse complement: the same canonical k-mers
+    assert got[1][0] > got[1][-1] and got[1][0] > 0.2    # the strain: most 30-mers survive 3 % substitutions, few 60-mers do
+    sel = open(kit / "ours" / "subset_db_info.txt").read()
+    for g in expect["present"]:
+        assert "NZ_VERIFY%04d.1" % g in sel

@@ -549,3 +549,34 @@ def test_build_db_refuses_an_unsupported_k_of_the_cmash_mode_before_reading_a_ge
             build_db.main([str(listing), str(tmp_path / "out")] + argv)
         err = capsys.readouterr().err
         assert "built for k in {1, 5, 10" in err and ("28, 36" in err or "52" in err)
+
+
+def test_the_verification_kit_runs_dry_and_its_comparison_tells_differences_apart(tmp_path, capsys):
+    """tools/verify_against_cmash.sh --dry_run (no KMC, no CMash, no GPU): the fixture is written and checked, every command of
+    both sides is printed; tools/verify_kit/compare_csv.py: identical tables (row order aside) pass, a differing last column and a
+    row present on one side only are reported with what they would mean."""
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "verify_against_cmash.sh"), "--dry_run", str(tmp_path / "kit")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for needle in ("kmc -v -k60 -fq -ci2 -cs3", "kmc_tools simple", "intersect", "StreamingQueryDNADatabase.py", "30-60-10 -c 0 -r 1000000 -v -f",
+                   "--sensitive", "MakeStreamingDNADatabase.py", "-n 1000 -k 60", "metalign_amd.build_db", "--reference_pipeline --hash_mode cmash",
+                   "metalign_amd.select_db", "dry run fine: fixture of 20 genomes"):
+        assert needle in r.stdout, needle
+    expect = json.load(open(tmp_path / "kit" / "expected.json"))
+    assert expect["present"] == [0, 2, 5, 6, 7] and expect["expected_k60"]["3"] == "high" and expect["expected_k60"]["9"] == "low"
+    spec = importlib.util.spec_from_file_location("compare_csv", os.path.join(root, "tools", "verify_kit", "compare_csv.py"))
+    cmp_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmp_mod)
+    a, b, c = tmp_path / "a.csv", tmp_path / "b.csv", tmp_path / "c.csv"
+    a.write_text(",k=30,k=60\n/x/g1.fna.gz,0.9,0.8\n/x/g2.fna.gz,0.5,0.1\n")
+    b.write_text(",k=30,k=60\ng2.fna.gz,0.5,0.1\ng1.fna.gz,0.9,0.8\n")
+    c.write_text(",k=30,k=60\ng1.fna.gz,0.9,0.7\ng3.fna.gz,0.2,0.0\n")
+    assert cmp_mod.main([str(a), str(b)]) == 0
+    assert "identical within" in capsys.readouterr().out
+    assert cmp_mod.main([str(a), str(c)]) == 1
+    out = capsys.readouterr().out
+    assert "only in REFERENCE: g2.fna.gz" in out and "only in OURS: g3.fna.gz" in out and "column k=60: 1 organisms differ" in out
+    assert "the LAST column (k_max) differs" in out
