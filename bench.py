@@ -120,8 +120,14 @@ def resolve_config(args, world):
     pre["custom"] = bool(args.reads or args.genomes or args.genome_len or args.ks)
     pre["config"] = cfg
     pre["definition"], pre["hash_mode"] = args.definition, args.hash_mode
-    pre["match"] = args.match if args.definition == "reference_pipeline" else None
+    pre["match"] = _match_for(args, pre["ks"]) if args.definition == "reference_pipeline" else None
     return pre
+
+
+def _match_for(args, ks):
+    """--match kmer (the default) means what the package does by default: identity from k_max = 27 on, the read sketch below."""
+    from metalign_amd.distributed import kmer_match_by_default
+    return "kmer" if (args.match == "kmer" and kmer_match_by_default(max(ks))) else "hash"
 
 
 def build_tables(cfg, sketch_n, hip, gb, go, definition, hash_mode, world=1):
@@ -398,7 +404,7 @@ def committed_run(name, cfg):
 
 def secondary_config1(hip, args):
     """configs[1] (1M reads, 1k genomes, k = 21) in the same process: reads/s of the pipelined passes."""
-    cfg = dict(PRESETS[1], config=1, match=args.match if args.definition == "reference_pipeline" else None)
+    cfg = dict(PRESETS[1], config=1, match=_match_for(args, PRESETS[1]["ks"]) if args.definition == "reference_pipeline" else None)
     w = build_workload(cfg, args.sketch_n, 0, hip, args.definition, args.hash_mode)
     job = make_job(hip, None, 0, 1, cfg, w)
     job.run(60)

@@ -889,7 +889,7 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.shared.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
            kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), 32u - ix.gbits, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
   {
-    ProfScope ps("count_kmers");
+    ProfScope ps("count_kmers", st);
     MG_TRY(dispatch_kc(ix.k, a, grid, lds, st));
     MG_HIP(hipGetLastError());
   }

@@ -91,6 +91,17 @@ class _CudaView:
                                          "version": 2, "strides": None}
 
 
+# Stage A by k-mer identity against the read sketch, one k alone (2M reads x 2k genomes, one MI355X, tools/kcount_probe.py): k = 17: 2.39 against
+# 1.08 ms, 21: 1.62 / 1.09, 25: 1.23 / 1.16, 31: 0.79 / 1.13, 41: 0.60 / 1.36, 51: 0.45 / 1.4 — a window of k has k - 14 - 2 e candidates, and a
+# read of 150 bases closes 300 / (k - 13 - 2 e) runs: below k = 27 the runs cost more than the hashes they save.
+KMER_MATCH_MIN_K, KMER_MATCH_MAX_K = 15, 64   # what mg_kcount.hip is built for
+KMER_MATCH_DEFAULT_FROM_K = 27                # ... and from where it is what a job does when nobody says
+
+
+def kmer_match_by_default(kmax):
+    return KMER_MATCH_DEFAULT_FROM_K <= int(kmax) <= KMER_MATCH_MAX_K
+
+
 class _KmerSketch:
     """What stage A BY K-MER IDENTITY leaves for stage B (the reference pipeline's default since round 6): one sample's
     occurrence counters of the table's k_max-mers (_hip.KmerCounts) instead of a sketch of hashes.  Quacks like a _hip.Sketch
@@ -695,7 +706,7 @@ class ShardJob:
         `kmc_tools intersect` do (scripts/select_db.py:50-59; mg_kcount.hip: no hash on the read side; 15 <= k_max <= 64; every
         rank of a multi-GPU job holds the whole table and counts ITS reads, the ranks' counters — two bits per pair at the
         reference's -cs3 — are all-gathered and summed: _sum_kmer_counts); "hash": by its MurmurHash3 value (rounds 4-5; any k;
-        the table sharded by hash range); None: "kmer" where it applies."""
+        the table sharded by hash range); None: "kmer" for k_max from 27 to 64 when the table holds its k-mers, "hash" otherwise."""
         self.dist, self.rank, self.world = dist, rank, world
         # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
         self.exchange = dist is not None and (world > 1 or always_exchange)
@@ -711,10 +722,11 @@ class ShardJob:
         self.sks_k = [self.ks[-1]] if self.refpipe else self.ks  # the k the READS are sketched at
         if match not in (None, "kmer", "hash"):
             raise ValueError("match is 'kmer' or 'hash', not %r" % (match,))
-        can_kmer = self.refpipe and 15 <= self.ks[-1] <= 64 and engine is None
+        can_kmer = self.refpipe and KMER_MATCH_MIN_K <= self.ks[-1] <= KMER_MATCH_MAX_K and engine is None
         if match == "kmer" and not can_kmer:
             raise ValueError("match='kmer' needs the reference pipeline, the library's engine and 15 <= k_max <= 64")
-        self.match = "kmer" if (match in (None, "kmer") and can_kmer) else ("hash" if self.refpipe else None)
+        by_default = can_kmer and kmer_match_by_default(self.ks[-1])  # (a small k_max: the read sketch is the faster of the two)
+        self.match = "kmer" if (can_kmer and (match == "kmer" or (match is None and by_default))) else ("hash" if self.refpipe else None)
         self._match_asked = match  # (None: a table that does not hold its k-mers falls back to "hash" at load())
         self.ci, self.pct_id, self.s = ci, pct_id, s
         if engine is not None:

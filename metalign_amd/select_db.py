@@ -591,13 +591,15 @@ def kmer_match_applies(args, table, arrays):
     """Stage A BY K-MER IDENTITY (mg_kcount.hip; the default): the reads' k_max-mers are counted among the table's as `kmc` +
     `kmc_tools intersect` do it (:50-59) — as k-mers, nothing on the read side hashed.  Needs the table's k-mers (format 3 stores
     them) and 15 <= k_max <= 64; `--kmer_match hash` keeps the read sketch of rounds 4-5."""
+    from .distributed import kmer_match_by_default
     want = str(getattr(args, 'kmer_match', 'identity'))
     if want == 'hash':
         return False
     ok = arrays.get('kmer_hi') is not None and 15 <= table.ks[-1] <= 64
     if not ok and want == 'identity_only':
         sys.exit('Error: --kmer_match identity_only needs a reference-pipeline table that stores its k-mers, with the largest k in [15, 64].')
-    return ok
+    # (identity: where it is the faster of the two — from k_max = 27 on; identity_only: wherever it can run)
+    return ok and (want == 'identity_only' or kmer_match_by_default(table.ks[-1]))
 
 
 def _run_count_steps(args, hip, table, arrays, t_start):
