@@ -20,7 +20,13 @@
  *            computes for those stages; the GPU must match it bit for bit.
  *            That includes the "reference pipeline" below (mgo_refpipe_*): the
  *            reference's own wiring of those tools (k_max-mers only on the read
- *            side, smaller-k columns from prefixes of the matched k_max-mers).
+ *            side, smaller-k columns from prefixes of the matched k_max-mers)
+ *            and mgo_refpipe_count_kmers (round 6): the read side of that wiring
+ *            by k-mer IDENTITY — canonical k_max-mers of the reads counted among
+ *            the table's, no hash — which is what kmc + kmc_tools intersect
+ *            compute and what the product's default stage A (mg_kcount.hip) is
+ *            held to.  tools/verify_against_cmash.sh is how to pin all of this
+ *            on a machine that has the two tools.
  *
  * All paths below are relative to /root/reference.
  */
