@@ -42,11 +42,12 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 hip = Hip.get(0, stream=stream.cuda_stream)
 oracle.build()
 t0 = time.perf_counter()
-cfg = dict(bench.PRESETS[3], config=3, custom=False, definition=definition, hash_mode=mode)
+match = sys.argv[5] if len(sys.argv) > 5 else None  # "kmer": stage A by k-mer identity (what bench.py --gpus N runs since round 6); None / "hash": by hash value
+cfg = dict(bench.PRESETS[3], config=3, custom=False, definition=definition, hash_mode=mode, match=match)
 w = bench.build_workload(cfg, 1000, 0, hip, definition, mode)
 G, nreads = cfg["genomes"], len(w["ro"]) - 1
 assert G == 200_000 and nreads == 12_500_000 and w["ntax"] == 10_001
-report = {"definition": definition, "hash_mode": mode, "build_s": time.perf_counter() - t0}
+report = {"definition": definition, "hash_mode": mode, "match": match, "build_s": time.perf_counter() - t0}
 # ---- a sample against the oracle, every collective in the path; then once more with everything undersized ----
 min_sample = int(sys.argv[3]) if len(sys.argv) > 3 else 2_000_000
 args = argparse.Namespace(cpu_seconds=float(os.environ.get("MG_TEST_CPU_SECONDS", "6")), min_sample=min_sample)
@@ -70,6 +71,7 @@ assert np.array_equal(out["hits_k"], one["hits_k"]) and np.array_equal(out["size
 for key in ("count", "bases", "first_seen"):
     assert np.array_equal(out[key], one[key]), key
 assert out["sketch_sizes"] == one["sketch_sizes"] and (out["tot_rds"], out["n_ambig"]) == (one["tot_rds"], one["n_ambig"])
+assert job.match == (match or "hash") or definition != "reference_pipeline", job.match
 assert out["hits_k"].shape == (3, G) and out["tot_rds"] == nreads
 assert out["sketched_ks"] == ([51] if definition == "reference_pipeline" else [21, 31, 51])
 # every genome that was sampled deeply is recovered at every k; the absent ones are not

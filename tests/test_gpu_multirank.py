@@ -248,11 +248,15 @@ def test_hash_major_table_on_disk_sliced_loads(hip, oracle_lib, tmp_path):
 # (rounds 1-3's sketch per k at this size costs the ORACLE three minutes per sample — three 60M-hash sketches merged, 6 x 10^8
 # table hashes walked — so it runs on request only, MG_TEST_CONFIG3_SKETCH_PER_K=1; its 2M-read result of round 4, forced
 # overflow included, is recorded in profiles/r04/config3_checks.txt)
-_C3 = [("reference_pipeline", 0)] + ([("sketch_per_k", 0)] if __import__("os").environ.get("MG_TEST_CONFIG3_SKETCH_PER_K") == "1" else [])
+# (round 6: what `bench.py --gpus N` runs is stage A by k-mer identity — every rank the whole 200k-genome table and its k-mer index, the ranks'
+# counters all-gathered; the hash-range path of rounds 2-5 at this size on request, MG_TEST_CONFIG3_HASH=1: its results are in
+# profiles/r04/config3_checks.txt and it is unchanged)
+_C3 = [("reference_pipeline", 0, "kmer")] + ([("reference_pipeline", 0, "hash")] if __import__("os").environ.get("MG_TEST_CONFIG3_HASH") == "1" else []) + \
+    ([("sketch_per_k", 0, None)] if __import__("os").environ.get("MG_TEST_CONFIG3_SKETCH_PER_K") == "1" else [])
 
 
-@pytest.mark.parametrize("definition,mode", _C3)
-def test_config3_default_path_at_full_size_with_every_collective(definition, mode):
+@pytest.mark.parametrize("definition,mode,match", _C3)
+def test_config3_default_path_at_full_size_with_every_collective(definition, mode, match):
     """bench.py --config 3 (the N > 1 driver workload) AS THE JOB RUNS IT on a rank, at full size: 12.5M reads, 15.6M
     records, the 200k-genome table with the resident index the job chooses for itself, RCCL at world size 1 with every
     collective of the pass in the path — a >= 2M-read sample against the threaded C oracle (hits and sizes of all 200 000
@@ -268,12 +272,14 @@ def test_config3_default_path_at_full_size_with_every_collective(definition, mod
     # (the default definition — the reference pipeline — on >= 2M reads, with and without the forced overflow: 36 s; rounds
     # 1-3's sketch per k, whose oracle merges three 60M-hash sketches and walks 6 x 10^8 table hashes per sample, on 500k
     # reads without the repeat: the full-size figures of that path are in profiles/r04/config3_checks.txt, 2M reads, 456 s)
-    extra = [] if definition == "reference_pipeline" else ["500000", "plain"]
+    extra = ["2000000", "plain", "kmer"] if match == "kmer" else ([] if definition == "reference_pipeline" else ["500000", "plain"])
     r = subprocess.run([sys.executable, os.path.join(here, "dist_config3_full.py"), definition, str(mode)] + extra, capture_output=True,
                        text=True, timeout=1500, env=env)
     assert r.returncode == 0 and "config3-full ok" in r.stdout, (r.stdout[-3000:], r.stderr[-6000:])
     rep = json.loads(r.stdout.split("config3-full ok ", 1)[1].splitlines()[0])
-    if definition == "reference_pipeline":
+    if match == "kmer":
+        assert rep["check_hint_None"]["sample_reads"] >= 2_000_000 and rep["match"] == "kmer" and rep["resident_index_bytes"] == 0
+    elif definition == "reference_pipeline":
         assert rep["check_hint_None"]["sample_reads"] >= 2_000_000 and rep["check_hint_0.002"]["sample_reads"] >= 2_000_000
         assert rep["resident_index_bytes"] > 0  # (the job chose the index for this dense table, and kept it after measuring)
     print(json.dumps(rep))
