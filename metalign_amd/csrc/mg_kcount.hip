@@ -2,10 +2,11 @@
 //
 // Replaces `kmc -k<kmax> -ci2 -cs3` + `kmc_tools simple ... intersect` (scripts/select_db.py:50-59) without hashing a single read
 // position: the design, the definitions and every per-lane piece are in mg_kcount_core.h; here are
-//   * the index over the table's distinct canonical k_max-mers (mg_refdb_index_kmers): entries ascending by minimizer, a bucket
-//     directory over the leading bits of the minimizer, a gate bitmap over all 2^30 minimizer values, and per pair of the
-//     hash-major table the pair that counts for its k-mer (`head`: equal k-mers are adjacent in hash order, so stage B reads
-//     counts[head[i]] nearly sequentially);
+//   * the index over the table's distinct canonical k_max-mers (mg_refdb_index_kmers): an entry per k-mer and hash it is filed
+//     under (the 19 bases around a smallest-rank candidate, hashed: nearly always one), buckets of four entries = one 128-byte line
+//     by the hash's low bits with an overflow list, a gate bitmap over the hash's leading bits (and the bitmap of the bits two hashes
+//     share), and per pair of the hash-major table the pair that counts for its k-mer (`head`: equal k-mers are adjacent in hash
+//     order, so stage B reads counts[head[i]] nearly sequentially);
 //   * the kernel: one wavefront per tile of 64 reads, one lane per read.  The tile's bases go HBM -> LDS with 16-byte coalesced
 //     loads, packed to 2 bits per base on the way (a big-endian stream: 32 bits at any base offset are sixteen bases as k-mers
 //     compare); every lane slides the minimizer over its read (kc_walk) and leaves the runs it closes in a list of its own in
@@ -47,7 +48,7 @@ __global__ void k_kc_heads(const uint64_t* __restrict__ hi, const uint64_t* __re
   KC_FOR(j, n) flag[j] = (j == 0 || hi[j] != hi[j - 1] || lo[j] != lo[j - 1]) ? 1u : 0u;
 }
 // sorted position j opens distinct k-mer number before[j]: its words, the pair that counts for it (the sort is stable and
-// started from pair order: the first of a group is its lowest pair), its minimizer
+// started from pair order: the first of a group is its lowest pair), how many hashes it is filed under
 __global__ void k_kc_distinct(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, const uint32_t* __restrict__ order,
                               const uint32_t* __restrict__ flag, const uint64_t* __restrict__ before, uint64_t n, int k,
                               uint64_t* __restrict__ dhi, uint64_t* __restrict__ dlo, uint32_t* __restrict__ dhead,
@@ -622,7 +623,7 @@ int dispatch_kc(int k, const KcArgs& a, unsigned grid, size_t lds, hipStream_t s
 
 struct mg_kcounts {
   mg::DevBuf counts;  // u32[npairs + 1]
-  mg::DevBuf live;    // the sample's gate: the table's, minus the minimizers all of whose k-mers are saturated (mg_kcount_core.h)
+  mg::DevBuf live;    // the sample's gate: the table's, minus the hashes all of whose k-mers are saturated (mg_kcount_core.h)
   mg::DevBuf sat;     // a counter per entry number: what has been found under it (at the saturation value the entry is skipped)
   mg::DevBuf stats;   // u64[4]
   uint64_t n = 0, live_words = 0, sat_words = 0;
@@ -760,7 +761,7 @@ int mg_refdb_index_kmers(mg_refdb* db, const uint64_t* kmer_hi, const uint64_t* 
     MG_TRY(sort_pairs(ekey.as<uint64_t>(), skey.as<uint64_t>(), eid.as<uint32_t>(), perm.as<uint32_t>(), ne));
   }
   ix->nentries = ne;
-  // the entries in (bucket, minimizer) order, the buckets' bounds, then their places: two per bucket in prim, the rest in ovf
+  // the entries in (bucket, hash) order, the buckets' bounds, then their places: four per bucket in prim, the rest in ovf
   DevBuf offs, ent, extra, obefore;
   MG_TRY(offs.alloc((ix->nbuckets + 2) * 4));
   MG_TRY(ent.alloc((ne + 1) * sizeof(KcEntry)));
