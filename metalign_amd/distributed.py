@@ -278,6 +278,28 @@ class HipEngine:
         return self.hip.sketch_reads_multi_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, ks, hmaxs, s,
                                                      self.filters[: len(ks)])
 
+    # ---- stage A by k-mer identity on several ranks: what ShardJob._sum_kmer_counts asks of an engine ----
+    def kmer_saturation(self):
+        return self.hip.count_saturation()
+
+    def kmer_pack(self, kc):
+        """min(counter, 3) of every pair, two bits each -> an int32 tensor on the device (mg_kcounts_pack2_dev)."""
+        t = self.torch
+        n32 = max(kc.pack2_bytes() // 4, 1)
+        mine = t.empty(n32, dtype=t.int32, device="cuda")
+        kc.pack2_dev(mine.data_ptr())
+        return mine
+
+    def kmer_merge(self, kc, every):
+        """The counters := the sum over the ranks' packed arrays (rows of `every`)."""
+        kc.merge2_dev(every.data_ptr(), int(every.shape[0]), 4 * int(every.shape[1]))
+
+    def kmer_raw(self, kc):
+        """The 32-bit counters as an int32 tensor (for an all-reduce in place), the main stream behind whoever wrote them last."""
+        ptr, n = kc.device()
+        kc.wait()
+        return self.torch.as_tensor(_CudaView(ptr, max(n, 1), "<i4"), device="cuda")
+
     def export_sketch(self, sk):
         """(hashes int64 tensor, counts int32 tensor) on this rank's device, zero-copy."""
         t = self.torch
@@ -730,7 +752,8 @@ class ShardJob:
         self.sks_k = [self.ks[-1]] if self.refpipe else self.ks  # the k the READS are sketched at
         if match not in (None, "kmer", "hash"):
             raise ValueError("match is 'kmer' or 'hash', not %r" % (match,))
-        can_kmer = self.refpipe and KMER_MATCH_MIN_K <= self.ks[-1] <= KMER_MATCH_MAX_K and engine is None
+        # (an engine of the tests serves it when it says so: tests/test_distributed_gloo.py, the exchange on the CPU)
+        can_kmer = self.refpipe and KMER_MATCH_MIN_K <= self.ks[-1] <= KMER_MATCH_MAX_K and (engine is None or getattr(engine, "supports_kmer", False))
         if match == "kmer" and not can_kmer:
             raise ValueError("match='kmer' needs the reference pipeline, the library's engine and 15 <= k_max <= 64")
         by_default = can_kmer and kmer_match_by_default(self.ks[-1])  # (a small k_max: the read sketch is the faster of the two)
@@ -896,6 +919,8 @@ class ShardJob:
                 if full.get("kmer_hi") is None:
                     raise ValueError("match='kmer' needs the table's k-mers (format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64); "
                                      "this table has none: ShardJob(match='hash')")
+                if not hasattr(eng, "hip"):  # (a host engine of the tests takes the arrays themselves: the WHOLE table)
+                    return dict(full, ks=self.ks, ngenomes=self.G)
                 reftable = eng.hip.refdb_upload(self.ks, self.G, ph, full["pair_gen"], full["gsize"], hmax, small_all)
                 reftable.index_kmers(full["kmer_hi"], full["kmer_lo"])
             elif not reftable.has_kmer_index:
@@ -990,22 +1015,18 @@ class ShardJob:
         two bits, ONE all-gather of those arrays (2.5 MB per ten million pairs and rank) and their sum on every rank;
         otherwise the 32-bit counters themselves through an all-reduce.  Everything is queued on the main stream (torch's
         current one); -> the tensors that must outlive the queue."""
-        t, dist, W = self.torch, self.dist, self.world
-        cs = self.engine.hip.count_saturation()
+        t, dist, W, eng = self.torch, self.dist, self.world, self.engine
+        cs = eng.kmer_saturation()
         if 1 <= cs <= 3:
-            n32 = kc.pack2_bytes() // 4
-            mine = t.empty(max(n32, 1), dtype=t.int32, device="cuda")
-            kc.pack2_dev(mine.data_ptr())
-            every = t.empty((W, max(n32, 1)), dtype=t.int32, device="cuda")
+            mine = eng.kmer_pack(kc)
+            every = t.empty((W, int(mine.numel())), dtype=t.int32, device=mine.device)
             dist.all_gather(list(every.unbind(0)), mine)
-            self._sent("kmer_counts_all_gather", 4 * n32 * (W - 1))
-            kc.merge2_dev(every.data_ptr(), W, 4 * max(n32, 1))
+            self._sent("kmer_counts_all_gather", 4 * int(mine.numel()) * (W - 1))
+            eng.kmer_merge(kc, every)
             return mine, every
-        ptr, n = kc.device()
-        kc.wait()
-        tv = t.as_tensor(_CudaView(ptr, max(n, 1), "<i4"), device="cuda")
+        tv = eng.kmer_raw(kc)
         dist.all_reduce(tv, op=dist.ReduceOp.SUM)
-        self._sent("kmer_counts_all_gather", 4 * n if W > 1 else 0)
+        self._sent("kmer_counts_all_gather", 4 * int(tv.numel()) if W > 1 else 0)
         return (tv,)
 
     # ------------------------------------------------------------------

@@ -21,7 +21,40 @@ class OracleEngine:
         self.o = oracle
         self.torch = torch_mod
 
+    supports_kmer = True  # stage A by k-mer identity (ShardJob(match="kmer")): this rank's reads against the WHOLE table, counters summed
+    cs = 3                # the counters' saturation value (0: they do not saturate: the all-reduce instead of the two-bit all-gather)
+
+    class _KSk:
+        """What HipEngine's _KmerSketch is to a job: a sample's counters, no sketch."""
+        class _Counters:  # (the handle a job passes back to kmer_pack / kmer_merge / kmer_raw: _hip.KmerCounts in the library's engine)
+            def __init__(self, counts):
+                self.counts = counts
+
+        def __init__(self, counts):
+            self.counts, self.size = self._Counters(counts), None
+
+        def free(self):
+            pass
+
+    def kmer_saturation(self):
+        return self.cs
+
+    def kmer_pack(self, kc):
+        c = np.minimum(kc.counts, 3).astype(np.uint32)
+        c = np.concatenate([c, np.zeros((-len(c)) % 16, np.uint32)]).reshape(-1, 16)
+        return self.torch.from_numpy((c << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint32).view(np.int32).copy())
+
+    def kmer_merge(self, kc, every):
+        w = every.numpy().view(np.uint32)  # [ranks][words]
+        fields = (w[:, :, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3
+        kc.counts = fields.sum(axis=0, dtype=np.uint32).reshape(-1)[: len(kc.counts)]
+
+    def kmer_raw(self, kc):
+        kc.counts = np.ascontiguousarray(kc.counts, dtype=np.uint32)
+        return self.torch.from_numpy(kc.counts.view(np.int32))  # (shares its memory: the all-reduce lands in the counters)
+
     def load(self, rbases, roffsets, recs, has_lookahead, ref2tax, ntax, tables, reftable=None):
+        self.kmer = reftable is not None and bool(getattr(self, "match_kmer", False))
         self.rb, self.ro = rbases, roffsets
         self.recs, self.has_look = recs, has_lookahead
         self.ref2tax, self.ntax = ref2tax, ntax
@@ -46,6 +79,9 @@ class OracleEngine:
         sk.truncated, sk.bound = bool(truncated), int(bound)
 
     def sketch_local(self, ks, hmaxs, s):
+        if getattr(self, "kmer", False):
+            c, _ = self.o.refpipe_count_kmers(self.rb, self.ro, ks[-1], self.reftable["kmer_hi"], self.reftable["kmer_lo"], cs=self.cs)
+            return [self._KSk(c)]
         out = []
         for ki, (k, hmax) in enumerate(zip(ks, hmaxs)):
             h, c, t, _ = self.o.sketch_reads(self.rb, self.ro, k, hmax=hmax, s=s)
@@ -75,6 +111,8 @@ class OracleEngine:
         return self._Sk(uh, uc, trunc)
 
     def containment(self, sks, ci):
+        if isinstance(sks[0], self._KSk):  # the counters are the sample's by now (ShardJob._sum_kmer_counts): every column, on every rank
+            return self.o.refpipe_containment_counts(sks[0].counts.counts, ci, self.reftable)
         if self.reftable is not None:
             # the reference pipeline: mark from this rank's pairs, the job's OR exchange, count over this rank's count-list runs
             share, sk = self.reftable, sks[0]
@@ -142,6 +180,8 @@ class PipelinedOracleEngine(OracleEngine):
 
     def _word(self, P, overflow):
         W, word = self._xW, []
+        if getattr(self, "kmer", False):  # (no sketch to cut into slices)
+            return [0] * (len(self._xbounds_list) * (W + 4)) + [P["maps"][0], P["maps"][1], P["ngroups"]]
         for ki, sk in enumerate(P["sks"]):
             cuts = [0] + self.split_sketch(sk, self._xbounds_list[ki][1:W]) + [sk.size]
             last = sk.last_hash
@@ -179,7 +219,7 @@ class PipelinedOracleEngine(OracleEngine):
     def x_collect(self, P, ci, want_multimapped):
         count, bases, first, scal, mm = self.profile_commit(*P["commit"], want_multimapped)
         hits, sizes = P["hs"]
-        return hits, sizes, count, bases, first, scal, mm, [m.size for m in P["merged"]]
+        return hits, sizes, count, bases, first, scal, mm, [m.size for m in P["merged"]]  # (None for counters: ShardJob._fill_reduce)
 
     def x_reduce_buffer(self, P):
         P["buf"] = np.zeros(self._xnred, dtype=np.int64)
@@ -273,13 +313,13 @@ def _worker(rank, world, port, tmpdir):
         full = oracle.refpipe_build(h, khi, klo, o, ks)
         qh, qc, _, _ = oracle.sketch_reads(rb, ro, ks[-1], hmax=int(h.max()))
         whits, wsizes = oracle.refpipe_containment(qh, qc, 2, full)
-        job = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=OracleEngine(torch), definition="reference_pipeline")
+        job = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=OracleEngine(torch), definition="reference_pipeline", match="hash")
         job.load(my_reads[0], my_reads[1], my_recs, ref2tax, full, ntax=ntax)
         out = job.step()
         checks = dict(hits=np.array_equal(out["hits_k"], whits), sizes=np.array_equal(out["sizes_k"], wsizes),
                       qn=out["sketch_sizes"] == [len(qh)], count=np.array_equal(out["count"], want["count"]),
                       first=np.array_equal(out["first_seen"], want["first_seen"]), some=bool(whits.any()))
-        pjob = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=PipelinedOracleEngine(torch), definition="reference_pipeline")
+        pjob = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=PipelinedOracleEngine(torch), definition="reference_pipeline", match="hash")
         pjob.load(my_reads[0], my_reads[1], my_recs, ref2tax, full, ntax=ntax)
         pout = pjob.run(4)
         for key in ("hits_k", "sizes_k", "count", "bases", "first_seen"):
@@ -298,6 +338,28 @@ def _worker(rank, world, port, tmpdir):
         if not ok:
             print("rank", rank, "refpipe case", case, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
         res[case] = bool(ok)
+        # ... and with k-mers met BY IDENTITY: every rank the whole table and its own reads, the ranks' counters summed — two bits a
+        # pair through one all-gather (cs = 3) or the counters themselves through an all-reduce (cs = 0) — on every rank every column
+        if ks[-1] >= 15:
+            for cs in (3, 0):
+                checks = {}
+                for label, eng_cls, passes in (("step", OracleEngine, 0), ("run", PipelinedOracleEngine, 3)):
+                    eng = eng_cls(torch)
+                    eng.cs = cs
+                    kjob = mgd.ShardJob(None, dist, rank, world, k=ks, ci=2, pct_id=0.5, engine=eng, definition="reference_pipeline", match="kmer")
+                    kjob.load(my_reads[0], my_reads[1], my_recs, ref2tax, full, ntax=ntax)
+                    kout = kjob.run(passes) if passes else kjob.step()
+                    checks[label + "_match"] = kjob.match == "kmer" and kout["match"] == "kmer"
+                    checks[label + "_hits"] = np.array_equal(kout["hits_k"], whits) and np.array_equal(kout["sizes_k"], wsizes)
+                    checks[label + "_qn"] = kout["sketch_sizes"] == [int(whits[-1].sum())]
+                    checks[label + "_stage_c"] = np.array_equal(kout["count"], want["count"]) and np.array_equal(kout["first_seen"], want["first_seen"])
+                    ktr = kjob.traffic_per_pass()
+                    npairs = len(full["pair_hash"])
+                    checks[label + "_traffic"] = ktr["kmer_counts_all_gather"] == ((world - 1) * 4 * ((npairs + 15) // 16) if cs else 4 * npairs) and \
+                        ktr["sketch_all_to_all"] == 0 and ktr["prefix_marks_all_to_all"] == 0
+                if not all(checks.values()):
+                    print("rank", rank, "refpipe-by-identity case", case, "cs", cs, "FAILED:", [k for k, v in checks.items() if not v], flush=True)
+                res[(case, "kmer", cs)] = bool(all(checks.values()))
         oracle.set_hash_mode(0)
     with open(os.path.join(tmpdir, "rank%d.txt" % rank), "w") as fh:
         fh.write(repr(res))
@@ -315,7 +377,10 @@ def test_sharding_matches_single_process(tmp_path, world):
     s.close()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr({0: True, 1: True, 2: True, 3: True, 100: True, 101: True, 102: True})
+        want = {0: True, 1: True, 2: True, 3: True}
+        for case in (100, 101, 102):  # the reference pipeline by hash value, then by identity with both ways of summing the counters
+            want.update({case: True, (case, "kmer", 3): True, (case, "kmer", 0): True})
+        assert (tmp_path / ("rank%d.txt" % r)).read_text() == repr(want)
 
 
 def _sam_worker(rank, world, port, tmpdir):
