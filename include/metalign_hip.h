@@ -621,6 +621,10 @@ int mg_refpipe_mark_counts_ptr_dev(const uint32_t* d_counts, const mg_refdb* db,
                                    uint32_t* d_sizes_kmax);
 int mg_refpipe_containment_counts_dev(const mg_kcounts* kc, const mg_refdb* db, uint32_t ci, uint32_t* const* d_hits,
                                       uint32_t* const* d_sizes);
+/* A rank of a multi-GPU job that holds the WHOLE table (stage A by k-mer identity): from now on the count step of this handle streams
+ * only entries [n r / W, n (r + 1) / W) of every smaller k's count list — the columns of k < k_max it writes are this rank's PART of
+ * them (the ranks' parts add up: the job's all-reduce), the k_max column and every size stay whole.  (1 of 1: everything, the default.) */
+int mg_refdb_set_count_share(const mg_refdb* db, uint32_t rank, uint32_t world);
 
 /* ------------------------------------------------------------------------ *
  * Stage C — per-read taxon assignment + abundance histogram.

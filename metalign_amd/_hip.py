@@ -30,7 +30,7 @@ EXPORTS = [
     "mg_prof_enable", "mg_prof_only", "mg_prof_reset", "mg_prof_get",
     "mg_refdb_index_kmers", "mg_refdb_has_kmer_index", "mg_refdb_distinct_kmers", "mg_refdb_kmer_heads", "mg_kcounts_new", "mg_kcounts_reset", "mg_count_kmers_dev",
     "mg_kcounts_stats", "mg_kcounts_download", "mg_kcounts_device", "mg_kcounts_wait", "mg_kcounts_pack2_bytes", "mg_kcounts_pack2_dev", "mg_kcounts_merge2_dev", "mg_kcounts_free", "mg_refpipe_mark_counts_dev", "mg_refpipe_mark_counts_ptr_dev",
-    "mg_refpipe_containment_counts_dev",
+    "mg_refpipe_containment_counts_dev", "mg_refdb_set_count_share",
     "mg_set_count_saturation", "mg_count_saturation", "mg_set_hash_mode", "mg_hash_mode", "mg_hash_mode1_ks", "mg_sketch_reads_dev", "mg_sketch_reads_dev_async", "mg_sketch_reads_multi_dev_async", "mg_sketch_resolve", "mg_filter_build", "mg_filter_download", "mg_filter_from_bits", "mg_filter_log2_bits", "mg_filter_make_resident", "mg_filter_drop_resident", "mg_filter_use_resident", "mg_filter_resident_bytes", "mg_filter_free",
     "mg_sketch_reads_filtered_dev", "mg_sketch_reads_filtered_dev_async", "mg_sketch_from_pairs_dev", "mg_sketch_merge_dev", "mg_sketch_merge_dev_async", "mg_sketch_split", "mg_sketch_slice_words_dev", "mg_sketch_set_bound", "mg_sketch_size", "mg_sketch_truncated", "mg_sketch_last_hash",
     "mg_sketch_kmers_seen", "mg_sketch_device_ptrs", "mg_sketch_download", "mg_sketch_free", "mg_sketch_reads",
@@ -660,6 +660,11 @@ class RefTable:
                                                        _np(cid, ctypes.c_uint32), _np(cgen, ctypes.c_uint32), _np(gk, ctypes.c_uint32)))
             out["small"][k] = dict(pa=pa[:npairs], pb=pb[:npairs], cid=cid[:nc[ki]], cgen=cgen[:nc[ki]], gsize=gk[:g], nprefix=npre[ki])
         return out
+
+    def set_count_share(self, rank, world):
+        """A rank of a multi-GPU job that holds the whole table: the count step streams only this rank's share of every smaller k's
+        count list from now on (the columns of k < k_max are then this rank's part of them; the ranks' parts add up)."""
+        self.hip._chk(self.hip.lib.mg_refdb_set_count_share(self.handle, ctypes.c_uint32(int(rank)), ctypes.c_uint32(int(world))))
 
     def index_kmers(self, kmer_hi=None, kmer_lo=None):
         """The index stage A BY K-MER IDENTITY reads (mg_refdb_index_kmers): over the table's distinct canonical k_max-mers,

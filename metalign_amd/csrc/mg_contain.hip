@@ -789,9 +789,11 @@ static int refpipe_count_launch(const mg_refdb* rp, const uint32_t* const* d_mar
   uint64_t tiles = 0;
   for (int s = 0; s < m; ++s) {
     CountK& K = a.k[s];
-    K.cid = rp->small[s].cid.as<uint32_t>();
-    K.cgen = rp->small[s].cgen.as<uint32_t>();
-    K.n = rp->small[s].ncount;
+    const uint64_t nc = rp->small[s].ncount, W = rp->share_world ? rp->share_world : 1, r = rp->share_rank;
+    const uint64_t lo = nc / W * r + (nc % W) * r / W, hi = r + 1 == W ? nc : nc / W * (r + 1) + (nc % W) * (r + 1) / W;
+    K.cid = rp->small[s].cid.as<uint32_t>() + lo;
+    K.cgen = rp->small[s].cgen.as<uint32_t>() + lo;
+    K.n = hi - lo;
     K.tile0 = tiles;
     tiles += (K.n + kCTile - 1) / kCTile;
     K.ngenomes = G;
@@ -824,6 +826,13 @@ int mg_refpipe_mark_dev(const mg_sketch* q, const mg_refdb* db, uint32_t ci, uin
   MG_TRY(refdb_ready(db));
   const mg_db* kdb = &db->kmax;
   return containment_launch(1, &q, &kdb, ci, &d_hits_kmax, &d_sizes_kmax, db);
+}
+
+int mg_refdb_set_count_share(const mg_refdb* db, uint32_t rank, uint32_t world) {
+  if (!db || world == 0 || rank >= world) return fail(MG_ERR_ARG, "rank %u of %u", rank, world);
+  db->share_rank = rank;
+  db->share_world = world;
+  return MG_OK;
 }
 
 int mg_refpipe_count_dev(const mg_refdb* db, const uint32_t* const* d_marks, uint32_t* const* d_hits, uint32_t* const* d_sizes) {

@@ -389,6 +389,9 @@ struct mg_refdb {
   // mg_refdb_upload_begin: the arrays still on their way up (settled, and the table checked, by the first call that reads it)
   mutable mg::UploadJob* pending = nullptr;
   mutable bool unchecked = false;
+  // (a rank of a multi-GPU job that holds the WHOLE table — stage A by k-mer identity — streams only its share of every count list:
+  // entries [n r / W, n (r + 1) / W); the ranks' partial columns are summed by the job's all-reduce.  mg_refdb_set_count_share)
+  mutable uint32_t share_rank = 0, share_world = 1;
   mutable int failed = 0;  // the upload or the check failed: every later call on the handle answers this (mg_refpipe.hip: refdb_ready)
   std::unique_ptr<mg::KmerIndex> kidx;  // mg_refdb_index_kmers
   ~mg_refdb();

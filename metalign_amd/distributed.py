@@ -170,6 +170,11 @@ class HipEngine:
         # stage A by k-mer identity (ShardJob(match="kmer")): the counters of the passes in flight, handed out and taken back
         self.kmer = reftable is not None and bool(getattr(self, "match_kmer", False))
         self._kc_free = []
+        # (several ranks, each with the whole table: a rank streams its share of the count lists, the columns of k < k_max are summed)
+        share = getattr(self, "count_share", None)
+        self.kmer_count_sharded = bool(self.kmer and share and share[1] > 1)
+        if reftable is not None and hasattr(reftable, "set_count_share"):
+            reftable.set_count_share(*(share if self.kmer_count_sharded else (0, 1)))  # (the handle remembers: a job says it every time)
         if self.kmer and not reftable.has_kmer_index:
             raise _hip.HipError("the reference-pipeline table has no k-mer index (RefTable.index_kmers)")
 
@@ -855,6 +860,7 @@ class ShardJob:
         if self.refpipe:
             self.engine.mark_exchange = self._or_marks if (self.exchange and self.match != "kmer") else None
             self.engine.match_kmer = self.match == "kmer"
+            self.engine.count_share = (self.rank, self.world) if (self.exchange and self.match == "kmer") else None
             self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, [], reftable=reftable)
         else:
             self.engine.load(rbases, roffsets, recs, has_look, ref2tax, self.T, tables)
@@ -1247,7 +1253,12 @@ class ShardJob:
             # go into the sum (the matched pairs of the largest k stand in for a sketch size)
             qn = [int(np.asarray(hits)[-1].sum()) if q is None else q for q in qn]
             if self.rank != 0:
-                hits, sizes, qn = np.zeros_like(np.asarray(hits)), np.zeros_like(np.asarray(sizes)), [0] * len(qn)
+                part = np.asarray(hits).copy()
+                if getattr(self.engine, "kmer_count_sharded", False):
+                    part[-1] = 0  # (the columns of k < k_max are this rank's share of the count lists: they add up; the k_max column is whole)
+                else:
+                    part[:] = 0
+                hits, sizes, qn = part, np.zeros_like(np.asarray(sizes)), [0] * len(qn)
         buf[:K * G] = np.asarray(hits).reshape(-1)  # per-slice partial sums: the all-reduce adds them up
         buf[o_sizes:o_sizes + K * G] = np.asarray(sizes).reshape(-1)
         buf[o_count:o_count + T] = count.view(np.int64)
