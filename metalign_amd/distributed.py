@@ -174,6 +174,15 @@ class HipEngine:
             reftable.set_count_share(*(share if self.kmer_count_sharded else (0, 1)))  # (the handle remembers: a job says it every time)
         if self.kmer and not reftable.has_kmer_index:
             raise _hip.HipError("the reference-pipeline table has no k-mer index (RefTable.index_kmers)")
+        if self.kmer:
+            self.reserve_counters(3)
+
+    def reserve_counters(self, n):
+        """Stage A by k-mer identity: the sets of counters the passes in flight will hand around, made NOW — a set is gigabytes at a
+        RefSeq-scale table (5.6 GB at 2 x 10^8 k-mers) and a hipMalloc of that size is a tenth of a second: made on demand they
+        landed in the first passes of a run, sometimes inside a timed region (configs[3] shapes: 13 or 130 ms per pass, by luck)."""
+        while len(self._kc_free) < n:
+            self._kc_free.append(self.reftable.kmer_counts())
 
     # ---- stage A ----
     def set_filter(self, ki, table_hashes):
@@ -495,6 +504,8 @@ class HipEngine:
                              h_red=hip.pinned(self._xnred, np.int64), h_red_in=hip.pinned(self._xnred, np.int64),
                              d_red=hip.empty(self._xnred, np.int64), ev=hip.event()) for _ in range(nslot)]
             self._xbounds = [hip.array(np.asarray(b[1:W] if W > 1 else [0], dtype=np.uint64)) for b in bounds]
+        if getattr(self, "kmer", False):
+            self.reserve_counters(nslot + 4)  # (four passes in flight and three fronts queued ahead of them)
 
     def x_begin(self):
         # four of the hashing kernel's five workgroups per CU: with no host wait left in the chain the small kernels
