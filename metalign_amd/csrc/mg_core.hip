@@ -97,7 +97,7 @@ static void seal_open_batch() {
   if (c.fence_open.empty()) return;
   Context::FenceBatch b;
   b.blocks.swap(c.fence_open);
-  hipStream_t streams[5] = {c.stream, c.stream_a, c.stream_a2, c.stream_c, c.stream_inf};
+  hipStream_t streams[6] = {c.stream, c.stream_a, c.stream_a2, c.stream_c, c.stream_inf, c.stream_r};
   for (hipStream_t st : streams) {
     if (!st) continue;
     hipEvent_t e = fence_event();
@@ -295,6 +295,7 @@ void mg_shutdown(void) {
   if (c.pend_pinned) (void)hipHostFree(c.pend_pinned);
   if (c.stream_c) { (void)hipStreamSynchronize(c.stream_c); (void)hipStreamDestroy(c.stream_c); }
   if (c.stream_inf) { (void)hipStreamSynchronize(c.stream_inf); (void)hipStreamDestroy(c.stream_inf); }
+  if (c.stream_r) { (void)hipStreamSynchronize(c.stream_r); (void)hipStreamDestroy(c.stream_r); }
   if (c.stream_a) { (void)hipStreamSynchronize(c.stream_a); (void)hipStreamDestroy(c.stream_a); }
   if (c.stream_a2) { (void)hipStreamSynchronize(c.stream_a2); (void)hipStreamDestroy(c.stream_a2); }
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);

@@ -44,6 +44,7 @@ struct Context {
   hipStream_t stream_a = nullptr, stream_a2 = nullptr;  // two, so that consecutive batches' stage A can overlap
   // the device inflater's stream (mg_inflate.hip): a stage of a .gz file decodes while the previous stage's text is parsed and hashed
   hipStream_t stream_inf = nullptr;
+  hipStream_t stream_r = nullptr;   // where a sample's k-mer counters are zeroed (mg_kcounts_reset): beside everything else
   bool inf_side = false;
   int a_side = 0;                                        // 0 off, 1 / 2 = which of them the next sketch goes to
   unsigned a_side_wg_per_cu = 2;                         // k_sketch_reads workgroups per CU on those streams (0 = LDS limit)

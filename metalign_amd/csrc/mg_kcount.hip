@@ -633,7 +633,12 @@ struct mg_kcounts {
   // stream waits for this event first.
   hipEvent_t ev = nullptr;
   hipStream_t ev_stream = nullptr;
-  ~mg_kcounts() { if (ev) (void)hipEventDestroy(ev); }
+  ~mg_kcounts() {
+    if (ev) {
+      if (ev_stream) (void)hipEventSynchronize(ev);  // (its buffers go back to the pool: nothing may still be writing them)
+      (void)hipEventDestroy(ev);
+    }
+  }
 };
 
 using namespace mg;
@@ -817,7 +822,12 @@ int mg_kcounts_new(const mg_refdb* db, mg_kcounts** out) {
 int mg_kcounts_reset(mg_kcounts* kc) {
   MG_REQUIRE_READY();
   if (!kc) return fail(MG_ERR_ARG, "null argument");
-  hipStream_t st = kcounts_stage_stream();
+  // (on a stream of its own: a caller that zeroes a set of counters when it is done with it — not in front of the next counting
+  // kernel — gets the 0.2 ms of copies and fills beside that kernel instead of before it, and behind nothing: on the main stream
+  // they queued behind the next pass's stage B, which waits for ITS counting kernel, and two passes' counting no longer overlapped)
+  Context& c = ctx();
+  if (!c.stream_r) MG_HIP(hipStreamCreateWithFlags(&c.stream_r, hipStreamNonBlocking));
+  hipStream_t st = c.stream_r;
   MG_TRY(kcounts_order(kc, st));
   MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, st));
   MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, st));

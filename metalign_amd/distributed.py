@@ -116,6 +116,9 @@ class _KmerSketch:
 
     def free(self):
         if self.counts is not None:
+            # zeroed NOW, on the main stream (0.2 ms of copies and fills that run beside the next pass's counting), not in front of
+            # the counting kernel on the stage-A stream, where they were a hole of that length between two launches
+            self.counts.reset()
             self.engine._kc_free.append(self.counts)
             self.counts = None
 
@@ -282,8 +285,8 @@ class HipEngine:
         """The read sketches for every k, queued without a host sync (one fused launch when the library has the k set).
         match = "kmer": the reads' k_max-mers counted against the table's by identity instead (one launch, no sync)."""
         if getattr(self, "kmer", False):
-            kc = self._kc_free.pop() if self._kc_free else self.reftable.kmer_counts()
-            kc.reset()
+            # (a set of counters comes zeroed: when it was made, or when it was handed back — the one handed back longest ago first)
+            kc = self._kc_free.pop(0) if self._kc_free else self.reftable.kmer_counts()
             kc.add_dev(self.d_rb.ptr, self.d_ro.ptr, self.nreads, int(self.d_rb.count))
             return [_KmerSketch(self, kc)]
         return self.hip.sketch_reads_multi_dev_async(self.d_rb.ptr, self.d_ro.ptr, self.nreads, ks, hmaxs, s,
@@ -526,6 +529,11 @@ class HipEngine:
         self.hip.stage_a_side_stream(False)
 
     def x_front(self, ks, hmaxs, s, pct_id):
+        if getattr(self, "kmer", False):
+            # the counting kernels of consecutive passes on the two stage-A streams in turn: the next one's launch does not wait
+            # for the previous one's last wavefronts (measured for the hash path's sketch, x_begin: worse; for this kernel: better)
+            self._xturn = 1 - getattr(self, "_xturn", 1)
+            self.hip.stage_a_side_stream(1 + self._xturn)
         return dict(sks=self.sketch_local_async(ks, hmaxs, s), shard=self.new_shard_async(pct_id))
 
     def x_words(self, P, slot):
