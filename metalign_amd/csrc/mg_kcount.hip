@@ -205,10 +205,13 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef MG_KC_WAVES_PER_EU
 #define MG_KC_WAVES_PER_EU 3
 #endif
-#ifdef MG_KC_INLINE_DRAIN  // (A/B builds)
-constexpr bool kKcInlineDrain = true;
-#else
+// The drain of the usual tile's walk is INLINED since the end of round 6 (the chunked path of long reads calls the one copy): around a
+// call the kernel's live registers went to scratch and back — 0.7 GB of the launch's 1.17 GB written and 0.3 GB of its 5.8 GB fetched
+// (WRITE_SIZE / FETCH_SIZE, 10M reads: 1.17 -> 0.44 GB, 5.82 -> 5.53 GB), 1.2 % of its time — for 20 KB more code per k.
+#ifdef MG_KC_CALL_DRAIN  // (A/B builds)
 constexpr bool kKcInlineDrain = false;
+#else
+constexpr bool kKcInlineDrain = true;
 #endif
 
 // The lists of a wavefront, in two phases that each keep all 64 lanes on one kind of work and wait for memory ONCE:
@@ -660,6 +663,16 @@ static hipStream_t kcounts_stage_stream() {
   return c.a_side ? (c.a_side == 2 ? c.stream_a2 : c.stream_a) : c.stream;
 }
 
+// a sample's gate := the table's (a kernel: hipMemcpyAsync device-to-device goes through a DMA engine at ~100 GB/s — 1.2 ms for the
+// 128 MB of a ten-million-k-mer table, where these loads and stores take 0.08)
+__global__ void k_kc_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t nwords) {
+  const uint64_t n4 = nwords / 4;
+  const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+  uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
+  KC_FOR(i, n4) d4[i] = s4[i];
+  KC_FOR(i, nwords - 4 * n4) dst[4 * n4 + i] = src[4 * n4 + i];
+}
+
 // a sample's counters for the other ranks: min(counter, 3) in two bits, pair i in bits 2 (i & 15) of dword i >> 4
 __global__ void k_kc_pack2(const uint32_t* __restrict__ counts, uint64_t n, uint32_t* __restrict__ out) {
   KC_FOR(w, (n + 15) / 16) {
@@ -829,7 +842,9 @@ int mg_kcounts_reset(mg_kcounts* kc) {
   if (!c.stream_r) MG_HIP(hipStreamCreateWithFlags(&c.stream_r, hipStreamNonBlocking));
   hipStream_t st = c.stream_r;
   MG_TRY(kcounts_order(kc, st));
-  MG_HIP(hipMemcpyAsync(kc->live.p, kc->gate, kc->live_words * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_kc_copy_words, dim3(g256(kc->live_words / 4 + 1)), dim3(256), 0, st, static_cast<const uint32_t*>(kc->gate),
+                     kc->live.as<uint32_t>(), kc->live_words);
+  MG_HIP(hipGetLastError());
   MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, st));
   MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, st));
   MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, st));
