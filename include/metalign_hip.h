@@ -595,8 +595,9 @@ int mg_refdb_marks(const mg_refdb* db, int ki, uint32_t** d_marks, uint64_t* nwo
  *   rank packs min(counter, 3) of every pair into two bits (mg_kcounts_pack2_bytes bytes, a multiple of four), the ranks
  *   all-gather the arrays (2.5 MB per ten million pairs and rank), and every rank sets its counters to the sum over the ranks'
  *   arrays (d_all: nranks arrays, stride_dwords apart) — min(sum, cs) is what the sample's reads, counted together, would give.
- *   With mg_stage_a_side_stream on, mg_kcounts_reset and mg_count_kmers_dev run on the stage-A stream; every other call here
- *   runs on the main stream, after them (an event per set of counters).
+ *   Streams: mg_count_kmers_dev runs on the stage-A stream when mg_stage_a_side_stream is on (the main stream otherwise),
+ *   mg_kcounts_reset always on a stream of its own (zero a set of counters when you are done with it: the copies and fills then run
+ *   beside the next sample's counting), every other call here on the main stream; an event per set of counters orders them all.
  * mg_refpipe_mark_counts_dev / _containment_counts_dev: mg_refpipe_mark_dev / _containment_dev with "the pair's k-mer occurred
  *   >= ci times" read from the counters instead of a read sketch (_ptr_: from counters the caller summed over the ranks). */
 typedef struct mg_kcounts mg_kcounts;
