@@ -60,7 +60,7 @@ PRESETS = {
     2: dict(reads=10_000_000, genomes=10_000, genome_len=50_000, ks=[21, 31, 51], ntax=None,
             name="configs[2]: 10M reads vs 10k-genome DB, multi-k {21,31,51} containment"),
     3: dict(reads=12_500_000, genomes=200_000, genome_len=5_000, ks=[21, 31, 51], ntax=10_001,
-            name="configs[3]: 12.5M reads/GPU (100M at 8 GPUs) vs RefSeq-scale 200k-genome sketch DB sharded by hash range"),
+            name="configs[3]: 12.5M reads/GPU (100M at 8 GPUs) vs RefSeq-scale 200k-genome sketch DB"),
     4: dict(reads=12_500_000, genomes=200_000, genome_len=5_000, ks=[21, 31, 51], ntax=10_001,
             name="configs[4]: configs[3] + alignment replay -> full CAMI profile"),
 }
@@ -756,7 +756,10 @@ def main():
                        "baseline_config": cfg["config"],
                        "stage_a_definition": w["definition"], "hash_mode": w["hash_mode"], "stage_a_match": getattr(job, "match", None),
                        "stage_a_sketched_ks": out.get("sketched_ks"),
-                       "parallelism": "reads + alignment records sharded x%d, read sketches and sketch tables sharded by hash range" % world},
+                       "parallelism": ("reads + alignment records sharded x%d; every rank the whole table and its k-mer index, the ranks' counters "
+                                       "all-gathered (two bits a pair) and summed, the count lists streamed in shares" % world)
+                       if getattr(job, "match", None) == "kmer" else
+                       ("reads + alignment records sharded x%d, read sketches and sketch tables sharded by hash range" % world)},
             "roofline": roof,
             "kernels": kern,
             "kernel_ms_per_pass": kernels_ms,
