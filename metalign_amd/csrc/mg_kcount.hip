@@ -331,8 +331,9 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
     }
   };
 
-  const uint32_t maxc = wave_max_u32(cnt);
+  const uint32_t maxc = MG_UNIFORM(wave_max_u32(cnt));  // (in a scalar register: the slots beyond it are skipped by scalar branches)
   const uint32_t myp0 = p0s[lane];
+  limit = MG_UNIFORM(limit);
   const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
   // All of a lane's runs in one round trip to memory (a 150 bp read has seven), then ONE look-up for the runs that passed — a
   // single call: a copy of the look-up per slot of the unrolled loop was 80 KB of code.  hitq holds 128: when a round's runs past
@@ -345,7 +346,13 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
     for (int j = 0; j < G; ++j) {
       ev[j] = ~0u; hk[j] = 0; gw[j] = 0;
       if (s0 + j >= maxc) continue;  // (uniform)
-      if (s0 + j < cnt) ev[j] = kc_event_first(lists[(s0 + j) * 64u + (uint32_t)lane], first);
+      {  // (the slot is there whether the lane has filled it or not — kKcListCap + 1 of them: read, then selected, no branch)
+        uint32_t nxt = first;
+        const uint32_t got = kc_event_first(lists[(s0 + j) * 64u + (uint32_t)lane], nxt);
+        const bool mine = s0 + j < cnt;
+        ev[j] = mine ? got : ~0u;
+        first = mine ? nxt : first;
+      }
       if (clip) {  // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
         const uint32_t i1 = ev[j] & 1023u, i2 = (ev[j] >> 10) & 1023u;
         if (i1 >= limit) ev[j] = ~0u;

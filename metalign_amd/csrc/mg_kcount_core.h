@@ -97,12 +97,15 @@ MG_HD uint32_t kc_ext_hash(uint64_t v, int k) {
   const int nb = 2 * (kKcM + 2 * kc_flank(k));
   const uint64_t f = v >> (64 - nb);
   const uint64_t r = ((((uint64_t)kc_rc32((uint32_t)v)) << 32) | kc_rc32((uint32_t)(v >> 32))) & ((1ull << nb) - 1ull);
-  const uint64_t c = f < r ? f : r;  // (38 bits at most)
-  uint32_t h = (uint32_t)c * 0x9E3779B1u ^ ((uint32_t)(c >> 32) + 0x7F4A7C15u) * 0x85EBCA6Bu;
-  h ^= h >> 15; h *= 0x2C1B3C6Du;
-  h ^= h >> 12; h *= 0x297A2D39u;
-  h ^= h >> 15;
-  return h == kKcNone ? 0x7fffffffu : h;
+  const uint64_t c = f < r ? f : r;  // (38 bits at most: the six above the low word go in through a 24-bit multiply-add, full rate)
+#ifdef MG_HOST_CHECK
+  uint32_t h = (uint32_t)c * 0x9E3779B1u + ((uint32_t)(c >> 32) & 0x3fu) * 0x85EBCBu;
+#else
+  uint32_t h = (uint32_t)c * 0x9E3779B1u + __umul24((uint32_t)(c >> 32) & 0x3fu, 0x85EBCBu);
+#endif
+  h ^= h >> 15; h *= 0x2C1B3C6Du;  // (two quarter-rate multiplies in all: this runs once per run of every read)
+  h ^= h >> 13;
+  return h & 0xfffffffeu;  // (never kKcNone: one AND instead of a compare and a select)
 }
 // bits of the gate bitmap for a table of nd distinct k-mers: 2^extra bits per k-mer (one run in 2^extra that has nothing to find
 // passes), between 2^16 and 2^32
@@ -137,7 +140,13 @@ MG_HD uint32_t kc_bits32(const MG_LDS uint32_t* s, uint32_t p) {
 MG_HD uint64_t kc_ext64(const MG_LDS uint32_t* s, uint32_t p) {
   const uint32_t d = p >> 4, sh = (p & 15u) << 1;
   const uint32_t a = s[d], b = s[d + 1], c = s[d + 2];
+#ifdef MG_HOST_CHECK
   const uint32_t hi = (uint32_t)(((((uint64_t)a) << 32 | b) << sh) >> 32), lo = (uint32_t)(((((uint64_t)b) << 32 | c) << sh) >> 32);
+#else
+  // (two funnel shifts — v_alignbit_b32 takes (hi : lo) >> n for n in 0 .. 31 — and a select for sh = 0, instead of two 64-bit shifts)
+  const uint32_t n = (sh ^ 31u) + 1u;  // 32 - sh for sh in 1 .. 31 (written so that the compiler does not make a multiply of it)
+  const uint32_t hi = sh ? __builtin_amdgcn_alignbit(a, b, n) : a, lo = sh ? __builtin_amdgcn_alignbit(b, c, n) : b;
+#endif
   return ((uint64_t)hi << 32) | lo;
 }
 // the hash a closed run is looked up by (pos: where its candidate starts in the read that starts at stream position p0)
