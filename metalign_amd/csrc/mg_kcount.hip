@@ -156,6 +156,10 @@ __global__ void k_kc_per_pair(const uint32_t* __restrict__ counts, const uint32_
 #endif
 constexpr int kKcWaves = MG_KC_WAVES;    // wavefronts per workgroup (each works alone)
 constexpr uint32_t kKcListCap = MG_KC_LIST_CAP;  // closed runs a lane can hold before the lists are emptied (150 bp, k = 51: six per read)
+#ifndef MG_KC_DIRECT
+#define MG_KC_DIRECT 7
+#endif
+constexpr uint32_t kKcDirect = MG_KC_DIRECT;  // slots of a lane's list that the drain takes lane by lane; the rest are gathered (kc_drain)
 constexpr uint32_t kKcHitCap = 128;      // runs past the gate waiting for their look-up (hitq, hitl): it comes when 64 or more wait
 constexpr uint32_t kKcSlack = 8;         // dwords a k-mer taken at the end of the stream may read past it
 
@@ -335,23 +339,60 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
   const uint32_t myp0 = p0s[lane];
   limit = MG_UNIFORM(limit);
   const bool clip = limit < 1024u;  // (the usual call: the walk went to the end of the tile, nothing to cut)
-  // All of a lane's runs in one round trip to memory (a 150 bp read has seven), then ONE look-up for the runs that passed — a
-  // single call: a copy of the look-up per slot of the unrolled loop was 80 KB of code.  hitq holds 128: when a round's runs past
-  // the gate do not fit (a tile of reads from unsaturated k-mers), the slots that did not get in are taken again next round.
-  constexpr int G = (int)kKcListCap;
+  // All of a tile's runs in one round trip to memory, then ONE look-up for the runs that passed (a single call: a copy of the
+  // look-up per slot of the unrolled loop was 80 KB of code).  A 150 bp read closes seven runs, the tile's longest list has eleven
+  // or twelve: the first kKcDirect slots of every lane are taken lane by lane, and what the lanes hold BEYOND them — some thirty
+  // runs of a tile — is gathered into one more slot, a run to a lane (tokens through LDS: whose, which slot), when it fits 64;
+  // slot by slot, most lanes idle, those tail slots were 7 % of the kernel.  hitq holds 128: when a round's runs past the gate do
+  // not fit (a tile of reads from unsaturated k-mers), the slots that did not get in are taken again next round.
+  constexpr int G = (int)kKcDirect;
+  MG_LDS uint32_t* tokens = hitl;  // (the tokens are read before the first run is queued)
   uint32_t done = G, first = from;  // (first: the first window of the lane's next run — the walk leaves it out of the events)
   for (uint32_t s0 = 0; s0 < maxc; s0 += done) {
-    uint32_t ev[G], hk[G], gw[G];
+    uint32_t ev[G + 1], hk[G + 1], gw[G + 1], src = (uint32_t)lane, srcp0 = myp0;
+    // ---- the tail beyond this round's direct slots: gathered when it fits one slot
+    bool gathered = false;
+    if (s0 + (uint32_t)G < maxc) {  // (uniform)
+      const uint32_t ex = cnt > s0 + (uint32_t)G ? cnt - (s0 + (uint32_t)G) : 0u;
+      uint32_t total = 0;
+#pragma unroll 1
+      for (uint32_t e = 0; s0 + (uint32_t)G + e < maxc; ++e) total += (uint32_t)__popcll(__ballot(ex > e));
+      if (total <= 64u) {  // (uniform)
+        uint32_t off = 0;
+#pragma unroll 1
+        for (uint32_t e = 0; s0 + (uint32_t)G + e < maxc; ++e) {
+          const unsigned long long m = __ballot(ex > e);
+          if (ex > e) tokens[off + (uint32_t)__popcll(m & below)] = (uint32_t)lane | ((s0 + (uint32_t)G + e) << 8);
+          off += (uint32_t)__popcll(m);
+        }
+        wave_lds_sync();
+        ev[G] = ~0u;
+        if ((uint32_t)lane < total) {
+          const uint32_t tok = tokens[lane], slot = tok >> 8;
+          src = tok & 63u;
+          srcp0 = p0s[src];
+          uint32_t nxt = ((lists[(slot - 1u) * 64u + src] >> 10) & 1023u) + 1u;  // (the run before it in its lane's list ends one window earlier)
+          ev[G] = kc_event_first(lists[slot * 64u + src], nxt);
+        }
+        wave_lds_sync();
+        gathered = true;
+      }
+    }
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      ev[j] = ~0u; hk[j] = 0; gw[j] = 0;
-      if (s0 + j >= maxc) continue;  // (uniform)
-      {  // (the slot is there whether the lane has filled it or not — kKcListCap + 1 of them: read, then selected, no branch)
+    for (int j = 0; j < G + 1; ++j) {
+      hk[j] = 0; gw[j] = 0;
+      if (j < G) {
+        ev[j] = ~0u;
+        if (s0 + j >= maxc) continue;  // (uniform)
+        // (the slot is there whether the lane has filled it or not — kKcListCap + 1 of them: read, then selected, no branch)
         uint32_t nxt = first;
         const uint32_t got = kc_event_first(lists[(s0 + j) * 64u + (uint32_t)lane], nxt);
         const bool mine = s0 + j < cnt;
         ev[j] = mine ? got : ~0u;
         first = mine ? nxt : first;
+      } else if (!gathered) {
+        ev[j] = ~0u;
+        continue;  // (uniform)
       }
       if (clip) {  // what lies at or beyond `limit` is walked again (mg_kcount_core.h: kc_walk): not now
         const uint32_t i1 = ev[j] & 1023u, i2 = (ev[j] >> 10) & 1023u;
@@ -359,23 +400,27 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
         else if (i2 >= limit) ev[j] = (ev[j] & ~(1023u << 10)) | ((limit - 1u) << 10);
       }
       // a run's event says where its candidate starts: the bases around it, hashed, are what the table files k-mers under
-      hk[j] = kc_run_hash(fwd, myp0, kc_event_pos(ev[j]), k);
+      hk[j] = kc_run_hash(fwd, j < G ? myp0 : srcp0, kc_event_pos(ev[j]), k);
       if (!kc_event_none(ev[j])) gw[j] = MG_KC_LOAD(&live[(hk[j] >> gshift) >> 5]);
     }
-    done = G;
+    done = gathered ? maxc - s0 : (uint32_t)G;  // (the gathered slot stands for every slot beyond the direct ones)
     hn = 0;
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      if (s0 + j >= maxc || (uint32_t)j >= done) continue;  // (uniform)
+    for (int j = 0; j < G + 1; ++j) {
+      if (j < G ? (s0 + j >= maxc || (uint32_t)j >= done) : (!gathered || done < maxc - s0)) continue;  // (uniform)
       const bool pass = (gw[j] >> ((hk[j] >> gshift) & 31u)) & 1u;
       const unsigned long long m = __ballot(pass);
-      if (hn + (uint32_t)__popcll(m) > kKcHitCap) { done = (uint32_t)j; first = ev[j] & 1023u; continue; }
+      if (hn + (uint32_t)__popcll(m) > kKcHitCap) {  // no room: this slot and what follows it come again (the gathered one: its slots, lane by lane or gathered anew)
+        done = (uint32_t)j;
+        if (j < G) first = ev[j] & 1023u;
+        continue;
+      }
       nev += kc_event_none(ev[j]) ? 0u : 1u;
       if (m == 0ull) continue;
       if (pass) {
         const uint32_t at = hn + (uint32_t)__popcll(m & below);
         hitq[at] = (unsigned long long)hk[j] | ((unsigned long long)ev[j] << 32);
-        hitl[at] = (uint32_t)lane;
+        hitl[at] = j < G ? (uint32_t)lane : src;
       }
       hn += (uint32_t)__popcll(m);
       npass += pass ? 1u : 0u;
