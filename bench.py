@@ -125,7 +125,7 @@ def resolve_config(args, world):
 
 
 def _match_for(args, ks):
-    """--match kmer (the default) means what the package does by default: identity from k_max = 27 on, the read sketch below."""
+    """--match kmer (the default) means what the package does by default: identity from k_max = 25 on, the read sketch below."""
     from metalign_amd.distributed import kmer_match_by_default
     return "kmer" if (args.match == "kmer" and kmer_match_by_default(max(ks))) else "hash"
 

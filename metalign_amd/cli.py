@@ -41,7 +41,7 @@ _OPTIONS = {
     'kmer_match': dict(default='identity', choices=['identity', 'identity_only', 'hash'],
                        help='A reference-pipeline sketch table: a read k-mer meets a sketched one by what it IS, as kmc and kmc_tools '
                             'intersect compare k-mers (default where it is the faster way: a table that stores its k-mers, the largest k '
-                            'from 27 to 64; "hash" otherwise), wherever that can run at all (identity_only: the largest k from 15 to 64), or '
+                            'from 25 to 64; "hash" otherwise), wherever that can run at all (identity_only: the largest k from 15 to 64), or '
                             'by its MurmurHash3 value.'),
     'device_multimap': dict(action='store_true', help='Resolve multimapped reads on the GPU (their lists never leave '
                             'the device; abundances equal the default path to ~1e-15 relative, not byte for byte).'),

@@ -91,11 +91,12 @@ class _CudaView:
                                          "version": 2, "strides": None}
 
 
-# Stage A by k-mer identity against the read sketch, one k alone (2M reads x 2k genomes, one MI355X, tools/kcount_probe.py): k = 17: 2.39 against
-# 1.08 ms, 21: 1.62 / 1.09, 25: 1.23 / 1.16, 31: 0.79 / 1.13, 41: 0.60 / 1.36, 51: 0.45 / 1.4 — a window of k has k - 14 - 2 e candidates, and a
-# read of 150 bases closes 300 / (k - 13 - 2 e) runs: below k = 27 the runs cost more than the hashes they save.
+# Stage A by k-mer identity against the read sketch, one k alone (2M reads x 2k genomes, one MI355X, tools/kcount_probe.py, the round's last
+# kernel): k = 21: 1.37 against 1.09 ms, 23: 1.35 / 1.13, 24: 1.19 / 1.05, 25: 1.08 / 1.14, 26: 0.97 / 1.22, 27: 0.92 / 1.16, 31: 0.72 / 1.16,
+# 41: 0.61 / 1.42, 60: 0.52 / 1.46 — a window of k has k - 14 - 2 e candidates, and a read of 150 bases closes 300 / (k - 13 - 2 e)
+# runs: below k = 25 the runs cost more than the hashes they save.
 KMER_MATCH_MIN_K, KMER_MATCH_MAX_K = 15, 64   # what mg_kcount.hip is built for
-KMER_MATCH_DEFAULT_FROM_K = 27                # ... and from where it is what a job does when nobody says
+KMER_MATCH_DEFAULT_FROM_K = 25                # ... and from where it is what a job does when nobody says
 
 
 def kmer_match_by_default(kmax):
@@ -752,7 +753,7 @@ class ShardJob:
         `kmc_tools intersect` do (scripts/select_db.py:50-59; mg_kcount.hip: no hash on the read side; 15 <= k_max <= 64; every
         rank of a multi-GPU job holds the whole table and counts ITS reads, the ranks' counters — two bits per pair at the
         reference's -cs3 — are all-gathered and summed: _sum_kmer_counts); "hash": by its MurmurHash3 value (rounds 4-5; any k;
-        the table sharded by hash range); None: "kmer" for k_max from 27 to 64 when the table holds its k-mers, "hash" otherwise."""
+        the table sharded by hash range); None: "kmer" for k_max from 25 to 64 when the table holds its k-mers, "hash" otherwise."""
         self.dist, self.rank, self.world = dist, rank, world
         # always_exchange: run the collectives even when world == 1 (single-GPU validation of the RCCL path)
         self.exchange = dist is not None and (world > 1 or always_exchange)

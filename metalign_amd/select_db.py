@@ -598,7 +598,7 @@ def kmer_match_applies(args, table, arrays):
     ok = arrays.get('kmer_hi') is not None and 15 <= table.ks[-1] <= 64
     if not ok and want == 'identity_only':
         sys.exit('Error: --kmer_match identity_only needs a reference-pipeline table that stores its k-mers, with the largest k in [15, 64].')
-    # (identity: where it is the faster of the two — from k_max = 27 on; identity_only: wherever it can run)
+    # (identity: where it is the faster of the two — from k_max = 25 on; identity_only: wherever it can run)
     return ok and (want == 'identity_only' or kmer_match_by_default(table.ks[-1]))
 
 

@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 config = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # BASELINE configs[1] by default (configs[2]: python tools/soak.py 300 2)
 hip = Hip.get(0)
 cfg = dict(bench.PRESETS[config], config=config)
-cfg["match"] = "kmer" if mgd.kmer_match_by_default(max(cfg["ks"])) else "hash"  # (what bench.py runs by default: identity from k_max = 27 on)
+cfg["match"] = "kmer" if mgd.kmer_match_by_default(max(cfg["ks"])) else "hash"  # (what bench.py runs by default: identity from k_max = 25 on)
 w = bench.build_workload(cfg, 1000, 0, hip)
 job = bench.make_job(hip, None, 0, 1, cfg, w)
 MM = os.environ.get("SOAK_MM", "1") == "1"

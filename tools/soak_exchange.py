@@ -16,7 +16,7 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 config = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # BASELINE configs[1] by default
 hip = Hip.get(0, stream=st.cuda_stream)
 cfg = dict(bench.PRESETS[config], config=config)
-cfg["match"] = "kmer" if mgd.kmer_match_by_default(max(cfg["ks"])) else "hash"  # (what bench.py runs by default: identity from k_max = 27 on)
+cfg["match"] = "kmer" if mgd.kmer_match_by_default(max(cfg["ks"])) else "hash"  # (what bench.py runs by default: identity from k_max = 25 on)
 w = bench.build_workload(cfg, 1000, 0, hip)
 job = bench.make_job(hip, dist, 0, 1, cfg, w, force_dist=True)
 first = job.run(10)
