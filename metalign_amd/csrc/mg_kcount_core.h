@@ -76,7 +76,10 @@ constexpr uint32_t kKcSlots = 4;             // entries of a bucket that sit in 
 constexpr uint32_t kKcMaxRead = 1023;        // window numbers of an event take ten bits: longer reads go through in chunks
 
 // bases of the k-mer that a candidate has on either side, and how many candidates that leaves
-constexpr int kc_flank(int k) { return k >= 23 ? 2 : (k >= 19 ? 1 : 0); }
+// (two from k = 23 on; from k = 53 on as many as keep the candidates at 33 or 34: the walk holds a block of candidates in registers, and
+// with the 42 of k = 60 under two flank bases it spilled inside its loop — 2.26 ms per 10M reads against 2.08 at k = 51; the wider
+// flanks cost a fifth more runs and nothing else: the filed bases, 15 + 2 e <= 31, still come out of one 64-bit read of the stream)
+constexpr int kc_flank(int k) { return k >= 53 ? 2 + (k - 51) / 2 : (k >= 23 ? 2 : (k >= 19 ? 1 : 0)); }
 constexpr int kc_cands(int k) { return k - kKcM + 1 - 2 * kc_flank(k); }
 
 // the WORD of a candidate given both strands of its m-mer 2-bit packed (first base most significant, right-aligned in 30 bits)
@@ -97,11 +100,12 @@ MG_HD uint32_t kc_ext_hash(uint64_t v, int k) {
   const int nb = 2 * (kKcM + 2 * kc_flank(k));
   const uint64_t f = v >> (64 - nb);
   const uint64_t r = ((((uint64_t)kc_rc32((uint32_t)v)) << 32) | kc_rc32((uint32_t)(v >> 32))) & ((1ull << nb) - 1ull);
-  const uint64_t c = f < r ? f : r;  // (38 bits at most: the six above the low word go in through a 24-bit multiply-add, full rate)
+  const uint64_t c = f < r ? f : r;  // (38 bits up to k = 52, 62 at most: what lies above the low word goes in through 24-bit multiply-adds, full rate)
+  const uint32_t hi = (uint32_t)(c >> 32);
 #ifdef MG_HOST_CHECK
-  uint32_t h = (uint32_t)c * 0x9E3779B1u + ((uint32_t)(c >> 32) & 0x3fu) * 0x85EBCBu;
+  uint32_t h = (uint32_t)c * 0x9E3779B1u + (hi & 0xffffffu) * 0x85EBCBu + (hi >> 24) * 0xC2B2AFu;
 #else
-  uint32_t h = (uint32_t)c * 0x9E3779B1u + __umul24((uint32_t)(c >> 32) & 0x3fu, 0x85EBCBu);
+  uint32_t h = (uint32_t)c * 0x9E3779B1u + __umul24(hi & 0xffffffu, 0x85EBCBu) + __umul24(hi >> 24, 0xC2B2AFu);
 #endif
   h ^= h >> 15; h *= 0x2C1B3C6Du;  // (two quarter-rate multiplies in all: this runs once per run of every read)
   h ^= h >> 13;
