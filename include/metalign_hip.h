@@ -578,10 +578,12 @@ int mg_refdb_marks(const mg_refdb* db, int ki, uint32_t** d_marks, uint64_t* nwo
  * (scripts/select_db.py:50-59) as those tools compute it: canonical k-mers compared as k-mers — the read side hashes
  * nothing (MurmurHash3 only SELECTS a genome's sketch, when the table is built).  Normative: oracle/mg_oracle.c,
  * mgo_refpipe_count_kmers.  Differs from the hash path (mg_sketch_* + mg_refpipe_mark_dev) only where two k-mers share a
- * hash value.  k_max in [15, 64]; other k stay with the hash path.
+ * hash value.  k_max in [15, 64]; other k stay with the hash path (and below k_max = 25 the hash path is the faster of the two:
+ * the host code chooses it there unless told otherwise).
  *
  * mg_refdb_index_kmers: builds, on the device, the index the read side needs over the table's distinct canonical k_max-mers
- *   (grouped by minimizer: metalign_amd/csrc/mg_kcount_core.h).  kmer_hi / kmer_lo: the kept k_max-mer of every pair in pair
+ *   (filed under the hash of the 19 to 31 bases around a k-mer's minimizer, four entries to a 128-byte bucket, a gate bitmap
+ *   over the hash's leading bits: metalign_amd/csrc/mg_kcount_core.h; 210 B per k-mer, 7 ms for ten million).  kmer_hi / kmer_lo: the kept k_max-mer of every pair in pair
  *   order, 2-bit packed, first base most significant (table format 3: k<K>.kmer_hi.u64 / .kmer_lo.u64) — or NULL for a table
  *   built here by mg_refdb_build, which holds them.  A rank of a multi-GPU job indexes the WHOLE table's pairs it was given.
  * mg_kcounts: one sample's occurrence counters for one table (zeroed when made; mg_kcounts_reset zeroes again, stream-ordered).
