@@ -392,9 +392,20 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
   auto take = [&](uint32_t u) -> uint32_t {  // base u comes in; the word of the candidate that ends there (number u - 14)
     if ((u & 15u) == 0) word = kc_ext32(fwd, p0 + u);
     const uint32_t c = (word >> (30u - 2u * (u & 15u))) & 3u;
-    f = ((f << 2) | c) & kKcMask;
-    r = (r >> 2) | ((c ^ 3u) << 28);
-    uint32_t key = kc_word(f, r, u - (uint32_t)(M - 1));
+    // both strands of the m-mer LEFT-aligned in their dwords (bits 31 .. 2): the oldest base falls off the top of f by itself, the
+    // newest complement comes into r from above by one funnel shift (what that leaves in r's two low bits is an older base: below
+    // every bit a comparison of two different m-mers can turn on — m is odd: no m-mer is its own reverse complement — and below
+    // the rank's bits); the word is kc_word's: ((c ^ X) >> 8) << 10 | number, with c << 2 in hand instead of c.  Two operations
+    // fewer per base than with right-aligned strands and a mask.
+    f = (f << 2) | (c << 2);
+#ifdef MG_HOST_CHECK
+    r = (r >> 2) | ((c ^ 3u) << 30);
+#else
+    r = __builtin_amdgcn_alignbit(c ^ 3u, r, 2);
+#endif
+    const uint32_t ct = f < r ? f : r;
+    // ((ct ^ X) & ~1023) | number, written as (ct & ~1023) ^ (a uniform word): one three-input operation
+    uint32_t key = (ct & ~kKcPos) ^ (((kKcXor << 2) & ~kKcPos) | (u - (uint32_t)(M - 1)));
     if constexpr (MODE == 0) {
       if ((u & 31u) == 0) iw = kc_bits32(inv, p0 + u);
       const uint32_t bad = (iw >> (31u - (u & 31u))) & 1u;
@@ -425,16 +436,17 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
     const bool tail = j0 + (uint32_t)W > nmers;
     // (the windows past a lane's own read have no minimizer: one compare against the lane's window count — which is "none" while
     // every lane's read goes on, so that the compare's result goes straight into the select, not through a scalar OR with `tail`)
-    const uint32_t nwt = (MODE != 1 || tail) ? nw : kKcNone;
-    auto step = [&]<int T>() -> bool {
+    // MODE 1 (every read as long as the longest) away from the tile's end: no compare at all — the block's code twice, the one without
+    // (two operations of a step's seventeen) for every block but the last of a tile
+    auto step = [&]<int T, bool ENDS>() -> bool {
       const uint32_t j = j0 + (uint32_t)T;
-      if constexpr (T % 8 == 0 && T > 0) { if (tail && j >= nmers) return false; }
+      if constexpr (ENDS && T % 8 == 0 && T > 0) { if (j >= nmers) return false; }
       const uint32_t key = take(j + (uint32_t)M - 1u);
       P = T == 0 ? key : (key < P ? key : P);
       uint32_t Mc = P;
       if constexpr (T != W - 1) { const uint32_t s = A[T + 1 < W ? T + 1 : 0]; Mc = s < P ? s : P; }
       const uint32_t i = j - (uint32_t)(W - 1);
-      Mc = i < nwt ? Mc : kKcNone;
+      if constexpr (MODE != 1 || ENDS) Mc = i < nw ? Mc : kKcNone;
       out.put(cnt, Mprev, ((i - 1u) & 1023u) << 10);
       const bool ch = Mc != Mprev;
       cnt += ch ? 1u : 0u;  // (add with carry, then the cap: no scalar AND of two compares in between)
@@ -444,8 +456,13 @@ MG_HD uint32_t kc_walk(const MG_LDS uint32_t* fwd, const MG_LDS uint32_t* inv, u
       walked = i + 1u;
       return true;
     };
-    const bool whole = [&]<int... T>(std::integer_sequence<int, T...>) { return (step.template operator()<T>() && ...); }(
-        std::make_integer_sequence<int, W>{});
+    bool whole;
+    if (tail)
+      whole = [&]<int... T>(std::integer_sequence<int, T...>) { return (step.template operator()<T, true>() && ...); }(
+          std::make_integer_sequence<int, W>{});
+    else
+      whole = [&]<int... T>(std::integer_sequence<int, T...>) { return (step.template operator()<T, false>() && ...); }(
+          std::make_integer_sequence<int, W>{});
     if (!whole) break;
   }
   walked = walked < nwmax ? walked : nwmax;  // (the tail block may have walked past the end)
