@@ -712,8 +712,9 @@ def main():
                           "that pass read their bucket's 128-byte line. achieved / frac = 158 B/read x reads / kernel_ms_alone against 8 TB/s; "
                           "traffic (FETCH_SIZE + WRITE_SIZE of the committed PMC passes) is 4.5 x that: the gate's sectors. The walk alone "
                           "is 1.3 of the kernel's 2.1-2.2 ms (SQ_INSTS_VALU 33 per wave-step, three wavefronts per SIMD at 168 VGPRs); "
-                          "valu_frac / valu_model are null: no per-opcode pricing of this kernel was made (profiles/r06/kcount_*.txt hold "
-                          "its SQ counters and ablations). ") if by_kmer else
+                          "valu_frac = SQ_INSTS_VALU x 4 cycles (every opcode of the walk's step is full rate: valu_model.source says how that was "
+                          "taken) / the SIMD cycles of the launch (GRBM_GUI_ACTIVE / 8 x 1024), from the committed PMC pass: the kernel is an "
+                          "integer-VALU kernel with a latency tail (profiles/r06/kcount_*_final.txt hold its SQ counters). ") if by_kmer else
                          ("integer-VALU bound (one MurmurHash3 per k-mer per k): valu_frac = SQ_INSTS_VALU x the measured issue "
                           "cycles per VALU instruction of this kernel's opcode mix / the SIMD cycles of the launch (GRBM_GUI_ACTIVE "
                           "/ 8 x 1024), all from the committed PMC pass of this workload, is the figure that describes it; achieved "
