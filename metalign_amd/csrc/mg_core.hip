@@ -435,9 +435,28 @@ int mg_stage_c_side_stream(int on) {
 int mg_stage_a_side_stream(int on) {
   MG_REQUIRE_READY();
   mg::Context& c = ctx();
-  if (on < 0 || on > 2) return fail(MG_ERR_ARG, "stage-A stream selector %d outside [0,2]", on);
-  if (on == 1 && !c.stream_a) MG_HIP(hipStreamCreateWithFlags(&c.stream_a, hipStreamNonBlocking));
-  if (on == 2 && !c.stream_a2) MG_HIP(hipStreamCreateWithFlags(&c.stream_a2, hipStreamNonBlocking));
+  if (on < 0 || on > 4) return fail(MG_ERR_ARG, "stage-A stream selector %d outside [0,4]", on);
+  // 3 / 4: streams 1 / 2 at the LOWEST priority the device has.  A single shard's passes (stage A of consecutive passes on the two
+  // streams in turn, no collective anywhere) run 5 % faster with them — the short kernels of stage B and C on the other streams
+  // get their wavefronts ahead of the next pass's persistent counting kernel: 2.33 -> 2.22 ms per pass at configs[2]; with the
+  // exchange's collectives on the main stream it is the other way round (2.51 -> 2.76 ms), so a job asks for what it runs.
+  const bool want_low = on >= 3;
+  if (on >= 3) on -= 2;
+  if (on && want_low != c.a_low) {  // the other kind: the streams are made anew (rare: once per job)
+    for (hipStream_t* s : {&c.stream_a, &c.stream_a2})
+      if (*s) { MG_HIP(hipStreamSynchronize(*s)); MG_HIP(hipStreamDestroy(*s)); *s = nullptr; }
+    c.a_low = want_low;
+  }
+  {
+    int lo = 0, hi = 0;  // (numerically hi <= lo: hi is the greatest priority)
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int w = 1; w <= 2; ++w) {
+      hipStream_t* s = w == 1 ? &c.stream_a : &c.stream_a2;
+      if (on != w || *s) continue;
+      if (c.a_low) MG_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo));
+      else MG_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    }
+  }
   if (!on && c.a_side) {
     if (c.stream_a) MG_HIP(hipStreamSynchronize(c.stream_a));
     if (c.stream_a2) MG_HIP(hipStreamSynchronize(c.stream_a2));

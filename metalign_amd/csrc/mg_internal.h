@@ -47,6 +47,7 @@ struct Context {
   hipStream_t stream_r = nullptr;   // where a sample's k-mer counters are zeroed (mg_kcounts_reset): beside everything else
   bool inf_side = false;
   int a_side = 0;                                        // 0 off, 1 / 2 = which of them the next sketch goes to
+  bool a_low = false;                                    // ... made at the device's lowest stream priority (mg_stage_a_side_stream(3 / 4))
   unsigned a_side_wg_per_cu = 2;                         // k_sketch_reads workgroups per CU on those streams (0 = LDS limit)
   bool is_stage_a(hipStream_t st) const { return st && (st == stream_a || st == stream_a2); }
   const char* stage_a_prefix(hipStream_t st) const { return st == stream_a2 ? "b:" : "a:"; }

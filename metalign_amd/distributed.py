@@ -452,7 +452,10 @@ class HipEngine:
         rs = self._result_sets()[slot]
         T = self.ntax
         if side:  # stage A of consecutive passes on alternating streams: pass i+1's overlaps pass i's tail
-            self.hip.stage_a_side_stream(1 + (slot & 1))
+            # (3 / 4: the two stage-A streams at the lowest priority — no collective in this schedule, and the short kernels of stage B and C
+            # then get in ahead of the next pass's persistent stage-A kernel: 2.33 -> 2.22 ms per pass at configs[2])
+            # (by hash value the sketch's own small kernels — sort, pack — ride the stage-A streams: default priority, as measured: 5.4 against 5.6 ms)
+            self.hip.stage_a_side_stream((3 if getattr(self, "kmer", False) else 1) + (slot & 1))
         sks = self.sketch_local_async(ks, hmaxs, s)                                               # stage A
         shard = self.hip.profile_begin_dev(self.d_recs.ptr, self.nrecs, self.has_lookahead, self.d_r2t.ptr,
                                            self.nref, self.ntax, pct_id)
