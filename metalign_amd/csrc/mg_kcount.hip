@@ -244,7 +244,9 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
   MG_LDS uint32_t* hitl = (MG_LDS uint32_t*)(size_t)(lds + L.hitl);                      // ... and whose it is
   MG_LDS uint32_t* stat = (MG_LDS uint32_t*)(size_t)(lds + L.stat);
   const uint32_t ablate = (cfg >> 17) & 7u;
-  const KcIndexView ix{live, shared, prim, ovf, counts, csat, (1u << (cfg & 0xffu)) - 1u, gshift, cfg >> 20, ablate};
+  const uint32_t epoch = (gshift >> 8) & 0xffu;  // (the pass number of the entry counters rides above the gate's shift)
+  gshift &= 63u;
+  const KcIndexView ix{live, shared, prim, ovf, counts, csat, (1u << (cfg & 0xffu)) - 1u, gshift, cfg >> 20, ablate, epoch};
   const uint32_t nprim = kKcSlots * (ix.bmask + 1u);
   const int k = (int)((cfg >> 8) & 0xffu);
   const bool bad = (cfg >> 16) & 1u;
@@ -284,7 +286,7 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
       uint32_t slow = 0, fastm = 0;    // entries of the line to match: whose hash is of several candidates / of one: bit t
 #pragma unroll
       for (uint32_t t = 0; t < kKcSlots; ++t) {
-        const bool mine = active && eb[t].y == key, want = mine && !(ix.cs != 0u && cv[t] >= ix.cs);
+        const bool mine = active && eb[t].y == key, want = mine && !(ix.cs != 0u && kc_entry_count(cv[t], ix.epoch) >= ix.cs);
         any = any || mine;
         open = open || want;
         fastm |= (want && eb[t].z != kKcSeveral && ablate != 3u) ? 1u << t : 0u;
@@ -296,9 +298,10 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
         if (__ballot(fast) == 0ull) continue;
         const kc_u32x4 a = t == 0 ? ea[0] : (t == 1 ? ea[1] : (t == 2 ? ea[2] : ea[3]));
         const kc_u32x4 b = t == 0 ? eb[0] : (t == 1 ? eb[1] : (t == 2 ? eb[2] : eb[3]));
+        const uint32_t seen = t == 0 ? cv[0] : (t == 1 ? cv[1] : (t == 2 ? cv[2] : cv[3]));
         if (fast) {
           const uint32_t f = kc_match_windows(fwd, inv, k, bad, a.x, a.y, a.z, a.w, b.z, p0, pos, i1, i2);
-          kc_count_entry(ix, num0 + t, b.x, f);
+          kc_count_entry(ix, num0 + t, b.x, f, seen);
           found += f;
         }
       }
@@ -312,16 +315,17 @@ __device__ __forceinline__ void kc_drain_body(MG_GLB uint32_t* live, const MG_GL
           if (line) { num = num0 + (uint32_t)__builtin_ctz(slow); slow &= slow - 1u; }
           else { num = nprim + oa + tv; ++tv; }
           const KcEntry E = kc_entry(ix, num);
+          const uint32_t seen = ix.cs != 0u ? MG_KC_LOAD(&ix.csat[num]) : 0u;
           bool want = line;
           if (!line && E.key == key) {
             any = true;
-            want = !(ix.cs != 0u && MG_KC_LOAD(&ix.csat[num]) >= ix.cs);
+            want = !(ix.cs != 0u && kc_entry_count(seen, ix.epoch) >= ix.cs);
             open = open || want;
           }
           if (want && ablate != 3u) {
             const uint32_t f = E.off == kKcSeveral ? kc_scan_run(fwd, inv, k, bad, E.w, p0, i1, i2)
                                                    : kc_match_windows(fwd, inv, k, bad, E.w[0], E.w[1], E.w[2], E.w[3], E.off, p0, pos, i1, i2);
-            kc_count_entry(ix, num, E.head, f);
+            kc_count_entry(ix, num, E.head, f, seen);
             found += f;
           }
         }
@@ -682,6 +686,7 @@ struct mg_kcounts {
   mg::DevBuf sat;     // a counter per entry number: what has been found under it (at the saturation value the entry is skipped)
   mg::DevBuf stats;   // u64[4]
   uint64_t n = 0, live_words = 0, sat_words = 0;
+  uint32_t epoch = 0;  // the pass number the entry counters' words are tagged with (mg_kcount_core.h: kc_entry_count); 0: never reset yet
   const void* gate = nullptr;  // the table's gate bitmap the live one is reset from (owned by the table: it outlives the counters)
   // Who wrote last, and when: with mg_stage_a_side_stream on, a reset and the counting go to the stage-A stream (so that a
   // rank's collectives on the main stream do not hold the next pass's counting back); whoever touches the counters on another
@@ -897,7 +902,9 @@ int mg_kcounts_reset(mg_kcounts* kc) {
   hipLaunchKernelGGL(k_kc_copy_words, dim3(g256(kc->live_words / 4 + 1)), dim3(256), 0, st, static_cast<const uint32_t*>(kc->gate),
                      kc->live.as<uint32_t>(), kc->live_words);
   MG_HIP(hipGetLastError());
-  MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, st));
+  // (the entry counters are not zeroed: their words carry the pass number — only when that wraps, every 255 passes)
+  kc->epoch = kc->epoch % 255u + 1u;
+  if (kc->epoch == 1u) MG_HIP(hipMemsetAsync(kc->sat.p, 0, kc->sat_words * 4, st));
   MG_HIP(hipMemsetAsync(kc->counts.p, 0, (kc->n + 1) * 4, st));
   MG_HIP(hipMemsetAsync(kc->stats.p, 0, 12 * 8, st));
   return kcounts_wrote(kc, st);
@@ -965,7 +972,7 @@ int mg_count_kmers_dev(const uint8_t* d_bases, const uint64_t* d_offsets, uint64
   const uint64_t ntiles = (nreads + 63) / 64;
   const unsigned grid = grid_for(ntiles, kKcWaves, (unsigned)c.num_cus * per_cu);
   KcArgs a{d_bases, d_offsets, nreads, kc->live.as<uint32_t>(), ix.shared.as<uint32_t>(), ix.prim.as<KcEntry>(), ix.ovf.as<KcEntry>(), kc->counts.as<uint32_t>(),
-           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), 32u - ix.gbits, ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
+           kc->sat.as<uint32_t>(), kc->stats.as<unsigned long long>(), (32u - ix.gbits) | (kc->epoch << 8), ix.bmask, (uint32_t)sd, c.count_sat, (uint32_t)dbg("kc_ablate"), (uint32_t)dbg("kc_stagger")};
   {
     ProfScope ps("count_kmers", st);
     MG_TRY(dispatch_kc(ix.k, a, grid, lds, st));

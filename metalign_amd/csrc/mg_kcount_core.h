@@ -48,6 +48,7 @@
 #define MG_KC_OR(ptr, v) (*(ptr) |= (v))
 #define MG_KC_AND(ptr, v) (*(ptr) &= (v))
 #define MG_KC_LOAD(ptr) (*(ptr))
+#define MG_KC_CAS(ptr, expected, desired) (*(ptr) = (*(ptr) == (expected)) ? (desired) : *(ptr))
 #else
 // (a sample's bits are set by lanes all over the device; each XCD's L2 keeps what it has read: a plain load may see a word as it
 // was long ago — and a k-mer that is saturated be scanned for again and again.  Device-scope loads for those words.)
@@ -59,6 +60,13 @@
 #define MG_KC_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MG_KC_OR(ptr, v) __hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MG_KC_AND(ptr, v) __hip_atomic_fetch_and((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// (nobody asks whether it took: a lost exchange loses a HINT — see kc_count_entry)
+#define MG_KC_CAS(ptr, expected, desired)                                                                                          \
+  do {                                                                                                                             \
+    uint32_t mg_kc_expected_ = (expected);                                                                                         \
+    (void)__hip_atomic_compare_exchange_strong((ptr), &mg_kc_expected_, (desired), __ATOMIC_RELAXED, __ATOMIC_RELAXED,             \
+                                               __HIP_MEMORY_SCOPE_AGENT);                                                          \
+  } while (0)
 #endif
 
 namespace mg {
@@ -113,7 +121,7 @@ MG_HD uint32_t kc_ext_hash(uint64_t v, int k) {
 }
 // bits of the gate bitmap for a table of nd distinct k-mers: 2^extra bits per k-mer (one run in 2^extra that has nothing to find
 // passes), between 2^16 and 2^32
-constexpr uint32_t kKcGateExtra = 6;
+constexpr uint32_t kKcGateExtra = 5;  // (2^5 bits per k-mer: a run in 32 that has nothing to find passes; 6 measured the same kernel and a pass 2.5 % slower — the sample's copy of the gate is made anew every pass)
 constexpr uint32_t kc_gate_bits(uint64_t nd, uint32_t extra) {
   uint32_t b = 0;
   while (b < 32u && (1ull << b) < nd) ++b;
@@ -511,7 +519,14 @@ struct KcIndexView {
   uint32_t gshift;        // a hash's gate bit is number hash >> gshift (32 - kc_gate_bits)
   uint32_t cs;            // counters are read as min(counter, cs) (kmc -cs<cs>; 0: exact, nothing ever saturates)
   uint32_t ablate;        // measurements only (knob kc_ablate): 3 = no run is scanned; 4 = signatures only; 5 = no count
+  uint32_t epoch;         // 1 .. 255: which of the sample's passes the entry counters' words are of (kc_entry_count)
 };
+
+// An entry's counter word: the pass it was written in (top eight bits) above what has been found under the entry in that pass (24
+// bits: the lanes in flight on the device times the fifty windows of a run are under ten million).  A word of another pass counts
+// as zero — so that nothing has to zero 4 bytes per SLOT of the index before every pass (268 MB at ten million k-mers, 4.3 GB at
+// two hundred million); the words are zeroed when the pass number wraps, every 255 passes.
+MG_HD uint32_t kc_entry_count(uint32_t word, uint32_t epoch) { return (word >> 24) == epoch ? (word & 0xffffffu) : 0u; }
 
 // an entry out of device memory (class types do not copy out of a qualified address space: as vectors)
 #ifdef MG_HOST_CHECK
@@ -614,11 +629,18 @@ MG_HD uint32_t kc_match_windows(const MG_LDS uint32_t* fwd, const MG_LDS uint32_
 
 // `found` windows of a run were entry number n (counted at `head`): one add to the k-mer's counter and — counters that saturate —
 // one to the ENTRY's own (what the next run that comes to this entry reads with its bucket: at the saturation value it is
-// skipped).  Neither add's old value is asked for: nothing waits for them.  (The k-mer's counter is at least the entry's.)
-MG_HD void kc_count_entry(const KcIndexView& ix, uint32_t n, uint32_t head, uint32_t found) {
+// skipped).  Neither add's old value is asked for: nothing waits for them.  `seen`: the entry's word as the run read it; a word
+// of an earlier pass is REPLACED (compare-and-swap, result not looked at) instead of added to.  The entry's counter is a HINT: it
+// may run behind the k-mer's (a lost exchange, two lanes replacing at once) — then the entry is matched a few times more than
+// needed — and never ahead of it (what is added to it is added to the k-mer's counter too), so an entry is skipped only when the
+// k-mer's counter has reached the saturation value.
+MG_HD void kc_count_entry(const KcIndexView& ix, uint32_t n, uint32_t head, uint32_t found, uint32_t seen) {
   if (!found || ix.ablate == 5u) return;
   (void)MG_KC_ADD(&ix.counts[head], found);
-  if (ix.cs) (void)MG_KC_ADD(&ix.csat[n], found);
+  if (ix.cs) {
+    if ((seen >> 24) == ix.epoch) (void)MG_KC_ADD(&ix.csat[n], found);
+    else MG_KC_CAS(&ix.csat[n], seen, (ix.epoch << 24) | found);
+  }
 }
 
 // A run past the gate against its bucket, one lane on its own (the host check, and the statement of what the kernel's batched
@@ -636,11 +658,12 @@ MG_HD uint32_t kc_match_run(const KcIndexView& ix, const MG_LDS uint32_t* fwd, c
     if (t == 1) ovf_at = E.pad;
     if (E.key != key) continue;
     any = true;
-    if (ix.cs && MG_KC_LOAD(&ix.csat[n]) >= ix.cs) continue;
+    const uint32_t seen = MG_KC_LOAD(&ix.csat[n]);
+    if (ix.cs && kc_entry_count(seen, ix.epoch) >= ix.cs) continue;
     open = true;
     const uint32_t f = E.off == kKcSeveral ? kc_scan_run(fwd, inv, k, bad, E.w, p0, i1, i2)
                                            : kc_match_windows(fwd, inv, k, bad, E.w[0], E.w[1], E.w[2], E.w[3], E.off, p0, pos, i1, i2);
-    kc_count_entry(ix, n, E.head, f);
+    kc_count_entry(ix, n, E.head, f, seen);
     found += f;
   }
   const uint32_t g = key >> ix.gshift;

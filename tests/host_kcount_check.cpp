@@ -59,7 +59,7 @@ struct Index {
   std::vector<uint32_t> live, shared, counts, sat;
   std::vector<KcEntry> ent, prim, ovf;
   uint32_t bmask = 0, gshift = 0, cs = 0;
-  KcIndexView view() { return KcIndexView{live.data(), shared.data(), prim.data(), ovf.data(), counts.data(), sat.data(), bmask, gshift, cs, 0u}; }
+  KcIndexView view() { return KcIndexView{live.data(), shared.data(), prim.data(), ovf.data(), counts.data(), sat.data(), bmask, gshift, cs, 0u, 1u}; }
 };
 
 template <int K, uint32_t CAP>

@@ -158,3 +158,31 @@ def test_a_larger_sample_against_a_larger_table(hip, oracle_lib):
     assert set(np.argsort(-hits[-1].astype(np.int64))[:4]) == {1, 5, 7, 30}
     kc.free()
     table.free()
+
+
+def test_three_hundred_samples_through_one_set_of_counters(hip, oracle_lib):
+    """The entry counters are not zeroed between samples: their words carry a pass number of eight bits (mg_kcount_core.h:
+    kc_entry_count) and are zeroed when it wraps.  300 resets of one set of counters, two samples in turn — one that saturates its
+    k-mers, one that barely touches them: every sample's counts are its own, before, at and after the wrap."""
+    ks = [31, 51]
+    rng = np.random.default_rng(6500)
+    gb, go = random_genomes(rng, 8, 8000)
+    h, khi, klo, o = hip.sketch_genomes_kmers(gb, go, ks[-1], 300)
+    table = hip.refdb_build(h, khi, klo, o, ks)
+    want_table = oracle_lib.refpipe_build(h, khi, klo, o, ks)
+    table.index_kmers()
+    samples = []
+    for present, n in (([1, 4], 6000), ([6], 300)):
+        rb, ro, _ = sample_reads(rng, gb, go, n, 150, err=0.01, present=present)
+        want, _ = oracle_lib.refpipe_count_kmers(rb, ro, ks[-1], want_table["kmer_hi"], want_table["kmer_lo"], cs=3)
+        samples.append((hip.array(np.concatenate([rb, np.zeros(64, np.uint8)])), hip.array(ro), len(ro) - 1, int(ro[-1]), want))
+    assert samples[0][4].max() == 3 and 0 < samples[1][4].sum() < samples[0][4].sum()
+    kc = table.kmer_counts()
+    for i in range(300):
+        d_b, d_o, n, nb, want = samples[i & 1]
+        kc.reset()
+        kc.add_dev(d_b.ptr, d_o.ptr, n, nb)
+        if i < 4 or i % 37 == 0 or 250 <= i <= 262 or i >= 296:
+            assert np.array_equal(kc.download(), want), i
+    kc.free()
+    table.free()
