@@ -708,7 +708,7 @@ def main():
                 "valu_insts_per_pass": valu_insts,
                 "note": (("stage A by k-mer identity (k_count_kmers): one lane per read slides a 15-mer minimizer over its windows — no k-mer is "
                           "hashed — and leaves one event per run of windows; per run the 19 bases around the minimizer are hashed and ONE bit "
-                          "of a 2^30-bit gate is probed (6.9 runs per 150 bp read: 6.9 x 10^7 random 64-byte sectors per 10M reads), the 4 % "
+                          "of a 2^29-bit gate is probed (6.9 runs per 150 bp read: 6.9 x 10^7 random 64-byte sectors per 10M reads), the 4 % "
                           "that pass read their bucket's 128-byte line. achieved / frac = 158 B/read x reads / kernel_ms_alone against 8 TB/s; "
                           "traffic (FETCH_SIZE + WRITE_SIZE of the committed PMC passes) is 4.5 x that: the gate's sectors. The walk alone "
                           "is 1.3 of the kernel's 2.1-2.2 ms (SQ_INSTS_VALU 33 per wave-step, three wavefronts per SIMD at 168 VGPRs); "
